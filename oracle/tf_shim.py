@@ -1,0 +1,268 @@
+"""ORACLE tooling (test infrastructure only).
+
+A NumPy stand-in for the handful of `tf.*` primitives that the reference's pure-Python hot-path files call,
+so that the reference's OWN source files can be executed in this container (TensorFlow is not installed):
+    tensorflow_asr/losses/impl/rnnt.py                    (RNN-T loss + closed-form gradient)
+    tensorflow_asr/models/layers/multihead_attention.py   (rel_left_shift, compute_streaming_mask — function bodies)
+    tensorflow_asr/models/layers/positional_encoding.py   (compute_sinusoid_position_encoding)
+Each primitive follows the documented TF semantics (eager mode, float32 default).  Used only by
+oracle/gen_golden_from_reference.py to write tests/golden/*.npz; nothing here is shipped.
+"""
+import contextlib
+import importlib.util
+import sys
+import types
+
+import numpy as np
+
+REFERENCE_ROOT = "/root/reference"
+
+
+class _DType:
+    def __init__(self, np_dtype, name):
+        self.np = np_dtype
+        self.name = name
+
+    def __eq__(self, o):
+        return np.dtype(getattr(o, "np", o)) == np.dtype(self.np) if not isinstance(o, str) else self.name == o
+
+    def __hash__(self):
+        return hash(self.name)
+
+    @property
+    def min(self):
+        return np.finfo(self.np).min
+
+    @property
+    def max(self):
+        return np.finfo(self.np).max
+
+
+def _npd(dt):
+    if dt is None:
+        return None
+    return getattr(dt, "np", dt)
+
+
+class _Shape(tuple):
+    def as_list(self):
+        return list(self)
+
+
+class T(np.ndarray):
+    """ndarray whose .shape has .as_list() and whose dtype compares with shim dtypes."""
+
+    @property
+    def shape(self):  # noqa: D401
+        return _Shape(np.ndarray.shape.__get__(self))
+
+    def numpy(self):
+        return np.asarray(self)
+
+
+def _t(x, dtype=None):
+    a = np.asarray(x, dtype=_npd(dtype))
+    if a.dtype == np.float64 and dtype is None and not isinstance(x, np.ndarray):
+        a = a.astype(np.float32)  # python floats become float32 like tf.constant
+    return a.view(T)
+
+
+def _diag_part_v2(input, k, padding_value):  # noqa: A002
+    """tf.raw_ops.MatrixDiagPartV2: out[..., d, :] = diagonal (k_hi - d), LEFT-aligned, padded on the right."""
+    x = np.asarray(input)
+    k_lo, k_hi = (int(k[0]), int(k[1])) if isinstance(k, (tuple, list)) else (int(k), int(k))
+    M, N = x.shape[-2], x.shape[-1]
+    lens = [min(M + min(d, 0), N - max(d, 0)) for d in range(k_lo, k_hi + 1)]
+    maxlen = max(lens)
+    out = np.full(x.shape[:-2] + (k_hi - k_lo + 1, maxlen), padding_value, dtype=x.dtype)
+    for row, d in enumerate(range(k_hi, k_lo - 1, -1)):
+        ln = min(M + min(d, 0), N - max(d, 0))
+        if ln <= 0:
+            continue
+        i = np.arange(ln)
+        out[..., row, :ln] = x[..., i - min(d, 0), i + max(d, 0)]
+    if k_lo == k_hi:
+        out = out[..., 0, :]
+    return out.view(T)
+
+
+def _scan(fn, elems, initializer, reverse=False):
+    n = len(elems[0]) if isinstance(elems, (tuple, list)) else len(elems)
+    order = range(n - 1, -1, -1) if reverse else range(n)
+    acc = initializer
+    outs = [None] * n
+    for i in order:
+        e = tuple(x[i] for x in elems) if isinstance(elems, (tuple, list)) else elems[i]
+        acc = fn(acc, e)
+        outs[i] = acc
+    return _t(np.stack([np.asarray(o) for o in outs], axis=0))
+
+
+def _gather_nd(params, indices, batch_dims=0):
+    p, idx = np.asarray(params), np.asarray(indices)
+    if batch_dims == 0:
+        return _t(p[tuple(np.moveaxis(idx, -1, 0))])
+    assert batch_dims == 1
+    return _t(np.stack([p[b][tuple(np.moveaxis(idx[b], -1, 0))] for b in range(p.shape[0])], axis=0))
+
+
+def _scatter_nd(indices, updates, shape, name=None):
+    out = np.zeros([int(s) for s in shape], dtype=np.asarray(updates).dtype)
+    idx = np.asarray(indices)
+    np.add.at(out, tuple(np.moveaxis(idx, -1, 0)), np.asarray(updates))
+    return _t(out)
+
+
+def _sequence_mask(lengths, maxlen=None, dtype=None):
+    lengths = np.asarray(lengths)
+    maxlen = int(lengths.max()) if maxlen is None else int(maxlen)
+    m = np.arange(maxlen)[(None,) * lengths.ndim] < lengths[..., None]
+    return _t(m.astype(_npd(dtype) or np.bool_))
+
+
+def _one_hot(indices, depth, dtype=None):
+    idx = np.asarray(indices)
+    out = (idx[..., None] == np.arange(int(depth))).astype(_npd(dtype) or np.float32)
+    return _t(out)
+
+
+def _pad(x, paddings, mode="CONSTANT", constant_values=0):
+    return _t(np.pad(np.asarray(x), [(int(a), int(b)) for a, b in paddings], constant_values=constant_values))
+
+
+def _slice(x, begin, size):
+    x = np.asarray(x)
+    sl = tuple(slice(int(b), None if int(s) == -1 else int(b) + int(s)) for b, s in zip(begin, size))
+    return _t(x[sl])
+
+
+def _logsumexp(x, axis=None, keepdims=False):
+    x = np.asarray(x)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        m = np.max(x, axis=axis, keepdims=True)
+        m0 = np.where(np.isfinite(m), m, 0)
+        r = np.log(np.sum(np.exp(x - m0), axis=axis, keepdims=True)) + m0
+    return _t(r if keepdims else np.squeeze(r, axis=axis))
+
+
+def _log_softmax(x, axis=-1):
+    x = np.asarray(x)
+    m = x.max(axis=axis, keepdims=True)
+    return _t(x - m - np.log(np.exp(x - m).sum(axis=axis, keepdims=True)))
+
+
+def make_tf():
+    tf = types.ModuleType("tensorflow")
+    for nm, d in [("float32", np.float32), ("float64", np.float64), ("float16", np.float16), ("int32", np.int32),
+                  ("int64", np.int64), ("bool", np.bool_)]:
+        setattr(tf, nm, _DType(d, nm))
+    tf.bfloat16 = _DType(np.float16, "bfloat16_unused")  # only ever compared against, never produced
+    tf.dtypes = types.SimpleNamespace(float32=tf.float32)
+    tf.Tensor = T
+    np_err = dict(invalid="ignore", divide="ignore", over="ignore")
+
+    def w(f):
+        def g(*a, **k):
+            k.pop("name", None)
+            with np.errstate(**np_err):
+                return _t(f(*a, **k))
+        return g
+
+    tf.convert_to_tensor = lambda x, dtype=None, name=None: _t(x, dtype)
+    tf.constant = lambda x, dtype=None, shape=None: _t(x, dtype)
+    tf.cast = lambda x, dtype: _t(np.asarray(x).astype(_npd(dtype)))
+    tf.shape = lambda x, out_type=None: _t(np.array(np.asarray(x).shape, dtype=_npd(out_type) or np.int32))
+    tf.reshape = lambda x, shape: _t(np.reshape(np.asarray(x), [int(s) for s in np.asarray(shape).reshape(-1)]
+                                                if not isinstance(shape, (list, tuple)) else [int(s) for s in shape]))
+    tf.transpose = lambda x, perm=None: _t(np.transpose(np.asarray(x), perm))
+    tf.reverse = lambda x, axis: _t(np.flip(np.asarray(x), axis=tuple(axis)))
+    tf.concat = lambda xs, axis: _t(np.concatenate([np.asarray(v) for v in xs], axis=axis))
+    tf.stack = lambda xs, axis=0: _t(np.stack([np.asarray(v) for v in xs], axis=axis))
+    tf.unstack = lambda x, axis=0: [_t(v) for v in np.moveaxis(np.asarray(x), axis, 0)]
+    tf.expand_dims = lambda x, axis: _t(np.expand_dims(np.asarray(x), axis))
+    tf.tile = lambda x, multiples: _t(np.tile(np.asarray(x), [int(m) for m in multiples]))
+    tf.repeat = lambda x, repeats, axis=None: _t(np.repeat(np.asarray(x), repeats, axis=axis))
+    tf.range = lambda *a, dtype=None, **k: _t(np.arange(*[np.asarray(v).item() if np.ndim(v) == 0 else v for v in a],
+                                                        dtype=_npd(dtype) or _npd(k.get("dtype"))))
+    _shp = lambda shape: [int(s) for s in np.atleast_1d(np.asarray(shape))]
+    tf.ones = lambda shape, dtype=None, name=None: _t(np.ones(_shp(shape), _npd(dtype) or np.float32))
+    tf.zeros = lambda shape, dtype=None, name=None: _t(np.zeros(_shp(shape), _npd(dtype) or np.float32))
+    tf.fill = lambda shape, v: _t(np.full([int(s) for s in shape], v))
+    tf.zeros_like = lambda x, dtype=None: _t(np.zeros_like(np.asarray(x), dtype=_npd(dtype)))
+    tf.ones_like = lambda x, dtype=None: _t(np.ones_like(np.asarray(x), dtype=_npd(dtype)))
+    tf.where = w(lambda c, x=None, y=None: np.where(np.asarray(c), np.asarray(x), np.asarray(y)))
+    tf.equal = w(lambda a, b: np.asarray(a) == np.asarray(b))
+    tf.less = w(lambda a, b: np.asarray(a) < np.asarray(b))
+    tf.multiply = w(lambda a, b: np.asarray(a) * np.asarray(b))
+    tf.add = w(lambda a, b: np.asarray(a) + np.asarray(b))
+    tf.exp = w(lambda x: np.exp(np.asarray(x)))
+    tf.sin = w(lambda x: np.sin(np.asarray(x)))
+    tf.cos = w(lambda x: np.cos(np.asarray(x)))
+    tf.pow = w(lambda a, b: np.power(np.asarray(a), np.asarray(b)))
+    tf.maximum = w(lambda a, b: np.maximum(np.asarray(a), np.asarray(b)))
+    tf.minimum = w(lambda a, b: np.minimum(np.asarray(a), np.asarray(b)))
+    tf.reduce_max = w(lambda x, axis=None, keepdims=False: np.max(np.asarray(x), axis=axis, keepdims=keepdims))
+    tf.reduce_sum = w(lambda x, axis=None, keepdims=False: np.sum(np.asarray(x), axis=axis, keepdims=keepdims))
+    tf.reduce_all = w(lambda x, axis=None: np.all(np.asarray(x), axis=axis))
+    tf.einsum = w(lambda eq, *ops, **k: np.einsum(eq, *[np.asarray(o) for o in ops]))
+    tf.pad = _pad
+    tf.slice = _slice
+    tf.scan = _scan
+    tf.one_hot = _one_hot
+    tf.sequence_mask = _sequence_mask
+    tf.gather_nd = _gather_nd
+    tf.scatter_nd = _scatter_nd
+    tf.ensure_shape = lambda x, shape: x
+    tf.map_fn = lambda fn, elems, dtype=None, fn_output_signature=None: _t(np.stack([np.asarray(fn(e)) for e in elems]))
+    tf.device = lambda *_a, **_k: contextlib.nullcontext()
+    tf.name_scope = lambda *_a, **_k: contextlib.nullcontext()
+    tf.newaxis = None
+    tf.math = types.SimpleNamespace(
+        is_nan=w(lambda x: np.isnan(np.asarray(x))), log=w(lambda x: np.log(np.asarray(x))),
+        reduce_logsumexp=lambda x, axis=None, keepdims=False: _logsumexp(x, axis, keepdims),
+        floordiv=w(lambda a, b: np.asarray(a) // np.asarray(b)), logical_not=w(lambda a: ~np.asarray(a)),
+        logical_and=w(lambda a, b: np.asarray(a) & np.asarray(b)), minimum=tf.minimum, maximum=tf.maximum)
+    tf.nn = types.SimpleNamespace(log_softmax=lambda x, axis=-1: _log_softmax(x, axis))
+    tf.raw_ops = types.SimpleNamespace(MatrixDiagPartV2=_diag_part_v2)
+    tf.compat = types.SimpleNamespace(dimension_value=lambda d: None if d is None else int(d))
+    tf.linalg = types.SimpleNamespace(
+        band_part=w(lambda x, lo, hi: np.asarray(x) & (np.tril(np.ones(np.asarray(x).shape[-2:], bool), hi if hi >= 0 else 10**9)
+                                                        & np.triu(np.ones(np.asarray(x).shape[-2:], bool), -lo if lo >= 0 else -10**9))))
+    tf.custom_gradient = lambda f: f
+    return tf
+
+
+def load_reference_module(rel_path, mod_name, extra_modules=None):
+    """Execute one reference source file (by path) with `tensorflow_asr.tf` bound to the shim."""
+    tf = make_tf()
+    pkg = types.ModuleType("tensorflow_asr")
+    pkg.__path__ = []
+    pkg.tf = tf
+    pkg.schemas = types.ModuleType("tensorflow_asr.schemas")
+    pkg.schemas.TrainOutput = tuple  # only used as a type annotation by impl/rnnt.py:187
+    pkg.keras = types.ModuleType("keras")
+    utils = types.ModuleType("tensorflow_asr.utils")
+    utils.__path__ = []
+    saved = {k: sys.modules.get(k) for k in ("tensorflow", "tensorflow_asr", "tensorflow_asr.schemas",
+                                             "tensorflow_asr.utils", "tensorflow_asr.utils.shape_util")}
+    sys.modules.update({"tensorflow": tf, "tensorflow_asr": pkg, "tensorflow_asr.schemas": pkg.schemas,
+                        "tensorflow_asr.utils": utils})
+    try:
+        spec = importlib.util.spec_from_file_location("tensorflow_asr.utils.shape_util",
+                                                      f"{REFERENCE_ROOT}/tensorflow_asr/utils/shape_util.py")
+        su = importlib.util.module_from_spec(spec)
+        sys.modules["tensorflow_asr.utils.shape_util"] = su
+        spec.loader.exec_module(su)
+        utils.shape_util = su
+        for k, v in (extra_modules or {}).items():
+            sys.modules[k] = v
+        spec = importlib.util.spec_from_file_location(mod_name, f"{REFERENCE_ROOT}/{rel_path}")
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        return mod, tf
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v

@@ -1,0 +1,83 @@
+"""ctypes binding of libtfasr_hip.so (include/tfasr_hip.h).
+
+The product path has NO fallback: if the HIP library cannot be loaded every op raises. PyTorch is used
+only for device memory, streams and torch.distributed; all arithmetic on the hot path is in the .so.
+"""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_long, c_size_t, c_void_p
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libtfasr_hip.so")
+
+TFASR_F32, TFASR_BF16 = 0, 1
+ACT_NONE, ACT_SWISH, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3
+
+
+class TfasrError(RuntimeError):
+    pass
+
+
+class GemmArgs(Structure):
+    _fields_ = [
+        ("A", c_void_p), ("B", c_void_p), ("D", c_void_p),
+        ("bias", c_void_p), ("res", c_void_p), ("dact_z", c_void_p), ("prez", c_void_p),
+        ("M", c_int), ("N", c_int), ("K", c_int),
+        ("lda", c_int), ("ldb", c_int), ("ldd", c_int),
+        ("trans_a", c_int), ("trans_b", c_int),
+        ("nb1", c_int), ("nb2", c_int),
+        ("sA1", c_long), ("sA2", c_long), ("sB1", c_long), ("sB2", c_long), ("sD1", c_long), ("sD2", c_long),
+        ("alpha", c_float), ("beta", c_float),
+        ("act", c_int), ("dact", c_int), ("dtype", c_int), ("out_f32", c_int), ("accumulate", c_int), ("split_k", c_int),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/tfasr_hip.h declares must be listed here
+# (tests/test_abi.py cross-checks this table against the header).
+SIGNATURES = {
+    "tfasr_status_string": (c_char_p, [c_int]),
+    "tfasr_abi_version": (c_int, []),
+    "tfasr_rnnt_loss_workspace_size": (c_int, [c_int, c_int, c_int, c_int, POINTER(c_size_t)]),
+    "tfasr_rnnt_loss": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "tfasr_gemm": (c_int, [POINTER(GemmArgs), c_void_p]),
+}
+
+_lib = None
+
+
+def load(build_if_missing=True):
+    """Load (building first if the .so is absent and hipcc exists). Raises TfasrError on failure."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        if not build_if_missing:
+            raise TfasrError(f"{LIB_PATH} is missing: run `python -m tensorflowasr_amd.build`")
+        from . import build as _build
+
+        _build.build(verbose=False)
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as e:  # loud, no fallback
+        raise TfasrError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise TfasrError(f"{LIB_PATH} does not export {name}; rebuild with `python -m tensorflowasr_amd.build --force`") from e
+        fn.restype = res
+        fn.argtypes = args
+    if lib.tfasr_abi_version() != ABI_VERSION:
+        raise TfasrError(f"ABI mismatch: library {lib.tfasr_abi_version()} vs python {ABI_VERSION}; rebuild")
+    _lib = lib
+    return lib
+
+
+ABI_VERSION = 1
+
+
+def check(status, what=""):
+    if status != 0:
+        msg = load().tfasr_status_string(status).decode()
+        raise TfasrError(f"{what}: {msg} (status {status})")

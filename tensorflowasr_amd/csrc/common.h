@@ -1,0 +1,100 @@
+// Shared device helpers for the tensorflowasr_amd HIP kernels (gfx950 / CDNA4 only).
+// wave = 64 lanes everywhere in this code base.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+
+#include "../../include/tfasr_hip.h"
+
+#define TFASR_WAVE 64
+
+typedef uint16_t bf16_t;  // raw bfloat16 bits
+
+typedef __attribute__((ext_vector_type(8))) short short8_t;
+typedef __attribute__((ext_vector_type(4))) float float4_t;
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+
+// round-to-nearest-even, NaN preserved (same rule as TF / torch bfloat16 casts)
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40u);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+
+template <typename T> struct Num;
+template <> struct Num<float> {
+  static __device__ __forceinline__ float ld(const float* p) { return *p; }
+  static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
+};
+template <> struct Num<bf16_t> {
+  static __device__ __forceinline__ float ld(const bf16_t* p) { return bf16_to_f32(*p); }
+  static __device__ __forceinline__ void st(bf16_t* p, float v) { *p = f32_to_bf16(v); }
+};
+
+// 8-element vector load/store (16 B for bf16, 32 B for f32). Pointer must be aligned to 16 B.
+__device__ __forceinline__ void ld8(const float* p, float (&v)[8]) {
+  const float4 a = *reinterpret_cast<const float4*>(p);
+  const float4 b = *reinterpret_cast<const float4*>(p + 4);
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+__device__ __forceinline__ void ld8(const bf16_t* p, float (&v)[8]) {
+  const uint4 a = *reinterpret_cast<const uint4*>(p);
+  v[0] = __uint_as_float(a.x << 16); v[1] = __uint_as_float(a.x & 0xffff0000u);
+  v[2] = __uint_as_float(a.y << 16); v[3] = __uint_as_float(a.y & 0xffff0000u);
+  v[4] = __uint_as_float(a.z << 16); v[5] = __uint_as_float(a.z & 0xffff0000u);
+  v[6] = __uint_as_float(a.w << 16); v[7] = __uint_as_float(a.w & 0xffff0000u);
+}
+__device__ __forceinline__ void st8(float* p, const float (&v)[8]) {
+  *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+  *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
+__device__ __forceinline__ void st8(bf16_t* p, const float (&v)[8]) {
+  uint4 a;
+  a.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+  a.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+  a.z = (uint32_t)f32_to_bf16(v[4]) | ((uint32_t)f32_to_bf16(v[5]) << 16);
+  a.w = (uint32_t)f32_to_bf16(v[6]) | ((uint32_t)f32_to_bf16(v[7]) << 16);
+  *reinterpret_cast<uint4*>(p) = a;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// block-wide sum for blockDim.x <= 1024 (multiple of 64); `red` = >= 16 floats of LDS scratch
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if (lane == 0) red[w] = v;
+  __syncthreads();
+  float r = 0.f;
+  for (int i = 0; i < nw; ++i) r += red[i];
+  return r;
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
+__device__ __forceinline__ float swishf_(float x) { return x * sigmoidf_(x); }
+// d/dx [x * sigmoid(x)] = s + x*s*(1-s)
+__device__ __forceinline__ float dswishf_(float x) { const float s = sigmoidf_(x); return s * (1.f + x * (1.f - s)); }
+
+// log(exp(a)+exp(b)) with -inf handling (the 2-term log-sum-exp of losses/impl/rnnt.py:72-78,126)
+__device__ __forceinline__ float logaddexpf_(float a, float b) {
+  const float m = fmaxf(a, b);
+  if (m == -INFINITY) return -INFINITY;
+  return m + log1pf(expf(-fabsf(a - b)));
+}
+
+#define TFASR_CHECK_LAUNCH() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return TFASR_STATUS_EXECUTION_FAILED; } while (0)
+
+static inline int tfasr_ceil_div(long a, long b) { return (int)((a + b - 1) / b); }

@@ -1,0 +1,292 @@
+// MFMA GEMM family for gfx950 (wave64).  See include/tfasr_hip.h for the contract.
+//
+// Structure (round-1 version): 128x128 output tile per 256-thread workgroup (4 waves as 2x2, each
+// wave a 64x64 sub-tile = 4x4 MFMA 16x16 fragments, f32 accumulators), K staged through LDS in
+// BK-deep slabs, both operands stored k-contiguous in LDS so every MFMA fragment is one 16-byte
+// ds_read (bf16) / one dword (f32).  Operands whose k index is the strided one in memory
+// (B of an NN product, A and B of a weight-gradient TN product) are transposed in registers on the
+// way in (8x8 bf16 blocks) so global loads stay 16 B per lane and coalesced.
+//   bf16 : __builtin_amdgcn_mfma_f32_16x16x32_bf16   (dense peak ~2.5 PFLOP/s)
+//   f32  : __builtin_amdgcn_mfma_f32_16x16x4f32      (exact f32, 157 TFLOP/s)  -- the parity mode
+// C/D fragment map (both): col = lane & 15, row = (lane >> 4) * 4 + reg.
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128;
+
+template <typename T> struct Cfg;
+template <> struct Cfg<bf16_t> { static constexpr int BK = 64, LD = 72; };
+template <> struct Cfg<float>  { static constexpr int BK = 16, LD = 17; };
+
+__device__ __forceinline__ bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+// ---- tile loaders --------------------------------------------------------------------------
+// "direct": operand stored [rows, K] (ld), k contiguous.  rows0 = first row of the tile.
+__device__ __forceinline__ void load_direct(bf16_t* s, const bf16_t* g, long ld, int rows0, int nrows_total,
+                                            int kt, int k_end) {
+  constexpr int BK = Cfg<bf16_t>::BK, LD = Cfg<bf16_t>::LD;
+  for (int c = threadIdx.x; c < BM * BK / 8; c += 256) {
+    const int row = c / (BK / 8), kc = (c % (BK / 8)) * 8;
+    const int gr = rows0 + row, gk = kt + kc;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (gr < nrows_total) {
+      const bf16_t* p = g + (long)gr * ld + gk;
+      if (gk + 8 <= k_end && aligned16(p)) v = *reinterpret_cast<const uint4*>(p);
+      else {
+        uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          if (gk + i < k_end) w[i >> 1] |= ((uint32_t)p[i]) << ((i & 1) * 16);
+        v = make_uint4(w[0], w[1], w[2], w[3]);
+      }
+    }
+    *reinterpret_cast<uint4*>(s + row * LD + kc) = v;
+  }
+}
+__device__ __forceinline__ void load_direct(float* s, const float* g, long ld, int rows0, int nrows_total, int kt,
+                                            int k_end) {
+  constexpr int BK = Cfg<float>::BK, LD = Cfg<float>::LD;
+  for (int c = threadIdx.x; c < BM * BK / 4; c += 256) {
+    const int row = c / (BK / 4), kc = (c % (BK / 4)) * 4;
+    const int gr = rows0 + row, gk = kt + kc;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (gr < nrows_total) {
+      const float* p = g + (long)gr * ld + gk;
+      if (gk + 4 <= k_end && aligned16(p)) {
+        const float4 q = *reinterpret_cast<const float4*>(p);
+        v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) if (gk + i < k_end) v[i] = p[i];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s[row * LD + kc + i] = v[i];
+  }
+}
+
+// "transposed": operand stored [K, rows] (ld), rows contiguous.  8x8 bf16 blocks transposed in registers.
+__device__ __forceinline__ void load_trans(bf16_t* s, const bf16_t* g, long ld, int rows0, int nrows_total, int kt,
+                                           int k_end) {
+  constexpr int BK = Cfg<bf16_t>::BK, LD = Cfg<bf16_t>::LD;
+  constexpr int NRB = BM / 8;  // row blocks
+  for (int blk = threadIdx.x; blk < (BK / 8) * NRB; blk += 256) {
+    const int kb = (blk / NRB) * 8, rb = (blk % NRB) * 8;
+    const int gr = rows0 + rb;
+    uint32_t in[8][4];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int gk = kt + kb + j;
+      in[j][0] = in[j][1] = in[j][2] = in[j][3] = 0;
+      if (gk < k_end && gr < nrows_total) {
+        const bf16_t* p = g + (long)gk * ld + gr;
+        if (gr + 8 <= nrows_total && aligned16(p)) {
+          const uint4 q = *reinterpret_cast<const uint4*>(p);
+          in[j][0] = q.x; in[j][1] = q.y; in[j][2] = q.z; in[j][3] = q.w;
+        } else {
+#pragma unroll
+          for (int i = 0; i < 8; ++i)
+            if (gr + i < nrows_total) in[j][i >> 1] |= ((uint32_t)p[i]) << ((i & 1) * 16);
+        }
+      }
+    }
+    // out row i (0..7) holds k = 0..7 : word w = (k=2w, k=2w+1)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      uint32_t o[4];
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        const uint32_t lo = in[2 * w][i >> 1], hi = in[2 * w + 1][i >> 1];
+        o[w] = (i & 1) ? ((lo >> 16) | (hi & 0xffff0000u)) : ((lo & 0xffffu) | (hi << 16));
+      }
+      *reinterpret_cast<uint4*>(s + (rb + i) * LD + kb) = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+  }
+}
+__device__ __forceinline__ void load_trans(float* s, const float* g, long ld, int rows0, int nrows_total, int kt,
+                                           int k_end) {
+  constexpr int BK = Cfg<float>::BK, LD = Cfg<float>::LD;
+  for (int c = threadIdx.x; c < BK * (BM / 4); c += 256) {
+    const int k = c / (BM / 4), r4 = (c % (BM / 4)) * 4;
+    const int gk = kt + k, gr = rows0 + r4;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (gk < k_end && gr < nrows_total) {
+      const float* p = g + (long)gk * ld + gr;
+      if (gr + 4 <= nrows_total && aligned16(p)) {
+        const float4 q = *reinterpret_cast<const float4*>(p);
+        v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) if (gr + i < nrows_total) v[i] = p[i];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s[(r4 + i) * LD + k] = v[i];
+  }
+}
+
+// ---- MFMA inner product over one LDS slab ---------------------------------------------------
+__device__ __forceinline__ void mma_slab(const bf16_t* sA, const bf16_t* sB, int wm, int wn, int lane,
+                                         float4_t (&acc)[4][4]) {
+  constexpr int BK = Cfg<bf16_t>::BK, LD = Cfg<bf16_t>::LD;
+  const int r = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int kk = 0; kk < BK / 32; ++kk) {
+    short8_t a[4], b[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      a[i] = *reinterpret_cast<const short8_t*>(sA + (wm * 64 + i * 16 + r) * LD + kk * 32 + g * 8);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      b[j] = *reinterpret_cast<const short8_t*>(sB + (wn * 64 + j * 16 + r) * LD + kk * 32 + g * 8);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+  }
+}
+__device__ __forceinline__ void mma_slab(const float* sA, const float* sB, int wm, int wn, int lane,
+                                         float4_t (&acc)[4][4]) {
+  constexpr int BK = Cfg<float>::BK, LD = Cfg<float>::LD;
+  const int r = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int kk = 0; kk < BK / 4; ++kk) {
+    float a[4], b[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[i] = sA[(wm * 64 + i * 16 + r) * LD + kk * 4 + g];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b[j] = sB[(wn * 64 + j * 16 + r) * LD + kk * 4 + g];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+  }
+}
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+  switch (act) {
+    case TFASR_ACT_SWISH: return swishf_(v);
+    case TFASR_ACT_TANH: return tanhf(v);
+    case TFASR_ACT_SIGMOID: return sigmoidf_(v);
+    default: return v;
+  }
+}
+__device__ __forceinline__ float apply_dact(float z, int act) {
+  switch (act) {
+    case TFASR_ACT_SWISH: return dswishf_(z);
+    case TFASR_ACT_TANH: { const float t = tanhf(z); return 1.f - t * t; }
+    case TFASR_ACT_SIGMOID: { const float s = sigmoidf_(z); return s * (1.f - s); }
+    default: return 1.f;
+  }
+}
+
+template <typename T, bool TA, bool TB>
+__global__ __launch_bounds__(256) void gemm_kernel(const tfasr_gemm_args p) {
+  constexpr int BK = Cfg<T>::BK, LD = Cfg<T>::LD;
+  __shared__ __attribute__((aligned(16))) T smem[(BM + BN) * LD];
+  T* sA = smem;
+  T* sB = smem + BM * LD;
+
+  const int split = p.split_k > 1 ? p.split_k : 1;
+  const int ks = blockIdx.z % split;
+  const int bidx = blockIdx.z / split;
+  const int b1 = bidx / p.nb2, b2 = bidx % p.nb2;
+  const T* A = (const T*)p.A + b1 * p.sA1 + b2 * p.sA2;
+  const T* Bm = (const T*)p.B + b1 * p.sB1 + b2 * p.sB2;
+  const long doff = b1 * p.sD1 + b2 * p.sD2;
+
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  int kchunk = (p.K + split - 1) / split;
+  kchunk = ((kchunk + BK - 1) / BK) * BK;
+  const int k_begin = ks * kchunk;
+  const int k_end = min(p.K, k_begin + kchunk);
+
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int wm = w >> 1, wn = w & 1;
+
+  float4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = float4_t{0.f, 0.f, 0.f, 0.f};
+
+  for (int kt = k_begin; kt < k_end; kt += BK) {
+    if (TA) load_trans(sA, A, p.lda, m0, p.M, kt, k_end); else load_direct(sA, A, p.lda, m0, p.M, kt, k_end);
+    // B: trans_b==1 -> stored [N,K] (k contiguous) = "direct"; trans_b==0 -> stored [K,N] = needs transpose
+    if (TB) load_direct(sB, Bm, p.ldb, n0, p.N, kt, k_end); else load_trans(sB, Bm, p.ldb, n0, p.N, kt, k_end);
+    __syncthreads();
+    mma_slab(sA, sB, wm, wn, lane, acc);
+    __syncthreads();
+  }
+
+  // ---- epilogue ----
+  const int r = lane & 15, g = lane >> 4;
+  const bool first_split = (ks == 0);
+  T* Dt = (T*)p.D + doff;
+  float* Df = (float*)p.D + doff;
+  const T* res = p.res ? (const T*)p.res + doff : nullptr;
+  const T* dz = p.dact_z ? (const T*)p.dact_z + doff : nullptr;
+  T* prez = p.prez ? (T*)p.prez + doff : nullptr;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int col = n0 + wn * 64 + j * 16 + r;
+      if (col >= p.N) continue;
+      const float bias = (p.bias && first_split) ? p.bias[col] : 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int row = m0 + wm * 64 + i * 16 + g * 4 + e;
+        if (row >= p.M) continue;
+        const long idx = (long)row * p.ldd + col;
+        float v = p.alpha * acc[i][j][e] + bias;
+        if (prez) Num<T>::st(prez + idx, v);
+        v = apply_act(v, p.act);
+        if (dz) v *= apply_dact(Num<T>::ld(dz + idx), p.dact);
+        if (res) v = Num<T>::ld(res + idx) + p.beta * v;
+        if (p.out_f32) {
+          if (p.accumulate) atomicAdd(Df + idx, v);
+          else Df[idx] = v;
+        } else {
+          Num<T>::st(Dt + idx, v);
+        }
+      }
+    }
+  }
+}
+
+template <typename T>
+int launch(const tfasr_gemm_args& a, hipStream_t stream) {
+  const int split = a.split_k > 1 ? a.split_k : 1;
+  dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, a.nb1 * a.nb2 * split);
+  if (grid.y > 65535 || grid.z > 65535) return TFASR_STATUS_INVALID_VALUE;
+  dim3 block(256);
+  if (a.trans_a) {
+    if (a.trans_b) hipLaunchKernelGGL((gemm_kernel<T, true, true>), grid, block, 0, stream, a);
+    else           hipLaunchKernelGGL((gemm_kernel<T, true, false>), grid, block, 0, stream, a);
+  } else {
+    if (a.trans_b) hipLaunchKernelGGL((gemm_kernel<T, false, true>), grid, block, 0, stream, a);
+    else           hipLaunchKernelGGL((gemm_kernel<T, false, false>), grid, block, 0, stream, a);
+  }
+  TFASR_CHECK_LAUNCH();
+  return TFASR_STATUS_SUCCESS;
+}
+
+}  // namespace
+
+extern "C" int tfasr_gemm(const tfasr_gemm_args* args, void* stream_) {
+  if (!args || !args->A || !args->B || !args->D) return TFASR_STATUS_INVALID_VALUE;
+  tfasr_gemm_args a = *args;
+  if (a.M <= 0 || a.N <= 0 || a.K <= 0) return TFASR_STATUS_INVALID_VALUE;
+  if (a.nb1 < 1) a.nb1 = 1;
+  if (a.nb2 < 1) a.nb2 = 1;
+  if (a.split_k < 1) a.split_k = 1;
+  if (a.accumulate && !a.out_f32) return TFASR_STATUS_INVALID_VALUE;
+  if (a.split_k > 1 && !a.accumulate) return TFASR_STATUS_INVALID_VALUE;
+  if (a.split_k > 1 && (a.res || a.dact_z || a.prez || a.act != TFASR_ACT_NONE)) return TFASR_STATUS_INVALID_VALUE;
+  hipStream_t stream = (hipStream_t)stream_;
+  if (a.dtype == TFASR_BF16) return launch<bf16_t>(a, stream);
+  if (a.dtype == TFASR_F32) return launch<float>(a, stream);
+  return TFASR_STATUS_INVALID_VALUE;
+}

@@ -1,0 +1,307 @@
+// RNN-T (transducer) loss + gradient for gfx950.
+//
+// Semantics follow tensorflow_asr/losses/impl/rnnt.py:181-278 (compute_rnnt_loss_and_grad_helper):
+//   lp = log_softmax(logits); blank[t,u] = lp[t,u,0]; truth[t,u] = lp[t,u,labels[u]]      (:94-105,:211)
+//   alpha[t,u] = lse(alpha[t-1,u]+blank[t-1,u], alpha[t,u-1]+truth[t,u-1])                (:108-137)
+//   beta[Tl-1,Ul] = blank[Tl-1,Ul]; beta[t,u] = lse(beta[t+1,u]+blank[t,u], beta[t,u+1]+truth[t,u]) (:140-178)
+//   loss = -beta[0,0]                                                                     (:277)
+//   g_blank[t,u] = -exp(alpha[t,u]+beta[t+1,u]+blank[t,u]-beta00), t<Tl-1,u<=Ul; -1 at (Tl-1,Ul) (:233-248)
+//   g_truth[t,u] = -exp(alpha[t,u]+beta[t,u+1]+truth[t,u]-beta00), t<Tl, u<Ul             (:251-254)
+//   dlogits[v]   = g[v] - softmax[v]*sum_v g[v]                                           (:267-275)
+// (the anti-diagonal packing of :81-91 is only a vectorisation; per-node arithmetic is the 2-term
+//  log-sum-exp reproduced here: SURVEY.md A.4 item 10).
+//
+// Three kernels, all HBM-bound except the (latency-bound) lattice scan:
+//   1. rnnt_logprobs : one wave per lattice node, single pass over V (online max/sum), writes
+//                      lse / blank / truth  (reads B*T*U1*V logits once; skips padded nodes)
+//   2. rnnt_lattice  : one workgroup per (utterance, {alpha|beta}); one thread per u walks the
+//                      anti-diagonals, neighbours exchanged through a double-buffered LDS row
+//   3. rnnt_grad     : one wave per lattice node, rewrites the row with the gradient
+#include "common.h"
+#include <algorithm>
+
+namespace {
+
+struct RowStat { float m, s; };
+
+__device__ __forceinline__ void online_add(RowStat& st, float x) {
+  if (x > st.m) { st.s = st.s * __expf(st.m - x) + 1.f; st.m = x; }
+  else          { st.s += __expf(x - st.m); }
+}
+__device__ __forceinline__ void online_merge(RowStat& a, float m2, float s2) {
+  const float m = fmaxf(a.m, m2);
+  if (m == -INFINITY) { a.m = m; a.s = 0.f; return; }
+  a.s = a.s * __expf(a.m - m) + s2 * __expf(m2 - m);
+  a.m = m;
+}
+
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void rnnt_logprobs_kernel(
+    const T* __restrict__ logits, const int32_t* __restrict__ labels, const int32_t* __restrict__ label_len,
+    const int32_t* __restrict__ logit_len, int B, int Tm, int U1, int V, float* __restrict__ lse,
+    float* __restrict__ blank_lp, float* __restrict__ truth_lp) {
+  const int lane = threadIdx.x & 63;
+  const long nrows = (long)B * Tm * U1;
+  const long wave0 = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const long nwaves = (long)gridDim.x * (blockDim.x >> 6);
+  const bool vec_ok = (V % 8 == 0);
+  for (long r = wave0; r < nrows; r += nwaves) {
+    const int u = (int)(r % U1);
+    const int t = (int)((r / U1) % Tm);
+    const int b = (int)(r / ((long)U1 * Tm));
+    const int Tl = min(logit_len[b], Tm), Ul = min(label_len[b], U1 - 1);
+    if (t >= Tl || u > Ul) continue;  // padded node: never read by the lattice / grad kernels
+    const T* row = logits + r * V;
+    RowStat st{-INFINITY, 0.f};
+    if (vec_ok) {
+      for (int v0 = lane * 8; v0 < V; v0 += 64 * 8) {
+        float x[8];
+        ld8(row + v0, x);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) online_add(st, x[i]);
+      }
+    } else {
+      for (int v = lane; v < V; v += 64) online_add(st, Num<T>::ld(row + v));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float m2 = __shfl_xor(st.m, o, 64), s2 = __shfl_xor(st.s, o, 64);
+      online_merge(st, m2, s2);
+    }
+    if (lane == 0) {
+      const float l = st.m + logf(st.s);
+      lse[r] = l;
+      blank_lp[r] = Num<T>::ld(row) - l;
+      float tr = -INFINITY;
+      if (u < U1 - 1) {
+        int lab = labels[(long)b * (U1 - 1) + u];
+        lab = min(max(lab, 0), V - 1);
+        tr = Num<T>::ld(row + lab) - l;
+      }
+      truth_lp[r] = tr;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// grid = (B, 2): y==0 -> alpha (forward), y==1 -> beta (backward). blockDim.x >= U1 (multiple of 64).
+__global__ void rnnt_lattice_kernel(const float* __restrict__ blank_lp, const float* __restrict__ truth_lp,
+                                    const int32_t* __restrict__ label_len, const int32_t* __restrict__ logit_len,
+                                    int Tm, int U1, float* __restrict__ alpha, float* __restrict__ beta,
+                                    float* __restrict__ costs) {
+  extern __shared__ float sh[];  // 2 * blockDim.x floats
+  const int b = blockIdx.x;
+  const int u = threadIdx.x;
+  const int nthr = blockDim.x;
+  const int Tl = min(logit_len[b], Tm), Ul = min(label_len[b], U1 - 1);
+  const long base = (long)b * Tm * U1;
+  const float* bl = blank_lp + base;
+  const float* tr = truth_lp + base;
+  float* buf0 = sh;
+  float* buf1 = sh + nthr;
+  buf0[u] = -INFINITY;
+  buf1[u] = -INFINITY;
+  __syncthreads();
+  if (Tl <= 0) { if (u == 0 && blockIdx.y == 1) costs[b] = 0.f; return; }
+  const int ndiag = Tl + Ul;  // diagonals n = t+u in [0, Tl-1+Ul]
+  const bool ucol = (u <= Ul);
+
+  if (blockIdx.y == 0) {
+    float* al = alpha + base;
+    float self = -INFINITY;  // alpha[t-1,u]
+    // prefetch operands of the first cell this thread touches (t = 0 at n = u)
+    float nb = -INFINITY, nt = -INFINITY;
+    if (ucol && Tl > 0 && u > 0) nt = tr[(long)0 * U1 + (u - 1)];
+    for (int n = 0; n < ndiag; ++n) {
+      float* cur = (n & 1) ? buf1 : buf0;
+      const float* prev = (n & 1) ? buf0 : buf1;
+      const int t = n - u;
+      const bool act = ucol && t >= 0 && t < Tl;
+      const float pb = nb, pt = nt;
+      // prefetch next diagonal's operands: cell (t+1,u): blank[t,u], truth[t+1,u-1]
+      if (ucol && t + 1 >= 0 && t + 1 < Tl) {
+        nb = (t + 1 > 0) ? bl[(long)t * U1 + u] : -INFINITY;
+        nt = (u > 0) ? tr[(long)(t + 1) * U1 + (u - 1)] : -INFINITY;
+      }
+      if (act) {
+        float a;
+        if (t == 0 && u == 0) a = 0.f;
+        else {
+          const float xb = (t > 0) ? self + pb : -INFINITY;
+          const float xt = (u > 0) ? prev[u - 1] + pt : -INFINITY;
+          a = logaddexpf_(xb, xt);
+        }
+        al[(long)t * U1 + u] = a;
+        self = a;
+        cur[u] = a;
+      }
+      __syncthreads();
+    }
+  } else {
+    float* be = beta + base;
+    float self = -INFINITY;  // beta[t+1,u]
+    float nb = -INFINITY, nt = -INFINITY;
+    {
+      const int t = (ndiag - 1) - u;  // first diagonal processed
+      if (ucol && t >= 0 && t < Tl) { nb = bl[(long)t * U1 + u]; nt = (u < Ul) ? tr[(long)t * U1 + u] : -INFINITY; }
+    }
+    int it = 0;
+    for (int n = ndiag - 1; n >= 0; --n, ++it) {
+      float* cur = (it & 1) ? buf1 : buf0;
+      const float* prev = (it & 1) ? buf0 : buf1;
+      const int t = n - u;
+      const bool act = ucol && t >= 0 && t < Tl;
+      const float pb = nb, pt = nt;
+      if (ucol && t - 1 >= 0 && t - 1 < Tl) {
+        nb = bl[(long)(t - 1) * U1 + u];
+        nt = (u < Ul) ? tr[(long)(t - 1) * U1 + u] : -INFINITY;
+      }
+      if (act) {
+        float v;
+        if (t == Tl - 1 && u == Ul) v = pb;
+        else {
+          const float xb = (t + 1 < Tl) ? self + pb : -INFINITY;
+          const float xt = (u < Ul) ? prev[u + 1] + pt : -INFINITY;
+          v = logaddexpf_(xb, xt);
+        }
+        be[(long)t * U1 + u] = v;
+        self = v;
+        cur[u] = v;
+        if (t == 0 && u == 0) costs[b] = -v;
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void rnnt_grad_kernel(
+    const T* logits, T* grads, const int32_t* __restrict__ labels,
+    const int32_t* __restrict__ label_len, const int32_t* __restrict__ logit_len,
+    const float* __restrict__ grad_scale, int B, int Tm, int U1, int V, const float* __restrict__ lse,
+    const float* __restrict__ blank_lp, const float* __restrict__ truth_lp, const float* __restrict__ alpha,
+    const float* __restrict__ beta) {
+  const int lane = threadIdx.x & 63;
+  const long nrows = (long)B * Tm * U1;
+  const long wave0 = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const long nwaves = (long)gridDim.x * (blockDim.x >> 6);
+  const bool vec_ok = (V % 8 == 0);
+  for (long r = wave0; r < nrows; r += nwaves) {
+    const int u = (int)(r % U1);
+    const int t = (int)((r / U1) % Tm);
+    const int b = (int)(r / ((long)U1 * Tm));
+    const int Tl = min(logit_len[b], Tm), Ul = min(label_len[b], U1 - 1);
+    const T* row = logits + r * V;
+    T* out = grads + r * V;
+    if (t >= Tl || u > Ul) {  // outside the lattice: zero gradient (impl/rnnt.py masks :218-224)
+      if (vec_ok) {
+        const float z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int v0 = lane * 8; v0 < V; v0 += 64 * 8) st8(out + v0, z);
+      } else {
+        for (int v = lane; v < V; v += 64) Num<T>::st(out + v, 0.f);
+      }
+      continue;
+    }
+    const long lb = (long)b * Tm * U1;
+    const float b00 = beta[lb];
+    const float a = alpha[r];
+    float gb = 0.f, gt = 0.f;
+    if (t < Tl - 1) gb = -__expf(a + beta[r + U1] + blank_lp[r] - b00);
+    else if (u == Ul) gb = -1.f;
+    int lab = -1;
+    if (u < Ul) {
+      gt = -__expf(a + beta[r + 1] + truth_lp[r] - b00);
+      lab = min(max(labels[(long)b * (U1 - 1) + u], 0), V - 1);
+    }
+    const float sc = grad_scale ? grad_scale[b] : 1.f;
+    const float l = lse[r];
+    const float ssum = gb + gt;
+    if (vec_ok) {
+      for (int v0 = lane * 8; v0 < V; v0 += 64 * 8) {
+        float x[8];
+        ld8(row + v0, x);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          float g = -__expf(x[i] - l) * ssum;
+          const int v = v0 + i;
+          if (v == 0) g += gb;
+          if (v == lab) g += gt;
+          x[i] = g * sc;
+        }
+        st8(out + v0, x);
+      }
+    } else {
+      for (int v = lane; v < V; v += 64) {
+        float g = -__expf(Num<T>::ld(row + v) - l) * ssum;
+        if (v == 0) g += gb;
+        if (v == lab) g += gt;
+        Num<T>::st(out + v, g * sc);
+      }
+    }
+  }
+}
+
+inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+}  // namespace
+
+extern "C" int tfasr_rnnt_loss_workspace_size(int B, int T, int U1, int V, size_t* bytes) {
+  if (!bytes || B <= 0 || T <= 0 || U1 <= 0 || V <= 0) return TFASR_STATUS_INVALID_VALUE;
+  const size_t n = (size_t)B * T * U1;
+  *bytes = 5 * align256(n * sizeof(float));  // lse, blank, truth, alpha, beta
+  return TFASR_STATUS_SUCCESS;
+}
+
+extern "C" int tfasr_rnnt_loss(const void* logits, void* grads, const int32_t* labels, const int32_t* label_len,
+                               const int32_t* logit_len, const float* grad_scale, int B, int T, int U1, int V,
+                               int blank, int dtype, float* costs, void* workspace, size_t workspace_bytes,
+                               void* stream_) {
+  if (!logits || !labels || !label_len || !logit_len || !costs || !workspace) return TFASR_STATUS_INVALID_VALUE;
+  if (blank != 0) return TFASR_STATUS_UNSUPPORTED;  // losses/base_loss.py:24
+  if (B <= 0 || T <= 0 || U1 <= 0 || V <= 1 || U1 > 1024) return TFASR_STATUS_INVALID_VALUE;
+  size_t need = 0;
+  tfasr_rnnt_loss_workspace_size(B, T, U1, V, &need);
+  if (workspace_bytes < need) return TFASR_STATUS_INVALID_VALUE;
+  hipStream_t stream = (hipStream_t)stream_;
+  const size_t n = (size_t)B * T * U1;
+  const size_t seg = align256(n * sizeof(float));
+  char* ws = (char*)workspace;
+  float* lse = (float*)(ws);
+  float* blank_lp = (float*)(ws + seg);
+  float* truth_lp = (float*)(ws + 2 * seg);
+  float* alpha = (float*)(ws + 3 * seg);
+  float* beta = (float*)(ws + 4 * seg);
+
+  const long nrows = (long)n;
+  const int wpb = 4;
+  int grid = (int)std::min<long>((nrows + wpb - 1) / wpb, 256L * 32);
+  if (dtype == TFASR_F32)
+    hipLaunchKernelGGL(rnnt_logprobs_kernel<float>, dim3(grid), dim3(256), 0, stream, (const float*)logits, labels,
+                       label_len, logit_len, B, T, U1, V, lse, blank_lp, truth_lp);
+  else if (dtype == TFASR_BF16)
+    hipLaunchKernelGGL(rnnt_logprobs_kernel<bf16_t>, dim3(grid), dim3(256), 0, stream, (const bf16_t*)logits, labels,
+                       label_len, logit_len, B, T, U1, V, lse, blank_lp, truth_lp);
+  else
+    return TFASR_STATUS_INVALID_VALUE;
+  TFASR_CHECK_LAUNCH();
+
+  const int nthr = ((U1 + 63) / 64) * 64;
+  hipLaunchKernelGGL(rnnt_lattice_kernel, dim3(B, 2), dim3(nthr), 2 * nthr * sizeof(float), stream, blank_lp,
+                     truth_lp, label_len, logit_len, T, U1, alpha, beta, costs);
+  TFASR_CHECK_LAUNCH();
+
+  if (grads) {
+    if (dtype == TFASR_F32)
+      hipLaunchKernelGGL(rnnt_grad_kernel<float>, dim3(grid), dim3(256), 0, stream, (const float*)logits,
+                         (float*)grads, labels, label_len, logit_len, grad_scale, B, T, U1, V, lse, blank_lp,
+                         truth_lp, alpha, beta);
+    else
+      hipLaunchKernelGGL(rnnt_grad_kernel<bf16_t>, dim3(grid), dim3(256), 0, stream, (const bf16_t*)logits,
+                         (bf16_t*)grads, labels, label_len, logit_len, grad_scale, B, T, U1, V, lse, blank_lp,
+                         truth_lp, alpha, beta);
+    TFASR_CHECK_LAUNCH();
+  }
+  return TFASR_STATUS_SUCCESS;
+}

@@ -1,0 +1,92 @@
+"""GPU numerics: the MFMA GEMM family vs a plain PyTorch fp32 (CPU) reference of the same op."""
+import numpy as np
+import pytest
+import torch
+
+from tensorflowasr_amd import kernels
+from tensorflowasr_amd.kernels import ACT_NONE, ACT_SWISH, ACT_TANH
+
+pytestmark = pytest.mark.gpu
+
+
+def _tol(dtype):
+    return (2e-2, 2e-2) if dtype == torch.bfloat16 else (1e-5, 1e-4)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, False), (True, True)])
+@pytest.mark.parametrize("mnk", [(128, 128, 64), (200, 144, 144), (77, 1000, 320), (300, 36, 250), (5, 7, 3), (256, 576, 2880)])
+def test_layouts(dev, dtype, ta, tb, mnk):
+    M, N, K = mnk
+    g = torch.Generator().manual_seed(M * 7 + N)
+    A = torch.randn((K, M) if ta else (M, K), generator=g)
+    B = torch.randn((N, K) if tb else (K, N), generator=g)
+    Ad, Bd = A.to(dev).to(dtype), B.to(dev).to(dtype)
+    ref = (Ad.float().cpu().T if ta else Ad.float().cpu()) @ (Bd.float().cpu().T if tb else Bd.float().cpu())
+    out = kernels.matmul(Ad, Bd, trans_a=ta, trans_b=tb, out_dtype=torch.float32)
+    torch.cuda.synchronize()
+    rtol, atol = _tol(dtype)
+    scale = float(np.sqrt(K))
+    np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=rtol, atol=atol * scale)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_asymmetric_identity(dev, dtype):
+    """A = I with an asymmetric B catches a row/col swap in the C write (guide rule 16)."""
+    n = 160
+    A = torch.eye(n)
+    B = (torch.arange(n)[:, None] * 3 + torch.arange(n)[None, :] * 0.5).float() / 64.0
+    out = kernels.matmul(A.to(dev).to(dtype), B.to(dev).to(dtype), out_dtype=torch.float32)
+    np.testing.assert_allclose(out.cpu().numpy(), B.to(dtype).float().numpy(), rtol=1e-6)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_epilogue_bias_act_residual_prez(dev, dtype):
+    M, N, K = 130, 200, 96
+    g = torch.Generator().manual_seed(1)
+    A, B = torch.randn(M, K, generator=g) * 0.3, torch.randn(K, N, generator=g) * 0.3
+    bias, res = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    Ad, Bd, resd = A.to(dev).to(dtype), B.to(dev).to(dtype), res.to(dev).to(dtype)
+    z = Ad.float().cpu() @ Bd.float().cpu() * 0.5 + bias
+    ref = resd.float().cpu() + 0.25 * torch.nn.functional.silu(z)
+    prez = torch.empty(M, N, dtype=dtype, device=dev)
+    out = kernels.matmul(Ad, Bd, bias=bias.to(dev), res=resd, prez=prez, alpha=0.5, beta=0.25, act=ACT_SWISH)
+    rtol, atol = _tol(dtype)
+    np.testing.assert_allclose(out.float().cpu().numpy(), ref.numpy(), rtol=rtol, atol=atol * 4)
+    np.testing.assert_allclose(prez.float().cpu().numpy(), z.numpy(), rtol=rtol, atol=atol * 4)
+    # backward-style epilogue: multiply by swish'(z)
+    dz = kernels.matmul(Ad, Bd, dact_z=prez, dact=ACT_SWISH)
+    zz = prez.float().cpu()
+    s = torch.sigmoid(zz)
+    ref2 = (Ad.float().cpu() @ Bd.float().cpu()) * (s * (1 + zz * (1 - s)))
+    np.testing.assert_allclose(dz.float().cpu().numpy(), ref2.numpy(), rtol=rtol * 2, atol=atol * 4)
+    t = kernels.matmul(Ad, Bd, act=ACT_TANH)
+    np.testing.assert_allclose(t.float().cpu().numpy(), torch.tanh(Ad.float().cpu() @ Bd.float().cpu()).numpy(), rtol=rtol, atol=atol)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_batched_strided_heads(dev, dtype):
+    """scores[b,h] = q[b,:,h,:] @ k[b,:,h,:]^T with q,k laid out [B,T,H,dh] (the attention layout)."""
+    Bn, T, H, dh = 3, 70, 4, 36
+    g = torch.Generator().manual_seed(2)
+    q, k = torch.randn(Bn, T, H, dh, generator=g), torch.randn(Bn, T, H, dh, generator=g)
+    qd, kd = q.to(dev).to(dtype), k.to(dev).to(dtype)
+    out = torch.empty(Bn, H, T, T, dtype=torch.float32, device=dev)
+    kernels.gemm(qd, kd, out, T, T, dh, H * dh, H * dh, T, trans_b=True, nb1=Bn, nb2=H, sA=(T * H * dh, dh),
+                 sB=(T * H * dh, dh), sD=(H * T * T, T * T), alpha=0.125)
+    ref = torch.einsum("bthd,bshd->bhts", qd.float().cpu(), kd.float().cpu()) * 0.125
+    rtol, atol = _tol(dtype)
+    np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=rtol, atol=atol * 6)
+
+
+def test_split_k_accumulate(dev):
+    M, N, K = 144, 576, 5000
+    g = torch.Generator().manual_seed(3)
+    X, dY = torch.randn(K, M, generator=g), torch.randn(K, N, generator=g)
+    for dtype in (torch.float32, torch.bfloat16):
+        Xd, Yd = X.to(dev).to(dtype), dY.to(dev).to(dtype)
+        out = torch.ones(M, N, dtype=torch.float32, device=dev)
+        kernels.gemm(Xd, Yd, out, M, N, K, M, N, N, trans_a=True, accumulate=True, split_k=8)
+        ref = 1.0 + Xd.float().cpu().T @ Yd.float().cpu()
+        rtol, atol = _tol(dtype)
+        np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=rtol, atol=atol * 70)
