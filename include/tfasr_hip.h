@@ -98,6 +98,113 @@ typedef struct {
 
 int tfasr_gemm(const tfasr_gemm_args* args, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * LayerNorm (keras LayerNormalization eps 1e-3: conformer.py:59-64, base_transducer.py:88-93) and
+ * BatchNorm in training mode (keras BatchNormalization(synchronized=True), momentum .99, eps 1e-3:
+ * conformer.py:327-333, subsampling.py:197-203).  x,y,dy,dx are [rows, C] `dtype`; parameters,
+ * statistics and gradients f32.  dgamma/dbeta/stats are ACCUMULATED (atomicAdd): zero them first.
+ *   bn: stats[2C] = (sum x, sum x^2) -> (all-reduce across ranks for sync-BN) -> finalize ->
+ *       fin[4C] = (mean, rstd, scale, shift); y = act(x*scale+shift).  Backward: bstats[2C] =
+ *       (sum dz, sum dz*xhat) -> (all-reduce) -> dx; dgamma = bstats[C:2C], dbeta = bstats[0:C].
+ * ---------------------------------------------------------------------------------------------- */
+int tfasr_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                        long rows, int C, float eps, int dtype, void* stream);
+int tfasr_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
+                        const void* add, void* dx, float* dgamma, float* dbeta, long rows, int C, int dtype,
+                        void* stream);
+int tfasr_bn_stats(const void* x, float* stats, long rows, int C, int dtype, void* stream);
+int tfasr_bn_finalize(const float* stats, float count, const float* gamma, const float* beta, float* fin,
+                      float* moving_mean, float* moving_var, float momentum, float eps, int C, int training,
+                      void* stream);
+int tfasr_bn_apply_fwd(const void* x, const float* fin, void* y, long rows, int C, int act, int dtype, void* stream);
+int tfasr_bn_bwd_stats(const void* x, const void* dy, const float* fin, float* bstats, long rows, int C, int act,
+                       int dtype, void* stream);
+int tfasr_bn_apply_bwd(const void* x, const void* dy, const float* fin, const float* bstats, float count, void* dx,
+                       long rows, int C, int act, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Pointwise / small-reduction stages (see csrc/elementwise.hip for the reference sites).
+ * ---------------------------------------------------------------------------------------------- */
+int tfasr_cast(const void* src, void* dst, long n, int src_dtype, int dst_dtype, void* stream);
+/* out[c] += scale * sum_r x[r*ld + c]   (bias gradients) */
+int tfasr_colsum(const void* x, long ld, float* out, long rows, int C, float scale, int dtype, void* stream);
+/* GLU over the last axis: x [rows, 2C] -> y [rows, C] = x[:, :C] * sigmoid(x[:, C:])  (activations/glu.py:25-28) */
+int tfasr_glu_fwd(const void* x, void* y, long rows, int C, int dtype, void* stream);
+int tfasr_glu_bwd(const void* x, const void* dy, void* dx, long rows, int C, int dtype, void* stream);
+/* causal depthwise Conv1D, channel-last, w [K, C] f32 (keras depthwise kernel [K,C,1]), K <= 32
+ * (convolution.py:159-228, conformer.py:305-313) */
+int tfasr_dwconv_fwd(const void* x, const float* w, const float* bias, void* y, int B, int T, int C, int K, int dtype,
+                     void* stream);
+int tfasr_dwconv_bwd_data(const void* dy, const float* w, void* dx, int B, int T, int C, int K, int dtype, void* stream);
+int tfasr_dwconv_bwd_weight(const void* x, const void* dy, float* dw, float* dbias, int B, int T, int C, int K,
+                            int dtype, void* stream);
+/* y1 = x + u, y2 = x + v (content / positional attention biases, multihead_attention.py:554-558) and its backward */
+int tfasr_bias2_fwd(const void* x, long ldx, const float* u, const float* v, void* y1, void* y2, long rows, int C,
+                    int dtype, void* stream);
+int tfasr_bias2_bwd(const void* d1, const void* d2, void* dx, long lddx, float* du, float* dv, long rows, int C,
+                    int dtype, void* stream);
+/* Embedding gather (table f32 [V,E]) and scatter-add gradient (embedding.py:41-48) */
+int tfasr_embedding_fwd(const int32_t* idx, const float* table, void* out, long rows, int E, int V, int dtype,
+                        void* stream);
+int tfasr_embedding_bwd(const int32_t* idx, const void* dout, float* dtable, long rows, int E, int V, int dtype,
+                        void* stream);
+/* TransducerJointMerge + tanh: h[b,t,u,:] = tanh(enc[b,t,:] + pred[b,u,:])  (base_transducer.py:199-207,291);
+ * backward reduces dh*(1-h^2) over u (-> denc [B,T,J]) and over t (-> dpred [B,U1,J]) */
+int tfasr_joint_fwd(const void* enc, const void* pred, void* h, int B, int T, int U1, int J, int dtype, void* stream);
+int tfasr_joint_bwd(const void* h, const void* dh, void* denc, void* dpred, int B, int T, int U1, int J, int dtype,
+                    void* stream);
+/* keras Adam step over one flat f32 buffer: p -= lr*wd*p; g' = grad_scale*g (+ 2*l2*p for i < n_reg);
+ * m,v update; p -= lr*sqrt(1-b2^t)/(1-b1^t) * m/(sqrt(v)+eps)   (small.yml.j2:73-87; L2: :67-69) */
+int tfasr_adam(float* p, const float* g, float* m, float* v, long n, long n_reg, float lr, float beta1, float beta2,
+               float eps, float weight_decay, float l2, float grad_scale, long step, void* stream);
+int tfasr_sumsq(const float* p, long n, float* out, void* stream);
+/* SpecAugment mask application, in place: fmask [B,nf,2] = (f0, width), tmask [B,nt,2] = (t0, width)
+ * (augmentations/methods/specaugment.py:58-87,108-137; random draws are made by the caller) */
+int tfasr_specaugment(void* x, const int32_t* fmask, const int32_t* tmask, int nf, int nt, int B, int T, int F,
+                      float mask_value, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Relative-position attention softmax (multihead_attention.py:543-582, 27-77; positional_encoding.py:152-172)
+ *   content [B,H,T,T], pos [B,H,T,2T] (column 2T-1 = bias column), probs [B,H,T,T] (may alias content),
+ *   lengths [B] or NULL; use_mask: padded query rows -> uniform.  Backward: dcontent may alias dprobs.
+ * ---------------------------------------------------------------------------------------------- */
+int tfasr_relattn_softmax_fwd(const void* content, const void* pos, const int32_t* lengths, void* probs, int B, int H,
+                              int T, int use_mask, int dtype, void* stream);
+int tfasr_relattn_softmax_bwd(const void* probs, const void* dprobs, const int32_t* lengths, void* dcontent, void* dpos,
+                              int B, int H, int T, int use_mask, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * LSTM cell pointwise stages (keras LSTM, gates i,f,c,o; base_transducer.py:71-85,123-159)
+ * ---------------------------------------------------------------------------------------------- */
+int tfasr_lstm_step_fwd(const void* xg, long xg_stride_b, const float* hr, const void* h_prev, long hprev_stride_b,
+                        const float* c_prev, long cprev_stride_b, const int32_t* lengths, int t, void* gates,
+                        long gates_stride_b, float* c_out, long c_stride_b, void* h_out, long h_stride_b, void* y_out,
+                        long y_stride_b, int B, int P, int dtype, void* stream);
+int tfasr_lstm_step_bwd(const void* dy, long dy_stride_b, const float* dhr, float* dh_carry, float* dc_carry,
+                        const void* gates, long gates_stride_b, const float* c_t, long c_stride_b, const float* c_prev,
+                        long cprev_stride_b, const int32_t* lengths, int t, void* dz, long dz_stride_b, int B, int P,
+                        int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Conv2dSubsampling pieces (subsampling.py:163-254; causal 3x3 stride 2, convolution.py:25-37,132-144)
+ *   conv1: x [B,T0,F0] (Cin=1) -> y [B,ceil(T0/2),ceil(F0/2),C]; w [3,3,1,C] f32
+ *   im2col/col2im for the second conv: x [B,T1,F1,C] <-> col [B*T2*F2, 9*C]
+ * ---------------------------------------------------------------------------------------------- */
+int tfasr_conv1_fwd(const void* x, const float* w, const float* bias, void* y, int B, int T0, int F0, int C, int dtype,
+                    void* stream);
+int tfasr_conv1_bwd_weight(const void* x, const void* dy, float* dw, float* db, int B, int T0, int F0, int C,
+                           int dtype, void* stream);
+int tfasr_im2col_3x3s2(const void* x, void* col, int B, int T1, int F1, int C, int dtype, void* stream);
+int tfasr_col2im_3x3s2(const void* dcol, void* dx, int B, int T1, int F1, int C, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Log-mel frontend (feature_extraction.py:170-231,255-303): signal [B,N] f32 -> out [B,T0,F] (dtype),
+ * T0 = ceil(N/frame_step).  window [frame_len], melw [nfft/2+1, F], band [F,2] = first/last non-zero row of melw.
+ * ---------------------------------------------------------------------------------------------- */
+int tfasr_logmel(const float* signal, int B, int N, float preemph, const float* window, int frame_len, int frame_step,
+                 int nfft, const float* melw, const int32_t* band, int F, float eps, void* out, int T0, int dtype,
+                 void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -213,7 +213,17 @@ def make_tf():
     tf.gather_nd = _gather_nd
     tf.scatter_nd = _scatter_nd
     tf.ensure_shape = lambda x, shape: x
-    tf.map_fn = lambda fn, elems, dtype=None, fn_output_signature=None: _t(np.stack([np.asarray(fn(e)) for e in elems]))
+    def _map_fn(fn, elems, dtype=None, fn_output_signature=None):
+        if isinstance(elems, (tuple, list)):
+            outs = [fn(tuple(_t(e[i]) for e in elems)) for i in range(len(elems[0]))]
+        else:
+            outs = [fn(_t(e)) for e in elems]
+        if isinstance(outs[0], (tuple, list)):
+            return tuple(_t(np.stack([np.asarray(o[k]) for o in outs])) for k in range(len(outs[0])))
+        return _t(np.stack([np.asarray(o) for o in outs]))
+
+    tf.map_fn = _map_fn
+    tf.roll = lambda input, shift, axis: _t(np.roll(np.asarray(input), int(shift), axis=axis))  # noqa: A002
     tf.device = lambda *_a, **_k: contextlib.nullcontext()
     tf.name_scope = lambda *_a, **_k: contextlib.nullcontext()
     tf.newaxis = None
@@ -230,6 +240,34 @@ def make_tf():
                                                         & np.triu(np.ones(np.asarray(x).shape[-2:], bool), -lo if lo >= 0 else -10**9))))
     tf.custom_gradient = lambda f: f
     return tf
+
+
+def extract_functions(rel_path, names, namespace):
+    """exec only the named top-level functions / class methods (`Class.method`) of a reference source file inside
+    `namespace` (used when the module itself imports Keras internals that do not exist here)."""
+    import ast
+
+    src = open(f"{REFERENCE_ROOT}/{rel_path}").read()
+    tree = ast.parse(src)
+    out = {}
+    for node in tree.body:
+        if isinstance(node, ast.FunctionDef) and node.name in names:
+            code = compile(ast.Module(body=[node], type_ignores=[]), rel_path, "exec")
+            exec(code, namespace)
+            out[node.name] = namespace[node.name]
+        if isinstance(node, ast.ClassDef):
+            for sub in node.body:
+                key = f"{node.name}.{sub.name}" if isinstance(sub, ast.FunctionDef) else None
+                if key in names:
+                    sub.decorator_list = []
+                    code = compile(ast.Module(body=[sub], type_ignores=[]), rel_path, "exec")
+                    ns = dict(namespace)
+                    exec(code, ns)
+                    out[key] = ns[sub.name]
+    missing = set(names) - set(out)
+    if missing:
+        raise KeyError(f"{missing} not found in {rel_path}")
+    return out
 
 
 def load_reference_module(rel_path, mod_name, extra_modules=None):

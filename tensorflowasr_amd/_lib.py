@@ -32,16 +32,45 @@ class GemmArgs(Structure):
     ]
 
 
-# name -> (restype, argtypes); every symbol include/tfasr_hip.h declares must be listed here
-# (tests/test_abi.py cross-checks this table against the header).
-SIGNATURES = {
-    "tfasr_status_string": (c_char_p, [c_int]),
-    "tfasr_abi_version": (c_int, []),
-    "tfasr_rnnt_loss_workspace_size": (c_int, [c_int, c_int, c_int, c_int, POINTER(c_size_t)]),
-    "tfasr_rnnt_loss": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
-                                c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
-    "tfasr_gemm": (c_int, [POINTER(GemmArgs), c_void_p]),
-}
+def _parse_header():
+    """Derive the ctypes signature table from include/tfasr_hip.h (single source of truth for the ABI)."""
+    import re
+
+    hdr = os.path.join(HERE, "..", "include", "tfasr_hip.h")
+    if not os.path.exists(hdr):
+        hdr = os.path.join(HERE, "tfasr_hip.h")
+    src = open(hdr).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    src = re.sub(r"typedef\s+struct\s*\{.*?\}\s*\w+\s*;", "", src, flags=re.S)
+    sigs = {}
+    for m in re.finditer(r"(const\s+char\s*\*|int)\s+(tfasr_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", src):
+        ret, name, args = m.group(1), m.group(2), m.group(3).strip()
+        res = c_char_p if "char" in ret else c_int
+        at = []
+        if args and args != "void":
+            for a in args.split(","):
+                a = a.strip()
+                if "tfasr_gemm_args" in a:
+                    at.append(POINTER(GemmArgs))
+                elif "size_t*" in a.replace(" ", ""):
+                    at.append(POINTER(c_size_t))
+                elif "*" in a:
+                    at.append(c_void_p)
+                elif a.startswith("size_t"):
+                    at.append(c_size_t)
+                elif a.startswith("long"):
+                    at.append(c_long)
+                elif a.startswith("float"):
+                    at.append(c_float)
+                elif a.startswith("int") or a.startswith("int32_t"):
+                    at.append(c_int)
+                else:
+                    raise TfasrError(f"cannot map C parameter '{a}' of {name}")
+        sigs[name] = (res, at)
+    return sigs
+
+
+SIGNATURES = _parse_header()
 
 _lib = None
 

@@ -1,0 +1,206 @@
+// Conv2dSubsampling pieces for gfx950 (subsampling.py:163-254; causal 3x3 stride-2 Conv2D = left-pad 2 in
+// time AND frequency then VALID, convolution.py:25-37,132-144; output length ceil(L/2), math_util.py:282-305).
+//   conv1 (Cin = 1): direct kernel, 9 taps per output, channel-last write (HBM-bound on the output)
+//   conv2 (Cin = C): im2col -> MFMA GEMM (K = 9*C) -> col2im for the data gradient
+// Layout: activations [B, T, F, C] channel-last; kernels keras-style [kh, kw, cin, cout].
+#include "common.h"
+#include <algorithm>
+
+namespace {
+
+inline int flat_grid(long n) { return (int)std::max<long>(1, std::min<long>((n + 255) / 256, 256L * 32)); }
+
+// y[b,t,f,c] = bias[c] + sum_{kh,kw} w[kh,kw,0,c] * x[b, 2t+kh-2, 2f+kw-2]
+template <typename T>
+__global__ __launch_bounds__(256) void conv1_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, T* __restrict__ y, int B, int T0,
+                                                        int F0, int T1, int F1, int C) {
+  const int c8n = C / 8;
+  const long n8 = (long)B * T1 * F1 * c8n;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % c8n) * 8;
+    long pos = i / c8n;
+    const int f = (int)(pos % F1); pos /= F1;
+    const int t = (int)(pos % T1);
+    const int b = (int)(pos / T1);
+    float acc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = bias ? bias[c + k] : 0.f;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      const int ti = 2 * t + kh - 2;
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int fi = 2 * f + kw - 2;
+        float xv = 0.f;
+        if (ti >= 0 && ti < T0 && fi >= 0 && fi < F0) xv = Num<T>::ld(x + ((long)b * T0 + ti) * F0 + fi);
+        const float* wp = w + (kh * 3 + kw) * C + c;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] += wp[k] * xv;
+      }
+    }
+    st8(y + i * 8, acc);
+  }
+}
+
+// dw[kh,kw,c] += sum dy[b,t,f,c]*x[...]; db[c] += sum dy.  One wave per strided set of positions; lanes own channels.
+template <typename T>
+__global__ __launch_bounds__(256) void conv1_bwd_weight_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                               float* __restrict__ dw, float* __restrict__ db, int B,
+                                                               int T0, int F0, int T1, int F1, int C) {
+  constexpr int MAXCL = 8;  // C <= 512
+  const int lane = threadIdx.x & 63;
+  const long npos = (long)B * T1 * F1;
+  const long w0 = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const long nw = (long)gridDim.x * (blockDim.x >> 6);
+  float acc[MAXCL][10];
+#pragma unroll
+  for (int q = 0; q < MAXCL; ++q)
+#pragma unroll
+    for (int k = 0; k < 10; ++k) acc[q][k] = 0.f;
+  for (long pos = w0; pos < npos; pos += nw) {
+    long pp = pos;
+    const int f = (int)(pp % F1); pp /= F1;
+    const int t = (int)(pp % T1);
+    const int b = (int)(pp / T1);
+    float xv[9];
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int ti = 2 * t + kh - 2, fi = 2 * f + kw - 2;
+        xv[kh * 3 + kw] = (ti >= 0 && ti < T0 && fi >= 0 && fi < F0) ? Num<T>::ld(x + ((long)b * T0 + ti) * F0 + fi) : 0.f;
+      }
+#pragma unroll
+    for (int q = 0; q < MAXCL; ++q) {
+      const int c = lane + q * 64;
+      if (c < C) {
+        const float d = Num<T>::ld(dy + pos * C + c);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) acc[q][k] += d * xv[k];
+        acc[q][9] += d;
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < MAXCL; ++q) {
+    const int c = lane + q * 64;
+    if (c < C) {
+#pragma unroll
+      for (int k = 0; k < 9; ++k) atomicAdd(dw + k * C + c, acc[q][k]);
+      if (db) atomicAdd(db + c, acc[q][9]);
+    }
+  }
+}
+
+// col[(b,t2,f2), (kh*3+kw)*C + c] = x[b, 2*t2+kh-2, 2*f2+kw-2, c] (0 outside)
+template <typename T>
+__global__ __launch_bounds__(256) void im2col_kernel(const T* __restrict__ x, T* __restrict__ col, int B, int T1, int F1,
+                                                     int T2, int F2, int C) {
+  const int c8n = C / 8;
+  const long n8 = (long)B * T2 * F2 * 9 * c8n;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % c8n) * 8;
+    long r = i / c8n;
+    const int tap = (int)(r % 9); r /= 9;
+    const int f = (int)(r % F2); r /= F2;
+    const int t = (int)(r % T2);
+    const int b = (int)(r / T2);
+    const int ti = 2 * t + tap / 3 - 2, fi = 2 * f + tap % 3 - 2;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    float vf[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (ti >= 0 && ti < T1 && fi >= 0 && fi < F1) ld8(x + (((long)b * T1 + ti) * F1 + fi) * C + c, vf);
+    (void)v;
+    st8(col + i * 8, vf);
+  }
+}
+
+// dx[b,t1,f1,c] = sum over taps with matching parity of dcol[(b,(t1+2-kh)/2,(f1+2-kw)/2), tap*C + c]
+template <typename T>
+__global__ __launch_bounds__(256) void col2im_kernel(const T* __restrict__ dcol, T* __restrict__ dx, int B, int T1,
+                                                     int F1, int T2, int F2, int C) {
+  const int c8n = C / 8;
+  const long n8 = (long)B * T1 * F1 * c8n;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % c8n) * 8;
+    long r = i / c8n;
+    const int f1 = (int)(r % F1); r /= F1;
+    const int t1 = (int)(r % T1);
+    const int b = (int)(r / T1);
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      const int tt = t1 + 2 - kh;
+      if (tt < 0 || (tt & 1)) continue;
+      const int t2 = tt >> 1;
+      if (t2 >= T2) continue;
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int ff = f1 + 2 - kw;
+        if (ff < 0 || (ff & 1)) continue;
+        const int f2 = ff >> 1;
+        if (f2 >= F2) continue;
+        float v[8];
+        ld8(dcol + ((((long)b * T2 + t2) * F2 + f2) * 9 + kh * 3 + kw) * C + c, v);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] += v[k];
+      }
+    }
+    st8(dx + i * 8, acc);
+  }
+}
+
+}  // namespace
+
+#define DISPATCH_T(dtype, CALL_F32, CALL_BF16) \
+  do { if ((dtype) == TFASR_F32) { CALL_F32; } else if ((dtype) == TFASR_BF16) { CALL_BF16; } else return TFASR_STATUS_INVALID_VALUE; } while (0)
+
+extern "C" int tfasr_conv1_fwd(const void* x, const float* w, const float* bias, void* y, int B, int T0, int F0, int C,
+                               int dtype, void* stream_) {
+  if (!x || !w || !y || B <= 0 || T0 <= 0 || F0 <= 0 || C <= 0 || C % 8) return TFASR_STATUS_INVALID_VALUE;
+  const int T1 = (T0 + 1) / 2, F1 = (F0 + 1) / 2;
+  hipStream_t s = (hipStream_t)stream_;
+  const int grid = flat_grid((long)B * T1 * F1 * C / 8);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(conv1_fwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, w, bias, (float*)y, B, T0, F0, T1, F1, C),
+             hipLaunchKernelGGL(conv1_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)x, w, bias, (bf16_t*)y, B, T0, F0, T1, F1, C));
+  TFASR_CHECK_LAUNCH();
+  return TFASR_STATUS_SUCCESS;
+}
+
+extern "C" int tfasr_conv1_bwd_weight(const void* x, const void* dy, float* dw, float* db, int B, int T0, int F0, int C,
+                                      int dtype, void* stream_) {
+  if (!x || !dy || !dw || B <= 0 || T0 <= 0 || F0 <= 0 || C <= 0 || C > 512) return TFASR_STATUS_INVALID_VALUE;
+  const int T1 = (T0 + 1) / 2, F1 = (F0 + 1) / 2;
+  hipStream_t s = (hipStream_t)stream_;
+  const int grid = (int)std::max<long>(1, std::min<long>((long)B * T1 * F1 / 16 + 1, 2048));
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(conv1_bwd_weight_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, (const float*)dy, dw, db, B, T0, F0, T1, F1, C),
+             hipLaunchKernelGGL(conv1_bwd_weight_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)dy, dw, db, B, T0, F0, T1, F1, C));
+  TFASR_CHECK_LAUNCH();
+  return TFASR_STATUS_SUCCESS;
+}
+
+extern "C" int tfasr_im2col_3x3s2(const void* x, void* col, int B, int T1, int F1, int C, int dtype, void* stream_) {
+  if (!x || !col || B <= 0 || T1 <= 0 || F1 <= 0 || C <= 0 || C % 8) return TFASR_STATUS_INVALID_VALUE;
+  const int T2 = (T1 + 1) / 2, F2 = (F1 + 1) / 2;
+  hipStream_t s = (hipStream_t)stream_;
+  const int grid = flat_grid((long)B * T2 * F2 * 9 * C / 8);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(im2col_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, (float*)col, B, T1, F1, T2, F2, C),
+             hipLaunchKernelGGL(im2col_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)col, B, T1, F1, T2, F2, C));
+  TFASR_CHECK_LAUNCH();
+  return TFASR_STATUS_SUCCESS;
+}
+
+extern "C" int tfasr_col2im_3x3s2(const void* dcol, void* dx, int B, int T1, int F1, int C, int dtype, void* stream_) {
+  if (!dcol || !dx || B <= 0 || T1 <= 0 || F1 <= 0 || C <= 0 || C % 8) return TFASR_STATUS_INVALID_VALUE;
+  const int T2 = (T1 + 1) / 2, F2 = (F1 + 1) / 2;
+  hipStream_t s = (hipStream_t)stream_;
+  const int grid = flat_grid((long)B * T1 * F1 * C / 8);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(col2im_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)dcol, (float*)dx, B, T1, F1, T2, F2, C),
+             hipLaunchKernelGGL(col2im_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)dcol, (bf16_t*)dx, B, T1, F1, T2, F2, C));
+  TFASR_CHECK_LAUNCH();
+  return TFASR_STATUS_SUCCESS;
+}

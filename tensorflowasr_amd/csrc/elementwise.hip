@@ -1,0 +1,542 @@
+// HBM-bound pointwise / small-reduction kernels of the Conformer-Transducer hot path (gfx950).
+// Every kernel moves 16 B per lane where the layout allows it (channel-last, C % 8 == 0) and keeps
+// channel = fastest index so a wave reads/writes whole 128-B lines.
+//   cast, colsum (bias gradients), GLU fwd/bwd (activations/glu.py:25-28), causal depthwise conv
+//   fwd/bwd (convolution.py:159-228), shared attention biases u/v (conformer.py:647-663,
+//   multihead_attention.py:554-558), embedding gather/scatter (embedding.py:41-48), joint
+//   broadcast-add+tanh fwd/bwd (base_transducer.py:199-207,291), Adam (+L2, decoupled weight decay).
+#include "common.h"
+#include <algorithm>
+
+namespace {
+
+inline int flat_grid(long n, int per = 256) { return (int)std::max<long>(1, std::min<long>((n + per - 1) / per, 256L * 16)); }
+
+// ---------------------------------------------------------------------------------------- cast
+template <typename S, typename D>
+__global__ __launch_bounds__(256) void cast_kernel(const S* __restrict__ src, D* __restrict__ dst, long n) {
+  const long n8 = n / 8;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+    float v[8];
+    ld8(src + i * 8, v);
+    st8(dst + i * 8, v);
+  }
+  for (long i = n8 * 8 + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    Num<D>::st(dst + i, Num<S>::ld(src + i));
+}
+
+// -------------------------------------------------------------------------------------- colsum
+// out[c] (+)= scale * sum_r x[r, c]; x has row stride ld.  grid = (row blocks, ceil(C/64))
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, long ld, float* __restrict__ out,
+                                                     long rows, int C, float scale) {
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int c = blockIdx.y * 64 + lane;
+  float acc = 0.f;
+  if (c < C)
+    for (long r = (long)blockIdx.x * 4 + w; r < rows; r += (long)gridDim.x * 4) acc += Num<T>::ld(x + r * ld + c);
+  red[w][lane] = acc;
+  __syncthreads();
+  if (w == 0 && c < C) atomicAdd(out + c, scale * (red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]));
+}
+
+// ----------------------------------------------------------------------------------------- GLU
+template <typename T>
+__global__ __launch_bounds__(256) void glu_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, long rows, int C) {
+  const long n8 = rows * C / 8;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+    const long e = i * 8, r = e / C;
+    const int c = (int)(e % C);
+    float a[8], b[8];
+    ld8(x + r * 2 * C + c, a);
+    ld8(x + r * 2 * C + C + c, b);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a[k] *= sigmoidf_(b[k]);
+    st8(y + e, a);
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void glu_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                      T* __restrict__ dx, long rows, int C) {
+  const long n8 = rows * C / 8;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+    const long e = i * 8, r = e / C;
+    const int c = (int)(e % C);
+    float a[8], b[8], d[8];
+    ld8(x + r * 2 * C + c, a);
+    ld8(x + r * 2 * C + C + c, b);
+    ld8(dy + e, d);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float s = sigmoidf_(b[k]);
+      b[k] = d[k] * a[k] * s * (1.f - s);
+      a[k] = d[k] * s;
+    }
+    st8(dx + r * 2 * C + c, a);
+    st8(dx + r * 2 * C + C + c, b);
+  }
+}
+
+// ---------------------------------------------------------------------- causal depthwise conv
+constexpr int DW_TT = 8;
+constexpr int DW_MAXK = 32;
+// y[b,t,c] = bias[c] + sum_k w[k,c] * x[b, t-(K-1)+k, c]
+template <typename T>
+__global__ __launch_bounds__(256) void dwconv_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w,
+                                                         const float* __restrict__ bias, T* __restrict__ y, int Tn,
+                                                         int C, int K) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const int t0 = blockIdx.y * DW_TT;
+  const long base = (long)blockIdx.z * Tn * C;
+  float wk[DW_MAXK];
+#pragma unroll
+  for (int k = 0; k < DW_MAXK; ++k) wk[k] = (k < K) ? w[k * C + c] : 0.f;
+  float acc[DW_TT];
+  const float bv = bias ? bias[c] : 0.f;
+#pragma unroll
+  for (int i = 0; i < DW_TT; ++i) acc[i] = bv;
+#pragma unroll
+  for (int j = 0; j < DW_MAXK - 1 + DW_TT; ++j) {  // input time index ti = t0-(K-1)+j (fully unrolled: register indices static)
+    if (j < K - 1 + DW_TT) {
+      const int ti = t0 - (K - 1) + j;
+      const float xv = (ti >= 0 && ti < Tn) ? Num<T>::ld(x + base + (long)ti * C + c) : 0.f;
+#pragma unroll
+      for (int i = 0; i < DW_TT; ++i) {
+        const int k = j - i;  // ti = (t0+i)-(K-1)+k  (compile-time after unrolling)
+        if (k >= 0 && k < DW_MAXK) acc[i] += wk[k] * xv;  // wk[k] == 0 for k >= K
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < DW_TT; ++i)
+    if (t0 + i < Tn) Num<T>::st(y + base + (long)(t0 + i) * C + c, acc[i]);
+}
+// dx[b,t,c] = sum_k w[k,c] * dy[b, t+(K-1)-k, c]
+template <typename T>
+__global__ __launch_bounds__(256) void dwconv_bwd_data_kernel(const T* __restrict__ dy, const float* __restrict__ w,
+                                                              T* __restrict__ dx, int Tn, int C, int K) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const int t0 = blockIdx.y * DW_TT;
+  const long base = (long)blockIdx.z * Tn * C;
+  float wr[DW_MAXK];  // reversed taps: wr[q] = w[K-1-q]
+#pragma unroll
+  for (int q = 0; q < DW_MAXK; ++q) wr[q] = (q < K) ? w[(K - 1 - q) * C + c] : 0.f;
+  float acc[DW_TT];
+#pragma unroll
+  for (int i = 0; i < DW_TT; ++i) acc[i] = 0.f;
+#pragma unroll
+  for (int j = 0; j < DW_MAXK - 1 + DW_TT; ++j) {  // output-gradient time index to = t0 + j
+    if (j < K - 1 + DW_TT) {
+      const int to = t0 + j;
+      const float dv = (to < Tn) ? Num<T>::ld(dy + base + (long)to * C + c) : 0.f;
+#pragma unroll
+      for (int i = 0; i < DW_TT; ++i) {
+        const int q = j - i;  // to = (t0+i)+q, tap k = K-1-q
+        if (q >= 0 && q < DW_MAXK) acc[i] += wr[q] * dv;
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < DW_TT; ++i)
+    if (t0 + i < Tn) Num<T>::st(dx + base + (long)(t0 + i) * C + c, acc[i]);
+}
+// dw[k,c] += sum_{b,t} dy[b,t,c]*x[b,t-(K-1)+k,c]; dbias[c] += sum dy.  grid = (C/blk, t chunks of DW_WT, B)
+constexpr int DW_WT = 64;
+template <typename T>
+__global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                                float* __restrict__ dw, float* __restrict__ dbias,
+                                                                int Tn, int C, int K) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const int t0 = blockIdx.y * DW_WT;
+  const long base = (long)blockIdx.z * Tn * C;
+  float acc[DW_MAXK];
+#pragma unroll
+  for (int k = 0; k < DW_MAXK; ++k) acc[k] = 0.f;
+  float ab = 0.f;
+  // sliding window of x over ti in [t-(K-1), t]
+  float win[DW_MAXK];
+#pragma unroll
+  for (int k = 0; k < DW_MAXK; ++k) {
+    const int ti = t0 - (K - 1) + k - 1;  // window before first shift: positions t0-1-(K-1)+k
+    win[k] = (k < K && ti >= 0 && ti < Tn) ? Num<T>::ld(x + base + (long)ti * C + c) : 0.f;
+  }
+  const int tend = min(t0 + DW_WT, Tn);
+  for (int t = t0; t < tend; ++t) {
+#pragma unroll
+    for (int k = 0; k < DW_MAXK - 1; ++k) win[k] = win[k + 1];
+    // newest element sits at index K-1 (ti = t)
+    const float xn = Num<T>::ld(x + base + (long)t * C + c);
+#pragma unroll
+    for (int k = 0; k < DW_MAXK; ++k) if (k == K - 1) win[k] = xn;
+    const float d = Num<T>::ld(dy + base + (long)t * C + c);
+    ab += d;
+#pragma unroll
+    for (int k = 0; k < DW_MAXK; ++k) acc[k] += d * win[k];
+  }
+#pragma unroll
+  for (int k = 0; k < DW_MAXK; ++k) if (k < K) atomicAdd(dw + k * C + c, acc[k]);
+  if (dbias) atomicAdd(dbias + c, ab);
+}
+
+// ---------------------------------------------------------------- shared attention biases u,v
+// y1 = x + u, y2 = x + v  (x has row stride ldx; y contiguous [rows, C])
+template <typename T>
+__global__ __launch_bounds__(256) void bias2_fwd_kernel(const T* __restrict__ x, long ldx, const float* __restrict__ u,
+                                                        const float* __restrict__ v, T* __restrict__ y1,
+                                                        T* __restrict__ y2, long rows, int C) {
+  const long n = rows * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / C;
+    const int c = (int)(i % C);
+    const float xv = Num<T>::ld(x + r * ldx + c);
+    Num<T>::st(y1 + i, xv + u[c]);
+    Num<T>::st(y2 + i, xv + v[c]);
+  }
+}
+// dx = d1 + d2 (row stride lddx); du += colsum(d1); dv += colsum(d2)
+template <typename T>
+__global__ __launch_bounds__(256) void bias2_bwd_kernel(const T* __restrict__ d1, const T* __restrict__ d2,
+                                                        T* __restrict__ dx, long lddx, float* __restrict__ du,
+                                                        float* __restrict__ dv, long rows, int C) {
+  __shared__ float red[2][4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int c = blockIdx.y * 64 + lane;
+  float a1 = 0.f, a2 = 0.f;
+  if (c < C)
+    for (long r = (long)blockIdx.x * 4 + w; r < rows; r += (long)gridDim.x * 4) {
+      const float x1 = Num<T>::ld(d1 + r * C + c), x2 = Num<T>::ld(d2 + r * C + c);
+      Num<T>::st(dx + r * lddx + c, x1 + x2);
+      a1 += x1;
+      a2 += x2;
+    }
+  red[0][w][lane] = a1;
+  red[1][w][lane] = a2;
+  __syncthreads();
+  if (w == 0 && c < C) {
+    atomicAdd(du + c, red[0][0][lane] + red[0][1][lane] + red[0][2][lane] + red[0][3][lane]);
+    atomicAdd(dv + c, red[1][0][lane] + red[1][1][lane] + red[1][2][lane] + red[1][3][lane]);
+  }
+}
+
+// ------------------------------------------------------------------------------------ embedding
+template <typename T>
+__global__ __launch_bounds__(256) void embedding_fwd_kernel(const int32_t* __restrict__ idx,
+                                                            const float* __restrict__ table, T* __restrict__ out,
+                                                            long rows, int E, int V) {
+  const long n = rows * E;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / E;
+    const int e = (int)(i % E);
+    const int id = min(max(idx[r], 0), V - 1);
+    Num<T>::st(out + i, table[(long)id * E + e]);
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void embedding_bwd_kernel(const int32_t* __restrict__ idx, const T* __restrict__ dout,
+                                                            float* __restrict__ dtable, long rows, int E, int V) {
+  const long n = rows * E;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / E;
+    const int e = (int)(i % E);
+    const int id = min(max(idx[r], 0), V - 1);
+    atomicAdd(dtable + (long)id * E + e, Num<T>::ld(dout + i));
+  }
+}
+
+// ---------------------------------------------------------------------------------------- joint
+// h[b,t,u,:] = tanh(enc[b,t,:] + pred[b,u,:])
+template <typename T>
+__global__ __launch_bounds__(256) void joint_fwd_kernel(const T* __restrict__ enc, const T* __restrict__ pred,
+                                                        T* __restrict__ h, int B, int Tn, int U1, int J) {
+  const long n8 = (long)B * Tn * U1 * J / 8;
+  const int j8 = J / 8;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+    const int j = (int)(i % j8) * 8;
+    const long row = i / j8;  // (b,t,u)
+    const int u = (int)(row % U1);
+    const long bt = row / U1;
+    const int b = (int)(bt / Tn);
+    float a[8], p[8];
+    ld8(enc + bt * J + j, a);
+    ld8(pred + ((long)b * U1 + u) * J + j, p);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a[k] = tanhf(a[k] + p[k]);
+    st8(h + i * 8, a);
+  }
+}
+// MODE 0: denc[b,t,:] = sum_u dh*(1-h^2)   (grid.x = B*T)
+// MODE 1: dpred[b,u,:] = sum_t dh*(1-h^2)  (grid.x = B*U1)
+template <typename T, int MODE>
+__global__ __launch_bounds__(128) void joint_bwd_kernel(const T* __restrict__ h, const T* __restrict__ dh,
+                                                        T* __restrict__ dout, int B, int Tn, int U1, int J) {
+  const int j = (blockIdx.y * blockDim.x + threadIdx.x) * 8;
+  if (j >= J) return;
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long base, stride;
+  int count;
+  if (MODE == 0) { base = (long)blockIdx.x * U1 * J; stride = J; count = U1; }
+  else {
+    const int b = blockIdx.x / U1, u = blockIdx.x % U1;
+    base = ((long)b * Tn * U1 + u) * J; stride = (long)U1 * J; count = Tn;
+  }
+  for (int k = 0; k < count; ++k) {
+    float hv[8], dv[8];
+    ld8(h + base + k * stride + j, hv);
+    ld8(dh + base + k * stride + j, dv);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) acc[q] += dv[q] * (1.f - hv[q] * hv[q]);
+  }
+  st8(dout + (long)blockIdx.x * J + j, acc);
+}
+
+// ----------------------------------------------------------------------------------------- Adam
+// keras.optimizers.Adam semantics (bias-corrected, decoupled weight_decay applied first) + the L2
+// kernel regulariser gradient 2*l2*p on the first n_reg elements (small.yml.j2:67-69,73-87).
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, long n, long n_reg,
+                                                   float lr, float b1, float b2, float eps, float wd, float l2,
+                                                   float gscale, float bc1, float bc2) {
+  const float alpha = lr * sqrtf(bc2) / bc1;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float pv = p[i];
+    float gv = g[i] * gscale;
+    if (i < n_reg) gv += 2.f * l2 * pv;
+    pv -= pv * wd * lr;
+    const float mv = m[i] + (gv - m[i]) * (1.f - b1);
+    const float vv = v[i] + (gv * gv - v[i]) * (1.f - b2);
+    m[i] = mv;
+    v[i] = vv;
+    p[i] = pv - alpha * mv / (sqrtf(vv) + eps);
+  }
+}
+
+// sum of squares (regularisation loss term); out[0] += sum p^2
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ p, long n, float* __restrict__ out) {
+  __shared__ float red[16];
+  float a = 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) a += p[i] * p[i];
+  a = block_sum(a, red);
+  if (threadIdx.x == 0) atomicAdd(out, a);
+}
+
+// ------------------------------------------------------------------------------- SpecAugment
+// x[b,t,f] = mval where any (f0<=f<f0+fw) or (t0<=t<t0+tw)  (specaugment.py:78-86,128-136)
+template <typename T>
+__global__ __launch_bounds__(256) void specaug_kernel(T* __restrict__ x, const int32_t* __restrict__ fmask,
+                                                      const int32_t* __restrict__ tmask, int nf, int nt, int B, int Tn,
+                                                      int F, float mval) {
+  const long n = (long)B * Tn * F;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int f = (int)(i % F);
+    const int t = (int)((i / F) % Tn);
+    const int b = (int)(i / ((long)F * Tn));
+    bool hit = false;
+    for (int k = 0; k < nf; ++k) {
+      const int f0 = fmask[(b * nf + k) * 2], fw = fmask[(b * nf + k) * 2 + 1];
+      hit |= (f >= f0 && f < f0 + fw);
+    }
+    for (int k = 0; k < nt; ++k) {
+      const int t0 = tmask[(b * nt + k) * 2], tw = tmask[(b * nt + k) * 2 + 1];
+      hit |= (t >= t0 && t < t0 + tw);
+    }
+    if (hit) Num<T>::st(x + i, mval);
+  }
+}
+
+}  // namespace
+
+#define DISPATCH_T(dtype, CALL_F32, CALL_BF16) \
+  do { if ((dtype) == TFASR_F32) { CALL_F32; } else if ((dtype) == TFASR_BF16) { CALL_BF16; } else return TFASR_STATUS_INVALID_VALUE; } while (0)
+
+extern "C" int tfasr_cast(const void* src, void* dst, long n, int src_dtype, int dst_dtype, void* stream_) {
+  if (!src || !dst || n <= 0) return TFASR_STATUS_INVALID_VALUE;
+  hipStream_t s = (hipStream_t)stream_;
+  const int grid = flat_grid(n / 8 + 1);
+  if (src_dtype == TFASR_F32 && dst_dtype == TFASR_BF16)
+    hipLaunchKernelGGL((cast_kernel<float, bf16_t>), dim3(grid), dim3(256), 0, s, (const float*)src, (bf16_t*)dst, n);
+  else if (src_dtype == TFASR_BF16 && dst_dtype == TFASR_F32)
+    hipLaunchKernelGGL((cast_kernel<bf16_t, float>), dim3(grid), dim3(256), 0, s, (const bf16_t*)src, (float*)dst, n);
+  else if (src_dtype == TFASR_F32 && dst_dtype == TFASR_F32)
+    hipLaunchKernelGGL((cast_kernel<float, float>), dim3(grid), dim3(256), 0, s, (const float*)src, (float*)dst, n);
+  else if (src_dtype == TFASR_BF16 && dst_dtype == TFASR_BF16)
+    hipLaunchKernelGGL((cast_kernel<bf16_t, bf16_t>), dim3(grid), dim3(256), 0, s, (const bf16_t*)src, (bf16_t*)dst, n);
+  else return TFASR_STATUS_INVALID_VALUE;
+  TFASR_CHECK_LAUNCH();
+  return TFASR_STATUS_SUCCESS;
+}
+
+extern "C" int tfasr_colsum(const void* x, long ld, float* out, long rows, int C, float scale, int dtype, void* stream_) {
+  if (!x || !out || rows <= 0 || C <= 0) return TFASR_STATUS_INVALID_VALUE;
+  hipStream_t s = (hipStream_t)stream_;
+  const int gx = (int)std::max<long>(1, std::min<long>(rows / 64 + 1, 256));
+  dim3 grid(gx, (C + 63) / 64);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, s, (const float*)x, ld, out, rows, C, scale),
+             hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, ld, out, rows, C, scale));
+  TFASR_CHECK_LAUNCH();
+  return TFASR_STATUS_SUCCESS;
+}
+
+extern "C" int tfasr_glu_fwd(const void* x, void* y, long rows, int C, int dtype, void* stream_) {
+  if (!x || !y || rows <= 0 || C <= 0 || C % 8) return TFASR_STATUS_INVALID_VALUE;
+  hipStream_t s = (hipStream_t)stream_;
+  const int grid = flat_grid(rows * C / 8);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(glu_fwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, (float*)y, rows, C),
+             hipLaunchKernelGGL(glu_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, rows, C));
+  TFASR_CHECK_LAUNCH();
+  return TFASR_STATUS_SUCCESS;
+}
+extern "C" int tfasr_glu_bwd(const void* x, const void* dy, void* dx, long rows, int C, int dtype, void* stream_) {
+  if (!x || !dy || !dx || rows <= 0 || C <= 0 || C % 8) return TFASR_STATUS_INVALID_VALUE;
+  hipStream_t s = (hipStream_t)stream_;
+  const int grid = flat_grid(rows * C / 8);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(glu_bwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, (const float*)dy, (float*)dx, rows, C),
+             hipLaunchKernelGGL(glu_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)dx, rows, C));
+  TFASR_CHECK_LAUNCH();
+  return TFASR_STATUS_SUCCESS;
+}
+
+extern "C" int tfasr_dwconv_fwd(const void* x, const float* w, const float* bias, void* y, int B, int T, int C, int K,
+                                int dtype, void* stream_) {
+  if (!x || !w || !y || B <= 0 || T <= 0 || C <= 0 || K <= 0 || K > DW_MAXK) return TFASR_STATUS_INVALID_VALUE;
+  hipStream_t s = (hipStream_t)stream_;
+  const int bx = C >= 256 ? 256 : ((C + 63) / 64) * 64;
+  dim3 grid((C + bx - 1) / bx, (T + DW_TT - 1) / DW_TT, B);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(dwconv_fwd_kernel<float>, grid, dim3(bx), 0, s, (const float*)x, w, bias, (float*)y, T, C, K),
+             hipLaunchKernelGGL(dwconv_fwd_kernel<bf16_t>, grid, dim3(bx), 0, s, (const bf16_t*)x, w, bias, (bf16_t*)y, T, C, K));
+  TFASR_CHECK_LAUNCH();
+  return TFASR_STATUS_SUCCESS;
+}
+extern "C" int tfasr_dwconv_bwd_data(const void* dy, const float* w, void* dx, int B, int T, int C, int K, int dtype,
+                                     void* stream_) {
+  if (!dy || !w || !dx || B <= 0 || T <= 0 || C <= 0 || K <= 0 || K > DW_MAXK) return TFASR_STATUS_INVALID_VALUE;
+  hipStream_t s = (hipStream_t)stream_;
+  const int bx = C >= 256 ? 256 : ((C + 63) / 64) * 64;
+  dim3 grid((C + bx - 1) / bx, (T + DW_TT - 1) / DW_TT, B);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(dwconv_bwd_data_kernel<float>, grid, dim3(bx), 0, s, (const float*)dy, w, (float*)dx, T, C, K),
+             hipLaunchKernelGGL(dwconv_bwd_data_kernel<bf16_t>, grid, dim3(bx), 0, s, (const bf16_t*)dy, w, (bf16_t*)dx, T, C, K));
+  TFASR_CHECK_LAUNCH();
+  return TFASR_STATUS_SUCCESS;
+}
+extern "C" int tfasr_dwconv_bwd_weight(const void* x, const void* dy, float* dw, float* dbias, int B, int T, int C,
+                                       int K, int dtype, void* stream_) {
+  if (!x || !dy || !dw || B <= 0 || T <= 0 || C <= 0 || K <= 0 || K > DW_MAXK) return TFASR_STATUS_INVALID_VALUE;
+  hipStream_t s = (hipStream_t)stream_;
+  const int bx = C >= 256 ? 256 : ((C + 63) / 64) * 64;
+  dim3 grid((C + bx - 1) / bx, (T + DW_WT - 1) / DW_WT, B);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(dwconv_bwd_weight_kernel<float>, grid, dim3(bx), 0, s, (const float*)x, (const float*)dy, dw, dbias, T, C, K),
+             hipLaunchKernelGGL(dwconv_bwd_weight_kernel<bf16_t>, grid, dim3(bx), 0, s, (const bf16_t*)x, (const bf16_t*)dy, dw, dbias, T, C, K));
+  TFASR_CHECK_LAUNCH();
+  return TFASR_STATUS_SUCCESS;
+}
+
+extern "C" int tfasr_bias2_fwd(const void* x, long ldx, const float* u, const float* v, void* y1, void* y2, long rows,
+                               int C, int dtype, void* stream_) {
+  if (!x || !u || !v || !y1 || !y2 || rows <= 0 || C <= 0) return TFASR_STATUS_INVALID_VALUE;
+  hipStream_t s = (hipStream_t)stream_;
+  const int grid = flat_grid(rows * C);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(bias2_fwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, ldx, u, v, (float*)y1, (float*)y2, rows, C),
+             hipLaunchKernelGGL(bias2_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)x, ldx, u, v, (bf16_t*)y1, (bf16_t*)y2, rows, C));
+  TFASR_CHECK_LAUNCH();
+  return TFASR_STATUS_SUCCESS;
+}
+extern "C" int tfasr_bias2_bwd(const void* d1, const void* d2, void* dx, long lddx, float* du, float* dv, long rows,
+                               int C, int dtype, void* stream_) {
+  if (!d1 || !d2 || !dx || !du || !dv || rows <= 0 || C <= 0) return TFASR_STATUS_INVALID_VALUE;
+  hipStream_t s = (hipStream_t)stream_;
+  const int gx = (int)std::max<long>(1, std::min<long>(rows / 64 + 1, 256));
+  dim3 grid(gx, (C + 63) / 64);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(bias2_bwd_kernel<float>, grid, dim3(256), 0, s, (const float*)d1, (const float*)d2, (float*)dx, lddx, du, dv, rows, C),
+             hipLaunchKernelGGL(bias2_bwd_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)d1, (const bf16_t*)d2, (bf16_t*)dx, lddx, du, dv, rows, C));
+  TFASR_CHECK_LAUNCH();
+  return TFASR_STATUS_SUCCESS;
+}
+
+extern "C" int tfasr_embedding_fwd(const int32_t* idx, const float* table, void* out, long rows, int E, int V,
+                                   int dtype, void* stream_) {
+  if (!idx || !table || !out || rows <= 0 || E <= 0 || V <= 0) return TFASR_STATUS_INVALID_VALUE;
+  hipStream_t s = (hipStream_t)stream_;
+  const int grid = flat_grid(rows * E);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(embedding_fwd_kernel<float>, dim3(grid), dim3(256), 0, s, idx, table, (float*)out, rows, E, V),
+             hipLaunchKernelGGL(embedding_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, idx, table, (bf16_t*)out, rows, E, V));
+  TFASR_CHECK_LAUNCH();
+  return TFASR_STATUS_SUCCESS;
+}
+extern "C" int tfasr_embedding_bwd(const int32_t* idx, const void* dout, float* dtable, long rows, int E, int V,
+                                   int dtype, void* stream_) {
+  if (!idx || !dout || !dtable || rows <= 0 || E <= 0 || V <= 0) return TFASR_STATUS_INVALID_VALUE;
+  hipStream_t s = (hipStream_t)stream_;
+  const int grid = flat_grid(rows * E);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(embedding_bwd_kernel<float>, dim3(grid), dim3(256), 0, s, idx, (const float*)dout, dtable, rows, E, V),
+             hipLaunchKernelGGL(embedding_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, idx, (const bf16_t*)dout, dtable, rows, E, V));
+  TFASR_CHECK_LAUNCH();
+  return TFASR_STATUS_SUCCESS;
+}
+
+extern "C" int tfasr_joint_fwd(const void* enc, const void* pred, void* h, int B, int T, int U1, int J, int dtype,
+                               void* stream_) {
+  if (!enc || !pred || !h || B <= 0 || T <= 0 || U1 <= 0 || J <= 0 || J % 8) return TFASR_STATUS_INVALID_VALUE;
+  hipStream_t s = (hipStream_t)stream_;
+  const int grid = flat_grid((long)B * T * U1 * J / 8);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(joint_fwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)enc, (const float*)pred, (float*)h, B, T, U1, J),
+             hipLaunchKernelGGL(joint_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)enc, (const bf16_t*)pred, (bf16_t*)h, B, T, U1, J));
+  TFASR_CHECK_LAUNCH();
+  return TFASR_STATUS_SUCCESS;
+}
+extern "C" int tfasr_joint_bwd(const void* h, const void* dh, void* denc, void* dpred, int B, int T, int U1, int J,
+                               int dtype, void* stream_) {
+  if (!h || !dh || !denc || !dpred || B <= 0 || T <= 0 || U1 <= 0 || J <= 0 || J % 8) return TFASR_STATUS_INVALID_VALUE;
+  hipStream_t s = (hipStream_t)stream_;
+  const int gy = (J / 8 + 127) / 128;
+  dim3 g0(B * T, gy), g1(B * U1, gy);
+  DISPATCH_T(dtype,
+             { hipLaunchKernelGGL((joint_bwd_kernel<float, 0>), g0, dim3(128), 0, s, (const float*)h, (const float*)dh, (float*)denc, B, T, U1, J);
+               hipLaunchKernelGGL((joint_bwd_kernel<float, 1>), g1, dim3(128), 0, s, (const float*)h, (const float*)dh, (float*)dpred, B, T, U1, J); },
+             { hipLaunchKernelGGL((joint_bwd_kernel<bf16_t, 0>), g0, dim3(128), 0, s, (const bf16_t*)h, (const bf16_t*)dh, (bf16_t*)denc, B, T, U1, J);
+               hipLaunchKernelGGL((joint_bwd_kernel<bf16_t, 1>), g1, dim3(128), 0, s, (const bf16_t*)h, (const bf16_t*)dh, (bf16_t*)dpred, B, T, U1, J); });
+  TFASR_CHECK_LAUNCH();
+  return TFASR_STATUS_SUCCESS;
+}
+
+extern "C" int tfasr_adam(float* p, const float* g, float* m, float* v, long n, long n_reg, float lr, float beta1,
+                          float beta2, float eps, float weight_decay, float l2, float grad_scale, long step,
+                          void* stream_) {
+  if (!p || !g || !m || !v || n <= 0 || step <= 0) return TFASR_STATUS_INVALID_VALUE;
+  const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
+  hipLaunchKernelGGL(adam_kernel, dim3(flat_grid(n)), dim3(256), 0, (hipStream_t)stream_, p, g, m, v, n, n_reg, lr, beta1,
+                     beta2, eps, weight_decay, l2, grad_scale, bc1, bc2);
+  TFASR_CHECK_LAUNCH();
+  return TFASR_STATUS_SUCCESS;
+}
+
+extern "C" int tfasr_sumsq(const float* p, long n, float* out, void* stream_) {
+  if (!p || !out || n <= 0) return TFASR_STATUS_INVALID_VALUE;
+  hipLaunchKernelGGL(sumsq_kernel, dim3(flat_grid(n)), dim3(256), 0, (hipStream_t)stream_, p, n, out);
+  TFASR_CHECK_LAUNCH();
+  return TFASR_STATUS_SUCCESS;
+}
+
+extern "C" int tfasr_specaugment(void* x, const int32_t* fmask, const int32_t* tmask, int nf, int nt, int B, int T,
+                                 int F, float mask_value, int dtype, void* stream_) {
+  if (!x || B <= 0 || T <= 0 || F <= 0 || (nf > 0 && !fmask) || (nt > 0 && !tmask)) return TFASR_STATUS_INVALID_VALUE;
+  hipStream_t s = (hipStream_t)stream_;
+  const int grid = flat_grid((long)B * T * F);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(specaug_kernel<float>, dim3(grid), dim3(256), 0, s, (float*)x, fmask, tmask, nf, nt, B, T, F, mask_value),
+             hipLaunchKernelGGL(specaug_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (bf16_t*)x, fmask, tmask, nf, nt, B, T, F, mask_value));
+  TFASR_CHECK_LAUNCH();
+  return TFASR_STATUS_SUCCESS;
+}

@@ -1,0 +1,296 @@
+// LayerNorm / BatchNorm (training-mode batch statistics) forward + backward for gfx950.
+//
+// Reference sites: keras.layers.LayerNormalization (epsilon 1e-3) at conformer.py:59-64,101-109,
+// base_transducer.py:88-93; keras.layers.BatchNormalization(synchronized=True, momentum .99,
+// epsilon 1e-3) at conformer.py:327-333 and subsampling.py:197-203; swish fused after BN
+// (conformer.py:342, subsampling.py:214).  All are HBM-bound row/column reductions: one wave per
+// row (LayerNorm) or lanes-own-columns accumulation with one f32 atomic per column per wave
+// (BatchNorm statistics, gamma/beta gradients).
+#include "common.h"
+
+namespace {
+
+constexpr int MAXC_PER_LANE = 16;  // C <= 1024
+
+// ------------------------------------------------------------------------------------ LayerNorm
+template <typename T>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, T* __restrict__ y,
+                                                     float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                     long rows, int C, float eps) {
+  const int lane = threadIdx.x & 63;
+  const long w0 = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const long nw = (long)gridDim.x * (blockDim.x >> 6);
+  for (long r = w0; r < rows; r += nw) {
+    const T* xr = x + r * C;
+    float v[MAXC_PER_LANE];
+    float s = 0.f;
+    int n = 0;
+    for (int c = lane; c < C; c += 64, ++n) { v[n] = Num<T>::ld(xr + c); s += v[n]; }
+    const float mean = wave_sum(s) / C;
+    float q = 0.f;
+    for (int i = 0; i < n; ++i) { const float d = v[i] - mean; q += d * d; }
+    const float var = wave_sum(q) / C;
+    const float rstd = rsqrtf(var + eps);
+    T* yr = y + r * C;
+    n = 0;
+    for (int c = lane; c < C; c += 64, ++n) Num<T>::st(yr + c, (v[n] - mean) * rstd * gamma[c] + beta[c]);
+    if (lane == 0) { if (mean_out) mean_out[r] = mean; if (rstd_out) rstd_out[r] = rstd; }
+  }
+}
+
+// dx = add + rstd*(dy*g - mean(dy*g) - xhat*mean(dy*g*xhat)); dgamma += dy*xhat; dbeta += dy
+template <typename T>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                     const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                     const float* __restrict__ rstd, const T* add, T* dx,
+                                                     float* __restrict__ dgamma, float* __restrict__ dbeta, long rows,
+                                                     int C) {
+  const int lane = threadIdx.x & 63;
+  const long w0 = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const long nw = (long)gridDim.x * (blockDim.x >> 6);
+  float ag[MAXC_PER_LANE], ab[MAXC_PER_LANE], g[MAXC_PER_LANE];
+  int ncol = 0;
+  for (int c = lane; c < C; c += 64, ++ncol) { ag[ncol] = 0.f; ab[ncol] = 0.f; g[ncol] = gamma[c]; }
+  for (long r = w0; r < rows; r += nw) {
+    const T* xr = x + r * C;
+    const T* dyr = dy + r * C;
+    const float m = mean[r], rs = rstd[r];
+    float xh[MAXC_PER_LANE], dg[MAXC_PER_LANE];
+    float s1 = 0.f, s2 = 0.f;
+    int n = 0;
+    for (int c = lane; c < C; c += 64, ++n) {
+      const float d = Num<T>::ld(dyr + c);
+      xh[n] = (Num<T>::ld(xr + c) - m) * rs;
+      dg[n] = d * g[n];
+      s1 += dg[n];
+      s2 += dg[n] * xh[n];
+      ag[n] += d * xh[n];
+      ab[n] += d;
+    }
+    s1 = wave_sum(s1) / C;
+    s2 = wave_sum(s2) / C;
+    n = 0;
+    for (int c = lane; c < C; c += 64, ++n) {
+      float v = rs * (dg[n] - s1 - xh[n] * s2);
+      if (add) v += Num<T>::ld(add + r * C + c);
+      Num<T>::st(dx + r * C + c, v);
+    }
+  }
+  int n = 0;
+  for (int c = lane; c < C; c += 64, ++n) {
+    if (dgamma) atomicAdd(dgamma + c, ag[n]);
+    if (dbeta) atomicAdd(dbeta + c, ab[n]);
+  }
+}
+
+// ------------------------------------------------------------------------------------ BatchNorm
+// stats[0:C] += sum_rows f(x), stats[C:2C] += sum_rows g(x)
+//   MODE 0: f = x,  g = x*x                                  (forward moments)
+//   MODE 1: f = dz, g = dz*xhat  with z = x*scale+shift, dz = dy*act'(z), xhat = (x-mean)*rstd (backward sums)
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                       const float* __restrict__ fin /*[4C] mean,rstd,scale,shift*/,
+                                                       float* __restrict__ stats, long rows, int C, int act) {
+  const int lane = threadIdx.x & 63;
+  const long w0 = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const long nw = (long)gridDim.x * (blockDim.x >> 6);
+  float a0[MAXC_PER_LANE], a1[MAXC_PER_LANE], mean[MAXC_PER_LANE], rstd[MAXC_PER_LANE], sc[MAXC_PER_LANE],
+      sh[MAXC_PER_LANE];
+  int ncol = 0;
+  for (int c = lane; c < C; c += 64, ++ncol) {
+    a0[ncol] = 0.f; a1[ncol] = 0.f;
+    if (MODE == 1) { mean[ncol] = fin[c]; rstd[ncol] = fin[C + c]; sc[ncol] = fin[2 * C + c]; sh[ncol] = fin[3 * C + c]; }
+  }
+  for (long r = w0; r < rows; r += nw) {
+    int n = 0;
+    for (int c = lane; c < C; c += 64, ++n) {
+      const float xv = Num<T>::ld(x + r * C + c);
+      if (MODE == 0) { a0[n] += xv; a1[n] += xv * xv; }
+      else {
+        float d = Num<T>::ld(dy + r * C + c);
+        if (act == TFASR_ACT_SWISH) d *= dswishf_(xv * sc[n] + sh[n]);
+        a0[n] += d;
+        a1[n] += d * (xv - mean[n]) * rstd[n];
+      }
+    }
+  }
+  int n = 0;
+  for (int c = lane; c < C; c += 64, ++n) { atomicAdd(stats + c, a0[n]); atomicAdd(stats + C + c, a1[n]); }
+}
+
+// fin[0:C]=mean, [C:2C]=rstd, [2C:3C]=scale=gamma*rstd, [3C:4C]=shift=beta-mean*scale; moving stats updated
+// as keras: moving = moving*momentum + batch*(1-momentum)   (biased batch variance)
+__global__ void bn_finalize_kernel(const float* __restrict__ stats, float count, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, float* __restrict__ fin, float* moving_mean,
+                                   float* moving_var, float momentum, float eps, int C, int training) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float mean, var;
+  if (training) {
+    mean = stats[c] / count;
+    var = fmaxf(stats[C + c] / count - mean * mean, 0.f);
+    if (moving_mean) moving_mean[c] = moving_mean[c] * momentum + mean * (1.f - momentum);
+    if (moving_var) moving_var[c] = moving_var[c] * momentum + var * (1.f - momentum);
+  } else {
+    mean = moving_mean[c];
+    var = moving_var[c];
+  }
+  const float rstd = rsqrtf(var + eps);
+  const float scale = gamma[c] * rstd;
+  fin[c] = mean;
+  fin[C + c] = rstd;
+  fin[2 * C + c] = scale;
+  fin[3 * C + c] = beta[c] - mean * scale;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_apply_fwd_kernel(const T* __restrict__ x, const float* __restrict__ fin,
+                                                           T* __restrict__ y, long n8, int C, int act) {
+  // 8 elements per thread; C % 8 == 0
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+    const long e = i * 8;
+    const int c = (int)(e % C);
+    float v[8];
+    ld8(x + e, v);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      float z = v[k] * fin[2 * C + c + k] + fin[3 * C + c + k];
+      if (act == TFASR_ACT_SWISH) z = swishf_(z);
+      v[k] = z;
+    }
+    st8(y + e, v);
+  }
+}
+
+// dx = scale*(dz - S0/n - xhat*S1/n)
+template <typename T>
+__global__ __launch_bounds__(256) void bn_apply_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                           const float* __restrict__ fin,
+                                                           const float* __restrict__ bstats, float count, T* dx, long n8,
+                                                           int C, int act) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+    const long e = i * 8;
+    const int c = (int)(e % C);
+    float xv[8], d[8];
+    ld8(x + e, xv);
+    ld8(dy + e, d);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int cc = c + k;
+      const float sc = fin[2 * C + cc];
+      float dz = d[k];
+      if (act == TFASR_ACT_SWISH) dz *= dswishf_(xv[k] * sc + fin[3 * C + cc]);
+      const float xh = (xv[k] - fin[cc]) * fin[C + cc];
+      d[k] = sc * (dz - bstats[cc] / count - xh * bstats[C + cc] / count);
+    }
+    st8(dx + e, d);
+  }
+}
+
+inline int rows_grid(long rows) { return (int)std::min<long>((rows + 3) / 4, 256L * 8); }
+inline int flat_grid(long n) { return (int)std::min<long>((n + 255) / 256, 256L * 16); }
+
+}  // namespace
+
+extern "C" int tfasr_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean,
+                                   float* rstd, long rows, int C, float eps, int dtype, void* stream_) {
+  if (!x || !gamma || !beta || !y || rows <= 0 || C <= 0 || C > 64 * MAXC_PER_LANE) return TFASR_STATUS_INVALID_VALUE;
+  hipStream_t s = (hipStream_t)stream_;
+  if (dtype == TFASR_F32)
+    hipLaunchKernelGGL(ln_fwd_kernel<float>, dim3(rows_grid(rows)), dim3(256), 0, s, (const float*)x, gamma, beta,
+                       (float*)y, mean, rstd, rows, C, eps);
+  else
+    hipLaunchKernelGGL(ln_fwd_kernel<bf16_t>, dim3(rows_grid(rows)), dim3(256), 0, s, (const bf16_t*)x, gamma, beta,
+                       (bf16_t*)y, mean, rstd, rows, C, eps);
+  TFASR_CHECK_LAUNCH();
+  return TFASR_STATUS_SUCCESS;
+}
+
+extern "C" int tfasr_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean,
+                                   const float* rstd, const void* add, void* dx, float* dgamma, float* dbeta, long rows,
+                                   int C, int dtype, void* stream_) {
+  if (!dy || !x || !gamma || !mean || !rstd || !dx || rows <= 0 || C <= 0 || C > 64 * MAXC_PER_LANE)
+    return TFASR_STATUS_INVALID_VALUE;
+  hipStream_t s = (hipStream_t)stream_;
+  const int grid = (int)std::min<long>((rows + 3) / 4, 512L);
+  if (dtype == TFASR_F32)
+    hipLaunchKernelGGL(ln_bwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)dy, (const float*)x, gamma, mean,
+                       rstd, (const float*)add, (float*)dx, dgamma, dbeta, rows, C);
+  else
+    hipLaunchKernelGGL(ln_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x, gamma,
+                       mean, rstd, (const bf16_t*)add, (bf16_t*)dx, dgamma, dbeta, rows, C);
+  TFASR_CHECK_LAUNCH();
+  return TFASR_STATUS_SUCCESS;
+}
+
+extern "C" int tfasr_bn_stats(const void* x, float* stats, long rows, int C, int dtype, void* stream_) {
+  if (!x || !stats || rows <= 0 || C <= 0 || C > 64 * MAXC_PER_LANE) return TFASR_STATUS_INVALID_VALUE;
+  hipStream_t s = (hipStream_t)stream_;
+  const int grid = (int)std::min<long>((rows + 3) / 4, 1024L);
+  if (dtype == TFASR_F32)
+    hipLaunchKernelGGL((bn_stats_kernel<float, 0>), dim3(grid), dim3(256), 0, s, (const float*)x, (const float*)nullptr,
+                       (const float*)nullptr, stats, rows, C, 0);
+  else
+    hipLaunchKernelGGL((bn_stats_kernel<bf16_t, 0>), dim3(grid), dim3(256), 0, s, (const bf16_t*)x,
+                       (const bf16_t*)nullptr, (const float*)nullptr, stats, rows, C, 0);
+  TFASR_CHECK_LAUNCH();
+  return TFASR_STATUS_SUCCESS;
+}
+
+extern "C" int tfasr_bn_finalize(const float* stats, float count, const float* gamma, const float* beta, float* fin,
+                                 float* moving_mean, float* moving_var, float momentum, float eps, int C, int training,
+                                 void* stream_) {
+  if (!gamma || !beta || !fin || C <= 0) return TFASR_STATUS_INVALID_VALUE;
+  if (training && !stats) return TFASR_STATUS_INVALID_VALUE;
+  if (!training && (!moving_mean || !moving_var)) return TFASR_STATUS_INVALID_VALUE;
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream_, stats, count, gamma,
+                     beta, fin, moving_mean, moving_var, momentum, eps, C, training);
+  TFASR_CHECK_LAUNCH();
+  return TFASR_STATUS_SUCCESS;
+}
+
+extern "C" int tfasr_bn_apply_fwd(const void* x, const float* fin, void* y, long rows, int C, int act, int dtype,
+                                  void* stream_) {
+  if (!x || !fin || !y || rows <= 0 || C <= 0 || (C % 8) != 0) return TFASR_STATUS_INVALID_VALUE;
+  const long n8 = rows * C / 8;
+  hipStream_t s = (hipStream_t)stream_;
+  if (dtype == TFASR_F32)
+    hipLaunchKernelGGL(bn_apply_fwd_kernel<float>, dim3(flat_grid(n8)), dim3(256), 0, s, (const float*)x, fin, (float*)y,
+                       n8, C, act);
+  else
+    hipLaunchKernelGGL(bn_apply_fwd_kernel<bf16_t>, dim3(flat_grid(n8)), dim3(256), 0, s, (const bf16_t*)x, fin,
+                       (bf16_t*)y, n8, C, act);
+  TFASR_CHECK_LAUNCH();
+  return TFASR_STATUS_SUCCESS;
+}
+
+extern "C" int tfasr_bn_bwd_stats(const void* x, const void* dy, const float* fin, float* bstats, long rows, int C,
+                                  int act, int dtype, void* stream_) {
+  if (!x || !dy || !fin || !bstats || rows <= 0 || C <= 0 || C > 64 * MAXC_PER_LANE) return TFASR_STATUS_INVALID_VALUE;
+  hipStream_t s = (hipStream_t)stream_;
+  const int grid = (int)std::min<long>((rows + 3) / 4, 1024L);
+  if (dtype == TFASR_F32)
+    hipLaunchKernelGGL((bn_stats_kernel<float, 1>), dim3(grid), dim3(256), 0, s, (const float*)x, (const float*)dy, fin,
+                       bstats, rows, C, act);
+  else
+    hipLaunchKernelGGL((bn_stats_kernel<bf16_t, 1>), dim3(grid), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)dy,
+                       fin, bstats, rows, C, act);
+  TFASR_CHECK_LAUNCH();
+  return TFASR_STATUS_SUCCESS;
+}
+
+extern "C" int tfasr_bn_apply_bwd(const void* x, const void* dy, const float* fin, const float* bstats, float count,
+                                  void* dx, long rows, int C, int act, int dtype, void* stream_) {
+  if (!x || !dy || !fin || !bstats || !dx || rows <= 0 || C <= 0 || (C % 8) != 0) return TFASR_STATUS_INVALID_VALUE;
+  const long n8 = rows * C / 8;
+  hipStream_t s = (hipStream_t)stream_;
+  if (dtype == TFASR_F32)
+    hipLaunchKernelGGL(bn_apply_bwd_kernel<float>, dim3(flat_grid(n8)), dim3(256), 0, s, (const float*)x,
+                       (const float*)dy, fin, bstats, count, (float*)dx, n8, C, act);
+  else
+    hipLaunchKernelGGL(bn_apply_bwd_kernel<bf16_t>, dim3(flat_grid(n8)), dim3(256), 0, s, (const bf16_t*)x,
+                       (const bf16_t*)dy, fin, bstats, count, (bf16_t*)dx, n8, C, act);
+  TFASR_CHECK_LAUNCH();
+  return TFASR_STATUS_SUCCESS;
+}

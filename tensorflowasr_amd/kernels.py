@@ -104,3 +104,235 @@ def matmul(A, B, trans_a=False, trans_b=False, out=None, out_dtype=None, **kw):
     if out is None:
         out = torch.empty(M, N, dtype=out_dtype or A.dtype, device=A.device)
     return gemm(A, B, out, M, N, K, A.stride(0), B.stride(0), out.stride(0), trans_a, trans_b, **kw)
+
+
+# ------------------------------------------------------------------------------------- norms
+def _L():
+    return _lib.load()
+
+
+def layernorm_fwd(x, gamma, beta, eps=1e-3, save_stats=True):
+    rows, C = x.numel() // x.shape[-1], x.shape[-1]
+    y = torch.empty_like(x)
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device) if save_stats else None
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device) if save_stats else None
+    check(_L().tfasr_layernorm_fwd(_p(x), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), rows, C, eps, _dt(x), _stream()), "layernorm_fwd")
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, add=None, dx=None):
+    rows, C = x.numel() // x.shape[-1], x.shape[-1]
+    if dx is None:
+        dx = torch.empty_like(x)
+    check(_L().tfasr_layernorm_bwd(_p(dy), _p(x), _p(gamma), _p(mean), _p(rstd), _p(add), _p(dx), _p(dgamma), _p(dbeta), rows, C, _dt(x), _stream()), "layernorm_bwd")
+    return dx
+
+
+def bn_stats(x, stats):
+    rows, C = x.numel() // x.shape[-1], x.shape[-1]
+    check(_L().tfasr_bn_stats(_p(x), _p(stats), rows, C, _dt(x), _stream()), "bn_stats")
+
+
+def bn_finalize(stats, count, gamma, beta, fin, moving_mean, moving_var, momentum=0.99, eps=1e-3, training=True):
+    C = gamma.numel()
+    check(_L().tfasr_bn_finalize(_p(stats), float(count), _p(gamma), _p(beta), _p(fin), _p(moving_mean), _p(moving_var), momentum, eps, C, int(training), _stream()), "bn_finalize")
+
+
+def bn_apply_fwd(x, fin, act=ACT_NONE, y=None):
+    rows, C = x.numel() // x.shape[-1], x.shape[-1]
+    if y is None:
+        y = torch.empty_like(x)
+    check(_L().tfasr_bn_apply_fwd(_p(x), _p(fin), _p(y), rows, C, act, _dt(x), _stream()), "bn_apply_fwd")
+    return y
+
+
+def bn_bwd_stats(x, dy, fin, bstats, act=ACT_NONE):
+    rows, C = x.numel() // x.shape[-1], x.shape[-1]
+    check(_L().tfasr_bn_bwd_stats(_p(x), _p(dy), _p(fin), _p(bstats), rows, C, act, _dt(x), _stream()), "bn_bwd_stats")
+
+
+def bn_apply_bwd(x, dy, fin, bstats, count, act=ACT_NONE, dx=None):
+    rows, C = x.numel() // x.shape[-1], x.shape[-1]
+    if dx is None:
+        dx = torch.empty_like(x)
+    check(_L().tfasr_bn_apply_bwd(_p(x), _p(dy), _p(fin), _p(bstats), float(count), _p(dx), rows, C, act, _dt(x), _stream()), "bn_apply_bwd")
+    return dx
+
+
+# --------------------------------------------------------------------------------- pointwise
+def cast(src, dst):
+    check(_L().tfasr_cast(_p(src), _p(dst), src.numel(), _dt(src), _dt(dst), _stream()), "cast")
+    return dst
+
+
+def colsum(x2d, out, scale=1.0, rows=None, C=None, ld=None):
+    rows = x2d.shape[0] if rows is None else rows
+    C = x2d.shape[1] if C is None else C
+    ld = x2d.stride(0) if ld is None else ld
+    check(_L().tfasr_colsum(_p(x2d), ld, _p(out), rows, C, scale, _dt(x2d), _stream()), "colsum")
+
+
+def glu_fwd(x):
+    rows, C2 = x.numel() // x.shape[-1], x.shape[-1]
+    y = torch.empty(*x.shape[:-1], C2 // 2, dtype=x.dtype, device=x.device)
+    check(_L().tfasr_glu_fwd(_p(x), _p(y), rows, C2 // 2, _dt(x), _stream()), "glu_fwd")
+    return y
+
+
+def glu_bwd(x, dy):
+    rows, C2 = x.numel() // x.shape[-1], x.shape[-1]
+    dx = torch.empty_like(x)
+    check(_L().tfasr_glu_bwd(_p(x), _p(dy), _p(dx), rows, C2 // 2, _dt(x), _stream()), "glu_bwd")
+    return dx
+
+
+def dwconv_fwd(x, w, bias):
+    B, T, C = x.shape
+    y = torch.empty_like(x)
+    check(_L().tfasr_dwconv_fwd(_p(x), _p(w), _p(bias), _p(y), B, T, C, w.shape[0], _dt(x), _stream()), "dwconv_fwd")
+    return y
+
+
+def dwconv_bwd_data(dy, w):
+    B, T, C = dy.shape
+    dx = torch.empty_like(dy)
+    check(_L().tfasr_dwconv_bwd_data(_p(dy), _p(w), _p(dx), B, T, C, w.shape[0], _dt(dy), _stream()), "dwconv_bwd_data")
+    return dx
+
+
+def dwconv_bwd_weight(x, dy, dw, dbias):
+    B, T, C = x.shape
+    check(_L().tfasr_dwconv_bwd_weight(_p(x), _p(dy), _p(dw), _p(dbias), B, T, C, dw.shape[0], _dt(x), _stream()), "dwconv_bwd_weight")
+
+
+def bias2_fwd(x, ldx, u, v, rows, C):
+    y1 = torch.empty(rows, C, dtype=x.dtype, device=x.device)
+    y2 = torch.empty(rows, C, dtype=x.dtype, device=x.device)
+    check(_L().tfasr_bias2_fwd(_p(x), ldx, _p(u), _p(v), _p(y1), _p(y2), rows, C, _dt(x), _stream()), "bias2_fwd")
+    return y1, y2
+
+
+def bias2_bwd(d1, d2, dx, lddx, du, dv, rows, C):
+    check(_L().tfasr_bias2_bwd(_p(d1), _p(d2), _p(dx), lddx, _p(du), _p(dv), rows, C, _dt(d1), _stream()), "bias2_bwd")
+
+
+def embedding_fwd(idx, table, dtype):
+    rows = idx.numel()
+    V, E = table.shape
+    out = torch.empty(*idx.shape, E, dtype=dtype, device=table.device)
+    check(_L().tfasr_embedding_fwd(_p(idx), _p(table), _p(out), rows, E, V, _dt(out), _stream()), "embedding_fwd")
+    return out
+
+
+def embedding_bwd(idx, dout, dtable):
+    V, E = dtable.shape
+    check(_L().tfasr_embedding_bwd(_p(idx), _p(dout), _p(dtable), idx.numel(), E, V, _dt(dout), _stream()), "embedding_bwd")
+
+
+def joint_fwd(enc, pred):
+    B, T, J = enc.shape
+    U1 = pred.shape[1]
+    h = torch.empty(B, T, U1, J, dtype=enc.dtype, device=enc.device)
+    check(_L().tfasr_joint_fwd(_p(enc), _p(pred), _p(h), B, T, U1, J, _dt(enc), _stream()), "joint_fwd")
+    return h
+
+
+def joint_bwd(h, dh):
+    B, T, U1, J = h.shape
+    denc = torch.empty(B, T, J, dtype=h.dtype, device=h.device)
+    dpred = torch.empty(B, U1, J, dtype=h.dtype, device=h.device)
+    check(_L().tfasr_joint_bwd(_p(h), _p(dh), _p(denc), _p(dpred), B, T, U1, J, _dt(h), _stream()), "joint_bwd")
+    return denc, dpred
+
+
+def adam(p, g, m, v, n_reg, lr, step, beta1=0.9, beta2=0.999, eps=1e-7, weight_decay=0.0, l2=0.0, grad_scale=1.0):
+    check(_L().tfasr_adam(_p(p), _p(g), _p(m), _p(v), p.numel(), n_reg, lr, beta1, beta2, eps, weight_decay, l2, grad_scale, step, _stream()), "adam")
+
+
+def sumsq(p, n, out):
+    check(_L().tfasr_sumsq(_p(p), n, _p(out), _stream()), "sumsq")
+
+
+def specaugment(x, fmask, tmask, mask_value=0.0):
+    B, T, F = x.shape[:3]
+    nf = 0 if fmask is None else fmask.shape[1]
+    nt = 0 if tmask is None else tmask.shape[1]
+    check(_L().tfasr_specaugment(_p(x), _p(fmask), _p(tmask), nf, nt, B, T, F, mask_value, _dt(x), _stream()), "specaugment")
+    return x
+
+
+# --------------------------------------------------------------------------------- attention
+def relattn_softmax_fwd(content, pos, lengths, use_mask=True, probs=None):
+    B, H, T, _ = content.shape
+    if probs is None:
+        probs = torch.empty_like(content)
+    check(_L().tfasr_relattn_softmax_fwd(_p(content), _p(pos), _p(lengths), _p(probs), B, H, T, int(use_mask), _dt(content), _stream()), "relattn_softmax_fwd")
+    return probs
+
+
+def relattn_softmax_bwd(probs, dprobs, lengths, use_mask=True, dcontent=None, dpos=None):
+    B, H, T, _ = probs.shape
+    if dcontent is None:
+        dcontent = torch.empty_like(probs)
+    if dpos is None:
+        dpos = torch.empty(B, H, T, 2 * T, dtype=probs.dtype, device=probs.device)
+    check(_L().tfasr_relattn_softmax_bwd(_p(probs), _p(dprobs), _p(lengths), _p(dcontent), _p(dpos), B, H, T, int(use_mask), _dt(probs), _stream()), "relattn_softmax_bwd")
+    return dcontent, dpos
+
+
+# -------------------------------------------------------------------------------------- LSTM
+def lstm_step_fwd(xg_t, hr, h_prev, c_prev, lengths, t, gates_t, c_out, h_out, y_out, B, P):
+    check(_L().tfasr_lstm_step_fwd(
+        _p(xg_t), xg_t.stride(0), _p(hr), _p(h_prev), 0 if h_prev is None else h_prev.stride(0), _p(c_prev),
+        0 if c_prev is None else c_prev.stride(0), _p(lengths), t, _p(gates_t), 0 if gates_t is None else gates_t.stride(0),
+        _p(c_out), c_out.stride(0), _p(h_out), h_out.stride(0), _p(y_out), 0 if y_out is None else y_out.stride(0), B, P,
+        _dt(xg_t), _stream()), "lstm_step_fwd")
+
+
+def lstm_step_bwd(dy_t, dhr, dh_carry, dc_carry, gates_t, c_t, c_prev, lengths, t, dz_t, B, P):
+    check(_L().tfasr_lstm_step_bwd(
+        _p(dy_t), dy_t.stride(0), _p(dhr), _p(dh_carry), _p(dc_carry), _p(gates_t), gates_t.stride(0), _p(c_t), c_t.stride(0),
+        _p(c_prev), 0 if c_prev is None else c_prev.stride(0), _p(lengths), t, _p(dz_t), dz_t.stride(0), B, P, _dt(dy_t),
+        _stream()), "lstm_step_bwd")
+
+
+# --------------------------------------------------------------------------------- subsampling
+def conv1_fwd(x, w, bias):
+    B, T0, F0 = x.shape[:3]
+    C = w.shape[-1]
+    y = torch.empty(B, (T0 + 1) // 2, (F0 + 1) // 2, C, dtype=x.dtype, device=x.device)
+    check(_L().tfasr_conv1_fwd(_p(x), _p(w), _p(bias), _p(y), B, T0, F0, C, _dt(x), _stream()), "conv1_fwd")
+    return y
+
+
+def conv1_bwd_weight(x, dy, dw, db):
+    B, T0, F0 = x.shape[:3]
+    C = dy.shape[-1]
+    check(_L().tfasr_conv1_bwd_weight(_p(x), _p(dy), _p(dw), _p(db), B, T0, F0, C, _dt(x), _stream()), "conv1_bwd_weight")
+
+
+def im2col_3x3s2(x, col=None):
+    B, T1, F1, C = x.shape
+    T2, F2 = (T1 + 1) // 2, (F1 + 1) // 2
+    if col is None:
+        col = torch.empty(B * T2 * F2, 9 * C, dtype=x.dtype, device=x.device)
+    check(_L().tfasr_im2col_3x3s2(_p(x), _p(col), B, T1, F1, C, _dt(x), _stream()), "im2col")
+    return col
+
+
+def col2im_3x3s2(dcol, B, T1, F1, C):
+    dx = torch.empty(B, T1, F1, C, dtype=dcol.dtype, device=dcol.device)
+    check(_L().tfasr_col2im_3x3s2(_p(dcol), _p(dx), B, T1, F1, C, _dt(dcol), _stream()), "col2im")
+    return dx
+
+
+# ------------------------------------------------------------------------------------ frontend
+def logmel(signal, window, melw, band, frame_step, nfft, preemph, eps, out_dtype):
+    B, N = signal.shape
+    T0 = -(-N // frame_step)
+    F = melw.shape[1]
+    out = torch.empty(B, T0, F, dtype=out_dtype, device=signal.device)
+    assert signal.dtype == torch.float32
+    check(_L().tfasr_logmel(_p(signal), B, N, preemph, _p(window), window.numel(), frame_step, nfft, _p(melw), _p(band), F,
+                            eps, _p(out), T0, _dt(out), _stream()), "logmel")
+    return out

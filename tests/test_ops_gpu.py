@@ -1,0 +1,294 @@
+"""GPU numerics of the pointwise / reduction / frontend kernels vs torch-CPU fp32 (oracle/conformer_ref.py pieces)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import conformer_ref as R
+from tensorflowasr_amd import kernels as K
+from tensorflowasr_amd.kernels import ACT_NONE, ACT_SWISH
+
+pytestmark = pytest.mark.gpu
+DT = [torch.float32, torch.bfloat16]
+
+
+def tol(dtype, f32=(1e-5, 1e-5), bf16=(2e-2, 2e-2)):
+    return dict(rtol=f32[0], atol=f32[1]) if dtype == torch.float32 else dict(rtol=bf16[0], atol=bf16[1])
+
+
+def rt(x, dtype):
+    """round-trip through the storage dtype so the reference sees the same inputs"""
+    return x.to(dtype).float()
+
+
+def cmp(a, b, **kw):
+    np.testing.assert_allclose(a.float().cpu().numpy(), b.float().cpu().numpy(), **kw)
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("C", [144, 256, 40])
+def test_layernorm(dev, dtype, C):
+    g = torch.Generator().manual_seed(C)
+    rows = 77
+    x = rt(torch.randn(rows, C, generator=g) * 2 + 0.5, dtype)
+    gam, bet = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    dy = rt(torch.randn(rows, C, generator=g), dtype)
+    add = rt(torch.randn(rows, C, generator=g), dtype)
+    xr = x.clone().requires_grad_(True)
+    gr, br = gam.clone().requires_grad_(True), bet.clone().requires_grad_(True)
+    yr = R.layer_norm(xr, gr, br)
+    yr.backward(dy)
+    y, mean, rstd = K.layernorm_fwd(x.to(dev).to(dtype), gam.to(dev), bet.to(dev))
+    cmp(y, yr.detach(), **tol(dtype, (1e-5, 2e-5)))
+    dgam, dbet = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+    dx = K.layernorm_bwd(dy.to(dev).to(dtype), x.to(dev).to(dtype), gam.to(dev), mean, rstd, dgam, dbet, add=add.to(dev).to(dtype))
+    cmp(dx, xr.grad + add, **tol(dtype, (1e-4, 2e-5), (3e-2, 3e-2)))
+    cmp(dgam, gr.grad, rtol=1e-4, atol=1e-3)
+    cmp(dbet, br.grad, rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_batchnorm_swish(dev, dtype):
+    g = torch.Generator().manual_seed(0)
+    rows, C = 500, 144
+    x = rt(torch.randn(rows, C, generator=g) * 1.5 + 0.3, dtype)
+    gam, bet = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.1
+    dy = rt(torch.randn(rows, C, generator=g), dtype)
+    xr, gr, br = x.clone().requires_grad_(True), gam.clone().requires_grad_(True), bet.clone().requires_grad_(True)
+    yr, mean, var = R.batch_norm_train(xr, gr, br)
+    yr = R.swish(yr)
+    yr.backward(dy)
+    xd = x.to(dev).to(dtype)
+    stats = torch.zeros(2 * C, device=dev)
+    K.bn_stats(xd, stats)
+    fin = torch.empty(4 * C, device=dev)
+    mm, mv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+    K.bn_finalize(stats, rows, gam.to(dev), bet.to(dev), fin, mm, mv)
+    cmp(fin[:C], mean.detach(), rtol=1e-4, atol=1e-5)
+    cmp(mm, mean.detach() * 0.01, rtol=1e-3, atol=1e-6)
+    cmp(mv, 0.99 + var.detach() * 0.01, rtol=1e-4, atol=1e-6)
+    y = K.bn_apply_fwd(xd, fin, ACT_SWISH)
+    cmp(y, yr.detach(), **tol(dtype, (1e-4, 1e-5)))
+    bstats = torch.zeros(2 * C, device=dev)
+    dyd = dy.to(dev).to(dtype)
+    K.bn_bwd_stats(xd, dyd, fin, bstats, ACT_SWISH)
+    dx = K.bn_apply_bwd(xd, dyd, fin, bstats, rows, ACT_SWISH)
+    cmp(dx, xr.grad, **tol(dtype, (1e-3, 2e-5), (3e-2, 3e-2)))
+    cmp(bstats[C:], gr.grad, rtol=1e-3, atol=1e-3)
+    cmp(bstats[:C], br.grad, rtol=1e-3, atol=1e-3)
+    # inference mode uses the moving statistics
+    K.bn_finalize(None, 1, gam.to(dev), bet.to(dev), fin, mm, mv, training=False)
+    yi = K.bn_apply_fwd(xd, fin, ACT_NONE)
+    cmp(yi, R.batch_norm_infer(x, gam, bet, mm.cpu(), mv.cpu()), **tol(dtype, (1e-4, 1e-5)))
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_glu_dwconv(dev, dtype):
+    g = torch.Generator().manual_seed(1)
+    B, T, C, Kk = 3, 53, 144, 31
+    x = rt(torch.randn(B, T, 2 * C, generator=g), dtype)
+    w, b = torch.randn(Kk, C, generator=g) * 0.2, torch.randn(C, generator=g) * 0.1
+    dy = rt(torch.randn(B, T, C, generator=g), dtype)
+    xr, wr, brr = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    a, bb = xr.chunk(2, -1)
+    gl = a * torch.sigmoid(bb)
+    gl.retain_grad()
+    yr = R.depthwise_conv1d_causal(gl, wr, brr)
+    yr.backward(dy)
+    xd = x.to(dev).to(dtype)
+    gd = K.glu_fwd(xd)
+    cmp(gd, gl.detach(), **tol(dtype))
+    gin = gl.detach().to(dev).to(dtype)
+    y = K.dwconv_fwd(gin, w.to(dev), b.to(dev))
+    ref_y = R.depthwise_conv1d_causal(rt(gl.detach(), dtype), w, b)
+    cmp(y, ref_y, **tol(dtype, (1e-4, 1e-5)))
+    dyd = dy.to(dev).to(dtype)
+    dg = K.dwconv_bwd_data(dyd, w.to(dev))
+    cmp(dg, gl.grad, **tol(dtype, (1e-4, 1e-5)))
+    dw, db = torch.zeros(Kk, C, device=dev), torch.zeros(C, device=dev)
+    K.dwconv_bwd_weight(gin, dyd, dw, db)
+    # reference weight grad with the same (rounded) input
+    g2 = rt(gl.detach(), dtype).requires_grad_(False)
+    w2 = w.clone().requires_grad_(True)
+    R.depthwise_conv1d_causal(g2, w2, b).backward(dy)
+    cmp(dw, w2.grad, rtol=1e-3, atol=2e-3)
+    cmp(db, dy.sum((0, 1)), rtol=1e-3, atol=1e-3)
+    dx = K.glu_bwd(xd, gl.grad.to(dev).to(dtype))
+    cmp(dx, xr.grad, **tol(dtype, (1e-4, 1e-5), (3e-2, 3e-2)))
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_bias2_embedding_colsum_cast(dev, dtype):
+    g = torch.Generator().manual_seed(2)
+    rows, C = 90, 144
+    qkv = rt(torch.randn(rows, 3 * C, generator=g), dtype)
+    u, v = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    qd = qkv.to(dev).to(dtype)
+    y1, y2 = K.bias2_fwd(qd, 3 * C, u.to(dev), v.to(dev), rows, C)
+    cmp(y1, qkv[:, :C] + u, **tol(dtype))
+    cmp(y2, qkv[:, :C] + v, **tol(dtype))
+    d1, d2 = rt(torch.randn(rows, C, generator=g), dtype), rt(torch.randn(rows, C, generator=g), dtype)
+    dq = torch.zeros(rows, 3 * C, device=dev, dtype=dtype)
+    du, dv = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+    K.bias2_bwd(d1.to(dev).to(dtype), d2.to(dev).to(dtype), dq, 3 * C, du, dv, rows, C)
+    cmp(dq[:, :C], d1 + d2, **tol(dtype))
+    assert dq[:, C:].abs().max().item() == 0
+    cmp(du, d1.sum(0), rtol=1e-4, atol=1e-3)
+    cmp(dv, d2.sum(0), rtol=1e-4, atol=1e-3)
+    # embedding
+    V, E = 50, 24
+    table = torch.randn(V, E, generator=g)
+    idx = torch.randint(0, V, (4, 9), generator=g, dtype=torch.int32)
+    out = K.embedding_fwd(idx.to(dev), table.to(dev), dtype)
+    cmp(out, table[idx.long()], **tol(dtype))
+    dout = rt(torch.randn(4, 9, E, generator=g), dtype)
+    dt_ = torch.zeros(V, E, device=dev)
+    K.embedding_bwd(idx.to(dev), dout.to(dev).to(dtype), dt_)
+    ref = torch.zeros(V, E).index_add_(0, idx.view(-1).long(), dout.view(-1, E))
+    cmp(dt_, ref, rtol=1e-4, atol=1e-4)
+    # colsum over a strided view + cast
+    x = rt(torch.randn(300, 1000, generator=g), dtype)
+    o = torch.zeros(1000, device=dev)
+    K.colsum(x.to(dev).to(dtype), o, scale=0.5)
+    cmp(o, 0.5 * x.sum(0), rtol=1e-4, atol=2e-3)
+    src = torch.randn(1003, generator=g)
+    dst = torch.empty(1003, device=dev, dtype=torch.bfloat16)
+    K.cast(src.to(dev), dst)
+    cmp(dst, src.to(torch.bfloat16), rtol=0, atol=0)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_joint(dev, dtype):
+    g = torch.Generator().manual_seed(3)
+    B, T, U1, J = 2, 7, 5, 40
+    e, p = rt(torch.randn(B, T, J, generator=g), dtype), rt(torch.randn(B, U1, J, generator=g), dtype)
+    er, pr = e.clone().requires_grad_(True), p.clone().requires_grad_(True)
+    hr = torch.tanh(er[:, :, None] + pr[:, None])
+    dh = rt(torch.randn(B, T, U1, J, generator=g), dtype)
+    hr.backward(dh)
+    h = K.joint_fwd(e.to(dev).to(dtype), p.to(dev).to(dtype))
+    cmp(h, hr.detach(), **tol(dtype, (1e-5, 1e-6)))
+    denc, dpred = K.joint_bwd(hr.detach().to(dev).to(dtype), dh.to(dev).to(dtype))
+    cmp(denc, er.grad, **tol(dtype, (1e-4, 1e-5), (3e-2, 5e-2)))
+    cmp(dpred, pr.grad, **tol(dtype, (1e-4, 1e-5), (3e-2, 5e-2)))
+
+
+def test_adam_specaug(dev):
+    g = torch.Generator().manual_seed(4)
+    n, n_reg = 1000, 600
+    p, gr = torch.randn(n, generator=g), torch.randn(n, generator=g)
+    m, v = torch.rand(n, generator=g) * 0.1, torch.rand(n, generator=g) * 0.01
+    step, lr, l2, wd, gs = 7, 3e-3, 1e-2, 1e-2, 0.5
+    geff = gr * gs
+    geff[:n_reg] += 2 * l2 * p[:n_reg]
+    pr, mr, vr = R.adam_step(p, geff, m, v, step, lr, 0.9, 0.98, 1e-9, wd)
+    pd, md, vd = p.to(dev), m.to(dev), v.to(dev)
+    K.adam(pd, gr.to(dev), md, vd, n_reg, lr, step, 0.9, 0.98, 1e-9, wd, l2, gs)
+    cmp(pd, pr, rtol=1e-5, atol=1e-6)
+    cmp(md, mr, rtol=1e-5, atol=1e-7)
+    cmp(vd, vr, rtol=1e-5, atol=1e-8)
+    out = torch.zeros(1, device=dev)
+    K.sumsq(pd, n_reg, out)
+    cmp(out, (pd[:n_reg].cpu() ** 2).sum()[None], rtol=1e-5, atol=1e-4)
+    # specaugment
+    rng = np.random.default_rng(0)
+    feat = rng.standard_normal((3, 120, 80)).astype(np.float32)
+    fm, tm = R.specaugment_draw(rng, [120, 100, 60])
+    ref = R.specaugment_apply(feat, fm, tm)
+    x = torch.from_numpy(feat).to(dev)
+    K.specaugment(x, torch.from_numpy(fm).to(dev), torch.from_numpy(tm).to(dev))
+    np.testing.assert_array_equal(x.cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("lens", [[9, 9], [9, 5], [6, 1]])
+def test_relattn_softmax(dev, dtype, lens):
+    """scores = content + shifted positional with the per-sample rolled PE, masked query rows, softmax; then backward."""
+    g = torch.Generator().manual_seed(5)
+    B, H, T, dh, d = 2, 2, 9, 8, 16
+    Rr = 2 * T - 1
+    pe_b, table = R.relative_position_encoding(T, d, lens)
+    Wp, bp = torch.randn(d, H, dh, generator=g) * 0.3, torch.randn(H, dh, generator=g) * 0.3
+    qv = rt(torch.randn(B, T, H, dh, generator=g), dtype)
+    content = rt(torch.randn(B, H, T, T, generator=g), dtype)
+    # reference: project the per-sample PE, einsum, rel_left_shift, slice
+    p_b = torch.einsum("brd,dhe->brhe", pe_b, Wp) + bp
+    positional = torch.einsum("brhe,bthe->bhtr", p_b, qv)
+    shifted = R.rel_left_shift(positional)[..., -T:]
+    # device form: shared projected table + bias row, gathered inside the kernel
+    p_ext = torch.cat([torch.einsum("rd,dhe->rhe", table, Wp) + bp, bp[None]], 0)  # [R+1,H,dh]
+    pos = rt(torch.einsum("rhe,bthe->bhtr", p_ext, qv), dtype)  # [B,H,T,R+1]
+    cr, pr = content.clone().requires_grad_(True), pos.clone().requires_grad_(True)
+    # reference scores built from the same rounded `pos` through the gather identity (checked vs `shifted` below)
+    idx = torch.zeros(B, T, T, dtype=torch.long)
+    for b in range(B):
+        for i in range(T):
+            for j in range(T):
+                r = T - 1 - i + j
+                idx[b, i, j] = (r + T - lens[b]) % Rr if r < 2 * lens[b] - 1 else Rr
+    gathered = torch.gather(pr, 3, idx[:, None].expand(B, H, T, T))
+    np.testing.assert_allclose(torch.gather(torch.einsum("rhe,bthe->bhtr", p_ext, qv), 3, idx[:, None].expand(B, H, T, T)).numpy(),
+                               shifted.numpy(), atol=1e-5)
+    scores = cr + gathered
+    qmask = (torch.arange(T)[None] < torch.tensor(lens)[:, None])[:, None, :, None]
+    probs_r = torch.softmax(torch.where(qmask, scores, torch.full_like(scores, -1e9)), -1)
+    dP = rt(torch.randn(B, H, T, T, generator=g), dtype)
+    probs_r.backward(dP)
+    ln = torch.tensor(lens, dtype=torch.int32, device=dev)
+    probs = K.relattn_softmax_fwd(content.to(dev).to(dtype), pos.to(dev).to(dtype), ln)
+    cmp(probs, probs_r.detach(), **tol(dtype, (1e-4, 1e-6), (2e-2, 4e-3)))
+    dc, dpos = K.relattn_softmax_bwd(probs_r.detach().to(dev).to(dtype), dP.to(dev).to(dtype), ln)
+    cmp(dc, cr.grad, **tol(dtype, (1e-4, 1e-6), (3e-2, 1e-2)))
+    cmp(dpos, pr.grad, **tol(dtype, (1e-4, 1e-6), (3e-2, 1e-2)))
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_subsampling_pieces(dev, dtype):
+    g = torch.Generator().manual_seed(6)
+    B, T0, F0, C = 2, 21, 80, 32
+    x = rt(torch.randn(B, T0, F0, generator=g), dtype)
+    w1, b1 = torch.randn(3, 3, 1, C, generator=g) * 0.3, torch.randn(C, generator=g) * 0.1
+    ref1 = R.conv2d_causal_s2(x[..., None], w1, b1)
+    y1 = K.conv1_fwd(x.to(dev).to(dtype), w1.to(dev), b1.to(dev))
+    assert y1.shape == ref1.shape == (B, 11, 40, C)
+    cmp(y1, ref1, **tol(dtype, (1e-4, 1e-5)))
+    dy1 = rt(torch.randn(*ref1.shape, generator=g), dtype)
+    w1r = w1.clone().requires_grad_(True)
+    R.conv2d_causal_s2(x[..., None], w1r, b1).backward(dy1)
+    dw, db = torch.zeros(3, 3, 1, C, device=dev), torch.zeros(C, device=dev)
+    K.conv1_bwd_weight(x.to(dev).to(dtype), dy1.to(dev).to(dtype), dw, db)
+    cmp(dw, w1r.grad, rtol=1e-3, atol=2e-3)
+    cmp(db, dy1.sum((0, 1, 2)), rtol=1e-3, atol=2e-3)
+    # conv2 = im2col + GEMM; data grad = GEMM + col2im
+    x1 = rt(torch.randn(B, 11, 40, C, generator=g), dtype)
+    w2, b2 = torch.randn(3, 3, C, C, generator=g) * 0.1, torch.randn(C, generator=g) * 0.1
+    x1r, w2r = x1.clone().requires_grad_(True), w2.clone().requires_grad_(True)
+    ref2 = R.conv2d_causal_s2(x1r, w2r, b2)
+    dy2 = rt(torch.randn(*ref2.shape, generator=g), dtype)
+    ref2.backward(dy2)
+    col = K.im2col_3x3s2(x1.to(dev).to(dtype))
+    w2d = w2.reshape(9 * C, C).to(dev).to(dtype)
+    y2 = K.matmul(col, w2d, bias=b2.to(dev))
+    cmp(y2.view(*ref2.shape), R.conv2d_causal_s2(x1, rt(w2, dtype), b2), **tol(dtype, (1e-4, 1e-4), (3e-2, 3e-2)))
+    dyd = dy2.reshape(-1, C).to(dev).to(dtype)
+    dcol = K.matmul(dyd, w2d, trans_b=True)
+    dx1 = K.col2im_3x3s2(dcol, B, 11, 40, C)
+    cmp(dx1, x1r.grad, **tol(dtype, (1e-4, 1e-4), (4e-2, 4e-2)))
+    dw2 = torch.zeros(9 * C, C, device=dev)
+    K.gemm(col, dyd, dw2, 9 * C, C, col.shape[0], col.stride(0), dyd.stride(0), C, trans_a=True, accumulate=True, split_k=4)
+    cmp(dw2.view(3, 3, C, C), w2r.grad, **tol(dtype, (1e-4, 2e-4), (3e-2, 1e-1)))
+
+
+@pytest.mark.parametrize("n", [160000, 4321])
+def test_logmel(dev, n):
+    cfg = R.conformer_config("S")
+    rng = np.random.default_rng(n)
+    sig = np.clip(rng.standard_normal((3, n)) * 0.1, -1, 1).astype(np.float32)
+    ref = R.log_mel(sig, cfg)
+    melw = R.mel_weight_matrix()
+    out = K.logmel(torch.from_numpy(sig).to(dev), torch.from_numpy(R.hann_periodic(400)).to(dev), torch.from_numpy(melw).to(dev),
+                   torch.from_numpy(R.mel_bands(melw)).to(dev), 160, 512, 0.97, 1e-6, torch.float32)
+    assert out.shape == ref.shape
+    # <= 1e-4 abs in the log domain
+    np.testing.assert_allclose(out.cpu().numpy(), ref, atol=1e-4, rtol=1e-5)

@@ -48,7 +48,7 @@ def test_vs_oracle_ragged(dev, shape):
     ref_loss, ref_g = rnnt_ref.rnnt_loss_and_grad(logits, labels, ul, tl)
     loss, grads = _run(dev, logits, labels, ul, tl, grad_scale=scale)
     np.testing.assert_allclose(loss, ref_loss, rtol=1e-5, atol=1e-4)
-    np.testing.assert_allclose(grads, ref_g * scale[:, None, None, None], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(grads, ref_g * scale[:, None, None, None], rtol=5e-4, atol=2e-5)  # __expf in the grad pass
     # in-place variant gives the same gradient
     _, g2 = _run(dev, logits, labels, ul, tl, grad_scale=scale, inplace=True)
     np.testing.assert_array_equal(g2, grads)
