@@ -158,6 +158,8 @@ int tfasr_joint_bwd(const void* h, const void* dh, void* denc, void* dpred, int 
 int tfasr_adam(float* p, const float* g, float* m, float* v, long n, long n_reg, float lr, float beta1, float beta2,
                float eps, float weight_decay, float l2, float grad_scale, long step, void* stream);
 int tfasr_sumsq(const float* p, long n, float* out, void* stream);
+/* y += alpha * x over f32 vectors (sync-BN gamma/beta gradient hand-off, gradient accumulation: accumulation.py:54-70) */
+int tfasr_axpy(float* y, const float* x, float alpha, long n, void* stream);
 /* SpecAugment mask application, in place: fmask [B,nf,2] = (f0, width), tmask [B,nt,2] = (t0, width)
  * (augmentations/methods/specaugment.py:58-87,108-137; random draws are made by the caller) */
 int tfasr_specaugment(void* x, const int32_t* fmask, const int32_t* tmask, int nf, int nt, int B, int T, int F,

@@ -1,0 +1,123 @@
+"""Model configuration with the reference's keyword surface.
+
+`ConformerConfig.from_reference(config)` accepts the `model_config.config` mapping of
+examples/models/transducer/conformer/small.yml.j2:3-69 (= the kwargs of
+tensorflow_asr/models/transducer/conformer.py:23-79) unchanged.  `conformer_s()` is that file's values;
+`conformer_m()` is the Conformer-M of arXiv:2005.08100 Table 1 expressed through the same keys (the reference ships
+no M config: SURVEY.md §0.1).
+"""
+import math
+from dataclasses import dataclass, field
+
+
+@dataclass
+class ConformerConfig:
+    # speech_config (models/layers/feature_extraction.py:34-55)
+    sample_rate: int = 16000
+    frame_ms: int = 25
+    stride_ms: int = 10
+    nfft: int = 512
+    num_feature_bins: int = 80
+    preemphasis: float = 0.97
+    epsilon: float = 1e-6
+    lower_edge_hertz: float = 0.0
+    upper_edge_hertz: float = 8000.0
+    # augmentation (small.yml.j2:11-24)
+    time_masking: dict = field(default_factory=lambda: dict(prob=1.0, num_masks=10, mask_factor=-1, p_upperbound=0.05, mask_value=0))
+    freq_masking: dict = field(default_factory=lambda: dict(prob=1.0, num_masks=1, mask_factor=27, mask_value=0))
+    # encoder
+    filters: int = 144
+    dmodel: int = 144
+    num_blocks: int = 16
+    head_size: int = 36
+    num_heads: int = 4
+    kernel_size: int = 31
+    ffm_scale: int = 4
+    ffm_residual: float = 0.5
+    mhsam_residual: float = 1.0
+    convm_residual: float = 1.0
+    dropout: float = 0.1
+    use_attention_auto_mask: bool = True
+    # prediction / joint
+    embed_dim: int = 320
+    rnn_units: int = 320
+    joint_dim: int = 320
+    vocab_size: int = 1000
+    blank: int = 0
+    l2: float = 1e-6
+
+    @property
+    def frame_length(self):
+        return int(round(self.sample_rate * self.frame_ms / 1000.0))
+
+    @property
+    def frame_step(self):
+        return int(round(self.sample_rate * self.stride_ms / 1000.0))
+
+    @property
+    def time_reduction_factor(self):
+        return 4
+
+    @classmethod
+    def from_reference(cls, config: dict):
+        """Map the reference's Conformer kwargs (models/transducer/conformer.py:23-79) onto this dataclass."""
+        c = dict(config)
+        sc = dict(c.get("speech_config", {}))
+        aug = (sc.get("augmentation_config") or {}).get("feature_augment", {}) or {}
+        sub = (c.get("encoder_subsampling") or {}).get("config", {})
+        unsupported = {
+            "encoder_mha_type": ("relmha",), "encoder_padding": ("causal",), "prediction_rnn_type": ("lstm",),
+            "prediction_num_rnns": (1,), "joint_activation": ("tanh",), "joint_mode": ("add",),
+            "encoder_convm_dw_norm_type": ("batch",), "prediction_label_encode_mode": ("embedding",),
+        }
+        for k, ok in unsupported.items():
+            if k in c and c[k] not in ok:
+                raise NotImplementedError(f"{k}={c[k]!r}: only {ok} is on the MI355X hot path")
+        if sub and (list(sub.get("kernels", [3, 3])) != [3, 3] or list(sub.get("strides", [2, 2])) != [2, 2]):
+            raise NotImplementedError("only the 3x3 stride-2 causal Conv2dSubsampling of small.yml.j2:26-33 is supported")
+        reg = c.get("kernel_regularizer") or {}
+        l2 = float((reg.get("config") or {}).get("l2", 1e-6)) if isinstance(reg, dict) else 1e-6
+        kw = dict(
+            sample_rate=sc.get("sample_rate", 16000), frame_ms=sc.get("frame_ms", 25), stride_ms=sc.get("stride_ms", 10),
+            nfft=sc.get("nfft", 512), num_feature_bins=sc.get("num_feature_bins", 80), preemphasis=sc.get("preemphasis", 0.97),
+            filters=(sub.get("filters") or [c.get("encoder_dmodel", 144)])[0], dmodel=c.get("encoder_dmodel", 144),
+            num_blocks=c.get("encoder_num_blocks", 16), head_size=c.get("encoder_head_size", 36),
+            num_heads=c.get("encoder_num_heads", 4), kernel_size=c.get("encoder_kernel_size", 31),
+            ffm_scale=c.get("encoder_ffm_scale_factor", 4), ffm_residual=c.get("encoder_ffm_residual_factor", 0.5),
+            mhsam_residual=c.get("encoder_mhsam_residual_factor", 1.0), convm_residual=c.get("encoder_convm_residual_factor", 1.0),
+            dropout=c.get("encoder_dropout", 0.1), use_attention_auto_mask=c.get("encoder_use_attention_auto_mask", True),
+            embed_dim=c.get("prediction_embed_dim", 512), rnn_units=c.get("prediction_rnn_units", 320),
+            joint_dim=c.get("joint_dim", 1024), vocab_size=int(c.get("vocab_size", 1000)), blank=c.get("blank", 0), l2=l2)
+        if "time_masking" in aug:
+            kw["time_masking"] = dict(aug["time_masking"])
+        if "freq_masking" in aug:
+            kw["freq_masking"] = dict(aug["freq_masking"])
+        return cls(**kw)
+
+
+def conformer_s(vocab_size=1000, **over):
+    return ConformerConfig(vocab_size=vocab_size, **over)
+
+
+def conformer_m(vocab_size=1000, **over):
+    kw = dict(filters=256, dmodel=256, head_size=64, num_heads=4, embed_dim=640, rnn_units=640, joint_dim=640, vocab_size=vocab_size)
+    kw.update(over)
+    return ConformerConfig(**kw)
+
+
+def conformer_tiny(vocab_size=29, **over):
+    kw = dict(filters=32, dmodel=32, head_size=8, num_heads=4, embed_dim=24, rnn_units=24, joint_dim=40, num_blocks=2,
+              kernel_size=7, vocab_size=vocab_size)
+    kw.update(over)
+    return ConformerConfig(**kw)
+
+
+def transformer_schedule(step, dmodel, warmup_steps=10000, scale=2.0, max_lr=None, min_lr=None):
+    """TransformerSchedule.__call__ (optimizers/schedules.py:28-37)."""
+    step = float(step)
+    lr = scale * dmodel ** -0.5 * min(step ** -0.5, step * warmup_steps ** -1.5)
+    if max_lr is not None:
+        lr = min(max_lr, lr)
+    if min_lr is not None:
+        lr = max(min_lr, lr)
+    return lr

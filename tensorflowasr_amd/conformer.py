@@ -1,0 +1,587 @@
+"""Conformer-Transducer on MI355X: explicit forward / backward over the HIP kernels of libtfasr_hip.so.
+
+Mirrors the reference's model surface for this path:
+    tensorflow_asr.models.transducer.conformer.Conformer        (models/transducer/conformer.py:22-143)
+    Transducer.call / call_next / recognize*                    (models/transducer/base_transducer.py:427-712)
+    BaseModel.train_step / _train_step / _apply_gradients       (models/base_model.py:149-198)
+but is NOT a Keras graph: every module has a hand-written backward that reuses the forward's saved tensors, the
+residual additions / biases / activations are fused into GEMM epilogues, and the whole step is a fixed sequence of
+C-ABI kernel launches on one HIP stream (prediction network on a second stream, overlapped with the encoder).
+PyTorch only owns device memory and streams here.  There is no CPU / eager fallback.
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import kernels as K
+from .kernels import ACT_NONE, ACT_SWISH
+from .params import ParamStore
+from .schemas import PredictInput, PredictOutput, TrainData, TrainInput, TrainOutput
+
+
+class SingleProcess:
+    """Collective hooks for one GPU (tensorflowasr_amd.dp.DataParallel implements them over RCCL)."""
+
+    world = 1
+    rank = 0
+
+    def allreduce_stats_(self, t):  # sync-BN statistics (sum over replicas)
+        return t
+
+    def grads_ready(self, lo, hi):  # gradient slice [lo, hi) of the flat buffer is final
+        pass
+
+    def finish_grads(self):
+        pass
+
+
+def _split_k(M, N, Kd):
+    tiles = -(-M // 128) * -(-N // 128)
+    if tiles >= 512 or Kd <= 2048:
+        return 1
+    return int(max(1, min(-(-1024 // tiles), Kd // 1024, 64)))
+
+
+class ConformerTransducer:
+    def __init__(self, cfg, device=None, dtype=torch.bfloat16, seed=0, dp=None):
+        if not torch.cuda.is_available():
+            raise K._lib.TfasrError("ConformerTransducer needs an MI355X (HIP) device; there is no CPU fallback")
+        self.cfg = cfg
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.dtype = dtype
+        self.ps = ParamStore(cfg, self.device, dtype, seed)
+        self.dp = dp or SingleProcess()
+        self.blank = cfg.blank
+        self.time_reduction_factor = cfg.time_reduction_factor
+        self.step = 0
+        self._consts = {}
+        self._rng = np.random.default_rng(seed + 1000)
+        self.pred_stream = torch.cuda.Stream(device=self.device)
+        self.use_pred_stream = True
+        self.optimizer = dict(beta1=0.9, beta2=0.98, eps=1e-9, weight_decay=1e-6, schedule=dict(
+            dmodel=cfg.dmodel, warmup_steps=10000, scale=2.0, max_lr=0.05 / math.sqrt(cfg.dmodel)))
+        self.ga_steps = 1
+        self._ga_count = 0
+        self.timers = None  # optional dict name -> list[(start_event, end_event)] filled by bench.py
+
+    # =================================================================================== constants
+    def _frontend_consts(self):
+        if "fe" not in self._consts:
+            c = self.cfg
+            n = c.frame_length
+            window = (0.5 - 0.5 * np.cos(2.0 * np.pi * np.arange(n) / n)).astype(np.float32)  # periodic Hann
+            melw = _mel_weight_matrix(c.num_feature_bins, c.nfft // 2 + 1, c.sample_rate, c.lower_edge_hertz, c.upper_edge_hertz)
+            band = np.zeros((melw.shape[1], 2), np.int32)
+            for m in range(melw.shape[1]):
+                nz = np.nonzero(melw[:, m])[0]
+                band[m] = (nz[0], nz[-1]) if len(nz) else (0, -1)
+            dev = self.device
+            self._consts["fe"] = (torch.from_numpy(window).to(dev), torch.from_numpy(melw).to(dev), torch.from_numpy(band).to(dev))
+        return self._consts["fe"]
+
+    def _pe_ext(self, T):
+        """Relative sinusoid table for length T: rows r=0..2T-2 <-> positions T-1..-(T-1) (positional_encoding.py:119-121,
+        31-52 interleaved), plus one zero row (the projection of a masked-out encoding row = the bias)."""
+        key = ("pe", T)
+        if key not in self._consts:
+            d = self.cfg.dmodel
+            pos = np.concatenate([np.arange(T - 1, 0, -1), np.arange(0, -T, -1)]).astype(np.float32)
+            ts = np.power(np.float32(1.0 / 10000.0), (2 * (np.arange(d, dtype=np.float32) // 2)) / np.float32(d)).astype(np.float32)
+            ang = pos[:, None] * ts[None, :]
+            pe = np.where((np.arange(d) % 2 == 1)[None, :], np.cos(ang), np.sin(ang)).astype(np.float32)
+            pe = np.concatenate([pe, np.zeros((1, d), np.float32)], 0)
+            self._consts[key] = torch.from_numpy(pe).to(self.device).to(self.dtype).contiguous()
+        return self._consts[key]
+
+    # =================================================================================== dense helpers
+    def _dense_bwd(self, dy, x, wname, bname, alpha=1.0, dact_z=None, dact=ACT_NONE, need_dx=True):
+        """dx = alpha * (dy @ W^T) [* dact'(z)];  gW += alpha * x^T dy;  gb += alpha * colsum(dy)."""
+        ps = self.ps
+        W = ps.w2d(wname)
+        rows = dy.shape[0]
+        din, dout = W.shape
+        K.gemm(x, dy, ps.g2d(wname), din, dout, rows, x.stride(0), dy.stride(0), dout, trans_a=True, accumulate=True,
+               split_k=_split_k(din, dout, rows), alpha=alpha)
+        if bname is not None:
+            K.colsum(dy, ps.g(bname), scale=alpha, rows=rows, C=dout, ld=dy.stride(0))
+        if not need_dx:
+            return None
+        return K.matmul(dy, W, trans_b=True, alpha=alpha, dact_z=dact_z, dact=dact)
+
+    # =================================================================================== frontend
+    def frontend(self, signals, signals_length, training=False, masks=None):
+        """FeatureExtraction.call (feature_extraction.py:255-303) -> features [B,T0,F] (compute dtype), feature lengths (host)."""
+        c = self.cfg
+        window, melw, band = self._frontend_consts()
+        feats = K.logmel(signals, window, melw, band, c.frame_step, c.nfft, c.preemphasis, c.epsilon, self.dtype)
+        flen = [-(-int(n) // c.frame_step) for n in signals_length]
+        if training:
+            if masks is None:
+                masks = self.draw_specaugment(flen)
+            fm, tm = masks
+            if fm is not None or tm is not None:
+                K.specaugment(feats, None if fm is None else fm.to(self.device), None if tm is None else tm.to(self.device), 0.0)
+        return feats, flen
+
+    def draw_specaugment(self, flen):
+        """Random draws of FreqMasking/TimeMasking.augment (specaugment.py:72-77,122-131; freq before time:
+        augmentation.py:95; TimeMasking ignores mask_factor)."""
+        c = self.cfg
+        fcfg, tcfg = c.freq_masking, c.time_masking
+        B = len(flen)
+        rng = self._rng
+        fm = tm = None
+        if fcfg and fcfg.get("num_masks", 0) > 0:
+            fm = np.zeros((B, fcfg["num_masks"], 2), np.int32)
+            for b in range(B):
+                for k in range(fcfg["num_masks"]):
+                    if rng.uniform() <= fcfg.get("prob", 1.0):
+                        f = min(int(rng.integers(0, fcfg["mask_factor"])), c.num_feature_bins)
+                        fm[b, k] = (int(rng.integers(0, max(1, c.num_feature_bins - f))), f)
+            fm = torch.from_numpy(fm)
+        if tcfg and tcfg.get("num_masks", 0) > 0:
+            tm = np.zeros((B, tcfg["num_masks"], 2), np.int32)
+            for b in range(B):
+                Tb = int(math.floor(flen[b] * tcfg.get("p_upperbound", 1.0)))
+                for k in range(tcfg["num_masks"]):
+                    if rng.uniform() <= tcfg.get("prob", 1.0):
+                        t = min(int(rng.integers(0, max(1, Tb))), flen[b])
+                        tm[b, k] = (int(rng.integers(0, max(1, flen[b] - t))), t)
+            tm = torch.from_numpy(tm)
+        return fm, tm
+
+    # =================================================================================== batch norm
+    def _bn_fwd(self, x2d, name, training, act):
+        ps = self.ps
+        C = x2d.shape[1]
+        fin = torch.empty(4 * C, dtype=torch.float32, device=self.device)
+        if training:
+            stats = torch.zeros(2 * C + 1, dtype=torch.float32, device=self.device)
+            K.bn_stats(x2d, stats)
+            count = x2d.shape[0] * self.dp.world
+            self.dp.allreduce_stats_(stats[:2 * C])
+            K.bn_finalize(stats, count, ps.p(name + "/g"), ps.p(name + "/b"), fin, ps.state[name + "/mm"], ps.state[name + "/mv"], 0.99, 1e-3, True)
+        else:
+            count = x2d.shape[0]
+            K.bn_finalize(None, 1, ps.p(name + "/g"), ps.p(name + "/b"), fin, ps.state[name + "/mm"], ps.state[name + "/mv"], 0.99, 1e-3, False)
+        y = K.bn_apply_fwd(x2d, fin, act)
+        return y, (fin, count)
+
+    def _bn_bwd(self, x2d, dy2d, name, saved, act):
+        fin, count = saved
+        ps = self.ps
+        C = x2d.shape[1]
+        bstats = torch.zeros(2 * C, dtype=torch.float32, device=self.device)
+        K.bn_bwd_stats(x2d, dy2d, fin, bstats, act)
+        self.dp.allreduce_stats_(bstats)
+        dx = K.bn_apply_bwd(x2d, dy2d, fin, bstats, count, act)
+        # bstats = (sum dz, sum dz*xhat) over the GLOBAL batch; the flat-gradient all-reduce sums over ranks again
+        inv = 1.0 / self.dp.world
+        K.axpy(ps.g(name + "/b"), bstats[:C].contiguous(), inv)
+        K.axpy(ps.g(name + "/g"), bstats[C:].contiguous(), inv)
+        return dx
+
+    # =================================================================================== subsampling
+    def _subsampling_fwd(self, feats, flen, training, ctx):
+        ps, c = self.ps, self.cfg
+        B, T0, F0 = feats.shape
+        C = c.filters
+        c1 = K.conv1_fwd(feats, ps.p("enc/sub/conv0/w"), ps.p("enc/sub/conv0/b"))  # [B,T1,F1,C]
+        T1, F1 = c1.shape[1], c1.shape[2]
+        a1, bn0 = self._bn_fwd(c1.view(-1, C), "enc/sub/bn0", training, ACT_SWISH)
+        a1 = a1.view(B, T1, F1, C)
+        col = K.im2col_3x3s2(a1)  # [B*T2*F2, 9C]
+        T2, F2 = (T1 + 1) // 2, (F1 + 1) // 2
+        c2 = K.matmul(col, ps.w2d("enc/sub/conv1/w"), bias=ps.p("enc/sub/conv1/b"))  # [B*T2*F2, C]
+        a2, bn1 = self._bn_fwd(c2, "enc/sub/bn1", training, ACT_SWISH)
+        merged = a2.view(B * T2, F2 * C)  # math_util.merge_two_last_dims
+        x0 = K.matmul(merged, ps.w2d("enc/linear/w"), bias=ps.p("enc/linear/b"))  # [B*T2, d]
+        elen = [-(-(-(-n // 2)) // 2) for n in flen]
+        if ctx is not None:
+            ctx["sub"] = dict(feats=feats, c1=c1, bn0=bn0, col=col, c2=c2, bn1=bn1, merged=merged, dims=(B, T0, F0, T1, F1, T2, F2))
+        return x0, T2, elen
+
+    def _subsampling_bwd(self, dx0, ctx):
+        ps, c = self.ps, self.cfg
+        s = ctx["sub"]
+        B, T0, F0, T1, F1, T2, F2 = s["dims"]
+        C = c.filters
+        dmerged = self._dense_bwd(dx0, s["merged"], "enc/linear/w", "enc/linear/b")
+        dc2 = self._bn_bwd(s["c2"], dmerged.view(-1, C), "enc/sub/bn1", s["bn1"], ACT_SWISH)
+        dcol = self._dense_bwd(dc2, s["col"], "enc/sub/conv1/w", "enc/sub/conv1/b")
+        da1 = K.col2im_3x3s2(dcol, B, T1, F1, C)
+        dc1 = self._bn_bwd(s["c1"].view(-1, C), da1.view(-1, C), "enc/sub/bn0", s["bn0"], ACT_SWISH)
+        K.conv1_bwd_weight(s["feats"], dc1.view(B, T1, F1, C), ps.g("enc/sub/conv0/w"), ps.g("enc/sub/conv0/b"))
+
+    # =================================================================================== conformer block
+    def _ffm_fwd(self, x, pfx, ctx):
+        ps, f = self.ps, self.cfg.ffm_residual
+        ln, mean, rstd = K.layernorm_fwd(x, ps.p(pfx + "ln/g"), ps.p(pfx + "ln/b"))
+        z = torch.empty(x.shape[0], ps.shapes[pfx + "d1/w"][1], dtype=self.dtype, device=self.device) if ctx is not None else None
+        h = K.matmul(ln, ps.w2d(pfx + "d1/w"), bias=ps.p(pfx + "d1/b"), act=ACT_SWISH, prez=z)
+        y = K.matmul(h, ps.w2d(pfx + "d2/w"), bias=ps.p(pfx + "d2/b"), res=x, beta=f)
+        if ctx is not None:
+            ctx[pfx] = dict(x=x, ln=ln, mean=mean, rstd=rstd, z=z, h=h)
+        return y
+
+    def _ffm_bwd(self, dy, pfx, ctx):
+        ps, f = self.ps, self.cfg.ffm_residual
+        s = ctx.pop(pfx)
+        dz = self._dense_bwd(dy, s["h"], pfx + "d2/w", pfx + "d2/b", alpha=f, dact_z=s["z"], dact=ACT_SWISH)
+        dln = self._dense_bwd(dz, s["ln"], pfx + "d1/w", pfx + "d1/b")
+        return K.layernorm_bwd(dln, s["x"], ps.p(pfx + "ln/g"), s["mean"], s["rstd"], ps.g(pfx + "ln/g"), ps.g(pfx + "ln/b"), add=dy)
+
+    def _mhsa_fwd(self, x, pfx, B, T, elen_dev, ctx):
+        ps, c = self.ps, self.cfg
+        H, dh = c.num_heads, c.head_size
+        HD = H * dh
+        R1 = 2 * T
+        scale = 1.0 / math.sqrt(dh)
+        ln, mean, rstd = K.layernorm_fwd(x, ps.p(pfx + "ln/g"), ps.p(pfx + "ln/b"))
+        qkv = K.matmul(ln, ps.w2d(pfx + "qkv/w"), bias=ps.p(pfx + "qkv/b"))  # [B*T, 3HD]
+        qu, qv = K.bias2_fwd(qkv, 3 * HD, ps.p("enc/u"), ps.p("enc/v"), B * T, HD)
+        pe = self._pe_ext(T)
+        pext = K.matmul(pe, ps.w2d(pfx + "pos/w"), bias=ps.p(pfx + "pos/b"))  # [2T, HD]
+        kk = qkv[:, HD:]
+        vv = qkv[:, 2 * HD:]
+        content = torch.empty(B, H, T, T, dtype=self.dtype, device=self.device)
+        K.gemm(qu, kk, content, T, T, dh, HD, 3 * HD, T, trans_b=True, nb1=B, nb2=H, sA=(T * HD, dh), sB=(T * 3 * HD, dh),
+               sD=(H * T * T, T * T), alpha=scale)
+        pos = torch.empty(B, H, T, R1, dtype=self.dtype, device=self.device)
+        K.gemm(qv, pext, pos, T, R1, dh, HD, HD, R1, trans_b=True, nb1=B, nb2=H, sA=(T * HD, dh), sB=(0, dh),
+               sD=(H * T * R1, T * R1), alpha=scale)
+        probs = K.relattn_softmax_fwd(content, pos, elen_dev, use_mask=c.use_attention_auto_mask, probs=content)
+        att = torch.empty(B * T, HD, dtype=self.dtype, device=self.device)
+        K.gemm(probs, vv, att, T, dh, T, T, 3 * HD, HD, nb1=B, nb2=H, sA=(H * T * T, T * T), sB=(T * 3 * HD, dh), sD=(T * HD, dh))
+        y = K.matmul(att, ps.w2d(pfx + "o/w"), bias=ps.p(pfx + "o/b"), res=x, beta=c.mhsam_residual)
+        if ctx is not None:
+            ctx[pfx] = dict(x=x, ln=ln, mean=mean, rstd=rstd, qkv=qkv, qu=qu, qv=qv, pext=pext, probs=probs, att=att)
+        return y
+
+    def _mhsa_bwd(self, dy, pfx, B, T, elen_dev, ctx):
+        ps, c = self.ps, self.cfg
+        H, dh = c.num_heads, c.head_size
+        HD = H * dh
+        R1 = 2 * T
+        scale = 1.0 / math.sqrt(dh)
+        s = ctx.pop(pfx)
+        qkv, probs = s["qkv"], s["probs"]
+        kk, vv = qkv[:, HD:], qkv[:, 2 * HD:]
+        datt = self._dense_bwd(dy, s["att"], pfx + "o/w", pfx + "o/b", alpha=c.mhsam_residual)
+        dqkv = torch.empty_like(qkv)
+        # dprobs = datt @ v^T
+        dprobs = torch.empty(B, H, T, T, dtype=self.dtype, device=self.device)
+        K.gemm(datt, vv, dprobs, T, T, dh, HD, 3 * HD, T, trans_b=True, nb1=B, nb2=H, sA=(T * HD, dh), sB=(T * 3 * HD, dh),
+               sD=(H * T * T, T * T))
+        # dv = probs^T @ datt -> v slice of dqkv
+        K.gemm(probs, datt, dqkv[:, 2 * HD:], T, dh, T, T, HD, 3 * HD, trans_a=True, nb1=B, nb2=H, sA=(H * T * T, T * T),
+               sB=(T * HD, dh), sD=(T * 3 * HD, dh))
+        dcontent, dpos = K.relattn_softmax_bwd(probs, dprobs, elen_dev, use_mask=c.use_attention_auto_mask, dcontent=dprobs)
+        # dqu = scale * dcontent @ k ; dk = scale * dcontent^T @ qu
+        dqu = torch.empty(B * T, HD, dtype=self.dtype, device=self.device)
+        K.gemm(dcontent, kk, dqu, T, dh, T, T, 3 * HD, HD, nb1=B, nb2=H, sA=(H * T * T, T * T), sB=(T * 3 * HD, dh),
+               sD=(T * HD, dh), alpha=scale)
+        K.gemm(dcontent, s["qu"], dqkv[:, HD:], T, dh, T, T, HD, 3 * HD, trans_a=True, nb1=B, nb2=H, sA=(H * T * T, T * T),
+               sB=(T * HD, dh), sD=(T * 3 * HD, dh), alpha=scale)
+        # dqv = scale * dpos @ pext ; dpext += scale * sum_b dpos^T @ qv
+        dqv = torch.empty(B * T, HD, dtype=self.dtype, device=self.device)
+        K.gemm(dpos, s["pext"], dqv, T, dh, R1, R1, HD, HD, nb1=B, nb2=H, sA=(H * T * R1, T * R1), sB=(0, dh), sD=(T * HD, dh),
+               alpha=scale)
+        dpext = torch.zeros(R1, HD, dtype=torch.float32, device=self.device)
+        K.gemm(dpos, s["qv"], dpext, R1, dh, T, R1, HD, HD, trans_a=True, nb1=B, nb2=H, sA=(H * T * R1, T * R1), sB=(T * HD, dh),
+               sD=(0, dh), alpha=scale, accumulate=True)
+        K.bias2_bwd(dqu, dqv, dqkv, 3 * HD, ps.g("enc/u"), ps.g("enc/v"), B * T, HD)
+        # positional projection: gWpos += pe^T dpext ; gbpos += colsum(dpext)
+        dpext_t = dpext if self.dtype == torch.float32 else K.cast(dpext, torch.empty(R1, HD, dtype=self.dtype, device=self.device))
+        pe = self._pe_ext(T)
+        d = c.dmodel
+        K.gemm(pe, dpext_t, ps.g2d(pfx + "pos/w"), d, HD, R1, d, HD, HD, trans_a=True, accumulate=True)
+        K.colsum(dpext, ps.g(pfx + "pos/b"))
+        dln = self._dense_bwd(dqkv, s["ln"], pfx + "qkv/w", pfx + "qkv/b")
+        return K.layernorm_bwd(dln, s["x"], ps.p(pfx + "ln/g"), s["mean"], s["rstd"], ps.g(pfx + "ln/g"), ps.g(pfx + "ln/b"), add=dy)
+
+    def _convm_fwd(self, x, pfx, B, T, training, ctx):
+        ps, c = self.ps, self.cfg
+        d = c.dmodel
+        ln, mean, rstd = K.layernorm_fwd(x, ps.p(pfx + "ln/g"), ps.p(pfx + "ln/b"))
+        a = K.matmul(ln, ps.w2d(pfx + "pw1/w"), bias=ps.p(pfx + "pw1/b"))  # [B*T, 2d]
+        g = K.glu_fwd(a)  # [B*T, d]
+        cv = K.dwconv_fwd(g.view(B, T, d), ps.p(pfx + "dw/w"), ps.p(pfx + "dw/b")).view(B * T, d)
+        sw, bn = self._bn_fwd(cv, pfx + "bn", training, ACT_SWISH)
+        y = K.matmul(sw, ps.w2d(pfx + "pw2/w"), bias=ps.p(pfx + "pw2/b"), res=x, beta=c.convm_residual)
+        if ctx is not None:
+            ctx[pfx] = dict(x=x, ln=ln, mean=mean, rstd=rstd, a=a, g=g, cv=cv, bn=bn, sw=sw)
+        return y
+
+    def _convm_bwd(self, dy, pfx, B, T, ctx):
+        ps, c = self.ps, self.cfg
+        d = c.dmodel
+        s = ctx.pop(pfx)
+        dsw = self._dense_bwd(dy, s["sw"], pfx + "pw2/w", pfx + "pw2/b", alpha=c.convm_residual)
+        dcv = self._bn_bwd(s["cv"], dsw, pfx + "bn", s["bn"], ACT_SWISH)
+        dcv3 = dcv.view(B, T, d)
+        K.dwconv_bwd_weight(s["g"].view(B, T, d), dcv3, ps.g(pfx + "dw/w"), ps.g(pfx + "dw/b"))
+        dg = K.dwconv_bwd_data(dcv3, ps.p(pfx + "dw/w")).view(B * T, d)
+        da = K.glu_bwd(s["a"], dg)
+        dln = self._dense_bwd(da, s["ln"], pfx + "pw1/w", pfx + "pw1/b")
+        return K.layernorm_bwd(dln, s["x"], ps.p(pfx + "ln/g"), s["mean"], s["rstd"], ps.g(pfx + "ln/g"), ps.g(pfx + "ln/b"), add=dy)
+
+    def _block_fwd(self, x, i, B, T, elen_dev, training, ctx):
+        p = f"enc/block{i}/"
+        ps = self.ps
+        x = self._ffm_fwd(x, p + "ff1/", ctx)
+        x = self._mhsa_fwd(x, p + "mhsa/", B, T, elen_dev, ctx)
+        x = self._convm_fwd(x, p + "conv/", B, T, training, ctx)
+        x = self._ffm_fwd(x, p + "ff2/", ctx)
+        y, mean, rstd = K.layernorm_fwd(x, ps.p(p + "ln/g"), ps.p(p + "ln/b"))
+        if ctx is not None:
+            ctx[p + "ln"] = dict(x=x, mean=mean, rstd=rstd)
+        return y
+
+    def _block_bwd(self, dy, i, B, T, elen_dev, ctx):
+        p = f"enc/block{i}/"
+        ps = self.ps
+        s = ctx.pop(p + "ln")
+        dx = K.layernorm_bwd(dy, s["x"], ps.p(p + "ln/g"), s["mean"], s["rstd"], ps.g(p + "ln/g"), ps.g(p + "ln/b"))
+        dx = self._ffm_bwd(dx, p + "ff2/", ctx)
+        dx = self._convm_bwd(dx, p + "conv/", B, T, ctx)
+        dx = self._mhsa_bwd(dx, p + "mhsa/", B, T, elen_dev, ctx)
+        dx = self._ffm_bwd(dx, p + "ff1/", ctx)
+        return dx
+
+    # =================================================================================== encoder
+    def encoder_fwd(self, feats, flen, training, ctx):
+        """ConformerEncoder.call (conformer.py:672-701): subsample -> linear -> relpe -> blocks.  -> [B*T', d], T', lengths."""
+        x, T, elen = self._subsampling_fwd(feats, flen, training, ctx)
+        B = feats.shape[0]
+        elen_dev = torch.tensor(elen, dtype=torch.int32).to(self.device, non_blocking=True)
+        for i in range(self.cfg.num_blocks):
+            x = self._block_fwd(x, i, B, T, elen_dev, training, ctx)
+        if ctx is not None:
+            ctx["enc"] = dict(B=B, T=T, elen_dev=elen_dev)
+        return x, T, elen, elen_dev
+
+    def encoder_bwd(self, dx, ctx):
+        e = ctx["enc"]
+        for i in reversed(range(self.cfg.num_blocks)):
+            dx = self._block_bwd(dx, i, e["B"], e["T"], e["elen_dev"], ctx)
+            self._bucket_after_block(i)
+        self._subsampling_bwd(dx, ctx)
+
+    def _bucket_after_block(self, i):
+        lo = self.ps.offsets[f"enc/block{i}/ff1/ln/g"]
+        hi = self.ps.offsets[f"enc/block{i + 1}/ff1/ln/g"] if i + 1 < self.cfg.num_blocks else self.ps.offsets["pred/emb"]
+        self.dp.grads_ready(lo, hi)
+
+    # =================================================================================== prediction network
+    def prediction_fwd(self, tokens_dev, plen_dev, ctx, h0=None, c0=None):
+        """TransducerPrediction.call (base_transducer.py:123-132): Embedding -> LSTM -> LayerNorm. tokens [B,U1] int32."""
+        ps, c = self.ps, self.cfg
+        B, U1 = tokens_dev.shape
+        E, P = c.embed_dim, c.rnn_units
+        emb = K.embedding_fwd(tokens_dev, ps.p("pred/emb"), self.dtype).view(B * U1, E)
+        xg = K.matmul(emb, ps.w2d("pred/lstm/k"), bias=ps.p("pred/lstm/b")).view(B, U1, 4 * P)
+        gates = torch.empty(B, U1, 4 * P, dtype=self.dtype, device=self.device)
+        cseq = torch.empty(B, U1, P, dtype=torch.float32, device=self.device)
+        hseq = torch.empty(B, U1, P, dtype=self.dtype, device=self.device)
+        yseq = torch.empty(B, U1, P, dtype=self.dtype, device=self.device)
+        hr = torch.empty(B, 4 * P, dtype=torch.float32, device=self.device)
+        Wrk = ps.w2d("pred/lstm/rk")
+        for t in range(U1):
+            hprev = hseq[:, t - 1] if t > 0 else h0
+            cprev = cseq[:, t - 1] if t > 0 else c0
+            use_hr = hprev is not None
+            if use_hr:
+                K.gemm(hprev, Wrk, hr, B, 4 * P, P, hprev.stride(0), 4 * P, 4 * P)
+            K.lstm_step_fwd(xg[:, t], hr if use_hr else None, hprev, cprev, plen_dev, t, gates[:, t], cseq[:, t], hseq[:, t], yseq[:, t], B, P)
+        y2 = yseq.view(B * U1, P)
+        pred, mean, rstd = K.layernorm_fwd(y2, ps.p("pred/ln/g"), ps.p("pred/ln/b"))
+        if ctx is not None:
+            ctx["pred"] = dict(tokens=tokens_dev, plen=plen_dev, emb=emb, gates=gates, cseq=cseq, hseq=hseq, y2=y2, mean=mean, rstd=rstd, B=B, U1=U1)
+        return pred  # [B*U1, P]
+
+    def prediction_bwd(self, dpred, ctx):
+        ps, c = self.ps, self.cfg
+        s = ctx["pred"]
+        B, U1 = s["B"], s["U1"]
+        E, P = c.embed_dim, c.rnn_units
+        dy = K.layernorm_bwd(dpred, s["y2"], ps.p("pred/ln/g"), s["mean"], s["rstd"], ps.g("pred/ln/g"), ps.g("pred/ln/b")).view(B, U1, P)
+        dz = torch.empty(B, U1, 4 * P, dtype=self.dtype, device=self.device)
+        dh_carry = torch.zeros(B, P, dtype=torch.float32, device=self.device)
+        dc_carry = torch.zeros(B, P, dtype=torch.float32, device=self.device)
+        dhr = torch.empty(B, P, dtype=torch.float32, device=self.device)
+        Wrk = ps.w2d("pred/lstm/rk")
+        for t in reversed(range(U1)):
+            K.lstm_step_bwd(dy[:, t], dhr if t < U1 - 1 else None, dh_carry, dc_carry, s["gates"][:, t], s["cseq"][:, t],
+                            s["cseq"][:, t - 1] if t > 0 else None, s["plen"], t, dz[:, t], B, P)
+            if t > 0:
+                K.gemm(dz[:, t], Wrk, dhr, B, P, 4 * P, dz.stride(0), 4 * P, P, trans_b=True)
+        dz2 = dz.view(B * U1, 4 * P)
+        # recurrent kernel: gR += sum_b h[b, :-1]^T @ dz[b, 1:]
+        if U1 > 1:
+            K.gemm(s["hseq"], dz[:, 1:], ps.g2d("pred/lstm/rk"), P, 4 * P, U1 - 1, P, 4 * P, 4 * P, trans_a=True, nb1=B,
+                   sA=(U1 * P, 0), sB=(U1 * 4 * P, 0), sD=(0, 0), accumulate=True)
+        demb = self._dense_bwd(dz2, s["emb"], "pred/lstm/k", "pred/lstm/b")
+        K.embedding_bwd(s["tokens"], demb, ps.g("pred/emb"))
+
+    # =================================================================================== joint + loss
+    def joint_fwd(self, enc, pred, B, T, U1, ctx):
+        """TransducerJoint.call (base_transducer.py:280-293) -> logits [B,T,U1,V]."""
+        ps, c = self.ps, self.cfg
+        J, V = c.joint_dim, c.vocab_size
+        e = K.matmul(enc, ps.w2d("joint/enc/w"), bias=ps.p("joint/enc/b"))
+        p = K.matmul(pred, ps.w2d("joint/pred/w"), bias=ps.p("joint/pred/b"))
+        h = K.joint_fwd(e.view(B, T, J), p.view(B, U1, J))
+        logits = K.matmul(h.view(B * T * U1, J), ps.w2d("joint/vocab/w"), bias=ps.p("joint/vocab/b")).view(B, T, U1, V)
+        if ctx is not None:
+            ctx["joint"] = dict(enc=enc, pred=pred, h=h, B=B, T=T, U1=U1)
+        return logits
+
+    def joint_bwd(self, dlogits, ctx):
+        ps, c = self.ps, self.cfg
+        s = ctx["joint"]
+        B, T, U1 = s["B"], s["T"], s["U1"]
+        J, V = c.joint_dim, c.vocab_size
+        h2 = s["h"].view(B * T * U1, J)
+        dh = self._dense_bwd(dlogits.view(B * T * U1, V), h2, "joint/vocab/w", "joint/vocab/b")
+        de, dp = K.joint_bwd(s["h"], dh.view(B, T, U1, J))
+        denc = self._dense_bwd(de.view(B * T, J), s["enc"], "joint/enc/w", "joint/enc/b")
+        dpred = self._dense_bwd(dp.view(B * U1, J), s["pred"], "joint/pred/w", "joint/pred/b")
+        return denc, dpred
+
+    # =================================================================================== public API
+    def __call__(self, inputs: TrainInput, training=False):
+        """Transducer.call (base_transducer.py:427-435)."""
+        logits, elen, _ = self._forward(inputs, training, None)
+        return TrainOutput(logits=logits, logits_length=torch.tensor(elen, dtype=torch.int32))
+
+    def _forward(self, inputs: TrainInput, training, ctx, masks=None):
+        dev = self.device
+        sig = inputs.inputs.to(dev, non_blocking=True)
+        slen = [int(v) for v in inputs.inputs_length.tolist()]
+        tokens = inputs.predictions.to(dev, non_blocking=True).to(torch.int32).contiguous()
+        plen = inputs.predictions_length.to(dev, non_blocking=True).to(torch.int32)
+        B, U1 = tokens.shape
+        main = torch.cuda.current_stream()
+        if self.use_pred_stream:
+            self.pred_stream.wait_stream(main)
+            tokens.record_stream(self.pred_stream)
+            plen.record_stream(self.pred_stream)
+            with torch.cuda.stream(self.pred_stream):
+                pred = self.prediction_fwd(tokens, plen, ctx)
+            pred.record_stream(main)
+        feats, flen = self.frontend(sig, slen, training, masks)
+        enc, T, elen, elen_dev = self.encoder_fwd(feats, flen, training, ctx)
+        if self.use_pred_stream:
+            main.wait_stream(self.pred_stream)
+        else:
+            pred = self.prediction_fwd(tokens, plen, ctx)
+        logits = self.joint_fwd(enc, pred, B, T, U1, ctx)
+        return logits, elen, elen_dev
+
+    def loss_and_backward(self, data: TrainData, training=True, masks=None, want_backward=True):
+        """BaseModel._train_step (base_model.py:149-183): forward, RnntLoss (mean over the batch, rnnt_loss.py:34) and
+        the full backward into the flat gradient buffer (gradients ACCUMULATE; zero_grad() first)."""
+        ctx = {} if want_backward else None
+        logits, elen, elen_dev = self._forward(data.inputs, training, ctx, masks)
+        B, T, U1, V = logits.shape
+        dev = self.device
+        labels = data.labels.labels.to(dev, non_blocking=True).to(torch.int32).contiguous()
+        llen = data.labels.labels_length.to(dev, non_blocking=True).to(torch.int32)
+        # BaseLoss.call: logit_length = max(logit_length, label_length)  (losses/base_loss.py:36)
+        tl = [max(int(a), int(b)) for a, b in zip(elen, data.labels.labels_length.tolist())]
+        tl_dev = torch.tensor(tl, dtype=torch.int32).to(dev, non_blocking=True)
+        gscale = torch.full((B,), 1.0 / (B * self.dp.world), dtype=torch.float32, device=dev)
+        t0 = self._tick("rnnt_loss")
+        costs, dlogits = K.rnnt_loss_fwd_bwd(logits, labels, llen, tl_dev, grad_scale=gscale, grads=logits, want_grads=want_backward)
+        self._tock("rnnt_loss", t0)
+        if not want_backward:
+            return costs
+        denc, dpred = self.joint_bwd(dlogits, ctx)
+        main = torch.cuda.current_stream()
+        self.dp.grads_ready(self.ps.offsets["joint/enc/w"], self.ps.n_reg)
+        if self.use_pred_stream:
+            self.pred_stream.wait_stream(main)
+            dpred.record_stream(self.pred_stream)
+            with torch.cuda.stream(self.pred_stream):
+                self.prediction_bwd(dpred, ctx)
+        else:
+            self.prediction_bwd(dpred, ctx)
+        self.encoder_bwd(denc, ctx)
+        if self.use_pred_stream:
+            main.wait_stream(self.pred_stream)
+        self.dp.finish_grads()
+        return costs
+
+    def zero_grad(self):
+        self.ps.grad.zero_()
+
+    def learning_rate(self, step):
+        s = self.optimizer["schedule"]
+        if isinstance(s, (int, float)):
+            return float(s)
+        from .configs import transformer_schedule
+
+        return transformer_schedule(step, **s)
+
+    def apply_gradients(self, grad_scale=1.0):
+        """BaseModel._apply_gradients -> keras Adam (base_model.py:185-192; small.yml.j2:73-87) + L2 regulariser gradient."""
+        o = self.optimizer
+        self.step += 1
+        lr = self.learning_rate(self.step)
+        ps = self.ps
+        K.adam(ps.flat, ps.grad, ps.adam_m, ps.adam_v, ps.n_reg, lr, self.step, o["beta1"], o["beta2"], o["eps"], o["weight_decay"],
+               self.cfg.l2, grad_scale)
+        ps.refresh_shadow()
+        return lr
+
+    def regularization_loss(self):
+        out = torch.zeros(1, dtype=torch.float32, device=self.device)
+        K.sumsq(self.ps.flat, self.ps.n_reg, out)
+        return out * self.cfg.l2
+
+    def train_step(self, data: TrainData, masks=None):
+        """BaseModel.train_step / train_step_ga (base_model.py:194-209): returns {'loss': per-utterance costs [B]}.
+        With ga_steps > 1 the optimizer is applied every ga_steps-th call with (sum of micro-grads)/ga_steps
+        (optimizers/accumulation.py:64-70)."""
+        if self._ga_count == 0:
+            self.zero_grad()
+        costs = self.loss_and_backward(data, True, masks)
+        self._ga_count += 1
+        if self._ga_count >= self.ga_steps:
+            self.apply_gradients(1.0 / self.ga_steps)
+            self._ga_count = 0
+        return {"loss": costs}
+
+    # ----------------------------------------------------------------- timing hooks (bench.py)
+    def _tick(self, name):
+        if self.timers is None:
+            return None
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    def _tock(self, name, start):
+        if self.timers is None:
+            return
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        self.timers.setdefault(name, []).append((start, e))
+
+
+def _mel_weight_matrix(num_mel_bins, num_spectrogram_bins, sample_rate, lower, upper):
+    """tf.signal.linear_to_mel_weight_matrix semantics (feature_extraction.py:222-229): HTK mel scale, DC row zero,
+    un-normalised triangles, float32 arithmetic."""
+    f32 = np.float32
+
+    def mel(f):
+        return (f32(1127.0) * np.log(f32(1.0) + np.asarray(f, f32) / f32(700.0))).astype(f32)
+
+    nyquist = f32(sample_rate) / f32(2.0)
+    linear = np.linspace(f32(0.0), nyquist, num_spectrogram_bins, dtype=f32)[1:]
+    spec_mel = mel(linear)[:, None]
+    edges = np.linspace(mel(lower), mel(upper), num_mel_bins + 2, dtype=f32)
+    lo, ce, hi = edges[:-2][None, :], edges[1:-1][None, :], edges[2:][None, :]
+    w = np.maximum(f32(0.0), np.minimum((spec_mel - lo) / (ce - lo), (hi - spec_mel) / (hi - ce))).astype(f32)
+    return np.pad(w, [[1, 0], [0, 0]]).astype(f32)

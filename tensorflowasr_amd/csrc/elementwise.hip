@@ -314,6 +314,11 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
   }
 }
 
+// y += alpha * x  (f32 vectors: sync-BN gradient hand-off, gradient accumulation)
+__global__ __launch_bounds__(256) void axpy_kernel(float* __restrict__ y, const float* __restrict__ x, float alpha, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) y[i] += alpha * x[i];
+}
+
 // sum of squares (regularisation loss term); out[0] += sum p^2
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ p, long n, float* __restrict__ out) {
   __shared__ float red[16];
@@ -518,6 +523,13 @@ extern "C" int tfasr_adam(float* p, const float* g, float* m, float* v, long n, 
   const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
   hipLaunchKernelGGL(adam_kernel, dim3(flat_grid(n)), dim3(256), 0, (hipStream_t)stream_, p, g, m, v, n, n_reg, lr, beta1,
                      beta2, eps, weight_decay, l2, grad_scale, bc1, bc2);
+  TFASR_CHECK_LAUNCH();
+  return TFASR_STATUS_SUCCESS;
+}
+
+extern "C" int tfasr_axpy(float* y, const float* x, float alpha, long n, void* stream_) {
+  if (!x || !y || n <= 0) return TFASR_STATUS_INVALID_VALUE;
+  hipLaunchKernelGGL(axpy_kernel, dim3(flat_grid(n)), dim3(256), 0, (hipStream_t)stream_, y, x, alpha, n);
   TFASR_CHECK_LAUNCH();
   return TFASR_STATUS_SUCCESS;
 }

@@ -25,6 +25,17 @@ def _p(t):
         return None
     if not t.is_cuda:
         raise _lib.TfasrError("tensorflowasr_amd ops need HIP device tensors (no CPU fallback on the product path)")
+    if not t.is_contiguous():
+        raise _lib.TfasrError(f"non-contiguous tensor passed to a HIP kernel (shape {tuple(t.shape)}, strides {t.stride()})")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _pv(t):
+    """pointer of a strided VIEW (the kernel receives the strides explicitly)"""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise _lib.TfasrError("tensorflowasr_amd ops need HIP device tensors (no CPU fallback on the product path)")
     return ctypes.c_void_p(t.data_ptr())
 
 
@@ -88,7 +99,7 @@ def gemm(A, B, out, M, N, K, lda, ldb, ldd, trans_a=False, trans_b=False, bias=N
     a.act, a.dact = act, dact
     a.dtype = _dt(A)
     assert B.dtype == A.dtype and A.is_cuda and B.is_cuda and out.is_cuda
-    a.out_f32 = int(out.dtype == torch.float32 and A.dtype != torch.float32) or int(accumulate)
+    a.out_f32 = int(out.dtype == torch.float32)
     a.accumulate = int(accumulate)
     a.split_k = split_k
     if accumulate:
@@ -169,7 +180,7 @@ def colsum(x2d, out, scale=1.0, rows=None, C=None, ld=None):
     rows = x2d.shape[0] if rows is None else rows
     C = x2d.shape[1] if C is None else C
     ld = x2d.stride(0) if ld is None else ld
-    check(_L().tfasr_colsum(_p(x2d), ld, _p(out), rows, C, scale, _dt(x2d), _stream()), "colsum")
+    check(_L().tfasr_colsum(_pv(x2d), ld, _p(out), rows, C, scale, _dt(x2d), _stream()), "colsum")
 
 
 def glu_fwd(x):
@@ -208,12 +219,12 @@ def dwconv_bwd_weight(x, dy, dw, dbias):
 def bias2_fwd(x, ldx, u, v, rows, C):
     y1 = torch.empty(rows, C, dtype=x.dtype, device=x.device)
     y2 = torch.empty(rows, C, dtype=x.dtype, device=x.device)
-    check(_L().tfasr_bias2_fwd(_p(x), ldx, _p(u), _p(v), _p(y1), _p(y2), rows, C, _dt(x), _stream()), "bias2_fwd")
+    check(_L().tfasr_bias2_fwd(_pv(x), ldx, _p(u), _p(v), _p(y1), _p(y2), rows, C, _dt(x), _stream()), "bias2_fwd")
     return y1, y2
 
 
 def bias2_bwd(d1, d2, dx, lddx, du, dv, rows, C):
-    check(_L().tfasr_bias2_bwd(_p(d1), _p(d2), _p(dx), lddx, _p(du), _p(dv), rows, C, _dt(d1), _stream()), "bias2_bwd")
+    check(_L().tfasr_bias2_bwd(_p(d1), _p(d2), _pv(dx), lddx, _p(du), _p(dv), rows, C, _dt(d1), _stream()), "bias2_bwd")
 
 
 def embedding_fwd(idx, table, dtype):
@@ -247,6 +258,10 @@ def joint_bwd(h, dh):
 
 def adam(p, g, m, v, n_reg, lr, step, beta1=0.9, beta2=0.999, eps=1e-7, weight_decay=0.0, l2=0.0, grad_scale=1.0):
     check(_L().tfasr_adam(_p(p), _p(g), _p(m), _p(v), p.numel(), n_reg, lr, beta1, beta2, eps, weight_decay, l2, grad_scale, step, _stream()), "adam")
+
+
+def axpy(y, x, alpha=1.0):
+    check(_L().tfasr_axpy(_p(y), _p(x), alpha, x.numel(), _stream()), "axpy")
 
 
 def sumsq(p, n, out):
@@ -283,16 +298,16 @@ def relattn_softmax_bwd(probs, dprobs, lengths, use_mask=True, dcontent=None, dp
 # -------------------------------------------------------------------------------------- LSTM
 def lstm_step_fwd(xg_t, hr, h_prev, c_prev, lengths, t, gates_t, c_out, h_out, y_out, B, P):
     check(_L().tfasr_lstm_step_fwd(
-        _p(xg_t), xg_t.stride(0), _p(hr), _p(h_prev), 0 if h_prev is None else h_prev.stride(0), _p(c_prev),
-        0 if c_prev is None else c_prev.stride(0), _p(lengths), t, _p(gates_t), 0 if gates_t is None else gates_t.stride(0),
-        _p(c_out), c_out.stride(0), _p(h_out), h_out.stride(0), _p(y_out), 0 if y_out is None else y_out.stride(0), B, P,
+        _pv(xg_t), xg_t.stride(0), _pv(hr), _pv(h_prev), 0 if h_prev is None else h_prev.stride(0), _pv(c_prev),
+        0 if c_prev is None else c_prev.stride(0), _pv(lengths), t, _pv(gates_t), 0 if gates_t is None else gates_t.stride(0),
+        _pv(c_out), c_out.stride(0), _pv(h_out), h_out.stride(0), _pv(y_out), 0 if y_out is None else y_out.stride(0), B, P,
         _dt(xg_t), _stream()), "lstm_step_fwd")
 
 
 def lstm_step_bwd(dy_t, dhr, dh_carry, dc_carry, gates_t, c_t, c_prev, lengths, t, dz_t, B, P):
     check(_L().tfasr_lstm_step_bwd(
-        _p(dy_t), dy_t.stride(0), _p(dhr), _p(dh_carry), _p(dc_carry), _p(gates_t), gates_t.stride(0), _p(c_t), c_t.stride(0),
-        _p(c_prev), 0 if c_prev is None else c_prev.stride(0), _p(lengths), t, _p(dz_t), dz_t.stride(0), B, P, _dt(dy_t),
+        _pv(dy_t), dy_t.stride(0), _pv(dhr), _pv(dh_carry), _pv(dc_carry), _pv(gates_t), gates_t.stride(0), _pv(c_t), c_t.stride(0),
+        _pv(c_prev), 0 if c_prev is None else c_prev.stride(0), _pv(lengths), t, _pv(dz_t), dz_t.stride(0), B, P, _dt(dy_t),
         _stream()), "lstm_step_bwd")
 
 

@@ -1,0 +1,218 @@
+"""Flat parameter / gradient / optimizer-state store.
+
+All trainable variables live in ONE contiguous f32 buffer (regularised variables first, each group in forward
+order), mirrored by one f32 gradient buffer and — in bf16 mode — one bf16 shadow copy that the MFMA GEMMs read.
+Consequences: the optimizer is a single kernel launch, the shadow refresh is a single cast, the data-parallel
+gradient exchange is a handful of all-reduces over contiguous slices (no per-tensor collectives), and the L2
+kernel-regulariser (small.yml.j2:67-69) is the prefix [0, n_reg) of the buffer.
+
+Variable names / layouts are the Keras ones of the reference except that the attention q/k/v kernels
+[d,H,dh] are stored fused as one [d, 3*H*dh] matrix (columns q|k|v) so the projection is one GEMM; `export_keras()`
+/ `import_keras()` split / fuse them, so a checkpoint in the reference's layout is a rename away.
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import kernels as K
+
+
+def param_specs(cfg):
+    """[(name, shape, regularized, init)] in forward order. init in {glorot, zeros, ones, embed, orth, lstm_bias}."""
+    d, H, dh, C = cfg.dmodel, cfg.num_heads, cfg.head_size, cfg.filters
+    Kk, V, E, P, J = cfg.kernel_size, cfg.vocab_size, cfg.embed_dim, cfg.rnn_units, cfg.joint_dim
+    F2 = -(-(-(-cfg.num_feature_bins // 2)) // 2)
+    HD = H * dh
+    s = []
+
+    def add(name, shape, reg, init, fans=None):
+        s.append((name, tuple(shape), reg, init, fans))
+
+    add("enc/sub/conv0/w", (3, 3, 1, C), True, "glorot", (9, 9 * C))
+    add("enc/sub/conv0/b", (C,), False, "zeros")
+    add("enc/sub/bn0/b", (C,), True, "zeros")
+    add("enc/sub/bn0/g", (C,), True, "ones")
+    add("enc/sub/conv1/w", (3, 3, C, C), True, "glorot", (9 * C, 9 * C))
+    add("enc/sub/conv1/b", (C,), False, "zeros")
+    add("enc/sub/bn1/b", (C,), True, "zeros")
+    add("enc/sub/bn1/g", (C,), True, "ones")
+    add("enc/linear/w", (F2 * C, d), True, "glorot")
+    add("enc/linear/b", (d,), False, "zeros")
+    add("enc/u", (HD,), False, "zeros")
+    add("enc/v", (HD,), False, "zeros")
+    for i in range(cfg.num_blocks):
+        p = f"enc/block{i}/"
+        for ff in ("ff1/", "ff2/"):
+            add(p + ff + "ln/g", (d,), True, "ones"); add(p + ff + "ln/b", (d,), True, "zeros")
+            add(p + ff + "d1/w", (d, cfg.ffm_scale * d), True, "glorot"); add(p + ff + "d1/b", (cfg.ffm_scale * d,), False, "zeros")
+            add(p + ff + "d2/w", (cfg.ffm_scale * d, d), True, "glorot"); add(p + ff + "d2/b", (d,), False, "zeros")
+            if ff == "ff1/":
+                m = p + "mhsa/"
+                add(m + "ln/g", (d,), True, "ones"); add(m + "ln/b", (d,), True, "zeros")
+                add(m + "qkv/w", (d, 3 * HD), True, "glorot", (H * d, dh * d)); add(m + "qkv/b", (3 * HD,), False, "zeros")
+                add(m + "pos/w", (d, HD), True, "glorot", (H * d, dh * d)); add(m + "pos/b", (HD,), False, "zeros")
+                add(m + "o/w", (HD, d), True, "glorot", (dh * H, d * H)); add(m + "o/b", (d,), False, "zeros")
+                c = p + "conv/"
+                add(c + "ln/g", (d,), True, "ones"); add(c + "ln/b", (d,), True, "zeros")
+                add(c + "pw1/w", (d, 2 * d), True, "glorot"); add(c + "pw1/b", (2 * d,), False, "zeros")
+                add(c + "dw/w", (Kk, d), True, "glorot", (Kk * d, Kk)); add(c + "dw/b", (d,), False, "zeros")
+                add(c + "bn/b", (d,), True, "zeros"); add(c + "bn/g", (d,), True, "ones")
+                add(c + "pw2/w", (d, d), True, "glorot"); add(c + "pw2/b", (d,), False, "zeros")
+        add(p + "ln/g", (d,), True, "ones"); add(p + "ln/b", (d,), True, "zeros")
+    add("pred/emb", (V, E), True, "embed")
+    add("pred/lstm/k", (E, 4 * P), True, "glorot")
+    add("pred/lstm/rk", (P, 4 * P), False, "orth")
+    add("pred/lstm/b", (4 * P,), False, "lstm_bias")
+    add("pred/ln/g", (P,), True, "ones"); add("pred/ln/b", (P,), True, "zeros")
+    add("joint/enc/w", (d, J), True, "glorot"); add("joint/enc/b", (J,), False, "zeros")
+    add("joint/pred/w", (P, J), True, "glorot"); add("joint/pred/b", (J,), False, "zeros")
+    add("joint/vocab/w", (J, V), True, "glorot"); add("joint/vocab/b", (V,), False, "zeros")
+    return s
+
+
+def bn_names(cfg):
+    return ["enc/sub/bn0", "enc/sub/bn1"] + [f"enc/block{i}/conv/bn" for i in range(cfg.num_blocks)]
+
+
+class ParamStore:
+    ALIGN = 64  # elements; keeps every variable 256-B aligned in f32 and 128-B aligned in bf16
+
+    def __init__(self, cfg, device, dtype, seed=0):
+        self.cfg, self.device, self.dtype = cfg, device, dtype
+        specs = param_specs(cfg)
+        ordered = [x for x in specs if x[2]] + [x for x in specs if not x[2]]
+        self.offsets, self.shapes = {}, {}
+        off = 0
+        for name, shape, reg, init, fans in ordered:
+            self.offsets[name] = off
+            self.shapes[name] = shape
+            off += -(-int(np.prod(shape)) // self.ALIGN) * self.ALIGN
+            if reg:
+                self.n_reg = off
+        self.n = off
+        self.names = [x[0] for x in ordered]
+        self.flat = torch.zeros(self.n, dtype=torch.float32, device=device)
+        self.grad = torch.zeros(self.n, dtype=torch.float32, device=device)
+        self.adam_m = torch.zeros(self.n, dtype=torch.float32, device=device)
+        self.adam_v = torch.zeros(self.n, dtype=torch.float32, device=device)
+        self.shadow = self.flat if dtype == torch.float32 else torch.zeros(self.n, dtype=dtype, device=device)
+        # non-trainable BatchNorm moving statistics (keras: moving_mean zeros, moving_variance ones)
+        self.state = {}
+        for nm in bn_names(cfg):
+            C = cfg.filters if "/sub/" in nm else cfg.dmodel
+            self.state[nm + "/mm"] = torch.zeros(C, dtype=torch.float32, device=device)
+            self.state[nm + "/mv"] = torch.ones(C, dtype=torch.float32, device=device)
+        self._init(ordered, seed)
+        self.refresh_shadow()
+
+    # ------------------------------------------------------------------ views
+    def _view(self, buf, name):
+        o, shp = self.offsets[name], self.shapes[name]
+        return buf[o:o + int(np.prod(shp))].view(*shp)
+
+    def p(self, name):  # f32 master
+        return self._view(self.flat, name)
+
+    def w(self, name):  # compute-dtype copy read by the GEMMs
+        return self._view(self.shadow, name)
+
+    def g(self, name):  # f32 gradient
+        return self._view(self.grad, name)
+
+    def w2d(self, name):
+        shp = self.shapes[name]
+        return self.w(name).view(-1, shp[-1])
+
+    def g2d(self, name):
+        shp = self.shapes[name]
+        return self.g(name).view(-1, shp[-1])
+
+    def refresh_shadow(self):
+        if self.shadow is not self.flat:
+            K.cast(self.flat, self.shadow)
+
+    def num_trainable(self):
+        return sum(int(np.prod(s)) for s in self.shapes.values())
+
+    # ------------------------------------------------------------------ init (Keras defaults)
+    def _init(self, ordered, seed):
+        rng = np.random.default_rng(seed)
+        host = np.zeros(self.n, np.float32)
+        for name, shape, reg, init, fans in ordered:
+            n = int(np.prod(shape))
+            if init == "zeros":
+                w = np.zeros(shape, np.float32)
+            elif init == "ones":
+                w = np.ones(shape, np.float32)
+            elif init == "embed":
+                w = rng.uniform(-0.05, 0.05, shape).astype(np.float32)
+            elif init == "orth":
+                P = shape[0]
+                q, r = np.linalg.qr(rng.standard_normal((shape[1], P)))
+                w = (q * np.sign(np.diag(r))).T.astype(np.float32)
+            elif init == "lstm_bias":
+                P = shape[0] // 4
+                w = np.zeros(shape, np.float32)
+                w[P:2 * P] = 1.0  # unit_forget_bias
+            else:
+                fi, fo = fans if fans else (shape[0], shape[-1])
+                lim = math.sqrt(6.0 / (fi + fo))
+                w = rng.uniform(-lim, lim, shape).astype(np.float32)
+            host[self.offsets[name]:self.offsets[name] + n] = w.reshape(-1)
+        self.flat.copy_(torch.from_numpy(host))
+
+    # ------------------------------------------------------------------ Keras-layout import / export
+    def import_keras(self, W):
+        """W: name -> tensor in the reference/Keras layouts (the oracle's naming, oracle/conformer_ref.py)."""
+        H, dh = self.cfg.num_heads, self.cfg.head_size
+        host = self.flat.cpu().clone()
+
+        def put(name, t):
+            t = torch.as_tensor(t).detach().float().reshape(-1)
+            o = self.offsets[name]
+            assert t.numel() == int(np.prod(self.shapes[name])), name
+            host[o:o + t.numel()] = t
+
+        for name in self.names:
+            if name.endswith("qkv/w"):
+                base = name[:-len("qkv/w")]
+                put(name, torch.cat([W[base + k + "/w"].reshape(-1, H * dh) for k in ("q", "k", "v")], dim=1))
+            elif name.endswith("qkv/b"):
+                base = name[:-len("qkv/b")]
+                put(name, torch.cat([W[base + k + "/b"].reshape(-1) for k in ("q", "k", "v")]))
+            else:
+                put(name, W[name])
+        self.flat.copy_(host)
+        for k in self.state:
+            if k in W:
+                self.state[k].copy_(torch.as_tensor(W[k]).float())
+        self.refresh_shadow()
+
+    def export_keras(self, buf=None):
+        """name -> CPU tensor in Keras layouts (q/k/v split into [d,H,dh], biases [H,dh], o [H,dh,d])."""
+        H, dh, d = self.cfg.num_heads, self.cfg.head_size, self.cfg.dmodel
+        buf = self.flat if buf is None else buf
+        out = {}
+        for name in self.names:
+            t = self._view(buf, name).detach().float().cpu()
+            if name.endswith("qkv/w"):
+                base = name[:-len("qkv/w")]
+                for i, k in enumerate(("q", "k", "v")):
+                    out[base + k + "/w"] = t[:, i * H * dh:(i + 1) * H * dh].reshape(d, H, dh).clone()
+            elif name.endswith("qkv/b"):
+                base = name[:-len("qkv/b")]
+                for i, k in enumerate(("q", "k", "v")):
+                    out[base + k + "/b"] = t[i * H * dh:(i + 1) * H * dh].reshape(H, dh).clone()
+            elif name.endswith("pos/w"):
+                out[name] = t.reshape(d, H, dh).clone()
+            elif name.endswith("pos/b") or name in ("enc/u", "enc/v"):
+                out[name] = t.reshape(H, dh).clone()
+            elif name.endswith("mhsa/o/w"):
+                out[name] = t.reshape(H, dh, d).clone()
+            else:
+                out[name] = t.clone()
+        if buf is self.flat:
+            for k, v in self.state.items():
+                out[k] = v.detach().cpu().clone()
+        return out

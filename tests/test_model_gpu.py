@@ -1,0 +1,132 @@
+"""GPU parity of the whole Conformer-Transducer step (forward, RNN-T loss, every gradient, Adam) vs the torch-CPU oracle
+with identical weights and inputs (dropout 0, SpecAugment masks injected: SURVEY.md §7 'hard parts')."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import conformer_ref as R
+from oracle import rnnt_ref
+from tensorflowasr_amd import configs
+from tensorflowasr_amd.conformer import ConformerTransducer
+from tensorflowasr_amd.schemas import TrainData, TrainInput, TrainLabel
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(dev, dtype, lens, ulens, seed=0, N=4000, U=6):
+    cfg = configs.conformer_tiny()
+    ocfg = R.conformer_config("tiny")
+    model = ConformerTransducer(cfg, dev, dtype=dtype, seed=seed)
+    model.use_pred_stream = True
+    W = R.init_weights(ocfg, seed=seed + 1, scale_bias=0.1)
+    for k in W:  # make BN / LN affine parameters non-trivial
+        if k.endswith("/g"):
+            W[k] = W[k] + 0.1 * torch.randn_like(W[k])
+    model.ps.import_keras(W)
+    rng = np.random.default_rng(seed)
+    B = len(lens)
+    sig = np.clip(rng.standard_normal((B, N)) * 0.1, -1, 1).astype(np.float32)
+    for b, n in enumerate(lens):
+        sig[b, n:] = 0.0
+    labels = rng.integers(1, cfg.vocab_size, (B, U)).astype(np.int32)
+    for b, u in enumerate(ulens):
+        labels[b, u:] = 0
+    preds = np.concatenate([np.zeros((B, 1), np.int32), labels], 1)  # blank-prepended (tokenizers.py:165-167)
+    data = TrainData(
+        TrainInput(torch.from_numpy(sig), torch.tensor(lens, dtype=torch.int32), torch.from_numpy(preds),
+                   torch.tensor([u + 1 for u in ulens], dtype=torch.int32)),
+        TrainLabel(torch.from_numpy(labels), torch.tensor(ulens, dtype=torch.int32)))
+    return cfg, ocfg, model, W, data, sig, labels, preds
+
+
+def _oracle_step(ocfg, W, sig, lens, preds, ulens, labels, masks=None, use_mask=True):
+    Wg = {k: v.clone().requires_grad_(R.is_trainable(k)) for k, v in W.items()}
+    feat = R.log_mel(sig, ocfg)
+    flen = R.get_nframes(lens)
+    if masks is not None:
+        feat = R.specaugment_apply(feat, masks[0], masks[1])
+    stats = {}
+    logits, elen = R.transducer_forward(torch.from_numpy(feat), flen, torch.from_numpy(preds), torch.tensor([u + 1 for u in ulens]),
+                                        Wg, ocfg, training=True, use_mask=use_mask, stats=stats)
+    tl, ul = rnnt_ref.clamp_lengths(elen.numpy(), np.asarray(ulens))
+    loss, g = rnnt_ref.rnnt_loss_and_grad(logits.detach().numpy(), labels, ul, np.minimum(tl, logits.shape[1]), np.float32)
+    B = len(lens)
+    logits.backward(torch.from_numpy(g / B).to(logits.dtype))
+    grads = {k: v.grad for k, v in Wg.items() if v.requires_grad}
+    return logits.detach(), elen, loss, grads, stats
+
+
+@pytest.mark.parametrize("lens,ulens", [([4000, 4000], [6, 6]), ([4000, 2500, 3100], [6, 3, 5])])
+def test_f32_step_matches_oracle(dev, lens, ulens):
+    cfg, ocfg, model, W, data, sig, labels, preds = _setup(dev, torch.float32, lens, ulens)
+    masks = model.draw_specaugment([int(n) for n in R.get_nframes(lens)])
+    ref_logits, elen, ref_loss, ref_grads, stats = _oracle_step(ocfg, W, sig, lens, preds, ulens, labels,
+                                                                 (masks[0].numpy(), masks[1].numpy()))
+    # forward only (training-mode statistics) -----------------------------------------------------
+    logits, my_elen, _ = model._forward(data.inputs, True, None, masks)
+    assert my_elen == elen.tolist()
+    np.testing.assert_allclose(logits.cpu().numpy(), ref_logits.numpy(), rtol=2e-3, atol=2e-3)
+    # full step -------------------------------------------------------------------------------------
+    model.zero_grad()
+    costs = model.loss_and_backward(data, True, masks)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(costs.cpu().numpy(), ref_loss, rtol=1e-3)  # BASELINE.json: loss within 1e-3 relative
+    mine = model.ps.export_keras(model.ps.grad)
+    worst = []
+    for k, g in ref_grads.items():
+        a, b = mine[k].numpy().reshape(-1), g.numpy().reshape(-1)
+        err = np.abs(a - b).max() / (np.abs(b).max() + 1e-6)
+        worst.append((err, k))
+    worst.sort(reverse=True)
+    assert worst[0][0] < 2e-2, worst[:8]
+    # moving statistics updated like keras (momentum .99)
+    mm = model.ps.state["enc/block0/conv/bn/mm"].cpu()
+    np.testing.assert_allclose(mm.numpy(), (0.01 * stats["enc/block0/conv/bn"][0]).numpy(), rtol=2e-2, atol=1e-5)
+    # optimizer --------------------------------------------------------------------------------------
+    before = model.ps.export_keras()
+    lr = model.apply_gradients()
+    after = model.ps.export_keras()
+    k = "enc/block1/ff2/d1/w"
+    g = mine[k] + 2 * cfg.l2 * before[k]
+    p_ref, _, _ = R.adam_step(before[k], g, torch.zeros_like(g), torch.zeros_like(g), 1, lr, 0.9, 0.98, 1e-9, 1e-6)
+    np.testing.assert_allclose(after[k].numpy(), p_ref.numpy(), rtol=1e-5, atol=1e-7)
+    k = "enc/block1/ff2/d1/b"  # not regularised
+    p_ref, _, _ = R.adam_step(before[k], mine[k], torch.zeros_like(mine[k]), torch.zeros_like(mine[k]), 1, lr, 0.9, 0.98, 1e-9, 1e-6)
+    np.testing.assert_allclose(after[k].numpy(), p_ref.numpy(), rtol=1e-5, atol=1e-7)
+
+
+def test_bf16_step_close_to_oracle(dev):
+    lens, ulens = [4000, 3300], [6, 4]
+    cfg, ocfg, model, W, data, sig, labels, preds = _setup(dev, torch.bfloat16, lens, ulens)
+    ref_logits, elen, ref_loss, ref_grads, _ = _oracle_step(ocfg, W, sig, lens, preds, ulens, labels, None)
+    model.zero_grad()
+    costs = model.loss_and_backward(data, True, (None, None))
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(costs.cpu().numpy(), ref_loss, rtol=3e-2)
+    mine = model.ps.export_keras(model.ps.grad)
+    num = sum(float(((mine[k] - g) ** 2).sum()) for k, g in ref_grads.items())
+    den = sum(float((g ** 2).sum()) for g in ref_grads.values())
+    assert (num / den) ** 0.5 < 0.15
+
+
+def test_train_steps_reduce_loss_and_ga(dev):
+    lens, ulens = [4000, 4000], [6, 5]
+    cfg, ocfg, model, W, data, *_ = _setup(dev, torch.float32, lens, ulens)
+    model.optimizer["schedule"] = 2e-3
+    losses = []
+    for _ in range(8):
+        losses.append(float(model.train_step(data, masks=(None, None))["loss"].mean()))
+    assert losses[-1] < losses[0]
+    # gradient accumulation: 2 identical micro-batches == 1 step on the same batch (accumulation.py:64-70)
+    m1 = _setup(dev, torch.float32, lens, ulens)[2]
+    m2 = _setup(dev, torch.float32, lens, ulens)[2]
+    for m in (m1, m2):
+        m.optimizer["schedule"] = 1e-3
+    m2.ga_steps = 2
+    m1.train_step(data, masks=(None, None))
+    m2.train_step(data, masks=(None, None))
+    assert m2.step == 0
+    m2.train_step(data, masks=(None, None))
+    assert m2.step == 1
+    a, b = m1.ps.flat.cpu().numpy(), m2.ps.flat.cpu().numpy()
+    np.testing.assert_allclose(a, b, rtol=0, atol=5e-5)

@@ -218,7 +218,7 @@ def test_relattn_softmax(dev, dtype, lens):
     shifted = R.rel_left_shift(positional)[..., -T:]
     # device form: shared projected table + bias row, gathered inside the kernel
     p_ext = torch.cat([torch.einsum("rd,dhe->rhe", table, Wp) + bp, bp[None]], 0)  # [R+1,H,dh]
-    pos = rt(torch.einsum("rhe,bthe->bhtr", p_ext, qv), dtype)  # [B,H,T,R+1]
+    pos = rt(torch.einsum("rhe,bthe->bhtr", p_ext, qv).contiguous(), dtype)  # [B,H,T,R+1]
     cr, pr = content.clone().requires_grad_(True), pos.clone().requires_grad_(True)
     # reference scores built from the same rounded `pos` through the gather identity (checked vs `shifted` below)
     idx = torch.zeros(B, T, T, dtype=torch.long)
