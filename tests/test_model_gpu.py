@@ -19,9 +19,10 @@ def _setup(dev, dtype, lens, ulens, seed=0, N=4000, U=6):
     model = ConformerTransducer(cfg, dev, dtype=dtype, seed=seed)
     model.use_pred_stream = True
     W = R.init_weights(ocfg, seed=seed + 1, scale_bias=0.1)
+    gen = torch.Generator().manual_seed(seed + 7)
     for k in W:  # make BN / LN affine parameters non-trivial
         if k.endswith("/g"):
-            W[k] = W[k] + 0.1 * torch.randn_like(W[k])
+            W[k] = W[k] + 0.1 * torch.randn(W[k].shape, generator=gen)
     model.ps.import_keras(W)
     rng = np.random.default_rng(seed)
     B = len(lens)
@@ -73,15 +74,19 @@ def test_f32_step_matches_oracle(dev, lens, ulens):
     np.testing.assert_allclose(costs.cpu().numpy(), ref_loss, rtol=1e-3)  # BASELINE.json: loss within 1e-3 relative
     mine = model.ps.export_keras(model.ps.grad)
     worst = []
+    gmax = max(float(g.abs().max()) for g in ref_grads.values())
     for k, g in ref_grads.items():
         a, b = mine[k].numpy().reshape(-1), g.numpy().reshape(-1)
-        err = np.abs(a - b).max() / (np.abs(b).max() + 1e-6)
+        # biases feeding a BatchNorm / the k and pos biases have an analytically ZERO gradient (pure rounding noise in
+        # both implementations), so errors are measured against max(|g|, 1e-3 * largest gradient in the model)
+        err = np.abs(a - b).max() / max(np.abs(b).max(), 1e-3 * gmax)
         worst.append((err, k))
     worst.sort(reverse=True)
     assert worst[0][0] < 2e-2, worst[:8]
     # moving statistics updated like keras (momentum .99)
     mm = model.ps.state["enc/block0/conv/bn/mm"].cpu()
-    np.testing.assert_allclose(mm.numpy(), (0.01 * stats["enc/block0/conv/bn"][0]).numpy(), rtol=2e-2, atol=1e-5)
+    # two training-mode forwards ran above: moving = mean * (1 - 0.99^2)
+    np.testing.assert_allclose(mm.numpy(), ((1 - 0.99 ** 2) * stats["enc/block0/conv/bn"][0]).numpy(), rtol=2e-2, atol=1e-5)
     # optimizer --------------------------------------------------------------------------------------
     before = model.ps.export_keras()
     lr = model.apply_gradients()
@@ -122,6 +127,7 @@ def test_train_steps_reduce_loss_and_ga(dev):
     m2 = _setup(dev, torch.float32, lens, ulens)[2]
     for m in (m1, m2):
         m.optimizer["schedule"] = 1e-3
+        m.optimizer["eps"] = 1e-4  # keeps the update of (analytically) zero-gradient variables out of the rounding noise
     m2.ga_steps = 2
     m1.train_step(data, masks=(None, None))
     m2.train_step(data, masks=(None, None))
