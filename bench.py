@@ -1,0 +1,212 @@
+#!/usr/bin/env python
+"""bench.py — audio-hours/sec of one full Conformer-Transducer train step on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run, one rank per GPU)
+
+A "step" = log-mel + SpecAugment + Conformer encoder + LSTM prediction net + joint + RNN-T loss + full backward +
+(RCCL gradient all-reduce) + Adam, on one batch of synthetic 16 kHz utterances already resident in HBM.
+Workload (BASELINE.json metric "audio-hours/sec (train step) Conformer-M RNN-T"): Conformer-M, 32 utterances per GPU
+(weak scaling: global batch = 32 x N), LibriSpeech-shaped durations (lognormal, mean ~12.3 s, clipped to [1.3, 29.7] s,
+~3.7 BPE tokens/s), padded to the batch maximum.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA
+MFMA_F32_PEAK_TFLOPS = 157.3
+
+
+def make_batch(cfg, B, seed, padding, size):
+    """LibriSpeech-shaped synthetic batch: returns host tensors + total audio seconds."""
+    rng = np.random.default_rng(seed)
+    if size == "S-10s":
+        dur = np.full(B, 10.0)
+        ulen = rng.integers(32, 65, B)
+        Umax = 64
+    else:
+        sigma = 0.55
+        dur = np.clip(rng.lognormal(math.log(12.3) - sigma * sigma / 2, sigma, B), 1.3, 29.7)
+        ulen = np.clip(np.round(dur * 3.7), 1, 230).astype(np.int64)
+        Umax = 230 if padding == "reference" else int(ulen.max())
+    nsamp = (dur * 16000).astype(np.int64)
+    N = 475760 if padding == "reference" and size != "S-10s" else int(nsamp.max())
+    sig = np.clip(rng.standard_normal((B, N)).astype(np.float32) * 0.1, -1, 1)
+    for b in range(B):
+        sig[b, nsamp[b]:] = 0.0
+    labels = rng.integers(1, cfg.vocab_size, (B, Umax)).astype(np.int32)
+    for b in range(B):
+        labels[b, ulen[b]:] = 0
+    preds = np.concatenate([np.zeros((B, 1), np.int32), labels], 1)
+    return dict(sig=sig, nsamp=nsamp.astype(np.int32), labels=labels, preds=preds, ulen=ulen.astype(np.int32),
+                seconds=float(nsamp.sum()) / 16000.0)
+
+
+def to_train_data(batch, dev):
+    from tensorflowasr_amd.schemas import TrainData, TrainInput, TrainLabel
+
+    return TrainData(
+        TrainInput(torch.from_numpy(batch["sig"]).to(dev), torch.from_numpy(batch["nsamp"]),
+                   torch.from_numpy(batch["preds"]).to(dev), torch.from_numpy(batch["ulen"] + 1).to(dev)),
+        TrainLabel(torch.from_numpy(batch["labels"]).to(dev), torch.from_numpy(batch["ulen"])))
+
+
+def cpu_baseline(size, vocab, seconds_budget=30.0):
+    """Reference-path stand-in: the oracle's torch-CPU restatement of the same train step (TensorFlow is not
+    installable: BASELINE.md §2), timed on this box's host cores on a bounded sample of the same workload."""
+    from oracle import conformer_ref as R
+    from oracle import rnnt_ref
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    ocfg = R.conformer_config("M" if size.startswith("M") else "S", vocab)
+    W = R.init_weights(ocfg, seed=3)
+    Wg = {k: v.clone().requires_grad_(R.is_trainable(k)) for k, v in W.items()}
+    rng = np.random.default_rng(0)
+    B, secs, U = 2, 6.0, 22
+    N = int(secs * 16000)
+    sig = np.clip(rng.standard_normal((B, N)).astype(np.float32) * 0.1, -1, 1)
+    labels = rng.integers(1, vocab, (B, U)).astype(np.int32)
+    preds = np.concatenate([np.zeros((B, 1), np.int32), labels], 1)
+    state = {k: (torch.zeros_like(v), torch.zeros_like(v)) for k, v in Wg.items() if v.requires_grad}
+
+    def step(i):
+        feat = R.log_mel(sig, ocfg)
+        flen = R.get_nframes([N] * B)
+        logits, elen = R.transducer_forward(torch.from_numpy(feat), flen, torch.from_numpy(preds), torch.tensor([U + 1] * B), Wg, ocfg, training=True)
+        loss, g = rnnt_ref.rnnt_loss_and_grad(logits.detach().numpy(), labels, np.array([U] * B), elen.numpy(), np.float32)
+        logits.backward(torch.from_numpy(g / B))
+        with torch.no_grad():
+            for k, v in Wg.items():
+                if v.grad is None:
+                    continue
+                gk = v.grad + (2e-6 * v if R.is_regularized(k) else 0)
+                p, m, vv = R.adam_step(v, gk, state[k][0], state[k][1], i + 1, 1e-4)
+                v.copy_(p)
+                state[k] = (m, vv)
+                v.grad = None
+        return float(loss.mean())
+
+    step(0)  # warm-up
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        step(n + 1)
+        n += 1
+        if time.perf_counter() - t0 > seconds_budget * 0.5 or n >= 3:
+            break
+    dt = (time.perf_counter() - t0) / n
+    return dict(value=(B * secs / 3600.0) / dt, unit="audio-hours/sec", cores=cores, kind="port",
+                sample=f"oracle (torch-CPU fp32 restatement of tensorflow_asr; TF unavailable) full train step, Conformer-{ocfg['dmodel']}d, "
+                       f"{B} x {secs:.0f} s utterances, U={U}, {n} timed steps, {dt:.2f} s/step")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--model", default="M", choices=["M", "S"])
+    ap.add_argument("--batch", type=int, default=32, help="utterances per GPU")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--padding", default="batch", choices=["batch", "reference"])
+    ap.add_argument("--workload", default=None, help="'S-10s' = BASELINE cfg2 (10 s utterances); default LibriSpeech-shaped")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-specaugment", action="store_true")
+    args = ap.parse_args()
+
+    from tensorflowasr_amd import configs, dp as dpmod
+    from tensorflowasr_amd.conformer import ConformerTransducer
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dp = dpmod.init_from_env() if world > 1 else None
+    rank = dp.rank if dp else 0
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if dp and args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    cfg = configs.conformer_m() if args.model == "M" else configs.conformer_s()
+    if args.no_specaugment:
+        cfg.time_masking, cfg.freq_masking = {}, {}
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    model = ConformerTransducer(cfg, dev, dtype=dtype, seed=0, dp=dp)
+    if dp:
+        dp.attach(model.ps.grad)
+    size = args.workload or ("LibriSpeech-shaped" if args.model == "M" else "S-10s")
+    # a few distinct batches per rank, resident in HBM before the timed region
+    nb = 2
+    batches = [make_batch(cfg, args.batch, seed=10 + 97 * rank + 13 * i, padding=args.padding, size=size) for i in range(nb)]
+    data = [to_train_data(b, dev) for b in batches]
+    model.timers = {}
+
+    def one_step(i):
+        return model.train_step(data[i % nb])
+
+    for i in range(args.warmup):
+        one_step(i)
+    model.timers, model.timer_work = {}, {}
+    torch.cuda.synchronize()
+    if dp:
+        dp.barrier()
+    t0 = time.perf_counter()
+    secs_local = 0.0
+    for i in range(args.steps):
+        one_step(i)
+        secs_local += batches[i % nb]["seconds"]
+    torch.cuda.synchronize()
+    if dp:
+        dp.barrier()
+    dt = time.perf_counter() - t0
+    if dp:
+        dt = dp.max_scalar(dt, dev)
+        secs_total = dp.mean_scalar(torch.tensor([secs_local], dtype=torch.float64, device=dev)).item() * world
+    else:
+        secs_total = secs_local
+    ms_per_step = dt / args.steps * 1e3
+    value = (secs_total / 3600.0) / dt
+
+    if rank == 0:
+        roof = None
+        tm = model.timers.get("joint_vocab_gemm") or []
+        if tm:
+            torch.cuda.synchronize()
+            ms = float(np.mean([a.elapsed_time(b) for a, b in tm]))
+            fl = float(np.mean(model.timer_work["joint_vocab_gemm"]))
+            peak = MFMA_BF16_PEAK_TFLOPS if dtype == torch.bfloat16 else MFMA_F32_PEAK_TFLOPS
+            ach = fl / (ms * 1e-3) / 1e12
+            roof = {"kernel": "gemm_kernel (joint vocab projection, fwd)", "bound": "mfma", "achieved": round(ach, 2), "peak": peak,
+                    "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None, "ms_per_launch": round(ms, 4)}
+        out = {
+            "metric": "audio-hours/sec (train step) Conformer-M RNN-T" if args.model == "M" else "audio-hours/sec (train step) Conformer-S RNN-T",
+            "value": round(value, 4), "unit": "audio-hours/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"Conformer-{args.model} transducer full train step (fwd+RNN-T loss+bwd+Adam), {size} 16 kHz utterances, "
+                                   f"{args.batch}/GPU, padding={args.padding}, SpecAugment {'off' if args.no_specaugment else 'on'}, dropout 0",
+                       "global_batch": args.batch * world, "parallelism": f"dp{world}", "params": model.ps.num_trainable()},
+            "roofline": roof,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            try:
+                out["cpu_baseline"] = cpu_baseline(size if args.model == "S" else "M", cfg.vocab_size)
+            except Exception as e:  # the GPU number must still be reported
+                out["cpu_baseline"] = {"value": None, "error": repr(e)}
+        print(json.dumps(out))
+    if dp:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -64,6 +64,7 @@ class ConformerTransducer:
         self.ga_steps = 1
         self._ga_count = 0
         self.timers = None  # optional dict name -> list[(start_event, end_event)] filled by bench.py
+        self.timer_work = {}
 
     # =================================================================================== constants
     def _frontend_consts(self):
@@ -433,7 +434,9 @@ class ConformerTransducer:
         e = K.matmul(enc, ps.w2d("joint/enc/w"), bias=ps.p("joint/enc/b"))
         p = K.matmul(pred, ps.w2d("joint/pred/w"), bias=ps.p("joint/pred/b"))
         h = K.joint_fwd(e.view(B, T, J), p.view(B, U1, J))
+        t0 = self._tick("joint_vocab_gemm")
         logits = K.matmul(h.view(B * T * U1, J), ps.w2d("joint/vocab/w"), bias=ps.p("joint/vocab/b")).view(B, T, U1, V)
+        self._tock("joint_vocab_gemm", t0, 2.0 * B * T * U1 * J * V)
         if ctx is not None:
             ctx["joint"] = dict(enc=enc, pred=pred, h=h, B=B, T=T, U1=U1)
         return logits
@@ -562,12 +565,13 @@ class ConformerTransducer:
         e.record()
         return e
 
-    def _tock(self, name, start):
+    def _tock(self, name, start, work=0.0):
         if self.timers is None:
             return
         e = torch.cuda.Event(enable_timing=True)
         e.record()
         self.timers.setdefault(name, []).append((start, e))
+        self.timer_work.setdefault(name, []).append(work)
 
 
 def _mel_weight_matrix(num_mel_bins, num_spectrogram_bins, sample_rate, lower, upper):

@@ -1,0 +1,66 @@
+"""CPU, world_size 2, gloo: the data-parallel hooks (bucketed gradient all-reduce over the flat buffer, sync-BN statistic
+sums, metric mean, utterance sharding) behave like a single process on the concatenated batch."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, outdir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from tensorflowasr_amd import dp
+
+    d = dp.init_from_env(backend="gloo")
+    assert d.world == world and d.rank == rank
+    n = 10_000
+    g = torch.Generator().manual_seed(100 + rank)
+    grad = torch.randn(n, generator=g)
+    d.bucket_bytes = 8_000
+    d.attach(grad)
+    # backward announces slices from the end of the buffer towards the front, with gaps
+    d.grads_ready(9000, 10000)
+    d.grads_ready(7000, 9000)
+    d.grads_ready(6500, 7000)
+    d.grads_ready(1000, 3000)
+    d.finish_grads()
+    # sync-BN: x rows sharded; global moments from summed (sum, sumsq)
+    x = torch.arange(40, dtype=torch.float32).view(10, 4) + 100 * rank
+    stats = torch.cat([x.sum(0), (x * x).sum(0)])
+    d.allreduce_stats_(stats)
+    loss = d.mean_scalar(torch.tensor([float(rank + 1)]))
+    lo, hi = dp.shard_bounds(8, world, rank)
+    torch.save(dict(grad=grad, stats=stats, loss=loss, shard=(lo, hi)), os.path.join(outdir, f"r{rank}.pt"))
+    d.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_two_process_gloo(tmp_path):
+    world = 2
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    outs = [torch.load(os.path.join(tmp_path, f"r{r}.pt")) for r in range(world)]
+    want = sum(torch.randn(10_000, generator=torch.Generator().manual_seed(100 + r)) for r in range(world))
+    for o in outs:
+        np.testing.assert_allclose(o["grad"].numpy(), want.numpy(), rtol=1e-6, atol=1e-6)
+    xs = torch.cat([torch.arange(40, dtype=torch.float32).view(10, 4) + 100 * r for r in range(world)])
+    np.testing.assert_allclose(outs[0]["stats"].numpy(), torch.cat([xs.sum(0), (xs * xs).sum(0)]).numpy(), rtol=1e-6)
+    assert float(outs[1]["loss"]) == 1.5
+    assert outs[0]["shard"] == (0, 4) and outs[1]["shard"] == (4, 8)
+
+
+def test_shard_bounds_rejects_ragged():
+    from tensorflowasr_amd import dp
+
+    with pytest.raises(ValueError):
+        dp.shard_bounds(7, 2, 0)
