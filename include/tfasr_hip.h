@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define TFASR_ABI_VERSION 1
+#define TFASR_ABI_VERSION 2
 
 typedef enum {
   TFASR_STATUS_SUCCESS = 0,
@@ -167,13 +167,14 @@ int tfasr_specaugment(void* x, const int32_t* fmask, const int32_t* tmask, int n
 
 /* ------------------------------------------------------------------------------------------------
  * Relative-position attention softmax (multihead_attention.py:543-582, 27-77; positional_encoding.py:152-172)
- *   content [B,H,T,T], pos [B,H,T,2T] (column 2T-1 = bias column), probs [B,H,T,T] (may alias content),
+ *   content [B,H,T,ldc>=T], pos [B,H,T,ldp>=2T] (column 2T-1 = bias column), probs like content (may alias it),
  *   lengths [B] or NULL; use_mask: padded query rows -> uniform.  Backward: dcontent may alias dprobs.
+ *   ldc / ldp are row strides in elements (pad them to a multiple of 8 so the MFMA GEMMs can DMA the rows).
  * ---------------------------------------------------------------------------------------------- */
 int tfasr_relattn_softmax_fwd(const void* content, const void* pos, const int32_t* lengths, void* probs, int B, int H,
-                              int T, int use_mask, int dtype, void* stream);
+                              int T, int ldc, int ldp, int use_mask, int dtype, void* stream);
 int tfasr_relattn_softmax_bwd(const void* probs, const void* dprobs, const int32_t* lengths, void* dcontent, void* dpos,
-                              int B, int H, int T, int use_mask, int dtype, void* stream);
+                              int B, int H, int T, int ldc, int ldp, int use_mask, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * LSTM cell pointwise stages (keras LSTM, gates i,f,c,o; base_transducer.py:71-85,123-159)

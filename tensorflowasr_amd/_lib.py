@@ -103,7 +103,7 @@ def load(build_if_missing=True):
     return lib
 
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 def check(status, what=""):

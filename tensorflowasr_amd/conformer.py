@@ -246,15 +246,16 @@ class ConformerTransducer:
         pext = K.matmul(pe, ps.w2d(pfx + "pos/w"), bias=ps.p(pfx + "pos/b"))  # [2T, HD]
         kk = qkv[:, HD:]
         vv = qkv[:, 2 * HD:]
-        content = torch.empty(B, H, T, T, dtype=self.dtype, device=self.device)
-        K.gemm(qu, kk, content, T, T, dh, HD, 3 * HD, T, trans_b=True, nb1=B, nb2=H, sA=(T * HD, dh), sB=(T * 3 * HD, dh),
-               sD=(H * T * T, T * T), alpha=scale)
-        pos = torch.empty(B, H, T, R1, dtype=self.dtype, device=self.device)
-        K.gemm(qv, pext, pos, T, R1, dh, HD, HD, R1, trans_b=True, nb1=B, nb2=H, sA=(T * HD, dh), sB=(0, dh),
-               sD=(H * T * R1, T * R1), alpha=scale)
-        probs = K.relattn_softmax_fwd(content, pos, elen_dev, use_mask=c.use_attention_auto_mask, probs=content)
+        Tp, R1p = -(-T // 8) * 8, -(-R1 // 8) * 8  # row strides padded to 16 B so the score matrices can be LDS-DMA'd
+        content = torch.empty(B, H, T, Tp, dtype=self.dtype, device=self.device)
+        K.gemm(qu, kk, content, T, T, dh, HD, 3 * HD, Tp, trans_b=True, nb1=B, nb2=H, sA=(T * HD, dh), sB=(T * 3 * HD, dh),
+               sD=(H * T * Tp, T * Tp), alpha=scale)
+        pos = torch.empty(B, H, T, R1p, dtype=self.dtype, device=self.device)
+        K.gemm(qv, pext, pos, T, R1, dh, HD, HD, R1p, trans_b=True, nb1=B, nb2=H, sA=(T * HD, dh), sB=(0, dh),
+               sD=(H * T * R1p, T * R1p), alpha=scale)
+        probs = K.relattn_softmax_fwd(content, pos, elen_dev, T, use_mask=c.use_attention_auto_mask, probs=content)
         att = torch.empty(B * T, HD, dtype=self.dtype, device=self.device)
-        K.gemm(probs, vv, att, T, dh, T, T, 3 * HD, HD, nb1=B, nb2=H, sA=(H * T * T, T * T), sB=(T * 3 * HD, dh), sD=(T * HD, dh))
+        K.gemm(probs, vv, att, T, dh, T, Tp, 3 * HD, HD, nb1=B, nb2=H, sA=(H * T * Tp, T * Tp), sB=(T * 3 * HD, dh), sD=(T * HD, dh))
         y = K.matmul(att, ps.w2d(pfx + "o/w"), bias=ps.p(pfx + "o/b"), res=x, beta=c.mhsam_residual)
         if ctx is not None:
             ctx[pfx] = dict(x=x, ln=ln, mean=mean, rstd=rstd, qkv=qkv, qu=qu, qv=qv, pext=pext, probs=probs, att=att)
@@ -272,25 +273,26 @@ class ConformerTransducer:
         datt = self._dense_bwd(dy, s["att"], pfx + "o/w", pfx + "o/b", alpha=c.mhsam_residual)
         dqkv = torch.empty_like(qkv)
         # dprobs = datt @ v^T
-        dprobs = torch.empty(B, H, T, T, dtype=self.dtype, device=self.device)
-        K.gemm(datt, vv, dprobs, T, T, dh, HD, 3 * HD, T, trans_b=True, nb1=B, nb2=H, sA=(T * HD, dh), sB=(T * 3 * HD, dh),
-               sD=(H * T * T, T * T))
+        Tp, R1p = -(-T // 8) * 8, -(-R1 // 8) * 8
+        dprobs = torch.empty(B, H, T, Tp, dtype=self.dtype, device=self.device)
+        K.gemm(datt, vv, dprobs, T, T, dh, HD, 3 * HD, Tp, trans_b=True, nb1=B, nb2=H, sA=(T * HD, dh), sB=(T * 3 * HD, dh),
+               sD=(H * T * Tp, T * Tp))
         # dv = probs^T @ datt -> v slice of dqkv
-        K.gemm(probs, datt, dqkv[:, 2 * HD:], T, dh, T, T, HD, 3 * HD, trans_a=True, nb1=B, nb2=H, sA=(H * T * T, T * T),
+        K.gemm(probs, datt, dqkv[:, 2 * HD:], T, dh, T, Tp, HD, 3 * HD, trans_a=True, nb1=B, nb2=H, sA=(H * T * Tp, T * Tp),
                sB=(T * HD, dh), sD=(T * 3 * HD, dh))
-        dcontent, dpos = K.relattn_softmax_bwd(probs, dprobs, elen_dev, use_mask=c.use_attention_auto_mask, dcontent=dprobs)
+        dcontent, dpos = K.relattn_softmax_bwd(probs, dprobs, elen_dev, T, R1p, use_mask=c.use_attention_auto_mask, dcontent=dprobs)
         # dqu = scale * dcontent @ k ; dk = scale * dcontent^T @ qu
         dqu = torch.empty(B * T, HD, dtype=self.dtype, device=self.device)
-        K.gemm(dcontent, kk, dqu, T, dh, T, T, 3 * HD, HD, nb1=B, nb2=H, sA=(H * T * T, T * T), sB=(T * 3 * HD, dh),
+        K.gemm(dcontent, kk, dqu, T, dh, T, Tp, 3 * HD, HD, nb1=B, nb2=H, sA=(H * T * Tp, T * Tp), sB=(T * 3 * HD, dh),
                sD=(T * HD, dh), alpha=scale)
-        K.gemm(dcontent, s["qu"], dqkv[:, HD:], T, dh, T, T, HD, 3 * HD, trans_a=True, nb1=B, nb2=H, sA=(H * T * T, T * T),
+        K.gemm(dcontent, s["qu"], dqkv[:, HD:], T, dh, T, Tp, HD, 3 * HD, trans_a=True, nb1=B, nb2=H, sA=(H * T * Tp, T * Tp),
                sB=(T * HD, dh), sD=(T * 3 * HD, dh), alpha=scale)
         # dqv = scale * dpos @ pext ; dpext += scale * sum_b dpos^T @ qv
         dqv = torch.empty(B * T, HD, dtype=self.dtype, device=self.device)
-        K.gemm(dpos, s["pext"], dqv, T, dh, R1, R1, HD, HD, nb1=B, nb2=H, sA=(H * T * R1, T * R1), sB=(0, dh), sD=(T * HD, dh),
+        K.gemm(dpos, s["pext"], dqv, T, dh, R1, R1p, HD, HD, nb1=B, nb2=H, sA=(H * T * R1p, T * R1p), sB=(0, dh), sD=(T * HD, dh),
                alpha=scale)
         dpext = torch.zeros(R1, HD, dtype=torch.float32, device=self.device)
-        K.gemm(dpos, s["qv"], dpext, R1, dh, T, R1, HD, HD, trans_a=True, nb1=B, nb2=H, sA=(H * T * R1, T * R1), sB=(T * HD, dh),
+        K.gemm(dpos, s["qv"], dpext, R1, dh, T, R1p, HD, HD, trans_a=True, nb1=B, nb2=H, sA=(H * T * R1p, T * R1p), sB=(T * HD, dh),
                sD=(0, dh), alpha=scale, accumulate=True)
         K.bias2_bwd(dqu, dqv, dqkv, 3 * HD, ps.g("enc/u"), ps.g("enc/v"), B * T, HD)
         # positional projection: gWpos += pe^T dpext ; gbpos += colsum(dpext)

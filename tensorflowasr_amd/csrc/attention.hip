@@ -31,9 +31,9 @@ __device__ __forceinline__ int pos_col(int i, int j, int T, int R, int len) {
 template <typename T_>
 __global__ __launch_bounds__(256) void relattn_softmax_fwd_kernel(const T_* content, const T_* __restrict__ pos,
                                                                   const int32_t* __restrict__ lengths, T_* probs, int B,
-                                                                  int H, int T, int use_mask) {
+                                                                  int H, int T, int ldc, int ldp, int use_mask) {
   const int lane = threadIdx.x & 63;
-  const int R = 2 * T - 1, R1 = R + 1;
+  const int R = 2 * T - 1;
   const long nrows = (long)B * H * T;
   const long w0 = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const long nw = (long)gridDim.x * (blockDim.x >> 6);
@@ -41,14 +41,14 @@ __global__ __launch_bounds__(256) void relattn_softmax_fwd_kernel(const T_* cont
     const int i = (int)(row % T);
     const int b = (int)(row / ((long)H * T));
     const int len = lengths ? min(lengths[b], T) : T;
-    T_* out = probs + row * T;
+    T_* out = probs + row * ldc;
     if (use_mask && i >= len) {  // masked query row: every score == -1e9 -> uniform
       const float uval = 1.f / T;
       for (int j = lane; j < T; j += 64) Num<T_>::st(out + j, uval);
       continue;
     }
-    const T_* crow = content + row * T;
-    const T_* prow = pos + row * R1;
+    const T_* crow = content + row * ldc;
+    const T_* prow = pos + row * ldp;
     float s[MAXJ];
     float mx = -INFINITY;
     int n = 0;
@@ -71,7 +71,7 @@ template <typename T_>
 __global__ __launch_bounds__(256) void relattn_softmax_bwd_kernel(const T_* __restrict__ probs, const T_* dprobs,
                                                                   const int32_t* __restrict__ lengths, T_* dcontent,
                                                                   T_* __restrict__ dpos, int B, int H, int T,
-                                                                  int use_mask) {
+                                                                  int ldc, int ldp, int use_mask) {
   extern __shared__ float sh[];  // 4 waves * T floats
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   float* ds = sh + (long)w * T;
@@ -83,15 +83,15 @@ __global__ __launch_bounds__(256) void relattn_softmax_bwd_kernel(const T_* __re
     const int i = (int)(row % T);
     const int b = (int)(row / ((long)H * T));
     const int len = lengths ? min(lengths[b], T) : T;
-    T_* dc = dcontent + row * T;
-    T_* dp = dpos + row * R1;
+    T_* dc = dcontent + row * ldc;
+    T_* dp = dpos + row * ldp;
     if (use_mask && i >= len) {  // constant scores: zero gradient
       for (int j = lane; j < T; j += 64) Num<T_>::st(dc + j, 0.f);
-      for (int r = lane; r < R1; r += 64) Num<T_>::st(dp + r, 0.f);
+      for (int r = lane; r < ldp; r += 64) Num<T_>::st(dp + r, 0.f);
       continue;
     }
-    const T_* p = probs + row * T;
-    const T_* d = dprobs + row * T;
+    const T_* p = probs + row * ldc;
+    const T_* d = dprobs + row * ldc;
     float pv[MAXJ], dv[MAXJ];
     float dot = 0.f;
     int n = 0;
@@ -125,6 +125,7 @@ __global__ __launch_bounds__(256) void relattn_softmax_bwd_kernel(const T_* __re
       Num<T_>::st(dp + rr, g);
     }
     if (lane == 0) Num<T_>::st(dp + R, left);
+    for (int r = R1 + lane; r < ldp; r += 64) Num<T_>::st(dp + r, 0.f);  // keep the row padding finite
     __builtin_amdgcn_s_waitcnt(0xc07f);
   }
 }
@@ -134,34 +135,34 @@ inline int rows_grid(long rows) { return (int)std::max<long>(1, std::min<long>((
 }  // namespace
 
 extern "C" int tfasr_relattn_softmax_fwd(const void* content, const void* pos, const int32_t* lengths, void* probs,
-                                         int B, int H, int T, int use_mask, int dtype, void* stream_) {
-  if (!content || !pos || !probs || B <= 0 || H <= 0 || T <= 0 || T > 64 * MAXJ) return TFASR_STATUS_INVALID_VALUE;
+                                         int B, int H, int T, int ldc, int ldp, int use_mask, int dtype, void* stream_) {
+  if (!content || !pos || !probs || B <= 0 || H <= 0 || T <= 0 || T > 64 * MAXJ || ldc < T || ldp < 2 * T) return TFASR_STATUS_INVALID_VALUE;
   hipStream_t s = (hipStream_t)stream_;
   const int grid = rows_grid((long)B * H * T);
   if (dtype == TFASR_F32)
     hipLaunchKernelGGL(relattn_softmax_fwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)content,
-                       (const float*)pos, lengths, (float*)probs, B, H, T, use_mask);
+                       (const float*)pos, lengths, (float*)probs, B, H, T, ldc, ldp, use_mask);
   else if (dtype == TFASR_BF16)
     hipLaunchKernelGGL(relattn_softmax_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)content,
-                       (const bf16_t*)pos, lengths, (bf16_t*)probs, B, H, T, use_mask);
+                       (const bf16_t*)pos, lengths, (bf16_t*)probs, B, H, T, ldc, ldp, use_mask);
   else return TFASR_STATUS_INVALID_VALUE;
   TFASR_CHECK_LAUNCH();
   return TFASR_STATUS_SUCCESS;
 }
 
 extern "C" int tfasr_relattn_softmax_bwd(const void* probs, const void* dprobs, const int32_t* lengths, void* dcontent,
-                                         void* dpos, int B, int H, int T, int use_mask, int dtype, void* stream_) {
-  if (!probs || !dprobs || !dcontent || !dpos || B <= 0 || H <= 0 || T <= 0 || T > 64 * MAXJ)
+                                         void* dpos, int B, int H, int T, int ldc, int ldp, int use_mask, int dtype, void* stream_) {
+  if (!probs || !dprobs || !dcontent || !dpos || B <= 0 || H <= 0 || T <= 0 || T > 64 * MAXJ || ldc < T || ldp < 2 * T)
     return TFASR_STATUS_INVALID_VALUE;
   hipStream_t s = (hipStream_t)stream_;
   const int grid = rows_grid((long)B * H * T);
   const size_t shmem = 4 * (size_t)T * sizeof(float);
   if (dtype == TFASR_F32)
     hipLaunchKernelGGL(relattn_softmax_bwd_kernel<float>, dim3(grid), dim3(256), shmem, s, (const float*)probs,
-                       (const float*)dprobs, lengths, (float*)dcontent, (float*)dpos, B, H, T, use_mask);
+                       (const float*)dprobs, lengths, (float*)dcontent, (float*)dpos, B, H, T, ldc, ldp, use_mask);
   else if (dtype == TFASR_BF16)
     hipLaunchKernelGGL(relattn_softmax_bwd_kernel<bf16_t>, dim3(grid), dim3(256), shmem, s, (const bf16_t*)probs,
-                       (const bf16_t*)dprobs, lengths, (bf16_t*)dcontent, (bf16_t*)dpos, B, H, T, use_mask);
+                       (const bf16_t*)dprobs, lengths, (bf16_t*)dcontent, (bf16_t*)dpos, B, H, T, ldc, ldp, use_mask);
   else return TFASR_STATUS_INVALID_VALUE;
   TFASR_CHECK_LAUNCH();
   return TFASR_STATUS_SUCCESS;

@@ -10,6 +10,7 @@
 //   f32  : __builtin_amdgcn_mfma_f32_16x16x4f32      (exact f32, 157 TFLOP/s)  -- the parity mode
 // C/D fragment map (both): col = lane & 15, row = (lane >> 4) * 4 + reg.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -233,12 +234,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(const tfasr_gemm_args p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int col = n0 + wn * 64 + j * 16 + r;
-      if (col >= p.N) continue;
-      const float bias = (p.bias && first_split) ? p.bias[col] : 0.f;
+      const bool col_ok = col < p.N;
+      const float bias = (p.bias && first_split && col_ok) ? p.bias[col] : 0.f;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int row = m0 + wm * 64 + i * 16 + g * 4 + e;
-        if (row >= p.M) continue;
+        if (col_ok && row < p.M) {
         const long idx = (long)row * p.ldd + col;
         float v = p.alpha * acc[i][j][e] + bias;
         if (prez) Num<T>::st(prez + idx, v);
@@ -250,6 +251,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const tfasr_gemm_args p) {
           else Df[idx] = v;
         } else {
           Num<T>::st(Dt + idx, v);
+        }
         }
       }
     }
@@ -275,6 +277,14 @@ int launch(const tfasr_gemm_args& a, hipStream_t stream) {
 
 }  // namespace
 
+int tfasr_gemm_fast_try(const tfasr_gemm_args& a, hipStream_t stream);  // gemm_fast.hip
+
+static bool use_fast_path() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("TFASR_GEMM_SLOW"); v = (e && e[0] == '1') ? 0 : 1; }
+  return v == 1;
+}
+
 extern "C" int tfasr_gemm(const tfasr_gemm_args* args, void* stream_) {
   if (!args || !args->A || !args->B || !args->D) return TFASR_STATUS_INVALID_VALUE;
   tfasr_gemm_args a = *args;
@@ -286,6 +296,10 @@ extern "C" int tfasr_gemm(const tfasr_gemm_args* args, void* stream_) {
   if (a.split_k > 1 && !a.accumulate) return TFASR_STATUS_INVALID_VALUE;
   if (a.split_k > 1 && (a.res || a.dact_z || a.prez || a.act != TFASR_ACT_NONE)) return TFASR_STATUS_INVALID_VALUE;
   hipStream_t stream = (hipStream_t)stream_;
+  if (a.dtype == TFASR_BF16 && use_fast_path()) {
+    const int st = tfasr_gemm_fast_try(a, stream);
+    if (st != TFASR_STATUS_UNSUPPORTED) return st;
+  }
   if (a.dtype == TFASR_BF16) return launch<bf16_t>(a, stream);
   if (a.dtype == TFASR_F32) return launch<float>(a, stream);
   return TFASR_STATUS_INVALID_VALUE;

@@ -7,6 +7,7 @@
 // row (LayerNorm) or lanes-own-columns accumulation with one f32 atomic per column per wave
 // (BatchNorm statistics, gamma/beta gradients).
 #include "common.h"
+#include <algorithm>
 
 namespace {
 
@@ -77,10 +78,15 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
       Num<T>::st(dx + r * C + c, v);
     }
   }
+  // block-level reduction of the per-wave column sums, then ONE atomic per column per block
+  __shared__ float red[2][4][64 * MAXC_PER_LANE];
+  const int w = threadIdx.x >> 6;
   int n = 0;
-  for (int c = lane; c < C; c += 64, ++n) {
-    if (dgamma) atomicAdd(dgamma + c, ag[n]);
-    if (dbeta) atomicAdd(dbeta + c, ab[n]);
+  for (int c = lane; c < C; c += 64, ++n) { red[0][w][c] = ag[n]; red[1][w][c] = ab[n]; }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    if (dgamma) atomicAdd(dgamma + c, red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
+    if (dbeta) atomicAdd(dbeta + c, red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
   }
 }
 
@@ -115,8 +121,15 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, 
       }
     }
   }
+  __shared__ float red[2][4][64 * MAXC_PER_LANE];
+  const int w = threadIdx.x >> 6;
   int n = 0;
-  for (int c = lane; c < C; c += 64, ++n) { atomicAdd(stats + c, a0[n]); atomicAdd(stats + C + c, a1[n]); }
+  for (int c = lane; c < C; c += 64, ++n) { red[0][w][c] = a0[n]; red[1][w][c] = a1[n]; }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    atomicAdd(stats + c, red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
+    atomicAdd(stats + C + c, red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
+  }
 }
 
 // fin[0:C]=mean, [C:2C]=rstd, [2C:3C]=scale=gamma*rstd, [3C:4C]=shift=beta-mean*scale; moving stats updated
@@ -213,7 +226,7 @@ extern "C" int tfasr_layernorm_bwd(const void* dy, const void* x, const float* g
   if (!dy || !x || !gamma || !mean || !rstd || !dx || rows <= 0 || C <= 0 || C > 64 * MAXC_PER_LANE)
     return TFASR_STATUS_INVALID_VALUE;
   hipStream_t s = (hipStream_t)stream_;
-  const int grid = (int)std::min<long>((rows + 3) / 4, 512L);
+  const int grid = (int)std::min<long>((rows + 3) / 4, 256L);
   if (dtype == TFASR_F32)
     hipLaunchKernelGGL(ln_bwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)dy, (const float*)x, gamma, mean,
                        rstd, (const float*)add, (float*)dx, dgamma, dbeta, rows, C);

@@ -277,21 +277,23 @@ def specaugment(x, fmask, tmask, mask_value=0.0):
 
 
 # --------------------------------------------------------------------------------- attention
-def relattn_softmax_fwd(content, pos, lengths, use_mask=True, probs=None):
-    B, H, T, _ = content.shape
+def relattn_softmax_fwd(content, pos, lengths, T, use_mask=True, probs=None):
+    """content [B,H,T,ldc], pos [B,H,T,ldp] (row strides may be padded)."""
+    B, H, _, ldc = content.shape
+    ldp = pos.shape[3]
     if probs is None:
         probs = torch.empty_like(content)
-    check(_L().tfasr_relattn_softmax_fwd(_p(content), _p(pos), _p(lengths), _p(probs), B, H, T, int(use_mask), _dt(content), _stream()), "relattn_softmax_fwd")
+    check(_L().tfasr_relattn_softmax_fwd(_p(content), _p(pos), _p(lengths), _p(probs), B, H, T, ldc, ldp, int(use_mask), _dt(content), _stream()), "relattn_softmax_fwd")
     return probs
 
 
-def relattn_softmax_bwd(probs, dprobs, lengths, use_mask=True, dcontent=None, dpos=None):
-    B, H, T, _ = probs.shape
+def relattn_softmax_bwd(probs, dprobs, lengths, T, ldp, use_mask=True, dcontent=None, dpos=None):
+    B, H, _, ldc = probs.shape
     if dcontent is None:
         dcontent = torch.empty_like(probs)
     if dpos is None:
-        dpos = torch.empty(B, H, T, 2 * T, dtype=probs.dtype, device=probs.device)
-    check(_L().tfasr_relattn_softmax_bwd(_p(probs), _p(dprobs), _p(lengths), _p(dcontent), _p(dpos), B, H, T, int(use_mask), _dt(probs), _stream()), "relattn_softmax_bwd")
+        dpos = torch.empty(B, H, T, ldp, dtype=probs.dtype, device=probs.device)
+    check(_L().tfasr_relattn_softmax_bwd(_p(probs), _p(dprobs), _p(lengths), _p(dcontent), _p(dpos), B, H, T, ldc, ldp, int(use_mask), _dt(probs), _stream()), "relattn_softmax_bwd")
     return dcontent, dpos
 
 

@@ -236,9 +236,9 @@ def test_relattn_softmax(dev, dtype, lens):
     dP = rt(torch.randn(B, H, T, T, generator=g), dtype)
     probs_r.backward(dP)
     ln = torch.tensor(lens, dtype=torch.int32, device=dev)
-    probs = K.relattn_softmax_fwd(content.to(dev).to(dtype), pos.to(dev).to(dtype), ln)
+    probs = K.relattn_softmax_fwd(content.to(dev).to(dtype), pos.to(dev).to(dtype), ln, T)
     cmp(probs, probs_r.detach(), **tol(dtype, (1e-4, 1e-6), (2e-2, 4e-3)))
-    dc, dpos = K.relattn_softmax_bwd(probs_r.detach().to(dev).to(dtype), dP.to(dev).to(dtype), ln)
+    dc, dpos = K.relattn_softmax_bwd(probs_r.detach().to(dev).to(dtype), dP.to(dev).to(dtype), ln, T, 2 * T)
     cmp(dc, cr.grad, **tol(dtype, (1e-4, 1e-6), (3e-2, 1e-2)))
     cmp(dpos, pr.grad, **tol(dtype, (1e-4, 1e-6), (3e-2, 1e-2)))
 
