@@ -41,6 +41,33 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, lo
   if (w == 0 && c < C) atomicAdd(out + c, scale * (red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]));
 }
 
+// 16-B variant: 32 lanes x 8 columns = 256 columns per block.y, 8 rows per block iteration, LDS reduction, 1 atomic/column/block
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_vec_kernel(const T* __restrict__ x, long ld, float* __restrict__ out,
+                                                         long rows, int C, float scale) {
+  __shared__ float red[8][256];
+  const int lane = threadIdx.x & 63, li = lane & 31, sub = lane >> 5, w = threadIdx.x >> 6;
+  const int c0 = blockIdx.y * 256 + li * 8;
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (c0 < C)
+    for (long r = (long)blockIdx.x * 8 + w * 2 + sub; r < rows; r += (long)gridDim.x * 8) {
+      float v[8];
+      ld8(x + r * ld + c0, v);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc[k] += v[k];
+    }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) red[w * 2 + sub][li * 8 + k] = acc[k];
+  __syncthreads();
+  const int c = blockIdx.y * 256 + threadIdx.x;
+  if (c < C) {
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) s += red[q][threadIdx.x];
+    atomicAdd(out + c, scale * s);
+  }
+}
+
 // ----------------------------------------------------------------------------------------- GLU
 template <typename T>
 __global__ __launch_bounds__(256) void glu_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, long rows, int C) {
@@ -377,6 +404,12 @@ extern "C" int tfasr_cast(const void* src, void* dst, long n, int src_dtype, int
 extern "C" int tfasr_colsum(const void* x, long ld, float* out, long rows, int C, float scale, int dtype, void* stream_) {
   if (!x || !out || rows <= 0 || C <= 0) return TFASR_STATUS_INVALID_VALUE;
   hipStream_t s = (hipStream_t)stream_;
+  if (dtype == TFASR_BF16 && (C % 8) == 0 && (ld % 8) == 0 && ((((uintptr_t)x) & 15) == 0)) {
+    dim3 gridv((int)std::max<long>(1, std::min<long>(rows / 64 + 1, 512)), (C + 255) / 256);
+    hipLaunchKernelGGL(colsum_vec_kernel<bf16_t>, gridv, dim3(256), 0, s, (const bf16_t*)x, ld, out, rows, C, scale);
+    TFASR_CHECK_LAUNCH();
+    return TFASR_STATUS_SUCCESS;
+  }
   const int gx = (int)std::max<long>(1, std::min<long>(rows / 64 + 1, 256));
   dim3 grid(gx, (C + 63) / 64);
   DISPATCH_T(dtype,

@@ -164,11 +164,13 @@ __global__ __launch_bounds__(256) void bn_apply_fwd_kernel(const T* __restrict__
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
     const long e = i * 8;
     const int c = (int)(e % C);
-    float v[8];
+    float v[8], sc[8], sh[8];
     ld8(x + e, v);
+    ld8(fin + 2 * C + c, sc);
+    ld8(fin + 3 * C + c, sh);
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      float z = v[k] * fin[2 * C + c + k] + fin[3 * C + c + k];
+      float z = v[k] * sc[k] + sh[k];
       if (act == TFASR_ACT_SWISH) z = swishf_(z);
       v[k] = z;
     }
@@ -185,19 +187,171 @@ __global__ __launch_bounds__(256) void bn_apply_bwd_kernel(const T* __restrict__
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
     const long e = i * 8;
     const int c = (int)(e % C);
-    float xv[8], d[8];
+    float xv[8], d[8], mean[8], rstd[8], sc[8], sh[8], s0[8], s1[8];
     ld8(x + e, xv);
     ld8(dy + e, d);
+    ld8(fin + c, mean); ld8(fin + C + c, rstd); ld8(fin + 2 * C + c, sc); ld8(fin + 3 * C + c, sh);
+    ld8(bstats + c, s0); ld8(bstats + C + c, s1);
+    const float inv = 1.f / count;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      const int cc = c + k;
-      const float sc = fin[2 * C + cc];
       float dz = d[k];
-      if (act == TFASR_ACT_SWISH) dz *= dswishf_(xv[k] * sc + fin[3 * C + cc]);
-      const float xh = (xv[k] - fin[cc]) * fin[C + cc];
-      d[k] = sc * (dz - bstats[cc] / count - xh * bstats[C + cc] / count);
+      if (act == TFASR_ACT_SWISH) dz *= dswishf_(xv[k] * sc[k] + sh[k]);
+      const float xh = (xv[k] - mean[k]) * rstd[k];
+      d[k] = sc[k] * (dz - s0[k] * inv - xh * s1[k] * inv);
     }
     st8(dx + e, d);
+  }
+}
+
+
+// ------------------------------------------------------------------------- vec8 variants (C % 8 == 0, C <= 512)
+// LPR lanes cover one row with 16-B accesses (8 channels per lane); 64/LPR rows per wave iteration.
+template <int LPR> __device__ __forceinline__ float seg_sum(float v) {
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+template <typename T, int LPR>
+__global__ __launch_bounds__(256) void ln_fwd_vec_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, T* __restrict__ y,
+                                                         float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                         long rows, int C, float eps) {
+  constexpr int RPW = 64 / LPR;
+  const int lane = threadIdx.x & 63, li = lane % LPR, sub = lane / LPR;
+  const int c0 = li * 8;
+  const bool act = c0 < C;
+  float g[8], b[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { g[k] = act ? gamma[c0 + k] : 0.f; b[k] = act ? beta[c0 + k] : 0.f; }
+  const long w0 = ((long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * RPW + sub;
+  const long step = (long)gridDim.x * (blockDim.x >> 6) * RPW;
+  const float invC = 1.f / C;
+  for (long r = w0; r < rows; r += step) {  // shuffles stay inside one LPR-lane segment (= one row)
+    const bool rv = true;
+    float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (rv && act) ld8(x + r * C + c0, v);
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s += v[k];
+    const float mean = seg_sum<LPR>(s) * invC;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { const float d = act ? v[k] - mean : 0.f; q += d * d; }
+    const float rstd = rsqrtf(seg_sum<LPR>(q) * invC + eps);
+    if (rv && act) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = (v[k] - mean) * rstd * g[k] + b[k];
+      st8(y + r * C + c0, v);
+    }
+    if (rv && li == 0) { if (mean_out) mean_out[r] = mean; if (rstd_out) rstd_out[r] = rstd; }
+  }
+}
+
+template <typename T, int LPR>
+__global__ __launch_bounds__(256) void ln_bwd_vec_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                         const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                         const float* __restrict__ rstd, const T* add, T* dx,
+                                                         float* __restrict__ dgamma, float* __restrict__ dbeta, long rows,
+                                                         int C) {
+  constexpr int RPW = 64 / LPR;
+  __shared__ float red[2][4 * RPW][LPR * 8];
+  const int lane = threadIdx.x & 63, li = lane % LPR, sub = lane / LPR, w = threadIdx.x >> 6;
+  const int c0 = li * 8;
+  const bool act = c0 < C;
+  float g[8], ag[8], ab[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { g[k] = act ? gamma[c0 + k] : 0.f; ag[k] = 0.f; ab[k] = 0.f; }
+  const long w0 = ((long)blockIdx.x * (blockDim.x >> 6) + w) * RPW + sub;
+  const long step = (long)gridDim.x * (blockDim.x >> 6) * RPW;
+  const float invC = 1.f / C;
+  for (long r = w0; r < rows; r += step) {
+    const bool rv = act;
+    float d[8] = {0, 0, 0, 0, 0, 0, 0, 0}, xv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    float m = 0.f, rs = 0.f;
+    if (rv) { ld8(dy + r * C + c0, d); ld8(x + r * C + c0, xv); m = mean[r]; rs = rstd[r]; }
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      xv[k] = (xv[k] - m) * rs;        // xhat
+      const float dg = d[k] * g[k];
+      s1 += dg;
+      s2 += dg * xv[k];
+      ag[k] += d[k] * xv[k];
+      ab[k] += d[k];
+    }
+    s1 = seg_sum<LPR>(s1) * invC;
+    s2 = seg_sum<LPR>(s2) * invC;
+    if (rv) {
+      float o[8];
+      if (add) ld8(add + r * C + c0, o);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float t = rs * (d[k] * g[k] - s1 - xv[k] * s2);
+        o[k] = add ? o[k] + t : t;
+      }
+      st8(dx + r * C + c0, o);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { red[0][w * RPW + sub][c0 + k] = ag[k]; red[1][w * RPW + sub][c0 + k] = ab[k]; }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float sg = 0.f, sb = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4 * RPW; ++q) { sg += red[0][q][c]; sb += red[1][q][c]; }
+    if (dgamma) atomicAdd(dgamma + c, sg);
+    if (dbeta) atomicAdd(dbeta + c, sb);
+  }
+}
+
+template <typename T, int MODE, int LPR>
+__global__ __launch_bounds__(256) void bn_stats_vec_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                           const float* __restrict__ fin, float* __restrict__ stats,
+                                                           long rows, int C, int act_kind) {
+  constexpr int RPW = 64 / LPR;
+  __shared__ float red[2][4 * RPW][LPR * 8];
+  const int lane = threadIdx.x & 63, li = lane % LPR, sub = lane / LPR, w = threadIdx.x >> 6;
+  const int c0 = li * 8;
+  const bool act = c0 < C;
+  float a0[8], a1[8], mean[8], rstd[8], sc[8], sh[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    a0[k] = 0.f; a1[k] = 0.f;
+    if (MODE == 1 && act) { mean[k] = fin[c0 + k]; rstd[k] = fin[C + c0 + k]; sc[k] = fin[2 * C + c0 + k]; sh[k] = fin[3 * C + c0 + k]; }
+    else { mean[k] = 0.f; rstd[k] = 0.f; sc[k] = 0.f; sh[k] = 0.f; }
+  }
+  const long w0 = ((long)blockIdx.x * (blockDim.x >> 6) + w) * RPW + sub;
+  const long step = (long)gridDim.x * (blockDim.x >> 6) * RPW;
+  if (act)
+    for (long r = w0; r < rows; r += step) {
+      float xv[8];
+      ld8(x + r * C + c0, xv);
+      if (MODE == 0) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { a0[k] += xv[k]; a1[k] += xv[k] * xv[k]; }
+      } else {
+        float d[8];
+        ld8(dy + r * C + c0, d);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          float dz = d[k];
+          if (act_kind == TFASR_ACT_SWISH) dz *= dswishf_(xv[k] * sc[k] + sh[k]);
+          a0[k] += dz;
+          a1[k] += dz * (xv[k] - mean[k]) * rstd[k];
+        }
+      }
+    }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { red[0][w * RPW + sub][c0 + k] = a0[k]; red[1][w * RPW + sub][c0 + k] = a1[k]; }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4 * RPW; ++q) { s0 += red[0][q][c]; s1 += red[1][q][c]; }
+    atomicAdd(stats + c, s0);
+    atomicAdd(stats + C + c, s1);
   }
 }
 
@@ -210,6 +364,17 @@ extern "C" int tfasr_layernorm_fwd(const void* x, const float* gamma, const floa
                                    float* rstd, long rows, int C, float eps, int dtype, void* stream_) {
   if (!x || !gamma || !beta || !y || rows <= 0 || C <= 0 || C > 64 * MAXC_PER_LANE) return TFASR_STATUS_INVALID_VALUE;
   hipStream_t s = (hipStream_t)stream_;
+  if (dtype == TFASR_BF16 && (C % 8) == 0 && C <= 512) {
+    if (C <= 256) {
+      const int grid = (int)std::min<long>((rows + 7) / 8, 2048L);
+      hipLaunchKernelGGL((ln_fwd_vec_kernel<bf16_t, 32>), dim3(grid), dim3(256), 0, s, (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, rows, C, eps);
+    } else {
+      const int grid = (int)std::min<long>((rows + 3) / 4, 2048L);
+      hipLaunchKernelGGL((ln_fwd_vec_kernel<bf16_t, 64>), dim3(grid), dim3(256), 0, s, (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, rows, C, eps);
+    }
+    TFASR_CHECK_LAUNCH();
+    return TFASR_STATUS_SUCCESS;
+  }
   if (dtype == TFASR_F32)
     hipLaunchKernelGGL(ln_fwd_kernel<float>, dim3(rows_grid(rows)), dim3(256), 0, s, (const float*)x, gamma, beta,
                        (float*)y, mean, rstd, rows, C, eps);
@@ -226,6 +391,17 @@ extern "C" int tfasr_layernorm_bwd(const void* dy, const void* x, const float* g
   if (!dy || !x || !gamma || !mean || !rstd || !dx || rows <= 0 || C <= 0 || C > 64 * MAXC_PER_LANE)
     return TFASR_STATUS_INVALID_VALUE;
   hipStream_t s = (hipStream_t)stream_;
+  if (dtype == TFASR_BF16 && (C % 8) == 0 && C <= 512) {
+    if (C <= 256) {
+      const int grid = (int)std::min<long>((rows + 7) / 8, 512L);
+      hipLaunchKernelGGL((ln_bwd_vec_kernel<bf16_t, 32>), dim3(grid), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x, gamma, mean, rstd, (const bf16_t*)add, (bf16_t*)dx, dgamma, dbeta, rows, C);
+    } else {
+      const int grid = (int)std::min<long>((rows + 3) / 4, 512L);
+      hipLaunchKernelGGL((ln_bwd_vec_kernel<bf16_t, 64>), dim3(grid), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x, gamma, mean, rstd, (const bf16_t*)add, (bf16_t*)dx, dgamma, dbeta, rows, C);
+    }
+    TFASR_CHECK_LAUNCH();
+    return TFASR_STATUS_SUCCESS;
+  }
   const int grid = (int)std::min<long>((rows + 3) / 4, 256L);
   if (dtype == TFASR_F32)
     hipLaunchKernelGGL(ln_bwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)dy, (const float*)x, gamma, mean,
@@ -240,6 +416,12 @@ extern "C" int tfasr_layernorm_bwd(const void* dy, const void* x, const float* g
 extern "C" int tfasr_bn_stats(const void* x, float* stats, long rows, int C, int dtype, void* stream_) {
   if (!x || !stats || rows <= 0 || C <= 0 || C > 64 * MAXC_PER_LANE) return TFASR_STATUS_INVALID_VALUE;
   hipStream_t s = (hipStream_t)stream_;
+  if (dtype == TFASR_BF16 && (C % 8) == 0 && C <= 512) {
+    if (C <= 256) hipLaunchKernelGGL((bn_stats_vec_kernel<bf16_t, 0, 32>), dim3((int)std::min<long>((rows + 7) / 8, 2048L)), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)nullptr, (const float*)nullptr, stats, rows, C, 0);
+    else hipLaunchKernelGGL((bn_stats_vec_kernel<bf16_t, 0, 64>), dim3((int)std::min<long>((rows + 3) / 4, 2048L)), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)nullptr, (const float*)nullptr, stats, rows, C, 0);
+    TFASR_CHECK_LAUNCH();
+    return TFASR_STATUS_SUCCESS;
+  }
   const int grid = (int)std::min<long>((rows + 3) / 4, 1024L);
   if (dtype == TFASR_F32)
     hipLaunchKernelGGL((bn_stats_kernel<float, 0>), dim3(grid), dim3(256), 0, s, (const float*)x, (const float*)nullptr,
@@ -282,6 +464,12 @@ extern "C" int tfasr_bn_bwd_stats(const void* x, const void* dy, const float* fi
                                   int act, int dtype, void* stream_) {
   if (!x || !dy || !fin || !bstats || rows <= 0 || C <= 0 || C > 64 * MAXC_PER_LANE) return TFASR_STATUS_INVALID_VALUE;
   hipStream_t s = (hipStream_t)stream_;
+  if (dtype == TFASR_BF16 && (C % 8) == 0 && C <= 512) {
+    if (C <= 256) hipLaunchKernelGGL((bn_stats_vec_kernel<bf16_t, 1, 32>), dim3((int)std::min<long>((rows + 7) / 8, 2048L)), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)dy, fin, bstats, rows, C, act);
+    else hipLaunchKernelGGL((bn_stats_vec_kernel<bf16_t, 1, 64>), dim3((int)std::min<long>((rows + 3) / 4, 2048L)), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)dy, fin, bstats, rows, C, act);
+    TFASR_CHECK_LAUNCH();
+    return TFASR_STATUS_SUCCESS;
+  }
   const int grid = (int)std::min<long>((rows + 3) / 4, 1024L);
   if (dtype == TFASR_F32)
     hipLaunchKernelGGL((bn_stats_kernel<float, 1>), dim3(grid), dim3(256), 0, s, (const float*)x, (const float*)dy, fin,
