@@ -61,13 +61,13 @@ def to_train_data(batch, dev):
         TrainLabel(torch.from_numpy(batch["labels"]).to(dev), torch.from_numpy(batch["ulen"])))
 
 
-def cpu_baseline(size, vocab, seconds_budget=30.0):
+def cpu_baseline_worker(size, vocab):
     """Reference-path stand-in: the oracle's torch-CPU restatement of the same train step (TensorFlow is not
     installable: BASELINE.md §2), timed on this box's host cores on a bounded sample of the same workload."""
     from oracle import conformer_ref as R
     from oracle import rnnt_ref
 
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 16)  # more threads than this only add contention for these op sizes
     torch.set_num_threads(cores)
     ocfg = R.conformer_config("M" if size.startswith("M") else "S", vocab)
     W = R.init_weights(ocfg, seed=3)
@@ -99,16 +99,30 @@ def cpu_baseline(size, vocab, seconds_budget=30.0):
 
     step(0)  # warm-up
     t0 = time.perf_counter()
-    n = 0
-    while True:
-        step(n + 1)
-        n += 1
-        if time.perf_counter() - t0 > seconds_budget * 0.5 or n >= 3:
-            break
+    n = 2
+    for i in range(n):
+        step(i + 1)
     dt = (time.perf_counter() - t0) / n
     return dict(value=(B * secs / 3600.0) / dt, unit="audio-hours/sec", cores=cores, kind="port",
                 sample=f"oracle (torch-CPU fp32 restatement of tensorflow_asr; TF unavailable) full train step, Conformer-{ocfg['dmodel']}d, "
-                       f"{B} x {secs:.0f} s utterances, U={U}, {n} timed steps, {dt:.2f} s/step")
+                       f"{B} x {secs:.0f} s utterances, U={U}, {n} timed steps, {dt:.2f} s/step, {cores} threads")
+
+
+def cpu_baseline(size, vocab, timeout_s=240):
+    """Run the CPU baseline in a child process with a hard wall-clock bound so the default bench always finishes."""
+    import subprocess
+
+    code = ("import json,sys; sys.path.insert(0, %r); import bench; "
+            "print('CPU_BASELINE ' + json.dumps(bench.cpu_baseline_worker(%r, %d)))" % (ROOT, size, vocab))
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+    try:
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=timeout_s, env=env)
+        for line in r.stdout.splitlines():
+            if line.startswith("CPU_BASELINE "):
+                return json.loads(line[len("CPU_BASELINE "):])
+        return {"value": None, "unit": "audio-hours/sec", "error": (r.stderr or r.stdout)[-300:]}
+    except subprocess.TimeoutExpired:
+        return {"value": None, "unit": "audio-hours/sec", "error": f"CPU baseline exceeded {timeout_s} s"}
 
 
 def main():
