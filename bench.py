@@ -73,7 +73,7 @@ def cpu_baseline_worker(size, vocab):
     W = R.init_weights(ocfg, seed=3)
     Wg = {k: v.clone().requires_grad_(R.is_trainable(k)) for k, v in W.items()}
     rng = np.random.default_rng(0)
-    B, secs, U = 2, 6.0, 22
+    B, secs, U = 4, 10.0, 37
     N = int(secs * 16000)
     sig = np.clip(rng.standard_normal((B, N)).astype(np.float32) * 0.1, -1, 1)
     labels = rng.integers(1, vocab, (B, U)).astype(np.int32)
@@ -99,9 +99,10 @@ def cpu_baseline_worker(size, vocab):
 
     step(0)  # warm-up
     t0 = time.perf_counter()
-    n = 2
-    for i in range(n):
-        step(i + 1)
+    n = 0
+    while n < 8 and (n < 2 or time.perf_counter() - t0 < 15.0):
+        step(n + 1)
+        n += 1
     dt = (time.perf_counter() - t0) / n
     return dict(value=(B * secs / 3600.0) / dt, unit="audio-hours/sec", cores=cores, kind="port",
                 sample=f"oracle (torch-CPU fp32 restatement of tensorflow_asr; TF unavailable) full train step, Conformer-{ocfg['dmodel']}d, "

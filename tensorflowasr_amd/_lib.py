@@ -86,6 +86,11 @@ def load(build_if_missing=True):
         from . import build as _build
 
         _build.build(verbose=False)
+    # The process must hold ONE HIP runtime: PyTorch bundles its own libamdhip64.so.7 (same SONAME as /opt/rocm's), and
+    # whichever copy is mapped first serves both.  Import torch first so device memory, streams and our kernels all live
+    # in the runtime torch initialised (loading ours first made torch's later HIP calls see "no ROCm-capable device").
+    import torch  # noqa: F401
+
     try:
         lib = ctypes.CDLL(LIB_PATH)
     except OSError as e:  # loud, no fallback

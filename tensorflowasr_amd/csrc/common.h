@@ -97,6 +97,8 @@ __device__ __forceinline__ float logaddexpf_(float a, float b) {
 
 // hipGetLastError() also reports stale, benign results of OTHER runtime calls made on this thread by the host framework
 // (e.g. the caching allocator polling hipEventQuery -> hipErrorNotReady), so "not ready" is not a launch failure.
-#define TFASR_CHECK_LAUNCH() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess && e_ != hipErrorNotReady) return TFASR_STATUS_EXECUTION_FAILED; } while (0)
+#include <stdio.h>
+#define TFASR_CHECK_LAUNCH() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess && e_ != hipErrorNotReady) { \
+    fprintf(stderr, "[tfasr_hip] %s:%d: %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); return TFASR_STATUS_EXECUTION_FAILED; } } while (0)
 
 static inline int tfasr_ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
