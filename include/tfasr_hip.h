@@ -189,6 +189,20 @@ int tfasr_lstm_step_bwd(const void* dy, long dy_stride_b, const float* dhr, floa
                         int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Greedy transducer search control (Transducer.recognize_batch / recognize_single, base_transducer.py:496-712).
+ * mode 0 = batch variant, 1 = single (B == 1, `per_frame` [nframes] zero-initialised, tok_idx starts at -1).
+ * `active` [1]: the while_loop condition evaluated on device by `prepare`; `update` is a no-op when it is 0.
+ * encj [B,T,J] = joint encoder projection of every frame; ecur [B,J] receives the current frames.
+ * ---------------------------------------------------------------------------------------------- */
+int tfasr_decode_prepare(const void* encj, const int32_t* nframes, const int32_t* frame_idx, const int32_t* tok_idx,
+                         int32_t* active, void* ecur, int B, int T, int J, int max_tokens, int mode, int dtype,
+                         void* stream);
+int tfasr_decode_update(const void* logits, const int32_t* active, const int32_t* nframes, int32_t* frame_idx,
+                        int32_t* prev_tok, int32_t* tok_idx, int32_t* tokens, int32_t* per_frame, const void* h_new,
+                        const float* c_new, void* h, float* c, int B, int V, int P, int max_tokens, int blank, int mode,
+                        int max_tokens_per_frame, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Conv2dSubsampling pieces (subsampling.py:163-254; causal 3x3 stride 2, convolution.py:25-37,132-144)
  *   conv1: x [B,T0,F0] (Cin=1) -> y [B,ceil(T0/2),ceil(F0/2),C]; w [3,3,1,C] f32
  *   im2col/col2im for the second conv: x [B,T1,F1,C] <-> col [B*T2*F2, 9*C]

@@ -551,7 +551,7 @@ def _call_next(enc_frame, prev_tok, h, c, W):
     return torch.log_softmax(logits, -1), hn, cn
 
 
-def recognize_batch(encoded, encoded_length, W, blank=0):
+def recognize_batch(encoded, encoded_length, W, blank=0, max_iters=None):
     """Transducer.recognize_batch (base_transducer.py:496-575) on already-encoded frames. Returns tokens [B, 2T+1]."""
     B, T, _ = encoded.shape
     nframes = torch.as_tensor(encoded_length).long().view(B, 1)
@@ -563,8 +563,15 @@ def recognize_batch(encoded, encoded_length, W, blank=0):
     max_tokens = T * 2 + 1
     tokens = torch.full((B, max_tokens), blank, dtype=torch.long)
     tok_idx = torch.ones(B, 1, dtype=torch.long)
+    iters = 0
     while True:
         if bool((frame_idx >= nframes - 1).all()) or bool((tok_idx >= max_tokens - 1).all()):
+            break
+        iters += 1
+        # the reference's tf.while_loop has no bound: a sample that keeps emitting non-blank symbols at
+        # tok_idx == max_tokens-1 never advances its frame, so the loop can spin forever.  The product caps the trip count
+        # at T + max_tokens + 2 (every useful iteration advances a frame or appends a token); mirror that here.
+        if iters > (max_iters if max_iters is not None else T + max_tokens + 2):
             break
         fi = torch.minimum(frame_idx, nframes - 1)
         cur = encoded[torch.arange(B), fi[:, 0]][:, None, :]

@@ -559,6 +559,91 @@ class ConformerTransducer:
             self._ga_count = 0
         return {"loss": costs}
 
+    # =================================================================================== greedy inference
+    def get_initial_decoder_states(self, batch_size=1):
+        """TransducerPrediction.get_initial_state (base_transducer.py:109-121): zeros [B, num_rnns=1, 2 (h,c), P]."""
+        return torch.zeros(batch_size, 1, 2, self.cfg.rnn_units, dtype=torch.float32, device=self.device)
+
+    def get_initial_tokens(self, batch_size=1):
+        return torch.full((batch_size, 1), self.blank, dtype=torch.int32, device=self.device)
+
+    @torch.no_grad()
+    def encode(self, signals, signals_length):
+        """frontend + ConformerEncoder.call_next (conformer.py:703-718), inference mode (moving BN statistics)."""
+        sig = signals.to(self.device, non_blocking=True)
+        slen = [int(v) for v in signals_length.tolist()]
+        feats, flen = self.frontend(sig, slen, training=False)
+        enc, T, elen, _ = self.encoder_fwd(feats, flen, False, None)
+        return enc.view(sig.shape[0], T, self.cfg.dmodel), elen
+
+    @torch.no_grad()
+    def recognize(self, inputs: PredictInput, max_tokens_per_frame=3, check_every=16):
+        """Transducer.recognize (base_transducer.py:474-494): batch size 1 -> recognize_single (<=3 symbols per frame),
+        otherwise recognize_batch — the two variants are NOT equivalent in the reference and both are reproduced."""
+        enc, elen = self.encode(inputs.inputs, inputs.inputs_length)
+        return self.recognize_encoded(enc, elen, inputs.previous_tokens, inputs.previous_decoder_states, max_tokens_per_frame,
+                                      check_every)
+
+    def recognize_beam(self, inputs: PredictInput, beam_width=10, **kw):
+        """The reference's recognize_beam falls back to greedy (base_transducer.py:841-842)."""
+        return self.recognize(inputs, **kw)
+
+    @torch.no_grad()
+    def recognize_encoded(self, enc, elen, previous_tokens=None, previous_decoder_states=None, max_tokens_per_frame=3,
+                          check_every=16):
+        ps, c, dev = self.ps, self.cfg, self.device
+        B, T, d = enc.shape
+        E, P, J, V = c.embed_dim, c.rnn_units, c.joint_dim, c.vocab_size
+        mode = 1 if B == 1 else 0
+        nframes = torch.tensor([int(v) for v in elen], dtype=torch.int32).to(dev)
+        encj = K.matmul(enc.reshape(B * T, d), ps.w2d("joint/enc/w"), bias=ps.p("joint/enc/b")).view(B, T, J)
+        max_tokens = int(elen[0]) * max_tokens_per_frame if mode == 1 else 2 * T + 1
+        tokens = torch.full((B, max(max_tokens, 1)), self.blank, dtype=torch.int32, device=dev)
+        frame_idx = torch.zeros(B, dtype=torch.int32, device=dev)
+        tok_idx = torch.full((B,), -1 if mode == 1 else 1, dtype=torch.int32, device=dev)
+        prev_tok = (torch.full((B,), self.blank, dtype=torch.int32, device=dev) if previous_tokens is None
+                    else previous_tokens.to(dev).to(torch.int32).reshape(B).contiguous())
+        if previous_decoder_states is None:
+            h = torch.zeros(B, P, dtype=self.dtype, device=dev)
+            cst = torch.zeros(B, P, dtype=torch.float32, device=dev)
+        else:
+            st = previous_decoder_states.to(dev)
+            h = st[:, 0, 0].to(self.dtype).contiguous()
+            cst = st[:, 0, 1].float().contiguous()
+        per_frame = torch.zeros(max(int(elen[0]), 1), dtype=torch.int32, device=dev) if mode == 1 else None
+        active = torch.ones(1, dtype=torch.int32, device=dev)
+        ecur = torch.empty(B, J, dtype=self.dtype, device=dev)
+        xg = torch.empty(B, 4 * P, dtype=self.dtype, device=dev)
+        hr = torch.empty(B, 4 * P, dtype=torch.float32, device=dev)
+        h_new = torch.empty(B, P, dtype=self.dtype, device=dev)
+        c_new = torch.empty(B, P, dtype=torch.float32, device=dev)
+        pj = torch.empty(B, J, dtype=self.dtype, device=dev)
+        logits = torch.empty(B, V, dtype=self.dtype, device=dev)
+        Wk, Wrk, Wjp, Wv = ps.w2d("pred/lstm/k"), ps.w2d("pred/lstm/rk"), ps.w2d("joint/pred/w"), ps.w2d("joint/vocab/w")
+        # every useful iteration advances a frame or appends a token; the reference's while_loop is unbounded and can
+        # spin forever once a sample saturates its token buffer (SURVEY.md A.4 item 6) — cap the trip count instead
+        max_iters = T + max_tokens + 2
+        it = 0
+        while it < max_iters:
+            for _ in range(min(check_every, max_iters - it)):
+                K.decode_prepare(encj, nframes, frame_idx, tok_idx, active, ecur, max_tokens, mode)
+                emb = K.embedding_fwd(prev_tok, ps.p("pred/emb"), self.dtype)
+                K.matmul(emb, Wk, bias=ps.p("pred/lstm/b"), out=xg)
+                K.gemm(h, Wrk, hr, B, 4 * P, P, P, 4 * P, 4 * P)
+                K.lstm_step_fwd(xg, hr, h, cst, None, 0, None, c_new, h_new, None, B, P)
+                y, _, _ = K.layernorm_fwd(h_new, ps.p("pred/ln/g"), ps.p("pred/ln/b"), save_stats=False)
+                K.matmul(y, Wjp, bias=ps.p("joint/pred/b"), out=pj)
+                z = K.joint_fwd(ecur.view(B, 1, J), pj.view(B, 1, J))
+                K.matmul(z.view(B, J), Wv, bias=ps.p("joint/vocab/b"), out=logits)
+                K.decode_update(logits, active, nframes, frame_idx, prev_tok, tok_idx, tokens, per_frame, h_new, c_new, h, cst,
+                                max_tokens, self.blank, mode, max_tokens_per_frame)
+                it += 1
+            if int(active.item()) == 0:
+                break
+        states = torch.stack([h.float(), cst], dim=1).unsqueeze(1)  # [B, 1, 2, P]
+        return PredictOutput(tokens=tokens[:, :max_tokens], next_tokens=prev_tok.view(B, 1), next_encoder_states=None,
+                             next_decoder_states=states)
+
     # ----------------------------------------------------------------- timing hooks (bench.py)
     def _tick(self, name):
         if self.timers is None:

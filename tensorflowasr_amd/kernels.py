@@ -353,3 +353,19 @@ def logmel(signal, window, melw, band, frame_step, nfft, preemph, eps, out_dtype
     check(_L().tfasr_logmel(_p(signal), B, N, preemph, _p(window), window.numel(), frame_step, nfft, _p(melw), _p(band), F,
                             eps, _p(out), T0, _dt(out), _stream()), "logmel")
     return out
+
+
+# -------------------------------------------------------------------------------------- greedy search
+def decode_prepare(encj, nframes, frame_idx, tok_idx, active, ecur, max_tokens, mode):
+    B, T, J = encj.shape
+    check(_L().tfasr_decode_prepare(_p(encj), _p(nframes), _p(frame_idx), _p(tok_idx), _p(active), _p(ecur), B, T, J, max_tokens,
+                                    mode, _dt(encj), _stream()), "decode_prepare")
+
+
+def decode_update(logits, active, nframes, frame_idx, prev_tok, tok_idx, tokens, per_frame, h_new, c_new, h, c, max_tokens,
+                  blank, mode, max_tokens_per_frame):
+    B, V = logits.shape
+    P = h.shape[1]
+    check(_L().tfasr_decode_update(_p(logits), _p(active), _p(nframes), _p(frame_idx), _p(prev_tok), _p(tok_idx), _p(tokens),
+                                   _p(per_frame), _p(h_new), _p(c_new), _p(h), _p(c), B, V, P, max_tokens, blank, mode,
+                                   max_tokens_per_frame, _dt(logits), _stream()), "decode_update")

@@ -136,3 +136,30 @@ def test_train_steps_reduce_loss_and_ga(dev):
     assert m2.step == 1
     a, b = m1.ps.flat.cpu().numpy(), m2.ps.flat.cpu().numpy()
     np.testing.assert_allclose(a, b, rtol=0, atol=5e-5)
+
+
+@pytest.mark.parametrize("bias", [1.2, 1.6])
+@pytest.mark.parametrize("lens", [[4000, 4000, 4000], [4000, 2000, 3000], [4000]])
+def test_greedy_decode_tokens_bit_exact(dev, lens, bias):
+    """BASELINE north_star: bit-exact token indices for greedy decode vs the reference semantics (f32 path), including the
+    batch-loop quirks (last frame of the slowest sample never decoded, tokens from column 2) and the bs=1 variant."""
+    ulens = [3] * len(lens)
+    cfg, ocfg, model, W, data, sig, labels, preds = _setup(dev, torch.float32, lens, ulens, seed=3)
+    W["joint/vocab/b"] = W["joint/vocab/b"].clone()
+    W["joint/vocab/b"][0] += bias  # blank/non-blank mix: some samples saturate their token buffer, others emit a few
+    model.ps.import_keras(W)
+    # oracle: inference-mode encoder (moving BN statistics) + the reference's greedy loops
+    feat = R.log_mel(sig, ocfg)
+    enc_ref, elen = R.encoder(torch.from_numpy(feat)[..., None], R.get_nframes(lens), W, ocfg, training=False)
+    from tensorflowasr_amd.schemas import PredictInput
+    out = model.recognize(PredictInput(torch.from_numpy(sig), torch.tensor(lens, dtype=torch.int32)))
+    enc_mine, my_elen = model.encode(torch.from_numpy(sig), torch.tensor(lens, dtype=torch.int32))
+    np.testing.assert_allclose(enc_mine.cpu().numpy(), enc_ref.numpy(), rtol=2e-3, atol=2e-3)
+    if len(lens) == 1:
+        tok_ref, prev_ref, h_ref, c_ref = R.recognize_single(enc_ref, elen.tolist(), W)
+    else:
+        tok_ref, prev_ref, h_ref, c_ref = R.recognize_batch(enc_ref, elen.tolist(), W)
+    assert out.tokens.shape == tok_ref.shape
+    np.testing.assert_array_equal(out.tokens.cpu().numpy(), tok_ref.numpy())
+    np.testing.assert_array_equal(out.next_tokens.cpu().numpy().reshape(-1), prev_ref.numpy().reshape(-1))
+    np.testing.assert_allclose(out.next_decoder_states[:, 0, 0].cpu().numpy(), h_ref.numpy(), rtol=1e-3, atol=1e-4)
