@@ -63,6 +63,20 @@ int tfasr_rnnt_loss(const void* logits, void* grads, const int32_t* labels, cons
                     void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * CTC loss (CtcLoss.call -> tf.nn.ctc_loss(logits_time_major=False, blank_index=0), losses/ctc_loss.py:47-66) and
+ * CTC greedy decoding (tf.nn.ctc_greedy_decoder(merge_repeated=True), models/ctc/base_ctc.py:102-124).
+ * logits [B,T,V] raw activations, labels [B,U] dense, costs [B] = -log p(labels|x); grads (may alias logits) =
+ * grad_scale[b] * dcost_b/dlogits, zero for t >= logit_len[b].  2U+1 <= 1024.
+ * greedy: tokens [B,T] (blank padded), tokens_len [B]; workspace_argmax [B*T] int32.
+ * ---------------------------------------------------------------------------------------------- */
+int tfasr_ctc_loss_workspace_size(int B, int T, int U, int V, size_t* bytes);
+int tfasr_ctc_loss(const void* logits, void* grads, const int32_t* labels, const int32_t* label_len,
+                   const int32_t* logit_len, const float* grad_scale, int B, int T, int U, int V, int blank, int dtype,
+                   float* costs, void* workspace, size_t workspace_bytes, void* stream);
+int tfasr_ctc_greedy_decode(const void* logits, const int32_t* logit_len, int32_t* workspace_argmax, int32_t* tokens,
+                            int32_t* tokens_len, int B, int T, int V, int blank, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * GEMM family (Dense / EinsumDense / pointwise Conv1D / attention products / joint vocab projection:
  * keras Dense sites conformer.py:72-87, multihead_attention.py:628-637,654, base_transducer.py:238-293)
  *

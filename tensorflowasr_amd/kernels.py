@@ -369,3 +369,28 @@ def decode_update(logits, active, nframes, frame_idx, prev_tok, tok_idx, tokens,
     check(_L().tfasr_decode_update(_p(logits), _p(active), _p(nframes), _p(frame_idx), _p(prev_tok), _p(tok_idx), _p(tokens),
                                    _p(per_frame), _p(h_new), _p(c_new), _p(h), _p(c), B, V, P, max_tokens, blank, mode,
                                    max_tokens_per_frame, _dt(logits), _stream()), "decode_update")
+
+
+# ------------------------------------------------------------------------------------------------ CTC
+def ctc_loss_fwd_bwd(logits, labels, label_len, logit_len, grad_scale=None, grads=None, want_grads=True, blank=0):
+    """logits [B,T,V] -> (costs [B], grads or None); tf.nn.ctc_loss semantics (losses/ctc_loss.py:57-66)."""
+    B, T, V = logits.shape
+    U = labels.shape[1]
+    costs = torch.empty(B, dtype=torch.float32, device=logits.device)
+    if want_grads and grads is None:
+        grads = torch.empty_like(logits)
+    n = ctypes.c_size_t(0)
+    check(_L().tfasr_ctc_loss_workspace_size(B, T, U, V, ctypes.byref(n)), "ctc_ws")
+    ws = workspace(n.value, logits.device, "ctc")
+    check(_L().tfasr_ctc_loss(_p(logits), _p(grads) if want_grads else None, _p(labels), _p(label_len), _p(logit_len), _p(grad_scale),
+                              B, T, U, V, blank, _dt(logits), _p(costs), _p(ws), ws.numel(), _stream()), "ctc_loss")
+    return costs, (grads if want_grads else None)
+
+
+def ctc_greedy_decode(logits, logit_len, blank=0):
+    B, T, V = logits.shape
+    am = torch.empty(B * T, dtype=torch.int32, device=logits.device)
+    tokens = torch.empty(B, T, dtype=torch.int32, device=logits.device)
+    tlen = torch.empty(B, dtype=torch.int32, device=logits.device)
+    check(_L().tfasr_ctc_greedy_decode(_p(logits), _p(logit_len), _p(am), _p(tokens), _p(tlen), B, T, V, blank, _dt(logits), _stream()), "ctc_greedy")
+    return tokens, tlen
