@@ -138,6 +138,7 @@ def main():
     ap.add_argument("--workload", default=None, help="'S-10s' = BASELINE cfg2 (10 s utterances); default LibriSpeech-shaped")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-specaugment", action="store_true")
+    ap.add_argument("--dropout", type=float, default=None, help="override encoder dropout (default: reference value 0.1)")
     args = ap.parse_args()
 
     from tensorflowasr_amd import configs, dp as dpmod
@@ -155,6 +156,8 @@ def main():
     cfg = configs.conformer_m() if args.model == "M" else configs.conformer_s()
     if args.no_specaugment:
         cfg.time_masking, cfg.freq_masking = {}, {}
+    if args.dropout is not None:
+        cfg.dropout = args.dropout
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     model = ConformerTransducer(cfg, dev, dtype=dtype, seed=0, dp=dp)
     if dp:
@@ -209,7 +212,7 @@ def main():
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"Conformer-{args.model} transducer full train step (fwd+RNN-T loss+bwd+Adam), {size} 16 kHz utterances, "
-                                   f"{args.batch}/GPU, padding={args.padding}, SpecAugment {'off' if args.no_specaugment else 'on'}, dropout 0",
+                                   f"{args.batch}/GPU, padding={args.padding}, SpecAugment {'off' if args.no_specaugment else 'on'}, dropout {cfg.dropout}",
                        "global_batch": args.batch * world, "parallelism": f"dp{world}", "params": model.ps.num_trainable()},
             "roofline": roof,
         }

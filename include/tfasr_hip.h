@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define TFASR_ABI_VERSION 2
+#define TFASR_ABI_VERSION 3
 
 typedef enum {
   TFASR_STATUS_SUCCESS = 0,
@@ -84,7 +84,9 @@ int tfasr_ctc_greedy_decode(const void* logits, const int32_t* logit_len, int32_
  *   op(A) is [M,K]: trans_a==0 -> A stored [M,K] (lda), trans_a==1 -> A stored [K,M] (lda)
  *   op(B) is [K,N]: trans_b==0 -> B stored [K,N] (ldb), trans_b==1 -> B stored [N,K] (ldb)
  *   epilogue: v = alpha*acc + bias[n]; if (prez) prez = v; v = act(v);
- *             if (dact_z) v *= dact'(dact_z[m,n]);  if (res) v = res[m,n] + beta*v;
+ *             if (dact_z) v *= dact'(dact_z[m,n]);
+ *             if (drop_p > 0) v = keep(drop_seed, m*ldd+n) ? v/(1-drop_p) : 0      (keras Dropout, conformer.py:80-87)
+ *             if (res) v = res[m,n] + beta*v;
  *             D = v   (out_f32 ? f32 : dtype);  accumulate!=0 -> atomicAdd into f32 D (split-K legal)
  * A, B, res, dact_z, prez are `dtype`; bias is f32.
  * ---------------------------------------------------------------------------------------------- */
@@ -108,6 +110,8 @@ typedef struct {
   int out_f32;             /* D is f32 */
   int accumulate;          /* D += (atomic, requires out_f32) */
   int split_k;             /* >=1; >1 requires accumulate */
+  float drop_p;            /* dropout rate applied to v (0 = off); the mask is a pure function of (drop_seed, element index) */
+  long drop_seed;
 } tfasr_gemm_args;
 
 int tfasr_gemm(const tfasr_gemm_args* args, void* stream);
@@ -140,6 +144,8 @@ int tfasr_bn_apply_bwd(const void* x, const void* dy, const float* fin, const fl
  * Pointwise / small-reduction stages (see csrc/elementwise.hip for the reference sites).
  * ---------------------------------------------------------------------------------------------- */
 int tfasr_cast(const void* src, void* dst, long n, int src_dtype, int dst_dtype, void* stream);
+/* y[i] = keep(seed, i) ? x[i]/(1-p) : 0 — the same counter-based mask as the GEMM epilogue's (index = row*ld+col) */
+int tfasr_dropout(const void* x, void* y, long n, float p, long seed, int dtype, void* stream);
 /* out[c] += scale * sum_r x[r*ld + c]   (bias gradients) */
 int tfasr_colsum(const void* x, long ld, float* out, long rows, int C, float scale, int dtype, void* stream);
 /* GLU over the last axis: x [rows, 2C] -> y [rows, C] = x[:, :C] * sigmoid(x[:, C:])  (activations/glu.py:25-28) */

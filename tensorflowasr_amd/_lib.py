@@ -29,6 +29,7 @@ class GemmArgs(Structure):
         ("sA1", c_long), ("sA2", c_long), ("sB1", c_long), ("sB2", c_long), ("sD1", c_long), ("sD2", c_long),
         ("alpha", c_float), ("beta", c_float),
         ("act", c_int), ("dact", c_int), ("dtype", c_int), ("out_f32", c_int), ("accumulate", c_int), ("split_k", c_int),
+        ("drop_p", c_float), ("drop_seed", c_long),
     ]
 
 
@@ -108,7 +109,7 @@ def load(build_if_missing=True):
     return lib
 
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 def check(status, what=""):

@@ -106,7 +106,7 @@ def conformer_m(vocab_size=1000, **over):
 
 
 def conformer_tiny(vocab_size=29, **over):
-    kw = dict(filters=32, dmodel=32, head_size=8, num_heads=4, embed_dim=24, rnn_units=24, joint_dim=40, num_blocks=2,
+    kw = dict(dropout=0.0, filters=32, dmodel=32, head_size=8, num_heads=4, embed_dim=24, rnn_units=24, joint_dim=40, num_blocks=2,
               kernel_size=7, vocab_size=vocab_size)
     kw.update(over)
     return ConformerConfig(**kw)

@@ -63,6 +63,7 @@ class ConformerTransducer:
             dmodel=cfg.dmodel, warmup_steps=10000, scale=2.0, max_lr=0.05 / math.sqrt(cfg.dmodel)))
         self.ga_steps = 1
         self._ga_count = 0
+        self._drop_epoch = 0  # bumped once per forward pass so every step draws fresh dropout masks
         self.timers = None  # optional dict name -> list[(start_event, end_event)] filled by bench.py
         self.timer_work = {}
 
@@ -95,8 +96,20 @@ class ConformerTransducer:
             self._consts[key] = torch.from_numpy(pe).to(self.device).to(self.dtype).contiguous()
         return self._consts[key]
 
+    # =================================================================================== dropout bookkeeping
+    def _drop(self, site, training):
+        """(rate, seed) of dropout site `site` for the current step; masks are a pure function of (seed, element index), so
+        the backward regenerates them instead of storing them (keras Dropout sites: conformer.py:80-87,197,358,681)."""
+        p = float(self.cfg.dropout) if training else 0.0
+        if p <= 0.0:
+            return 0.0, 0
+        return p, (self._drop_epoch * 8192 + site) & 0x7FFFFFFFFFFF
+
+    def _mask_grad(self, dy, drop):
+        return K.dropout(dy, drop[0], drop[1]) if drop[0] > 0.0 else dy
+
     # =================================================================================== dense helpers
-    def _dense_bwd(self, dy, x, wname, bname, alpha=1.0, dact_z=None, dact=ACT_NONE, need_dx=True):
+    def _dense_bwd(self, dy, x, wname, bname, alpha=1.0, dact_z=None, dact=ACT_NONE, need_dx=True, drop=(0.0, 0)):
         """dx = alpha * (dy @ W^T) [* dact'(z)];  gW += alpha * x^T dy;  gb += alpha * colsum(dy)."""
         ps = self.ps
         W = ps.w2d(wname)
@@ -108,7 +121,7 @@ class ConformerTransducer:
             K.colsum(dy, ps.g(bname), scale=alpha, rows=rows, C=dout, ld=dy.stride(0))
         if not need_dx:
             return None
-        return K.matmul(dy, W, trans_b=True, alpha=alpha, dact_z=dact_z, dact=dact)
+        return K.matmul(dy, W, trans_b=True, alpha=alpha, dact_z=dact_z, dact=dact, drop_p=drop[0], drop_seed=drop[1])
 
     # =================================================================================== frontend
     def frontend(self, signals, signals_length, training=False, masks=None):
@@ -197,10 +210,11 @@ class ConformerTransducer:
         c2 = K.matmul(col, ps.w2d("enc/sub/conv1/w"), bias=ps.p("enc/sub/conv1/b"))  # [B*T2*F2, C]
         a2, bn1 = self._bn_fwd(c2, "enc/sub/bn1", training, ACT_SWISH)
         merged = a2.view(B * T2, F2 * C)  # math_util.merge_two_last_dims
-        x0 = K.matmul(merged, ps.w2d("enc/linear/w"), bias=ps.p("enc/linear/b"))  # [B*T2, d]
+        drop = self._drop(0, training)
+        x0 = K.matmul(merged, ps.w2d("enc/linear/w"), bias=ps.p("enc/linear/b"), drop_p=drop[0], drop_seed=drop[1])  # [B*T2, d]
         elen = [-(-(-(-n // 2)) // 2) for n in flen]
         if ctx is not None:
-            ctx["sub"] = dict(feats=feats, c1=c1, bn0=bn0, col=col, c2=c2, bn1=bn1, merged=merged, dims=(B, T0, F0, T1, F1, T2, F2))
+            ctx["sub"] = dict(feats=feats, c1=c1, bn0=bn0, col=col, c2=c2, bn1=bn1, merged=merged, dims=(B, T0, F0, T1, F1, T2, F2), drop=drop)
         return x0, T2, elen
 
     def _subsampling_bwd(self, dx0, ctx):
@@ -208,7 +222,7 @@ class ConformerTransducer:
         s = ctx["sub"]
         B, T0, F0, T1, F1, T2, F2 = s["dims"]
         C = c.filters
-        dmerged = self._dense_bwd(dx0, s["merged"], "enc/linear/w", "enc/linear/b")
+        dmerged = self._dense_bwd(self._mask_grad(dx0, s["drop"]), s["merged"], "enc/linear/w", "enc/linear/b")
         dc2 = self._bn_bwd(s["c2"], dmerged.view(-1, C), "enc/sub/bn1", s["bn1"], ACT_SWISH)
         dcol = self._dense_bwd(dc2, s["col"], "enc/sub/conv1/w", "enc/sub/conv1/b")
         da1 = K.col2im_3x3s2(dcol, B, T1, F1, C)
@@ -216,24 +230,26 @@ class ConformerTransducer:
         K.conv1_bwd_weight(s["feats"], dc1.view(B, T1, F1, C), ps.g("enc/sub/conv0/w"), ps.g("enc/sub/conv0/b"))
 
     # =================================================================================== conformer block
-    def _ffm_fwd(self, x, pfx, ctx):
+    def _ffm_fwd(self, x, pfx, ctx, site, training):
         ps, f = self.ps, self.cfg.ffm_residual
+        d1, d2 = self._drop(site, training), self._drop(site + 1, training)
         ln, mean, rstd = K.layernorm_fwd(x, ps.p(pfx + "ln/g"), ps.p(pfx + "ln/b"))
         z = torch.empty(x.shape[0], ps.shapes[pfx + "d1/w"][1], dtype=self.dtype, device=self.device) if ctx is not None else None
-        h = K.matmul(ln, ps.w2d(pfx + "d1/w"), bias=ps.p(pfx + "d1/b"), act=ACT_SWISH, prez=z)
-        y = K.matmul(h, ps.w2d(pfx + "d2/w"), bias=ps.p(pfx + "d2/b"), res=x, beta=f)
+        h = K.matmul(ln, ps.w2d(pfx + "d1/w"), bias=ps.p(pfx + "d1/b"), act=ACT_SWISH, prez=z, drop_p=d1[0], drop_seed=d1[1])
+        y = K.matmul(h, ps.w2d(pfx + "d2/w"), bias=ps.p(pfx + "d2/b"), res=x, beta=f, drop_p=d2[0], drop_seed=d2[1])
         if ctx is not None:
-            ctx[pfx] = dict(x=x, ln=ln, mean=mean, rstd=rstd, z=z, h=h)
+            ctx[pfx] = dict(x=x, ln=ln, mean=mean, rstd=rstd, z=z, h=h, d1=d1, d2=d2)
         return y
 
     def _ffm_bwd(self, dy, pfx, ctx):
         ps, f = self.ps, self.cfg.ffm_residual
         s = ctx.pop(pfx)
-        dz = self._dense_bwd(dy, s["h"], pfx + "d2/w", pfx + "d2/b", alpha=f, dact_z=s["z"], dact=ACT_SWISH)
+        dz = self._dense_bwd(self._mask_grad(dy, s["d2"]), s["h"], pfx + "d2/w", pfx + "d2/b", alpha=f, dact_z=s["z"], dact=ACT_SWISH,
+                             drop=s["d1"])
         dln = self._dense_bwd(dz, s["ln"], pfx + "d1/w", pfx + "d1/b")
         return K.layernorm_bwd(dln, s["x"], ps.p(pfx + "ln/g"), s["mean"], s["rstd"], ps.g(pfx + "ln/g"), ps.g(pfx + "ln/b"), add=dy)
 
-    def _mhsa_fwd(self, x, pfx, B, T, elen_dev, ctx):
+    def _mhsa_fwd(self, x, pfx, B, T, elen_dev, ctx, site, training):
         ps, c = self.ps, self.cfg
         H, dh = c.num_heads, c.head_size
         HD = H * dh
@@ -256,9 +272,10 @@ class ConformerTransducer:
         probs = K.relattn_softmax_fwd(content, pos, elen_dev, T, use_mask=c.use_attention_auto_mask, probs=content)
         att = torch.empty(B * T, HD, dtype=self.dtype, device=self.device)
         K.gemm(probs, vv, att, T, dh, T, Tp, 3 * HD, HD, nb1=B, nb2=H, sA=(H * T * Tp, T * Tp), sB=(T * 3 * HD, dh), sD=(T * HD, dh))
-        y = K.matmul(att, ps.w2d(pfx + "o/w"), bias=ps.p(pfx + "o/b"), res=x, beta=c.mhsam_residual)
+        drop = self._drop(site, training)
+        y = K.matmul(att, ps.w2d(pfx + "o/w"), bias=ps.p(pfx + "o/b"), res=x, beta=c.mhsam_residual, drop_p=drop[0], drop_seed=drop[1])
         if ctx is not None:
-            ctx[pfx] = dict(x=x, ln=ln, mean=mean, rstd=rstd, qkv=qkv, qu=qu, qv=qv, pext=pext, probs=probs, att=att)
+            ctx[pfx] = dict(x=x, ln=ln, mean=mean, rstd=rstd, qkv=qkv, qu=qu, qv=qv, pext=pext, probs=probs, att=att, drop=drop)
         return y
 
     def _mhsa_bwd(self, dy, pfx, B, T, elen_dev, ctx):
@@ -270,7 +287,7 @@ class ConformerTransducer:
         s = ctx.pop(pfx)
         qkv, probs = s["qkv"], s["probs"]
         kk, vv = qkv[:, HD:], qkv[:, 2 * HD:]
-        datt = self._dense_bwd(dy, s["att"], pfx + "o/w", pfx + "o/b", alpha=c.mhsam_residual)
+        datt = self._dense_bwd(self._mask_grad(dy, s["drop"]), s["att"], pfx + "o/w", pfx + "o/b", alpha=c.mhsam_residual)
         dqkv = torch.empty_like(qkv)
         # dprobs = datt @ v^T
         Tp, R1p = -(-T // 8) * 8, -(-R1 // 8) * 8
@@ -304,7 +321,7 @@ class ConformerTransducer:
         dln = self._dense_bwd(dqkv, s["ln"], pfx + "qkv/w", pfx + "qkv/b")
         return K.layernorm_bwd(dln, s["x"], ps.p(pfx + "ln/g"), s["mean"], s["rstd"], ps.g(pfx + "ln/g"), ps.g(pfx + "ln/b"), add=dy)
 
-    def _convm_fwd(self, x, pfx, B, T, training, ctx):
+    def _convm_fwd(self, x, pfx, B, T, training, ctx, site):
         ps, c = self.ps, self.cfg
         d = c.dmodel
         ln, mean, rstd = K.layernorm_fwd(x, ps.p(pfx + "ln/g"), ps.p(pfx + "ln/b"))
@@ -312,16 +329,17 @@ class ConformerTransducer:
         g = K.glu_fwd(a)  # [B*T, d]
         cv = K.dwconv_fwd(g.view(B, T, d), ps.p(pfx + "dw/w"), ps.p(pfx + "dw/b")).view(B * T, d)
         sw, bn = self._bn_fwd(cv, pfx + "bn", training, ACT_SWISH)
-        y = K.matmul(sw, ps.w2d(pfx + "pw2/w"), bias=ps.p(pfx + "pw2/b"), res=x, beta=c.convm_residual)
+        drop = self._drop(site, training)
+        y = K.matmul(sw, ps.w2d(pfx + "pw2/w"), bias=ps.p(pfx + "pw2/b"), res=x, beta=c.convm_residual, drop_p=drop[0], drop_seed=drop[1])
         if ctx is not None:
-            ctx[pfx] = dict(x=x, ln=ln, mean=mean, rstd=rstd, a=a, g=g, cv=cv, bn=bn, sw=sw)
+            ctx[pfx] = dict(x=x, ln=ln, mean=mean, rstd=rstd, a=a, g=g, cv=cv, bn=bn, sw=sw, drop=drop)
         return y
 
     def _convm_bwd(self, dy, pfx, B, T, ctx):
         ps, c = self.ps, self.cfg
         d = c.dmodel
         s = ctx.pop(pfx)
-        dsw = self._dense_bwd(dy, s["sw"], pfx + "pw2/w", pfx + "pw2/b", alpha=c.convm_residual)
+        dsw = self._dense_bwd(self._mask_grad(dy, s["drop"]), s["sw"], pfx + "pw2/w", pfx + "pw2/b", alpha=c.convm_residual)
         dcv = self._bn_bwd(s["cv"], dsw, pfx + "bn", s["bn"], ACT_SWISH)
         dcv3 = dcv.view(B, T, d)
         K.dwconv_bwd_weight(s["g"].view(B, T, d), dcv3, ps.g(pfx + "dw/w"), ps.g(pfx + "dw/b"))
@@ -333,10 +351,11 @@ class ConformerTransducer:
     def _block_fwd(self, x, i, B, T, elen_dev, training, ctx):
         p = f"enc/block{i}/"
         ps = self.ps
-        x = self._ffm_fwd(x, p + "ff1/", ctx)
-        x = self._mhsa_fwd(x, p + "mhsa/", B, T, elen_dev, ctx)
-        x = self._convm_fwd(x, p + "conv/", B, T, training, ctx)
-        x = self._ffm_fwd(x, p + "ff2/", ctx)
+        site = 16 + i * 8
+        x = self._ffm_fwd(x, p + "ff1/", ctx, site, training)
+        x = self._mhsa_fwd(x, p + "mhsa/", B, T, elen_dev, ctx, site + 2, training)
+        x = self._convm_fwd(x, p + "conv/", B, T, training, ctx, site + 3)
+        x = self._ffm_fwd(x, p + "ff2/", ctx, site + 4, training)
         y, mean, rstd = K.layernorm_fwd(x, ps.p(p + "ln/g"), ps.p(p + "ln/b"))
         if ctx is not None:
             ctx[p + "ln"] = dict(x=x, mean=mean, rstd=rstd)
@@ -463,6 +482,7 @@ class ConformerTransducer:
 
     def _forward(self, inputs: TrainInput, training, ctx, masks=None):
         dev = self.device
+        self._drop_epoch += 1
         sig = inputs.inputs.to(dev, non_blocking=True)
         slen = [int(v) for v in inputs.inputs_length.tolist()]
         tokens = inputs.predictions.to(dev, non_blocking=True).to(torch.int32).contiguous()

@@ -88,6 +88,13 @@ __device__ __forceinline__ float swishf_(float x) { return x * sigmoidf_(x); }
 // d/dx [x * sigmoid(x)] = s + x*s*(1-s)
 __device__ __forceinline__ float dswishf_(float x) { const float s = sigmoidf_(x); return s * (1.f + x * (1.f - s)); }
 
+// counter-based dropout mask: keep iff the mixed 64-bit (seed, index) hash, as a uniform in [0,1), is >= p
+__device__ __forceinline__ bool drop_keep(uint64_t seed, uint64_t idx, float p) {
+  uint64_t x = idx + seed * 0x9E3779B97F4A7C15ull;
+  x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33;
+  return (float)(uint32_t)(x >> 40) * (1.0f / 16777216.0f) >= p;
+}
+
 // log(exp(a)+exp(b)) with -inf handling (the 2-term log-sum-exp of losses/impl/rnnt.py:72-78,126)
 __device__ __forceinline__ float logaddexpf_(float a, float b) {
   const float m = fmaxf(a, b);

@@ -25,6 +25,22 @@ __global__ __launch_bounds__(256) void cast_kernel(const S* __restrict__ src, D*
     Num<D>::st(dst + i, Num<S>::ld(src + i));
 }
 
+// ------------------------------------------------------------------------------------- dropout
+template <typename T>
+__global__ __launch_bounds__(256) void dropout_kernel(const T* x, T* y, long n, float p, uint64_t seed) {
+  const long n8 = n / 8;
+  const float inv = 1.f / (1.f - p);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+    float v[8];
+    ld8(x + i * 8, v);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = drop_keep(seed, (uint64_t)(i * 8 + k), p) ? v[k] * inv : 0.f;
+    st8(y + i * 8, v);
+  }
+  for (long i = n8 * 8 + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    Num<T>::st(y + i, drop_keep(seed, (uint64_t)i, p) ? Num<T>::ld(x + i) * inv : 0.f);
+}
+
 // -------------------------------------------------------------------------------------- colsum
 // out[c] (+)= scale * sum_r x[r, c]; x has row stride ld.  grid = (row blocks, ceil(C/64))
 template <typename T>
@@ -397,6 +413,16 @@ extern "C" int tfasr_cast(const void* src, void* dst, long n, int src_dtype, int
   else if (src_dtype == TFASR_BF16 && dst_dtype == TFASR_BF16)
     hipLaunchKernelGGL((cast_kernel<bf16_t, bf16_t>), dim3(grid), dim3(256), 0, s, (const bf16_t*)src, (bf16_t*)dst, n);
   else return TFASR_STATUS_INVALID_VALUE;
+  TFASR_CHECK_LAUNCH();
+  return TFASR_STATUS_SUCCESS;
+}
+
+extern "C" int tfasr_dropout(const void* x, void* y, long n, float p, long seed, int dtype, void* stream_) {
+  if (!x || !y || n <= 0 || p < 0.f || p >= 1.f) return TFASR_STATUS_INVALID_VALUE;
+  hipStream_t s = (hipStream_t)stream_;
+  const int grid = flat_grid(n / 8 + 1);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(dropout_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, (float*)y, n, p, (uint64_t)seed),
+             hipLaunchKernelGGL(dropout_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, n, p, (uint64_t)seed));
   TFASR_CHECK_LAUNCH();
   return TFASR_STATUS_SUCCESS;
 }

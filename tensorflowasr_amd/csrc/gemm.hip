@@ -245,6 +245,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const tfasr_gemm_args p) {
         if (prez) Num<T>::st(prez + idx, v);
         v = apply_act(v, p.act);
         if (dz) v *= apply_dact(Num<T>::ld(dz + idx), p.dact);
+        if (p.drop_p > 0.f) v = drop_keep((uint64_t)p.drop_seed, (uint64_t)(doff + idx), p.drop_p) ? v * (1.f / (1.f - p.drop_p)) : 0.f;
         if (res) v = Num<T>::ld(res + idx) + p.beta * v;
         if (p.out_f32) {
           if (p.accumulate) atomicAdd(Df + idx, v);
@@ -294,7 +295,8 @@ extern "C" int tfasr_gemm(const tfasr_gemm_args* args, void* stream_) {
   if (a.split_k < 1) a.split_k = 1;
   if (a.accumulate && !a.out_f32) return TFASR_STATUS_INVALID_VALUE;
   if (a.split_k > 1 && !a.accumulate) return TFASR_STATUS_INVALID_VALUE;
-  if (a.split_k > 1 && (a.res || a.dact_z || a.prez || a.act != TFASR_ACT_NONE)) return TFASR_STATUS_INVALID_VALUE;
+  if (a.split_k > 1 && (a.res || a.dact_z || a.prez || a.act != TFASR_ACT_NONE || a.drop_p > 0.f)) return TFASR_STATUS_INVALID_VALUE;
+  if (a.drop_p < 0.f || a.drop_p >= 1.f) return TFASR_STATUS_INVALID_VALUE;
   hipStream_t stream = (hipStream_t)stream_;
   if (a.dtype == TFASR_BF16 && use_fast_path()) {
     const int st = tfasr_gemm_fast_try(a, stream);

@@ -279,6 +279,11 @@ _Pragma("unroll")
 #pragma unroll
         for (int q = 0; q < 16; ++q) v[q] *= dact_f(z[q], p.dact);
       }
+      if (p.drop_p > 0.f) {
+        const float inv = 1.f / (1.f - p.drop_p);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v[q] = drop_keep((uint64_t)p.drop_seed, (uint64_t)(doff + idx0 + q), p.drop_p) ? v[q] * inv : 0.f;
+      }
       if (res) {
         float z[16];
         if (full) { ld8(res + idx0, *reinterpret_cast<float(*)[8]>(z)); ld8(res + idx0 + 8, *reinterpret_cast<float(*)[8]>(z + 8)); }

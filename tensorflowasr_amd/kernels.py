@@ -82,7 +82,7 @@ def rnnt_loss_fwd_bwd(logits, labels, label_len, logit_len, grad_scale=None, gra
 # ---------------------------------------------------------------------------------------------- GEMM
 def gemm(A, B, out, M, N, K, lda, ldb, ldd, trans_a=False, trans_b=False, bias=None, res=None, dact_z=None,
          prez=None, alpha=1.0, beta=1.0, act=ACT_NONE, dact=ACT_NONE, nb1=1, nb2=1, sA=(0, 0), sB=(0, 0), sD=(0, 0),
-         accumulate=False, split_k=1):
+         accumulate=False, split_k=1, drop_p=0.0, drop_seed=0):
     """Raw strided (two-level batched) GEMM; see include/tfasr_hip.h."""
     a = GemmArgs()
     a.A, a.B, a.D = A.data_ptr(), B.data_ptr(), out.data_ptr()
@@ -102,6 +102,7 @@ def gemm(A, B, out, M, N, K, lda, ldb, ldd, trans_a=False, trans_b=False, bias=N
     a.out_f32 = int(out.dtype == torch.float32)
     a.accumulate = int(accumulate)
     a.split_k = split_k
+    a.drop_p, a.drop_seed = drop_p, drop_seed
     if accumulate:
         assert out.dtype == torch.float32
     check(_lib.load().tfasr_gemm(ctypes.byref(a), _stream()), "gemm")
@@ -174,6 +175,13 @@ def bn_apply_bwd(x, dy, fin, bstats, count, act=ACT_NONE, dx=None):
 def cast(src, dst):
     check(_L().tfasr_cast(_p(src), _p(dst), src.numel(), _dt(src), _dt(dst), _stream()), "cast")
     return dst
+
+
+def dropout(x, p, seed, out=None):
+    if out is None:
+        out = torch.empty_like(x)
+    check(_L().tfasr_dropout(_p(x), _p(out), x.numel(), p, seed, _dt(x), _stream()), "dropout")
+    return out
 
 
 def colsum(x2d, out, scale=1.0, rows=None, C=None, ld=None):

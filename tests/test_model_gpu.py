@@ -163,3 +163,51 @@ def test_greedy_decode_tokens_bit_exact(dev, lens, bias):
     np.testing.assert_array_equal(out.tokens.cpu().numpy(), tok_ref.numpy())
     np.testing.assert_array_equal(out.next_tokens.cpu().numpy().reshape(-1), prev_ref.numpy().reshape(-1))
     np.testing.assert_allclose(out.next_decoder_states[:, 0, 0].cpu().numpy(), h_ref.numpy(), rtol=1e-3, atol=1e-4)
+
+
+def test_dropout_kernel_statistics_and_gemm_consistency(dev):
+    from tensorflowasr_amd import kernels as K
+
+    x = torch.ones(1000, 256, device=dev)
+    y = K.dropout(x, 0.1, 1234)
+    keep = (y != 0).float().mean().item()
+    assert abs(keep - 0.9) < 0.005
+    np.testing.assert_allclose(y[y != 0].cpu().numpy(), 1.0 / 0.9, rtol=1e-6)
+    y2 = K.dropout(x, 0.1, 1235)
+    assert (y != y2).any()
+    # the GEMM epilogue draws the SAME mask as the standalone kernel for the same (seed, element index)
+    for dtype in (torch.float32, torch.bfloat16):
+        A = torch.eye(256, device=dev, dtype=dtype)
+        out = K.matmul(torch.ones(1000, 256, device=dev, dtype=dtype), A, drop_p=0.1, drop_seed=1234)
+        np.testing.assert_array_equal((out.float() != 0).cpu().numpy(), (y != 0).cpu().numpy())
+
+
+def test_dropout_backward_consistent_finite_difference(dev):
+    """With dropout ON the regenerated backward masks must match the forward ones: directional finite difference of the
+    mean loss along a random parameter direction vs <grad, direction> (f32 path, fixed mask epoch)."""
+    lens, ulens = [4000, 4000], [6, 5]
+    cfg, ocfg, model, W, data, *_ = _setup(dev, torch.float32, lens, ulens)
+    model.cfg.dropout = 0.2
+    model.use_pred_stream = False
+
+    def loss_at(flat):
+        model.ps.flat.copy_(flat)
+        model.ps.refresh_shadow()
+        model._drop_epoch = 41  # _forward bumps it to 42 every time -> identical masks
+        for k, v in model.ps.state.items():  # undo the moving-average side effect
+            v.copy_(state0[k])
+        return float(model.loss_and_backward(data, True, (None, None), want_backward=False).double().mean())
+
+    state0 = {k: v.clone() for k, v in model.ps.state.items()}
+    base = model.ps.flat.clone()
+    model._drop_epoch = 41
+    model.zero_grad()
+    model.loss_and_backward(data, True, (None, None))
+    g = model.ps.grad.clone()
+    gen = torch.Generator(device="cpu").manual_seed(0)
+    direction = torch.randn(base.numel(), generator=gen).to(dev)
+    direction *= (base != 0).float()  # stay inside real parameters (alignment padding is zero)
+    eps = 2e-3
+    fd = (loss_at(base + eps * direction) - loss_at(base - eps * direction)) / (2 * eps)
+    an = float((g.double() * direction.double()).sum())
+    assert abs(fd - an) < 5e-2 * max(1.0, abs(an)), (fd, an)
