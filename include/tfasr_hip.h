@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define TFASR_ABI_VERSION 3
+#define TFASR_ABI_VERSION 4
 
 typedef enum {
   TFASR_STATUS_SUCCESS = 0,
@@ -61,6 +61,14 @@ int tfasr_rnnt_loss(const void* logits, void* grads, const int32_t* labels, cons
                     const int32_t* logit_len, const float* grad_scale, int B, int T, int U1, int V,
                     int blank, int dtype, float* costs, void* workspace, size_t workspace_bytes,
                     void* stream);
+/* PACKED lattice: only the valid nodes exist.  Utterance b owns rows [cell_off[b], cell_off[b+1]) of logits/grads
+ * [total_cells, V], laid out row-major (t, u) with (label_len[b]+1) columns and logit_len[b] rows; cell_off [B+1] int64
+ * on the device.  Same loss/gradient as the dense entry (padded nodes carry zero gradient there, impl/rnnt.py:218-224),
+ * at sum_b T_b*U1_b instead of B*T*U1 rows.  Workspace: tfasr_rnnt_loss_workspace_size(1, total_cells, 1, V). */
+int tfasr_rnnt_loss_packed(const void* logits, void* grads, const int32_t* labels, const int32_t* label_len,
+                           const int32_t* logit_len, const float* grad_scale, const long* cell_off, long total_cells, int B,
+                           int T, int U1, int V, int blank, int dtype, float* costs, void* workspace,
+                           size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * CTC loss (CtcLoss.call -> tf.nn.ctc_loss(logits_time_major=False, blank_index=0), losses/ctc_loss.py:47-66) and
@@ -173,6 +181,13 @@ int tfasr_embedding_bwd(const int32_t* idx, const void* dout, float* dtable, lon
 int tfasr_joint_fwd(const void* enc, const void* pred, void* h, int B, int T, int U1, int J, int dtype, void* stream);
 int tfasr_joint_bwd(const void* h, const void* dh, void* denc, void* dpred, int B, int T, int U1, int J, int dtype,
                     void* stream);
+/* packed-lattice variants (see tfasr_rnnt_loss_packed): h/dh [total_cells, J]; denc [B,T,J] / dpred [B,U1,J] are dense
+ * (zero outside the valid ranges) */
+int tfasr_joint_fwd_packed(const void* enc, const void* pred, void* h, const long* cell_off, const int32_t* label_len,
+                           long total_cells, int B, int T, int U1, int J, int dtype, void* stream);
+int tfasr_joint_bwd_packed(const void* h, const void* dh, void* denc, void* dpred, const long* cell_off,
+                           const int32_t* label_len, const int32_t* logit_len, int B, int T, int U1, int J, int dtype,
+                           void* stream);
 /* keras Adam step over one flat f32 buffer: p -= lr*wd*p; g' = grad_scale*g (+ 2*l2*p for i < n_reg);
  * m,v update; p -= lr*sqrt(1-b2^t)/(1-b1^t) * m/(sqrt(v)+eps)   (small.yml.j2:73-87; L2: :67-69) */
 int tfasr_adam(float* p, const float* g, float* m, float* v, long n, long n_reg, float lr, float beta1, float beta2,

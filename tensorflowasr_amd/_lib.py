@@ -109,7 +109,7 @@ def load(build_if_missing=True):
     return lib
 
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 def check(status, what=""):

@@ -480,7 +480,7 @@ class ConformerTransducer:
         logits, elen, _ = self._forward(inputs, training, None)
         return TrainOutput(logits=logits, logits_length=torch.tensor(elen, dtype=torch.int32))
 
-    def _forward(self, inputs: TrainInput, training, ctx, masks=None):
+    def _forward(self, inputs: TrainInput, training, ctx, masks=None, joint=True):
         dev = self.device
         self._drop_epoch += 1
         sig = inputs.inputs.to(dev, non_blocking=True)
@@ -502,28 +502,60 @@ class ConformerTransducer:
             main.wait_stream(self.pred_stream)
         else:
             pred = self.prediction_fwd(tokens, plen, ctx)
+        if not joint:
+            return enc, pred, (B, T, U1), elen, elen_dev
         logits = self.joint_fwd(enc, pred, B, T, U1, ctx)
         return logits, elen, elen_dev
 
-    def loss_and_backward(self, data: TrainData, training=True, masks=None, want_backward=True):
+    def loss_and_backward(self, data: TrainData, training=True, masks=None, want_backward=True, packed=True):
         """BaseModel._train_step (base_model.py:149-183): forward, RnntLoss (mean over the batch, rnnt_loss.py:34) and
-        the full backward into the flat gradient buffer (gradients ACCUMULATE; zero_grad() first)."""
+        the full backward into the flat gradient buffer (gradients ACCUMULATE; zero_grad() first).
+
+        packed=True evaluates the joint network and the loss only on the valid lattice nodes (t < logit_len_b,
+        u <= label_len_b): padded nodes carry exactly zero gradient in the reference (impl/rnnt.py:218-224), so skipping them
+        changes no result while removing the padding's share of the largest GEMMs of the step."""
         ctx = {} if want_backward else None
-        logits, elen, elen_dev = self._forward(data.inputs, training, ctx, masks)
-        B, T, U1, V = logits.shape
         dev = self.device
+        ps, c = self.ps, self.cfg
+        enc, pred, (B, T, U1), elen, elen_dev = self._forward(data.inputs, training, ctx, masks, joint=False)
+        J, V = c.joint_dim, c.vocab_size
         labels = data.labels.labels.to(dev, non_blocking=True).to(torch.int32).contiguous()
-        llen = data.labels.labels_length.to(dev, non_blocking=True).to(torch.int32)
+        llen_host = [int(v) for v in data.labels.labels_length.tolist()]
         # BaseLoss.call: logit_length = max(logit_length, label_length)  (losses/base_loss.py:36)
-        tl = [max(int(a), int(b)) for a, b in zip(elen, data.labels.labels_length.tolist())]
+        tl = [min(max(int(a), b), T) for a, b in zip(elen, llen_host)]
+        ul = [min(b, U1 - 1) for b in llen_host]
         tl_dev = torch.tensor(tl, dtype=torch.int32).to(dev, non_blocking=True)
+        ul_dev = torch.tensor(ul, dtype=torch.int32).to(dev, non_blocking=True)
         gscale = torch.full((B,), 1.0 / (B * self.dp.world), dtype=torch.float32, device=dev)
-        t0 = self._tick("rnnt_loss")
-        costs, dlogits = K.rnnt_loss_fwd_bwd(logits, labels, llen, tl_dev, grad_scale=gscale, grads=logits, want_grads=want_backward)
-        self._tock("rnnt_loss", t0)
-        if not want_backward:
-            return costs
-        denc, dpred = self.joint_bwd(dlogits, ctx)
+        if not packed:
+            logits = self.joint_fwd(enc, pred, B, T, U1, ctx)
+            t0 = self._tick("rnnt_loss")
+            costs, dlogits = K.rnnt_loss_fwd_bwd(logits, labels, ul_dev, tl_dev, grad_scale=gscale, grads=logits, want_grads=want_backward)
+            self._tock("rnnt_loss", t0)
+            if not want_backward:
+                return costs
+            denc, dpred = self.joint_bwd(dlogits, ctx)
+        else:
+            off = np.zeros(B + 1, np.int64)
+            off[1:] = np.cumsum([t * (u + 1) for t, u in zip(tl, ul)])
+            total = int(off[-1])
+            off_dev = torch.from_numpy(off).to(dev, non_blocking=True)
+            e = K.matmul(enc, ps.w2d("joint/enc/w"), bias=ps.p("joint/enc/b"))
+            p = K.matmul(pred, ps.w2d("joint/pred/w"), bias=ps.p("joint/pred/b"))
+            h = K.joint_fwd_packed(e.view(B, T, J), p.view(B, U1, J), off_dev, ul_dev, total)
+            t0 = self._tick("joint_vocab_gemm")
+            logits = K.matmul(h, ps.w2d("joint/vocab/w"), bias=ps.p("joint/vocab/b"))  # [total, V]
+            self._tock("joint_vocab_gemm", t0, 2.0 * total * J * V)
+            t0 = self._tick("rnnt_loss")
+            costs, dlogits = K.rnnt_loss_packed(logits, labels, ul_dev, tl_dev, off_dev, total, T, grad_scale=gscale, grads=logits,
+                                                want_grads=want_backward)
+            self._tock("rnnt_loss", t0)
+            if not want_backward:
+                return costs
+            dh = self._dense_bwd(dlogits, h, "joint/vocab/w", "joint/vocab/b")
+            de, dp = K.joint_bwd_packed(h, dh, off_dev, ul_dev, tl_dev, B, T, U1)
+            denc = self._dense_bwd(de.view(B * T, J), enc, "joint/enc/w", "joint/enc/b")
+            dpred = self._dense_bwd(dp.view(B * U1, J), pred, "joint/pred/w", "joint/pred/b")
         main = torch.cuda.current_stream()
         self.dp.grads_ready(self.ps.offsets["joint/enc/w"], self.ps.n_reg)
         if self.use_pred_stream:

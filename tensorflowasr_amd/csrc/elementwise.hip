@@ -336,6 +336,59 @@ __global__ __launch_bounds__(128) void joint_bwd_kernel(const T* __restrict__ h,
   st8(dout + (long)blockIdx.x * J + j, acc);
 }
 
+// packed lattice variants: only the valid nodes (t < Tl_b, u <= Ul_b) exist, utterance b starts at row cell_off[b]
+template <typename T>
+__global__ __launch_bounds__(256) void joint_fwd_packed_kernel(const T* __restrict__ enc, const T* __restrict__ pred,
+                                                               T* __restrict__ h, const long* __restrict__ cell_off,
+                                                               const int32_t* __restrict__ label_len, long nrows, int B, int Tn,
+                                                               int U1, int J) {
+  const int j8 = J / 8;
+  const long n8 = nrows * j8;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+    const int j = (int)(i % j8) * 8;
+    const long row = i / j8;
+    int lo = 0, hi = B;
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (cell_off[mid] <= row) lo = mid; else hi = mid; }
+    const int b = lo, u1b = min(label_len[b], U1 - 1) + 1;
+    const long q = row - cell_off[b];
+    const int t = (int)(q / u1b), u = (int)(q % u1b);
+    float a[8], p[8];
+    ld8(enc + ((long)b * Tn + t) * J + j, a);
+    ld8(pred + ((long)b * U1 + u) * J + j, p);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a[k] = tanhf(a[k] + p[k]);
+    st8(h + i * 8, a);
+  }
+}
+template <typename T, int MODE>
+__global__ __launch_bounds__(128) void joint_bwd_packed_kernel(const T* __restrict__ h, const T* __restrict__ dh,
+                                                               T* __restrict__ dout, const long* __restrict__ cell_off,
+                                                               const int32_t* __restrict__ label_len,
+                                                               const int32_t* __restrict__ logit_len, int B, int Tn, int U1, int J) {
+  const int j = (blockIdx.y * blockDim.x + threadIdx.x) * 8;
+  if (j >= J) return;
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long base = 0, stride = 0;
+  int count = 0;
+  if (MODE == 0) {
+    const int b = blockIdx.x / Tn, t = blockIdx.x % Tn;
+    const int Tl = min(logit_len[b], Tn), u1b = min(label_len[b], U1 - 1) + 1;
+    if (t < Tl) { base = (cell_off[b] + (long)t * u1b) * J; stride = J; count = u1b; }
+  } else {
+    const int b = blockIdx.x / U1, u = blockIdx.x % U1;
+    const int Tl = min(logit_len[b], Tn), u1b = min(label_len[b], U1 - 1) + 1;
+    if (u < u1b) { base = (cell_off[b] + u) * J; stride = (long)u1b * J; count = Tl; }
+  }
+  for (int k = 0; k < count; ++k) {
+    float hv[8], dv[8];
+    ld8(h + base + k * stride + j, hv);
+    ld8(dh + base + k * stride + j, dv);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) acc[q] += dv[q] * (1.f - hv[q] * hv[q]);
+  }
+  st8(dout + (long)blockIdx.x * J + j, acc);
+}
+
 // ----------------------------------------------------------------------------------------- Adam
 // keras.optimizers.Adam semantics (bias-corrected, decoupled weight_decay applied first) + the L2
 // kernel regulariser gradient 2*l2*p on the first n_reg elements (small.yml.j2:67-69,73-87).
@@ -571,6 +624,35 @@ extern "C" int tfasr_joint_bwd(const void* h, const void* dh, void* denc, void* 
                hipLaunchKernelGGL((joint_bwd_kernel<float, 1>), g1, dim3(128), 0, s, (const float*)h, (const float*)dh, (float*)dpred, B, T, U1, J); },
              { hipLaunchKernelGGL((joint_bwd_kernel<bf16_t, 0>), g0, dim3(128), 0, s, (const bf16_t*)h, (const bf16_t*)dh, (bf16_t*)denc, B, T, U1, J);
                hipLaunchKernelGGL((joint_bwd_kernel<bf16_t, 1>), g1, dim3(128), 0, s, (const bf16_t*)h, (const bf16_t*)dh, (bf16_t*)dpred, B, T, U1, J); });
+  TFASR_CHECK_LAUNCH();
+  return TFASR_STATUS_SUCCESS;
+}
+
+extern "C" int tfasr_joint_fwd_packed(const void* enc, const void* pred, void* h, const long* cell_off, const int32_t* label_len,
+                                      long total_cells, int B, int T, int U1, int J, int dtype, void* stream_) {
+  if (!enc || !pred || !h || !cell_off || !label_len || total_cells <= 0 || B <= 0 || T <= 0 || U1 <= 0 || J <= 0 || J % 8)
+    return TFASR_STATUS_INVALID_VALUE;
+  hipStream_t s = (hipStream_t)stream_;
+  const int grid = flat_grid(total_cells * J / 8);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(joint_fwd_packed_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)enc, (const float*)pred, (float*)h, cell_off, label_len, total_cells, B, T, U1, J),
+             hipLaunchKernelGGL(joint_fwd_packed_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)enc, (const bf16_t*)pred, (bf16_t*)h, cell_off, label_len, total_cells, B, T, U1, J));
+  TFASR_CHECK_LAUNCH();
+  return TFASR_STATUS_SUCCESS;
+}
+extern "C" int tfasr_joint_bwd_packed(const void* h, const void* dh, void* denc, void* dpred, const long* cell_off,
+                                      const int32_t* label_len, const int32_t* logit_len, int B, int T, int U1, int J, int dtype,
+                                      void* stream_) {
+  if (!h || !dh || !denc || !dpred || !cell_off || !label_len || !logit_len || B <= 0 || T <= 0 || U1 <= 0 || J <= 0 || J % 8)
+    return TFASR_STATUS_INVALID_VALUE;
+  hipStream_t s = (hipStream_t)stream_;
+  const int gy = (J / 8 + 127) / 128;
+  dim3 g0(B * T, gy), g1(B * U1, gy);
+  DISPATCH_T(dtype,
+             { hipLaunchKernelGGL((joint_bwd_packed_kernel<float, 0>), g0, dim3(128), 0, s, (const float*)h, (const float*)dh, (float*)denc, cell_off, label_len, logit_len, B, T, U1, J);
+               hipLaunchKernelGGL((joint_bwd_packed_kernel<float, 1>), g1, dim3(128), 0, s, (const float*)h, (const float*)dh, (float*)dpred, cell_off, label_len, logit_len, B, T, U1, J); },
+             { hipLaunchKernelGGL((joint_bwd_packed_kernel<bf16_t, 0>), g0, dim3(128), 0, s, (const bf16_t*)h, (const bf16_t*)dh, (bf16_t*)denc, cell_off, label_len, logit_len, B, T, U1, J);
+               hipLaunchKernelGGL((joint_bwd_packed_kernel<bf16_t, 1>), g1, dim3(128), 0, s, (const bf16_t*)h, (const bf16_t*)dh, (bf16_t*)dpred, cell_off, label_len, logit_len, B, T, U1, J); });
   TFASR_CHECK_LAUNCH();
   return TFASR_STATUS_SUCCESS;
 }

@@ -35,23 +35,42 @@ __device__ __forceinline__ void online_merge(RowStat& a, float m2, float s2) {
   a.m = m;
 }
 
+// lattice node addressing: dense [B,T,U1] (cell_off == nullptr) or PACKED (only the valid nodes t < Tl_b, u <= Ul_b of
+// every utterance, utterance b starting at row cell_off[b], row-major (t,u) with U1_b = Ul_b+1 columns).
+struct Cell { int b, t, u, Tl, Ul; bool valid; };
+__device__ __forceinline__ Cell locate(long r, const long* __restrict__ cell_off, int B, int Tm, int U1,
+                                       const int32_t* __restrict__ label_len, const int32_t* __restrict__ logit_len) {
+  Cell c;
+  if (cell_off) {
+    int lo = 0, hi = B;  // largest b with cell_off[b] <= r
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (cell_off[mid] <= r) lo = mid; else hi = mid; }
+    c.b = lo;
+    c.Tl = min(logit_len[lo], Tm); c.Ul = min(label_len[lo], U1 - 1);
+    const long q = r - cell_off[lo];
+    c.t = (int)(q / (c.Ul + 1)); c.u = (int)(q % (c.Ul + 1));
+    c.valid = true;
+  } else {
+    c.u = (int)(r % U1); c.t = (int)((r / U1) % Tm); c.b = (int)(r / ((long)U1 * Tm));
+    c.Tl = min(logit_len[c.b], Tm); c.Ul = min(label_len[c.b], U1 - 1);
+    c.valid = (c.t < c.Tl && c.u <= c.Ul);
+  }
+  return c;
+}
+
 // ---------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void rnnt_logprobs_kernel(
     const T* __restrict__ logits, const int32_t* __restrict__ labels, const int32_t* __restrict__ label_len,
-    const int32_t* __restrict__ logit_len, int B, int Tm, int U1, int V, float* __restrict__ lse,
-    float* __restrict__ blank_lp, float* __restrict__ truth_lp) {
+    const int32_t* __restrict__ logit_len, const long* __restrict__ cell_off, long nrows, int B, int Tm, int U1, int V,
+    float* __restrict__ lse, float* __restrict__ blank_lp, float* __restrict__ truth_lp) {
   const int lane = threadIdx.x & 63;
-  const long nrows = (long)B * Tm * U1;
   const long wave0 = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const long nwaves = (long)gridDim.x * (blockDim.x >> 6);
   const bool vec_ok = (V % 8 == 0);
   for (long r = wave0; r < nrows; r += nwaves) {
-    const int u = (int)(r % U1);
-    const int t = (int)((r / U1) % Tm);
-    const int b = (int)(r / ((long)U1 * Tm));
-    const int Tl = min(logit_len[b], Tm), Ul = min(label_len[b], U1 - 1);
-    if (t >= Tl || u > Ul) continue;  // padded node: never read by the lattice / grad kernels
+    const Cell cl = locate(r, cell_off, B, Tm, U1, label_len, logit_len);
+    const int u = cl.u, b = cl.b;
+    if (!cl.valid) continue;  // padded node: never read by the lattice / grad kernels
     const T* row = logits + r * V;
     RowStat st{-INFINITY, 0.f};
     if (vec_ok) {
@@ -88,14 +107,15 @@ __global__ __launch_bounds__(256) void rnnt_logprobs_kernel(
 // grid = (B, 2): y==0 -> alpha (forward), y==1 -> beta (backward). blockDim.x >= U1 (multiple of 64).
 __global__ void rnnt_lattice_kernel(const float* __restrict__ blank_lp, const float* __restrict__ truth_lp,
                                     const int32_t* __restrict__ label_len, const int32_t* __restrict__ logit_len,
-                                    int Tm, int U1, float* __restrict__ alpha, float* __restrict__ beta,
-                                    float* __restrict__ costs) {
+                                    const long* __restrict__ cell_off, int Tm, int U1m, float* __restrict__ alpha,
+                                    float* __restrict__ beta, float* __restrict__ costs) {
   extern __shared__ float sh[];  // 2 * blockDim.x floats
   const int b = blockIdx.x;
   const int u = threadIdx.x;
   const int nthr = blockDim.x;
-  const int Tl = min(logit_len[b], Tm), Ul = min(label_len[b], U1 - 1);
-  const long base = (long)b * Tm * U1;
+  const int Tl = min(logit_len[b], Tm), Ul = min(label_len[b], U1m - 1);
+  const int U1 = cell_off ? Ul + 1 : U1m;  // row stride of this utterance's lattice
+  const long base = cell_off ? cell_off[b] : (long)b * Tm * U1m;
   const float* bl = blank_lp + base;
   const float* tr = truth_lp + base;
   float* buf0 = sh;
@@ -180,22 +200,20 @@ template <typename T>
 __global__ __launch_bounds__(256) void rnnt_grad_kernel(
     const T* logits, T* grads, const int32_t* __restrict__ labels,
     const int32_t* __restrict__ label_len, const int32_t* __restrict__ logit_len,
-    const float* __restrict__ grad_scale, int B, int Tm, int U1, int V, const float* __restrict__ lse,
-    const float* __restrict__ blank_lp, const float* __restrict__ truth_lp, const float* __restrict__ alpha,
-    const float* __restrict__ beta) {
+    const float* __restrict__ grad_scale, const long* __restrict__ cell_off, long nrows, int B, int Tm, int U1, int V,
+    const float* __restrict__ lse, const float* __restrict__ blank_lp, const float* __restrict__ truth_lp,
+    const float* __restrict__ alpha, const float* __restrict__ beta) {
   const int lane = threadIdx.x & 63;
-  const long nrows = (long)B * Tm * U1;
   const long wave0 = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const long nwaves = (long)gridDim.x * (blockDim.x >> 6);
   const bool vec_ok = (V % 8 == 0);
   for (long r = wave0; r < nrows; r += nwaves) {
-    const int u = (int)(r % U1);
-    const int t = (int)((r / U1) % Tm);
-    const int b = (int)(r / ((long)U1 * Tm));
-    const int Tl = min(logit_len[b], Tm), Ul = min(label_len[b], U1 - 1);
+    const Cell cl = locate(r, cell_off, B, Tm, U1, label_len, logit_len);
+    const int u = cl.u, t = cl.t, b = cl.b, Tl = cl.Tl, Ul = cl.Ul;
+    const int ustride = cell_off ? Ul + 1 : U1;
     const T* row = logits + r * V;
     T* out = grads + r * V;
-    if (t >= Tl || u > Ul) {  // outside the lattice: zero gradient (impl/rnnt.py masks :218-224)
+    if (!cl.valid) {  // outside the lattice: zero gradient (impl/rnnt.py masks :218-224)
       if (vec_ok) {
         const float z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         for (int v0 = lane * 8; v0 < V; v0 += 64 * 8) st8(out + v0, z);
@@ -204,11 +222,11 @@ __global__ __launch_bounds__(256) void rnnt_grad_kernel(
       }
       continue;
     }
-    const long lb = (long)b * Tm * U1;
+    const long lb = cell_off ? cell_off[b] : (long)b * Tm * U1;
     const float b00 = beta[lb];
     const float a = alpha[r];
     float gb = 0.f, gt = 0.f;
-    if (t < Tl - 1) gb = -__expf(a + beta[r + U1] + blank_lp[r] - b00);
+    if (t < Tl - 1) gb = -__expf(a + beta[r + ustride] + blank_lp[r] - b00);
     else if (u == Ul) gb = -1.f;
     int lab = -1;
     if (u < Ul) {
@@ -254,54 +272,64 @@ extern "C" int tfasr_rnnt_loss_workspace_size(int B, int T, int U1, int V, size_
   return TFASR_STATUS_SUCCESS;
 }
 
-extern "C" int tfasr_rnnt_loss(const void* logits, void* grads, const int32_t* labels, const int32_t* label_len,
-                               const int32_t* logit_len, const float* grad_scale, int B, int T, int U1, int V,
-                               int blank, int dtype, float* costs, void* workspace, size_t workspace_bytes,
-                               void* stream_) {
+static int rnnt_impl(const void* logits, void* grads, const int32_t* labels, const int32_t* label_len,
+                     const int32_t* logit_len, const float* grad_scale, const long* cell_off, long nrows, int B, int T, int U1,
+                     int V, int blank, int dtype, float* costs, void* workspace, size_t workspace_bytes, void* stream_) {
   if (!logits || !labels || !label_len || !logit_len || !costs || !workspace) return TFASR_STATUS_INVALID_VALUE;
   if (blank != 0) return TFASR_STATUS_UNSUPPORTED;  // losses/base_loss.py:24
-  if (B <= 0 || T <= 0 || U1 <= 0 || V <= 1 || U1 > 1024) return TFASR_STATUS_INVALID_VALUE;
-  size_t need = 0;
-  tfasr_rnnt_loss_workspace_size(B, T, U1, V, &need);
-  if (workspace_bytes < need) return TFASR_STATUS_INVALID_VALUE;
-  hipStream_t stream = (hipStream_t)stream_;
-  const size_t n = (size_t)B * T * U1;
+  if (B <= 0 || T <= 0 || U1 <= 0 || V <= 1 || U1 > 1024 || nrows <= 0) return TFASR_STATUS_INVALID_VALUE;
+  const size_t n = (size_t)nrows;
   const size_t seg = align256(n * sizeof(float));
+  if (workspace_bytes < 5 * seg) return TFASR_STATUS_INVALID_VALUE;
+  hipStream_t stream = (hipStream_t)stream_;
   char* ws = (char*)workspace;
   float* lse = (float*)(ws);
   float* blank_lp = (float*)(ws + seg);
   float* truth_lp = (float*)(ws + 2 * seg);
   float* alpha = (float*)(ws + 3 * seg);
   float* beta = (float*)(ws + 4 * seg);
-
-  const long nrows = (long)n;
   const int wpb = 4;
   int grid = (int)std::min<long>((nrows + wpb - 1) / wpb, 256L * 32);
   if (dtype == TFASR_F32)
     hipLaunchKernelGGL(rnnt_logprobs_kernel<float>, dim3(grid), dim3(256), 0, stream, (const float*)logits, labels,
-                       label_len, logit_len, B, T, U1, V, lse, blank_lp, truth_lp);
+                       label_len, logit_len, cell_off, nrows, B, T, U1, V, lse, blank_lp, truth_lp);
   else if (dtype == TFASR_BF16)
     hipLaunchKernelGGL(rnnt_logprobs_kernel<bf16_t>, dim3(grid), dim3(256), 0, stream, (const bf16_t*)logits, labels,
-                       label_len, logit_len, B, T, U1, V, lse, blank_lp, truth_lp);
+                       label_len, logit_len, cell_off, nrows, B, T, U1, V, lse, blank_lp, truth_lp);
   else
     return TFASR_STATUS_INVALID_VALUE;
   TFASR_CHECK_LAUNCH();
-
   const int nthr = ((U1 + 63) / 64) * 64;
   hipLaunchKernelGGL(rnnt_lattice_kernel, dim3(B, 2), dim3(nthr), 2 * nthr * sizeof(float), stream, blank_lp,
-                     truth_lp, label_len, logit_len, T, U1, alpha, beta, costs);
+                     truth_lp, label_len, logit_len, cell_off, T, U1, alpha, beta, costs);
   TFASR_CHECK_LAUNCH();
-
   if (grads) {
     if (dtype == TFASR_F32)
       hipLaunchKernelGGL(rnnt_grad_kernel<float>, dim3(grid), dim3(256), 0, stream, (const float*)logits,
-                         (float*)grads, labels, label_len, logit_len, grad_scale, B, T, U1, V, lse, blank_lp,
+                         (float*)grads, labels, label_len, logit_len, grad_scale, cell_off, nrows, B, T, U1, V, lse, blank_lp,
                          truth_lp, alpha, beta);
     else
       hipLaunchKernelGGL(rnnt_grad_kernel<bf16_t>, dim3(grid), dim3(256), 0, stream, (const bf16_t*)logits,
-                         (bf16_t*)grads, labels, label_len, logit_len, grad_scale, B, T, U1, V, lse, blank_lp,
+                         (bf16_t*)grads, labels, label_len, logit_len, grad_scale, cell_off, nrows, B, T, U1, V, lse, blank_lp,
                          truth_lp, alpha, beta);
     TFASR_CHECK_LAUNCH();
   }
   return TFASR_STATUS_SUCCESS;
+}
+
+extern "C" int tfasr_rnnt_loss(const void* logits, void* grads, const int32_t* labels, const int32_t* label_len,
+                               const int32_t* logit_len, const float* grad_scale, int B, int T, int U1, int V,
+                               int blank, int dtype, float* costs, void* workspace, size_t workspace_bytes,
+                               void* stream_) {
+  return rnnt_impl(logits, grads, labels, label_len, logit_len, grad_scale, nullptr, (long)B * T * U1, B, T, U1, V, blank, dtype,
+                   costs, workspace, workspace_bytes, stream_);
+}
+
+extern "C" int tfasr_rnnt_loss_packed(const void* logits, void* grads, const int32_t* labels, const int32_t* label_len,
+                                      const int32_t* logit_len, const float* grad_scale, const long* cell_off, long total_cells,
+                                      int B, int T, int U1, int V, int blank, int dtype, float* costs, void* workspace,
+                                      size_t workspace_bytes, void* stream_) {
+  if (!cell_off) return TFASR_STATUS_INVALID_VALUE;
+  return rnnt_impl(logits, grads, labels, label_len, logit_len, grad_scale, cell_off, total_cells, B, T, U1, V, blank, dtype,
+                   costs, workspace, workspace_bytes, stream_);
 }

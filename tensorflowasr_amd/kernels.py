@@ -79,6 +79,22 @@ def rnnt_loss_fwd_bwd(logits, labels, label_len, logit_len, grad_scale=None, gra
     return costs, (grads if want_grads else None)
 
 
+def rnnt_loss_packed(logits, labels, label_len, logit_len, cell_off, total_cells, T, grad_scale=None, grads=None, want_grads=True, blank=0):
+    """logits [total_cells, V] over the packed lattice (see include/tfasr_hip.h) -> (costs [B], grads)."""
+    assert logits.dim() == 2 and logits.is_contiguous() and cell_off.dtype == torch.int64
+    B, U = labels.shape
+    V = logits.shape[1]
+    costs = torch.empty(B, dtype=torch.float32, device=logits.device)
+    if want_grads and grads is None:
+        grads = torch.empty_like(logits)
+    nbytes = rnnt_loss_workspace_size(1, total_cells, 1, V)
+    ws = workspace(nbytes, logits.device, "rnnt")
+    check(_lib.load().tfasr_rnnt_loss_packed(
+        _p(logits), _p(grads) if want_grads else None, _p(labels), _p(label_len), _p(logit_len), _p(grad_scale), _p(cell_off),
+        total_cells, B, T, U + 1, V, blank, _dt(logits), _p(costs), _p(ws), ws.numel(), _stream()), "rnnt_loss_packed")
+    return costs, (grads if want_grads else None)
+
+
 # ---------------------------------------------------------------------------------------------- GEMM
 def gemm(A, B, out, M, N, K, lda, ldb, ldd, trans_a=False, trans_b=False, bias=None, res=None, dact_z=None,
          prez=None, alpha=1.0, beta=1.0, act=ACT_NONE, dact=ACT_NONE, nb1=1, nb2=1, sA=(0, 0), sB=(0, 0), sD=(0, 0),
@@ -261,6 +277,22 @@ def joint_bwd(h, dh):
     denc = torch.empty(B, T, J, dtype=h.dtype, device=h.device)
     dpred = torch.empty(B, U1, J, dtype=h.dtype, device=h.device)
     check(_L().tfasr_joint_bwd(_p(h), _p(dh), _p(denc), _p(dpred), B, T, U1, J, _dt(h), _stream()), "joint_bwd")
+    return denc, dpred
+
+
+def joint_fwd_packed(enc, pred, cell_off, label_len, total_cells):
+    B, T, J = enc.shape
+    U1 = pred.shape[1]
+    h = torch.empty(total_cells, J, dtype=enc.dtype, device=enc.device)
+    check(_L().tfasr_joint_fwd_packed(_p(enc), _p(pred), _p(h), _p(cell_off), _p(label_len), total_cells, B, T, U1, J, _dt(enc), _stream()), "joint_fwd_packed")
+    return h
+
+
+def joint_bwd_packed(h, dh, cell_off, label_len, logit_len, B, T, U1):
+    J = h.shape[1]
+    denc = torch.empty(B, T, J, dtype=h.dtype, device=h.device)
+    dpred = torch.empty(B, U1, J, dtype=h.dtype, device=h.device)
+    check(_L().tfasr_joint_bwd_packed(_p(h), _p(dh), _p(denc), _p(dpred), _p(cell_off), _p(label_len), _p(logit_len), B, T, U1, J, _dt(h), _stream()), "joint_bwd_packed")
     return denc, dpred
 
 

@@ -116,3 +116,29 @@ def test_reference_smoke_shape(dev):
     rl, rg = rnnt_ref.rnnt_loss_and_grad(logits.numpy(), labels.numpy(), ul.numpy(), tl.numpy(), np.float64)
     np.testing.assert_allclose(costs.cpu().numpy(), rl, rtol=1e-5)
     np.testing.assert_allclose(grads.cpu().numpy(), rg, rtol=1e-2, atol=1e-4)  # 943-diagonal f32 lattice (like the f32 TF reference) + __expf
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_packed_lattice_equals_dense(dev, dtype):
+    """tfasr_rnnt_loss_packed on the valid nodes only == the dense entry (padded nodes have zero gradient)."""
+    B, T, U, V = 5, 23, 9, 64
+    rng = np.random.default_rng(9)
+    logits = rng.standard_normal((B, T, U + 1, V)).astype(np.float32)
+    labels = rng.integers(1, V, (B, U)).astype(np.int32)
+    tl = np.array([23, 11, 17, 1, 20], np.int32)
+    ul = np.array([9, 3, 0, 1, 9], np.int32)
+    scale = rng.uniform(0.5, 2, B).astype(np.float32)
+    dense = torch.from_numpy(logits).to(dev).to(dtype)
+    costs_d, g_d = kernels.rnnt_loss_fwd_bwd(dense, torch.from_numpy(labels).to(dev), torch.from_numpy(ul).to(dev),
+                                             torch.from_numpy(tl).to(dev), grad_scale=torch.from_numpy(scale).to(dev))
+    off = np.zeros(B + 1, np.int64)
+    off[1:] = np.cumsum(tl.astype(np.int64) * (ul + 1))
+    packed = torch.cat([dense[b, :tl[b], :ul[b] + 1].reshape(-1, V) for b in range(B)]).contiguous()
+    costs_p, g_p = kernels.rnnt_loss_packed(packed, torch.from_numpy(labels).to(dev), torch.from_numpy(ul).to(dev), torch.from_numpy(tl).to(dev),
+                                            torch.from_numpy(off).to(dev), int(off[-1]), T, grad_scale=torch.from_numpy(scale).to(dev))
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(costs_p.cpu().numpy(), costs_d.cpu().numpy(), rtol=1e-6)
+    want = torch.cat([g_d[b, :tl[b], :ul[b] + 1].reshape(-1, V) for b in range(B)])
+    np.testing.assert_array_equal(g_p.float().cpu().numpy(), want.float().cpu().numpy())
+    ref_loss, _ = rnnt_ref.rnnt_loss_and_grad(dense.float().cpu().numpy(), labels, ul, tl)
+    np.testing.assert_allclose(costs_p.cpu().numpy(), ref_loss, rtol=1e-3 if dtype == torch.bfloat16 else 1e-5)
