@@ -195,6 +195,10 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     value = (secs_total / 3600.0) / dt
 
+    if rank == 0 and os.environ.get("TFASR_BENCH_SECTIONS"):
+        torch.cuda.synchronize()
+        for name, tm in sorted(model.timers.items()):
+            sys.stderr.write(f"[section] {name:18s} {sum(a.elapsed_time(b) for a, b in tm) / args.steps:8.3f} ms/step over {len(tm) // args.steps} calls\n")
     if rank == 0:
         roof = None
         tm = model.timers.get("joint_vocab_gemm") or []

@@ -352,10 +352,18 @@ class ConformerTransducer:
         p = f"enc/block{i}/"
         ps = self.ps
         site = 16 + i * 8
+        t0 = self._tick("ffm_fwd")
         x = self._ffm_fwd(x, p + "ff1/", ctx, site, training)
+        self._tock("ffm_fwd", t0)
+        t0 = self._tick("mhsa_fwd")
         x = self._mhsa_fwd(x, p + "mhsa/", B, T, elen_dev, ctx, site + 2, training)
+        self._tock("mhsa_fwd", t0)
+        t0 = self._tick("convm_fwd")
         x = self._convm_fwd(x, p + "conv/", B, T, training, ctx, site + 3)
+        self._tock("convm_fwd", t0)
+        t0 = self._tick("ffm_fwd")
         x = self._ffm_fwd(x, p + "ff2/", ctx, site + 4, training)
+        self._tock("ffm_fwd", t0)
         y, mean, rstd = K.layernorm_fwd(x, ps.p(p + "ln/g"), ps.p(p + "ln/b"))
         if ctx is not None:
             ctx[p + "ln"] = dict(x=x, mean=mean, rstd=rstd)
@@ -366,16 +374,26 @@ class ConformerTransducer:
         ps = self.ps
         s = ctx.pop(p + "ln")
         dx = K.layernorm_bwd(dy, s["x"], ps.p(p + "ln/g"), s["mean"], s["rstd"], ps.g(p + "ln/g"), ps.g(p + "ln/b"))
+        t0 = self._tick("ffm_bwd")
         dx = self._ffm_bwd(dx, p + "ff2/", ctx)
+        self._tock("ffm_bwd", t0)
+        t0 = self._tick("convm_bwd")
         dx = self._convm_bwd(dx, p + "conv/", B, T, ctx)
+        self._tock("convm_bwd", t0)
+        t0 = self._tick("mhsa_bwd")
         dx = self._mhsa_bwd(dx, p + "mhsa/", B, T, elen_dev, ctx)
+        self._tock("mhsa_bwd", t0)
+        t0 = self._tick("ffm_bwd")
         dx = self._ffm_bwd(dx, p + "ff1/", ctx)
+        self._tock("ffm_bwd", t0)
         return dx
 
     # =================================================================================== encoder
     def encoder_fwd(self, feats, flen, training, ctx):
         """ConformerEncoder.call (conformer.py:672-701): subsample -> linear -> relpe -> blocks.  -> [B*T', d], T', lengths."""
+        t0 = self._tick("subsampling_fwd")
         x, T, elen = self._subsampling_fwd(feats, flen, training, ctx)
+        self._tock("subsampling_fwd", t0)
         B = feats.shape[0]
         elen_dev = torch.tensor(elen, dtype=torch.int32).to(self.device, non_blocking=True)
         for i in range(self.cfg.num_blocks):
@@ -389,7 +407,9 @@ class ConformerTransducer:
         for i in reversed(range(self.cfg.num_blocks)):
             dx = self._block_bwd(dx, i, e["B"], e["T"], e["elen_dev"], ctx)
             self._bucket_after_block(i)
+        t0 = self._tick("subsampling_bwd")
         self._subsampling_bwd(dx, ctx)
+        self._tock("subsampling_bwd", t0)
 
     def _bucket_after_block(self, i):
         lo = self.ps.offsets[f"enc/block{i}/ff1/ln/g"]

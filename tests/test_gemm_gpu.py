@@ -15,7 +15,8 @@ def _tol(dtype):
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, False), (True, True)])
-@pytest.mark.parametrize("mnk", [(128, 128, 64), (200, 144, 144), (77, 1000, 320), (300, 36, 250), (5, 7, 3), (256, 576, 2880)])
+@pytest.mark.parametrize("mnk", [(128, 128, 64), (200, 144, 144), (77, 1000, 320), (300, 36, 250), (5, 7, 3), (256, 576, 2880),
+                                 (595, 64, 600), (200, 64, 136), (130, 48, 64)])
 def test_layouts(dev, dtype, ta, tb, mnk):
     M, N, K = mnk
     g = torch.Generator().manual_seed(M * 7 + N)
@@ -90,3 +91,30 @@ def test_split_k_accumulate(dev):
         ref = 1.0 + Xd.float().cpu().T @ Yd.float().cpu()
         rtol, atol = _tol(dtype)
         np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=rtol, atol=atol * 70)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_attention_product_shapes_narrow_tile(dev, dtype):
+    """probs @ v and probs^T @ dctx with head size 64 and a padded score stride (the N<=64 tile variant + tr-read path)."""
+    Bn, T, H, dh = 2, 75, 4, 64
+    Tp = 80
+    g = torch.Generator().manual_seed(5)
+    probs = torch.zeros(Bn, H, T, Tp)
+    probs[..., :T] = torch.rand(Bn, H, T, T, generator=g)
+    qkv = torch.randn(Bn * T, 3 * H * dh, generator=g)
+    pd, qd = probs.to(dev).to(dtype), qkv.to(dev).to(dtype)
+    HD = H * dh
+    vv = qd[:, 2 * HD:]
+    att = torch.empty(Bn * T, HD, device=dev, dtype=dtype)
+    kernels.gemm(pd, vv, att, T, dh, T, Tp, 3 * HD, HD, nb1=Bn, nb2=H, sA=(H * T * Tp, T * Tp), sB=(T * 3 * HD, dh), sD=(T * HD, dh))
+    v4 = qd.float().cpu()[:, 2 * HD:].view(Bn, T, H, dh)
+    ref = torch.einsum("bhts,bshe->bthe", pd.float().cpu()[..., :T], v4).reshape(Bn * T, HD)
+    rtol, atol = _tol(dtype)
+    np.testing.assert_allclose(att.float().cpu().numpy(), ref.numpy(), rtol=rtol, atol=atol * 6)
+    # dv = probs^T @ datt  (trans_a on the padded-stride score matrix)
+    datt = torch.randn(Bn * T, HD, generator=g).to(dev).to(dtype)
+    dv = torch.zeros(Bn * T, 3 * HD, device=dev, dtype=dtype)
+    kernels.gemm(pd, datt, dv[:, 2 * HD:], T, dh, T, Tp, HD, 3 * HD, trans_a=True, nb1=Bn, nb2=H, sA=(H * T * Tp, T * Tp), sB=(T * HD, dh), sD=(T * 3 * HD, dh))
+    ref = torch.einsum("bhts,bthe->bshe", pd.float().cpu()[..., :T], datt.float().cpu().view(Bn, T, H, dh)).reshape(Bn * T, HD)
+    np.testing.assert_allclose(dv[:, 2 * HD:].float().cpu().numpy(), ref.numpy(), rtol=rtol, atol=atol * 6)
+    assert dv[:, :2 * HD].abs().max().item() == 0

@@ -55,6 +55,42 @@ def probe_gemm():
                               "TFLOPs": 2.0 * M * N * K / ms / 1e9}))
 
 
+
+
+def probe_modelgemm():
+    """The GEMM shapes of one Conformer-M step (B=32, T'=595): (M, N, K, ta, tb, batch, count per step)."""
+    dt = torch.bfloat16
+    R = 19040
+    shapes = [
+        ("ffn1 fwd", R, 1024, 256, 0, 0, 1, 32), ("ffn2 fwd", R, 256, 1024, 0, 0, 1, 32),
+        ("ffn2 dgrad", R, 1024, 256, 0, 1, 1, 32), ("ffn1 dgrad", R, 256, 1024, 0, 1, 1, 32),
+        ("ffn1 wgrad", 256, 1024, R, 1, 0, 1, 32), ("ffn2 wgrad", 1024, 256, R, 1, 0, 1, 32),
+        ("qkv fwd", R, 768, 256, 0, 0, 1, 16), ("proj fwd (o/pw2)", R, 256, 256, 0, 0, 1, 32), ("pw1 fwd", R, 512, 256, 0, 0, 1, 16),
+        ("proj wgrad", 256, 256, R, 1, 0, 1, 32), ("qkv wgrad", 256, 768, R, 1, 0, 1, 16),
+        ("attn content (NT)", 595, 595, 64, 0, 1, 128, 48), ("attn PV (NN)", 595, 64, 595, 0, 0, 128, 48), ("attn dV (TN)", 595, 64, 595, 1, 0, 128, 32),
+        ("attn pos (NT)", 595, 1190, 64, 0, 1, 128, 16), ("attn dqv (NN)", 595, 64, 1190, 0, 0, 128, 16),
+        ("conv2 fwd", 380800, 256, 2304, 0, 0, 1, 1), ("conv2 dgrad", 380800, 2304, 256, 0, 1, 1, 1), ("conv2 wgrad", 2304, 256, 380800, 1, 0, 1, 1),
+        ("linear fwd", R, 256, 5120, 0, 0, 1, 1), ("joint vocab fwd", 590000, 1000, 640, 0, 0, 1, 1),
+        ("joint vocab dgrad", 590000, 640, 1000, 0, 1, 1, 1), ("joint vocab wgrad", 640, 1000, 590000, 1, 0, 1, 1),
+    ]
+    tot = 0.0
+    for name, M, N, Kd, ta, tb, nb, cnt in shapes:
+        A = torch.randn(nb, *((Kd, M) if ta else (M, Kd)), device=dev).to(dt)
+        B = torch.randn(nb, *((N, Kd) if tb else (Kd, N)), device=dev).to(dt)
+        acc = bool(ta) and nb == 1
+        out = torch.zeros(nb, M, N, device=dev, dtype=torch.float32 if acc else dt)
+        tiles = -(-M // 128) * -(-N // 128)
+        sk = 1 if (not acc or tiles >= 512 or Kd <= 2048) else int(max(1, min(-(-1024 // tiles), Kd // 1024, 64)))
+        lda, ldb = A.shape[2], B.shape[2]
+        fn = lambda: kernels.gemm(A, B, out, M, N, Kd, lda, ldb, N, trans_a=bool(ta), trans_b=bool(tb), nb1=nb, sA=(A.shape[1] * A.shape[2], 0),
+                                  sB=(B.shape[1] * B.shape[2], 0), sD=(M * N, 0), accumulate=acc, split_k=sk)
+        ms = timeit(fn, iters=10)
+        tot += ms * cnt
+        print(json.dumps({"gemm": name, "mnk": [M, N, Kd], "batch": nb, "split_k": sk, "us": round(ms * 1e3, 1), "TFLOPs": round(2.0 * nb * M * N * Kd / ms / 1e9, 1),
+                          "ms_per_step": round(ms * cnt, 2)}))
+    print(json.dumps({"sum_ms_per_step": round(tot, 2)}))
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["rnnt", "gemm"]
     for w in which:
