@@ -88,11 +88,16 @@ __device__ __forceinline__ float swishf_(float x) { return x * sigmoidf_(x); }
 // d/dx [x * sigmoid(x)] = s + x*s*(1-s)
 __device__ __forceinline__ float dswishf_(float x) { const float s = sigmoidf_(x); return s * (1.f + x * (1.f - s)); }
 
-// counter-based dropout mask: keep iff the mixed 64-bit (seed, index) hash, as a uniform in [0,1), is >= p
+// counter-based dropout mask: keep iff a 32-bit avalanche hash of (seed, element index), as a uniform in [0,1), is >= p.
+// Two 32-bit multiplies per element (murmur3 finaliser); the seed and the index's high word are folded in first.
+__device__ __forceinline__ uint32_t fmix32(uint32_t x) {
+  x ^= x >> 16; x *= 0x85ebca6bu; x ^= x >> 13; x *= 0xc2b2ae35u; x ^= x >> 16;
+  return x;
+}
 __device__ __forceinline__ bool drop_keep(uint64_t seed, uint64_t idx, float p) {
-  uint64_t x = idx + seed * 0x9E3779B97F4A7C15ull;
-  x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33;
-  return (float)(uint32_t)(x >> 40) * (1.0f / 16777216.0f) >= p;
+  const uint32_t k = (uint32_t)seed * 0x9E3779B1u ^ (uint32_t)(seed >> 32) ^ ((uint32_t)(idx >> 32) * 0x7FEB352Du);
+  const uint32_t h = fmix32((uint32_t)idx ^ k);
+  return (float)(h >> 8) * (1.0f / 16777216.0f) >= p;
 }
 
 // log(exp(a)+exp(b)) with -inf handling (the 2-term log-sum-exp of losses/impl/rnnt.py:72-78,126)

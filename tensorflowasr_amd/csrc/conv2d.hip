@@ -11,21 +11,31 @@ namespace {
 inline int flat_grid(long n) { return (int)std::max<long>(1, std::min<long>((n + 255) / 256, 256L * 32)); }
 
 // y[b,t,f,c] = bias[c] + sum_{kh,kw} w[kh,kw,0,c] * x[b, 2t+kh-2, 2f+kw-2]
+// The grid stride is a multiple of C/8, so every thread keeps ONE channel group: its 72 taps + 8 biases live in registers.
 template <typename T>
 __global__ __launch_bounds__(256) void conv1_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ bias, T* __restrict__ y, int B, int T0,
                                                         int F0, int T1, int F1, int C) {
   const int c8n = C / 8;
   const long n8 = (long)B * T1 * F1 * c8n;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
-    const int c = (int)(i % c8n) * 8;
+  const long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long stride = (long)gridDim.x * blockDim.x;  // host guarantees stride % c8n == 0
+  const int c = (int)(i0 % c8n) * 8;
+  float wr[9][8], br[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) br[k] = bias ? bias[c + k] : 0.f;
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) wr[tap][k] = w[tap * C + c + k];
+  for (long i = i0; i < n8; i += stride) {
     long pos = i / c8n;
     const int f = (int)(pos % F1); pos /= F1;
     const int t = (int)(pos % T1);
     const int b = (int)(pos / T1);
     float acc[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) acc[k] = bias ? bias[c + k] : 0.f;
+    for (int k = 0; k < 8; ++k) acc[k] = br[k];
 #pragma unroll
     for (int kh = 0; kh < 3; ++kh) {
       const int ti = 2 * t + kh - 2;
@@ -34,62 +44,68 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const T* __restrict__ x,
         const int fi = 2 * f + kw - 2;
         float xv = 0.f;
         if (ti >= 0 && ti < T0 && fi >= 0 && fi < F0) xv = Num<T>::ld(x + ((long)b * T0 + ti) * F0 + fi);
-        const float* wp = w + (kh * 3 + kw) * C + c;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) acc[k] += wp[k] * xv;
+        for (int k = 0; k < 8; ++k) acc[k] += wr[kh * 3 + kw][k] * xv;
       }
     }
     st8(y + i * 8, acc);
   }
 }
 
-// dw[kh,kw,c] += sum dy[b,t,f,c]*x[...]; db[c] += sum dy.  One wave per strided set of positions; lanes own channels.
-template <typename T>
+// dw[kh,kw,c] += sum dy[b,t,f,c]*x[...]; db[c] += sum dy.  LPR lanes x 8 channels cover one position (16-B loads of dy);
+// 64/LPR positions per wave iteration; per-block LDS reduction, one atomic per (tap, channel) per block.
+template <typename T, int LPR>
 __global__ __launch_bounds__(256) void conv1_bwd_weight_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                                float* __restrict__ dw, float* __restrict__ db, int B,
                                                                int T0, int F0, int T1, int F1, int C) {
-  constexpr int MAXCL = 8;  // C <= 512
-  const int lane = threadIdx.x & 63;
+  constexpr int PPW = 64 / LPR;
+  __shared__ float red[4][10][LPR * 8 + 1];
+  const int lane = threadIdx.x & 63, li = lane % LPR, sub = lane / LPR, w = threadIdx.x >> 6;
+  const int c0 = li * 8;
+  const bool act = c0 < C;
   const long npos = (long)B * T1 * F1;
-  const long w0 = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  const long nw = (long)gridDim.x * (blockDim.x >> 6);
-  float acc[MAXCL][10];
+  float acc[10][8];
 #pragma unroll
-  for (int q = 0; q < MAXCL; ++q)
+  for (int q = 0; q < 10; ++q)
 #pragma unroll
-    for (int k = 0; k < 10; ++k) acc[q][k] = 0.f;
-  for (long pos = w0; pos < npos; pos += nw) {
-    long pp = pos;
-    const int f = (int)(pp % F1); pp /= F1;
-    const int t = (int)(pp % T1);
-    const int b = (int)(pp / T1);
-    float xv[9];
+    for (int k = 0; k < 8; ++k) acc[q][k] = 0.f;
+  const long p0 = ((long)blockIdx.x * 4 + w) * PPW + sub, pstep = (long)gridDim.x * 4 * PPW;
+  if (act)
+    for (long pos = p0; pos < npos; pos += pstep) {
+      long pp = pos;
+      const int f = (int)(pp % F1); pp /= F1;
+      const int t = (int)(pp % T1);
+      const int b = (int)(pp / T1);
+      float d[8];
+      ld8(dy + pos * C + c0, d);
 #pragma unroll
-    for (int kh = 0; kh < 3; ++kh)
+      for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
-      for (int kw = 0; kw < 3; ++kw) {
-        const int ti = 2 * t + kh - 2, fi = 2 * f + kw - 2;
-        xv[kh * 3 + kw] = (ti >= 0 && ti < T0 && fi >= 0 && fi < F0) ? Num<T>::ld(x + ((long)b * T0 + ti) * F0 + fi) : 0.f;
-      }
+        for (int kw = 0; kw < 3; ++kw) {
+          const int ti = 2 * t + kh - 2, fi = 2 * f + kw - 2;
+          const float xv = (ti >= 0 && ti < T0 && fi >= 0 && fi < F0) ? Num<T>::ld(x + ((long)b * T0 + ti) * F0 + fi) : 0.f;
 #pragma unroll
-    for (int q = 0; q < MAXCL; ++q) {
-      const int c = lane + q * 64;
-      if (c < C) {
-        const float d = Num<T>::ld(dy + pos * C + c);
+          for (int k = 0; k < 8; ++k) acc[kh * 3 + kw][k] += d[k] * xv;
+        }
 #pragma unroll
-        for (int k = 0; k < 9; ++k) acc[q][k] += d * xv[k];
-        acc[q][9] += d;
-      }
+      for (int k = 0; k < 8; ++k) acc[9][k] += d[k];
     }
-  }
 #pragma unroll
-  for (int q = 0; q < MAXCL; ++q) {
-    const int c = lane + q * 64;
-    if (c < C) {
+  for (int q = 0; q < 10; ++q)
 #pragma unroll
-      for (int k = 0; k < 9; ++k) atomicAdd(dw + k * C + c, acc[q][k]);
-      if (db) atomicAdd(db + c, acc[q][9]);
+    for (int k = 0; k < 8; ++k) {
+      float v = acc[q][k];
+      if (PPW == 2) v += __shfl_xor(v, 32, 64);  // the two positions handled by one wave own the same channels
+      if (sub == 0) red[w][q][c0 + k] = v;
     }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 10 * C; i += blockDim.x) {
+    const int q = i / C, c = i % C;
+    float sum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sum += red[r][q][c];
+    if (q < 9) atomicAdd(dw + q * C + c, sum);
+    else if (db) atomicAdd(db + c, sum);
   }
 }
 
@@ -160,7 +176,11 @@ extern "C" int tfasr_conv1_fwd(const void* x, const float* w, const float* bias,
   if (!x || !w || !y || B <= 0 || T0 <= 0 || F0 <= 0 || C <= 0 || C % 8) return TFASR_STATUS_INVALID_VALUE;
   const int T1 = (T0 + 1) / 2, F1 = (F0 + 1) / 2;
   hipStream_t s = (hipStream_t)stream_;
-  const int grid = flat_grid((long)B * T1 * F1 * C / 8);
+  int grid = flat_grid((long)B * T1 * F1 * C / 8);
+  if ((256 % (C / 8)) != 0) {  // keep (grid*256) a multiple of C/8 so each thread owns one channel group
+    const int c8n = C / 8;
+    grid = ((grid + c8n - 1) / c8n) * c8n;
+  }
   DISPATCH_T(dtype,
              hipLaunchKernelGGL(conv1_fwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, w, bias, (float*)y, B, T0, F0, T1, F1, C),
              hipLaunchKernelGGL(conv1_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)x, w, bias, (bf16_t*)y, B, T0, F0, T1, F1, C));
@@ -170,13 +190,14 @@ extern "C" int tfasr_conv1_fwd(const void* x, const float* w, const float* bias,
 
 extern "C" int tfasr_conv1_bwd_weight(const void* x, const void* dy, float* dw, float* db, int B, int T0, int F0, int C,
                                       int dtype, void* stream_) {
-  if (!x || !dy || !dw || B <= 0 || T0 <= 0 || F0 <= 0 || C <= 0 || C > 512) return TFASR_STATUS_INVALID_VALUE;
+  if (!x || !dy || !dw || B <= 0 || T0 <= 0 || F0 <= 0 || C <= 0 || C > 256 || (C % 8)) return TFASR_STATUS_INVALID_VALUE;
   const int T1 = (T0 + 1) / 2, F1 = (F0 + 1) / 2;
   hipStream_t s = (hipStream_t)stream_;
-  const int grid = (int)std::max<long>(1, std::min<long>((long)B * T1 * F1 / 16 + 1, 2048));
+  const long npos = (long)B * T1 * F1;
+  const int grid = (int)std::max<long>(1, std::min<long>(npos / 64 + 1, 1024));
   DISPATCH_T(dtype,
-             hipLaunchKernelGGL(conv1_bwd_weight_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, (const float*)dy, dw, db, B, T0, F0, T1, F1, C),
-             hipLaunchKernelGGL(conv1_bwd_weight_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)dy, dw, db, B, T0, F0, T1, F1, C));
+             hipLaunchKernelGGL((conv1_bwd_weight_kernel<float, 32>), dim3(grid), dim3(256), 0, s, (const float*)x, (const float*)dy, dw, db, B, T0, F0, T1, F1, C),
+             hipLaunchKernelGGL((conv1_bwd_weight_kernel<bf16_t, 32>), dim3(grid), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)dy, dw, db, B, T0, F0, T1, F1, C));
   TFASR_CHECK_LAUNCH();
   return TFASR_STATUS_SUCCESS;
 }

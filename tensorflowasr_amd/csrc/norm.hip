@@ -417,8 +417,8 @@ extern "C" int tfasr_bn_stats(const void* x, float* stats, long rows, int C, int
   if (!x || !stats || rows <= 0 || C <= 0 || C > 64 * MAXC_PER_LANE) return TFASR_STATUS_INVALID_VALUE;
   hipStream_t s = (hipStream_t)stream_;
   if (dtype == TFASR_BF16 && (C % 8) == 0 && C <= 512) {
-    if (C <= 256) hipLaunchKernelGGL((bn_stats_vec_kernel<bf16_t, 0, 32>), dim3((int)std::min<long>((rows + 7) / 8, 2048L)), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)nullptr, (const float*)nullptr, stats, rows, C, 0);
-    else hipLaunchKernelGGL((bn_stats_vec_kernel<bf16_t, 0, 64>), dim3((int)std::min<long>((rows + 3) / 4, 2048L)), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)nullptr, (const float*)nullptr, stats, rows, C, 0);
+    if (C <= 256) hipLaunchKernelGGL((bn_stats_vec_kernel<bf16_t, 0, 32>), dim3((int)std::max<long>(32, std::min<long>(rows / 256, 1024L))), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)nullptr, (const float*)nullptr, stats, rows, C, 0);
+    else hipLaunchKernelGGL((bn_stats_vec_kernel<bf16_t, 0, 64>), dim3((int)std::max<long>(32, std::min<long>(rows / 128, 1024L))), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)nullptr, (const float*)nullptr, stats, rows, C, 0);
     TFASR_CHECK_LAUNCH();
     return TFASR_STATUS_SUCCESS;
   }
@@ -465,8 +465,8 @@ extern "C" int tfasr_bn_bwd_stats(const void* x, const void* dy, const float* fi
   if (!x || !dy || !fin || !bstats || rows <= 0 || C <= 0 || C > 64 * MAXC_PER_LANE) return TFASR_STATUS_INVALID_VALUE;
   hipStream_t s = (hipStream_t)stream_;
   if (dtype == TFASR_BF16 && (C % 8) == 0 && C <= 512) {
-    if (C <= 256) hipLaunchKernelGGL((bn_stats_vec_kernel<bf16_t, 1, 32>), dim3((int)std::min<long>((rows + 7) / 8, 2048L)), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)dy, fin, bstats, rows, C, act);
-    else hipLaunchKernelGGL((bn_stats_vec_kernel<bf16_t, 1, 64>), dim3((int)std::min<long>((rows + 3) / 4, 2048L)), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)dy, fin, bstats, rows, C, act);
+    if (C <= 256) hipLaunchKernelGGL((bn_stats_vec_kernel<bf16_t, 1, 32>), dim3((int)std::max<long>(32, std::min<long>(rows / 256, 1024L))), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)dy, fin, bstats, rows, C, act);
+    else hipLaunchKernelGGL((bn_stats_vec_kernel<bf16_t, 1, 64>), dim3((int)std::max<long>(32, std::min<long>(rows / 128, 1024L))), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)dy, fin, bstats, rows, C, act);
     TFASR_CHECK_LAUNCH();
     return TFASR_STATUS_SUCCESS;
   }
