@@ -126,6 +126,35 @@ def cpu_baseline(size, vocab, timeout_s=240):
         return {"value": None, "unit": "audio-hours/sec", "error": f"CPU baseline exceeded {timeout_s} s"}
 
 
+def bench_decode(args, model, cfg, dev):
+    """Greedy transducer search (Transducer.recognize, base_transducer.py:474-575) RTF = wall time / audio duration on
+    32 x 10 s synthetic utterances; random-init weights, blank logit biased so that the search emits a speech-like
+    handful of tokens per second instead of saturating its token buffer."""
+    from tensorflowasr_amd.schemas import PredictInput
+
+    model.ps.p("joint/vocab/b")[0] += 2.5
+    model.ps.refresh_shadow()
+    rng = np.random.default_rng(0)
+    B, secs = args.batch, 10.0
+    sig = torch.from_numpy(np.clip(rng.standard_normal((B, int(secs * 16000))).astype(np.float32) * 0.1, -1, 1)).to(dev)
+    lens = torch.full((B,), int(secs * 16000), dtype=torch.int32)
+    inp = PredictInput(sig, lens)
+    for _ in range(args.warmup):
+        out = model.recognize(inp)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = model.recognize(inp)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    ntok = int((out.tokens != 0).sum().item())
+    print(json.dumps({"metric": "greedy-decode RTF Conformer-%s RNN-T" % args.model, "value": round(dt / (B * secs), 6), "unit": "RTF (wall s / audio s)",
+                      "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt * 1e3, 3), "higher_is_better": False,
+                      "dtype": args.dtype, "data": "synthetic", "vs_baseline": None,
+                      "config": {"workload": f"greedy search (recognize_batch) over {B} x {secs:.0f} s utterances incl. log-mel + encoder, {ntok} tokens emitted",
+                                 "global_batch": B}}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -136,6 +165,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--padding", default="batch", choices=["batch", "reference"])
     ap.add_argument("--workload", default=None, help="'S-10s' = BASELINE cfg2 (10 s utterances); default LibriSpeech-shaped")
+    ap.add_argument("--mode", default="train", choices=["train", "decode"], help="decode = greedy-search RTF (second half of BASELINE.json's metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-specaugment", action="store_true")
     ap.add_argument("--dropout", type=float, default=None, help="override encoder dropout (default: reference value 0.1)")
@@ -162,6 +192,8 @@ def main():
     model = ConformerTransducer(cfg, dev, dtype=dtype, seed=0, dp=dp)
     if dp:
         dp.attach(model.ps.grad)
+    if args.mode == "decode":
+        return bench_decode(args, model, cfg, dev)
     size = args.workload or ("LibriSpeech-shaped" if args.model == "M" else "S-10s")
     # a few distinct batches per rank, resident in HBM before the timed region
     nb = 2

@@ -1,0 +1,40 @@
+"""CPU: the reference's own model config (examples/models/transducer/conformer/small.yml.j2) maps onto ConformerConfig
+unchanged (drop-in surface).  Skipped where /root/reference is absent (the GPU box)."""
+import os
+
+import pytest
+
+from tensorflowasr_amd import configs
+
+REF = "/root/reference/examples/models/transducer/conformer/small.yml.j2"
+
+
+@pytest.mark.skipif(not os.path.exists(REF), reason="reference tree not present")
+def test_small_yml_maps_onto_config():
+    import jinja2
+    import yaml
+
+    txt = jinja2.Template(open(REF).read()).render(decoder_config={"vocabsize": 1000}, modeldir="/tmp/m", kaggle_model_handle="x")
+    doc = yaml.safe_load(txt)
+    assert doc["model_config"]["class_name"] == "tensorflow_asr.models.transducer.conformer>Conformer"
+    cfg = configs.ConformerConfig.from_reference(doc["model_config"]["config"])
+    s = configs.conformer_s()
+    for k in ("dmodel", "num_blocks", "head_size", "num_heads", "kernel_size", "filters", "embed_dim", "rnn_units", "joint_dim",
+              "vocab_size", "dropout", "ffm_residual", "l2", "num_feature_bins", "nfft"):
+        assert getattr(cfg, k) == getattr(s, k), k
+    assert cfg.time_masking["num_masks"] == 10 and cfg.time_masking["p_upperbound"] == 0.05
+    assert cfg.freq_masking["mask_factor"] == 27
+    lr = doc["learning_config"]["optimizer_config"]["config"]["learning_rate"]["config"]
+    assert configs.transformer_schedule(1, lr["dmodel"], lr["warmup_steps"], lr["scale"], eval(lr["max_lr"])) > 0
+
+
+def test_unsupported_options_fail_loudly():
+    with pytest.raises(NotImplementedError):
+        configs.ConformerConfig.from_reference({"encoder_mha_type": "mha", "vocab_size": 10})
+    with pytest.raises(NotImplementedError):
+        configs.ConformerConfig.from_reference({"prediction_rnn_type": "gru", "vocab_size": 10})
+
+
+def test_m_config_is_the_paper_shape():
+    m = configs.conformer_m()
+    assert (m.dmodel, m.num_heads, m.head_size, m.num_blocks, m.rnn_units, m.joint_dim) == (256, 4, 64, 16, 640, 640)
