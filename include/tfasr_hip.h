@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define TFASR_ABI_VERSION 4
+#define TFASR_ABI_VERSION 5
 
 typedef enum {
   TFASR_STATUS_SUCCESS = 0,
@@ -210,6 +210,25 @@ int tfasr_relattn_softmax_fwd(const void* content, const void* pos, const int32_
                               int T, int ldc, int ldp, int use_mask, int dtype, void* stream);
 int tfasr_relattn_softmax_bwd(const void* probs, const void* dprobs, const int32_t* lengths, void* dcontent, void* dpos,
                               int B, int H, int T, int ldc, int ldp, int use_mask, int dtype, void* stream);
+
+/* Fused (flash-style) forward of the same attention: nothing of size T x T is written.  qkv [B*T, 3*H*dh] (fused
+ * projection output, q|k|v column blocks), ubias/vbias [H*dh] f32 (content / positional biases), pext [2T, H*dh]
+ * (projected relative table + bias row), out [B*T, H*dh], lse [B,H,T] f32.  bf16, dh == 64 only (else UNSUPPORTED). */
+int tfasr_relattn_fused_fwd(const void* qkv, const float* ubias, const float* vbias, const void* pext,
+                            const int32_t* lengths, void* out, float* lse, int B, int H, int T, int dh, float scale,
+                            int use_mask, int dtype, void* stream);
+
+/* Fused backward, query side: recomputes the probabilities from lse, returns dqu [B*T, H*dh] = d/d(q+u) and the skewed
+ * score gradient dpos [B,H,T,ldp] (same meaning as tfasr_relattn_softmax_bwd's dpos, fully written); o/dout [B*T, H*dh]. */
+int tfasr_relattn_fused_bwd_q(const void* qkv, const float* ubias, const float* vbias, const void* pext,
+                              const int32_t* lengths, const void* o, const void* dout, const float* lse, void* dqu, void* dpos,
+                              float* dvec, int B, int H, int T, int dh, int ldp, float scale, int use_mask, int dtype,
+                              void* stream);
+/* Fused backward, key side (run after _bwd_q, which also emits dvec [B,H,T] = rowsum(dout*o)): writes the k and v column
+ * blocks of dqkv [B*T, 3*H*dh]; qu/qv [B*T, H*dh] = q+u / q+v (tfasr_bias2_fwd). */
+int tfasr_relattn_fused_bwd_k(const void* qkv, const void* qu, const void* qv, const void* pext, const int32_t* lengths,
+                              const void* dout, const float* lse, const float* dvec, void* dqkv, int B, int H, int T, int dh,
+                              float scale, int use_mask, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * LSTM cell pointwise stages (keras LSTM, gates i,f,c,o; base_transducer.py:71-85,123-159)

@@ -109,7 +109,7 @@ def load(build_if_missing=True):
     return lib
 
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 def check(status, what=""):

@@ -1,0 +1,619 @@
+// Fused relative-position attention, forward (flash style) for gfx950, head size 64, bf16.
+//
+//   out[b,i,h,:] = softmax_j( scale*[(q_i+u).k_j + (q_i+v).p_{idx(i,j)}] ) @ v      (multihead_attention.py:543-582)
+// with the relative shift (:27-77) and the per-sample roll/zero of the relative PE (positional_encoding.py:152-172) as
+// index arithmetic:  idx(i,j) = r + (T-len_b) if r = T-1-i+j < 2*len_b-1 else R (the bias row), R = 2T-1
+// (see attention.hip for the derivation; `pext` is the projected table [R+1, H*64]).
+// Nothing of size T x T touches HBM: per (b, h, 64-query block) the kernel streams 64-key blocks of K, V and the
+// 127-row window of `pext` that the block's (i,j) pairs need through LDS (global_load_lds), computes the content
+// scores and the window scores G = (q+v) @ window^T with MFMA, reads G back skewed (col = 63-il+jl) from a per-wave LDS
+// strip, runs an online softmax in registers and accumulates P@V.  Saves lse[b,h,i] = log sum_j exp(s_ij) for the backward.
+// Auto-mask semantics as in attention.hip: padded QUERY rows give uniform attention over all T keys; keys are never masked.
+#include "common.h"
+#include <algorithm>
+
+typedef __attribute__((ext_vector_type(4))) short short4_t;
+
+namespace {
+
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+#define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+
+constexpr int DH = 64, BI = 64, BJ = 64, WIN = 128;
+constexpr int SK_BYTES = BJ * DH * 2, SV_BYTES = BJ * DH * 2, SP_BYTES = WIN * DH * 2;
+constexpr int GLD = 132;                                   // f32 row stride of the per-wave G strip
+constexpr int SG_BYTES = 16 * GLD * 4, SPB_BYTES = 16 * BJ * 2;
+constexpr int SMEM_FWD = SK_BYTES + SV_BYTES + SP_BYTES + 4 * SG_BYTES + 4 * SPB_BYTES;
+
+__device__ __forceinline__ int key_d(int row) { return (row >> 1) & 7; }
+__device__ __forceinline__ int key_t64(int k) { return (((k >> 1) & 1) | (((k >> 3) & 1) << 1)) << 1; }
+
+// [rows][64] bf16 image, 128-B rows, 16-B chunk ^= key_d(row); global rows clamped to [0, nrows-1]
+template <int ROWS>
+__device__ __forceinline__ void load_rows(char* s, const bf16_t* g, long ld, int row0, int nrows, int w, int lane) {
+#pragma unroll
+  for (int i = 0; i < ROWS / 32; ++i) {
+    const int q = w * (ROWS / 32) + i;
+    const int row = q * 8 + (lane >> 3), p = lane & 7;
+    const int gr = min(max(row0 + row, 0), nrows - 1);
+    const bf16_t* src = g + (long)gr * ld + ((p ^ key_d(row)) << 3);
+    __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(s + __builtin_amdgcn_readfirstlane(q * 1024)), 16, 0, 0);
+  }
+}
+// V block as [64 k=j][64 n=dh] "trans" image (128-B k-rows, chunk ^= key_t64(k)); k rows clamped to nrows-1
+__device__ __forceinline__ void load_v(char* s, const bf16_t* g, long ld, int j0, int nrows, int w, int lane) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int q = w * 2 + i;
+    const int k = q * 8 + (lane >> 3), p = lane & 7;
+    const int gr = min(j0 + k, nrows - 1);
+    const bf16_t* src = g + (long)gr * ld + ((p ^ key_t64(k)) << 3);
+    __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(s + __builtin_amdgcn_readfirstlane(q * 1024)), 16, 0, 0);
+  }
+}
+__device__ __forceinline__ short8_t frag_rows(const char* s, int row, int c) {
+  return *reinterpret_cast<const short8_t*>(s + row * 128 + ((c ^ key_d(row)) << 4));
+}
+__device__ __forceinline__ short8_t frag_v(const char* s, int nbase, int kbase, int r) {
+  const int col = nbase + ((r & 3) << 2);
+  const int chunk = col >> 3, half = (col >> 2) & 1;
+  const int k0 = kbase + (r >> 2), k1 = k0 + 4;
+  const short4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (__attribute__((address_space(3))) short4_t*)(s + k0 * 128 + ((chunk ^ key_t64(k0)) << 4) + half * 8));
+  const short4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (__attribute__((address_space(3))) short4_t*)(s + k1 * 128 + ((chunk ^ key_t64(k1)) << 4) + half * 8));
+  short8_t v;
+  v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
+  v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+  return v;
+}
+
+
+// transposed fragment (k = image row) of a [64 rows][64] image swizzled with key_d (the row-major images above)
+__device__ __forceinline__ short8_t frag_kt(const char* s, int nbase, int kbase, int r) {
+  const int col = nbase + ((r & 3) << 2);
+  const int chunk = col >> 3, half = (col >> 2) & 1;
+  const int k0 = kbase + (r >> 2), k1 = k0 + 4;
+  const short4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (__attribute__((address_space(3))) short4_t*)(s + k0 * 128 + ((chunk ^ key_d(k0)) << 4) + half * 8));
+  const short4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (__attribute__((address_space(3))) short4_t*)(s + k1 * 128 + ((chunk ^ key_d(k1)) << 4) + half * 8));
+  short8_t v;
+  v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
+  v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+  return v;
+}
+
+// (q + bias) rounded to bf16, as an MFMA A fragment: lane (r = row, g = k group) holds 8 consecutive k
+__device__ __forceinline__ short8_t q_frag(const bf16_t* qrow, const float* bias, int k0) {
+  float x[8];
+  ld8(qrow + k0, x);
+  short8_t f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) f[e] = (short)f32_to_bf16(x[e] + bias[k0 + e]);
+  return f;
+}
+
+__global__ __launch_bounds__(256, 2) void relattn_fused_fwd_kernel(
+    const bf16_t* __restrict__ qkv, const float* __restrict__ ubias, const float* __restrict__ vbias,
+    const bf16_t* __restrict__ pext, const int32_t* __restrict__ lengths, bf16_t* __restrict__ out, float* __restrict__ lse_out,
+    int B, int H, int T, float scale, int use_mask) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sK = smem;
+  char* sV = sK + SK_BYTES;
+  char* sP = sV + SV_BYTES;
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  float* sG = reinterpret_cast<float*>(sP + SP_BYTES + w * SG_BYTES);
+  char* sPb = sP + SP_BYTES + 4 * SG_BYTES + w * SPB_BYTES;
+  const int r = lane & 15, g = lane >> 4;
+  const int b = blockIdx.z, h = blockIdx.y, i0 = blockIdx.x * BI;
+  const int HD = H * DH, LDQ = 3 * HD, R = 2 * T - 1, R1 = 2 * T;
+  const int len = lengths ? min(lengths[b], T) : T;
+  const int shift = T - len;
+  const bf16_t* qb = qkv + (long)b * T * LDQ + h * DH;  // q columns of head h
+  const bf16_t* kb = qb + HD;
+  const bf16_t* vb = qb + 2 * HD;
+  const bf16_t* pb = pext + h * DH;
+
+  // Q fragments (A operand): this lane's row
+  const int irow = min(i0 + w * 16 + r, T - 1);
+  short8_t aqu[2], aqv[2];
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) {
+    aqu[kk] = q_frag(qb + (long)irow * LDQ, ubias + h * DH, kk * 32 + g * 8);
+    aqv[kk] = q_frag(qb + (long)irow * LDQ, vbias + h * DH, kk * 32 + g * 8);
+  }
+
+  float m_run[4], l_run[4];
+  float4_t acc_o[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { m_run[e] = -INFINITY; l_run[e] = 0.f; }
+#pragma unroll
+  for (int n = 0; n < 4; ++n) acc_o[n] = float4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int njb = (T + BJ - 1) / BJ;
+  for (int jb = 0; jb < njb; ++jb) {
+    const int j0 = jb * BJ;
+    const int pw0 = (T - 1 - (i0 + BI - 1) + j0) + shift;  // pext row of window column 0
+    load_rows<BJ>(sK, kb, LDQ, j0, T, w, lane);
+    load_v(sV, vb, LDQ, j0, T, w, lane);
+    load_rows<WIN>(sP, pb, HD, pw0, R1, w, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    // window row 127 <- the bias row R (one 128-B row, written by wave 0 after the DMA so it wins)
+    if (w == 0 && lane < 8) {
+      const uint4 v = *reinterpret_cast<const uint4*>(pb + (long)R * HD + ((lane ^ key_d(127)) << 3));
+      *reinterpret_cast<uint4*>(sP + 127 * 128 + lane * 16) = v;
+    }
+    __syncthreads();
+
+    // content scores: 16 query rows x 64 keys
+    float4_t acc_s[4];
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) {
+      acc_s[jt] = float4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+        acc_s[jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aqu[kk], frag_rows(sK, jt * 16 + r, kk * 4 + g), acc_s[jt], 0, 0, 0);
+    }
+    // window scores G[il][c], c in [ (3-w)*16, 128 ): this wave's skew needs columns 48-16w .. 126-16w, plus column 127 (bias row)
+#pragma unroll
+    for (int gt = 0; gt < 8; ++gt) {
+      if (gt >= 3 - w && (gt <= 7 - w || gt == 7)) {
+        float4_t a = float4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aqv[kk], frag_rows(sP, gt * 16 + r, kk * 4 + g), a, 0, 0, 0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sG[(g * 4 + e) * GLD + gt * 16 + r] = a[e];
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+
+    // scores in C layout: row il = g*4+e, col jl = jt*16 + r
+    float rmax[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int il = g * 4 + e;
+      const int i = i0 + w * 16 + il;
+      const bool qmask = use_mask && (i >= len);
+      const float gbias = sG[il * GLD + 127];
+      float mx = -INFINITY;
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt) {
+        const int jl = jt * 16 + r, j = j0 + jl;
+        const int rr = T - 1 - i + j;
+        const float pos = (rr < 2 * len - 1) ? sG[il * GLD + (63 - w * 16 - il + jl)] : gbias;
+        float s = (acc_s[jt][e] + pos) * scale;
+        if (qmask) s = 0.f;
+        if (j >= T) s = -INFINITY;
+        acc_s[jt][e] = s;
+        mx = fmaxf(mx, s);
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 4, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 8, 64));
+      rmax[e] = mx;
+    }
+    // online softmax update + P (bf16) into the per-wave A-operand image
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int il = g * 4 + e;
+      const float m_new = fmaxf(m_run[e], rmax[e]);
+      const float corr = (m_run[e] == -INFINITY) ? 0.f : __expf(m_run[e] - m_new);
+      float rs = 0.f;
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt) {
+        const float p = (acc_s[jt][e] == -INFINITY) ? 0.f : __expf(acc_s[jt][e] - m_new);
+        rs += p;
+        const int jl = jt * 16 + r;
+        *reinterpret_cast<bf16_t*>(sPb + il * 128 + (((jl >> 3) ^ key_d(il)) << 4) + (jl & 7) * 2) = f32_to_bf16(p);
+      }
+      rs += __shfl_xor(rs, 1, 64);
+      rs += __shfl_xor(rs, 2, 64);
+      rs += __shfl_xor(rs, 4, 64);
+      rs += __shfl_xor(rs, 8, 64);
+      l_run[e] = l_run[e] * corr + rs;
+      m_run[e] = m_new;
+#pragma unroll
+      for (int n = 0; n < 4; ++n) acc_o[n][e] *= corr;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    // O += P @ V
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const short8_t ap = frag_rows(sPb, r, kk * 4 + g);
+#pragma unroll
+      for (int n = 0; n < 4; ++n)
+        acc_o[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap, frag_v(sV, n * 16, kk * 32 + g * 8, r), acc_o[n], 0, 0, 0);
+    }
+    __syncthreads();  // everyone is done with sK / sV / sP before the next block's DMA lands
+  }
+
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int i = i0 + w * 16 + g * 4 + e;
+    if (i < T) {
+      const float inv = 1.f / l_run[e];
+#pragma unroll
+      for (int n = 0; n < 4; ++n) out[((long)b * T + i) * HD + h * DH + n * 16 + r] = f32_to_bf16(acc_o[n][e] * inv);
+      if (r == 0) lse_out[((long)b * H + h) * T + i] = m_run[e] + logf(l_run[e]);
+    }
+  }
+}
+
+
+// ======================================================================================================================
+// Backward, part 1 (query side): block = (b, h, 64 query rows), wave = 16 rows, loop over 64-key blocks.
+//   recompute s_ij and p_ij = exp(s_ij - lse_i);  dp_ij = dO_i . v_j;  ds_ij = p_ij (dp_ij - D_i),  D_i = dO_i . O_i
+//   dqu_i  += scale * sum_j ds_ij k_j                       (in registers, written once)
+//   dpos[b,h,i, idx(i,j)] = scale * ds_ij                   (the skewed score gradient, [B,H,T,ldp] like attention.hip's
+//                                                            backward: the (q+v) / pext gradients are two GEMMs on it)
+// ======================================================================================================================
+constexpr int SMEM_BWD_Q = SK_BYTES + SV_BYTES + SP_BYTES + 4 * SG_BYTES;
+
+__device__ __forceinline__ short8_t row_frag(const bf16_t* row, int k0) {
+  return *reinterpret_cast<const short8_t*>(row + k0);
+}
+
+__global__ __launch_bounds__(256, 2) void relattn_fused_bwd_q_kernel(
+    const bf16_t* __restrict__ qkv, const float* __restrict__ ubias, const float* __restrict__ vbias,
+    const bf16_t* __restrict__ pext, const int32_t* __restrict__ lengths, const bf16_t* __restrict__ o,
+    const bf16_t* __restrict__ dout, const float* __restrict__ lse, bf16_t* __restrict__ dqu, bf16_t* __restrict__ dpos,
+    float* __restrict__ dvec, int B, int H, int T, int ldp, float scale, int use_mask) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sK = smem;              // [64 j][64 dh], read both as rows (k = dh) and transposed (k = j)
+  char* sV = sK + SK_BYTES;     // [64 j][64 dh]
+  char* sP = sV + SV_BYTES;     // window rows
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  float* sG = reinterpret_cast<float*>(sP + SP_BYTES + w * SG_BYTES);
+  char* sA = reinterpret_cast<char*>(sG);  // the G strip is dead once the scores are formed: reuse it for the dS A-image
+  const int r = lane & 15, g = lane >> 4;
+  const int b = blockIdx.z, h = blockIdx.y, i0 = blockIdx.x * BI;
+  const int HD = H * DH, LDQ = 3 * HD, R = 2 * T - 1, R1 = 2 * T;
+  const int len = lengths ? min(lengths[b], T) : T;
+  const int shift = T - len;
+  const bf16_t* qb = qkv + (long)b * T * LDQ + h * DH;
+  const bf16_t* kb = qb + HD;
+  const bf16_t* vb = qb + 2 * HD;
+  const bf16_t* pb = pext + h * DH;
+
+  const int irow = min(i0 + w * 16 + r, T - 1);
+  short8_t aqu[2], aqv[2], ado[2];
+  float dpart = 0.f;
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) {
+    aqu[kk] = q_frag(qb + (long)irow * LDQ, ubias + h * DH, kk * 32 + g * 8);
+    aqv[kk] = q_frag(qb + (long)irow * LDQ, vbias + h * DH, kk * 32 + g * 8);
+    const bf16_t* dorow = dout + ((long)b * T + irow) * HD + h * DH + kk * 32 + g * 8;
+    const bf16_t* orow = o + ((long)b * T + irow) * HD + h * DH + kk * 32 + g * 8;
+    ado[kk] = row_frag(dorow, 0);
+    float a[8], c[8];
+    ld8(dorow, a);
+    ld8(orow, c);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dpart += a[e] * c[e];
+  }
+  // D_i for row r: reduce over the 4 k-groups (lanes r, r+16, r+32, r+48), then re-distribute to the C layout rows g*4+e
+  dpart += __shfl_xor(dpart, 16, 64);
+  dpart += __shfl_xor(dpart, 32, 64);
+  if (g == 0 && i0 + w * 16 + r < T) dvec[((long)b * H + h) * T + i0 + w * 16 + r] = dpart;  // D_i for the key-side kernel
+  float Di[4], lsei[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    Di[e] = __shfl(dpart, g * 4 + e, 64);
+    const int i = min(i0 + w * 16 + g * 4 + e, T - 1);
+    lsei[e] = lse[((long)b * H + h) * T + i];
+  }
+
+  float4_t acc_q[4];
+#pragma unroll
+  for (int n = 0; n < 4; ++n) acc_q[n] = float4_t{0.f, 0.f, 0.f, 0.f};
+  float bias_acc[4] = {0.f, 0.f, 0.f, 0.f};
+
+  const int njb = (T + BJ - 1) / BJ;
+  for (int jb = 0; jb < njb; ++jb) {
+    const int j0 = jb * BJ;
+    const int pw0 = (T - 1 - (i0 + BI - 1) + j0) + shift;
+    load_rows<BJ>(sK, kb, LDQ, j0, T, w, lane);
+    load_rows<BJ>(sV, vb, LDQ, j0, T, w, lane);
+    load_rows<WIN>(sP, pb, HD, pw0, R1, w, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (w == 0 && lane < 8) {
+      const uint4 v = *reinterpret_cast<const uint4*>(pb + (long)R * HD + ((lane ^ key_d(127)) << 3));
+      *reinterpret_cast<uint4*>(sP + 127 * 128 + lane * 16) = v;
+    }
+    __syncthreads();
+
+    float4_t acc_s[4], acc_p[4];
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) {
+      acc_s[jt] = float4_t{0.f, 0.f, 0.f, 0.f};
+      acc_p[jt] = float4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        acc_s[jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aqu[kk], frag_rows(sK, jt * 16 + r, kk * 4 + g), acc_s[jt], 0, 0, 0);
+        acc_p[jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ado[kk], frag_rows(sV, jt * 16 + r, kk * 4 + g), acc_p[jt], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int gt = 0; gt < 8; ++gt) {
+      if (gt >= 3 - w && (gt <= 7 - w || gt == 7)) {
+        float4_t a = float4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aqv[kk], frag_rows(sP, gt * 16 + r, kk * 4 + g), a, 0, 0, 0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sG[(g * 4 + e) * GLD + gt * 16 + r] = a[e];
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ds in C layout (row il = g*4+e, col jl = jt*16+r); skewed copy straight to HBM
+    float ds[4][4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int il = g * 4 + e;
+      const int i = i0 + w * 16 + il;
+      const bool qmask = use_mask && (i >= len);
+      const float gbias = sG[il * GLD + 127];
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt) {
+        const int jl = jt * 16 + r, j = j0 + jl;
+        const int rr = T - 1 - i + j;
+        const bool valid_r = rr < 2 * len - 1;
+        const float pos = valid_r ? sG[il * GLD + (63 - w * 16 - il + jl)] : gbias;
+        float d = 0.f;
+        if (!qmask && j < T && i < T) {
+          const float sc = (acc_s[jt][e] + pos) * scale;
+          const float p = __expf(sc - lsei[e]);
+          d = p * (acc_p[jt][e] - Di[e]) * scale;
+        }
+        ds[e][jt] = d;
+        if (i < T && j < T) {
+          if (valid_r) dpos[(((long)b * H + h) * T + i) * ldp + rr + shift] = f32_to_bf16(d);
+          else bias_acc[e] += d;
+        }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    // dS (bf16) as A operand image [16 rows il][64 k = jl] in the (now dead) G strip
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int il = g * 4 + e;
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt) {
+        const int jl = jt * 16 + r;
+        *reinterpret_cast<bf16_t*>(sA + il * 128 + (((jl >> 3) ^ key_d(il)) << 4) + (jl & 7) * 2) = f32_to_bf16(ds[e][jt]);
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    // dqu += dS @ K   (B operand: K block read transposed, k = j)
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const short8_t a = frag_rows(sA, r, kk * 4 + g);
+#pragma unroll
+      for (int n = 0; n < 4; ++n)
+        acc_q[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, frag_kt(sK, n * 16, kk * 32 + g * 8, r), acc_q[n], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  // epilogue: dqu, the bias column, and zeros over the part of each dpos row that no (i,j) pair maps to
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int i = i0 + w * 16 + g * 4 + e;
+    float bsum = bias_acc[e];
+    bsum += __shfl_xor(bsum, 1, 64);
+    bsum += __shfl_xor(bsum, 2, 64);
+    bsum += __shfl_xor(bsum, 4, 64);
+    bsum += __shfl_xor(bsum, 8, 64);
+    if (i < T) {
+#pragma unroll
+      for (int n = 0; n < 4; ++n) dqu[((long)b * T + i) * HD + h * DH + n * 16 + r] = f32_to_bf16(acc_q[n][e]);
+      bf16_t* prow = dpos + (((long)b * H + h) * T + i) * ldp;
+      // valid columns: rr + shift for j in [0,T) with rr = T-1-i+j < 2len-1  ->  [T-1-i+shift, min(2T-1-i, 2len-1)+shift )
+      const int lo = T - 1 - i + shift;
+      const int hi = min(2 * T - 1 - i, 2 * len - 1) + shift;  // exclusive; may be <= lo when no pair is valid
+      const int hi2 = max(hi, lo);
+      for (int c = r; c < ldp; c += 16)
+        if (c < lo || c >= hi2) prow[c] = (c == R) ? f32_to_bf16(bsum) : (bf16_t)0;
+    }
+  }
+}
+
+
+// ======================================================================================================================
+// Backward, part 2 (key side): block = (b, h, 64 key rows), wave = 16 key rows, loop over 64-query blocks.  Everything is
+// computed transposed (rows = keys) so dK / dV accumulate in registers:
+//   sT[j,i] = k_j.qu_i + G[i, c(i,j)],  pT = exp(sT - lse_i),  dpT[j,i] = v_j.dO_i,  dsT = pT (dpT - D_i) scale
+//   dv_j += sum_i pT[j,i] dO_i ;   dk_j += sum_i dsT[j,i] qu_i
+// The window scores are produced block-wide as Gt[c, i] = window_c . qv_i (each wave 2 of the 8 c-tiles) in LDS.
+// ======================================================================================================================
+constexpr int GTLD = 68;
+constexpr int SGT_BYTES = WIN * GTLD * 4;
+constexpr int SMEM_BWD_K = 3 * SK_BYTES + SP_BYTES + SGT_BYTES;  // qu, qv, dO blocks + window + Gt
+
+__global__ __launch_bounds__(256, 2) void relattn_fused_bwd_k_kernel(
+    const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ qu, const bf16_t* __restrict__ qv,
+    const bf16_t* __restrict__ pext, const int32_t* __restrict__ lengths, const bf16_t* __restrict__ dout,
+    const float* __restrict__ lse, const float* __restrict__ dvec, bf16_t* __restrict__ dqkv, int B, int H, int T, float scale,
+    int use_mask) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sQu = smem;
+  char* sQv = sQu + SK_BYTES;
+  char* sdO = sQv + SK_BYTES;
+  char* sP = sdO + SK_BYTES;
+  float* sGt = reinterpret_cast<float*>(sP + SP_BYTES);
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  char* sAp = sP + w * 4096;         // per-wave A images (P^T then dS^T), carved out of the window once it is dead
+  char* sAs = sAp + 2048;
+  const int r = lane & 15, g = lane >> 4;
+  const int b = blockIdx.z, h = blockIdx.y, j0 = blockIdx.x * BJ;
+  const int HD = H * DH, LDQ = 3 * HD, R = 2 * T - 1, R1 = 2 * T;
+  const int len = lengths ? min(lengths[b], T) : T;
+  const int shift = T - len;
+  const bf16_t* kb = qkv + (long)b * T * LDQ + HD + h * DH;
+  const bf16_t* vb = kb + HD;
+  const bf16_t* qub = qu + (long)b * T * HD + h * DH;
+  const bf16_t* qvb = qv + (long)b * T * HD + h * DH;
+  const bf16_t* dob = dout + (long)b * T * HD + h * DH;
+  const bf16_t* pb = pext + h * DH;
+
+  const int jrow = min(j0 + w * 16 + r, T - 1);
+  short8_t ak[2], av[2];
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) {
+    ak[kk] = row_frag(kb + (long)jrow * LDQ, kk * 32 + g * 8);
+    av[kk] = row_frag(vb + (long)jrow * LDQ, kk * 32 + g * 8);
+  }
+  float4_t acc_k[4], acc_v[4];
+#pragma unroll
+  for (int n = 0; n < 4; ++n) { acc_k[n] = float4_t{0.f, 0.f, 0.f, 0.f}; acc_v[n] = float4_t{0.f, 0.f, 0.f, 0.f}; }
+
+  const int nib = (T + BI - 1) / BI;
+  for (int ib = 0; ib < nib; ++ib) {
+    const int i0 = ib * BI;
+    const int pw0 = (T - 1 - (i0 + BI - 1) + j0) + shift;
+    load_rows<BI>(sQu, qub, HD, i0, T, w, lane);
+    load_rows<BI>(sQv, qvb, HD, i0, T, w, lane);
+    load_rows<BI>(sdO, dob, HD, i0, T, w, lane);
+    load_rows<WIN>(sP, pb, HD, pw0, R1, w, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (w == 0 && lane < 8) {
+      const uint4 v = *reinterpret_cast<const uint4*>(pb + (long)R * HD + ((lane ^ key_d(127)) << 3));
+      *reinterpret_cast<uint4*>(sP + 127 * 128 + lane * 16) = v;
+    }
+    __syncthreads();
+
+    // transposed content scores and dP: rows = this wave's 16 keys, cols = 64 queries
+    float4_t acc_s[4], acc_p[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      acc_s[it] = float4_t{0.f, 0.f, 0.f, 0.f};
+      acc_p[it] = float4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        acc_s[it] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ak[kk], frag_rows(sQu, it * 16 + r, kk * 4 + g), acc_s[it], 0, 0, 0);
+        acc_p[it] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[kk], frag_rows(sdO, it * 16 + r, kk * 4 + g), acc_p[it], 0, 0, 0);
+      }
+    }
+    // Gt[c, i] for c-tiles 2w, 2w+1
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc) {
+      const int ct = 2 * w + cc;
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        float4_t a = float4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(sP, ct * 16 + r, kk * 4 + g), frag_rows(sQv, it * 16 + r, kk * 4 + g), a, 0, 0, 0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sGt[(ct * 16 + g * 4 + e) * GTLD + it * 16 + r] = a[e];
+      }
+    }
+    __syncthreads();  // Gt complete; the window and the qv block are dead from here on
+
+    // pT and dsT in C layout (row jl = g*4+e of this wave, col il = it*16+r) -> A-operand images [16 jl][64 k = il]
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int il = it * 16 + r, i = i0 + il;
+      const int ic = min(i, T - 1);
+      const float lse_i = lse[((long)b * H + h) * T + ic];
+      const float D_i = dvec[((long)b * H + h) * T + ic];
+      const bool qmask = use_mask && (i >= len);
+      const float gbias = sGt[127 * GTLD + il];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int jl = w * 16 + g * 4 + e, j = j0 + jl;
+        const int rr = T - 1 - i + j;
+        const float pos = (rr < 2 * len - 1) ? sGt[((63 - il) + jl) * GTLD + il] : gbias;
+        float p = 0.f, d = 0.f;
+        if (i < T && j < T) {
+          const float sc = qmask ? 0.f : (acc_s[it][e] + pos) * scale;
+          p = __expf(sc - lse_i);
+          d = qmask ? 0.f : p * (acc_p[it][e] - D_i) * scale;
+        }
+        const int row = g * 4 + e;
+        const int off = row * 128 + (((il >> 3) ^ key_d(row)) << 4) + (il & 7) * 2;
+        *reinterpret_cast<bf16_t*>(sAp + off) = f32_to_bf16(p);
+        *reinterpret_cast<bf16_t*>(sAs + off) = f32_to_bf16(d);
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    // dv += pT @ dO ; dk += dsT @ qu    (B operands: the dO / qu blocks read transposed, k = i)
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const short8_t ap = frag_rows(sAp, r, kk * 4 + g);
+      const short8_t as = frag_rows(sAs, r, kk * 4 + g);
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        acc_v[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap, frag_kt(sdO, n * 16, kk * 32 + g * 8, r), acc_v[n], 0, 0, 0);
+        acc_k[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as, frag_kt(sQu, n * 16, kk * 32 + g * 8, r), acc_k[n], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int j = j0 + w * 16 + g * 4 + e;
+    if (j < T) {
+      bf16_t* row = dqkv + ((long)b * T + j) * LDQ + h * DH;
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        row[HD + n * 16 + r] = f32_to_bf16(acc_k[n][e]);
+        row[2 * HD + n * 16 + r] = f32_to_bf16(acc_v[n][e]);
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int tfasr_relattn_fused_fwd(const void* qkv, const float* ubias, const float* vbias, const void* pext,
+                                       const int32_t* lengths, void* out, float* lse, int B, int H, int T, int dh, float scale,
+                                       int use_mask, int dtype, void* stream_) {
+  if (!qkv || !ubias || !vbias || !pext || !out || !lse || B <= 0 || H <= 0 || T <= 0) return TFASR_STATUS_INVALID_VALUE;
+  if (dtype != TFASR_BF16 || dh != DH) return TFASR_STATUS_UNSUPPORTED;
+  dim3 grid((T + BI - 1) / BI, H, B);
+  hipLaunchKernelGGL(relattn_fused_fwd_kernel, grid, dim3(256), SMEM_FWD, (hipStream_t)stream_, (const bf16_t*)qkv, ubias, vbias,
+                     (const bf16_t*)pext, lengths, (bf16_t*)out, lse, B, H, T, scale, use_mask);
+  TFASR_CHECK_LAUNCH();
+  return TFASR_STATUS_SUCCESS;
+}
+
+extern "C" int tfasr_relattn_fused_bwd_q(const void* qkv, const float* ubias, const float* vbias, const void* pext,
+                                         const int32_t* lengths, const void* o, const void* dout, const float* lse, void* dqu,
+                                         void* dpos, float* dvec, int B, int H, int T, int dh, int ldp, float scale, int use_mask, int dtype,
+                                         void* stream_) {
+  if (!qkv || !ubias || !vbias || !pext || !o || !dout || !lse || !dqu || !dpos || !dvec || B <= 0 || H <= 0 || T <= 0 || ldp < 2 * T)
+    return TFASR_STATUS_INVALID_VALUE;
+  if (dtype != TFASR_BF16 || dh != DH) return TFASR_STATUS_UNSUPPORTED;
+  dim3 grid((T + BI - 1) / BI, H, B);
+  hipLaunchKernelGGL(relattn_fused_bwd_q_kernel, grid, dim3(256), SMEM_BWD_Q, (hipStream_t)stream_, (const bf16_t*)qkv, ubias, vbias,
+                     (const bf16_t*)pext, lengths, (const bf16_t*)o, (const bf16_t*)dout, lse, (bf16_t*)dqu, (bf16_t*)dpos, dvec, B, H, T, ldp,
+                     scale, use_mask);
+  TFASR_CHECK_LAUNCH();
+  return TFASR_STATUS_SUCCESS;
+}
+
+extern "C" int tfasr_relattn_fused_bwd_k(const void* qkv, const void* qu, const void* qv, const void* pext, const int32_t* lengths,
+                                         const void* dout, const float* lse, const float* dvec, void* dqkv, int B, int H, int T,
+                                         int dh, float scale, int use_mask, int dtype, void* stream_) {
+  if (!qkv || !qu || !qv || !pext || !dout || !lse || !dvec || !dqkv || B <= 0 || H <= 0 || T <= 0) return TFASR_STATUS_INVALID_VALUE;
+  if (dtype != TFASR_BF16 || dh != DH) return TFASR_STATUS_UNSUPPORTED;
+  dim3 grid((T + BJ - 1) / BJ, H, B);
+  hipLaunchKernelGGL(relattn_fused_bwd_k_kernel, grid, dim3(256), SMEM_BWD_K, (hipStream_t)stream_, (const bf16_t*)qkv, (const bf16_t*)qu,
+                     (const bf16_t*)qv, (const bf16_t*)pext, lengths, (const bf16_t*)dout, lse, dvec, (bf16_t*)dqkv, B, H, T, scale, use_mask);
+  TFASR_CHECK_LAUNCH();
+  return TFASR_STATUS_SUCCESS;
+}

@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256) void dwconv_bwd_data_kernel(const T* __restric
     if (t0 + i < Tn) Num<T>::st(dx + base + (long)(t0 + i) * C + c, acc[i]);
 }
 // dw[k,c] += sum_{b,t} dy[b,t,c]*x[b,t-(K-1)+k,c]; dbias[c] += sum dy.  grid = (C/blk, t chunks of DW_WT, B)
-constexpr int DW_WT = 160;  // time steps per block: fewer, fatter blocks -> fewer (K+1) atomics per channel
+constexpr int DW_WT = 64;
 template <typename T>
 __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                                 float* __restrict__ dw, float* __restrict__ dbias,

@@ -337,6 +337,29 @@ def relattn_softmax_bwd(probs, dprobs, lengths, T, ldp, use_mask=True, dcontent=
     return dcontent, dpos
 
 
+def relattn_fused_fwd(qkv, ubias, vbias, pext, lengths, B, H, T, dh, scale, use_mask=True):
+    out = torch.empty(B * T, H * dh, dtype=qkv.dtype, device=qkv.device)
+    lse = torch.empty(B, H, T, dtype=torch.float32, device=qkv.device)
+    check(_L().tfasr_relattn_fused_fwd(_p(qkv), _p(ubias), _p(vbias), _p(pext), _p(lengths), _p(out), _p(lse), B, H, T, dh, scale,
+                                       int(use_mask), _dt(qkv), _stream()), "relattn_fused_fwd")
+    return out, lse
+
+
+def relattn_fused_bwd_q(qkv, ubias, vbias, pext, lengths, o, dout, lse, B, H, T, dh, ldp, scale, use_mask=True):
+    dqu = torch.empty(B * T, H * dh, dtype=qkv.dtype, device=qkv.device)
+    dpos = torch.empty(B, H, T, ldp, dtype=qkv.dtype, device=qkv.device)
+    dvec = torch.empty(B, H, T, dtype=torch.float32, device=qkv.device)
+    check(_L().tfasr_relattn_fused_bwd_q(_p(qkv), _p(ubias), _p(vbias), _p(pext), _p(lengths), _p(o), _p(dout), _p(lse), _p(dqu), _p(dpos),
+                                         _p(dvec), B, H, T, dh, ldp, scale, int(use_mask), _dt(qkv), _stream()), "relattn_fused_bwd_q")
+    return dqu, dpos, dvec
+
+
+def relattn_fused_bwd_k(qkv, qu, qv, pext, lengths, dout, lse, dvec, dqkv, B, H, T, dh, scale, use_mask=True):
+    check(_L().tfasr_relattn_fused_bwd_k(_p(qkv), _p(qu), _p(qv), _p(pext), _p(lengths), _p(dout), _p(lse), _p(dvec), _p(dqkv), B, H, T, dh,
+                                         scale, int(use_mask), _dt(qkv), _stream()), "relattn_fused_bwd_k")
+    return dqkv
+
+
 # -------------------------------------------------------------------------------------- LSTM
 def lstm_step_fwd(xg_t, hr, h_prev, c_prev, lengths, t, gates_t, c_out, h_out, y_out, B, P):
     check(_L().tfasr_lstm_step_fwd(

@@ -292,3 +292,100 @@ def test_logmel(dev, n):
     assert out.shape == ref.shape
     # <= 1e-4 abs in the log domain
     np.testing.assert_allclose(out.cpu().numpy(), ref, atol=1e-4, rtol=1e-5)
+
+
+def _relattn_reference(qkv, u, v, pext, lens, B, H, T, dh, scale, use_mask=True):
+    """f32 reference of the fused kernel from the same (bf16-rounded) inputs, via the gather identity of attention.hip."""
+    HD = H * dh
+    Rr = 2 * T - 1
+    q = qkv[:, :HD].view(B, T, H, dh)
+    k = qkv[:, HD:2 * HD].view(B, T, H, dh)
+    vv = qkv[:, 2 * HD:].view(B, T, H, dh)
+    qu = (q + u.view(H, dh)).to(torch.bfloat16).float()
+    qv = (q + v.view(H, dh)).to(torch.bfloat16).float()
+    content = torch.einsum("bthe,bshe->bhts", qu, k)
+    pos_all = torch.einsum("bthe,rhe->bhtr", qv, pext.view(2 * T, H, dh))
+    idx = torch.zeros(B, T, T, dtype=torch.long)
+    ii, jj = torch.meshgrid(torch.arange(T), torch.arange(T), indexing="ij")
+    for b in range(B):
+        r = T - 1 - ii + jj
+        idx[b] = torch.where(r < 2 * lens[b] - 1, r + T - lens[b], torch.full_like(r, Rr))
+    pos = torch.gather(pos_all, 3, idx[:, None].expand(B, H, T, T))
+    s = (content + pos) * scale
+    if use_mask:
+        qmask = (torch.arange(T)[None] < torch.tensor(lens)[:, None])[:, None, :, None]
+        s = torch.where(qmask, s, torch.zeros_like(s))
+    lse = torch.logsumexp(s, -1)
+    out = torch.einsum("bhts,bshe->bthe", torch.softmax(s, -1), vv).reshape(B * T, HD)
+    return out, lse
+
+
+@pytest.mark.parametrize("T,lens", [(75, [75, 75]), (130, [130, 97]), (64, [64, 1]), (200, [150, 200])])
+def test_relattn_fused_forward(dev, T, lens):
+    g = torch.Generator().manual_seed(T)
+    B, H, dh = 2, 4, 64
+    HD = H * dh
+    qkv = (torch.randn(B * T, 3 * HD, generator=g) * 0.7).to(torch.bfloat16)
+    u, v = torch.randn(HD, generator=g) * 0.3, torch.randn(HD, generator=g) * 0.3
+    pext = (torch.randn(2 * T, HD, generator=g) * 0.7).to(torch.bfloat16)
+    scale = 1.0 / 8.0
+    ref_out, ref_lse = _relattn_reference(qkv.float(), u, v, pext.float(), lens, B, H, T, dh, scale)
+    out, lse = K.relattn_fused_fwd(qkv.to(dev), u.to(dev), v.to(dev), pext.to(dev), torch.tensor(lens, dtype=torch.int32, device=dev), B, H, T, dh, scale)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(lse.cpu().numpy(), ref_lse.numpy(), rtol=2e-3, atol=2e-3)
+    np.testing.assert_allclose(out.float().cpu().numpy(), ref_out.numpy(), rtol=2e-2, atol=2e-2)
+
+
+def _relattn_ref_parts(qkv, u, v, pext, lens, B, H, T, dh, scale):
+    """autograd-able pieces: leaves qu, kk, vv, pos_all -> out."""
+    HD = H * dh
+    Rr = 2 * T - 1
+    q = qkv[:, :HD].view(B, T, H, dh)
+    qu = (q + u.view(H, dh)).to(torch.bfloat16).float().requires_grad_(True)
+    qv = (q + v.view(H, dh)).to(torch.bfloat16).float()
+    k = qkv[:, HD:2 * HD].view(B, T, H, dh).clone().requires_grad_(True)
+    vv = qkv[:, 2 * HD:].view(B, T, H, dh).clone().requires_grad_(True)
+    pos_all = torch.einsum("bthe,rhe->bhtr", qv, pext.view(2 * T, H, dh)).detach().requires_grad_(True)
+    ii, jj = torch.meshgrid(torch.arange(T), torch.arange(T), indexing="ij")
+    idx = torch.zeros(B, T, T, dtype=torch.long)
+    for b in range(B):
+        r = T - 1 - ii + jj
+        idx[b] = torch.where(r < 2 * lens[b] - 1, r + T - lens[b], torch.full_like(r, Rr))
+    s = (torch.einsum("bthe,bshe->bhts", qu, k) + torch.gather(pos_all, 3, idx[:, None].expand(B, H, T, T))) * scale
+    qmask = (torch.arange(T)[None] < torch.tensor(lens)[:, None])[:, None, :, None]
+    s = torch.where(qmask, s, torch.zeros_like(s))
+    out = torch.einsum("bhts,bshe->bthe", torch.softmax(s, -1), vv).reshape(B * T, HD)
+    return out, torch.logsumexp(s, -1), qu, k, vv, pos_all
+
+
+@pytest.mark.parametrize("T,lens", [(75, [75, 75]), (130, [130, 97]), (64, [64, 1]), (200, [150, 200])])
+def test_relattn_fused_backward(dev, T, lens):
+    g = torch.Generator().manual_seed(T + 1)
+    B, H, dh = 2, 4, 64
+    HD = H * dh
+    qkv = (torch.randn(B * T, 3 * HD, generator=g) * 0.7).to(torch.bfloat16)
+    u, v = torch.randn(HD, generator=g) * 0.3, torch.randn(HD, generator=g) * 0.3
+    pext = (torch.randn(2 * T, HD, generator=g) * 0.7).to(torch.bfloat16)
+    dout = torch.randn(B * T, HD, generator=g).to(torch.bfloat16)
+    scale = 1.0 / 8.0
+    out, lse, qu, k, vv, pos_all = _relattn_ref_parts(qkv.float(), u, v, pext.float(), lens, B, H, T, dh, scale)
+    out.backward(dout.float())
+    ln = torch.tensor(lens, dtype=torch.int32, device=dev)
+    o_d, lse_d = K.relattn_fused_fwd(qkv.to(dev), u.to(dev), v.to(dev), pext.to(dev), ln, B, H, T, dh, scale)
+    ldp = -(-2 * T // 8) * 8
+    dqu, dpos, dvec = K.relattn_fused_bwd_q(qkv.to(dev), u.to(dev), v.to(dev), pext.to(dev), ln, o_d, dout.to(dev), lse_d, B, H, T, dh, ldp, scale)
+    torch.cuda.synchronize()
+    gq = qu.grad.reshape(B * T, HD)
+    np.testing.assert_allclose(dqu.float().cpu().numpy(), gq.numpy(), rtol=3e-2, atol=3e-2 * float(gq.abs().max()))
+    gp = pos_all.grad  # [B,H,T,2T]
+    np.testing.assert_allclose(dpos[..., :2 * T].float().cpu().numpy(), gp.numpy(), rtol=3e-2, atol=3e-2 * float(gp.abs().max()))
+    assert dpos[..., 2 * T:].abs().max().item() == 0 if ldp > 2 * T else True
+    # key side
+    qud, qvd = K.bias2_fwd(qkv.to(dev), 3 * HD, u.to(dev), v.to(dev), B * T, HD)
+    dqkv = torch.zeros(B * T, 3 * HD, dtype=torch.bfloat16, device=dev)
+    K.relattn_fused_bwd_k(qkv.to(dev), qud, qvd, pext.to(dev), ln, dout.to(dev), lse_d, dvec, dqkv, B, H, T, dh, scale)
+    torch.cuda.synchronize()
+    gk, gv = k.grad.reshape(B * T, HD), vv.grad.reshape(B * T, HD)
+    np.testing.assert_allclose(dqkv[:, HD:2 * HD].float().cpu().numpy(), gk.numpy(), rtol=3e-2, atol=3e-2 * float(gk.abs().max()))
+    np.testing.assert_allclose(dqkv[:, 2 * HD:].float().cpu().numpy(), gv.numpy(), rtol=3e-2, atol=3e-2 * float(gv.abs().max()))
+    assert dqkv[:, :HD].abs().max().item() == 0

@@ -91,6 +91,21 @@ def probe_modelgemm():
     print(json.dumps({"sum_ms_per_step": round(tot, 2)}))
 
 
+def probe_attn():
+    """fused forward vs the unfused GEMM + softmax sequence at Conformer-M bench shape."""
+    import math
+    B, H, T, dh = 32, 4, 595, 64
+    HD = H * dh
+    dt = torch.bfloat16
+    qkv = torch.randn(B * T, 3 * HD, device=dev).to(dt)
+    u, v = torch.randn(HD, device=dev) * 0.1, torch.randn(HD, device=dev) * 0.1
+    pext = torch.randn(2 * T, HD, device=dev).to(dt)
+    ln = torch.full((B,), T, dtype=torch.int32, device=dev)
+    ms = timeit(lambda: kernels.relattn_fused_fwd(qkv, u, v, pext, ln, B, H, T, dh, 0.125), iters=10)
+    fl = 2.0 * B * H * T * T * dh * 4  # QK, QP(window ~2x counted as 1 useful), PV
+    print(json.dumps({"kernel": "relattn_fused_fwd", "ms": ms, "useful_TFLOPs": 2.0 * B * H * T * T * dh * 3 / ms / 1e9}))
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["rnnt", "gemm"]
     for w in which:
