@@ -10,6 +10,7 @@ C-ABI kernel launches on one HIP stream (prediction network on a second stream, 
 PyTorch only owns device memory and streams here.  There is no CPU / eager fallback.
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -257,9 +258,18 @@ class ConformerTransducer:
         scale = 1.0 / math.sqrt(dh)
         ln, mean, rstd = K.layernorm_fwd(x, ps.p(pfx + "ln/g"), ps.p(pfx + "ln/b"))
         qkv = K.matmul(ln, ps.w2d(pfx + "qkv/w"), bias=ps.p(pfx + "qkv/b"))  # [B*T, 3HD]
-        qu, qv = K.bias2_fwd(qkv, 3 * HD, ps.p("enc/u"), ps.p("enc/v"), B * T, HD)
         pe = self._pe_ext(T)
         pext = K.matmul(pe, ps.w2d(pfx + "pos/w"), bias=ps.p(pfx + "pos/b"))  # [2T, HD]
+        drop = self._drop(site, training)
+        if self._fused_attention():
+            # flash-style kernel: scores, shift, mask, softmax and P@V never leave the CU (csrc/attn_fused.hip)
+            att, lse = K.relattn_fused_fwd(qkv, ps.p("enc/u"), ps.p("enc/v"), pext, elen_dev, B, H, T, dh, scale,
+                                           use_mask=c.use_attention_auto_mask)
+            y = K.matmul(att, ps.w2d(pfx + "o/w"), bias=ps.p(pfx + "o/b"), res=x, beta=c.mhsam_residual, drop_p=drop[0], drop_seed=drop[1])
+            if ctx is not None:
+                ctx[pfx] = dict(x=x, ln=ln, mean=mean, rstd=rstd, qkv=qkv, pext=pext, lse=lse, att=att, drop=drop)
+            return y
+        qu, qv = K.bias2_fwd(qkv, 3 * HD, ps.p("enc/u"), ps.p("enc/v"), B * T, HD)
         kk = qkv[:, HD:]
         vv = qkv[:, 2 * HD:]
         Tp, R1p = -(-T // 8) * 8, -(-R1 // 8) * 8  # row strides padded to 16 B so the score matrices can be LDS-DMA'd
@@ -272,7 +282,6 @@ class ConformerTransducer:
         probs = K.relattn_softmax_fwd(content, pos, elen_dev, T, use_mask=c.use_attention_auto_mask, probs=content)
         att = torch.empty(B * T, HD, dtype=self.dtype, device=self.device)
         K.gemm(probs, vv, att, T, dh, T, Tp, 3 * HD, HD, nb1=B, nb2=H, sA=(H * T * Tp, T * Tp), sB=(T * 3 * HD, dh), sD=(T * HD, dh))
-        drop = self._drop(site, training)
         y = K.matmul(att, ps.w2d(pfx + "o/w"), bias=ps.p(pfx + "o/b"), res=x, beta=c.mhsam_residual, drop_p=drop[0], drop_seed=drop[1])
         if ctx is not None:
             ctx[pfx] = dict(x=x, ln=ln, mean=mean, rstd=rstd, qkv=qkv, qu=qu, qv=qv, pext=pext, probs=probs, att=att, drop=drop)
@@ -285,10 +294,19 @@ class ConformerTransducer:
         R1 = 2 * T
         scale = 1.0 / math.sqrt(dh)
         s = ctx.pop(pfx)
-        qkv, probs = s["qkv"], s["probs"]
-        kk, vv = qkv[:, HD:], qkv[:, 2 * HD:]
+        qkv = s["qkv"]
         datt = self._dense_bwd(self._mask_grad(dy, s["drop"]), s["att"], pfx + "o/w", pfx + "o/b", alpha=c.mhsam_residual)
         dqkv = torch.empty_like(qkv)
+        if "lse" in s:
+            R1p = -(-R1 // 8) * 8
+            um = c.use_attention_auto_mask
+            dqu, dpos, dvec = K.relattn_fused_bwd_q(qkv, ps.p("enc/u"), ps.p("enc/v"), s["pext"], elen_dev, s["att"], datt, s["lse"], B, H, T, dh,
+                                                    R1p, scale, use_mask=um)
+            qu, qv = K.bias2_fwd(qkv, 3 * HD, ps.p("enc/u"), ps.p("enc/v"), B * T, HD)
+            K.relattn_fused_bwd_k(qkv, qu, qv, s["pext"], elen_dev, datt, s["lse"], dvec, dqkv, B, H, T, dh, scale, use_mask=um)
+            return self._mhsa_bwd_tail(dy, pfx, B, T, s, dqkv, dqu, dpos, qv, R1p, 1.0)
+        probs = s["probs"]
+        kk, vv = qkv[:, HD:], qkv[:, 2 * HD:]
         # dprobs = datt @ v^T
         Tp, R1p = -(-T // 8) * 8, -(-R1 // 8) * 8
         dprobs = torch.empty(B, H, T, Tp, dtype=self.dtype, device=self.device)
@@ -304,12 +322,23 @@ class ConformerTransducer:
                sD=(T * HD, dh), alpha=scale)
         K.gemm(dcontent, s["qu"], dqkv[:, HD:], T, dh, T, Tp, HD, 3 * HD, trans_a=True, nb1=B, nb2=H, sA=(H * T * Tp, T * Tp),
                sB=(T * HD, dh), sD=(T * 3 * HD, dh), alpha=scale)
+        return self._mhsa_bwd_tail(dy, pfx, B, T, s, dqkv, dqu, dpos, s["qv"], R1p, scale)
+
+    def _fused_attention(self):
+        return self.dtype == torch.bfloat16 and self.cfg.head_size == 64 and os.environ.get("TFASR_ATTN_UNFUSED", "0") != "1"
+
+    def _mhsa_bwd_tail(self, dy, pfx, B, T, s, dqkv, dqu, dpos, qv, R1p, scale):
+        """dpos [B,H,T,R1p] (gradient of the un-shifted position scores) -> dqv, dpext, bias and projection gradients."""
+        ps, c = self.ps, self.cfg
+        H, dh = c.num_heads, c.head_size
+        HD = H * dh
+        R1 = 2 * T
         # dqv = scale * dpos @ pext ; dpext += scale * sum_b dpos^T @ qv
         dqv = torch.empty(B * T, HD, dtype=self.dtype, device=self.device)
         K.gemm(dpos, s["pext"], dqv, T, dh, R1, R1p, HD, HD, nb1=B, nb2=H, sA=(H * T * R1p, T * R1p), sB=(0, dh), sD=(T * HD, dh),
                alpha=scale)
         dpext = torch.zeros(R1, HD, dtype=torch.float32, device=self.device)
-        K.gemm(dpos, s["qv"], dpext, R1, dh, T, R1p, HD, HD, trans_a=True, nb1=B, nb2=H, sA=(H * T * R1p, T * R1p), sB=(T * HD, dh),
+        K.gemm(dpos, qv, dpext, R1, dh, T, R1p, HD, HD, trans_a=True, nb1=B, nb2=H, sA=(H * T * R1p, T * R1p), sB=(T * HD, dh),
                sD=(0, dh), alpha=scale, accumulate=True)
         K.bias2_bwd(dqu, dqv, dqkv, 3 * HD, ps.g("enc/u"), ps.g("enc/v"), B * T, HD)
         # positional projection: gWpos += pe^T dpext ; gbpos += colsum(dpext)
