@@ -83,21 +83,26 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
   return r;
 }
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }  // v_rcp_f32: 1 ulp
 __device__ __forceinline__ float swishf_(float x) { return x * sigmoidf_(x); }
 // d/dx [x * sigmoid(x)] = s + x*s*(1-s)
 __device__ __forceinline__ float dswishf_(float x) { const float s = sigmoidf_(x); return s * (1.f + x * (1.f - s)); }
 
-// counter-based dropout mask: keep iff a 32-bit avalanche hash of (seed, element index), as a uniform in [0,1), is >= p.
-// Two 32-bit multiplies per element (murmur3 finaliser); the seed and the index's high word are folded in first.
+// counter-based dropout mask: one 32-bit avalanche hash (murmur3 finaliser) of (seed, element index / 2) serves an
+// even/odd element pair, 16 bits each; keep iff the 16-bit uniform >= round(p * 65536).  Forward and backward regenerate
+// the identical mask from (seed, index), nothing is stored.
 __device__ __forceinline__ uint32_t fmix32(uint32_t x) {
   x ^= x >> 16; x *= 0x85ebca6bu; x ^= x >> 13; x *= 0xc2b2ae35u; x ^= x >> 16;
   return x;
 }
+__device__ __forceinline__ uint32_t drop_thr(float p) { return (uint32_t)(p * 65536.f + 0.5f); }
+__device__ __forceinline__ uint32_t drop_hash(uint64_t seed, uint64_t pair) {
+  const uint32_t k = (uint32_t)seed * 0x9E3779B1u ^ (uint32_t)(seed >> 32) ^ ((uint32_t)(pair >> 32) * 0x7FEB352Du);
+  return fmix32((uint32_t)pair ^ k);
+}
 __device__ __forceinline__ bool drop_keep(uint64_t seed, uint64_t idx, float p) {
-  const uint32_t k = (uint32_t)seed * 0x9E3779B1u ^ (uint32_t)(seed >> 32) ^ ((uint32_t)(idx >> 32) * 0x7FEB352Du);
-  const uint32_t h = fmix32((uint32_t)idx ^ k);
-  return (float)(h >> 8) * (1.0f / 16777216.0f) >= p;
+  const uint32_t h = drop_hash(seed, idx >> 1);
+  return ((idx & 1) ? (h >> 16) : (h & 0xffffu)) >= drop_thr(p);
 }
 
 // log(exp(a)+exp(b)) with -inf handling (the 2-term log-sum-exp of losses/impl/rnnt.py:72-78,126)

@@ -165,7 +165,21 @@ __global__ __launch_bounds__(256, 2) void gemm_fast_kernel(const tfasr_gemm_args
   const bf16_t* A = (const bf16_t*)p.A + b1 * p.sA1 + b2 * p.sA2;
   const bf16_t* Bm = (const bf16_t*)p.B + b1 * p.sB1 + b2 * p.sB2;
   const long doff = b1 * p.sD1 + b2 * p.sD2;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  // XCD-aware tile order: hardware deals consecutive workgroup ids round-robin over the 8 XCDs (each with its own L2),
+  // so give every XCD one contiguous run of the n-fastest tile sequence: the n-tiles that share an A row-block then hit
+  // the same L2 instead of fetching it over the fabric once per XCD (bijective remap, guide "XCD swizzle").
+  int tile_x = blockIdx.x, tile_y = blockIdx.y;
+  {
+    const int gx = gridDim.x, total = gx * gridDim.y;
+    if (total >= 16) {
+      const int L = blockIdx.x + gx * blockIdx.y;
+      const int q = total >> 3, rem = total & 7, xcd = L & 7, slot = L >> 3;
+      const int Lp = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + slot;
+      tile_x = Lp % gx;
+      tile_y = Lp / gx;
+    }
+  }
+  const int m0 = tile_y * BM, n0 = tile_x * BN;
   int kchunk = (p.K + split - 1) / split;
   kchunk = ((kchunk + BK - 1) / BK) * BK;
   const int k_begin = ks * kchunk;
@@ -250,6 +264,27 @@ __global__ __launch_bounds__(256, 2) void gemm_fast_kernel(const tfasr_gemm_args
   float* sc = reinterpret_cast<float*>(smem) + w * (16 * SLD);
   const int rr = lane >> 2, cseg = (lane & 3) * CPL;
   const bool vec_ok = ((p.ldd & 7) == 0) && ((((uintptr_t)p.D) & 15) == 0) && ((doff & 7) == 0);
+  // bias for this lane's CPL columns (the same in all four strips)
+  float bv[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) bv[q] = 0.f;
+  {
+    const int col0 = n0 + wn * WN + cseg;
+    if (p.bias && first_split && col0 < p.N) {
+      const float* bp = p.bias + col0;
+      if (col0 + CPL <= p.N && ((((uintptr_t)bp) & 15) == 0)) {
+#pragma unroll
+        for (int q = 0; q < CPL / 4; ++q) {
+          const float4 t = *reinterpret_cast<const float4*>(bp + q * 4);
+          bv[q * 4] = t.x; bv[q * 4 + 1] = t.y; bv[q * 4 + 2] = t.z; bv[q * 4 + 3] = t.w;
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) if (col0 + q < p.N) bv[q] = bp[q];
+      }
+    }
+  }
+  const uint32_t dthr = drop_thr(p.drop_p);
   auto strip = [&](auto I_) {
     constexpr int i = decltype(I_)::value;
 #pragma unroll
@@ -272,11 +307,7 @@ __global__ __launch_bounds__(256, 2) void gemm_fast_kernel(const tfasr_gemm_args
       const long idx0 = (long)row * p.ldd + col0;
       const bool full = vec_ok && (col0 + CPL <= p.N);
 #pragma unroll
-      for (int q = 0; q < CPL; ++q) {
-        float x = p.alpha * v[q];
-        if (p.bias && first_split && col0 + q < p.N) x += p.bias[col0 + q];
-        v[q] = x;
-      }
+      for (int q = 0; q < CPL; ++q) v[q] = p.alpha * v[q] + bv[q];
       if (prez) {
         if (full) { st8(prez + idx0, *reinterpret_cast<const float(*)[8]>(v)); if (CPL == 16) st8(prez + idx0 + 8, *reinterpret_cast<const float(*)[8]>(v + 8)); }
         else
@@ -298,8 +329,18 @@ _Pragma("unroll")
       }
       if (p.drop_p > 0.f) {
         const float inv = 1.f / (1.f - p.drop_p);
+        const uint64_t e0 = (uint64_t)(doff + idx0);
+        if ((e0 & 1) == 0) {  // one hash per even/odd element pair
 #pragma unroll
-        for (int q = 0; q < CPL; ++q) v[q] = drop_keep((uint64_t)p.drop_seed, (uint64_t)(doff + idx0 + q), p.drop_p) ? v[q] * inv : 0.f;
+          for (int q = 0; q < CPL; q += 2) {
+            const uint32_t h = drop_hash((uint64_t)p.drop_seed, (e0 >> 1) + (q >> 1));
+            v[q] = (h & 0xffffu) >= dthr ? v[q] * inv : 0.f;
+            v[q + 1] = (h >> 16) >= dthr ? v[q + 1] * inv : 0.f;
+          }
+        } else {
+#pragma unroll
+          for (int q = 0; q < CPL; ++q) v[q] = drop_keep((uint64_t)p.drop_seed, e0 + q, p.drop_p) ? v[q] * inv : 0.f;
+        }
       }
       if (res) {
         float z[16];

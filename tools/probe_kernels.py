@@ -4,6 +4,7 @@ import sys
 import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+from tensorflowasr_amd.kernels import ACT_SWISH
 
 from tensorflowasr_amd import kernels
 
@@ -104,6 +105,30 @@ def probe_attn():
     ms = timeit(lambda: kernels.relattn_fused_fwd(qkv, u, v, pext, ln, B, H, T, dh, 0.125), iters=10)
     fl = 2.0 * B * H * T * T * dh * 4  # QK, QP(window ~2x counted as 1 useful), PV
     print(json.dumps({"kernel": "relattn_fused_fwd", "ms": ms, "useful_TFLOPs": 2.0 * B * H * T * T * dh * 3 / ms / 1e9}))
+
+
+def probe_epi():
+    """Cost of each fused epilogue term on the ffn1-forward / ffn2-dgrad shapes."""
+    dt = torch.bfloat16
+    M = 23808
+    x = torch.randn(M, 256, device=dev).to(dt)
+    w = torch.randn(256, 1024, device=dev).to(dt)
+    b = torch.randn(1024, device=dev)
+    out = torch.empty(M, 1024, device=dev, dtype=dt)
+    z = torch.empty(M, 1024, device=dev, dtype=dt)
+    zz = torch.randn(M, 1024, device=dev).to(dt)
+    variants = [("plain", {}), ("bias", dict(bias=b)), ("bias+prez", dict(bias=b, prez=z)), ("bias+swish", dict(bias=b, act=ACT_SWISH)),
+                ("bias+drop", dict(bias=b, drop_p=0.1, drop_seed=1234)), ("bias+prez+swish+drop", dict(bias=b, prez=z, act=ACT_SWISH, drop_p=0.1, drop_seed=1234)),
+                ("dact_z", dict(dact_z=zz, dact=ACT_SWISH)), ("dact_z+drop", dict(dact_z=zz, dact=ACT_SWISH, drop_p=0.1, drop_seed=77))]
+    for name, kw in variants:
+        ms = timeit(lambda: kernels.matmul(x, w, out=out, **kw), iters=20)
+        print(json.dumps({"epilogue": name, "us": round(ms * 1e3, 1)}))
+    h = torch.randn(M, 1024, device=dev).to(dt)
+    w2 = torch.randn(1024, 256, device=dev).to(dt)
+    o2 = torch.empty(M, 256, device=dev, dtype=dt)
+    for name, kw in [("ffn2 plain", {}), ("ffn2 bias+res", dict(bias=b[:256], res=x, beta=0.5)), ("ffn2 bias+res+drop", dict(bias=b[:256], res=x, beta=0.5, drop_p=0.1, drop_seed=5))]:
+        ms = timeit(lambda: kernels.matmul(h, w2, out=o2, **kw), iters=20)
+        print(json.dumps({"epilogue": name, "us": round(ms * 1e3, 1)}))
 
 
 if __name__ == "__main__":
