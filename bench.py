@@ -200,6 +200,7 @@ def main():
     batches = [make_batch(cfg, args.batch, seed=10 + 97 * rank + 13 * i, padding=args.padding, size=size) for i in range(nb)]
     data = [to_train_data(b, dev) for b in batches]
     model.timers = {}
+    model.time_sections = bool(os.environ.get("TFASR_BENCH_SECTIONS"))
 
     def one_step(i):
         return model.train_step(data[i % nb])
@@ -215,10 +216,13 @@ def main():
     for i in range(args.steps):
         one_step(i)
         secs_local += batches[i % nb]["seconds"]
+    t_host = time.perf_counter() - t0  # host-side enqueue time (the GPU may still be running)
     torch.cuda.synchronize()
     if dp:
         dp.barrier()
     dt = time.perf_counter() - t0
+    if rank == 0 and os.environ.get("TFASR_BENCH_HOST"):
+        sys.stderr.write(f"[host] enqueue {t_host / args.steps * 1e3:.2f} ms/step of {dt / args.steps * 1e3:.2f} ms/step\n")
     if dp:
         dt = dp.max_scalar(dt, dev)
         secs_total = dp.mean_scalar(torch.tensor([secs_local], dtype=torch.float64, device=dev)).item() * world

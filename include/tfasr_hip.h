@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define TFASR_ABI_VERSION 5
+#define TFASR_ABI_VERSION 6
 
 typedef enum {
   TFASR_STATUS_SUCCESS = 0,
@@ -275,6 +275,66 @@ int tfasr_col2im_3x3s2(const void* dcol, void* dx, int B, int T1, int F1, int C,
 int tfasr_logmel(const float* signal, int B, int N, float preemph, const float* window, int frame_len, int frame_step,
                  int nfft, const float* melw, const int32_t* band, int F, float eps, void* out, int T0, int dtype,
                  void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Native executor of one Conformer block (ConformerBlock.call, encoders/conformer.py:430-520, and its backward):
+ * queues every kernel of FFModule -> MHSAModule -> ConvModule -> FFModule -> LayerNorm on `stream` with one host call.
+ * All parameters live in three flat buffers (f32 master, compute-dtype shadow, f32 gradient) addressed by the element
+ * offsets off[TFASR_BP_*]; intermediates are carved from the caller's arenas: `stash` keeps what the backward needs
+ * (sizes: tfasr_block_workspace_sizes), `scratch` is free again after the call (between phase A and B of one backward it
+ * must stay untouched).  ctx = tfasr_block_ctx_bytes() bytes of host memory, written by _fwd and read by _bwd.
+ * Phases (TFASR_PHASE_A|TFASR_PHASE_B = everything): A ends after the conv module's BatchNorm statistics are in
+ * io->bn_stats [2d+1] (forward) / io->bn_bstats [2d] (backward) so that a data-parallel caller can all-reduce them
+ * before phase B (keras BatchNormalization(synchronized=True), conformer.py:327-333).
+ * ---------------------------------------------------------------------------------------------- */
+typedef enum {
+  TFASR_BP_FF1_LN_G = 0, TFASR_BP_FF1_LN_B, TFASR_BP_FF1_D1_W, TFASR_BP_FF1_D1_B, TFASR_BP_FF1_D2_W, TFASR_BP_FF1_D2_B,
+  TFASR_BP_FF2_LN_G, TFASR_BP_FF2_LN_B, TFASR_BP_FF2_D1_W, TFASR_BP_FF2_D1_B, TFASR_BP_FF2_D2_W, TFASR_BP_FF2_D2_B,
+  TFASR_BP_AT_LN_G, TFASR_BP_AT_LN_B, TFASR_BP_AT_QKV_W, TFASR_BP_AT_QKV_B, TFASR_BP_AT_POS_W, TFASR_BP_AT_POS_B,
+  TFASR_BP_AT_O_W, TFASR_BP_AT_O_B, TFASR_BP_AT_U, TFASR_BP_AT_V,
+  TFASR_BP_CV_LN_G, TFASR_BP_CV_LN_B, TFASR_BP_CV_PW1_W, TFASR_BP_CV_PW1_B, TFASR_BP_CV_DW_W, TFASR_BP_CV_DW_B,
+  TFASR_BP_CV_BN_G, TFASR_BP_CV_BN_B, TFASR_BP_CV_PW2_W, TFASR_BP_CV_PW2_B,
+  TFASR_BP_LN_G, TFASR_BP_LN_B, TFASR_BP_COUNT
+} tfasr_block_param_t;
+#define TFASR_PHASE_A 1
+#define TFASR_PHASE_B 2
+
+typedef struct {
+  int B, T, d, H, dh, dff, ksize;   /* batch, frames, model dim, heads, head size, FFN dim, depthwise kernel size */
+  int dtype;                        /* tfasr_dtype_t of activations / shadow weights */
+  int training;                     /* dropout + batch statistics on */
+  int save;                         /* keep what the backward needs (pre-activations) */
+  int use_mask;                     /* attention auto mask (query rows >= length) */
+  int force_unfused;                /* 1: never use the fused attention kernels */
+  int world;                        /* data-parallel world size (BatchNorm count / gradient scaling) */
+  int site0;                        /* first dropout site id of this block */
+  long drop_epoch;                  /* bumped once per forward pass: seed = drop_epoch*8192 + site */
+  float drop_p, ffm_res, mhsa_res, conv_res, ln_eps, bn_eps, bn_momentum;
+} tfasr_block_cfg;
+
+typedef struct {
+  const float* flat; const void* shadow; float* grad;  /* flat parameter buffers */
+  float* bn_mm; float* bn_mv;                          /* conv-module BatchNorm moving mean / variance [d] */
+  const void* pe;                                      /* relative sinusoid table [2T, d], compute dtype (row 2T-1 zero) */
+  long off[TFASR_BP_COUNT];
+} tfasr_block_params;
+
+typedef struct {
+  const void* x_in; void* x_out;        /* forward: block input / output [B*T, d] */
+  const void* dy; void* dx;             /* backward: gradient w.r.t. output / input */
+  const int32_t* lengths;               /* [B] valid frames */
+  float* bn_stats; float* bn_bstats;    /* [2d+1] / [2d] f32 */
+  void* stash; size_t stash_bytes;
+  void* scratch; size_t scratch_bytes;
+} tfasr_block_io;
+
+size_t tfasr_block_ctx_bytes(void);
+int tfasr_block_workspace_sizes(const tfasr_block_cfg* cfg, size_t* stash_bytes, size_t* fwd_scratch_bytes,
+                                size_t* bwd_scratch_bytes);
+int tfasr_block_fwd(const tfasr_block_cfg* cfg, const tfasr_block_params* params, const tfasr_block_io* io, void* ctx,
+                    int phase, void* stream);
+int tfasr_block_bwd(const tfasr_block_cfg* cfg, const tfasr_block_params* params, const tfasr_block_io* io, void* ctx,
+                    int phase, void* stream);
 
 #ifdef __cplusplus
 }

@@ -33,6 +33,41 @@ class GemmArgs(Structure):
     ]
 
 
+BLOCK_PARAM_NAMES = [  # order of tfasr_block_param_t (include/tfasr_hip.h); names relative to "enc/block{i}/"
+    "ff1/ln/g", "ff1/ln/b", "ff1/d1/w", "ff1/d1/b", "ff1/d2/w", "ff1/d2/b",
+    "ff2/ln/g", "ff2/ln/b", "ff2/d1/w", "ff2/d1/b", "ff2/d2/w", "ff2/d2/b",
+    "mhsa/ln/g", "mhsa/ln/b", "mhsa/qkv/w", "mhsa/qkv/b", "mhsa/pos/w", "mhsa/pos/b", "mhsa/o/w", "mhsa/o/b", "/enc/u", "/enc/v",
+    "conv/ln/g", "conv/ln/b", "conv/pw1/w", "conv/pw1/b", "conv/dw/w", "conv/dw/b", "conv/bn/g", "conv/bn/b", "conv/pw2/w", "conv/pw2/b",
+    "ln/g", "ln/b",
+]
+PHASE_A, PHASE_B = 1, 2
+
+
+class BlockCfg(Structure):
+    _fields_ = [
+        ("B", c_int), ("T", c_int), ("d", c_int), ("H", c_int), ("dh", c_int), ("dff", c_int), ("ksize", c_int),
+        ("dtype", c_int), ("training", c_int), ("save", c_int), ("use_mask", c_int), ("force_unfused", c_int), ("world", c_int),
+        ("site0", c_int), ("drop_epoch", c_long),
+        ("drop_p", c_float), ("ffm_res", c_float), ("mhsa_res", c_float), ("conv_res", c_float), ("ln_eps", c_float), ("bn_eps", c_float),
+        ("bn_momentum", c_float),
+    ]
+
+
+class BlockParams(Structure):
+    _fields_ = [
+        ("flat", c_void_p), ("shadow", c_void_p), ("grad", c_void_p), ("bn_mm", c_void_p), ("bn_mv", c_void_p), ("pe", c_void_p),
+        ("off", c_long * len(BLOCK_PARAM_NAMES)),
+    ]
+
+
+class BlockIO(Structure):
+    _fields_ = [
+        ("x_in", c_void_p), ("x_out", c_void_p), ("dy", c_void_p), ("dx", c_void_p), ("lengths", c_void_p),
+        ("bn_stats", c_void_p), ("bn_bstats", c_void_p),
+        ("stash", c_void_p), ("stash_bytes", c_size_t), ("scratch", c_void_p), ("scratch_bytes", c_size_t),
+    ]
+
+
 def _parse_header():
     """Derive the ctypes signature table from include/tfasr_hip.h (single source of truth for the ABI)."""
     import re
@@ -44,9 +79,9 @@ def _parse_header():
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     src = re.sub(r"typedef\s+struct\s*\{.*?\}\s*\w+\s*;", "", src, flags=re.S)
     sigs = {}
-    for m in re.finditer(r"(const\s+char\s*\*|int)\s+(tfasr_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", src):
+    for m in re.finditer(r"(const\s+char\s*\*|int|size_t)\s+(tfasr_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", src):
         ret, name, args = m.group(1), m.group(2), m.group(3).strip()
-        res = c_char_p if "char" in ret else c_int
+        res = c_char_p if "char" in ret else (c_size_t if ret == "size_t" else c_int)
         at = []
         if args and args != "void":
             for a in args.split(","):
@@ -109,7 +144,7 @@ def load(build_if_missing=True):
     return lib
 
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 def check(status, what=""):

@@ -65,8 +65,12 @@ class ConformerTransducer:
         self.ga_steps = 1
         self._ga_count = 0
         self._drop_epoch = 0  # bumped once per forward pass so every step draws fresh dropout masks
+        # one native call per Conformer block (csrc/block.hip) instead of ~70 per-kernel calls from Python
+        self.native_blocks = os.environ.get("TFASR_NATIVE_BLOCK", "1") != "0"
+        self._blk_params, self._blk_sizes = {}, {}
         self.timers = None  # optional dict name -> list[(start_event, end_event)] filled by bench.py
         self.timer_work = {}
+        self.time_sections = False  # per-module section timers (bench.py TFASR_BENCH_SECTIONS) need the per-kernel Python path
 
     # =================================================================================== constants
     def _frontend_consts(self):
@@ -124,6 +128,17 @@ class ConformerTransducer:
             return None
         return K.matmul(dy, W, trans_b=True, alpha=alpha, dact_z=dact_z, dact=dact, drop_p=drop[0], drop_seed=drop[1])
 
+    def _h2d(self, x, dtype=torch.int32):
+        """Small host array -> device through PINNED staging: a pageable hipMemcpyAsync makes the host wait until the stream
+        has drained up to the copy, which stops the host from queueing kernels ahead of the GPU several times per step."""
+        t = x if isinstance(x, torch.Tensor) else torch.as_tensor(np.asarray(x))
+        t = t.to(dtype)
+        if t.device.type == "cpu":
+            if self.device.type == "cuda":
+                t = t.pin_memory()
+            t = t.to(self.device, non_blocking=True)
+        return t
+
     # =================================================================================== frontend
     def frontend(self, signals, signals_length, training=False, masks=None):
         """FeatureExtraction.call (feature_extraction.py:255-303) -> features [B,T0,F] (compute dtype), feature lengths (host)."""
@@ -136,7 +151,7 @@ class ConformerTransducer:
                 masks = self.draw_specaugment(flen)
             fm, tm = masks
             if fm is not None or tm is not None:
-                K.specaugment(feats, None if fm is None else fm.to(self.device), None if tm is None else tm.to(self.device), 0.0)
+                K.specaugment(feats, None if fm is None else self._h2d(fm), None if tm is None else self._h2d(tm), 0.0)
         return feats, flen
 
     def draw_specaugment(self, flen):
@@ -417,6 +432,86 @@ class ConformerTransducer:
         self._tock("ffm_bwd", t0)
         return dx
 
+    # =================================================================================== native block executor
+    def _native_cfg(self, i, B, T, training, save):
+        c = self.cfg
+        k = K._lib.BlockCfg()
+        k.B, k.T, k.d, k.H, k.dh, k.dff, k.ksize = B, T, c.dmodel, c.num_heads, c.head_size, self.ps.shapes["enc/block0/ff1/d1/w"][1], c.kernel_size
+        k.dtype = K._dt(self.ps.shadow)
+        k.training, k.save, k.use_mask = int(training), int(save), int(c.use_attention_auto_mask)
+        k.force_unfused = int(not self._fused_attention())
+        k.world = self.dp.world
+        k.site0 = 16 + i * 8
+        k.drop_epoch = self._drop_epoch
+        k.drop_p = float(c.dropout)
+        k.ffm_res, k.mhsa_res, k.conv_res = c.ffm_residual, c.mhsam_residual, c.convm_residual
+        k.ln_eps, k.bn_eps, k.bn_momentum = 1e-3, 1e-3, 0.99
+        return k
+
+    def _native_params(self, i, T):
+        ps = self.ps
+        P = self._blk_params.get(i)
+        if P is None:
+            P = K._lib.BlockParams()
+            P.flat, P.shadow, P.grad = ps.flat.data_ptr(), ps.shadow.data_ptr(), ps.grad.data_ptr()
+            P.bn_mm, P.bn_mv = ps.state[f"enc/block{i}/conv/bn/mm"].data_ptr(), ps.state[f"enc/block{i}/conv/bn/mv"].data_ptr()
+            for j, nm in enumerate(K._lib.BLOCK_PARAM_NAMES):
+                P.off[j] = ps.offsets[nm[1:] if nm.startswith("/") else f"enc/block{i}/{nm}"]
+            self._blk_params[i] = P
+        P.pe = self._pe_ext(T).data_ptr()
+        return P
+
+    def _native_sizes(self, cfgk):
+        key = (cfgk.B, cfgk.T, cfgk.training, cfgk.save, cfgk.force_unfused, cfgk.drop_p > 0)
+        v = self._blk_sizes.get(key)
+        if v is None:
+            v = K.block_workspace_sizes(cfgk)
+            self._blk_sizes[key] = v
+        return v
+
+    def _block_fwd_native(self, x, i, B, T, elen_dev, training, ctx):
+        d = self.cfg.dmodel
+        save = ctx is not None
+        cfgk = self._native_cfg(i, B, T, training, save)
+        P = self._native_params(i, T)
+        stash_b, fscr_b, _ = self._native_sizes(cfgk)
+        y = torch.empty(B * T, d, dtype=self.dtype, device=self.device)
+        stash = torch.empty(stash_b, dtype=torch.uint8, device=self.device)
+        stats = torch.empty(2 * d + 1, dtype=torch.float32, device=self.device)
+        scratch = K.workspace(fscr_b, self.device, "blk_fwd")
+        io = K._lib.BlockIO()
+        io.x_in, io.x_out, io.lengths = x.data_ptr(), y.data_ptr(), elen_dev.data_ptr()
+        io.bn_stats = stats.data_ptr()
+        io.stash, io.stash_bytes, io.scratch, io.scratch_bytes = stash.data_ptr(), stash_b, scratch.data_ptr(), scratch.numel()
+        cbuf = K.block_ctx()
+        if training and self.dp.world > 1:
+            K.block_fwd(cfgk, P, io, cbuf, K._lib.PHASE_A)
+            self.dp.allreduce_stats_(stats[:2 * d])
+            K.block_fwd(cfgk, P, io, cbuf, K._lib.PHASE_B)
+        else:
+            K.block_fwd(cfgk, P, io, cbuf, K._lib.PHASE_A | K._lib.PHASE_B)
+        if save:
+            ctx[f"enc/block{i}/native"] = dict(cfg=cfgk, P=P, io=io, cbuf=cbuf, keep=(x, y, stash, stats, elen_dev))
+        return y
+
+    def _block_bwd_native(self, dy, i, ctx):
+        s = ctx.pop(f"enc/block{i}/native")
+        cfgk, P, io, cbuf = s["cfg"], s["P"], s["io"], s["cbuf"]
+        d = self.cfg.dmodel
+        _, _, bscr_b = self._native_sizes(cfgk)
+        dx = torch.empty(cfgk.B * cfgk.T, d, dtype=self.dtype, device=self.device)
+        bstats = torch.empty(2 * d, dtype=torch.float32, device=self.device)
+        scratch = K.workspace(bscr_b, self.device, "blk_bwd")
+        io.dy, io.dx, io.bn_bstats = dy.data_ptr(), dx.data_ptr(), bstats.data_ptr()
+        io.scratch, io.scratch_bytes = scratch.data_ptr(), scratch.numel()
+        if self.dp.world > 1:
+            K.block_bwd(cfgk, P, io, cbuf, K._lib.PHASE_A)
+            self.dp.allreduce_stats_(bstats)
+            K.block_bwd(cfgk, P, io, cbuf, K._lib.PHASE_B)
+        else:
+            K.block_bwd(cfgk, P, io, cbuf, K._lib.PHASE_A | K._lib.PHASE_B)
+        return dx
+
     # =================================================================================== encoder
     def encoder_fwd(self, feats, flen, training, ctx):
         """ConformerEncoder.call (conformer.py:672-701): subsample -> linear -> relpe -> blocks.  -> [B*T', d], T', lengths."""
@@ -424,9 +519,10 @@ class ConformerTransducer:
         x, T, elen = self._subsampling_fwd(feats, flen, training, ctx)
         self._tock("subsampling_fwd", t0)
         B = feats.shape[0]
-        elen_dev = torch.tensor(elen, dtype=torch.int32).to(self.device, non_blocking=True)
+        elen_dev = self._h2d(elen)
+        native = self.native_blocks and not self.time_sections
         for i in range(self.cfg.num_blocks):
-            x = self._block_fwd(x, i, B, T, elen_dev, training, ctx)
+            x = self._block_fwd_native(x, i, B, T, elen_dev, training, ctx) if native else self._block_fwd(x, i, B, T, elen_dev, training, ctx)
         if ctx is not None:
             ctx["enc"] = dict(B=B, T=T, elen_dev=elen_dev)
         return x, T, elen, elen_dev
@@ -434,7 +530,10 @@ class ConformerTransducer:
     def encoder_bwd(self, dx, ctx):
         e = ctx["enc"]
         for i in reversed(range(self.cfg.num_blocks)):
-            dx = self._block_bwd(dx, i, e["B"], e["T"], e["elen_dev"], ctx)
+            if f"enc/block{i}/native" in ctx:
+                dx = self._block_bwd_native(dx, i, ctx)
+            else:
+                dx = self._block_bwd(dx, i, e["B"], e["T"], e["elen_dev"], ctx)
             self._bucket_after_block(i)
         t0 = self._tick("subsampling_bwd")
         self._subsampling_bwd(dx, ctx)
@@ -573,8 +672,8 @@ class ConformerTransducer:
         # BaseLoss.call: logit_length = max(logit_length, label_length)  (losses/base_loss.py:36)
         tl = [min(max(int(a), b), T) for a, b in zip(elen, llen_host)]
         ul = [min(b, U1 - 1) for b in llen_host]
-        tl_dev = torch.tensor(tl, dtype=torch.int32).to(dev, non_blocking=True)
-        ul_dev = torch.tensor(ul, dtype=torch.int32).to(dev, non_blocking=True)
+        tl_dev = self._h2d(tl)
+        ul_dev = self._h2d(ul)
         gscale = torch.full((B,), 1.0 / (B * self.dp.world), dtype=torch.float32, device=dev)
         if not packed:
             logits = self.joint_fwd(enc, pred, B, T, U1, ctx)
@@ -588,7 +687,7 @@ class ConformerTransducer:
             off = np.zeros(B + 1, np.int64)
             off[1:] = np.cumsum([t * (u + 1) for t, u in zip(tl, ul)])
             total = int(off[-1])
-            off_dev = torch.from_numpy(off).to(dev, non_blocking=True)
+            off_dev = self._h2d(off, torch.int64)
             e = K.matmul(enc, ps.w2d("joint/enc/w"), bias=ps.p("joint/enc/b"))
             p = K.matmul(pred, ps.w2d("joint/pred/w"), bias=ps.p("joint/pred/b"))
             h = K.joint_fwd_packed(e.view(B, T, J), p.view(B, U1, J), off_dev, ul_dev, total)

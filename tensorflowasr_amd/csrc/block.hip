@@ -1,0 +1,505 @@
+// Native executor of one Conformer block (host code only): queues every kernel of ConformerBlock.call
+// (encoders/conformer.py:430-520: FFModule -> MHSAModule -> ConvModule -> FFModule -> LayerNorm) and of its backward on
+// one HIP stream, carving all intermediates out of two caller-owned arenas.  One ctypes call replaces ~20 (forward) /
+// ~50 (backward) per-kernel calls from the Python host, whose per-launch overhead (~25 us) otherwise rivals the GPU time
+// of a Conformer-M step.  The kernels are the same C-ABI entry points the Python host uses, so results are identical.
+//
+// Phases: the synchronised BatchNorm of the conv module needs an all-reduce of its batch statistics between
+// tfasr_bn_stats and tfasr_bn_finalize (forward) and between tfasr_bn_bwd_stats and tfasr_bn_apply_bwd (backward);
+// that communicator belongs to the caller, so each direction can be run as phase A | all-reduce | phase B.
+#include "common.h"
+#include <string.h>
+
+namespace {
+
+struct Arena {
+  char* base;
+  size_t off, cap;
+  bool ok;
+  size_t peak;
+  void* get(size_t n) {
+    const size_t a = (off + 255) & ~(size_t)255;
+    if (base && a + n > cap) { ok = false; return nullptr; }
+    off = a + n;
+    if (off > peak) peak = off;
+    return base ? base + a : (void*)(uintptr_t)256;  // dry run (sizing): non-null dummy, never dereferenced
+  }
+};
+
+// saved-for-backward pointers + phase carry (lives in the caller's opaque ctx buffer)
+struct Ctx {
+  // feed-forward modules
+  void *ff_x[2], *ff_ln[2], *ff_z[2], *ff_h[2];
+  float *ff_mean[2], *ff_rstd[2];
+  // attention
+  void *at_x, *at_ln, *at_qkv, *at_pext, *at_att, *at_qu, *at_qv, *at_probs;
+  float *at_mean, *at_rstd, *at_lse;
+  // convolution module
+  void *cv_x, *cv_ln, *cv_a, *cv_g, *cv_cv, *cv_sw;
+  float *cv_mean, *cv_rstd, *cv_fin;
+  // block layer norm
+  void* ln_x;
+  float *ln_mean, *ln_rstd;
+  // phase carry
+  size_t stash_off, scratch_off;
+  void *bw_dx, *bw_dsw, *bw_cur, *bw_nxt;
+  long drop_epoch;
+  int fused;
+};
+
+// one GEMM launch description (defaults = plain product)
+struct G {
+  const void* A = nullptr; int lda = 0; int ta = 0; const void* B = nullptr; int ldb = 0; int tb = 0; void* D = nullptr; int ldd = 0; int M = 0, N = 0, K = 0;
+  const float* bias = nullptr; const void* res = nullptr; const void* dact_z = nullptr; void* prez = nullptr;
+  float alpha = 1.f, beta = 1.f; int act = 0, dact = 0, out_f32 = 0, accumulate = 0, split_k = 1; float drop_p = 0.f; long drop_seed = 0;
+  int nb1 = 1, nb2 = 1; long sA1 = 0, sA2 = 0, sB1 = 0, sB2 = 0, sD1 = 0, sD2 = 0;
+};
+
+struct Ex {
+  const tfasr_block_cfg* c;
+  const tfasr_block_params* P;
+  const tfasr_block_io* io;
+  Ctx* k;
+  Arena stash, scratch;
+  hipStream_t s;
+  bool dry;
+  int st;
+  long rows;
+  int esz;
+
+  const float* fp(int i) const { return P->flat + P->off[i]; }
+  const void* wp(int i) const { return (const char*)P->shadow + P->off[i] * (long)esz; }
+  float* gp(int i) const { return P->grad + P->off[i]; }
+  void chk(int status) { if (status != TFASR_STATUS_SUCCESS && st == TFASR_STATUS_SUCCESS) st = status; }
+  void* act(Arena& a, long elems) { return a.get((size_t)elems * esz); }
+  float* f32(Arena& a, long elems) { return (float*)a.get((size_t)elems * 4); }
+  void zero(void* p, size_t bytes) { if (!dry) { if (hipMemsetAsync(p, 0, bytes, s) != hipSuccess) chk(TFASR_STATUS_EXECUTION_FAILED); } }
+
+  float drop_p() const { return c->training ? c->drop_p : 0.f; }
+  long seed(int site) const { return drop_p() > 0.f ? ((k->drop_epoch * 8192 + c->site0 + site) & 0x7FFFFFFFFFFFL) : 0; }
+
+  void gemm(const G& g) {
+    if (dry) return;
+    tfasr_gemm_args a;
+    memset(&a, 0, sizeof(a));
+    a.A = g.A; a.B = g.B; a.D = g.D; a.bias = g.bias; a.res = g.res; a.dact_z = g.dact_z; a.prez = g.prez;
+    a.M = g.M; a.N = g.N; a.K = g.K; a.lda = g.lda; a.ldb = g.ldb; a.ldd = g.ldd; a.trans_a = g.ta; a.trans_b = g.tb;
+    a.nb1 = g.nb1; a.nb2 = g.nb2; a.sA1 = g.sA1; a.sA2 = g.sA2; a.sB1 = g.sB1; a.sB2 = g.sB2; a.sD1 = g.sD1; a.sD2 = g.sD2;
+    a.alpha = g.alpha; a.beta = g.beta; a.act = g.act; a.dact = g.dact; a.dtype = c->dtype; a.out_f32 = g.out_f32;
+    a.accumulate = g.accumulate; a.split_k = g.split_k; a.drop_p = g.drop_p; a.drop_seed = g.drop_seed;
+    chk(tfasr_gemm(&a, s));
+  }
+  static int split_k(int M, int N, long K) {
+    const long tiles = (long)((M + 127) / 128) * ((N + 127) / 128);
+    if (tiles >= 512 || K <= 2048) return 1;
+    long v = (1024 + tiles - 1) / tiles;
+    if (K / 1024 < v) v = K / 1024;
+    if (v > 64) v = 64;
+    return (int)(v < 1 ? 1 : v);
+  }
+  // y = x @ W + b with the fused epilogue terms (W stored [din, dout] in the compute-dtype shadow)
+  void dense(const void* x, int wi, int bi, void* y, int din, int dout, G o = G()) {
+    o.A = x; o.lda = din; o.ta = 0; o.B = wp(wi); o.ldb = dout; o.tb = 0; o.D = y; o.ldd = dout; o.M = (int)rows; o.N = dout; o.K = din;
+    o.bias = fp(bi);
+    gemm(o);
+  }
+  // gW += alpha x^T dy ; gb += alpha colsum(dy) ; dx = alpha (dy @ W^T) [* act'(z)] [* dropmask]
+  void dense_bwd(const void* dy, const void* x, int wi, int bi, int din, int dout, void* dx, float alpha = 1.f, const void* dact_z = nullptr,
+                 int dact = 0, float dp = 0.f, long dseed = 0) {
+    G w; w.A = x; w.lda = din; w.ta = 1; w.B = dy; w.ldb = dout; w.tb = 0; w.D = gp(wi); w.ldd = dout; w.M = din; w.N = dout; w.K = (int)rows;
+    w.alpha = alpha; w.out_f32 = 1; w.accumulate = 1; w.split_k = split_k(din, dout, rows);
+    gemm(w);
+    if (!dry) chk(tfasr_colsum(dy, dout, gp(bi), rows, dout, alpha, c->dtype, s));
+    if (!dx) return;
+    G d; d.A = dy; d.lda = dout; d.ta = 0; d.B = wp(wi); d.ldb = dout; d.tb = 1; d.D = dx; d.ldd = din; d.M = (int)rows; d.N = din; d.K = dout;
+    d.alpha = alpha; d.dact_z = dact_z; d.dact = dact; d.drop_p = dp; d.drop_seed = dseed;
+    gemm(d);
+  }
+  const void* mask_grad(const void* dy, long elems, int site) {
+    if (drop_p() <= 0.f) return dy;
+    void* t = act(scratch, elems);
+    if (!dry) chk(tfasr_dropout(dy, t, elems, drop_p(), seed(site), c->dtype, s));
+    return t;
+  }
+  void ln_fwd(const void* x, int gi, int bi, void* y, float* mean, float* rstd) {
+    if (!dry) chk(tfasr_layernorm_fwd(x, fp(gi), fp(bi), y, mean, rstd, rows, c->d, c->ln_eps, c->dtype, s));
+  }
+  void ln_bwd(const void* dy, const void* x, int gi, int bi, const float* mean, const float* rstd, const void* add, void* dx) {
+    if (!dry) chk(tfasr_layernorm_bwd(dy, x, fp(gi), mean, rstd, add, dx, gp(gi), gp(bi), rows, c->d, c->dtype, s));
+  }
+
+  // ------------------------------------------------------------------------------------------ FFModule
+  void ffm_fwd(int m, const void* x, void* y, int site) {
+    const int b0 = m == 0 ? TFASR_BP_FF1_LN_G : TFASR_BP_FF2_LN_G;
+    const int d = c->d, F = c->dff;
+    k->ff_x[m] = (void*)x;
+    k->ff_ln[m] = act(stash, rows * d);
+    k->ff_mean[m] = f32(stash, rows);
+    k->ff_rstd[m] = f32(stash, rows);
+    k->ff_z[m] = c->save ? act(stash, rows * F) : nullptr;
+    k->ff_h[m] = act(stash, rows * F);
+    ln_fwd(x, b0, b0 + 1, k->ff_ln[m], k->ff_mean[m], k->ff_rstd[m]);
+    G a; a.act = TFASR_ACT_SWISH; a.prez = k->ff_z[m]; a.drop_p = drop_p(); a.drop_seed = seed(site);
+    dense(k->ff_ln[m], b0 + 2, b0 + 3, k->ff_h[m], d, F, a);
+    G b; b.res = x; b.beta = c->ffm_res; b.drop_p = drop_p(); b.drop_seed = seed(site + 1);
+    b.A = k->ff_h[m]; b.lda = F; b.ta = 0; b.B = wp(b0 + 4); b.ldb = d; b.tb = 0; b.D = y; b.ldd = d; b.M = (int)rows; b.N = d; b.K = F;
+    b.bias = fp(b0 + 5);
+    gemm(b);
+  }
+  void ffm_bwd(int m, const void* dy, void* dx, int site) {
+    const int b0 = m == 0 ? TFASR_BP_FF1_LN_G : TFASR_BP_FF2_LN_G;
+    const int d = c->d, F = c->dff;
+    const size_t mark = scratch.off;
+    const void* dyd = mask_grad(dy, rows * d, site + 1);
+    void* dz = act(scratch, rows * F);
+    // (x = h, W = d2) -> dz [rows, F] = f * (dyd @ W2^T) * swish'(z) * mask1
+    {
+      G w; w.A = k->ff_h[m]; w.lda = F; w.ta = 1; w.B = dyd; w.ldb = d; w.tb = 0; w.D = gp(b0 + 4); w.ldd = d; w.M = F; w.N = d; w.K = (int)rows;
+      w.alpha = c->ffm_res; w.out_f32 = 1; w.accumulate = 1; w.split_k = split_k(F, d, rows);
+      gemm(w);
+      if (!dry) chk(tfasr_colsum(dyd, d, gp(b0 + 5), rows, d, c->ffm_res, c->dtype, s));
+      G g; g.A = dyd; g.lda = d; g.ta = 0; g.B = wp(b0 + 4); g.ldb = d; g.tb = 1; g.D = dz; g.ldd = F; g.M = (int)rows; g.N = F; g.K = d;
+      g.alpha = c->ffm_res; g.dact_z = k->ff_z[m]; g.dact = TFASR_ACT_SWISH; g.drop_p = drop_p(); g.drop_seed = seed(site);
+      gemm(g);
+    }
+    void* dln = act(scratch, rows * d);
+    dense_bwd(dz, k->ff_ln[m], b0 + 2, b0 + 3, d, F, dln);
+    ln_bwd(dln, k->ff_x[m], b0, b0 + 1, k->ff_mean[m], k->ff_rstd[m], dy, dx);
+    scratch.off = mark;
+  }
+
+  // ------------------------------------------------------------------------------------------ MHSAModule
+  void mhsa_fwd(const void* x, void* y, int site) {
+    const int d = c->d, H = c->H, dh = c->dh, HD = H * dh, T = c->T, B = c->B, R1 = 2 * T;
+    const float scale = 1.f / sqrtf((float)dh);
+    k->at_x = (void*)x;
+    k->at_ln = act(stash, rows * d);
+    k->at_mean = f32(stash, rows);
+    k->at_rstd = f32(stash, rows);
+    k->at_qkv = act(stash, rows * 3 * HD);
+    k->at_pext = act(stash, (long)R1 * HD);
+    k->at_att = act(stash, rows * HD);
+    ln_fwd(x, TFASR_BP_AT_LN_G, TFASR_BP_AT_LN_B, k->at_ln, k->at_mean, k->at_rstd);
+    dense(k->at_ln, TFASR_BP_AT_QKV_W, TFASR_BP_AT_QKV_B, k->at_qkv, d, 3 * HD);
+    {
+      G p; p.A = P->pe; p.lda = d; p.ta = 0; p.B = wp(TFASR_BP_AT_POS_W); p.ldb = HD; p.tb = 0; p.D = k->at_pext; p.ldd = HD; p.M = R1; p.N = HD; p.K = d;
+      p.bias = fp(TFASR_BP_AT_POS_B);
+      gemm(p);
+    }
+    if (k->fused) {
+      k->at_lse = f32(stash, (long)B * H * T);
+      if (!dry)
+        chk(tfasr_relattn_fused_fwd(k->at_qkv, fp(TFASR_BP_AT_U), fp(TFASR_BP_AT_V), k->at_pext, io->lengths, k->at_att, k->at_lse, B, H, T, dh,
+                                    scale, c->use_mask, c->dtype, s));
+    } else {
+      const int Tp = (T + 7) / 8 * 8, R1p = (R1 + 7) / 8 * 8;
+      k->at_qu = act(stash, rows * HD);
+      k->at_qv = act(stash, rows * HD);
+      k->at_probs = act(stash, (long)B * H * T * Tp);
+      const size_t mark = scratch.off;
+      void* pos = act(scratch, (long)B * H * T * R1p);
+      if (!dry) chk(tfasr_bias2_fwd(k->at_qkv, 3 * HD, fp(TFASR_BP_AT_U), fp(TFASR_BP_AT_V), k->at_qu, k->at_qv, rows, HD, c->dtype, s));
+      const char* kk = (const char*)k->at_qkv + (size_t)HD * esz;
+      const char* vv = (const char*)k->at_qkv + (size_t)2 * HD * esz;
+      G cg; cg.A = k->at_qu; cg.lda = HD; cg.ta = 0; cg.B = kk; cg.ldb = 3 * HD; cg.tb = 1; cg.D = k->at_probs; cg.ldd = Tp; cg.M = T; cg.N = T; cg.K = dh;
+      cg.nb1 = B; cg.nb2 = H; cg.sA1 = (long)T * HD; cg.sA2 = dh; cg.sB1 = (long)T * 3 * HD; cg.sB2 = dh; cg.sD1 = (long)H * T * Tp; cg.sD2 = (long)T * Tp;
+      cg.alpha = scale;
+      gemm(cg);
+      G pg; pg.A = k->at_qv; pg.lda = HD; pg.ta = 0; pg.B = k->at_pext; pg.ldb = HD; pg.tb = 1; pg.D = pos; pg.ldd = R1p; pg.M = T; pg.N = R1; pg.K = dh;
+      pg.nb1 = B; pg.nb2 = H; pg.sA1 = (long)T * HD; pg.sA2 = dh; pg.sB1 = 0; pg.sB2 = dh; pg.sD1 = (long)H * T * R1p; pg.sD2 = (long)T * R1p;
+      pg.alpha = scale;
+      gemm(pg);
+      if (!dry) chk(tfasr_relattn_softmax_fwd(k->at_probs, pos, io->lengths, k->at_probs, B, H, T, Tp, R1p, c->use_mask, c->dtype, s));
+      G ag; ag.A = k->at_probs; ag.lda = Tp; ag.ta = 0; ag.B = vv; ag.ldb = 3 * HD; ag.tb = 0; ag.D = k->at_att; ag.ldd = HD; ag.M = T; ag.N = dh; ag.K = T;
+      ag.nb1 = B; ag.nb2 = H; ag.sA1 = (long)H * T * Tp; ag.sA2 = (long)T * Tp; ag.sB1 = (long)T * 3 * HD; ag.sB2 = dh; ag.sD1 = (long)T * HD; ag.sD2 = dh;
+      gemm(ag);
+      scratch.off = mark;
+    }
+    G o; o.res = x; o.beta = c->mhsa_res; o.drop_p = drop_p(); o.drop_seed = seed(site);
+    o.A = k->at_att; o.lda = HD; o.ta = 0; o.B = wp(TFASR_BP_AT_O_W); o.ldb = d; o.tb = 0; o.D = y; o.ldd = d; o.M = (int)rows; o.N = d; o.K = HD;
+    o.bias = fp(TFASR_BP_AT_O_B);
+    gemm(o);
+  }
+  void mhsa_bwd(const void* dy, void* dx, int site) {
+    const int d = c->d, H = c->H, dh = c->dh, HD = H * dh, T = c->T, B = c->B, R1 = 2 * T;
+    const int Tp = (T + 7) / 8 * 8, R1p = (R1 + 7) / 8 * 8;
+    const float scale = 1.f / sqrtf((float)dh);
+    const size_t mark = scratch.off;
+    const void* dyd = mask_grad(dy, rows * d, site);
+    void* datt = act(scratch, rows * HD);
+    // output projection (din = HD, dout = d)
+    {
+      G w; w.A = k->at_att; w.lda = HD; w.ta = 1; w.B = dyd; w.ldb = d; w.tb = 0; w.D = gp(TFASR_BP_AT_O_W); w.ldd = d; w.M = HD; w.N = d; w.K = (int)rows;
+      w.alpha = c->mhsa_res; w.out_f32 = 1; w.accumulate = 1; w.split_k = split_k(HD, d, rows);
+      gemm(w);
+      if (!dry) chk(tfasr_colsum(dyd, d, gp(TFASR_BP_AT_O_B), rows, d, c->mhsa_res, c->dtype, s));
+      G g; g.A = dyd; g.lda = d; g.ta = 0; g.B = wp(TFASR_BP_AT_O_W); g.ldb = d; g.tb = 1; g.D = datt; g.ldd = HD; g.M = (int)rows; g.N = HD; g.K = d;
+      g.alpha = c->mhsa_res;
+      gemm(g);
+    }
+    void* dqkv = act(scratch, rows * 3 * HD);
+    void* dqu = act(scratch, rows * HD);
+    void* dqv = act(scratch, rows * HD);
+    void* dpos = act(scratch, (long)B * H * T * R1p);
+    const void* qv;
+    float tail_scale;
+    if (k->fused) {
+      float* dvec = f32(scratch, (long)B * H * T);
+      void* qu = act(scratch, rows * HD);
+      void* qvb = act(scratch, rows * HD);
+      if (!dry) {
+        chk(tfasr_relattn_fused_bwd_q(k->at_qkv, fp(TFASR_BP_AT_U), fp(TFASR_BP_AT_V), k->at_pext, io->lengths, k->at_att, datt, k->at_lse, dqu,
+                                      dpos, dvec, B, H, T, dh, R1p, scale, c->use_mask, c->dtype, s));
+        chk(tfasr_bias2_fwd(k->at_qkv, 3 * HD, fp(TFASR_BP_AT_U), fp(TFASR_BP_AT_V), qu, qvb, rows, HD, c->dtype, s));
+        chk(tfasr_relattn_fused_bwd_k(k->at_qkv, qu, qvb, k->at_pext, io->lengths, datt, k->at_lse, dvec, dqkv, B, H, T, dh, scale, c->use_mask,
+                                      c->dtype, s));
+      }
+      qv = qvb;
+      tail_scale = 1.f;
+    } else {
+      const char* kk = (const char*)k->at_qkv + (size_t)HD * esz;
+      const char* vv = (const char*)k->at_qkv + (size_t)2 * HD * esz;
+      char* dk = (char*)dqkv + (size_t)HD * esz;
+      char* dv = (char*)dqkv + (size_t)2 * HD * esz;
+      void* dprobs = act(scratch, (long)B * H * T * Tp);
+      G a; a.A = datt; a.lda = HD; a.ta = 0; a.B = vv; a.ldb = 3 * HD; a.tb = 1; a.D = dprobs; a.ldd = Tp; a.M = T; a.N = T; a.K = dh;
+      a.nb1 = B; a.nb2 = H; a.sA1 = (long)T * HD; a.sA2 = dh; a.sB1 = (long)T * 3 * HD; a.sB2 = dh; a.sD1 = (long)H * T * Tp; a.sD2 = (long)T * Tp;
+      gemm(a);
+      G b; b.A = k->at_probs; b.lda = Tp; b.ta = 1; b.B = datt; b.ldb = HD; b.tb = 0; b.D = dv; b.ldd = 3 * HD; b.M = T; b.N = dh; b.K = T;
+      b.nb1 = B; b.nb2 = H; b.sA1 = (long)H * T * Tp; b.sA2 = (long)T * Tp; b.sB1 = (long)T * HD; b.sB2 = dh; b.sD1 = (long)T * 3 * HD; b.sD2 = dh;
+      gemm(b);
+      if (!dry) chk(tfasr_relattn_softmax_bwd(k->at_probs, dprobs, io->lengths, dprobs, dpos, B, H, T, Tp, R1p, c->use_mask, c->dtype, s));
+      G q; q.A = dprobs; q.lda = Tp; q.ta = 0; q.B = kk; q.ldb = 3 * HD; q.tb = 0; q.D = dqu; q.ldd = HD; q.M = T; q.N = dh; q.K = T;
+      q.nb1 = B; q.nb2 = H; q.sA1 = (long)H * T * Tp; q.sA2 = (long)T * Tp; q.sB1 = (long)T * 3 * HD; q.sB2 = dh; q.sD1 = (long)T * HD; q.sD2 = dh;
+      q.alpha = scale;
+      gemm(q);
+      G kq; kq.A = dprobs; kq.lda = Tp; kq.ta = 1; kq.B = k->at_qu; kq.ldb = HD; kq.tb = 0; kq.D = dk; kq.ldd = 3 * HD; kq.M = T; kq.N = dh; kq.K = T;
+      kq.nb1 = B; kq.nb2 = H; kq.sA1 = (long)H * T * Tp; kq.sA2 = (long)T * Tp; kq.sB1 = (long)T * HD; kq.sB2 = dh; kq.sD1 = (long)T * 3 * HD; kq.sD2 = dh;
+      kq.alpha = scale;
+      gemm(kq);
+      qv = k->at_qv;
+      tail_scale = scale;
+    }
+    // dqv = s * dpos @ pext ; dpext (f32) = s * sum_b dpos^T @ qv
+    {
+      G a; a.A = dpos; a.lda = R1p; a.ta = 0; a.B = k->at_pext; a.ldb = HD; a.tb = 0; a.D = dqv; a.ldd = HD; a.M = T; a.N = dh; a.K = R1;
+      a.nb1 = B; a.nb2 = H; a.sA1 = (long)H * T * R1p; a.sA2 = (long)T * R1p; a.sB1 = 0; a.sB2 = dh; a.sD1 = (long)T * HD; a.sD2 = dh;
+      a.alpha = tail_scale;
+      gemm(a);
+    }
+    float* dpext = f32(scratch, (long)R1 * HD);
+    zero(dpext, (size_t)R1 * HD * 4);
+    {
+      G a; a.A = dpos; a.lda = R1p; a.ta = 1; a.B = qv; a.ldb = HD; a.tb = 0; a.D = dpext; a.ldd = HD; a.M = R1; a.N = dh; a.K = T;
+      a.nb1 = B; a.nb2 = H; a.sA1 = (long)H * T * R1p; a.sA2 = (long)T * R1p; a.sB1 = (long)T * HD; a.sB2 = dh; a.sD1 = 0; a.sD2 = dh;
+      a.alpha = tail_scale; a.out_f32 = 1; a.accumulate = 1;
+      gemm(a);
+    }
+    if (!dry) chk(tfasr_bias2_bwd(dqu, dqv, dqkv, 3 * HD, gp(TFASR_BP_AT_U), gp(TFASR_BP_AT_V), rows, HD, c->dtype, s));
+    // positional projection: gWpos += pe^T dpext ; gbpos += colsum(dpext)
+    const void* dpext_t = dpext;
+    if (c->dtype != TFASR_F32) {
+      void* t = act(scratch, (long)R1 * HD);
+      if (!dry) chk(tfasr_cast(dpext, t, (long)R1 * HD, TFASR_F32, c->dtype, s));
+      dpext_t = t;
+    }
+    {
+      G a; a.A = P->pe; a.lda = d; a.ta = 1; a.B = dpext_t; a.ldb = HD; a.tb = 0; a.D = gp(TFASR_BP_AT_POS_W); a.ldd = HD; a.M = d; a.N = HD; a.K = R1;
+      a.out_f32 = 1; a.accumulate = 1;
+      gemm(a);
+    }
+    if (!dry) chk(tfasr_colsum(dpext, HD, gp(TFASR_BP_AT_POS_B), R1, HD, 1.f, TFASR_F32, s));
+    void* dln = act(scratch, rows * d);
+    dense_bwd(dqkv, k->at_ln, TFASR_BP_AT_QKV_W, TFASR_BP_AT_QKV_B, d, 3 * HD, dln);
+    ln_bwd(dln, k->at_x, TFASR_BP_AT_LN_G, TFASR_BP_AT_LN_B, k->at_mean, k->at_rstd, dy, dx);
+    scratch.off = mark;
+  }
+
+  // ------------------------------------------------------------------------------------------ ConvModule
+  void conv_fwd_a(const void* x) {
+    const int d = c->d;
+    k->cv_x = (void*)x;
+    k->cv_ln = act(stash, rows * d);
+    k->cv_mean = f32(stash, rows);
+    k->cv_rstd = f32(stash, rows);
+    k->cv_a = act(stash, rows * 2 * d);
+    k->cv_g = act(stash, rows * d);
+    k->cv_cv = act(stash, rows * d);
+    k->cv_fin = f32(stash, 4 * d);
+    k->cv_sw = act(stash, rows * d);
+    ln_fwd(x, TFASR_BP_CV_LN_G, TFASR_BP_CV_LN_B, k->cv_ln, k->cv_mean, k->cv_rstd);
+    dense(k->cv_ln, TFASR_BP_CV_PW1_W, TFASR_BP_CV_PW1_B, k->cv_a, d, 2 * d);
+    if (!dry) {
+      chk(tfasr_glu_fwd(k->cv_a, k->cv_g, rows, d, c->dtype, s));
+      chk(tfasr_dwconv_fwd(k->cv_g, fp(TFASR_BP_CV_DW_W), fp(TFASR_BP_CV_DW_B), k->cv_cv, c->B, c->T, d, c->ksize, c->dtype, s));
+      if (c->training) {
+        zero(io->bn_stats, (size_t)(2 * d + 1) * 4);
+        chk(tfasr_bn_stats(k->cv_cv, io->bn_stats, rows, d, c->dtype, s));
+      }
+    }
+  }
+  void conv_fwd_b(void* y, int site) {
+    const int d = c->d;
+    if (!dry) {
+      if (c->training)
+        chk(tfasr_bn_finalize(io->bn_stats, (float)(rows * c->world), fp(TFASR_BP_CV_BN_G), fp(TFASR_BP_CV_BN_B), k->cv_fin, P->bn_mm, P->bn_mv,
+                              c->bn_momentum, c->bn_eps, d, 1, s));
+      else
+        chk(tfasr_bn_finalize(nullptr, 1.f, fp(TFASR_BP_CV_BN_G), fp(TFASR_BP_CV_BN_B), k->cv_fin, P->bn_mm, P->bn_mv, c->bn_momentum, c->bn_eps,
+                              d, 0, s));
+      chk(tfasr_bn_apply_fwd(k->cv_cv, k->cv_fin, k->cv_sw, rows, d, TFASR_ACT_SWISH, c->dtype, s));
+    }
+    G o; o.res = k->cv_x; o.beta = c->conv_res; o.drop_p = drop_p(); o.drop_seed = seed(site);
+    o.A = k->cv_sw; o.lda = d; o.ta = 0; o.B = wp(TFASR_BP_CV_PW2_W); o.ldb = d; o.tb = 0; o.D = y; o.ldd = d; o.M = (int)rows; o.N = d; o.K = d;
+    o.bias = fp(TFASR_BP_CV_PW2_B);
+    gemm(o);
+  }
+  void conv_bwd_a(const void* dy, int site) {
+    const int d = c->d;
+    const void* dyd = mask_grad(dy, rows * d, site);
+    void* dsw = act(scratch, rows * d);
+    dense_bwd(dyd, k->cv_sw, TFASR_BP_CV_PW2_W, TFASR_BP_CV_PW2_B, d, d, dsw, c->conv_res);
+    zero(io->bn_bstats, (size_t)2 * d * 4);
+    if (!dry) chk(tfasr_bn_bwd_stats(k->cv_cv, dsw, k->cv_fin, io->bn_bstats, rows, d, TFASR_ACT_SWISH, c->dtype, s));
+    k->bw_dsw = dsw;
+  }
+  void conv_bwd_b(const void* dy, void* dx) {
+    const int d = c->d;
+    void* dcv = act(scratch, rows * d);
+    void* dg = act(scratch, rows * d);
+    void* da = act(scratch, rows * 2 * d);
+    void* dln = act(scratch, rows * d);
+    if (!dry) {
+      chk(tfasr_bn_apply_bwd(k->cv_cv, k->bw_dsw, k->cv_fin, io->bn_bstats, (float)(rows * c->world), dcv, rows, d, TFASR_ACT_SWISH, c->dtype, s));
+      const float inv = 1.f / (float)c->world;
+      chk(tfasr_axpy(gp(TFASR_BP_CV_BN_B), io->bn_bstats, inv, d, s));
+      chk(tfasr_axpy(gp(TFASR_BP_CV_BN_G), io->bn_bstats + d, inv, d, s));
+      chk(tfasr_dwconv_bwd_weight(k->cv_g, dcv, gp(TFASR_BP_CV_DW_W), gp(TFASR_BP_CV_DW_B), c->B, c->T, d, c->ksize, c->dtype, s));
+      chk(tfasr_dwconv_bwd_data(dcv, fp(TFASR_BP_CV_DW_W), dg, c->B, c->T, d, c->ksize, c->dtype, s));
+      chk(tfasr_glu_bwd(k->cv_a, dg, da, rows, d, c->dtype, s));
+    }
+    dense_bwd(da, k->cv_ln, TFASR_BP_CV_PW1_W, TFASR_BP_CV_PW1_B, d, 2 * d, dln);
+    ln_bwd(dln, k->cv_x, TFASR_BP_CV_LN_G, TFASR_BP_CV_LN_B, k->cv_mean, k->cv_rstd, dy, dx);
+  }
+
+  // ------------------------------------------------------------------------------------------ block
+  // dropout sites inside a block (conformer.py site numbering): ff1 = 0,1; mhsa = 2; conv = 3; ff2 = 4,5
+  void forward(int phase) {
+    const int d = c->d;
+    if (phase & TFASR_PHASE_A) {
+      void* x1 = act(stash, rows * d);
+      void* x2 = act(stash, rows * d);
+      ffm_fwd(0, io->x_in, x1, 0);
+      mhsa_fwd(x1, x2, 2);
+      conv_fwd_a(x2);
+      k->stash_off = stash.off;
+    }
+    if (phase & TFASR_PHASE_B) {
+      stash.off = k->stash_off;
+      void* x3 = act(stash, rows * d);
+      void* x4 = act(stash, rows * d);
+      conv_fwd_b(x3, 3);
+      ffm_fwd(1, x3, x4, 4);
+      k->ln_x = x4;
+      k->ln_mean = f32(stash, rows);
+      k->ln_rstd = f32(stash, rows);
+      ln_fwd(x4, TFASR_BP_LN_G, TFASR_BP_LN_B, io->x_out, k->ln_mean, k->ln_rstd);
+      k->stash_off = stash.off;
+    }
+  }
+  void backward(int phase) {
+    const int d = c->d;
+    if (phase & TFASR_PHASE_A) {
+      k->bw_cur = act(scratch, rows * d);
+      k->bw_nxt = act(scratch, rows * d);
+      ln_bwd(io->dy, k->ln_x, TFASR_BP_LN_G, TFASR_BP_LN_B, k->ln_mean, k->ln_rstd, nullptr, k->bw_cur);
+      ffm_bwd(1, k->bw_cur, k->bw_nxt, 4);
+      { void* t = k->bw_cur; k->bw_cur = k->bw_nxt; k->bw_nxt = t; }
+      conv_bwd_a(k->bw_cur, 3);
+      k->scratch_off = scratch.off;
+    }
+    if (phase & TFASR_PHASE_B) {
+      scratch.off = k->scratch_off;
+      const size_t mark = scratch.off;
+      conv_bwd_b(k->bw_cur, k->bw_nxt);
+      scratch.off = mark;
+      { void* t = k->bw_cur; k->bw_cur = k->bw_nxt; k->bw_nxt = t; }
+      mhsa_bwd(k->bw_cur, k->bw_nxt, 2);
+      ffm_bwd(0, k->bw_nxt, io->dx, 0);
+    }
+  }
+};
+
+int check_args(const tfasr_block_cfg* c, const tfasr_block_params* P, const tfasr_block_io* io, const void* ctx) {
+  if (!c || !P || !io || !ctx) return TFASR_STATUS_INVALID_VALUE;
+  if (c->B <= 0 || c->T <= 0 || c->d <= 0 || c->H <= 0 || c->dh <= 0 || c->dff <= 0 || c->ksize <= 0 || c->world <= 0) return TFASR_STATUS_INVALID_VALUE;
+  if (c->dtype != TFASR_F32 && c->dtype != TFASR_BF16) return TFASR_STATUS_INVALID_VALUE;
+  if (!P->flat || !P->shadow || !P->grad || !P->bn_mm || !P->bn_mv || !P->pe) return TFASR_STATUS_INVALID_VALUE;
+  return TFASR_STATUS_SUCCESS;
+}
+
+void setup(Ex& e, const tfasr_block_cfg* c, const tfasr_block_params* P, const tfasr_block_io* io, void* ctx, void* stream, bool dry) {
+  e.c = c; e.P = P; e.io = io; e.k = (Ctx*)ctx; e.s = (hipStream_t)stream; e.dry = dry; e.st = TFASR_STATUS_SUCCESS;
+  e.rows = (long)c->B * c->T;
+  e.esz = c->dtype == TFASR_F32 ? 4 : 2;
+  e.stash = Arena{dry ? nullptr : (char*)io->stash, 0, dry ? 0 : io->stash_bytes, true, 0};
+  e.scratch = Arena{dry ? nullptr : (char*)io->scratch, 0, dry ? 0 : io->scratch_bytes, true, 0};
+}
+
+bool use_fused(const tfasr_block_cfg* c) { return c->dtype == TFASR_BF16 && c->dh == 64 && !c->force_unfused; }
+
+}  // namespace
+
+extern "C" size_t tfasr_block_ctx_bytes(void) { return sizeof(Ctx); }
+
+extern "C" int tfasr_block_workspace_sizes(const tfasr_block_cfg* c, size_t* stash_bytes, size_t* fwd_scratch_bytes, size_t* bwd_scratch_bytes) {
+  if (!c || !stash_bytes || !fwd_scratch_bytes || !bwd_scratch_bytes) return TFASR_STATUS_INVALID_VALUE;
+  // sizing = a dry run of the very same allocation sequence (no launches, null arenas)
+  tfasr_block_params P;
+  memset(&P, 0, sizeof(P));
+  tfasr_block_io io;
+  memset(&io, 0, sizeof(io));
+  Ctx k;
+  memset(&k, 0, sizeof(k));
+  k.fused = use_fused(c);
+  Ex e;
+  setup(e, c, &P, &io, &k, nullptr, true);
+  e.forward(TFASR_PHASE_A | TFASR_PHASE_B);
+  *stash_bytes = e.stash.peak + 256;
+  *fwd_scratch_bytes = e.scratch.peak + 256;
+  Ex b;
+  setup(b, c, &P, &io, &k, nullptr, true);
+  b.backward(TFASR_PHASE_A | TFASR_PHASE_B);
+  *bwd_scratch_bytes = b.scratch.peak + 256;
+  return TFASR_STATUS_SUCCESS;
+}
+
+extern "C" int tfasr_block_fwd(const tfasr_block_cfg* c, const tfasr_block_params* P, const tfasr_block_io* io, void* ctx, int phase,
+                               void* stream) {
+  int st = check_args(c, P, io, ctx);
+  if (st != TFASR_STATUS_SUCCESS) return st;
+  if (!io->x_in || !io->x_out || !io->stash || (c->training && !io->bn_stats) || !(phase & (TFASR_PHASE_A | TFASR_PHASE_B)))
+    return TFASR_STATUS_INVALID_VALUE;
+  Ex e;
+  setup(e, c, P, io, ctx, stream, false);
+  if (phase & TFASR_PHASE_A) {
+    memset(e.k, 0, sizeof(Ctx));
+    e.k->fused = use_fused(c);
+    e.k->drop_epoch = c->drop_epoch;
+  }
+  e.forward(phase);
+  if (!e.stash.ok || !e.scratch.ok) return TFASR_STATUS_INVALID_VALUE;  // arena too small
+  return e.st;
+}
+
+extern "C" int tfasr_block_bwd(const tfasr_block_cfg* c, const tfasr_block_params* P, const tfasr_block_io* io, void* ctx, int phase,
+                               void* stream) {
+  int st = check_args(c, P, io, ctx);
+  if (st != TFASR_STATUS_SUCCESS) return st;
+  if (!io->dy || !io->dx || !io->scratch || !io->bn_bstats || !(phase & (TFASR_PHASE_A | TFASR_PHASE_B))) return TFASR_STATUS_INVALID_VALUE;
+  Ex e;
+  setup(e, c, P, io, ctx, stream, false);
+  e.backward(phase);
+  if (!e.scratch.ok) return TFASR_STATUS_INVALID_VALUE;
+  return e.st;
+}

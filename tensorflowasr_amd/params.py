@@ -92,6 +92,7 @@ class ParamStore:
                 self.n_reg = off
         self.n = off
         self.names = [x[0] for x in ordered]
+        self._views = {}
         self.flat = torch.zeros(self.n, dtype=torch.float32, device=device)
         self.grad = torch.zeros(self.n, dtype=torch.float32, device=device)
         self.adam_m = torch.zeros(self.n, dtype=torch.float32, device=device)
@@ -107,9 +108,17 @@ class ParamStore:
         self.refresh_shadow()
 
     # ------------------------------------------------------------------ views
-    def _view(self, buf, name):
-        o, shp = self.offsets[name], self.shapes[name]
-        return buf[o:o + int(np.prod(shp))].view(*shp)
+    def _view(self, buf, name, two_d=False):
+        # views into the flat buffers never move: build each once (this is on the per-launch host path)
+        key = (id(buf), name, two_d)
+        v = self._views.get(key)
+        if v is None:
+            o, shp = self.offsets[name], self.shapes[name]
+            v = buf[o:o + int(np.prod(shp))].view(*shp)
+            if two_d:
+                v = v.view(-1, shp[-1])
+            self._views[key] = v
+        return v
 
     def p(self, name):  # f32 master
         return self._view(self.flat, name)
@@ -121,12 +130,10 @@ class ParamStore:
         return self._view(self.grad, name)
 
     def w2d(self, name):
-        shp = self.shapes[name]
-        return self.w(name).view(-1, shp[-1])
+        return self._view(self.shadow, name, True)
 
     def g2d(self, name):
-        shp = self.shapes[name]
-        return self.g(name).view(-1, shp[-1])
+        return self._view(self.grad, name, True)
 
     def refresh_shadow(self):
         if self.shadow is not self.flat:

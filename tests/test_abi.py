@@ -43,3 +43,26 @@ def test_product_path_refuses_cpu_tensors():
     with pytest.raises(Exception):
         kernels.rnnt_loss_fwd_bwd(x, torch.zeros(1, 1, dtype=torch.int32), torch.ones(1, dtype=torch.int32),
                                   torch.ones(1, dtype=torch.int32))
+
+
+def test_block_executor_sizing_is_host_only():
+    """tfasr_block_workspace_sizes is a dry run of the executor's allocation sequence: callable without a GPU."""
+    import ctypes
+
+    from tensorflowasr_amd import _lib
+
+    lib = _lib.load()
+    assert lib.tfasr_block_ctx_bytes() > 0
+    k = _lib.BlockCfg()
+    k.B, k.T, k.d, k.H, k.dh, k.dff, k.ksize = 4, 100, 256, 4, 64, 1024, 31
+    k.dtype, k.training, k.save, k.use_mask, k.world, k.drop_p = _lib.TFASR_BF16, 1, 1, 1, 1, 0.1
+    a, b, c = ctypes.c_size_t(0), ctypes.c_size_t(0), ctypes.c_size_t(0)
+    assert lib.tfasr_block_workspace_sizes(ctypes.byref(k), ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)) == 0
+    rows = 400
+    assert a.value > rows * (2 * 2 * 1024 + 768 + 512) * 2  # at least z, h of both FFNs + qkv + pw1 output
+    assert c.value > rows * 1024 * 2
+    k.force_unfused = 1
+    a2 = ctypes.c_size_t(0)
+    assert lib.tfasr_block_workspace_sizes(ctypes.byref(k), ctypes.byref(a2), ctypes.byref(b), ctypes.byref(c)) == 0
+    assert a2.value > a.value  # the unfused path stores the probabilities
+    assert lib.tfasr_block_workspace_sizes(None, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)) != 0
