@@ -59,7 +59,7 @@ class ConformerTransducer:
         self._consts = {}
         self._rng = np.random.default_rng(seed + 1000)
         self.pred_stream = torch.cuda.Stream(device=self.device)
-        self.use_pred_stream = True
+        self.use_pred_stream = os.environ.get("TFASR_NO_PRED_STREAM", "0") != "1"
         self.optimizer = dict(beta1=0.9, beta2=0.98, eps=1e-9, weight_decay=1e-6, schedule=dict(
             dmodel=cfg.dmodel, warmup_steps=10000, scale=2.0, max_lr=0.05 / math.sqrt(cfg.dmodel)))
         self.ga_steps = 1

@@ -1,0 +1,173 @@
+// Causal depthwise Conv1D (DepthwiseConv1D, layers/convolution.py:159-228; ConvModule, encoders/conformer.py:305-313),
+// bf16 channel-pair kernels: one lane owns two adjacent channels (one 4-byte load per time step, packed f32 FMAs), a
+// register tile of TT output steps and the K taps of its two channels in registers.  Used by tfasr_dwconv_* for bf16
+// activations with an even channel count; everything else takes the scalar kernels in elementwise.hip.
+#include "common.h"
+#include <stdlib.h>
+#include <utility>
+
+typedef __attribute__((ext_vector_type(2))) float float2_t;
+
+namespace {
+
+constexpr int MAXK = 32;
+
+__device__ __forceinline__ float2_t ld2(const bf16_t* p) {
+  const uint32_t u = *reinterpret_cast<const uint32_t*>(p);
+  return float2_t{__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)};
+}
+__device__ __forceinline__ void st2(bf16_t* p, float2_t v) {
+  *reinterpret_cast<uint32_t*>(p) = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+}
+__device__ __forceinline__ float2_t fma2(float2_t a, float2_t b, float2_t c) { return __builtin_elementwise_fma(a, b, c); }
+
+// ---- LDS staging: a block owns a slab of 256 channels x 64 output steps; the input rows it needs are brought in once with
+// 16-byte loads (all in flight together) and then read back 4 bytes per lane (conflict free), so no lane ever waits on a
+// dependent chain of global loads.
+constexpr int SLAB = 256;             // channels per block
+constexpr int ROWB = SLAB * 2;        // bytes per staged row
+constexpr int TG = 32;                // output steps per thread group (2 groups of 128 channel-pair lanes per block)
+
+// rows [r0, r0+nrows) of src (time index = tbase + row) -> LDS, zero filled outside [0, Tn) and beyond C
+__device__ __forceinline__ void stage_rows(char* lds, const bf16_t* __restrict__ src, long ubase, int tbase, int nrows, int Tn, int C, int c0) {
+  for (int id = threadIdx.x; id < nrows * (SLAB / 8); id += blockDim.x) {
+    const int row = id / (SLAB / 8), ch = (id % (SLAB / 8)) * 8;
+    const int ti = tbase + row;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (ti >= 0 && ti < Tn && c0 + ch < C) v = *reinterpret_cast<const uint4*>(src + ubase + (long)ti * C + c0 + ch);
+    *reinterpret_cast<uint4*>(lds + row * ROWB + ch * 2) = v;
+  }
+}
+__device__ __forceinline__ float2_t lds2(const char* p) {
+  const uint32_t u = *reinterpret_cast<const uint32_t*>(p);
+  return float2_t{__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)};
+}
+
+// REV == false: y[t] = bias + sum_k w[k] x[t-(K-1)+k]          (forward)
+// REV == true : dx[t] = sum_k w[k] dy[t+(K-1)-k]               (data gradient) = same loop with reversed taps
+// The (input step j) x (output i) loops are expanded with compile-time indices (fold over integer sequences) so that the
+// tap / accumulator arrays stay in registers.
+template <int TT, int J, int... I>
+__device__ __forceinline__ void dw_step(float2_t (&acc)[TT], const float2_t (&wk)[MAXK], float2_t xv, std::integer_sequence<int, I...>) {
+  ((void)((J - I >= 0 && J - I < MAXK) ? (acc[I] = fma2(wk[(J - I >= 0 && J - I < MAXK) ? J - I : 0], xv, acc[I]), 0) : 0), ...);
+}
+template <int TT, int... J>
+__device__ __forceinline__ void dw_all(float2_t (&acc)[TT], const float2_t (&wk)[MAXK], const char* col, std::integer_sequence<int, J...>) {
+  ((dw_step<TT, J>(acc, wk, lds2(col + J * ROWB), std::make_integer_sequence<int, TT>{})), ...);
+}
+template <bool REV>
+__global__ __launch_bounds__(256) void dwconv_tile_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w,
+                                                          const float* __restrict__ bias, bf16_t* __restrict__ y, int Tn, int C, int K) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];  // (2*TG + MAXK - 1) rows; rows past K-1+2*TG stay zero-weighted
+  const int c0 = blockIdx.x * SLAB;
+  const int t0 = blockIdx.y * (2 * TG);
+  const long ubase = (long)blockIdx.z * Tn * C;
+  const int tin0 = REV ? t0 : t0 - (K - 1);
+  stage_rows(lds, x, ubase, tin0, 2 * TG + MAXK - 1, Tn, C, c0);
+  const int grp = threadIdx.x >> 7, pr = threadIdx.x & 127;
+  const int c = c0 + 2 * pr;
+  const bool live = c < C;
+  const int cc = live ? c : c0;
+  float2_t wk[MAXK];
+#pragma unroll
+  for (int k = 0; k < MAXK; ++k) {
+    const int kk = max(min(REV ? (K - 1 - k) : k, K - 1), 0);
+    const float2_t v = float2_t{w[kk * C + cc], w[kk * C + cc + 1]};
+    wk[k] = (k < K) ? v : float2_t{0.f, 0.f};
+  }
+  float2_t acc[TG];
+  const float2_t bv = (!REV && bias) ? float2_t{bias[cc], bias[cc + 1]} : float2_t{0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < TG; ++i) acc[i] = bv;
+  __syncthreads();
+  dw_all<TG>(acc, wk, lds + (grp * TG) * ROWB + pr * 4, std::make_integer_sequence<int, MAXK - 1 + TG>{});
+  if (live) {
+    const int tg0 = t0 + grp * TG;
+#pragma unroll
+    for (int i = 0; i < TG; ++i)
+      if (tg0 + i < Tn) st2(y + ubase + (long)(tg0 + i) * C + c, acc[i]);
+  }
+}
+
+// dw[k,c] += sum_{b,t} dy[b,t,c] x[b,t-(K-1)+k,c]; dbias[c] += sum dy.  Same staging (x rows t0-(K-1).., dy rows t0..); each
+// thread group walks its 32 steps with the x window held in a 32-slot circular register buffer (compile-time slots).
+template <int K>
+__global__ __launch_bounds__(256) void dwconv_wgrad_tile_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
+                                                                float* __restrict__ dw, float* __restrict__ dbias, int Tn, int C) {
+  static_assert(K <= MAXK, "window");
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  char* lx = lds;                                   // 2*TG + K - 1 rows
+  char* ld = lds + (2 * TG + MAXK - 1) * ROWB;      // 2*TG rows
+  const int c0 = blockIdx.x * SLAB;
+  const int t0 = blockIdx.y * (2 * TG);
+  const long ubase = (long)blockIdx.z * Tn * C;
+  stage_rows(lx, x, ubase, t0 - (K - 1), 2 * TG + K - 1, Tn, C, c0);
+  stage_rows(ld, dy, ubase, t0, 2 * TG, Tn, C, c0);
+  const int grp = threadIdx.x >> 7, pr = threadIdx.x & 127;
+  const int c = c0 + 2 * pr;
+  float2_t acc[K], win[MAXK];
+  float2_t ab = float2_t{0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < K; ++k) acc[k] = float2_t{0.f, 0.f};
+  __syncthreads();
+  const char* colx = lx + (grp * TG) * ROWB + pr * 4;  // row r of this group = x[t_g0 - (K-1) + r]
+  const char* cold = ld + (grp * TG) * ROWB + pr * 4;
+#pragma unroll
+  for (int q = 0; q < MAXK; ++q) win[q] = float2_t{0.f, 0.f};
+#pragma unroll
+  for (int h = 1; h < K; ++h) win[(MAXK - h) & (MAXK - 1)] = lds2(colx + (K - 1 - h) * ROWB);  // x[t_g0 - h]
+#pragma unroll
+  for (int s = 0; s < TG; ++s) {
+    win[s] = lds2(colx + (K - 1 + s) * ROWB);
+    const float2_t d = lds2(cold + s * ROWB);
+    ab += d;
+#pragma unroll
+    for (int k = 0; k < K; ++k) acc[k] = fma2(d, win[(s - (K - 1) + k) & (MAXK - 1)], acc[k]);
+  }
+  if (c < C) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      atomicAdd(dw + k * C + c, acc[k][0]);
+      atomicAdd(dw + k * C + c + 1, acc[k][1]);
+    }
+    if (dbias) { atomicAdd(dbias + c, ab[0]); atomicAdd(dbias + c + 1, ab[1]); }
+  }
+}
+
+inline bool al4(const void* p) { return (((uintptr_t)p) & 3) == 0; }
+inline bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+}  // namespace
+
+// return TFASR_STATUS_UNSUPPORTED when the caller must use the scalar kernels
+int tfasr_dwconv_pair_try(int which, const void* x, const void* dy, const float* w, const float* bias, void* y, float* dw, float* dbias, int B,
+                          int T, int C, int K, hipStream_t s) {
+  if ((C & 7) || K > MAXK) return TFASR_STATUS_UNSUPPORTED;
+  const int gx = (C + SLAB - 1) / SLAB;
+  dim3 grid(gx, (T + 2 * TG - 1) / (2 * TG), B);
+  if (which == 0 || which == 1) {
+    const void* in = which == 0 ? x : dy;
+    if (!al16(in) || !al4(y)) return TFASR_STATUS_UNSUPPORTED;
+    const int smem = (2 * TG + MAXK - 1) * ROWB;
+    if (which == 0)
+      hipLaunchKernelGGL((dwconv_tile_kernel<false>), grid, dim3(256), smem, s, (const bf16_t*)in, w, bias, (bf16_t*)y, T, C, K);
+    else
+      hipLaunchKernelGGL((dwconv_tile_kernel<true>), grid, dim3(256), smem, s, (const bf16_t*)in, w, (const float*)nullptr, (bf16_t*)y, T, C, K);
+    TFASR_CHECK_LAUNCH();
+    return TFASR_STATUS_SUCCESS;
+  }
+  // weight gradient: measured slower than the scalar kernel (100 us vs 45 us at B=32,T=744,C=256) because the per-block f32 atomics
+  // (K x C per 64 steps) dominate; opt-in until it reduces through a workspace instead.
+  static const bool wgrad_tile = getenv("TFASR_DWCONV_WGRAD_TILE") != nullptr;
+  if (!wgrad_tile || !al16(x) || !al16(dy)) return TFASR_STATUS_UNSUPPORTED;
+  const int smem = (2 * TG + MAXK - 1 + 2 * TG) * ROWB;
+  switch (K) {
+    case 31: hipLaunchKernelGGL((dwconv_wgrad_tile_kernel<31>), grid, dim3(256), smem, s, (const bf16_t*)x, (const bf16_t*)dy, dw, dbias, T, C); break;
+    case 32: hipLaunchKernelGGL((dwconv_wgrad_tile_kernel<32>), grid, dim3(256), smem, s, (const bf16_t*)x, (const bf16_t*)dy, dw, dbias, T, C); break;
+    case 15: hipLaunchKernelGGL((dwconv_wgrad_tile_kernel<15>), grid, dim3(256), smem, s, (const bf16_t*)x, (const bf16_t*)dy, dw, dbias, T, C); break;
+    case 7: hipLaunchKernelGGL((dwconv_wgrad_tile_kernel<7>), grid, dim3(256), smem, s, (const bf16_t*)x, (const bf16_t*)dy, dw, dbias, T, C); break;
+    default: return TFASR_STATUS_UNSUPPORTED;
+  }
+  TFASR_CHECK_LAUNCH();
+  return TFASR_STATUS_SUCCESS;
+}

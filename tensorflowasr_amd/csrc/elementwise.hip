@@ -6,6 +6,7 @@
 //   multihead_attention.py:554-558), embedding gather/scatter (embedding.py:41-48), joint
 //   broadcast-add+tanh fwd/bwd (base_transducer.py:199-207,291), Adam (+L2, decoupled weight decay).
 #include "common.h"
+#include <stdlib.h>
 #include <algorithm>
 
 namespace {
@@ -59,27 +60,36 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, lo
 
 // 16-B variant: 32 lanes x 8 columns = 256 columns per block.y, 8 rows per block iteration, LDS reduction, 1 atomic/column/block
 template <typename T>
-__global__ __launch_bounds__(256) void colsum_vec_kernel(const T* __restrict__ x, long ld, float* __restrict__ out,
-                                                         long rows, int C, float scale) {
-  __shared__ float red[8][256];
-  const int lane = threadIdx.x & 63, li = lane & 31, sub = lane >> 5, w = threadIdx.x >> 6;
+__global__ __launch_bounds__(512) void colsum_vec_kernel(const T* __restrict__ x, long ld, float* __restrict__ out,
+                                                          long rows, int C, float scale) {
+  // fat blocks (see norm.hip): 32 lanes x 8 columns per row, 2 rows per wave, 4 row loads in flight per lane, LDS atomics
+  __shared__ float red[16][256];  // up to 8 waves x 2 rows
+  const int lane = threadIdx.x & 63, li = lane & 31, sub = lane >> 5, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const int c0 = blockIdx.y * 256 + li * 8;
   float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  if (c0 < C)
-    for (long r = (long)blockIdx.x * 8 + w * 2 + sub; r < rows; r += (long)gridDim.x * 8) {
-      float v[8];
-      ld8(x + r * ld + c0, v);
+  if (c0 < C) {
+    const long S = (long)gridDim.x * nw * 2;
+    for (long r = ((long)blockIdx.x * nw + w) * 2 + sub; r < rows; r += 4 * S) {
+      float v[4][8];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) acc[k] += v[k];
+      for (int u = 0; u < 4; ++u) {
+        if (r + u * S < rows) ld8(x + (r + u * S) * ld + c0, v[u]);
+        else {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) v[u][k] = 0.f;
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc[k] += (v[0][k] + v[1][k]) + (v[2][k] + v[3][k]);
     }
+  }
 #pragma unroll
   for (int k = 0; k < 8; ++k) red[w * 2 + sub][li * 8 + k] = acc[k];
   __syncthreads();
   const int c = blockIdx.y * 256 + threadIdx.x;
-  if (c < C) {
+  if (threadIdx.x < 256 && c < C) {
     float s = 0.f;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) s += red[q][threadIdx.x];
+    for (int q = 0; q < nw * 2; ++q) s += red[q][threadIdx.x];
     atomicAdd(out + c, scale * s);
   }
 }
@@ -262,6 +272,70 @@ __global__ __launch_bounds__(256) void bias2_bwd_kernel(const T* __restrict__ d1
   if (w == 0 && c < C) {
     atomicAdd(du + c, red[0][0][lane] + red[0][1][lane] + red[0][2][lane] + red[0][3][lane]);
     atomicAdd(dv + c, red[1][0][lane] + red[1][1][lane] + red[1][2][lane] + red[1][3][lane]);
+  }
+}
+
+// 16-B variants (bf16, C % 8 == 0, 16-B aligned rows): no per-element division, 8 channels per lane
+__global__ __launch_bounds__(256) void bias2_fwd_vec_kernel(const bf16_t* __restrict__ x, long ldx, const float* __restrict__ u,
+                                                            const float* __restrict__ v, bf16_t* __restrict__ y1, bf16_t* __restrict__ y2,
+                                                            long rows, int C) {
+  const int c8 = C >> 3;
+  const long n = rows * c8;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / c8;
+    const int c = (int)(i - r * c8) << 3;
+    float xv[8], a[8], b[8];
+    ld8(x + r * ldx + c, xv);
+    const float4 u0 = *reinterpret_cast<const float4*>(u + c), u1 = *reinterpret_cast<const float4*>(u + c + 4);
+    const float4 v0 = *reinterpret_cast<const float4*>(v + c), v1 = *reinterpret_cast<const float4*>(v + c + 4);
+    a[0] = xv[0] + u0.x; a[1] = xv[1] + u0.y; a[2] = xv[2] + u0.z; a[3] = xv[3] + u0.w;
+    a[4] = xv[4] + u1.x; a[5] = xv[5] + u1.y; a[6] = xv[6] + u1.z; a[7] = xv[7] + u1.w;
+    b[0] = xv[0] + v0.x; b[1] = xv[1] + v0.y; b[2] = xv[2] + v0.z; b[3] = xv[3] + v0.w;
+    b[4] = xv[4] + v1.x; b[5] = xv[5] + v1.y; b[6] = xv[6] + v1.z; b[7] = xv[7] + v1.w;
+    st8(y1 + r * C + c, a);
+    st8(y2 + r * C + c, b);
+  }
+}
+// grid (row chunks, C/256): 32 lanes x 8 columns per row, fat 1024-thread blocks, LDS atomics, 1 global atomic/column/block
+__global__ __launch_bounds__(512) void bias2_bwd_vec_kernel(const bf16_t* __restrict__ d1, const bf16_t* __restrict__ d2,
+                                                             bf16_t* __restrict__ dx, long lddx, float* __restrict__ du,
+                                                             float* __restrict__ dv, long rows, int C) {
+  __shared__ float red[2][16][256];  // up to 8 waves x 2 rows
+  const int lane = threadIdx.x & 63, li = lane & 31, sub = lane >> 5, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int c0 = blockIdx.y * 256 + li * 8;
+  float a1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, a2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (c0 < C) {
+    const long S = (long)gridDim.x * nw * 2;
+    for (long r = ((long)blockIdx.x * nw + w) * 2 + sub; r < rows; r += 2 * S) {
+      float p[2][8], q[2][8];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        if (r + t * S < rows) { ld8(d1 + (r + t * S) * C + c0, p[t]); ld8(d2 + (r + t * S) * C + c0, q[t]); }
+        else {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) { p[t][k] = 0.f; q[t][k] = 0.f; }
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        if (r + t * S < rows) {
+          float o[8];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) { o[k] = p[t][k] + q[t][k]; a1[k] += p[t][k]; a2[k] += q[t][k]; }
+          st8(dx + (r + t * S) * lddx + c0, o);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { red[0][w * 2 + sub][li * 8 + k] = a1[k]; red[1][w * 2 + sub][li * 8 + k] = a2[k]; }
+  __syncthreads();
+  const int c = blockIdx.y * 256 + threadIdx.x;
+  if (threadIdx.x < 256 && c < C) {
+    float s1 = 0.f, s2 = 0.f;
+    for (int q = 0; q < nw * 2; ++q) { s1 += red[0][q][threadIdx.x]; s2 += red[1][q][threadIdx.x]; }
+    atomicAdd(du + c, s1);
+    atomicAdd(dv + c, s2);
   }
 }
 
@@ -484,8 +558,11 @@ extern "C" int tfasr_colsum(const void* x, long ld, float* out, long rows, int C
   if (!x || !out || rows <= 0 || C <= 0) return TFASR_STATUS_INVALID_VALUE;
   hipStream_t s = (hipStream_t)stream_;
   if (dtype == TFASR_BF16 && (C % 8) == 0 && (ld % 8) == 0 && ((((uintptr_t)x) & 15) == 0)) {
-    dim3 gridv((int)std::max<long>(1, std::min<long>(rows / 64 + 1, 512)), (C + 255) / 256);
-    hipLaunchKernelGGL(colsum_vec_kernel<bf16_t>, gridv, dim3(256), 0, s, (const bf16_t*)x, ld, out, rows, C, scale);
+    const int cb = (C + 255) / 256;
+    static const int thr = getenv("TFASR_RED_THREADS") ? atoi(getenv("TFASR_RED_THREADS")) : 512;
+    static const int cap = getenv("TFASR_RED_GRID") ? atoi(getenv("TFASR_RED_GRID")) : 192;
+    dim3 gridv((int)std::max<long>(1, std::min<long>(rows / (thr / 8) + 1, std::max(32, cap / cb))), cb);
+    hipLaunchKernelGGL(colsum_vec_kernel<bf16_t>, gridv, dim3(thr), 0, s, (const bf16_t*)x, ld, out, rows, C, scale);
     TFASR_CHECK_LAUNCH();
     return TFASR_STATUS_SUCCESS;
   }
@@ -518,10 +595,18 @@ extern "C" int tfasr_glu_bwd(const void* x, const void* dy, void* dx, long rows,
   return TFASR_STATUS_SUCCESS;
 }
 
+// dwconv.hip: bf16 channel-pair kernels (which: 0 fwd, 1 data gradient, 2 weight gradient); UNSUPPORTED -> scalar kernels below
+int tfasr_dwconv_pair_try(int which, const void* x, const void* dy, const float* w, const float* bias, void* y, float* dw, float* dbias, int B,
+                          int T, int C, int K, hipStream_t s);
+
 extern "C" int tfasr_dwconv_fwd(const void* x, const float* w, const float* bias, void* y, int B, int T, int C, int K,
                                 int dtype, void* stream_) {
   if (!x || !w || !y || B <= 0 || T <= 0 || C <= 0 || K <= 0 || K > DW_MAXK) return TFASR_STATUS_INVALID_VALUE;
   hipStream_t s = (hipStream_t)stream_;
+  if (dtype == TFASR_BF16) {
+    const int st = tfasr_dwconv_pair_try(0, x, nullptr, w, bias, y, nullptr, nullptr, B, T, C, K, s);
+    if (st != TFASR_STATUS_UNSUPPORTED) return st;
+  }
   const int bx = C >= 256 ? 256 : ((C + 63) / 64) * 64;
   dim3 grid((C + bx - 1) / bx, (T + DW_TT - 1) / DW_TT, B);
   DISPATCH_T(dtype,
@@ -534,6 +619,10 @@ extern "C" int tfasr_dwconv_bwd_data(const void* dy, const float* w, void* dx, i
                                      void* stream_) {
   if (!dy || !w || !dx || B <= 0 || T <= 0 || C <= 0 || K <= 0 || K > DW_MAXK) return TFASR_STATUS_INVALID_VALUE;
   hipStream_t s = (hipStream_t)stream_;
+  if (dtype == TFASR_BF16) {
+    const int st = tfasr_dwconv_pair_try(1, nullptr, dy, w, nullptr, dx, nullptr, nullptr, B, T, C, K, s);
+    if (st != TFASR_STATUS_UNSUPPORTED) return st;
+  }
   const int bx = C >= 256 ? 256 : ((C + 63) / 64) * 64;
   dim3 grid((C + bx - 1) / bx, (T + DW_TT - 1) / DW_TT, B);
   DISPATCH_T(dtype,
@@ -546,6 +635,10 @@ extern "C" int tfasr_dwconv_bwd_weight(const void* x, const void* dy, float* dw,
                                        int K, int dtype, void* stream_) {
   if (!x || !dy || !dw || B <= 0 || T <= 0 || C <= 0 || K <= 0 || K > DW_MAXK) return TFASR_STATUS_INVALID_VALUE;
   hipStream_t s = (hipStream_t)stream_;
+  if (dtype == TFASR_BF16) {
+    const int st = tfasr_dwconv_pair_try(2, x, dy, nullptr, nullptr, nullptr, dw, dbias, B, T, C, K, s);
+    if (st != TFASR_STATUS_UNSUPPORTED) return st;
+  }
   const int bx = C >= 256 ? 256 : ((C + 63) / 64) * 64;
   dim3 grid((C + bx - 1) / bx, (T + DW_WT - 1) / DW_WT, B);
   DISPATCH_T(dtype,
@@ -559,6 +652,12 @@ extern "C" int tfasr_bias2_fwd(const void* x, long ldx, const float* u, const fl
                                int C, int dtype, void* stream_) {
   if (!x || !u || !v || !y1 || !y2 || rows <= 0 || C <= 0) return TFASR_STATUS_INVALID_VALUE;
   hipStream_t s = (hipStream_t)stream_;
+  auto al = [](const void* p) { return (((uintptr_t)p) & 15) == 0; };
+  if (dtype == TFASR_BF16 && (C % 8) == 0 && (ldx % 8) == 0 && al(x) && al(u) && al(v) && al(y1) && al(y2)) {
+    hipLaunchKernelGGL(bias2_fwd_vec_kernel, dim3(flat_grid(rows * C / 8)), dim3(256), 0, s, (const bf16_t*)x, ldx, u, v, (bf16_t*)y1, (bf16_t*)y2, rows, C);
+    TFASR_CHECK_LAUNCH();
+    return TFASR_STATUS_SUCCESS;
+  }
   const int grid = flat_grid(rows * C);
   DISPATCH_T(dtype,
              hipLaunchKernelGGL(bias2_fwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, ldx, u, v, (float*)y1, (float*)y2, rows, C),
@@ -570,6 +669,15 @@ extern "C" int tfasr_bias2_bwd(const void* d1, const void* d2, void* dx, long ld
                                int C, int dtype, void* stream_) {
   if (!d1 || !d2 || !dx || !du || !dv || rows <= 0 || C <= 0) return TFASR_STATUS_INVALID_VALUE;
   hipStream_t s = (hipStream_t)stream_;
+  auto al = [](const void* p) { return (((uintptr_t)p) & 15) == 0; };
+  if (dtype == TFASR_BF16 && (C % 8) == 0 && (lddx % 8) == 0 && al(d1) && al(d2) && al(dx)) {
+    static const int thr = getenv("TFASR_RED_THREADS") ? atoi(getenv("TFASR_RED_THREADS")) : 512;
+    static const int cap = getenv("TFASR_RED_GRID") ? atoi(getenv("TFASR_RED_GRID")) : 192;
+    dim3 gridv((int)std::max<long>(1, std::min<long>(rows / (thr / 8) + 1, cap)), (C + 255) / 256);
+    hipLaunchKernelGGL(bias2_bwd_vec_kernel, gridv, dim3(thr), 0, s, (const bf16_t*)d1, (const bf16_t*)d2, (bf16_t*)dx, lddx, du, dv, rows, C);
+    TFASR_CHECK_LAUNCH();
+    return TFASR_STATUS_SUCCESS;
+  }
   const int gx = (int)std::max<long>(1, std::min<long>(rows / 64 + 1, 256));
   dim3 grid(gx, (C + 63) / 64);
   DISPATCH_T(dtype,

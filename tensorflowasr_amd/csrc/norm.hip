@@ -7,6 +7,7 @@
 // row (LayerNorm) or lanes-own-columns accumulation with one f32 atomic per column per wave
 // (BatchNorm statistics, gamma/beta gradients).
 #include "common.h"
+#include <stdlib.h>
 #include <algorithm>
 
 namespace {
@@ -207,6 +208,22 @@ __global__ __launch_bounds__(256) void bn_apply_bwd_kernel(const T* __restrict__
 
 // ------------------------------------------------------------------------- vec8 variants (C % 8 == 0, C <= 512)
 // LPR lanes cover one row with 16-B accesses (8 channels per lane); 64/LPR rows per wave iteration.
+// 8 consecutive f32 coefficients of a live lane: two 16-byte loads when the address allows, never 8 branchy dword loads
+// (with 32 lanes x 32-B stride every scalar load instruction touches 8 cache lines: the parameter loads then cost more
+// memory-pipeline work than the activation stream itself -- 18.9 us vs 6.3 us for a [23808,256] LayerNorm)
+__device__ __forceinline__ void ldf8(const float* __restrict__ p, float (&v)[8], bool live) {
+#pragma unroll
+  for (int k = 0; k < 8; ++k) v[k] = 0.f;
+  if (!live) return;
+  if ((((uintptr_t)p) & 15) == 0) {
+    const float4 a = reinterpret_cast<const float4*>(p)[0], b = reinterpret_cast<const float4*>(p)[1];
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+  } else {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = p[k];
+  }
+}
+
 template <int LPR> __device__ __forceinline__ float seg_sum(float v) {
 #pragma unroll
   for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -223,8 +240,8 @@ __global__ __launch_bounds__(256) void ln_fwd_vec_kernel(const T* __restrict__ x
   const int c0 = li * 8;
   const bool act = c0 < C;
   float g[8], b[8];
-#pragma unroll
-  for (int k = 0; k < 8; ++k) { g[k] = act ? gamma[c0 + k] : 0.f; b[k] = act ? beta[c0 + k] : 0.f; }
+  ldf8(gamma + c0, g, act);
+  ldf8(beta + c0, b, act);
   const long w0 = ((long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * RPW + sub;
   const long step = (long)gridDim.x * (blockDim.x >> 6) * RPW;
   const float invC = 1.f / C;
@@ -249,49 +266,61 @@ __global__ __launch_bounds__(256) void ln_fwd_vec_kernel(const T* __restrict__ x
   }
 }
 
+// Row-reduction kernels below end in one global atomicAdd per column per BLOCK, and same-address atomics serialise
+// (~20-30 ns each on this chip): with 512 blocks that tail alone cost ~10 us.  So: few (<= 128) fat 1024-thread blocks,
+// two rows in flight per lane for bandwidth, partial sums combined with LDS atomics, then <= 128 global atomics per column.
 template <typename T, int LPR>
-__global__ __launch_bounds__(256) void ln_bwd_vec_kernel(const T* __restrict__ dy, const T* __restrict__ x,
-                                                         const float* __restrict__ gamma, const float* __restrict__ mean,
-                                                         const float* __restrict__ rstd, const T* add, T* dx,
-                                                         float* __restrict__ dgamma, float* __restrict__ dbeta, long rows,
-                                                         int C) {
+__global__ __launch_bounds__(512) void ln_bwd_vec_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                          const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                          const float* __restrict__ rstd, const T* add, T* dx,
+                                                          float* __restrict__ dgamma, float* __restrict__ dbeta, long rows,
+                                                          int C) {
   constexpr int RPW = 64 / LPR;
-  __shared__ float red[2][4 * RPW][LPR * 8];
-  const int lane = threadIdx.x & 63, li = lane % LPR, sub = lane / LPR, w = threadIdx.x >> 6;
+  __shared__ float red[2][8 * RPW][LPR * 8];  // up to 8 waves (512 threads)
+  const int lane = threadIdx.x & 63, li = lane % LPR, sub = lane / LPR, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const int c0 = li * 8;
   const bool act = c0 < C;
   float g[8], ag[8], ab[8];
+  ldf8(gamma + c0, g, act);
 #pragma unroll
-  for (int k = 0; k < 8; ++k) { g[k] = act ? gamma[c0 + k] : 0.f; ag[k] = 0.f; ab[k] = 0.f; }
-  const long w0 = ((long)blockIdx.x * (blockDim.x >> 6) + w) * RPW + sub;
-  const long step = (long)gridDim.x * (blockDim.x >> 6) * RPW;
+  for (int k = 0; k < 8; ++k) { ag[k] = 0.f; ab[k] = 0.f; }
+  const long w0 = ((long)blockIdx.x * nw + w) * RPW + sub;
+  const long step = (long)gridDim.x * nw * RPW;
   const float invC = 1.f / C;
-  for (long r = w0; r < rows; r += step) {
-    const bool rv = act;
-    float d[8] = {0, 0, 0, 0, 0, 0, 0, 0}, xv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    float m = 0.f, rs = 0.f;
-    if (rv) { ld8(dy + r * C + c0, d); ld8(x + r * C + c0, xv); m = mean[r]; rs = rstd[r]; }
-    float s1 = 0.f, s2 = 0.f;
+  for (long r0 = w0; r0 < rows; r0 += 2 * step) {
+    float d[2][8], xv[2][8], o[2][8], m[2], rs[2];
+    bool rv[2];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      xv[k] = (xv[k] - m) * rs;        // xhat
-      const float dg = d[k] * g[k];
-      s1 += dg;
-      s2 += dg * xv[k];
-      ag[k] += d[k] * xv[k];
-      ab[k] += d[k];
+    for (int u = 0; u < 2; ++u) {
+      const long r = r0 + u * step;
+      rv[u] = act && r < rows;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { d[u][k] = 0.f; xv[u][k] = 0.f; o[u][k] = 0.f; }
+      m[u] = 0.f; rs[u] = 0.f;
+      if (rv[u]) {
+        ld8(dy + r * C + c0, d[u]); ld8(x + r * C + c0, xv[u]); m[u] = mean[r]; rs[u] = rstd[r];
+        if (add) ld8(add + r * C + c0, o[u]);
+      }
     }
-    s1 = seg_sum<LPR>(s1) * invC;
-    s2 = seg_sum<LPR>(s2) * invC;
-    if (rv) {
-      float o[8];
-      if (add) ld8(add + r * C + c0, o);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      float s1 = 0.f, s2 = 0.f;
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
-        const float t = rs * (d[k] * g[k] - s1 - xv[k] * s2);
-        o[k] = add ? o[k] + t : t;
+        xv[u][k] = (xv[u][k] - m[u]) * rs[u];  // xhat
+        const float dg = d[u][k] * g[k];
+        s1 += dg;
+        s2 += dg * xv[u][k];
+        ag[k] += d[u][k] * xv[u][k];
+        ab[k] += d[u][k];
       }
-      st8(dx + r * C + c0, o);
+      s1 = seg_sum<LPR>(s1) * invC;
+      s2 = seg_sum<LPR>(s2) * invC;
+      if (rv[u]) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[u][k] += rs[u] * (d[u][k] * g[k] - s1 - xv[u][k] * s2);
+        st8(dx + (r0 + u * step) * C + c0, o[u]);
+      }
     }
   }
 #pragma unroll
@@ -299,47 +328,56 @@ __global__ __launch_bounds__(256) void ln_bwd_vec_kernel(const T* __restrict__ d
   __syncthreads();
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
     float sg = 0.f, sb = 0.f;
-#pragma unroll
-    for (int q = 0; q < 4 * RPW; ++q) { sg += red[0][q][c]; sb += red[1][q][c]; }
+    for (int q = 0; q < nw * RPW; ++q) { sg += red[0][q][c]; sb += red[1][q][c]; }
     if (dgamma) atomicAdd(dgamma + c, sg);
     if (dbeta) atomicAdd(dbeta + c, sb);
   }
 }
 
 template <typename T, int MODE, int LPR>
-__global__ __launch_bounds__(256) void bn_stats_vec_kernel(const T* __restrict__ x, const T* __restrict__ dy,
-                                                           const float* __restrict__ fin, float* __restrict__ stats,
-                                                           long rows, int C, int act_kind) {
+__global__ __launch_bounds__(512) void bn_stats_vec_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                            const float* __restrict__ fin, float* __restrict__ stats,
+                                                            long rows, int C, int act_kind) {
   constexpr int RPW = 64 / LPR;
-  __shared__ float red[2][4 * RPW][LPR * 8];
-  const int lane = threadIdx.x & 63, li = lane % LPR, sub = lane / LPR, w = threadIdx.x >> 6;
+  __shared__ float red[2][8 * RPW][LPR * 8];  // up to 8 waves (512 threads)
+  const int lane = threadIdx.x & 63, li = lane % LPR, sub = lane / LPR, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const int c0 = li * 8;
   const bool act = c0 < C;
   float a0[8], a1[8], mean[8], rstd[8], sc[8], sh[8];
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    a0[k] = 0.f; a1[k] = 0.f;
-    if (MODE == 1 && act) { mean[k] = fin[c0 + k]; rstd[k] = fin[C + c0 + k]; sc[k] = fin[2 * C + c0 + k]; sh[k] = fin[3 * C + c0 + k]; }
-    else { mean[k] = 0.f; rstd[k] = 0.f; sc[k] = 0.f; sh[k] = 0.f; }
-  }
-  const long w0 = ((long)blockIdx.x * (blockDim.x >> 6) + w) * RPW + sub;
-  const long step = (long)gridDim.x * (blockDim.x >> 6) * RPW;
+  for (int k = 0; k < 8; ++k) { a0[k] = 0.f; a1[k] = 0.f; }
+  ldf8(fin + c0, mean, MODE == 1 && act);
+  ldf8(fin + C + c0, rstd, MODE == 1 && act);
+  ldf8(fin + 2 * C + c0, sc, MODE == 1 && act);
+  ldf8(fin + 3 * C + c0, sh, MODE == 1 && act);
+  const long w0 = ((long)blockIdx.x * nw + w) * RPW + sub;
+  const long step = (long)gridDim.x * nw * RPW;
   if (act)
-    for (long r = w0; r < rows; r += step) {
-      float xv[8];
-      ld8(x + r * C + c0, xv);
-      if (MODE == 0) {
+    for (long r0 = w0; r0 < rows; r0 += 2 * step) {
+      float xv[2][8], d[2][8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) { a0[k] += xv[k]; a1[k] += xv[k] * xv[k]; }
-      } else {
-        float d[8];
-        ld8(dy + r * C + c0, d);
+      for (int u = 0; u < 2; ++u) {
+        const long r = r0 + u * step;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          float dz = d[k];
-          if (act_kind == TFASR_ACT_SWISH) dz *= dswishf_(xv[k] * sc[k] + sh[k]);
-          a0[k] += dz;
-          a1[k] += dz * (xv[k] - mean[k]) * rstd[k];
+        for (int k = 0; k < 8; ++k) { xv[u][k] = 0.f; d[u][k] = 0.f; }
+        if (r < rows) {
+          ld8(x + r * C + c0, xv[u]);
+          if (MODE == 1) ld8(dy + r * C + c0, d[u]);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        if (MODE == 0) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) { a0[k] += xv[u][k]; a1[k] += xv[u][k] * xv[u][k]; }
+        } else if (r0 + u * step < rows) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            float dz = d[u][k];
+            if (act_kind == TFASR_ACT_SWISH) dz *= dswishf_(xv[u][k] * sc[k] + sh[k]);
+            a0[k] += dz;
+            a1[k] += dz * (xv[u][k] - mean[k]) * rstd[k];
+          }
         }
       }
     }
@@ -348,11 +386,20 @@ __global__ __launch_bounds__(256) void bn_stats_vec_kernel(const T* __restrict__
   __syncthreads();
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
     float s0 = 0.f, s1 = 0.f;
-#pragma unroll
-    for (int q = 0; q < 4 * RPW; ++q) { s0 += red[0][q][c]; s1 += red[1][q][c]; }
+    for (int q = 0; q < nw * RPW; ++q) { s0 += red[0][q][c]; s1 += red[1][q][c]; }
     atomicAdd(stats + c, s0);
     atomicAdd(stats + C + c, s1);
   }
+}
+
+// launch shape of the fat row-reduction kernels: 1024 threads, <= 128 blocks, >= 2 row-pairs per wave
+inline int red_threads() { static int v = 0; if (!v) { const char* e = getenv("TFASR_RED_THREADS"); v = e ? atoi(e) : 512; } return v; }
+inline int red_grid_cap() { static int v = 0; if (!v) { const char* e = getenv("TFASR_RED_GRID"); v = e ? atoi(e) : 192; } return v; }
+inline int fat_grid(long rows, int rows_per_wave_iter) {
+  const long per_block = (long)(red_threads() / 64) * rows_per_wave_iter;
+  // the per-block atomic tail (~17 ns per block per column) is only worth limiting for small inputs
+  const long cap = std::max<long>(red_grid_cap(), std::min<long>(rows / 4096, 1024L));
+  return (int)std::max<long>(1, std::min<long>(rows / (2L * per_block) + 1, cap));
 }
 
 inline int rows_grid(long rows) { return (int)std::min<long>((rows + 3) / 4, 256L * 8); }
@@ -393,11 +440,11 @@ extern "C" int tfasr_layernorm_bwd(const void* dy, const void* x, const float* g
   hipStream_t s = (hipStream_t)stream_;
   if (dtype == TFASR_BF16 && (C % 8) == 0 && C <= 512) {
     if (C <= 256) {
-      const int grid = (int)std::min<long>((rows + 7) / 8, 512L);
-      hipLaunchKernelGGL((ln_bwd_vec_kernel<bf16_t, 32>), dim3(grid), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x, gamma, mean, rstd, (const bf16_t*)add, (bf16_t*)dx, dgamma, dbeta, rows, C);
+      const int grid = fat_grid(rows, 2);
+      hipLaunchKernelGGL((ln_bwd_vec_kernel<bf16_t, 32>), dim3(grid), dim3(red_threads()), 0, s, (const bf16_t*)dy, (const bf16_t*)x, gamma, mean, rstd, (const bf16_t*)add, (bf16_t*)dx, dgamma, dbeta, rows, C);
     } else {
-      const int grid = (int)std::min<long>((rows + 3) / 4, 512L);
-      hipLaunchKernelGGL((ln_bwd_vec_kernel<bf16_t, 64>), dim3(grid), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x, gamma, mean, rstd, (const bf16_t*)add, (bf16_t*)dx, dgamma, dbeta, rows, C);
+      const int grid = fat_grid(rows, 1);
+      hipLaunchKernelGGL((ln_bwd_vec_kernel<bf16_t, 64>), dim3(grid), dim3(red_threads()), 0, s, (const bf16_t*)dy, (const bf16_t*)x, gamma, mean, rstd, (const bf16_t*)add, (bf16_t*)dx, dgamma, dbeta, rows, C);
     }
     TFASR_CHECK_LAUNCH();
     return TFASR_STATUS_SUCCESS;
@@ -417,8 +464,8 @@ extern "C" int tfasr_bn_stats(const void* x, float* stats, long rows, int C, int
   if (!x || !stats || rows <= 0 || C <= 0 || C > 64 * MAXC_PER_LANE) return TFASR_STATUS_INVALID_VALUE;
   hipStream_t s = (hipStream_t)stream_;
   if (dtype == TFASR_BF16 && (C % 8) == 0 && C <= 512) {
-    if (C <= 256) hipLaunchKernelGGL((bn_stats_vec_kernel<bf16_t, 0, 32>), dim3((int)std::max<long>(32, std::min<long>(rows / 256, 1024L))), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)nullptr, (const float*)nullptr, stats, rows, C, 0);
-    else hipLaunchKernelGGL((bn_stats_vec_kernel<bf16_t, 0, 64>), dim3((int)std::max<long>(32, std::min<long>(rows / 128, 1024L))), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)nullptr, (const float*)nullptr, stats, rows, C, 0);
+    if (C <= 256) hipLaunchKernelGGL((bn_stats_vec_kernel<bf16_t, 0, 32>), dim3(fat_grid(rows, 2)), dim3(red_threads()), 0, s, (const bf16_t*)x, (const bf16_t*)nullptr, (const float*)nullptr, stats, rows, C, 0);
+    else hipLaunchKernelGGL((bn_stats_vec_kernel<bf16_t, 0, 64>), dim3(fat_grid(rows, 1)), dim3(red_threads()), 0, s, (const bf16_t*)x, (const bf16_t*)nullptr, (const float*)nullptr, stats, rows, C, 0);
     TFASR_CHECK_LAUNCH();
     return TFASR_STATUS_SUCCESS;
   }
@@ -465,8 +512,8 @@ extern "C" int tfasr_bn_bwd_stats(const void* x, const void* dy, const float* fi
   if (!x || !dy || !fin || !bstats || rows <= 0 || C <= 0 || C > 64 * MAXC_PER_LANE) return TFASR_STATUS_INVALID_VALUE;
   hipStream_t s = (hipStream_t)stream_;
   if (dtype == TFASR_BF16 && (C % 8) == 0 && C <= 512) {
-    if (C <= 256) hipLaunchKernelGGL((bn_stats_vec_kernel<bf16_t, 1, 32>), dim3((int)std::max<long>(32, std::min<long>(rows / 256, 1024L))), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)dy, fin, bstats, rows, C, act);
-    else hipLaunchKernelGGL((bn_stats_vec_kernel<bf16_t, 1, 64>), dim3((int)std::max<long>(32, std::min<long>(rows / 128, 1024L))), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)dy, fin, bstats, rows, C, act);
+    if (C <= 256) hipLaunchKernelGGL((bn_stats_vec_kernel<bf16_t, 1, 32>), dim3(fat_grid(rows, 2)), dim3(red_threads()), 0, s, (const bf16_t*)x, (const bf16_t*)dy, fin, bstats, rows, C, act);
+    else hipLaunchKernelGGL((bn_stats_vec_kernel<bf16_t, 1, 64>), dim3(fat_grid(rows, 1)), dim3(red_threads()), 0, s, (const bf16_t*)x, (const bf16_t*)dy, fin, bstats, rows, C, act);
     TFASR_CHECK_LAUNCH();
     return TFASR_STATUS_SUCCESS;
   }

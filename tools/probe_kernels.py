@@ -131,6 +131,67 @@ def probe_epi():
         print(json.dumps({"epilogue": name, "us": round(ms * 1e3, 1)}))
 
 
+def probe_splitk():
+    dt = torch.bfloat16
+    R = 19040
+    for M, N in [(256, 1024), (1024, 256), (256, 256), (256, 768), (256, 512), (640, 1000)]:
+        Kd = R if M != 640 else 343000
+        A = torch.randn(Kd, M, device=dev).to(dt)
+        B = torch.randn(Kd, N, device=dev).to(dt)
+        out = torch.zeros(M, N, device=dev, dtype=torch.float32)
+        for sk in (8, 12, 18, 24, 32, 48, 64, 96):
+            ms = timeit(lambda: kernels.gemm(A, B, out, M, N, Kd, M, N, N, trans_a=True, accumulate=True, split_k=sk), iters=20)
+            print(json.dumps({"wgrad": [M, N, Kd], "split_k": sk, "us": round(ms * 1e3, 1)}))
+
+
+def probe_pointwise():
+    """HBM-bound pointwise / reduction kernels at the Conformer-M bench shape: achieved GB/s of algorithmic traffic."""
+    dt = torch.bfloat16
+    B, T, d = 32, 744, 256
+    rows = B * T
+    x = torch.randn(rows, d, device=dev).to(dt)
+    dy = torch.randn(rows, d, device=dev).to(dt)
+    g = torch.randn(d, device=dev)
+    b = torch.randn(d, device=dev)
+    e2 = 2.0 * rows * d  # bytes of one [rows, d] bf16 tensor
+
+    def rep(name, fn, nbytes):
+        ms = timeit(fn, iters=20)
+        print(json.dumps({"kernel": name, "us": round(ms * 1e3, 1), "GBps": round(nbytes / ms / 1e6, 0)}))
+
+    y, mean, rstd = kernels.layernorm_fwd(x, g, b)
+    rep("ln_fwd", lambda: kernels.layernorm_fwd(x, g, b), 2 * e2)
+    dg, db = torch.zeros(d, device=dev), torch.zeros(d, device=dev)
+    rep("ln_bwd(+add)", lambda: kernels.layernorm_bwd(dy, x, g, mean, rstd, dg, db, add=dy), 4 * e2)
+    stats = torch.zeros(2 * d + 1, device=dev)
+    rep("bn_stats", lambda: kernels.bn_stats(x, stats), e2)
+    fin = torch.empty(4 * d, device=dev)
+    mm, mv = torch.zeros(d, device=dev), torch.ones(d, device=dev)
+    kernels.bn_finalize(stats, rows * 24, g, b, fin, mm, mv)
+    rep("bn_apply_fwd(swish)", lambda: kernels.bn_apply_fwd(x, fin, ACT_SWISH), 2 * e2)
+    bst = torch.zeros(2 * d, device=dev)
+    rep("bn_bwd_stats", lambda: kernels.bn_bwd_stats(x, dy, fin, bst, ACT_SWISH), 2 * e2)
+    rep("bn_apply_bwd", lambda: kernels.bn_apply_bwd(x, dy, fin, bst, rows, ACT_SWISH), 3 * e2)
+    w = torch.randn(31, d, device=dev)
+    x3, dy3 = x.view(B, T, d), dy.view(B, T, d)
+    rep("dwconv_fwd", lambda: kernels.dwconv_fwd(x3, w, b), 2 * e2)
+    rep("dwconv_bwd_data", lambda: kernels.dwconv_bwd_data(dy3, w), 2 * e2)
+    dw = torch.zeros(31, d, device=dev)
+    rep("dwconv_bwd_weight", lambda: kernels.dwconv_bwd_weight(x3, dy3, dw, db), 2 * e2)
+    a2 = torch.randn(rows, 2 * d, device=dev).to(dt)
+    rep("glu_fwd", lambda: kernels.glu_fwd(a2), 3 * e2)
+    rep("glu_bwd", lambda: kernels.glu_bwd(a2, dy), 5 * e2)
+    for C in (256, 1024):
+        z = torch.randn(rows, C, device=dev).to(dt)
+        o = torch.zeros(C, device=dev)
+        rep(f"colsum C={C}", lambda: kernels.colsum(z, o), 2.0 * rows * C)
+    rep("dropout", lambda: kernels.dropout(x, 0.1, 123), 2 * e2)
+    q3 = torch.randn(rows, 3 * d, device=dev).to(dt)
+    rep("bias2_fwd", lambda: kernels.bias2_fwd(q3, 3 * d, g, b, rows, d), 3 * e2)
+    dq = torch.empty(rows, 3 * d, device=dev, dtype=dt)
+    rep("bias2_bwd", lambda: kernels.bias2_bwd(x, dy, dq, 3 * d, dg, db, rows, d), 3 * e2)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["rnnt", "gemm"]
     for w in which:
