@@ -41,7 +41,8 @@ def _split_k(M, N, Kd):
     tiles = -(-M // 128) * -(-N // 128)
     if tiles >= 512 or Kd <= 2048:
         return 1
-    return int(max(1, min(-(-1024 // tiles), Kd // 1024, 64)))
+    v = int(max(1, min(-(-1024 // tiles), Kd // 1024, 64)))
+    return (v + 4) // 8 * 8 if v >= 12 else v  # whole k-slices per XCD (gemm_fast.hip split-K mapping needs split % 8 == 0)
 
 
 class ConformerTransducer:

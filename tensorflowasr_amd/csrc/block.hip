@@ -95,6 +95,7 @@ struct Ex {
     long v = (1024 + tiles - 1) / tiles;
     if (K / 1024 < v) v = K / 1024;
     if (v > 64) v = 64;
+    if (v >= 12) v = (v + 4) / 8 * 8;  // whole k-slices per XCD (gemm_fast.hip split-K mapping needs split % 8 == 0)
     return (int)(v < 1 ? 1 : v);
   }
   // y = x @ W + b with the fused epilogue terms (W stored [din, dout] in the compute-dtype shadow)

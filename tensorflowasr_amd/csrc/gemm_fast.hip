@@ -159,19 +159,23 @@ __global__ __launch_bounds__(256, 2) void gemm_fast_kernel(const tfasr_gemm_args
   constexpr int STAGE_BYTES = A_BYTES + BN_ * BK * 2;
   extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 stages x (16 KiB A + 16|8 KiB B)
   const int split = p.split_k > 1 ? p.split_k : 1;
-  const int ks = blockIdx.z % split;
-  const int bidx = blockIdx.z / split;
-  const int b1 = bidx / p.nb2, b2 = bidx % p.nb2;
-  const bf16_t* A = (const bf16_t*)p.A + b1 * p.sA1 + b2 * p.sA2;
-  const bf16_t* Bm = (const bf16_t*)p.B + b1 * p.sB1 + b2 * p.sB2;
-  const long doff = b1 * p.sD1 + b2 * p.sD2;
   // XCD-aware tile order: hardware deals consecutive workgroup ids round-robin over the 8 XCDs (each with its own L2),
   // so give every XCD one contiguous run of the n-fastest tile sequence: the n-tiles that share an A row-block then hit
   // the same L2 instead of fetching it over the fabric once per XCD (bijective remap, guide "XCD swizzle").
-  int tile_x = blockIdx.x, tile_y = blockIdx.y;
+  int tile_x = blockIdx.x, tile_y = blockIdx.y, tile_z = blockIdx.z;
   {
     const int gx = gridDim.x, total = gx * gridDim.y;
-    if (total >= 16) {
+    if (split > 1 && (gridDim.z & 7) == 0) {
+      // split-K (weight gradients): every k-slice's tiles re-read the same A / B slabs, so put a whole slice on ONE XCD
+      // (hardware deals linear workgroup ids round-robin over the 8 XCDs) - the slab is then fetched once per slice
+      // instead of once per tile (5x less HBM traffic measured on the joint weight gradient).  Bijective for gz % 8 == 0.
+      const int L = blockIdx.x + gx * (blockIdx.y + gridDim.y * blockIdx.z);
+      const int xcd = L & 7, slot = L >> 3;
+      tile_z = xcd + 8 * (slot / total);
+      const int t = slot % total;
+      tile_x = t % gx;
+      tile_y = t / gx;
+    } else if (total >= 16) {
       const int L = blockIdx.x + gx * blockIdx.y;
       const int q = total >> 3, rem = total & 7, xcd = L & 7, slot = L >> 3;
       const int Lp = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + slot;
@@ -179,6 +183,12 @@ __global__ __launch_bounds__(256, 2) void gemm_fast_kernel(const tfasr_gemm_args
       tile_y = Lp / gx;
     }
   }
+  const int ks = tile_z % split;
+  const int bidx = tile_z / split;
+  const int b1 = bidx / p.nb2, b2 = bidx % p.nb2;
+  const bf16_t* A = (const bf16_t*)p.A + b1 * p.sA1 + b2 * p.sA2;
+  const bf16_t* Bm = (const bf16_t*)p.B + b1 * p.sB1 + b2 * p.sB2;
+  const long doff = b1 * p.sD1 + b2 * p.sD2;
   const int m0 = tile_y * BM, n0 = tile_x * BN;
   int kchunk = (p.K + split - 1) / split;
   kchunk = ((kchunk + BK - 1) / BK) * BK;

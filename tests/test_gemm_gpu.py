@@ -80,14 +80,15 @@ def test_batched_strided_heads(dev, dtype):
     np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=rtol, atol=atol * 6)
 
 
-def test_split_k_accumulate(dev):
+@pytest.mark.parametrize("split", [8, 5, 24])  # multiples of 8 take the slice-per-XCD workgroup mapping
+def test_split_k_accumulate(dev, split):
     M, N, K = 144, 576, 5000
     g = torch.Generator().manual_seed(3)
     X, dY = torch.randn(K, M, generator=g), torch.randn(K, N, generator=g)
     for dtype in (torch.float32, torch.bfloat16):
         Xd, Yd = X.to(dev).to(dtype), dY.to(dev).to(dtype)
         out = torch.ones(M, N, dtype=torch.float32, device=dev)
-        kernels.gemm(Xd, Yd, out, M, N, K, M, N, N, trans_a=True, accumulate=True, split_k=8)
+        kernels.gemm(Xd, Yd, out, M, N, K, M, N, N, trans_a=True, accumulate=True, split_k=split)
         ref = 1.0 + Xd.float().cpu().T @ Yd.float().cpu()
         rtol, atol = _tol(dtype)
         np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=rtol, atol=atol * 70)
