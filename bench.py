@@ -61,6 +61,25 @@ def to_train_data(batch, dev):
         TrainLabel(torch.from_numpy(batch["labels"]).to(dev), torch.from_numpy(batch["ulen"])))
 
 
+def pmc_traffic(flops_per_launch, J, V):
+    """HBM bytes per launch of the joint vocabulary GEMM from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE,
+    profiles/r01_pmc_traffic.json, collected on this same command).  PMC counters cannot be read inside a timed run, so
+    the figure is looked up by the launch's grid (m-tiles of the packed lattice); None when no launch of that grid was
+    profiled."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+    if not os.path.exists(path):
+        return None
+    rows = json.load(open(path))
+    vals = []
+    for fl in flops_per_launch:
+        cells = int(round(fl / (2.0 * J * V)))
+        mt = -(-cells // 128)
+        for r in rows:
+            if r["kernel"].startswith("gemm_fast_kernel<false, false, 128>") and r["grid_threads"][1] == mt and r["grid_threads"][0] == 256 * -(-V // 128):
+                vals.append(r["hbm_MB"] * 1e6)
+    return round(float(np.mean(vals)), 0) if vals else None
+
+
 def cpu_baseline_worker(size, vocab):
     """Reference-path stand-in: the oracle's torch-CPU restatement of the same train step (TensorFlow is not
     installable: BASELINE.md §2), timed on this box's host cores on a bounded sample of the same workload."""
@@ -244,8 +263,10 @@ def main():
             fl = float(np.mean(model.timer_work["joint_vocab_gemm"]))
             peak = MFMA_BF16_PEAK_TFLOPS if dtype == torch.bfloat16 else MFMA_F32_PEAK_TFLOPS
             ach = fl / (ms * 1e-3) / 1e12
-            roof = {"kernel": "gemm_kernel (joint vocab projection, fwd)", "bound": "mfma", "achieved": round(ach, 2), "peak": peak,
-                    "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None, "ms_per_launch": round(ms, 4)}
+            roof = {"kernel": "gemm_fast_kernel (joint vocab projection, fwd)", "bound": "mfma", "achieved": round(ach, 2), "peak": peak,
+                    "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                    "traffic": pmc_traffic(model.timer_work["joint_vocab_gemm"], cfg.joint_dim, cfg.vocab_size),
+                    "ms_per_launch": round(ms, 4)}
         out = {
             "metric": "audio-hours/sec (train step) Conformer-M RNN-T" if args.model == "M" else "audio-hours/sec (train step) Conformer-S RNN-T",
             "value": round(value, 4), "unit": "audio-hours/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
