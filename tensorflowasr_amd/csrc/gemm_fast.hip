@@ -20,6 +20,10 @@
 
 typedef __attribute__((ext_vector_type(4))) short short4_t;
 
+#ifdef TFASR_GEMM_TIMING
+__device__ long long g_gemm_timing[16 * 32768];  // per workgroup: start, first slab landed, mainloop end, end (cycles)
+#endif
+
 namespace {
 
 constexpr int BM = 128, BK = 64;
@@ -116,24 +120,30 @@ template <bool TA, bool TB, int BN_>
 __device__ __forceinline__ void mma_slab(const char* sA, const char* sB, int wm, int wn, int lane, float4_t (&acc)[4][BN_ / 32]) {
   constexpr int NJ = BN_ / 32, WN = BN_ / 2;
   const int r = lane & 15, g = lane >> 4;
+  // All fragment reads of the slab are issued first (LDS returns in order, so the first MFMAs start as soon as their
+  // operands land and the rest of the reads fly under them).  Left to itself the compiler reused one A register quad and
+  // serialised "ds_read -> wait -> 4 MFMA" eight times per slab: ~2000 cycles per slab for 512 cycles of MFMA.
+  short8_t a[2][4], b[2][NJ];
 #pragma unroll
   for (int kk = 0; kk < 2; ++kk) {
-    short8_t a[4], b[NJ];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      if (TA) a[i] = frag_trans<128>(sA, wm * 64 + i * 16, kk * 32 + g * 8, r);
-      else    a[i] = frag_direct(sA, wm * 64 + i * 16 + r, kk * 4 + g);
+      if (TA) a[kk][i] = frag_trans<128>(sA, wm * 64 + i * 16, kk * 32 + g * 8, r);
+      else    a[kk][i] = frag_direct(sA, wm * 64 + i * 16 + r, kk * 4 + g);
     }
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-      if (TB) b[j] = frag_direct(sB, wn * WN + j * 16 + r, kk * 4 + g);
-      else    b[j] = frag_trans<BN_>(sB, wn * WN + j * 16, kk * 32 + g * 8, r);
+      if (TB) b[kk][j] = frag_direct(sB, wn * WN + j * 16 + r, kk * 4 + g);
+      else    b[kk][j] = frag_trans<BN_>(sB, wn * WN + j * 16, kk * 32 + g * 8, r);
     }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
-  }
+      for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[kk][i], b[kk][j], acc[i][j], 0, 0, 0);
 }
 
 __device__ __forceinline__ float act_f(float v, int act) {
@@ -153,236 +163,339 @@ __device__ __forceinline__ float dact_f(float z, int act) {
   }
 }
 
-template <bool TA, bool TB, int BN_>
-__global__ __launch_bounds__(256, 2) void gemm_fast_kernel(const tfasr_gemm_args p) {
+// EPI selects which epilogue terms are COMPILED IN.  The fully generic epilogue (every term behind a runtime branch, tanh /
+// sigmoid / f32 outputs included) is ~20k instructions and thrashes the instruction cache: a plain bias epilogue took 1700
+// cycles per 16-row strip.  The step's common combinations get lean instantiations; anything else falls back to E_GEN.
+enum : int { E_ACT = 1 /* swish(+prez) */, E_DACT = 2 /* * swish'(dact_z) */, E_DROP = 4, E_RES = 8, E_GEN = 256 };
+
+// Persistent workgroups (2 per CU) walk a strided list of tiles.  Measured on [23808,256]x[256,1024] (cycle counters,
+// tools/hwprobe/gemm_timing.hip): a tile spent 1900 cycles waiting for its first slab, ~2400 per further slab (the LDS-DMA
+// round trip; the 512 cycles of MFMA per slab hide nothing) and 4300 in the epilogue.  So the NEXT tile's first two slabs
+// are issued into the two (then idle) stages BEFORE this tile's epilogue: they land under it, and the epilogue's strip
+// lives in its own 8.5 KiB so nothing waits for it.
+template <bool TA, bool TB, int BN_, int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_fast_kernel(const tfasr_gemm_args p, const int gx, const int gy, const int gz, const int ntiles) {
+  constexpr bool GEN = (EPI & E_GEN) != 0;
+  constexpr bool C_ACT = GEN || (EPI & E_ACT), C_DACT = GEN || (EPI & E_DACT), C_DROP = GEN || (EPI & E_DROP), C_RES = GEN || (EPI & E_RES);
   constexpr int BN = BN_, NJ = BN_ / 32, WN = BN_ / 2;
   constexpr int STAGE_BYTES = A_BYTES + BN_ * BK * 2;
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 stages x (16 KiB A + 16|8 KiB B)
+  constexpr int GI = 4 + BN_ / 32;  // DMA wave-instructions per slab per wave
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 stages x (16 KiB A + 16|8 KiB B) + epilogue strips
   const int split = p.split_k > 1 ? p.split_k : 1;
-  // XCD-aware tile order: hardware deals consecutive workgroup ids round-robin over the 8 XCDs (each with its own L2),
-  // so give every XCD one contiguous run of the n-fastest tile sequence: the n-tiles that share an A row-block then hit
-  // the same L2 instead of fetching it over the fabric once per XCD (bijective remap, guide "XCD swizzle").
-  int tile_x = blockIdx.x, tile_y = blockIdx.y, tile_z = blockIdx.z;
-  {
-    const int gx = gridDim.x, total = gx * gridDim.y;
-    if (split > 1 && (gridDim.z & 7) == 0) {
-      // split-K (weight gradients): every k-slice's tiles re-read the same A / B slabs, so put a whole slice on ONE XCD
-      // (hardware deals linear workgroup ids round-robin over the 8 XCDs) - the slab is then fetched once per slice
-      // instead of once per tile (5x less HBM traffic measured on the joint weight gradient).  Bijective for gz % 8 == 0.
-      const int L = blockIdx.x + gx * (blockIdx.y + gridDim.y * blockIdx.z);
-      const int xcd = L & 7, slot = L >> 3;
-      tile_z = xcd + 8 * (slot / total);
-      const int t = slot % total;
-      tile_x = t % gx;
-      tile_y = t / gx;
-    } else if (total >= 16) {
-      const int L = blockIdx.x + gx * blockIdx.y;
-      const int q = total >> 3, rem = total & 7, xcd = L & 7, slot = L >> 3;
-      const int Lp = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + slot;
-      tile_x = Lp % gx;
-      tile_y = Lp / gx;
-    }
-  }
-  const int ks = tile_z % split;
-  const int bidx = tile_z / split;
-  const int b1 = bidx / p.nb2, b2 = bidx % p.nb2;
-  const bf16_t* A = (const bf16_t*)p.A + b1 * p.sA1 + b2 * p.sA2;
-  const bf16_t* Bm = (const bf16_t*)p.B + b1 * p.sB1 + b2 * p.sB2;
-  const long doff = b1 * p.sD1 + b2 * p.sD2;
-  const int m0 = tile_y * BM, n0 = tile_x * BN;
-  int kchunk = (p.K + split - 1) / split;
-  kchunk = ((kchunk + BK - 1) / BK) * BK;
-  const int k_begin = ks * kchunk;
-  const int k_end = min(p.K, k_begin + kchunk);
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = w >> 1, wn = w & 1;
+  const int r = lane & 15, g = lane >> 4;
+  const int G = gridDim.x;
+  int kchunk = (p.K + split - 1) / split;
+  kchunk = ((kchunk + BK - 1) / BK) * BK;
 
-  float4_t acc[4][NJ];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) acc[i][j] = float4_t{0.f, 0.f, 0.f, 0.f};
-
-  const int nfull = (k_end - k_begin) / BK;  // slabs served by LDS-DMA
-  const bool has_tail = (k_begin + nfull * BK) < k_end;
-
-  auto issue = [&](int slab, int stage) {
+  struct Tile { const bf16_t* A; const bf16_t* B; long doff; int m0, n0, k_begin, k_end, nfull, tail, ks; };
+  // XCD-aware tile order (hardware deals consecutive workgroup ids round-robin over the 8 XCDs, each with its own L2):
+  //  * plain / batched: in every round each XCD owns one contiguous run of the n-fastest tile sequence, so the n-tiles
+  //    sharing an A row-block hit the same L2 instead of fetching it over the fabric once per XCD;
+  //  * split-K with gz % 8 == 0 (weight gradients): a whole k-slice (all its M x N tiles re-read the same slabs) stays
+  //    on ONE XCD - 5x less HBM traffic measured on the joint weight gradient.
+  auto tile_of = [&](int it) {
+    Tile T;
+    T.nfull = -1;
+    const int tpp = gx * gy;
+    int tx, ty, tz;
+    if ((G & 7) == 0) {
+      const int x = blockIdx.x & 7, j = (blockIdx.x >> 3) + it * (G >> 3);
+      if (split > 1 && (gz & 7) == 0) {
+        if (j >= (gz >> 3) * tpp) return T;
+        tz = x + 8 * (j / tpp);
+        const int t = j % tpp;
+        tx = t % gx; ty = t / gx;
+      } else {
+        // round `it` covers tiles [it*G, (it+1)*G); XCD x takes the x-th eighth of it
+        const int t = it * G + x * (G >> 3) + (blockIdx.x >> 3);
+        if (t >= ntiles) return T;
+        tx = t % gx; const int rest = t / gx; ty = rest % gy; tz = rest / gy;
+      }
+    } else {  // G == ntiles (fewer tiles than resident slots): one round, ragged but bijective runs
+      if (it > 0) return T;
+      const int q = G >> 3, rem = G & 7, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+      const int t = G >= 16 ? (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + slot : (int)blockIdx.x;
+      tx = t % gx; const int rest = t / gx; ty = rest % gy; tz = rest / gy;
+    }
+    const int ks = tz % split, bidx = tz / split;
+    const int b1 = bidx / p.nb2, b2 = bidx % p.nb2;
+    T.A = (const bf16_t*)p.A + b1 * p.sA1 + b2 * p.sA2;
+    T.B = (const bf16_t*)p.B + b1 * p.sB1 + b2 * p.sB2;
+    T.doff = b1 * p.sD1 + b2 * p.sD2;
+    T.m0 = ty * BM;
+    T.n0 = tx * BN;
+    T.ks = ks;
+    T.k_begin = ks * kchunk;
+    T.k_end = min(p.K, T.k_begin + kchunk);
+    const int len = max(T.k_end - T.k_begin, 0);
+    T.nfull = len / BK;
+    T.tail = (len % BK) != 0;
+    return T;
+  };
+  auto issue = [&](const Tile& T, int slab, int stage) {
     char* sA = smem + stage * STAGE_BYTES;
     char* sB = sA + A_BYTES;
-    const int kt = k_begin + slab * BK;
-    if (TA) issue_trans<128>(sA, A, p.lda, m0, p.M, kt, w, lane); else issue_direct<128>(sA, A, p.lda, m0, p.M, kt, w, lane);
-    if (TB) issue_direct<BN_>(sB, Bm, p.ldb, n0, p.N, kt, w, lane); else issue_trans<BN_>(sB, Bm, p.ldb, n0, p.N, kt, w, lane);
+    const int kt = T.k_begin + slab * BK;
+    if (TA) issue_trans<128>(sA, T.A, p.lda, T.m0, p.M, kt, w, lane); else issue_direct<128>(sA, T.A, p.lda, T.m0, p.M, kt, w, lane);
+    if (TB) issue_direct<BN_>(sB, T.B, p.ldb, T.n0, p.N, kt, w, lane); else issue_trans<BN_>(sB, T.B, p.ldb, T.n0, p.N, kt, w, lane);
   };
 
-  if (nfull > 0) issue(0, 0);
-  for (int s = 0; s < nfull; ++s) {
-    const int stage = s & 1;
-    if (s + 1 < nfull) {
-      issue(s + 1, stage ^ 1);
-      // this wave's DMA pieces of slab s (4 for A + BN/32 for B) have landed; the next slab's stay in flight
-      if (BN_ == 128) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier();
-    mma_slab<TA, TB, BN_>(smem + stage * STAGE_BYTES, smem + stage * STAGE_BYTES + A_BYTES, wm, wn, lane, acc);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();  // every wave is done reading this stage before it is refilled
-  }
-  if (has_tail) {
-    char* sA = smem;
-    char* sB = smem + A_BYTES;
-    const int kt = k_begin + nfull * BK;
-    if (TA) tail_trans<128>(sA, A, p.lda, m0, p.M, kt, k_end); else tail_direct<128>(sA, A, p.lda, m0, p.M, kt, k_end);
-    if (TB) tail_direct<BN_>(sB, Bm, p.ldb, n0, p.N, kt, k_end); else tail_trans<BN_>(sB, Bm, p.ldb, n0, p.N, kt, k_end);
-    __syncthreads();
-    mma_slab<TA, TB, BN_>(sA, sB, wm, wn, lane, acc);
-  }
+  Tile cur = tile_of(0);
+  if (cur.nfull < 0) return;
+  if (cur.nfull > 0) issue(cur, 0, 0);
+  if (cur.nfull > 1) issue(cur, 1, 1);
+  bool drained = false;  // true after a tile boundary: slabs 0 and 1 of `cur` have landed
 
-  // ---- epilogue: C fragments -> per-wave LDS strip (16 rows x 64 cols f32) -> row-major, 16 columns per lane,
-  //      so bias / activation / residual / stores all move 16-32 B per lane on whole 128-B lines ----
-  __syncthreads();
-  const int r = lane & 15, g = lane >> 4;
-  const bool first_split = (ks == 0);
-  bf16_t* Dt = (bf16_t*)p.D + doff;
-  float* Df = (float*)p.D + doff;
-  const bf16_t* res = p.res ? (const bf16_t*)p.res + doff : nullptr;
-  const bf16_t* dz = p.dact_z ? (const bf16_t*)p.dact_z + doff : nullptr;
-  bf16_t* prez = p.prez ? (bf16_t*)p.prez + doff : nullptr;
-  if (p.accumulate) {
-    // split-K / gradient accumulation: f32 atomics straight from the MFMA fragment layout (16 consecutive
-    // columns x 4 rows per instruction = 4 cache lines), no other epilogue terms are legal here
+  for (int it = 0;; ++it) {
+#ifdef TFASR_GEMM_TIMING
+    const long long t_start = __builtin_readcyclecounter();
+#endif
+    float4_t acc[4][NJ];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        const int col = n0 + wn * WN + j * 16 + r;
+      for (int j = 0; j < NJ; ++j) acc[i][j] = float4_t{0.f, 0.f, 0.f, 0.f};
+
+    const int n = cur.nfull;
+#ifdef TFASR_GEMM_TIMING
+    long long ph[5] = {0, 0, 0, 0, 0};
+#define TFASR_TICK(k) { const long long t_ = __builtin_readcyclecounter(); ph[k] += t_ - tp; tp = t_; }
+#else
+#define TFASR_TICK(k)
+#endif
+    for (int s = 0; s < n; ++s) {
+      const int stage = s & 1;
+#ifdef TFASR_GEMM_TIMING
+      long long tp = __builtin_readcyclecounter();
+#endif
+      if (!(drained && s < 2)) {
+        // this wave's DMA pieces of slab s have landed; slab s+1 (when it exists) stays in flight
+        if (s + 1 < n) { if (GI == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      TFASR_TICK(0)
+      __builtin_amdgcn_s_barrier();
+      TFASR_TICK(1)
+      mma_slab<TA, TB, BN_>(smem + stage * STAGE_BYTES, smem + stage * STAGE_BYTES + A_BYTES, wm, wn, lane, acc);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      TFASR_TICK(2)
+      __builtin_amdgcn_s_barrier();  // every wave is done reading this stage before it is refilled
+      TFASR_TICK(3)
+      if (s + 2 < n) issue(cur, s + 2, stage);
+      TFASR_TICK(4)
+    }
+    if (cur.tail) {
+      char* sA = smem;
+      char* sB = smem + A_BYTES;
+      const int kt = cur.k_begin + n * BK;
+      if (TA) tail_trans<128>(sA, cur.A, p.lda, cur.m0, p.M, kt, cur.k_end); else tail_direct<128>(sA, cur.A, p.lda, cur.m0, p.M, kt, cur.k_end);
+      if (TB) tail_direct<BN_>(sB, cur.B, p.ldb, cur.n0, p.N, kt, cur.k_end); else tail_trans<BN_>(sB, cur.B, p.ldb, cur.n0, p.N, kt, cur.k_end);
+      __syncthreads();
+      mma_slab<TA, TB, BN_>(sA, sB, wm, wn, lane, acc);
+      __syncthreads();
+    }
+    // ---- cross-tile prefetch: both stages are idle now ----
+    const Tile nxt = tile_of(it + 1);
+    if (nxt.nfull > 0) issue(nxt, 0, 0);
+    if (nxt.nfull > 1) issue(nxt, 1, 1);
+#ifdef TFASR_GEMM_TIMING
+    const long long t_main = __builtin_readcyclecounter();
+#endif
+
+    // ---- epilogue ----
+    const int m0 = cur.m0, n0 = cur.n0;
+    const long doff = cur.doff;
+    const bool first_split = (cur.ks == 0);
+    bf16_t* Dt = (bf16_t*)p.D + doff;
+    float* Df = (float*)p.D + doff;
+    const bf16_t* res = p.res ? (const bf16_t*)p.res + doff : nullptr;
+    const bf16_t* dz = p.dact_z ? (const bf16_t*)p.dact_z + doff : nullptr;
+    bf16_t* prez = p.prez ? (bf16_t*)p.prez + doff : nullptr;
+    if (p.accumulate) {
+      // split-K / gradient accumulation: f32 atomics straight from the MFMA fragment layout (16 consecutive
+      // columns x 4 rows per instruction = 4 cache lines), no other epilogue terms are legal here
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int row = m0 + wm * 64 + i * 16 + g * 4 + e;
-          if (col < p.N && row < p.M) {
-            float v = p.alpha * acc[i][j][e];
-            if (p.bias && first_split) v += p.bias[col];
-            atomicAdd(Df + (long)row * p.ldd + col, v);
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          const int col = n0 + wn * WN + j * 16 + r;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int row = m0 + wm * 64 + i * 16 + g * 4 + e;
+            if (col < p.N && row < p.M) {
+              float v = p.alpha * acc[i][j][e];
+              if (p.bias && first_split) v += p.bias[col];
+              atomicAdd(Df + (long)row * p.ldd + col, v);
+            }
           }
         }
-      }
-    return;
-  }
-  constexpr int SLD = WN + 4;
-  constexpr int CPL = WN / 4;  // columns per lane on the way out: 16 (BN 128) or 8 (BN 64)
-  float* sc = reinterpret_cast<float*>(smem) + w * (16 * SLD);
-  const int rr = lane >> 2, cseg = (lane & 3) * CPL;
-  const bool vec_ok = ((p.ldd & 7) == 0) && ((((uintptr_t)p.D) & 15) == 0) && ((doff & 7) == 0);
-  // bias for this lane's CPL columns (the same in all four strips)
-  float bv[16];
+    } else {
+      // Each wave turns its 16 x WN fragment strip into row-major order through LDS (RPP rows at a time), then every store /
+      // load instruction of the epilogue covers WHOLE rows: 8 lanes x 16 B = one 128-B line per row (BN 128), so HBM sees
+      // full lines (16-B pieces at a 32-B stride cost ~5000 extra cycles per tile in store-issue stalls).
+      constexpr int SLD = WN + 4;
+      constexpr int LPRW = WN / 8;        // lanes per strip row: 8 (BN 128) or 4 (BN 64), 8 columns each
+      constexpr int RPP = 64 / LPRW;      // rows per pass: 8 or 16
+      constexpr int NPASS = 16 / RPP;     // 2 or 1
+      float* sc = reinterpret_cast<float*>(smem + 2 * STAGE_BYTES) + w * (RPP * SLD);
+      const int prow = lane / LPRW, c8 = (lane % LPRW) * 8;
+      const int col0 = n0 + wn * WN + c8;
+      const bool vec_ok = ((p.ldd & 7) == 0) && ((((uintptr_t)p.D) & 15) == 0) && ((doff & 7) == 0);
+      const bool full = vec_ok && (col0 + 8 <= p.N);
+      float bv[8];
 #pragma unroll
-  for (int q = 0; q < 16; ++q) bv[q] = 0.f;
-  {
-    const int col0 = n0 + wn * WN + cseg;
-    if (p.bias && first_split && col0 < p.N) {
-      const float* bp = p.bias + col0;
-      if (col0 + CPL <= p.N && ((((uintptr_t)bp) & 15) == 0)) {
+      for (int q = 0; q < 8; ++q) bv[q] = 0.f;
+      if (p.bias && first_split && col0 < p.N) {
+        const float* bp = p.bias + col0;
+        if (col0 + 8 <= p.N && ((((uintptr_t)bp) & 15) == 0)) {
+          const float4 t0 = *reinterpret_cast<const float4*>(bp), t1 = *reinterpret_cast<const float4*>(bp + 4);
+          bv[0] = t0.x; bv[1] = t0.y; bv[2] = t0.z; bv[3] = t0.w; bv[4] = t1.x; bv[5] = t1.y; bv[6] = t1.z; bv[7] = t1.w;
+        } else {
 #pragma unroll
-        for (int q = 0; q < CPL / 4; ++q) {
-          const float4 t = *reinterpret_cast<const float4*>(bp + q * 4);
-          bv[q * 4] = t.x; bv[q * 4 + 1] = t.y; bv[q * 4 + 2] = t.z; bv[q * 4 + 3] = t.w;
+          for (int q = 0; q < 8; ++q) if (col0 + q < p.N) bv[q] = bp[q];
         }
-      } else {
-#pragma unroll
-        for (int q = 0; q < CPL; ++q) if (col0 + q < p.N) bv[q] = bp[q];
       }
-    }
-  }
-  const uint32_t dthr = drop_thr(p.drop_p);
-  auto strip = [&](auto I_) {
-    constexpr int i = decltype(I_)::value;
+      const uint32_t dthr = drop_thr(p.drop_p);
+      const float dinv = p.drop_p > 0.f ? 1.f / (1.f - p.drop_p) : 1.f;
+      auto strip = [&](auto I_, auto H_) {
+        constexpr int i = decltype(I_)::value, h = decltype(H_)::value;
+        if ((g * 4) / RPP == h) {
 #pragma unroll
-    for (int j = 0; j < NJ; ++j)
+          for (int j = 0; j < NJ; ++j)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) sc[(g * 4 + e) * SLD + j * 16 + r] = acc[i][j][e];
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    const int row = m0 + wm * 64 + i * 16 + rr;
-    const int col0 = n0 + wn * WN + cseg;
-    float v[16];
+            for (int e = 0; e < 4; ++e) sc[(g * 4 + e - h * RPP) * SLD + j * 16 + r] = acc[i][j][e];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        float x[8];
+        {
+          const float4 t0 = *reinterpret_cast<const float4*>(sc + prow * SLD + c8);
+          const float4 t1 = *reinterpret_cast<const float4*>(sc + prow * SLD + c8 + 4);
+          x[0] = t0.x; x[1] = t0.y; x[2] = t0.z; x[3] = t0.w; x[4] = t1.x; x[5] = t1.y; x[6] = t1.z; x[7] = t1.w;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const int row = m0 + wm * 64 + i * 16 + h * RPP + prow;
+        if (row < p.M && col0 < p.N) {
+          const long idx0 = (long)row * p.ldd + col0;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) v[q] = 0.f;  // (array stays 16 wide; CPL of it are live)
-#pragma unroll
-    for (int q = 0; q < CPL / 4; ++q) {
-      const float4 t = *reinterpret_cast<const float4*>(sc + rr * SLD + cseg + q * 4);
-      v[q * 4] = t.x; v[q * 4 + 1] = t.y; v[q * 4 + 2] = t.z; v[q * 4 + 3] = t.w;
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (row < p.M && col0 < p.N) {
-      const long idx0 = (long)row * p.ldd + col0;
-      const bool full = vec_ok && (col0 + CPL <= p.N);
-#pragma unroll
-      for (int q = 0; q < CPL; ++q) v[q] = p.alpha * v[q] + bv[q];
-      if (prez) {
-        if (full) { st8(prez + idx0, *reinterpret_cast<const float(*)[8]>(v)); if (CPL == 16) st8(prez + idx0 + 8, *reinterpret_cast<const float(*)[8]>(v + 8)); }
-        else
+          for (int q = 0; q < 8; ++q) x[q] = p.alpha * x[q] + bv[q];
+          if constexpr (C_ACT) {
+            if (prez) {
+              if (full) st8(prez + idx0, x);
+              else
 _Pragma("unroll")
-          for (int q = 0; q < CPL; ++q) if (col0 + q < p.N) prez[idx0 + q] = f32_to_bf16(v[q]);
-      }
-      if (p.act != TFASR_ACT_NONE) {
+                for (int q = 0; q < 8; ++q) if (col0 + q < p.N) prez[idx0 + q] = f32_to_bf16(x[q]);
+            }
+            if constexpr (GEN) {
+              if (p.act != TFASR_ACT_NONE) {
 #pragma unroll
-        for (int q = 0; q < CPL; ++q) v[q] = act_f(v[q], p.act);
-      }
-      if (dz) {
-        float z[16];
-        if (full) { ld8(dz + idx0, *reinterpret_cast<float(*)[8]>(z)); if (CPL == 16) ld8(dz + idx0 + 8, *reinterpret_cast<float(*)[8]>(z + 8)); }
-        else
-_Pragma("unroll")
-          for (int q = 0; q < CPL; ++q) z[q] = (col0 + q < p.N) ? bf16_to_f32(dz[idx0 + q]) : 0.f;
+                for (int q = 0; q < 8; ++q) x[q] = act_f(x[q], p.act);
+              }
+            } else {
 #pragma unroll
-        for (int q = 0; q < CPL; ++q) v[q] *= dact_f(z[q], p.dact);
-      }
-      if (p.drop_p > 0.f) {
-        const float inv = 1.f / (1.f - p.drop_p);
-        const uint64_t e0 = (uint64_t)(doff + idx0);
-        if ((e0 & 1) == 0) {  // one hash per even/odd element pair
-#pragma unroll
-          for (int q = 0; q < CPL; q += 2) {
-            const uint32_t h = drop_hash((uint64_t)p.drop_seed, (e0 >> 1) + (q >> 1));
-            v[q] = (h & 0xffffu) >= dthr ? v[q] * inv : 0.f;
-            v[q + 1] = (h >> 16) >= dthr ? v[q + 1] * inv : 0.f;
+              for (int q = 0; q < 8; ++q) x[q] = swishf_(x[q]);
+            }
           }
-        } else {
+          if constexpr (C_DACT) if (dz) {
+            float z[8];
+            if (full) ld8(dz + idx0, z);
+            else
+_Pragma("unroll")
+              for (int q = 0; q < 8; ++q) z[q] = (col0 + q < p.N) ? bf16_to_f32(dz[idx0 + q]) : 0.f;
 #pragma unroll
-          for (int q = 0; q < CPL; ++q) v[q] = drop_keep((uint64_t)p.drop_seed, e0 + q, p.drop_p) ? v[q] * inv : 0.f;
+            for (int q = 0; q < 8; ++q) x[q] *= GEN ? dact_f(z[q], p.dact) : dswishf_(z[q]);
+          }
+          if constexpr (C_DROP) if (p.drop_p > 0.f) {
+            const uint64_t e0 = (uint64_t)(doff + idx0);
+            if ((e0 & 1) == 0) {  // one hash per even/odd element pair
+#pragma unroll
+              for (int q = 0; q < 8; q += 2) {
+                const uint32_t hh = drop_hash((uint64_t)p.drop_seed, (e0 >> 1) + (q >> 1));
+                x[q] = (hh & 0xffffu) >= dthr ? x[q] * dinv : 0.f;
+                x[q + 1] = (hh >> 16) >= dthr ? x[q + 1] * dinv : 0.f;
+              }
+            } else {
+#pragma unroll
+              for (int q = 0; q < 8; ++q) x[q] = drop_keep((uint64_t)p.drop_seed, e0 + q, p.drop_p) ? x[q] * dinv : 0.f;
+            }
+          }
+          if constexpr (C_RES) if (res) {
+            float z[8];
+            if (full) ld8(res + idx0, z);
+            else
+_Pragma("unroll")
+              for (int q = 0; q < 8; ++q) z[q] = (col0 + q < p.N) ? bf16_to_f32(res[idx0 + q]) : 0.f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) x[q] = z[q] + p.beta * x[q];
+          }
+          if (GEN && p.out_f32) {
+            if (full) st8(Df + idx0, x);
+            else
+_Pragma("unroll")
+              for (int q = 0; q < 8; ++q) if (col0 + q < p.N) Df[idx0 + q] = x[q];
+          } else {
+            if (full) st8(Dt + idx0, x);
+            else
+_Pragma("unroll")
+              for (int q = 0; q < 8; ++q) if (col0 + q < p.N) Dt[idx0 + q] = f32_to_bf16(x[q]);
+          }
         }
-      }
-      if (res) {
-        float z[16];
-        if (full) { ld8(res + idx0, *reinterpret_cast<float(*)[8]>(z)); if (CPL == 16) ld8(res + idx0 + 8, *reinterpret_cast<float(*)[8]>(z + 8)); }
-        else
-_Pragma("unroll")
-          for (int q = 0; q < CPL; ++q) z[q] = (col0 + q < p.N) ? bf16_to_f32(res[idx0 + q]) : 0.f;
-#pragma unroll
-        for (int q = 0; q < CPL; ++q) v[q] = z[q] + p.beta * v[q];
-      }
-      if (p.out_f32) {
-        if (p.accumulate) {
-#pragma unroll
-          for (int q = 0; q < CPL; ++q) if (col0 + q < p.N) atomicAdd(Df + idx0 + q, v[q]);
-        } else if (full) {
-          st8(Df + idx0, *reinterpret_cast<const float(*)[8]>(v)); if (CPL == 16) st8(Df + idx0 + 8, *reinterpret_cast<const float(*)[8]>(v + 8));
-        } else {
-_Pragma("unroll")
-          for (int q = 0; q < CPL; ++q) if (col0 + q < p.N) Df[idx0 + q] = v[q];
-        }
-      } else {
-        if (full) { st8(Dt + idx0, *reinterpret_cast<const float(*)[8]>(v)); if (CPL == 16) st8(Dt + idx0 + 8, *reinterpret_cast<const float(*)[8]>(v + 8)); }
-        else
-_Pragma("unroll")
-          for (int q = 0; q < CPL; ++q) if (col0 + q < p.N) Dt[idx0 + q] = f32_to_bf16(v[q]);
-      }
+      };
+      auto strips = [&](auto I_) {
+        strip(I_, std::integral_constant<int, 0>{});
+        if constexpr (NPASS == 2) strip(I_, std::integral_constant<int, 1>{});
+      };
+      strips(std::integral_constant<int, 0>{});
+      strips(std::integral_constant<int, 1>{});
+      strips(std::integral_constant<int, 2>{});
+      strips(std::integral_constant<int, 3>{});
     }
-  };
-  strip(std::integral_constant<int, 0>{});
-  strip(std::integral_constant<int, 1>{});
-  strip(std::integral_constant<int, 2>{});
-  strip(std::integral_constant<int, 3>{});
+#ifdef TFASR_GEMM_TIMING
+    if (threadIdx.x == 0 && it == 0) {
+      const long long t_end = __builtin_readcyclecounter();
+      long long* o = g_gemm_timing + 4L * blockIdx.x;
+      o[0] = t_start; o[1] = 0; o[2] = t_main - t_start; o[3] = t_end - t_start;
+    }
+    if (threadIdx.x == 0 && it == 1) {
+      const long long t_end = __builtin_readcyclecounter();
+      long long* o = g_gemm_timing + 4L * 32768 + 2L * blockIdx.x;
+      o[0] = t_main - t_start; o[1] = t_end - t_start;
+    }
+    if (threadIdx.x == 0 && it == 0) {
+      long long* o = g_gemm_timing + 6L * 32768 + 5L * blockIdx.x;
+      for (int k = 0; k < 5; ++k) o[k] = ph[k];
+    }
+#endif
+    if (nxt.nfull < 0) break;
+    // tile boundary: the epilogue's stores / loads are mixed into the vector-memory queue, so counted waits are void until
+    // it drains once (the prefetched slabs had the whole epilogue to land)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    drained = true;
+    cur = nxt;
+  }
+}
+
+int num_cus() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v;
+    else n = 256;
+  }
+  return n;
+}
+
+template <bool TA, bool TB, int BN_, int EPI>
+int launch_epi(const tfasr_gemm_args& a, dim3 tiles, hipStream_t stream) {
+  const long ntiles = (long)tiles.x * tiles.y * tiles.z;
+  const int slots = 2 * num_cus();  // 2 resident workgroups per CU
+  int G = (int)(ntiles < slots ? ntiles : slots);
+  if (ntiles >= slots) G &= ~7;
+  constexpr int SMEM = 2 * (A_BYTES + BN_ * BK * 2) + 4 * (64 / (BN_ / 16)) * (BN_ / 2 + 4) * 4;  // stages + 4 waves' strips
+  hipLaunchKernelGGL((gemm_fast_kernel<TA, TB, BN_, EPI>), dim3(G), dim3(256), SMEM, stream, a, (int)tiles.x, (int)tiles.y, (int)tiles.z, (int)ntiles);
+  TFASR_CHECK_LAUNCH();
+  return TFASR_STATUS_SUCCESS;
 }
 
 template <bool TA, bool TB>
@@ -391,11 +504,32 @@ int launch_one(const tfasr_gemm_args& a, hipStream_t stream) {
   const bool narrow = a.N <= 64;  // per-head attention products etc.: halve the wasted B tile
   const int bn = narrow ? 64 : 128;
   dim3 grid((a.N + bn - 1) / bn, (a.M + BM - 1) / BM, a.nb1 * a.nb2 * split);
-  if (grid.y > 65535 || grid.z > 65535) return TFASR_STATUS_INVALID_VALUE;
-  if (narrow) hipLaunchKernelGGL((gemm_fast_kernel<TA, TB, 64>), grid, dim3(256), 2 * (A_BYTES + 64 * BK * 2), stream, a);
-  else        hipLaunchKernelGGL((gemm_fast_kernel<TA, TB, 128>), grid, dim3(256), 2 * (A_BYTES + 128 * BK * 2), stream, a);
-  TFASR_CHECK_LAUNCH();
-  return TFASR_STATUS_SUCCESS;
+  if ((long)grid.x * grid.y * grid.z > 0x7fffffffL) return TFASR_STATUS_INVALID_VALUE;
+  // epilogue terms this call needs; accumulate (atomics from fragments) needs none of them
+  int need = 0;
+  bool generic = false;
+  if (!a.accumulate) {
+    if (a.out_f32) generic = true;
+    if (a.act != TFASR_ACT_NONE || a.prez) { if (a.act == TFASR_ACT_SWISH) need |= E_ACT; else generic = true; }
+    if (a.dact_z) { if (a.dact == TFASR_ACT_SWISH) need |= E_DACT; else generic = true; }
+    if (a.drop_p > 0.f) need |= E_DROP;
+    if (a.res) need |= E_RES;
+  }
+  if (narrow) return generic || need ? launch_epi<TA, TB, 64, E_GEN>(a, grid, stream) : launch_epi<TA, TB, 64, 0>(a, grid, stream);
+  if (!generic) {
+    if (need == 0) return launch_epi<TA, TB, 128, 0>(a, grid, stream);
+    if constexpr (!TA && !TB) {  // forward Dense layers
+      if (need == E_RES) return launch_epi<TA, TB, 128, E_RES>(a, grid, stream);
+      if (need == (E_RES | E_DROP)) return launch_epi<TA, TB, 128, E_RES | E_DROP>(a, grid, stream);
+      if (need == E_ACT) return launch_epi<TA, TB, 128, E_ACT>(a, grid, stream);
+      if (need == (E_ACT | E_DROP)) return launch_epi<TA, TB, 128, E_ACT | E_DROP>(a, grid, stream);
+    }
+    if constexpr (!TA && TB) {  // data gradients (dy @ W^T)
+      if (need == E_DACT) return launch_epi<TA, TB, 128, E_DACT>(a, grid, stream);
+      if (need == (E_DACT | E_DROP)) return launch_epi<TA, TB, 128, E_DACT | E_DROP>(a, grid, stream);
+    }
+  }
+  return launch_epi<TA, TB, 128, E_GEN>(a, grid, stream);
 }
 
 inline bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
