@@ -7,7 +7,9 @@
 //   Workgroups are persistent: 2 per CU, each walks a strided list of tiles; the next tile's first three slabs are
 //   issued BEFORE the current tile's epilogue, so the epilogue (bias / activation / dropout / residual / stores) runs
 //   under the DMA latency instead of in front of it, and the pipeline never drains between tiles.
-//   The epilogue's fragment -> row-major transpose strip lives in the one stage no DMA is aimed at.
+//   The DMA instructions of slab i+3 are issued BETWEEN the fragment reads and the MFMAs of slab i: measured with cycle
+//   counters on gemm_fast.hip, issuing a slab's 8 global_load_lds per wave costs ~900 cycles of issue stall - more than
+//   the slab's MFMAs - when it sits in its own phase.
 //   Tile order is XCD-aware: in every round each XCD (workgroup id mod 8) owns one contiguous run of the n-fastest tile
 //   sequence, so the n-tiles sharing an A row-block hit the same L2.
 //   LDS images (bank-conflict free, swizzle applied on the DMA source address, undone on the fragment read):
@@ -105,8 +107,8 @@ __device__ __forceinline__ short8_t frag_trans(const char* s, int rowbase, int k
   return v;
 }
 
-template <bool TA, bool TB, int BN_>
-__device__ __forceinline__ void mma_slab(const char* sA, const char* sB, int wm, int wn, int lane, float4_t (&acc)[4][BN_ / 32]) {
+template <bool TA, bool TB, int BN_, typename F>
+__device__ __forceinline__ void mma_slab(const char* sA, const char* sB, int wm, int wn, int lane, float4_t (&acc)[4][BN_ / 32], F&& between) {
   constexpr int NJ = BN_ / 32, WN = BN_ / 2;
   const int r = lane & 15, g = lane >> 4;
   short8_t a[4], b[NJ];
@@ -120,6 +122,9 @@ __device__ __forceinline__ void mma_slab(const char* sA, const char* sB, int wm,
     if (TB) b[j] = frag_direct(sB, wn * WN + j * 16 + r, g);
     else    b[j] = frag_trans<BN_>(sB, wn * WN + j * 16, g * 8, r);
   }
+  __builtin_amdgcn_sched_barrier(0);
+  between();  // the next slab's DMA issue rides under the LDS latency of the fragment reads
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -143,6 +148,9 @@ __device__ __forceinline__ float dact_f(float z, int act) {
   }
 }
 
+enum : int { E_ACT = 1 /* swish(+prez) */, E_DACT = 2 /* * swish'(dact_z) */, E_DROP = 4, E_RES = 8, E_GEN = 256 };
+
+
 // wait until at most `groups` DMA groups (GI wave-instructions each) are still in flight
 template <int GI>
 __device__ __forceinline__ void wait_groups(int groups) {
@@ -155,37 +163,53 @@ __device__ __forceinline__ void wait_groups(int groups) {
   }
 }
 
-template <bool TA, bool TB, int BN_>
-__global__ __launch_bounds__(256, 2) void gemm_pipe_kernel(const tfasr_gemm_args p, const int gx, const int gy, const int ntiles) {
+template <bool TA, bool TB, int BN_, int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_pipe_kernel(const tfasr_gemm_args p, const int gx, const int gy, const int gz, const int ntiles) {
+  constexpr bool GEN = (EPI & E_GEN) != 0;
+  constexpr bool C_ACT = GEN || (EPI & E_ACT), C_DACT = GEN || (EPI & E_DACT), C_DROP = GEN || (EPI & E_DROP), C_RES = GEN || (EPI & E_RES);
   constexpr int BN = BN_, NJ = BN_ / 32, WN = BN_ / 2;
   constexpr int B_BYTES = BN_ * BK * 2;
   constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
   constexpr int GI = 2 + BN_ / 64;  // DMA wave-instructions per slab per wave
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // NST stages
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // NST stages + epilogue strips
   const int split = p.split_k > 1 ? p.split_k : 1;
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = w >> 1, wn = w & 1;
   const int r = lane & 15, g = lane >> 4;
-  const int G = gridDim.x;  // multiple of 8 (or == ntiles when small)
-
+  const int G = gridDim.x;
   int kchunk = (p.K + split - 1) / split;
   kchunk = ((kchunk + BK - 1) / BK) * BK;
 
   struct Tile { const bf16_t* A; const bf16_t* B; long doff; int m0, n0, k_begin, k_end, nfull, tail, ks; };
+  // XCD-aware tile order (hardware deals consecutive workgroup ids round-robin over the 8 XCDs, each with its own L2):
+  //  * plain / batched: in every round each XCD owns one contiguous run of the n-fastest tile sequence, so the n-tiles
+  //    sharing an A row-block hit the same L2 instead of fetching it over the fabric once per XCD;
+  //  * split-K with gz % 8 == 0 (weight gradients): a whole k-slice (all its M x N tiles re-read the same slabs) stays
+  //    on ONE XCD - 5x less HBM traffic measured on the joint weight gradient.
   auto tile_of = [&](int it) {
-    // round `it`: XCD x (= blockIdx.x & 7) owns tiles [it*G + x*G/8, it*G + (x+1)*G/8) of the n-fastest sequence
-    int t;
-    if ((G & 7) == 0) {
-      t = it * G + (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
-    } else {  // single round (G == ntiles): same idea with ragged run lengths (bijective)
-      const int q = G >> 3, rem = G & 7, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-      t = it * G + (G >= 16 ? (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + slot : (int)blockIdx.x);
-    }
     Tile T;
     T.nfull = -1;
-    if (t >= ntiles) return T;
-    const int tx = t % gx, rest = t / gx;
-    const int ty = rest % gy, tz = rest / gy;
+    const int tpp = gx * gy;
+    int tx, ty, tz;
+    if ((G & 7) == 0) {
+      const int x = blockIdx.x & 7, j = (blockIdx.x >> 3) + it * (G >> 3);
+      if (split > 1 && (gz & 7) == 0) {
+        if (j >= (gz >> 3) * tpp) return T;
+        tz = x + 8 * (j / tpp);
+        const int t = j % tpp;
+        tx = t % gx; ty = t / gx;
+      } else {
+        // round `it` covers tiles [it*G, (it+1)*G); XCD x takes the x-th eighth of it
+        const int t = it * G + x * (G >> 3) + (blockIdx.x >> 3);
+        if (t >= ntiles) return T;
+        tx = t % gx; const int rest = t / gx; ty = rest % gy; tz = rest / gy;
+      }
+    } else {  // G == ntiles (fewer tiles than resident slots): one round, ragged but bijective runs
+      if (it > 0) return T;
+      const int q = G >> 3, rem = G & 7, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+      const int t = G >= 16 ? (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + slot : (int)blockIdx.x;
+      tx = t % gx; const int rest = t / gx; ty = rest % gy; tz = rest / gy;
+    }
     const int ks = tz % split, bidx = tz / split;
     const int b1 = bidx / p.nb2, b2 = bidx % p.nb2;
     T.A = (const bf16_t*)p.A + b1 * p.sA1 + b2 * p.sA2;
@@ -229,10 +253,9 @@ __global__ __launch_bounds__(256, 2) void gemm_pipe_kernel(const tfasr_gemm_args
     for (int i = 0; i < n; ++i) {
       // slab i landed?  groups issued after it so far: slabs i+1, i+2 (when they exist)
       if (!drained || i >= NST - 1) wait_groups<GI>(min(2, n - 1 - i));
-      __builtin_amdgcn_s_barrier();  // slab i visible to all waves; all waves finished slab i-1
-      if (i + NST - 1 < n) issue(cur, i + NST - 1, ring + i + NST - 1);
+      __builtin_amdgcn_s_barrier();  // slab i visible to all waves; all waves finished slab i-1 (whose stage slab i+3 reuses)
       const char* st = smem + ((ring + i) & (NST - 1)) * STAGE_BYTES;
-      mma_slab<TA, TB, BN_>(st, st + A_BYTES, wm, wn, lane, acc);
+      mma_slab<TA, TB, BN_>(st, st + A_BYTES, wm, wn, lane, acc, [&] { if (i + NST - 1 < n) issue(cur, i + NST - 1, ring + i + NST - 1); });
     }
     int used = n;
     if (cur.tail) {
@@ -244,29 +267,31 @@ __global__ __launch_bounds__(256, 2) void gemm_pipe_kernel(const tfasr_gemm_args
       if (TA) tail_trans<128>(sA, cur.A, p.lda, cur.m0, p.M, kt, cur.k_end); else tail_direct<128>(sA, cur.A, p.lda, cur.m0, p.M, kt, cur.k_end);
       if (TB) tail_direct<BN_>(sB, cur.B, p.ldb, cur.n0, p.N, kt, cur.k_end); else tail_trans<BN_>(sB, cur.B, p.ldb, cur.n0, p.N, kt, cur.k_end);
       __syncthreads();
-      mma_slab<TA, TB, BN_>(sA, sB, wm, wn, lane, acc);
+      mma_slab<TA, TB, BN_>(sA, sB, wm, wn, lane, acc, [] {});
       used = n + 1;
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // every wave is done with this tile's last stages
     ring += used;
     // ---- cross-tile prefetch: the next tile's first slabs go out before this tile's epilogue ----
-    Tile nxt = tile_of(it + 1);
-    const int pre = nxt.nfull > 0 ? min(nxt.nfull, NST - 1) : 0;
-    for (int i = 0; i < pre; ++i) issue(nxt, i, ring + i);
-    char* strip_base = smem + ((ring + NST - 1) & (NST - 1)) * STAGE_BYTES;  // the one stage no DMA is aimed at
+    const Tile nxt = tile_of(it + 1);
+    {
+      const int pre = nxt.nfull > 0 ? min(nxt.nfull, NST - 1) : 0;
+      for (int i = 0; i < pre; ++i) issue(nxt, i, ring + i);
+    }
 
     // ---- epilogue ----
-    const bool first_split = (cur.ks == 0);
     const int m0 = cur.m0, n0 = cur.n0;
     const long doff = cur.doff;
+    const bool first_split = (cur.ks == 0);
     bf16_t* Dt = (bf16_t*)p.D + doff;
     float* Df = (float*)p.D + doff;
     const bf16_t* res = p.res ? (const bf16_t*)p.res + doff : nullptr;
     const bf16_t* dz = p.dact_z ? (const bf16_t*)p.dact_z + doff : nullptr;
     bf16_t* prez = p.prez ? (bf16_t*)p.prez + doff : nullptr;
     if (p.accumulate) {
-      // split-K / gradient accumulation: f32 atomics straight from the MFMA fragment layout
+      // split-K / gradient accumulation: f32 atomics straight from the MFMA fragment layout (16 consecutive
+      // columns x 4 rows per instruction = 4 cache lines), no other epilogue terms are legal here
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -283,120 +308,124 @@ __global__ __launch_bounds__(256, 2) void gemm_pipe_kernel(const tfasr_gemm_args
           }
         }
     } else {
-      constexpr int CPL = WN / 4;  // columns per lane on the way out: 16 (BN 128) or 8 (BN 64)
-      float* sc = reinterpret_cast<float*>(strip_base) + w * (16 * WN);
-      const int rr = lane >> 2, cseg = (lane & 3) * CPL;
+      // Each wave turns its 16 x WN fragment strip into row-major order through LDS (RPP rows at a time), then every store /
+      // load instruction of the epilogue covers WHOLE rows: 8 lanes x 16 B = one 128-B line per row (BN 128), so HBM sees
+      // full lines (16-B pieces at a 32-B stride cost ~5000 extra cycles per tile in store-issue stalls).
+      constexpr int SLD = WN + 4;
+      constexpr int LPRW = WN / 8;        // lanes per strip row: 8 (BN 128) or 4 (BN 64), 8 columns each
+      constexpr int RPP = 64 / LPRW;      // rows per pass: 8 or 16
+      constexpr int NPASS = 16 / RPP;     // 2 or 1
+      float* sc = reinterpret_cast<float*>(smem + NST * STAGE_BYTES) + w * (RPP * SLD);
+      const int prow = lane / LPRW, c8 = (lane % LPRW) * 8;
+      const int col0 = n0 + wn * WN + c8;
       const bool vec_ok = ((p.ldd & 7) == 0) && ((((uintptr_t)p.D) & 15) == 0) && ((doff & 7) == 0);
-      float bv[16];
+      const bool full = vec_ok && (col0 + 8 <= p.N);
+      float bv[8];
 #pragma unroll
-      for (int q = 0; q < 16; ++q) bv[q] = 0.f;
-      {
-        const int col0 = n0 + wn * WN + cseg;
-        if (p.bias && first_split && col0 < p.N) {
-          const float* bp = p.bias + col0;
-          if (col0 + CPL <= p.N && ((((uintptr_t)bp) & 15) == 0)) {
+      for (int q = 0; q < 8; ++q) bv[q] = 0.f;
+      if (p.bias && first_split && col0 < p.N) {
+        const float* bp = p.bias + col0;
+        if (col0 + 8 <= p.N && ((((uintptr_t)bp) & 15) == 0)) {
+          const float4 t0 = *reinterpret_cast<const float4*>(bp), t1 = *reinterpret_cast<const float4*>(bp + 4);
+          bv[0] = t0.x; bv[1] = t0.y; bv[2] = t0.z; bv[3] = t0.w; bv[4] = t1.x; bv[5] = t1.y; bv[6] = t1.z; bv[7] = t1.w;
+        } else {
 #pragma unroll
-            for (int q = 0; q < CPL / 4; ++q) {
-              const float4 t = *reinterpret_cast<const float4*>(bp + q * 4);
-              bv[q * 4] = t.x; bv[q * 4 + 1] = t.y; bv[q * 4 + 2] = t.z; bv[q * 4 + 3] = t.w;
-            }
-          } else {
-#pragma unroll
-            for (int q = 0; q < CPL; ++q) if (col0 + q < p.N) bv[q] = bp[q];
-          }
+          for (int q = 0; q < 8; ++q) if (col0 + q < p.N) bv[q] = bp[q];
         }
       }
       const uint32_t dthr = drop_thr(p.drop_p);
-      auto strip = [&](auto I_) {
-        constexpr int i = decltype(I_)::value;
-        // fragment (row g*4+e, col j*16+r) -> strip[row][(col + 4*row) mod WN]: the rotation makes both the scattered
-        // writes and the row-major float4 reads bank-conflict free without padding
+      const float dinv = p.drop_p > 0.f ? 1.f / (1.f - p.drop_p) : 1.f;
+      auto strip = [&](auto I_, auto H_) {
+        constexpr int i = decltype(I_)::value, h = decltype(H_)::value;
+        if ((g * 4) / RPP == h) {
 #pragma unroll
-        for (int j = 0; j < NJ; ++j)
+          for (int j = 0; j < NJ; ++j)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int row = g * 4 + e;
-            sc[row * WN + ((j * 16 + r + 4 * row) & (WN - 1))] = acc[i][j][e];
-          }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        const int row = m0 + wm * 64 + i * 16 + rr;
-        const int col0 = n0 + wn * WN + cseg;
-        float v[16];
-#pragma unroll
-        for (int q = 0; q < 16; ++q) v[q] = 0.f;
-#pragma unroll
-        for (int q = 0; q < CPL / 4; ++q) {
-          const float4 t = *reinterpret_cast<const float4*>(sc + rr * WN + ((cseg + q * 4 + 4 * rr) & (WN - 1)));
-          v[q * 4] = t.x; v[q * 4 + 1] = t.y; v[q * 4 + 2] = t.z; v[q * 4 + 3] = t.w;
+            for (int e = 0; e < 4; ++e) sc[(g * 4 + e - h * RPP) * SLD + j * 16 + r] = acc[i][j][e];
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        float x[8];
+        {
+          const float4 t0 = *reinterpret_cast<const float4*>(sc + prow * SLD + c8);
+          const float4 t1 = *reinterpret_cast<const float4*>(sc + prow * SLD + c8 + 4);
+          x[0] = t0.x; x[1] = t0.y; x[2] = t0.z; x[3] = t0.w; x[4] = t1.x; x[5] = t1.y; x[6] = t1.z; x[7] = t1.w;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const int row = m0 + wm * 64 + i * 16 + h * RPP + prow;
         if (row < p.M && col0 < p.N) {
           const long idx0 = (long)row * p.ldd + col0;
-          const bool full = vec_ok && (col0 + CPL <= p.N);
 #pragma unroll
-          for (int q = 0; q < CPL; ++q) v[q] = p.alpha * v[q] + bv[q];
-          if (prez) {
-            if (full) { st8(prez + idx0, *reinterpret_cast<const float(*)[8]>(v)); if (CPL == 16) st8(prez + idx0 + 8, *reinterpret_cast<const float(*)[8]>(v + 8)); }
-            else
+          for (int q = 0; q < 8; ++q) x[q] = p.alpha * x[q] + bv[q];
+          if constexpr (C_ACT) {
+            if (prez) {
+              if (full) st8(prez + idx0, x);
+              else
 _Pragma("unroll")
-              for (int q = 0; q < CPL; ++q) if (col0 + q < p.N) prez[idx0 + q] = f32_to_bf16(v[q]);
-          }
-          if (p.act != TFASR_ACT_NONE) {
+                for (int q = 0; q < 8; ++q) if (col0 + q < p.N) prez[idx0 + q] = f32_to_bf16(x[q]);
+            }
+            if constexpr (GEN) {
+              if (p.act != TFASR_ACT_NONE) {
 #pragma unroll
-            for (int q = 0; q < CPL; ++q) v[q] = act_f(v[q], p.act);
-          }
-          if (dz) {
-            float z[16];
-            if (full) { ld8(dz + idx0, *reinterpret_cast<float(*)[8]>(z)); if (CPL == 16) ld8(dz + idx0 + 8, *reinterpret_cast<float(*)[8]>(z + 8)); }
-            else
-_Pragma("unroll")
-              for (int q = 0; q < CPL; ++q) z[q] = (col0 + q < p.N) ? bf16_to_f32(dz[idx0 + q]) : 0.f;
-#pragma unroll
-            for (int q = 0; q < CPL; ++q) v[q] *= dact_f(z[q], p.dact);
-          }
-          if (p.drop_p > 0.f) {
-            const float inv = 1.f / (1.f - p.drop_p);
-            const uint64_t e0 = (uint64_t)(doff + idx0);
-            if ((e0 & 1) == 0) {  // one hash per even/odd element pair
-#pragma unroll
-              for (int q = 0; q < CPL; q += 2) {
-                const uint32_t h = drop_hash((uint64_t)p.drop_seed, (e0 >> 1) + (q >> 1));
-                v[q] = (h & 0xffffu) >= dthr ? v[q] * inv : 0.f;
-                v[q + 1] = (h >> 16) >= dthr ? v[q + 1] * inv : 0.f;
+                for (int q = 0; q < 8; ++q) x[q] = act_f(x[q], p.act);
               }
             } else {
 #pragma unroll
-              for (int q = 0; q < CPL; ++q) v[q] = drop_keep((uint64_t)p.drop_seed, e0 + q, p.drop_p) ? v[q] * inv : 0.f;
+              for (int q = 0; q < 8; ++q) x[q] = swishf_(x[q]);
             }
           }
-          if (res) {
-            float z[16];
-            if (full) { ld8(res + idx0, *reinterpret_cast<float(*)[8]>(z)); if (CPL == 16) ld8(res + idx0 + 8, *reinterpret_cast<float(*)[8]>(z + 8)); }
+          if constexpr (C_DACT) if (dz) {
+            float z[8];
+            if (full) ld8(dz + idx0, z);
             else
 _Pragma("unroll")
-              for (int q = 0; q < CPL; ++q) z[q] = (col0 + q < p.N) ? bf16_to_f32(res[idx0 + q]) : 0.f;
+              for (int q = 0; q < 8; ++q) z[q] = (col0 + q < p.N) ? bf16_to_f32(dz[idx0 + q]) : 0.f;
 #pragma unroll
-            for (int q = 0; q < CPL; ++q) v[q] = z[q] + p.beta * v[q];
+            for (int q = 0; q < 8; ++q) x[q] *= GEN ? dact_f(z[q], p.dact) : dswishf_(z[q]);
           }
-          if (p.out_f32) {
-            if (full) {
-              st8(Df + idx0, *reinterpret_cast<const float(*)[8]>(v)); if (CPL == 16) st8(Df + idx0 + 8, *reinterpret_cast<const float(*)[8]>(v + 8));
+          if constexpr (C_DROP) if (p.drop_p > 0.f) {
+            const uint64_t e0 = (uint64_t)(doff + idx0);
+            if ((e0 & 1) == 0) {  // one hash per even/odd element pair
+#pragma unroll
+              for (int q = 0; q < 8; q += 2) {
+                const uint32_t hh = drop_hash((uint64_t)p.drop_seed, (e0 >> 1) + (q >> 1));
+                x[q] = (hh & 0xffffu) >= dthr ? x[q] * dinv : 0.f;
+                x[q + 1] = (hh >> 16) >= dthr ? x[q + 1] * dinv : 0.f;
+              }
             } else {
-_Pragma("unroll")
-              for (int q = 0; q < CPL; ++q) if (col0 + q < p.N) Df[idx0 + q] = v[q];
+#pragma unroll
+              for (int q = 0; q < 8; ++q) x[q] = drop_keep((uint64_t)p.drop_seed, e0 + q, p.drop_p) ? x[q] * dinv : 0.f;
             }
-          } else {
-            if (full) { st8(Dt + idx0, *reinterpret_cast<const float(*)[8]>(v)); if (CPL == 16) st8(Dt + idx0 + 8, *reinterpret_cast<const float(*)[8]>(v + 8)); }
+          }
+          if constexpr (C_RES) if (res) {
+            float z[8];
+            if (full) ld8(res + idx0, z);
             else
 _Pragma("unroll")
-              for (int q = 0; q < CPL; ++q) if (col0 + q < p.N) Dt[idx0 + q] = f32_to_bf16(v[q]);
+              for (int q = 0; q < 8; ++q) z[q] = (col0 + q < p.N) ? bf16_to_f32(res[idx0 + q]) : 0.f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) x[q] = z[q] + p.beta * x[q];
+          }
+          if (GEN && p.out_f32) {
+            if (full) st8(Df + idx0, x);
+            else
+_Pragma("unroll")
+              for (int q = 0; q < 8; ++q) if (col0 + q < p.N) Df[idx0 + q] = x[q];
+          } else {
+            if (full) st8(Dt + idx0, x);
+            else
+_Pragma("unroll")
+              for (int q = 0; q < 8; ++q) if (col0 + q < p.N) Dt[idx0 + q] = f32_to_bf16(x[q]);
           }
         }
       };
-      strip(std::integral_constant<int, 0>{});
-      strip(std::integral_constant<int, 1>{});
-      strip(std::integral_constant<int, 2>{});
-      strip(std::integral_constant<int, 3>{});
+      auto strips = [&](auto I_) {
+        strip(I_, std::integral_constant<int, 0>{});
+        if constexpr (NPASS == 2) strip(I_, std::integral_constant<int, 1>{});
+      };
+      strips(std::integral_constant<int, 0>{});
+      strips(std::integral_constant<int, 1>{});
+      strips(std::integral_constant<int, 2>{});
+      strips(std::integral_constant<int, 3>{});
     }
     if (nxt.nfull < 0) break;
     // tile boundary: epilogue stores and loads are mixed into the vector-memory queue, so counted waits are void until
@@ -417,22 +446,50 @@ int num_cus() {
   return n;
 }
 
-template <bool TA, bool TB>
-int launch_one(const tfasr_gemm_args& a, hipStream_t stream) {
-  const int split = a.split_k > 1 ? a.split_k : 1;
-  const bool narrow = a.N <= 64;
-  const int bn = narrow ? 64 : 128;
-  const long gx = (a.N + bn - 1) / bn, gy = (a.M + BM - 1) / BM, gz = (long)a.nb1 * a.nb2 * split;
-  const long ntiles = gx * gy * gz;
-  if (ntiles <= 0 || ntiles > 0x7fffffffL) return TFASR_STATUS_INVALID_VALUE;
+template <bool TA, bool TB, int BN_, int EPI>
+int launch_epi(const tfasr_gemm_args& a, dim3 tiles, hipStream_t stream) {
+  const long ntiles = (long)tiles.x * tiles.y * tiles.z;
   const int slots = 2 * num_cus();  // 2 resident workgroups per CU
   int G = (int)(ntiles < slots ? ntiles : slots);
   if (ntiles >= slots) G &= ~7;
-  const int smem = NST * (A_BYTES + bn * BK * 2);
-  if (narrow) hipLaunchKernelGGL((gemm_pipe_kernel<TA, TB, 64>), dim3(G), dim3(256), smem, stream, a, (int)gx, (int)gy, (int)ntiles);
-  else        hipLaunchKernelGGL((gemm_pipe_kernel<TA, TB, 128>), dim3(G), dim3(256), smem, stream, a, (int)gx, (int)gy, (int)ntiles);
+  constexpr int SMEM = NST * (A_BYTES + BN_ * BK * 2) + 4 * (64 / (BN_ / 16)) * (BN_ / 2 + 4) * 4;  // stages + 4 waves' strips
+  hipLaunchKernelGGL((gemm_pipe_kernel<TA, TB, BN_, EPI>), dim3(G), dim3(256), SMEM, stream, a, (int)tiles.x, (int)tiles.y, (int)tiles.z, (int)ntiles);
   TFASR_CHECK_LAUNCH();
   return TFASR_STATUS_SUCCESS;
+}
+
+template <bool TA, bool TB>
+int launch_one(const tfasr_gemm_args& a, hipStream_t stream) {
+  const int split = a.split_k > 1 ? a.split_k : 1;
+  const bool narrow = a.N <= 64;  // per-head attention products etc.: halve the wasted B tile
+  const int bn = narrow ? 64 : 128;
+  dim3 grid((a.N + bn - 1) / bn, (a.M + BM - 1) / BM, a.nb1 * a.nb2 * split);
+  if ((long)grid.x * grid.y * grid.z > 0x7fffffffL) return TFASR_STATUS_INVALID_VALUE;
+  // epilogue terms this call needs; accumulate (atomics from fragments) needs none of them
+  int need = 0;
+  bool generic = false;
+  if (!a.accumulate) {
+    if (a.out_f32) generic = true;
+    if (a.act != TFASR_ACT_NONE || a.prez) { if (a.act == TFASR_ACT_SWISH) need |= E_ACT; else generic = true; }
+    if (a.dact_z) { if (a.dact == TFASR_ACT_SWISH) need |= E_DACT; else generic = true; }
+    if (a.drop_p > 0.f) need |= E_DROP;
+    if (a.res) need |= E_RES;
+  }
+  if (narrow) return generic || need ? launch_epi<TA, TB, 64, E_GEN>(a, grid, stream) : launch_epi<TA, TB, 64, 0>(a, grid, stream);
+  if (!generic) {
+    if (need == 0) return launch_epi<TA, TB, 128, 0>(a, grid, stream);
+    if constexpr (!TA && !TB) {  // forward Dense layers
+      if (need == E_RES) return launch_epi<TA, TB, 128, E_RES>(a, grid, stream);
+      if (need == (E_RES | E_DROP)) return launch_epi<TA, TB, 128, E_RES | E_DROP>(a, grid, stream);
+      if (need == E_ACT) return launch_epi<TA, TB, 128, E_ACT>(a, grid, stream);
+      if (need == (E_ACT | E_DROP)) return launch_epi<TA, TB, 128, E_ACT | E_DROP>(a, grid, stream);
+    }
+    if constexpr (!TA && TB) {  // data gradients (dy @ W^T)
+      if (need == E_DACT) return launch_epi<TA, TB, 128, E_DACT>(a, grid, stream);
+      if (need == (E_DACT | E_DROP)) return launch_epi<TA, TB, 128, E_DACT | E_DROP>(a, grid, stream);
+    }
+  }
+  return launch_epi<TA, TB, 128, E_GEN>(a, grid, stream);
 }
 
 inline bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
