@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define TFASR_ABI_VERSION 6
+#define TFASR_ABI_VERSION 7
 
 typedef enum {
   TFASR_STATUS_SUCCESS = 0,
@@ -120,6 +120,11 @@ typedef struct {
   int split_k;             /* >=1; >1 requires accumulate */
   float drop_p;            /* dropout rate applied to v (0 = off); the mask is a pure function of (drop_seed, element index) */
   long drop_seed;
+  float* ws;               /* optional split-K workspace (f32, >= split_k*M*N elements), NULL = reduce with atomics.  With it the
+                            * k-slices store their partial tiles with plain vector stores and a second small kernel sums them
+                            * into D: the f32 atomics of a [256,1024] weight gradient (4 M of them) otherwise cost more than
+                            * its MFMAs.  Used only when accumulate != 0, split_k > 1 and nb1*nb2 == 1. */
+  long ws_elems;
 } tfasr_gemm_args;
 
 int tfasr_gemm(const tfasr_gemm_args* args, void* stream);

@@ -9,6 +9,7 @@
 // that communicator belongs to the caller, so each direction can be run as phase A | all-reduce | phase B.
 #include "common.h"
 #include <string.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -79,6 +80,16 @@ struct Ex {
   long seed(int site) const { return drop_p() > 0.f ? ((k->drop_epoch * 8192 + c->site0 + site) & 0x7FFFFFFFFFFFL) : 0; }
 
   void gemm(const G& g) {
+    // split-K weight gradients reduce through scratch (released right after the call: same-stream ordering keeps it safe)
+    float* ws = nullptr;
+    long ws_elems = 0;
+    const size_t mark = scratch.off;
+    static const bool splitk_ws = getenv("TFASR_SPLITK_WS") && getenv("TFASR_SPLITK_WS")[0] == '1';  // opt-in (not faster, deterministic)
+    if (splitk_ws && g.accumulate && g.split_k > 1 && g.nb1 * g.nb2 == 1) {
+      ws_elems = (long)g.split_k * g.M * g.N;
+      ws = (float*)scratch.get((size_t)ws_elems * 4);
+    }
+    scratch.off = mark;
     if (dry) return;
     tfasr_gemm_args a;
     memset(&a, 0, sizeof(a));
@@ -87,6 +98,7 @@ struct Ex {
     a.nb1 = g.nb1; a.nb2 = g.nb2; a.sA1 = g.sA1; a.sA2 = g.sA2; a.sB1 = g.sB1; a.sB2 = g.sB2; a.sD1 = g.sD1; a.sD2 = g.sD2;
     a.alpha = g.alpha; a.beta = g.beta; a.act = g.act; a.dact = g.dact; a.dtype = c->dtype; a.out_f32 = g.out_f32;
     a.accumulate = g.accumulate; a.split_k = g.split_k; a.drop_p = g.drop_p; a.drop_seed = g.drop_seed;
+    a.ws = ws; a.ws_elems = ws ? ws_elems : 0;
     chk(tfasr_gemm(&a, s));
   }
   static int split_k(int M, int N, long K) {

@@ -166,7 +166,7 @@ __device__ __forceinline__ float dact_f(float z, int act) {
 // EPI selects which epilogue terms are COMPILED IN.  The fully generic epilogue (every term behind a runtime branch, tanh /
 // sigmoid / f32 outputs included) is ~20k instructions and thrashes the instruction cache: a plain bias epilogue took 1700
 // cycles per 16-row strip.  The step's common combinations get lean instantiations; anything else falls back to E_GEN.
-enum : int { E_ACT = 1 /* swish(+prez) */, E_DACT = 2 /* * swish'(dact_z) */, E_DROP = 4, E_RES = 8, E_GEN = 256 };
+enum : int { E_ACT = 1 /* swish(+prez) */, E_DACT = 2 /* * swish'(dact_z) */, E_DROP = 4, E_RES = 8, E_WS = 16 /* split-K partial -> workspace */, E_GEN = 256 };
 
 // Persistent workgroups (2 per CU) walk a strided list of tiles.  Measured on [23808,256]x[256,1024] (cycle counters,
 // tools/hwprobe/gemm_timing.hip): a tile spent 1900 cycles waiting for its first slab, ~2400 per further slab (the LDS-DMA
@@ -177,6 +177,7 @@ template <bool TA, bool TB, int BN_, int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_fast_kernel(const tfasr_gemm_args p, const int gx, const int gy, const int gz, const int ntiles) {
   constexpr bool GEN = (EPI & E_GEN) != 0;
   constexpr bool C_ACT = GEN || (EPI & E_ACT), C_DACT = GEN || (EPI & E_DACT), C_DROP = GEN || (EPI & E_DROP), C_RES = GEN || (EPI & E_RES);
+  constexpr bool C_WS = (EPI & E_WS) != 0;
   constexpr int BN = BN_, NJ = BN_ / 32, WN = BN_ / 2;
   constexpr int STAGE_BYTES = A_BYTES + BN_ * BK * 2;
   constexpr int GI = 4 + BN_ / 32;  // DMA wave-instructions per slab per wave
@@ -313,7 +314,7 @@ __global__ __launch_bounds__(256, 2) void gemm_fast_kernel(const tfasr_gemm_args
     const bf16_t* res = p.res ? (const bf16_t*)p.res + doff : nullptr;
     const bf16_t* dz = p.dact_z ? (const bf16_t*)p.dact_z + doff : nullptr;
     bf16_t* prez = p.prez ? (bf16_t*)p.prez + doff : nullptr;
-    if (p.accumulate) {
+    if (!C_WS && p.accumulate) {
       // split-K / gradient accumulation: f32 atomics straight from the MFMA fragment layout (16 consecutive
       // columns x 4 rows per instruction = 4 cache lines), no other epilogue terms are legal here
 #pragma unroll
@@ -342,8 +343,9 @@ __global__ __launch_bounds__(256, 2) void gemm_fast_kernel(const tfasr_gemm_args
       float* sc = reinterpret_cast<float*>(smem + 2 * STAGE_BYTES) + w * (RPP * SLD);
       const int prow = lane / LPRW, c8 = (lane % LPRW) * 8;
       const int col0 = n0 + wn * WN + c8;
-      const bool vec_ok = ((p.ldd & 7) == 0) && ((((uintptr_t)p.D) & 15) == 0) && ((doff & 7) == 0);
+      const bool vec_ok = C_WS ? ((p.N & 7) == 0) : (((p.ldd & 7) == 0) && ((((uintptr_t)p.D) & 15) == 0) && ((doff & 7) == 0));
       const bool full = vec_ok && (col0 + 8 <= p.N);
+      float* wsp = C_WS ? p.ws + (long)cur.ks * p.M * p.N : nullptr;  // this k-slice's [M, N] partial (row stride N)
       float bv[8];
 #pragma unroll
       for (int q = 0; q < 8; ++q) bv[q] = 0.f;
@@ -429,7 +431,13 @@ _Pragma("unroll")
 #pragma unroll
             for (int q = 0; q < 8; ++q) x[q] = z[q] + p.beta * x[q];
           }
-          if (GEN && p.out_f32) {
+          if constexpr (C_WS) {
+            const long wi = (long)row * p.N + col0;
+            if (full) st8(wsp + wi, x);
+            else
+_Pragma("unroll")
+              for (int q = 0; q < 8; ++q) if (col0 + q < p.N) wsp[wi + q] = x[q];
+          } else if (GEN && p.out_f32) {
             if (full) st8(Df + idx0, x);
             else
 _Pragma("unroll")
@@ -476,6 +484,33 @@ _Pragma("unroll")
   }
 }
 
+// second pass of the workspace split-K: D[m, n] += sum_s ws[s][m][n]
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ D, int M, int N, int ldd, int split) {
+  const long mn = (long)M * N;
+  if ((N & 3) == 0 && (ldd & 3) == 0 && ((((uintptr_t)D) & 15) == 0)) {
+    const int n4 = N >> 2;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < mn / 4; i += (long)gridDim.x * blockDim.x) {
+      float4 acc = *reinterpret_cast<const float4*>(ws + 4 * i);
+      for (int s2 = 1; s2 < split; ++s2) {
+        const float4 t = *reinterpret_cast<const float4*>(ws + s2 * mn + 4 * i);
+        acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
+      }
+      const long m = i / n4;
+      float4* d = reinterpret_cast<float4*>(D + m * ldd + 4 * (i - m * n4));
+      float4 o = *d;
+      o.x += acc.x; o.y += acc.y; o.z += acc.z; o.w += acc.w;
+      *d = o;
+    }
+  } else {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < mn; i += (long)gridDim.x * blockDim.x) {
+      float acc = 0.f;
+      for (int s2 = 0; s2 < split; ++s2) acc += ws[s2 * mn + i];
+      const long m = i / N;
+      D[m * ldd + (i - m * N)] += acc;
+    }
+  }
+}
+
 int num_cus() {
   static int n = 0;
   if (n == 0) {
@@ -514,6 +549,17 @@ int launch_one(const tfasr_gemm_args& a, hipStream_t stream) {
     if (a.dact_z) { if (a.dact == TFASR_ACT_SWISH) need |= E_DACT; else generic = true; }
     if (a.drop_p > 0.f) need |= E_DROP;
     if (a.res) need |= E_RES;
+  }
+  // (measured: NOT faster than the atomics - 34.8 vs 33.0 us on the [256,1024,19040] weight gradient, +5 ms on the step from
+  // the extra workspace traffic - so callers only pass a workspace when TFASR_SPLITK_WS=1; kept as the deterministic option)
+  if (a.accumulate && split > 1 && a.nb1 * a.nb2 == 1 && a.ws && a.ws_elems >= (long)split * a.M * a.N && !narrow) {
+    const int st = launch_epi<TA, TB, 128, E_WS>(a, grid, stream);
+    if (st != TFASR_STATUS_SUCCESS) return st;
+    const long work = ((long)a.M * a.N + 3) / 4;
+    const int rg = (int)(work / 256 + 1 < 2048 ? work / 256 + 1 : 2048);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rg), dim3(256), 0, stream, (const float*)a.ws, (float*)a.D, a.M, a.N, a.ldd, split);
+    TFASR_CHECK_LAUNCH();
+    return TFASR_STATUS_SUCCESS;
   }
   if (narrow) return generic || need ? launch_epi<TA, TB, 64, E_GEN>(a, grid, stream) : launch_epi<TA, TB, 64, 0>(a, grid, stream);
   if (!generic) {

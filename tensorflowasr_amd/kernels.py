@@ -3,6 +3,7 @@
 Every function here requires CUDA(HIP) tensors and fails loudly otherwise: there is no CPU fallback.
 """
 import ctypes
+import os
 
 import torch
 
@@ -10,6 +11,7 @@ from . import _lib
 from ._lib import ACT_NONE, ACT_SIGMOID, ACT_SWISH, ACT_TANH, TFASR_BF16, TFASR_F32, GemmArgs, check  # noqa: F401
 
 _WS_CACHE = {}
+_SPLITK_WS = os.environ.get("TFASR_SPLITK_WS", "0") == "1"
 
 
 def _dt(t):
@@ -128,6 +130,9 @@ def gemm(A, B, out, M, N, K, lda, ldb, ldd, trans_a=False, trans_b=False, bias=N
     a.drop_p, a.drop_seed = drop_p, drop_seed
     if accumulate:
         assert out.dtype == torch.float32
+        if _SPLITK_WS and split_k > 1 and nb1 * nb2 == 1:  # opt-in: k-slices reduce through a workspace (deterministic sums)
+            ws = workspace(4 * split_k * M * N, out.device, "splitk_%d" % (_raw_stream(torch.cuda.current_device()) if _raw_stream else 0))
+            a.ws, a.ws_elems = ws.data_ptr(), ws.numel() // 4
     check(_lib.load().tfasr_gemm(ctypes.byref(a), _stream()), "gemm")
     return out
 
