@@ -10,6 +10,9 @@
 // strip, runs an online softmax in registers and accumulates P@V.  Saves lse[b,h,i] = log sum_j exp(s_ij) for the backward.
 // Auto-mask semantics as in attention.hip: padded QUERY rows give uniform attention over all T keys; keys are never masked.
 #include "common.h"
+#ifdef TFASR_ATTN_TIMING
+__device__ long long g_attn_timing[5 * 8192];
+#endif
 #include <algorithm>
 
 typedef __attribute__((ext_vector_type(4))) short short4_t;
@@ -131,10 +134,36 @@ __global__ __launch_bounds__(256, 2) void relattn_fused_fwd_kernel(
 #pragma unroll
   for (int n = 0; n < 4; ++n) acc_o[n] = float4_t{0.f, 0.f, 0.f, 0.f};
 
+  // loop-invariant per-lane quantities of the softmax phase
+  const float scale2 = scale * 1.4426950408889634f;  // scores in log2 units
+  const int lim = 2 * len - 1;
+  int rr0[4], goff[4], poff[4][4];
+  bool qm[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int il = g * 4 + e, i = i0 + w * 16 + il;
+    rr0[e] = T - 1 - i + r;                       // + jt*16 + j0 = relative-position row of key j
+    goff[e] = il * GLD + (63 - w * 16 - il + r);  // + jt*16 = skewed column of the window scores
+    qm[e] = use_mask && (i >= len);
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) {
+      const int jl = jt * 16 + r;
+      poff[e][jt] = il * 128 + (((jl >> 3) ^ key_d(il)) << 4) + (jl & 7) * 2;
+    }
+  }
+#ifdef TFASR_ATTN_TIMING
+  long long ph[5] = {0, 0, 0, 0, 0};
+#define ATT_TICK(k) { const long long t_ = __builtin_readcyclecounter(); ph[k] += t_ - tp; tp = t_; }
+#else
+#define ATT_TICK(k)
+#endif
   const int njb = (T + BJ - 1) / BJ;
   for (int jb = 0; jb < njb; ++jb) {
     const int j0 = jb * BJ;
     const int pw0 = (T - 1 - (i0 + BI - 1) + j0) + shift;  // pext row of window column 0
+#ifdef TFASR_ATTN_TIMING
+    long long tp = __builtin_readcyclecounter();
+#endif
     load_rows<BJ>(sK, kb, LDQ, j0, T, w, lane);
     load_v(sV, vb, LDQ, j0, T, w, lane);
     load_rows<WIN>(sP, pb, HD, pw0, R1, w, lane);
@@ -146,6 +175,7 @@ __global__ __launch_bounds__(256, 2) void relattn_fused_fwd_kernel(
       *reinterpret_cast<uint4*>(sP + 127 * 128 + lane * 16) = v;
     }
     __syncthreads();
+    ATT_TICK(0)
 
     // content scores: 16 query rows x 64 keys
     float4_t acc_s[4];
@@ -170,51 +200,41 @@ __global__ __launch_bounds__(256, 2) void relattn_fused_fwd_kernel(
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
+    ATT_TICK(1)
 
-    // scores in C layout: row il = g*4+e, col jl = jt*16 + r
+    // scores in C layout: row il = g*4+e, col jl = jt*16 + r.  Everything that does not depend on the key block (skew
+    // read offsets, P-image write offsets, validity thresholds) was hoisted out of the loop; scores are kept in the
+    // log2 domain (scale * log2(e) folded in) so that each probability is one v_exp_f32.
     float rmax[4];
+    const bool ragged = (j0 + BJ > T);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const int il = g * 4 + e;
-      const int i = i0 + w * 16 + il;
-      const bool qmask = use_mask && (i >= len);
-      const float gbias = sG[il * GLD + 127];
+      const float gbias = sG[(g * 4 + e) * GLD + 127];
       float mx = -INFINITY;
 #pragma unroll
       for (int jt = 0; jt < 4; ++jt) {
-        const int jl = jt * 16 + r, j = j0 + jl;
-        const int rr = T - 1 - i + j;
-        const float pos = (rr < 2 * len - 1) ? sG[il * GLD + (63 - w * 16 - il + jl)] : gbias;
-        float s = (acc_s[jt][e] + pos) * scale;
-        if (qmask) s = 0.f;
-        if (j >= T) s = -INFINITY;
-        acc_s[jt][e] = s;
-        mx = fmaxf(mx, s);
+        const float pos = (rr0[e] + jt * 16 + j0 < lim) ? sG[goff[e] + jt * 16] : gbias;
+        float s2 = (acc_s[jt][e] + pos) * scale2;
+        if (qm[e]) s2 = 0.f;
+        if (ragged && j0 + jt * 16 + r >= T) s2 = -INFINITY;
+        acc_s[jt][e] = s2;
+        mx = fmaxf(mx, s2);
       }
-      mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 4, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 8, 64));
-      rmax[e] = mx;
+      rmax[e] = row16_max(mx);
     }
     // online softmax update + P (bf16) into the per-wave A-operand image
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const int il = g * 4 + e;
       const float m_new = fmaxf(m_run[e], rmax[e]);
-      const float corr = (m_run[e] == -INFINITY) ? 0.f : __expf(m_run[e] - m_new);
+      const float corr = __builtin_amdgcn_exp2f(m_run[e] - m_new);  // exp2(-inf) = 0 on the first block
       float rs = 0.f;
 #pragma unroll
       for (int jt = 0; jt < 4; ++jt) {
-        const float p = (acc_s[jt][e] == -INFINITY) ? 0.f : __expf(acc_s[jt][e] - m_new);
+        const float p = __builtin_amdgcn_exp2f(acc_s[jt][e] - m_new);  // masked keys: exp2(-inf) = 0
         rs += p;
-        const int jl = jt * 16 + r;
-        *reinterpret_cast<bf16_t*>(sPb + il * 128 + (((jl >> 3) ^ key_d(il)) << 4) + (jl & 7) * 2) = f32_to_bf16(p);
+        *reinterpret_cast<bf16_t*>(sPb + poff[e][jt]) = f32_to_bf16(p);
       }
-      rs += __shfl_xor(rs, 1, 64);
-      rs += __shfl_xor(rs, 2, 64);
-      rs += __shfl_xor(rs, 4, 64);
-      rs += __shfl_xor(rs, 8, 64);
+      rs = row16_sum(rs);
       l_run[e] = l_run[e] * corr + rs;
       m_run[e] = m_new;
 #pragma unroll
@@ -222,6 +242,7 @@ __global__ __launch_bounds__(256, 2) void relattn_fused_fwd_kernel(
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
+    ATT_TICK(2)
     // O += P @ V
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
@@ -230,8 +251,16 @@ __global__ __launch_bounds__(256, 2) void relattn_fused_fwd_kernel(
       for (int n = 0; n < 4; ++n)
         acc_o[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap, frag_v(sV, n * 16, kk * 32 + g * 8, r), acc_o[n], 0, 0, 0);
     }
+    ATT_TICK(3)
     __syncthreads();  // everyone is done with sK / sV / sP before the next block's DMA lands
+    ATT_TICK(4)
   }
+#ifdef TFASR_ATTN_TIMING
+  if (threadIdx.x == 0) {
+    long long* o = g_attn_timing + 5L * (blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z));
+    for (int k = 0; k < 5; ++k) o[k] = ph[k];
+  }
+#endif
 
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
@@ -240,7 +269,7 @@ __global__ __launch_bounds__(256, 2) void relattn_fused_fwd_kernel(
       const float inv = 1.f / l_run[e];
 #pragma unroll
       for (int n = 0; n < 4; ++n) out[((long)b * T + i) * HD + h * DH + n * 16 + r] = f32_to_bf16(acc_o[n][e] * inv);
-      if (r == 0) lse_out[((long)b * H + h) * T + i] = m_run[e] + logf(l_run[e]);
+      if (r == 0) lse_out[((long)b * H + h) * T + i] = m_run[e] * 0.6931471805599453f + logf(l_run[e]);  // back to natural log
     }
   }
 }
@@ -411,10 +440,7 @@ __global__ __launch_bounds__(256, 2) void relattn_fused_bwd_q_kernel(
   for (int e = 0; e < 4; ++e) {
     const int i = i0 + w * 16 + g * 4 + e;
     float bsum = bias_acc[e];
-    bsum += __shfl_xor(bsum, 1, 64);
-    bsum += __shfl_xor(bsum, 2, 64);
-    bsum += __shfl_xor(bsum, 4, 64);
-    bsum += __shfl_xor(bsum, 8, 64);
+    bsum = row16_sum(bsum);
     if (i < T) {
 #pragma unroll
       for (int n = 0; n < 4; ++n) dqu[((long)b * T + i) * HD + h * DH + n * 16 + r] = f32_to_bf16(acc_q[n][e]);

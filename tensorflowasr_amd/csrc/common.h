@@ -62,6 +62,27 @@ __device__ __forceinline__ void st8(bf16_t* p, const float (&v)[8]) {
   *reinterpret_cast<uint4*>(p) = a;
 }
 
+// All-reduce inside each row of 16 lanes with DPP row rotations (plain VALU, ~8 cycles each): __shfl_xor compiles to
+// ds_bpermute_b32 (an LDS round trip, ~100 cycles, and these chains are dependent) - the 32 of them per key block were
+// half of the fused attention forward's time.
+template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_mov<0x128>(v);  // row_ror:8
+  v += dpp_mov<0x124>(v);  // row_ror:4
+  v += dpp_mov<0x122>(v);  // row_ror:2
+  v += dpp_mov<0x121>(v);  // row_ror:1
+  return v;
+}
+__device__ __forceinline__ float row16_max(float v) {
+  v = fmaxf(v, dpp_mov<0x128>(v));
+  v = fmaxf(v, dpp_mov<0x124>(v));
+  v = fmaxf(v, dpp_mov<0x122>(v));
+  v = fmaxf(v, dpp_mov<0x121>(v));
+  return v;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

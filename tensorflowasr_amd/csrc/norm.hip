@@ -225,8 +225,9 @@ __device__ __forceinline__ void ldf8(const float* __restrict__ p, float (&v)[8],
 }
 
 template <int LPR> __device__ __forceinline__ float seg_sum(float v) {
+  v = row16_sum(v);  // DPP inside each 16-lane row, then the (1 or 2) cross-row steps through the permute unit
 #pragma unroll
-  for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  for (int o = 16; o < LPR; o <<= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
 
