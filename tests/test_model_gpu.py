@@ -253,5 +253,6 @@ def test_native_block_executor_matches_per_kernel_host_path(dev, dtype, head):
     np.testing.assert_allclose(out[True][0], out[False][0], rtol=tol)
     g0, g1 = out[False][1], out[True][1]
     np.testing.assert_allclose(g1, g0, rtol=tol, atol=tol * float(np.abs(g0).max()))
-    np.testing.assert_allclose(out[True][2], out[False][2], rtol=1e-5, atol=1e-7)
+    # moving mean of a zero-mean activation: absolute scale ~1e-5, f32 atomics order differs between runs
+    np.testing.assert_allclose(out[True][2], out[False][2], rtol=1e-5 if dtype == torch.float32 else 1e-2, atol=1e-7 if dtype == torch.float32 else 2e-5)
     np.testing.assert_allclose(out[True][3], out[False][3], rtol=tol, atol=tol)
