@@ -109,6 +109,105 @@ __global__ __launch_bounds__(256) void conv1_bwd_weight_kernel(const T* __restri
   }
 }
 
+// Row-structured variants for C == 256: one (b, t) output row per block iteration, thread = (channel group, f sub-lane), so no
+// thread ever divides a flat 64-bit index (three 64-bit div/mods per element made the flat kernels VALU-bound: 543 us to write
+// 1 GB, 935 us to read it back).  The three input rows a block needs are staged in LDS once.
+template <typename T>
+__global__ __launch_bounds__(256) void conv1_fwd_rows_kernel(const T* __restrict__ x, const float* __restrict__ w,
+                                                             const float* __restrict__ bias, T* __restrict__ y, int B, int T0,
+                                                             int F0, int T1, int F1) {
+  constexpr int C = 256;
+  __shared__ float xs[3][260];
+  const int c = (threadIdx.x & 31) * 8, fs = threadIdx.x >> 5;
+  float wr[9][8], br[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) br[k] = bias ? bias[c + k] : 0.f;
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) wr[tap][k] = w[tap * C + c + k];
+  const int nrows = B * T1;
+  for (int row = blockIdx.x; row < nrows; row += gridDim.x) {
+    const int b = row / T1, t = row - b * T1;
+    __syncthreads();
+    for (int i = threadIdx.x; i < 3 * (F0 + 2); i += 256) {  // xs[kh][fi + 2] = x[b, 2t+kh-2, fi], zero outside
+      const int kh = i / (F0 + 2), fi = i - kh * (F0 + 2) - 2, ti = 2 * t + kh - 2;
+      xs[kh][fi + 2] = (ti >= 0 && ti < T0 && fi >= 0 && fi < F0) ? Num<T>::ld(x + ((long)b * T0 + ti) * F0 + fi) : 0.f;
+    }
+    __syncthreads();
+    for (int f = fs; f < F1; f += 8) {
+      float acc[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc[k] = br[k];
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const float xv = xs[kh][2 * f + kw];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) acc[k] += wr[kh * 3 + kw][k] * xv;
+        }
+      st8(y + ((long)row * F1 + f) * C + c, acc);
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void conv1_bwd_weight_rows_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                                    float* __restrict__ dw, float* __restrict__ db, int B, int T0,
+                                                                    int F0, int T1, int F1) {
+  constexpr int C = 256;
+  __shared__ float xs[3][260];
+  __shared__ float red[4][10][C + 1];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int c = (threadIdx.x & 31) * 8, fs = threadIdx.x >> 5;
+  float acc[10][8];
+#pragma unroll
+  for (int q = 0; q < 10; ++q)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[q][k] = 0.f;
+  const int nrows = B * T1;
+  for (int row = blockIdx.x; row < nrows; row += gridDim.x) {
+    const int b = row / T1, t = row - b * T1;
+    __syncthreads();
+    for (int i = threadIdx.x; i < 3 * (F0 + 2); i += 256) {
+      const int kh = i / (F0 + 2), fi = i - kh * (F0 + 2) - 2, ti = 2 * t + kh - 2;
+      xs[kh][fi + 2] = (ti >= 0 && ti < T0 && fi >= 0 && fi < F0) ? Num<T>::ld(x + ((long)b * T0 + ti) * F0 + fi) : 0.f;
+    }
+    __syncthreads();
+    for (int f = fs; f < F1; f += 8) {
+      float d[8];
+      ld8(dy + ((long)row * F1 + f) * C + c, d);
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const float xv = xs[kh][2 * f + kw];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) acc[kh * 3 + kw][k] += d[k] * xv;
+        }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc[9][k] += d[k];
+    }
+  }
+  (void)lane;
+#pragma unroll
+  for (int q = 0; q < 10; ++q)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      float v = acc[q][k];
+      v += __shfl_xor(v, 32, 64);  // the two f sub-lanes of one wave own the same channels
+      if ((threadIdx.x & 32) == 0) red[w][q][c + k] = v;
+    }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 10 * C; i += blockDim.x) {
+    const int q = i / C, cc = i % C;
+    const float sum = red[0][q][cc] + red[1][q][cc] + red[2][q][cc] + red[3][q][cc];
+    if (q < 9) atomicAdd(dw + q * C + cc, sum);
+    else if (db) atomicAdd(db + cc, sum);
+  }
+}
+
 // col[(b,t2,f2), (kh*3+kw)*C + c] = x[b, 2*t2+kh-2, 2*f2+kw-2, c] (0 outside)
 template <typename T>
 __global__ __launch_bounds__(256) void im2col_kernel(const T* __restrict__ x, T* __restrict__ col, int B, int T1, int F1,
@@ -176,6 +275,14 @@ extern "C" int tfasr_conv1_fwd(const void* x, const float* w, const float* bias,
   if (!x || !w || !y || B <= 0 || T0 <= 0 || F0 <= 0 || C <= 0 || C % 8) return TFASR_STATUS_INVALID_VALUE;
   const int T1 = (T0 + 1) / 2, F1 = (F0 + 1) / 2;
   hipStream_t s = (hipStream_t)stream_;
+  if (C == 256 && F0 + 2 <= 260) {
+    const int g2 = std::min(B * T1, 8192);
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL(conv1_fwd_rows_kernel<float>, dim3(g2), dim3(256), 0, s, (const float*)x, w, bias, (float*)y, B, T0, F0, T1, F1),
+               hipLaunchKernelGGL(conv1_fwd_rows_kernel<bf16_t>, dim3(g2), dim3(256), 0, s, (const bf16_t*)x, w, bias, (bf16_t*)y, B, T0, F0, T1, F1));
+    TFASR_CHECK_LAUNCH();
+    return TFASR_STATUS_SUCCESS;
+  }
   int grid = flat_grid((long)B * T1 * F1 * C / 8);
   if ((256 % (C / 8)) != 0) {  // keep (grid*256) a multiple of C/8 so each thread owns one channel group
     const int c8n = C / 8;
@@ -193,6 +300,14 @@ extern "C" int tfasr_conv1_bwd_weight(const void* x, const void* dy, float* dw, 
   if (!x || !dy || !dw || B <= 0 || T0 <= 0 || F0 <= 0 || C <= 0 || C > 256 || (C % 8)) return TFASR_STATUS_INVALID_VALUE;
   const int T1 = (T0 + 1) / 2, F1 = (F0 + 1) / 2;
   hipStream_t s = (hipStream_t)stream_;
+  if (C == 256 && F0 + 2 <= 260) {
+    const int g2 = std::min(B * T1, 1024);
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL(conv1_bwd_weight_rows_kernel<float>, dim3(g2), dim3(256), 0, s, (const float*)x, (const float*)dy, dw, db, B, T0, F0, T1, F1),
+               hipLaunchKernelGGL(conv1_bwd_weight_rows_kernel<bf16_t>, dim3(g2), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)dy, dw, db, B, T0, F0, T1, F1));
+    TFASR_CHECK_LAUNCH();
+    return TFASR_STATUS_SUCCESS;
+  }
   const long npos = (long)B * T1 * F1;
   const int grid = (int)std::max<long>(1, std::min<long>(npos / 64 + 1, 1024));
   DISPATCH_T(dtype,

@@ -260,6 +260,20 @@ def test_subsampling_pieces(dev, dtype):
     K.conv1_bwd_weight(x.to(dev).to(dtype), dy1.to(dev).to(dtype), dw, db)
     cmp(dw, w1r.grad, rtol=1e-3, atol=2e-3)
     cmp(db, dy1.sum((0, 1, 2)), rtol=1e-3, atol=2e-3)
+    # C == 256 takes the row-structured kernels (the flagship filter count)
+    Cb = 256
+    wb, bb = torch.randn(3, 3, 1, Cb, generator=g) * 0.3, torch.randn(Cb, generator=g) * 0.1
+    xb = rt(torch.randn(3, 23, 80, generator=g), dtype)
+    refb = R.conv2d_causal_s2(xb[..., None], wb, bb)
+    yb = K.conv1_fwd(xb.to(dev).to(dtype), wb.to(dev), bb.to(dev))
+    cmp(yb, refb, **tol(dtype, (1e-4, 1e-5)))
+    dyb = rt(torch.randn(*refb.shape, generator=g), dtype)
+    wbr = wb.clone().requires_grad_(True)
+    R.conv2d_causal_s2(xb[..., None], wbr, bb).backward(dyb)
+    dwb, dbb = torch.zeros(3, 3, 1, Cb, device=dev), torch.zeros(Cb, device=dev)
+    K.conv1_bwd_weight(xb.to(dev).to(dtype), dyb.to(dev).to(dtype), dwb, dbb)
+    cmp(dwb, wbr.grad, rtol=1e-3, atol=3e-3)
+    cmp(dbb, dyb.sum((0, 1, 2)), rtol=1e-3, atol=3e-3)
     # conv2 = im2col + GEMM; data grad = GEMM + col2im
     x1 = rt(torch.randn(B, 11, 40, C, generator=g), dtype)
     w2, b2 = torch.randn(3, 3, C, C, generator=g) * 0.1, torch.randn(C, generator=g) * 0.1
