@@ -64,19 +64,19 @@ def to_train_data(batch, dev):
 def pmc_traffic(flops_per_launch, J, V):
     """HBM bytes per launch of the joint vocabulary GEMM from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE,
     profiles/r01_pmc_traffic.json, collected on this same command).  PMC counters cannot be read inside a timed run, so
-    the figure is looked up by the launch's grid (m-tiles of the packed lattice); None when no launch of that grid was
-    profiled."""
+    the figure is looked up: the forward vocabulary projection is the plain NN gemm_fast launch whose WRITE_SIZE equals its
+    output (cells x V bf16) - no other launch of the step writes that much from that kernel.  None if it was not profiled."""
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
     if not os.path.exists(path):
         return None
     rows = json.load(open(path))
     vals = []
     for fl in flops_per_launch:
-        cells = int(round(fl / (2.0 * J * V)))
-        mt = -(-cells // 128)
-        for r in rows:
-            if r["kernel"].startswith("gemm_fast_kernel<false, false, 128>") and r["grid_threads"][1] == mt and r["grid_threads"][0] == 256 * -(-V // 128):
-                vals.append(r["hbm_MB"] * 1e6)
+        cells = fl / (2.0 * J * V)
+        out_mb = cells * V * 2 / 1e6
+        m = [r["hbm_MB"] for r in rows if r["kernel"].startswith("gemm_fast_kernel<false, false, 128, 0>") and abs(r["write_MB"] - out_mb) < 0.03 * out_mb]
+        if m:
+            vals.append(float(np.mean(m)) * 1e6)
     return round(float(np.mean(vals)), 0) if vals else None
 
 
