@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define TFASR_ABI_VERSION 7
+#define TFASR_ABI_VERSION 8
 
 typedef enum {
   TFASR_STATUS_SUCCESS = 0,
@@ -125,6 +125,9 @@ typedef struct {
                             * into D: the f32 atomics of a [256,1024] weight gradient (4 M of them) otherwise cost more than
                             * its MFMAs.  Used only when accumulate != 0, split_k > 1 and nb1*nb2 == 1. */
   long ws_elems;
+  float* colsum;           /* optional [N] f32, only with accumulate != 0, trans_a == 1, trans_b == 0, nb1*nb2 == 1 (a Dense layer's
+                            * weight gradient x^T dy): colsum[n] += alpha * sum_k B[k, n], i.e. the BIAS gradient, produced by the
+                            * same launch (one extra all-ones MFMA row in the first row of tiles) instead of a second pass over dy */
 } tfasr_gemm_args;
 
 int tfasr_gemm(const tfasr_gemm_args* args, void* stream);

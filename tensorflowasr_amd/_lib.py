@@ -30,7 +30,7 @@ class GemmArgs(Structure):
         ("alpha", c_float), ("beta", c_float),
         ("act", c_int), ("dact", c_int), ("dtype", c_int), ("out_f32", c_int), ("accumulate", c_int), ("split_k", c_int),
         ("drop_p", c_float), ("drop_seed", c_long),
-        ("ws", c_void_p), ("ws_elems", c_long),
+        ("ws", c_void_p), ("ws_elems", c_long), ("colsum", c_void_p),
     ]
 
 
@@ -145,7 +145,7 @@ def load(build_if_missing=True):
     return lib
 
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 def check(status, what=""):

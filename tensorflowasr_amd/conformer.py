@@ -121,10 +121,9 @@ class ConformerTransducer:
         W = ps.w2d(wname)
         rows = dy.shape[0]
         din, dout = W.shape
+        # weight gradient; the bias gradient (column sums of dy) rides in the same launch
         K.gemm(x, dy, ps.g2d(wname), din, dout, rows, x.stride(0), dy.stride(0), dout, trans_a=True, accumulate=True,
-               split_k=_split_k(din, dout, rows), alpha=alpha)
-        if bname is not None:
-            K.colsum(dy, ps.g(bname), scale=alpha, rows=rows, C=dout, ld=dy.stride(0))
+               split_k=_split_k(din, dout, rows), alpha=alpha, colsum=ps.g(bname) if bname is not None else None)
         if not need_dx:
             return None
         return K.matmul(dy, W, trans_b=True, alpha=alpha, dact_z=dact_z, dact=dact, drop_p=drop[0], drop_seed=drop[1])

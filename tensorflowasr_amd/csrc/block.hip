@@ -53,6 +53,7 @@ struct G {
   const void* A = nullptr; int lda = 0; int ta = 0; const void* B = nullptr; int ldb = 0; int tb = 0; void* D = nullptr; int ldd = 0; int M = 0, N = 0, K = 0;
   const float* bias = nullptr; const void* res = nullptr; const void* dact_z = nullptr; void* prez = nullptr;
   float alpha = 1.f, beta = 1.f; int act = 0, dact = 0, out_f32 = 0, accumulate = 0, split_k = 1; float drop_p = 0.f; long drop_seed = 0;
+  float* colsum = nullptr;
   int nb1 = 1, nb2 = 1; long sA1 = 0, sA2 = 0, sB1 = 0, sB2 = 0, sD1 = 0, sD2 = 0;
 };
 
@@ -99,6 +100,7 @@ struct Ex {
     a.alpha = g.alpha; a.beta = g.beta; a.act = g.act; a.dact = g.dact; a.dtype = c->dtype; a.out_f32 = g.out_f32;
     a.accumulate = g.accumulate; a.split_k = g.split_k; a.drop_p = g.drop_p; a.drop_seed = g.drop_seed;
     a.ws = ws; a.ws_elems = ws ? ws_elems : 0;
+    a.colsum = g.colsum;
     chk(tfasr_gemm(&a, s));
   }
   static int split_k(int M, int N, long K) {
@@ -121,8 +123,8 @@ struct Ex {
                  int dact = 0, float dp = 0.f, long dseed = 0) {
     G w; w.A = x; w.lda = din; w.ta = 1; w.B = dy; w.ldb = dout; w.tb = 0; w.D = gp(wi); w.ldd = dout; w.M = din; w.N = dout; w.K = (int)rows;
     w.alpha = alpha; w.out_f32 = 1; w.accumulate = 1; w.split_k = split_k(din, dout, rows);
+    w.colsum = gp(bi);  // bias gradient in the same launch
     gemm(w);
-    if (!dry) chk(tfasr_colsum(dy, dout, gp(bi), rows, dout, alpha, c->dtype, s));
     if (!dx) return;
     G d; d.A = dy; d.lda = dout; d.ta = 0; d.B = wp(wi); d.ldb = dout; d.tb = 1; d.D = dx; d.ldd = din; d.M = (int)rows; d.N = din; d.K = dout;
     d.alpha = alpha; d.dact_z = dact_z; d.dact = dact; d.drop_p = dp; d.drop_seed = dseed;
@@ -169,8 +171,8 @@ struct Ex {
     {
       G w; w.A = k->ff_h[m]; w.lda = F; w.ta = 1; w.B = dyd; w.ldb = d; w.tb = 0; w.D = gp(b0 + 4); w.ldd = d; w.M = F; w.N = d; w.K = (int)rows;
       w.alpha = c->ffm_res; w.out_f32 = 1; w.accumulate = 1; w.split_k = split_k(F, d, rows);
+      w.colsum = gp(b0 + 5);
       gemm(w);
-      if (!dry) chk(tfasr_colsum(dyd, d, gp(b0 + 5), rows, d, c->ffm_res, c->dtype, s));
       G g; g.A = dyd; g.lda = d; g.ta = 0; g.B = wp(b0 + 4); g.ldb = d; g.tb = 1; g.D = dz; g.ldd = F; g.M = (int)rows; g.N = F; g.K = d;
       g.alpha = c->ffm_res; g.dact_z = k->ff_z[m]; g.dact = TFASR_ACT_SWISH; g.drop_p = drop_p(); g.drop_seed = seed(site);
       gemm(g);
@@ -244,8 +246,8 @@ struct Ex {
     {
       G w; w.A = k->at_att; w.lda = HD; w.ta = 1; w.B = dyd; w.ldb = d; w.tb = 0; w.D = gp(TFASR_BP_AT_O_W); w.ldd = d; w.M = HD; w.N = d; w.K = (int)rows;
       w.alpha = c->mhsa_res; w.out_f32 = 1; w.accumulate = 1; w.split_k = split_k(HD, d, rows);
+      w.colsum = gp(TFASR_BP_AT_O_B);
       gemm(w);
-      if (!dry) chk(tfasr_colsum(dyd, d, gp(TFASR_BP_AT_O_B), rows, d, c->mhsa_res, c->dtype, s));
       G g; g.A = dyd; g.lda = d; g.ta = 0; g.B = wp(TFASR_BP_AT_O_W); g.ldb = d; g.tb = 1; g.D = datt; g.ldd = HD; g.M = (int)rows; g.N = HD; g.K = d;
       g.alpha = c->mhsa_res;
       gemm(g);

@@ -116,8 +116,9 @@ __device__ __forceinline__ short8_t frag_trans(const char* s, int rowbase, int k
   return v;
 }
 
-template <bool TA, bool TB, int BN_>
-__device__ __forceinline__ void mma_slab(const char* sA, const char* sB, int wm, int wn, int lane, float4_t (&acc)[4][BN_ / 32]) {
+template <bool TA, bool TB, int BN_, bool CS = false>
+__device__ __forceinline__ void mma_slab(const char* sA, const char* sB, int wm, int wn, int lane, float4_t (&acc)[4][BN_ / 32],
+                                         float4_t* accb = nullptr, bool do_cs = false) {
   constexpr int NJ = BN_ / 32, WN = BN_ / 2;
   const int r = lane & 15, g = lane >> 4;
   // All fragment reads of the slab are issued first (LDS returns in order, so the first MFMAs start as soon as their
@@ -144,6 +145,16 @@ __device__ __forceinline__ void mma_slab(const char* sA, const char* sB, int wm,
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[kk][i], b[kk][j], acc[i][j], 0, 0, 0);
+  if constexpr (CS) {
+    if (do_cs) {  // all-ones A fragment: every row of the result is sum_k B[k, n] (the bias gradient's share of this slab)
+      const short one = (short)0x3F80;
+      const short8_t ones = {one, one, one, one, one, one, one, one};
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) accb[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, b[kk][j], accb[j], 0, 0, 0);
+    }
+  }
 }
 
 __device__ __forceinline__ float act_f(float v, int act) {
@@ -166,7 +177,7 @@ __device__ __forceinline__ float dact_f(float z, int act) {
 // EPI selects which epilogue terms are COMPILED IN.  The fully generic epilogue (every term behind a runtime branch, tanh /
 // sigmoid / f32 outputs included) is ~20k instructions and thrashes the instruction cache: a plain bias epilogue took 1700
 // cycles per 16-row strip.  The step's common combinations get lean instantiations; anything else falls back to E_GEN.
-enum : int { E_ACT = 1 /* swish(+prez) */, E_DACT = 2 /* * swish'(dact_z) */, E_DROP = 4, E_RES = 8, E_WS = 16 /* split-K partial -> workspace */, E_GEN = 256 };
+enum : int { E_ACT = 1 /* swish(+prez) */, E_DACT = 2 /* * swish'(dact_z) */, E_DROP = 4, E_RES = 8, E_WS = 16 /* split-K partial -> workspace */, E_CSUM = 32 /* + column sums of B (bias gradient) */, E_GEN = 256 };
 
 // Persistent workgroups (2 per CU) walk a strided list of tiles.  Measured on [23808,256]x[256,1024] (cycle counters,
 // tools/hwprobe/gemm_timing.hip): a tile spent 1900 cycles waiting for its first slab, ~2400 per further slab (the LDS-DMA
@@ -178,6 +189,7 @@ __global__ __launch_bounds__(256, 2) void gemm_fast_kernel(const tfasr_gemm_args
   constexpr bool GEN = (EPI & E_GEN) != 0;
   constexpr bool C_ACT = GEN || (EPI & E_ACT), C_DACT = GEN || (EPI & E_DACT), C_DROP = GEN || (EPI & E_DROP), C_RES = GEN || (EPI & E_RES);
   constexpr bool C_WS = (EPI & E_WS) != 0;
+  constexpr bool C_CS = (EPI & E_CSUM) != 0;
   constexpr int BN = BN_, NJ = BN_ / 32, WN = BN_ / 2;
   constexpr int STAGE_BYTES = A_BYTES + BN_ * BK * 2;
   constexpr int GI = 4 + BN_ / 32;  // DMA wave-instructions per slab per wave
@@ -258,6 +270,10 @@ __global__ __launch_bounds__(256, 2) void gemm_fast_kernel(const tfasr_gemm_args
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < NJ; ++j) acc[i][j] = float4_t{0.f, 0.f, 0.f, 0.f};
+    float4_t accb[C_CS ? NJ : 1];
+#pragma unroll
+    for (int j = 0; j < (C_CS ? NJ : 1); ++j) accb[j] = float4_t{0.f, 0.f, 0.f, 0.f};
+    const bool do_cs = C_CS && p.colsum && cur.m0 == 0 && wm == 0;  // first row of tiles, the two waves that cover its columns
 
     const int n = cur.nfull;
 #ifdef TFASR_GEMM_TIMING
@@ -279,7 +295,7 @@ __global__ __launch_bounds__(256, 2) void gemm_fast_kernel(const tfasr_gemm_args
       TFASR_TICK(0)
       __builtin_amdgcn_s_barrier();
       TFASR_TICK(1)
-      mma_slab<TA, TB, BN_>(smem + stage * STAGE_BYTES, smem + stage * STAGE_BYTES + A_BYTES, wm, wn, lane, acc);
+      mma_slab<TA, TB, BN_, C_CS>(smem + stage * STAGE_BYTES, smem + stage * STAGE_BYTES + A_BYTES, wm, wn, lane, acc, accb, do_cs);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       TFASR_TICK(2)
       __builtin_amdgcn_s_barrier();  // every wave is done reading this stage before it is refilled
@@ -294,7 +310,7 @@ __global__ __launch_bounds__(256, 2) void gemm_fast_kernel(const tfasr_gemm_args
       if (TA) tail_trans<128>(sA, cur.A, p.lda, cur.m0, p.M, kt, cur.k_end); else tail_direct<128>(sA, cur.A, p.lda, cur.m0, p.M, kt, cur.k_end);
       if (TB) tail_direct<BN_>(sB, cur.B, p.ldb, cur.n0, p.N, kt, cur.k_end); else tail_trans<BN_>(sB, cur.B, p.ldb, cur.n0, p.N, kt, cur.k_end);
       __syncthreads();
-      mma_slab<TA, TB, BN_>(sA, sB, wm, wn, lane, acc);
+      mma_slab<TA, TB, BN_, C_CS>(sA, sB, wm, wn, lane, acc, accb, do_cs);
       __syncthreads();
     }
     // ---- cross-tile prefetch: both stages are idle now ----
@@ -314,6 +330,15 @@ __global__ __launch_bounds__(256, 2) void gemm_fast_kernel(const tfasr_gemm_args
     const bf16_t* res = p.res ? (const bf16_t*)p.res + doff : nullptr;
     const bf16_t* dz = p.dact_z ? (const bf16_t*)p.dact_z + doff : nullptr;
     bf16_t* prez = p.prez ? (bf16_t*)p.prez + doff : nullptr;
+    if constexpr (C_CS) {
+      if (do_cs && g == 0) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          const int col = n0 + wn * WN + j * 16 + r;
+          if (col < p.N) atomicAdd(p.colsum + col, p.alpha * accb[j][0]);
+        }
+      }
+    }
     if (!C_WS && p.accumulate) {
       // split-K / gradient accumulation: f32 atomics straight from the MFMA fragment layout (16 consecutive
       // columns x 4 rows per instruction = 4 cache lines), no other epilogue terms are legal here
@@ -552,7 +577,7 @@ int launch_one(const tfasr_gemm_args& a, hipStream_t stream) {
   }
   // (measured: NOT faster than the atomics - 34.8 vs 33.0 us on the [256,1024,19040] weight gradient, +5 ms on the step from
   // the extra workspace traffic - so callers only pass a workspace when TFASR_SPLITK_WS=1; kept as the deterministic option)
-  if (a.accumulate && split > 1 && a.nb1 * a.nb2 == 1 && a.ws && a.ws_elems >= (long)split * a.M * a.N && !narrow) {
+  if (a.accumulate && split > 1 && a.nb1 * a.nb2 == 1 && a.ws && a.ws_elems >= (long)split * a.M * a.N && !narrow && !a.colsum) {
     const int st = launch_epi<TA, TB, 128, E_WS>(a, grid, stream);
     if (st != TFASR_STATUS_SUCCESS) return st;
     const long work = ((long)a.M * a.N + 3) / 4;
@@ -560,6 +585,12 @@ int launch_one(const tfasr_gemm_args& a, hipStream_t stream) {
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rg), dim3(256), 0, stream, (const float*)a.ws, (float*)a.D, a.M, a.N, a.ldd, split);
     TFASR_CHECK_LAUNCH();
     return TFASR_STATUS_SUCCESS;
+  }
+  if (a.colsum) {
+    if constexpr (TA && !TB) {
+      if (!narrow && a.accumulate) return launch_epi<TA, TB, 128, E_CSUM>(a, grid, stream);
+    }
+    return TFASR_STATUS_UNSUPPORTED;  // tfasr_gemm falls back to a separate column-sum pass
   }
   if (narrow) return generic || need ? launch_epi<TA, TB, 64, E_GEN>(a, grid, stream) : launch_epi<TA, TB, 64, 0>(a, grid, stream);
   if (!generic) {

@@ -498,7 +498,7 @@ inline bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 // returns TFASR_STATUS_UNSUPPORTED when the preconditions do not hold (caller falls back)
 int tfasr_gemm_pipe_try(const tfasr_gemm_args& a, hipStream_t stream) {
-  if (a.dtype != TFASR_BF16) return TFASR_STATUS_UNSUPPORTED;
+  if (a.dtype != TFASR_BF16 || a.colsum) return TFASR_STATUS_UNSUPPORTED;
   if (!al16(a.A) || !al16(a.B) || (a.lda & 7) || (a.ldb & 7)) return TFASR_STATUS_UNSUPPORTED;
   if ((a.sA1 & 7) || (a.sA2 & 7) || (a.sB1 & 7) || (a.sB2 & 7)) return TFASR_STATUS_UNSUPPORTED;
   if (a.trans_a && ((a.M + 7) & ~7) > a.lda) return TFASR_STATUS_UNSUPPORTED;

@@ -107,7 +107,7 @@ def rnnt_loss_packed(logits, labels, label_len, logit_len, cell_off, total_cells
 # ---------------------------------------------------------------------------------------------- GEMM
 def gemm(A, B, out, M, N, K, lda, ldb, ldd, trans_a=False, trans_b=False, bias=None, res=None, dact_z=None,
          prez=None, alpha=1.0, beta=1.0, act=ACT_NONE, dact=ACT_NONE, nb1=1, nb2=1, sA=(0, 0), sB=(0, 0), sD=(0, 0),
-         accumulate=False, split_k=1, drop_p=0.0, drop_seed=0):
+         accumulate=False, split_k=1, drop_p=0.0, drop_seed=0, colsum=None):
     """Raw strided (two-level batched) GEMM; see include/tfasr_hip.h."""
     a = GemmArgs()
     a.A, a.B, a.D = A.data_ptr(), B.data_ptr(), out.data_ptr()
@@ -128,6 +128,7 @@ def gemm(A, B, out, M, N, K, lda, ldb, ldd, trans_a=False, trans_b=False, bias=N
     a.accumulate = int(accumulate)
     a.split_k = split_k
     a.drop_p, a.drop_seed = drop_p, drop_seed
+    a.colsum = colsum.data_ptr() if colsum is not None else None
     if accumulate:
         assert out.dtype == torch.float32
         if _SPLITK_WS and split_k > 1 and nb1 * nb2 == 1:  # opt-in: k-slices reduce through a workspace (deterministic sums)

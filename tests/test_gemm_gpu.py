@@ -119,3 +119,21 @@ def test_attention_product_shapes_narrow_tile(dev, dtype):
     ref = torch.einsum("bhts,bthe->bshe", pd.float().cpu()[..., :T], datt.float().cpu().view(Bn, T, H, dh)).reshape(Bn * T, HD)
     np.testing.assert_allclose(dv[:, 2 * HD:].float().cpu().numpy(), ref.numpy(), rtol=rtol, atol=atol * 6)
     assert dv[:, :2 * HD].abs().max().item() == 0
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K,split", [(144, 576, 5000, 8), (256, 1024, 4096, 1), (40, 48, 333, 3)])
+def test_weight_gradient_with_fused_bias_gradient(dev, dtype, M, N, K, split):
+    """tfasr_gemm_args.colsum: gW += alpha x^T dy and gb += alpha colsum(dy) from one launch (bf16 fast path: an all-ones MFMA
+    row in the first row of tiles; f32 / narrow shapes: the library falls back to a separate pass)."""
+    g = torch.Generator().manual_seed(11)
+    X, dY = torch.randn(K, M, generator=g), torch.randn(K, N, generator=g)
+    Xd, Yd = X.to(dev).to(dtype), dY.to(dev).to(dtype)
+    out = torch.ones(M, N, dtype=torch.float32, device=dev)
+    gb = torch.full((N,), 2.0, dtype=torch.float32, device=dev)
+    kernels.gemm(Xd, Yd, out, M, N, K, M, N, N, trans_a=True, accumulate=True, split_k=split, alpha=0.5, colsum=gb)
+    ref = 1.0 + 0.5 * (Xd.float().cpu().T @ Yd.float().cpu())
+    refb = 2.0 + 0.5 * Yd.float().cpu().sum(0)
+    rtol, atol = _tol(dtype)
+    np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=rtol, atol=atol * 70)
+    np.testing.assert_allclose(gb.cpu().numpy(), refb.numpy(), rtol=1e-3, atol=atol * 70)
