@@ -66,6 +66,40 @@ __device__ __forceinline__ void issue_trans(char* s, const bf16_t* g, long ld, i
     __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(s + __builtin_amdgcn_readfirstlane(q * 1024)), 16, 0, 0);
   }
 }
+// Per-tile source pointers for the DMA (slab 0), so that issuing a slab costs one 64-bit add per instruction instead of the
+// whole address computation (row clamp, swizzle key, 64-bit multiply): measured, the 8 DMA instructions of a slab took ~950
+// cycles to issue per wave - more than the slab's 32 MFMAs - with the addresses recomputed every slab.
+template <int ROWS>
+__device__ __forceinline__ void prep_direct(const bf16_t* (&src)[ROWS / 32], const bf16_t* g, long ld, int rows0, int nrows, int kt, int w, int lane) {
+#pragma unroll
+  for (int i = 0; i < ROWS / 32; ++i) {
+    const int q = w * (ROWS / 32) + i;
+    const int row = q * 8 + (lane >> 3), p = lane & 7;
+    const int gr = min(rows0 + row, nrows - 1);
+    src[i] = g + (long)gr * ld + kt + ((p ^ key_d(row)) << 3);
+  }
+}
+template <int ROWS>
+__device__ __forceinline__ void prep_trans(const bf16_t* (&src)[ROWS / 32], const bf16_t* g, long ld, int rows0, int nrows, int kt, int w, int lane) {
+  const int maxchunk = ((nrows + 7) >> 3) - 1;
+  constexpr int CPR = ROWS / 8, KPI = 64 / CPR;
+#pragma unroll
+  for (int i = 0; i < ROWS / 32; ++i) {
+    const int q = w * (ROWS / 32) + i;
+    const int k = q * KPI + lane / CPR, p = lane % CPR;
+    const int c = min((rows0 >> 3) + (p ^ (ROWS == 128 ? key_t(k) : key_t64(k))), maxchunk);
+    src[i] = g + (long)(kt + k) * ld + ((long)c << 3);
+  }
+}
+// issue one slab: src + delta elements (delta = slab*BK for a k-contiguous operand, slab*BK*ld for a k-strided one)
+template <int ROWS>
+__device__ __forceinline__ void issue_from(char* s, const bf16_t* const (&src)[ROWS / 32], long delta, int w) {
+#pragma unroll
+  for (int i = 0; i < ROWS / 32; ++i) {
+    const int q = w * (ROWS / 32) + i;
+    __builtin_amdgcn_global_load_lds(GLB_PTR(src[i] + delta), LDS_PTR(s + __builtin_amdgcn_readfirstlane(q * 1024)), 16, 0, 0);
+  }
+}
 // K-tail staging with zero fill (plain stores into the same swizzled images)
 template <int ROWS>
 __device__ __forceinline__ void tail_direct(char* s, const bf16_t* g, long ld, int rows0, int nrows, int kt, int k_end) {
@@ -202,7 +236,7 @@ __global__ __launch_bounds__(256, 2) void gemm_fast_kernel(const tfasr_gemm_args
   int kchunk = (p.K + split - 1) / split;
   kchunk = ((kchunk + BK - 1) / BK) * BK;
 
-  struct Tile { const bf16_t* A; const bf16_t* B; long doff; int m0, n0, k_begin, k_end, nfull, tail, ks; };
+  struct Tile { const bf16_t* A; const bf16_t* B; long doff; int m0, n0, k_begin, k_end, nfull, tail, ks; const bf16_t* sa[4]; const bf16_t* sb[BN_ / 32]; };
   // XCD-aware tile order (hardware deals consecutive workgroup ids round-robin over the 8 XCDs, each with its own L2):
   //  * plain / batched: in every round each XCD owns one contiguous run of the n-fastest tile sequence, so the n-tiles
   //    sharing an A row-block hit the same L2 instead of fetching it over the fabric once per XCD;
@@ -245,14 +279,16 @@ __global__ __launch_bounds__(256, 2) void gemm_fast_kernel(const tfasr_gemm_args
     const int len = max(T.k_end - T.k_begin, 0);
     T.nfull = len / BK;
     T.tail = (len % BK) != 0;
+    if (TA) prep_trans<128>(T.sa, T.A, p.lda, T.m0, p.M, T.k_begin, w, lane); else prep_direct<128>(T.sa, T.A, p.lda, T.m0, p.M, T.k_begin, w, lane);
+    if (TB) prep_direct<BN_>(T.sb, T.B, p.ldb, T.n0, p.N, T.k_begin, w, lane); else prep_trans<BN_>(T.sb, T.B, p.ldb, T.n0, p.N, T.k_begin, w, lane);
     return T;
   };
+  const long stepA = TA ? (long)BK * p.lda : (long)BK, stepB = TB ? (long)BK : (long)BK * p.ldb;  // elements per slab
   auto issue = [&](const Tile& T, int slab, int stage) {
     char* sA = smem + stage * STAGE_BYTES;
     char* sB = sA + A_BYTES;
-    const int kt = T.k_begin + slab * BK;
-    if (TA) issue_trans<128>(sA, T.A, p.lda, T.m0, p.M, kt, w, lane); else issue_direct<128>(sA, T.A, p.lda, T.m0, p.M, kt, w, lane);
-    if (TB) issue_direct<BN_>(sB, T.B, p.ldb, T.n0, p.N, kt, w, lane); else issue_trans<BN_>(sB, T.B, p.ldb, T.n0, p.N, kt, w, lane);
+    issue_from<128>(sA, T.sa, slab * stepA, w);
+    issue_from<BN_>(sB, T.sb, slab * stepB, w);
   };
 
   Tile cur = tile_of(0);
