@@ -381,7 +381,7 @@ __global__ __launch_bounds__(256) void joint_fwd_kernel(const T* __restrict__ en
     ld8(enc + bt * J + j, a);
     ld8(pred + ((long)b * U1 + u) * J + j, p);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) a[k] = tanhf(a[k] + p[k]);
+    for (int k = 0; k < 8; ++k) a[k] = tanh_fast(a[k] + p[k]);
     st8(h + i * 8, a);
   }
 }
@@ -430,8 +430,32 @@ __global__ __launch_bounds__(256) void joint_fwd_packed_kernel(const T* __restri
     ld8(enc + ((long)b * Tn + t) * J + j, a);
     ld8(pred + ((long)b * U1 + u) * J + j, p);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) a[k] = tanhf(a[k] + p[k]);
+    for (int k = 0; k < 8; ++k) a[k] = tanh_fast(a[k] + p[k]);
     st8(h + i * 8, a);
+  }
+}
+// row-structured variant: block = (t, b); thread = (u sub-lane, 8-column chunk): no per-chunk binary search / 64-bit division,
+// the encoder row is read once per thread and reused for every u
+template <typename T>
+__global__ __launch_bounds__(256) void joint_fwd_packed_rows_kernel(const T* __restrict__ enc, const T* __restrict__ pred,
+                                                                    T* __restrict__ h, const long* __restrict__ cell_off,
+                                                                    const int32_t* __restrict__ label_len, int Tn, int U1, int J) {
+  const int b = blockIdx.y, t = blockIdx.x;
+  const int u1b = min(label_len[b], U1 - 1) + 1;
+  const long r0 = cell_off[b];
+  const int Tl = (int)((cell_off[b + 1] - r0) / u1b);
+  if (t >= Tl) return;
+  const int j8 = J / 8, nu = blockDim.x / j8;
+  const int us = threadIdx.x / j8, c = (threadIdx.x - us * j8) * 8;
+  if (us >= nu) return;
+  float a[8];
+  ld8(enc + ((long)b * Tn + t) * J + c, a);
+  for (int u = us; u < u1b; u += nu) {
+    float p[8];
+    ld8(pred + ((long)b * U1 + u) * J + c, p);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) p[k] = tanh_fast(a[k] + p[k]);
+    st8(h + (r0 + (long)t * u1b + u) * J + c, p);
   }
 }
 template <typename T, int MODE>
@@ -741,6 +765,14 @@ extern "C" int tfasr_joint_fwd_packed(const void* enc, const void* pred, void* h
   if (!enc || !pred || !h || !cell_off || !label_len || total_cells <= 0 || B <= 0 || T <= 0 || U1 <= 0 || J <= 0 || J % 8)
     return TFASR_STATUS_INVALID_VALUE;
   hipStream_t s = (hipStream_t)stream_;
+  if (J / 8 <= 256) {
+    dim3 g2(T, B);
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL(joint_fwd_packed_rows_kernel<float>, g2, dim3(256), 0, s, (const float*)enc, (const float*)pred, (float*)h, cell_off, label_len, T, U1, J),
+               hipLaunchKernelGGL(joint_fwd_packed_rows_kernel<bf16_t>, g2, dim3(256), 0, s, (const bf16_t*)enc, (const bf16_t*)pred, (bf16_t*)h, cell_off, label_len, T, U1, J));
+    TFASR_CHECK_LAUNCH();
+    return TFASR_STATUS_SUCCESS;
+  }
   const int grid = flat_grid(total_cells * J / 8);
   DISPATCH_T(dtype,
              hipLaunchKernelGGL(joint_fwd_packed_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)enc, (const float*)pred, (float*)h, cell_off, label_len, total_cells, B, T, U1, J),

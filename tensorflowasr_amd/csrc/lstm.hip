@@ -45,9 +45,9 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(
     z[q] = Num<T>::ld(xg + b * xg_stride_b + q * P + p);
     if (hr) z[q] += hr[(long)b * 4 * P + q * P + p];
   }
-  const float ig = sigmoidf_(z[0]), fg = sigmoidf_(z[1]), gg = tanhf(z[2]), og = sigmoidf_(z[3]);
+  const float ig = sigmoidf_(z[0]), fg = sigmoidf_(z[1]), gg = tanh_fast(z[2]), og = sigmoidf_(z[3]);
   const float c = fg * cp + ig * gg;
-  const float h = og * tanhf(c);
+  const float h = og * tanh_fast(c);
   c_out[b * c_stride_b + p] = c;
   Num<T>::st(h_out + b * h_stride_b + p, h);
   if (y_out) Num<T>::st(y_out + b * y_stride_b + p, h);
