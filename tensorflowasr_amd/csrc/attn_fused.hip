@@ -342,6 +342,28 @@ __global__ __launch_bounds__(256, 2) void relattn_fused_bwd_q_kernel(
 #pragma unroll
   for (int n = 0; n < 4; ++n) acc_q[n] = float4_t{0.f, 0.f, 0.f, 0.f};
   float bias_acc[4] = {0.f, 0.f, 0.f, 0.f};
+  // loop-invariant per-lane quantities of the dS phase
+  const float scale2 = scale * 1.4426950408889634f;
+  const int lim = 2 * len - 1;
+  int rr0[4], goff[4], poff[4][4];
+  bool live[4], inrow[4];
+  float lsei2[4];
+  bf16_t* prow_e[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int il = g * 4 + e, i = i0 + w * 16 + il;
+    rr0[e] = T - 1 - i + r;
+    goff[e] = il * GLD + (63 - w * 16 - il + r);
+    inrow[e] = i < T;
+    live[e] = inrow[e] && !(use_mask && i >= len);
+    lsei2[e] = lsei[e] * 1.4426950408889634f;
+    prow_e[e] = dpos + (((long)b * H + h) * T + min(i, T - 1)) * ldp + (T - 1 - i + shift) + r;  // + jl + j0 = column rr + shift
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) {
+      const int jl = jt * 16 + r;
+      poff[e][jt] = il * 128 + (((jl >> 3) ^ key_d(il)) << 4) + (jl & 7) * 2;
+    }
+  }
 
   const int njb = (T + BJ - 1) / BJ;
   for (int jb = 0; jb < njb; ++jb) {
@@ -383,29 +405,26 @@ __global__ __launch_bounds__(256, 2) void relattn_fused_bwd_q_kernel(
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
 
-    // ds in C layout (row il = g*4+e, col jl = jt*16+r); skewed copy straight to HBM
+    // ds in C layout (row il = g*4+e, col jl = jt*16+r); skewed copy straight to HBM.  All per-lane offsets (window gather,
+    // dpos row pointer, A-image slot, validity threshold) are loop invariants computed once before the key loop.
     float ds[4][4];
+    const bool ragged = (j0 + BJ > T);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const int il = g * 4 + e;
-      const int i = i0 + w * 16 + il;
-      const bool qmask = use_mask && (i >= len);
-      const float gbias = sG[il * GLD + 127];
+      const float gbias = sG[(g * 4 + e) * GLD + 127];
 #pragma unroll
       for (int jt = 0; jt < 4; ++jt) {
-        const int jl = jt * 16 + r, j = j0 + jl;
-        const int rr = T - 1 - i + j;
-        const bool valid_r = rr < 2 * len - 1;
-        const float pos = valid_r ? sG[il * GLD + (63 - w * 16 - il + jl)] : gbias;
+        const bool valid_r = rr0[e] + jt * 16 + j0 < lim;
+        const float pos = valid_r ? sG[goff[e] + jt * 16] : gbias;
         float d = 0.f;
-        if (!qmask && j < T && i < T) {
-          const float sc = (acc_s[jt][e] + pos) * scale;
-          const float p = __expf(sc - lsei[e]);
+        const bool jin = !ragged || (j0 + jt * 16 + r < T);
+        if (live[e] && jin) {
+          const float p = __builtin_amdgcn_exp2f((acc_s[jt][e] + pos) * scale2 - lsei2[e]);
           d = p * (acc_p[jt][e] - Di[e]) * scale;
         }
         ds[e][jt] = d;
-        if (i < T && j < T) {
-          if (valid_r) dpos[(((long)b * H + h) * T + i) * ldp + rr + shift] = f32_to_bf16(d);
+        if (inrow[e] && jin) {
+          if (valid_r) prow_e[e][jt * 16 + j0] = f32_to_bf16(d);
           else bias_acc[e] += d;
         }
       }
@@ -414,14 +433,9 @@ __global__ __launch_bounds__(256, 2) void relattn_fused_bwd_q_kernel(
     __builtin_amdgcn_sched_barrier(0);
     // dS (bf16) as A operand image [16 rows il][64 k = jl] in the (now dead) G strip
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int il = g * 4 + e;
+    for (int e = 0; e < 4; ++e)
 #pragma unroll
-      for (int jt = 0; jt < 4; ++jt) {
-        const int jl = jt * 16 + r;
-        *reinterpret_cast<bf16_t*>(sA + il * 128 + (((jl >> 3) ^ key_d(il)) << 4) + (jl & 7) * 2) = f32_to_bf16(ds[e][jt]);
-      }
-    }
+      for (int jt = 0; jt < 4; ++jt) *reinterpret_cast<bf16_t*>(sA + poff[e][jt]) = f32_to_bf16(ds[e][jt]);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     // dqu += dS @ K   (B operand: K block read transposed, k = j)
@@ -504,6 +518,24 @@ __global__ __launch_bounds__(256, 2) void relattn_fused_bwd_k_kernel(
 #pragma unroll
   for (int n = 0; n < 4; ++n) { acc_k[n] = float4_t{0.f, 0.f, 0.f, 0.f}; acc_v[n] = float4_t{0.f, 0.f, 0.f, 0.f}; }
 
+  // loop-invariant per-lane quantities of the pT / dsT phase (this block's keys are fixed: j = j0 + w*16 + g*4 + e)
+  const float scale2 = scale * 1.4426950408889634f;
+  const int lim = 2 * len - 1;
+  const long lrow = ((long)b * H + h) * T;
+  int rrk[4], gtoff[4], aoff[4][4];
+  bool jin[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int jl = w * 16 + g * 4 + e, row = g * 4 + e;
+    rrk[e] = T - 1 + j0 + jl;                          // - i = relative-position row
+    gtoff[e] = (63 + jl) * GTLD + r * (1 - GTLD);      // + it*16*(1-GTLD): Gt[(63 - il) + jl][il]
+    jin[e] = j0 + jl < T;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int il = it * 16 + r;
+      aoff[e][it] = row * 128 + (((il >> 3) ^ key_d(row)) << 4) + (il & 7) * 2;
+    }
+  }
   const int nib = (T + BI - 1) / BI;
   for (int ib = 0; ib < nib; ++ib) {
     const int i0 = ib * BI;
@@ -549,29 +581,27 @@ __global__ __launch_bounds__(256, 2) void relattn_fused_bwd_k_kernel(
     __syncthreads();  // Gt complete; the window and the qv block are dead from here on
 
     // pT and dsT in C layout (row jl = g*4+e of this wave, col il = it*16+r) -> A-operand images [16 jl][64 k = il]
+    // (window-gather offsets, image slots and the validity threshold are loop invariants hoisted above the query loop)
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
       const int il = it * 16 + r, i = i0 + il;
       const int ic = min(i, T - 1);
-      const float lse_i = lse[((long)b * H + h) * T + ic];
-      const float D_i = dvec[((long)b * H + h) * T + ic];
+      const float lse2 = lse[lrow + ic] * 1.4426950408889634f;
+      const float D_i = dvec[lrow + ic];
       const bool qmask = use_mask && (i >= len);
+      const bool iin = i < T;
       const float gbias = sGt[127 * GTLD + il];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const int jl = w * 16 + g * 4 + e, j = j0 + jl;
-        const int rr = T - 1 - i + j;
-        const float pos = (rr < 2 * len - 1) ? sGt[((63 - il) + jl) * GTLD + il] : gbias;
+        const float pos = (rrk[e] - i < lim) ? sGt[gtoff[e] + it * 16 * (1 - GTLD)] : gbias;
         float p = 0.f, d = 0.f;
-        if (i < T && j < T) {
-          const float sc = qmask ? 0.f : (acc_s[it][e] + pos) * scale;
-          p = __expf(sc - lse_i);
+        if (iin && jin[e]) {
+          const float s2 = qmask ? 0.f : (acc_s[it][e] + pos) * scale2;
+          p = __builtin_amdgcn_exp2f(s2 - lse2);
           d = qmask ? 0.f : p * (acc_p[it][e] - D_i) * scale;
         }
-        const int row = g * 4 + e;
-        const int off = row * 128 + (((il >> 3) ^ key_d(row)) << 4) + (il & 7) * 2;
-        *reinterpret_cast<bf16_t*>(sAp + off) = f32_to_bf16(p);
-        *reinterpret_cast<bf16_t*>(sAs + off) = f32_to_bf16(d);
+        *reinterpret_cast<bf16_t*>(sAp + aoff[e][it]) = f32_to_bf16(p);
+        *reinterpret_cast<bf16_t*>(sAs + aoff[e][it]) = f32_to_bf16(d);
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
