@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define TFASR_ABI_VERSION 8
+#define TFASR_ABI_VERSION 9
 
 typedef enum {
   TFASR_STATUS_SUCCESS = 0,
@@ -283,6 +283,13 @@ int tfasr_col2im_3x3s2(const void* dcol, void* dx, int B, int T1, int F1, int C,
 int tfasr_logmel(const float* signal, int B, int N, float preemph, const float* window, int frame_len, int frame_step,
                  int nfft, const float* melw, const int32_t* band, int F, float eps, void* out, int T0, int dtype,
                  void* stream);
+
+/* CTC prefix beam search (CtcModel.recognize_beam -> tf.nn.ctc_beam_search_decoder(beam_width), base_ctc.py:127-149).  A HOST
+ * routine, like the reference's op: logits [B,T,V] and logit_len [B] are HOST pointers; tokens [B,T] (0-padded, the dense
+ * form of the top path), tokens_len [B], log_prob [B] (optional) are HOST outputs.  blank_index: the reference's call treats
+ * class V-1 as blank (TF's decoder convention) although the model's blank is 0 - pass V-1 to reproduce it. */
+int tfasr_ctc_beam_search_host(const float* logits, const int32_t* logit_len, int B, int T, int V, int beam_width,
+                               int blank_index, int32_t* tokens, int32_t* tokens_len, float* log_prob);
 
 /* ------------------------------------------------------------------------------------------------
  * Native executor of one Conformer block (ConformerBlock.call, encoders/conformer.py:430-520, and its backward):

@@ -57,3 +57,55 @@ def ctc_greedy_decode(logits, logit_len, blank=0):
             prev = c
         lens[b] = n
     return out, lens
+
+
+def ctc_beam_search(logits, T_len, beam_width, blank):
+    """Textbook CTC prefix beam search in the log domain (the algorithm of tf.nn.ctc_beam_search_decoder, top path, no
+    repeated-label merging beyond CTC's collapse).  logits [T,V] of one utterance -> (labels, log prob)."""
+    x = np.asarray(logits, np.float64)[:T_len]
+    lp = x - np.logaddexp.reduce(x, axis=1, keepdims=True)
+    NEG = -np.inf
+    beams = {(): (0.0, NEG)}
+    for t in range(T_len):
+        nxt = {}
+
+        def add(k, pb=NEG, pnb=NEG):
+            a, b_ = nxt.get(k, (NEG, NEG))
+            nxt[k] = (np.logaddexp(a, pb), np.logaddexp(b_, pnb))
+
+        for pre, (pb, pnb) in beams.items():
+            tot = np.logaddexp(pb, pnb)
+            add(pre, pb=tot + lp[t, blank])
+            if pre:
+                add(pre, pnb=pnb + lp[t, pre[-1]])
+            for c in range(lp.shape[1]):
+                if c == blank:
+                    continue
+                src = pb if (pre and pre[-1] == c) else tot
+                if src > NEG:
+                    add(pre + (c,), pnb=src + lp[t, c])
+        ranked = sorted(nxt.items(), key=lambda kv: (-np.logaddexp(*kv[1]), kv[0]))[:beam_width]
+        beams = dict(ranked)
+    best = min(beams.items(), key=lambda kv: (-np.logaddexp(*kv[1]), kv[0]))
+    return list(best[0]), float(np.logaddexp(*best[1]))
+
+
+def ctc_best_labelling_bruteforce(logits, blank):
+    """argmax over LABELLINGS of the total path probability, by enumerating every alignment (tiny T, V only)."""
+    import itertools
+
+    x = np.asarray(logits, np.float64)
+    lp = x - np.logaddexp.reduce(x, axis=1, keepdims=True)
+    T, V = lp.shape
+    tot = {}
+    for path in itertools.product(range(V), repeat=T):
+        lab, prev = [], None
+        for c in path:
+            if c != blank and c != prev:
+                lab.append(c)
+            prev = c
+        p = sum(lp[t, c] for t, c in enumerate(path))
+        k = tuple(lab)
+        tot[k] = np.logaddexp(tot.get(k, -np.inf), p)
+    best = min(tot.items(), key=lambda kv: (-kv[1], kv[0]))
+    return list(best[0]), float(best[1])

@@ -463,6 +463,23 @@ def ctc_loss_fwd_bwd(logits, labels, label_len, logit_len, grad_scale=None, grad
     return costs, (grads if want_grads else None)
 
 
+def ctc_beam_search(logits, logit_len, beam_width=10, blank_index=None):
+    """tf.nn.ctc_beam_search_decoder semantics (top path, dense, 0 padded).  Host routine (as in the reference): the logits
+    are copied to host memory.  blank_index=None reproduces the reference call (TF convention: the LAST class is blank)."""
+    import numpy as np
+
+    x = logits.detach().float().cpu().contiguous().numpy()
+    B, T, V = x.shape
+    ln = np.ascontiguousarray(logit_len.detach().cpu().numpy() if hasattr(logit_len, "detach") else logit_len, dtype=np.int32)
+    toks = np.zeros((B, T), np.int32)
+    n = np.zeros(B, np.int32)
+    lp = np.zeros(B, np.float32)
+    bi = V - 1 if blank_index is None else int(blank_index)
+    check(_L().tfasr_ctc_beam_search_host(x.ctypes.data, ln.ctypes.data, B, T, V, int(beam_width), bi, toks.ctypes.data, n.ctypes.data,
+                                          lp.ctypes.data), "ctc_beam_search")
+    return torch.from_numpy(toks), torch.from_numpy(n), torch.from_numpy(lp)
+
+
 def ctc_greedy_decode(logits, logit_len, blank=0):
     B, T, V = logits.shape
     am = torch.empty(B * T, dtype=torch.int32, device=logits.device)

@@ -87,3 +87,44 @@ def test_loss_objects_reference_interface(dev):
     cl, _ = ctc_ref.ctc_loss_and_grad(clog, labels, ul, [12, 12, 9])
     got = CtcLoss()(TrainLabel(torch.from_numpy(labels), torch.from_numpy(ul)), TrainOutput(torch.from_numpy(clog).to(dev), torch.tensor([12, 12, 9], dtype=torch.int32)))
     np.testing.assert_allclose(float(got), cl.mean(), rtol=2e-5)
+
+
+def test_ctc_beam_search_host_routine_matches_oracle_and_bruteforce():
+    """a25: tf.nn.ctc_beam_search_decoder semantics.  The library routine is host code (like the reference's op), so this runs
+    without a GPU: vs the oracle's prefix beam search on random cases, and vs exhaustive enumeration when the beam is wide
+    enough to be exact."""
+    import ctypes
+
+    from tensorflowasr_amd import _lib
+
+    lib = _lib.load()
+    rng = np.random.default_rng(5)
+
+    def run(x, lens, beam, blank):
+        B, T, V = x.shape
+        toks, n, lp = np.zeros((B, T), np.int32), np.zeros(B, np.int32), np.zeros(B, np.float32)
+        x = np.ascontiguousarray(x, np.float32)
+        ln = np.asarray(lens, np.int32)
+        st = lib.tfasr_ctc_beam_search_host(x.ctypes.data, ln.ctypes.data, B, T, V, beam, blank, toks.ctypes.data, n.ctypes.data, lp.ctypes.data)
+        assert st == 0
+        return toks, n, lp
+
+    # exact against enumeration (T=5, V=4: 1024 alignments), both blank conventions
+    for blank in (0, 3):
+        x = rng.standard_normal((3, 5, 4)) * 2.0
+        toks, n, lp = run(x, [5, 5, 4], 64, blank)
+        for b, Tb in enumerate([5, 5, 4]):
+            lab, p = ctc_ref.ctc_best_labelling_bruteforce(x[b, :Tb], blank)
+            assert toks[b, :n[b]].tolist() == lab and abs(lp[b] - p) < 1e-4
+            assert (toks[b, n[b]:] == 0).all()
+    # narrow beams on longer inputs: same pruning decisions as the oracle
+    x = rng.standard_normal((4, 30, 12)) * 3.0
+    lens = [30, 17, 25, 1]
+    for beam in (1, 4, 10):
+        toks, n, lp = run(x, lens, beam, 11)
+        for b, Tb in enumerate(lens):
+            lab, p = ctc_ref.ctc_beam_search(x[b], Tb, beam, 11)
+            assert toks[b, :n[b]].tolist() == lab, (beam, b)
+            assert abs(lp[b] - p) < 1e-3
+    # argument checking
+    assert lib.tfasr_ctc_beam_search_host(None, None, 1, 1, 2, 1, 0, None, None, None) != 0
