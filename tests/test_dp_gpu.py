@@ -1,0 +1,89 @@
+"""GPU, world_size 2 on ONE device (gloo carries the collectives; RCCL refuses two ranks on one GPU): the data-parallel
+train step - utterance sharding, sync-BN statistics all-reduced between the native block executor's phases A and B (forward
+and backward), bucketed gradient all-reduce announced while the backward walks down the encoder - gives the gradients of the
+single-process step on the concatenated batch."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _batch(cfg, lens, ulens, seed=4, N=4000, U=6):
+    from tensorflowasr_amd.schemas import TrainData, TrainInput, TrainLabel
+
+    rng = np.random.default_rng(seed)
+    B = len(lens)
+    sig = np.clip(rng.standard_normal((B, N)) * 0.1, -1, 1).astype(np.float32)
+    for b, n in enumerate(lens):
+        sig[b, n:] = 0.0
+    labels = rng.integers(1, cfg.vocab_size, (B, U)).astype(np.int32)
+    for b, u in enumerate(ulens):
+        labels[b, u:] = 0
+    preds = np.concatenate([np.zeros((B, 1), np.int32), labels], 1)
+
+    def make(lo, hi):
+        return TrainData(
+            TrainInput(torch.from_numpy(sig[lo:hi]), torch.tensor(lens[lo:hi], dtype=torch.int32), torch.from_numpy(preds[lo:hi]),
+                       torch.tensor([u + 1 for u in ulens[lo:hi]], dtype=torch.int32)),
+            TrainLabel(torch.from_numpy(labels[lo:hi]), torch.tensor(ulens[lo:hi], dtype=torch.int32)))
+
+    return make
+
+
+LENS, ULENS = [4000, 2700, 3300, 3900], [6, 3, 5, 4]
+
+
+def _worker(rank, world, port, outdir, dtype_name):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from tensorflowasr_amd import configs, dp
+    from tensorflowasr_amd.conformer import ConformerTransducer
+
+    torch.cuda.set_device(0)
+    d = dp.init_from_env(backend="gloo")
+    dtype = getattr(torch, dtype_name)
+    cfg = configs.conformer_tiny(dropout=0.0)
+    model = ConformerTransducer(cfg, torch.device("cuda", 0), dtype=dtype, seed=5, dp=d)
+    d.attach(model.ps.grad)
+    lo, hi = dp.shard_bounds(len(LENS), world, rank)
+    data = _batch(cfg, LENS, ULENS)(lo, hi)
+    model.zero_grad()
+    costs = model.loss_and_backward(data, True, (None, None))
+    torch.cuda.synchronize()
+    torch.save(dict(costs=costs.cpu(), grad=model.ps.grad.cpu(), mm=model.ps.state["enc/block1/conv/bn/mm"].cpu()), os.path.join(outdir, f"r{rank}.pt"))
+    d.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize("dtype_name", ["float32", "bfloat16"])
+def test_two_ranks_match_single_process(dev, tmp_path, dtype_name):
+    from tensorflowasr_amd import configs
+    from tensorflowasr_amd.conformer import ConformerTransducer
+
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), dtype_name), nprocs=world, join=True)
+    outs = [torch.load(os.path.join(tmp_path, f"r{r}.pt")) for r in range(world)]
+    dtype = getattr(torch, dtype_name)
+    cfg = configs.conformer_tiny(dropout=0.0)
+    model = ConformerTransducer(cfg, dev, dtype=dtype, seed=5)
+    model.zero_grad()
+    costs = model.loss_and_backward(_batch(cfg, LENS, ULENS)(0, len(LENS)), True, (None, None))
+    torch.cuda.synchronize()
+    tol = 2e-4 if dtype == torch.float32 else 3e-2
+    np.testing.assert_allclose(torch.cat([o["costs"] for o in outs]).numpy(), costs.cpu().numpy(), rtol=tol)
+    g = model.ps.grad.cpu().numpy()
+    for o in outs:  # every rank holds the all-reduced global-batch gradient
+        np.testing.assert_allclose(o["grad"].numpy(), g, rtol=tol, atol=tol * float(np.abs(g).max()))
+        np.testing.assert_allclose(o["mm"].numpy(), model.ps.state["enc/block1/conv/bn/mm"].cpu().numpy(), rtol=tol, atol=1e-5)
