@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define TFASR_ABI_VERSION 9
+#define TFASR_ABI_VERSION 10
 
 typedef enum {
   TFASR_STATUS_SUCCESS = 0,
@@ -174,6 +174,11 @@ int tfasr_dwconv_fwd(const void* x, const float* w, const float* bias, void* y, 
 int tfasr_dwconv_bwd_data(const void* dy, const float* w, void* dx, int B, int T, int C, int K, int dtype, void* stream);
 int tfasr_dwconv_bwd_weight(const void* x, const void* dy, float* dw, float* dbias, int B, int T, int C, int K,
                             int dtype, void* stream);
+/* same result through a caller-owned workspace of per-block partial sums + a reduce kernel (no atomics; 2.5x faster at the
+ * Conformer-M shape).  Falls back to the entry above when the workspace is NULL / too small or the shape is not covered. */
+int tfasr_dwconv_bwd_weight_workspace_size(int B, int T, int C, int K, size_t* bytes);
+int tfasr_dwconv_bwd_weight_ws(const void* x, const void* dy, float* dw, float* dbias, int B, int T, int C, int K, int dtype,
+                               void* workspace, size_t workspace_bytes, void* stream);
 /* y1 = x + u, y2 = x + v (content / positional attention biases, multihead_attention.py:554-558) and its backward */
 int tfasr_bias2_fwd(const void* x, long ldx, const float* u, const float* v, void* y1, void* y2, long rows, int C,
                     int dtype, void* stream);

@@ -380,6 +380,9 @@ struct Ex {
   }
   void conv_bwd_b(const void* dy, void* dx) {
     const int d = c->d;
+    size_t dwws_bytes = 0;
+    tfasr_dwconv_bwd_weight_workspace_size(c->B, c->T, d, c->ksize, &dwws_bytes);
+    void* dwws = scratch.get(dwws_bytes);  // per-block partial sums of the depthwise weight gradient
     void* dcv = act(scratch, rows * d);
     void* dg = act(scratch, rows * d);
     void* da = act(scratch, rows * 2 * d);
@@ -389,7 +392,7 @@ struct Ex {
       const float inv = 1.f / (float)c->world;
       chk(tfasr_axpy(gp(TFASR_BP_CV_BN_B), io->bn_bstats, inv, d, s));
       chk(tfasr_axpy(gp(TFASR_BP_CV_BN_G), io->bn_bstats + d, inv, d, s));
-      chk(tfasr_dwconv_bwd_weight(k->cv_g, dcv, gp(TFASR_BP_CV_DW_W), gp(TFASR_BP_CV_DW_B), c->B, c->T, d, c->ksize, c->dtype, s));
+      chk(tfasr_dwconv_bwd_weight_ws(k->cv_g, dcv, gp(TFASR_BP_CV_DW_W), gp(TFASR_BP_CV_DW_B), c->B, c->T, d, c->ksize, c->dtype, dwws, dwws_bytes, s));
       chk(tfasr_dwconv_bwd_data(dcv, fp(TFASR_BP_CV_DW_W), dg, c->B, c->T, d, c->ksize, c->dtype, s));
       chk(tfasr_glu_bwd(k->cv_a, dg, da, rows, d, c->dtype, s));
     }

@@ -91,9 +91,12 @@ __global__ __launch_bounds__(256) void dwconv_tile_kernel(const bf16_t* __restri
 
 // dw[k,c] += sum_{b,t} dy[b,t,c] x[b,t-(K-1)+k,c]; dbias[c] += sum dy.  Same staging (x rows t0-(K-1).., dy rows t0..); each
 // thread group walks its 32 steps with the x window held in a 32-slot circular register buffer (compile-time slots).
+// part != nullptr: the block stores its partial sums to part[block][K+1][C] with plain stores (no atomics; a second kernel
+// reduces over blocks) - with atomics the K x C adds per 64 steps made this kernel 2x slower than the scalar one.
 template <int K>
 __global__ __launch_bounds__(256) void dwconv_wgrad_tile_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
-                                                                float* __restrict__ dw, float* __restrict__ dbias, int Tn, int C) {
+                                                                float* __restrict__ dw, float* __restrict__ dbias, int Tn, int C,
+                                                                float* __restrict__ part) {
   static_assert(K <= MAXK, "window");
   extern __shared__ __attribute__((aligned(16))) char lds[];
   char* lx = lds;                                   // 2*TG + K - 1 rows
@@ -124,6 +127,27 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_tile_kernel(const bf16_t* __
 #pragma unroll
     for (int k = 0; k < K; ++k) acc[k] = fma2(d, win[(s - (K - 1) + k) & (MAXK - 1)], acc[k]);
   }
+  if (part) {
+    // combine the two thread groups through LDS (the staged rows are dead), then one partial slab per block
+    __syncthreads();
+    float2_t* red = reinterpret_cast<float2_t*>(lds);  // [K+1][128]
+    if (grp == 1) {
+#pragma unroll
+      for (int k = 0; k < K; ++k) red[k * 128 + pr] = acc[k];
+      red[K * 128 + pr] = ab;
+    }
+    __syncthreads();
+    if (grp == 0 && c < C) {
+      float* o = part + ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * (size_t)(K + 1) * SLAB + 2 * pr;
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        const float2_t v = acc[k] + red[k * 128 + pr];
+        *reinterpret_cast<float2_t*>(o + (size_t)k * SLAB) = v;
+      }
+      *reinterpret_cast<float2_t*>(o + (size_t)K * SLAB) = ab + red[K * 128 + pr];
+    }
+    return;
+  }
   if (c < C) {
 #pragma unroll
     for (int k = 0; k < K; ++k) {
@@ -134,10 +158,52 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_tile_kernel(const bf16_t* __
   }
 }
 
+// dw[k, c] += sum_blocks part[blk][k][c_local] ; dbias likewise (row K).  grid.x = channel slabs, threads over (k, c)
+__global__ __launch_bounds__(256) void dwconv_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, float* __restrict__ dbias,
+                                                                  int nblk_per_slab, int nslab, int K, int C) {
+  const int slab = blockIdx.y;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < (K + 1) * SLAB; i += gridDim.x * blockDim.x) {
+    const int k = i / SLAB, cl = i - k * SLAB, c = slab * SLAB + cl;
+    if (c >= C) continue;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    const float* p = part + (size_t)slab * (K + 1) * SLAB + i;
+    const size_t stride = (size_t)nslab * (K + 1) * SLAB;
+    int b = 0;
+    for (; b + 4 <= nblk_per_slab; b += 4) { s0 += p[(size_t)b * stride]; s1 += p[(size_t)(b + 1) * stride]; s2 += p[(size_t)(b + 2) * stride]; s3 += p[(size_t)(b + 3) * stride]; }
+    for (; b < nblk_per_slab; ++b) s0 += p[(size_t)b * stride];
+    const float v = (s0 + s1) + (s2 + s3);
+    if (k < K) dw[k * C + c] += v;
+    else if (dbias) dbias[c] += v;
+  }
+}
+
 inline bool al4(const void* p) { return (((uintptr_t)p) & 3) == 0; }
 inline bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 }  // namespace
+
+// weight gradient through a workspace of partial sums (no atomics): returns UNSUPPORTED when the shape / workspace does not fit
+int tfasr_dwconv_wgrad_ws_try(const void* x, const void* dy, float* dw, float* dbias, int B, int T, int C, int K, float* ws, size_t ws_bytes,
+                              hipStream_t s) {
+  if ((C & 7) || !al16(x) || !al16(dy) || !ws) return TFASR_STATUS_UNSUPPORTED;
+  const int gx = (C + SLAB - 1) / SLAB, gy = (T + 2 * TG - 1) / (2 * TG);
+  const size_t need = (size_t)B * gy * gx * (K + 1) * SLAB * 4;
+  if (ws_bytes < need) return TFASR_STATUS_UNSUPPORTED;
+  dim3 grid(gx, gy, B);
+  const int smem = (2 * TG + MAXK - 1 + 2 * TG) * ROWB;
+  switch (K) {
+    case 31: hipLaunchKernelGGL((dwconv_wgrad_tile_kernel<31>), grid, dim3(256), smem, s, (const bf16_t*)x, (const bf16_t*)dy, dw, dbias, T, C, ws); break;
+    case 32: hipLaunchKernelGGL((dwconv_wgrad_tile_kernel<32>), grid, dim3(256), smem, s, (const bf16_t*)x, (const bf16_t*)dy, dw, dbias, T, C, ws); break;
+    case 15: hipLaunchKernelGGL((dwconv_wgrad_tile_kernel<15>), grid, dim3(256), smem, s, (const bf16_t*)x, (const bf16_t*)dy, dw, dbias, T, C, ws); break;
+    case 7: hipLaunchKernelGGL((dwconv_wgrad_tile_kernel<7>), grid, dim3(256), smem, s, (const bf16_t*)x, (const bf16_t*)dy, dw, dbias, T, C, ws); break;
+    default: return TFASR_STATUS_UNSUPPORTED;
+  }
+  TFASR_CHECK_LAUNCH();
+  dim3 rg(((K + 1) * SLAB + 255) / 256, gx);
+  hipLaunchKernelGGL(dwconv_wgrad_reduce_kernel, rg, dim3(256), 0, s, (const float*)ws, dw, dbias, B * gy, gx, K, C);
+  TFASR_CHECK_LAUNCH();
+  return TFASR_STATUS_SUCCESS;
+}
 
 // return TFASR_STATUS_UNSUPPORTED when the caller must use the scalar kernels
 int tfasr_dwconv_pair_try(int which, const void* x, const void* dy, const float* w, const float* bias, void* y, float* dw, float* dbias, int B,
@@ -162,10 +228,10 @@ int tfasr_dwconv_pair_try(int which, const void* x, const void* dy, const float*
   if (!wgrad_tile || !al16(x) || !al16(dy)) return TFASR_STATUS_UNSUPPORTED;
   const int smem = (2 * TG + MAXK - 1 + 2 * TG) * ROWB;
   switch (K) {
-    case 31: hipLaunchKernelGGL((dwconv_wgrad_tile_kernel<31>), grid, dim3(256), smem, s, (const bf16_t*)x, (const bf16_t*)dy, dw, dbias, T, C); break;
-    case 32: hipLaunchKernelGGL((dwconv_wgrad_tile_kernel<32>), grid, dim3(256), smem, s, (const bf16_t*)x, (const bf16_t*)dy, dw, dbias, T, C); break;
-    case 15: hipLaunchKernelGGL((dwconv_wgrad_tile_kernel<15>), grid, dim3(256), smem, s, (const bf16_t*)x, (const bf16_t*)dy, dw, dbias, T, C); break;
-    case 7: hipLaunchKernelGGL((dwconv_wgrad_tile_kernel<7>), grid, dim3(256), smem, s, (const bf16_t*)x, (const bf16_t*)dy, dw, dbias, T, C); break;
+    case 31: hipLaunchKernelGGL((dwconv_wgrad_tile_kernel<31>), grid, dim3(256), smem, s, (const bf16_t*)x, (const bf16_t*)dy, dw, dbias, T, C, (float*)nullptr); break;
+    case 32: hipLaunchKernelGGL((dwconv_wgrad_tile_kernel<32>), grid, dim3(256), smem, s, (const bf16_t*)x, (const bf16_t*)dy, dw, dbias, T, C, (float*)nullptr); break;
+    case 15: hipLaunchKernelGGL((dwconv_wgrad_tile_kernel<15>), grid, dim3(256), smem, s, (const bf16_t*)x, (const bf16_t*)dy, dw, dbias, T, C, (float*)nullptr); break;
+    case 7: hipLaunchKernelGGL((dwconv_wgrad_tile_kernel<7>), grid, dim3(256), smem, s, (const bf16_t*)x, (const bf16_t*)dy, dw, dbias, T, C, (float*)nullptr); break;
     default: return TFASR_STATUS_UNSUPPORTED;
   }
   TFASR_CHECK_LAUNCH();

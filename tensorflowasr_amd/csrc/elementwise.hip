@@ -655,6 +655,25 @@ extern "C" int tfasr_dwconv_bwd_data(const void* dy, const float* w, void* dx, i
   TFASR_CHECK_LAUNCH();
   return TFASR_STATUS_SUCCESS;
 }
+int tfasr_dwconv_wgrad_ws_try(const void* x, const void* dy, float* dw, float* dbias, int B, int T, int C, int K, float* ws, size_t ws_bytes,
+                              hipStream_t s);  // dwconv.hip
+
+extern "C" int tfasr_dwconv_bwd_weight_workspace_size(int B, int T, int C, int K, size_t* bytes) {
+  if (!bytes || B <= 0 || T <= 0 || C <= 0 || K <= 0) return TFASR_STATUS_INVALID_VALUE;
+  *bytes = (size_t)B * ((T + 63) / 64) * ((C + 255) / 256) * (size_t)(K + 1) * 256 * 4;
+  return TFASR_STATUS_SUCCESS;
+}
+
+extern "C" int tfasr_dwconv_bwd_weight_ws(const void* x, const void* dy, float* dw, float* dbias, int B, int T, int C, int K, int dtype,
+                                          void* workspace, size_t workspace_bytes, void* stream_) {
+  if (!x || !dy || !dw || B <= 0 || T <= 0 || C <= 0 || K <= 0 || K > DW_MAXK) return TFASR_STATUS_INVALID_VALUE;
+  if (dtype == TFASR_BF16 && workspace) {
+    const int st = tfasr_dwconv_wgrad_ws_try(x, dy, dw, dbias, B, T, C, K, (float*)workspace, workspace_bytes, (hipStream_t)stream_);
+    if (st != TFASR_STATUS_UNSUPPORTED) return st;
+  }
+  return tfasr_dwconv_bwd_weight(x, dy, dw, dbias, B, T, C, K, dtype, stream_);
+}
+
 extern "C" int tfasr_dwconv_bwd_weight(const void* x, const void* dy, float* dw, float* dbias, int B, int T, int C,
                                        int K, int dtype, void* stream_) {
   if (!x || !dy || !dw || B <= 0 || T <= 0 || C <= 0 || K <= 0 || K > DW_MAXK) return TFASR_STATUS_INVALID_VALUE;

@@ -250,7 +250,11 @@ def dwconv_bwd_data(dy, w):
 
 def dwconv_bwd_weight(x, dy, dw, dbias):
     B, T, C = x.shape
-    check(_L().tfasr_dwconv_bwd_weight(_p(x), _p(dy), _p(dw), _p(dbias), B, T, C, dw.shape[0], _dt(x), _stream()), "dwconv_bwd_weight")
+    n = ctypes.c_size_t(0)
+    check(_L().tfasr_dwconv_bwd_weight_workspace_size(B, T, C, dw.shape[0], ctypes.byref(n)), "dwconv_bwd_weight_workspace_size")
+    ws = workspace(n.value, x.device, "dwconv_wgrad_%d" % (_raw_stream(torch.cuda.current_device()) if _raw_stream else 0))
+    check(_L().tfasr_dwconv_bwd_weight_ws(_p(x), _p(dy), _p(dw), _p(dbias), B, T, C, dw.shape[0], _dt(x), _p(ws), ws.numel(), _stream()),
+          "dwconv_bwd_weight_ws")
 
 
 def bias2_fwd(x, ldx, u, v, rows, C):
