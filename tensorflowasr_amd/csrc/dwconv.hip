@@ -168,12 +168,15 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_reduce_kernel(const float* _
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     const float* p = part + (size_t)slab * (K + 1) * SLAB + i;
     const size_t stride = (size_t)nslab * (K + 1) * SLAB;
-    int b = 0;
-    for (; b + 4 <= nblk_per_slab; b += 4) { s0 += p[(size_t)b * stride]; s1 += p[(size_t)(b + 1) * stride]; s2 += p[(size_t)(b + 2) * stride]; s3 += p[(size_t)(b + 3) * stride]; }
-    for (; b < nblk_per_slab; ++b) s0 += p[(size_t)b * stride];
+    // blockIdx.z owns one slice of the partial slabs (a handful of atomics per address instead of one long serial sum)
+    const int per = (nblk_per_slab + gridDim.z - 1) / gridDim.z;
+    const int b0 = blockIdx.z * per, b1 = min(b0 + per, nblk_per_slab);
+    int b = b0;
+    for (; b + 4 <= b1; b += 4) { s0 += p[(size_t)b * stride]; s1 += p[(size_t)(b + 1) * stride]; s2 += p[(size_t)(b + 2) * stride]; s3 += p[(size_t)(b + 3) * stride]; }
+    for (; b < b1; ++b) s0 += p[(size_t)b * stride];
     const float v = (s0 + s1) + (s2 + s3);
-    if (k < K) dw[k * C + c] += v;
-    else if (dbias) dbias[c] += v;
+    if (k < K) atomicAdd(dw + k * C + c, v);
+    else if (dbias) atomicAdd(dbias + c, v);
   }
 }
 
@@ -199,7 +202,7 @@ int tfasr_dwconv_wgrad_ws_try(const void* x, const void* dy, float* dw, float* d
     default: return TFASR_STATUS_UNSUPPORTED;
   }
   TFASR_CHECK_LAUNCH();
-  dim3 rg(((K + 1) * SLAB + 255) / 256, gx);
+  dim3 rg(((K + 1) * SLAB + 255) / 256, gx, 16);
   hipLaunchKernelGGL(dwconv_wgrad_reduce_kernel, rg, dim3(256), 0, s, (const float*)ws, dw, dbias, B * gy, gx, K, C);
   TFASR_CHECK_LAUNCH();
   return TFASR_STATUS_SUCCESS;

@@ -73,20 +73,48 @@ __global__ __launch_bounds__(256) void rnnt_logprobs_kernel(
     if (!cl.valid) continue;  // padded node: never read by the lattice / grad kernels
     const T* row = logits + r * V;
     RowStat st{-INFINITY, 0.f};
-    if (vec_ok) {
-      for (int v0 = lane * 8; v0 < V; v0 += 64 * 8) {
-        float x[8];
-        ld8(row + v0, x);
+    if (vec_ok && V <= 2 * 64 * 8) {
+      // the whole row sits in registers (<= 16 values per lane): row max first, then one exp2 per element
+      float x[2][8];
+      bool on[2];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) online_add(st, x[i]);
+      for (int c = 0; c < 2; ++c) {
+        const int v0 = lane * 8 + c * 512;
+        on[c] = v0 < V;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) x[c][i] = -INFINITY;
+        if (on[c]) ld8(row + v0, x[c]);
       }
-    } else {
-      for (int v = lane; v < V; v += 64) online_add(st, Num<T>::ld(row + v));
-    }
+      float m = -INFINITY;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const float m2 = __shfl_xor(st.m, o, 64), s2 = __shfl_xor(st.s, o, 64);
-      online_merge(st, m2, s2);
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) m = fmaxf(m, x[c][i]);
+      m = wave_max(m);
+      float sum = 0.f;
+      const float m2 = m * 1.4426950408889634f;
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) sum += __builtin_amdgcn_exp2f(x[c][i] * 1.4426950408889634f - m2);  // exp2(-inf) = 0 for the padding
+      st.m = m;
+      st.s = wave_sum(sum);
+    } else {
+      if (vec_ok) {
+        for (int v0 = lane * 8; v0 < V; v0 += 64 * 8) {
+          float x[8];
+          ld8(row + v0, x);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) online_add(st, x[i]);
+        }
+      } else {
+        for (int v = lane; v < V; v += 64) online_add(st, Num<T>::ld(row + v));
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const float m2 = __shfl_xor(st.m, o, 64), s2 = __shfl_xor(st.s, o, 64);
+        online_merge(st, m2, s2);
+      }
     }
     if (lane == 0) {
       const float l = st.m + logf(st.s);
@@ -237,16 +265,19 @@ __global__ __launch_bounds__(256) void rnnt_grad_kernel(
     const float l = lse[r];
     const float ssum = gb + gt;
     if (vec_ok) {
+      // g_v = (-softmax_v * (gb+gt) + [v==0] gb + [v==lab] gt) * sc, with exp((x-l)) as one exp2 and the two special columns
+      // patched per 8-value chunk (they are rare) instead of two compares per element
+      const float l2 = l * 1.4426950408889634f, k1 = -ssum * sc, gbs = gb * sc, gts = gt * sc;
       for (int v0 = lane * 8; v0 < V; v0 += 64 * 8) {
         float x[8];
         ld8(row + v0, x);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          float g = -__expf(x[i] - l) * ssum;
-          const int v = v0 + i;
-          if (v == 0) g += gb;
-          if (v == lab) g += gt;
-          x[i] = g * sc;
+        for (int i = 0; i < 8; ++i) x[i] = __builtin_amdgcn_exp2f(x[i] * 1.4426950408889634f - l2) * k1;
+        if (v0 == 0) x[0] += gbs;
+        if (lab >= 0 && (lab >> 3) == (v0 >> 3)) {
+          const int q = lab & 7;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) x[i] += (i == q) ? gts : 0.f;
         }
         st8(out + v0, x);
       }
