@@ -61,6 +61,29 @@ def to_train_data(batch, dev):
         TrainLabel(torch.from_numpy(batch["labels"]).to(dev), torch.from_numpy(batch["ulen"])))
 
 
+def step_matmul_flops(cfg, batch):
+    """Multiply-accumulate work (x2) of one train step on the MATRIX cores for this batch: every Dense / attention / conv2 /
+    joint product of the forward, times 3 for the two gradient products, with the joint on the packed (valid) lattice only.
+    Depthwise conv, norms and the loss are not MFMA work and are not counted."""
+    nsamp = np.asarray(batch["nsamp"], np.int64)
+    B = len(nsamp)
+    T0 = -(-int(nsamp.max()) // cfg.frame_step)
+    T1, T2 = -(-T0 // 2), -(-(-(-T0 // 2)) // 2)
+    F2 = -(-(-(-cfg.num_feature_bins // 2)) // 2)
+    rows = B * T2
+    d, C, H, dh, J, V, P, E = cfg.dmodel, cfg.filters, cfg.num_heads, cfg.head_size, cfg.joint_dim, cfg.vocab_size, cfg.rnn_units, cfg.embed_dim
+    enc_block = rows * (2 * (2 * d * 4 * d) + d * 3 * H * dh + H * dh * d + d * 2 * d + d * d) + 2 * T2 * H * dh * d  # per block MACs
+    attn = B * H * T2 * T2 * dh * 3  # content, position (skewed), P@V
+    enc = cfg.num_blocks * (enc_block + attn) + rows * F2 * 9 * C * C + rows * F2 * C * d
+    ul = np.asarray(batch["ulen"], np.int64)
+    U1 = int(ul.max()) + 1
+    tl = np.minimum(np.maximum(-(-(-(-(-(-nsamp // cfg.frame_step)) // 2)) // 2), ul), T2)
+    cells = int((tl * (ul + 1)).sum())
+    pred = B * U1 * (E * 4 * P + P * 4 * P)
+    joint = rows * d * J + B * U1 * P * J + cells * J * V
+    return 2.0 * 3.0 * (enc + pred + joint)
+
+
 def pmc_traffic(flops_per_launch, J, V):
     """HBM bytes per launch of the joint vocabulary GEMM from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE,
     profiles/r01_pmc_traffic.json, collected on this same command).  PMC counters cannot be read inside a timed run, so
@@ -267,6 +290,11 @@ def main():
                     "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                     "traffic": pmc_traffic(model.timer_work["joint_vocab_gemm"], cfg.joint_dim, cfg.vocab_size),
                     "ms_per_launch": round(ms, 4)}
+            # whole-step view (north_star asks for the step's fraction of the MFMA roofline as well): matrix-core flop of
+            # the step / step time; mean over the batches the timed region cycles through
+            sf = float(np.mean([step_matmul_flops(cfg, batches[i % nb]) for i in range(args.steps)]))
+            roof["step_matmul_tflops"] = round(sf / (ms_per_step * 1e-3) / 1e12, 1)
+            roof["step_frac"] = round(sf / (ms_per_step * 1e-3) / 1e12 / peak, 4)
         out = {
             "metric": "audio-hours/sec (train step) Conformer-M RNN-T" if args.model == "M" else "audio-hours/sec (train step) Conformer-S RNN-T",
             "value": round(value, 4), "unit": "audio-hours/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
