@@ -57,7 +57,11 @@ def _oracle_step(ocfg, W, sig, lens, preds, ulens, labels, masks=None, use_mask=
     return logits.detach(), elen, loss, grads, stats
 
 
-@pytest.mark.parametrize("lens,ulens", [([4000, 4000], [6, 6]), ([4000, 2500, 3100], [6, 3, 5])])
+@pytest.mark.parametrize("lens,ulens", [([4000, 4000], [6, 6]), ([4000, 2500, 3100], [6, 3, 5]),
+                                        # edge cases: an EMPTY transcript, a one-frame utterance (161 samples -> 2 -> 1 -> 1 frames)
+                                        # whose label is longer than its encoder output (logit_length is raised to it,
+                                        # losses/base_loss.py:36), a single-label utterance
+                                        ([4000, 161, 1600, 3000], [6, 2, 0, 1])])
 def test_f32_step_matches_oracle(dev, lens, ulens):
     cfg, ocfg, model, W, data, sig, labels, preds = _setup(dev, torch.float32, lens, ulens)
     masks = model.draw_specaugment([int(n) for n in R.get_nframes(lens)])
