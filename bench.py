@@ -239,7 +239,10 @@ def main():
     size = args.workload or ("LibriSpeech-shaped" if args.model == "M" else "S-10s")
     # a few distinct batches per rank, resident in HBM before the timed region
     nb = 2
-    batches = [make_batch(cfg, args.batch, seed=10 + 97 * rank + 13 * i, padding=args.padding, size=size) for i in range(nb)]
+    # weak scaling with the per-GPU work EXACTLY fixed: every rank runs the same synthetic shard shapes (same seeds), so padded
+    # lengths agree across ranks - which the synchronised BatchNorm's count (rows x world) assumes, as in the reference where
+    # the global batch is padded as one (datasets.py:102-138,342-365) - and no rank waits for a longer batch on another.
+    batches = [make_batch(cfg, args.batch, seed=10 + 13 * i, padding=args.padding, size=size) for i in range(nb)]
     data = [to_train_data(b, dev) for b in batches]
     model.timers = {}
     model.time_sections = bool(os.environ.get("TFASR_BENCH_SECTIONS"))
