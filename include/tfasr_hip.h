@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define TFASR_ABI_VERSION 10
+#define TFASR_ABI_VERSION 11
 
 typedef enum {
   TFASR_STATUS_SUCCESS = 0,
@@ -288,6 +288,26 @@ int tfasr_col2im_3x3s2(const void* dcol, void* dx, int B, int T1, int F1, int C,
 int tfasr_logmel(const float* signal, int B, int N, float preemph, const float* window, int frame_len, int frame_step,
                  int nfft, const float* melw, const int32_t* band, int F, float eps, void* out, int T0, int dtype,
                  void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * ContextNet encoder pieces (models/encoders/contextnet.py:40-298) beyond the shared conv / BN / GEMM kernels.
+ * x, y, dy, dx: [B, T, C] channel-last `dtype`, C % 8 == 0; pool / scale / dscale / dpool: [B, C] f32.
+ *   rows_subsample: y[b, t'] = x[b, t' * stride], T' = ceil(T / stride) (a strided CAUSAL conv = the stride-1 one sampled);
+ *                   _bwd scatters dy back and zero-fills the skipped rows
+ *   se_pool: masked mean over t < lengths[b] (GlobalAveragePooling1D with the sequence mask, :159-163)
+ *   se_scale_fwd: y = x * scale[b, c] (:168-169); se_scale_bwd_reduce: dscale[b,c] = sum_t dy*x;
+ *   se_bwd_apply: dx = dy * scale[b,c] + (t < len_b) * dpool[b,c] / len_b
+ *   add_act: y = act(a + b) (b may be NULL), _bwd: d = dy * act'(a + b)      (ConvBlock residual + activation, :283-292)
+ * ---------------------------------------------------------------------------------------------- */
+int tfasr_rows_subsample_fwd(const void* x, void* y, int B, int T, int C, int stride, int dtype, void* stream);
+int tfasr_rows_subsample_bwd(const void* dy, void* dx, int B, int T, int C, int stride, int dtype, void* stream);
+int tfasr_se_pool(const void* x, const int32_t* lengths, float* pool, int B, int T, int C, int dtype, void* stream);
+int tfasr_se_scale_fwd(const void* x, const float* scale, void* y, int B, int T, int C, int dtype, void* stream);
+int tfasr_se_scale_bwd_reduce(const void* x, const void* dy, float* dscale, int B, int T, int C, int dtype, void* stream);
+int tfasr_se_bwd_apply(const void* dy, const float* scale, const float* dpool, const int32_t* lengths, void* dx, int B, int T,
+                       int C, int dtype, void* stream);
+int tfasr_add_act_fwd(const void* a, const void* b, void* y, long n, int act, int dtype, void* stream);
+int tfasr_add_act_bwd(const void* a, const void* b, const void* dy, void* d, long n, int act, int dtype, void* stream);
 
 /* CTC prefix beam search (CtcModel.recognize_beam -> tf.nn.ctc_beam_search_decoder(beam_width), base_ctc.py:127-149).  A HOST
  * routine, like the reference's op: logits [B,T,V] and logit_len [B] are HOST pointers; tokens [B,T] (0-padded, the dense

@@ -145,7 +145,7 @@ def load(build_if_missing=True):
     return lib
 
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 
 def check(status, what=""):

@@ -45,6 +45,11 @@ class ConformerConfig:
     vocab_size: int = 1000
     blank: int = 0
     l2: float = 1e-6
+    prediction_layer_norm: bool = True
+    # encoder family: "conformer" (default) or "contextnet" (models/encoders/contextnet.py)
+    encoder: str = "conformer"
+    contextnet_blocks: list = None   # [dict(nlayers, kernel_size, filters, strides, residual)], the yml's encoder_blocks
+    contextnet_alpha: float = 1.0
 
     @property
     def frame_length(self):
@@ -56,6 +61,11 @@ class ConformerConfig:
 
     @property
     def time_reduction_factor(self):
+        if self.encoder == "contextnet":
+            f = 1
+            for b in self.contextnet_blocks:
+                f *= int(b.get("strides", 1))
+            return f
         return 4
 
     @classmethod
@@ -101,6 +111,33 @@ def conformer_s(vocab_size=1000, **over):
 
 def conformer_m(vocab_size=1000, **over):
     kw = dict(filters=256, dmodel=256, head_size=64, num_heads=4, embed_dim=640, rnn_units=640, joint_dim=640, vocab_size=vocab_size)
+    kw.update(over)
+    return ConformerConfig(**kw)
+
+
+CONTEXTNET_BLOCKS = (  # examples/models/transducer/contextnet/small.yml.j2:25-190 (nlayers, kernel, filters, stride, residual)
+    [(1, 5, 256, 1, False)] + [(5, 5, 256, 1, True)] * 2 + [(5, 5, 256, 2, True)] + [(5, 5, 256, 1, True)] * 3 + [(5, 5, 256, 2, True)]
+    + [(5, 5, 256, 1, True)] * 3 + [(5, 5, 512, 1, True)] * 3 + [(5, 5, 512, 2, True)] + [(5, 5, 512, 1, True)] * 7 + [(1, 5, 640, 1, False)])
+
+
+def _cn_blocks(spec):
+    return [dict(nlayers=n, kernel_size=k, filters=f, strides=s, residual=r) for n, k, f, s, r in spec]
+
+
+def contextnet(vocab_size=1000, alpha=0.5, **over):
+    """The reference's ContextNet transducer (contextnet/small.yml.j2: alpha 0.5, 23 blocks, time reduction 8, prediction
+    LSTM 512 without LayerNorm, joint 512); alpha 1 / 2 give the paper's M / L widths."""
+    blocks = _cn_blocks(CONTEXTNET_BLOCKS)
+    kw = dict(encoder="contextnet", contextnet_blocks=blocks, contextnet_alpha=alpha, dmodel=int(blocks[-1]["filters"] * alpha), embed_dim=640,
+              rnn_units=512, joint_dim=512, prediction_layer_norm=False, vocab_size=vocab_size, dropout=0.0)
+    kw.update(over)
+    return ConformerConfig(**kw)
+
+
+def contextnet_tiny(vocab_size=29, **over):
+    blocks = _cn_blocks([(1, 5, 32, 1, False), (3, 5, 32, 1, True), (3, 5, 32, 2, True), (2, 3, 48, 2, True), (1, 5, 64, 1, False)])
+    kw = dict(encoder="contextnet", contextnet_blocks=blocks, contextnet_alpha=0.5, dmodel=32, embed_dim=24, rnn_units=24, joint_dim=40,
+              prediction_layer_norm=False, vocab_size=vocab_size, dropout=0.0)
     kw.update(over)
     return ConformerConfig(**kw)
 

@@ -566,7 +566,10 @@ class ConformerTransducer:
                 K.gemm(hprev, Wrk, hr, B, 4 * P, P, hprev.stride(0), 4 * P, 4 * P)
             K.lstm_step_fwd(xg[:, t], hr if use_hr else None, hprev, cprev, plen_dev, t, gates[:, t], cseq[:, t], hseq[:, t], yseq[:, t], B, P)
         y2 = yseq.view(B * U1, P)
-        pred, mean, rstd = K.layernorm_fwd(y2, ps.p("pred/ln/g"), ps.p("pred/ln/b"))
+        if c.prediction_layer_norm:
+            pred, mean, rstd = K.layernorm_fwd(y2, ps.p("pred/ln/g"), ps.p("pred/ln/b"))
+        else:  # prediction_layer_norm: False (contextnet/small.yml.j2)
+            pred, mean, rstd = y2, None, None
         if ctx is not None:
             ctx["pred"] = dict(tokens=tokens_dev, plen=plen_dev, emb=emb, gates=gates, cseq=cseq, hseq=hseq, y2=y2, mean=mean, rstd=rstd, B=B, U1=U1)
         return pred  # [B*U1, P]
@@ -576,7 +579,10 @@ class ConformerTransducer:
         s = ctx["pred"]
         B, U1 = s["B"], s["U1"]
         E, P = c.embed_dim, c.rnn_units
-        dy = K.layernorm_bwd(dpred, s["y2"], ps.p("pred/ln/g"), s["mean"], s["rstd"], ps.g("pred/ln/g"), ps.g("pred/ln/b")).view(B, U1, P)
+        if c.prediction_layer_norm:
+            dy = K.layernorm_bwd(dpred, s["y2"], ps.p("pred/ln/g"), s["mean"], s["rstd"], ps.g("pred/ln/g"), ps.g("pred/ln/b")).view(B, U1, P)
+        else:
+            dy = dpred.view(B, U1, P)
         dz = torch.empty(B, U1, 4 * P, dtype=self.dtype, device=self.device)
         dh_carry = torch.zeros(B, P, dtype=torch.float32, device=self.device)
         dc_carry = torch.zeros(B, P, dtype=torch.float32, device=self.device)

@@ -510,3 +510,58 @@ def block_fwd(cfg, params, io, ctx, phase):
 
 def block_bwd(cfg, params, io, ctx, phase):
     check(_L().tfasr_block_bwd(ctypes.byref(cfg), ctypes.byref(params), ctypes.byref(io), ctx, phase, _stream()), "block_bwd")
+
+
+# --------------------------------------------------------------------------------- ContextNet pieces
+def rows_subsample_fwd(x, stride):
+    B, T, C = x.shape
+    y = torch.empty(B, -(-T // stride), C, dtype=x.dtype, device=x.device)
+    check(_L().tfasr_rows_subsample_fwd(_p(x), _p(y), B, T, C, stride, _dt(x), _stream()), "rows_subsample_fwd")
+    return y
+
+
+def rows_subsample_bwd(dy, T, stride):
+    B, T2, C = dy.shape
+    dx = torch.empty(B, T, C, dtype=dy.dtype, device=dy.device)
+    check(_L().tfasr_rows_subsample_bwd(_p(dy), _p(dx), B, T, C, stride, _dt(dy), _stream()), "rows_subsample_bwd")
+    return dx
+
+
+def se_pool(x, lengths):
+    B, T, C = x.shape
+    pool = torch.empty(B, C, dtype=torch.float32, device=x.device)
+    check(_L().tfasr_se_pool(_p(x), _p(lengths), _p(pool), B, T, C, _dt(x), _stream()), "se_pool")
+    return pool
+
+
+def se_scale_fwd(x, scale):
+    B, T, C = x.shape
+    y = torch.empty_like(x)
+    check(_L().tfasr_se_scale_fwd(_p(x), _p(scale), _p(y), B, T, C, _dt(x), _stream()), "se_scale_fwd")
+    return y
+
+
+def se_scale_bwd_reduce(x, dy):
+    B, T, C = x.shape
+    ds = torch.empty(B, C, dtype=torch.float32, device=x.device)
+    check(_L().tfasr_se_scale_bwd_reduce(_p(x), _p(dy), _p(ds), B, T, C, _dt(x), _stream()), "se_scale_bwd_reduce")
+    return ds
+
+
+def se_bwd_apply(dy, scale, dpool, lengths):
+    B, T, C = dy.shape
+    dx = torch.empty_like(dy)
+    check(_L().tfasr_se_bwd_apply(_p(dy), _p(scale), _p(dpool), _p(lengths), _p(dx), B, T, C, _dt(dy), _stream()), "se_bwd_apply")
+    return dx
+
+
+def add_act_fwd(a, b, act=ACT_NONE):
+    y = torch.empty_like(a)
+    check(_L().tfasr_add_act_fwd(_p(a), _p(b), _p(y), a.numel(), act, _dt(a), _stream()), "add_act_fwd")
+    return y
+
+
+def add_act_bwd(a, b, dy, act=ACT_NONE):
+    d = torch.empty_like(a)
+    check(_L().tfasr_add_act_bwd(_p(a), _p(b), _p(dy), _p(d), a.numel(), act, _dt(a), _stream()), "add_act_bwd")
+    return d

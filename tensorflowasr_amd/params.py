@@ -29,6 +29,9 @@ def param_specs(cfg):
     def add(name, shape, reg, init, fans=None):
         s.append((name, tuple(shape), reg, init, fans))
 
+    if getattr(cfg, "encoder", "conformer") == "contextnet":
+        contextnet_specs(cfg, add)
+        return _tail_specs(cfg, add, s)
     add("enc/sub/conv0/w", (3, 3, 1, C), True, "glorot", (9, 9 * C))
     add("enc/sub/conv0/b", (C,), False, "zeros")
     add("enc/sub/bn0/b", (C,), True, "zeros")
@@ -60,18 +63,64 @@ def param_specs(cfg):
                 add(c + "bn/b", (d,), True, "zeros"); add(c + "bn/g", (d,), True, "ones")
                 add(c + "pw2/w", (d, d), True, "glorot"); add(c + "pw2/b", (d,), False, "zeros")
         add(p + "ln/g", (d,), True, "ones"); add(p + "ln/b", (d,), True, "zeros")
+    return _tail_specs(cfg, add, s)
+
+
+def _tail_specs(cfg, add, s):
+    """prediction + joint networks (shared by every encoder family)"""
+    d, V, E, P, J = cfg.dmodel, cfg.vocab_size, cfg.embed_dim, cfg.rnn_units, cfg.joint_dim
     add("pred/emb", (V, E), True, "embed")
     add("pred/lstm/k", (E, 4 * P), True, "glorot")
     add("pred/lstm/rk", (P, 4 * P), False, "orth")
     add("pred/lstm/b", (4 * P,), False, "lstm_bias")
-    add("pred/ln/g", (P,), True, "ones"); add("pred/ln/b", (P,), True, "zeros")
+    if getattr(cfg, "prediction_layer_norm", True):
+        add("pred/ln/g", (P,), True, "ones"); add("pred/ln/b", (P,), True, "zeros")
     add("joint/enc/w", (d, J), True, "glorot"); add("joint/enc/b", (J,), False, "zeros")
     add("joint/pred/w", (P, J), True, "glorot"); add("joint/pred/b", (J,), False, "zeros")
     add("joint/vocab/w", (J, V), True, "glorot"); add("joint/vocab/b", (V,), False, "zeros")
     return s
 
 
+def contextnet_modules(cfg):
+    """[(prefix, Cin, Cout, kernel, stride, activation)] of every ConvModule in forward order, per block, plus SE sizes:
+    returns a list of blocks: dict(convs=[...], se=(prefix, C), res=module-or-None, C=Cout, stride=s)."""
+    blocks, cin = [], cfg.num_feature_bins
+    for i, b in enumerate(cfg.contextnet_blocks):
+        C = int(b["filters"] * cfg.contextnet_alpha)
+        K, s, n = int(b["kernel_size"]), int(b.get("strides", 1)), int(b["nlayers"])
+        p = f"enc/block{i}/"
+        convs, c = [], cin
+        for j in range(n - 1):
+            convs.append((p + f"conv{j}", c, C, K, 1, "swish"))
+            c = C
+        convs.append((p + f"conv{n - 1}", c, C, K, s, "swish"))           # last_conv carries the block's stride
+        convs.append((p + "se/conv", C, C, K, 1, "swish"))               # SEModule's own conv module
+        res = (p + "res", cin, C, K, s, "none") if b.get("residual", True) else None
+        blocks.append(dict(prefix=p, convs=convs, res=res, C=C, stride=s))
+        cin = C
+    return blocks
+
+
+def contextnet_specs(cfg, add):
+    for blk in contextnet_modules(cfg):
+        for (m, ci, co, K, _s, _a) in blk["convs"] + ([blk["res"]] if blk["res"] else []):
+            add(m + "/dw", (K, ci), True, "glorot", (K * ci, K))
+            add(m + "/pw/w", (ci, co), True, "glorot")
+            add(m + "/pw/b", (co,), False, "zeros")
+            add(m + "/bn/b", (co,), True, "zeros")
+            add(m + "/bn/g", (co,), True, "ones")
+        C = blk["C"]
+        p = blk["prefix"] + "se/"
+        add(p + "fc1/w", (C, C // 8), True, "glorot"); add(p + "fc1/b", (C // 8,), False, "zeros")
+        add(p + "fc2/w", (C // 8, C), True, "glorot"); add(p + "fc2/b", (C,), False, "zeros")
+
+
 def bn_names(cfg):
+    if getattr(cfg, "encoder", "conformer") == "contextnet":
+        out = []
+        for blk in contextnet_modules(cfg):
+            out += [m[0] + "/bn" for m in blk["convs"]] + ([blk["res"][0] + "/bn"] if blk["res"] else [])
+        return out
     return ["enc/sub/bn0", "enc/sub/bn1"] + [f"enc/block{i}/conv/bn" for i in range(cfg.num_blocks)]
 
 
@@ -101,7 +150,7 @@ class ParamStore:
         # non-trainable BatchNorm moving statistics (keras: moving_mean zeros, moving_variance ones)
         self.state = {}
         for nm in bn_names(cfg):
-            C = cfg.filters if "/sub/" in nm else cfg.dmodel
+            C = self.shapes[nm + "/g"][0]
             self.state[nm + "/mm"] = torch.zeros(C, dtype=torch.float32, device=device)
             self.state[nm + "/mv"] = torch.ones(C, dtype=torch.float32, device=device)
         self._init(ordered, seed)
