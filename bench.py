@@ -202,7 +202,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--model", default="M", choices=["M", "S"])
+    ap.add_argument("--model", default="M", choices=["M", "S", "contextnet"], help="M / S = Conformer sizes; contextnet = BASELINE configs[3] family")
+    ap.add_argument("--alpha", type=float, default=2.0, help="ContextNet width multiplier (0.5 small, 1 medium, 2 large)")
     ap.add_argument("--batch", type=int, default=32, help="utterances per GPU")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--padding", default="batch", choices=["batch", "reference"])
@@ -225,18 +226,26 @@ def main():
     if dp and args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
-    cfg = configs.conformer_m() if args.model == "M" else configs.conformer_s()
+    if args.model == "contextnet":
+        cfg = configs.contextnet(alpha=args.alpha)
+    else:
+        cfg = configs.conformer_m() if args.model == "M" else configs.conformer_s()
     if args.no_specaugment:
         cfg.time_masking, cfg.freq_masking = {}, {}
     if args.dropout is not None:
         cfg.dropout = args.dropout
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-    model = ConformerTransducer(cfg, dev, dtype=dtype, seed=0, dp=dp)
+    if args.model == "contextnet":
+        from tensorflowasr_amd.contextnet import ContextNetTransducer
+
+        model = ContextNetTransducer(cfg, dev, dtype=dtype, seed=0, dp=dp)
+    else:
+        model = ConformerTransducer(cfg, dev, dtype=dtype, seed=0, dp=dp)
     if dp:
         dp.attach(model.ps.grad)
     if args.mode == "decode":
         return bench_decode(args, model, cfg, dev)
-    size = args.workload or ("LibriSpeech-shaped" if args.model == "M" else "S-10s")
+    size = args.workload or ("S-10s" if args.model == "S" else "LibriSpeech-shaped")
     # a few distinct batches per rank, resident in HBM before the timed region
     nb = 2
     # weak scaling with the per-GPU work EXACTLY fixed: every rank runs the same synthetic shard shapes (same seeds), so padded
@@ -283,7 +292,18 @@ def main():
     if rank == 0:
         roof = None
         tm = model.timers.get("joint_vocab_gemm") or []
-        if tm:
+        cn = model.timers.get("cn_dwconv_fwd") or []
+        if args.model == "contextnet" and cn:
+            # ContextNet is depthwise-conv / BatchNorm heavy: report the HBM roofline of its depthwise convolution (all launches of
+            # the timed region: achieved = algorithmic bytes (read x + write y) / measured time)
+            torch.cuda.synchronize()
+            ms_tot = float(np.sum([a.elapsed_time(b) for a, b in cn]))
+            by = float(np.sum(model.timer_work["cn_dwconv_fwd"]))
+            ach = by / (ms_tot * 1e-3) / 1e9
+            roof = {"kernel": "dwconv_tile_kernel (causal depthwise Conv1D k=5, forward, all layers)", "bound": "hbm", "achieved": round(ach, 1),
+                    "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4), "traffic": None,
+                    "ms_per_launch": round(ms_tot / len(cn), 4)}
+        elif tm:
             torch.cuda.synchronize()
             ms = float(np.mean([a.elapsed_time(b) for a, b in tm]))
             fl = float(np.mean(model.timer_work["joint_vocab_gemm"]))
@@ -295,22 +315,25 @@ def main():
                     "ms_per_launch": round(ms, 4)}
             # whole-step view (north_star asks for the step's fraction of the MFMA roofline as well): matrix-core flop of
             # the step / step time; mean over the batches the timed region cycles through
-            sf = float(np.mean([step_matmul_flops(cfg, batches[i % nb]) for i in range(args.steps)]))
-            roof["step_matmul_tflops"] = round(sf / (ms_per_step * 1e-3) / 1e12, 1)
-            roof["step_frac"] = round(sf / (ms_per_step * 1e-3) / 1e12 / peak, 4)
+            if args.model != "contextnet":
+                sf = float(np.mean([step_matmul_flops(cfg, batches[i % nb]) for i in range(args.steps)]))
+                roof["step_matmul_tflops"] = round(sf / (ms_per_step * 1e-3) / 1e12, 1)
+                roof["step_frac"] = round(sf / (ms_per_step * 1e-3) / 1e12 / peak, 4)
         out = {
-            "metric": "audio-hours/sec (train step) Conformer-M RNN-T" if args.model == "M" else "audio-hours/sec (train step) Conformer-S RNN-T",
+            "metric": ("audio-hours/sec (train step) ContextNet(alpha=%g) RNN-T" % args.alpha) if args.model == "contextnet"
+                      else "audio-hours/sec (train step) Conformer-%s RNN-T" % args.model,
             "value": round(value, 4), "unit": "audio-hours/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"Conformer-{args.model} transducer full train step (fwd+RNN-T loss+bwd+Adam), {size} 16 kHz utterances, "
+            "config": {"workload": f"{'ContextNet' if args.model == 'contextnet' else 'Conformer-' + args.model} transducer full train step (fwd+RNN-T loss+bwd+Adam), {size} 16 kHz utterances, "
                                    f"{args.batch}/GPU, padding={args.padding}, SpecAugment {'off' if args.no_specaugment else 'on'}, dropout {cfg.dropout}",
                        "global_batch": args.batch * world, "parallelism": f"dp{world}", "params": model.ps.num_trainable()},
             "roofline": roof,
         }
         if not args.no_cpu_baseline and world == 1:
             try:
-                out["cpu_baseline"] = cpu_baseline(size if args.model == "S" else "M", cfg.vocab_size)
+                if args.model != "contextnet":  # the CPU port baseline is the Conformer oracle
+                    out["cpu_baseline"] = cpu_baseline(size if args.model == "S" else "M", cfg.vocab_size)
             except Exception as e:  # the GPU number must still be reported
                 out["cpu_baseline"] = {"value": None, "error": repr(e)}
         print(json.dumps(out))

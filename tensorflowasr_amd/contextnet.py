@@ -37,7 +37,9 @@ class ContextNetTransducer(ConformerTransducer):
         """x [B*T, Cin] -> y [B*T2, Cout]."""
         name, ci, co, Kk, stride, act = mod
         ps = self.ps
+        t0 = self._tick("cn_dwconv_fwd")
         dw = K.dwconv_fwd(x.view(B, T, ci), ps.p(name + "/dw"), None)
+        self._tock("cn_dwconv_fwd", t0, 2.0 * B * T * ci * x.element_size())  # algorithmic bytes: read x once, write y once
         T2 = -(-T // stride)
         if stride > 1:
             dw = K.rows_subsample_fwd(dw, stride)

@@ -342,7 +342,8 @@ __global__ __launch_bounds__(512) void bn_stats_vec_kernel(const T* __restrict__
   constexpr int RPW = 64 / LPR;
   __shared__ float red[2][8 * RPW][LPR * 8];  // up to 8 waves (512 threads)
   const int lane = threadIdx.x & 63, li = lane % LPR, sub = lane / LPR, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  const int c0 = li * 8;
+  const int cs = blockIdx.y * (LPR * 8);  // channel slab (C > LPR*8: ContextNet widths up to 1280)
+  const int c0 = cs + li * 8;
   const bool act = c0 < C;
   float a0[8], a1[8], mean[8], rstd[8], sc[8], sh[8];
 #pragma unroll
@@ -383,13 +384,13 @@ __global__ __launch_bounds__(512) void bn_stats_vec_kernel(const T* __restrict__
       }
     }
 #pragma unroll
-  for (int k = 0; k < 8; ++k) { red[0][w * RPW + sub][c0 + k] = a0[k]; red[1][w * RPW + sub][c0 + k] = a1[k]; }
+  for (int k = 0; k < 8; ++k) { red[0][w * RPW + sub][li * 8 + k] = a0[k]; red[1][w * RPW + sub][li * 8 + k] = a1[k]; }
   __syncthreads();
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+  for (int cl = threadIdx.x; cl < LPR * 8 && cs + cl < C; cl += blockDim.x) {
     float s0 = 0.f, s1 = 0.f;
-    for (int q = 0; q < nw * RPW; ++q) { s0 += red[0][q][c]; s1 += red[1][q][c]; }
-    atomicAdd(stats + c, s0);
-    atomicAdd(stats + C + c, s1);
+    for (int q = 0; q < nw * RPW; ++q) { s0 += red[0][q][cl]; s1 += red[1][q][cl]; }
+    atomicAdd(stats + cs + cl, s0);
+    atomicAdd(stats + C + cs + cl, s1);
   }
 }
 
@@ -462,11 +463,11 @@ extern "C" int tfasr_layernorm_bwd(const void* dy, const void* x, const float* g
 }
 
 extern "C" int tfasr_bn_stats(const void* x, float* stats, long rows, int C, int dtype, void* stream_) {
-  if (!x || !stats || rows <= 0 || C <= 0 || C > 64 * MAXC_PER_LANE) return TFASR_STATUS_INVALID_VALUE;
+  if (!x || !stats || rows <= 0 || C <= 0 || (C > 64 * MAXC_PER_LANE && (dtype != TFASR_BF16 || (C % 8)))) return TFASR_STATUS_INVALID_VALUE;
   hipStream_t s = (hipStream_t)stream_;
-  if (dtype == TFASR_BF16 && (C % 8) == 0 && C <= 512) {
+  if (dtype == TFASR_BF16 && (C % 8) == 0) {
     if (C <= 256) hipLaunchKernelGGL((bn_stats_vec_kernel<bf16_t, 0, 32>), dim3(fat_grid(rows, 2)), dim3(red_threads()), 0, s, (const bf16_t*)x, (const bf16_t*)nullptr, (const float*)nullptr, stats, rows, C, 0);
-    else hipLaunchKernelGGL((bn_stats_vec_kernel<bf16_t, 0, 64>), dim3(fat_grid(rows, 1)), dim3(red_threads()), 0, s, (const bf16_t*)x, (const bf16_t*)nullptr, (const float*)nullptr, stats, rows, C, 0);
+    else hipLaunchKernelGGL((bn_stats_vec_kernel<bf16_t, 0, 64>), dim3(fat_grid(rows, 1), (C + 511) / 512), dim3(red_threads()), 0, s, (const bf16_t*)x, (const bf16_t*)nullptr, (const float*)nullptr, stats, rows, C, 0);
     TFASR_CHECK_LAUNCH();
     return TFASR_STATUS_SUCCESS;
   }
@@ -510,11 +511,11 @@ extern "C" int tfasr_bn_apply_fwd(const void* x, const float* fin, void* y, long
 
 extern "C" int tfasr_bn_bwd_stats(const void* x, const void* dy, const float* fin, float* bstats, long rows, int C,
                                   int act, int dtype, void* stream_) {
-  if (!x || !dy || !fin || !bstats || rows <= 0 || C <= 0 || C > 64 * MAXC_PER_LANE) return TFASR_STATUS_INVALID_VALUE;
+  if (!x || !dy || !fin || !bstats || rows <= 0 || C <= 0 || (C > 64 * MAXC_PER_LANE && (dtype != TFASR_BF16 || (C % 8)))) return TFASR_STATUS_INVALID_VALUE;
   hipStream_t s = (hipStream_t)stream_;
-  if (dtype == TFASR_BF16 && (C % 8) == 0 && C <= 512) {
+  if (dtype == TFASR_BF16 && (C % 8) == 0) {
     if (C <= 256) hipLaunchKernelGGL((bn_stats_vec_kernel<bf16_t, 1, 32>), dim3(fat_grid(rows, 2)), dim3(red_threads()), 0, s, (const bf16_t*)x, (const bf16_t*)dy, fin, bstats, rows, C, act);
-    else hipLaunchKernelGGL((bn_stats_vec_kernel<bf16_t, 1, 64>), dim3(fat_grid(rows, 1)), dim3(red_threads()), 0, s, (const bf16_t*)x, (const bf16_t*)dy, fin, bstats, rows, C, act);
+    else hipLaunchKernelGGL((bn_stats_vec_kernel<bf16_t, 1, 64>), dim3(fat_grid(rows, 1), (C + 511) / 512), dim3(red_threads()), 0, s, (const bf16_t*)x, (const bf16_t*)dy, fin, bstats, rows, C, act);
     TFASR_CHECK_LAUNCH();
     return TFASR_STATUS_SUCCESS;
   }

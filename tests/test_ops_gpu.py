@@ -49,9 +49,12 @@ def test_layernorm(dev, dtype, C):
 
 
 @pytest.mark.parametrize("dtype", DT)
-def test_batchnorm_swish(dev, dtype):
+@pytest.mark.parametrize("C", [144, 1280])  # 1280 = ContextNet-L width: channel slabs in the statistics kernels
+def test_batchnorm_swish(dev, dtype, C):
+    if C > 1024 and dtype == torch.float32:
+        pytest.skip("the f32 (parity-mode) statistics kernels cover C <= 1024")
     g = torch.Generator().manual_seed(0)
-    rows, C = 500, 144
+    rows = 500
     x = rt(torch.randn(rows, C, generator=g) * 1.5 + 0.3, dtype)
     gam, bet = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.1
     dy = rt(torch.randn(rows, C, generator=g), dtype)
