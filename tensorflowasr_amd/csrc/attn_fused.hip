@@ -365,10 +365,16 @@ __global__ __launch_bounds__(256, 2) void relattn_fused_bwd_q_kernel(
     }
   }
 
+#ifdef TFASR_ATTN_TIMING
+  long long ph[5] = {0, 0, 0, 0, 0};
+#endif
   const int njb = (T + BJ - 1) / BJ;
   for (int jb = 0; jb < njb; ++jb) {
     const int j0 = jb * BJ;
     const int pw0 = (T - 1 - (i0 + BI - 1) + j0) + shift;
+#ifdef TFASR_ATTN_TIMING
+    long long tp = __builtin_readcyclecounter();
+#endif
     load_rows<BJ>(sK, kb, LDQ, j0, T, w, lane);
     load_rows<BJ>(sV, vb, LDQ, j0, T, w, lane);
     load_rows<WIN>(sP, pb, HD, pw0, R1, w, lane);
@@ -379,6 +385,7 @@ __global__ __launch_bounds__(256, 2) void relattn_fused_bwd_q_kernel(
       *reinterpret_cast<uint4*>(sP + 127 * 128 + lane * 16) = v;
     }
     __syncthreads();
+    ATT_TICK(0)
 
     float4_t acc_s[4], acc_p[4];
 #pragma unroll
@@ -404,6 +411,7 @@ __global__ __launch_bounds__(256, 2) void relattn_fused_bwd_q_kernel(
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
+    ATT_TICK(1)
 
     // ds in C layout (row il = g*4+e, col jl = jt*16+r); skewed copy straight to HBM.  All per-lane offsets (window gather,
     // dpos row pointer, A-image slot, validity threshold) are loop invariants computed once before the key loop.
@@ -431,6 +439,7 @@ __global__ __launch_bounds__(256, 2) void relattn_fused_bwd_q_kernel(
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
+    ATT_TICK(2)
     // dS (bf16) as A operand image [16 rows il][64 k = jl] in the (now dead) G strip
 #pragma unroll
     for (int e = 0; e < 4; ++e)
@@ -446,8 +455,16 @@ __global__ __launch_bounds__(256, 2) void relattn_fused_bwd_q_kernel(
       for (int n = 0; n < 4; ++n)
         acc_q[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, frag_kt(sK, n * 16, kk * 32 + g * 8, r), acc_q[n], 0, 0, 0);
     }
+    ATT_TICK(3)
     __syncthreads();
+    ATT_TICK(4)
   }
+#ifdef TFASR_ATTN_TIMING
+  if (threadIdx.x == 0) {
+    long long* o = g_attn_timing + 5L * (blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z));
+    for (int kq = 0; kq < 5; ++kq) o[kq] = ph[kq];
+  }
+#endif
 
   // epilogue: dqu, the bias column, and zeros over the part of each dpos row that no (i,j) pair maps to
 #pragma unroll
