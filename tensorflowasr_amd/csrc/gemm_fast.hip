@@ -597,7 +597,13 @@ int launch_epi(const tfasr_gemm_args& a, dim3 tiles, hipStream_t stream) {
 template <bool TA, bool TB>
 int launch_one(const tfasr_gemm_args& a, hipStream_t stream) {
   const int split = a.split_k > 1 ? a.split_k : 1;
-  const bool narrow = a.N <= 64;  // per-head attention products etc.: halve the wasted B tile
+  // 128x64 tiles: per-head attention products (N = head size: halves the wasted B tile) and every product whose 128x128 tiling
+  // would leave at most one workgroup per CU (the N = 256 Dense layers of a Conformer block: 190 tiles): with a single resident
+  // workgroup the DMA issue, the fragment reads and the MFMAs of a slab serialise (1530 cycles / slab measured); two 128x64
+  // workgroups per CU overlap them (14.2 vs 16.9 us on [12096,256,1024]).  TFASR_GEMM_BN64=0 restores the old rule.
+  static const bool bn64_off = getenv("TFASR_GEMM_BN64") && getenv("TFASR_GEMM_BN64")[0] == '0';
+  const long t128 = (long)((a.N + 127) / 128) * ((a.M + BM - 1) / BM) * a.nb1 * a.nb2 * split;
+  const bool narrow = a.N <= 64 || (!bn64_off && t128 <= num_cus() && a.N > 64 && !a.colsum && !a.accumulate);
   const int bn = narrow ? 64 : 128;
   dim3 grid((a.N + bn - 1) / bn, (a.M + BM - 1) / BM, a.nb1 * a.nb2 * split);
   if ((long)grid.x * grid.y * grid.z > 0x7fffffffL) return TFASR_STATUS_INVALID_VALUE;
@@ -628,7 +634,14 @@ int launch_one(const tfasr_gemm_args& a, hipStream_t stream) {
     }
     return TFASR_STATUS_UNSUPPORTED;  // tfasr_gemm falls back to a separate column-sum pass
   }
-  if (narrow) return generic || need ? launch_epi<TA, TB, 64, E_GEN>(a, grid, stream) : launch_epi<TA, TB, 64, 0>(a, grid, stream);
+  if (narrow) {
+    if (!generic && need == 0) return launch_epi<TA, TB, 64, 0>(a, grid, stream);
+    if constexpr (!TA && !TB) {
+      if (!generic && need == E_RES) return launch_epi<TA, TB, 64, E_RES>(a, grid, stream);
+      if (!generic && need == (E_RES | E_DROP)) return launch_epi<TA, TB, 64, E_RES | E_DROP>(a, grid, stream);
+    }
+    return launch_epi<TA, TB, 64, E_GEN>(a, grid, stream);
+  }
   if (!generic) {
     if (need == 0) return launch_epi<TA, TB, 128, 0>(a, grid, stream);
     if constexpr (!TA && !TB) {  // forward Dense layers
