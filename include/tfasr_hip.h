@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define TFASR_ABI_VERSION 11
+#define TFASR_ABI_VERSION 12
 
 typedef enum {
   TFASR_STATUS_SUCCESS = 0,
@@ -366,6 +366,12 @@ typedef struct {
   float* bn_stats; float* bn_bstats;    /* [2d+1] / [2d] f32 */
   void* stash; size_t stash_bytes;
   void* scratch; size_t scratch_bytes;
+  /* Optional: accumulators the CALLER has already zeroed (e.g. slices of one buffer cleared by a single memset for all the
+     blocks of a step, instead of three small in-stream memsets per block).  prezeroed & 1: bn_stats is zero on entry of
+     forward phase A; & 2: bn_bstats is zero on entry of backward phase A; dpext_zero != NULL: a zeroed f32 [2T * H*dh]
+     buffer for the positional-projection gradient (otherwise carved out of scratch and cleared in-stream). */
+  int prezeroed;
+  float* dpext_zero;
 } tfasr_block_io;
 
 size_t tfasr_block_ctx_bytes(void);

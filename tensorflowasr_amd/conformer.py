@@ -69,6 +69,7 @@ class ConformerTransducer:
         # one native call per Conformer block (csrc/block.hip) instead of ~70 per-kernel calls from Python
         self.native_blocks = os.environ.get("TFASR_NATIVE_BLOCK", "1") != "0"
         self._blk_params, self._blk_sizes = {}, {}
+        self._zero_pool = {}
         self.timers = None  # optional dict name -> list[(start_event, end_event)] filled by bench.py
         self.timer_work = {}
         self.time_sections = False  # per-module section timers (bench.py TFASR_BENCH_SECTIONS) need the per-kernel Python path
@@ -477,11 +478,13 @@ class ConformerTransducer:
         stash_b, fscr_b, _ = self._native_sizes(cfgk)
         y = torch.empty(B * T, d, dtype=self.dtype, device=self.device)
         stash = torch.empty(stash_b, dtype=torch.uint8, device=self.device)
-        stats = torch.empty(2 * d + 1, dtype=torch.float32, device=self.device)
+        pool = self._zero_pool.get("fwd") if training else None
+        stats = pool[i, :2 * d + 1] if pool is not None else torch.empty(2 * d + 1, dtype=torch.float32, device=self.device)
         scratch = K.workspace(fscr_b, self.device, "blk_fwd")
         io = K._lib.BlockIO()
         io.x_in, io.x_out, io.lengths = x.data_ptr(), y.data_ptr(), elen_dev.data_ptr()
         io.bn_stats = stats.data_ptr()
+        io.prezeroed = 1 if pool is not None else 0
         io.stash, io.stash_bytes, io.scratch, io.scratch_bytes = stash.data_ptr(), stash_b, scratch.data_ptr(), scratch.numel()
         cbuf = K.block_ctx()
         if training and self.dp.world > 1:
@@ -500,7 +503,17 @@ class ConformerTransducer:
         d = self.cfg.dmodel
         _, _, bscr_b = self._native_sizes(cfgk)
         dx = torch.empty(cfgk.B * cfgk.T, d, dtype=self.dtype, device=self.device)
-        bstats = torch.empty(2 * d, dtype=torch.float32, device=self.device)
+        pool = self._zero_pool.get("bwd")
+        n_dpext = 2 * cfgk.T * cfgk.H * cfgk.dh
+        off = -(-2 * d // 64) * 64
+        if pool is not None and pool.shape[1] >= off + n_dpext:
+            bstats = pool[i, :2 * d]
+            io.prezeroed |= 2
+            io.dpext_zero = pool[i, off:off + n_dpext].data_ptr()
+        else:
+            bstats = torch.empty(2 * d, dtype=torch.float32, device=self.device)
+            io.prezeroed &= ~2
+            io.dpext_zero = None
         scratch = K.workspace(bscr_b, self.device, "blk_bwd")
         io.dy, io.dx, io.bn_bstats = dy.data_ptr(), dx.data_ptr(), bstats.data_ptr()
         io.scratch, io.scratch_bytes = scratch.data_ptr(), scratch.numel()
@@ -521,6 +534,14 @@ class ConformerTransducer:
         B = feats.shape[0]
         elen_dev = self._h2d(elen)
         native = self.native_blocks and not self.time_sections
+        # one memset clears every block's BatchNorm accumulators (forward) / BN + positional-gradient accumulators (backward)
+        # instead of three small in-stream memsets per block (tfasr_block_io.prezeroed)
+        self._zero_pool = {}
+        if native and training:
+            c = self.cfg
+            self._zero_pool["fwd"] = torch.zeros(c.num_blocks, -(-(2 * c.dmodel + 1) // 64) * 64, dtype=torch.float32, device=self.device)
+            if ctx is not None:
+                self._zero_pool["bwd_shape"] = (c.num_blocks, -(-2 * c.dmodel // 64) * 64 + -(-2 * T * c.num_heads * c.head_size // 64) * 64)
         for i in range(self.cfg.num_blocks):
             x = self._block_fwd_native(x, i, B, T, elen_dev, training, ctx) if native else self._block_fwd(x, i, B, T, elen_dev, training, ctx)
         if ctx is not None:
@@ -529,6 +550,8 @@ class ConformerTransducer:
 
     def encoder_bwd(self, dx, ctx):
         e = ctx["enc"]
+        if "bwd_shape" in self._zero_pool:
+            self._zero_pool["bwd"] = torch.zeros(*self._zero_pool.pop("bwd_shape"), dtype=torch.float32, device=self.device)
         for i in reversed(range(self.cfg.num_blocks)):
             if f"enc/block{i}/native" in ctx:
                 dx = self._block_bwd_native(dx, i, ctx)

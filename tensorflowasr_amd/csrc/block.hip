@@ -354,8 +354,11 @@ struct Ex {
       a.alpha = tail_scale;
       gemm(a);
     }
-    float* dpext = f32(scratch, (long)R1 * HD);
-    zero(dpext, (size_t)R1 * HD * 4);
+    float* dpext = io->dpext_zero;
+    if (!dpext) {
+      dpext = f32(scratch, (long)R1 * HD);
+      zero(dpext, (size_t)R1 * HD * 4);
+    }
     {
       G a; a.A = dpos; a.lda = R1p; a.ta = 1; a.B = qv; a.ldb = HD; a.tb = 0; a.D = dpext; a.ldd = HD; a.M = R1; a.N = dh; a.K = T;
       a.nb1 = B; a.nb2 = H; a.sA1 = (long)H * T * R1p; a.sA2 = (long)T * R1p; a.sB1 = (long)T * HD; a.sB2 = dh; a.sD1 = 0; a.sD2 = dh;
@@ -400,7 +403,7 @@ struct Ex {
       chk(tfasr_glu_fwd(k->cv_a, k->cv_g, rows, d, c->dtype, s));
       chk(tfasr_dwconv_fwd(k->cv_g, fp(TFASR_BP_CV_DW_W), fp(TFASR_BP_CV_DW_B), k->cv_cv, c->B, c->T, d, c->ksize, c->dtype, s));
       if (c->training) {
-        zero(io->bn_stats, (size_t)(2 * d + 1) * 4);
+        if (!(io->prezeroed & 1)) zero(io->bn_stats, (size_t)(2 * d + 1) * 4);
         chk(tfasr_bn_stats(k->cv_cv, io->bn_stats, rows, d, c->dtype, s));
       }
     }
@@ -426,7 +429,7 @@ struct Ex {
     const void* dyd = mask_grad(dy, rows * d, site);
     void* dsw = act(scratch, rows * d);
     dense_bwd(dyd, k->cv_sw, TFASR_BP_CV_PW2_W, TFASR_BP_CV_PW2_B, d, d, dsw, c->conv_res);
-    zero(io->bn_bstats, (size_t)2 * d * 4);
+    if (!(io->prezeroed & 2)) zero(io->bn_bstats, (size_t)2 * d * 4);
     if (!dry) chk(tfasr_bn_bwd_stats(k->cv_cv, dsw, k->cv_fin, io->bn_bstats, rows, d, TFASR_ACT_SWISH, c->dtype, s));
     k->bw_dsw = dsw;
   }

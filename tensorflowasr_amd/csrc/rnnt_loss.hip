@@ -73,6 +73,10 @@ __global__ __launch_bounds__(256) void rnnt_logprobs_kernel(
     if (!cl.valid) continue;  // padded node: never read by the lattice / grad kernels
     const T* row = logits + r * V;
     RowStat st{-INFINITY, 0.f};
+    int lab = -1;  // issued before the row so that it is not a second dependent round trip
+    if (u < U1 - 1) lab = min(max(labels[(long)b * (U1 - 1) + u], 0), V - 1);
+    float x_blank = 0.f, x_truth = 0.f;
+    bool from_regs = false;
     if (vec_ok && V <= 2 * 64 * 8) {
       // the whole row sits in registers (<= 16 values per lane): row max first, then one exp2 per element
       float x[2][8];
@@ -99,6 +103,16 @@ __global__ __launch_bounds__(256) void rnnt_logprobs_kernel(
         for (int i = 0; i < 8; ++i) sum += __builtin_amdgcn_exp2f(x[c][i] * 1.4426950408889634f - m2);  // exp2(-inf) = 0 for the padding
       st.m = m;
       st.s = wave_sum(sum);
+      // blank = column 0 (lane 0, first value); truth = column lab: picked out of its owner's registers
+      from_regs = true;
+      x_blank = __shfl(x[0][0], 0, 64);
+      if (lab >= 0) {
+        const int q = lab & 7, c = lab >> 9;
+        float mine = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) mine = (i == q) ? (c ? x[1][i] : x[0][i]) : mine;
+        x_truth = __shfl(mine, (lab & 511) >> 3, 64);
+      }
     } else {
       if (vec_ok) {
         for (int v0 = lane * 8; v0 < V; v0 += 64 * 8) {
@@ -119,13 +133,9 @@ __global__ __launch_bounds__(256) void rnnt_logprobs_kernel(
     if (lane == 0) {
       const float l = st.m + logf(st.s);
       lse[r] = l;
-      blank_lp[r] = Num<T>::ld(row) - l;
+      blank_lp[r] = (from_regs ? x_blank : Num<T>::ld(row)) - l;
       float tr = -INFINITY;
-      if (u < U1 - 1) {
-        int lab = labels[(long)b * (U1 - 1) + u];
-        lab = min(max(lab, 0), V - 1);
-        tr = Num<T>::ld(row + lab) - l;
-      }
+      if (lab >= 0) tr = (from_regs ? x_truth : Num<T>::ld(row + lab)) - l;
       truth_lp[r] = tr;
     }
   }
@@ -271,6 +281,16 @@ __global__ __launch_bounds__(256) void rnnt_grad_kernel(
       }
       continue;
     }
+    // rows of <= 1024 values live in registers: their loads are issued before the (dependent, memory-side) lattice operands
+    const bool in_regs = vec_ok && V <= 2 * 64 * 8;
+    float xr[2][8];
+    if (in_regs) {
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const int v0 = lane * 8 + c * 512;
+        if (v0 < V) ld8(row + v0, xr[c]);
+      }
+    }
     const long lb = cell_off ? cell_off[b] : (long)b * Tm * U1;
     const float b00 = beta[lb];
     const float a = alpha[r];
@@ -289,9 +309,7 @@ __global__ __launch_bounds__(256) void rnnt_grad_kernel(
       // g_v = (-softmax_v * (gb+gt) + [v==0] gb + [v==lab] gt) * sc, with exp((x-l)) as one exp2 and the two special columns
       // patched per 8-value chunk (they are rare) instead of two compares per element
       const float l2 = l * 1.4426950408889634f, k1 = -ssum * sc, gbs = gb * sc, gts = gt * sc;
-      for (int v0 = lane * 8; v0 < V; v0 += 64 * 8) {
-        float x[8];
-        ld8(row + v0, x);
+      auto chunk = [&](float (&x)[8], int v0) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) x[i] = __builtin_amdgcn_exp2f(x[i] * 1.4426950408889634f - l2) * k1;
         if (v0 == 0) x[0] += gbs;
@@ -301,6 +319,19 @@ __global__ __launch_bounds__(256) void rnnt_grad_kernel(
           for (int i = 0; i < 8; ++i) x[i] += (i == q) ? gts : 0.f;
         }
         st8(out + v0, x);
+      };
+      if (in_regs) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const int v0 = lane * 8 + c * 512;
+          if (v0 < V) chunk(xr[c], v0);
+        }
+      } else {
+        for (int v0 = lane * 8; v0 < V; v0 += 64 * 8) {
+          float x[8];
+          ld8(row + v0, x);
+          chunk(x, v0);
+        }
       }
     } else {
       for (int v = lane; v < V; v += 64) {
