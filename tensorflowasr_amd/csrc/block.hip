@@ -149,13 +149,16 @@ struct Ex {
     forked = false;
     if (hipEventRecord(side->join, side->s2) != hipSuccess || hipStreamWaitEvent(s, side->join, 0) != hipSuccess) chk(TFASR_STATUS_EXECUTION_FAILED);
   }
+  // Split-K factor of a block's weight gradient (few 128x128 output tiles, K = B*T rows).  The f32 accumulate costs a flat
+  // ~3.1 ns per 1000 atomics (320 G atomics/s, independent of contention or XCD placement: tools/hwprobe/atomic_bench.hip),
+  // i.e. every extra k-slice adds M*N atomics, so the sweet spot is ONE workgroup per CU, not two: on [256,1024,12096]
+  // split 16 = 24.0 us, 11 = 26.6, 24 = 28.4, 32 = 33.3 (tools/hwprobe/gemm_timing.hip).
   static int split_k(int M, int N, long K) {
     const long tiles = (long)((M + 127) / 128) * ((N + 127) / 128);
-    if (tiles >= 512 || K <= 2048) return 1;
-    long v = (1024 + tiles - 1) / tiles;
-    if (K / 1024 < v) v = K / 1024;
-    if (v > 64) v = 64;
-    if (v >= 12) v = (v + 4) / 8 * 8;  // whole k-slices per XCD (gemm_fast.hip split-K mapping needs split % 8 == 0)
+    if (tiles >= 256 || K <= 2048) return 1;
+    long v = 256 / tiles;
+    if (K / 512 < v) v = K / 512;
+    if (v >= 8) v = v / 8 * 8;  // whole k-slices per XCD (gemm_fast.hip split-K mapping needs split % 8 == 0)
     return (int)(v < 1 ? 1 : v);
   }
   // y = x @ W + b with the fused epilogue terms (W stored [din, dout] in the compute-dtype shadow)
