@@ -603,7 +603,7 @@ int launch_one(const tfasr_gemm_args& a, hipStream_t stream) {
   // workgroups per CU overlap them (14.2 vs 16.9 us on [12096,256,1024]).  TFASR_GEMM_BN64=0 restores the old rule.
   static const bool bn64_off = getenv("TFASR_GEMM_BN64") && getenv("TFASR_GEMM_BN64")[0] == '0';
   const long t128 = (long)((a.N + 127) / 128) * ((a.M + BM - 1) / BM) * a.nb1 * a.nb2 * split;
-  const bool narrow = a.N <= 64 || (!bn64_off && t128 <= num_cus() && a.N > 64 && !a.colsum && !a.accumulate);
+  const bool narrow = a.N <= 64 || (!bn64_off && t128 <= num_cus() && a.N > 64 && !(a.accumulate && a.ws));
   const int bn = narrow ? 64 : 128;
   dim3 grid((a.N + bn - 1) / bn, (a.M + BM - 1) / BM, a.nb1 * a.nb2 * split);
   if ((long)grid.x * grid.y * grid.z > 0x7fffffffL) return TFASR_STATUS_INVALID_VALUE;
@@ -630,7 +630,7 @@ int launch_one(const tfasr_gemm_args& a, hipStream_t stream) {
   }
   if (a.colsum) {
     if constexpr (TA && !TB) {
-      if (!narrow && a.accumulate) return launch_epi<TA, TB, 128, E_CSUM>(a, grid, stream);
+      if (a.accumulate && a.N > 64) return narrow ? launch_epi<TA, TB, 64, E_CSUM>(a, grid, stream) : launch_epi<TA, TB, 128, E_CSUM>(a, grid, stream);
     }
     return TFASR_STATUS_UNSUPPORTED;  // tfasr_gemm falls back to a separate column-sum pass
   }
