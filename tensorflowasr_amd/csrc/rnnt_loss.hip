@@ -281,16 +281,6 @@ __global__ __launch_bounds__(256) void rnnt_grad_kernel(
       }
       continue;
     }
-    // rows of <= 1024 values live in registers: their loads are issued before the (dependent, memory-side) lattice operands
-    const bool in_regs = vec_ok && V <= 2 * 64 * 8;
-    float xr[2][8];
-    if (in_regs) {
-#pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        const int v0 = lane * 8 + c * 512;
-        if (v0 < V) ld8(row + v0, xr[c]);
-      }
-    }
     const long lb = cell_off ? cell_off[b] : (long)b * Tm * U1;
     const float b00 = beta[lb];
     const float a = alpha[r];
@@ -307,9 +297,12 @@ __global__ __launch_bounds__(256) void rnnt_grad_kernel(
     const float ssum = gb + gt;
     if (vec_ok) {
       // g_v = (-softmax_v * (gb+gt) + [v==0] gb + [v==lab] gt) * sc, with exp((x-l)) as one exp2 and the two special columns
-      // patched per 8-value chunk (they are rare) instead of two compares per element
+      // patched per 8-value chunk (they are rare) instead of two compares per element.  (Issuing the row loads ahead of the
+      // lattice operands, the whole row held in registers, was measured SLOWER: 611 vs 505 us - lower occupancy.)
       const float l2 = l * 1.4426950408889634f, k1 = -ssum * sc, gbs = gb * sc, gts = gt * sc;
-      auto chunk = [&](float (&x)[8], int v0) {
+      for (int v0 = lane * 8; v0 < V; v0 += 64 * 8) {
+        float x[8];
+        ld8(row + v0, x);
 #pragma unroll
         for (int i = 0; i < 8; ++i) x[i] = __builtin_amdgcn_exp2f(x[i] * 1.4426950408889634f - l2) * k1;
         if (v0 == 0) x[0] += gbs;
@@ -319,19 +312,6 @@ __global__ __launch_bounds__(256) void rnnt_grad_kernel(
           for (int i = 0; i < 8; ++i) x[i] += (i == q) ? gts : 0.f;
         }
         st8(out + v0, x);
-      };
-      if (in_regs) {
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-          const int v0 = lane * 8 + c * 512;
-          if (v0 < V) chunk(xr[c], v0);
-        }
-      } else {
-        for (int v0 = lane * 8; v0 < V; v0 += 64 * 8) {
-          float x[8];
-          ld8(row + v0, x);
-          chunk(x, v0);
-        }
       }
     } else {
       for (int v = lane; v < V; v += 64) {

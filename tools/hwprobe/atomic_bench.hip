@@ -21,6 +21,36 @@ __global__ __launch_bounds__(256) void atomic_epi(float* out, int ldd, int tiles
       else __hip_atomic_fetch_add(p, 1.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
 }
+// the MFMA fragment layout gemm_fast uses for its accumulate epilogue: one instruction = 4 rows x 16 consecutive columns
+__global__ __launch_bounds__(256) void atomic_frag(float* out, int ldd, int tiles_n, int ntiles, int split) {
+  const int id = blockIdx.x, x = id & 7, j = id >> 3;
+  const int per = split / 8, tile = j / per;
+  const int tm = tile / tiles_n, tn = tile % tiles_n;
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63, r = l & 15, g = l >> 4;
+  const int wm = w >> 1, wn = w & 1;
+  (void)x;
+  for (int i = 0; i < 4; ++i)
+    for (int jj = 0; jj < 4; ++jj)
+      for (int e = 0; e < 4; ++e) {
+        const int row = tm * 128 + wm * 64 + i * 16 + g * 4 + e, col = tn * 128 + wn * 64 + jj * 16 + r;
+        atomicAdd(out + (long)row * ldd + col, 1.0f);
+      }
+}
+void run_frag(float* out, int M, int N, int split) {
+  const int tiles_n = N / 128, ntiles = (M / 128) * tiles_n, grid = ntiles * split;
+  hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  for (int i = 0; i < 3; ++i) atomic_frag<<<grid, 256>>>(out, N, tiles_n, ntiles, split);
+  (void)hipMemset(out, 0, (size_t)M * N * 4);
+  (void)hipEventRecord(e0);
+  for (int i = 0; i < 20; ++i) atomic_frag<<<grid, 256>>>(out, N, tiles_n, ntiles, split);
+  (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+  float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+  float* h = (float*)malloc((size_t)M * N * 4);
+  (void)hipMemcpy(h, out, (size_t)M * N * 4, hipMemcpyDeviceToHost);
+  long bad = 0; for (long i = 0; i < (long)M * N; ++i) bad += h[i] != 20.f * split;
+  printf("%-34s %dx%d split %d: %.1f us/launch, wrong sums %ld\n", "fragment layout (4 rows x 64 B)", M, N, split, ms / 20 * 1e3, bad);
+  free(h);
+}
 template <int SCOPE, int MAP>
 void run(const char* name, float* out, int M, int N, int split) {
   const int tiles_n = N / 128, ntiles = (M / 128) * tiles_n, grid = ntiles * split;
@@ -47,5 +77,7 @@ int main() {
   run<0, 0>("48 per address (12.6M)", out, 256, 1024, 48);
   run<0, 0>("1 per address x 8 (8.4M)", out, 1024, 1024, 8);
   run<0, 0>("4096x1024 split 8 (33M)", out, 4096, 1024, 8);
+  run_frag(out, 256, 1024, 24);
+  run_frag(out, 256, 1024, 16);
   return 0;
 }
