@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define TFASR_ABI_VERSION 12
+#define TFASR_ABI_VERSION 13
 
 typedef enum {
   TFASR_STATUS_SUCCESS = 0,
@@ -146,6 +146,12 @@ int tfasr_layernorm_fwd(const void* x, const float* gamma, const float* beta, vo
 int tfasr_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
                         const void* add, void* dx, float* dgamma, float* dbeta, long rows, int C, int dtype,
                         void* stream);
+/* tfasr_layernorm_bwd with a second output: dx_dropped = tfasr_dropout(dx, drop_p, drop_seed) (the gradient entering the NEXT
+   module's dropped branch in backward order), written by the same kernel instead of a separate pass over dx.
+   dx_dropped == NULL: identical to tfasr_layernorm_bwd. */
+int tfasr_layernorm_bwd_drop(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
+                             const void* add, void* dx, float* dgamma, float* dbeta, void* dx_dropped, float drop_p,
+                             long drop_seed, long rows, int C, int dtype, void* stream);
 int tfasr_bn_stats(const void* x, float* stats, long rows, int C, int dtype, void* stream);
 int tfasr_bn_finalize(const float* stats, float count, const float* gamma, const float* beta, float* fin,
                       float* moving_mean, float* moving_var, float momentum, float eps, int C, int training,

@@ -146,7 +146,7 @@ def load(build_if_missing=True):
     return lib
 
 
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 
 def check(status, what=""):

@@ -44,6 +44,7 @@ struct Ctx {
   // phase carry
   size_t stash_off, scratch_off;
   void *bw_dx, *bw_dsw, *bw_cur, *bw_nxt;
+  void *bw_curd, *bw_nxtd;  // dropout(bw_cur / bw_nxt) for the consumer's dropped branch, written by the producing LayerNorm backward
   long drop_epoch;
   int fused;
 };
@@ -190,8 +191,19 @@ struct Ex {
   void ln_fwd(const void* x, int gi, int bi, void* y, float* mean, float* rstd) {
     if (!dry) chk(tfasr_layernorm_fwd(x, fp(gi), fp(bi), y, mean, rstd, rows, c->d, c->ln_eps, c->dtype, s));
   }
-  void ln_bwd(const void* dy, const void* x, int gi, int bi, const float* mean, const float* rstd, const void* add, void* dx) {
-    if (!dry) chk(tfasr_layernorm_bwd(dy, x, fp(gi), mean, rstd, add, dx, gp(gi), gp(bi), rows, c->d, c->dtype, s));
+  // dxd != nullptr: the same kernel also writes dropout(dx) with the NEXT module's (backward order) output-dropout mask, which
+  // that module would otherwise produce with a separate pass over dx (mask_grad): 4-5 launches and 2 x rows*d of traffic per block
+  void ln_bwd(const void* dy, const void* x, int gi, int bi, const float* mean, const float* rstd, const void* add, void* dx,
+              void* dxd = nullptr, int next_site = -1) {
+    if (dry) return;
+    if (dxd && drop_p() > 0.f && next_site >= 0)
+      chk(tfasr_layernorm_bwd_drop(dy, x, fp(gi), mean, rstd, add, dx, gp(gi), gp(bi), dxd, drop_p(), seed(next_site), rows, c->d, c->dtype, s));
+    else
+      chk(tfasr_layernorm_bwd(dy, x, fp(gi), mean, rstd, add, dx, gp(gi), gp(bi), rows, c->d, c->dtype, s));
+  }
+  const void* masked(const void* dy, const void* pre, long elems, int site) {
+    if (drop_p() <= 0.f) return dy;
+    return pre ? pre : mask_grad(dy, elems, site);
   }
 
   // ------------------------------------------------------------------------------------------ FFModule
@@ -212,11 +224,11 @@ struct Ex {
     b.bias = fp(b0 + 5);
     gemm(b);
   }
-  void ffm_bwd(int m, const void* dy, void* dx, int site) {
+  void ffm_bwd(int m, const void* dy, const void* dy_dropped, void* dx, void* dxd, int site, int next_site) {
     const int b0 = m == 0 ? TFASR_BP_FF1_LN_G : TFASR_BP_FF2_LN_G;
     const int d = c->d, F = c->dff;
     const size_t mark = scratch.off;
-    const void* dyd = mask_grad(dy, rows * d, site + 1);
+    const void* dyd = masked(dy, dy_dropped, rows * d, site + 1);
     void* dz = act(scratch, rows * F);
     // (x = h, W = d2) -> dz [rows, F] = f * (dyd @ W2^T) * swish'(z) * mask1
     {
@@ -232,7 +244,7 @@ struct Ex {
     }
     void* dln = act(scratch, rows * d);
     dense_bwd(dz, k->ff_ln[m], b0 + 2, b0 + 3, d, F, dln);
-    ln_bwd(dln, k->ff_x[m], b0, b0 + 1, k->ff_mean[m], k->ff_rstd[m], dy, dx);
+    ln_bwd(dln, k->ff_x[m], b0, b0 + 1, k->ff_mean[m], k->ff_rstd[m], dy, dx, dxd, next_site);
     scratch.off = mark;
   }
 
@@ -288,12 +300,12 @@ struct Ex {
     o.bias = fp(TFASR_BP_AT_O_B);
     gemm(o);
   }
-  void mhsa_bwd(const void* dy, void* dx, int site) {
+  void mhsa_bwd(const void* dy, const void* dy_dropped, void* dx, void* dxd, int site, int next_site) {
     const int d = c->d, H = c->H, dh = c->dh, HD = H * dh, T = c->T, B = c->B, R1 = 2 * T;
     const int Tp = (T + 7) / 8 * 8, R1p = (R1 + 7) / 8 * 8;
     const float scale = 1.f / sqrtf((float)dh);
     const size_t mark = scratch.off;
-    const void* dyd = mask_grad(dy, rows * d, site);
+    const void* dyd = masked(dy, dy_dropped, rows * d, site);
     void* datt = act(scratch, rows * HD);
     // output projection (din = HD, dout = d)
     {
@@ -384,7 +396,7 @@ struct Ex {
     if (!dry) chk(tfasr_colsum(dpext, HD, gp(TFASR_BP_AT_POS_B), R1, HD, 1.f, TFASR_F32, s));
     void* dln = act(scratch, rows * d);
     dense_bwd(dqkv, k->at_ln, TFASR_BP_AT_QKV_W, TFASR_BP_AT_QKV_B, d, 3 * HD, dln);
-    ln_bwd(dln, k->at_x, TFASR_BP_AT_LN_G, TFASR_BP_AT_LN_B, k->at_mean, k->at_rstd, dy, dx);
+    ln_bwd(dln, k->at_x, TFASR_BP_AT_LN_G, TFASR_BP_AT_LN_B, k->at_mean, k->at_rstd, dy, dx, dxd, next_site);
     scratch.off = mark;
   }
 
@@ -427,16 +439,16 @@ struct Ex {
     o.bias = fp(TFASR_BP_CV_PW2_B);
     gemm(o);
   }
-  void conv_bwd_a(const void* dy, int site) {
+  void conv_bwd_a(const void* dy, const void* dy_dropped, int site) {
     const int d = c->d;
-    const void* dyd = mask_grad(dy, rows * d, site);
+    const void* dyd = masked(dy, dy_dropped, rows * d, site);
     void* dsw = act(scratch, rows * d);
     dense_bwd(dyd, k->cv_sw, TFASR_BP_CV_PW2_W, TFASR_BP_CV_PW2_B, d, d, dsw, c->conv_res);
     if (!(io->prezeroed & 2)) zero(io->bn_bstats, (size_t)2 * d * 4);
     if (!dry) chk(tfasr_bn_bwd_stats(k->cv_cv, dsw, k->cv_fin, io->bn_bstats, rows, d, TFASR_ACT_SWISH, c->dtype, s));
     k->bw_dsw = dsw;
   }
-  void conv_bwd_b(const void* dy, void* dx) {
+  void conv_bwd_b(const void* dy, void* dx, void* dxd, int next_site) {
     const int d = c->d;
     size_t dwws_bytes = 0;
     tfasr_dwconv_bwd_weight_workspace_size(c->B, c->T, d, c->ksize, &dwws_bytes);
@@ -455,7 +467,7 @@ struct Ex {
       chk(tfasr_glu_bwd(k->cv_a, dg, da, rows, d, c->dtype, s));
     }
     dense_bwd(da, k->cv_ln, TFASR_BP_CV_PW1_W, TFASR_BP_CV_PW1_B, d, 2 * d, dln);
-    ln_bwd(dln, k->cv_x, TFASR_BP_CV_LN_G, TFASR_BP_CV_LN_B, k->cv_mean, k->cv_rstd, dy, dx);
+    ln_bwd(dln, k->cv_x, TFASR_BP_CV_LN_G, TFASR_BP_CV_LN_B, k->cv_mean, k->cv_rstd, dy, dx, dxd, next_site);
   }
 
   // ------------------------------------------------------------------------------------------ block
@@ -488,20 +500,23 @@ struct Ex {
     if (phase & TFASR_PHASE_A) {
       k->bw_cur = act(scratch, rows * d);
       k->bw_nxt = act(scratch, rows * d);
-      ln_bwd(io->dy, k->ln_x, TFASR_BP_LN_G, TFASR_BP_LN_B, k->ln_mean, k->ln_rstd, nullptr, k->bw_cur);
-      ffm_bwd(1, k->bw_cur, k->bw_nxt, 4);
-      { void* t = k->bw_cur; k->bw_cur = k->bw_nxt; k->bw_nxt = t; }
-      conv_bwd_a(k->bw_cur, 3);
+      const bool dr = drop_p() > 0.f;
+      k->bw_curd = dr ? act(scratch, rows * d) : nullptr;
+      k->bw_nxtd = dr ? act(scratch, rows * d) : nullptr;
+      ln_bwd(io->dy, k->ln_x, TFASR_BP_LN_G, TFASR_BP_LN_B, k->ln_mean, k->ln_rstd, nullptr, k->bw_cur, k->bw_curd, 5);
+      ffm_bwd(1, k->bw_cur, k->bw_curd, k->bw_nxt, k->bw_nxtd, 4, 3);
+      { void* t = k->bw_cur; k->bw_cur = k->bw_nxt; k->bw_nxt = t; t = k->bw_curd; k->bw_curd = k->bw_nxtd; k->bw_nxtd = t; }
+      conv_bwd_a(k->bw_cur, k->bw_curd, 3);
       k->scratch_off = scratch.off;
     }
     if (phase & TFASR_PHASE_B) {
       scratch.off = k->scratch_off;
       const size_t mark = scratch.off;
-      conv_bwd_b(k->bw_cur, k->bw_nxt);
+      conv_bwd_b(k->bw_cur, k->bw_nxt, k->bw_nxtd, 2);
       scratch.off = mark;
-      { void* t = k->bw_cur; k->bw_cur = k->bw_nxt; k->bw_nxt = t; }
-      mhsa_bwd(k->bw_cur, k->bw_nxt, 2);
-      ffm_bwd(0, k->bw_nxt, io->dx, 0);
+      { void* t = k->bw_cur; k->bw_cur = k->bw_nxt; k->bw_nxt = t; t = k->bw_curd; k->bw_curd = k->bw_nxtd; k->bw_nxtd = t; }
+      mhsa_bwd(k->bw_cur, k->bw_curd, k->bw_nxt, k->bw_nxtd, 2, 1);
+      ffm_bwd(0, k->bw_nxt, k->bw_nxtd, io->dx, nullptr, 0, -1);
     }
     join();
   }

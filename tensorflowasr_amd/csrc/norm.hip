@@ -275,12 +275,13 @@ __global__ __launch_bounds__(512) void ln_bwd_vec_kernel(const T* __restrict__ d
                                                           const float* __restrict__ gamma, const float* __restrict__ mean,
                                                           const float* __restrict__ rstd, const T* add, T* dx,
                                                           float* __restrict__ dgamma, float* __restrict__ dbeta, long rows,
-                                                          int C) {
+                                                          int C, T* dxm, float drop_p, uint64_t drop_seed) {
   constexpr int RPW = 64 / LPR;
   __shared__ float red[2][8 * RPW][LPR * 8];  // up to 8 waves (512 threads)
   const int lane = threadIdx.x & 63, li = lane % LPR, sub = lane / LPR, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const int c0 = li * 8;
   const bool act = c0 < C;
+  const float drop_inv = 1.f / (1.f - drop_p);
   float g[8], ag[8], ab[8];
   ldf8(gamma + c0, g, act);
 #pragma unroll
@@ -320,7 +321,18 @@ __global__ __launch_bounds__(512) void ln_bwd_vec_kernel(const T* __restrict__ d
       if (rv[u]) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) o[u][k] += rs[u] * (d[u][k] * g[k] - s1 - xv[u][k] * s2);
-        st8(dx + (r0 + u * step) * C + c0, o[u]);
+        const long base = (r0 + u * step) * C + c0;
+        st8(dx + base, o[u]);
+        if (dxm) {  // second output: dropout(dx) for the consumer's masked branch, computed from the ROUNDED dx (= tfasr_dropout(dx))
+          float mv[8];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            float rr = o[u][k];
+            if (sizeof(T) == 2) rr = bf16_to_f32(f32_to_bf16(rr));
+            mv[k] = drop_keep(drop_seed, (uint64_t)(base + k), drop_p) ? rr * drop_inv : 0.f;
+          }
+          st8(dxm + base, mv);
+        }
       }
     }
   }
@@ -434,19 +446,20 @@ extern "C" int tfasr_layernorm_fwd(const void* x, const float* gamma, const floa
   return TFASR_STATUS_SUCCESS;
 }
 
-extern "C" int tfasr_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean,
-                                   const float* rstd, const void* add, void* dx, float* dgamma, float* dbeta, long rows,
-                                   int C, int dtype, void* stream_) {
+extern "C" int tfasr_layernorm_bwd_drop(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
+                                        const void* add, void* dx, float* dgamma, float* dbeta, void* dx_dropped, float drop_p,
+                                        long drop_seed, long rows, int C, int dtype, void* stream_) {
   if (!dy || !x || !gamma || !mean || !rstd || !dx || rows <= 0 || C <= 0 || C > 64 * MAXC_PER_LANE)
     return TFASR_STATUS_INVALID_VALUE;
+  if (dx_dropped && !(drop_p >= 0.f && drop_p < 1.f)) return TFASR_STATUS_INVALID_VALUE;
   hipStream_t s = (hipStream_t)stream_;
   if (dtype == TFASR_BF16 && (C % 8) == 0 && C <= 512) {
     if (C <= 256) {
       const int grid = fat_grid(rows, 2);
-      hipLaunchKernelGGL((ln_bwd_vec_kernel<bf16_t, 32>), dim3(grid), dim3(red_threads()), 0, s, (const bf16_t*)dy, (const bf16_t*)x, gamma, mean, rstd, (const bf16_t*)add, (bf16_t*)dx, dgamma, dbeta, rows, C);
+      hipLaunchKernelGGL((ln_bwd_vec_kernel<bf16_t, 32>), dim3(grid), dim3(red_threads()), 0, s, (const bf16_t*)dy, (const bf16_t*)x, gamma, mean, rstd, (const bf16_t*)add, (bf16_t*)dx, dgamma, dbeta, rows, C, (bf16_t*)dx_dropped, drop_p, (uint64_t)drop_seed);
     } else {
       const int grid = fat_grid(rows, 1);
-      hipLaunchKernelGGL((ln_bwd_vec_kernel<bf16_t, 64>), dim3(grid), dim3(red_threads()), 0, s, (const bf16_t*)dy, (const bf16_t*)x, gamma, mean, rstd, (const bf16_t*)add, (bf16_t*)dx, dgamma, dbeta, rows, C);
+      hipLaunchKernelGGL((ln_bwd_vec_kernel<bf16_t, 64>), dim3(grid), dim3(red_threads()), 0, s, (const bf16_t*)dy, (const bf16_t*)x, gamma, mean, rstd, (const bf16_t*)add, (bf16_t*)dx, dgamma, dbeta, rows, C, (bf16_t*)dx_dropped, drop_p, (uint64_t)drop_seed);
     }
     TFASR_CHECK_LAUNCH();
     return TFASR_STATUS_SUCCESS;
@@ -459,7 +472,15 @@ extern "C" int tfasr_layernorm_bwd(const void* dy, const void* x, const float* g
     hipLaunchKernelGGL(ln_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x, gamma,
                        mean, rstd, (const bf16_t*)add, (bf16_t*)dx, dgamma, dbeta, rows, C);
   TFASR_CHECK_LAUNCH();
+  // shapes outside the vectorised kernel: the dropped copy is a separate pass (same mask, same rounding)
+  if (dx_dropped) return tfasr_dropout(dx, dx_dropped, rows * C, drop_p, drop_seed, dtype, stream_);
   return TFASR_STATUS_SUCCESS;
+}
+
+extern "C" int tfasr_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean,
+                                   const float* rstd, const void* add, void* dx, float* dgamma, float* dbeta, long rows,
+                                   int C, int dtype, void* stream_) {
+  return tfasr_layernorm_bwd_drop(dy, x, gamma, mean, rstd, add, dx, dgamma, dbeta, nullptr, 0.f, 0, rows, C, dtype, stream_);
 }
 
 extern "C" int tfasr_bn_stats(const void* x, float* stats, long rows, int C, int dtype, void* stream_) {

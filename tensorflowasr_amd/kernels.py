@@ -161,10 +161,15 @@ def layernorm_fwd(x, gamma, beta, eps=1e-3, save_stats=True):
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, add=None, dx=None):
+def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, add=None, dx=None, dropped=None, drop_p=0.0, drop_seed=0):
+    """dropped (optional, same shape as dx): also receives dropout(dx, drop_p, drop_seed) from the same kernel."""
     rows, C = x.numel() // x.shape[-1], x.shape[-1]
     if dx is None:
         dx = torch.empty_like(x)
+    if dropped is not None:
+        check(_L().tfasr_layernorm_bwd_drop(_p(dy), _p(x), _p(gamma), _p(mean), _p(rstd), _p(add), _p(dx), _p(dgamma), _p(dbeta), _p(dropped),
+                                            float(drop_p), int(drop_seed), rows, C, _dt(x), _stream()), "layernorm_bwd_drop")
+        return dx
     check(_L().tfasr_layernorm_bwd(_p(dy), _p(x), _p(gamma), _p(mean), _p(rstd), _p(add), _p(dx), _p(dgamma), _p(dbeta), rows, C, _dt(x), _stream()), "layernorm_bwd")
     return dx
 

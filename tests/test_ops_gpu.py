@@ -49,6 +49,29 @@ def test_layernorm(dev, dtype, C):
 
 
 @pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("C", [256, 144, 40])
+def test_layernorm_bwd_with_dropped_copy(dev, dtype, C):
+    """tfasr_layernorm_bwd_drop == tfasr_layernorm_bwd followed by tfasr_dropout(dx) (bit-exact: same mask, same rounding), for the
+    vectorised kernel (bf16, C % 8 == 0) and the fallback shapes."""
+    g = torch.Generator().manual_seed(C)
+    rows = 301
+    x = (torch.randn(rows, C, generator=g) * 2 + 0.5).to(dev).to(dtype)
+    dy = torch.randn(rows, C, generator=g).to(dev).to(dtype)
+    add = torch.randn(rows, C, generator=g).to(dev).to(dtype)
+    gam, bet = torch.randn(C, generator=g).to(dev), torch.randn(C, generator=g).to(dev)
+    _, mean, rstd = K.layernorm_fwd(x, gam, bet)
+    dg1, db1, dg2, db2 = (torch.zeros(C, device=dev) for _ in range(4))
+    dx1 = K.layernorm_bwd(dy, x, gam, mean, rstd, dg1, db1, add=add)
+    want = K.dropout(dx1, 0.1, 12345)
+    dropped = torch.empty_like(x)
+    dx2 = K.layernorm_bwd(dy, x, gam, mean, rstd, dg2, db2, add=add, dropped=dropped, drop_p=0.1, drop_seed=12345)
+    assert torch.equal(dx1, dx2) and torch.equal(dropped, want)
+    cmp(dg1, dg2, rtol=1e-5, atol=1e-4)
+    frac = float((dropped == 0).float().mean())
+    assert 0.05 < frac < 0.16
+
+
+@pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("C", [144, 1280])  # 1280 = ContextNet-L width: channel slabs in the statistics kernels
 def test_batchnorm_swish(dev, dtype, C):
     if C > 1024 and dtype == torch.float32:
