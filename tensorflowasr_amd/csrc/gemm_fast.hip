@@ -572,6 +572,173 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   }
 }
 
+int num_cus();
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Small-output weight gradient: D[M,N] (f32) += alpha * A^T B over K = rows, A stored [K, M], B stored [K, N], few output tiles.
+// The f32 accumulate costs a flat ~3.1 us per million atomics (tools/hwprobe/atomic_bench.hip), i.e. `workgroups x tile area`,
+// while filling the chip needs ~one workgroup per CU - so the only way to pay fewer atomics at full occupancy is to reduce
+// INSIDE the CU first.  One 8-wave workgroup per (128x64 tile, k-slice): its two 4-wave groups run the 2-stage LDS-DMA
+// pipeline of gemm_fast_kernel on the two halves of the slice (they overlap each other's DMA-issue stalls like two resident
+// workgroups would), then group 1 hands its accumulators to group 0 through LDS and group 0 alone issues the atomics:
+// half the atomics of two independent 128x64 workgroups per CU, a quarter of the 128x128 split-K kernel at one per CU.
+// A partial last slab (K % 64) is DMA'd from clamped rows and its invalid k-rows of the B image are zeroed in LDS.
+template <bool CS>
+__global__ __launch_bounds__(512, 1) void wgrad_kg2_kernel(const tfasr_gemm_args p, const int gx, const int gy, const int split) {
+  constexpr int BN_ = 64, NJ = 2, WN = 32;
+  constexpr int B_BYTES = BN_ * BK * 2;
+  constexpr int STAGE_BYTES = A_BYTES + B_BYTES;      // 24 KiB
+  constexpr int GROUP_BYTES = 2 * STAGE_BYTES;        // 48 KiB per wave group
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int grp = w >> 2, w4 = w & 3, wm = w4 >> 1, wn = w4 & 1;
+  const int r = lane & 15, g = lane >> 4;
+  const int t256 = threadIdx.x & 255;
+  char* gmem = smem + grp * GROUP_BYTES;
+
+  // (tile, k-slice) of this workgroup; with split % 8 == 0 a whole k-slice (all its tiles re-read the same rows) stays on one XCD
+  const int tpp = gx * gy;
+  int ks, t;
+  if ((split & 7) == 0 && (gridDim.x & 7) == 0) { const int x = blockIdx.x & 7, j = blockIdx.x >> 3; ks = x + 8 * (j / tpp); t = j % tpp; }
+  else { ks = blockIdx.x / tpp; t = blockIdx.x % tpp; }
+  const int m0 = (t / gx) * BM, n0 = (t % gx) * BN_;
+  int kchunk = (p.K + split - 1) / split;
+  kchunk = ((kchunk + BK - 1) / BK) * BK;
+  const int k_begin = ks * kchunk, k_end = min(p.K, k_begin + kchunk);
+  const int len = max(k_end - k_begin, 0);
+  const int nsl = (len + BK - 1) / BK;                // slabs of this workgroup (the last one may be partial)
+  if (nsl == 0) return;                               // uniform over the workgroup
+  const int kv_last = len - (nsl - 1) * BK;           // valid k-rows of the last slab (64 = full)
+  const int n_g0 = (nsl + 1) >> 1;                    // group 0: slabs [0, n_g0), group 1: [n_g0, nsl)
+  const int base = grp ? n_g0 : 0, n_g = grp ? nsl - n_g0 : n_g0;
+  const int part_grp = nsl >= 2 ? 1 : 0, part_idx = (nsl >= 2 ? nsl - n_g0 : n_g0) - 1;  // owner / local index of the last slab
+  const bool has_part = kv_last < BK;
+
+  const bf16_t* A = (const bf16_t*)p.A;
+  const bf16_t* B = (const bf16_t*)p.B;
+  const bf16_t* sa[4];
+  const bf16_t* sb[2];
+  prep_trans<128>(sa, A, p.lda, m0, p.M, k_begin + base * BK, w4, lane);
+  prep_trans<BN_>(sb, B, p.ldb, n0, p.N, k_begin + base * BK, w4, lane);
+  const long stepA = (long)BK * p.lda, stepB = (long)BK * p.ldb;
+  auto issue = [&](int s, int stage) {  // group-local slab s
+    char* sA = gmem + stage * STAGE_BYTES;
+    char* sB = sA + A_BYTES;
+    if (has_part && grp == part_grp && s == part_idx) {
+      // partial slab: k-rows past the end are fetched from the last valid row (finite data), then zeroed in LDS
+      const int kt = k_begin + (base + s) * BK, kmax = p.K - 1;
+      const int maxa = ((p.M + 7) >> 3) - 1, maxb = ((p.N + 7) >> 3) - 1;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int q = w4 * 4 + i, k = q * 4 + lane / 16, c = min((m0 >> 3) + ((lane % 16) ^ key_t(k)), maxa);
+        __builtin_amdgcn_global_load_lds(GLB_PTR(A + (long)min(kt + k, kmax) * p.lda + ((long)c << 3)), LDS_PTR(sA + __builtin_amdgcn_readfirstlane(q * 1024)), 16, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int q = w4 * 2 + i, k = q * 8 + lane / 8, c = min((n0 >> 3) + ((lane % 8) ^ key_t64(k)), maxb);
+        __builtin_amdgcn_global_load_lds(GLB_PTR(B + (long)min(kt + k, kmax) * p.ldb + ((long)c << 3)), LDS_PTR(sB + __builtin_amdgcn_readfirstlane(q * 1024)), 16, 0, 0);
+      }
+    } else {
+      issue_from<128>(sA, sa, s * stepA, w4);
+      issue_from<BN_>(sB, sb, s * stepB, w4);
+    }
+  };
+
+  float4_t acc[4][NJ];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[i][j] = float4_t{0.f, 0.f, 0.f, 0.f};
+  float4_t accb[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) accb[j] = float4_t{0.f, 0.f, 0.f, 0.f};
+  const bool do_cs = CS && p.colsum && m0 == 0 && wm == 0;
+
+  if (n_g > 0) issue(0, 0);
+  if (n_g > 1) issue(1, 1);
+  // both groups run n_g0 iterations (group 1 may idle through the last one): the barriers are workgroup-wide
+  for (int s = 0; s < n_g0; ++s) {
+    const int stage = s & 1;
+    const bool active = s < n_g;
+    if (active) {
+      if (s + 1 < n_g) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    if (has_part && s == part_idx) {  // uniform: every wave takes this branch in the same iteration
+      if (grp == part_grp) {
+        char* sB = gmem + stage * STAGE_BYTES + A_BYTES;
+        for (int c = t256; c < (BK - kv_last) * 8; c += 256) *reinterpret_cast<uint4*>(sB + kv_last * 128 + c * 16) = make_uint4(0, 0, 0, 0);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+    if (active) mma_slab<true, false, BN_, CS>(gmem + stage * STAGE_BYTES, gmem + stage * STAGE_BYTES + A_BYTES, wm, wn, lane, acc, accb, do_cs);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (active && s + 2 < n_g) issue(s + 2, stage);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  // ---- reduce group 1 into group 0 through LDS (element-major layout: consecutive lanes, consecutive dwords) ----
+  float* red = reinterpret_cast<float*>(smem + GROUP_BYTES);  // group 1's own (now idle) stages: 40 x 256 floats = 40 KiB <= 48 KiB
+  if (grp == 1) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) red[((i * NJ + j) * 4 + e) * 256 + t256] = acc[i][j][e];
+    if constexpr (CS) {
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) red[(32 + j * 4 + e) * 256 + t256] = accb[j][e];
+    }
+  }
+  __syncthreads();
+  if (grp == 1) return;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[i][j][e] += red[((i * NJ + j) * 4 + e) * 256 + t256];
+  if constexpr (CS) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) accb[j][e] += red[(32 + j * 4 + e) * 256 + t256];
+    if (do_cs && g == 0) {
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int col = n0 + wn * WN + j * 16 + r;
+        if (col < p.N) atomicAdd(p.colsum + col, p.alpha * accb[j][0]);
+      }
+    }
+  }
+  float* Df = (float*)p.D;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int col = n0 + wn * WN + j * 16 + r;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int row = m0 + wm * 64 + i * 16 + g * 4 + e;
+        if (col < p.N && row < p.M) atomicAdd(Df + (long)row * p.ldd + col, p.alpha * acc[i][j][e]);
+      }
+    }
+}
+
+// the k-split this kernel wants: one workgroup per CU, at least two slabs per workgroup
+inline int wgrad_kg2_split(long tiles64, int K) {
+  long v = num_cus() / tiles64;
+  if (K / 128 < v) v = K / 128;
+  if (v >= 8) v = v / 8 * 8;
+  return (int)(v < 1 ? 1 : v);
+}
+
 int num_cus() {
   static int n = 0;
   if (n == 0) {
@@ -628,6 +795,24 @@ int launch_one(const tfasr_gemm_args& a, hipStream_t stream) {
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rg), dim3(256), 0, stream, (const float*)a.ws, (float*)a.D, a.M, a.N, a.ldd, split);
     TFASR_CHECK_LAUNCH();
     return TFASR_STATUS_SUCCESS;
+  }
+  if constexpr (TA && !TB) {
+    // small-output weight gradients: reduce the k-slices inside the CU before the atomics (wgrad_kg2_kernel).  OPT-IN
+    // (TFASR_GEMM_KG2=1, read per call so that tests can switch it): in isolation it wins (FFN layer 22.4 -> 18.6 us, L2-warm
+    // operands), inside the train step it lost 0.26 ms (36.45 vs 36.19 ms/step on the same box) - one 8-wave workgroup per CU
+    // with two 2-stage pipelines hides the HBM-cold operand latency worse than two independent 128x64 workgroups do.
+    const char* kg2_env = getenv("TFASR_GEMM_KG2");
+    const bool kg2_on = kg2_env && kg2_env[0] == '1';
+    const long tiles64 = (long)((a.N + 63) / 64) * ((a.M + BM - 1) / BM);
+    if (kg2_on && a.accumulate && a.out_f32 && !a.ws && !a.bias && a.nb1 * a.nb2 == 1 && split > 1 && tiles64 <= 128 && a.N > 64) {
+      const int ks = wgrad_kg2_split(tiles64, a.K);
+      const int gxx = (a.N + 63) / 64, gyy = (a.M + BM - 1) / BM;
+      constexpr int SMEM = 4 * (A_BYTES + 64 * BK * 2);
+      if (a.colsum) hipLaunchKernelGGL(wgrad_kg2_kernel<true>, dim3(gxx * gyy * ks), dim3(512), SMEM, stream, a, gxx, gyy, ks);
+      else hipLaunchKernelGGL(wgrad_kg2_kernel<false>, dim3(gxx * gyy * ks), dim3(512), SMEM, stream, a, gxx, gyy, ks);
+      TFASR_CHECK_LAUNCH();
+      return TFASR_STATUS_SUCCESS;
+    }
   }
   if (a.colsum) {
     if constexpr (TA && !TB) {
