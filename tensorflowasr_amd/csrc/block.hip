@@ -157,7 +157,8 @@ struct Ex {
   static int split_k(int M, int N, long K) {
     const long tiles = (long)((M + 127) / 128) * ((N + 127) / 128);
     if (tiles >= 256 || K <= 2048) return 1;
-    long v = 256 / tiles;
+    static const long target = getenv("TFASR_BLOCK_SPLIT_TARGET") ? atol(getenv("TFASR_BLOCK_SPLIT_TARGET")) : 256;
+    long v = target / tiles;
     if (K / 512 < v) v = K / 512;
     if (v >= 8) v = v / 8 * 8;  // whole k-slices per XCD (gemm_fast.hip split-K mapping needs split % 8 == 0)
     return (int)(v < 1 ? 1 : v);
