@@ -1,0 +1,110 @@
+"""Checkpoint interop: Keras variable paths / layouts of tensorflowasr_amd/checkpoint.py."""
+import numpy as np
+import pytest
+import torch
+
+from tensorflowasr_amd import checkpoint as ck
+from tensorflowasr_amd import configs, params
+
+
+def _exported_template(cfg, seed=0):
+    """What ParamStore.export_keras() returns (names, Keras layouts), built on the host from the parameter specs."""
+    g = torch.Generator().manual_seed(seed)
+    H, dh, d = cfg.num_heads, cfg.head_size, cfg.dmodel
+    out = {}
+    for spec in params.param_specs(cfg):
+        name, shape = spec[0], tuple(spec[1])
+        t = torch.randn(*shape, generator=g)
+        if name.endswith("qkv/w"):
+            for i, k in enumerate("qkv"):
+                out[name[:-5] + k + "/w"] = t[:, i * H * dh:(i + 1) * H * dh].reshape(d, H, dh).clone()
+        elif name.endswith("qkv/b"):
+            for i, k in enumerate("qkv"):
+                out[name[:-5] + k + "/b"] = t[i * H * dh:(i + 1) * H * dh].reshape(H, dh).clone()
+        elif name.endswith("pos/w"):
+            out[name] = t.reshape(d, H, dh)
+        elif name.endswith("pos/b") or name in ("enc/u", "enc/v"):
+            out[name] = t.reshape(H, dh)
+        elif name.endswith("mhsa/o/w"):
+            out[name] = t.reshape(H, dh, d)
+        else:
+            out[name] = t
+    for bn in params.bn_names(cfg):
+        C = out[bn + "/g"].shape[0]
+        out[bn + "/mm"], out[bn + "/mv"] = torch.randn(C, generator=g), torch.rand(C, generator=g) + 0.5
+    return out
+
+
+def test_keras_paths_and_layouts():
+    cfg = configs.conformer_tiny()
+    tpl = _exported_template(cfg)
+    arrays = ck.to_keras(tpl)
+    assert len(arrays) == len(tpl)                                   # one Keras variable per tensor, no collisions
+    d, H, dh, K = cfg.dmodel, cfg.num_heads, cfg.head_size, cfg.kernel_size
+    b0 = "conformer_encoder/block_0/"
+    want = {
+        "conformer_encoder/subsampling/block_0/conv_0/kernel": (3, 3, 1, cfg.filters),
+        "conformer_encoder/subsampling/block_1/bn_1/moving_variance": (cfg.filters,),
+        "conformer_encoder/linear/kernel": tuple(tpl["enc/linear/w"].shape),
+        "conformer_encoder/content_attention_bias": (H, dh),
+        b0 + "ff_module_1/dense_1/kernel": (d, 4 * d),
+        b0 + "ff_module_2/ln/gamma": (d,),
+        b0 + "mhsa_module/mhsa/query/kernel": (d, H, dh),
+        b0 + "mhsa_module/mhsa/value/bias": (H, dh),
+        b0 + "mhsa_module/mhsa/encoding/kernel": (d, H, dh),
+        b0 + "mhsa_module/mhsa/attention_output/kernel": (H, dh, d),
+        b0 + "conv_module/pw_conv_1/kernel": (1, d, 2 * d),           # Conv1D kernel
+        b0 + "conv_module/dw_conv/kernel": (K, d, 1),                  # DepthwiseConv1D kernel
+        b0 + "conv_module/dw_bn/moving_mean": (d,),
+        b0 + "ln/beta": (d,),
+        "prediction/embedding/embeddings": (cfg.vocab_size, cfg.embed_dim),
+        "prediction/lstm_0/lstm_cell/recurrent_kernel": (cfg.rnn_units, 4 * cfg.rnn_units),
+        "prediction/ln_0/gamma": (cfg.rnn_units,),
+        "joint/vocab/kernel": (cfg.joint_dim, cfg.vocab_size),
+    }
+    for path, shape in want.items():
+        assert path in arrays and arrays[path].shape == shape and arrays[path].dtype == np.float32, path
+    back = ck.from_keras(arrays, tpl)
+    assert set(back) == set(tpl)
+    for k in tpl:
+        assert back[k].shape == tuple(tpl[k].shape) and np.array_equal(back[k], tpl[k].numpy()), k
+
+
+def test_strict_loading_errors():
+    cfg = configs.conformer_tiny()
+    tpl = _exported_template(cfg)
+    arrays = ck.to_keras(tpl)
+    missing = dict(arrays)
+    missing.pop("joint/vocab/bias")
+    with pytest.raises(KeyError, match="joint/vocab/bias"):
+        ck.from_keras(missing, tpl)
+    assert "joint/vocab/b" not in ck.from_keras(missing, tpl, strict=False)
+    extra = dict(arrays, **{"optimizer/iterations": np.zeros(1)})
+    with pytest.raises(KeyError, match="optimizer/iterations"):
+        ck.from_keras(extra, tpl)
+    bad = dict(arrays)
+    bad["joint/enc/kernel"] = np.zeros((3, 3), np.float32)
+    with pytest.raises(ValueError, match="joint/enc/kernel"):
+        ck.from_keras(bad, tpl)
+    with pytest.raises(KeyError):
+        ck.keras_path("enc/cn/block0/whatever")
+
+
+@pytest.mark.gpu
+def test_save_and_load_weights_round_trip(tmp_path):
+    from tensorflowasr_amd.conformer import ConformerTransducer
+
+    dev = torch.device("cuda", 0)
+    cfg = configs.conformer_tiny()
+    a = ConformerTransducer(cfg, dev, dtype=torch.bfloat16, seed=1)
+    for k, v in a.ps.state.items():                                   # non-trivial BatchNorm moving statistics
+        v.copy_(torch.rand_like(v) + (0.5 if k.endswith("mv") else 0.0))
+    path = tmp_path / "model.weights.npz"
+    names = ck.save_weights(a, str(path))
+    assert "conformer_encoder/block_1/conv_module/dw_bn/moving_variance" in names
+    b = ConformerTransducer(cfg, dev, dtype=torch.bfloat16, seed=2)
+    assert not torch.equal(a.ps.flat, b.ps.flat)
+    ck.load_weights(b, str(path))
+    assert torch.equal(a.ps.flat, b.ps.flat) and torch.equal(a.ps.shadow, b.ps.shadow)
+    for k in a.ps.state:
+        assert torch.equal(a.ps.state[k], b.ps.state[k]), k
