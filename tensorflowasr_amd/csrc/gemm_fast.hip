@@ -255,9 +255,18 @@ __global__ __launch_bounds__(256, 2) void gemm_fast_kernel(const tfasr_gemm_args
         const int t = j % tpp;
         tx = t % gx; ty = t / gx;
       } else {
-        // round `it` covers tiles [it*G, (it+1)*G); XCD x takes the x-th eighth of it
-        const int t = it * G + x * (G >> 3) + (blockIdx.x >> 3);
-        if (t >= ntiles) return T;
+        // round `it` covers tiles [it*G, (it+1)*G); XCD x takes the x-th eighth of it.  A PARTIAL last round (R < G tiles left)
+        // is dealt in ragged eighths of R instead: with eighths of G its tiles all land on the first XCDs, two per CU, while
+        // the other XCDs idle (760 tiles on 512 workgroups: the second round ran on XCDs 0-3 only).
+        const int round0 = it * G, R = ntiles - round0, slot = blockIdx.x >> 3;
+        if (R <= 0) return T;
+        int t;
+        if (R >= G) t = round0 + x * (G >> 3) + slot;
+        else {
+          const int q = R >> 3, rem = R & 7;
+          if (slot >= q + (x < rem ? 1 : 0)) return T;
+          t = round0 + (x < rem ? x * (q + 1) : rem * (q + 1) + (x - rem) * q) + slot;
+        }
         tx = t % gx; const int rest = t / gx; ty = rest % gy; tz = rest / gy;
       }
     } else {  // G == ntiles (fewer tiles than resident slots): one round, ragged but bijective runs
