@@ -761,7 +761,9 @@ int num_cus() {
 template <bool TA, bool TB, int BN_, int EPI>
 int launch_epi(const tfasr_gemm_args& a, dim3 tiles, hipStream_t stream) {
   const long ntiles = (long)tiles.x * tiles.y * tiles.z;
-  const int slots = 2 * num_cus();  // 2 resident workgroups per CU
+  // 2 resident workgroups per CU; TFASR_GEMM_SLOTS=1 is an experiment hook: one persistent workgroup per CU walking more tiles
+  static const int per_cu = getenv("TFASR_GEMM_SLOTS") && getenv("TFASR_GEMM_SLOTS")[0] == '1' ? 1 : 2;
+  const int slots = per_cu * num_cus();
   int G = (int)(ntiles < slots ? ntiles : slots);
   if (ntiles >= slots) G &= ~7;
   constexpr int SMEM = 2 * (A_BYTES + BN_ * BK * 2) + 4 * (64 / (BN_ / 16)) * (BN_ / 2 + 4) * 4;  // stages + 4 waves' strips
@@ -834,6 +836,18 @@ int launch_one(const tfasr_gemm_args& a, hipStream_t stream) {
     if constexpr (!TA && !TB) {
       if (!generic && need == E_RES) return launch_epi<TA, TB, 64, E_RES>(a, grid, stream);
       if (!generic && need == (E_RES | E_DROP)) return launch_epi<TA, TB, 64, E_RES | E_DROP>(a, grid, stream);
+    }
+    // Experiment hook (not reachable with the default threshold): 128x64 tiles for layers of MORE than one workgroup per CU need
+    // the compiled activation epilogues, or they fall to the generic one and lose (measured with TFASR_GEMM_BN64_T=1024).
+    if (t128 > num_cus() && a.N > 64 && !generic) {
+      if constexpr (!TA && !TB) {
+        if (need == E_ACT) return launch_epi<TA, TB, 64, E_ACT>(a, grid, stream);
+        if (need == (E_ACT | E_DROP)) return launch_epi<TA, TB, 64, E_ACT | E_DROP>(a, grid, stream);
+      }
+      if constexpr (!TA && TB) {
+        if (need == E_DACT) return launch_epi<TA, TB, 64, E_DACT>(a, grid, stream);
+        if (need == (E_DACT | E_DROP)) return launch_epi<TA, TB, 64, E_DACT | E_DROP>(a, grid, stream);
+      }
     }
     return launch_epi<TA, TB, 64, E_GEN>(a, grid, stream);
   }
