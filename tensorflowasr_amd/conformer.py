@@ -30,6 +30,9 @@ class SingleProcess:
     def allreduce_stats_(self, t):  # sync-BN statistics (sum over replicas)
         return t
 
+    def set_reduce(self, on):  # gradient accumulation: only the apply micro-step exchanges gradients
+        pass
+
     def grads_ready(self, lo, hi):  # gradient slice [lo, hi) of the flat buffer is final
         pass
 
@@ -58,7 +61,9 @@ class ConformerTransducer:
         self.time_reduction_factor = cfg.time_reduction_factor
         self.step = 0
         self._consts = {}
-        self._rng = np.random.default_rng(seed + 1000)
+        # SpecAugment draws and dropout masks are per replica (MirroredStrategy draws independent randomness on every
+        # replica); the parameter initialisation seed above is shared by all ranks
+        self._rng = np.random.default_rng([seed + 1000, int(self.dp.rank)])
         self.pred_stream = torch.cuda.Stream(device=self.device)
         self.use_pred_stream = os.environ.get("TFASR_NO_PRED_STREAM", "0") != "1"
         self.optimizer = dict(beta1=0.9, beta2=0.98, eps=1e-9, weight_decay=1e-6, schedule=dict(
@@ -110,7 +115,12 @@ class ConformerTransducer:
         p = float(self.cfg.dropout) if training else 0.0
         if p <= 0.0:
             return 0.0, 0
-        return p, (self._drop_epoch * 8192 + site) & 0x7FFFFFFFFFFF
+        return p, (self._drop_epoch_eff() * 8192 + site) & 0x7FFFFFFFFFFF
+
+    def _drop_epoch_eff(self):
+        """Mask epoch with the data-parallel rank folded into bits 40..46 of the seed (epoch * 8192 + site stays below 2^40
+        for 2^27 forward passes): replicas draw different dropout masks; the native block executor forms the same seed."""
+        return self._drop_epoch + ((int(self.dp.rank) & 0x7F) << 27)
 
     def _mask_grad(self, dy, drop):
         return K.dropout(dy, drop[0], drop[1]) if drop[0] > 0.0 else dy
@@ -443,7 +453,7 @@ class ConformerTransducer:
         k.force_unfused = int(not self._fused_attention())
         k.world = self.dp.world
         k.site0 = 16 + i * 8
-        k.drop_epoch = self._drop_epoch
+        k.drop_epoch = self._drop_epoch_eff()
         k.drop_p = float(c.dropout)
         k.ffm_res, k.mhsa_res, k.conv_res = c.ffm_residual, c.mhsam_residual, c.convm_residual
         k.ln_eps, k.bn_eps, k.bn_momentum = 1e-3, 1e-3, 0.99
@@ -451,15 +461,15 @@ class ConformerTransducer:
 
     def _native_params(self, i, T):
         ps = self.ps
-        P = self._blk_params.get(i)
+        P = self._blk_params.get((i, T))  # one struct per (block, T'): a saved forward keeps ITS positional table
         if P is None:
             P = K._lib.BlockParams()
             P.flat, P.shadow, P.grad = ps.flat.data_ptr(), ps.shadow.data_ptr(), ps.grad.data_ptr()
             P.bn_mm, P.bn_mv = ps.state[f"enc/block{i}/conv/bn/mm"].data_ptr(), ps.state[f"enc/block{i}/conv/bn/mv"].data_ptr()
             for j, nm in enumerate(K._lib.BLOCK_PARAM_NAMES):
                 P.off[j] = ps.offsets[nm[1:] if nm.startswith("/") else f"enc/block{i}/{nm}"]
-            self._blk_params[i] = P
-        P.pe = self._pe_ext(T).data_ptr()
+            P.pe = self._pe_ext(T).data_ptr()
+            self._blk_params[(i, T)] = P
         return P
 
     def _native_sizes(self, cfgk):
@@ -684,13 +694,17 @@ class ConformerTransducer:
         logits = self.joint_fwd(enc, pred, B, T, U1, ctx)
         return logits, elen, elen_dev
 
-    def loss_and_backward(self, data: TrainData, training=True, masks=None, want_backward=True, packed=True):
+    def loss_and_backward(self, data: TrainData, training=True, masks=None, want_backward=True, packed=True, reduce=True):
         """BaseModel._train_step (base_model.py:149-183): forward, RnntLoss (mean over the batch, rnnt_loss.py:34) and
         the full backward into the flat gradient buffer (gradients ACCUMULATE; zero_grad() first).
 
         packed=True evaluates the joint network and the loss only on the valid lattice nodes (t < logit_len_b,
         u <= label_len_b): padded nodes carry exactly zero gradient in the reference (impl/rnnt.py:218-224), so skipping them
-        changes no result while removing the padding's share of the largest GEMMs of the step."""
+        changes no result while removing the padding's share of the largest GEMMs of the step.
+
+        reduce=False keeps this micro-step's gradients local (train_step_ga, base_model.py:200-209: the replicas exchange
+        gradients only when the accumulated gradient is applied)."""
+        self.dp.set_reduce(bool(reduce))
         ctx = {} if want_backward else None
         dev = self.device
         ps, c = self.ps, self.cfg
@@ -781,7 +795,9 @@ class ConformerTransducer:
         (optimizers/accumulation.py:64-70)."""
         if self._ga_count == 0:
             self.zero_grad()
-        costs = self.loss_and_backward(data, True, masks)
+        # the flat buffer accumulates LOCAL micro-gradients; it is all-reduced once, on the apply micro-step, where the
+        # bucketed slices still overlap that micro-step's backward (base_model.py:200-209)
+        costs = self.loss_and_backward(data, True, masks, reduce=self._ga_count + 1 >= self.ga_steps)
         self._ga_count += 1
         if self._ga_count >= self.ga_steps:
             self.apply_gradients(1.0 / self.ga_steps)
@@ -860,7 +876,10 @@ class ConformerTransducer:
                 K.matmul(emb, Wk, bias=ps.p("pred/lstm/b"), out=xg)
                 K.gemm(h, Wrk, hr, B, 4 * P, P, P, 4 * P, 4 * P)
                 K.lstm_step_fwd(xg, hr, h, cst, None, 0, None, c_new, h_new, None, B, P)
-                y, _, _ = K.layernorm_fwd(h_new, ps.p("pred/ln/g"), ps.p("pred/ln/b"), save_stats=False)
+                if c.prediction_layer_norm:
+                    y, _, _ = K.layernorm_fwd(h_new, ps.p("pred/ln/g"), ps.p("pred/ln/b"), save_stats=False)
+                else:  # prediction_layer_norm: False (contextnet/small.yml.j2), as prediction_fwd
+                    y = h_new
                 K.matmul(y, Wjp, bias=ps.p("joint/pred/b"), out=pj)
                 z = K.joint_fwd(ecur.view(B, 1, J), pj.view(B, 1, J))
                 K.matmul(z.view(B, J), Wv, bias=ps.p("joint/vocab/b"), out=logits)

@@ -57,6 +57,12 @@ class DataParallel:
         self._done = []
         self._pending = []
         self._staged = None
+        self._reduce = True
+
+    def set_reduce(self, on):
+        """Gradient accumulation: micro-steps before the apply step keep their gradients local (the reference all-reduces
+        inside optimizer.apply only, base_model.py:200-209); grads_ready / finish_grads are no-ops while this is off."""
+        self._reduce = bool(on)
 
     def attach(self, flat_grad):
         self.flat_grad = flat_grad
@@ -71,7 +77,7 @@ class DataParallel:
     def grads_ready(self, lo, hi):
         """[lo, hi) of the flat gradient is final: start its all-reduce now (async; overlaps the rest of backward).
         Adjacent small slices are coalesced until `bucket_bytes` so each message is large enough for the xGMI ring."""
-        if hi <= lo:
+        if hi <= lo or not self._reduce:
             return
         if self._staged is not None and (self._staged[0] == hi or self._staged[1] == lo):
             self._staged = (min(lo, self._staged[0]), max(hi, self._staged[1]))
@@ -92,6 +98,8 @@ class DataParallel:
 
     def finish_grads(self):
         """Reduce whatever has not been announced yet and wait for everything."""
+        if not self._reduce:
+            return
         self._flush()
         n = self.flat_grad.numel()
         cur = 0

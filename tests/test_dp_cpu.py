@@ -64,3 +64,41 @@ def test_shard_bounds_rejects_ragged():
 
     with pytest.raises(ValueError):
         dp.shard_bounds(7, 2, 0)
+
+
+def _worker_ga(rank, world, port, outdir):
+    """The train_step_ga contract through the DP hooks: local accumulation, one exchange on the apply micro-step."""
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from tensorflowasr_amd import dp
+
+    d = dp.init_from_env(backend="gloo")
+    n, ga = 4096, 3
+    grad = torch.zeros(n)
+    d.attach(grad)
+    d.bucket_bytes = 4096
+    snaps = []
+    for micro in range(ga):
+        d.set_reduce(micro + 1 >= ga)
+        g = torch.randn(n, generator=torch.Generator().manual_seed(1000 * micro + rank))
+        grad[2048:] += g[2048:]      # "joint / top of the encoder" becomes final first ...
+        d.grads_ready(2048, 4096)
+        grad[:2048] += g[:2048]      # ... then the bottom
+        d.grads_ready(0, 1024)
+        d.finish_grads()
+        snaps.append(grad.clone())
+    torch.save(snaps, os.path.join(outdir, f"ga{rank}.pt"))
+    d.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_two_process_gloo_gradient_accumulation(tmp_path):
+    world, ga, n = 2, 3, 4096
+    mp.spawn(_worker_ga, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    outs = [torch.load(os.path.join(tmp_path, f"ga{r}.pt")) for r in range(world)]
+    g = lambda micro, rank: torch.randn(n, generator=torch.Generator().manual_seed(1000 * micro + rank))
+    for r in range(world):
+        for micro in range(ga - 1):  # before the apply micro-step: purely local sums, nothing exchanged
+            want = sum(g(m, r) for m in range(micro + 1))
+            np.testing.assert_allclose(outs[r][micro].numpy(), want.numpy(), rtol=1e-6, atol=1e-6)
+        want = sum(g(m, rr) for m in range(ga) for rr in range(world))  # every micro-gradient of every rank exactly ONCE
+        np.testing.assert_allclose(outs[r][ga - 1].numpy(), want.numpy(), rtol=1e-5, atol=1e-5)

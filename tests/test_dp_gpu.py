@@ -87,3 +87,58 @@ def test_two_ranks_match_single_process(dev, tmp_path, dtype_name):
     for o in outs:  # every rank holds the all-reduced global-batch gradient
         np.testing.assert_allclose(o["grad"].numpy(), g, rtol=tol, atol=tol * float(np.abs(g).max()))
         np.testing.assert_allclose(o["mm"].numpy(), model.ps.state["enc/block1/conv/bn/mm"].cpu().numpy(), rtol=tol, atol=1e-5)
+
+
+def _worker_ga(rank, world, port, outdir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from tensorflowasr_amd import configs, dp
+    from tensorflowasr_amd.conformer import ConformerTransducer
+
+    torch.cuda.set_device(0)
+    d = dp.init_from_env(backend="gloo")
+    cfg = configs.conformer_tiny(dropout=0.0)
+    model = ConformerTransducer(cfg, torch.device("cuda", 0), dtype=torch.float32, seed=5, dp=d)
+    d.attach(model.ps.grad)
+    model.ga_steps = 2
+    model.optimizer["schedule"] = 1e-3
+    model.optimizer["eps"] = 1e-4
+    make = _batch(cfg, LENS, ULENS)
+    for micro in range(2):  # micro-batch m = utterances [2m, 2m+2); this rank's shard is one utterance of it
+        model.train_step(make(2 * micro + rank, 2 * micro + rank + 1), masks=(None, None))
+        if micro == 0:
+            local_after_first = model.ps.grad.clone()
+    torch.cuda.synchronize()
+    torch.save(dict(flat=model.ps.flat.cpu(), grad=model.ps.grad.cpu(), first=local_after_first.cpu(), step=model.step),
+               os.path.join(outdir, f"ga{rank}.pt"))
+    d.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_two_ranks_with_gradient_accumulation_match_single_process(dev, tmp_path):
+    """DP x GA (base_model.py:200-209): micro-gradients accumulate LOCALLY and are all-reduced once, on the apply micro-step.
+    Two ranks x ga_steps=2 on one-utterance shards == one process with ga_steps=2 on the two-utterance micro-batches."""
+    from tensorflowasr_amd import configs
+    from tensorflowasr_amd.conformer import ConformerTransducer
+
+    world = 2
+    mp.spawn(_worker_ga, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    outs = [torch.load(os.path.join(tmp_path, f"ga{r}.pt")) for r in range(world)]
+    cfg = configs.conformer_tiny(dropout=0.0)
+    model = ConformerTransducer(cfg, dev, dtype=torch.float32, seed=5)
+    model.ga_steps = 2
+    model.optimizer["schedule"] = 1e-3
+    model.optimizer["eps"] = 1e-4
+    make = _batch(cfg, LENS, ULENS)
+    model.train_step(make(0, 2), masks=(None, None))
+    first = model.ps.grad.clone()
+    model.train_step(make(2, 4), masks=(None, None))
+    torch.cuda.synchronize()
+    assert model.step == 1 and all(o["step"] == 1 for o in outs)
+    g = model.ps.grad.cpu().numpy()
+    tol = 5e-4
+    # after micro-step 1 the ranks hold un-reduced LOCAL gradients whose sum is the single-process micro-gradient
+    np.testing.assert_allclose((outs[0]["first"] + outs[1]["first"]).numpy(), first.cpu().numpy(), rtol=tol, atol=tol * float(np.abs(g).max()))
+    assert float((outs[0]["first"] - outs[1]["first"]).abs().max()) > 0
+    for o in outs:
+        np.testing.assert_allclose(o["grad"].numpy(), g, rtol=tol, atol=tol * float(np.abs(g).max()))
+        np.testing.assert_allclose(o["flat"].numpy(), model.ps.flat.cpu().numpy(), rtol=0, atol=5e-5)
