@@ -863,7 +863,9 @@ class ConformerTransducer:
         h_new = torch.empty(B, P, dtype=self.dtype, device=dev)
         c_new = torch.empty(B, P, dtype=torch.float32, device=dev)
         pj = torch.empty(B, J, dtype=self.dtype, device=dev)
-        logits = torch.empty(B, V, dtype=self.dtype, device=dev)
+        # vocabulary logits stay f32 out of the MFMA accumulators (the reference's log_softmax / argmax run on f32 logits,
+        # base_transducer.py:463): no bf16 rounding between the projection and the arg-max decision
+        logits = torch.empty(B, V, dtype=torch.float32, device=dev)
         Wk, Wrk, Wjp, Wv = ps.w2d("pred/lstm/k"), ps.w2d("pred/lstm/rk"), ps.w2d("joint/pred/w"), ps.w2d("joint/vocab/w")
         # every useful iteration advances a frame or appends a token; the reference's while_loop is unbounded and can
         # spin forever once a sample saturates its token buffer — cap the trip count instead
