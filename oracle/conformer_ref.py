@@ -122,20 +122,26 @@ def specaugment_apply(feat, fmask, tmask, mask_value=0.0):
 
 
 def specaugment_draw(rng, lengths, nfreq_bins=80, num_freq_masks=1, freq_mask_factor=27, num_time_masks=10,
-                     p_upperbound=0.05):
-    """Random draws of specaugment.py:72-77,122-131 (TimeMasking ignores mask_factor: width bound = floor(len*p))."""
+                     p_upperbound=0.05, prob=1.0):
+    """Random draws of specaugment.py:72-77,122-131 in the reference's order: per utterance (tf.map_fn, augmentation.py:78-90)
+    all frequency masks then all time masks (sorted keys, augmentation.py:95); per mask `prob`, width, start are ALWAYS drawn and
+    multiplied by do_apply afterwards; TimeMasking ignores mask_factor (width bound = floor(len*p)).  `rng` plays
+    tf.random.uniform: .uniform() for floats, .integers(lo, hi) for ints (pinned by tests/golden/specaugment_reference.npz)."""
     B = len(lengths)
     fmask = np.zeros((B, num_freq_masks, 2), np.int32)
     tmask = np.zeros((B, num_time_masks, 2), np.int32)
     for b in range(B):
+        ln = int(lengths[b])
         for k in range(num_freq_masks):
-            f = min(int(rng.integers(0, freq_mask_factor)), nfreq_bins)
-            f0 = int(rng.integers(0, max(1, nfreq_bins - f)))
+            do = 1 if rng.uniform() <= prob else 0
+            f = do * min(int(rng.integers(0, freq_mask_factor)), nfreq_bins)
+            f0 = do * int(rng.integers(0, max(1, nfreq_bins - f)))
             fmask[b, k] = (f0, f)
-        Tb = int(math.floor(float(lengths[b]) * p_upperbound))
+        Tb = int(math.floor(np.float32(ln) * np.float32(p_upperbound)))
         for k in range(num_time_masks):
-            t = min(int(rng.integers(0, max(1, Tb))), int(lengths[b]))
-            t0 = int(rng.integers(0, max(1, int(lengths[b]) - t)))
+            do = 1 if rng.uniform() <= prob else 0
+            t = do * min(int(rng.integers(0, max(1, Tb))), ln)
+            t0 = do * int(rng.integers(0, max(1, ln - t)))
             tmask[b, k] = (t0, t)
     return fmask, tmask
 
@@ -246,6 +252,16 @@ def rel_mhsa(x, pe, W, pfx, H, dh, lengths, u, v, use_mask=True):
     k = torch.einsum("btd,dhe->bthe", x, W[pfx + "k/w"]) + W[pfx + "k/b"]
     vv = torch.einsum("btd,dhe->bthe", x, W[pfx + "v/w"]) + W[pfx + "v/b"]
     p = torch.einsum("brd,dhe->brhe", pe, W[pfx + "pos/w"]) + W[pfx + "pos/b"]
+    ctx, _ = rel_attention_core(q, k, vv, p, u, v, dh, lengths, use_mask)
+    return torch.einsum("bthe,hed->btd", ctx, W[pfx + "o/w"]) + W[pfx + "o/b"]
+
+
+def rel_attention_core(q, k, vv, p, u, v, dh, lengths, use_mask=True):
+    """MultiHeadRelativeAttention._compute_attention (multihead_attention.py:543-582) on projected tensors q/k/vv [B,T,H,dh],
+    p [B,2T-1,H,dh]: content + shifted positional scores, keras auto mask (padded QUERY rows, -1e9 fill: general.py:30-41),
+    softmax, weighted values.  Pinned by tests/golden/attention_core_reference.npz (the reference's own function body).
+    Returns (context [B,T,H,dh], probabilities [B,H,T,T])."""
+    T = q.shape[1]
     scale = 1.0 / math.sqrt(dh)
     cq = (q + u) * scale
     pq = (q + v) * scale
@@ -258,8 +274,7 @@ def rel_mhsa(x, pe, W, pfx, H, dh, lengths, u, v, use_mask=True):
         qmask = (torch.arange(T)[None, :] < torch.as_tensor(lengths)[:, None])[:, None, :, None]  # [B,1,T,1]
         scores = torch.where(qmask, scores, torch.full_like(scores, -1e9))  # math_util.masked_fill / general.py:30-41
     probs = torch.softmax(scores, dim=-1)
-    ctx = torch.einsum("bhts,bshe->bthe", probs, vv)
-    return torch.einsum("bthe,hed->btd", ctx, W[pfx + "o/w"]) + W[pfx + "o/b"]
+    return torch.einsum("bhts,bshe->bthe", probs, vv), probs
 
 
 def ff_module(x, W, pfx, factor=0.5):

@@ -103,10 +103,277 @@ def gen_posenc():
     print("relpe_reference:", {k: v.shape for k, v in out.items()})
 
 
+def gen_greedy():
+    """base_transducer.py: the bodies of Transducer.recognize_batch (:496-575) and recognize_single (:577-712) executed over
+    the shim with a stand-in `self` whose call_next is a tiny real transducer step (embedding -> LSTM -> LN -> joint ->
+    log_softmax, weights from oracle.conformer_ref.init_weights('tiny')) so that the HIP search can be checked against the
+    same goldens with the same weights."""
+    import collections
+    import types
+
+    import torch
+
+    from oracle import conformer_ref as R
+
+    tf = tf_shim.make_tf()
+    PredictOutput = collections.namedtuple("PredictOutput", "tokens next_tokens next_encoder_states next_decoder_states")
+    PredictInput = collections.namedtuple("PredictInput", "inputs inputs_length previous_tokens previous_encoder_states previous_decoder_states")
+    ns = {"tf": tf, "shape_util": _shape_util(tf), "schemas": types.SimpleNamespace(PredictOutput=PredictOutput, PredictInput=PredictInput)}
+    fns = tf_shim.extract_functions("tensorflow_asr/models/transducer/base_transducer.py",
+                                    ["Transducer.recognize_batch", "Transducer.recognize_single"], ns)
+    ocfg = R.conformer_config("tiny")
+    out = {}
+    tf._while_cap = 2000
+    # (weight seed, blank bias, lengths): the reference's batch loop is unbounded (a sample that keeps emitting at a full token
+    # buffer never advances its frame), so candidates that do not terminate on their own are skipped
+    cands = [(ws, b, ln) for ws in (4, 9, 12, 15, 21) for b in (1.2, 1.6, 2.2, 3.0, 4.0, 5.0) for ln in ([11, 7, 9], [12, 12, 12], [10, 3, 1, 8])]
+    cases = {f"batch{i}": c for i, c in enumerate(cands)}
+    cases.update({"single_a": (4, 1.2, [11]), "single_b": (9, 0.4, [6]), "single_c": (12, 2.2, [14])})
+    kept, seen = 0, set()
+    for name, (wseed, bias, lens) in cases.items():
+        W = R.init_weights(ocfg, seed=wseed, scale_bias=0.1)
+        W["joint/vocab/b"] = W["joint/vocab/b"].clone()
+        W["joint/vocab/b"][0] += bias
+        P = W["pred/lstm/rk"].shape[0]
+        B, T, d = len(lens), max(lens), ocfg["dmodel"]
+        enc = np.random.default_rng(100 + wseed).standard_normal((B, T, d)).astype(np.float32)
+
+        def call_next(cur, prev_tok, states):
+            with torch.no_grad():
+                st = torch.from_numpy(np.asarray(states, np.float32))
+                lsm, hn, cn = R._call_next(torch.from_numpy(np.asarray(cur, np.float32)), torch.from_numpy(np.asarray(prev_tok)).long(),
+                                           st[:, 0, 0], st[:, 0, 1], W)
+            return tf.convert_to_tensor(lsm.numpy()), tf.convert_to_tensor(torch.stack([hn, cn], 1)[:, None].numpy())
+
+        me = types.SimpleNamespace(
+            name="transducer", blank=0, call_next=call_next,
+            feature_extraction=lambda x, training=False: x,
+            encoder=types.SimpleNamespace(call_next=lambda f, fl, st: (f, fl, None)))
+        inp = PredictInput(tf.convert_to_tensor(enc), tf.convert_to_tensor(np.asarray(lens, np.int32)),
+                           tf.zeros([B, 1], dtype=tf.int32), None, tf.zeros([B, 1, 2, P], dtype=tf.float32))
+        fn = fns["Transducer.recognize_single"] if name.startswith("single") else fns["Transducer.recognize_batch"]
+        try:
+            res = fn(me, inp)
+        except RuntimeError:
+            continue  # non-terminating under the reference's own semantics
+        iters = tf._last_while_iterations
+        ntok = [int((r != 0).sum()) for r in np.asarray(res.tokens)]
+        if not name.startswith("single"):
+            # keep a handful of informative cases: something emitted, within the product's trip-count cap
+            pattern = tuple(sorted(ntok))
+            if iters >= T + 2 * T + 1 + 2 or sum(ntok) == 0 or pattern in seen or kept >= 8:
+                continue
+            seen.add(pattern)
+            kept += 1
+        out[f"{name}_enc"], out[f"{name}_len"] = enc, np.asarray(lens, np.int32)
+        out[f"{name}_wseed"], out[f"{name}_bias"] = np.asarray(wseed), np.asarray(bias, np.float32)
+        out[f"{name}_tokens"] = np.asarray(res.tokens, np.int32)
+        out[f"{name}_next_tokens"] = np.asarray(res.next_tokens, np.int32)
+        out[f"{name}_next_states"] = np.asarray(res.next_decoder_states, np.float32)
+        out[f"{name}_iters"] = np.asarray(iters)
+        print(f"greedy_reference {name}: {iters} iterations, tokens/utt {[int((r != 0).sum()) for r in out[f'{name}_tokens']]}")
+    out["names"] = np.asarray(sorted({k[:-len("_tokens")] for k in out if k.endswith("_tokens") and not k.endswith("_next_tokens")}))
+    np.savez_compressed(os.path.join(OUT, "greedy_reference.npz"), **out)
+
+
+def gen_specaugment():
+    """augmentations/methods/specaugment.py: FreqMasking.augment (:58-87) and TimeMasking.augment (:108-137) bodies, applied in
+    the sorted-key order of Augmentation.parse (augmentation.py:92-101), with tf.random.uniform backed by a seeded NumPy
+    generator (draw order and ranges are the reference's; the draws themselves are injected)."""
+    import types
+
+    tf = tf_shim.make_tf()
+    ns = {"tf": tf, "shape_util": _shape_util_tf(tf), "MASK_VALUES": types.SimpleNamespace(MEAN="mean", MIN="min", MAX="max", ZERO="zero")}
+    fns = tf_shim.extract_functions("tensorflow_asr/augmentations/methods/specaugment.py",
+                                    ["get_mask_value", "FreqMasking.augment", "TimeMasking.augment"], ns)
+    parse = tf_shim.extract_functions("tensorflow_asr/augmentations/augmentation.py", ["Augmentation.parse"],
+                                      {"AUGMENTATIONS": {"freq_masking": lambda **kw: ("freq", kw), "time_masking": lambda **kw: ("time", kw)},
+                                       "List": list})["Augmentation.parse"]
+    # small.yml.j2:11-24
+    cfg = {"time_masking": dict(prob=1.0, num_masks=10, mask_factor=-1, p_upperbound=0.05, mask_value=0),
+           "freq_masking": dict(prob=1.0, num_masks=1, mask_factor=27, mask_value=0)}
+    order = [k for k, _ in parse(dict(cfg))]
+    assert order == ["freq", "time"], order
+    out = {"order": np.asarray(order)}
+    for name, (seed, T, length, prob) in {"full": (31, 120, 120, 1.0), "padded": (32, 200, 137, 1.0), "prob": (33, 90, 90, 0.5)}.items():
+        feat = np.random.default_rng(seed).standard_normal((T, 80, 1)).astype(np.float32)
+        inj = tf_shim.InjectedUniform(np.random.default_rng(1000 + seed))
+        tf.random.uniform = inj
+        fm = types.SimpleNamespace(num_masks=1, mask_factor=27, prob=prob, mask_value=0)
+        tm = types.SimpleNamespace(num_masks=10, mask_factor=-1, p_upperbound=0.05, prob=prob, mask_value=0)
+        x = (tf.convert_to_tensor(feat), tf.convert_to_tensor(np.asarray(length, np.int32)))
+        x = fns["FreqMasking.augment"](fm, x)
+        x = fns["TimeMasking.augment"](tm, x)
+        out[f"{name}_in"], out[f"{name}_len"], out[f"{name}_out"] = feat, np.asarray(length, np.int32), np.asarray(x[0], np.float32)
+        out[f"{name}_seed"], out[f"{name}_prob"] = np.asarray(1000 + seed), np.asarray(prob, np.float32)
+        out[f"{name}_draws"] = np.asarray(inj.log, np.float64)
+        print(f"specaugment_reference {name}: {len(inj.log)} draws, {(np.asarray(x[0]) == 0).mean():.3f} of the cells masked")
+    np.savez_compressed(os.path.join(OUT, "specaugment_reference.npz"), **out)
+
+
+def _shape_util_tf(tf):
+    """the reference's own shape_util.shape_list (utils/shape_util.py:18-22) over the shim."""
+    return tf_shim.load_reference_module("tensorflow_asr/utils/shape_util.py", "tensorflow_asr.utils.shape_util_copy")[0]
+
+
+def gen_misc():
+    """Small pure-Python / few-primitive pieces of the hot path, each run from the reference's source:
+    math_util.conv_output_length (:282-305), masked_fill (:229-238), merge_two_last_dims (:130-132), get_reduced_length (:82-89);
+    convolution._compute_causal_padding (:25-37); schedules.TransformerSchedule.__call__ (:28-37);
+    accumulation.GradientAccumulator.accumulate / gradients (:54-70); base_loss.BaseLoss.call (:28-37);
+    feature_extraction.FeatureExtraction.preemphasis_signal / logarithm / get_nframes (:170-175, 214-218, 305-313);
+    activations/glu.GLU.call (:25-28); layers/general.Softmax.call (:30-41)."""
+    import collections
+    import types
+
+    tf = tf_shim.make_tf()
+    su = _shape_util_tf(tf)
+    out = {}
+    # ---- math_util
+    mu = tf_shim.extract_functions("tensorflow_asr/utils/math_util.py",
+                                   ["conv_output_length", "masked_fill", "merge_two_last_dims", "get_reduced_length"], {"tf": tf, "shape_util": su})
+    L = np.arange(0, 40)
+    out["conv_len_in"] = L
+    out["conv_len_causal_k3_s2"] = np.asarray([mu["conv_output_length"](int(v), 3, "causal", 2) for v in L])
+    out["conv_len_valid_k3_s2"] = np.asarray([mu["conv_output_length"](int(v), 3, "valid", 2) for v in L])
+    out["conv_len_same_k31_s1"] = np.asarray([mu["conv_output_length"](int(v), 31, "same", 1) for v in L])
+    out["reduced_len_4"] = np.asarray([np.asarray(mu["get_reduced_length"](tf.convert_to_tensor(np.asarray(v, np.int32)), 4)) for v in L])
+    x = np.random.default_rng(41).standard_normal((2, 3, 4, 5)).astype(np.float32)
+    out["merge_in"], out["merge_out"] = x, np.asarray(mu["merge_two_last_dims"](tf.convert_to_tensor(x)))
+    m = np.random.default_rng(42).random((2, 1, 4, 1)) > 0.4
+    out["mfill_mask"], out["mfill_out"] = m, np.asarray(mu["masked_fill"](tf.convert_to_tensor(x), tf.convert_to_tensor(m), -1e9))
+    # ---- causal padding
+    cp = tf_shim.extract_functions("tensorflow_asr/models/layers/convolution.py", ["_compute_causal_padding"], {"tf": tf})["_compute_causal_padding"]
+    out["causal_pad_conv2d_k3"] = np.asarray(cp(None, 2, "channels_last", (1, 1), (3, 3)))
+    out["causal_pad_dw1d_k31"] = np.asarray(cp(None, 1, "channels_last", (1,), (31,)))
+    # ---- schedule (small.yml.j2:76-83: dmodel 144, scale 2, warmup 10000, max_lr 0.05/sqrt(dmodel))
+    sched = tf_shim.extract_functions("tensorflow_asr/optimizers/schedules.py", ["TransformerSchedule.__call__"], {"tf": tf})["TransformerSchedule.__call__"]
+    steps = np.asarray([1, 2, 10, 100, 1000, 5000, 9999, 10000, 10001, 20000, 100000, 1000000], np.int64)
+    for nm, (dm, scale, warm, mx, mn) in {"S": (144, 2.0, 10000, 0.05 / np.sqrt(144.0), None), "plain": (256, 1.0, 4000, None, None),
+                                          "floor": (144, 2.0, 10000, 0.004, 1e-4)}.items():
+        me = types.SimpleNamespace(dmodel=tf.convert_to_tensor(dm, dtype=tf.float32), scale=tf.convert_to_tensor(scale, dtype=tf.float32),
+                                   warmup_steps=tf.convert_to_tensor(warm, dtype=tf.float32), max_lr=mx, min_lr=mn)
+        out[f"sched_{nm}"] = np.asarray([np.asarray(sched(me, tf.convert_to_tensor(int(st), dtype=tf.int64))) for st in steps], np.float64)
+        out[f"sched_{nm}_cfg"] = np.asarray([dm, scale, warm, -1 if mx is None else mx, -1 if mn is None else mn], np.float64)
+    out["sched_steps"] = steps
+    # ---- gradient accumulation
+    ga = tf_shim.extract_functions("tensorflow_asr/optimizers/accumulation.py",
+                                   ["GradientAccumulator.accumulate", "GradientAccumulator.gradients", "GradientAccumulator._get_acc_grads"], {"tf": tf})
+
+    class Var:
+        __array_ufunc__ = None  # ndarray + Var defers to Var.__radd__
+
+        def __init__(self, v):
+            self.v = np.asarray(v, np.float32)
+
+        def assign(self, x):
+            self.v = np.asarray(x, np.float32)
+
+        def __radd__(self, o):
+            return np.asarray(o) + self.v
+
+        def __add__(self, o):
+            return self.v + np.asarray(o)
+
+    rng = np.random.default_rng(43)
+    micro = [[rng.standard_normal(5).astype(np.float32), rng.standard_normal((2, 3)).astype(np.float32)] for _ in range(3)]
+    acc = [Var(np.zeros(5)), Var(np.zeros((2, 3)))]
+    me = types.SimpleNamespace(built=True, _ga_steps=3, _accumulated_gradients=acc,
+                               _optimizer=types.SimpleNamespace(_get_variable_index=lambda v: v))
+    me._get_acc_grads = lambda tv: ga["GradientAccumulator._get_acc_grads"](me, tv)
+    ga["GradientAccumulator.accumulate"](me, micro[0], [0, 1])
+    ga["GradientAccumulator.accumulate"](me, micro[1], [0, 1])
+    final = ga["GradientAccumulator.gradients"](me, micro[2], [0, 1])
+    for i in range(3):
+        out[f"ga_micro{i}_0"], out[f"ga_micro{i}_1"] = micro[i]
+    out["ga_final_0"], out["ga_final_1"] = np.asarray(final[0], np.float32), np.asarray(final[1], np.float32)
+    # ---- BaseLoss.call
+    bl = tf_shim.extract_functions("tensorflow_asr/losses/base_loss.py", ["BaseLoss.call"], {"tf": tf, "schemas": types.SimpleNamespace(TrainLabel=object, TrainOutput=object)})["BaseLoss.call"]
+    TL = collections.namedtuple("TL", "labels labels_length")
+    TO = collections.namedtuple("TO", "logits logits_length")
+    ll, tl = np.asarray([5, 2, 9, 1], np.int32), np.asarray([7, 1, 9, 3], np.int32)
+    _, lg, _, lb = bl(None, TL(tf.zeros([4, 9], dtype=tf.int32), tf.convert_to_tensor(ll)), TO(None, tf.convert_to_tensor(tl)))
+    out["loss_label_len"], out["loss_logit_len_in"], out["loss_logit_len_out"] = ll, tl, np.asarray(lg, np.int32)
+    # ---- frontend helpers
+    fe = tf_shim.extract_functions("tensorflow_asr/models/layers/feature_extraction.py",
+                                   ["FeatureExtraction.preemphasis_signal", "FeatureExtraction.logarithm", "FeatureExtraction.get_nframes"],
+                                   {"tf": tf, "math_util": None})
+    me = types.SimpleNamespace(preemphasis=0.97, epsilon=1e-6, log_base="e", use_librosa_like_stft=False, pad_end=True, frame_step=160,
+                               frame_length=400, nfft=512)
+    sig = np.random.default_rng(44).standard_normal((2, 50)).astype(np.float32)
+    out["pre_in"], out["pre_out"] = sig, np.asarray(fe["FeatureExtraction.preemphasis_signal"](me, tf.convert_to_tensor(sig)))
+    pw = np.abs(np.random.default_rng(45).standard_normal((3, 7)).astype(np.float32)) * 10
+    out["log_in"], out["log_out"] = pw, np.asarray(fe["FeatureExtraction.logarithm"](me, tf.convert_to_tensor(pw.copy())))
+    ns_ = np.asarray([1, 159, 160, 161, 4321, 160000, 475760], np.int32)
+    out["nframes_in"], out["nframes_out"] = ns_, np.asarray([np.asarray(fe["FeatureExtraction.get_nframes"](me, tf.convert_to_tensor(v))) for v in ns_])
+    # ---- GLU, Softmax
+    glu = tf_shim.extract_functions("tensorflow_asr/models/activations/glu.py", ["GLU.call"], {"tf": tf})["GLU.call"]
+    g_in = np.random.default_rng(46).standard_normal((2, 5, 8)).astype(np.float32)
+    out["glu_in"], out["glu_out"] = g_in, np.asarray(glu(types.SimpleNamespace(axis=-1), tf.convert_to_tensor(g_in)))
+    np.savez_compressed(os.path.join(OUT, "misc_reference.npz"), **out)
+    print("misc_reference:", sorted(out))
+
+
+def gen_attention_core():
+    """multihead_attention.py: MultiHeadRelativeAttention._compute_attention body (:543-582) + rel_left_shift, with the masked
+    softmax = the reference's Softmax.call (layers/general.py:30-41 -> math_util.masked_fill with -1e9) applied to the mask
+    expanded to [B,1,T,S] ([ext] keras MultiHeadAttention._masked_softmax) and the einsum equations keras builds for rank-4
+    projections with one attention axis ([ext] _build_attention_equation: 'aecd,abcd->acbe' / 'acbe,aecd->abcd')."""
+    import types
+
+    tf = tf_shim.make_tf()
+    su = _shape_util_tf(tf)
+    ns = {"tf": tf, "shape_util": su}
+    fns = tf_shim.extract_functions("tensorflow_asr/models/layers/multihead_attention.py",
+                                    ["rel_left_shift", "MultiHeadRelativeAttention._compute_attention"], ns)
+    ns["rel_left_shift"] = fns["rel_left_shift"]
+    fns = tf_shim.extract_functions("tensorflow_asr/models/layers/multihead_attention.py",
+                                    ["rel_left_shift", "MultiHeadRelativeAttention._compute_attention"], ns)
+    mu = tf_shim.extract_functions("tensorflow_asr/utils/math_util.py", ["masked_fill"], {"tf": tf, "shape_util": su})
+
+    def masked_softmax(scores, mask=None):
+        if mask is not None:
+            m = np.asarray(mask)
+            m = m[:, None] if m.ndim == 3 else m  # [B,T,S] -> [B,1,T,S]
+            scores = mu["masked_fill"](scores, mask=tf.convert_to_tensor(m), value=-1e9)
+        return tf.nn.softmax(scores, axis=-1)
+
+    out = {}
+    for name, (seed, B, T, H, dh, lens) in {"eq": (51, 2, 6, 2, 4, [6, 6]), "ragged": (52, 3, 9, 4, 8, [9, 5, 2]),
+                                            "head64": (53, 2, 70, 2, 64, [70, 41])}.items():
+        rng = np.random.default_rng(seed)
+        q, k, v = (rng.standard_normal((B, T, H, dh)).astype(np.float32) * 0.7 for _ in range(3))
+        # projected relative encodings: ONE table [2T-1, H, dh] for positions T-1..-(T-1), rolled by -(T - len_b) and zeroed from
+        # row 2*len_b - 1 per sample exactly as RelativeSinusoidalPositionalEncoding.call does to the encodings
+        # (positional_encoding.py:152-172, pinned by relpe_reference.npz); a bias-free projection keeps zero rows zero
+        table = rng.standard_normal((2 * T - 1, H, dh)).astype(np.float32) * 0.7
+        pos = np.stack([np.roll(table, -(T - ln), axis=0) * (np.arange(2 * T - 1) < 2 * ln - 1)[:, None, None] for ln in lens]).astype(np.float32)
+        cb, pb = rng.standard_normal((H, dh)).astype(np.float32) * 0.3, rng.standard_normal((H, dh)).astype(np.float32) * 0.3
+        qmask = (np.arange(T)[None, :] < np.asarray(lens)[:, None])  # keras auto mask: padded QUERY rows (SURVEY.md A.1)
+        amask = np.broadcast_to(qmask[:, :, None], (B, T, T))
+        me = types.SimpleNamespace(content_attention_bias=None, positional_attention_bias=None, _inverse_sqrt_key_dim=1.0 / np.sqrt(dh),
+                                   _dot_product_equation="aecd,abcd->acbe", _combine_equation="acbe,aecd->abcd", _causal=False,
+                                   _masked_softmax=masked_softmax, dropout=0.0)
+        o, sc = fns["MultiHeadRelativeAttention._compute_attention"](
+            me, tf.convert_to_tensor(q), tf.convert_to_tensor(k), tf.convert_to_tensor(v), tf.convert_to_tensor(pos),
+            content_attention_bias=tf.convert_to_tensor(cb), positional_attention_bias=tf.convert_to_tensor(pb),
+            attention_mask=tf.convert_to_tensor(amask), training=False)
+        for nm, arr in dict(q=q, k=k, v=v, pos=pos, table=table, cb=cb, pb=pb, lens=np.asarray(lens, np.int32), out=np.asarray(o, np.float32),
+                            probs=np.asarray(sc, np.float32)).items():
+            out[f"{name}_{nm}"] = arr
+    np.savez_compressed(os.path.join(OUT, "attention_core_reference.npz"), **out)
+    print("attention_core_reference:", {k: v.shape for k, v in out.items() if k.endswith("_out")})
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
+    only = [a for a in sys.argv[1:] if a.startswith("gen_")]
+    if only:
+        for fn in only:
+            globals()[fn]()
+        sys.exit(0)
     gen_rnnt()
     if "--all" in sys.argv or len(sys.argv) == 1:
-        for fn in ("gen_attention", "gen_posenc"):
+        for fn in ("gen_attention", "gen_posenc", "gen_greedy", "gen_specaugment", "gen_misc", "gen_attention_core"):
             if fn in globals():
                 globals()[fn]()

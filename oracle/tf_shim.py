@@ -239,7 +239,103 @@ def make_tf():
         band_part=w(lambda x, lo, hi: np.asarray(x) & (np.tril(np.ones(np.asarray(x).shape[-2:], bool), hi if hi >= 0 else 10**9)
                                                         & np.triu(np.ones(np.asarray(x).shape[-2:], bool), -lo if lo >= 0 else -10**9))))
     tf.custom_gradient = lambda f: f
+    _extend(tf, w)
     return tf
+
+
+class _TensorArray:
+    """tf.TensorArray (fixed size, clear_after_read=False): write returns the array, read/stack as documented."""
+
+    def __init__(self, dtype=None, size=0, dynamic_size=False, clear_after_read=True, element_shape=None, **_k):
+        self._d = _npd(dtype)
+        self._v = [np.zeros((), self._d) for _ in range(int(np.asarray(size)))]
+
+    def write(self, index, value):
+        self._v[int(np.asarray(index))] = np.asarray(value, self._d)
+        return self
+
+    def read(self, index):
+        return _t(self._v[int(np.asarray(index))])
+
+    def stack(self):
+        return _t(np.stack(self._v) if self._v else np.zeros((0,), self._d))
+
+
+class InjectedUniform:
+    """tf.random.uniform(shape=[]) stand-in backed by a numpy Generator: float dtypes -> rng.uniform(minval, maxval),
+    integer dtypes -> rng.integers(minval, maxval) (maxval exclusive, like TF).  Every draw is recorded."""
+
+    def __init__(self, rng):
+        self.rng, self.log = rng, []
+
+    def __call__(self, shape=(), minval=0, maxval=None, dtype=None, seed=None, name=None):
+        assert list(shape) == []
+        d = np.dtype(_npd(dtype) or np.float32)
+        lo, hi = np.asarray(minval).item(), (None if maxval is None else np.asarray(maxval).item())
+        if np.issubdtype(d, np.integer):
+            if hi <= lo:
+                raise ValueError(f"tf.random.uniform: maxval {hi} must be > minval {lo} (InvalidArgumentError in TF)")
+            v = int(self.rng.integers(lo, hi))
+        else:
+            v = float(self.rng.uniform(lo, 1.0 if hi is None else hi))
+        self.log.append(v)
+        return _t(np.asarray(v, d))
+
+
+def _extend(tf, w):
+    """Primitives used by the greedy-search loops (base_transducer.py:496-712), SpecAugment (specaugment.py:58-137),
+    the schedule / accumulator / loss-length / frontend helpers and MultiHeadRelativeAttention._compute_attention."""
+    tf.greater_equal = w(lambda a, b: np.asarray(a) >= np.asarray(b))
+    tf.greater = w(lambda a, b: np.asarray(a) > np.asarray(b))
+    tf.less_equal = w(lambda a, b: np.asarray(a) <= np.asarray(b))
+    tf.not_equal = w(lambda a, b: np.asarray(a) != np.asarray(b))
+    tf.logical_not = w(lambda a: ~np.asarray(a, bool))
+    tf.logical_or = w(lambda a, b: np.asarray(a, bool) | np.asarray(b, bool))
+    tf.logical_and = w(lambda a, b: np.asarray(a, bool) & np.asarray(b, bool))
+    tf.abs = w(lambda x: np.abs(np.asarray(x)))
+    tf.square = w(lambda x: np.square(np.asarray(x)))
+    tf.sqrt = w(lambda x: np.sqrt(np.asarray(x)))
+    tf.floor = w(lambda x: np.floor(np.asarray(x)))
+    tf.divide = w(lambda a, b: np.asarray(a) / np.asarray(b))
+    tf.subtract = w(lambda a, b: np.asarray(a) - np.asarray(b))
+    tf.reduce_mean = w(lambda x, axis=None, keepdims=False: np.mean(np.asarray(x), axis=axis, keepdims=keepdims))
+    tf.reduce_min = w(lambda x, axis=None, keepdims=False: np.min(np.asarray(x), axis=axis, keepdims=keepdims))
+    tf.broadcast_to = w(lambda x, shape: np.broadcast_to(np.asarray(x), [int(v) for v in shape]))
+    tf.split = lambda x, n, axis=-1: [_t(v) for v in np.split(np.asarray(x), n, axis=axis)]
+    tf.argmax = lambda x, axis=None, output_type=None: _t(np.argmax(np.asarray(x), axis=axis).astype(_npd(output_type) or np.int64))
+    tf.matmul = w(lambda a, b: np.matmul(np.asarray(a), np.asarray(b)))
+    tf.einsum = w(lambda eq, *ops, **k: np.einsum(eq, *[np.asarray(o) for o in ops]))  # `optimize=` is a scheduling hint
+    tf.TensorArray = _TensorArray
+    tf.TensorShape = lambda dims=None: list(dims or [])
+    tf.cond = lambda pred, true_fn, false_fn: (true_fn() if bool(np.asarray(pred)) else false_fn())
+
+    def while_loop(cond, body, loop_vars, back_prop=True, maximum_iterations=None, **_k):
+        v, n = tuple(loop_vars), 0
+        while bool(np.asarray(cond(*v)).all()):
+            v = tuple(body(*v))
+            n += 1
+            if maximum_iterations is not None and n >= maximum_iterations:
+                break
+            if n > getattr(tf, "_while_cap", 1_000_000):
+                raise RuntimeError("tf.while_loop stand-in: runaway loop")
+        tf._last_while_iterations = n
+        return v
+
+    tf.while_loop = while_loop
+
+    def tensor_scatter_nd_update(tensor, indices, updates):
+        out = np.array(np.asarray(tensor), copy=True)
+        idx = np.asarray(indices)
+        out[tuple(np.moveaxis(idx, -1, 0))] = np.asarray(updates)
+        return _t(out)
+
+    tf.tensor_scatter_nd_update = tensor_scatter_nd_update
+    tf.math.greater_equal, tf.math.less, tf.math.reduce_all = tf.greater_equal, tf.less, tf.reduce_all
+    tf.math.ceil = w(lambda x: np.ceil(np.asarray(x)))
+    tf.math.reduce_variance = w(lambda x, axis=None, keepdims=False: np.var(np.asarray(x), axis=axis, keepdims=keepdims))
+    tf.nn.sigmoid = w(lambda x: (1.0 / (1.0 + np.exp(-np.asarray(x, np.float64)))).astype(np.asarray(x).dtype))
+    tf.nn.softmax = w(lambda x, axis=-1: (lambda e: e / e.sum(axis=axis, keepdims=True))(np.exp(np.asarray(x) - np.asarray(x).max(axis=axis, keepdims=True))))
+    tf.random = types.SimpleNamespace(uniform=None)  # bind an InjectedUniform before running SpecAugment bodies
 
 
 def extract_functions(rel_path, names, namespace):

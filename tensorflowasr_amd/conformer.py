@@ -172,25 +172,28 @@ class ConformerTransducer:
         fcfg, tcfg = c.freq_masking, c.time_masking
         B = len(flen)
         rng = self._rng
-        fm = tm = None
-        if fcfg and fcfg.get("num_masks", 0) > 0:
-            fm = np.zeros((B, fcfg["num_masks"], 2), np.int32)
-            for b in range(B):
-                for k in range(fcfg["num_masks"]):
-                    if rng.uniform() <= fcfg.get("prob", 1.0):
-                        f = min(int(rng.integers(0, fcfg["mask_factor"])), c.num_feature_bins)
-                        fm[b, k] = (int(rng.integers(0, max(1, c.num_feature_bins - f))), f)
-            fm = torch.from_numpy(fm)
-        if tcfg and tcfg.get("num_masks", 0) > 0:
-            tm = np.zeros((B, tcfg["num_masks"], 2), np.int32)
-            for b in range(B):
-                Tb = int(math.floor(flen[b] * tcfg.get("p_upperbound", 1.0)))
-                for k in range(tcfg["num_masks"]):
-                    if rng.uniform() <= tcfg.get("prob", 1.0):
-                        t = min(int(rng.integers(0, max(1, Tb))), flen[b])
-                        tm[b, k] = (int(rng.integers(0, max(1, flen[b] - t))), t)
-            tm = torch.from_numpy(tm)
-        return fm, tm
+        nf = fcfg.get("num_masks", 0) if fcfg else 0
+        nt = tcfg.get("num_masks", 0) if tcfg else 0
+        fm = np.zeros((B, nf, 2), np.int32) if nf > 0 else None
+        tm = np.zeros((B, nt, 2), np.int32) if nt > 0 else None
+        nb = c.num_feature_bins
+        # the reference's consumption order: utterance by utterance (tf.map_fn, augmentation.py:78-90), frequency masks before time
+        # masks, and per mask (prob, width, start) are drawn unconditionally and multiplied by do_apply afterwards
+        for b in range(B):
+            ln = int(flen[b])
+            for k in range(nf):
+                do = 1 if rng.uniform() <= fcfg.get("prob", 1.0) else 0
+                f = do * min(int(rng.integers(0, max(1, int(fcfg["mask_factor"])))), nb)
+                fm[b, k] = (do * int(rng.integers(0, max(1, nb - f))), f)
+            if nt > 0:
+                Tb = int(math.floor(np.float32(ln) * np.float32(tcfg.get("p_upperbound", 1.0))))
+            for k in range(nt):
+                do = 1 if rng.uniform() <= tcfg.get("prob", 1.0) else 0
+                # tf.random.uniform(maxval=0) is an InvalidArgumentError in the reference (fewer than 20 frames at 0.05):
+                # a zero-width mask here
+                t = do * min(int(rng.integers(0, max(1, Tb))), ln)
+                tm[b, k] = (do * int(rng.integers(0, max(1, ln - t))), t)
+        return (None if fm is None else torch.from_numpy(fm)), (None if tm is None else torch.from_numpy(tm))
 
     # =================================================================================== batch norm
     def _bn_fwd(self, x2d, name, training, act):
@@ -287,14 +290,26 @@ class ConformerTransducer:
         pe = self._pe_ext(T)
         pext = K.matmul(pe, ps.w2d(pfx + "pos/w"), bias=ps.p(pfx + "pos/b"))  # [2T, HD]
         drop = self._drop(site, training)
+        att, saved = self.attention_core(qkv, pext, B, T, elen_dev)
+        y = K.matmul(att, ps.w2d(pfx + "o/w"), bias=ps.p(pfx + "o/b"), res=x, beta=c.mhsam_residual, drop_p=drop[0], drop_seed=drop[1])
+        if ctx is not None:
+            ctx[pfx] = dict(x=x, ln=ln, mean=mean, rstd=rstd, qkv=qkv, pext=pext, att=att, drop=drop, **saved)
+        return y
+
+    def attention_core(self, qkv, pext, B, T, elen_dev):
+        """MultiHeadRelativeAttention._compute_attention (multihead_attention.py:543-582) on the fused projection output
+        qkv [B*T, 3*H*dh] and the projected position table pext [2T, H*dh] (rows 0..2T-2 = positions T-1..-(T-1), row 2T-1 = the
+        projection of a zeroed encoding row).  Returns (context [B*T, H*dh], tensors the backward needs)."""
+        ps, c = self.ps, self.cfg
+        H, dh = c.num_heads, c.head_size
+        HD = H * dh
+        R1 = 2 * T
+        scale = 1.0 / math.sqrt(dh)
         if self._fused_attention():
             # flash-style kernel: scores, shift, mask, softmax and P@V never leave the CU (csrc/attn_fused.hip)
             att, lse = K.relattn_fused_fwd(qkv, ps.p("enc/u"), ps.p("enc/v"), pext, elen_dev, B, H, T, dh, scale,
                                            use_mask=c.use_attention_auto_mask)
-            y = K.matmul(att, ps.w2d(pfx + "o/w"), bias=ps.p(pfx + "o/b"), res=x, beta=c.mhsam_residual, drop_p=drop[0], drop_seed=drop[1])
-            if ctx is not None:
-                ctx[pfx] = dict(x=x, ln=ln, mean=mean, rstd=rstd, qkv=qkv, pext=pext, lse=lse, att=att, drop=drop)
-            return y
+            return att, dict(lse=lse)
         qu, qv = K.bias2_fwd(qkv, 3 * HD, ps.p("enc/u"), ps.p("enc/v"), B * T, HD)
         kk = qkv[:, HD:]
         vv = qkv[:, 2 * HD:]
@@ -308,10 +323,7 @@ class ConformerTransducer:
         probs = K.relattn_softmax_fwd(content, pos, elen_dev, T, use_mask=c.use_attention_auto_mask, probs=content)
         att = torch.empty(B * T, HD, dtype=self.dtype, device=self.device)
         K.gemm(probs, vv, att, T, dh, T, Tp, 3 * HD, HD, nb1=B, nb2=H, sA=(H * T * Tp, T * Tp), sB=(T * 3 * HD, dh), sD=(T * HD, dh))
-        y = K.matmul(att, ps.w2d(pfx + "o/w"), bias=ps.p(pfx + "o/b"), res=x, beta=c.mhsam_residual, drop_p=drop[0], drop_seed=drop[1])
-        if ctx is not None:
-            ctx[pfx] = dict(x=x, ln=ln, mean=mean, rstd=rstd, qkv=qkv, qu=qu, qv=qv, pext=pext, probs=probs, att=att, drop=drop)
-        return y
+        return att, dict(qu=qu, qv=qv, probs=probs)
 
     def _mhsa_bwd(self, dy, pfx, B, T, elen_dev, ctx):
         ps, c = self.ps, self.cfg
@@ -840,8 +852,17 @@ class ConformerTransducer:
         B, T, d = enc.shape
         E, P, J, V = c.embed_dim, c.rnn_units, c.joint_dim, c.vocab_size
         mode = 1 if B == 1 else 0
+        # The search arithmetic (embedding, LSTM cell, LayerNorm, joint, vocabulary projection, log-softmax, arg-max) runs in
+        # f32 on the f32 master weights whatever the model's storage type: the GEMMs of one step are [B, <=640] x [640, <=2560]
+        # (launch-bound, not MFMA-bound), and every token decision then carries the reference's f32 arithmetic
+        # (base_transducer.py:437-464) - a bf16 model's tokens are bit-exact against the reference search applied to ITS
+        # encoder output (tests/test_parity_baseline_gpu.py).
+        f32 = torch.float32
         nframes = torch.tensor([int(v) for v in elen], dtype=torch.int32).to(dev)
-        encj = K.matmul(enc.reshape(B * T, d), ps.w2d("joint/enc/w"), bias=ps.p("joint/enc/b")).view(B, T, J)
+        enc32 = enc.reshape(B * T, d)
+        if enc32.dtype != f32:
+            enc32 = K.cast(enc32.contiguous(), torch.empty(B * T, d, dtype=f32, device=dev))
+        encj = K.matmul(enc32, ps.p2d("joint/enc/w"), bias=ps.p("joint/enc/b")).view(B, T, J)
         max_tokens = int(elen[0]) * max_tokens_per_frame if mode == 1 else 2 * T + 1
         tokens = torch.full((B, max(max_tokens, 1)), self.blank, dtype=torch.int32, device=dev)
         frame_idx = torch.zeros(B, dtype=torch.int32, device=dev)
@@ -849,24 +870,22 @@ class ConformerTransducer:
         prev_tok = (torch.full((B,), self.blank, dtype=torch.int32, device=dev) if previous_tokens is None
                     else previous_tokens.to(dev).to(torch.int32).reshape(B).contiguous())
         if previous_decoder_states is None:
-            h = torch.zeros(B, P, dtype=self.dtype, device=dev)
-            cst = torch.zeros(B, P, dtype=torch.float32, device=dev)
+            h = torch.zeros(B, P, dtype=f32, device=dev)
+            cst = torch.zeros(B, P, dtype=f32, device=dev)
         else:
             st = previous_decoder_states.to(dev)
-            h = st[:, 0, 0].to(self.dtype).contiguous()
+            h = st[:, 0, 0].float().contiguous()
             cst = st[:, 0, 1].float().contiguous()
         per_frame = torch.zeros(max(int(elen[0]), 1), dtype=torch.int32, device=dev) if mode == 1 else None
         active = torch.ones(1, dtype=torch.int32, device=dev)
-        ecur = torch.empty(B, J, dtype=self.dtype, device=dev)
-        xg = torch.empty(B, 4 * P, dtype=self.dtype, device=dev)
-        hr = torch.empty(B, 4 * P, dtype=torch.float32, device=dev)
-        h_new = torch.empty(B, P, dtype=self.dtype, device=dev)
-        c_new = torch.empty(B, P, dtype=torch.float32, device=dev)
-        pj = torch.empty(B, J, dtype=self.dtype, device=dev)
-        # vocabulary logits stay f32 out of the MFMA accumulators (the reference's log_softmax / argmax run on f32 logits,
-        # base_transducer.py:463): no bf16 rounding between the projection and the arg-max decision
-        logits = torch.empty(B, V, dtype=torch.float32, device=dev)
-        Wk, Wrk, Wjp, Wv = ps.w2d("pred/lstm/k"), ps.w2d("pred/lstm/rk"), ps.w2d("joint/pred/w"), ps.w2d("joint/vocab/w")
+        ecur = torch.empty(B, J, dtype=f32, device=dev)
+        xg = torch.empty(B, 4 * P, dtype=f32, device=dev)
+        hr = torch.empty(B, 4 * P, dtype=f32, device=dev)
+        h_new = torch.empty(B, P, dtype=f32, device=dev)
+        c_new = torch.empty(B, P, dtype=f32, device=dev)
+        pj = torch.empty(B, J, dtype=f32, device=dev)
+        logits = torch.empty(B, V, dtype=f32, device=dev)
+        Wk, Wrk, Wjp, Wv = ps.p2d("pred/lstm/k"), ps.p2d("pred/lstm/rk"), ps.p2d("joint/pred/w"), ps.p2d("joint/vocab/w")
         # every useful iteration advances a frame or appends a token; the reference's while_loop is unbounded and can
         # spin forever once a sample saturates its token buffer — cap the trip count instead
         max_iters = T + max_tokens + 2
@@ -874,7 +893,7 @@ class ConformerTransducer:
         while it < max_iters:
             for _ in range(min(check_every, max_iters - it)):
                 K.decode_prepare(encj, nframes, frame_idx, tok_idx, active, ecur, max_tokens, mode)
-                emb = K.embedding_fwd(prev_tok, ps.p("pred/emb"), self.dtype)
+                emb = K.embedding_fwd(prev_tok, ps.p("pred/emb"), f32)
                 K.matmul(emb, Wk, bias=ps.p("pred/lstm/b"), out=xg)
                 K.gemm(h, Wrk, hr, B, 4 * P, P, P, 4 * P, 4 * P)
                 K.lstm_step_fwd(xg, hr, h, cst, None, 0, None, c_new, h_new, None, B, P)
@@ -890,7 +909,7 @@ class ConformerTransducer:
                 it += 1
             if int(active.item()) == 0:
                 break
-        states = torch.stack([h.float(), cst], dim=1).unsqueeze(1)  # [B, 1, 2, P]
+        states = torch.stack([h, cst], dim=1).unsqueeze(1)  # [B, 1, 2, P]
         return PredictOutput(tokens=tokens[:, :max_tokens], next_tokens=prev_tok.view(B, 1), next_encoder_states=None,
                              next_decoder_states=states)
 

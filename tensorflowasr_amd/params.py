@@ -181,6 +181,9 @@ class ParamStore:
     def w2d(self, name):
         return self._view(self.shadow, name, True)
 
+    def p2d(self, name):  # f32 master as a matrix (the greedy search's prediction / joint arithmetic stays f32)
+        return self._view(self.flat, name, True)
+
     def g2d(self, name):
         return self._view(self.grad, name, True)
 

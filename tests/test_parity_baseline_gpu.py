@@ -200,9 +200,9 @@ def test_conformer_s_greedy_tokens_bf16_and_f32_vs_f32_oracle(dev, sharpen, blan
     """Greedy search (base_transducer.py:496-712) on a seeded Conformer-S (16 blocks, random weights; the vocabulary
     projection is sharpened and the blank biased so that some utterances emit nothing, some a handful of tokens and some
     saturate their token buffer): the f32 model's tokens are bit-exact against the f32 oracle.  The bf16 model (what
-    `bench.py --mode decode` runs; vocabulary logits, log-softmax and arg-max in f32) is compared token by token: a bf16
-    encoder cannot promise bit-exact tokens against an f32 one, so every utterance either agrees completely or its FIRST
-    disagreement sits between two emissions whose f32 top-2 log-probability margin is inside bf16's error band."""
+    `bench.py --mode decode` runs) keeps the whole search arithmetic in f32: its tokens are bit-exact against the reference
+    search applied to its own (bf16) encoder output; what differs from the all-f32 oracle is attributable to the encoder's
+    bf16 rounding alone and is reported (agreement, margin at the first divergence)."""
     B = 4
     nsamp = [64000, 64000, 48000, 30000]
     ulens = [3] * B
@@ -225,10 +225,21 @@ def test_conformer_s_greedy_tokens_bf16_and_f32_vs_f32_oracle(dev, sharpen, blan
     model16.ps.import_keras(W)
     out16 = model16.recognize(inp)
     t16, tr = out16.tokens.cpu().numpy(), tok_ref.numpy()
+    # (a) the search itself is exact: the reference loop applied to the bf16 model's OWN encoder output gives its tokens
+    enc16, elen16 = model16.encode(torch.from_numpy(sig), torch.tensor(nsamp, dtype=torch.int32))
+    assert list(elen16) == elen.tolist()
+    with torch.no_grad():
+        tok_ref16, _, _, _ = R.recognize_batch(enc16.float().cpu(), elen.tolist(), W)
+    np.testing.assert_array_equal(t16, tok_ref16.numpy())
+    # (b) against the all-f32 oracle a bf16 ENCODER cannot promise identical arg-max decisions: report the agreement and
+    # the f32 top-2 margin at each utterance's first disagreement (near-ties of the random-weight model)
+    enc_err = float((enc16.float().cpu() - enc_ref).norm() / enc_ref.norm())
     agree = float((t16 == tr).mean())
     first_div = [int(np.argmax(t16[b] != tr[b])) if (t16[b] != tr[b]).any() else -1 for b in range(B)]
-    print(f"\n[g1] greedy S x{sharpen:g} blank+{blank_bias:g}: f32 bit-exact (tokens per utterance {per_utt}); bf16 agreement "
-          f"{agree:.4f}, first divergent column per utterance {first_div}")
+    print(f"\n[g1] greedy S x{sharpen:g} blank+{blank_bias:g}: f32 bit-exact (tokens per utterance {per_utt}); bf16: search bit-exact "
+          f"on its own encoder output; encoder rel L2 error {enc_err:.3e}; token agreement with the f32 oracle {agree:.4f}, first "
+          f"divergent column per utterance {first_div}")
+    assert enc_err < 3e-2
     if any(d >= 0 for d in first_div):
         with torch.no_grad():
             margins = _oracle_margins(enc_ref, elen.tolist(), W)
@@ -238,8 +249,8 @@ def test_conformer_s_greedy_tokens_bf16_and_f32_vs_f32_oracle(dev, sharpen, blan
             # column `col` holds emission number col - 1 (tokens start at column 2, base_transducer.py:518-520,545-552): the
             # decision that flipped lies among those taken after col - 2 emissions
             window = [m for m, ne in margins[b] if ne == max(col - 2, 0)] or [m for m, _ in margins[b]]
-            print(f"[g1]   utterance {b}: smallest f32 top-2 margin around the first divergence {min(window):.4f}")
-            assert min(window) < 0.25, (b, col, min(window))
+            print(f"[g1]   utterance {b}: smallest f32 top-2 log-prob margin around the first divergence {min(window):.4f} "
+                  f"(logits sharpened x{sharpen:g})")
     # single-utterance variant (recognize_single: <= 3 symbols per frame)
     inp1 = PredictInput(torch.from_numpy(sig[:1]), torch.tensor(nsamp[:1], dtype=torch.int32))
     with torch.no_grad():
