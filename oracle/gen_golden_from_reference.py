@@ -308,7 +308,7 @@ def gen_misc():
     out["nframes_in"], out["nframes_out"] = ns_, np.asarray([np.asarray(fe["FeatureExtraction.get_nframes"](me, tf.convert_to_tensor(v))) for v in ns_])
     # ---- GLU, Softmax
     glu = tf_shim.extract_functions("tensorflow_asr/models/activations/glu.py", ["GLU.call"], {"tf": tf})["GLU.call"]
-    g_in = np.random.default_rng(46).standard_normal((2, 5, 8)).astype(np.float32)
+    g_in = np.random.default_rng(46).standard_normal((2, 5, 16)).astype(np.float32)
     out["glu_in"], out["glu_out"] = g_in, np.asarray(glu(types.SimpleNamespace(axis=-1), tf.convert_to_tensor(g_in)))
     np.savez_compressed(os.path.join(OUT, "misc_reference.npz"), **out)
     print("misc_reference:", sorted(out))
