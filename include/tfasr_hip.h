@@ -131,6 +131,10 @@ typedef struct {
 } tfasr_gemm_args;
 
 int tfasr_gemm(const tfasr_gemm_args* args, void* stream);
+/* n independent products queued as ONE launch when all of them are bf16 weight gradients (trans_a, !trans_b, accumulate into
+   f32, no batch, no epilogue terms; split_k is chosen for the group): the Dense-layer gradients of one Conformer block
+   (models/encoders/conformer.py:101-109,209-239,366-377 under keras autodiff).  Anything else is launched one by one, in order. */
+int tfasr_gemm_group(const tfasr_gemm_args* args, int n, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * LayerNorm (keras LayerNormalization eps 1e-3: conformer.py:59-64, base_transducer.py:88-93) and

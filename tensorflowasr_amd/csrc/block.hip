@@ -10,6 +10,7 @@
 #include "common.h"
 #include <string.h>
 #include <stdlib.h>
+#include <vector>
 
 namespace {
 
@@ -101,6 +102,11 @@ struct Ex {
   int st;
   long rows;
   int esz;
+  // Deferred weight gradients (backward only): the Dense-layer gradients of the block are collected and queued as ONE grouped
+  // launch at the end of the phase (tfasr_gemm_group).  Their operands must then outlive the module that produced them, so
+  // in this mode the backward never rewinds its scratch arena and every module writes into fresh gradient buffers.
+  bool defer = false;
+  std::vector<tfasr_gemm_args> pending;
 
   const float* fp(int i) const { return P->flat + P->off[i]; }
   const void* wp(int i) const { return (const char*)P->shadow + P->off[i] * (long)esz; }
@@ -134,6 +140,7 @@ struct Ex {
     a.accumulate = g.accumulate; a.split_k = g.split_k; a.drop_p = g.drop_p; a.drop_seed = g.drop_seed;
     a.ws = ws; a.ws_elems = ws ? ws_elems : 0;
     a.colsum = g.colsum;
+    if (defer && g.side && !ws) { pending.push_back(a); return; }
     if (g.side && side && side->ok && !ws) {
       if (!forked) {
         if (hipEventRecord(side->fork, s) != hipSuccess || hipStreamWaitEvent(side->s2, side->fork, 0) != hipSuccess) chk(TFASR_STATUS_EXECUTION_FAILED);
@@ -144,6 +151,12 @@ struct Ex {
     }
     chk(tfasr_gemm(&a, s));
   }
+  void flush_wgrads() {
+    if (pending.empty()) return;
+    chk(tfasr_gemm_group(pending.data(), (int)pending.size(), s));
+    pending.clear();
+  }
+  void rewind(size_t mark) { if (!defer) scratch.off = mark; }
   // main stream waits for everything queued on the side stream since the last fork
   void join() {
     if (!forked) return;
@@ -246,7 +259,7 @@ struct Ex {
     void* dln = act(scratch, rows * d);
     dense_bwd(dz, k->ff_ln[m], b0 + 2, b0 + 3, d, F, dln);
     ln_bwd(dln, k->ff_x[m], b0, b0 + 1, k->ff_mean[m], k->ff_rstd[m], dy, dx, dxd, next_site);
-    scratch.off = mark;
+    rewind(mark);
   }
 
   // ------------------------------------------------------------------------------------------ MHSAModule
@@ -392,13 +405,14 @@ struct Ex {
     {
       G a; a.A = P->pe; a.lda = d; a.ta = 1; a.B = dpext_t; a.ldb = HD; a.tb = 0; a.D = gp(TFASR_BP_AT_POS_W); a.ldd = HD; a.M = d; a.N = HD; a.K = R1;
       a.out_f32 = 1; a.accumulate = 1;
+      a.side = 1;
       gemm(a);
     }
     if (!dry) chk(tfasr_colsum(dpext, HD, gp(TFASR_BP_AT_POS_B), R1, HD, 1.f, TFASR_F32, s));
     void* dln = act(scratch, rows * d);
     dense_bwd(dqkv, k->at_ln, TFASR_BP_AT_QKV_W, TFASR_BP_AT_QKV_B, d, 3 * HD, dln);
     ln_bwd(dln, k->at_x, TFASR_BP_AT_LN_G, TFASR_BP_AT_LN_B, k->at_mean, k->at_rstd, dy, dx, dxd, next_site);
-    scratch.off = mark;
+    rewind(mark);
   }
 
   // ------------------------------------------------------------------------------------------ ConvModule
@@ -496,29 +510,43 @@ struct Ex {
       k->stash_off = stash.off;
     }
   }
+  // gradient buffer pair for the next module: rotating (two buffers) normally, fresh ones when weight gradients are deferred
+  void next_bufs(bool dr) {
+    const int d = c->d;
+    if (defer) {
+      k->bw_cur = k->bw_nxt; k->bw_curd = k->bw_nxtd;
+      k->bw_nxt = act(scratch, rows * d);
+      k->bw_nxtd = dr ? act(scratch, rows * d) : nullptr;
+    } else {
+      void* t = k->bw_cur; k->bw_cur = k->bw_nxt; k->bw_nxt = t; t = k->bw_curd; k->bw_curd = k->bw_nxtd; k->bw_nxtd = t;
+    }
+  }
   void backward(int phase) {
     const int d = c->d;
+    const bool dr = drop_p() > 0.f;
     if (phase & TFASR_PHASE_A) {
       k->bw_cur = act(scratch, rows * d);
       k->bw_nxt = act(scratch, rows * d);
-      const bool dr = drop_p() > 0.f;
       k->bw_curd = dr ? act(scratch, rows * d) : nullptr;
       k->bw_nxtd = dr ? act(scratch, rows * d) : nullptr;
       ln_bwd(io->dy, k->ln_x, TFASR_BP_LN_G, TFASR_BP_LN_B, k->ln_mean, k->ln_rstd, nullptr, k->bw_cur, k->bw_curd, 5);
       ffm_bwd(1, k->bw_cur, k->bw_curd, k->bw_nxt, k->bw_nxtd, 4, 3);
-      { void* t = k->bw_cur; k->bw_cur = k->bw_nxt; k->bw_nxt = t; t = k->bw_curd; k->bw_curd = k->bw_nxtd; k->bw_nxtd = t; }
+      next_bufs(dr);
       conv_bwd_a(k->bw_cur, k->bw_curd, 3);
       k->scratch_off = scratch.off;
     }
     if (phase & TFASR_PHASE_B) {
+      // deferred weight gradients of phase A are flushed with phase B's when both run in one call; in a split call they were
+      // flushed at the end of phase A, and the operands of phase A lie below scratch_off, untouched
       scratch.off = k->scratch_off;
       const size_t mark = scratch.off;
       conv_bwd_b(k->bw_cur, k->bw_nxt, k->bw_nxtd, 2);
-      scratch.off = mark;
-      { void* t = k->bw_cur; k->bw_cur = k->bw_nxt; k->bw_nxt = t; t = k->bw_curd; k->bw_curd = k->bw_nxtd; k->bw_nxtd = t; }
+      rewind(mark);
+      next_bufs(dr);
       mhsa_bwd(k->bw_cur, k->bw_curd, k->bw_nxt, k->bw_nxtd, 2, 1);
       ffm_bwd(0, k->bw_nxt, k->bw_nxtd, io->dx, nullptr, 0, -1);
     }
+    flush_wgrads();
     join();
   }
 };
@@ -535,6 +563,8 @@ void setup(Ex& e, const tfasr_block_cfg* c, const tfasr_block_params* P, const t
   e.c = c; e.P = P; e.io = io; e.k = (Ctx*)ctx; e.s = (hipStream_t)stream; e.dry = dry; e.st = TFASR_STATUS_SUCCESS;
   e.side = dry ? nullptr : &side_for_device();
   e.forked = false;
+  static const bool group_off = getenv("TFASR_BLOCK_GROUP_WGRAD") && getenv("TFASR_BLOCK_GROUP_WGRAD")[0] == '0';
+  e.defer = !group_off && c->dtype == TFASR_BF16;
   e.rows = (long)c->B * c->T;
   e.esz = c->dtype == TFASR_F32 ? 4 : 2;
   e.stash = Arena{dry ? nullptr : (char*)io->stash, 0, dry ? 0 : io->stash_bytes, true, 0};

@@ -293,6 +293,29 @@ static bool use_fast_path() {
   return v == 1;
 }
 
+int tfasr_gemm_group_fast_try(const tfasr_gemm_args* a, int n, hipStream_t stream);
+
+extern "C" int tfasr_gemm_group(const tfasr_gemm_args* args, int n, void* stream_) {
+  if (!args || n <= 0) return TFASR_STATUS_INVALID_VALUE;
+  static const bool off = getenv("TFASR_GEMM_GROUP") && getenv("TFASR_GEMM_GROUP")[0] == '0';
+  int i = 0;
+  while (i < n) {
+    const int m = n - i < 10 ? n - i : 10;
+    int st = TFASR_STATUS_UNSUPPORTED;
+    if (!off && use_fast_path()) st = tfasr_gemm_group_fast_try(args + i, m, (hipStream_t)stream_);
+    if (st == TFASR_STATUS_UNSUPPORTED) {
+      for (int j = 0; j < m; ++j) {
+        st = tfasr_gemm(args + i + j, stream_);
+        if (st != TFASR_STATUS_SUCCESS) return st;
+      }
+    } else if (st != TFASR_STATUS_SUCCESS) {
+      return st;
+    }
+    i += m;
+  }
+  return TFASR_STATUS_SUCCESS;
+}
+
 extern "C" int tfasr_gemm(const tfasr_gemm_args* args, void* stream_) {
   if (!args || !args->A || !args->B || !args->D) return TFASR_STATUS_INVALID_VALUE;
   tfasr_gemm_args a = *args;

@@ -17,6 +17,8 @@
 // operand its row extent (M for A, N for B) rounded up to 8 must fit inside the row stride.
 #include "common.h"
 #include <type_traits>
+#include <string.h>
+#include <stdlib.h>
 
 typedef __attribute__((ext_vector_type(4))) short short4_t;
 
@@ -218,8 +220,10 @@ enum : int { E_ACT = 1 /* swish(+prez) */, E_DACT = 2 /* * swish'(dact_z) */, E_
 // round trip; the 512 cycles of MFMA per slab hide nothing) and 4300 in the epilogue.  So the NEXT tile's first two slabs
 // are issued into the two (then idle) stages BEFORE this tile's epilogue: they land under it, and the epilogue's strip
 // lives in its own 8.5 KiB so nothing waits for it.
+// `bid` / `G` = this workgroup's index and the number of workgroups working on THIS product (blockIdx.x / gridDim.x for a plain
+// launch; a slice of the grid inside a grouped launch, whose slices start at multiples of 8 so that bid & 7 is still the XCD).
 template <bool TA, bool TB, int BN_, int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_fast_kernel(const tfasr_gemm_args p, const int gx, const int gy, const int gz, const int ntiles) {
+__device__ __forceinline__ void gemm_fast_body(const tfasr_gemm_args& p, const int gx, const int gy, const int gz, const int ntiles, const int bid, const int G) {
   constexpr bool GEN = (EPI & E_GEN) != 0;
   constexpr bool C_ACT = GEN || (EPI & E_ACT), C_DACT = GEN || (EPI & E_DACT), C_DROP = GEN || (EPI & E_DROP), C_RES = GEN || (EPI & E_RES);
   constexpr bool C_WS = (EPI & E_WS) != 0;
@@ -232,7 +236,6 @@ __global__ __launch_bounds__(256, 2) void gemm_fast_kernel(const tfasr_gemm_args
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = w >> 1, wn = w & 1;
   const int r = lane & 15, g = lane >> 4;
-  const int G = gridDim.x;
   int kchunk = (p.K + split - 1) / split;
   kchunk = ((kchunk + BK - 1) / BK) * BK;
 
@@ -248,7 +251,7 @@ __global__ __launch_bounds__(256, 2) void gemm_fast_kernel(const tfasr_gemm_args
     const int tpp = gx * gy;
     int tx, ty, tz;
     if ((G & 7) == 0) {
-      const int x = blockIdx.x & 7, j = (blockIdx.x >> 3) + it * (G >> 3);
+      const int x = bid & 7, j = (bid >> 3) + it * (G >> 3);
       if (split > 1 && (gz & 7) == 0) {
         if (j >= (gz >> 3) * tpp) return T;
         tz = x + 8 * (j / tpp);
@@ -258,7 +261,7 @@ __global__ __launch_bounds__(256, 2) void gemm_fast_kernel(const tfasr_gemm_args
         // round `it` covers tiles [it*G, (it+1)*G); XCD x takes the x-th eighth of it.  A PARTIAL last round (R < G tiles left)
         // is dealt in ragged eighths of R instead: with eighths of G its tiles all land on the first XCDs, two per CU, while
         // the other XCDs idle (760 tiles on 512 workgroups: the second round ran on XCDs 0-3 only).
-        const int round0 = it * G, R = ntiles - round0, slot = blockIdx.x >> 3;
+        const int round0 = it * G, R = ntiles - round0, slot = bid >> 3;
         if (R <= 0) return T;
         int t;
         if (R >= G) t = round0 + x * (G >> 3) + slot;
@@ -271,8 +274,8 @@ __global__ __launch_bounds__(256, 2) void gemm_fast_kernel(const tfasr_gemm_args
       }
     } else {  // G == ntiles (fewer tiles than resident slots): one round, ragged but bijective runs
       if (it > 0) return T;
-      const int q = G >> 3, rem = G & 7, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-      const int t = G >= 16 ? (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + slot : (int)blockIdx.x;
+      const int q = G >> 3, rem = G & 7, xcd = bid & 7, slot = bid >> 3;
+      const int t = G >= 16 ? (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + slot : (int)bid;
       tx = t % gx; const int rest = t / gx; ty = rest % gy; tz = rest / gy;
     }
     const int ks = tz % split, bidx = tz / split;
@@ -532,16 +535,16 @@ _Pragma("unroll")
 #ifdef TFASR_GEMM_TIMING
     if (threadIdx.x == 0 && it == 0) {
       const long long t_end = __builtin_readcyclecounter();
-      long long* o = g_gemm_timing + 4L * blockIdx.x;
+      long long* o = g_gemm_timing + 4L * bid;
       o[0] = t_start; o[1] = 0; o[2] = t_main - t_start; o[3] = t_end - t_start;
     }
     if (threadIdx.x == 0 && it == 1) {
       const long long t_end = __builtin_readcyclecounter();
-      long long* o = g_gemm_timing + 4L * 32768 + 2L * blockIdx.x;
+      long long* o = g_gemm_timing + 4L * 32768 + 2L * bid;
       o[0] = t_main - t_start; o[1] = t_end - t_start;
     }
     if (threadIdx.x == 0 && it == 0) {
-      long long* o = g_gemm_timing + 6L * 32768 + 5L * blockIdx.x;
+      long long* o = g_gemm_timing + 6L * 32768 + 5L * bid;
       for (int k = 0; k < 5; ++k) o[k] = ph[k];
     }
 #endif
@@ -552,6 +555,35 @@ _Pragma("unroll")
     drained = true;
     cur = nxt;
   }
+}
+
+template <bool TA, bool TB, int BN_, int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_fast_kernel(const tfasr_gemm_args p, const int gx, const int gy, const int gz, const int ntiles) {
+  gemm_fast_body<TA, TB, BN_, EPI>(p, gx, gy, gz, ntiles, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Grouped weight gradients: the ~9 Dense-layer gradients  gW += x^T dy  of one Conformer block (K = B*T rows, a few 128x64 output
+// tiles each) in ONE launch.  Launched one by one each of them has to split K 8-16 ways to occupy the chip - and pays
+// `tiles x split` f32 atomics at a flat 320 G/s plus a launch ramp/drain - while together their ~190 tiles fill the 512
+// resident workgroup slots with a split of 2.  Every workgroup of the grid belongs to one product (a contiguous slice of
+// blockIdx.x starting at a multiple of 8) and runs gemm_fast_body on it unchanged.
+constexpr int GROUP_MAX = 10;
+struct GroupArgs {
+  tfasr_gemm_args p[GROUP_MAX];
+  int start[GROUP_MAX + 1], cnt[GROUP_MAX], gx[GROUP_MAX], gy[GROUP_MAX], gz[GROUP_MAX];
+  int n;
+};
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void wgrad_group_kernel(const GroupArgs ga) {
+  int q = 0;
+  for (int i = 1; i < ga.n; ++i)
+    if ((int)blockIdx.x >= ga.start[i]) q = i;
+  q = __builtin_amdgcn_readfirstlane(q);
+  const int bid = (int)blockIdx.x - ga.start[q];
+  if (bid >= ga.cnt[q]) return;  // padding of the slice to a multiple of 8
+  const tfasr_gemm_args* pp = ga.p + q;
+  gemm_fast_body<true, false, 64, EPI>(*pp, ga.gx[q], ga.gy[q], ga.gz[q], ga.gx[q] * ga.gy[q] * ga.gz[q], bid, ga.cnt[q]);
 }
 
 // second pass of the workspace split-K: D[m, n] += sum_s ws[s][m][n]
@@ -869,7 +901,52 @@ int launch_one(const tfasr_gemm_args& a, hipStream_t stream) {
 
 inline bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
+bool group_eligible(const tfasr_gemm_args& a) {
+  return a.dtype == TFASR_BF16 && a.trans_a && !a.trans_b && a.accumulate && a.out_f32 && a.nb1 * a.nb2 <= 1 && !a.ws && !a.bias && !a.res &&
+         !a.dact_z && !a.prez && a.act == TFASR_ACT_NONE && a.drop_p == 0.f && al16(a.A) && al16(a.B) && !(a.lda & 7) && !(a.ldb & 7) &&
+         ((a.M + 7) & ~7) <= a.lda && ((a.N + 7) & ~7) <= a.ldb && a.K >= 8 && a.N > 64 && a.M > 0;
+}
+
 }  // namespace
+
+// One launch for up to GROUP_MAX weight-gradient products (see wgrad_group_kernel).  UNSUPPORTED -> the caller launches them one by one.
+int tfasr_gemm_group_fast_try(const tfasr_gemm_args* a, int n, hipStream_t stream) {
+  if (n < 2 || n > GROUP_MAX) return TFASR_STATUS_UNSUPPORTED;
+  for (int i = 0; i < n; ++i)
+    if (!group_eligible(a[i])) return TFASR_STATUS_UNSUPPORTED;
+  GroupArgs ga;
+  memset(&ga, 0, sizeof(ga));
+  ga.n = n;
+  long total = 0;
+  for (int i = 0; i < n; ++i) {
+    ga.gx[i] = (a[i].N + 63) / 64;
+    ga.gy[i] = (a[i].M + BM - 1) / BM;
+    total += (long)ga.gx[i] * ga.gy[i];
+  }
+  // k-split shared by the group: fill the resident slots (2 workgroups per CU) once; TFASR_GROUP_SLOTS overrides the slot count
+  static const long slots = getenv("TFASR_GROUP_SLOTS") ? atol(getenv("TFASR_GROUP_SLOTS")) : 2L * num_cus();
+  long split = slots / (total > 0 ? total : 1);
+  if (split < 1) split = 1;
+  int at = 0;
+  for (int i = 0; i < n; ++i) {
+    long sp = split;
+    if (a[i].K / 512 < sp) sp = a[i].K / 512;
+    if (sp < 1) sp = 1;
+    if (sp >= 8) sp = sp / 8 * 8;
+    ga.p[i] = a[i];
+    ga.p[i].split_k = (int)sp;
+    ga.p[i].nb1 = ga.p[i].nb2 = 1;
+    ga.gz[i] = (int)sp;
+    ga.cnt[i] = ga.gx[i] * ga.gy[i] * (int)sp;
+    ga.start[i] = at;
+    at += (ga.cnt[i] + 7) & ~7;
+  }
+  ga.start[n] = at;
+  constexpr int SMEM = 2 * (A_BYTES + 64 * BK * 2) + 4 * (64 / (64 / 16)) * (64 / 2 + 4) * 4;
+  hipLaunchKernelGGL((wgrad_group_kernel<E_CSUM>), dim3(at), dim3(256), SMEM, stream, ga);
+  TFASR_CHECK_LAUNCH();
+  return TFASR_STATUS_SUCCESS;
+}
 
 // returns TFASR_STATUS_UNSUPPORTED when the fast path's preconditions do not hold (caller falls back)
 int tfasr_gemm_fast_try(const tfasr_gemm_args& a, hipStream_t stream) {

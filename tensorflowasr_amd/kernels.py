@@ -109,6 +109,24 @@ def gemm(A, B, out, M, N, K, lda, ldb, ldd, trans_a=False, trans_b=False, bias=N
          prez=None, alpha=1.0, beta=1.0, act=ACT_NONE, dact=ACT_NONE, nb1=1, nb2=1, sA=(0, 0), sB=(0, 0), sD=(0, 0),
          accumulate=False, split_k=1, drop_p=0.0, drop_seed=0, colsum=None):
     """Raw strided (two-level batched) GEMM; see include/tfasr_hip.h."""
+    a = _gemm_args(A, B, out, M, N, K, lda, ldb, ldd, trans_a, trans_b, bias, res, dact_z, prez, alpha, beta, act, dact, nb1, nb2, sA, sB, sD,
+                   accumulate, split_k, drop_p, drop_seed, colsum)
+    check(_lib.load().tfasr_gemm(ctypes.byref(a), _stream()), "gemm")
+    return out
+
+
+def gemm_group(calls):
+    """Several independent products in one launch when they qualify (tfasr_gemm_group: bf16 weight gradients), else one by
+    one.  `calls` = list of dicts with gemm()'s keyword arguments."""
+    arr = (GemmArgs * len(calls))()
+    for i, kw in enumerate(calls):
+        arr[i] = _gemm_args(**kw)
+    check(_lib.load().tfasr_gemm_group(arr, len(calls), _stream()), "gemm_group")
+
+
+def _gemm_args(A, B, out, M, N, K, lda, ldb, ldd, trans_a=False, trans_b=False, bias=None, res=None, dact_z=None,
+               prez=None, alpha=1.0, beta=1.0, act=ACT_NONE, dact=ACT_NONE, nb1=1, nb2=1, sA=(0, 0), sB=(0, 0), sD=(0, 0),
+               accumulate=False, split_k=1, drop_p=0.0, drop_seed=0, colsum=None):
     a = GemmArgs()
     a.A, a.B, a.D = A.data_ptr(), B.data_ptr(), out.data_ptr()
     a.bias = bias.data_ptr() if bias is not None else None
@@ -134,8 +152,7 @@ def gemm(A, B, out, M, N, K, lda, ldb, ldd, trans_a=False, trans_b=False, bias=N
         if _SPLITK_WS and split_k > 1 and nb1 * nb2 == 1:  # opt-in: k-slices reduce through a workspace (deterministic sums)
             ws = workspace(4 * split_k * M * N, out.device, "splitk_%d" % (_raw_stream(torch.cuda.current_device()) if _raw_stream else 0))
             a.ws, a.ws_elems = ws.data_ptr(), ws.numel() // 4
-    check(_lib.load().tfasr_gemm(ctypes.byref(a), _stream()), "gemm")
-    return out
+    return a
 
 
 def matmul(A, B, trans_a=False, trans_b=False, out=None, out_dtype=None, **kw):

@@ -157,3 +157,31 @@ def test_weight_gradient_with_fused_bias_gradient(dev, dtype, M, N, K, split):
     rtol, atol = _tol(dtype)
     np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=rtol, atol=atol * 70)
     np.testing.assert_allclose(gb.cpu().numpy(), refb.numpy(), rtol=1e-3, atol=atol * 70)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_grouped_weight_gradients_one_launch(dev, dtype):
+    """tfasr_gemm_group: the Dense-layer weight gradients of a Conformer block (different shapes, one K = rows except the positional
+    projection, with and without a fused bias gradient, ragged edges) as ONE launch (bf16) / one by one (f32 falls back):
+    same results as separate tfasr_gemm calls."""
+    g = torch.Generator().manual_seed(21)
+    rows = 3000
+    shapes = [(1024, 256, rows, True), (256, 1024, rows, True), (256, 256, rows, True), (256, 512, rows, False), (256, 768, rows, True),
+              (256, 256, 150, False), (144, 576, rows - 7, True), (200, 72, 1000, True)]
+    calls, refs, outs = [], [], []
+    for i, (M, N, K, with_bias) in enumerate(shapes):
+        X, dY = torch.randn(K, M, generator=g), torch.randn(K, N, generator=g)
+        Xd, Yd = X.to(dev).to(dtype), dY.to(dev).to(dtype)
+        out = torch.full((M, N), float(i), dtype=torch.float32, device=dev)
+        gb = torch.full((N,), 1.0, dtype=torch.float32, device=dev) if with_bias else None
+        alpha = 0.5 if i % 2 else 1.0
+        calls.append(dict(A=Xd, B=Yd, out=out, M=M, N=N, K=K, lda=M, ldb=N, ldd=N, trans_a=True, accumulate=True, alpha=alpha, colsum=gb))
+        refs.append((float(i) + alpha * (Xd.float().cpu().T @ Yd.float().cpu()), None if gb is None else 1.0 + alpha * Yd.float().cpu().sum(0)))
+        outs.append((out, gb))
+    kernels.gemm_group(calls)
+    torch.cuda.synchronize()
+    rtol, atol = _tol(dtype)
+    for (out, gb), (ref, refb), (M, N, K, _) in zip(outs, refs, shapes):
+        np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=rtol, atol=atol * 70, err_msg=str((M, N, K)))
+        if gb is not None:
+            np.testing.assert_allclose(gb.cpu().numpy(), refb.numpy(), rtol=1e-3, atol=atol * 70)
