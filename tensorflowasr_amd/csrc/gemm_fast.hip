@@ -222,7 +222,11 @@ enum : int { E_ACT = 1 /* swish(+prez) */, E_DACT = 2 /* * swish'(dact_z) */, E_
 // lives in its own 8.5 KiB so nothing waits for it.
 // `bid` / `G` = this workgroup's index and the number of workgroups working on THIS product (blockIdx.x / gridDim.x for a plain
 // launch; a slice of the grid inside a grouped launch, whose slices start at multiples of 8 so that bid & 7 is still the XCD).
-template <bool TA, bool TB, int BN_, int EPI>
+// NST = LDS stages: 2 (two barriers per slab: the stage just read is refilled after the MFMAs) or 3 (one barrier per slab: slab s+2
+// goes into the stage slab s-1 was read from, TWO slabs in flight under the MFMAs - for long-K products on HBM-cold operands
+// (weight gradients), whose main loop runs at the DMA round trip per slab with a single slab in flight).
+// FIXED: the caller chose this workgroup's tile itself: bid = tile index inside the gx x gy grid, G = its k-slice (grouped launch).
+template <bool TA, bool TB, int BN_, int EPI, int NST = 2, bool FIXED = false>
 __device__ __forceinline__ void gemm_fast_body(const tfasr_gemm_args& p, const int gx, const int gy, const int gz, const int ntiles, const int bid, const int G) {
   constexpr bool GEN = (EPI & E_GEN) != 0;
   constexpr bool C_ACT = GEN || (EPI & E_ACT), C_DACT = GEN || (EPI & E_DACT), C_DROP = GEN || (EPI & E_DROP), C_RES = GEN || (EPI & E_RES);
@@ -250,7 +254,10 @@ __device__ __forceinline__ void gemm_fast_body(const tfasr_gemm_args& p, const i
     T.nfull = -1;
     const int tpp = gx * gy;
     int tx, ty, tz;
-    if ((G & 7) == 0) {
+    if constexpr (FIXED) {
+      if (it > 0) return T;
+      tx = bid % gx; ty = bid / gx; tz = G;
+    } else if ((G & 7) == 0) {
       const int x = bid & 7, j = (bid >> 3) + it * (G >> 3);
       if (split > 1 && (gz & 7) == 0) {
         if (j >= (gz >> 3) * tpp) return T;
@@ -330,26 +337,41 @@ __device__ __forceinline__ void gemm_fast_body(const tfasr_gemm_args& p, const i
 #else
 #define TFASR_TICK(k)
 #endif
-    for (int s = 0; s < n; ++s) {
-      const int stage = s & 1;
-#ifdef TFASR_GEMM_TIMING
-      long long tp = __builtin_readcyclecounter();
-#endif
-      if (!(drained && s < 2)) {
-        // this wave's DMA pieces of slab s have landed; slab s+1 (when it exists) stays in flight
-        if (s + 1 < n) { if (GI == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (NST == 3) {
+      for (int s = 0; s < n; ++s) {
+        const int stage = s % 3;
+        if (!(drained && s < 2)) {
+          if (s + 1 < n) { if (GI == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
+          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();  // slab s is visible to every wave, and every wave is done reading slab s-1's stage
+        if (s + 2 < n) issue(cur, s + 2, (s + 2) % 3);
+        mma_slab<TA, TB, BN_, C_CS>(smem + stage * STAGE_BYTES, smem + stage * STAGE_BYTES + A_BYTES, wm, wn, lane, acc, accb, do_cs);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       }
-      TFASR_TICK(0)
       __builtin_amdgcn_s_barrier();
-      TFASR_TICK(1)
-      mma_slab<TA, TB, BN_, C_CS>(smem + stage * STAGE_BYTES, smem + stage * STAGE_BYTES + A_BYTES, wm, wn, lane, acc, accb, do_cs);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      TFASR_TICK(2)
-      __builtin_amdgcn_s_barrier();  // every wave is done reading this stage before it is refilled
-      TFASR_TICK(3)
-      if (s + 2 < n) issue(cur, s + 2, stage);
-      TFASR_TICK(4)
+    } else {
+      for (int s = 0; s < n; ++s) {
+        const int stage = s & 1;
+  #ifdef TFASR_GEMM_TIMING
+        long long tp = __builtin_readcyclecounter();
+  #endif
+        if (!(drained && s < 2)) {
+          // this wave's DMA pieces of slab s have landed; slab s+1 (when it exists) stays in flight
+          if (s + 1 < n) { if (GI == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
+          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        TFASR_TICK(0)
+        __builtin_amdgcn_s_barrier();
+        TFASR_TICK(1)
+        mma_slab<TA, TB, BN_, C_CS>(smem + stage * STAGE_BYTES, smem + stage * STAGE_BYTES + A_BYTES, wm, wn, lane, acc, accb, do_cs);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        TFASR_TICK(2)
+        __builtin_amdgcn_s_barrier();  // every wave is done reading this stage before it is refilled
+        TFASR_TICK(3)
+        if (s + 2 < n) issue(cur, s + 2, stage);
+        TFASR_TICK(4)
+      }
     }
     if (cur.tail) {
       char* sA = smem;
@@ -413,7 +435,7 @@ __device__ __forceinline__ void gemm_fast_body(const tfasr_gemm_args& p, const i
       constexpr int LPRW = WN / 8;        // lanes per strip row: 8 (BN 128) or 4 (BN 64), 8 columns each
       constexpr int RPP = 64 / LPRW;      // rows per pass: 8 or 16
       constexpr int NPASS = 16 / RPP;     // 2 or 1
-      float* sc = reinterpret_cast<float*>(smem + 2 * STAGE_BYTES) + w * (RPP * SLD);
+      float* sc = reinterpret_cast<float*>(smem + NST * STAGE_BYTES) + w * (RPP * SLD);
       const int prow = lane / LPRW, c8 = (lane % LPRW) * 8;
       const int col0 = n0 + wn * WN + c8;
       const bool vec_ok = C_WS ? ((p.N & 7) == 0) : (((p.ldd & 7) == 0) && ((((uintptr_t)p.D) & 15) == 0) && ((doff & 7) == 0));
@@ -569,21 +591,31 @@ __global__ __launch_bounds__(256, 2) void gemm_fast_kernel(const tfasr_gemm_args
 // resident workgroup slots with a split of 2.  Every workgroup of the grid belongs to one product (a contiguous slice of
 // blockIdx.x starting at a multiple of 8) and runs gemm_fast_body on it unchanged.
 constexpr int GROUP_MAX = 10;
+constexpr int GROUP_UNITS = 8;  // (product, k-slice) units per XCD
 struct GroupArgs {
   tfasr_gemm_args p[GROUP_MAX];
-  int start[GROUP_MAX + 1], cnt[GROUP_MAX], gx[GROUP_MAX], gy[GROUP_MAX], gz[GROUP_MAX];
-  int n;
+  int gx[GROUP_MAX], gy[GROUP_MAX];
+  // XCD x (= blockIdx.x & 7) runs nunit[x] units; unit u covers slots [j0[x][u], j0[x][u+1]) of that XCD (slot = blockIdx.x >> 3)
+  short uq[8][GROUP_UNITS], uks[8][GROUP_UNITS];
+  int j0[8][GROUP_UNITS + 1];
+  int nunit[8];
 };
-template <int EPI>
+// A unit = ALL output tiles of one product for one k-slice, resident on ONE XCD at the same time: the tiles sharing an operand
+// panel march through k together, so the panel comes out of HBM once and its re-reads hit that XCD's L2.  (With the tiles of a
+// product dealt over all XCDs the panels were re-fetched per XCD: 1.5 GB of fabric traffic per block for 0.32 GB of operands,
+// and the launch ran at the fabric's rate, 156 us; 3 LDS stages instead of 2 changed nothing.)
+template <int EPI, int NST, int BN_>
 __global__ __launch_bounds__(256, 2) void wgrad_group_kernel(const GroupArgs ga) {
-  int q = 0;
-  for (int i = 1; i < ga.n; ++i)
-    if ((int)blockIdx.x >= ga.start[i]) q = i;
-  q = __builtin_amdgcn_readfirstlane(q);
-  const int bid = (int)blockIdx.x - ga.start[q];
-  if (bid >= ga.cnt[q]) return;  // padding of the slice to a multiple of 8
+  const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
+  const int nu = ga.nunit[x];
+  int u = -1;
+  for (int i = 0; i < nu; ++i)
+    if (j >= ga.j0[x][i] && j < ga.j0[x][i + 1]) u = i;
+  u = __builtin_amdgcn_readfirstlane(u);
+  if (u < 0) return;
+  const int q = ga.uq[x][u], ks = ga.uks[x][u], t = j - ga.j0[x][u];
   const tfasr_gemm_args* pp = ga.p + q;
-  gemm_fast_body<true, false, 64, EPI>(*pp, ga.gx[q], ga.gy[q], ga.gz[q], ga.gx[q] * ga.gy[q] * ga.gz[q], bid, ga.cnt[q]);
+  gemm_fast_body<true, false, BN_, EPI, NST, true>(*pp, ga.gx[q], ga.gy[q], 1, ga.gx[q] * ga.gy[q], t, ks);
 }
 
 // second pass of the workspace split-K: D[m, n] += sum_s ws[s][m][n]
@@ -916,10 +948,10 @@ int tfasr_gemm_group_fast_try(const tfasr_gemm_args* a, int n, hipStream_t strea
     if (!group_eligible(a[i])) return TFASR_STATUS_UNSUPPORTED;
   GroupArgs ga;
   memset(&ga, 0, sizeof(ga));
-  ga.n = n;
   long total = 0;
+  static const int bn = getenv("TFASR_GROUP_BN") ? atoi(getenv("TFASR_GROUP_BN")) : 128;
   for (int i = 0; i < n; ++i) {
-    ga.gx[i] = (a[i].N + 63) / 64;
+    ga.gx[i] = (a[i].N + bn - 1) / bn;
     ga.gy[i] = (a[i].M + BM - 1) / BM;
     total += (long)ga.gx[i] * ga.gy[i];
   }
@@ -927,23 +959,53 @@ int tfasr_gemm_group_fast_try(const tfasr_gemm_args* a, int n, hipStream_t strea
   static const long slots = getenv("TFASR_GROUP_SLOTS") ? atol(getenv("TFASR_GROUP_SLOTS")) : 2L * num_cus();
   long split = slots / (total > 0 ? total : 1);
   if (split < 1) split = 1;
-  int at = 0;
+  // units (product, k-slice), largest first, each onto the XCD with the fewest slots taken so far
+  struct U { int q, ks, tiles; };
+  U units[GROUP_MAX * 64];
+  int nu = 0;
   for (int i = 0; i < n; ++i) {
     long sp = split;
     if (a[i].K / 512 < sp) sp = a[i].K / 512;
     if (sp < 1) sp = 1;
-    if (sp >= 8) sp = sp / 8 * 8;
+    if (sp > 64) sp = 64;
     ga.p[i] = a[i];
     ga.p[i].split_k = (int)sp;
     ga.p[i].nb1 = ga.p[i].nb2 = 1;
-    ga.gz[i] = (int)sp;
-    ga.cnt[i] = ga.gx[i] * ga.gy[i] * (int)sp;
-    ga.start[i] = at;
-    at += (ga.cnt[i] + 7) & ~7;
+    for (int k2 = 0; k2 < (int)sp; ++k2) units[nu++] = U{i, k2, ga.gx[i] * ga.gy[i]};
   }
-  ga.start[n] = at;
-  constexpr int SMEM = 2 * (A_BYTES + 64 * BK * 2) + 4 * (64 / (64 / 16)) * (64 / 2 + 4) * 4;
-  hipLaunchKernelGGL((wgrad_group_kernel<E_CSUM>), dim3(at), dim3(256), SMEM, stream, ga);
+  for (int i = 1; i < nu; ++i) {  // insertion sort by tiles, descending
+    const U v = units[i];
+    int j = i - 1;
+    while (j >= 0 && units[j].tiles < v.tiles) { units[j + 1] = units[j]; --j; }
+    units[j + 1] = v;
+  }
+  int load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int i = 0; i < nu; ++i) {
+    int best = 0;
+    for (int x = 1; x < 8; ++x)
+      if (load[x] < load[best]) best = x;
+    const int c = ga.nunit[best];
+    if (c >= GROUP_UNITS) return TFASR_STATUS_UNSUPPORTED;
+    ga.uq[best][c] = (short)units[i].q;
+    ga.uks[best][c] = (short)units[i].ks;
+    ga.j0[best][c] = load[best];
+    load[best] += units[i].tiles;
+    ga.j0[best][c + 1] = load[best];
+    ga.nunit[best] = c + 1;
+  }
+  int maxload = 0;
+  for (int x = 0; x < 8; ++x)
+    if (load[x] > maxload) maxload = load[x];
+  static const int nst = getenv("TFASR_GROUP_NST") ? atoi(getenv("TFASR_GROUP_NST")) : 2;
+  // accumulate epilogue: atomics from the fragments, no strips in LDS
+  if (bn == 64) {
+    constexpr int STAGE = A_BYTES + 64 * BK * 2;
+    if (nst == 3) hipLaunchKernelGGL((wgrad_group_kernel<E_CSUM, 3, 64>), dim3(8 * maxload), dim3(256), 3 * STAGE, stream, ga);
+    else hipLaunchKernelGGL((wgrad_group_kernel<E_CSUM, 2, 64>), dim3(8 * maxload), dim3(256), 2 * STAGE, stream, ga);
+  } else {
+    constexpr int STAGE = A_BYTES + 128 * BK * 2;
+    hipLaunchKernelGGL((wgrad_group_kernel<E_CSUM, 2, 128>), dim3(8 * maxload), dim3(256), 2 * STAGE, stream, ga);
+  }
   TFASR_CHECK_LAUNCH();
   return TFASR_STATUS_SUCCESS;
 }
