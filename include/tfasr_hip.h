@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define TFASR_ABI_VERSION 13
+#define TFASR_ABI_VERSION 14
 
 typedef enum {
   TFASR_STATUS_SUCCESS = 0,
@@ -233,6 +233,13 @@ int tfasr_relattn_softmax_fwd(const void* content, const void* pos, const int32_
                               int T, int ldc, int ldp, int use_mask, int dtype, void* stream);
 int tfasr_relattn_softmax_bwd(const void* probs, const void* dprobs, const int32_t* lengths, void* dcontent, void* dpos,
                               int B, int H, int T, int ldc, int ldp, int use_mask, int dtype, void* stream);
+/* Same forward with the streaming attention mask of compute_streaming_mask (multihead_attention.py:104-143,331-345) ANDed into
+ * the auto mask: query i sees key j iff max(0, c*chunk - hist) <= j < min(T, c*chunk + chunk), c = i / chunk (history_size < 0
+ * = unlimited history); chunk_size <= 0 = no streaming mask.  Masked scores are -1e9 in the reference, i.e. exactly zero
+ * probability, so the backward (tfasr_relattn_softmax_bwd, which works from the probabilities) is unchanged. */
+int tfasr_relattn_softmax_fwd_streaming(const void* content, const void* pos, const int32_t* lengths, void* probs, int B, int H,
+                                        int T, int ldc, int ldp, int use_mask, int chunk_size, int history_size, int dtype,
+                                        void* stream);
 
 /* Fused (flash-style) forward of the same attention: nothing of size T x T is written.  qkv [B*T, 3*H*dh] (fused
  * projection output, q|k|v column blocks), ubias/vbias [H*dh] f32 (content / positional biases), pext [2T, H*dh]
@@ -360,6 +367,9 @@ typedef struct {
   int site0;                        /* first dropout site id of this block */
   long drop_epoch;                  /* bumped once per forward pass: seed = drop_epoch*8192 + site */
   float drop_p, ffm_res, mhsa_res, conv_res, ln_eps, bn_eps, bn_momentum;
+  int chunk_size, history_size;     /* streaming attention mask (chunk_size <= 0: off): unfused attention kernels only */
+  int dw_norm_layer;                /* 1: LayerNormalization after the depthwise conv (encoder_convm_dw_norm_type "layer",
+                                       encoders/conformer.py:334-340) in the CV_BN_G/B parameter slots; no batch statistics */
 } tfasr_block_cfg;
 
 typedef struct {

@@ -243,7 +243,7 @@ def compute_streaming_mask(chunk_size, history_size, q_len, v_len=None):
     return np.asarray(rows, bool)[None]
 
 
-def rel_mhsa(x, pe, W, pfx, H, dh, lengths, u, v, use_mask=True):
+def rel_mhsa(x, pe, W, pfx, H, dh, lengths, u, v, use_mask=True, chunk_size=None, history_size=None):
     """MultiHeadRelativeAttention.call/_compute_attention (multihead_attention.py:543-667); x is the LN output [B,T,d],
     pe [B,2T-1,d]; kernels q/k/v/encoding [d,H,dh] (+bias [H,dh]), out [H,dh,d] (+bias [d]).
     Auto mask = padded QUERY rows only."""
@@ -252,11 +252,11 @@ def rel_mhsa(x, pe, W, pfx, H, dh, lengths, u, v, use_mask=True):
     k = torch.einsum("btd,dhe->bthe", x, W[pfx + "k/w"]) + W[pfx + "k/b"]
     vv = torch.einsum("btd,dhe->bthe", x, W[pfx + "v/w"]) + W[pfx + "v/b"]
     p = torch.einsum("brd,dhe->brhe", pe, W[pfx + "pos/w"]) + W[pfx + "pos/b"]
-    ctx, _ = rel_attention_core(q, k, vv, p, u, v, dh, lengths, use_mask)
+    ctx, _ = rel_attention_core(q, k, vv, p, u, v, dh, lengths, use_mask, chunk_size, history_size)
     return torch.einsum("bthe,hed->btd", ctx, W[pfx + "o/w"]) + W[pfx + "o/b"]
 
 
-def rel_attention_core(q, k, vv, p, u, v, dh, lengths, use_mask=True):
+def rel_attention_core(q, k, vv, p, u, v, dh, lengths, use_mask=True, chunk_size=None, history_size=None):
     """MultiHeadRelativeAttention._compute_attention (multihead_attention.py:543-582) on projected tensors q/k/vv [B,T,H,dh],
     p [B,2T-1,H,dh]: content + shifted positional scores, keras auto mask (padded QUERY rows, -1e9 fill: general.py:30-41),
     softmax, weighted values.  Pinned by tests/golden/attention_core_reference.npz (the reference's own function body).
@@ -270,9 +270,14 @@ def rel_attention_core(q, k, vv, p, u, v, dh, lengths, use_mask=True):
     positional = rel_left_shift(positional)
     positional = positional[..., positional.shape[-1] - content.shape[-1]:]
     scores = content + positional
+    mask = None
     if use_mask and lengths is not None:
-        qmask = (torch.arange(T)[None, :] < torch.as_tensor(lengths)[:, None])[:, None, :, None]  # [B,1,T,1]
-        scores = torch.where(qmask, scores, torch.full_like(scores, -1e9))  # math_util.masked_fill / general.py:30-41
+        mask = (torch.arange(T)[None, :] < torch.as_tensor(lengths)[:, None])[:, None, :, None].expand(-1, 1, T, T)  # [B,1,T,S]
+    if chunk_size is not None and history_size is not None:  # _compute_attention_mask (multihead_attention.py:331-345)
+        sm = torch.from_numpy(compute_streaming_mask(int(chunk_size), int(history_size), T))[:, None]  # [1,1,T,S]
+        mask = sm if mask is None else (mask & sm)
+    if mask is not None:
+        scores = torch.where(mask, scores, torch.full_like(scores, -1e9))  # math_util.masked_fill / general.py:30-41
     probs = torch.softmax(scores, dim=-1)
     return torch.einsum("bhts,bshe->bthe", probs, vv), probs
 
@@ -285,21 +290,23 @@ def ff_module(x, W, pfx, factor=0.5):
     return x + factor * y
 
 
-def mhsa_module(x, pe, W, pfx, H, dh, lengths, u, v, use_mask=True):
+def mhsa_module(x, pe, W, pfx, H, dh, lengths, u, v, use_mask=True, chunk_size=None, history_size=None):
     """MHSAModule.call (conformer.py:209-239)."""
     y = layer_norm(x, W[pfx + "ln/g"], W[pfx + "ln/b"])
-    y = rel_mhsa(y, pe, W, pfx, H, dh, lengths, u, v, use_mask)
+    y = rel_mhsa(y, pe, W, pfx, H, dh, lengths, u, v, use_mask, chunk_size, history_size)
     return x + y
 
 
-def conv_module(x, W, pfx, training=True, stats=None):
+def conv_module(x, W, pfx, training=True, stats=None, dw_norm="batch"):
     """ConvModule.call (conformer.py:366-377): LN -> pw(2d) -> GLU -> causal depthwise K -> BN -> swish -> pw(d) -> +res."""
     y = layer_norm(x, W[pfx + "ln/g"], W[pfx + "ln/b"])
     y = y @ W[pfx + "pw1/w"] + W[pfx + "pw1/b"]
     a, b = y.chunk(2, dim=-1)
     y = a * torch.sigmoid(b)  # activations/glu.py:25-28
     y = depthwise_conv1d_causal(y, W[pfx + "dw/w"], W[pfx + "dw/b"])
-    if training:
+    if dw_norm == "layer":  # encoder_convm_dw_norm_type: layer -> keras LayerNormalization (conformer.py:334-340), stored in bn/g, bn/b
+        y = layer_norm(y, W[pfx + "bn/g"], W[pfx + "bn/b"])
+    elif training:
         y, mean, var = batch_norm_train(y, W[pfx + "bn/g"], W[pfx + "bn/b"])
         if stats is not None:
             stats[pfx + "bn"] = (mean.detach(), var.detach())
@@ -314,8 +321,8 @@ def conformer_block(x, pe, W, pfx, cfg, lengths, u, v, training=True, use_mask=T
     """ConformerBlock.call (conformer.py:504-535)."""
     H, dh = cfg["num_heads"], cfg["head_size"]
     x = ff_module(x, W, pfx + "ff1/", cfg["ffm_residual"])
-    x = mhsa_module(x, pe, W, pfx + "mhsa/", H, dh, lengths, u, v, use_mask)
-    x = conv_module(x, W, pfx + "conv/", training, stats)
+    x = mhsa_module(x, pe, W, pfx + "mhsa/", H, dh, lengths, u, v, use_mask, cfg.get("chunk_size"), cfg.get("history_size"))
+    x = conv_module(x, W, pfx + "conv/", training, stats, cfg.get("convm_dw_norm", "batch"))
     x = ff_module(x, W, pfx + "ff2/", cfg["ffm_residual"])
     return layer_norm(x, W[pfx + "ln/g"], W[pfx + "ln/b"])
 

@@ -38,6 +38,11 @@ class ConformerConfig:
     convm_residual: float = 1.0
     dropout: float = 0.1
     use_attention_auto_mask: bool = True
+    # streaming Conformer (examples/models/transducer/conformer/small-streaming.yml.j2:33,38-39): chunked attention mask
+    # (multihead_attention.py:104-143,331-345) and LayerNormalization after the depthwise conv (encoders/conformer.py:334-340)
+    chunk_size: int = None
+    history_size: int = None
+    convm_dw_norm: str = "batch"
     # prediction / joint
     embed_dim: int = 320
     rnn_units: int = 320
@@ -78,7 +83,9 @@ class ConformerConfig:
         unsupported = {
             "encoder_mha_type": ("relmha",), "encoder_padding": ("causal",), "prediction_rnn_type": ("lstm",),
             "prediction_num_rnns": (1,), "joint_activation": ("tanh",), "joint_mode": ("add",),
-            "encoder_convm_dw_norm_type": ("batch",), "prediction_label_encode_mode": ("embedding",),
+            "encoder_convm_dw_norm_type": ("batch", "layer"), "prediction_label_encode_mode": ("embedding",),
+            "encoder_memory_length": (None,), "encoder_use_attention_causal_mask": (False,),
+            "encoder_mhsam_use_attention_bias": (False,),
         }
         for k, ok in unsupported.items():
             if k in c and c[k] not in ok:
@@ -97,7 +104,11 @@ class ConformerConfig:
             mhsam_residual=c.get("encoder_mhsam_residual_factor", 1.0), convm_residual=c.get("encoder_convm_residual_factor", 1.0),
             dropout=c.get("encoder_dropout", 0.1), use_attention_auto_mask=c.get("encoder_use_attention_auto_mask", True),
             embed_dim=c.get("prediction_embed_dim", 512), rnn_units=c.get("prediction_rnn_units", 320),
-            joint_dim=c.get("joint_dim", 1024), vocab_size=int(c.get("vocab_size", 1000)), blank=c.get("blank", 0), l2=l2)
+            joint_dim=c.get("joint_dim", 1024), vocab_size=int(c.get("vocab_size", 1000)), blank=c.get("blank", 0), l2=l2,
+            chunk_size=c.get("encoder_chunk_size"), history_size=c.get("encoder_history_size"),
+            convm_dw_norm=c.get("encoder_convm_dw_norm_type", "batch"))
+        if (kw["chunk_size"] is None) != (kw["history_size"] is None):  # multihead_attention.py:339 needs both
+            kw["chunk_size"] = kw["history_size"] = None
         if "time_masking" in aug:
             kw["time_masking"] = dict(aug["time_masking"])
         if "freq_masking" in aug:

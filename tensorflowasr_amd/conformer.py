@@ -320,7 +320,8 @@ class ConformerTransducer:
         pos = torch.empty(B, H, T, R1p, dtype=self.dtype, device=self.device)
         K.gemm(qv, pext, pos, T, R1, dh, HD, HD, R1p, trans_b=True, nb1=B, nb2=H, sA=(T * HD, dh), sB=(0, dh),
                sD=(H * T * R1p, T * R1p), alpha=scale)
-        probs = K.relattn_softmax_fwd(content, pos, elen_dev, T, use_mask=c.use_attention_auto_mask, probs=content)
+        probs = K.relattn_softmax_fwd(content, pos, elen_dev, T, use_mask=c.use_attention_auto_mask, probs=content,
+                                      chunk_size=c.chunk_size, history_size=c.history_size)
         att = torch.empty(B * T, HD, dtype=self.dtype, device=self.device)
         K.gemm(probs, vv, att, T, dh, T, Tp, 3 * HD, HD, nb1=B, nb2=H, sA=(H * T * Tp, T * Tp), sB=(T * 3 * HD, dh), sD=(T * HD, dh))
         return att, dict(qu=qu, qv=qv, probs=probs)
@@ -363,7 +364,9 @@ class ConformerTransducer:
         return self._mhsa_bwd_tail(dy, pfx, B, T, s, dqkv, dqu, dpos, s["qv"], R1p, scale)
 
     def _fused_attention(self):
-        return self.dtype == torch.bfloat16 and self.cfg.head_size == 64 and os.environ.get("TFASR_ATTN_UNFUSED", "0") != "1"
+        # the streaming (chunked) mask lives in the unfused softmax kernel only (the reference's streaming model is Conformer-S, head 36)
+        return (self.dtype == torch.bfloat16 and self.cfg.head_size == 64 and not self.cfg.chunk_size
+                and os.environ.get("TFASR_ATTN_UNFUSED", "0") != "1")
 
     def _mhsa_bwd_tail(self, dy, pfx, B, T, s, dqkv, dqu, dpos, qv, R1p, scale):
         """dpos [B,H,T,R1p] (gradient of the un-shifted position scores) -> dqv, dpext, bias and projection gradients."""
@@ -395,7 +398,11 @@ class ConformerTransducer:
         a = K.matmul(ln, ps.w2d(pfx + "pw1/w"), bias=ps.p(pfx + "pw1/b"))  # [B*T, 2d]
         g = K.glu_fwd(a)  # [B*T, d]
         cv = K.dwconv_fwd(g.view(B, T, d), ps.p(pfx + "dw/w"), ps.p(pfx + "dw/b")).view(B * T, d)
-        sw, bn = self._bn_fwd(cv, pfx + "bn", training, ACT_SWISH)
+        if c.convm_dw_norm == "layer":  # encoder_convm_dw_norm_type: layer (encoders/conformer.py:334-340), in the bn/g, bn/b slots
+            yn, nmean, nrstd = K.layernorm_fwd(cv, ps.p(pfx + "bn/g"), ps.p(pfx + "bn/b"))
+            sw, bn = K.add_act_fwd(yn, None, ACT_SWISH), (yn, nmean, nrstd)
+        else:
+            sw, bn = self._bn_fwd(cv, pfx + "bn", training, ACT_SWISH)
         drop = self._drop(site, training)
         y = K.matmul(sw, ps.w2d(pfx + "pw2/w"), bias=ps.p(pfx + "pw2/b"), res=x, beta=c.convm_residual, drop_p=drop[0], drop_seed=drop[1])
         if ctx is not None:
@@ -407,7 +414,12 @@ class ConformerTransducer:
         d = c.dmodel
         s = ctx.pop(pfx)
         dsw = self._dense_bwd(self._mask_grad(dy, s["drop"]), s["sw"], pfx + "pw2/w", pfx + "pw2/b", alpha=c.convm_residual)
-        dcv = self._bn_bwd(s["cv"], dsw, pfx + "bn", s["bn"], ACT_SWISH)
+        if c.convm_dw_norm == "layer":
+            yn, nmean, nrstd = s["bn"]
+            dyn = K.add_act_bwd(yn, None, dsw, ACT_SWISH)
+            dcv = K.layernorm_bwd(dyn, s["cv"], ps.p(pfx + "bn/g"), nmean, nrstd, ps.g(pfx + "bn/g"), ps.g(pfx + "bn/b"))
+        else:
+            dcv = self._bn_bwd(s["cv"], dsw, pfx + "bn", s["bn"], ACT_SWISH)
         dcv3 = dcv.view(B, T, d)
         K.dwconv_bwd_weight(s["g"].view(B, T, d), dcv3, ps.g(pfx + "dw/w"), ps.g(pfx + "dw/b"))
         dg = K.dwconv_bwd_data(dcv3, ps.p(pfx + "dw/w")).view(B * T, d)
@@ -469,6 +481,9 @@ class ConformerTransducer:
         k.drop_p = float(c.dropout)
         k.ffm_res, k.mhsa_res, k.conv_res = c.ffm_residual, c.mhsam_residual, c.convm_residual
         k.ln_eps, k.bn_eps, k.bn_momentum = 1e-3, 1e-3, 0.99
+        k.chunk_size = int(c.chunk_size) if c.chunk_size else 0
+        k.history_size = int(c.history_size) if c.history_size is not None else 0
+        k.dw_norm_layer = int(c.convm_dw_norm == "layer")
         return k
 
     def _native_params(self, i, T):
@@ -509,7 +524,7 @@ class ConformerTransducer:
         io.prezeroed = 1 if pool is not None else 0
         io.stash, io.stash_bytes, io.scratch, io.scratch_bytes = stash.data_ptr(), stash_b, scratch.data_ptr(), scratch.numel()
         cbuf = K.block_ctx()
-        if training and self.dp.world > 1:
+        if training and self.dp.world > 1 and not cfgk.dw_norm_layer:
             K.block_fwd(cfgk, P, io, cbuf, K._lib.PHASE_A)
             self.dp.allreduce_stats_(stats[:2 * d])
             K.block_fwd(cfgk, P, io, cbuf, K._lib.PHASE_B)
@@ -539,7 +554,7 @@ class ConformerTransducer:
         scratch = K.workspace(bscr_b, self.device, "blk_bwd")
         io.dy, io.dx, io.bn_bstats = dy.data_ptr(), dx.data_ptr(), bstats.data_ptr()
         io.scratch, io.scratch_bytes = scratch.data_ptr(), scratch.numel()
-        if self.dp.world > 1:
+        if self.dp.world > 1 and not cfgk.dw_norm_layer:
             K.block_bwd(cfgk, P, io, cbuf, K._lib.PHASE_A)
             self.dp.allreduce_stats_(bstats)
             K.block_bwd(cfgk, P, io, cbuf, K._lib.PHASE_B)

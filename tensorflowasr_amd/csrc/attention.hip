@@ -31,7 +31,7 @@ __device__ __forceinline__ int pos_col(int i, int j, int T, int R, int len) {
 template <typename T_>
 __global__ __launch_bounds__(256) void relattn_softmax_fwd_kernel(const T_* content, const T_* __restrict__ pos,
                                                                   const int32_t* __restrict__ lengths, T_* probs, int B,
-                                                                  int H, int T, int ldc, int ldp, int use_mask) {
+                                                                  int H, int T, int ldc, int ldp, int use_mask, int chunk, int hist) {
   const int lane = threadIdx.x & 63;
   const int R = 2 * T - 1;
   const long nrows = (long)B * H * T;
@@ -52,8 +52,16 @@ __global__ __launch_bounds__(256) void relattn_softmax_fwd_kernel(const T_* cont
     float s[MAXJ];
     float mx = -INFINITY;
     int n = 0;
+    // streaming window of query i (compute_streaming_mask, multihead_attention.py:104-143): keys outside it carry -1e9 in the
+    // reference = probability exactly 0 (a window is never empty: it always contains the query's own chunk)
+    int jlo = 0, jhi = T;
+    if (chunk > 0) {
+      const int index = (i / chunk) * chunk;
+      jlo = hist < 0 ? 0 : max(0, index - hist);
+      jhi = min(T, index + chunk);
+    }
     for (int j = lane; j < T; j += 64, ++n) {
-      s[n] = Num<T_>::ld(crow + j) + Num<T_>::ld(prow + pos_col(i, j, T, R, len));
+      s[n] = (j >= jlo && j < jhi) ? Num<T_>::ld(crow + j) + Num<T_>::ld(prow + pos_col(i, j, T, R, len)) : -INFINITY;
       mx = fmaxf(mx, s[n]);
     }
     mx = wave_max(mx);
@@ -136,15 +144,21 @@ inline int rows_grid(long rows) { return (int)std::max<long>(1, std::min<long>((
 
 extern "C" int tfasr_relattn_softmax_fwd(const void* content, const void* pos, const int32_t* lengths, void* probs,
                                          int B, int H, int T, int ldc, int ldp, int use_mask, int dtype, void* stream_) {
+  return tfasr_relattn_softmax_fwd_streaming(content, pos, lengths, probs, B, H, T, ldc, ldp, use_mask, 0, 0, dtype, stream_);
+}
+
+extern "C" int tfasr_relattn_softmax_fwd_streaming(const void* content, const void* pos, const int32_t* lengths, void* probs,
+                                                   int B, int H, int T, int ldc, int ldp, int use_mask, int chunk, int hist, int dtype,
+                                                   void* stream_) {
   if (!content || !pos || !probs || B <= 0 || H <= 0 || T <= 0 || T > 64 * MAXJ || ldc < T || ldp < 2 * T) return TFASR_STATUS_INVALID_VALUE;
   hipStream_t s = (hipStream_t)stream_;
   const int grid = rows_grid((long)B * H * T);
   if (dtype == TFASR_F32)
     hipLaunchKernelGGL(relattn_softmax_fwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)content,
-                       (const float*)pos, lengths, (float*)probs, B, H, T, ldc, ldp, use_mask);
+                       (const float*)pos, lengths, (float*)probs, B, H, T, ldc, ldp, use_mask, chunk, hist);
   else if (dtype == TFASR_BF16)
     hipLaunchKernelGGL(relattn_softmax_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)content,
-                       (const bf16_t*)pos, lengths, (bf16_t*)probs, B, H, T, ldc, ldp, use_mask);
+                       (const bf16_t*)pos, lengths, (bf16_t*)probs, B, H, T, ldc, ldp, use_mask, chunk, hist);
   else return TFASR_STATUS_INVALID_VALUE;
   TFASR_CHECK_LAUNCH();
   return TFASR_STATUS_SUCCESS;

@@ -37,8 +37,8 @@ struct Ctx {
   void *at_x, *at_ln, *at_qkv, *at_pext, *at_att, *at_qu, *at_qv, *at_probs;
   float *at_mean, *at_rstd, *at_lse;
   // convolution module
-  void *cv_x, *cv_ln, *cv_a, *cv_g, *cv_cv, *cv_sw;
-  float *cv_mean, *cv_rstd, *cv_fin;
+  void *cv_x, *cv_ln, *cv_a, *cv_g, *cv_cv, *cv_sw, *cv_y;
+  float *cv_mean, *cv_rstd, *cv_fin, *cv_nmean, *cv_nrstd;
   // block layer norm
   void* ln_x;
   float *ln_mean, *ln_rstd;
@@ -303,7 +303,8 @@ struct Ex {
       pg.nb1 = B; pg.nb2 = H; pg.sA1 = (long)T * HD; pg.sA2 = dh; pg.sB1 = 0; pg.sB2 = dh; pg.sD1 = (long)H * T * R1p; pg.sD2 = (long)T * R1p;
       pg.alpha = scale;
       gemm(pg);
-      if (!dry) chk(tfasr_relattn_softmax_fwd(k->at_probs, pos, io->lengths, k->at_probs, B, H, T, Tp, R1p, c->use_mask, c->dtype, s));
+      if (!dry) chk(tfasr_relattn_softmax_fwd_streaming(k->at_probs, pos, io->lengths, k->at_probs, B, H, T, Tp, R1p, c->use_mask, c->chunk_size,
+                                                          c->history_size, c->dtype, s));
       G ag; ag.A = k->at_probs; ag.lda = Tp; ag.ta = 0; ag.B = vv; ag.ldb = 3 * HD; ag.tb = 0; ag.D = k->at_att; ag.ldd = HD; ag.M = T; ag.N = dh; ag.K = T;
       ag.nb1 = B; ag.nb2 = H; ag.sA1 = (long)H * T * Tp; ag.sA2 = (long)T * Tp; ag.sB1 = (long)T * 3 * HD; ag.sB2 = dh; ag.sD1 = (long)T * HD; ag.sD2 = dh;
       gemm(ag);
@@ -427,12 +428,17 @@ struct Ex {
     k->cv_cv = act(stash, rows * d);
     k->cv_fin = f32(stash, 4 * d);
     k->cv_sw = act(stash, rows * d);
+    if (c->dw_norm_layer) {  // LayerNormalization variant: its output (the swish input) and row statistics are kept for the backward
+      k->cv_y = act(stash, rows * d);
+      k->cv_nmean = f32(stash, rows);
+      k->cv_nrstd = f32(stash, rows);
+    }
     ln_fwd(x, TFASR_BP_CV_LN_G, TFASR_BP_CV_LN_B, k->cv_ln, k->cv_mean, k->cv_rstd);
     dense(k->cv_ln, TFASR_BP_CV_PW1_W, TFASR_BP_CV_PW1_B, k->cv_a, d, 2 * d);
     if (!dry) {
       chk(tfasr_glu_fwd(k->cv_a, k->cv_g, rows, d, c->dtype, s));
       chk(tfasr_dwconv_fwd(k->cv_g, fp(TFASR_BP_CV_DW_W), fp(TFASR_BP_CV_DW_B), k->cv_cv, c->B, c->T, d, c->ksize, c->dtype, s));
-      if (c->training) {
+      if (c->training && !c->dw_norm_layer) {
         if (!(io->prezeroed & 1)) zero(io->bn_stats, (size_t)(2 * d + 1) * 4);
         chk(tfasr_bn_stats(k->cv_cv, io->bn_stats, rows, d, c->dtype, s));
       }
@@ -440,7 +446,10 @@ struct Ex {
   }
   void conv_fwd_b(void* y, int site) {
     const int d = c->d;
-    if (!dry) {
+    if (!dry && c->dw_norm_layer) {
+      chk(tfasr_layernorm_fwd(k->cv_cv, fp(TFASR_BP_CV_BN_G), fp(TFASR_BP_CV_BN_B), k->cv_y, k->cv_nmean, k->cv_nrstd, rows, d, c->ln_eps, c->dtype, s));
+      chk(tfasr_add_act_fwd(k->cv_y, nullptr, k->cv_sw, rows * d, TFASR_ACT_SWISH, c->dtype, s));
+    } else if (!dry) {
       if (c->training)
         chk(tfasr_bn_finalize(io->bn_stats, (float)(rows * c->world), fp(TFASR_BP_CV_BN_G), fp(TFASR_BP_CV_BN_B), k->cv_fin, P->bn_mm, P->bn_mv,
                               c->bn_momentum, c->bn_eps, d, 1, s));
@@ -459,8 +468,10 @@ struct Ex {
     const void* dyd = masked(dy, dy_dropped, rows * d, site);
     void* dsw = act(scratch, rows * d);
     dense_bwd(dyd, k->cv_sw, TFASR_BP_CV_PW2_W, TFASR_BP_CV_PW2_B, d, d, dsw, c->conv_res);
-    if (!(io->prezeroed & 2)) zero(io->bn_bstats, (size_t)2 * d * 4);
-    if (!dry) chk(tfasr_bn_bwd_stats(k->cv_cv, dsw, k->cv_fin, io->bn_bstats, rows, d, TFASR_ACT_SWISH, c->dtype, s));
+    if (!c->dw_norm_layer) {
+      if (!(io->prezeroed & 2)) zero(io->bn_bstats, (size_t)2 * d * 4);
+      if (!dry) chk(tfasr_bn_bwd_stats(k->cv_cv, dsw, k->cv_fin, io->bn_bstats, rows, d, TFASR_ACT_SWISH, c->dtype, s));
+    }
     k->bw_dsw = dsw;
   }
   void conv_bwd_b(const void* dy, void* dx, void* dxd, int next_site) {
@@ -472,11 +483,18 @@ struct Ex {
     void* dg = act(scratch, rows * d);
     void* da = act(scratch, rows * 2 * d);
     void* dln = act(scratch, rows * d);
+    void* dyn = c->dw_norm_layer ? act(scratch, rows * d) : nullptr;
     if (!dry) {
-      chk(tfasr_bn_apply_bwd(k->cv_cv, k->bw_dsw, k->cv_fin, io->bn_bstats, (float)(rows * c->world), dcv, rows, d, TFASR_ACT_SWISH, c->dtype, s));
-      const float inv = 1.f / (float)c->world;
-      chk(tfasr_axpy(gp(TFASR_BP_CV_BN_B), io->bn_bstats, inv, d, s));
-      chk(tfasr_axpy(gp(TFASR_BP_CV_BN_G), io->bn_bstats + d, inv, d, s));
+      if (c->dw_norm_layer) {
+        chk(tfasr_add_act_bwd(k->cv_y, nullptr, k->bw_dsw, dyn, rows * d, TFASR_ACT_SWISH, c->dtype, s));
+        chk(tfasr_layernorm_bwd(dyn, k->cv_cv, fp(TFASR_BP_CV_BN_G), k->cv_nmean, k->cv_nrstd, nullptr, dcv, gp(TFASR_BP_CV_BN_G), gp(TFASR_BP_CV_BN_B), rows, d,
+                                c->dtype, s));
+      } else {
+        chk(tfasr_bn_apply_bwd(k->cv_cv, k->bw_dsw, k->cv_fin, io->bn_bstats, (float)(rows * c->world), dcv, rows, d, TFASR_ACT_SWISH, c->dtype, s));
+        const float inv = 1.f / (float)c->world;
+        chk(tfasr_axpy(gp(TFASR_BP_CV_BN_B), io->bn_bstats, inv, d, s));
+        chk(tfasr_axpy(gp(TFASR_BP_CV_BN_G), io->bn_bstats + d, inv, d, s));
+      }
       chk(tfasr_dwconv_bwd_weight_ws(k->cv_g, dcv, gp(TFASR_BP_CV_DW_W), gp(TFASR_BP_CV_DW_B), c->B, c->T, d, c->ksize, c->dtype, dwws, dwws_bytes, s));
       chk(tfasr_dwconv_bwd_data(dcv, fp(TFASR_BP_CV_DW_W), dg, c->B, c->T, d, c->ksize, c->dtype, s));
       chk(tfasr_glu_bwd(k->cv_a, dg, da, rows, d, c->dtype, s));
@@ -571,7 +589,7 @@ void setup(Ex& e, const tfasr_block_cfg* c, const tfasr_block_params* P, const t
   e.scratch = Arena{dry ? nullptr : (char*)io->scratch, 0, dry ? 0 : io->scratch_bytes, true, 0};
 }
 
-bool use_fused(const tfasr_block_cfg* c) { return c->dtype == TFASR_BF16 && c->dh == 64 && !c->force_unfused; }
+bool use_fused(const tfasr_block_cfg* c) { return c->dtype == TFASR_BF16 && c->dh == 64 && !c->force_unfused && c->chunk_size <= 0; }
 
 }  // namespace
 
@@ -603,7 +621,7 @@ extern "C" int tfasr_block_fwd(const tfasr_block_cfg* c, const tfasr_block_param
                                void* stream) {
   int st = check_args(c, P, io, ctx);
   if (st != TFASR_STATUS_SUCCESS) return st;
-  if (!io->x_in || !io->x_out || !io->stash || (c->training && !io->bn_stats) || !(phase & (TFASR_PHASE_A | TFASR_PHASE_B)))
+  if (!io->x_in || !io->x_out || !io->stash || (c->training && !c->dw_norm_layer && !io->bn_stats) || !(phase & (TFASR_PHASE_A | TFASR_PHASE_B)))
     return TFASR_STATUS_INVALID_VALUE;
   Ex e;
   setup(e, c, P, io, ctx, stream, false);
@@ -621,7 +639,7 @@ extern "C" int tfasr_block_bwd(const tfasr_block_cfg* c, const tfasr_block_param
                                void* stream) {
   int st = check_args(c, P, io, ctx);
   if (st != TFASR_STATUS_SUCCESS) return st;
-  if (!io->dy || !io->dx || !io->scratch || !io->bn_bstats || !(phase & (TFASR_PHASE_A | TFASR_PHASE_B))) return TFASR_STATUS_INVALID_VALUE;
+  if (!io->dy || !io->dx || !io->scratch || (!c->dw_norm_layer && !io->bn_bstats) || !(phase & (TFASR_PHASE_A | TFASR_PHASE_B))) return TFASR_STATUS_INVALID_VALUE;
   Ex e;
   setup(e, c, P, io, ctx, stream, false);
   e.backward(phase);

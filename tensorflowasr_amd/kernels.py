@@ -356,13 +356,16 @@ def specaugment(x, fmask, tmask, mask_value=0.0):
 
 
 # --------------------------------------------------------------------------------- attention
-def relattn_softmax_fwd(content, pos, lengths, T, use_mask=True, probs=None):
-    """content [B,H,T,ldc], pos [B,H,T,ldp] (row strides may be padded)."""
+def relattn_softmax_fwd(content, pos, lengths, T, use_mask=True, probs=None, chunk_size=None, history_size=None):
+    """content [B,H,T,ldc], pos [B,H,T,ldp] (row strides may be padded); chunk_size / history_size = streaming mask."""
     B, H, _, ldc = content.shape
     ldp = pos.shape[3]
     if probs is None:
         probs = torch.empty_like(content)
-    check(_L().tfasr_relattn_softmax_fwd(_p(content), _p(pos), _p(lengths), _p(probs), B, H, T, ldc, ldp, int(use_mask), _dt(content), _stream()), "relattn_softmax_fwd")
+    chunk = int(chunk_size) if chunk_size else 0
+    hist = int(history_size) if history_size is not None else 0
+    check(_L().tfasr_relattn_softmax_fwd_streaming(_p(content), _p(pos), _p(lengths), _p(probs), B, H, T, ldc, ldp, int(use_mask), chunk, hist,
+                                                   _dt(content), _stream()), "relattn_softmax_fwd")
     return probs
 
 

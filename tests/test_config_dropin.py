@@ -28,6 +28,20 @@ def test_small_yml_maps_onto_config():
     assert configs.transformer_schedule(1, lr["dmodel"], lr["warmup_steps"], lr["scale"], eval(lr["max_lr"])) > 0
 
 
+@pytest.mark.skipif(not os.path.exists(REF), reason="reference tree not present")
+def test_small_streaming_yml_maps_onto_config():
+    """examples/models/transducer/conformer/small-streaming.yml.j2 (the reference's other published Conformer result): chunked
+    attention mask (encoder_chunk_size 16, encoder_history_size 64) and LayerNormalization after the depthwise conv."""
+    import jinja2
+    import yaml
+
+    path = REF.replace("small.yml.j2", "small-streaming.yml.j2")
+    txt = jinja2.Template(open(path).read()).render(decoder_config={"vocabsize": 1000}, modeldir="/tmp/m", kaggle_model_handle="x")
+    cfg = configs.ConformerConfig.from_reference(yaml.safe_load(txt)["model_config"]["config"])
+    assert (cfg.chunk_size, cfg.history_size, cfg.convm_dw_norm) == (16, 64, "layer")
+    assert (cfg.dmodel, cfg.head_size, cfg.num_blocks, cfg.kernel_size) == (144, 36, 16, 31)
+
+
 def test_unsupported_options_fail_loudly():
     with pytest.raises(NotImplementedError):
         configs.ConformerConfig.from_reference({"encoder_mha_type": "mha", "vocab_size": 10})

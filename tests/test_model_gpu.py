@@ -13,9 +13,10 @@ from tensorflowasr_amd.schemas import TrainData, TrainInput, TrainLabel
 pytestmark = pytest.mark.gpu
 
 
-def _setup(dev, dtype, lens, ulens, seed=0, N=4000, U=6):
-    cfg = configs.conformer_tiny()
+def _setup(dev, dtype, lens, ulens, seed=0, N=4000, U=6, **over):
+    cfg = configs.conformer_tiny(**over)
     ocfg = R.conformer_config("tiny")
+    ocfg.update({k: v for k, v in over.items() if k in ("chunk_size", "history_size", "convm_dw_norm")})
     model = ConformerTransducer(cfg, dev, dtype=dtype, seed=seed)
     model.use_pred_stream = True
     W = R.init_weights(ocfg, seed=seed + 1, scale_bias=0.1)
@@ -108,6 +109,40 @@ def test_f32_step_matches_oracle(dev, lens, ulens):
     k = "enc/block1/ff2/d1/b"  # not regularised
     p_ref, _, _ = R.adam_step(before[k], mine[k], torch.zeros_like(mine[k]), torch.zeros_like(mine[k]), 1, lr, 0.9, 0.98, 1e-9, 1e-6)
     np.testing.assert_allclose(after[k].numpy(), p_ref.numpy(), rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("chunk,hist", [(2, 4), (3, -1)])
+def test_streaming_conformer_step_matches_oracle(dev, dtype, chunk, hist):
+    """small-streaming.yml.j2's encoder: chunked attention mask (multihead_attention.py:104-143,331-345, pinned to the reference's
+    truth tables) ANDed with the padded-query auto mask + LayerNormalization after the depthwise conv (conformer.py:334-340):
+    logits, loss and every gradient of the train step against the oracle, ragged lengths; native executor and host path."""
+    lens, ulens = [4000, 2500, 3100], [6, 3, 5]
+    cfg, ocfg, model, W, data, sig, labels, preds = _setup(dev, dtype, lens, ulens, chunk_size=chunk, history_size=hist, convm_dw_norm="layer")
+    assert not model._fused_attention()
+    ref_logits, elen, ref_loss, ref_grads, _ = _oracle_step(ocfg, W, sig, lens, preds, ulens, labels, None)
+    # the mask matters: the full-context oracle gives different logits
+    ocfg_full = dict(ocfg, chunk_size=None, history_size=None)
+    full_logits = _oracle_step(ocfg_full, W, sig, lens, preds, ulens, labels, None)[0]
+    assert float((full_logits - ref_logits).abs().max()) > 1e-3
+    tol = 2e-3 if dtype == torch.float32 else 6e-2
+    out = {}
+    for native in (True, False):
+        model.native_blocks = native
+        logits, _, _ = model._forward(data.inputs, True, None, (None, None))
+        np.testing.assert_allclose(logits.float().cpu().numpy(), ref_logits.numpy(), rtol=tol, atol=tol)
+        model.zero_grad()
+        costs = model.loss_and_backward(data, True, (None, None)).float().cpu().numpy()
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(costs, ref_loss, rtol=1e-3 if dtype == torch.float32 else 3e-2)
+        mine = model.ps.export_keras(model.ps.grad)
+        num = sum(float(((mine[k] - g) ** 2).sum()) for k, g in ref_grads.items())
+        den = sum(float((g ** 2).sum()) for g in ref_grads.values())
+        assert (num / den) ** 0.5 < (2e-3 if dtype == torch.float32 else 0.15), (native, (num / den) ** 0.5)
+        out[native] = model.ps.grad.clone()
+    g0, g1 = out[False].cpu().numpy(), out[True].cpu().numpy()
+    t2 = 1e-5 if dtype == torch.float32 else 2e-2
+    np.testing.assert_allclose(g1, g0, rtol=t2, atol=t2 * float(np.abs(g0).max()))
 
 
 def test_bf16_step_close_to_oracle(dev):
