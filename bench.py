@@ -197,6 +197,40 @@ def bench_decode(args, model, cfg, dev):
                                  "global_batch": B}}))
 
 
+def bench_ctc_decode(args, dev, dtype):
+    """Conformer-CTC (examples/models/ctc/conformer/small.yml.j2 dimensions) inference RTF: CtcModel.recognize (greedy) and
+    recognize_beam (tf.nn.ctc_beam_search_decoder semantics, host routine like the reference's) over 32 x 10 s utterances,
+    log-mel + encoder included.  BASELINE configs[4] names Jasper + fp16; the reference's Jasper streaming path is broken
+     and the MI355X path stores bf16, so the CTC family is benchmarked on its Conformer model."""
+    from tensorflowasr_amd import configs
+    from tensorflowasr_amd.ctc_model import ConformerCTC
+    from tensorflowasr_amd.schemas import PredictInput
+
+    cfg = configs.conformer_ctc_s()
+    model = ConformerCTC(cfg, dev, dtype=dtype, seed=0)
+    rng = np.random.default_rng(0)
+    B, secs = args.batch, 10.0
+    sig = torch.from_numpy(np.clip(rng.standard_normal((B, int(secs * 16000))).astype(np.float32) * 0.1, -1, 1)).to(dev)
+    inp = PredictInput(sig, torch.full((B,), int(secs * 16000), dtype=torch.int32))
+    res = {}
+    for name, fn in (("greedy", lambda: model.recognize(inp)), ("beam10", lambda: model.recognize_beam(inp, beam_width=10))):
+        for _ in range(args.warmup):
+            out = fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = fn()
+        torch.cuda.synchronize()
+        res[name] = (time.perf_counter() - t0) / args.steps
+    dt = res["greedy"]
+    print(json.dumps({"metric": "CTC greedy-decode RTF Conformer-CTC(S)", "value": round(dt / (B * secs), 6), "unit": "RTF (wall s / audio s)",
+                      "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt * 1e3, 3), "higher_is_better": False,
+                      "dtype": args.dtype, "data": "synthetic", "vs_baseline": None,
+                      "config": {"workload": f"CtcModel.recognize over {B} x {secs:.0f} s utterances incl. log-mel + encoder (random weights)",
+                                 "global_batch": B, "beam_search_width10_rtf": round(res["beam10"] / (B * secs), 6),
+                                 "beam_search_ms": round(res["beam10"] * 1e3, 2)}}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -208,7 +242,8 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--padding", default="batch", choices=["batch", "reference"])
     ap.add_argument("--workload", default=None, help="'S-10s' = BASELINE cfg2 (10 s utterances); default LibriSpeech-shaped")
-    ap.add_argument("--mode", default="train", choices=["train", "decode"], help="decode = greedy-search RTF (second half of BASELINE.json's metric)")
+    ap.add_argument("--mode", default="train", choices=["train", "decode", "ctc-decode"],
+                    help="decode = transducer greedy-search RTF (second half of BASELINE.json's metric); ctc-decode = Conformer-CTC greedy / beam RTF")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-specaugment", action="store_true")
     ap.add_argument("--dropout", type=float, default=None, help="override encoder dropout (default: reference value 0.1)")
@@ -235,6 +270,8 @@ def main():
     if args.dropout is not None:
         cfg.dropout = args.dropout
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    if args.mode == "ctc-decode":
+        return bench_ctc_decode(args, dev, dtype)
     if args.model == "contextnet":
         from tensorflowasr_amd.contextnet import ContextNetTransducer
 

@@ -352,8 +352,9 @@ def encoder(feat, lengths, W, cfg, training=True, use_mask=True, stats=None):
     B, T, d = x.shape
     pe, _ = relative_position_encoding(T, d, ln.tolist(), interleave=True)
     pe = pe.to(x.dtype)
-    u, v = W["enc/u"], W["enc/v"]
     for i in range(cfg["num_blocks"]):
+        # shared encoder-level biases (encoders/conformer.py:647-663) or the layer's own pair (multihead_attention.py:522-538)
+        u, v = (W[f"enc/block{i}/mhsa/u"], W[f"enc/block{i}/mhsa/v"]) if cfg.get("mhsam_use_attention_bias") else (W["enc/u"], W["enc/v"])
         x = conformer_block(x, pe, W, f"enc/block{i}/", cfg, ln, u, v, training, use_mask, stats)
     return x, ln
 
@@ -406,6 +407,12 @@ def transducer_forward(features, feat_len, predictions, pred_len, W, cfg, traini
     return joint_net(enc, pred, W), ln
 
 
+def ctc_forward(features, feat_len, W, cfg, training=True, use_mask=True, stats=None):
+    """CtcModel.call after the frontend (models/ctc/base_ctc.py:74-81): encoder -> ConformerDecoder Dense -> logits [B,T',V]."""
+    enc, ln = encoder(features[..., None], feat_len, W, cfg, training, use_mask, stats)
+    return enc @ W["dec/logits/w"] + W["dec/logits/b"], ln
+
+
 def l2_regularization(W, l2=1e-6):
     """Sum of keras l2 regularizers: kernels, LN/BN gamma+beta, embedding (conformer.py:63-68 etc.; biases and the
     shared u/v attention biases use bias_regularizer=None)."""
@@ -423,7 +430,7 @@ def is_regularized(name):
     and the shared u/v biases (bias_regularizer=None) do not."""
     parts = name.split("/")
     leaf, parent = parts[-1], parts[-2] if len(parts) > 1 else ""
-    if leaf in ("mm", "mv") or name in ("enc/u", "enc/v"):
+    if leaf in ("mm", "mv") or name in ("enc/u", "enc/v") or (parent == "mhsa" and leaf in ("u", "v")):
         return False
     if leaf == "w" or name in ("pred/emb", "pred/lstm/k"):
         return True
@@ -450,7 +457,8 @@ def param_shapes(cfg):
     s["enc/sub/conv1/w"] = (3, 3, C, C); s["enc/sub/conv1/b"] = (C,)
     s["enc/sub/bn1/g"] = (C,); s["enc/sub/bn1/b"] = (C,); s["enc/sub/bn1/mm"] = (C,); s["enc/sub/bn1/mv"] = (C,)
     s["enc/linear/w"] = (F2 * C, d); s["enc/linear/b"] = (d,)
-    s["enc/u"] = (H, dh); s["enc/v"] = (H, dh)
+    if not cfg.get("mhsam_use_attention_bias"):
+        s["enc/u"] = (H, dh); s["enc/v"] = (H, dh)
     for i in range(cfg["num_blocks"]):
         p = f"enc/block{i}/"
         for ff in ("ff1/", "ff2/"):
@@ -462,6 +470,8 @@ def param_shapes(cfg):
         for nm in ("q", "k", "v", "pos"):
             s[m + nm + "/w"] = (d, H, dh); s[m + nm + "/b"] = (H, dh)
         s[m + "o/w"] = (H, dh, d); s[m + "o/b"] = (d,)
+        if cfg.get("mhsam_use_attention_bias"):
+            s[m + "u"] = (H, dh); s[m + "v"] = (H, dh)
         c = p + "conv/"
         s[c + "ln/g"] = (d,); s[c + "ln/b"] = (d,)
         s[c + "pw1/w"] = (d, 2 * d); s[c + "pw1/b"] = (2 * d,)
@@ -469,6 +479,9 @@ def param_shapes(cfg):
         s[c + "bn/g"] = (d,); s[c + "bn/b"] = (d,); s[c + "bn/mm"] = (d,); s[c + "bn/mv"] = (d,)
         s[c + "pw2/w"] = (d, d); s[c + "pw2/b"] = (d,)
         s[p + "ln/g"] = (d,); s[p + "ln/b"] = (d,)
+    if cfg.get("head") == "ctc":  # ConformerDecoder: Dense(vocab_size) named "logits" (models/ctc/conformer.py:21-47)
+        s["dec/logits/w"] = (d, V); s["dec/logits/b"] = (V,)
+        return s
     s["pred/emb"] = (V, E)
     s["pred/lstm/k"] = (E, 4 * P); s["pred/lstm/rk"] = (P, 4 * P); s["pred/lstm/b"] = (4 * P,)
     s["pred/ln/g"] = (P,); s["pred/ln/b"] = (P,)

@@ -43,6 +43,11 @@ class ConformerConfig:
     chunk_size: int = None
     history_size: int = None
     convm_dw_norm: str = "batch"
+    # encoder_mhsam_use_attention_bias: True (examples/models/ctc/conformer/small.yml.j2:45): per-layer content / positional
+    # attention biases (multihead_attention.py:522-538) instead of the encoder-level shared pair (encoders/conformer.py:647-663)
+    mhsam_use_attention_bias: bool = False
+    # model head: "transducer" (prediction + joint networks) or "ctc" (models/ctc/conformer.py:21-47: one Dense(vocab) decoder)
+    head: str = "transducer"
     # prediction / joint
     embed_dim: int = 320
     rnn_units: int = 320
@@ -74,8 +79,9 @@ class ConformerConfig:
         return 4
 
     @classmethod
-    def from_reference(cls, config: dict):
-        """Map the reference's Conformer kwargs (models/transducer/conformer.py:23-79) onto this dataclass."""
+    def from_reference(cls, config: dict, class_name: str = None):
+        """Map the reference's Conformer kwargs (models/transducer/conformer.py:23-79; models/ctc/conformer.py:57-100 when
+        `class_name` is the YAML's "tensorflow_asr.models.ctc.conformer>Conformer") onto this dataclass."""
         c = dict(config)
         sc = dict(c.get("speech_config", {}))
         aug = (sc.get("augmentation_config") or {}).get("feature_augment", {}) or {}
@@ -85,7 +91,6 @@ class ConformerConfig:
             "prediction_num_rnns": (1,), "joint_activation": ("tanh",), "joint_mode": ("add",),
             "encoder_convm_dw_norm_type": ("batch", "layer"), "prediction_label_encode_mode": ("embedding",),
             "encoder_memory_length": (None,), "encoder_use_attention_causal_mask": (False,),
-            "encoder_mhsam_use_attention_bias": (False,),
         }
         for k, ok in unsupported.items():
             if k in c and c[k] not in ok:
@@ -106,7 +111,10 @@ class ConformerConfig:
             embed_dim=c.get("prediction_embed_dim", 512), rnn_units=c.get("prediction_rnn_units", 320),
             joint_dim=c.get("joint_dim", 1024), vocab_size=int(c.get("vocab_size", 1000)), blank=c.get("blank", 0), l2=l2,
             chunk_size=c.get("encoder_chunk_size"), history_size=c.get("encoder_history_size"),
-            convm_dw_norm=c.get("encoder_convm_dw_norm_type", "batch"))
+            convm_dw_norm=c.get("encoder_convm_dw_norm_type", "batch"),
+            mhsam_use_attention_bias=bool(c.get("encoder_mhsam_use_attention_bias", False)))
+        if class_name and ".ctc." in class_name:
+            kw["head"] = "ctc"
         if (kw["chunk_size"] is None) != (kw["history_size"] is None):  # multihead_attention.py:339 needs both
             kw["chunk_size"] = kw["history_size"] = None
         if "time_masking" in aug:
@@ -114,6 +122,13 @@ class ConformerConfig:
         if "freq_masking" in aug:
             kw["freq_masking"] = dict(aug["freq_masking"])
         return cls(**kw)
+
+
+def conformer_ctc_s(vocab_size=1000, **over):
+    """examples/models/ctc/conformer/small.yml.j2:26-46: d=176, 4 heads of 44, per-layer attention biases, Dense(vocab) decoder."""
+    kw = dict(filters=176, dmodel=176, head_size=44, num_heads=4, mhsam_use_attention_bias=True, head="ctc", vocab_size=vocab_size)
+    kw.update(over)
+    return ConformerConfig(**kw)
 
 
 def conformer_s(vocab_size=1000, **over):

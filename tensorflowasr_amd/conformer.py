@@ -75,6 +75,7 @@ class ConformerTransducer:
         self.native_blocks = os.environ.get("TFASR_NATIVE_BLOCK", "1") != "0"
         self._blk_params, self._blk_sizes = {}, {}
         self._zero_pool = {}
+        self._after_encoder = "pred/emb" if cfg.head == "transducer" else "dec/logits/w"  # first regularised variable after the encoder
         self.timers = None  # optional dict name -> list[(start_event, end_event)] filled by bench.py
         self.timer_work = {}
         self.time_sections = False  # per-module section timers (bench.py TFASR_BENCH_SECTIONS) need the per-kernel Python path
@@ -290,13 +291,20 @@ class ConformerTransducer:
         pe = self._pe_ext(T)
         pext = K.matmul(pe, ps.w2d(pfx + "pos/w"), bias=ps.p(pfx + "pos/b"))  # [2T, HD]
         drop = self._drop(site, training)
-        att, saved = self.attention_core(qkv, pext, B, T, elen_dev)
+        att, saved = self.attention_core(qkv, pext, B, T, elen_dev, pfx)
         y = K.matmul(att, ps.w2d(pfx + "o/w"), bias=ps.p(pfx + "o/b"), res=x, beta=c.mhsam_residual, drop_p=drop[0], drop_seed=drop[1])
         if ctx is not None:
             ctx[pfx] = dict(x=x, ln=ln, mean=mean, rstd=rstd, qkv=qkv, pext=pext, att=att, drop=drop, **saved)
         return y
 
-    def attention_core(self, qkv, pext, B, T, elen_dev):
+    def _uv(self, pfx, grad=False):
+        """content / positional attention biases of the attention layer `pfx` (shared pair or per-layer, see configs)."""
+        get = self.ps.g if grad else self.ps.p
+        if self.cfg.mhsam_use_attention_bias:
+            return get(pfx + "u"), get(pfx + "v")
+        return get("enc/u"), get("enc/v")
+
+    def attention_core(self, qkv, pext, B, T, elen_dev, pfx=None):
         """MultiHeadRelativeAttention._compute_attention (multihead_attention.py:543-582) on the fused projection output
         qkv [B*T, 3*H*dh] and the projected position table pext [2T, H*dh] (rows 0..2T-2 = positions T-1..-(T-1), row 2T-1 = the
         projection of a zeroed encoding row).  Returns (context [B*T, H*dh], tensors the backward needs)."""
@@ -305,12 +313,13 @@ class ConformerTransducer:
         HD = H * dh
         R1 = 2 * T
         scale = 1.0 / math.sqrt(dh)
+        ub, vb = self._uv(pfx) if pfx is not None else (ps.p("enc/u"), ps.p("enc/v"))
         if self._fused_attention():
             # flash-style kernel: scores, shift, mask, softmax and P@V never leave the CU (csrc/attn_fused.hip)
-            att, lse = K.relattn_fused_fwd(qkv, ps.p("enc/u"), ps.p("enc/v"), pext, elen_dev, B, H, T, dh, scale,
+            att, lse = K.relattn_fused_fwd(qkv, ub, vb, pext, elen_dev, B, H, T, dh, scale,
                                            use_mask=c.use_attention_auto_mask)
             return att, dict(lse=lse)
-        qu, qv = K.bias2_fwd(qkv, 3 * HD, ps.p("enc/u"), ps.p("enc/v"), B * T, HD)
+        qu, qv = K.bias2_fwd(qkv, 3 * HD, ub, vb, B * T, HD)
         kk = qkv[:, HD:]
         vv = qkv[:, 2 * HD:]
         Tp, R1p = -(-T // 8) * 8, -(-R1 // 8) * 8  # row strides padded to 16 B so the score matrices can be LDS-DMA'd
@@ -334,14 +343,15 @@ class ConformerTransducer:
         scale = 1.0 / math.sqrt(dh)
         s = ctx.pop(pfx)
         qkv = s["qkv"]
+        ub, vb = self._uv(pfx)
         datt = self._dense_bwd(self._mask_grad(dy, s["drop"]), s["att"], pfx + "o/w", pfx + "o/b", alpha=c.mhsam_residual)
         dqkv = torch.empty_like(qkv)
         if "lse" in s:
             R1p = -(-R1 // 8) * 8
             um = c.use_attention_auto_mask
-            dqu, dpos, dvec = K.relattn_fused_bwd_q(qkv, ps.p("enc/u"), ps.p("enc/v"), s["pext"], elen_dev, s["att"], datt, s["lse"], B, H, T, dh,
+            dqu, dpos, dvec = K.relattn_fused_bwd_q(qkv, ub, vb, s["pext"], elen_dev, s["att"], datt, s["lse"], B, H, T, dh,
                                                     R1p, scale, use_mask=um)
-            qu, qv = K.bias2_fwd(qkv, 3 * HD, ps.p("enc/u"), ps.p("enc/v"), B * T, HD)
+            qu, qv = K.bias2_fwd(qkv, 3 * HD, ub, vb, B * T, HD)
             K.relattn_fused_bwd_k(qkv, qu, qv, s["pext"], elen_dev, datt, s["lse"], dvec, dqkv, B, H, T, dh, scale, use_mask=um)
             return self._mhsa_bwd_tail(dy, pfx, B, T, s, dqkv, dqu, dpos, qv, R1p, 1.0)
         probs = s["probs"]
@@ -381,7 +391,8 @@ class ConformerTransducer:
         dpext = torch.zeros(R1, HD, dtype=torch.float32, device=self.device)
         K.gemm(dpos, qv, dpext, R1, dh, T, R1p, HD, HD, trans_a=True, nb1=B, nb2=H, sA=(H * T * R1p, T * R1p), sB=(T * HD, dh),
                sD=(0, dh), alpha=scale, accumulate=True)
-        K.bias2_bwd(dqu, dqv, dqkv, 3 * HD, ps.g("enc/u"), ps.g("enc/v"), B * T, HD)
+        gu, gv = self._uv(pfx, grad=True)
+        K.bias2_bwd(dqu, dqv, dqkv, 3 * HD, gu, gv, B * T, HD)
         # positional projection: gWpos += pe^T dpext ; gbpos += colsum(dpext)
         dpext_t = dpext if self.dtype == torch.float32 else K.cast(dpext, torch.empty(R1, HD, dtype=self.dtype, device=self.device))
         pe = self._pe_ext(T)
@@ -494,6 +505,8 @@ class ConformerTransducer:
             P.flat, P.shadow, P.grad = ps.flat.data_ptr(), ps.shadow.data_ptr(), ps.grad.data_ptr()
             P.bn_mm, P.bn_mv = ps.state[f"enc/block{i}/conv/bn/mm"].data_ptr(), ps.state[f"enc/block{i}/conv/bn/mv"].data_ptr()
             for j, nm in enumerate(K._lib.BLOCK_PARAM_NAMES):
+                if nm.startswith("/") and self.cfg.mhsam_use_attention_bias:  # "/enc/u" -> this layer's own bias
+                    nm = "mhsa/" + nm.rsplit("/", 1)[1]
                 P.off[j] = ps.offsets[nm[1:] if nm.startswith("/") else f"enc/block{i}/{nm}"]
             P.pe = self._pe_ext(T).data_ptr()
             self._blk_params[(i, T)] = P
@@ -601,7 +614,7 @@ class ConformerTransducer:
 
     def _bucket_after_block(self, i):
         lo = self.ps.offsets[f"enc/block{i}/ff1/ln/g"]
-        hi = self.ps.offsets[f"enc/block{i + 1}/ff1/ln/g"] if i + 1 < self.cfg.num_blocks else self.ps.offsets["pred/emb"]
+        hi = self.ps.offsets[f"enc/block{i + 1}/ff1/ln/g"] if i + 1 < self.cfg.num_blocks else self.ps.offsets[self._after_encoder]
         self.dp.grads_ready(lo, hi)
 
     # =================================================================================== prediction network

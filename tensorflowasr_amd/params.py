@@ -42,8 +42,10 @@ def param_specs(cfg):
     add("enc/sub/bn1/g", (C,), True, "ones")
     add("enc/linear/w", (F2 * C, d), True, "glorot")
     add("enc/linear/b", (d,), False, "zeros")
-    add("enc/u", (HD,), False, "zeros")
-    add("enc/v", (HD,), False, "zeros")
+    per_layer_bias = bool(getattr(cfg, "mhsam_use_attention_bias", False))
+    if not per_layer_bias:
+        add("enc/u", (HD,), False, "zeros")
+        add("enc/v", (HD,), False, "zeros")
     for i in range(cfg.num_blocks):
         p = f"enc/block{i}/"
         for ff in ("ff1/", "ff2/"):
@@ -56,6 +58,8 @@ def param_specs(cfg):
                 add(m + "qkv/w", (d, 3 * HD), True, "glorot", (H * d, dh * d)); add(m + "qkv/b", (3 * HD,), False, "zeros")
                 add(m + "pos/w", (d, HD), True, "glorot", (H * d, dh * d)); add(m + "pos/b", (HD,), False, "zeros")
                 add(m + "o/w", (HD, d), True, "glorot", (dh * H, d * H)); add(m + "o/b", (d,), False, "zeros")
+                if per_layer_bias:  # multihead_attention.py:522-538 (bias_regularizer: not regularised)
+                    add(m + "u", (HD,), False, "zeros"); add(m + "v", (HD,), False, "zeros")
                 c = p + "conv/"
                 add(c + "ln/g", (d,), True, "ones"); add(c + "ln/b", (d,), True, "zeros")
                 add(c + "pw1/w", (d, 2 * d), True, "glorot"); add(c + "pw1/b", (2 * d,), False, "zeros")
@@ -69,6 +73,9 @@ def param_specs(cfg):
 def _tail_specs(cfg, add, s):
     """prediction + joint networks (shared by every encoder family)"""
     d, V, E, P, J = cfg.dmodel, cfg.vocab_size, cfg.embed_dim, cfg.rnn_units, cfg.joint_dim
+    if getattr(cfg, "head", "transducer") == "ctc":  # ConformerDecoder (models/ctc/conformer.py:21-47): Dense(vocab_size) "logits"
+        add("dec/logits/w", (d, V), True, "glorot"); add("dec/logits/b", (V,), False, "zeros")
+        return s
     add("pred/emb", (V, E), True, "embed")
     add("pred/lstm/k", (E, 4 * P), True, "glorot")
     add("pred/lstm/rk", (P, 4 * P), False, "orth")
@@ -265,7 +272,7 @@ class ParamStore:
                     out[base + k + "/b"] = t[i * H * dh:(i + 1) * H * dh].reshape(H, dh).clone()
             elif name.endswith("pos/w"):
                 out[name] = t.reshape(d, H, dh).clone()
-            elif name.endswith("pos/b") or name in ("enc/u", "enc/v"):
+            elif name.endswith("pos/b") or name in ("enc/u", "enc/v") or name.endswith("mhsa/u") or name.endswith("mhsa/v"):
                 out[name] = t.reshape(H, dh).clone()
             elif name.endswith("mhsa/o/w"):
                 out[name] = t.reshape(H, dh, d).clone()

@@ -42,6 +42,26 @@ def test_small_streaming_yml_maps_onto_config():
     assert (cfg.dmodel, cfg.head_size, cfg.num_blocks, cfg.kernel_size) == (144, 36, 16, 31)
 
 
+@pytest.mark.skipif(not os.path.exists(REF), reason="reference tree not present")
+def test_ctc_conformer_yml_maps_onto_config():
+    """examples/models/ctc/conformer/small.yml.j2: d=176 / head 44, per-layer attention biases, Dense(vocab) decoder."""
+    import jinja2
+    import yaml
+
+    path = "/root/reference/examples/models/ctc/conformer/small.yml.j2"
+    txt = jinja2.Template(open(path).read()).render(decoder_config={"vocabsize": 1000}, modeldir="/tmp/m", kaggle_model_handle="x")
+    mc = yaml.safe_load(txt)["model_config"]
+    cfg = configs.ConformerConfig.from_reference(mc["config"], class_name=mc["class_name"])
+    ref = configs.conformer_ctc_s()
+    for k in ("head", "dmodel", "head_size", "num_heads", "num_blocks", "filters", "mhsam_use_attention_bias", "kernel_size", "vocab_size"):
+        assert getattr(cfg, k) == getattr(ref, k), k
+    assert cfg.freq_masking["num_masks"] == 2 and cfg.freq_masking["prob"] == 0.5
+    from tensorflowasr_amd import params
+
+    names = [n for n, *_ in params.param_specs(cfg)]
+    assert "dec/logits/w" in names and "enc/block3/mhsa/u" in names and "enc/u" not in names and "pred/emb" not in names
+
+
 def test_unsupported_options_fail_loudly():
     with pytest.raises(NotImplementedError):
         configs.ConformerConfig.from_reference({"encoder_mha_type": "mha", "vocab_size": 10})
