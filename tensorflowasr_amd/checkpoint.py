@@ -130,3 +130,169 @@ def load_weights(model, filepath, strict=True):
     merged = {k: (torch.from_numpy(np.ascontiguousarray(got[k])) if k in got else v) for k, v in template.items()}
     model.ps.import_keras(merged)
     return sorted(got)
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# Keras 3 `.weights.h5` containers (base_model.py:55-61 -> keras.Model.save_weights -> saving_lib.H5IOStore), read with the
+# pure-Python reader h5lite (h5py is not installable in the product image).
+#
+# keras stores every layer's variables as datasets `<object path>/vars/<i>` (i = position in layer.weights: Dense kernel, bias;
+# BatchNormalization gamma, beta, moving_mean, moving_variance; LSTM cell kernel, recurrent_kernel, bias; ...) where the object
+# path is built by walking the model's ATTRIBUTES (saving_lib._walk_saveable: `encoder`, `conformer_blocks`, `ffm1`, `ffn1`,
+# `_query_dense` ...), list members being named after their class (`conformer_block`, `conformer_block_1`, ...).  No Keras
+# installation exists here to confirm the exact spelling of those paths for tensorflow_asr's models ("parity unpinned"), so the
+# loader does not hard-code full paths: each model variable is located by an ordered list of anchor tokens, every anchor with the
+# attribute-name AND the layer-name spelling, plus the variable's position and its Keras shape; a variable must match exactly one
+# dataset or the load fails loudly with the candidates listed.
+# ------------------------------------------------------------------------------------------------------------------------
+_H5_MODULE_TOKENS = ("ffm1", "ffm2", "mhsam", "convm", "ff_module_1", "ff_module_2", "mhsa_module", "conv_module")
+
+
+def _blk(i):
+    return (f"conformer_block_{i}" if i else "conformer_block", f"block_{i}")
+
+
+def h5_anchors(name):
+    """(anchor groups, variable index, forbidden tokens) of one ParamStore.export_keras() name."""
+    idx = {"w": 0, "b": 1, "g": 0, "mm": 2, "mv": 3}
+    m = _SUB.match(name)
+    if m:
+        kind, i, leaf = m.group(1), int(m.group(2)), m.group(3)
+        seq = ("sequential" if i == 0 else f"sequential_{i}", f"block_{i}")
+        if kind == "conv":
+            return [("conv_subsampling", "subsampling"), seq, ("conv2d", f"conv_{i}", "conv2d_" + str(i))], idx[leaf], ()
+        return [("conv_subsampling", "subsampling"), seq, ("batch_normalization", f"bn_{i}")], {"g": 0, "b": 1, "mm": 2, "mv": 3}[leaf], ()
+    if name in ("enc/linear/w", "enc/linear/b"):
+        return [("linear",)], idx[name[-1]], ("conv_subsampling", "subsampling") + _H5_MODULE_TOKENS
+    if name in ("enc/u", "enc/v"):
+        return [("encoder", "conformer_encoder")], 0 if name.endswith("u") else 1, ("<own>",)
+    m = _BLOCK.match(name)
+    if m:
+        i, rest = int(m.group(1)), m.group(2)
+        a = [_blk(i)]
+        if rest in ("ln/g", "ln/b"):
+            return a + [("post_norm", "ln")], 0 if rest.endswith("g") else 1, _H5_MODULE_TOKENS
+        mod, sub = rest.split("/", 1)
+        a.append({"ff1": ("ffm1", "ff_module_1"), "ff2": ("ffm2", "ff_module_2"), "mhsa": ("mhsam", "mhsa_module"), "conv": ("convm", "conv_module")}[mod])
+        layer, leaf = sub.rsplit("/", 1) if "/" in sub else (sub, None)
+        if leaf is None:  # per-layer attention biases: the attention layer's own variables come after nothing else of its own
+            return a + [("mha", "mhsa")], 0 if layer == "u" else 1, ("<own>",)
+        table = {
+            "ln": ("pre_norm", "ln"), "d1": ("ffn1", "dense_1"), "d2": ("ffn2", "dense_2"),
+            "q": ("_query_dense", "query"), "k": ("_key_dense", "key"), "v": ("_value_dense", "value"), "pos": ("_relpe_dense", "encoding"),
+            "o": ("_output_dense", "attention_output"), "pw1": ("pw_conv_1",), "dw": ("dw_conv",), "bn": ("dw_norm", "dw_bn", "dw_ln"), "pw2": ("pw_conv_2",),
+        }
+        vi = {"g": 0, "b": 1, "mm": 2, "mv": 3}[leaf] if layer in ("ln", "bn") else idx[leaf]
+        forb = ("post_norm",) if layer == "ln" else ()
+        return a + [table[layer]], vi, forb
+    tail = {
+        "pred/emb": ([("predict_net", "transducer_prediction", "prediction"), ("label_encoder", "embedding")], 0),
+        "pred/lstm/k": ([("predict_net", "transducer_prediction", "prediction"), ("rnns", "lstm", "lstm_0")], 0),
+        "pred/lstm/rk": ([("predict_net", "transducer_prediction", "prediction"), ("rnns", "lstm", "lstm_0")], 1),
+        "pred/lstm/b": ([("predict_net", "transducer_prediction", "prediction"), ("rnns", "lstm", "lstm_0")], 2),
+        "pred/ln/g": ([("predict_net", "transducer_prediction", "prediction"), ("lns", "layer_normalization", "ln_0")], 0),
+        "pred/ln/b": ([("predict_net", "transducer_prediction", "prediction"), ("lns", "layer_normalization", "ln_0")], 1),
+        "joint/enc/w": ([("joint_net", "transducer_joint", "joint"), ("ffn_enc", "enc")], 0), "joint/enc/b": ([("joint_net", "transducer_joint", "joint"), ("ffn_enc", "enc")], 1),
+        "joint/pred/w": ([("joint_net", "transducer_joint", "joint"), ("ffn_pred", "pred")], 0), "joint/pred/b": ([("joint_net", "transducer_joint", "joint"), ("ffn_pred", "pred")], 1),
+        "joint/vocab/w": ([("joint_net", "transducer_joint", "joint"), ("ffn_out", "vocab")], 0), "joint/vocab/b": ([("joint_net", "transducer_joint", "joint"), ("ffn_out", "vocab")], 1),
+        "dec/logits/w": ([("decoder", "conformer_decoder"), ("vocab", "logits")], 0), "dec/logits/b": ([("decoder", "conformer_decoder"), ("vocab", "logits")], 1),
+    }
+    if name in tail:
+        return tail[name][0], tail[name][1], ()
+    raise KeyError(f"no .weights.h5 anchors are known for {name!r}")
+
+
+def _h5_match(tokens, anchors, vindex, forbidden):
+    if len(tokens) < 2 or tokens[-2] != "vars" or tokens[-1] != str(vindex):
+        return False
+    body = tokens[:-2]
+    if any(t in forbidden for t in body):
+        return False
+    if "<own>" in forbidden and (not body or body[-1] not in anchors[-1]):  # the anchor layer's OWN variables: .../<layer>/vars/i
+        return False
+    pos = 0
+    for alts in anchors:
+        hit = next((k for k in range(pos, len(body)) if body[k] in alts), None)
+        if hit is None:
+            return False
+        pos = hit + 1
+    return True
+
+
+def from_weights_h5(datasets, template):
+    """{h5 dataset path: ndarray} (h5lite.H5File.datasets()) -> dict in the layout of `template` (ParamStore.export_keras())."""
+    toks = {p: p.split("/") for p in datasets}
+    out, used = {}, set()
+    for name, t in template.items():
+        anchors, vi, forb = h5_anchors(name)
+        shp = tuple(_to_keras_layout(name, np.zeros(tuple(t.shape), np.float32)).shape)
+        cands = [p for p, tk in toks.items() if _h5_match(tk, anchors, vi, forb) and tuple(datasets[p].shape) in (shp, tuple(t.shape))]
+        if len(cands) != 1:
+            raise KeyError(f"{name} (Keras shape {shp}): expected exactly one dataset matching anchors {anchors} / vars/{vi}, found {sorted(cands)[:6]}")
+        out[name] = _from_keras_layout(name, datasets[cands[0]], tuple(t.shape))
+        used.add(cands[0])
+    return out, sorted(set(datasets) - used)
+
+
+def load_weights_h5(model, filepath, strict=True):
+    """BaseModel.load_weights (base_model.py:59-61) for a Keras 3 `.weights.h5` file.  strict: every float dataset of the file
+    outside `optimizer/` must have been consumed (so a silently ignored layer cannot go unnoticed)."""
+    import torch
+
+    from .h5lite import H5File
+
+    with H5File(filepath) as f:
+        datasets = f.datasets()
+    template = model.ps.export_keras()
+    got, unused = from_weights_h5(datasets, template)
+    left = [p for p in unused if not p.startswith("optimizer") and datasets[p].dtype.kind == "f" and datasets[p].size > 1]
+    if strict and left:
+        raise KeyError(f"{filepath}: {len(left)} weight datasets were not mapped onto the model, e.g. {left[:5]}")
+    model.ps.import_keras({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in got.items()})
+    return sorted(got)
+
+
+def keras3_h5_path(name, cfg=None):
+    """The attribute-walk path keras' saving_lib is expected to give the variable `name` (used to WRITE test fixtures; see the
+    caveat above: unconfirmed against a Keras-written file)."""
+    anchors, vi, _ = h5_anchors(name)
+    first = [a[0] for a in anchors]
+    extra = {"rnns": ["rnns", "lstm", "cell"], "lns": ["lns", "layer_normalization"], "conv2d": ["layers", "conv2d"],
+             "batch_normalization": ["layers", "batch_normalization"], "conv_subsampling": ["conv_subsampling", "convs"]}
+    first = [t for tok in first for t in extra.get(tok, [tok])]
+    if any(tok.startswith("_") and tok.endswith("_dense") for tok in first):
+        first.insert(len(first) - 1, "mha")
+    m = _BLOCK.match(name)
+    if m or name.startswith("enc/"):
+        if first[0] != "encoder":
+            first = ["encoder"] + (["conformer_blocks"] if m else []) + first
+    return "/".join(first + ["vars", str(vi)])
+
+
+def save_state(model, filepath):
+    """Everything a resumed run needs beyond the weights: the flat f32 parameters, Adam first / second moments, the
+    optimizer step (= position in the learning-rate schedule), the dropout epoch and the BatchNorm moving statistics."""
+    ps = model.ps
+    arrays = {"flat": ps.flat.cpu().numpy(), "adam_m": ps.adam_m.cpu().numpy(), "adam_v": ps.adam_v.cpu().numpy(),
+              "step": np.asarray(model.step, np.int64), "drop_epoch": np.asarray(model._drop_epoch, np.int64),
+              "ga_count": np.asarray(model._ga_count, np.int64), "names": np.asarray(ps.names), "n": np.asarray(ps.n, np.int64)}
+    for k, v in ps.state.items():
+        arrays["state|" + k.replace("/", "|")] = v.cpu().numpy()
+    with open(filepath, "wb") as f:
+        np.savez(f, **arrays)
+
+
+def load_state(model, filepath):
+    import torch
+
+    ps = model.ps
+    with np.load(filepath) as z:
+        if int(z["n"]) != ps.n or list(z["names"]) != list(ps.names):
+            raise ValueError(f"{filepath} was written by a different model configuration")
+        ps.flat.copy_(torch.from_numpy(z["flat"]))
+        ps.adam_m.copy_(torch.from_numpy(z["adam_m"]))
+        ps.adam_v.copy_(torch.from_numpy(z["adam_v"]))
+        model.step, model._drop_epoch, model._ga_count = int(z["step"]), int(z["drop_epoch"]), int(z["ga_count"])
+        for k in ps.state:
+            ps.state[k].copy_(torch.from_numpy(z["state|" + k.replace("/", "|")]))
+    ps.refresh_shadow()
