@@ -65,6 +65,16 @@ int tfasr_rnnt_loss(const void* logits, void* grads, const int32_t* labels, cons
  * [total_cells, V], laid out row-major (t, u) with (label_len[b]+1) columns and logit_len[b] rows; cell_off [B+1] int64
  * on the device.  Same loss/gradient as the dense entry (padded nodes carry zero gradient there, impl/rnnt.py:218-224),
  * at sum_b T_b*U1_b instead of B*T*U1 rows.  Workspace: tfasr_rnnt_loss_workspace_size(1, total_cells, 1, V). */
+/* The vocabulary id each lattice row's label transition emits (labels[b, u] for u < label_len[b], else -1), for the GEMM
+   epilogue's `row_label`; rows follow the packed (cell_off != NULL) or dense [B,T,U1] lattice order. */
+int tfasr_rnnt_row_labels(const int32_t* labels, const int32_t* label_len, const int32_t* logit_len, const long* cell_off,
+                          long total_cells, int B, int T, int U1, int V, int32_t* row_label, void* stream);
+/* tfasr_rnnt_loss_packed whose log-softmax statistics were already produced by the projection GEMM's epilogue (tfasr_gemm_args
+   lse_part / pick): the first pass over the logits (max / sum-exp / blank and label gathers) is skipped. */
+int tfasr_rnnt_loss_packed_stats(const void* logits, void* grads, const int32_t* labels, const int32_t* label_len,
+                                 const int32_t* logit_len, const float* grad_scale, const long* cell_off, long total_cells,
+                                 const float* lse_part, int lse_parts, const float* pick, int B, int T, int U1, int V, int blank,
+                                 int dtype, float* costs, void* workspace, size_t workspace_bytes, void* stream);
 int tfasr_rnnt_loss_packed(const void* logits, void* grads, const int32_t* labels, const int32_t* label_len,
                            const int32_t* logit_len, const float* grad_scale, const long* cell_off, long total_cells, int B,
                            int T, int U1, int V, int blank, int dtype, float* costs, void* workspace,
@@ -128,6 +138,12 @@ typedef struct {
   float* colsum;           /* optional [N] f32, only with accumulate != 0, trans_a == 1, trans_b == 0, nb1*nb2 == 1 (a Dense layer's
                             * weight gradient x^T dy): colsum[n] += alpha * sum_k B[k, n], i.e. the BIAS gradient, produced by the
                             * same launch (one extra all-ones MFMA row in the first row of tiles) instead of a second pass over dy */
+  /* Optional log-softmax statistics of the OUTPUT rows, produced by the epilogue from the f32 accumulators (the joint's vocabulary
+     projection feeding the RNN-T loss: base_transducer.py:291 -> impl/rnnt.py:211): per row m and per 64-column slice c of the
+     row, lse_part[(m*lse_parts + c)*2 + {0,1}] = (max, sum exp(x - max)) over that slice; pick[2m] = x[m,0] (blank logit),
+     pick[2m+1] = x[m, row_label[m]] (label logit; untouched when row_label[m] < 0).  lse_parts must be ceil(N/128)*2.
+     Only the bf16 fast path (plain NN product + bias, 128-wide tiles) implements it: otherwise tfasr_gemm returns UNSUPPORTED. */
+  float* lse_part; int lse_parts; const int32_t* row_label; float* pick;
 } tfasr_gemm_args;
 
 int tfasr_gemm(const tfasr_gemm_args* args, void* stream);

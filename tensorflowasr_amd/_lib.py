@@ -31,6 +31,7 @@ class GemmArgs(Structure):
         ("act", c_int), ("dact", c_int), ("dtype", c_int), ("out_f32", c_int), ("accumulate", c_int), ("split_k", c_int),
         ("drop_p", c_float), ("drop_seed", c_long),
         ("ws", c_void_p), ("ws_elems", c_long), ("colsum", c_void_p),
+        ("lse_part", c_void_p), ("lse_parts", c_int), ("row_label", c_void_p), ("pick", c_void_p),
     ]
 
 
@@ -148,6 +149,13 @@ def load(build_if_missing=True):
 
 
 ABI_VERSION = 14
+
+
+STATUS_UNSUPPORTED = 3
+
+
+class TfasrUnsupported(TfasrError):
+    pass
 
 
 def check(status, what=""):

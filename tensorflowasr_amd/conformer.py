@@ -75,6 +75,7 @@ class ConformerTransducer:
         self.native_blocks = os.environ.get("TFASR_NATIVE_BLOCK", "1") != "0"
         self._blk_params, self._blk_sizes = {}, {}
         self._zero_pool = {}
+        self.fuse_joint_stats = os.environ.get("TFASR_JOINT_STATS", "1") != "0"
         self._after_encoder = "pred/emb" if cfg.head == "transducer" else "dec/logits/w"  # first regularised variable after the encoder
         self.timers = None  # optional dict name -> list[(start_event, end_event)] filled by bench.py
         self.timer_work = {}
@@ -774,13 +775,32 @@ class ConformerTransducer:
             e = K.matmul(enc, ps.w2d("joint/enc/w"), bias=ps.p("joint/enc/b"))
             p = K.matmul(pred, ps.w2d("joint/pred/w"), bias=ps.p("joint/pred/b"))
             h = K.joint_fwd_packed(e.view(B, T, J), p.view(B, U1, J), off_dev, ul_dev, total)
-            t0 = self._tick("joint_vocab_gemm")
-            logits = K.matmul(h, ps.w2d("joint/vocab/w"), bias=ps.p("joint/vocab/b"))  # [total, V]
-            self._tock("joint_vocab_gemm", t0, 2.0 * total * J * V)
+            # The vocabulary projection's epilogue also emits the log-softmax statistics of every lattice row (max / sum-exp per
+            # 64-column slice, blank and label logits) from its f32 accumulators, so the loss skips its first pass over the logits
+            # (impl/rnnt.py:211 tf.nn.log_softmax + the gathers of :94-105).  bf16 fast path only; otherwise the plain route.
+            stats = None
+            logits = None
+            if self.dtype == torch.bfloat16 and self.fuse_joint_stats:
+                parts = -(-V // 128) * 2
+                lse_part = torch.empty(total, parts, 2, dtype=torch.float32, device=dev)
+                pick = torch.empty(total, 2, dtype=torch.float32, device=dev)
+                row_label = K.rnnt_row_labels(labels, ul_dev, tl_dev, off_dev, total, T, V)
+                t0 = self._tick("joint_vocab_gemm")
+                try:
+                    logits = torch.empty(total, V, dtype=self.dtype, device=dev)
+                    K.gemm(h, ps.w2d("joint/vocab/w"), logits, total, V, J, J, V, V, bias=ps.p("joint/vocab/b"), lse=(lse_part, row_label, pick))
+                    stats = (lse_part, pick)
+                    self._tock("joint_vocab_gemm", t0, 2.0 * total * J * V)
+                except K._lib.TfasrUnsupported:
+                    logits = None
+            if logits is None:
+                t0 = self._tick("joint_vocab_gemm")
+                logits = K.matmul(h, ps.w2d("joint/vocab/w"), bias=ps.p("joint/vocab/b"))  # [total, V]
+                self._tock("joint_vocab_gemm", t0, 2.0 * total * J * V)
             t0 = self._tick("rnnt_loss")
             costs, dlogits = K.rnnt_loss_packed(logits, labels, ul_dev, tl_dev, off_dev, total, T, grad_scale=gscale, grads=logits,
-                                                want_grads=want_backward)
-            self._tock("rnnt_loss", t0)
+                                                want_grads=want_backward, stats=stats)
+            self._tock("rnnt_loss", t0, 2.0 * total * V * logits.element_size())
             if not want_backward:
                 return costs
             dh = self._dense_bwd(dlogits, h, "joint/vocab/w", "joint/vocab/b")

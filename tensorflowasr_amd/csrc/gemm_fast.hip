@@ -213,7 +213,7 @@ __device__ __forceinline__ float dact_f(float z, int act) {
 // EPI selects which epilogue terms are COMPILED IN.  The fully generic epilogue (every term behind a runtime branch, tanh /
 // sigmoid / f32 outputs included) is ~20k instructions and thrashes the instruction cache: a plain bias epilogue took 1700
 // cycles per 16-row strip.  The step's common combinations get lean instantiations; anything else falls back to E_GEN.
-enum : int { E_ACT = 1 /* swish(+prez) */, E_DACT = 2 /* * swish'(dact_z) */, E_DROP = 4, E_RES = 8, E_WS = 16 /* split-K partial -> workspace */, E_CSUM = 32 /* + column sums of B (bias gradient) */, E_GEN = 256 };
+enum : int { E_ACT = 1 /* swish(+prez) */, E_DACT = 2 /* * swish'(dact_z) */, E_DROP = 4, E_RES = 8, E_WS = 16 /* split-K partial -> workspace */, E_CSUM = 32 /* + column sums of B (bias gradient) */, E_LSE = 64 /* + log-softmax statistics of the output rows */, E_GEN = 256 };
 
 // Persistent workgroups (2 per CU) walk a strided list of tiles.  Measured on [23808,256]x[256,1024] (cycle counters,
 // tools/hwprobe/gemm_timing.hip): a tile spent 1900 cycles waiting for its first slab, ~2400 per further slab (the LDS-DMA
@@ -232,6 +232,7 @@ __device__ __forceinline__ void gemm_fast_body(const tfasr_gemm_args& p, const i
   constexpr bool C_ACT = GEN || (EPI & E_ACT), C_DACT = GEN || (EPI & E_DACT), C_DROP = GEN || (EPI & E_DROP), C_RES = GEN || (EPI & E_RES);
   constexpr bool C_WS = (EPI & E_WS) != 0;
   constexpr bool C_CS = (EPI & E_CSUM) != 0;
+  constexpr bool C_LSE = (EPI & E_LSE) != 0;
   constexpr int BN = BN_, NJ = BN_ / 32, WN = BN_ / 2;
   constexpr int STAGE_BYTES = A_BYTES + BN_ * BK * 2;
   constexpr int GI = 4 + BN_ / 32;  // DMA wave-instructions per slab per wave
@@ -456,6 +457,16 @@ __device__ __forceinline__ void gemm_fast_body(const tfasr_gemm_args& p, const i
       }
       const uint32_t dthr = drop_thr(p.drop_p);
       const float dinv = p.drop_p > 0.f ? 1.f / (1.f - p.drop_p) : 1.f;
+      int lse_lab[4][2];
+      if constexpr (C_LSE) {
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+          for (int hh = 0; hh < NPASS; ++hh) {
+            const int rw = m0 + wm * 64 + ii * 16 + hh * RPP + prow;
+            lse_lab[ii][hh] = (rw < p.M) ? p.row_label[rw] : -1;
+          }
+      }
       auto strip = [&](auto I_, auto H_) {
         constexpr int i = decltype(I_)::value, h = decltype(H_)::value;
         if ((g * 4) / RPP == h) {
@@ -542,6 +553,48 @@ _Pragma("unroll")
             else
 _Pragma("unroll")
               for (int q = 0; q < 8; ++q) if (col0 + q < p.N) Dt[idx0 + q] = f32_to_bf16(x[q]);
+          }
+        }
+        if constexpr (C_LSE) {
+          // log-softmax statistics of this row's 64-column slice, from the f32 values (alpha * acc + bias): row max over the
+          // slice's 8 lanes first, then one exp2 per element against the common max and a plain sum (no exp in the merge).
+          // Every lane of the row takes part in the shuffles (lanes past N or M contribute an empty set).
+          const bool rok = row < p.M;
+          const float L2E = 1.4426950408889634f;
+          float mloc = -INFINITY;
+          if (rok && full) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) mloc = fmaxf(mloc, x[q]);
+          } else {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) if (rok && col0 + q < p.N) mloc = fmaxf(mloc, x[q]);
+          }
+#pragma unroll
+          for (int o = 1; o < LPRW; o <<= 1) mloc = fmaxf(mloc, __shfl_xor(mloc, o, 64));
+          const float mb = mloc * L2E;
+          float sloc = 0.f;
+          if (rok && full) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) sloc += __builtin_amdgcn_exp2f(x[q] * L2E - mb);
+          } else {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) if (rok && col0 + q < p.N) sloc += __builtin_amdgcn_exp2f(x[q] * L2E - mb);
+          }
+#pragma unroll
+          for (int o = 1; o < LPRW; o <<= 1) sloc += __shfl_xor(sloc, o, 64);
+          if (rok) {
+            if ((lane % LPRW) == 0) {
+              float2* dst = reinterpret_cast<float2*>(p.lse_part) + (long)row * p.lse_parts + ((n0 + wn * WN) >> 6);
+              *dst = make_float2(mloc, sloc);
+            }
+            if (col0 == 0) p.pick[2L * row] = x[0];
+            const int lab = lse_lab[i][h];  // preloaded for all strips (a load inside the strip would stall it for a round trip)
+            if (lab >= col0 && lab < col0 + 8) {
+              float v = x[0];
+#pragma unroll
+              for (int q = 1; q < 8; ++q) v = (lab - col0 == q) ? x[q] : v;
+              p.pick[2L * row + 1] = v;
+            }
           }
         }
       };
@@ -846,7 +899,7 @@ int launch_one(const tfasr_gemm_args& a, hipStream_t stream) {
   static const bool bn64_off = getenv("TFASR_GEMM_BN64") && getenv("TFASR_GEMM_BN64")[0] == '0';
   const long t128 = (long)((a.N + 127) / 128) * ((a.M + BM - 1) / BM) * a.nb1 * a.nb2 * split;
   static const long bn64_thr = getenv("TFASR_GEMM_BN64_T") ? atol(getenv("TFASR_GEMM_BN64_T")) : (long)num_cus();
-  const bool narrow = a.N <= 64 || (!bn64_off && t128 <= bn64_thr && a.N > 64 && !(a.accumulate && a.ws));
+  const bool narrow = !a.lse_part && (a.N <= 64 || (!bn64_off && t128 <= bn64_thr && a.N > 64 && !(a.accumulate && a.ws)));
   const int bn = narrow ? 64 : 128;
   dim3 grid((a.N + bn - 1) / bn, (a.M + BM - 1) / BM, a.nb1 * a.nb2 * split);
   if ((long)grid.x * grid.y * grid.z > 0x7fffffffL) return TFASR_STATUS_INVALID_VALUE;
@@ -914,6 +967,13 @@ int launch_one(const tfasr_gemm_args& a, hipStream_t stream) {
       }
     }
     return launch_epi<TA, TB, 64, E_GEN>(a, grid, stream);
+  }
+  if (a.lse_part) {  // joint vocabulary projection with fused log-softmax statistics
+    if constexpr (!TA && !TB) {
+      if (!generic && need == 0 && !a.accumulate && a.nb1 * a.nb2 == 1 && a.row_label && a.pick && a.lse_parts == ((a.N + 127) / 128) * 2)
+        return launch_epi<TA, TB, 128, E_LSE>(a, grid, stream);
+    }
+    return TFASR_STATUS_UNSUPPORTED;
   }
   if (!generic) {
     if (need == 0) return launch_epi<TA, TB, 128, 0>(a, grid, stream);

@@ -141,6 +141,39 @@ __global__ __launch_bounds__(256) void rnnt_logprobs_kernel(
   }
 }
 
+// Label id of every lattice row (for the projection GEMM's fused statistics epilogue): labels[b,u] for u < Ul_b, else -1.
+__global__ __launch_bounds__(256) void rnnt_row_labels_kernel(const int32_t* __restrict__ labels, const int32_t* __restrict__ label_len,
+                                                              const int32_t* __restrict__ logit_len, const long* __restrict__ cell_off,
+                                                              long nrows, int B, int Tm, int U1, int V, int32_t* __restrict__ row_label) {
+  for (long r = (long)blockIdx.x * blockDim.x + threadIdx.x; r < nrows; r += (long)gridDim.x * blockDim.x) {
+    const Cell cl = locate(r, cell_off, B, Tm, U1, label_len, logit_len);
+    int lab = -1;
+    if (cl.valid && cl.u < cl.Ul) lab = min(max(labels[(long)cl.b * (U1 - 1) + cl.u], 0), V - 1);
+    row_label[r] = lab;
+  }
+}
+
+// The statistics the GEMM epilogue left per 64-column slice -> lse / blank / truth log-probabilities of every lattice node
+// (what rnnt_logprobs_kernel computes with a full pass over the logits).
+__global__ __launch_bounds__(256) void rnnt_stats_finalize_kernel(const float2* __restrict__ part, int nparts, const float* __restrict__ pick,
+                                                                  const int32_t* __restrict__ label_len, const int32_t* __restrict__ logit_len,
+                                                                  const long* __restrict__ cell_off, long nrows, int B, int Tm, int U1,
+                                                                  float* __restrict__ lse, float* __restrict__ blank_lp, float* __restrict__ truth_lp) {
+  for (long r = (long)blockIdx.x * blockDim.x + threadIdx.x; r < nrows; r += (long)gridDim.x * blockDim.x) {
+    const Cell cl = locate(r, cell_off, B, Tm, U1, label_len, logit_len);
+    if (!cl.valid) continue;
+    RowStat st{-INFINITY, 0.f};
+    for (int c = 0; c < nparts; ++c) {
+      const float2 v = part[r * nparts + c];
+      online_merge(st, v.x, v.y);
+    }
+    const float l = st.m + logf(st.s);
+    lse[r] = l;
+    blank_lp[r] = pick[2 * r] - l;
+    truth_lp[r] = (cl.u < cl.Ul) ? pick[2 * r + 1] - l : -INFINITY;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it would wait for every prefetch
 // in flight; the lattice threads exchange data through LDS alone (global alpha / beta cells are written, never re-read here).
@@ -337,7 +370,8 @@ extern "C" int tfasr_rnnt_loss_workspace_size(int B, int T, int U1, int V, size_
 
 static int rnnt_impl(const void* logits, void* grads, const int32_t* labels, const int32_t* label_len,
                      const int32_t* logit_len, const float* grad_scale, const long* cell_off, long nrows, int B, int T, int U1,
-                     int V, int blank, int dtype, float* costs, void* workspace, size_t workspace_bytes, void* stream_) {
+                     int V, int blank, int dtype, float* costs, void* workspace, size_t workspace_bytes, void* stream_,
+                     const float* lse_part = nullptr, int lse_parts = 0, const float* pick = nullptr) {
   if (!logits || !labels || !label_len || !logit_len || !costs || !workspace) return TFASR_STATUS_INVALID_VALUE;
   if (blank != 0) return TFASR_STATUS_UNSUPPORTED;  // losses/base_loss.py:24
   if (B <= 0 || T <= 0 || U1 <= 0 || V <= 1 || U1 > 1024 || nrows <= 0) return TFASR_STATUS_INVALID_VALUE;
@@ -353,7 +387,11 @@ static int rnnt_impl(const void* logits, void* grads, const int32_t* labels, con
   float* beta = (float*)(ws + 4 * seg);
   const int wpb = 4;
   int grid = (int)std::min<long>((nrows + wpb - 1) / wpb, 256L * 32);
-  if (dtype == TFASR_F32)
+  if (lse_part) {
+    const int fg = (int)std::min<long>((nrows + 255) / 256, 256L * 8);
+    hipLaunchKernelGGL(rnnt_stats_finalize_kernel, dim3(fg), dim3(256), 0, stream, (const float2*)lse_part, lse_parts, pick, label_len, logit_len,
+                       cell_off, nrows, B, T, U1, lse, blank_lp, truth_lp);
+  } else if (dtype == TFASR_F32)
     hipLaunchKernelGGL(rnnt_logprobs_kernel<float>, dim3(grid), dim3(256), 0, stream, (const float*)logits, labels,
                        label_len, logit_len, cell_off, nrows, B, T, U1, V, lse, blank_lp, truth_lp);
   else if (dtype == TFASR_BF16)
@@ -395,4 +433,23 @@ extern "C" int tfasr_rnnt_loss_packed(const void* logits, void* grads, const int
   if (!cell_off) return TFASR_STATUS_INVALID_VALUE;
   return rnnt_impl(logits, grads, labels, label_len, logit_len, grad_scale, cell_off, total_cells, B, T, U1, V, blank, dtype,
                    costs, workspace, workspace_bytes, stream_);
+}
+
+extern "C" int tfasr_rnnt_loss_packed_stats(const void* logits, void* grads, const int32_t* labels, const int32_t* label_len,
+                                            const int32_t* logit_len, const float* grad_scale, const long* cell_off, long total_cells,
+                                            const float* lse_part, int lse_parts, const float* pick, int B, int T, int U1, int V, int blank,
+                                            int dtype, float* costs, void* workspace, size_t workspace_bytes, void* stream_) {
+  if (!cell_off || !lse_part || !pick || lse_parts <= 0) return TFASR_STATUS_INVALID_VALUE;
+  return rnnt_impl(logits, grads, labels, label_len, logit_len, grad_scale, cell_off, total_cells, B, T, U1, V, blank, dtype,
+                   costs, workspace, workspace_bytes, stream_, lse_part, lse_parts, pick);
+}
+
+extern "C" int tfasr_rnnt_row_labels(const int32_t* labels, const int32_t* label_len, const int32_t* logit_len, const long* cell_off,
+                                     long total_cells, int B, int T, int U1, int V, int32_t* row_label, void* stream_) {
+  if (!labels || !label_len || !logit_len || !row_label || total_cells <= 0 || B <= 0 || T <= 0 || U1 <= 0 || V <= 1) return TFASR_STATUS_INVALID_VALUE;
+  const int g = (int)std::min<long>((total_cells + 255) / 256, 256L * 8);
+  hipLaunchKernelGGL(rnnt_row_labels_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream_, labels, label_len, logit_len, cell_off, total_cells, B, T,
+                     U1, V, row_label);
+  TFASR_CHECK_LAUNCH();
+  return TFASR_STATUS_SUCCESS;
 }

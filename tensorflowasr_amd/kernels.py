@@ -88,8 +88,19 @@ def rnnt_loss_fwd_bwd(logits, labels, label_len, logit_len, grad_scale=None, gra
     return costs, (grads if want_grads else None)
 
 
-def rnnt_loss_packed(logits, labels, label_len, logit_len, cell_off, total_cells, T, grad_scale=None, grads=None, want_grads=True, blank=0):
-    """logits [total_cells, V] over the packed lattice (see include/tfasr_hip.h) -> (costs [B], grads)."""
+def rnnt_row_labels(labels, label_len, logit_len, cell_off, total_cells, T, V):
+    """[total_cells] i32: the label id each packed lattice row can emit (-1: none)."""
+    B, U = labels.shape
+    out = torch.empty(total_cells, dtype=torch.int32, device=labels.device)
+    check(_L().tfasr_rnnt_row_labels(_p(labels), _p(label_len), _p(logit_len), _p(cell_off), total_cells, B, T, U + 1, V, _p(out), _stream()),
+          "rnnt_row_labels")
+    return out
+
+
+def rnnt_loss_packed(logits, labels, label_len, logit_len, cell_off, total_cells, T, grad_scale=None, grads=None, want_grads=True, blank=0,
+                     stats=None):
+    """logits [total_cells, V] over the packed lattice (see include/tfasr_hip.h) -> (costs [B], grads).  stats = (lse_part, pick)
+    from the projection GEMM's epilogue (kernels.gemm lse=...): skips the first pass over the logits."""
     assert logits.dim() == 2 and logits.is_contiguous() and cell_off.dtype == torch.int64
     B, U = labels.shape
     V = logits.shape[1]
@@ -98,6 +109,13 @@ def rnnt_loss_packed(logits, labels, label_len, logit_len, cell_off, total_cells
         grads = torch.empty_like(logits)
     nbytes = rnnt_loss_workspace_size(1, total_cells, 1, V)
     ws = workspace(nbytes, logits.device, "rnnt")
+    if stats is not None:
+        part, pick = stats
+        check(_lib.load().tfasr_rnnt_loss_packed_stats(
+            _p(logits), _p(grads) if want_grads else None, _p(labels), _p(label_len), _p(logit_len), _p(grad_scale), _p(cell_off),
+            total_cells, _p(part), part.shape[1], _p(pick), B, T, U + 1, V, blank, _dt(logits), _p(costs), _p(ws), ws.numel(), _stream()),
+            "rnnt_loss_packed_stats")
+        return costs, (grads if want_grads else None)
     check(_lib.load().tfasr_rnnt_loss_packed(
         _p(logits), _p(grads) if want_grads else None, _p(labels), _p(label_len), _p(logit_len), _p(grad_scale), _p(cell_off),
         total_cells, B, T, U + 1, V, blank, _dt(logits), _p(costs), _p(ws), ws.numel(), _stream()), "rnnt_loss_packed")
@@ -107,11 +125,19 @@ def rnnt_loss_packed(logits, labels, label_len, logit_len, cell_off, total_cells
 # ---------------------------------------------------------------------------------------------- GEMM
 def gemm(A, B, out, M, N, K, lda, ldb, ldd, trans_a=False, trans_b=False, bias=None, res=None, dact_z=None,
          prez=None, alpha=1.0, beta=1.0, act=ACT_NONE, dact=ACT_NONE, nb1=1, nb2=1, sA=(0, 0), sB=(0, 0), sD=(0, 0),
-         accumulate=False, split_k=1, drop_p=0.0, drop_seed=0, colsum=None):
-    """Raw strided (two-level batched) GEMM; see include/tfasr_hip.h."""
+         accumulate=False, split_k=1, drop_p=0.0, drop_seed=0, colsum=None, lse=None):
+    """Raw strided (two-level batched) GEMM; see include/tfasr_hip.h.  lse = (lse_part [M, parts, 2] f32, row_label [M] i32,
+    pick [M, 2] f32): fused log-softmax statistics of the output rows (raises TfasrUnsupported when the fast path cannot)."""
     a = _gemm_args(A, B, out, M, N, K, lda, ldb, ldd, trans_a, trans_b, bias, res, dact_z, prez, alpha, beta, act, dact, nb1, nb2, sA, sB, sD,
                    accumulate, split_k, drop_p, drop_seed, colsum)
-    check(_lib.load().tfasr_gemm(ctypes.byref(a), _stream()), "gemm")
+    if lse is not None:
+        part, row_label, pick = lse
+        assert part.dtype == torch.float32 and pick.dtype == torch.float32 and row_label.dtype == torch.int32
+        a.lse_part, a.lse_parts, a.row_label, a.pick = part.data_ptr(), part.shape[1], row_label.data_ptr(), pick.data_ptr()
+    st = _lib.load().tfasr_gemm(ctypes.byref(a), _stream())
+    if lse is not None and st == _lib.STATUS_UNSUPPORTED:
+        raise _lib.TfasrUnsupported("gemm: fused row statistics are not available for this product")
+    check(st, "gemm")
     return out
 
 

@@ -142,3 +142,56 @@ def test_packed_lattice_equals_dense(dev, dtype):
     np.testing.assert_array_equal(g_p.float().cpu().numpy(), want.float().cpu().numpy())
     ref_loss, _ = rnnt_ref.rnnt_loss_and_grad(dense.float().cpu().numpy(), labels, ul, tl)
     np.testing.assert_allclose(costs_p.cpu().numpy(), ref_loss, rtol=1e-3 if dtype == torch.bfloat16 else 1e-5)
+
+
+@pytest.mark.parametrize("V", [1000, 256, 29 * 8])
+def test_joint_projection_epilogue_statistics_feed_the_loss(dev, V):
+    """tfasr_gemm_args.lse_part / pick: the vocabulary projection's epilogue emits max / sum-exp per 64-column slice and the blank /
+    label logits from its f32 accumulators; tfasr_rnnt_loss_packed_stats then skips the first pass over the logits.  Statistics vs
+    torch on the f32 product, loss vs the plain route and vs the oracle (packed ragged lattice, V not a multiple of 128)."""
+    from oracle import rnnt_ref
+    from tensorflowasr_amd import kernels as K
+
+    rng = np.random.default_rng(V)
+    B, T, U, J = 3, 37, 9, 64
+    tl, ul = np.array([37, 20, 31], np.int32), np.array([9, 4, 0], np.int32)
+    labels = rng.integers(1, V, (B, U)).astype(np.int32)
+    off = np.zeros(B + 1, np.int64)
+    off[1:] = np.cumsum(tl * (ul + 1))
+    total = int(off[-1])
+    h = torch.from_numpy(rng.standard_normal((total, J)).astype(np.float32)).to(dev).to(torch.bfloat16)
+    W = torch.from_numpy((rng.standard_normal((J, V)) * 0.3).astype(np.float32)).to(dev).to(torch.bfloat16)
+    bias = torch.from_numpy(rng.standard_normal(V).astype(np.float32)).to(dev)
+    lab_d, ul_d, tl_d, off_d = (torch.from_numpy(x).to(dev) for x in (labels, ul, tl, off))
+    parts = -(-V // 128) * 2
+    lse_part = torch.full((total, parts, 2), float("nan"), dtype=torch.float32, device=dev)
+    pick = torch.full((total, 2), float("nan"), dtype=torch.float32, device=dev)
+    row_label = K.rnnt_row_labels(lab_d, ul_d, tl_d, off_d, total, T, V)
+    logits = torch.empty(total, V, dtype=torch.bfloat16, device=dev)
+    K.gemm(h, W, logits, total, V, J, J, V, V, bias=bias, lse=(lse_part, row_label, pick))
+    plain = K.matmul(h, W, bias=bias)
+    torch.cuda.synchronize()
+    assert torch.equal(plain, logits)  # the stored logits are those of the plain epilogue
+    x32 = h.float() @ W.float() + bias  # what the accumulators hold (f32 sum of bf16 products)
+    m, s = lse_part[..., 0], lse_part[..., 1]
+    mx = m.max(dim=1).values
+    lse = mx + torch.log((s * torch.exp(m - mx[:, None])).sum(1))
+    np.testing.assert_allclose(lse.cpu().numpy(), torch.logsumexp(x32, 1).cpu().numpy(), rtol=1e-5, atol=2e-5)
+    np.testing.assert_allclose(pick[:, 0].cpu().numpy(), x32[:, 0].cpu().numpy(), rtol=1e-5, atol=1e-5)
+    rl = row_label.cpu().numpy()
+    has = rl >= 0
+    assert has.sum() == int((tl * ul).sum())
+    np.testing.assert_allclose(pick[:, 1].cpu().numpy()[has], x32.cpu().numpy()[np.nonzero(has)[0], rl[has]], rtol=1e-5, atol=1e-5)
+    # loss: fused statistics vs plain route vs oracle (on the f32 product)
+    c_stats, g_stats = K.rnnt_loss_packed(logits.clone(), lab_d, ul_d, tl_d, off_d, total, T, stats=(lse_part, pick))
+    c_plain, g_plain = K.rnnt_loss_packed(logits.clone(), lab_d, ul_d, tl_d, off_d, total, T)
+    torch.cuda.synchronize()
+    dense = np.zeros((B, T, U + 1, V), np.float32)
+    x_np = x32.cpu().numpy()
+    for b in range(B):
+        n = tl[b] * (ul[b] + 1)
+        dense[b, :tl[b], :ul[b] + 1] = x_np[off[b]:off[b] + n].reshape(tl[b], ul[b] + 1, V)
+    ref_loss, _ = rnnt_ref.rnnt_loss_and_grad(dense, labels, ul, tl, np.float32)
+    np.testing.assert_allclose(c_stats.cpu().numpy(), ref_loss, rtol=2e-4)       # f32 statistics: closer to the oracle than ...
+    np.testing.assert_allclose(c_plain.cpu().numpy(), ref_loss, rtol=3e-3)       # ... statistics of the bf16-rounded logits
+    np.testing.assert_allclose(g_stats.float().cpu().numpy(), g_plain.float().cpu().numpy(), rtol=5e-2, atol=2e-3)
