@@ -89,15 +89,16 @@ def pmc_traffic(flops_per_launch, J, V):
     profiles/r01_pmc_traffic.json, collected on this same command).  PMC counters cannot be read inside a timed run, so
     the figure is looked up: the forward vocabulary projection is the plain NN gemm_fast launch whose WRITE_SIZE equals its
     output (cells x V bf16) - no other launch of the step writes that much from that kernel.  None if it was not profiled."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
-    if not os.path.exists(path):
+    here = os.path.dirname(os.path.abspath(__file__))
+    path = next((q for q in (os.path.join(here, "profiles", f) for f in ("r02_pmc_traffic.json", "r01_pmc_traffic.json")) if os.path.exists(q)), None)
+    if path is None:
         return None
     rows = json.load(open(path))
     vals = []
     for fl in flops_per_launch:
         cells = fl / (2.0 * J * V)
         out_mb = cells * V * 2 / 1e6
-        m = [r["hbm_MB"] for r in rows if r["kernel"].startswith("gemm_fast_kernel<false, false, 128, 0>") and abs(r["write_MB"] - out_mb) < 0.03 * out_mb]
+        m = [r["hbm_MB"] for r in rows if (r["kernel"].startswith("gemm_fast_kernel<false, false, 128, 64>") or r["kernel"].startswith("gemm_fast_kernel<false, false, 128, 0>")) and abs(r["write_MB"] - out_mb) < 0.03 * out_mb]
         if m:
             vals.append(float(np.mean(m)) * 1e6)
     return round(float(np.mean(vals)), 0) if vals else None
@@ -114,19 +115,29 @@ def cpu_baseline_worker(size, vocab):
     ocfg = R.conformer_config("M" if size.startswith("M") else "S", vocab)
     W = R.init_weights(ocfg, seed=3)
     Wg = {k: v.clone().requires_grad_(R.is_trainable(k)) for k, v in W.items()}
-    rng = np.random.default_rng(0)
-    B, secs, U = 4, 10.0, 37
-    N = int(secs * 16000)
-    sig = np.clip(rng.standard_normal((B, N)).astype(np.float32) * 0.1, -1, 1)
-    labels = rng.integers(1, vocab, (B, U)).astype(np.int32)
+    # the SAME workload generator as the GPU line (make_batch, seed of its first batch), fewer utterances: the first B of the
+    # 32 durations / transcripts the GPU step sees, padded to their own maximum
+    B = 4
+    from tensorflowasr_amd import configs as _cfgs
+
+    pcfg = _cfgs.conformer_m(vocab) if size.startswith("M") else _cfgs.conformer_s(vocab)
+    full = make_batch(pcfg, 32, seed=10, padding="batch", size="S-10s" if not size.startswith("M") else "LibriSpeech-shaped")
+    nsamp = full["nsamp"][:B]
+    N = int(nsamp.max())
+    sig = full["sig"][:B, :N].copy()
+    ulen = full["ulen"][:B]
+    U = int(ulen.max())
+    labels = full["labels"][:B, :U].copy()
     preds = np.concatenate([np.zeros((B, 1), np.int32), labels], 1)
+    secs_total = float(nsamp.sum()) / 16000.0
     state = {k: (torch.zeros_like(v), torch.zeros_like(v)) for k, v in Wg.items() if v.requires_grad}
 
     def step(i):
         feat = R.log_mel(sig, ocfg)
-        flen = R.get_nframes([N] * B)
-        logits, elen = R.transducer_forward(torch.from_numpy(feat), flen, torch.from_numpy(preds), torch.tensor([U + 1] * B), Wg, ocfg, training=True)
-        loss, g = rnnt_ref.rnnt_loss_and_grad(logits.detach().numpy(), labels, np.array([U] * B), elen.numpy(), np.float32)
+        flen = R.get_nframes(nsamp)
+        logits, elen = R.transducer_forward(torch.from_numpy(feat), flen, torch.from_numpy(preds), torch.from_numpy(ulen.astype(np.int64) + 1), Wg, ocfg, training=True)
+        tl, ul = rnnt_ref.clamp_lengths(elen.numpy(), ulen)
+        loss, g = rnnt_ref.rnnt_loss_and_grad(logits.detach().numpy(), labels, ul, np.minimum(tl, logits.shape[1]), np.float32)
         logits.backward(torch.from_numpy(g / B))
         with torch.no_grad():
             for k, v in Wg.items():
@@ -146,9 +157,10 @@ def cpu_baseline_worker(size, vocab):
         step(n + 1)
         n += 1
     dt = (time.perf_counter() - t0) / n
-    return dict(value=(B * secs / 3600.0) / dt, unit="audio-hours/sec", cores=cores, kind="port",
-                sample=f"oracle (torch-CPU fp32 restatement of tensorflow_asr; TF unavailable) full train step, Conformer-{ocfg['dmodel']}d, "
-                       f"{B} x {secs:.0f} s utterances, U={U}, {n} timed steps, {dt:.2f} s/step, {cores} threads")
+    return dict(value=(secs_total / 3600.0) / dt, unit="audio-hours/sec", cores=cores, kind="port",
+                sample=f"oracle (torch-CPU fp32 restatement of tensorflow_asr; TF unavailable) full train step, Conformer-{ocfg['dmodel']}d, the first "
+                       f"{B} utterances of the GPU line's first batch (same generator and seed: {secs_total:.1f} s of audio, padded to {N / 16000.0:.1f} s, "
+                       f"U<={U}), {n} timed steps, {dt:.2f} s/step, {cores} threads")
 
 
 def cpu_baseline(size, vocab, timeout_s=240):
@@ -234,8 +246,8 @@ def bench_ctc_decode(args, dev, dtype):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--model", default="M", choices=["M", "S", "contextnet"], help="M / S = Conformer sizes; contextnet = BASELINE configs[3] family")
     ap.add_argument("--alpha", type=float, default=2.0, help="ContextNet width multiplier (0.5 small, 1 medium, 2 large)")
     ap.add_argument("--batch", type=int, default=32, help="utterances per GPU")
@@ -245,6 +257,7 @@ def main():
     ap.add_argument("--mode", default="train", choices=["train", "decode", "ctc-decode"],
                     help="decode = transducer greedy-search RTF (second half of BASELINE.json's metric); ctc-decode = Conformer-CTC greedy / beam RTF")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the reference-padding second measurement of the default run")
     ap.add_argument("--no-specaugment", action="store_true")
     ap.add_argument("--dropout", type=float, default=None, help="override encoder dropout (default: reference value 0.1)")
     args = ap.parse_args()
@@ -356,6 +369,18 @@ def main():
                 sf = float(np.mean([step_matmul_flops(cfg, batches[i % nb]) for i in range(args.steps)]))
                 roof["step_matmul_tflops"] = round(sf / (ms_per_step * 1e-3) / 1e12, 1)
                 roof["step_frac"] = round(sf / (ms_per_step * 1e-3) / 1e12 / peak, 4)
+        # RNN-T loss kernels (statistics finalize + alpha/beta lattice + gradient) against the HBM roofline: algorithmic bytes =
+        # cells x V x (logit + gradient), time = HIP events around exactly those launches in the timed region
+        roof_rnnt = None
+        tl_ = model.timers.get("rnnt_loss") or []
+        if tl_ and args.model != "contextnet":
+            ms = float(np.mean([a.elapsed_time(b) for a, b in tl_]))
+            by = float(np.mean(model.timer_work["rnnt_loss"]))
+            if by > 0:
+                ach = by / (ms * 1e-3) / 1e9
+                roof_rnnt = {"kernel": "rnnt_stats_finalize + rnnt_lattice + rnnt_grad (packed lattice)", "bound": "hbm", "achieved": round(ach, 1),
+                             "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4), "ms_per_launch": round(ms, 4),
+                             "algorithmic_bytes": by}
         out = {
             "metric": ("audio-hours/sec (train step) ContextNet(alpha=%g) RNN-T" % args.alpha) if args.model == "contextnet"
                       else "audio-hours/sec (train step) Conformer-%s RNN-T" % args.model,
@@ -366,7 +391,31 @@ def main():
                                    f"{args.batch}/GPU, padding={args.padding}, SpecAugment {'off' if args.no_specaugment else 'on'}, dropout {cfg.dropout}",
                        "global_batch": args.batch * world, "parallelism": f"dp{world}", "params": model.ps.num_trainable()},
             "roofline": roof,
+            "roofline_rnnt": roof_rnnt,
         }
+        if world == 1 and not args.no_extras and args.model == "M" and args.padding == "batch" and size == "LibriSpeech-shaped":
+            # BASELINE.md section 2 "report both": the same step with the reference's dataset-maximum padding (every utterance padded
+            # to 475 760 samples / 230 labels, datasets.py:342-365).  The packed lattice and the length-aware kernels make the
+            # padded LABEL positions free; the padded encoder frames are computed like the reference computes them.
+            try:
+                model.timers = None
+                rb = [make_batch(cfg, args.batch, seed=10 + 13 * i, padding="reference", size=size) for i in range(nb)]
+                rd = [to_train_data(b, dev) for b in rb]
+                for i in range(2):
+                    model.train_step(rd[i % nb])
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                nref = 10
+                for i in range(nref):
+                    model.train_step(rd[i % nb])
+                torch.cuda.synchronize()
+                dtr = (time.perf_counter() - t1) / nref
+                secs_r = float(np.mean([b["seconds"] for b in rb]))
+                out["reference_padding"] = {"ms_per_step": round(dtr * 1e3, 3), "value": round(secs_r / 3600.0 / dtr, 4), "unit": "audio-hours/sec",
+                                            "steps": nref, "padded_to": "475760 samples / 230 labels (datasets.py:342-365)"}
+                del rd, rb
+            except Exception as e:  # the headline number must still be reported
+                out["reference_padding"] = {"value": None, "error": repr(e)[:200]}
         if not args.no_cpu_baseline and world == 1:
             try:
                 if args.model != "contextnet":  # the CPU port baseline is the Conformer oracle
