@@ -270,6 +270,16 @@ int tfasr_relattn_fused_bwd_q(const void* qkv, const float* ubias, const float* 
                               const int32_t* lengths, const void* o, const void* dout, const float* lse, void* dqu, void* dpos,
                               float* dvec, int B, int H, int T, int dh, int ldp, float scale, int use_mask, int dtype,
                               void* stream);
+/* Query side without the skewed score gradient in HBM (default path): also returns dqv [B*T, H*dh] = d/d(q+v) (formed in the
+ * kernel against the window rows), stores the UNSKEWED score gradient ds [B,H,T,lds] (lds >= T, multiple of 8) and adds the bias
+ * row's share into dpext [2T, H*dh] f32 (zeroed by the caller).  tfasr_relattn_dpext then accumulates the rest of dpext from ds
+ * and qv = q + v ([B*T, H*dh], tfasr_bias2_fwd): one f32 atomic per (table row, column, sample group). */
+int tfasr_relattn_fused_bwd_q2(const void* qkv, const float* ubias, const float* vbias, const void* pext,
+                               const int32_t* lengths, const void* o, const void* dout, const float* lse, void* dqu, void* dqv, void* ds,
+                               float* dvec, float* dpext, int B, int H, int T, int dh, int lds, float scale, int use_mask, int dtype,
+                               void* stream);
+int tfasr_relattn_dpext(const void* ds, const void* qv, const int32_t* lengths, float* dpext, int B, int H, int T, int dh, int lds,
+                        int use_mask, int dtype, void* stream);
 /* Fused backward, key side (run after _bwd_q, which also emits dvec [B,H,T] = rowsum(dout*o)): writes the k and v column
  * blocks of dqkv [B*T, 3*H*dh]; qu/qv [B*T, H*dh] = q+u / q+v (tfasr_bias2_fwd). */
 int tfasr_relattn_fused_bwd_k(const void* qkv, const void* qu, const void* qv, const void* pext, const int32_t* lengths,

@@ -350,6 +350,16 @@ class ConformerTransducer:
         if "lse" in s:
             R1p = -(-R1 // 8) * 8
             um = c.use_attention_auto_mask
+            if os.environ.get("TFASR_ATTN_DPOS", "0") != "1":
+                # default: no skewed score gradient in HBM (attn_fused.hip V2) - dqv comes out of the query-side kernel, dpext is
+                # accumulated from the unskewed dS by tfasr_relattn_dpext
+                dpext = torch.zeros(R1, HD, dtype=torch.float32, device=self.device)
+                dqu, dqv, ds, dvec = K.relattn_fused_bwd_q2(qkv, ub, vb, s["pext"], elen_dev, s["att"], datt, s["lse"], dpext, B, H, T, dh, scale,
+                                                            use_mask=um)
+                qu, qv = K.bias2_fwd(qkv, 3 * HD, ub, vb, B * T, HD)
+                K.relattn_fused_bwd_k(qkv, qu, qv, s["pext"], elen_dev, datt, s["lse"], dvec, dqkv, B, H, T, dh, scale, use_mask=um)
+                K.relattn_dpext(ds, qv, elen_dev, dpext, B, H, T, dh, use_mask=um)
+                return self._mhsa_bwd_tail(dy, pfx, B, T, s, dqkv, dqu, None, qv, R1p, 1.0, dqv=dqv, dpext=dpext)
             dqu, dpos, dvec = K.relattn_fused_bwd_q(qkv, ub, vb, s["pext"], elen_dev, s["att"], datt, s["lse"], B, H, T, dh,
                                                     R1p, scale, use_mask=um)
             qu, qv = K.bias2_fwd(qkv, 3 * HD, ub, vb, B * T, HD)
@@ -379,19 +389,21 @@ class ConformerTransducer:
         return (self.dtype == torch.bfloat16 and self.cfg.head_size == 64 and not self.cfg.chunk_size
                 and os.environ.get("TFASR_ATTN_UNFUSED", "0") != "1")
 
-    def _mhsa_bwd_tail(self, dy, pfx, B, T, s, dqkv, dqu, dpos, qv, R1p, scale):
-        """dpos [B,H,T,R1p] (gradient of the un-shifted position scores) -> dqv, dpext, bias and projection gradients."""
+    def _mhsa_bwd_tail(self, dy, pfx, B, T, s, dqkv, dqu, dpos, qv, R1p, scale, dqv=None, dpext=None):
+        """dpos [B,H,T,R1p] (gradient of the un-shifted position scores) -> dqv, dpext, bias and projection gradients
+        (dqv / dpext already formed by the fused V2 kernels when given)."""
         ps, c = self.ps, self.cfg
         H, dh = c.num_heads, c.head_size
         HD = H * dh
         R1 = 2 * T
-        # dqv = scale * dpos @ pext ; dpext += scale * sum_b dpos^T @ qv
-        dqv = torch.empty(B * T, HD, dtype=self.dtype, device=self.device)
-        K.gemm(dpos, s["pext"], dqv, T, dh, R1, R1p, HD, HD, nb1=B, nb2=H, sA=(H * T * R1p, T * R1p), sB=(0, dh), sD=(T * HD, dh),
-               alpha=scale)
-        dpext = torch.zeros(R1, HD, dtype=torch.float32, device=self.device)
-        K.gemm(dpos, qv, dpext, R1, dh, T, R1p, HD, HD, trans_a=True, nb1=B, nb2=H, sA=(H * T * R1p, T * R1p), sB=(T * HD, dh),
-               sD=(0, dh), alpha=scale, accumulate=True)
+        if dqv is None:
+            # dqv = scale * dpos @ pext ; dpext += scale * sum_b dpos^T @ qv
+            dqv = torch.empty(B * T, HD, dtype=self.dtype, device=self.device)
+            K.gemm(dpos, s["pext"], dqv, T, dh, R1, R1p, HD, HD, nb1=B, nb2=H, sA=(H * T * R1p, T * R1p), sB=(0, dh), sD=(T * HD, dh),
+                   alpha=scale)
+            dpext = torch.zeros(R1, HD, dtype=torch.float32, device=self.device)
+            K.gemm(dpos, qv, dpext, R1, dh, T, R1p, HD, HD, trans_a=True, nb1=B, nb2=H, sA=(H * T * R1p, T * R1p), sB=(T * HD, dh),
+                   sD=(0, dh), alpha=scale, accumulate=True)
         gu, gv = self._uv(pfx, grad=True)
         K.bias2_bwd(dqu, dqv, dqkv, 3 * HD, gu, gv, B * T, HD)
         # positional projection: gWpos += pe^T dpext ; gbpos += colsum(dpext)

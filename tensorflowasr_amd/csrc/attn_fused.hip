@@ -288,11 +288,17 @@ __device__ __forceinline__ short8_t row_frag(const bf16_t* row, int k0) {
   return *reinterpret_cast<const short8_t*>(row + k0);
 }
 
+// V2 (no skewed score gradient in HBM): the positional part of the query gradient is formed HERE, dqv_i = sum_j ds_ij pext[idx(i,j)],
+// as one more MFMA product per key block on a skewed image of dS (per-wave [16 x 128] strip, column 63-il+jl) against the window
+// rows already in LDS; dS itself is stored UNSKEWED [B,H,T,ldp] (half the bytes of the skewed [B,H,T,2T] matrix, no zero fill) for
+// relattn_dpext_kernel, and the bias-row share of dpext (pairs whose relative position is outside the sample's 2*len-1 encodings)
+// is accumulated here.  `dpos` / `ldp` then mean dS and its row stride.
+template <bool V2>
 __global__ __launch_bounds__(256, 2) void relattn_fused_bwd_q_kernel(
     const bf16_t* __restrict__ qkv, const float* __restrict__ ubias, const float* __restrict__ vbias,
     const bf16_t* __restrict__ pext, const int32_t* __restrict__ lengths, const bf16_t* __restrict__ o,
     const bf16_t* __restrict__ dout, const float* __restrict__ lse, bf16_t* __restrict__ dqu, bf16_t* __restrict__ dpos,
-    float* __restrict__ dvec, int B, int H, int T, int ldp, float scale, int use_mask) {
+    float* __restrict__ dvec, int B, int H, int T, int ldp, float scale, int use_mask, bf16_t* __restrict__ dqv, float* __restrict__ dpext) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sK = smem;              // [64 j][64 dh], read both as rows (k = dh) and transposed (k = j)
   char* sV = sK + SK_BYTES;     // [64 j][64 dh]
@@ -357,13 +363,30 @@ __global__ __launch_bounds__(256, 2) void relattn_fused_bwd_q_kernel(
     inrow[e] = i < T;
     live[e] = inrow[e] && !(use_mask && i >= len);
     lsei2[e] = lsei[e] * 1.4426950408889634f;
-    prow_e[e] = dpos + (((long)b * H + h) * T + min(i, T - 1)) * ldp + (T - 1 - i + shift) + r;  // + jl + j0 = column rr + shift
+    prow_e[e] = dpos + (((long)b * H + h) * T + min(i, T - 1)) * ldp + (V2 ? 0 : (T - 1 - i + shift)) + r;  // + jl + j0 = column (V2: j itself)
 #pragma unroll
     for (int jt = 0; jt < 4; ++jt) {
       const int jl = jt * 16 + r;
       poff[e][jt] = il * 128 + (((jl >> 3) ^ key_d(il)) << 4) + (jl & 7) * 2;
     }
   }
+  // V2: slots of the skewed dS image [16 il][128 c] (256-B rows, 16-B chunk ^= key_d(il)): c = 63 - w*16 - il + jl
+  int goffA[4][4];
+  float4_t acc_v[4];
+#pragma unroll
+  for (int n = 0; n < 4; ++n) acc_v[n] = float4_t{0.f, 0.f, 0.f, 0.f};
+  if constexpr (V2) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int il = g * 4 + e;
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt) {
+        const int c = 63 - w * 16 - il + jt * 16 + r;
+        goffA[e][jt] = il * 256 + (((c >> 3) ^ key_d(il)) << 4) + (c & 7) * 2;
+      }
+    }
+  }
+  char* sAg = sA + 4096;  // dG image (4 KiB) behind the dS image (2 KiB) inside this wave's G strip (8448 B)
 
 #ifdef TFASR_ATTN_TIMING
   long long ph[5] = {0, 0, 0, 0, 0};
@@ -431,22 +454,56 @@ __global__ __launch_bounds__(256, 2) void relattn_fused_bwd_q_kernel(
           d = p * (acc_p[jt][e] - Di[e]) * scale;
         }
         ds[e][jt] = d;
-        if (inrow[e] && jin) {
-          if (valid_r) prow_e[e][jt * 16 + j0] = f32_to_bf16(d);
-          else bias_acc[e] += d;
+        if constexpr (V2) {
+          if (inrow[e] && jin) {
+            prow_e[e][jt * 16 + j0] = f32_to_bf16(valid_r ? d : 0.f);
+            if (!valid_r) bias_acc[e] += d;
+          }
+        } else {
+          if (inrow[e] && jin) {
+            if (valid_r) prow_e[e][jt * 16 + j0] = f32_to_bf16(d);
+            else bias_acc[e] += d;
+          }
         }
       }
+    }
+    bool vr[4][4];
+    if constexpr (V2) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) vr[e][jt] = rr0[e] + jt * 16 + j0 < lim;
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     ATT_TICK(2)
     // dS (bf16) as A operand image [16 rows il][64 k = jl] in the (now dead) G strip
+    if constexpr (V2) {
+      // the skewed image: clear this wave's [16 x 128] strip (the G values that lived there are consumed), then scatter
+      const uint4 z4 = make_uint4(0, 0, 0, 0);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) *reinterpret_cast<uint4*>(sAg + (q * 64 + lane) * 16) = z4;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
 #pragma unroll
     for (int e = 0; e < 4; ++e)
 #pragma unroll
-      for (int jt = 0; jt < 4; ++jt) *reinterpret_cast<bf16_t*>(sA + poff[e][jt]) = f32_to_bf16(ds[e][jt]);
+      for (int jt = 0; jt < 4; ++jt) {
+        *reinterpret_cast<bf16_t*>(sA + poff[e][jt]) = f32_to_bf16(ds[e][jt]);
+        if constexpr (V2) *reinterpret_cast<bf16_t*>(sAg + goffA[e][jt]) = f32_to_bf16(vr[e][jt] ? ds[e][jt] : 0.f);
+      }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (V2) {
+      // dqv += dG @ window   (A: skewed image, k = window column c; B: the window rows read transposed, k = c)
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const short8_t a = *reinterpret_cast<const short8_t*>(sAg + r * 256 + (((kk * 4 + g) ^ key_d(r)) << 4));
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+          acc_v[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, frag_kt(sP, n * 16, kk * 32 + g * 8, r), acc_v[n], 0, 0, 0);
+      }
+    }
     // dqu += dS @ K   (B operand: K block read transposed, k = j)
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
@@ -467,23 +524,147 @@ __global__ __launch_bounds__(256, 2) void relattn_fused_bwd_q_kernel(
 #endif
 
   // epilogue: dqu, the bias column, and zeros over the part of each dpos row that no (i,j) pair maps to
+  float bsum4[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     const int i = i0 + w * 16 + g * 4 + e;
     float bsum = bias_acc[e];
     bsum = row16_sum(bsum);
+    bsum4[e] = bsum;
     if (i < T) {
 #pragma unroll
       for (int n = 0; n < 4; ++n) dqu[((long)b * T + i) * HD + h * DH + n * 16 + r] = f32_to_bf16(acc_q[n][e]);
-      bf16_t* prow = dpos + (((long)b * H + h) * T + i) * ldp;
-      // valid columns: rr + shift for j in [0,T) with rr = T-1-i+j < 2len-1  ->  [T-1-i+shift, min(2T-1-i, 2len-1)+shift )
-      const int lo = T - 1 - i + shift;
-      const int hi = min(2 * T - 1 - i, 2 * len - 1) + shift;  // exclusive; may be <= lo when no pair is valid
-      const int hi2 = max(hi, lo);
-      for (int c = r; c < ldp; c += 16)
-        if (c < lo || c >= hi2) prow[c] = (c == R) ? f32_to_bf16(bsum) : (bf16_t)0;
+      if constexpr (!V2) {
+        bf16_t* prow = dpos + (((long)b * H + h) * T + i) * ldp;
+        // valid columns: rr + shift for j in [0,T) with rr = T-1-i+j < 2len-1  ->  [T-1-i+shift, min(2T-1-i, 2len-1)+shift )
+        const int lo = T - 1 - i + shift;
+        const int hi = min(2 * T - 1 - i, 2 * len - 1) + shift;  // exclusive; may be <= lo when no pair is valid
+        const int hi2 = max(hi, lo);
+        for (int c = r; c < ldp; c += 16)
+          if (c < lo || c >= hi2) prow[c] = (c == R) ? f32_to_bf16(bsum) : (bf16_t)0;
+      }
     }
   }
+  if constexpr (V2) {
+    // dqv_i = (dG @ window)_i + bsum_i * pext[R]   and   dpext[R] += sum_i bsum_i * (q_i + v)
+    float pbias[4], part[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) { pbias[n] = bf16_to_f32(pb[(long)R * HD + n * 16 + r]); part[n] = 0.f; }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int i = i0 + w * 16 + g * 4 + e;
+      if (i < T) {
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+          dqv[((long)b * T + i) * HD + h * DH + n * 16 + r] = f32_to_bf16(acc_v[n][e] + bsum4[e] * pbias[n]);
+          const float qvv = bf16_to_f32(f32_to_bf16(bf16_to_f32(qb[(long)i * LDQ + n * 16 + r]) + vbias[h * DH + n * 16 + r]));
+          part[n] += bsum4[e] * qvv;
+        }
+      }
+    }
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      float v = part[n];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      if (g == 0 && v != 0.f) atomicAdd(dpext + (long)R * HD + h * DH + n * 16 + r, v);
+    }
+  }
+}
+
+
+// ======================================================================================================================
+// Backward, part 3 (V2): the gradient of the projected position table,
+//   dpext[c, :] += sum_b sum_i dS_b[i, j(i,c)] * (q_i + v),     j(i,c) = (c - shift_b) - (T-1-i),   valid iff 0 <= c - shift_b < 2 len_b - 1
+// read from the UNSKEWED dS [B,H,T,lds].  Block = (128 table rows, head, group of samples); the 4 waves own 2 of the 8 16-row tiles
+// each and keep them in registers over every sample of the group and every 64-query block that can reach them, so dpext receives
+// one f32 atomic per (table row, column, group) instead of one per (sample, query block) pair.  The MFMA A operand (rows = c, k = i)
+// is the diagonal of the raw dS tile: element (il, c) sits at column (c - shift - T + 1 + i0 + il) of row il.
+// ======================================================================================================================
+constexpr int DPX_TLD = 208;                              // raw tile row stride in elements (192 columns + alignment slack)
+constexpr int SMEM_DPX = 64 * DPX_TLD * 2 + SK_BYTES;     // raw dS tile + (q+v) block
+
+__global__ __launch_bounds__(256, 2) void relattn_dpext_kernel(
+    const bf16_t* __restrict__ ds, const bf16_t* __restrict__ qv, const int32_t* __restrict__ lengths, float* __restrict__ dpext,
+    int B, int H, int T, int lds, int use_mask, int bchunk) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16_t* sT = reinterpret_cast<bf16_t*>(smem);
+  char* sQ = smem + 64 * DPX_TLD * 2;
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r = lane & 15, g = lane >> 4;
+  const int c0 = blockIdx.x * 128, h = blockIdx.y;
+  const int HD = H * DH, R = 2 * T - 1;
+  const int b_lo = blockIdx.z * bchunk, b_hi = min(B, b_lo + bchunk);
+  float4_t acc[2][4];
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+    for (int n = 0; n < 4; ++n) acc[ct][n] = float4_t{0.f, 0.f, 0.f, 0.f};
+  const int nib = (T + BI - 1) / BI;
+  for (int b = b_lo; b < b_hi; ++b) {
+    const int len = lengths ? min(lengths[b], T) : T;
+    const int shift = T - len, lim = 2 * len - 1;
+    if (c0 + 128 <= shift || c0 >= shift + lim) continue;  // no valid table row of this sample in the block
+    const bf16_t* dsb = ds + ((long)b * H + h) * T * lds;
+    const bf16_t* qvb = qv + (long)b * T * HD + h * DH;
+    const int nib_b = use_mask ? min(nib, (len + BI - 1) / BI) : nib;  // masked query rows carry dS = 0
+    for (int ib = 0; ib < nib_b; ++ib) {
+      const int i0 = ib * BI;
+      const int jmin = c0 - shift - T + 1 + i0;          // j of (il = 0, c = c0); (il, c) -> jmin + (c - c0) + il
+      if (jmin + 127 + 63 < 0 || jmin >= T) continue;
+      const int jb0 = (jmin >= 0 ? jmin : jmin - 7) / 8 * 8;  // aligned-down tile origin (may be negative)
+      __syncthreads();                                    // previous tile fully consumed
+      load_rows<BI>(sQ, qvb, HD, i0, T, w, lane);
+      for (int q = threadIdx.x; q < 64 * (DPX_TLD / 8); q += 256) {
+        const int il = q / (DPX_TLD / 8), ch = q % (DPX_TLD / 8);
+        const int i = i0 + il, j = jb0 + ch * 8;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (i < T && j >= 0 && j + 8 <= lds) v = *reinterpret_cast<const uint4*>(dsb + (long)i * lds + j);
+        else if (i < T && j + 8 > 0 && j < T) {            // ragged edge: element-wise
+          bf16_t t8[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) t8[e] = (j + e >= 0 && j + e < T) ? dsb[(long)i * lds + j + e] : (bf16_t)0;
+          v = *reinterpret_cast<const uint4*>(t8);
+        }
+        *reinterpret_cast<uint4*>(sT + il * DPX_TLD + ch * 8) = v;
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+        const int c = c0 + (2 * w + ct) * 16 + r;         // this lane's table row (A row)
+        const int rr = c - shift;
+        const bool cvalid = rr >= 0 && rr < lim && c < R;
+        const int base = (jmin - jb0) + (c - c0);          // column of (il = 0, c) in the raw tile; +il per row
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          short8_t a;
+#pragma unroll
+          for (int t = 0; t < 8; ++t) {
+            const int il = kk * 32 + g * 8 + t;
+            const int j = jmin + (c - c0) + il;            // real key index: pairs outside [0, T) do not exist
+            a[t] = (cvalid && j >= 0 && j < T) ? (short)sT[il * DPX_TLD + base + il] : (short)0;
+          }
+#pragma unroll
+          for (int n = 0; n < 4; ++n)
+            acc[ct][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, frag_kt(sQ, n * 16, kk * 32 + g * 8, r), acc[ct][n], 0, 0, 0);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int c = c0 + (2 * w + ct) * 16 + g * 4 + e;
+      if (c < R) {
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+          const float v = acc[ct][n][e];
+          if (v != 0.f) atomicAdd(dpext + (long)c * HD + h * DH + n * 16 + r, v);
+        }
+      }
+    }
 }
 
 
@@ -672,9 +853,40 @@ extern "C" int tfasr_relattn_fused_bwd_q(const void* qkv, const float* ubias, co
     return TFASR_STATUS_INVALID_VALUE;
   if (dtype != TFASR_BF16 || dh != DH) return TFASR_STATUS_UNSUPPORTED;
   dim3 grid((T + BI - 1) / BI, H, B);
-  hipLaunchKernelGGL(relattn_fused_bwd_q_kernel, grid, dim3(256), SMEM_BWD_Q, (hipStream_t)stream_, (const bf16_t*)qkv, ubias, vbias,
+  hipLaunchKernelGGL(relattn_fused_bwd_q_kernel<false>, grid, dim3(256), SMEM_BWD_Q, (hipStream_t)stream_, (const bf16_t*)qkv, ubias, vbias,
                      (const bf16_t*)pext, lengths, (const bf16_t*)o, (const bf16_t*)dout, lse, (bf16_t*)dqu, (bf16_t*)dpos, dvec, B, H, T, ldp,
-                     scale, use_mask);
+                     scale, use_mask, (bf16_t*)nullptr, (float*)nullptr);
+  TFASR_CHECK_LAUNCH();
+  return TFASR_STATUS_SUCCESS;
+}
+
+extern "C" int tfasr_relattn_fused_bwd_q2(const void* qkv, const float* ubias, const float* vbias, const void* pext,
+                                          const int32_t* lengths, const void* o, const void* dout, const float* lse, void* dqu, void* dqv,
+                                          void* ds, float* dvec, float* dpext, int B, int H, int T, int dh, int lds, float scale, int use_mask,
+                                          int dtype, void* stream_) {
+  if (!qkv || !ubias || !vbias || !pext || !o || !dout || !lse || !dqu || !dqv || !ds || !dvec || !dpext || B <= 0 || H <= 0 || T <= 0 || lds < T || (lds & 7))
+    return TFASR_STATUS_INVALID_VALUE;
+  if (dtype != TFASR_BF16 || dh != DH) return TFASR_STATUS_UNSUPPORTED;
+  dim3 grid((T + BI - 1) / BI, H, B);
+  hipLaunchKernelGGL(relattn_fused_bwd_q_kernel<true>, grid, dim3(256), SMEM_BWD_Q, (hipStream_t)stream_, (const bf16_t*)qkv, ubias, vbias,
+                     (const bf16_t*)pext, lengths, (const bf16_t*)o, (const bf16_t*)dout, lse, (bf16_t*)dqu, (bf16_t*)ds, dvec, B, H, T, lds,
+                     scale, use_mask, (bf16_t*)dqv, dpext);
+  TFASR_CHECK_LAUNCH();
+  return TFASR_STATUS_SUCCESS;
+}
+
+extern "C" int tfasr_relattn_dpext(const void* ds, const void* qv, const int32_t* lengths, float* dpext, int B, int H, int T, int dh, int lds,
+                                   int use_mask, int dtype, void* stream_) {
+  if (!ds || !qv || !dpext || B <= 0 || H <= 0 || T <= 0 || lds < T || (lds & 7)) return TFASR_STATUS_INVALID_VALUE;
+  if (dtype != TFASR_BF16 || dh != DH) return TFASR_STATUS_UNSUPPORTED;
+  const int cblocks = (2 * T - 1 + 127) / 128;
+  // sample groups: enough workgroups to fill the chip (2 per CU) without multiplying the atomics more than needed
+  static const int target = getenv("TFASR_DPEXT_WGS") ? atoi(getenv("TFASR_DPEXT_WGS")) : 512;
+  int groups = std::max(1, std::min(B, target / std::max(1, cblocks * H)));
+  const int bchunk = (B + groups - 1) / groups;
+  groups = (B + bchunk - 1) / bchunk;
+  hipLaunchKernelGGL(relattn_dpext_kernel, dim3(cblocks, H, groups), dim3(256), SMEM_DPX, (hipStream_t)stream_, (const bf16_t*)ds, (const bf16_t*)qv,
+                     lengths, dpext, B, H, T, lds, use_mask, bchunk);
   TFASR_CHECK_LAUNCH();
   return TFASR_STATUS_SUCCESS;
 }

@@ -337,10 +337,32 @@ struct Ex {
     void* dqkv = act(scratch, rows * 3 * HD);
     void* dqu = act(scratch, rows * HD);
     void* dqv = act(scratch, rows * HD);
-    void* dpos = act(scratch, (long)B * H * T * R1p);
+    // fused path, default: the skewed score gradient never exists in HBM (attn_fused.hip V2); TFASR_ATTN_DPOS=1 restores the old route
+    static const bool dpos_route = getenv("TFASR_ATTN_DPOS") && getenv("TFASR_ATTN_DPOS")[0] == '1';
+    const bool v2 = k->fused && !dpos_route;
+    void* dpos = act(scratch, v2 ? (long)B * H * T * Tp : (long)B * H * T * R1p);  // v2: the unskewed dS [B,H,T,Tp]
     const void* qv;
     float tail_scale;
-    if (k->fused) {
+    float* dpext = io->dpext_zero;
+    if (v2) {
+      if (!dpext) {
+        dpext = f32(scratch, (long)R1 * HD);
+        zero(dpext, (size_t)R1 * HD * 4);
+      }
+      float* dvec = f32(scratch, (long)B * H * T);
+      void* qu = act(scratch, rows * HD);
+      void* qvb = act(scratch, rows * HD);
+      if (!dry) {
+        chk(tfasr_relattn_fused_bwd_q2(k->at_qkv, fp(TFASR_BP_AT_U), fp(TFASR_BP_AT_V), k->at_pext, io->lengths, k->at_att, datt, k->at_lse, dqu,
+                                       dqv, dpos, dvec, dpext, B, H, T, dh, Tp, scale, c->use_mask, c->dtype, s));
+        chk(tfasr_bias2_fwd(k->at_qkv, 3 * HD, fp(TFASR_BP_AT_U), fp(TFASR_BP_AT_V), qu, qvb, rows, HD, c->dtype, s));
+        chk(tfasr_relattn_fused_bwd_k(k->at_qkv, qu, qvb, k->at_pext, io->lengths, datt, k->at_lse, dvec, dqkv, B, H, T, dh, scale, c->use_mask,
+                                      c->dtype, s));
+        chk(tfasr_relattn_dpext(dpos, qvb, io->lengths, dpext, B, H, T, dh, Tp, c->use_mask, c->dtype, s));
+      }
+      qv = qvb;
+      tail_scale = 1.f;
+    } else if (k->fused) {
       float* dvec = f32(scratch, (long)B * H * T);
       void* qu = act(scratch, rows * HD);
       void* qvb = act(scratch, rows * HD);
@@ -377,23 +399,24 @@ struct Ex {
       qv = k->at_qv;
       tail_scale = scale;
     }
-    // dqv = s * dpos @ pext ; dpext (f32) = s * sum_b dpos^T @ qv
-    {
-      G a; a.A = dpos; a.lda = R1p; a.ta = 0; a.B = k->at_pext; a.ldb = HD; a.tb = 0; a.D = dqv; a.ldd = HD; a.M = T; a.N = dh; a.K = R1;
-      a.nb1 = B; a.nb2 = H; a.sA1 = (long)H * T * R1p; a.sA2 = (long)T * R1p; a.sB1 = 0; a.sB2 = dh; a.sD1 = (long)T * HD; a.sD2 = dh;
-      a.alpha = tail_scale;
-      gemm(a);
-    }
-    float* dpext = io->dpext_zero;
-    if (!dpext) {
-      dpext = f32(scratch, (long)R1 * HD);
-      zero(dpext, (size_t)R1 * HD * 4);
-    }
-    {
-      G a; a.A = dpos; a.lda = R1p; a.ta = 1; a.B = qv; a.ldb = HD; a.tb = 0; a.D = dpext; a.ldd = HD; a.M = R1; a.N = dh; a.K = T;
-      a.nb1 = B; a.nb2 = H; a.sA1 = (long)H * T * R1p; a.sA2 = (long)T * R1p; a.sB1 = (long)T * HD; a.sB2 = dh; a.sD1 = 0; a.sD2 = dh;
-      a.alpha = tail_scale; a.out_f32 = 1; a.accumulate = 1;
-      gemm(a);
+    if (!v2) {
+      // dqv = s * dpos @ pext ; dpext (f32) = s * sum_b dpos^T @ qv
+      {
+        G a; a.A = dpos; a.lda = R1p; a.ta = 0; a.B = k->at_pext; a.ldb = HD; a.tb = 0; a.D = dqv; a.ldd = HD; a.M = T; a.N = dh; a.K = R1;
+        a.nb1 = B; a.nb2 = H; a.sA1 = (long)H * T * R1p; a.sA2 = (long)T * R1p; a.sB1 = 0; a.sB2 = dh; a.sD1 = (long)T * HD; a.sD2 = dh;
+        a.alpha = tail_scale;
+        gemm(a);
+      }
+      if (!dpext) {
+        dpext = f32(scratch, (long)R1 * HD);
+        zero(dpext, (size_t)R1 * HD * 4);
+      }
+      {
+        G a; a.A = dpos; a.lda = R1p; a.ta = 1; a.B = qv; a.ldb = HD; a.tb = 0; a.D = dpext; a.ldd = HD; a.M = R1; a.N = dh; a.K = T;
+        a.nb1 = B; a.nb2 = H; a.sA1 = (long)H * T * R1p; a.sA2 = (long)T * R1p; a.sB1 = (long)T * HD; a.sB2 = dh; a.sD1 = 0; a.sD2 = dh;
+        a.alpha = tail_scale; a.out_f32 = 1; a.accumulate = 1;
+        gemm(a);
+      }
     }
     if (!dry) chk(tfasr_bias2_bwd(dqu, dqv, dqkv, 3 * HD, gp(TFASR_BP_AT_U), gp(TFASR_BP_AT_V), rows, HD, c->dtype, s));
     // positional projection: gWpos += pe^T dpext ; gbpos += colsum(dpext)

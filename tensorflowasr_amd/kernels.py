@@ -422,6 +422,23 @@ def relattn_fused_bwd_q(qkv, ubias, vbias, pext, lengths, o, dout, lse, B, H, T,
     return dqu, dpos, dvec
 
 
+def relattn_fused_bwd_q2(qkv, ubias, vbias, pext, lengths, o, dout, lse, dpext, B, H, T, dh, scale, use_mask=True):
+    """Query side without a skewed score gradient in HBM: -> (dqu, dqv, ds [B,H,T,lds], dvec); adds the bias-row share into dpext."""
+    lds = -(-T // 8) * 8
+    dqu = torch.empty(B * T, H * dh, dtype=qkv.dtype, device=qkv.device)
+    dqv = torch.empty(B * T, H * dh, dtype=qkv.dtype, device=qkv.device)
+    ds = torch.empty(B, H, T, lds, dtype=qkv.dtype, device=qkv.device)
+    dvec = torch.empty(B, H, T, dtype=torch.float32, device=qkv.device)
+    check(_L().tfasr_relattn_fused_bwd_q2(_p(qkv), _p(ubias), _p(vbias), _p(pext), _p(lengths), _p(o), _p(dout), _p(lse), _p(dqu), _p(dqv), _p(ds),
+                                          _p(dvec), _p(dpext), B, H, T, dh, lds, scale, int(use_mask), _dt(qkv), _stream()), "relattn_fused_bwd_q2")
+    return dqu, dqv, ds, dvec
+
+
+def relattn_dpext(ds, qv, lengths, dpext, B, H, T, dh, use_mask=True):
+    check(_L().tfasr_relattn_dpext(_p(ds), _p(qv), _p(lengths), _p(dpext), B, H, T, dh, ds.shape[3], int(use_mask), _dt(ds), _stream()), "relattn_dpext")
+    return dpext
+
+
 def relattn_fused_bwd_k(qkv, qu, qv, pext, lengths, dout, lse, dvec, dqkv, B, H, T, dh, scale, use_mask=True):
     check(_L().tfasr_relattn_fused_bwd_k(_p(qkv), _p(qu), _p(qv), _p(pext), _p(lengths), _p(dout), _p(lse), _p(dvec), _p(dqkv), B, H, T, dh,
                                          scale, int(use_mask), _dt(qkv), _stream()), "relattn_fused_bwd_k")

@@ -429,3 +429,65 @@ def test_relattn_fused_backward(dev, T, lens):
     np.testing.assert_allclose(dqkv[:, HD:2 * HD].float().cpu().numpy(), gk.numpy(), rtol=3e-2, atol=3e-2 * float(gk.abs().max()))
     np.testing.assert_allclose(dqkv[:, 2 * HD:].float().cpu().numpy(), gv.numpy(), rtol=3e-2, atol=3e-2 * float(gv.abs().max()))
     assert dqkv[:, :HD].abs().max().item() == 0
+
+
+@pytest.mark.parametrize("T,lens,use_mask", [(75, [75, 75], True), (130, [130, 97], True), (64, [64, 1], True), (200, [150, 200], True),
+                                             (333, [333, 20, 200], True), (130, [130, 60], False)])
+def test_relattn_fused_backward_v2_no_skewed_gradient(dev, T, lens, use_mask):
+    """attn_fused.hip V2: dqv formed inside the query-side kernel, the UNSKEWED dS stored, dpext accumulated by tfasr_relattn_dpext
+    (+ the bias row's share from the query-side kernel): dqu, dqv, dS, dpext, dk, dv against torch autograd of the same attention."""
+    g = torch.Generator().manual_seed(T + 3)
+    B, H, dh = len(lens), 4, 64
+    HD = H * dh
+    qkv = (torch.randn(B * T, 3 * HD, generator=g) * 0.7).to(torch.bfloat16)
+    u, v = torch.randn(HD, generator=g) * 0.3, torch.randn(HD, generator=g) * 0.3
+    pext = (torch.randn(2 * T, HD, generator=g) * 0.7).to(torch.bfloat16)
+    dout = torch.randn(B * T, HD, generator=g).to(torch.bfloat16)
+    scale = 1.0 / 8.0
+    # reference: leaves qu, qv, k, v, pext -> out
+    q = qkv.float()[:, :HD].view(B, T, H, dh)
+    qu = (q + u.view(H, dh)).to(torch.bfloat16).float().requires_grad_(True)
+    qv = (q + v.view(H, dh)).to(torch.bfloat16).float().requires_grad_(True)
+    kk = qkv.float()[:, HD:2 * HD].view(B, T, H, dh).clone().requires_grad_(True)
+    vv = qkv.float()[:, 2 * HD:].view(B, T, H, dh).clone().requires_grad_(True)
+    pe = pext.float().view(2 * T, H, dh).clone().requires_grad_(True)
+    Rr = 2 * T - 1
+    ii, jj = torch.meshgrid(torch.arange(T), torch.arange(T), indexing="ij")
+    idx = torch.zeros(B, T, T, dtype=torch.long)
+    for b in range(B):
+        r = T - 1 - ii + jj
+        idx[b] = torch.where(r < 2 * lens[b] - 1, r + T - lens[b], torch.full_like(r, Rr))
+    pos_all = torch.einsum("bthe,rhe->bhtr", qv, pe)
+    s = (torch.einsum("bthe,bshe->bhts", qu, kk) + torch.gather(pos_all, 3, idx[:, None].expand(B, H, T, T))) * scale
+    if use_mask:
+        qmask = (torch.arange(T)[None] < torch.tensor(lens)[:, None])[:, None, :, None]
+        s = torch.where(qmask, s, torch.zeros_like(s))
+    s.retain_grad()
+    out = torch.einsum("bhts,bshe->bthe", torch.softmax(s, -1), vv).reshape(B * T, HD)
+    out.backward(dout.float())
+    ln = torch.tensor(lens, dtype=torch.int32, device=dev)
+    qd, ud, vd, pd, dod = qkv.to(dev), u.to(dev), v.to(dev), pext.to(dev), dout.to(dev)
+    o_d, lse_d = K.relattn_fused_fwd(qd, ud, vd, pd, ln, B, H, T, dh, scale, use_mask=use_mask)
+    dpext = torch.zeros(2 * T, HD, dtype=torch.float32, device=dev)
+    dqu, dqv, ds, dvec = K.relattn_fused_bwd_q2(qd, ud, vd, pd, ln, o_d, dod, lse_d, dpext, B, H, T, dh, scale, use_mask=use_mask)
+    qud, qvd = K.bias2_fwd(qd, 3 * HD, ud, vd, B * T, HD)
+    dqkv = torch.zeros(B * T, 3 * HD, dtype=torch.bfloat16, device=dev)
+    K.relattn_fused_bwd_k(qd, qud, qvd, pd, ln, dod, lse_d, dvec, dqkv, B, H, T, dh, scale, use_mask=use_mask)
+    K.relattn_dpext(ds, qvd, ln, dpext, B, H, T, dh, use_mask=use_mask)
+    torch.cuda.synchronize()
+
+    def close(a, b, what, tol=3e-2):
+        a, b = a.float().cpu().numpy(), b.numpy()
+        np.testing.assert_allclose(a, b, rtol=tol, atol=tol * float(np.abs(b).max()), err_msg=what)
+
+    close(dqu, qu.grad.reshape(B * T, HD), "dqu")
+    close(dqv, qv.grad.reshape(B * T, HD), "dqv")
+    close(dqkv[:, HD:2 * HD], kk.grad.reshape(B * T, HD), "dk")
+    close(dqkv[:, 2 * HD:], vv.grad.reshape(B * T, HD), "dv")
+    close(dpext, pe.grad.reshape(2 * T, HD), "dpext")
+    # unskewed score gradient (scale folded in), only where the pair reads a real table row (the bias-row pairs are stored as 0)
+    gs = (s.grad * scale)
+    valid = (idx != Rr)[:, None].expand(B, H, T, T)
+    if use_mask:  # masked query rows have constant scores: no gradient flows into them (s.grad above is taken after the fill)
+        valid = valid & (torch.arange(T)[None] < torch.tensor(lens)[:, None])[:, None, :, None]
+    close(ds[..., :T] * valid.to(dev), gs * valid, "ds")
