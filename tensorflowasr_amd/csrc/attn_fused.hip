@@ -582,14 +582,15 @@ __global__ __launch_bounds__(256, 2) void relattn_fused_bwd_q_kernel(
 // is the diagonal of the raw dS tile: element (il, c) sits at column (c - shift - T + 1 + i0 + il) of row il.
 // ======================================================================================================================
 constexpr int DPX_TLD = 208;                              // raw tile row stride in elements (192 columns + alignment slack)
-constexpr int SMEM_DPX = 64 * DPX_TLD * 2 + SK_BYTES;     // raw dS tile + (q+v) block
+constexpr int DPX_CHUNKS = 64 * (DPX_TLD / 8);            // 1664 16-B chunks
+constexpr int DPX_TILE_BYTES = 7 * 256 * 16;              // 7 DMA instructions per wave (the tail lanes land in the slack)
+constexpr int DPX_BUF = DPX_TILE_BYTES + SK_BYTES;        // raw dS tile + (q+v) block
+constexpr int SMEM_DPX = 2 * DPX_BUF;                     // double buffered
 
 __global__ __launch_bounds__(256, 2) void relattn_dpext_kernel(
     const bf16_t* __restrict__ ds, const bf16_t* __restrict__ qv, const int32_t* __restrict__ lengths, float* __restrict__ dpext,
     int B, int H, int T, int lds, int use_mask, int bchunk) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  bf16_t* sT = reinterpret_cast<bf16_t*>(smem);
-  char* sQ = smem + 64 * DPX_TLD * 2;
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int r = lane & 15, g = lane >> 4;
   const int c0 = blockIdx.x * 128, h = blockIdx.y;
@@ -601,56 +602,87 @@ __global__ __launch_bounds__(256, 2) void relattn_dpext_kernel(
 #pragma unroll
     for (int n = 0; n < 4; ++n) acc[ct][n] = float4_t{0.f, 0.f, 0.f, 0.f};
   const int nib = (T + BI - 1) / BI;
-  for (int b = b_lo; b < b_hi; ++b) {
+
+  // (sample, 64-query block) tiles that can reach this block's table rows, in order; `it` = b * nib + ib (uniform over the block)
+  struct Tl { int b, i0, shift, lim, jmin, jb0; };
+  auto tile_at = [&](int it, Tl& t) -> bool {
+    const int b = b_lo + it / nib, ib = it % nib;
     const int len = lengths ? min(lengths[b], T) : T;
-    const int shift = T - len, lim = 2 * len - 1;
-    if (c0 + 128 <= shift || c0 >= shift + lim) continue;  // no valid table row of this sample in the block
-    const bf16_t* dsb = ds + ((long)b * H + h) * T * lds;
-    const bf16_t* qvb = qv + (long)b * T * HD + h * DH;
-    const int nib_b = use_mask ? min(nib, (len + BI - 1) / BI) : nib;  // masked query rows carry dS = 0
-    for (int ib = 0; ib < nib_b; ++ib) {
-      const int i0 = ib * BI;
-      const int jmin = c0 - shift - T + 1 + i0;          // j of (il = 0, c = c0); (il, c) -> jmin + (c - c0) + il
-      if (jmin + 127 + 63 < 0 || jmin >= T) continue;
-      const int jb0 = (jmin >= 0 ? jmin : jmin - 7) / 8 * 8;  // aligned-down tile origin (may be negative)
-      __syncthreads();                                    // previous tile fully consumed
-      load_rows<BI>(sQ, qvb, HD, i0, T, w, lane);
-      for (int q = threadIdx.x; q < 64 * (DPX_TLD / 8); q += 256) {
-        const int il = q / (DPX_TLD / 8), ch = q % (DPX_TLD / 8);
-        const int i = i0 + il, j = jb0 + ch * 8;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (i < T && j >= 0 && j + 8 <= lds) v = *reinterpret_cast<const uint4*>(dsb + (long)i * lds + j);
-        else if (i < T && j + 8 > 0 && j < T) {            // ragged edge: element-wise
-          bf16_t t8[8];
+    t.b = b; t.i0 = ib * BI; t.shift = T - len; t.lim = 2 * len - 1;
+    if (c0 + 128 <= t.shift || c0 >= t.shift + t.lim) return false;   // no valid table row of this sample in the block
+    if (use_mask && t.i0 >= len) return false;                          // masked query rows carry dS = 0
+    t.jmin = c0 - t.shift - T + 1 + t.i0;                                // key index of (il = 0, c = c0); (il, c) -> jmin + (c - c0) + il
+    if (t.jmin + 127 + 63 < 0 || t.jmin >= T) return false;
+    t.jb0 = (t.jmin >= 0 ? t.jmin : t.jmin - 7) / 8 * 8;                  // aligned-down tile origin (may be negative)
+    return true;
+  };
+  const int nit = (b_hi - b_lo) * nib;
+  auto next_valid = [&](int it, Tl& t) -> int {
+    while (it < nit && !tile_at(it, t)) ++it;
+    return it;
+  };
+  // LDS-DMA of one tile: raw dS rows [64][208] (source columns clamped into the row: out-of-range pairs are masked at use) + qv block
+  auto issue = [&](const Tl& t, char* buf) {
+    const bf16_t* dsb = ds + ((long)t.b * H + h) * T * lds;
 #pragma unroll
-          for (int e = 0; e < 8; ++e) t8[e] = (j + e >= 0 && j + e < T) ? dsb[(long)i * lds + j + e] : (bf16_t)0;
-          v = *reinterpret_cast<const uint4*>(t8);
-        }
-        *reinterpret_cast<uint4*>(sT + il * DPX_TLD + ch * 8) = v;
-      }
+    for (int q7 = 0; q7 < 7; ++q7) {
+      const int q = (w * 7 + q7) * 64 + lane;
+      const int qq = min(q, DPX_CHUNKS - 1);
+      const int il = qq / (DPX_TLD / 8), ch = qq % (DPX_TLD / 8);
+      const int i = min(t.i0 + il, T - 1);
+      const int j = min(max(t.jb0 + ch * 8, 0), lds - 8);
+      __builtin_amdgcn_global_load_lds(GLB_PTR(dsb + (long)i * lds + j), LDS_PTR(buf + __builtin_amdgcn_readfirstlane((w * 7 + q7) * 1024)), 16, 0, 0);
+    }
+    load_rows<BI>(buf + DPX_TILE_BYTES, qv + (long)t.b * T * HD + h * DH, HD, t.i0, T, w, lane);
+  };
+
+  Tl cur, nxt;
+  int it = next_valid(0, cur);
+  int buf = 0;
+  if (it < nit) issue(cur, smem);
+  while (it < nit) {
+    const int itn = next_valid(it + 1, nxt);
+    if (itn < nit) {
+      issue(nxt, smem + (buf ^ 1) * DPX_BUF);
+      asm volatile("s_waitcnt vmcnt(9)" ::: "memory");   // this tile's 9 DMA instructions have landed, the next tile's stay in flight
+    } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
+    }
+    __builtin_amdgcn_s_barrier();
+    const bf16_t* sT = reinterpret_cast<const bf16_t*>(smem + buf * DPX_BUF);
+    const char* sQ = smem + buf * DPX_BUF + DPX_TILE_BYTES;
+    const int off = cur.jmin - cur.jb0;                   // tile column of key jmin
+    // a clamped source column shifts the row's content: rows whose first column was clamped (jb0 < 0) are addressed from column 0
+    const int cshift = cur.jb0 < 0 ? cur.jb0 : 0;         // source column of tile column 0 is max(jb0, 0) = jb0 - cshift
 #pragma unroll
-      for (int ct = 0; ct < 2; ++ct) {
-        const int c = c0 + (2 * w + ct) * 16 + r;         // this lane's table row (A row)
-        const int rr = c - shift;
-        const bool cvalid = rr >= 0 && rr < lim && c < R;
-        const int base = (jmin - jb0) + (c - c0);          // column of (il = 0, c) in the raw tile; +il per row
+    for (int ct = 0; ct < 2; ++ct) {
+      const int c = c0 + (2 * w + ct) * 16 + r;           // this lane's table row (A row)
+      const int rr = c - cur.shift;
+      const bool cvalid = rr >= 0 && rr < cur.lim && c < R;
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-          short8_t a;
+      for (int kk = 0; kk < 2; ++kk) {
+        short8_t a;
 #pragma unroll
-          for (int t = 0; t < 8; ++t) {
-            const int il = kk * 32 + g * 8 + t;
-            const int j = jmin + (c - c0) + il;            // real key index: pairs outside [0, T) do not exist
-            a[t] = (cvalid && j >= 0 && j < T) ? (short)sT[il * DPX_TLD + base + il] : (short)0;
-          }
-#pragma unroll
-          for (int n = 0; n < 4; ++n)
-            acc[ct][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, frag_kt(sQ, n * 16, kk * 32 + g * 8, r), acc[ct][n], 0, 0, 0);
+        for (int t = 0; t < 8; ++t) {
+          const int il = kk * 32 + g * 8 + t;
+          const int j = cur.jmin + (c - c0) + il;          // real key index: pairs outside [0, T) do not exist
+          const bool ok = cvalid && j >= 0 && j < T && cur.i0 + il < T;
+          // tile column of key j: chunk (j - jb0) / 8 was fetched from source column clamp(jb0 + 8*chunk): inside [0, T) the clamp is
+          // the identity except when jb0 < 0, where every chunk with a negative origin reads from column 0 (masked: j < 0)
+          const int col = j - cur.jb0;
+          a[t] = ok ? (short)sT[il * DPX_TLD + col] : (short)0;
         }
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+          acc[ct][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, frag_kt(sQ, n * 16, kk * 32 + g * 8, r), acc[ct][n], 0, 0, 0);
       }
     }
+    (void)off; (void)cshift;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                          // everyone is done with this buffer before the tile after next lands in it
+    cur = nxt;
+    it = itn;
+    buf ^= 1;
   }
 #pragma unroll
   for (int ct = 0; ct < 2; ++ct)
