@@ -97,7 +97,7 @@ def pmc_traffic(flops_per_launch, J, V):
     vals = []
     for fl in flops_per_launch:
         cells = fl / (2.0 * J * V)
-        out_mb = cells * V * 2 / 1e6
+        out_mb = cells * (V * 2 + (-(-V // 128) * 2) * 8 + 8) / 1e6  # bf16 logits + the epilogue's row statistics (lse_part, pick)
         m = [r["hbm_MB"] for r in rows if (r["kernel"].startswith("gemm_fast_kernel<false, false, 128, 64>") or r["kernel"].startswith("gemm_fast_kernel<false, false, 128, 0>")) and abs(r["write_MB"] - out_mb) < 0.03 * out_mb]
         if m:
             vals.append(float(np.mean(m)) * 1e6)
