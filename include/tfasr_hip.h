@@ -144,6 +144,10 @@ typedef struct {
      pick[2m+1] = x[m, row_label[m]] (label logit; untouched when row_label[m] < 0).  lse_parts must be ceil(N/128)*2.
      Only the bf16 fast path (plain NN product + bias, 128-wide tiles) implements it: otherwise tfasr_gemm returns UNSUPPORTED. */
   float* lse_part; int lse_parts; const int32_t* row_label; float* pick;
+  /* Optional K-segments (bf16 fast path, plain or bias epilogue, no split-K, K % 64 == 0, seg_k % 64 == 0, K / 64 <= 64): the k
+     range [s*seg_k, (s+1)*seg_k) reads op(A) from A + seg_a_off[s] and (when seg_b_off != NULL) op(B) from B + seg_b_off[s]
+     (element offsets, DEVICE arrays of K / seg_k entries) instead of a contiguous K: a convolution tap = the same rows shifted. */
+  const long* seg_a_off; const long* seg_b_off; int seg_k;
 } tfasr_gemm_args;
 
 int tfasr_gemm(const tfasr_gemm_args* args, void* stream);
@@ -321,6 +325,20 @@ int tfasr_conv1_fwd(const void* x, const float* w, const float* bias, void* y, i
                     void* stream);
 int tfasr_conv1_bwd_weight(const void* x, const void* dy, float* dw, float* db, int B, int T0, int F0, int C,
                            int dtype, void* stream);
+/* Haloed space-to-depth ("S") layout of a channel-last [B, T1, F1, C] activation: [B, T2+1, F2+1, 2, 2, C] (T2 = ceil(T1/2),
+ * F2 = ceil(F1/2)); element (b, t, f, :) lives in row (b, t/2+1, f/2+1), parity block (t%2, f%2); row 0 / column 0 of every sample
+ * and the slots past an odd T1 / F1 are zero.  There the input of tap (kh, kw) of the causal 3x3 stride-2 Conv2D
+ * (subsampling.py:218-230, convolution.py:25-37,132-144) for output row (b, tt, ff) is the same row index shifted by a constant,
+ * so conv2 forward / data gradient are tfasr_gemm calls with K-segments (tfasr_gemm_args.seg_*) and its weight gradient is 9
+ * shifted-pointer products (tfasr_gemm_group): no patch matrix exists.  _s2d variants of conv1 write / read that layout directly
+ * (only the valid slots); tfasr_halo_zero clears the halo rows of a [B, T2+1, F2+1, W] tensor, tfasr_s2d_edge_zero the slots past
+ * an odd edge. */
+int tfasr_conv1_fwd_s2d(const void* x, const float* w, const float* bias, void* y, int B, int T0, int F0, int C, int dtype,
+                        void* stream);
+int tfasr_conv1_bwd_weight_s2d(const void* x, const void* dy, float* dw, float* db, int B, int T0, int F0, int C, int dtype,
+                               void* stream);
+int tfasr_halo_zero(void* x, int B, int T2, int F2, int W, int dtype, void* stream);
+int tfasr_s2d_edge_zero(void* x, int B, int T1, int F1, int C, int dtype, void* stream);
 int tfasr_im2col_3x3s2(const void* x, void* col, int B, int T1, int F1, int C, int dtype, void* stream);
 int tfasr_col2im_3x3s2(const void* dcol, void* dx, int B, int T1, int F1, int C, int dtype, void* stream);
 

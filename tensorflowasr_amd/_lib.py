@@ -32,6 +32,7 @@ class GemmArgs(Structure):
         ("drop_p", c_float), ("drop_seed", c_long),
         ("ws", c_void_p), ("ws_elems", c_long), ("colsum", c_void_p),
         ("lse_part", c_void_p), ("lse_parts", c_int), ("row_label", c_void_p), ("pick", c_void_p),
+        ("seg_a_off", c_void_p), ("seg_b_off", c_void_p), ("seg_k", c_int),
     ]
 
 

@@ -198,30 +198,31 @@ class ConformerTransducer:
         return (None if fm is None else torch.from_numpy(fm)), (None if tm is None else torch.from_numpy(tm))
 
     # =================================================================================== batch norm
-    def _bn_fwd(self, x2d, name, training, act):
+    def _bn_fwd(self, x2d, name, training, act, rows=None, y=None):
+        """rows: number of REAL rows when x2d carries exactly-zero padding rows (haloed layouts): zeros change neither sum."""
         ps = self.ps
         C = x2d.shape[1]
         fin = torch.empty(4 * C, dtype=torch.float32, device=self.device)
         if training:
             stats = torch.zeros(2 * C + 1, dtype=torch.float32, device=self.device)
             K.bn_stats(x2d, stats)
-            count = x2d.shape[0] * self.dp.world
+            count = (x2d.shape[0] if rows is None else rows) * self.dp.world
             self.dp.allreduce_stats_(stats[:2 * C])
             K.bn_finalize(stats, count, ps.p(name + "/g"), ps.p(name + "/b"), fin, ps.state[name + "/mm"], ps.state[name + "/mv"], 0.99, 1e-3, True)
         else:
             count = x2d.shape[0]
             K.bn_finalize(None, 1, ps.p(name + "/g"), ps.p(name + "/b"), fin, ps.state[name + "/mm"], ps.state[name + "/mv"], 0.99, 1e-3, False)
-        y = K.bn_apply_fwd(x2d, fin, act)
+        y = K.bn_apply_fwd(x2d, fin, act, y=y)
         return y, (fin, count)
 
-    def _bn_bwd(self, x2d, dy2d, name, saved, act):
+    def _bn_bwd(self, x2d, dy2d, name, saved, act, dx=None):
         fin, count = saved
         ps = self.ps
         C = x2d.shape[1]
         bstats = torch.zeros(2 * C, dtype=torch.float32, device=self.device)
         K.bn_bwd_stats(x2d, dy2d, fin, bstats, act)
         self.dp.allreduce_stats_(bstats)
-        dx = K.bn_apply_bwd(x2d, dy2d, fin, bstats, count, act)
+        dx = K.bn_apply_bwd(x2d, dy2d, fin, bstats, count, act, dx=dx)
         # bstats = (sum dz, sum dz*xhat) over the GLOBAL batch; the flat-gradient all-reduce sums over ranks again
         inv = 1.0 / self.dp.world
         K.axpy(ps.g(name + "/b"), bstats[:C].contiguous(), inv)
@@ -229,7 +230,135 @@ class ConformerTransducer:
         return dx
 
     # =================================================================================== subsampling
+    # ---- conv2 without a patch matrix: haloed space-to-depth layout (csrc/conv2d.hip, include/tfasr_hip.h) -----------------
+    _SEG = [(kh, kw) for kh in range(3) for kw in range(3)]
+
+    def _s2d_enabled(self):
+        if os.environ.get("TFASR_CONV2_IM2COL", "0") == "1":
+            return False
+        # bf16: the K-segmented MFMA GEMM needs whole 64-wide slabs per tap; f32 (parity mode) issues one product per tap
+        return self.dtype == torch.float32 or self.cfg.filters % 64 == 0
+
+    def _salloc(self, rows, width, slack):
+        """[rows, width] buffer with `slack` zeroed rows before and after it (tap shifts reach outside the first / last sample)."""
+        full = torch.empty((rows + 2 * slack) * width, dtype=self.dtype, device=self.device)
+        full[:slack * width].zero_()
+        full[(slack + rows) * width:].zero_()
+        return full, full[slack * width:(slack + rows) * width].view(rows, width)
+
+    def _seg_tables(self, F2, C):
+        """per tap (kh, kw): (row shift, parity block) of its input in the S layout + device offset tables for the segmented GEMMs."""
+        key = ("seg", F2, C)
+        if key not in self._consts:
+            shift, blk = [], []
+            for kh, kw in self._SEG:
+                dt, pt = (-1, kh) if kh < 2 else (0, 0)
+                df, pf = (-1, kw) if kw < 2 else (0, 0)
+                shift.append(dt * (F2 + 1) + df)
+                blk.append(pt * 2 + pf)
+            dev = self.device
+            fwd_a = torch.tensor([sh * 4 * C + b * C for sh, b in zip(shift, blk)], dtype=torch.int64, device=dev)
+            dgrad = {}
+            for b in range(4):
+                segs = [i for i in range(9) if blk[i] == b]
+                dgrad[b] = (segs, torch.tensor([-shift[i] * C for i in segs], dtype=torch.int64, device=dev),
+                            torch.tensor([i * C * C for i in segs], dtype=torch.int64, device=dev))
+            self._consts[key] = (shift, blk, fwd_a, dgrad)
+        return self._consts[key]
+
+    def _subsampling_fwd_s2d(self, feats, flen, training, ctx):
+        ps, c = self.ps, self.cfg
+        B, T0, F0 = feats.shape
+        C = c.filters
+        T1, F1 = (T0 + 1) // 2, (F0 + 1) // 2
+        T2, F2 = (T1 + 1) // 2, (F1 + 1) // 2
+        rows, slack = B * (T2 + 1) * (F2 + 1), F2 + 2
+        shift, blk, fwd_a, _ = self._seg_tables(F2, C)
+        # conv1 -> S layout, BatchNorm + swish in place of the layout (halo slots are exactly zero, so they change no statistic)
+        _, s1 = self._salloc(rows, 4 * C, slack)
+        K.conv1_fwd_s2d(feats, ps.p("enc/sub/conv0/w"), ps.p("enc/sub/conv0/b"), s1)
+        K.halo_zero(s1, B, T2, F2, 4 * C)
+        K.s2d_edge_zero(s1, B, T1, F1, C)
+        a1_full, a1 = self._salloc(rows, 4 * C, slack)
+        _, bn0 = self._bn_fwd(s1.view(-1, C), "enc/sub/bn0", training, ACT_SWISH, rows=B * T1 * F1, y=a1.view(-1, C))
+        K.halo_zero(a1, B, T2, F2, 4 * C)
+        K.s2d_edge_zero(a1, B, T1, F1, C)
+        # conv2: every tap reads the same rows shifted by a constant -> one GEMM over 9 K-segments (bf16) / 9 products (f32)
+        W = ps.w2d("enc/sub/conv1/w")  # [9C, C]
+        _, o = self._salloc(rows, C, slack)
+        if self.dtype == torch.float32:
+            flat, base = a1_full, slack * 4 * C
+            for i in range(9):
+                K.gemm(flat[base + shift[i] * 4 * C + blk[i] * C:], W[i * C:(i + 1) * C], o, rows, C, C, 4 * C, C, C,
+                       bias=ps.p("enc/sub/conv1/b") if i == 0 else None, accumulate=i > 0)
+        else:
+            K.gemm(a1, W, o, rows, C, 9 * C, 4 * C, C, C, bias=ps.p("enc/sub/conv1/b"), seg=(fwd_a, None, C))
+        K.halo_zero(o, B, T2, F2, C)
+        _, a2 = self._salloc(rows, C, 0)
+        _, bn1 = self._bn_fwd(o, "enc/sub/bn1", training, ACT_SWISH, rows=B * T2 * F2, y=a2)
+        K.halo_zero(a2, B, T2, F2, C)  # finite halos: the linear layer's weight gradient runs over all (b, tt) rows
+        # linear over merge_two_last_dims: rows (b, tt >= 1), columns (ff >= 1, c) = one strided batch view of a2
+        drop = self._drop(0, training)
+        d = c.dmodel
+        x0 = torch.empty(B * T2, d, dtype=self.dtype, device=self.device)
+        a2flat = a2.view(-1)
+        K.gemm(a2flat[((F2 + 1) + 1) * C:], ps.w2d("enc/linear/w"), x0, T2, d, F2 * C, (F2 + 1) * C, d, d, bias=ps.p("enc/linear/b"),
+               nb1=B, sA=((T2 + 1) * (F2 + 1) * C, 0), sD=(T2 * d, 0), drop_p=drop[0], drop_seed=drop[1])
+        elen = [-(-(-(-n // 2)) // 2) for n in flen]
+        if ctx is not None:
+            ctx["sub"] = dict(s2d=True, feats=feats, s1=s1, bn0=bn0, a1=a1, a1_full=a1_full, o=o, bn1=bn1, a2=a2,
+                              dims=(B, T0, F0, T1, F1, T2, F2), drop=drop)
+        return x0, T2, elen
+
+    def _subsampling_bwd_s2d(self, dx0, ctx):
+        ps, c = self.ps, self.cfg
+        s = ctx["sub"]
+        B, T0, F0, T1, F1, T2, F2 = s["dims"]
+        C, d = c.filters, c.dmodel
+        rows, slack = B * (T2 + 1) * (F2 + 1), F2 + 2
+        shift, blk, _, dgrad = self._seg_tables(F2, C)
+        dx0m = self._mask_grad(dx0, s["drop"])
+        # gradient rows in the (b, tt) indexing of the S layout: one zero row per sample in front (plain device copy)
+        dx0h = torch.zeros(B, T2 + 1, d, dtype=self.dtype, device=self.device)
+        dx0h[:, 1:].copy_(dx0m.view(B, T2, d))
+        dx0h = dx0h.view(B * (T2 + 1), d)
+        a2flat = s["a2"].view(-1)
+        K.gemm(a2flat[C:], dx0h, ps.g2d("enc/linear/w"), F2 * C, d, B * (T2 + 1), (F2 + 1) * C, d, d, trans_a=True, accumulate=True,
+               split_k=_split_k(F2 * C, d, B * (T2 + 1)), colsum=ps.g("enc/linear/b"))
+        _, da2 = self._salloc(rows, C, 0)
+        K.gemm(dx0h, ps.w2d("enc/linear/w"), da2.view(-1)[C:], B * (T2 + 1), F2 * C, d, d, d, (F2 + 1) * C, trans_b=True)
+        K.halo_zero(da2, B, T2, F2, C)
+        do_full, do = self._salloc(rows, C, slack)
+        self._bn_bwd(s["o"], da2, "enc/sub/bn1", s["bn1"], ACT_SWISH, dx=do)
+        K.halo_zero(do, B, T2, F2, C)
+        # conv2 weight gradient: 9 products gW[tap] += a1[rows shifted by the tap]^T @ do; bias gradient = column sums of do
+        a1_full, base = s["a1_full"], slack * 4 * C
+        gW = ps.g2d("enc/sub/conv1/w")
+        calls = []
+        for i in range(9):
+            calls.append(dict(A=a1_full[base + shift[i] * 4 * C + blk[i] * C:], B=do, out=gW[i * C:(i + 1) * C], M=C, N=C, K=rows, lda=4 * C, ldb=C,
+                              ldd=C, trans_a=True, accumulate=True, split_k=_split_k(C, C, rows), colsum=ps.g("enc/sub/conv1/b") if i == 0 else None))
+        K.gemm_group(calls)
+        # conv2 data gradient, one product per parity block of the S layout: da1[:, block] = sum over its taps of do[rows shifted back] @ W[tap]^T
+        W = ps.w2d("enc/sub/conv1/w")
+        _, da1 = self._salloc(rows, 4 * C, 0)
+        dobase = slack * C
+        for b4 in range(4):
+            segs, a_off, b_off = dgrad[b4]
+            out = da1.view(-1)[b4 * C:]
+            if self.dtype == torch.float32:
+                for j, i in enumerate(segs):
+                    K.gemm(do_full[dobase - shift[i] * C:], W[i * C:(i + 1) * C], out, rows, C, C, C, C, 4 * C, trans_b=True, accumulate=j > 0)
+            else:
+                K.gemm(do, W, out, rows, C, len(segs) * C, C, C, 4 * C, trans_b=True, seg=(a_off, b_off, C))
+        K.halo_zero(da1, B, T2, F2, 4 * C)
+        K.s2d_edge_zero(da1, B, T1, F1, C)
+        ds1 = self._bn_bwd(s["s1"].view(-1, C), da1.view(-1, C), "enc/sub/bn0", s["bn0"], ACT_SWISH)
+        K.conv1_bwd_weight_s2d(s["feats"], ds1, ps.g("enc/sub/conv0/w"), ps.g("enc/sub/conv0/b"), C)
+
     def _subsampling_fwd(self, feats, flen, training, ctx):
+        if self._s2d_enabled():
+            return self._subsampling_fwd_s2d(feats, flen, training, ctx)
         ps, c = self.ps, self.cfg
         B, T0, F0 = feats.shape
         C = c.filters
@@ -250,6 +379,8 @@ class ConformerTransducer:
         return x0, T2, elen
 
     def _subsampling_bwd(self, dx0, ctx):
+        if ctx["sub"].get("s2d"):
+            return self._subsampling_bwd_s2d(dx0, ctx)
         ps, c = self.ps, self.cfg
         s = ctx["sub"]
         B, T0, F0, T1, F1, T2, F2 = s["dims"]

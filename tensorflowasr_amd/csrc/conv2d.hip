@@ -10,12 +10,20 @@ namespace {
 
 inline int flat_grid(long n) { return (int)std::max<long>(1, std::min<long>((n + 255) / 256, 256L * 32)); }
 
+// Haloed space-to-depth ("S") layout of a [B, T1, F1, C] activation: [B, T2+1, F2+1, 2, 2, C] with T2 = ceil(T1/2), F2 = ceil(F1/2);
+// element (b, t, f, :) sits in row (b, t/2 + 1, f/2 + 1), parity block (t%2, f%2); row 0 / column 0 of every sample and the
+// slots past an odd T1 / F1 are zero.  In this layout the input of tap (kh, kw) of the causal 3x3 stride-2 conv for output row
+// (b, tt, ff) is the SAME row shifted by a constant, so conv2 is a plain GEMM over 9 K-segments (no patch matrix).
+__device__ __forceinline__ long s2d_off(int b, int t, int f, int T2, int F2, int C) {
+  return ((((long)b * (T2 + 1) + (t >> 1) + 1) * (F2 + 1) + (f >> 1) + 1) * 4 + ((t & 1) * 2 + (f & 1))) * C;
+}
+
 // y[b,t,f,c] = bias[c] + sum_{kh,kw} w[kh,kw,0,c] * x[b, 2t+kh-2, 2f+kw-2]
 // The grid stride is a multiple of C/8, so every thread keeps ONE channel group: its 72 taps + 8 biases live in registers.
 template <typename T>
 __global__ __launch_bounds__(256) void conv1_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ bias, T* __restrict__ y, int B, int T0,
-                                                        int F0, int T1, int F1, int C) {
+                                                        int F0, int T1, int F1, int C, int s2d) {
   const int c8n = C / 8;
   const long n8 = (long)B * T1 * F1 * c8n;
   const long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -48,7 +56,7 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const T* __restrict__ x,
         for (int k = 0; k < 8; ++k) acc[k] += wr[kh * 3 + kw][k] * xv;
       }
     }
-    st8(y + i * 8, acc);
+    st8(s2d ? y + s2d_off(b, t, f, (T1 + 1) / 2, (F1 + 1) / 2, C) + c : y + i * 8, acc);
   }
 }
 
@@ -57,7 +65,7 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const T* __restrict__ x,
 template <typename T, int LPR>
 __global__ __launch_bounds__(256) void conv1_bwd_weight_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                                float* __restrict__ dw, float* __restrict__ db, int B,
-                                                               int T0, int F0, int T1, int F1, int C) {
+                                                               int T0, int F0, int T1, int F1, int C, int s2d) {
   constexpr int PPW = 64 / LPR;
   __shared__ float red[4][10][LPR * 8 + 1];
   const int lane = threadIdx.x & 63, li = lane % LPR, sub = lane / LPR, w = threadIdx.x >> 6;
@@ -77,7 +85,7 @@ __global__ __launch_bounds__(256) void conv1_bwd_weight_kernel(const T* __restri
       const int t = (int)(pp % T1);
       const int b = (int)(pp / T1);
       float d[8];
-      ld8(dy + pos * C + c0, d);
+      ld8(s2d ? dy + s2d_off(b, t, f, (T1 + 1) / 2, (F1 + 1) / 2, C) + c0 : dy + pos * C + c0, d);
 #pragma unroll
       for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
@@ -115,7 +123,7 @@ __global__ __launch_bounds__(256) void conv1_bwd_weight_kernel(const T* __restri
 template <typename T>
 __global__ __launch_bounds__(256) void conv1_fwd_rows_kernel(const T* __restrict__ x, const float* __restrict__ w,
                                                              const float* __restrict__ bias, T* __restrict__ y, int B, int T0,
-                                                             int F0, int T1, int F1) {
+                                                             int F0, int T1, int F1, int s2d) {
   constexpr int C = 256;
   __shared__ float xs[3][260];
   const int c = (threadIdx.x & 31) * 8, fs = threadIdx.x >> 5;
@@ -147,7 +155,7 @@ __global__ __launch_bounds__(256) void conv1_fwd_rows_kernel(const T* __restrict
 #pragma unroll
           for (int k = 0; k < 8; ++k) acc[k] += wr[kh * 3 + kw][k] * xv;
         }
-      st8(y + ((long)row * F1 + f) * C + c, acc);
+      st8(s2d ? y + s2d_off(b, t, f, (T1 + 1) / 2, (F1 + 1) / 2, C) + c : y + ((long)row * F1 + f) * C + c, acc);
     }
   }
 }
@@ -155,7 +163,7 @@ __global__ __launch_bounds__(256) void conv1_fwd_rows_kernel(const T* __restrict
 template <typename T>
 __global__ __launch_bounds__(256) void conv1_bwd_weight_rows_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                                     float* __restrict__ dw, float* __restrict__ db, int B, int T0,
-                                                                    int F0, int T1, int F1) {
+                                                                    int F0, int T1, int F1, int s2d) {
   constexpr int C = 256;
   __shared__ float xs[3][260];
   __shared__ float red[4][10][C + 1];
@@ -177,7 +185,7 @@ __global__ __launch_bounds__(256) void conv1_bwd_weight_rows_kernel(const T* __r
     __syncthreads();
     for (int f = fs; f < F1; f += 8) {
       float d[8];
-      ld8(dy + ((long)row * F1 + f) * C + c, d);
+      ld8(s2d ? dy + s2d_off(b, t, f, (T1 + 1) / 2, (F1 + 1) / 2, C) + c : dy + ((long)row * F1 + f) * C + c, d);
 #pragma unroll
       for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
@@ -265,21 +273,55 @@ __global__ __launch_bounds__(256) void col2im_kernel(const T* __restrict__ dcol,
   }
 }
 
+// Zero the halo rows (tt == 0 or ff == 0) of a [B, T2+1, F2+1, W] tensor (W = 4C for the S layout, C for the conv2 output side).
+template <typename T>
+__global__ __launch_bounds__(256) void halo_zero_kernel(T* __restrict__ x, int B, int T2, int F2, int W) {
+  const int w8 = W / 8, per_b = (F2 + 1) + T2;
+  const long n = (long)B * per_b * w8;
+  const float z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int c8 = (int)(i % w8);
+    long r = i / w8;
+    const int k = (int)(r % per_b), b = (int)(r / per_b);
+    const int tt = k <= F2 ? 0 : k - F2, ff = k <= F2 ? k : 0;
+    st8(x + (((long)b * (T2 + 1) + tt) * (F2 + 1) + ff) * W + (long)c8 * 8, z);
+  }
+}
+// Zero the slots of an S-layout tensor past an odd T1 (row tt = T2, parity pt = 1) / odd F1 (column ff = F2, parity pf = 1): only
+// those slots are visited (the first version scanned every slot of the tensor: 135 us for a 1 GB activation).
+template <typename T>
+__global__ __launch_bounds__(256) void s2d_edge_zero_kernel(T* __restrict__ x, int B, int T1, int F1, int T2, int F2, int C) {
+  const int c8n = C / 8;
+  const int nt = (T1 & 1) ? F2 * 2 : 0;          // (ff in 1..F2) x (pf in 0..1) at tt = T2, pt = 1
+  const int nf = (F1 & 1) ? T2 * 2 : 0;          // (tt in 1..T2) x (pt in 0..1) at ff = F2, pf = 1
+  const long n = (long)B * (nt + nf) * c8n;
+  const float z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int c8 = (int)(i % c8n);
+    long r = i / c8n;
+    const int k = (int)(r % (nt + nf)), b = (int)(r / (nt + nf));
+    int tt, ff, blk;
+    if (k < nt) { tt = T2; ff = 1 + (k >> 1); blk = 2 + (k & 1); }
+    else { const int q = k - nt; tt = 1 + (q >> 1); ff = F2; blk = (q & 1) * 2 + 1; }
+    st8(x + ((((long)b * (T2 + 1) + tt) * (F2 + 1) + ff) * 4 + blk) * C + (long)c8 * 8, z);
+  }
+}
+
 }  // namespace
 
 #define DISPATCH_T(dtype, CALL_F32, CALL_BF16) \
   do { if ((dtype) == TFASR_F32) { CALL_F32; } else if ((dtype) == TFASR_BF16) { CALL_BF16; } else return TFASR_STATUS_INVALID_VALUE; } while (0)
 
-extern "C" int tfasr_conv1_fwd(const void* x, const float* w, const float* bias, void* y, int B, int T0, int F0, int C,
-                               int dtype, void* stream_) {
+static int conv1_fwd_impl(const void* x, const float* w, const float* bias, void* y, int B, int T0, int F0, int C,
+                          int dtype, void* stream_, int s2d) {
   if (!x || !w || !y || B <= 0 || T0 <= 0 || F0 <= 0 || C <= 0 || C % 8) return TFASR_STATUS_INVALID_VALUE;
   const int T1 = (T0 + 1) / 2, F1 = (F0 + 1) / 2;
   hipStream_t s = (hipStream_t)stream_;
   if (C == 256 && F0 + 2 <= 260) {
     const int g2 = std::min(B * T1, 8192);
     DISPATCH_T(dtype,
-               hipLaunchKernelGGL(conv1_fwd_rows_kernel<float>, dim3(g2), dim3(256), 0, s, (const float*)x, w, bias, (float*)y, B, T0, F0, T1, F1),
-               hipLaunchKernelGGL(conv1_fwd_rows_kernel<bf16_t>, dim3(g2), dim3(256), 0, s, (const bf16_t*)x, w, bias, (bf16_t*)y, B, T0, F0, T1, F1));
+               hipLaunchKernelGGL(conv1_fwd_rows_kernel<float>, dim3(g2), dim3(256), 0, s, (const float*)x, w, bias, (float*)y, B, T0, F0, T1, F1, s2d),
+               hipLaunchKernelGGL(conv1_fwd_rows_kernel<bf16_t>, dim3(g2), dim3(256), 0, s, (const bf16_t*)x, w, bias, (bf16_t*)y, B, T0, F0, T1, F1, s2d));
     TFASR_CHECK_LAUNCH();
     return TFASR_STATUS_SUCCESS;
   }
@@ -289,30 +331,70 @@ extern "C" int tfasr_conv1_fwd(const void* x, const float* w, const float* bias,
     grid = ((grid + c8n - 1) / c8n) * c8n;
   }
   DISPATCH_T(dtype,
-             hipLaunchKernelGGL(conv1_fwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, w, bias, (float*)y, B, T0, F0, T1, F1, C),
-             hipLaunchKernelGGL(conv1_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)x, w, bias, (bf16_t*)y, B, T0, F0, T1, F1, C));
+             hipLaunchKernelGGL(conv1_fwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, w, bias, (float*)y, B, T0, F0, T1, F1, C, s2d),
+             hipLaunchKernelGGL(conv1_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)x, w, bias, (bf16_t*)y, B, T0, F0, T1, F1, C, s2d));
   TFASR_CHECK_LAUNCH();
   return TFASR_STATUS_SUCCESS;
 }
 
-extern "C" int tfasr_conv1_bwd_weight(const void* x, const void* dy, float* dw, float* db, int B, int T0, int F0, int C,
-                                      int dtype, void* stream_) {
+extern "C" int tfasr_conv1_fwd(const void* x, const float* w, const float* bias, void* y, int B, int T0, int F0, int C,
+                               int dtype, void* stream_) {
+  return conv1_fwd_impl(x, w, bias, y, B, T0, F0, C, dtype, stream_, 0);
+}
+extern "C" int tfasr_conv1_fwd_s2d(const void* x, const float* w, const float* bias, void* y, int B, int T0, int F0, int C,
+                                   int dtype, void* stream_) {
+  return conv1_fwd_impl(x, w, bias, y, B, T0, F0, C, dtype, stream_, 1);
+}
+
+static int conv1_bwd_weight_impl(const void* x, const void* dy, float* dw, float* db, int B, int T0, int F0, int C,
+                                 int dtype, void* stream_, int s2d) {
   if (!x || !dy || !dw || B <= 0 || T0 <= 0 || F0 <= 0 || C <= 0 || C > 256 || (C % 8)) return TFASR_STATUS_INVALID_VALUE;
   const int T1 = (T0 + 1) / 2, F1 = (F0 + 1) / 2;
   hipStream_t s = (hipStream_t)stream_;
   if (C == 256 && F0 + 2 <= 260) {
     const int g2 = std::min(B * T1, 1024);
     DISPATCH_T(dtype,
-               hipLaunchKernelGGL(conv1_bwd_weight_rows_kernel<float>, dim3(g2), dim3(256), 0, s, (const float*)x, (const float*)dy, dw, db, B, T0, F0, T1, F1),
-               hipLaunchKernelGGL(conv1_bwd_weight_rows_kernel<bf16_t>, dim3(g2), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)dy, dw, db, B, T0, F0, T1, F1));
+               hipLaunchKernelGGL(conv1_bwd_weight_rows_kernel<float>, dim3(g2), dim3(256), 0, s, (const float*)x, (const float*)dy, dw, db, B, T0, F0, T1, F1, s2d),
+               hipLaunchKernelGGL(conv1_bwd_weight_rows_kernel<bf16_t>, dim3(g2), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)dy, dw, db, B, T0, F0, T1, F1, s2d));
     TFASR_CHECK_LAUNCH();
     return TFASR_STATUS_SUCCESS;
   }
   const long npos = (long)B * T1 * F1;
   const int grid = (int)std::max<long>(1, std::min<long>(npos / 64 + 1, 1024));
   DISPATCH_T(dtype,
-             hipLaunchKernelGGL((conv1_bwd_weight_kernel<float, 32>), dim3(grid), dim3(256), 0, s, (const float*)x, (const float*)dy, dw, db, B, T0, F0, T1, F1, C),
-             hipLaunchKernelGGL((conv1_bwd_weight_kernel<bf16_t, 32>), dim3(grid), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)dy, dw, db, B, T0, F0, T1, F1, C));
+             hipLaunchKernelGGL((conv1_bwd_weight_kernel<float, 32>), dim3(grid), dim3(256), 0, s, (const float*)x, (const float*)dy, dw, db, B, T0, F0, T1, F1, C, s2d),
+             hipLaunchKernelGGL((conv1_bwd_weight_kernel<bf16_t, 32>), dim3(grid), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)dy, dw, db, B, T0, F0, T1, F1, C, s2d));
+  TFASR_CHECK_LAUNCH();
+  return TFASR_STATUS_SUCCESS;
+}
+
+extern "C" int tfasr_conv1_bwd_weight(const void* x, const void* dy, float* dw, float* db, int B, int T0, int F0, int C,
+                                      int dtype, void* stream_) {
+  return conv1_bwd_weight_impl(x, dy, dw, db, B, T0, F0, C, dtype, stream_, 0);
+}
+extern "C" int tfasr_conv1_bwd_weight_s2d(const void* x, const void* dy, float* dw, float* db, int B, int T0, int F0, int C,
+                                          int dtype, void* stream_) {
+  return conv1_bwd_weight_impl(x, dy, dw, db, B, T0, F0, C, dtype, stream_, 1);
+}
+
+extern "C" int tfasr_halo_zero(void* x, int B, int T2, int F2, int W, int dtype, void* stream_) {
+  if (!x || B <= 0 || T2 <= 0 || F2 <= 0 || W <= 0 || W % 8) return TFASR_STATUS_INVALID_VALUE;
+  hipStream_t s = (hipStream_t)stream_;
+  const int grid = flat_grid((long)B * ((F2 + 1) + T2) * (W / 8));
+  DISPATCH_T(dtype, hipLaunchKernelGGL(halo_zero_kernel<float>, dim3(grid), dim3(256), 0, s, (float*)x, B, T2, F2, W),
+             hipLaunchKernelGGL(halo_zero_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (bf16_t*)x, B, T2, F2, W));
+  TFASR_CHECK_LAUNCH();
+  return TFASR_STATUS_SUCCESS;
+}
+
+extern "C" int tfasr_s2d_edge_zero(void* x, int B, int T1, int F1, int C, int dtype, void* stream_) {
+  if (!x || B <= 0 || T1 <= 0 || F1 <= 0 || C <= 0 || C % 8) return TFASR_STATUS_INVALID_VALUE;
+  if (!(T1 & 1) && !(F1 & 1)) return TFASR_STATUS_SUCCESS;  // nothing past the edge
+  const int T2 = (T1 + 1) / 2, F2 = (F1 + 1) / 2;
+  hipStream_t s = (hipStream_t)stream_;
+  const int grid = flat_grid((long)B * (((T1 & 1) ? F2 * 2 : 0) + ((F1 & 1) ? T2 * 2 : 0)) * (C / 8));
+  DISPATCH_T(dtype, hipLaunchKernelGGL(s2d_edge_zero_kernel<float>, dim3(grid), dim3(256), 0, s, (float*)x, B, T1, F1, T2, F2, C),
+             hipLaunchKernelGGL(s2d_edge_zero_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (bf16_t*)x, B, T1, F1, T2, F2, C));
   TFASR_CHECK_LAUNCH();
   return TFASR_STATUS_SUCCESS;
 }

@@ -330,10 +330,11 @@ extern "C" int tfasr_gemm(const tfasr_gemm_args* args, void* stream_) {
   if (a.colsum && !(a.accumulate && a.trans_a && !a.trans_b && a.nb1 * a.nb2 == 1)) return TFASR_STATUS_INVALID_VALUE;
   hipStream_t stream = (hipStream_t)stream_;
   if (a.dtype == TFASR_BF16 && use_fast_path()) {
-    const int st = (use_pipe_path() && !a.lse_part) ? tfasr_gemm_pipe_try(a, stream) : tfasr_gemm_fast_try(a, stream);
+    const int st = (use_pipe_path() && !a.lse_part && !a.seg_a_off) ? tfasr_gemm_pipe_try(a, stream) : tfasr_gemm_fast_try(a, stream);
     if (st != TFASR_STATUS_UNSUPPORTED) return st;
   }
   if (a.lse_part) return TFASR_STATUS_UNSUPPORTED;  // only the bf16 fast path's epilogue produces the row statistics
+  if (a.seg_a_off) return TFASR_STATUS_UNSUPPORTED;  // K-segments: bf16 fast path only (the f32 host path issues one product per segment)
   if (a.colsum) {  // the generic kernels do not fuse the bias gradient: one extra pass over B = dy
     const int st = tfasr_colsum(a.B, a.ldb, a.colsum, a.K, a.N, a.alpha, a.dtype, stream_);
     if (st != TFASR_STATUS_SUCCESS) return st;

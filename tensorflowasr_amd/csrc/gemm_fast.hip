@@ -226,7 +226,8 @@ enum : int { E_ACT = 1 /* swish(+prez) */, E_DACT = 2 /* * swish'(dact_z) */, E_
 // goes into the stage slab s-1 was read from, TWO slabs in flight under the MFMAs - for long-K products on HBM-cold operands
 // (weight gradients), whose main loop runs at the DMA round trip per slab with a single slab in flight).
 // FIXED: the caller chose this workgroup's tile itself: bid = tile index inside the gx x gy grid, G = its k-slice (grouped launch).
-template <bool TA, bool TB, int BN_, int EPI, int NST = 2, bool FIXED = false>
+// SEG: K-segments (tfasr_gemm_args.seg_*): slab s of the k loop reads its operands at a table offset instead of s * BK.
+template <bool TA, bool TB, int BN_, int EPI, int NST = 2, bool FIXED = false, bool SEG = false>
 __device__ __forceinline__ void gemm_fast_body(const tfasr_gemm_args& p, const int gx, const int gy, const int gz, const int ntiles, const int bid, const int G) {
   constexpr bool GEN = (EPI & E_GEN) != 0;
   constexpr bool C_ACT = GEN || (EPI & E_ACT), C_DACT = GEN || (EPI & E_DACT), C_DROP = GEN || (EPI & E_DROP), C_RES = GEN || (EPI & E_RES);
@@ -244,6 +245,16 @@ __device__ __forceinline__ void gemm_fast_body(const tfasr_gemm_args& p, const i
   int kchunk = (p.K + split - 1) / split;
   kchunk = ((kchunk + BK - 1) / BK) * BK;
 
+  __shared__ long seg_tab[SEG ? 2 : 1][SEG ? 64 : 1];  // per-slab element offsets of op(A) / op(B) (K-segment mode)
+  if constexpr (SEG) {
+    const int nsl = p.K / BK;
+    if ((int)threadIdx.x < nsl) {
+      const int k = threadIdx.x * BK, sg = k / p.seg_k, within = k - sg * p.seg_k;
+      seg_tab[0][threadIdx.x] = p.seg_a_off[sg] + (TA ? (long)within * p.lda : (long)within);
+      seg_tab[1][threadIdx.x] = p.seg_b_off ? p.seg_b_off[sg] + (TB ? (long)within : (long)within * p.ldb) : (TB ? (long)k : (long)k * p.ldb);
+    }
+    __syncthreads();
+  }
   struct Tile { const bf16_t* A; const bf16_t* B; long doff; int m0, n0, k_begin, k_end, nfull, tail, ks; const bf16_t* sa[4]; const bf16_t* sb[BN_ / 32]; };
   // XCD-aware tile order (hardware deals consecutive workgroup ids round-robin over the 8 XCDs, each with its own L2):
   //  * plain / batched: in every round each XCD owns one contiguous run of the n-fastest tile sequence, so the n-tiles
@@ -307,8 +318,13 @@ __device__ __forceinline__ void gemm_fast_body(const tfasr_gemm_args& p, const i
   auto issue = [&](const Tile& T, int slab, int stage) {
     char* sA = smem + stage * STAGE_BYTES;
     char* sB = sA + A_BYTES;
-    issue_from<128>(sA, T.sa, slab * stepA, w);
-    issue_from<BN_>(sB, T.sb, slab * stepB, w);
+    if constexpr (SEG) {
+      issue_from<128>(sA, T.sa, seg_tab[0][slab], w);
+      issue_from<BN_>(sB, T.sb, seg_tab[1][slab], w);
+    } else {
+      issue_from<128>(sA, T.sa, slab * stepA, w);
+      issue_from<BN_>(sB, T.sb, slab * stepB, w);
+    }
   };
 
   Tile cur = tile_of(0);
@@ -636,6 +652,11 @@ template <bool TA, bool TB, int BN_, int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_fast_kernel(const tfasr_gemm_args p, const int gx, const int gy, const int gz, const int ntiles) {
   gemm_fast_body<TA, TB, BN_, EPI>(p, gx, gy, gz, ntiles, (int)blockIdx.x, (int)gridDim.x);
 }
+// K-segmented A / B operands (convolution taps as row shifts): same body, slab offsets from a table
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256, 2) void gemm_seg_kernel(const tfasr_gemm_args p, const int gx, const int gy, const int gz, const int ntiles) {
+  gemm_fast_body<TA, TB, 128, 0, 2, false, true>(p, gx, gy, gz, ntiles, (int)blockIdx.x, (int)gridDim.x);
+}
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Grouped weight gradients: the ~9 Dense-layer gradients  gW += x^T dy  of one Conformer block (K = B*T rows, a few 128x64 output
@@ -644,7 +665,7 @@ __global__ __launch_bounds__(256, 2) void gemm_fast_kernel(const tfasr_gemm_args
 // resident workgroup slots with a split of 2.  Every workgroup of the grid belongs to one product (a contiguous slice of
 // blockIdx.x starting at a multiple of 8) and runs gemm_fast_body on it unchanged.
 constexpr int GROUP_MAX = 10;
-constexpr int GROUP_UNITS = 8;  // (product, k-slice) units per XCD
+constexpr int GROUP_UNITS = 20;  // (product, k-slice) units per XCD
 struct GroupArgs {
   tfasr_gemm_args p[GROUP_MAX];
   int gx[GROUP_MAX], gy[GROUP_MAX];
@@ -967,6 +988,23 @@ int launch_one(const tfasr_gemm_args& a, hipStream_t stream) {
       }
     }
     return launch_epi<TA, TB, 64, E_GEN>(a, grid, stream);
+  }
+  if (a.seg_a_off) {  // K-segmented operands: conv2 forward (NN) / data gradient (NT) over the haloed space-to-depth layout
+    if constexpr (!TA) {
+      if (!generic && need == 0 && !a.accumulate && split == 1 && a.nb1 * a.nb2 == 1 && a.seg_k > 0 && (a.seg_k % BK) == 0 && (a.K % a.seg_k) == 0 &&
+          a.K / BK <= 64 && !a.lse_part) {
+        dim3 g128((a.N + 127) / 128, (a.M + BM - 1) / BM, 1);
+        const long ntiles = (long)g128.x * g128.y;
+        const int slots = 2 * num_cus();
+        int G = (int)(ntiles < slots ? ntiles : slots);
+        if (ntiles >= slots) G &= ~7;
+        constexpr int SMEM = 2 * (A_BYTES + 128 * BK * 2) + 4 * (64 / (128 / 16)) * (128 / 2 + 4) * 4;
+        hipLaunchKernelGGL((gemm_seg_kernel<TA, TB>), dim3(G), dim3(256), SMEM, stream, a, (int)g128.x, (int)g128.y, 1, (int)ntiles);
+        TFASR_CHECK_LAUNCH();
+        return TFASR_STATUS_SUCCESS;
+      }
+    }
+    return TFASR_STATUS_UNSUPPORTED;
   }
   if (a.lse_part) {  // joint vocabulary projection with fused log-softmax statistics
     if constexpr (!TA && !TB) {

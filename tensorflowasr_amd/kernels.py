@@ -125,18 +125,21 @@ def rnnt_loss_packed(logits, labels, label_len, logit_len, cell_off, total_cells
 # ---------------------------------------------------------------------------------------------- GEMM
 def gemm(A, B, out, M, N, K, lda, ldb, ldd, trans_a=False, trans_b=False, bias=None, res=None, dact_z=None,
          prez=None, alpha=1.0, beta=1.0, act=ACT_NONE, dact=ACT_NONE, nb1=1, nb2=1, sA=(0, 0), sB=(0, 0), sD=(0, 0),
-         accumulate=False, split_k=1, drop_p=0.0, drop_seed=0, colsum=None, lse=None):
+         accumulate=False, split_k=1, drop_p=0.0, drop_seed=0, colsum=None, lse=None, seg=None):
     """Raw strided (two-level batched) GEMM; see include/tfasr_hip.h.  lse = (lse_part [M, parts, 2] f32, row_label [M] i32,
     pick [M, 2] f32): fused log-softmax statistics of the output rows (raises TfasrUnsupported when the fast path cannot)."""
     a = _gemm_args(A, B, out, M, N, K, lda, ldb, ldd, trans_a, trans_b, bias, res, dact_z, prez, alpha, beta, act, dact, nb1, nb2, sA, sB, sD,
                    accumulate, split_k, drop_p, drop_seed, colsum)
+    if seg is not None:  # (seg_a_off i64 device tensor, seg_b_off or None, seg_k): K-segmented operands
+        a.seg_a_off, a.seg_b_off, a.seg_k = seg[0].data_ptr(), (seg[1].data_ptr() if seg[1] is not None else None), int(seg[2])
+        assert seg[0].dtype == torch.int64 and seg[0].is_cuda
     if lse is not None:
         part, row_label, pick = lse
         assert part.dtype == torch.float32 and pick.dtype == torch.float32 and row_label.dtype == torch.int32
         a.lse_part, a.lse_parts, a.row_label, a.pick = part.data_ptr(), part.shape[1], row_label.data_ptr(), pick.data_ptr()
     st = _lib.load().tfasr_gemm(ctypes.byref(a), _stream())
-    if lse is not None and st == _lib.STATUS_UNSUPPORTED:
-        raise _lib.TfasrUnsupported("gemm: fused row statistics are not available for this product")
+    if (lse is not None or seg is not None) and st == _lib.STATUS_UNSUPPORTED:
+        raise _lib.TfasrUnsupported("gemm: fused row statistics / K-segments are not available for this product")
     check(st, "gemm")
     return out
 
@@ -474,6 +477,28 @@ def conv1_bwd_weight(x, dy, dw, db):
     B, T0, F0 = x.shape[:3]
     C = dy.shape[-1]
     check(_L().tfasr_conv1_bwd_weight(_p(x), _p(dy), _p(dw), _p(db), B, T0, F0, C, _dt(x), _stream()), "conv1_bwd_weight")
+
+
+# haloed space-to-depth ("S") layout helpers (include/tfasr_hip.h): y / dy are [B, T2+1, F2+1, 4, C] buffers
+def conv1_fwd_s2d(x, w, bias, y):
+    B, T0, F0 = x.shape[:3]
+    check(_L().tfasr_conv1_fwd_s2d(_p(x), _p(w), _p(bias), _p(y), B, T0, F0, w.shape[-1], _dt(x), _stream()), "conv1_fwd_s2d")
+    return y
+
+
+def conv1_bwd_weight_s2d(x, dy, dw, db, C):
+    B, T0, F0 = x.shape[:3]
+    check(_L().tfasr_conv1_bwd_weight_s2d(_p(x), _p(dy), _p(dw), _p(db), B, T0, F0, C, _dt(x), _stream()), "conv1_bwd_weight_s2d")
+
+
+def halo_zero(x, B, T2, F2, W):
+    check(_L().tfasr_halo_zero(_p(x), B, T2, F2, W, _dt(x), _stream()), "halo_zero")
+    return x
+
+
+def s2d_edge_zero(x, B, T1, F1, C):
+    check(_L().tfasr_s2d_edge_zero(_p(x), B, T1, F1, C, _dt(x), _stream()), "s2d_edge_zero")
+    return x
 
 
 def im2col_3x3s2(x, col=None):
