@@ -920,7 +920,7 @@ int launch_one(const tfasr_gemm_args& a, hipStream_t stream) {
   static const bool bn64_off = getenv("TFASR_GEMM_BN64") && getenv("TFASR_GEMM_BN64")[0] == '0';
   const long t128 = (long)((a.N + 127) / 128) * ((a.M + BM - 1) / BM) * a.nb1 * a.nb2 * split;
   static const long bn64_thr = getenv("TFASR_GEMM_BN64_T") ? atol(getenv("TFASR_GEMM_BN64_T")) : (long)num_cus();
-  const bool narrow = !a.lse_part && (a.N <= 64 || (!bn64_off && t128 <= bn64_thr && a.N > 64 && !(a.accumulate && a.ws)));
+  const bool narrow = !a.lse_part && !a.seg_a_off && (a.N <= 64 || (!bn64_off && t128 <= bn64_thr && a.N > 64 && !(a.accumulate && a.ws)));
   const int bn = narrow ? 64 : 128;
   dim3 grid((a.N + bn - 1) / bn, (a.M + BM - 1) / BM, a.nb1 * a.nb2 * split);
   if ((long)grid.x * grid.y * grid.z > 0x7fffffffL) return TFASR_STATUS_INVALID_VALUE;

@@ -491,3 +491,56 @@ def test_relattn_fused_backward_v2_no_skewed_gradient(dev, T, lens, use_mask):
     if use_mask:  # masked query rows have constant scores: no gradient flows into them (s.grad above is taken after the fill)
         valid = valid & (torch.arange(T)[None] < torch.tensor(lens)[:, None])[:, None, :, None]
     close(ds[..., :T] * valid.to(dev), gs * valid, "ds")
+
+
+@pytest.mark.parametrize("dtype,C", [(torch.float32, 32), (torch.bfloat16, 64)])
+@pytest.mark.parametrize("T0,F0", [(25, 80), (26, 78), (9, 6)])
+def test_s2d_layout_conv2_equals_im2col_route(dev, dtype, C, T0, F0):
+    """Haloed space-to-depth layout (csrc/conv2d.hip): conv1 written straight into it, halo / odd-edge slots zeroed, and conv2 as a
+    GEMM over 9 K-segments of row-shifted operands == the im2col + GEMM route on the same activations (odd and even T1 / F1)."""
+    g = torch.Generator().manual_seed(T0 * 100 + F0)
+    B = 3
+    x = torch.randn(B, T0, F0, generator=g).to(dev).to(dtype)
+    w0 = (torch.randn(3, 3, 1, C, generator=g) * 0.3).to(dev)
+    b0 = torch.randn(C, generator=g).to(dev)
+    W = (torch.randn(9 * C, C, generator=g) * 0.1).to(dev).to(dtype)
+    b1 = torch.randn(C, generator=g).to(dev)
+    c1 = K.conv1_fwd(x, w0, b0)  # [B, T1, F1, C]
+    T1, F1 = c1.shape[1], c1.shape[2]
+    T2, F2 = (T1 + 1) // 2, (F1 + 1) // 2
+    rows, slack = B * (T2 + 1) * (F2 + 1), F2 + 2
+    full = torch.full(((rows + 2 * slack) * 4 * C,), float("nan"), dtype=dtype, device=dev)
+    full[:slack * 4 * C] = 0
+    full[(slack + rows) * 4 * C:] = 0
+    s1 = full[slack * 4 * C:(slack + rows) * 4 * C].view(rows, 4 * C)
+    K.conv1_fwd_s2d(x, w0, b0, s1)
+    K.halo_zero(s1, B, T2, F2, 4 * C)
+    K.s2d_edge_zero(s1, B, T1, F1, C)
+    # the layout: element (b, t, f) at row (b, t/2+1, f/2+1), block (t%2, f%2); everything else zero
+    want = torch.zeros(B, T2 + 1, F2 + 1, 2, 2, C, dtype=dtype, device=dev)
+    for pt in range(2):
+        for pf in range(2):
+            sub = c1[:, pt::2, pf::2]
+            want[:, 1:1 + sub.shape[1], 1:1 + sub.shape[2], pt, pf] = sub
+    assert torch.equal(s1.view(B, T2 + 1, F2 + 1, 2, 2, C), want)
+    # conv2 over the layout
+    shift, blk = [], []
+    for kh in range(3):
+        for kw in range(3):
+            dt, pt = (-1, kh) if kh < 2 else (0, 0)
+            df, pf = (-1, kw) if kw < 2 else (0, 0)
+            shift.append(dt * (F2 + 1) + df)
+            blk.append(pt * 2 + pf)
+    o = torch.empty(rows, C, dtype=dtype, device=dev)
+    if dtype == torch.float32:
+        base = slack * 4 * C
+        for i in range(9):
+            K.gemm(full[base + shift[i] * 4 * C + blk[i] * C:], W[i * C:(i + 1) * C], o, rows, C, C, 4 * C, C, C, bias=b1 if i == 0 else None,
+                   accumulate=i > 0)
+    else:
+        tab = torch.tensor([sh * 4 * C + b * C for sh, b in zip(shift, blk)], dtype=torch.int64, device=dev)
+        K.gemm(s1, W, o, rows, C, 9 * C, 4 * C, C, C, bias=b1, seg=(tab, None, C))
+    ref = K.matmul(K.im2col_3x3s2(c1), W, bias=b1).view(B, T2, F2, C)
+    got = o.view(B, T2 + 1, F2 + 1, C)[:, 1:, 1:]
+    tol = 1e-4 if dtype == torch.float32 else 2e-2
+    np.testing.assert_allclose(got.float().cpu().numpy(), ref.float().cpu().numpy(), rtol=tol, atol=tol)
