@@ -311,6 +311,24 @@ int tfasr_lstm_step_bwd(const void* dy, long dy_stride_b, const float* dhr, floa
 int tfasr_decode_prepare(const void* encj, const int32_t* nframes, const int32_t* frame_idx, const int32_t* tok_idx,
                          int32_t* active, void* ecur, int B, int T, int J, int max_tokens, int mode, int dtype,
                          void* stream);
+/* One search step up to the logits in three launches (embedding + LSTM cell incl. the loop condition, LayerNorm + prediction
+ * projection + frame gather + tanh, vocabulary projection), f32 on the f32 master weights: emb [V,E], lstm_k [E,4P], lstm_rk
+ * [P,4P], lstm_b [4P], ln_g/ln_b [P] (NULL: no prediction LayerNorm), joint_pred_w [P,J], vocab_w [J,V]; encj [B,T,J] f32.
+ * Writes active[0], h_new / c_new [B,P], z [B,J], logits [B,V]; follow with tfasr_decode_update (dtype f32).  B <= 64;
+ * P, J % 4 == 0 and V % 8 == 0, else UNSUPPORTED (use tfasr_decode_prepare + the per-op entry points). */
+int tfasr_decode_step(const float* emb, const float* lstm_k, const float* lstm_rk, const float* lstm_b, const float* ln_g,
+                      const float* ln_b, const float* joint_pred_w, const float* joint_pred_b, const float* vocab_w,
+                      const float* vocab_b, const float* encj, const int32_t* nframes, const int32_t* frame_idx,
+                      const int32_t* tok_idx, const int32_t* prev_tok, const float* h, const float* c, int32_t* active,
+                      float* h_new, float* c_new, float* z, float* logits, int B, int T, int E, int P, int J, int V,
+                      int max_tokens, int mode, float ln_eps, void* stream);
+/* `iters` iterations of (tfasr_decode_step + tfasr_decode_update) queued by one host call (f32 states h, c [B,P]). */
+int tfasr_decode_steps(const float* emb, const float* lstm_k, const float* lstm_rk, const float* lstm_b, const float* ln_g,
+                       const float* ln_b, const float* joint_pred_w, const float* joint_pred_b, const float* vocab_w,
+                       const float* vocab_b, const float* encj, const int32_t* nframes, int32_t* frame_idx, int32_t* tok_idx,
+                       int32_t* prev_tok, float* h, float* c, int32_t* active, float* h_new, float* c_new, float* z, float* logits,
+                       int32_t* tokens, int32_t* per_frame, int B, int T, int E, int P, int J, int V, int max_tokens, int blank,
+                       int mode, int max_tokens_per_frame, float ln_eps, int iters, void* stream);
 int tfasr_decode_update(const void* logits, const int32_t* active, const int32_t* nframes, int32_t* frame_idx,
                         int32_t* prev_tok, int32_t* tok_idx, int32_t* tokens, int32_t* per_frame, const void* h_new,
                         const float* c_new, void* h, float* c, int B, int V, int P, int max_tokens, int blank, int mode,

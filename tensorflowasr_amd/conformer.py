@@ -1081,8 +1081,22 @@ class ConformerTransducer:
         # spin forever once a sample saturates its token buffer — cap the trip count instead
         max_iters = T + max_tokens + 2
         it = 0
+        zbuf = torch.empty(B, J, dtype=f32, device=dev)
+        lng, lnb = (ps.p("pred/ln/g"), ps.p("pred/ln/b")) if c.prediction_layer_norm else (None, None)
+        fused = B <= 64 and os.environ.get("TFASR_DECODE_FUSED", "1") != "0"
         while it < max_iters:
-            for _ in range(min(check_every, max_iters - it)):
+            n = min(check_every * 4 if fused else check_every, max_iters - it)  # fused iterations are cheap no-ops once the loop has ended
+            if fused:
+                # `n` iterations = 3 skinny-product launches + the bookkeeping kernel each (csrc/decode_step.hip), queued by one host call
+                fused = K.decode_steps(ps.p("pred/emb"), Wk, Wrk, ps.p("pred/lstm/b"), lng, lnb, Wjp, ps.p("joint/pred/b"), Wv,
+                                       ps.p("joint/vocab/b"), encj, nframes, frame_idx, tok_idx, prev_tok, h, cst, active, h_new, c_new, zbuf,
+                                       logits, tokens, per_frame, max_tokens, self.blank, mode, max_tokens_per_frame, n)
+                if fused:
+                    it += n
+                    if int(active.item()) == 0:
+                        break
+                    continue
+            for _ in range(n):
                 K.decode_prepare(encj, nframes, frame_idx, tok_idx, active, ecur, max_tokens, mode)
                 emb = K.embedding_fwd(prev_tok, ps.p("pred/emb"), f32)
                 K.matmul(emb, Wk, bias=ps.p("pred/lstm/b"), out=xg)

@@ -535,6 +535,37 @@ def decode_prepare(encj, nframes, frame_idx, tok_idx, active, ecur, max_tokens, 
                                     mode, _dt(encj), _stream()), "decode_prepare")
 
 
+def decode_step(emb, lstm_k, lstm_rk, lstm_b, ln_g, ln_b, wjp, bjp, wv, bv, encj, nframes, frame_idx, tok_idx, prev_tok, h, c, active, h_new, c_new,
+                z, logits, max_tokens, mode, ln_eps=1e-3):
+    """Fused search step (three launches up to the f32 logits); returns False when the shapes need the per-op route."""
+    B, T, J = encj.shape
+    V, E = emb.shape
+    P = h.shape[1]
+    st = _L().tfasr_decode_step(_p(emb), _p(lstm_k), _p(lstm_rk), _p(lstm_b), _p(ln_g), _p(ln_b), _p(wjp), _p(bjp), _p(wv), _p(bv), _p(encj),
+                                _p(nframes), _p(frame_idx), _p(tok_idx), _p(prev_tok), _p(h), _p(c), _p(active), _p(h_new), _p(c_new), _p(z),
+                                _p(logits), B, T, E, P, J, V, max_tokens, mode, ln_eps, _stream())
+    if st == _lib.STATUS_UNSUPPORTED:
+        return False
+    check(st, "decode_step")
+    return True
+
+
+def decode_steps(emb, lstm_k, lstm_rk, lstm_b, ln_g, ln_b, wjp, bjp, wv, bv, encj, nframes, frame_idx, tok_idx, prev_tok, h, c, active, h_new, c_new,
+                 z, logits, tokens, per_frame, max_tokens, blank, mode, max_tokens_per_frame, iters, ln_eps=1e-3):
+    """`iters` fused search iterations from one host call; False when the shapes need the per-op route."""
+    B, T, J = encj.shape
+    V, E = emb.shape
+    P = h.shape[1]
+    st = _L().tfasr_decode_steps(_p(emb), _p(lstm_k), _p(lstm_rk), _p(lstm_b), _p(ln_g), _p(ln_b), _p(wjp), _p(bjp), _p(wv), _p(bv), _p(encj),
+                                 _p(nframes), _p(frame_idx), _p(tok_idx), _p(prev_tok), _p(h), _p(c), _p(active), _p(h_new), _p(c_new), _p(z),
+                                 _p(logits), _p(tokens), _p(per_frame), B, T, E, P, J, V, max_tokens, blank, mode, max_tokens_per_frame, ln_eps,
+                                 int(iters), _stream())
+    if st == _lib.STATUS_UNSUPPORTED:
+        return False
+    check(st, "decode_steps")
+    return True
+
+
 def decode_update(logits, active, nframes, frame_idx, prev_tok, tok_idx, tokens, per_frame, h_new, c_new, h, c, max_tokens,
                   blank, mode, max_tokens_per_frame):
     B, V = logits.shape
