@@ -355,6 +355,18 @@ int tfasr_conv1_fwd_s2d(const void* x, const float* w, const float* bias, void* 
                         void* stream);
 int tfasr_conv1_bwd_weight_s2d(const void* x, const void* dy, float* dw, float* db, int B, int T0, int F0, int C, int dtype,
                                void* stream);
+/* conv1 + BatchNorm(+swish) of Conv2dSubsampling's first block WITHOUT materialising conv1's output (it is recomputed from the
+   feature map: 9 FMAs per element instead of ~10 GB of HBM passes per step): statistics [2C] (sum, sum of squares; -> the caller's
+   all-reduce -> tfasr_bn_finalize), apply into the S layout, backward statistics [2C] (sum dz, sum dz*xhat), backward apply fused
+   with conv1's weight / bias gradients (`count` = rows x world of the statistics).  Act = swish (subsampling.py:163-230). */
+int tfasr_conv1_stats(const void* x, const float* w, const float* bias, float* stats, int B, int T0, int F0, int C, int dtype,
+                      void* stream);
+int tfasr_conv1_bn_apply_s2d(const void* x, const float* w, const float* bias, const float* fin, void* y, int B, int T0, int F0, int C,
+                             int dtype, void* stream);
+int tfasr_conv1_bn_bwd_stats_s2d(const void* x, const float* w, const float* bias, const float* fin, const void* dy, float* bstats, int B,
+                                 int T0, int F0, int C, int dtype, void* stream);
+int tfasr_conv1_bn_bwd_apply_s2d(const void* x, const float* w, const float* bias, const float* fin, const float* bstats, float count,
+                                 const void* dy, float* dw, float* db, int B, int T0, int F0, int C, int dtype, void* stream);
 int tfasr_halo_zero(void* x, int B, int T2, int F2, int W, int dtype, void* stream);
 int tfasr_s2d_edge_zero(void* x, int B, int T1, int F1, int C, int dtype, void* stream);
 int tfasr_im2col_3x3s2(const void* x, void* col, int B, int T1, int F1, int C, int dtype, void* stream);

@@ -274,15 +274,25 @@ class ConformerTransducer:
         T2, F2 = (T1 + 1) // 2, (F1 + 1) // 2
         rows, slack = B * (T2 + 1) * (F2 + 1), F2 + 2
         shift, blk, fwd_a, _ = self._seg_tables(F2, C)
-        # conv1 -> S layout, BatchNorm + swish in place of the layout (halo slots are exactly zero, so they change no statistic)
-        _, s1 = self._salloc(rows, 4 * C, slack)
-        K.conv1_fwd_s2d(feats, ps.p("enc/sub/conv0/w"), ps.p("enc/sub/conv0/b"), s1)
-        K.halo_zero(s1, B, T2, F2, 4 * C)
-        K.s2d_edge_zero(s1, B, T1, F1, C)
+        # conv1 + BatchNorm + swish straight into the S layout; conv1's own output is never stored (recomputed from the feature map
+        # by the statistics / apply / backward kernels: csrc/conv2d.hip conv1_bn_kernel)
+        w0, b0 = ps.p("enc/sub/conv0/w"), ps.p("enc/sub/conv0/b")
+        fin0 = torch.empty(4 * C, dtype=torch.float32, device=self.device)
+        nm = "enc/sub/bn0"
+        if training:
+            stats = torch.zeros(2 * C + 1, dtype=torch.float32, device=self.device)
+            K.conv1_stats(feats, w0, b0, stats)
+            count0 = B * T1 * F1 * self.dp.world
+            self.dp.allreduce_stats_(stats[:2 * C])
+            K.bn_finalize(stats, count0, ps.p(nm + "/g"), ps.p(nm + "/b"), fin0, ps.state[nm + "/mm"], ps.state[nm + "/mv"], 0.99, 1e-3, True)
+        else:
+            count0 = B * T1 * F1
+            K.bn_finalize(None, 1, ps.p(nm + "/g"), ps.p(nm + "/b"), fin0, ps.state[nm + "/mm"], ps.state[nm + "/mv"], 0.99, 1e-3, False)
         a1_full, a1 = self._salloc(rows, 4 * C, slack)
-        _, bn0 = self._bn_fwd(s1.view(-1, C), "enc/sub/bn0", training, ACT_SWISH, rows=B * T1 * F1, y=a1.view(-1, C))
+        K.conv1_bn_apply_s2d(feats, w0, b0, fin0, a1)
         K.halo_zero(a1, B, T2, F2, 4 * C)
         K.s2d_edge_zero(a1, B, T1, F1, C)
+        bn0 = (fin0, count0)
         # conv2: every tap reads the same rows shifted by a constant -> one GEMM over 9 K-segments (bf16) / 9 products (f32)
         W = ps.w2d("enc/sub/conv1/w")  # [9C, C]
         _, o = self._salloc(rows, C, slack)
@@ -306,7 +316,7 @@ class ConformerTransducer:
                nb1=B, sA=((T2 + 1) * (F2 + 1) * C, 0), sD=(T2 * d, 0), drop_p=drop[0], drop_seed=drop[1])
         elen = [-(-(-(-n // 2)) // 2) for n in flen]
         if ctx is not None:
-            ctx["sub"] = dict(s2d=True, feats=feats, s1=s1, bn0=bn0, a1=a1, a1_full=a1_full, o=o, bn1=bn1, a2=a2,
+            ctx["sub"] = dict(s2d=True, feats=feats, bn0=bn0, a1=a1, a1_full=a1_full, o=o, bn1=bn1, a2=a2,
                               dims=(B, T0, F0, T1, F1, T2, F2), drop=drop)
         return x0, T2, elen
 
@@ -351,10 +361,16 @@ class ConformerTransducer:
                     K.gemm(do_full[dobase - shift[i] * C:], W[i * C:(i + 1) * C], out, rows, C, C, C, C, 4 * C, trans_b=True, accumulate=j > 0)
             else:
                 K.gemm(do, W, out, rows, C, len(segs) * C, C, C, 4 * C, trans_b=True, seg=(a_off, b_off, C))
-        K.halo_zero(da1, B, T2, F2, 4 * C)
-        K.s2d_edge_zero(da1, B, T1, F1, C)
-        ds1 = self._bn_bwd(s["s1"].view(-1, C), da1.view(-1, C), "enc/sub/bn0", s["bn0"], ACT_SWISH)
-        K.conv1_bwd_weight_s2d(s["feats"], ds1, ps.g("enc/sub/conv0/w"), ps.g("enc/sub/conv0/b"), C)
+        # BatchNorm0 + conv1 backward from the feature map (only the valid slots of da1 are read: its halos need no clearing)
+        fin0, count0 = s["bn0"]
+        w0, b0 = ps.p("enc/sub/conv0/w"), ps.p("enc/sub/conv0/b")
+        bstats = torch.zeros(2 * C, dtype=torch.float32, device=self.device)
+        K.conv1_bn_bwd_stats_s2d(s["feats"], w0, b0, fin0, da1, bstats)
+        self.dp.allreduce_stats_(bstats)
+        K.conv1_bn_bwd_apply_s2d(s["feats"], w0, b0, fin0, bstats, count0, da1, ps.g("enc/sub/conv0/w"), ps.g("enc/sub/conv0/b"))
+        inv = 1.0 / self.dp.world
+        K.axpy(ps.g("enc/sub/bn0/b"), bstats[:C].contiguous(), inv)
+        K.axpy(ps.g("enc/sub/bn0/g"), bstats[C:].contiguous(), inv)
 
     def _subsampling_fwd(self, feats, flen, training, ctx):
         if self._s2d_enabled():

@@ -273,6 +273,130 @@ __global__ __launch_bounds__(256) void col2im_kernel(const T* __restrict__ dcol,
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// conv1 + BatchNorm + swish without ever storing conv1's output: conv1 (Cin = 1) costs 9 FMAs per element, its [B,T1,F1,C] output
+// is ~1 GB at the bench shape, and every pass over it (write, statistics, apply, backward statistics, backward apply, weight
+// gradient: ~10 GB per step) is pure HBM time.  Four kernels RECOMPUTE it from the 30 MB feature map instead:
+//   conv1_stats      : sum / sum of squares per channel                                    (-> tfasr_bn_finalize as usual)
+//   conv1_bn_apply   : y = swish(conv1(x) * scale + shift), written in the S layout
+//   conv1_bn_bwd_stats : sum dz, sum dz * xhat with dz = dy * swish'(z)                   (dy read from the S layout)
+//   conv1_bn_bwd_apply : d conv1 = scale (dz - mean dz - xhat mean(dz xhat)); its weight / bias gradients accumulated on the fly
+// One (b, t) output row per block iteration, thread = (8-channel group, f sub-lane); taps + bias live in registers.
+// MODE 0 stats, 1 apply, 2 backward stats, 3 backward apply + weight gradient.
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void conv1_bn_kernel(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                       const float* __restrict__ fin, const float* __restrict__ bstats, float inv_count,
+                                                       T* __restrict__ y, const T* __restrict__ dy, float* __restrict__ out0,
+                                                       float* __restrict__ out1, int B, int T0, int F0, int T1, int F1, int C) {
+  extern __shared__ float sm[];
+  float* xs = sm;                       // [3][F0 + 2] input rows of the current output row (zero padded)
+  float* red = sm + 3 * (F0 + 2);       // [NQ][C] block reduction
+  constexpr int NQ = MODE == 3 ? 10 : 2;
+  const int cgn = C / 8, FS = 256 / cgn;
+  const int cg = threadIdx.x % cgn, fs = threadIdx.x / cgn;
+  const bool on = fs < FS;
+  const int c = cg * 8;
+  const int T2 = (T1 + 1) / 2, F2 = (F1 + 1) / 2;
+  float wr[9][8], br[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) br[k] = bias ? bias[c + k] : 0.f;
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) wr[tap][k] = w[tap * C + c + k];
+  float mean[8], rstd[8], sc[8], sh[8], s0[8], s1[8];
+  if (MODE >= 1) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { mean[k] = fin[c + k]; rstd[k] = fin[C + c + k]; sc[k] = fin[2 * C + c + k]; sh[k] = fin[3 * C + c + k]; }
+  }
+  if (MODE == 3) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { s0[k] = bstats[c + k] * inv_count; s1[k] = bstats[C + c + k] * inv_count; }
+  }
+  float acc2[NQ][8];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc2[q][k] = 0.f;
+  const int nrows = B * T1;
+  for (int row = blockIdx.x; row < nrows; row += gridDim.x) {
+    const int b = row / T1, t = row - b * T1;
+    __syncthreads();
+    for (int i = threadIdx.x; i < 3 * (F0 + 2); i += 256) {  // xs[kh][fi + 2] = x[b, 2t+kh-2, fi], zero outside
+      const int kh = i / (F0 + 2), fi = i - kh * (F0 + 2) - 2, ti = 2 * t + kh - 2;
+      xs[i] = (ti >= 0 && ti < T0 && fi >= 0 && fi < F0) ? Num<T>::ld(x + ((long)b * T0 + ti) * F0 + fi) : 0.f;
+    }
+    __syncthreads();
+    if (!on) continue;
+    for (int f = fs; f < F1; f += FS) {
+      float a[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) a[k] = br[k];
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const float xv = xs[kh * (F0 + 2) + 2 * f + kw];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) a[k] += wr[kh * 3 + kw][k] * xv;
+        }
+      if (MODE == 0) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { acc2[0][k] += a[k]; acc2[1][k] += a[k] * a[k]; }
+      } else if (MODE == 1) {
+        float o[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = swishf_(a[k] * sc[k] + sh[k]);
+        st8(y + s2d_off(b, t, f, T2, F2, C) + c, o);
+      } else {
+        float d[8];
+        ld8(dy + s2d_off(b, t, f, T2, F2, C) + c, d);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const float dz = d[k] * dswishf_(a[k] * sc[k] + sh[k]);
+          const float xh = (a[k] - mean[k]) * rstd[k];
+          if (MODE == 2) { acc2[0][k] += dz; acc2[1][k] += dz * xh; }
+          else d[k] = sc[k] * (dz - s0[k] - xh * s1[k]);  // gradient w.r.t. conv1's output
+        }
+        if (MODE == 3) {
+#pragma unroll
+          for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+              const float xv = xs[kh * (F0 + 2) + 2 * f + kw];
+#pragma unroll
+              for (int k = 0; k < 8; ++k) acc2[kh * 3 + kw][k] += d[k] * xv;
+            }
+#pragma unroll
+          for (int k = 0; k < 8; ++k) acc2[9][k] += d[k];
+        }
+      }
+    }
+  }
+  if (MODE == 1) return;
+  // block reduction over the f sub-lanes that share a channel group (LDS float atomics: once per block), then one global atomic
+  // per (quantity, channel) per block
+  __syncthreads();
+  for (int i = threadIdx.x; i < NQ * C; i += 256) red[i] = 0.f;
+  __syncthreads();
+  if (on) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) atomicAdd(&red[q * C + c + k], acc2[q][k]);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < NQ * C; i += 256) {
+    const int q = i / C, cc = i % C;
+    if (MODE == 3) {
+      if (q < 9) atomicAdd(out0 + q * C + cc, red[i]);
+      else if (out1) atomicAdd(out1 + cc, red[i]);
+    } else {
+      atomicAdd(out0 + q * C + cc, red[i]);  // stats[0:C] = first quantity, stats[C:2C] = second
+    }
+  }
+}
+
 // Zero the halo rows (tt == 0 or ff == 0) of a [B, T2+1, F2+1, W] tensor (W = 4C for the S layout, C for the conv2 output side).
 template <typename T>
 __global__ __launch_bounds__(256) void halo_zero_kernel(T* __restrict__ x, int B, int T2, int F2, int W) {
@@ -375,6 +499,46 @@ extern "C" int tfasr_conv1_bwd_weight(const void* x, const void* dy, float* dw, 
 extern "C" int tfasr_conv1_bwd_weight_s2d(const void* x, const void* dy, float* dw, float* db, int B, int T0, int F0, int C,
                                           int dtype, void* stream_) {
   return conv1_bwd_weight_impl(x, dy, dw, db, B, T0, F0, C, dtype, stream_, 1);
+}
+
+template <int MODE>
+static int conv1_bn_launch(const void* x, const float* w, const float* bias, const float* fin, const float* bstats, float count, void* y,
+                           const void* dy, float* out0, float* out1, int B, int T0, int F0, int C, int dtype, void* stream_) {
+  if (!x || !w || B <= 0 || T0 <= 0 || F0 <= 0 || C <= 0 || C > 256 || (C % 8)) return TFASR_STATUS_INVALID_VALUE;
+  const int T1 = (T0 + 1) / 2, F1 = (F0 + 1) / 2;
+  hipStream_t s = (hipStream_t)stream_;
+  const int grid = std::min(B * T1, MODE == 1 ? 8192 : 1024);
+  const size_t smem = (size_t)(3 * (F0 + 2) + (MODE == 3 ? 10 : 2) * C) * sizeof(float);
+  const float inv = count > 0.f ? 1.f / count : 0.f;
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL((conv1_bn_kernel<float, MODE>), dim3(grid), dim3(256), smem, s, (const float*)x, w, bias, fin, bstats, inv, (float*)y,
+                                (const float*)dy, out0, out1, B, T0, F0, T1, F1, C),
+             hipLaunchKernelGGL((conv1_bn_kernel<bf16_t, MODE>), dim3(grid), dim3(256), smem, s, (const bf16_t*)x, w, bias, fin, bstats, inv, (bf16_t*)y,
+                                (const bf16_t*)dy, out0, out1, B, T0, F0, T1, F1, C));
+  TFASR_CHECK_LAUNCH();
+  return TFASR_STATUS_SUCCESS;
+}
+
+extern "C" int tfasr_conv1_stats(const void* x, const float* w, const float* bias, float* stats, int B, int T0, int F0, int C, int dtype,
+                                 void* stream_) {
+  if (!stats) return TFASR_STATUS_INVALID_VALUE;
+  return conv1_bn_launch<0>(x, w, bias, nullptr, nullptr, 0.f, nullptr, nullptr, stats, nullptr, B, T0, F0, C, dtype, stream_);
+}
+extern "C" int tfasr_conv1_bn_apply_s2d(const void* x, const float* w, const float* bias, const float* fin, void* y, int B, int T0, int F0,
+                                        int C, int dtype, void* stream_) {
+  if (!fin || !y) return TFASR_STATUS_INVALID_VALUE;
+  return conv1_bn_launch<1>(x, w, bias, fin, nullptr, 0.f, y, nullptr, nullptr, nullptr, B, T0, F0, C, dtype, stream_);
+}
+extern "C" int tfasr_conv1_bn_bwd_stats_s2d(const void* x, const float* w, const float* bias, const float* fin, const void* dy, float* bstats,
+                                            int B, int T0, int F0, int C, int dtype, void* stream_) {
+  if (!fin || !dy || !bstats) return TFASR_STATUS_INVALID_VALUE;
+  return conv1_bn_launch<2>(x, w, bias, fin, nullptr, 0.f, nullptr, dy, bstats, nullptr, B, T0, F0, C, dtype, stream_);
+}
+extern "C" int tfasr_conv1_bn_bwd_apply_s2d(const void* x, const float* w, const float* bias, const float* fin, const float* bstats,
+                                            float count, const void* dy, float* dw, float* db, int B, int T0, int F0, int C, int dtype,
+                                            void* stream_) {
+  if (!fin || !bstats || !dy || !dw || count <= 0.f) return TFASR_STATUS_INVALID_VALUE;
+  return conv1_bn_launch<3>(x, w, bias, fin, bstats, count, nullptr, dy, dw, db, B, T0, F0, C, dtype, stream_);
 }
 
 extern "C" int tfasr_halo_zero(void* x, int B, int T2, int F2, int W, int dtype, void* stream_) {

@@ -491,6 +491,29 @@ def conv1_bwd_weight_s2d(x, dy, dw, db, C):
     check(_L().tfasr_conv1_bwd_weight_s2d(_p(x), _p(dy), _p(dw), _p(db), B, T0, F0, C, _dt(x), _stream()), "conv1_bwd_weight_s2d")
 
 
+def conv1_stats(x, w, bias, stats):
+    B, T0, F0 = x.shape[:3]
+    check(_L().tfasr_conv1_stats(_p(x), _p(w), _p(bias), _p(stats), B, T0, F0, w.shape[-1], _dt(x), _stream()), "conv1_stats")
+
+
+def conv1_bn_apply_s2d(x, w, bias, fin, y):
+    B, T0, F0 = x.shape[:3]
+    check(_L().tfasr_conv1_bn_apply_s2d(_p(x), _p(w), _p(bias), _p(fin), _p(y), B, T0, F0, w.shape[-1], _dt(x), _stream()), "conv1_bn_apply")
+    return y
+
+
+def conv1_bn_bwd_stats_s2d(x, w, bias, fin, dy, bstats):
+    B, T0, F0 = x.shape[:3]
+    check(_L().tfasr_conv1_bn_bwd_stats_s2d(_p(x), _p(w), _p(bias), _p(fin), _p(dy), _p(bstats), B, T0, F0, w.shape[-1], _dt(x), _stream()),
+          "conv1_bn_bwd_stats")
+
+
+def conv1_bn_bwd_apply_s2d(x, w, bias, fin, bstats, count, dy, dw, db):
+    B, T0, F0 = x.shape[:3]
+    check(_L().tfasr_conv1_bn_bwd_apply_s2d(_p(x), _p(w), _p(bias), _p(fin), _p(bstats), float(count), _p(dy), _p(dw), _p(db), B, T0, F0,
+                                            w.shape[-1], _dt(x), _stream()), "conv1_bn_bwd_apply")
+
+
 def halo_zero(x, B, T2, F2, W):
     check(_L().tfasr_halo_zero(_p(x), B, T2, F2, W, _dt(x), _stream()), "halo_zero")
     return x
