@@ -63,7 +63,7 @@ __device__ __forceinline__ void issue_trans(char* s, const bf16_t* g, long ld, i
   for (int i = 0; i < ROWS / 32; ++i) {
     const int q = w * (ROWS / 32) + i;
     const int k = q * KPI + lane / CPR, p = lane % CPR;
-    const int c = min((rows0 >> 3) + (p ^ (ROWS == 128 ? key_t(k) : key_t64(k))), maxchunk);
+    const int c = min((rows0 >> 3) + (p ^ (ROWS >= 128 ? key_t(k) : key_t64(k))), maxchunk);
     const bf16_t* src = g + (long)(kt + k) * ld + ((long)c << 3);
     __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(s + __builtin_amdgcn_readfirstlane(q * 1024)), 16, 0, 0);
   }
@@ -89,7 +89,7 @@ __device__ __forceinline__ void prep_trans(const bf16_t* (&src)[ROWS / 32], cons
   for (int i = 0; i < ROWS / 32; ++i) {
     const int q = w * (ROWS / 32) + i;
     const int k = q * KPI + lane / CPR, p = lane % CPR;
-    const int c = min((rows0 >> 3) + (p ^ (ROWS == 128 ? key_t(k) : key_t64(k))), maxchunk);
+    const int c = min((rows0 >> 3) + (p ^ (ROWS >= 128 ? key_t(k) : key_t64(k))), maxchunk);
     src[i] = g + (long)(kt + k) * ld + ((long)c << 3);
   }
 }
@@ -125,7 +125,7 @@ __device__ __forceinline__ void tail_trans(char* s, const bf16_t* g, long ld, in
     const int k = c / CPR, p = c % CPR;
     uint4 v = make_uint4(0, 0, 0, 0);
     if (kt + k < k_end) {
-      const int ch = min((rows0 >> 3) + (p ^ (ROWS == 128 ? key_t(k) : key_t64(k))), maxchunk);
+      const int ch = min((rows0 >> 3) + (p ^ (ROWS >= 128 ? key_t(k) : key_t64(k))), maxchunk);
       v = *reinterpret_cast<const uint4*>(g + (long)(kt + k) * ld + ((long)ch << 3));
     }
     *reinterpret_cast<uint4*>(s + k * (ROWS * 2) + p * 16) = v;
@@ -143,9 +143,9 @@ __device__ __forceinline__ short8_t frag_trans(const char* s, int rowbase, int k
   const int chunk = col >> 3, half = (col >> 2) & 1;
   const int k0 = kbase + (r >> 2), k1 = k0 + 4;
   const short4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-      (__attribute__((address_space(3))) short4_t*)(s + k0 * (ROWS * 2) + ((chunk ^ (ROWS == 128 ? key_t(k0) : key_t64(k0))) << 4) + half * 8));
+      (__attribute__((address_space(3))) short4_t*)(s + k0 * (ROWS * 2) + ((chunk ^ (ROWS >= 128 ? key_t(k0) : key_t64(k0))) << 4) + half * 8));
   const short4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-      (__attribute__((address_space(3))) short4_t*)(s + k1 * (ROWS * 2) + ((chunk ^ (ROWS == 128 ? key_t(k1) : key_t64(k1))) << 4) + half * 8));
+      (__attribute__((address_space(3))) short4_t*)(s + k1 * (ROWS * 2) + ((chunk ^ (ROWS >= 128 ? key_t(k1) : key_t64(k1))) << 4) + half * 8));
   short8_t v;
   v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
   v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
@@ -910,6 +910,8 @@ int launch_epi(const tfasr_gemm_args& a, dim3 tiles, hipStream_t stream) {
   return TFASR_STATUS_SUCCESS;
 }
 
+#include "gemm_big.h"
+
 template <bool TA, bool TB>
 int launch_one(const tfasr_gemm_args& a, hipStream_t stream) {
   const int split = a.split_k > 1 ? a.split_k : 1;
@@ -933,6 +935,10 @@ int launch_one(const tfasr_gemm_args& a, hipStream_t stream) {
     if (a.dact_z) { if (a.dact == TFASR_ACT_SWISH) need |= E_DACT; else generic = true; }
     if (a.drop_p > 0.f) need |= E_DROP;
     if (a.res) need |= E_RES;
+  }
+  if constexpr (!TA) {  // thousands of tiles: 256-row tiles, one 4-wave workgroup per CU (gemm_big.h)
+    const int st = launch_big<TB>(a, generic, need, stream);
+    if (st != TFASR_STATUS_UNSUPPORTED) return st;
   }
   // (measured: NOT faster than the atomics - 34.8 vs 33.0 us on the [256,1024,19040] weight gradient, +5 ms on the step from
   // the extra workspace traffic - so callers only pass a workspace when TFASR_SPLITK_WS=1; kept as the deterministic option)

@@ -185,3 +185,24 @@ def test_grouped_weight_gradients_one_launch(dev, dtype):
         np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=rtol, atol=atol * 70, err_msg=str((M, N, K)))
         if gb is not None:
             np.testing.assert_allclose(gb.cpu().numpy(), refb.numpy(), rtol=1e-3, atol=atol * 70)
+
+
+@pytest.mark.parametrize("tb", [False, True])
+@pytest.mark.parametrize("mnk", [(140001, 1000, 320), (140001, 320, 1000), (133000, 256, 2304), (131072 + 77, 448, 200)])
+def test_256_row_tiles_for_products_with_thousands_of_tiles(dev, tb, mnk, monkeypatch):
+    """gemm_big.h: 256 x 256 / 256 x 320 tiles, one 8-wave workgroup per CU (joint projection, its data gradient, conv2).  Sizes of the
+    joint network (V = 1000, J = 320), a ragged last row tile (shifted, not clamped), a K tail (1000 = 15 * 64 + 40) and a partial
+    last column tile; vs torch's f32 product of the same bf16 operands and (bias case) bitwise vs the 128-row route."""
+    M, N, K = mnk
+    g = torch.Generator().manual_seed(M + N + K)
+    A = (torch.randn(M, K, generator=g) * 0.5).to(dev).to(torch.bfloat16)
+    B = (torch.randn((N, K) if tb else (K, N), generator=g) * 0.5).to(dev).to(torch.bfloat16)
+    bias = torch.randn(N, generator=g).to(dev)
+    out = kernels.matmul(A, B, trans_b=tb, bias=bias)
+    ref = A.float() @ (B.float().T if tb else B.float()) + bias
+    torch.cuda.synchronize()
+    err = (out.float() - ref).abs().max().item()
+    assert err <= 2e-2 * float(np.sqrt(K)) * 0.25 + 0.05 * ref.abs().max().item() * 2 ** -7, err
+    # rows of the shifted last tile are written exactly once with the same values: compare with the product of the last rows alone
+    tail_rows = kernels.matmul(A[-300:].contiguous(), B, trans_b=tb, bias=bias)
+    assert torch.equal(out[-300:], tail_rows)

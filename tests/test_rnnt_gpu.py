@@ -144,6 +144,36 @@ def test_packed_lattice_equals_dense(dev, dtype):
     np.testing.assert_allclose(costs_p.cpu().numpy(), ref_loss, rtol=1e-3 if dtype == torch.bfloat16 else 1e-5)
 
 
+def test_joint_projection_statistics_256_row_tiles(dev):
+    """The same statistics from gemm_big.h's epilogue (taken in the MFMA C layout with DPP row reductions): a joint of bench size
+    (150 000 packed rows x 1000 classes -> 2344 tiles of 256 x 256) against torch on the f32 product."""
+    from tensorflowasr_amd import kernels as K
+
+    g = torch.Generator().manual_seed(5)
+    total, V, J = 150001, 1000, 320
+    h = (torch.randn(total, J, generator=g) * 0.5).to(dev).to(torch.bfloat16)
+    W = (torch.randn(J, V, generator=g) * 0.3).to(dev).to(torch.bfloat16)
+    bias = torch.randn(V, generator=g).to(dev)
+    row_label = torch.randint(-1, V, (total,), generator=g, dtype=torch.int32).to(dev)
+    parts = -(-V // 128) * 2
+    lse_part = torch.full((total, parts, 2), float("nan"), dtype=torch.float32, device=dev)
+    pick = torch.full((total, 2), float("nan"), dtype=torch.float32, device=dev)
+    logits = torch.empty(total, V, dtype=torch.bfloat16, device=dev)
+    K.gemm(h, W, logits, total, V, J, J, V, V, bias=bias, lse=(lse_part, row_label, pick))
+    torch.cuda.synchronize()
+    x32 = h.float() @ W.float() + bias
+    assert (logits.float() - x32).abs().max().item() < 0.25
+    assert not torch.isnan(lse_part).any()
+    m, s = lse_part[..., 0], lse_part[..., 1]
+    mx = m.max(dim=1).values
+    lse = mx + torch.log((s * torch.exp(m - mx[:, None])).sum(1))
+    np.testing.assert_allclose(lse.cpu().numpy(), torch.logsumexp(x32, 1).cpu().numpy(), rtol=1e-5, atol=3e-5)
+    np.testing.assert_allclose(pick[:, 0].cpu().numpy(), x32[:, 0].cpu().numpy(), rtol=1e-5, atol=1e-5)
+    has = row_label >= 0
+    want = x32[has, row_label[has].long()]
+    np.testing.assert_allclose(pick[has, 1].cpu().numpy(), want.cpu().numpy(), rtol=1e-5, atol=1e-5)
+
+
 @pytest.mark.parametrize("V", [1000, 256, 29 * 8])
 def test_joint_projection_epilogue_statistics_feed_the_loss(dev, V):
     """tfasr_gemm_args.lse_part / pick: the vocabulary projection's epilogue emits max / sum-exp per 64-column slice and the blank /
