@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define TFASR_ABI_VERSION 14
+#define TFASR_ABI_VERSION 15
 
 typedef enum {
   TFASR_STATUS_SUCCESS = 0,
@@ -466,6 +466,13 @@ typedef struct {
      buffer for the positional-projection gradient (otherwise carved out of scratch and cleared in-stream). */
   int prezeroed;
   float* dpext_zero;
+  /* Backward: wgrad_slot = 1 or 2 lets the block queue its grouped weight-gradient launch on an internal second stream, so that it
+     runs beside the NEXT block's backward (whose chain of small dependent kernels leaves CUs idle) instead of in line.  The caller
+     then (i) gives the two slots disjoint `scratch` arenas and alternates them block by block - a call with slot k first makes
+     `stream` wait for the launches queued by the earlier calls with slot k, whose operands live in that arena - (ii) keeps the
+     forward stash of a block alive until tfasr_block_wgrad_join, and (iii) calls tfasr_block_wgrad_join before anything reads the
+     gradients.  0 = in line on `stream` (default). */
+  int wgrad_slot;
 } tfasr_block_io;
 
 size_t tfasr_block_ctx_bytes(void);
@@ -473,6 +480,8 @@ int tfasr_block_workspace_sizes(const tfasr_block_cfg* cfg, size_t* stash_bytes,
                                 size_t* bwd_scratch_bytes);
 int tfasr_block_fwd(const tfasr_block_cfg* cfg, const tfasr_block_params* params, const tfasr_block_io* io, void* ctx,
                     int phase, void* stream);
+/* `stream` waits for the weight-gradient launches queued under the slots in slot_mask (bit 0 = slot 1, bit 1 = slot 2); no-op if none */
+int tfasr_block_wgrad_join(int slot_mask, void* stream);
 int tfasr_block_bwd(const tfasr_block_cfg* cfg, const tfasr_block_params* params, const tfasr_block_io* io, void* ctx,
                     int phase, void* stream);
 

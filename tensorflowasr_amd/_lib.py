@@ -69,7 +69,7 @@ class BlockIO(Structure):
         ("x_in", c_void_p), ("x_out", c_void_p), ("dy", c_void_p), ("dx", c_void_p), ("lengths", c_void_p),
         ("bn_stats", c_void_p), ("bn_bstats", c_void_p),
         ("stash", c_void_p), ("stash_bytes", c_size_t), ("scratch", c_void_p), ("scratch_bytes", c_size_t),
-        ("prezeroed", c_int), ("dpext_zero", c_void_p),
+        ("prezeroed", c_int), ("dpext_zero", c_void_p), ("wgrad_slot", c_int),
     ]
 
 
@@ -149,7 +149,7 @@ def load(build_if_missing=True):
     return lib
 
 
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 
 STATUS_UNSUPPORTED = 3

@@ -73,6 +73,10 @@ class ConformerTransducer:
         self._drop_epoch = 0  # bumped once per forward pass so every step draws fresh dropout masks
         # one native call per Conformer block (csrc/block.hip) instead of ~70 per-kernel calls from Python
         self.native_blocks = os.environ.get("TFASR_NATIVE_BLOCK", "1") != "0"
+        # grouped weight gradients of a block on the executor's second stream (tfasr_block_io.wgrad_slot), beside the next block's
+        # backward.  MEASURED slower (same box, Conformer-M, 32 utterances: 29.06 vs 28.45 ms/step, also at lowest stream priority): the
+        # 512-workgroup group launch takes CUs from the dependent chain, which is the critical path.  Opt-in: TFASR_WGRAD_STREAM=1.
+        self.wgrad_stream = os.environ.get("TFASR_WGRAD_STREAM", "0") == "1"
         self._blk_params, self._blk_sizes = {}, {}
         self._zero_pool = {}
         self.fuse_joint_stats = os.environ.get("TFASR_JOINT_STATS", "1") != "0"
@@ -724,9 +728,16 @@ class ConformerTransducer:
             bstats = torch.empty(2 * d, dtype=torch.float32, device=self.device)
             io.prezeroed &= ~2
             io.dpext_zero = None
-        scratch = K.workspace(bscr_b, self.device, "blk_bwd")
+        # grouped weight gradients of this block on the executor's second stream, beside the next block's backward: two arenas, alternating
+        slot = 0
+        if self.wgrad_stream and self.dtype == torch.bfloat16:
+            self._wgrad_flip = 3 - getattr(self, "_wgrad_flip", 2)
+            slot = self._wgrad_flip
+        scratch = K.workspace(bscr_b, self.device, f"blk_bwd{slot}")
         io.dy, io.dx, io.bn_bstats = dy.data_ptr(), dx.data_ptr(), bstats.data_ptr()
         io.scratch, io.scratch_bytes = scratch.data_ptr(), scratch.numel()
+        io.wgrad_slot = slot
+        self._last_wgrad_slot = slot
         if self.dp.world > 1 and not cfgk.dw_norm_layer:
             K.block_bwd(cfgk, P, io, cbuf, K._lib.PHASE_A)
             self.dp.allreduce_stats_(bstats)
@@ -762,12 +773,24 @@ class ConformerTransducer:
         e = ctx["enc"]
         if "bwd_shape" in self._zero_pool:
             self._zero_pool["bwd"] = torch.zeros(*self._zero_pool.pop("bwd_shape"), dtype=torch.float32, device=self.device)
+        # a block's gradients are complete once its weight-gradient group on the second stream is: its bucket is released one block
+        # later, after this stream has been made to wait for that group (the wait the next user of the slot's arena needs anyway)
+        prev = None
         for i in reversed(range(self.cfg.num_blocks)):
+            self._last_wgrad_slot = 0
             if f"enc/block{i}/native" in ctx:
                 dx = self._block_bwd_native(dx, i, ctx)
             else:
                 dx = self._block_bwd(dx, i, e["B"], e["T"], e["elen_dev"], ctx)
-            self._bucket_after_block(i)
+            if prev is not None:
+                if prev[1]:
+                    K.block_wgrad_join(1 << (prev[1] - 1))
+                self._bucket_after_block(prev[0])
+            prev = (i, self._last_wgrad_slot)
+        if prev is not None:
+            if prev[1]:
+                K.block_wgrad_join(3)
+            self._bucket_after_block(prev[0])
         t0 = self._tick("subsampling_bwd")
         self._subsampling_bwd(dx, ctx)
         self._tock("subsampling_bwd", t0)

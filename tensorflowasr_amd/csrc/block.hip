@@ -70,6 +70,12 @@ struct Side {
   hipStream_t s2 = nullptr;
   hipEvent_t fork = nullptr, join = nullptr;
   bool ok = false;
+  // asynchronous grouped weight gradients (tfasr_block_io.wgrad_slot): a stream of their own, per slot the event behind the last
+  // launch queued under it
+  hipStream_t sw = nullptr;
+  hipEvent_t wfork = nullptr, wdone[2] = {nullptr, nullptr};
+  bool wpending[2] = {false, false};
+  bool wok = false, wtried = false;
 };
 Side& side_for_device() {
   static Side sides[64];
@@ -87,6 +93,27 @@ Side& side_for_device() {
     }
   }
   return sd;
+}
+// the weight-gradient stream, created on first use
+bool wgrad_stream_ready(Side& sd) {
+  if (!sd.wtried) {
+    sd.wtried = true;
+    int least = 0, greatest = 0;  // lowest priority: the group only fills what the main chain leaves idle
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = 0;
+    sd.wok = hipStreamCreateWithPriority(&sd.sw, hipStreamNonBlocking, least) == hipSuccess &&
+             hipEventCreateWithFlags(&sd.wfork, hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&sd.wdone[0], hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&sd.wdone[1], hipEventDisableTiming) == hipSuccess;
+  }
+  return sd.wok;
+}
+int wgrad_wait(Side& sd, int slot_mask, hipStream_t s) {
+  for (int k = 0; k < 2; ++k)
+    if ((slot_mask >> k & 1) && sd.wpending[k]) {
+      if (hipStreamWaitEvent(s, sd.wdone[k], 0) != hipSuccess) return TFASR_STATUS_EXECUTION_FAILED;
+      sd.wpending[k] = false;
+    }
+  return TFASR_STATUS_SUCCESS;
 }
 
 struct Ex {
@@ -153,7 +180,17 @@ struct Ex {
   }
   void flush_wgrads() {
     if (pending.empty()) return;
-    chk(tfasr_gemm_group(pending.data(), (int)pending.size(), s));
+    const int slot = io->wgrad_slot;
+    if ((slot == 1 || slot == 2) && side && wgrad_stream_ready(*side)) {
+      // beside the next block's backward: everything queued on `s` so far (the operands) precedes the launch, nothing on `s` waits
+      // for it until the slot's arena is reused or the caller joins
+      if (hipEventRecord(side->wfork, s) != hipSuccess || hipStreamWaitEvent(side->sw, side->wfork, 0) != hipSuccess) chk(TFASR_STATUS_EXECUTION_FAILED);
+      chk(tfasr_gemm_group(pending.data(), (int)pending.size(), side->sw));
+      if (hipEventRecord(side->wdone[slot - 1], side->sw) != hipSuccess) chk(TFASR_STATUS_EXECUTION_FAILED);
+      side->wpending[slot - 1] = true;
+    } else {
+      chk(tfasr_gemm_group(pending.data(), (int)pending.size(), s));
+    }
     pending.clear();
   }
   void rewind(size_t mark) { if (!defer) scratch.off = mark; }
@@ -566,6 +603,8 @@ struct Ex {
     const int d = c->d;
     const bool dr = drop_p() > 0.f;
     if (phase & TFASR_PHASE_A) {
+      // the arena of this slot may still be read by the weight gradients an earlier block queued on the second stream
+      if (!dry && side && (io->wgrad_slot == 1 || io->wgrad_slot == 2)) chk(wgrad_wait(*side, 1 << (io->wgrad_slot - 1), s));
       k->bw_cur = act(scratch, rows * d);
       k->bw_nxt = act(scratch, rows * d);
       k->bw_curd = dr ? act(scratch, rows * d) : nullptr;
@@ -656,6 +695,10 @@ extern "C" int tfasr_block_fwd(const tfasr_block_cfg* c, const tfasr_block_param
   e.forward(phase);
   if (!e.stash.ok || !e.scratch.ok) return TFASR_STATUS_INVALID_VALUE;  // arena too small
   return e.st;
+}
+
+extern "C" int tfasr_block_wgrad_join(int slot_mask, void* stream) {
+  return wgrad_wait(side_for_device(), slot_mask, (hipStream_t)stream);
 }
 
 extern "C" int tfasr_block_bwd(const tfasr_block_cfg* c, const tfasr_block_params* P, const tfasr_block_io* io, void* ctx, int phase,

@@ -659,6 +659,11 @@ def block_bwd(cfg, params, io, ctx, phase):
     check(_L().tfasr_block_bwd(ctypes.byref(cfg), ctypes.byref(params), ctypes.byref(io), ctx, phase, _stream()), "block_bwd")
 
 
+def block_wgrad_join(slot_mask=3):
+    """The current stream waits for the grouped weight-gradient launches queued on the executor's second stream (tfasr_block_io.wgrad_slot)."""
+    check(_L().tfasr_block_wgrad_join(int(slot_mask), _stream()), "block_wgrad_join")
+
+
 # --------------------------------------------------------------------------------- ContextNet pieces
 def rows_subsample_fwd(x, stride):
     B, T, C = x.shape
