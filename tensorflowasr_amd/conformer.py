@@ -261,13 +261,21 @@ class ConformerTransducer:
                 shift.append(dt * (F2 + 1) + df)
                 blk.append(pt * 2 + pf)
             dev = self.device
-            fwd_a = torch.tensor([sh * 4 * C + b * C for sh, b in zip(shift, blk)], dtype=torch.int64, device=dev)
+            # K order of the segmented GEMMs: 64-channel segments, channel chunk outermost and the taps of one parity block next to each
+            # other, so that consecutive slabs read the SAME rows of the S tensor shifted by one slot (taps of a parity block differ by a
+            # row shift only) while they are still in L2 - in tap-major order (a whole 256-channel tap at a time) every tap re-fetched
+            # its rows: 1.48 GB fetched for a 0.51 GB input (rocprofv3 FETCH_SIZE), L2 hit rate 0.49
+            nck = C // 64 if C % 64 == 0 and os.environ.get("TFASR_CONV2_TAPMAJOR", "0") != "1" else 1
+            ck = C // nck
+            order = sorted(range(9), key=lambda i: (blk[i], i))
+            fwd_a = torch.tensor([shift[i] * 4 * C + blk[i] * C + cc * ck for cc in range(nck) for i in order], dtype=torch.int64, device=dev)
+            fwd_b = torch.tensor([(i * C + cc * ck) * C for cc in range(nck) for i in order], dtype=torch.int64, device=dev)
             dgrad = {}
             for b in range(4):
                 segs = [i for i in range(9) if blk[i] == b]
-                dgrad[b] = (segs, torch.tensor([-shift[i] * C for i in segs], dtype=torch.int64, device=dev),
-                            torch.tensor([i * C * C for i in segs], dtype=torch.int64, device=dev))
-            self._consts[key] = (shift, blk, fwd_a, dgrad)
+                dgrad[b] = (segs, torch.tensor([-shift[i] * C + cc * ck for cc in range(nck) for i in segs], dtype=torch.int64, device=dev),
+                            torch.tensor([i * C * C + cc * ck for cc in range(nck) for i in segs], dtype=torch.int64, device=dev))
+            self._consts[key] = (shift, blk, (fwd_a, fwd_b, ck), dgrad)
         return self._consts[key]
 
     def _subsampling_fwd_s2d(self, feats, flen, training, ctx):
@@ -306,7 +314,7 @@ class ConformerTransducer:
                 K.gemm(flat[base + shift[i] * 4 * C + blk[i] * C:], W[i * C:(i + 1) * C], o, rows, C, C, 4 * C, C, C,
                        bias=ps.p("enc/sub/conv1/b") if i == 0 else None, accumulate=i > 0)
         else:
-            K.gemm(a1, W, o, rows, C, 9 * C, 4 * C, C, C, bias=ps.p("enc/sub/conv1/b"), seg=(fwd_a, None, C))
+            K.gemm(a1, W, o, rows, C, 9 * C, 4 * C, C, C, bias=ps.p("enc/sub/conv1/b"), seg=fwd_a)
         K.halo_zero(o, B, T2, F2, C)
         _, a2 = self._salloc(rows, C, 0)
         _, bn1 = self._bn_fwd(o, "enc/sub/bn1", training, ACT_SWISH, rows=B * T2 * F2, y=a2)
@@ -364,7 +372,7 @@ class ConformerTransducer:
                 for j, i in enumerate(segs):
                     K.gemm(do_full[dobase - shift[i] * C:], W[i * C:(i + 1) * C], out, rows, C, C, C, C, 4 * C, trans_b=True, accumulate=j > 0)
             else:
-                K.gemm(do, W, out, rows, C, len(segs) * C, C, C, 4 * C, trans_b=True, seg=(a_off, b_off, C))
+                K.gemm(do, W, out, rows, C, len(segs) * C, C, C, 4 * C, trans_b=True, seg=(a_off, b_off, C // (a_off.numel() // len(segs))))
         # BatchNorm0 + conv1 backward from the feature map (only the valid slots of da1 are read: its halos need no clearing)
         fin0, count0 = s["bn0"]
         w0, b0 = ps.p("enc/sub/conv0/w"), ps.p("enc/sub/conv0/b")
