@@ -283,7 +283,20 @@ __global__ __launch_bounds__(256) void col2im_kernel(const T* __restrict__ dcol,
 //   conv1_bn_bwd_apply : d conv1 = scale (dz - mean dz - xhat mean(dz xhat)); its weight / bias gradients accumulated on the fly
 // One (b, t) output row per block iteration, thread = (8-channel group, f sub-lane); taps + bias live in registers.
 // MODE 0 stats, 1 apply, 2 backward stats, 3 backward apply + weight gradient.
-template <typename T, int MODE>
+// CPT channels per thread: 8 (MODE 0 / 1) or 4 (the backward passes: 80 accumulators + 72 taps at 8 channels per thread left one
+// wave per SIMD - 257 registers - and the dependent activation chain had nothing to hide behind: 885 us for 0.3 ms of VALU work)
+template <int N> __device__ __forceinline__ void ldn(const float* p, float (&v)[N]) {
+#pragma unroll
+  for (int k = 0; k < N; k += 4) { const float4 a = *reinterpret_cast<const float4*>(p + k); v[k] = a.x; v[k + 1] = a.y; v[k + 2] = a.z; v[k + 3] = a.w; }
+}
+template <int N> __device__ __forceinline__ void ldn(const bf16_t* p, float (&v)[N]) {
+#pragma unroll
+  for (int k = 0; k < N; k += 4) {
+    const uint2 a = *reinterpret_cast<const uint2*>(p + k);
+    v[k] = __uint_as_float(a.x << 16); v[k + 1] = __uint_as_float(a.x & 0xffff0000u); v[k + 2] = __uint_as_float(a.y << 16); v[k + 3] = __uint_as_float(a.y & 0xffff0000u);
+  }
+}
+template <typename T, int MODE, int CPT>
 __global__ __launch_bounds__(256) void conv1_bn_kernel(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
                                                        const float* __restrict__ fin, const float* __restrict__ bstats, float inv_count,
                                                        T* __restrict__ y, const T* __restrict__ dy, float* __restrict__ out0,
@@ -292,32 +305,32 @@ __global__ __launch_bounds__(256) void conv1_bn_kernel(const T* __restrict__ x, 
   float* xs = sm;                       // [3][F0 + 2] input rows of the current output row (zero padded)
   float* red = sm + 3 * (F0 + 2);       // [NQ][C] block reduction
   constexpr int NQ = MODE == 3 ? 10 : 2;
-  const int cgn = C / 8, FS = 256 / cgn;
+  const int cgn = C / CPT, FS = 256 / cgn;
   const int cg = threadIdx.x % cgn, fs = threadIdx.x / cgn;
   const bool on = fs < FS;
-  const int c = cg * 8;
+  const int c = cg * CPT;
   const int T2 = (T1 + 1) / 2, F2 = (F1 + 1) / 2;
-  float wr[9][8], br[8];
+  float wr[9][CPT], br[CPT];
 #pragma unroll
-  for (int k = 0; k < 8; ++k) br[k] = bias ? bias[c + k] : 0.f;
+  for (int k = 0; k < CPT; ++k) br[k] = bias ? bias[c + k] : 0.f;
 #pragma unroll
   for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
-    for (int k = 0; k < 8; ++k) wr[tap][k] = w[tap * C + c + k];
-  float mean[8], rstd[8], sc[8], sh[8], s0[8], s1[8];
+    for (int k = 0; k < CPT; ++k) wr[tap][k] = w[tap * C + c + k];
+  float mean[CPT], rstd[CPT], sc[CPT], sh[CPT], s0[CPT], s1[CPT];
   if (MODE >= 1) {
 #pragma unroll
-    for (int k = 0; k < 8; ++k) { mean[k] = fin[c + k]; rstd[k] = fin[C + c + k]; sc[k] = fin[2 * C + c + k]; sh[k] = fin[3 * C + c + k]; }
+    for (int k = 0; k < CPT; ++k) { mean[k] = fin[c + k]; rstd[k] = fin[C + c + k]; sc[k] = fin[2 * C + c + k]; sh[k] = fin[3 * C + c + k]; }
   }
   if (MODE == 3) {
 #pragma unroll
-    for (int k = 0; k < 8; ++k) { s0[k] = bstats[c + k] * inv_count; s1[k] = bstats[C + c + k] * inv_count; }
+    for (int k = 0; k < CPT; ++k) { s0[k] = bstats[c + k] * inv_count; s1[k] = bstats[C + c + k] * inv_count; }
   }
-  float acc2[NQ][8];
+  float acc2[NQ][CPT];
 #pragma unroll
   for (int q = 0; q < NQ; ++q)
 #pragma unroll
-    for (int k = 0; k < 8; ++k) acc2[q][k] = 0.f;
+    for (int k = 0; k < CPT; ++k) acc2[q][k] = 0.f;
   const int nrows = B * T1;
   for (int row = blockIdx.x; row < nrows; row += gridDim.x) {
     const int b = row / T1, t = row - b * T1;
@@ -329,30 +342,31 @@ __global__ __launch_bounds__(256) void conv1_bn_kernel(const T* __restrict__ x, 
     __syncthreads();
     if (!on) continue;
     for (int f = fs; f < F1; f += FS) {
-      float a[8];
+      float a[CPT];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) a[k] = br[k];
+      for (int k = 0; k < CPT; ++k) a[k] = br[k];
 #pragma unroll
       for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
         for (int kw = 0; kw < 3; ++kw) {
           const float xv = xs[kh * (F0 + 2) + 2 * f + kw];
 #pragma unroll
-          for (int k = 0; k < 8; ++k) a[k] += wr[kh * 3 + kw][k] * xv;
+          for (int k = 0; k < CPT; ++k) a[k] += wr[kh * 3 + kw][k] * xv;
         }
       if (MODE == 0) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) { acc2[0][k] += a[k]; acc2[1][k] += a[k] * a[k]; }
+        for (int k = 0; k < CPT; ++k) { acc2[0][k] += a[k]; acc2[1][k] += a[k] * a[k]; }
       } else if (MODE == 1) {
-        float o[8];
+        float o[CPT];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) o[k] = swishf_(a[k] * sc[k] + sh[k]);
-        st8(y + s2d_off(b, t, f, T2, F2, C) + c, o);
+        for (int k = 0; k < CPT; ++k) o[k] = swishf_(a[k] * sc[k] + sh[k]);
+        static_assert(MODE != 1 || CPT == 8, "apply pass: 8 channels per thread");
+        if constexpr (CPT == 8) st8(y + s2d_off(b, t, f, T2, F2, C) + c, o);
       } else {
-        float d[8];
-        ld8(dy + s2d_off(b, t, f, T2, F2, C) + c, d);
+        float d[CPT];
+        ldn<CPT>(dy + s2d_off(b, t, f, T2, F2, C) + c, d);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
+        for (int k = 0; k < CPT; ++k) {
           const float dz = d[k] * dswishf_(a[k] * sc[k] + sh[k]);
           const float xh = (a[k] - mean[k]) * rstd[k];
           if (MODE == 2) { acc2[0][k] += dz; acc2[1][k] += dz * xh; }
@@ -365,10 +379,10 @@ __global__ __launch_bounds__(256) void conv1_bn_kernel(const T* __restrict__ x, 
             for (int kw = 0; kw < 3; ++kw) {
               const float xv = xs[kh * (F0 + 2) + 2 * f + kw];
 #pragma unroll
-              for (int k = 0; k < 8; ++k) acc2[kh * 3 + kw][k] += d[k] * xv;
+              for (int k = 0; k < CPT; ++k) acc2[kh * 3 + kw][k] += d[k] * xv;
             }
 #pragma unroll
-          for (int k = 0; k < 8; ++k) acc2[9][k] += d[k];
+          for (int k = 0; k < CPT; ++k) acc2[9][k] += d[k];
         }
       }
     }
@@ -383,7 +397,7 @@ __global__ __launch_bounds__(256) void conv1_bn_kernel(const T* __restrict__ x, 
 #pragma unroll
     for (int q = 0; q < NQ; ++q)
 #pragma unroll
-      for (int k = 0; k < 8; ++k) atomicAdd(&red[q * C + c + k], acc2[q][k]);
+      for (int k = 0; k < CPT; ++k) atomicAdd(&red[q * C + c + k], acc2[q][k]);
   }
   __syncthreads();
   for (int i = threadIdx.x; i < NQ * C; i += 256) {
@@ -505,15 +519,16 @@ template <int MODE>
 static int conv1_bn_launch(const void* x, const float* w, const float* bias, const float* fin, const float* bstats, float count, void* y,
                            const void* dy, float* out0, float* out1, int B, int T0, int F0, int C, int dtype, void* stream_) {
   if (!x || !w || B <= 0 || T0 <= 0 || F0 <= 0 || C <= 0 || C > 256 || (C % 8)) return TFASR_STATUS_INVALID_VALUE;
+  constexpr int CPT = MODE >= 2 ? 4 : 8;
   const int T1 = (T0 + 1) / 2, F1 = (F0 + 1) / 2;
   hipStream_t s = (hipStream_t)stream_;
   const int grid = std::min(B * T1, MODE == 1 ? 8192 : 1024);
   const size_t smem = (size_t)(3 * (F0 + 2) + (MODE == 3 ? 10 : 2) * C) * sizeof(float);
   const float inv = count > 0.f ? 1.f / count : 0.f;
   DISPATCH_T(dtype,
-             hipLaunchKernelGGL((conv1_bn_kernel<float, MODE>), dim3(grid), dim3(256), smem, s, (const float*)x, w, bias, fin, bstats, inv, (float*)y,
+             hipLaunchKernelGGL((conv1_bn_kernel<float, MODE, CPT>), dim3(grid), dim3(256), smem, s, (const float*)x, w, bias, fin, bstats, inv, (float*)y,
                                 (const float*)dy, out0, out1, B, T0, F0, T1, F1, C),
-             hipLaunchKernelGGL((conv1_bn_kernel<bf16_t, MODE>), dim3(grid), dim3(256), smem, s, (const bf16_t*)x, w, bias, fin, bstats, inv, (bf16_t*)y,
+             hipLaunchKernelGGL((conv1_bn_kernel<bf16_t, MODE, CPT>), dim3(grid), dim3(256), smem, s, (const bf16_t*)x, w, bias, fin, bstats, inv, (bf16_t*)y,
                                 (const bf16_t*)dy, out0, out1, B, T0, F0, T1, F1, C));
   TFASR_CHECK_LAUNCH();
   return TFASR_STATUS_SUCCESS;
