@@ -108,7 +108,8 @@ int tfasr_ctc_greedy_decode(const void* logits, const int32_t* logit_len, int32_
  *             D = v   (out_f32 ? f32 : dtype);  accumulate!=0 -> atomicAdd into f32 D (split-K legal)
  * A, B, res, dact_z, prez are `dtype`; bias is f32.
  * ---------------------------------------------------------------------------------------------- */
-typedef enum { TFASR_ACT_NONE = 0, TFASR_ACT_SWISH = 1, TFASR_ACT_TANH = 2, TFASR_ACT_SIGMOID = 3 } tfasr_act_t;
+/* TANH_OUT is a `dact` only: dact_z holds tanh's OUTPUT h (not its argument), the factor is 1 - h^2 (the joint network keeps h) */
+typedef enum { TFASR_ACT_NONE = 0, TFASR_ACT_SWISH = 1, TFASR_ACT_TANH = 2, TFASR_ACT_SIGMOID = 3, TFASR_ACT_TANH_OUT = 4 } tfasr_act_t;
 
 typedef struct {
   const void* A; const void* B; void* D;
@@ -228,6 +229,7 @@ int tfasr_joint_bwd(const void* h, const void* dh, void* denc, void* dpred, int 
  * (zero outside the valid ranges) */
 int tfasr_joint_fwd_packed(const void* enc, const void* pred, void* h, const long* cell_off, const int32_t* label_len,
                            long total_cells, int B, int T, int U1, int J, int dtype, void* stream);
+/* h == NULL: dh already carries the tanh' factor (the producing GEMM's dact = TFASR_ACT_TANH_OUT epilogue): plain segment sums */
 int tfasr_joint_bwd_packed(const void* h, const void* dh, void* denc, void* dpred, const long* cell_off,
                            const int32_t* label_len, const int32_t* logit_len, int B, int T, int U1, int J, int dtype,
                            void* stream);

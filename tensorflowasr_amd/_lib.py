@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libtfasr_hip.so")
 
 TFASR_F32, TFASR_BF16 = 0, 1
-ACT_NONE, ACT_SWISH, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3
+ACT_NONE, ACT_SWISH, ACT_TANH, ACT_SIGMOID, ACT_TANH_OUT = 0, 1, 2, 3, 4
 
 
 class TfasrError(RuntimeError):

@@ -16,7 +16,7 @@ import numpy as np
 import torch
 
 from . import kernels as K
-from .kernels import ACT_NONE, ACT_SWISH
+from .kernels import ACT_NONE, ACT_SWISH, ACT_TANH_OUT
 from .params import ParamStore
 from .schemas import PredictInput, PredictOutput, TrainData, TrainInput, TrainOutput
 
@@ -993,8 +993,9 @@ class ConformerTransducer:
             self._tock("rnnt_loss", t0, 2.0 * total * V * logits.element_size())
             if not want_backward:
                 return costs
-            dh = self._dense_bwd(dlogits, h, "joint/vocab/w", "joint/vocab/b")
-            de, dp = K.joint_bwd_packed(h, dh, off_dev, ul_dev, tl_dev, B, T, U1)
+            # tanh' folded into the data gradient's epilogue (dact = TANH_OUT: times 1 - h^2): the segment sums read one tensor, not two
+            dh = self._dense_bwd(dlogits, h, "joint/vocab/w", "joint/vocab/b", dact_z=h, dact=ACT_TANH_OUT)
+            de, dp = K.joint_bwd_packed(None, dh, off_dev, ul_dev, tl_dev, B, T, U1)
             denc = self._dense_bwd(de.view(B * T, J), enc, "joint/enc/w", "joint/enc/b")
             dpred = self._dense_bwd(dp.view(B * U1, J), pred, "joint/pred/w", "joint/pred/b")
         main = torch.cuda.current_stream()

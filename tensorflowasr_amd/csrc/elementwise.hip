@@ -402,10 +402,15 @@ __global__ __launch_bounds__(128) void joint_bwd_kernel(const T* __restrict__ h,
   }
   for (int k = 0; k < count; ++k) {
     float hv[8], dv[8];
-    ld8(h + base + k * stride + j, hv);
     ld8(dh + base + k * stride + j, dv);
+    if (h) {  // uniform
+      ld8(h + base + k * stride + j, hv);
 #pragma unroll
-    for (int q = 0; q < 8; ++q) acc[q] += dv[q] * (1.f - hv[q] * hv[q]);
+      for (int q = 0; q < 8; ++q) acc[q] += dv[q] * (1.f - hv[q] * hv[q]);
+    } else {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) acc[q] += dv[q];
+    }
   }
   st8(dout + (long)blockIdx.x * J + j, acc);
 }
@@ -479,10 +484,15 @@ __global__ __launch_bounds__(128) void joint_bwd_packed_kernel(const T* __restri
   }
   for (int k = 0; k < count; ++k) {
     float hv[8], dv[8];
-    ld8(h + base + k * stride + j, hv);
     ld8(dh + base + k * stride + j, dv);
+    if (h) {  // uniform
+      ld8(h + base + k * stride + j, hv);
 #pragma unroll
-    for (int q = 0; q < 8; ++q) acc[q] += dv[q] * (1.f - hv[q] * hv[q]);
+      for (int q = 0; q < 8; ++q) acc[q] += dv[q] * (1.f - hv[q] * hv[q]);
+    } else {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) acc[q] += dv[q];
+    }
   }
   st8(dout + (long)blockIdx.x * J + j, acc);
 }
@@ -802,7 +812,7 @@ extern "C" int tfasr_joint_fwd_packed(const void* enc, const void* pred, void* h
 extern "C" int tfasr_joint_bwd_packed(const void* h, const void* dh, void* denc, void* dpred, const long* cell_off,
                                       const int32_t* label_len, const int32_t* logit_len, int B, int T, int U1, int J, int dtype,
                                       void* stream_) {
-  if (!h || !dh || !denc || !dpred || !cell_off || !label_len || !logit_len || B <= 0 || T <= 0 || U1 <= 0 || J <= 0 || J % 8)
+  if (!dh || !denc || !dpred || !cell_off || !label_len || !logit_len || B <= 0 || T <= 0 || U1 <= 0 || J <= 0 || J % 8)
     return TFASR_STATUS_INVALID_VALUE;
   hipStream_t s = (hipStream_t)stream_;
   const int gy = (J / 8 + 127) / 128;

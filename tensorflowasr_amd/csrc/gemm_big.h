@@ -406,6 +406,16 @@ void gemm_big_kernel(const tfasr_gemm_args p, const int gx, const int gy, const 
             const int row = m0 + wm * 64 + i * 16 + h * RPP + prow;
             if (row >= mlo && row < p.M && col0 < p.N && col0 >= n0) {
               const long idx0 = (long)row * p.ldd + col0;
+              if constexpr ((EPI & E_DACT) != 0) {  // dact = TANH_OUT: times 1 - h^2, h = the activation's output (row-major like D)
+                const bf16_t* hz = (const bf16_t*)p.dact_z;
+                float z[8];
+                if (full) ld8(hz + idx0, z);
+                else
+_Pragma("unroll")
+                  for (int q = 0; q < 8; ++q) z[q] = (col0 + q < p.N) ? bf16_to_f32(hz[idx0 + q]) : 0.f;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) y[q] *= 1.f - z[q] * z[q];
+              }
               if (full) st8(Dt + idx0, y);
               else
 _Pragma("unroll")
@@ -437,7 +447,7 @@ int g_gemm_big_mode = -1;  // probes / tests: 0 = never, 1 = default rule; -1 = 
 
 // eligibility + launch; UNSUPPORTED -> the caller continues with the 128-row tiles
 template <bool TB>
-int launch_big(const tfasr_gemm_args& a, bool generic, int need, hipStream_t stream) {
+int launch_big(const tfasr_gemm_args& a, bool generic, int need, bool tanh_out, hipStream_t stream) {
   static const bool env_off = getenv("TFASR_GEMM_BIG") && getenv("TFASR_GEMM_BIG")[0] == '0';
   const bool off = g_gemm_big_mode < 0 ? env_off : g_gemm_big_mode == 0;
   if (off || generic || need != 0 || a.accumulate || a.split_k > 1 || a.nb1 * a.nb2 != 1 || a.colsum || a.out_f32 || a.K < 2 * BK || (a.K & 7) || a.M < 256 || (TB && (a.N & 7))) return TFASR_STATUS_UNSUPPORTED;
@@ -453,6 +463,7 @@ int launch_big(const tfasr_gemm_args& a, bool generic, int need, hipStream_t str
   const long ntiles = (long)gx * gy;
   static const long min_tiles = getenv("TFASR_GEMM_BIG_T") ? atol(getenv("TFASR_GEMM_BIG_T")) : 2L * num_cus();
   if (ntiles < min_tiles || ntiles > 0x7fffffffL) return TFASR_STATUS_UNSUPPORTED;
+  if (tanh_out && (!TB || seg || a.lse_part)) return TFASR_STATUS_UNSUPPORTED;
   if (a.lse_part && !(a.row_label && a.pick && bn == 256 && a.lse_parts == ((a.N + 127) / 128) * 2)) return TFASR_STATUS_UNSUPPORTED;
   const int ncu = num_cus();
   const int G = ntiles >= ncu ? (ncu & ~7) : (int)ntiles;
@@ -463,7 +474,12 @@ int launch_big(const tfasr_gemm_args& a, bool generic, int need, hipStream_t str
   };
   constexpr int S256 = 2 * (256 * BK * 2 + 256 * BK * 2) + 8 * 8 * 68 * 4;
   constexpr int S320 = 2 * (256 * BK * 2 + 320 * BK * 2);
-  if (bn == 320) {
+  if (tanh_out) {
+    if constexpr (TB) {
+      if (bn == 320) go(gemm_big_kernel<true, 320, E_DACT, false>, S320);
+      else go(gemm_big_kernel<true, 256, E_DACT, false>, S256);
+    } else return TFASR_STATUS_UNSUPPORTED;
+  } else if (bn == 320) {
     if constexpr (TB) go(gemm_big_kernel<true, 320, 0, false>, S320);
     else return TFASR_STATUS_UNSUPPORTED;
   } else if (a.lse_part) {

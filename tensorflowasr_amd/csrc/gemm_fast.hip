@@ -206,6 +206,7 @@ __device__ __forceinline__ float dact_f(float z, int act) {
     case TFASR_ACT_SWISH: return dswishf_(z);
     case TFASR_ACT_TANH: { const float t = tanhf(z); return 1.f - t * t; }
     case TFASR_ACT_SIGMOID: { const float s = sigmoidf_(z); return s * (1.f - s); }
+    case TFASR_ACT_TANH_OUT: return 1.f - z * z;
     default: return 1.f;
   }
 }
@@ -936,8 +937,10 @@ int launch_one(const tfasr_gemm_args& a, hipStream_t stream) {
     if (a.drop_p > 0.f) need |= E_DROP;
     if (a.res) need |= E_RES;
   }
-  if constexpr (!TA) {  // thousands of tiles: 256-row tiles, one 4-wave workgroup per CU (gemm_big.h)
-    const int st = launch_big<TB>(a, generic, need, stream);
+  if constexpr (!TA) {  // thousands of tiles: 256-row tiles, one 8-wave workgroup per CU (gemm_big.h)
+    const bool tanh_out = !a.accumulate && a.dact_z && a.dact == TFASR_ACT_TANH_OUT;  // the only epilogue term gemm_big knows beyond bias
+    const bool other = a.out_f32 || a.act != TFASR_ACT_NONE || a.prez || (a.dact_z && !tanh_out);
+    const int st = launch_big<TB>(a, other, need, tanh_out, stream);
     if (st != TFASR_STATUS_UNSUPPORTED) return st;
   }
   // (measured: NOT faster than the atomics - 34.8 vs 33.0 us on the [256,1024,19040] weight gradient, +5 ms on the step from

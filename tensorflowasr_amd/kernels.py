@@ -8,7 +8,7 @@ import os
 import torch
 
 from . import _lib
-from ._lib import ACT_NONE, ACT_SIGMOID, ACT_SWISH, ACT_TANH, TFASR_BF16, TFASR_F32, GemmArgs, check  # noqa: F401
+from ._lib import ACT_NONE, ACT_SIGMOID, ACT_SWISH, ACT_TANH, ACT_TANH_OUT, TFASR_BF16, TFASR_F32, GemmArgs, check  # noqa: F401
 
 _WS_CACHE = {}
 _SPLITK_WS = os.environ.get("TFASR_SPLITK_WS", "0") == "1"
@@ -357,10 +357,11 @@ def joint_fwd_packed(enc, pred, cell_off, label_len, total_cells):
 
 
 def joint_bwd_packed(h, dh, cell_off, label_len, logit_len, B, T, U1):
-    J = h.shape[1]
-    denc = torch.empty(B, T, J, dtype=h.dtype, device=h.device)
-    dpred = torch.empty(B, U1, J, dtype=h.dtype, device=h.device)
-    check(_L().tfasr_joint_bwd_packed(_p(h), _p(dh), _p(denc), _p(dpred), _p(cell_off), _p(label_len), _p(logit_len), B, T, U1, J, _dt(h), _stream()), "joint_bwd_packed")
+    """h = None: dh already carries the tanh' factor (produced with dact=ACT_TANH_OUT)."""
+    J = dh.shape[1]
+    denc = torch.empty(B, T, J, dtype=dh.dtype, device=dh.device)
+    dpred = torch.empty(B, U1, J, dtype=dh.dtype, device=dh.device)
+    check(_L().tfasr_joint_bwd_packed(_p(h) if h is not None else None, _p(dh), _p(denc), _p(dpred), _p(cell_off), _p(label_len), _p(logit_len), B, T, U1, J, _dt(dh), _stream()), "joint_bwd_packed")
     return denc, dpred
 
 

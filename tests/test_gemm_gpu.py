@@ -206,3 +206,19 @@ def test_256_row_tiles_for_products_with_thousands_of_tiles(dev, tb, mnk, monkey
     # rows of the shifted last tile are written exactly once with the same values: compare with the product of the last rows alone
     tail_rows = kernels.matmul(A[-300:].contiguous(), B, trans_b=tb, bias=bias)
     assert torch.equal(out[-300:], tail_rows)
+
+
+@pytest.mark.parametrize("M", [300, 140001])
+def test_data_gradient_times_tanh_prime_from_the_output(dev, M):
+    """dact = TANH_OUT: dx = (dy @ W^T) * (1 - h^2) with h = tanh's OUTPUT (the joint network keeps h, not its argument); the 128-row
+    route (generic epilogue) and the 256 x 320 tiles."""
+    from tensorflowasr_amd.kernels import ACT_TANH_OUT
+    g = torch.Generator().manual_seed(M)
+    N, K = 640, 1000
+    dy = (torch.randn(M, K, generator=g) * 0.3).to(dev).to(torch.bfloat16)
+    W = (torch.randn(N, K, generator=g) * 0.3).to(dev).to(torch.bfloat16)
+    h = torch.tanh(torch.randn(M, N, generator=g)).to(dev).to(torch.bfloat16)
+    out = kernels.matmul(dy, W, trans_b=True, dact_z=h, dact=ACT_TANH_OUT)
+    ref = (dy.float() @ W.float().T) * (1 - h.float() ** 2)
+    torch.cuda.synchronize()
+    assert (out.float() - ref).abs().max().item() <= 0.02 * ref.abs().max().item() + 1e-2
