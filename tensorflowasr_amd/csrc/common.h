@@ -65,8 +65,11 @@ __device__ __forceinline__ void st8(bf16_t* p, const float (&v)[8]) {
 // All-reduce inside each row of 16 lanes with DPP row rotations (plain VALU, ~8 cycles each): __shfl_xor compiles to
 // ds_bpermute_b32 (an LDS round trip, ~100 cycles, and these chains are dependent) - the 32 of them per key block were
 // half of the fused attention forward's time.
+// bound_ctrl on (every lane of a row rotation is valid, so it changes nothing): with old = 0 and bound_ctrl OFF the compiler
+// materialises the zero and keeps a separate v_mov_dpp per step - 3 instructions per step instead of one v_add / v_max with a DPP
+// operand (96 vs 32 instructions per key block in the fused attention forward)
 template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
 }
 __device__ __forceinline__ float row16_sum(float v) {
   v += dpp_mov<0x128>(v);  // row_ror:8
