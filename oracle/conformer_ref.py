@@ -550,7 +550,10 @@ def transformer_schedule(step, dmodel, warmup_steps=10000, scale=2.0, max_lr=Non
     """TransformerSchedule.__call__ (optimizers/schedules.py:28-37), float32 arithmetic."""
     f32 = np.float32
     step = f32(step)
-    lr = f32(dmodel) ** f32(-0.5) * min(step ** f32(-0.5), step * f32(warmup_steps) ** f32(-1.5))
+    if step <= 0:  # keras' `iterations` is 0 at the first update: tf gives min(inf, 0) = 0 (then max_lr / min_lr as usual)
+        lr = f32(0.0)
+    else:
+        lr = f32(dmodel) ** f32(-0.5) * min(step ** f32(-0.5), step * f32(warmup_steps) ** f32(-1.5))
     lr = f32(scale) * lr
     if max_lr is not None:
         lr = min(f32(max_lr), lr)

@@ -178,7 +178,8 @@ def conformer_tiny(vocab_size=29, **over):
 def transformer_schedule(step, dmodel, warmup_steps=10000, scale=2.0, max_lr=None, min_lr=None):
     """TransformerSchedule.__call__ (optimizers/schedules.py:28-37)."""
     step = float(step)
-    lr = scale * dmodel ** -0.5 * min(step ** -0.5, step * warmup_steps ** -1.5)
+    # step 0 (keras' `iterations` at the first update): tf gives min(inf, 0) = 0
+    lr = scale * dmodel ** -0.5 * min(step ** -0.5, step * warmup_steps ** -1.5) if step > 0 else 0.0
     if max_lr is not None:
         lr = min(max_lr, lr)
     if min_lr is not None:

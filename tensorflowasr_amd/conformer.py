@@ -1028,7 +1028,10 @@ class ConformerTransducer:
         """BaseModel._apply_gradients -> keras Adam (base_model.py:185-192; small.yml.j2:73-87) + L2 regulariser gradient."""
         o = self.optimizer
         self.step += 1
-        lr = self.learning_rate(self.step)
+        # keras evaluates the schedule at `iterations` BEFORE the increment (0 at the first update: the reference's first step has
+        # lr = 0 with TransformerSchedule) and bias-corrects with iterations + 1 [ext: keras BaseOptimizer._get_current_learning_rate,
+        # Adam.update_step]
+        lr = self.learning_rate(self.step - 1)
         ps = self.ps
         K.adam(ps.flat, ps.grad, ps.adam_m, ps.adam_v, ps.n_reg, lr, self.step, o["beta1"], o["beta2"], o["eps"], o["weight_decay"],
                self.cfg.l2, grad_scale)

@@ -64,8 +64,9 @@ __global__ void ctc_scan_kernel(const T* __restrict__ logits, const float* __res
   bool skipb = false; // transition s -> s+2 (beta) allowed
   if (act && (s & 1)) {
     lab = min(max(labels[(long)b * U + (s >> 1)], 0), V - 1);
-    if (s >= 2) skip = lab != labels[(long)b * U + (s >> 1) - 1];
-    if (s + 2 < S) skipb = lab != labels[(long)b * U + (s >> 1) + 1];
+    // neighbours clamped like `lab` itself (an out-of-range label is folded into [0, V-1] everywhere, not only at its own state)
+    if (s >= 2) skip = lab != min(max(labels[(long)b * U + (s >> 1) - 1], 0), V - 1);
+    if (s + 2 < S) skipb = lab != min(max(labels[(long)b * U + (s >> 1) + 1], 0), V - 1);
   }
   const T* lg = logits + (long)b * Tm * V;
   const float* ls = lse + (long)b * Tm;

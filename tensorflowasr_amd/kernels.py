@@ -604,6 +604,11 @@ def ctc_loss_fwd_bwd(logits, labels, label_len, logit_len, grad_scale=None, grad
     """logits [B,T,V] -> (costs [B], grads or None); tf.nn.ctc_loss semantics (losses/ctc_loss.py:57-66)."""
     B, T, V = logits.shape
     U = labels.shape[1]
+    # kernel limits (one lattice state per thread, per-class occupancy in LDS): say so instead of a bare INVALID_VALUE
+    if 2 * U + 1 > 1024:
+        raise ValueError(f"tfasr_ctc_loss: padded label length {U} > 511 (2U+1 lattice states must fit one 1024-thread workgroup); crop the label padding")
+    if V * 4 > 64 * 1024:
+        raise ValueError(f"tfasr_ctc_loss: vocabulary {V} > 16384 classes (the per-class occupancy buffer of the gradient kernel lives in LDS)")
     costs = torch.empty(B, dtype=torch.float32, device=logits.device)
     if want_grads and grads is None:
         grads = torch.empty_like(logits)

@@ -100,14 +100,17 @@ def test_f32_step_matches_oracle(dev, lens, ulens):
     np.testing.assert_allclose(mm.numpy(), ((1 - 0.99 ** 3) * stats["enc/block0/conv/bn"][0]).numpy(), rtol=2e-2, atol=1e-5)
     # optimizer --------------------------------------------------------------------------------------
     before = model.ps.export_keras()
+    assert model.step == 0 and model.learning_rate(0) == 0.0  # keras: schedule(iterations = 0) at the first update
+    model.step = 7                                              # a later update: lr = schedule(7), bias correction with 8
     lr = model.apply_gradients()
+    assert lr == model.learning_rate(7) > 0
     after = model.ps.export_keras()
     k = "enc/block1/ff2/d1/w"
     g = mine[k] + 2 * cfg.l2 * before[k]
-    p_ref, _, _ = R.adam_step(before[k], g, torch.zeros_like(g), torch.zeros_like(g), 1, lr, 0.9, 0.98, 1e-9, 1e-6)
+    p_ref, _, _ = R.adam_step(before[k], g, torch.zeros_like(g), torch.zeros_like(g), 8, lr, 0.9, 0.98, 1e-9, 1e-6)
     np.testing.assert_allclose(after[k].numpy(), p_ref.numpy(), rtol=1e-5, atol=1e-7)
     k = "enc/block1/ff2/d1/b"  # not regularised
-    p_ref, _, _ = R.adam_step(before[k], mine[k], torch.zeros_like(mine[k]), torch.zeros_like(mine[k]), 1, lr, 0.9, 0.98, 1e-9, 1e-6)
+    p_ref, _, _ = R.adam_step(before[k], mine[k], torch.zeros_like(mine[k]), torch.zeros_like(mine[k]), 8, lr, 0.9, 0.98, 1e-9, 1e-6)
     np.testing.assert_allclose(after[k].numpy(), p_ref.numpy(), rtol=1e-5, atol=1e-7)
 
 
