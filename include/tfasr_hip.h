@@ -184,6 +184,10 @@ int tfasr_bn_finalize(const float* stats, float count, const float* gamma, const
 int tfasr_bn_apply_fwd(const void* x, const float* fin, void* y, long rows, int C, int act, int dtype, void* stream);
 int tfasr_bn_bwd_stats(const void* x, const void* dy, const float* fin, float* bstats, long rows, int C, int act,
                        int dtype, void* stream);
+/* + the BatchNorm parameter gradients in the same launch: dbeta += grad_scale * bstats[0:C], dgamma += grad_scale * bstats[C:2C]
+ * (either may be NULL) */
+int tfasr_bn_apply_bwd_grads(const void* x, const void* dy, const float* fin, const float* bstats, float count, void* dx, long rows,
+                            int C, int act, float* dgamma, float* dbeta, float grad_scale, int dtype, void* stream);
 int tfasr_bn_apply_bwd(const void* x, const void* dy, const float* fin, const float* bstats, float count, void* dx,
                        long rows, int C, int act, int dtype, void* stream);
 
@@ -203,6 +207,10 @@ int tfasr_glu_bwd(const void* x, const void* dy, void* dx, long rows, int C, int
 int tfasr_dwconv_fwd(const void* x, const float* w, const float* bias, void* y, int B, int T, int C, int K, int dtype,
                      void* stream);
 int tfasr_dwconv_bwd_data(const void* dy, const float* w, void* dx, int B, int T, int C, int K, int dtype, void* stream);
+/* data gradient followed by the backward of the GLU in front of the conv (glu_x = the GLU's input [B*T, 2C], dglu = its gradient) in
+ * one launch; TFASR_STATUS_UNSUPPORTED (f32, C % 8 != 0, K > 32): call tfasr_dwconv_bwd_data + tfasr_glu_bwd instead */
+int tfasr_dwconv_bwd_data_glu(const void* dy, const float* w, const void* glu_x, void* dglu, int B, int T, int C, int K, int dtype,
+                              void* stream);
 int tfasr_dwconv_bwd_weight(const void* x, const void* dy, float* dw, float* dbias, int B, int T, int C, int K,
                             int dtype, void* stream);
 /* same result through a caller-owned workspace of per-block partial sums + a reduce kernel (no atomics; 2.5x faster at the

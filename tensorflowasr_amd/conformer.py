@@ -226,12 +226,8 @@ class ConformerTransducer:
         bstats = torch.zeros(2 * C, dtype=torch.float32, device=self.device)
         K.bn_bwd_stats(x2d, dy2d, fin, bstats, act)
         self.dp.allreduce_stats_(bstats)
-        dx = K.bn_apply_bwd(x2d, dy2d, fin, bstats, count, act, dx=dx)
-        # bstats = (sum dz, sum dz*xhat) over the GLOBAL batch; the flat-gradient all-reduce sums over ranks again
-        inv = 1.0 / self.dp.world
-        K.axpy(ps.g(name + "/b"), bstats[:C].contiguous(), inv)
-        K.axpy(ps.g(name + "/g"), bstats[C:].contiguous(), inv)
-        return dx
+        # bstats = (sum dz, sum dz*xhat) over the GLOBAL batch = the beta / gamma gradients; the flat-gradient all-reduce sums over ranks again
+        return K.bn_apply_bwd(x2d, dy2d, fin, bstats, count, act, dx=dx, dgamma=ps.g(name + "/g"), dbeta=ps.g(name + "/b"), grad_scale=1.0 / self.dp.world)
 
     # =================================================================================== subsampling
     # ---- conv2 without a patch matrix: haloed space-to-depth layout (csrc/conv2d.hip, include/tfasr_hip.h) -----------------

@@ -550,14 +550,17 @@ struct Ex {
         chk(tfasr_layernorm_bwd(dyn, k->cv_cv, fp(TFASR_BP_CV_BN_G), k->cv_nmean, k->cv_nrstd, nullptr, dcv, gp(TFASR_BP_CV_BN_G), gp(TFASR_BP_CV_BN_B), rows, d,
                                 c->dtype, s));
       } else {
-        chk(tfasr_bn_apply_bwd(k->cv_cv, k->bw_dsw, k->cv_fin, io->bn_bstats, (float)(rows * c->world), dcv, rows, d, TFASR_ACT_SWISH, c->dtype, s));
-        const float inv = 1.f / (float)c->world;
-        chk(tfasr_axpy(gp(TFASR_BP_CV_BN_B), io->bn_bstats, inv, d, s));
-        chk(tfasr_axpy(gp(TFASR_BP_CV_BN_G), io->bn_bstats + d, inv, d, s));
+        // bstats = (sum dz, sum dz xhat) over the GLOBAL batch = the beta / gamma gradients; the flat-gradient all-reduce sums over ranks again
+        chk(tfasr_bn_apply_bwd_grads(k->cv_cv, k->bw_dsw, k->cv_fin, io->bn_bstats, (float)(rows * c->world), dcv, rows, d, TFASR_ACT_SWISH,
+                                     gp(TFASR_BP_CV_BN_G), gp(TFASR_BP_CV_BN_B), 1.f / (float)c->world, c->dtype, s));
       }
       chk(tfasr_dwconv_bwd_weight_ws(k->cv_g, dcv, gp(TFASR_BP_CV_DW_W), gp(TFASR_BP_CV_DW_B), c->B, c->T, d, c->ksize, c->dtype, dwws, dwws_bytes, s));
-      chk(tfasr_dwconv_bwd_data(dcv, fp(TFASR_BP_CV_DW_W), dg, c->B, c->T, d, c->ksize, c->dtype, s));
-      chk(tfasr_glu_bwd(k->cv_a, dg, da, rows, d, c->dtype, s));
+      // depthwise data gradient + GLU backward in one launch when the channel-pair kernel applies
+      const int fst = tfasr_dwconv_bwd_data_glu(dcv, fp(TFASR_BP_CV_DW_W), k->cv_a, da, c->B, c->T, d, c->ksize, c->dtype, s);
+      if (fst == TFASR_STATUS_UNSUPPORTED) {
+        chk(tfasr_dwconv_bwd_data(dcv, fp(TFASR_BP_CV_DW_W), dg, c->B, c->T, d, c->ksize, c->dtype, s));
+        chk(tfasr_glu_bwd(k->cv_a, dg, da, rows, d, c->dtype, s));
+      } else chk(fst);
     }
     dense_bwd(da, k->cv_ln, TFASR_BP_CV_PW1_W, TFASR_BP_CV_PW1_B, d, 2 * d, dln);
     ln_bwd(dln, k->cv_x, TFASR_BP_CV_LN_G, TFASR_BP_CV_LN_B, k->cv_mean, k->cv_rstd, dy, dx, dxd, next_site);

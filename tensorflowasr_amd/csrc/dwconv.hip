@@ -55,9 +55,12 @@ template <int TT, int... J>
 __device__ __forceinline__ void dw_all(float2_t (&acc)[TT], const float2_t (&wk)[MAXK], const char* col, std::integer_sequence<int, J...>) {
   ((dw_step<TT, J>(acc, wk, lds2(col + J * ROWB), std::make_integer_sequence<int, TT>{})), ...);
 }
-template <bool REV>
+// GLU (data gradient only): the GLU backward of the layer in front of the depthwise conv in the same pass - `gx` = the GLU's input
+// [rows, 2C] (a | b halves), y = its gradient [rows, 2C]: da = dx sigma(b), db = dx a sigma(b) (1 - sigma(b)); dx itself is not stored.
+template <bool REV, bool GLU = false>
 __global__ __launch_bounds__(256) void dwconv_tile_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w,
-                                                          const float* __restrict__ bias, bf16_t* __restrict__ y, int Tn, int C, int K) {
+                                                          const float* __restrict__ bias, bf16_t* __restrict__ y, int Tn, int C, int K,
+                                                          const bf16_t* __restrict__ gx = nullptr) {
   extern __shared__ __attribute__((aligned(16))) char lds[];  // (2*TG + MAXK - 1) rows; rows past K-1+2*TG stay zero-weighted
   const int c0 = blockIdx.x * SLAB;
   const int t0 = blockIdx.y * (2 * TG);
@@ -85,7 +88,17 @@ __global__ __launch_bounds__(256) void dwconv_tile_kernel(const bf16_t* __restri
     const int tg0 = t0 + grp * TG;
 #pragma unroll
     for (int i = 0; i < TG; ++i)
-      if (tg0 + i < Tn) st2(y + ubase + (long)(tg0 + i) * C + c, acc[i]);
+      if (tg0 + i < Tn) {
+        if constexpr (GLU) {
+          const long row2 = (ubase + (long)(tg0 + i) * C) * 2;  // element offset of the row in the [rows, 2C] tensors
+          const float2_t a = ld2(gx + row2 + c), b = ld2(gx + row2 + C + c);
+          const float s0 = sigmoidf_(b[0]), s1 = sigmoidf_(b[1]);
+          st2(y + row2 + c, float2_t{acc[i][0] * s0, acc[i][1] * s1});
+          st2(y + row2 + C + c, float2_t{acc[i][0] * a[0] * s0 * (1.f - s0), acc[i][1] * a[1] * s1 * (1.f - s1)});
+        } else {
+          st2(y + ubase + (long)(tg0 + i) * C + c, acc[i]);
+        }
+      }
   }
 }
 
@@ -204,6 +217,20 @@ int tfasr_dwconv_wgrad_ws_try(const void* x, const void* dy, float* dw, float* d
   TFASR_CHECK_LAUNCH();
   dim3 rg(((K + 1) * SLAB + 255) / 256, gx, 16);
   hipLaunchKernelGGL(dwconv_wgrad_reduce_kernel, rg, dim3(256), 0, s, (const float*)ws, dw, dbias, B * gy, gx, K, C);
+  TFASR_CHECK_LAUNCH();
+  return TFASR_STATUS_SUCCESS;
+}
+
+// data gradient + GLU backward in one launch (bf16, C % 8 == 0); UNSUPPORTED -> the caller runs the two separately
+extern "C" int tfasr_dwconv_bwd_data_glu(const void* dy, const float* w, const void* glu_x, void* dglu, int B, int T, int C, int K, int dtype,
+                                         void* stream_) {
+  if (!dy || !w || !glu_x || !dglu || B <= 0 || T <= 0 || C <= 0 || K <= 0) return TFASR_STATUS_INVALID_VALUE;
+  if (dtype != TFASR_BF16 || (C & 7) || K > MAXK || !al16(dy) || !al4(dglu) || !al4(glu_x)) return TFASR_STATUS_UNSUPPORTED;
+  const int gx = (C + SLAB - 1) / SLAB;
+  dim3 grid(gx, (T + 2 * TG - 1) / (2 * TG), B);
+  const int smem = (2 * TG + MAXK - 1) * ROWB;
+  hipLaunchKernelGGL((dwconv_tile_kernel<true, true>), grid, dim3(256), smem, (hipStream_t)stream_, (const bf16_t*)dy, w, (const float*)nullptr, (bf16_t*)dglu, T, C, K,
+                     (const bf16_t*)glu_x);
   TFASR_CHECK_LAUNCH();
   return TFASR_STATUS_SUCCESS;
 }

@@ -243,11 +243,14 @@ def bn_bwd_stats(x, dy, fin, bstats, act=ACT_NONE):
     check(_L().tfasr_bn_bwd_stats(_p(x), _p(dy), _p(fin), _p(bstats), rows, C, act, _dt(x), _stream()), "bn_bwd_stats")
 
 
-def bn_apply_bwd(x, dy, fin, bstats, count, act=ACT_NONE, dx=None):
+def bn_apply_bwd(x, dy, fin, bstats, count, act=ACT_NONE, dx=None, dgamma=None, dbeta=None, grad_scale=1.0):
+    """dgamma / dbeta (f32 views of the gradient buffer): += grad_scale * the two statistics, in the same launch."""
     rows, C = x.numel() // x.shape[-1], x.shape[-1]
     if dx is None:
         dx = torch.empty_like(x)
-    check(_L().tfasr_bn_apply_bwd(_p(x), _p(dy), _p(fin), _p(bstats), float(count), _p(dx), rows, C, act, _dt(x), _stream()), "bn_apply_bwd")
+    check(_L().tfasr_bn_apply_bwd_grads(_p(x), _p(dy), _p(fin), _p(bstats), float(count), _p(dx), rows, C, act,
+                                        _p(dgamma) if dgamma is not None else None, _p(dbeta) if dbeta is not None else None, float(grad_scale),
+                                        _dt(x), _stream()), "bn_apply_bwd")
     return dx
 
 
@@ -297,6 +300,17 @@ def dwconv_bwd_data(dy, w):
     dx = torch.empty_like(dy)
     check(_L().tfasr_dwconv_bwd_data(_p(dy), _p(w), _p(dx), B, T, C, w.shape[0], _dt(dy), _stream()), "dwconv_bwd_data")
     return dx
+
+
+def dwconv_bwd_data_glu(dy, w, glu_x):
+    """Depthwise data gradient + the backward of the GLU in front of the conv in one launch (bf16); None if the fused kernel does not apply."""
+    B, T, C = dy.shape
+    dglu = torch.empty_like(glu_x)
+    st = _L().tfasr_dwconv_bwd_data_glu(_p(dy), _p(w), _p(glu_x), _p(dglu), B, T, C, w.shape[0], _dt(dy), _stream())
+    if st == _lib.STATUS_UNSUPPORTED:
+        return None
+    check(st, "dwconv_bwd_data_glu")
+    return dglu
 
 
 def dwconv_bwd_weight(x, dy, dw, dbias):

@@ -544,3 +544,19 @@ def test_s2d_layout_conv2_equals_im2col_route(dev, dtype, C, T0, F0):
     got = o.view(B, T2 + 1, F2 + 1, C)[:, 1:, 1:]
     tol = 1e-4 if dtype == torch.float32 else 2e-2
     np.testing.assert_allclose(got.float().cpu().numpy(), ref.float().cpu().numpy(), rtol=tol, atol=tol)
+
+
+def test_depthwise_data_gradient_with_glu_backward_fused(dev):
+    """tfasr_dwconv_bwd_data_glu = tfasr_dwconv_bwd_data followed by tfasr_glu_bwd (the fused launch keeps the depthwise gradient in f32)."""
+    from tensorflowasr_amd import kernels as K
+    g = torch.Generator().manual_seed(3)
+    B, T, C, Kw = 3, 77, 256, 31
+    dy = torch.randn(B, T, C, generator=g).to(dev).to(torch.bfloat16)
+    w = (torch.randn(Kw, C, generator=g) * 0.2).to(dev)
+    gx = torch.randn(B, T, 2 * C, generator=g).to(dev).to(torch.bfloat16)
+    fused = K.dwconv_bwd_data_glu(dy, w, gx)
+    assert fused is not None
+    ref = K.glu_bwd(gx, K.dwconv_bwd_data(dy, w))
+    torch.cuda.synchronize()
+    err = (fused.float() - ref.float()).abs().max().item()
+    assert err <= 2e-2 * ref.float().abs().max().item() + 1e-3, err
