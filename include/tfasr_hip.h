@@ -312,6 +312,15 @@ int tfasr_lstm_step_bwd(const void* dy, long dy_stride_b, const float* dhr, floa
                         long cprev_stride_b, const int32_t* lengths, int t, void* dz, long dz_stride_b, int B, int P,
                         int dtype, void* stream);
 
+/* The whole recurrence of the prediction network queued by one call (per step: recurrent GEMM h_{t-1} @ R into `hr` + the cell stage).
+ * xg / gates [B,U1,4P], cseq (f32) / hseq / yseq [B,U1,P] row-major; rk = recurrent kernel [P,4P]; h0 / c0 may be NULL (zero state);
+ * hr [B,4P], dhr [B,P] f32 scratch; dh_carry / dc_carry [B,P] f32, zero on entry of the backward. */
+int tfasr_lstm_seq_fwd(const void* xg, const void* rk, const void* h0, long h0_stride_b, const float* c0, long c0_stride_b,
+                       const int32_t* lengths, void* gates, float* cseq, void* hseq, void* yseq, float* hr, int B, int U1, int P,
+                       int dtype, void* stream);
+int tfasr_lstm_seq_bwd(const void* dy, const void* rk, const void* gates, const float* cseq, const int32_t* lengths, void* dz,
+                       float* dh_carry, float* dc_carry, float* dhr, int B, int U1, int P, int dtype, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Greedy transducer search control (Transducer.recognize_batch / recognize_single, base_transducer.py:496-712).
  * mode 0 = batch variant, 1 = single (B == 1, `per_frame` [nframes] zero-initialised, tok_idx starts at -1).

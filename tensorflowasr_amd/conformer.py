@@ -818,13 +818,7 @@ class ConformerTransducer:
         yseq = torch.empty(B, U1, P, dtype=self.dtype, device=self.device)
         hr = torch.empty(B, 4 * P, dtype=torch.float32, device=self.device)
         Wrk = ps.w2d("pred/lstm/rk")
-        for t in range(U1):
-            hprev = hseq[:, t - 1] if t > 0 else h0
-            cprev = cseq[:, t - 1] if t > 0 else c0
-            use_hr = hprev is not None
-            if use_hr:
-                K.gemm(hprev, Wrk, hr, B, 4 * P, P, hprev.stride(0), 4 * P, 4 * P)
-            K.lstm_step_fwd(xg[:, t], hr if use_hr else None, hprev, cprev, plen_dev, t, gates[:, t], cseq[:, t], hseq[:, t], yseq[:, t], B, P)
+        K.lstm_seq_fwd(xg, Wrk, h0, c0, plen_dev, gates, cseq, hseq, yseq, hr)  # the U1 steps queued from C (one host call)
         y2 = yseq.view(B * U1, P)
         if c.prediction_layer_norm:
             pred, mean, rstd = K.layernorm_fwd(y2, ps.p("pred/ln/g"), ps.p("pred/ln/b"))
@@ -848,11 +842,7 @@ class ConformerTransducer:
         dc_carry = torch.zeros(B, P, dtype=torch.float32, device=self.device)
         dhr = torch.empty(B, P, dtype=torch.float32, device=self.device)
         Wrk = ps.w2d("pred/lstm/rk")
-        for t in reversed(range(U1)):
-            K.lstm_step_bwd(dy[:, t], dhr if t < U1 - 1 else None, dh_carry, dc_carry, s["gates"][:, t], s["cseq"][:, t],
-                            s["cseq"][:, t - 1] if t > 0 else None, s["plen"], t, dz[:, t], B, P)
-            if t > 0:
-                K.gemm(dz[:, t], Wrk, dhr, B, P, 4 * P, dz.stride(0), 4 * P, P, trans_b=True)
+        K.lstm_seq_bwd(dy.contiguous(), Wrk, s["gates"], s["cseq"], s["plen"], dz, dh_carry, dc_carry, dhr)
         dz2 = dz.view(B * U1, 4 * P)
         # recurrent kernel: gR += sum_b h[b, :-1]^T @ dz[b, 1:]
         if U1 > 1:

@@ -7,6 +7,7 @@
 // The two GEMMs (x@W+b for all steps at once, h_{t-1}@R per step) run on the MFMA GEMM family; these
 // kernels do the per-step gate math, one thread per (batch row, hidden unit).
 #include "common.h"
+#include <string.h>
 
 namespace {
 
@@ -139,5 +140,61 @@ extern "C" int tfasr_lstm_step_bwd(const void* dy, long dy_stride_b, const float
                        lengths, t, (bf16_t*)dz, dz_stride_b, B, P);
   else return TFASR_STATUS_INVALID_VALUE;
   TFASR_CHECK_LAUNCH();
+  return TFASR_STATUS_SUCCESS;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The whole recurrence queued from C: per step one recurrent GEMM (h_{t-1} @ R, f32 out) + the cell kernel.  From Python the 2 x U1
+// launches of a direction cost ~15 us of host time each (ctypes marshalling), 2.8 ms per direction at U1 = 86 - with the train step's
+// host side at 25.8 of 28.0 ms the GPU idled between the steps of this chain.
+// Layouts as the step kernels take them: xg / gates [B, U1, 4P], cseq (f32) / hseq / yseq [B, U1, P]; hr [B, 4P] f32 scratch.
+// ---------------------------------------------------------------------------------------------------------------------------------
+extern "C" int tfasr_lstm_seq_fwd(const void* xg, const void* rk, const void* h0, long h0_stride_b, const float* c0, long c0_stride_b,
+                                  const int32_t* lengths, void* gates, float* cseq, void* hseq, void* yseq, float* hr, int B, int U1, int P,
+                                  int dtype, void* stream) {
+  if (!xg || !rk || !gates || !cseq || !hseq || !hr || B <= 0 || U1 <= 0 || P <= 0) return TFASR_STATUS_INVALID_VALUE;
+  const long esz = dtype == TFASR_F32 ? 4 : 2;
+  for (int t = 0; t < U1; ++t) {
+    const char* hprev = t > 0 ? (const char*)hseq + (long)(t - 1) * P * esz : (const char*)h0;
+    const long hps = t > 0 ? (long)U1 * P : h0_stride_b;
+    const float* cprev = t > 0 ? cseq + (long)(t - 1) * P : c0;
+    const long cps = t > 0 ? (long)U1 * P : c0_stride_b;
+    if (hprev) {
+      tfasr_gemm_args a;
+      memset(&a, 0, sizeof(a));
+      a.A = hprev; a.B = rk; a.D = hr; a.M = B; a.N = 4 * P; a.K = P; a.lda = hps; a.ldb = 4 * P; a.ldd = 4 * P;
+      a.nb1 = a.nb2 = 1; a.alpha = 1.f; a.beta = 1.f; a.dtype = dtype; a.out_f32 = 1; a.split_k = 1;
+      const int st = tfasr_gemm(&a, stream);
+      if (st != TFASR_STATUS_SUCCESS) return st;
+    }
+    const int st = tfasr_lstm_step_fwd((const char*)xg + (long)t * 4 * P * esz, (long)U1 * 4 * P, hprev ? hr : nullptr, hprev, hps, cprev, cps, lengths, t,
+                                       (char*)gates + (long)t * 4 * P * esz, (long)U1 * 4 * P, cseq + (long)t * P, (long)U1 * P,
+                                       (char*)hseq + (long)t * P * esz, (long)U1 * P, yseq ? (char*)yseq + (long)t * P * esz : nullptr, (long)U1 * P, B, P,
+                                       dtype, stream);
+    if (st != TFASR_STATUS_SUCCESS) return st;
+  }
+  return TFASR_STATUS_SUCCESS;
+}
+
+// backward through time: dz [B, U1, 4P] out; dh_carry / dc_carry [B, P] f32 zeroed by the caller; dhr [B, P] f32 scratch
+extern "C" int tfasr_lstm_seq_bwd(const void* dy, const void* rk, const void* gates, const float* cseq, const int32_t* lengths, void* dz,
+                                  float* dh_carry, float* dc_carry, float* dhr, int B, int U1, int P, int dtype, void* stream) {
+  if (!dy || !rk || !gates || !cseq || !dz || !dh_carry || !dc_carry || !dhr || B <= 0 || U1 <= 0 || P <= 0) return TFASR_STATUS_INVALID_VALUE;
+  const long esz = dtype == TFASR_F32 ? 4 : 2;
+  for (int t = U1 - 1; t >= 0; --t) {
+    int st = tfasr_lstm_step_bwd((const char*)dy + (long)t * P * esz, (long)U1 * P, t < U1 - 1 ? dhr : nullptr, dh_carry, dc_carry,
+                                 (const char*)gates + (long)t * 4 * P * esz, (long)U1 * 4 * P, cseq + (long)t * P, (long)U1 * P,
+                                 t > 0 ? cseq + (long)(t - 1) * P : nullptr, (long)U1 * P, lengths, t, (char*)dz + (long)t * 4 * P * esz, (long)U1 * 4 * P, B, P,
+                                 dtype, stream);
+    if (st != TFASR_STATUS_SUCCESS) return st;
+    if (t > 0) {  // dhr = dz_t @ R^T
+      tfasr_gemm_args a;
+      memset(&a, 0, sizeof(a));
+      a.A = (const char*)dz + (long)t * 4 * P * esz; a.B = rk; a.D = dhr; a.M = B; a.N = P; a.K = 4 * P; a.lda = (long)U1 * 4 * P; a.ldb = 4 * P; a.ldd = P;
+      a.trans_b = 1; a.nb1 = a.nb2 = 1; a.alpha = 1.f; a.beta = 1.f; a.dtype = dtype; a.out_f32 = 1; a.split_k = 1;
+      st = tfasr_gemm(&a, stream);
+      if (st != TFASR_STATUS_SUCCESS) return st;
+    }
+  }
   return TFASR_STATUS_SUCCESS;
 }

@@ -479,6 +479,22 @@ def lstm_step_bwd(dy_t, dhr, dh_carry, dc_carry, gates_t, c_t, c_prev, lengths, 
         _stream()), "lstm_step_bwd")
 
 
+def lstm_seq_fwd(xg, rk, h0, c0, lengths, gates, cseq, hseq, yseq, hr):
+    """All U1 steps of the recurrence in one host call (contiguous [B,U1,*] buffers)."""
+    B, U1, P4 = xg.shape
+    P = P4 // 4
+    assert xg.is_contiguous() and gates.is_contiguous() and cseq.is_contiguous() and hseq.is_contiguous() and (yseq is None or yseq.is_contiguous())
+    check(_L().tfasr_lstm_seq_fwd(_p(xg), _p(rk), _pv(h0), 0 if h0 is None else h0.stride(0), _pv(c0), 0 if c0 is None else c0.stride(0), _pv(lengths),
+                                  _p(gates), _p(cseq), _p(hseq), _pv(yseq), _p(hr), B, U1, P, _dt(xg), _stream()), "lstm_seq_fwd")
+
+
+def lstm_seq_bwd(dy, rk, gates, cseq, lengths, dz, dh_carry, dc_carry, dhr):
+    B, U1, P = dy.shape
+    assert dy.is_contiguous() and gates.is_contiguous() and cseq.is_contiguous() and dz.is_contiguous()
+    check(_L().tfasr_lstm_seq_bwd(_p(dy), _p(rk), _p(gates), _p(cseq), _pv(lengths), _p(dz), _p(dh_carry), _p(dc_carry), _p(dhr), B, U1, P, _dt(dy),
+                                  _stream()), "lstm_seq_bwd")
+
+
 # --------------------------------------------------------------------------------- subsampling
 def conv1_fwd(x, w, bias):
     B, T0, F0 = x.shape[:3]
