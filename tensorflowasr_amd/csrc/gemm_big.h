@@ -20,8 +20,8 @@
 // Measured (tools/hwprobe/gemm_big_test, [400000, 1000, 640] / [400000, 640, 1000]): joint projection + statistics 1147 -> 1025 us,
 // its data gradient 1113 -> 645 us (794 TFLOP/s) against the 128-row tiles; results bitwise equal (statistics: same to 5e-7).
 
-// acc += a x b, accumulator pinned IN PLACE in an accumulation register (ACC) or a vector register.  The compiler's own allocation
-// of 256-320 accumulator registers renamed them on every MFMA (destination != addend) and paid ~700 v_accvgpr moves per slab for it;
+// acc += a x b, accumulator pinned IN PLACE in an accumulation register (ACC) or a vector register.  Left to the compiler the accumulators
+// of this software-pipelined loop were renamed on every MFMA (destination != addend) at the price of ~700 v_accvgpr moves per slab;
 // the asm form also keeps the MFMA / DMA interleave exactly as written.  Hazards: an accumulator is re-read 64+ MFMAs after it was
 // written and fragment registers are rewritten a barrier later, far beyond any required wait states.
 template <bool ACC>
@@ -179,9 +179,9 @@ void gemm_big_kernel(const tfasr_gemm_args p, const int gx, const int gy, const 
   //   B  |  M1(s-1)+DMA  |   L0(s)      |   M0(s)      |   L1(s)      |  M1(s) + DMA ...     M = its 32-40 MFMAs
   // so every segment pairs one wave's MFMAs with its partner's LDS reads (all eight waves reading at once left the matrix pipe idle
   // for the ~500 clocks 96 KiB of fragments take, twice per slab).  The same instruction stream for both groups, B enters it through
-  // one extra barrier and A leaves it through one.  Stage s&1 is free once B has read L1(s), i.e. from P1(s+1): there both groups
-  // issue their pieces of slab s+2 (A beside its reads, B between its MFMAs); each wave waits for its own pieces before it arrives
-  // at the barrier that opens the slab (P1), so only one slab per wave is ever in flight and every vector-memory wait is vmcnt(0).
+  // one extra barrier and A leaves it through one.  Stage s&1 is free once B has read L1(s), i.e. from P1(s+1): from there the pieces of
+  // slab s+2 may be issued (schedule at the loop); each wave waits for its own pieces before it arrives at the barrier that opens the
+  // slab (P1), so only one slab per wave is ever in flight and every vector-memory wait is vmcnt(0).
   const bool grpB = w >= 4;
   Tile cur = tile_of(0);
   if (!cur.ok) return;
