@@ -292,6 +292,12 @@ int tfasr_relattn_fused_bwd_q2(const void* qkv, const float* ubias, const float*
                                const int32_t* lengths, const void* o, const void* dout, const float* lse, void* dqu, void* dqv, void* ds,
                                float* dvec, float* dpext, int B, int H, int T, int dh, int lds, float scale, int use_mask, int dtype,
                                void* stream);
+/* _q2 with the query gradient finished in the kernel: dq (row stride lddq, e.g. the q columns of the fused [B*T, 3*H*dh] gradient)
+ * = dqu + dqv, du [H*dh] += column sums of dqu, dv += column sums of dqv (what tfasr_bias2_bwd does in a separate pass) */
+int tfasr_relattn_fused_bwd_q3(const void* qkv, const float* ubias, const float* vbias, const void* pext, const int32_t* lengths,
+                               const void* o, const void* dout, const float* lse, void* dq, long lddq, float* du, float* dv, void* ds,
+                               float* dvec, float* dpext, int B, int H, int T, int dh, int lds, float scale, int use_mask, int dtype,
+                               void* stream);
 int tfasr_relattn_dpext(const void* ds, const void* qv, const int32_t* lengths, float* dpext, int B, int H, int T, int dh, int lds,
                         int use_mask, int dtype, void* stream);
 /* Fused backward, key side (run after _bwd_q, which also emits dvec [B,H,T] = rowsum(dout*o)): writes the k and v column

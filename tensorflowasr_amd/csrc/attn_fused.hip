@@ -293,12 +293,16 @@ __device__ __forceinline__ short8_t row_frag(const bf16_t* row, int k0) {
 // rows already in LDS; dS itself is stored UNSKEWED [B,H,T,ldp] (half the bytes of the skewed [B,H,T,2T] matrix, no zero fill) for
 // relattn_dpext_kernel, and the bias-row share of dpext (pairs whose relative position is outside the sample's 2*len-1 encodings)
 // is accumulated here.  `dpos` / `ldp` then mean dS and its row stride.
-template <bool V2>
+// DQ (V2 only): the query gradient leaves the kernel complete - dq = dqu + dqv written into the q columns of the fused qkv gradient
+// (`dqu` = that pointer, row stride `lddq`), du += colsum(dqu), dv += colsum(dqv) accumulated here - instead of two [B*T, H*dh]
+// tensors for a separate bias-gradient pass (tfasr_bias2_bwd).
+template <bool V2, bool DQ = false>
 __global__ __launch_bounds__(256, 2) void relattn_fused_bwd_q_kernel(
     const bf16_t* __restrict__ qkv, const float* __restrict__ ubias, const float* __restrict__ vbias,
     const bf16_t* __restrict__ pext, const int32_t* __restrict__ lengths, const bf16_t* __restrict__ o,
     const bf16_t* __restrict__ dout, const float* __restrict__ lse, bf16_t* __restrict__ dqu, bf16_t* __restrict__ dpos,
-    float* __restrict__ dvec, int B, int H, int T, int ldp, float scale, int use_mask, bf16_t* __restrict__ dqv, float* __restrict__ dpext) {
+    float* __restrict__ dvec, int B, int H, int T, int ldp, float scale, int use_mask, bf16_t* __restrict__ dqv, float* __restrict__ dpext,
+    long lddq = 0, float* __restrict__ du = nullptr, float* __restrict__ dv = nullptr) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sK = smem;              // [64 j][64 dh], read both as rows (k = dh) and transposed (k = j)
   char* sV = sK + SK_BYTES;     // [64 j][64 dh]
@@ -532,8 +536,10 @@ __global__ __launch_bounds__(256, 2) void relattn_fused_bwd_q_kernel(
     bsum = row16_sum(bsum);
     bsum4[e] = bsum;
     if (i < T) {
+      if constexpr (!DQ) {
 #pragma unroll
-      for (int n = 0; n < 4; ++n) dqu[((long)b * T + i) * HD + h * DH + n * 16 + r] = f32_to_bf16(acc_q[n][e]);
+        for (int n = 0; n < 4; ++n) dqu[((long)b * T + i) * HD + h * DH + n * 16 + r] = f32_to_bf16(acc_q[n][e]);
+      }
       if constexpr (!V2) {
         bf16_t* prow = dpos + (((long)b * H + h) * T + i) * ldp;
         // valid columns: rr + shift for j in [0,T) with rr = T-1-i+j < 2len-1  ->  [T-1-i+shift, min(2T-1-i, 2len-1)+shift )
@@ -547,16 +553,23 @@ __global__ __launch_bounds__(256, 2) void relattn_fused_bwd_q_kernel(
   }
   if constexpr (V2) {
     // dqv_i = (dG @ window)_i + bsum_i * pext[R]   and   dpext[R] += sum_i bsum_i * (q_i + v)
-    float pbias[4], part[4];
+    float pbias[4], part[4], su[4], sv[4];
 #pragma unroll
-    for (int n = 0; n < 4; ++n) { pbias[n] = bf16_to_f32(pb[(long)R * HD + n * 16 + r]); part[n] = 0.f; }
+    for (int n = 0; n < 4; ++n) { pbias[n] = bf16_to_f32(pb[(long)R * HD + n * 16 + r]); part[n] = 0.f; su[n] = 0.f; sv[n] = 0.f; }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int i = i0 + w * 16 + g * 4 + e;
       if (i < T) {
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
-          dqv[((long)b * T + i) * HD + h * DH + n * 16 + r] = f32_to_bf16(acc_v[n][e] + bsum4[e] * pbias[n]);
+          const float gqv = acc_v[n][e] + bsum4[e] * pbias[n];
+          if constexpr (DQ) {
+            dqu[((long)b * T + i) * lddq + h * DH + n * 16 + r] = f32_to_bf16(acc_q[n][e] + gqv);
+            su[n] += acc_q[n][e];
+            sv[n] += gqv;
+          } else {
+            dqv[((long)b * T + i) * HD + h * DH + n * 16 + r] = f32_to_bf16(gqv);
+          }
           const float qvv = bf16_to_f32(f32_to_bf16(bf16_to_f32(qb[(long)i * LDQ + n * 16 + r]) + vbias[h * DH + n * 16 + r]));
           part[n] += bsum4[e] * qvv;
         }
@@ -568,6 +581,24 @@ __global__ __launch_bounds__(256, 2) void relattn_fused_bwd_q_kernel(
       v += __shfl_xor(v, 16, 64);
       v += __shfl_xor(v, 32, 64);
       if (g == 0 && v != 0.f) atomicAdd(dpext + (long)R * HD + h * DH + n * 16 + r, v);
+    }
+    if constexpr (DQ) {
+      // column sums of this block's 64 rows: over the 4 lane rows by shuffles, over the 4 waves through LDS (the staged tiles are dead)
+      __syncthreads();
+      float* red = reinterpret_cast<float*>(smem);  // [4 waves][2][64]
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        float a = su[n], c = sv[n];
+        a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
+        c += __shfl_xor(c, 16, 64); c += __shfl_xor(c, 32, 64);
+        if (g == 0) { red[(w * 2 + 0) * 64 + n * 16 + r] = a; red[(w * 2 + 1) * 64 + n * 16 + r] = c; }
+      }
+      __syncthreads();
+      if (threadIdx.x < 128) {
+        const int which = threadIdx.x >> 6, col = threadIdx.x & 63;
+        const float v = red[(0 * 2 + which) * 64 + col] + red[(1 * 2 + which) * 64 + col] + red[(2 * 2 + which) * 64 + col] + red[(3 * 2 + which) * 64 + col];
+        atomicAdd((which ? dv : du) + h * DH + col, v);
+      }
     }
   }
 }
@@ -903,6 +934,22 @@ extern "C" int tfasr_relattn_fused_bwd_q2(const void* qkv, const float* ubias, c
   hipLaunchKernelGGL(relattn_fused_bwd_q_kernel<true>, grid, dim3(256), SMEM_BWD_Q, (hipStream_t)stream_, (const bf16_t*)qkv, ubias, vbias,
                      (const bf16_t*)pext, lengths, (const bf16_t*)o, (const bf16_t*)dout, lse, (bf16_t*)dqu, (bf16_t*)ds, dvec, B, H, T, lds,
                      scale, use_mask, (bf16_t*)dqv, dpext);
+  TFASR_CHECK_LAUNCH();
+  return TFASR_STATUS_SUCCESS;
+}
+
+extern "C" int tfasr_relattn_fused_bwd_q3(const void* qkv, const float* ubias, const float* vbias, const void* pext, const int32_t* lengths,
+                                          const void* o, const void* dout, const float* lse, void* dq, long lddq, float* du, float* dv, void* ds,
+                                          float* dvec, float* dpext, int B, int H, int T, int dh, int lds, float scale, int use_mask, int dtype,
+                                          void* stream_) {
+  if (!qkv || !ubias || !vbias || !pext || !o || !dout || !lse || !dq || !du || !dv || !ds || !dvec || !dpext || B <= 0 || H <= 0 || T <= 0 || lds < T ||
+      (lds & 7) || lddq < (long)H * dh)
+    return TFASR_STATUS_INVALID_VALUE;
+  if (dtype != TFASR_BF16 || dh != DH) return TFASR_STATUS_UNSUPPORTED;
+  dim3 grid((T + BI - 1) / BI, H, B);
+  hipLaunchKernelGGL((relattn_fused_bwd_q_kernel<true, true>), grid, dim3(256), SMEM_BWD_Q, (hipStream_t)stream_, (const bf16_t*)qkv, ubias, vbias,
+                     (const bf16_t*)pext, lengths, (const bf16_t*)o, (const bf16_t*)dout, lse, (bf16_t*)dq, (bf16_t*)ds, dvec, B, H, T, lds, scale,
+                     use_mask, (bf16_t*)nullptr, dpext, lddq, du, dv);
   TFASR_CHECK_LAUNCH();
   return TFASR_STATUS_SUCCESS;
 }

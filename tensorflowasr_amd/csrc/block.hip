@@ -372,6 +372,7 @@ struct Ex {
       join();
     }
     void* dqkv = act(scratch, rows * 3 * HD);
+    bool dq_done = false;
     void* dqu = act(scratch, rows * HD);
     void* dqv = act(scratch, rows * HD);
     // fused path, default: the skewed score gradient never exists in HBM (attn_fused.hip V2); TFASR_ATTN_DPOS=1 restores the old route
@@ -390,8 +391,17 @@ struct Ex {
       void* qu = act(scratch, rows * HD);
       void* qvb = act(scratch, rows * HD);
       if (!dry) {
-        chk(tfasr_relattn_fused_bwd_q2(k->at_qkv, fp(TFASR_BP_AT_U), fp(TFASR_BP_AT_V), k->at_pext, io->lengths, k->at_att, datt, k->at_lse, dqu,
-                                       dqv, dpos, dvec, dpext, B, H, T, dh, Tp, scale, c->use_mask, c->dtype, s));
+        // the query gradient (dq = dqu + dqv into the q columns of dqkv) and the u / v bias gradients finished inside the kernel;
+        // TFASR_ATTN_Q3=0: separate tfasr_bias2_bwd pass over dqu / dqv
+        static const bool q3_off = getenv("TFASR_ATTN_Q3") && getenv("TFASR_ATTN_Q3")[0] == '0';
+        if (!q3_off) {
+          chk(tfasr_relattn_fused_bwd_q3(k->at_qkv, fp(TFASR_BP_AT_U), fp(TFASR_BP_AT_V), k->at_pext, io->lengths, k->at_att, datt, k->at_lse, dqkv,
+                                         3L * HD, gp(TFASR_BP_AT_U), gp(TFASR_BP_AT_V), dpos, dvec, dpext, B, H, T, dh, Tp, scale, c->use_mask, c->dtype, s));
+          dq_done = true;
+        } else {
+          chk(tfasr_relattn_fused_bwd_q2(k->at_qkv, fp(TFASR_BP_AT_U), fp(TFASR_BP_AT_V), k->at_pext, io->lengths, k->at_att, datt, k->at_lse, dqu,
+                                         dqv, dpos, dvec, dpext, B, H, T, dh, Tp, scale, c->use_mask, c->dtype, s));
+        }
         chk(tfasr_bias2_fwd(k->at_qkv, 3 * HD, fp(TFASR_BP_AT_U), fp(TFASR_BP_AT_V), qu, qvb, rows, HD, c->dtype, s));
         chk(tfasr_relattn_fused_bwd_k(k->at_qkv, qu, qvb, k->at_pext, io->lengths, datt, k->at_lse, dvec, dqkv, B, H, T, dh, scale, c->use_mask,
                                       c->dtype, s));
@@ -455,7 +465,7 @@ struct Ex {
         gemm(a);
       }
     }
-    if (!dry) chk(tfasr_bias2_bwd(dqu, dqv, dqkv, 3 * HD, gp(TFASR_BP_AT_U), gp(TFASR_BP_AT_V), rows, HD, c->dtype, s));
+    if (!dry && !dq_done) chk(tfasr_bias2_bwd(dqu, dqv, dqkv, 3 * HD, gp(TFASR_BP_AT_U), gp(TFASR_BP_AT_V), rows, HD, c->dtype, s));
     // positional projection: gWpos += pe^T dpext ; gbpos += colsum(dpext)
     const void* dpext_t = dpext;
     if (c->dtype != TFASR_F32) {
