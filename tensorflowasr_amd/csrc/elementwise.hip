@@ -463,13 +463,17 @@ __global__ __launch_bounds__(256) void joint_fwd_packed_rows_kernel(const T* __r
     st8(h + (r0 + (long)t * u1b + u) * J + c, p);
   }
 }
+// blockDim = (128, JB_RL): threadIdx.y walks the summed axis in strides of JB_RL (four independent load streams per output instead of
+// one dependent loop: the t-strided MODE 1 ran at 1.4 TB/s), partial sums meet in LDS.
+constexpr int JB_RL = 4;
 template <typename T, int MODE>
-__global__ __launch_bounds__(128) void joint_bwd_packed_kernel(const T* __restrict__ h, const T* __restrict__ dh,
-                                                               T* __restrict__ dout, const long* __restrict__ cell_off,
-                                                               const int32_t* __restrict__ label_len,
-                                                               const int32_t* __restrict__ logit_len, int B, int Tn, int U1, int J) {
-  const int j = (blockIdx.y * blockDim.x + threadIdx.x) * 8;
-  if (j >= J) return;
+__global__ __launch_bounds__(128 * JB_RL) void joint_bwd_packed_kernel(const T* __restrict__ h, const T* __restrict__ dh,
+                                                                        T* __restrict__ dout, const long* __restrict__ cell_off,
+                                                                        const int32_t* __restrict__ label_len,
+                                                                        const int32_t* __restrict__ logit_len, int B, int Tn, int U1, int J) {
+  __shared__ float red[JB_RL][128][8];
+  const int j = (blockIdx.y * 128 + threadIdx.x) * 8;
+  const bool live = j < J;
   float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   long base = 0, stride = 0;
   int count = 0;
@@ -482,19 +486,30 @@ __global__ __launch_bounds__(128) void joint_bwd_packed_kernel(const T* __restri
     const int Tl = min(logit_len[b], Tn), u1b = min(label_len[b], U1 - 1) + 1;
     if (u < u1b) { base = (cell_off[b] + u) * J; stride = (long)u1b * J; count = Tl; }
   }
-  for (int k = 0; k < count; ++k) {
-    float hv[8], dv[8];
-    ld8(dh + base + k * stride + j, dv);
-    if (h) {  // uniform
-      ld8(h + base + k * stride + j, hv);
+  if (live) {
+    for (int k = threadIdx.y; k < count; k += JB_RL) {
+      float hv[8], dv[8];
+      ld8(dh + base + k * stride + j, dv);
+      if (h) {  // uniform
+        ld8(h + base + k * stride + j, hv);
 #pragma unroll
-      for (int q = 0; q < 8; ++q) acc[q] += dv[q] * (1.f - hv[q] * hv[q]);
-    } else {
+        for (int q = 0; q < 8; ++q) acc[q] += dv[q] * (1.f - hv[q] * hv[q]);
+      } else {
 #pragma unroll
-      for (int q = 0; q < 8; ++q) acc[q] += dv[q];
+        for (int q = 0; q < 8; ++q) acc[q] += dv[q];
+      }
     }
   }
-  st8(dout + (long)blockIdx.x * J + j, acc);
+#pragma unroll
+  for (int q = 0; q < 8; ++q) red[threadIdx.y][threadIdx.x][q] = acc[q];
+  __syncthreads();
+  if (threadIdx.y == 0 && live) {
+#pragma unroll
+    for (int y = 1; y < JB_RL; ++y)
+#pragma unroll
+      for (int q = 0; q < 8; ++q) acc[q] += red[y][threadIdx.x][q];
+    st8(dout + (long)blockIdx.x * J + j, acc);
+  }
 }
 
 // ----------------------------------------------------------------------------------------- Adam
@@ -818,10 +833,10 @@ extern "C" int tfasr_joint_bwd_packed(const void* h, const void* dh, void* denc,
   const int gy = (J / 8 + 127) / 128;
   dim3 g0(B * T, gy), g1(B * U1, gy);
   DISPATCH_T(dtype,
-             { hipLaunchKernelGGL((joint_bwd_packed_kernel<float, 0>), g0, dim3(128), 0, s, (const float*)h, (const float*)dh, (float*)denc, cell_off, label_len, logit_len, B, T, U1, J);
-               hipLaunchKernelGGL((joint_bwd_packed_kernel<float, 1>), g1, dim3(128), 0, s, (const float*)h, (const float*)dh, (float*)dpred, cell_off, label_len, logit_len, B, T, U1, J); },
-             { hipLaunchKernelGGL((joint_bwd_packed_kernel<bf16_t, 0>), g0, dim3(128), 0, s, (const bf16_t*)h, (const bf16_t*)dh, (bf16_t*)denc, cell_off, label_len, logit_len, B, T, U1, J);
-               hipLaunchKernelGGL((joint_bwd_packed_kernel<bf16_t, 1>), g1, dim3(128), 0, s, (const bf16_t*)h, (const bf16_t*)dh, (bf16_t*)dpred, cell_off, label_len, logit_len, B, T, U1, J); });
+             { hipLaunchKernelGGL((joint_bwd_packed_kernel<float, 0>), g0, dim3(128, JB_RL), 0, s, (const float*)h, (const float*)dh, (float*)denc, cell_off, label_len, logit_len, B, T, U1, J);
+               hipLaunchKernelGGL((joint_bwd_packed_kernel<float, 1>), g1, dim3(128, JB_RL), 0, s, (const float*)h, (const float*)dh, (float*)dpred, cell_off, label_len, logit_len, B, T, U1, J); },
+             { hipLaunchKernelGGL((joint_bwd_packed_kernel<bf16_t, 0>), g0, dim3(128, JB_RL), 0, s, (const bf16_t*)h, (const bf16_t*)dh, (bf16_t*)denc, cell_off, label_len, logit_len, B, T, U1, J);
+               hipLaunchKernelGGL((joint_bwd_packed_kernel<bf16_t, 1>), g1, dim3(128, JB_RL), 0, s, (const bf16_t*)h, (const bf16_t*)dh, (bf16_t*)dpred, cell_off, label_len, logit_len, B, T, U1, J); });
   TFASR_CHECK_LAUNCH();
   return TFASR_STATUS_SUCCESS;
 }
