@@ -26,7 +26,11 @@ constexpr int DH = 64, BI = 64, BJ = 64, WIN = 128;
 constexpr int SK_BYTES = BJ * DH * 2, SV_BYTES = BJ * DH * 2, SP_BYTES = WIN * DH * 2;
 constexpr int GLD = 132;                                   // f32 row stride of the per-wave G strip
 constexpr int SG_BYTES = 16 * GLD * 4, SPB_BYTES = 16 * BJ * 2;
-constexpr int SMEM_FWD = SK_BYTES + SV_BYTES + SP_BYTES + 4 * SG_BYTES + 4 * SPB_BYTES;
+// forward: the per-wave G strip holds only the 80 window columns the wave's skew reads + the bias column (stride 81), and the P image
+// of the block is written over it once the scores have been read: 53.5 KB per workgroup = THREE workgroups per CU (it was 74 KB = two;
+// the kernel is a dependent chain load -> MFMA -> LDS -> VALU -> LDS -> MFMA per key block and lives on co-resident workgroups)
+constexpr int GLDC = 81, SGC_BYTES = 16 * GLDC * 4;
+constexpr int SMEM_FWD = SK_BYTES + SV_BYTES + SP_BYTES + 4 * SGC_BYTES;
 
 __device__ __forceinline__ int key_d(int row) { return (row >> 1) & 7; }
 __device__ __forceinline__ int key_t64(int k) { return (((k >> 1) & 1) | (((k >> 3) & 1) << 1)) << 1; }
@@ -97,7 +101,7 @@ __device__ __forceinline__ short8_t q_frag(const bf16_t* qrow, const float* bias
   return f;
 }
 
-__global__ __launch_bounds__(256, 2) void relattn_fused_fwd_kernel(
+__global__ __launch_bounds__(256, 3) void relattn_fused_fwd_kernel(
     const bf16_t* __restrict__ qkv, const float* __restrict__ ubias, const float* __restrict__ vbias,
     const bf16_t* __restrict__ pext, const int32_t* __restrict__ lengths, bf16_t* __restrict__ out, float* __restrict__ lse_out,
     int B, int H, int T, float scale, int use_mask) {
@@ -106,8 +110,8 @@ __global__ __launch_bounds__(256, 2) void relattn_fused_fwd_kernel(
   char* sV = sK + SK_BYTES;
   char* sP = sV + SV_BYTES;
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  float* sG = reinterpret_cast<float*>(sP + SP_BYTES + w * SG_BYTES);
-  char* sPb = sP + SP_BYTES + 4 * SG_BYTES + w * SPB_BYTES;
+  float* sG = reinterpret_cast<float*>(sP + SP_BYTES + w * SGC_BYTES);  // [16][81]: columns 48-16w .. 127-16w of the window scores, then column 127
+  char* sPb = reinterpret_cast<char*>(sG);                              // P image [16][64] bf16, over the strip once it has been read
   const int r = lane & 15, g = lane >> 4;
   const int b = blockIdx.z, h = blockIdx.y, i0 = blockIdx.x * BI;
   const int HD = H * DH, LDQ = 3 * HD, R = 2 * T - 1, R1 = 2 * T;
@@ -143,7 +147,7 @@ __global__ __launch_bounds__(256, 2) void relattn_fused_fwd_kernel(
   for (int e = 0; e < 4; ++e) {
     const int il = g * 4 + e, i = i0 + w * 16 + il;
     rr0[e] = T - 1 - i + r;                       // + jt*16 + j0 = relative-position row of key j
-    goff[e] = il * GLD + (63 - w * 16 - il + r);  // + jt*16 = skewed column of the window scores
+    goff[e] = il * GLDC + (15 - il + r);          // + jt*16 = skewed column of the window scores, relative to the strip's first column
     qm[e] = use_mask && (i >= len);
 #pragma unroll
     for (int jt = 0; jt < 4; ++jt) {
@@ -194,8 +198,14 @@ __global__ __launch_bounds__(256, 2) void relattn_fused_fwd_kernel(
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
           a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aqv[kk], frag_rows(sP, gt * 16 + r, kk * 4 + g), a, 0, 0, 0);
+        if (gt <= 7 - w) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) sG[(g * 4 + e) * GLD + gt * 16 + r] = a[e];
+          for (int e = 0; e < 4; ++e) sG[(g * 4 + e) * GLDC + (gt - (3 - w)) * 16 + r] = a[e];
+        }
+        if (gt == 7 && r == 15) {  // the bias row's score (window column 127)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) sG[(g * 4 + e) * GLDC + 80] = a[e];
+        }
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -209,7 +219,7 @@ __global__ __launch_bounds__(256, 2) void relattn_fused_fwd_kernel(
     const bool ragged = (j0 + BJ > T);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const float gbias = sG[(g * 4 + e) * GLD + 127];
+      const float gbias = sG[(g * 4 + e) * GLDC + 80];
       float mx = -INFINITY;
 #pragma unroll
       for (int jt = 0; jt < 4; ++jt) {
@@ -222,6 +232,9 @@ __global__ __launch_bounds__(256, 2) void relattn_fused_fwd_kernel(
       }
       rmax[e] = row16_max(mx);
     }
+    // every score of the strip is in registers: the P image may now overwrite it (the fence keeps the bf16 stores below behind the
+    // f32 loads above - different types, so the compiler would otherwise be free to reorder them)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     // online softmax update + P (bf16) into the per-wave A-operand image
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
