@@ -72,3 +72,14 @@ def test_unsupported_options_fail_loudly():
 def test_m_config_is_the_paper_shape():
     m = configs.conformer_m()
     assert (m.dmodel, m.num_heads, m.head_size, m.num_blocks, m.rnn_units, m.joint_dim) == (256, 4, 64, 16, 640, 640)
+
+
+def test_schedule_at_keras_first_update_is_zero():
+    """keras evaluates a LearningRateSchedule at `iterations` BEFORE the increment, i.e. at 0 for the first update: TransformerSchedule gives
+    min(inf, 0) = 0 there (schedules.py:28-37), then max_lr / min_lr as usual; the oracle and the host restatement agree."""
+    from oracle import conformer_ref as R
+
+    for fn in (configs.transformer_schedule, R.transformer_schedule):
+        assert float(fn(0, 144, 10000, 2.0, 0.05 / 12)) == 0.0
+        assert float(fn(0, 144, 10000, 2.0, 0.05 / 12, 1e-6)) == pytest.approx(1e-6)
+        assert float(fn(1, 144, 10000, 2.0, 0.05 / 12)) == pytest.approx(2.0 * 144 ** -0.5 * 10000 ** -1.5, rel=1e-5)
