@@ -163,9 +163,26 @@ __global__ __launch_bounds__(256) void rnnt_stats_finalize_kernel(const float2* 
     const Cell cl = locate(r, cell_off, B, Tm, U1, label_len, logit_len);
     if (!cl.valid) continue;
     RowStat st{-INFINITY, 0.f};
-    for (int c = 0; c < nparts; ++c) {
-      const float2 v = part[r * nparts + c];
-      online_merge(st, v.x, v.y);
+    if (nparts == 16) {  // V = 1000: the row's 128 bytes as eight independent 16-byte loads, not sixteen dependent 8-byte ones
+      float4 q[8];
+      const float4* p4 = reinterpret_cast<const float4*>(part + r * 16);
+#pragma unroll
+      for (int c = 0; c < 8; ++c) q[c] = p4[c];
+      float mx = -INFINITY;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) mx = fmaxf(mx, fmaxf(q[c].x, q[c].z));
+      float sm = 0.f;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {  // sum of s_c * exp(m_c - mx); an empty slice is (-inf, 0)
+        sm += (q[c].y > 0.f ? q[c].y * __expf(q[c].x - mx) : 0.f) + (q[c].w > 0.f ? q[c].w * __expf(q[c].z - mx) : 0.f);
+      }
+      st.m = mx;
+      st.s = sm;
+    } else {
+      for (int c = 0; c < nparts; ++c) {
+        const float2 v = part[r * nparts + c];
+        online_merge(st, v.x, v.y);
+      }
     }
     const float l = st.m + logf(st.s);
     lse[r] = l;
