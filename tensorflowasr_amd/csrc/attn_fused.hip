@@ -288,6 +288,170 @@ __global__ __launch_bounds__(256, 3) void relattn_fused_fwd_kernel(
 }
 
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Forward with 32-key blocks: 4 KB of K, 4 KB of V, a 96-row window (12 KB) and 4 strips of [16][49] f32 = 32.5 KB per workgroup, so
+// FOUR (LDS) workgroups share a CU where the 64-key kernel fits three.  Same arithmetic per (query, key) pair; the online softmax
+// merges twice as many blocks.  Wave w needs window columns 48-16w .. 94-16w (3 tiles) + the bias row in column 95.
+// ---------------------------------------------------------------------------------------------------------------------------------
+constexpr int BJ3 = 32, WIN3 = 96, GLD3 = 49, SG3_BYTES = 16 * GLD3 * 4;
+constexpr int SMEM_FWD32 = 2 * (BJ3 * DH * 2) + WIN3 * DH * 2 + 4 * SG3_BYTES;
+
+__global__ __launch_bounds__(256, 4) void relattn_fused_fwd32_kernel(
+    const bf16_t* __restrict__ qkv, const float* __restrict__ ubias, const float* __restrict__ vbias,
+    const bf16_t* __restrict__ pext, const int32_t* __restrict__ lengths, bf16_t* __restrict__ out, float* __restrict__ lse_out,
+    int B, int H, int T, float scale, int use_mask) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sK = smem;                      // [32 j][64 dh]
+  char* sV = sK + BJ3 * DH * 2;         // [32 j][64 dh]
+  char* sP = sV + BJ3 * DH * 2;         // [96 c][64 dh]
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  float* sG = reinterpret_cast<float*>(sP + WIN3 * DH * 2 + w * SG3_BYTES);
+  char* sPb = reinterpret_cast<char*>(sG);  // P image [16][32] bf16 (64-B rows, 16-B chunk ^= (row >> 1) & 3), over the strip once it has been read
+  const int r = lane & 15, g = lane >> 4;
+  const int b = blockIdx.z, h = blockIdx.y, i0 = blockIdx.x * BI;
+  const int HD = H * DH, LDQ = 3 * HD, R = 2 * T - 1, R1 = 2 * T;
+  const int len = lengths ? min(lengths[b], T) : T;
+  const int shift = T - len;
+  const bf16_t* qb = qkv + (long)b * T * LDQ + h * DH;
+  const bf16_t* kb = qb + HD;
+  const bf16_t* vb = qb + 2 * HD;
+  const bf16_t* pb = pext + h * DH;
+
+  const int irow = min(i0 + w * 16 + r, T - 1);
+  short8_t aqu[2], aqv[2];
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) {
+    aqu[kk] = q_frag(qb + (long)irow * LDQ, ubias + h * DH, kk * 32 + g * 8);
+    aqv[kk] = q_frag(qb + (long)irow * LDQ, vbias + h * DH, kk * 32 + g * 8);
+  }
+  float m_run[4], l_run[4];
+  float4_t acc_o[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { m_run[e] = -INFINITY; l_run[e] = 0.f; }
+#pragma unroll
+  for (int n = 0; n < 4; ++n) acc_o[n] = float4_t{0.f, 0.f, 0.f, 0.f};
+
+  const float scale2 = scale * 1.4426950408889634f;
+  const int lim = 2 * len - 1;
+  int rr0[4], goff[4], poff[4][2];
+  bool qm[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int il = g * 4 + e, i = i0 + w * 16 + il;
+    rr0[e] = T - 1 - i + r;
+    goff[e] = il * GLD3 + (15 - il + r);
+    qm[e] = use_mask && (i >= len);
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt) {
+      const int jl = jt * 16 + r;
+      poff[e][jt] = il * 64 + (((jl >> 3) ^ ((il >> 1) & 3)) << 4) + (jl & 7) * 2;
+    }
+  }
+  const int njb = (T + BJ3 - 1) / BJ3;
+  for (int jb = 0; jb < njb; ++jb) {
+    const int j0 = jb * BJ3;
+    const int pw0 = (T - 1 - (i0 + BI - 1) + j0) + shift;  // pext row of window column 0
+    load_rows<BJ3>(sK, kb, LDQ, j0, T, w, lane);
+    {  // V block [32 k][64 dh] trans image: one piece per wave (8 k rows)
+      const int k = w * 8 + (lane >> 3), pc = lane & 7;
+      const int gr = min(j0 + k, T - 1);
+      const bf16_t* src = vb + (long)gr * LDQ + ((pc ^ key_t64(k)) << 3);
+      __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(sV + __builtin_amdgcn_readfirstlane(w * 1024)), 16, 0, 0);
+    }
+    load_rows<WIN3>(sP, pb, HD, pw0, R1, w, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (w == 0 && lane < 8) {  // window row 95 <- the bias row R
+      const uint4 v = *reinterpret_cast<const uint4*>(pb + (long)R * HD + ((lane ^ key_d(WIN3 - 1)) << 3));
+      *reinterpret_cast<uint4*>(sP + (WIN3 - 1) * 128 + lane * 16) = v;
+    }
+    __syncthreads();
+
+    float4_t acc_s[2];
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt) {
+      acc_s[jt] = float4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+        acc_s[jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aqu[kk], frag_rows(sK, jt * 16 + r, kk * 4 + g), acc_s[jt], 0, 0, 0);
+    }
+#pragma unroll
+    for (int gt = 0; gt < 6; ++gt) {
+      if ((gt >= 3 - w && gt <= 5 - w) || gt == 5) {
+        float4_t a = float4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aqv[kk], frag_rows(sP, gt * 16 + r, kk * 4 + g), a, 0, 0, 0);
+        if (gt <= 5 - w) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) sG[(g * 4 + e) * GLD3 + (gt - (3 - w)) * 16 + r] = a[e];
+        }
+        if (gt == 5 && r == 15) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) sG[(g * 4 + e) * GLD3 + 48] = a[e];
+        }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+
+    float rmax[4];
+    const bool ragged = (j0 + BJ3 > T);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float gbias = sG[(g * 4 + e) * GLD3 + 48];
+      float mx = -INFINITY;
+#pragma unroll
+      for (int jt = 0; jt < 2; ++jt) {
+        const float pos = (rr0[e] + jt * 16 + j0 < lim) ? sG[goff[e] + jt * 16] : gbias;
+        float s2 = (acc_s[jt][e] + pos) * scale2;
+        if (qm[e]) s2 = 0.f;
+        if (ragged && j0 + jt * 16 + r >= T) s2 = -INFINITY;
+        acc_s[jt][e] = s2;
+        mx = fmaxf(mx, s2);
+      }
+      rmax[e] = row16_max(mx);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the strip is in registers: the P image may overwrite it
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float m_new = fmaxf(m_run[e], rmax[e]);
+      const float corr = __builtin_amdgcn_exp2f(m_run[e] - m_new);
+      float rs = 0.f;
+#pragma unroll
+      for (int jt = 0; jt < 2; ++jt) {
+        const float pv = __builtin_amdgcn_exp2f(acc_s[jt][e] - m_new);
+        rs += pv;
+        *reinterpret_cast<bf16_t*>(sPb + poff[e][jt]) = f32_to_bf16(pv);
+      }
+      rs = row16_sum(rs);
+      l_run[e] = l_run[e] * corr + rs;
+      m_run[e] = m_new;
+#pragma unroll
+      for (int n = 0; n < 4; ++n) acc_o[n][e] *= corr;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    {  // O += P @ V  (one 32-key step)
+      const short8_t ap = *reinterpret_cast<const short8_t*>(sPb + r * 64 + ((g ^ ((r >> 1) & 3)) << 4));
+#pragma unroll
+      for (int n = 0; n < 4; ++n)
+        acc_o[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap, frag_v(sV, n * 16, g * 8, r), acc_o[n], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int i = i0 + w * 16 + g * 4 + e;
+    if (i < T) {
+      const float inv = 1.f / l_run[e];
+#pragma unroll
+      for (int n = 0; n < 4; ++n) out[((long)b * T + i) * HD + h * DH + n * 16 + r] = f32_to_bf16(acc_o[n][e] * inv);
+      if (r == 0) lse_out[((long)b * H + h) * T + i] = m_run[e] * 0.6931471805599453f + logf(l_run[e]);
+    }
+  }
+}
+
 // ======================================================================================================================
 // Backward, part 1 (query side): block = (b, h, 64 query rows), wave = 16 rows, loop over 64-key blocks.
 //   recompute s_ij and p_ij = exp(s_ij - lse_i);  dp_ij = dO_i . v_j;  ds_ij = p_ij (dp_ij - D_i),  D_i = dO_i . O_i
@@ -915,6 +1079,20 @@ extern "C" int tfasr_relattn_fused_fwd(const void* qkv, const float* ubias, cons
   if (!qkv || !ubias || !vbias || !pext || !out || !lse || B <= 0 || H <= 0 || T <= 0) return TFASR_STATUS_INVALID_VALUE;
   if (dtype != TFASR_BF16 || dh != DH) return TFASR_STATUS_UNSUPPORTED;
   dim3 grid((T + BI - 1) / BI, H, B);
+  // 32-key blocks / four workgroups per CU when the whole grid is then resident at once (T' = 462, 1024 workgroups: 59.5 -> 53.1 us;
+  // T' = 390: 50.0 -> 46.1); with more workgroups than that the 64-key kernel's three per CU win (T' = 743, 1536 workgroups: 103 vs
+  // 127 us).  TFASR_ATTN_FWD32=0 / 1 forces one of them.
+  static const char* env32 = getenv("TFASR_ATTN_FWD32");
+  static int ncu = 0;
+  if (ncu == 0) {
+    int dev = 0, v = 0;
+    ncu = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
+  }
+  const bool fwd32 = env32 ? env32[0] == '1' : (long)grid.x * grid.y * grid.z <= 4L * ncu;
+  if (fwd32)
+    hipLaunchKernelGGL(relattn_fused_fwd32_kernel, grid, dim3(256), SMEM_FWD32, (hipStream_t)stream_, (const bf16_t*)qkv, ubias, vbias,
+                       (const bf16_t*)pext, lengths, (bf16_t*)out, lse, B, H, T, scale, use_mask);
+  else
   hipLaunchKernelGGL(relattn_fused_fwd_kernel, grid, dim3(256), SMEM_FWD, (hipStream_t)stream_, (const bf16_t*)qkv, ubias, vbias,
                      (const bf16_t*)pext, lengths, (bf16_t*)out, lse, B, H, T, scale, use_mask);
   TFASR_CHECK_LAUNCH();
