@@ -243,6 +243,40 @@ def bench_ctc_decode(args, dev, dtype):
                                  "beam_search_ms": round(res["beam10"] * 1e3, 2)}}))
 
 
+def relaunch_cmd(gpus, argv, env):
+    """`python bench.py --gpus N` with N > 1 and no launcher environment re-executes itself under torch.distributed.run, one rank
+    per GPU over RCCL (the reference's MirroredStrategy spans every visible GPU from one process: utils/env_util.py:57-70).
+    Returns the command line, or None when this process is already a rank (WORLD_SIZE set by a launcher) or N == 1."""
+    if gpus <= 1 or env.get("WORLD_SIZE") is not None:
+        return None
+    import socket
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+class _StubModel:
+    """TFASR_BENCH_STUB=1 (tests/test_bench_launch.py): the launch / rendezvous / timing / reporting logic of this file on CPU
+    with the gloo backend, the train step replaced by one small all-reduce.  Never a measurement."""
+
+    class _PS:
+        def num_trainable(self):
+            return 0
+
+    def __init__(self, dp):
+        self.dp, self.ps, self.timers, self.timer_work, self.time_sections = dp, self._PS(), {}, {}, False
+        self.buf = torch.ones(1024)
+
+    def train_step(self, data):
+        if self.dp:
+            self.dp.allreduce_stats_(self.buf.clone())
+        return {"loss": None}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -261,18 +295,37 @@ def main():
     ap.add_argument("--no-specaugment", action="store_true")
     ap.add_argument("--dropout", type=float, default=None, help="override encoder dropout (default: reference value 0.1)")
     args = ap.parse_args()
+    stub = os.environ.get("TFASR_BENCH_STUB") == "1"
+
+    cmd = relaunch_cmd(args.gpus, sys.argv[1:], os.environ)
+    if cmd is not None:
+        import subprocess
+
+        if not stub and torch.cuda.device_count() < args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but only {torch.cuda.device_count()} HIP device(s) are visible")
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        sys.stdout.flush()
+        raise SystemExit(subprocess.run(cmd, env=env).returncode)
 
     from tensorflowasr_amd import configs, dp as dpmod
-    from tensorflowasr_amd.conformer import ConformerTransducer
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    dp = dpmod.init_from_env() if world > 1 else None
+    if args.gpus != world:
+        # never print a line whose n_gpus is not what was asked for
+        raise SystemExit(f"--gpus {args.gpus} but this process group has WORLD_SIZE={world}: refusing to report a {world}-GPU run as {args.gpus}")
+    dp = dpmod.init_from_env(backend="gloo" if stub else None) if world > 1 else None
+    if dp and dp.world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but the process group has {dp.world} ranks")
     rank = dp.rank if dp else 0
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if dp and args.gpus != world:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if stub:
+        dev = torch.device("cpu")
+        torch.cuda.synchronize = lambda *a, **k: None
+    else:
+        from tensorflowasr_amd.conformer import ConformerTransducer
+
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
 
     if args.model == "contextnet":
         cfg = configs.contextnet(alpha=args.alpha)
@@ -285,13 +338,15 @@ def main():
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     if args.mode == "ctc-decode":
         return bench_ctc_decode(args, dev, dtype)
-    if args.model == "contextnet":
+    if stub:
+        model = _StubModel(dp)
+    elif args.model == "contextnet":
         from tensorflowasr_amd.contextnet import ContextNetTransducer
 
         model = ContextNetTransducer(cfg, dev, dtype=dtype, seed=0, dp=dp)
     else:
         model = ConformerTransducer(cfg, dev, dtype=dtype, seed=0, dp=dp)
-    if dp:
+    if dp and not stub:
         dp.attach(model.ps.grad)
     if args.mode == "decode":
         return bench_decode(args, model, cfg, dev)
@@ -301,7 +356,7 @@ def main():
     # weak scaling with the per-GPU work EXACTLY fixed: every rank runs the same synthetic shard shapes (same seeds), so padded
     # lengths agree across ranks - which the synchronised BatchNorm's count (rows x world) assumes, as in the reference where
     # the global batch is padded as one (datasets.py:102-138,342-365) - and no rank waits for a longer batch on another.
-    batches = [make_batch(cfg, args.batch, seed=10 + 13 * i, padding=args.padding, size=size) for i in range(nb)]
+    batches = [make_batch(cfg, 2 if stub else args.batch, seed=10 + 13 * i, padding=args.padding, size="S-10s" if stub else size) for i in range(nb)]
     data = [to_train_data(b, dev) for b in batches]
     model.timers = {}
     model.time_sections = bool(os.environ.get("TFASR_BENCH_SECTIONS"))
@@ -387,7 +442,7 @@ def main():
             "value": round(value, 4), "unit": "audio-hours/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"{'ContextNet' if args.model == 'contextnet' else 'Conformer-' + args.model} transducer full train step (fwd+RNN-T loss+bwd+Adam), {size} 16 kHz utterances, "
+            "config": {"workload": "STUB (launch-logic test, not a measurement)" if stub else f"{'ContextNet' if args.model == 'contextnet' else 'Conformer-' + args.model} transducer full train step (fwd+RNN-T loss+bwd+Adam), {size} 16 kHz utterances, "
                                    f"{args.batch}/GPU, padding={args.padding}, SpecAugment {'off' if args.no_specaugment else 'on'}, dropout {cfg.dropout}",
                        "global_batch": args.batch * world, "parallelism": f"dp{world}", "params": model.ps.num_trainable()},
             "roofline": roof,
@@ -416,7 +471,7 @@ def main():
                 del rd, rb
             except Exception as e:  # the headline number must still be reported
                 out["reference_padding"] = {"value": None, "error": repr(e)[:200]}
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and not stub:
             try:
                 if args.model != "contextnet":  # the CPU port baseline is the Conformer oracle
                     out["cpu_baseline"] = cpu_baseline(size if args.model == "S" else "M", cfg.vocab_size)
