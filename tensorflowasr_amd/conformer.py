@@ -84,6 +84,11 @@ class ConformerTransducer:
         self.timers = None  # optional dict name -> list[(start_event, end_event)] filled by bench.py
         self.timer_work = {}
         self.time_sections = False  # per-module section timers (bench.py TFASR_BENCH_SECTIONS) need the per-kernel Python path
+        # Greedy search: the reference's tokens come from its f32 CPU path and the north star asks for bit-exact token indices, which a
+        # bf16 encoder cannot promise (near-tied arg-max decisions flip).  Inference therefore runs on the f32 master weights with the
+        # exact-f32 MFMA kernels by default, whatever the training storage type ("bf16" = the training kernels, faster, not token-exact)
+        self.decode_precision = os.environ.get("TFASR_DECODE_PRECISION", "f32")
+        self._twin = None
 
     # =================================================================================== constants
     def _frontend_consts(self):
@@ -1052,9 +1057,26 @@ class ConformerTransducer:
     def get_initial_tokens(self, batch_size=1):
         return torch.full((batch_size, 1), self.blank, dtype=torch.int32, device=self.device)
 
+    def inference_twin(self):
+        """This model in f32 parity mode over the SAME parameter buffers (f32 master weights, BatchNorm moving statistics): no copy,
+        always current.  The twin of an f32 model is the model itself."""
+        if self.dtype == torch.float32:
+            return self
+        if self._twin is None:
+            t = object.__new__(type(self))
+            t.__dict__.update(self.__dict__)
+            t.dtype, t.ps = torch.float32, self.ps.alias(torch.float32)
+            t._consts, t._blk_params, t._blk_sizes, t._zero_pool, t._twin = {}, {}, {}, {}, None
+            t.timers, t.timer_work = None, {}
+            self._twin = t
+        return self._twin
+
     @torch.no_grad()
-    def encode(self, signals, signals_length):
-        """frontend + ConformerEncoder.call_next (conformer.py:703-718), inference mode (moving BN statistics)."""
+    def encode(self, signals, signals_length, precision=None):
+        """frontend + ConformerEncoder.call_next (conformer.py:703-718), inference mode (moving BN statistics).
+        precision "f32" (default, self.decode_precision) runs it on the f32 master weights; "bf16" on the training kernels."""
+        if (precision or self.decode_precision) == "f32" and self.dtype != torch.float32:
+            return self.inference_twin().encode(signals, signals_length)
         sig = signals.to(self.device, non_blocking=True)
         slen = [int(v) for v in signals_length.tolist()]
         feats, flen = self.frontend(sig, slen, training=False)
@@ -1062,10 +1084,10 @@ class ConformerTransducer:
         return enc.view(sig.shape[0], T, self.cfg.dmodel), elen
 
     @torch.no_grad()
-    def recognize(self, inputs: PredictInput, max_tokens_per_frame=3, check_every=16):
+    def recognize(self, inputs: PredictInput, max_tokens_per_frame=3, check_every=16, precision=None):
         """Transducer.recognize (base_transducer.py:474-494): batch size 1 -> recognize_single (<=3 symbols per frame),
         otherwise recognize_batch — the two variants are NOT equivalent in the reference and both are reproduced."""
-        enc, elen = self.encode(inputs.inputs, inputs.inputs_length)
+        enc, elen = self.encode(inputs.inputs, inputs.inputs_length, precision)
         return self.recognize_encoded(enc, elen, inputs.previous_tokens, inputs.previous_decoder_states, max_tokens_per_frame,
                                       check_every)
 

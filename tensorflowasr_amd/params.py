@@ -163,6 +163,16 @@ class ParamStore:
         self._init(ordered, seed)
         self.refresh_shadow()
 
+    def alias(self, dtype=torch.float32):
+        """A second store over the SAME master / gradient / optimizer / BatchNorm-state buffers whose compute-type copy is the f32
+        master itself: what a bf16-trained model's f32 inference twin reads (conformer.ConformerTransducer.inference_twin)."""
+        if dtype != torch.float32:
+            raise ValueError("only the f32 master can be aliased")
+        o = object.__new__(ParamStore)
+        o.__dict__.update(self.__dict__)
+        o.dtype, o.shadow, o._views = dtype, self.flat, {}
+        return o
+
     # ------------------------------------------------------------------ views
     def _view(self, buf, name, two_d=False):
         # views into the flat buffers never move: build each once (this is on the per-launch host path)

@@ -199,10 +199,11 @@ def test_mhsa_module_T743_B8_fused_vs_oracle(dev):
 def test_conformer_s_greedy_tokens_bf16_and_f32_vs_f32_oracle(dev, sharpen, blank_bias):
     """Greedy search (base_transducer.py:496-712) on a seeded Conformer-S (16 blocks, random weights; the vocabulary
     projection is sharpened and the blank biased so that some utterances emit nothing, some a handful of tokens and some
-    saturate their token buffer): the f32 model's tokens are bit-exact against the f32 oracle.  The bf16 model (what
-    `bench.py --mode decode` runs) keeps the whole search arithmetic in f32: its tokens are bit-exact against the reference
-    search applied to its own (bf16) encoder output; what differs from the all-f32 oracle is attributable to the encoder's
-    bf16 rounding alone and is reported (agreement, margin at the first divergence)."""
+    saturate their token buffer): the f32 model's tokens are bit-exact against the f32 oracle, and so are the bf16-trained
+    model's in its default decode mode (f32 inference twin = what `bench.py --mode decode` times).  With precision="bf16" (the
+    training kernels) the search arithmetic is still f32: tokens are bit-exact against the reference search applied to its own
+    (bf16) encoder output; what differs from the all-f32 oracle is attributable to the encoder's bf16 rounding alone and is
+    reported (agreement, margin at the first divergence)."""
     B = 4
     nsamp = [64000, 64000, 48000, 30000]
     ulens = [3] * B
@@ -223,10 +224,16 @@ def test_conformer_s_greedy_tokens_bf16_and_f32_vs_f32_oracle(dev, sharpen, blan
     assert sum(per_utt) > 10 and min(per_utt) < 10, per_utt
     model16 = ConformerTransducer(cfg, dev, dtype=torch.bfloat16, seed=0)
     model16.ps.import_keras(W)
-    out16 = model16.recognize(inp)
+    # THE BENCHMARKED MODE (`bench.py --mode decode`, the default of recognize()): a bf16-trained model decodes on its f32 master
+    # weights with the exact-f32 kernels (inference_twin) -> bit-exact token indices against the f32 oracle, batch and single variant
+    assert model16.decode_precision == "f32"
+    np.testing.assert_array_equal(model16.recognize(inp).tokens.cpu().numpy(), tok_ref.numpy())
+    # the twin reads the live master buffers (no copy): a weight update is seen without a rebuild
+    assert model16.inference_twin().ps.flat.data_ptr() == model16.ps.flat.data_ptr()
+    out16 = model16.recognize(inp, precision="bf16")
     t16, tr = out16.tokens.cpu().numpy(), tok_ref.numpy()
     # (a) the search itself is exact: the reference loop applied to the bf16 model's OWN encoder output gives its tokens
-    enc16, elen16 = model16.encode(torch.from_numpy(sig), torch.tensor(nsamp, dtype=torch.int32))
+    enc16, elen16 = model16.encode(torch.from_numpy(sig), torch.tensor(nsamp, dtype=torch.int32), precision="bf16")
     assert list(elen16) == elen.tolist()
     with torch.no_grad():
         tok_ref16, _, _, _ = R.recognize_batch(enc16.float().cpu(), elen.tolist(), W)
@@ -256,6 +263,7 @@ def test_conformer_s_greedy_tokens_bf16_and_f32_vs_f32_oracle(dev, sharpen, blan
     with torch.no_grad():
         tok1, _, _, _ = R.recognize_single(enc_ref[:1], elen.tolist()[:1], W)
     np.testing.assert_array_equal(model32.recognize(inp1).tokens.cpu().numpy(), tok1.numpy())
+    np.testing.assert_array_equal(model16.recognize(inp1).tokens.cpu().numpy(), tok1.numpy())
 
 
 def _oracle_margins(enc, elen, W):
