@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define TFASR_ABI_VERSION 15
+#define TFASR_ABI_VERSION 16
 
 typedef enum {
   TFASR_STATUS_SUCCESS = 0,
@@ -246,6 +246,10 @@ int tfasr_joint_bwd_packed(const void* h, const void* dh, void* denc, void* dpre
 int tfasr_adam(float* p, const float* g, float* m, float* v, long n, long n_reg, float lr, float beta1, float beta2,
                float eps, float weight_decay, float l2, float grad_scale, long step, void* stream);
 int tfasr_sumsq(const float* p, long n, float* out, void* stream);
+/* x[i] += stddev * N(0,1) over an f32 vector, the deviate a pure function of (seed, i).  Replaces tf.random.normal in variational
+ * weight noise (utils/layer_util.py:42-52 add_gwn, models/transducer/base_transducer.py:382-425) and gradient noise
+ * (utils/math_util.py add_gauss_noise, models/base_model.py:185-191). */
+int tfasr_gauss_noise(float* x, long n, float stddev, long seed, void* stream);
 /* y += alpha * x over f32 vectors (sync-BN gamma/beta gradient hand-off, gradient accumulation: accumulation.py:54-70) */
 int tfasr_axpy(float* y, const float* x, float alpha, long n, void* stream);
 /* SpecAugment mask application, in place: fmask [B,nf,2] = (f0, width), tmask [B,nt,2] = (t0, width)

@@ -149,7 +149,7 @@ def load(build_if_missing=True):
     return lib
 
 
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 
 STATUS_UNSUPPORTED = 3

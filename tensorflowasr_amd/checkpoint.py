@@ -14,10 +14,12 @@ layers/subsampling.py:174-214, transducer/base_transducer.py:56-273) and stored 
     prediction/embedding/embeddings      prediction/lstm_0/lstm_cell/{kernel [E,4P], recurrent_kernel [P,4P], bias [4P]}      prediction/ln_0
     joint/{enc, pred, vocab}/{kernel, bias}
 
-The `.weights.h5` CONTAINER itself cannot be read or written here (h5py is not installed and there is no network), and the paths
-above are restated from the layer names in the reference source, not from a file Keras wrote (parity unpinned; INTEGRATION.md
-shows the h5py loop that copies between an `.h5` store and this `.npz` by matching path suffix and shape).  Everything below
-the container - names, layouts, q/k/v split, BatchNorm moving statistics - is exercised by tests/test_checkpoint.py.
+The Keras 3 `.weights.h5` CONTAINER is read and written by the pure-Python HDF5 subset in h5lite.py (h5py is not installable in the
+product image; reader and writer are validated against the real HDF5 library, tests/test_h5lite.py + tests/test_checkpoint.py):
+`load_weights_h5` / `save_weights_h5` below.  The variable PATHS inside the container are restated from the layer attributes in the
+reference source and keras' saving_lib, not from a file Keras wrote (no Keras here: parity unpinned), which is why the loader
+resolves variables by anchor tokens instead of hard-coded full paths.  Names, layouts, q/k/v split and BatchNorm moving statistics
+are exercised by tests/test_checkpoint.py.
 """
 import re
 
@@ -32,6 +34,8 @@ _MHSA = {
     "q/w": "mhsa/query/kernel", "q/b": "mhsa/query/bias", "k/w": "mhsa/key/kernel", "k/b": "mhsa/key/bias",
     "v/w": "mhsa/value/kernel", "v/b": "mhsa/value/bias", "pos/w": "mhsa/encoding/kernel", "pos/b": "mhsa/encoding/bias",
     "o/w": "mhsa/attention_output/kernel", "o/b": "mhsa/attention_output/bias",
+    # encoder_mhsam_use_attention_bias: True -> every attention layer owns its pair (multihead_attention.py:522-538)
+    "u": "mhsa/content_attention_bias", "v": "mhsa/positional_attention_bias",
 }
 _CONV = {
     "ln/g": "ln/gamma", "ln/b": "ln/beta", "pw1/w": "pw_conv_1/kernel", "pw1/b": "pw_conv_1/bias", "dw/w": "dw_conv/kernel",
@@ -46,11 +50,15 @@ _TAIL = {
     "pred/ln/g": "prediction/ln_0/gamma", "pred/ln/b": "prediction/ln_0/beta",
     "joint/enc/w": "joint/enc/kernel", "joint/enc/b": "joint/enc/bias", "joint/pred/w": "joint/pred/kernel", "joint/pred/b": "joint/pred/bias",
     "joint/vocab/w": "joint/vocab/kernel", "joint/vocab/b": "joint/vocab/bias",
+    # Conformer-CTC head (models/ctc/conformer.py:21-47): ConformerDecoder "conformer_decoder" -> Dense "logits"
+    "dec/logits/w": "conformer_decoder/logits/kernel", "dec/logits/b": "conformer_decoder/logits/bias",
 }
+_DW_LN = {"bn/g": "dw_ln/gamma", "bn/b": "dw_ln/beta"}  # encoder_convm_dw_norm_type: layer -> the layer is named dw_ln (encoders/conformer.py:334-340)
 
 
-def keras_path(name):
-    """Keras variable path of one tensor of ParamStore.export_keras() (q/k/v already split; BN state as .../mm, .../mv)."""
+def keras_path(name, dw_norm="batch"):
+    """Keras variable path of one tensor of ParamStore.export_keras() (q/k/v already split; BN state as .../mm, .../mv).
+    dw_norm = cfg.convm_dw_norm: the depthwise-norm slot of the conv module is `dw_bn` (BatchNormalization) or `dw_ln`."""
     if name in _TAIL:
         return _TAIL[name]
     m = _SUB.match(name)
@@ -62,6 +70,8 @@ def keras_path(name):
     if m:
         i, rest = m.group(1), m.group(2)
         base = f"conformer_encoder/block_{i}/"
+        if dw_norm == "layer" and rest.startswith("conv/") and rest[5:] in _DW_LN:
+            return base + "conv_module/" + _DW_LN[rest[5:]]
         for pfx, module, table in (("ff1/", "ff_module_1/", _FF), ("ff2/", "ff_module_2/", _FF), ("mhsa/", "mhsa_module/", _MHSA), ("conv/", "conv_module/", _CONV)):
             if rest.startswith(pfx) and rest[len(pfx):] in table:
                 return base + module + table[rest[len(pfx):]]
@@ -78,33 +88,33 @@ def _to_keras_layout(name, a):
     return a
 
 
-def _from_keras_layout(name, a, shape):
+def _from_keras_layout(name, a, shape, path=None):
     a = np.asarray(a)
     if int(np.prod(a.shape)) != int(np.prod(shape)):
-        raise ValueError(f"{keras_path(name)}: checkpoint shape {tuple(a.shape)} does not match {tuple(shape)}")
+        raise ValueError(f"{path or name}: checkpoint shape {tuple(a.shape)} does not match {tuple(shape)}")
     return a.reshape(shape)
 
 
-def to_keras(exported):
+def to_keras(exported, dw_norm="batch"):
     """ParamStore.export_keras() dict (name -> tensor) -> {Keras path: float32 ndarray in the Keras layout}."""
     out = {}
     for name, t in exported.items():
         a = np.asarray(t.detach().cpu().numpy() if hasattr(t, "detach") else t, dtype=np.float32)
-        out[keras_path(name)] = _to_keras_layout(name, a)
+        out[keras_path(name, dw_norm)] = _to_keras_layout(name, a)
     return out
 
 
-def from_keras(arrays, template, strict=True):
+def from_keras(arrays, template, strict=True, dw_norm="batch"):
     """{Keras path: array} -> dict in the layout of `template` (= ParamStore.export_keras(), which fixes names and shapes).
     strict: every variable of the model must be present and no unknown array may remain."""
     arrays = dict(arrays)
     out, missing = {}, []
     for name, t in template.items():
-        path = keras_path(name)
+        path = keras_path(name, dw_norm)
         if path not in arrays:
             missing.append(path)
             continue
-        out[name] = _from_keras_layout(name, arrays.pop(path), tuple(t.shape))
+        out[name] = _from_keras_layout(name, arrays.pop(path), tuple(t.shape), path)
     if strict and (missing or arrays):
         raise KeyError(f"checkpoint does not match the model: missing {missing[:5]}{'...' if len(missing) > 5 else ''}, "
                        f"unexpected {sorted(arrays)[:5]}{'...' if len(arrays) > 5 else ''}")
@@ -113,7 +123,7 @@ def from_keras(arrays, template, strict=True):
 
 def save_weights(model, filepath):
     """BaseModel.save_weights (base_model.py:55-57): every trainable variable + BatchNorm moving statistics -> `.npz`."""
-    arrays = to_keras(model.ps.export_keras())
+    arrays = to_keras(model.ps.export_keras(), getattr(model.cfg, "convm_dw_norm", "batch"))
     with open(filepath, "wb") as f:  # (np.savez would append ".npz" to a bare name)
         np.savez(f, **{k.replace("/", "|"): v for k, v in arrays.items()})
     return sorted(arrays)
@@ -126,7 +136,7 @@ def load_weights(model, filepath, strict=True):
     with np.load(filepath) as z:
         arrays = {k.replace("|", "/"): z[k] for k in z.files}
     template = model.ps.export_keras()
-    got = from_keras(arrays, template, strict=strict)
+    got = from_keras(arrays, template, strict=strict, dw_norm=getattr(model.cfg, "convm_dw_norm", "batch"))
     merged = {k: (torch.from_numpy(np.ascontiguousarray(got[k])) if k in got else v) for k, v in template.items()}
     model.ps.import_keras(merged)
     return sorted(got)
@@ -252,6 +262,25 @@ def load_weights_h5(model, filepath, strict=True):
     return sorted(got)
 
 
+def save_weights_h5(model, filepath):
+    """BaseModel.save_weights (base_model.py:55-57 -> keras.Model.save_weights -> saving_lib.save_weights_only -> H5IOStore) as a
+    Keras 3 `.weights.h5` container, written by the pure-Python HDF5 writer (h5lite.write_h5; validated against the real HDF5
+    library): every layer's variables as `<attribute-walk path>/vars/<i>` in the Keras layouts, plus the model's own empty `vars`
+    group.  Returns the dataset paths.  (The attribute-walk spelling is restated from the reference's layer attributes and keras'
+    saving_lib, not confirmed against a Keras-written file: see the caveat above.)"""
+    from .h5lite import write_h5
+
+    datasets = {}
+    for name, t in model.ps.export_keras().items():
+        a = np.asarray(t.detach().cpu().numpy() if hasattr(t, "detach") else t, dtype=np.float32)
+        path = keras3_h5_path(name)
+        if path in datasets:
+            raise KeyError(f"two variables map to {path}")
+        datasets[path] = _to_keras_layout(name, a)
+    write_h5(filepath, datasets, groups=["vars"])
+    return sorted(datasets)
+
+
 def keras3_h5_path(name, cfg=None):
     """The attribute-walk path keras' saving_lib is expected to give the variable `name` (used to WRITE test fixtures; see the
     caveat above: unconfirmed against a Keras-written file)."""
@@ -276,6 +305,13 @@ def save_state(model, filepath):
     arrays = {"flat": ps.flat.cpu().numpy(), "adam_m": ps.adam_m.cpu().numpy(), "adam_v": ps.adam_v.cpu().numpy(),
               "step": np.asarray(model.step, np.int64), "drop_epoch": np.asarray(model._drop_epoch, np.int64),
               "ga_count": np.asarray(model._ga_count, np.int64), "names": np.asarray(ps.names), "n": np.asarray(ps.n, np.int64)}
+    if model._ga_count > 0:  # saved in the middle of a gradient-accumulation cycle: the partial sum of micro-gradients belongs to the state
+        arrays["grad"] = ps.grad.cpu().numpy()
+    rng = getattr(model, "_rng", None)
+    if rng is not None:  # SpecAugment draws
+        import json
+
+        arrays["rng"] = np.asarray(json.dumps(rng.bit_generator.state))
     for k, v in ps.state.items():
         arrays["state|" + k.replace("/", "|")] = v.cpu().numpy()
     with open(filepath, "wb") as f:
@@ -293,6 +329,16 @@ def load_state(model, filepath):
         ps.adam_m.copy_(torch.from_numpy(z["adam_m"]))
         ps.adam_v.copy_(torch.from_numpy(z["adam_v"]))
         model.step, model._drop_epoch, model._ga_count = int(z["step"]), int(z["drop_epoch"]), int(z["ga_count"])
+        if model._ga_count > 0:
+            if "grad" in z.files:
+                ps.grad.copy_(torch.from_numpy(z["grad"]))
+            else:  # a state file without the partial sum: restart the accumulation cycle instead of applying a stale buffer
+                model._ga_count = 0
+                ps.grad.zero_()
+        if "rng" in z.files and getattr(model, "_rng", None) is not None:
+            import json
+
+            model._rng.bit_generator.state = json.loads(str(z["rng"]))
         for k in ps.state:
             ps.state[k].copy_(torch.from_numpy(z["state|" + k.replace("/", "|")]))
     ps.refresh_shadow()

@@ -160,6 +160,36 @@ def contextnet(vocab_size=1000, alpha=0.5, **over):
     return ConformerConfig(**kw)
 
 
+def contextnet_from_reference(config: dict):
+    """The reference's ContextNet kwargs (models/transducer/contextnet.py:23-52; contextnet/small.yml.j2:1-220) -> config."""
+    c = dict(config)
+    for k, ok in {"prediction_rnn_type": ("lstm",), "prediction_num_rnns": (1,), "joint_activation": ("tanh",), "joint_mode": ("add",),
+                  "prediction_label_encode_mode": ("embedding",), "prediction_projection_units": (0,)}.items():
+        if k in c and c[k] not in ok:
+            raise NotImplementedError(f"{k}={c[k]!r}: only {ok} is on the MI355X hot path")
+    blocks = []
+    for b in c["encoder_blocks"]:
+        if str(b.get("activation", "silu")) not in ("silu", "swish") or str(b.get("padding", "causal")) != "causal":
+            raise NotImplementedError(f"ContextNet block {b}: only silu activations / causal padding are built")
+        blocks.append(dict(nlayers=int(b["nlayers"]), kernel_size=int(b["kernel_size"]), filters=int(b["filters"]), strides=int(b.get("strides", 1)),
+                           residual=bool(b.get("residual", True))))
+    alpha = float(c.get("encoder_alpha", 0.5))
+    sc = dict(c.get("speech_config", {}))
+    aug = (sc.get("augmentation_config") or {}).get("feature_augment", {}) or {}
+    reg = c.get("kernel_regularizer") or {}
+    kw = dict(encoder="contextnet", contextnet_blocks=blocks, contextnet_alpha=alpha, dmodel=int(blocks[-1]["filters"] * alpha),
+              embed_dim=c.get("prediction_embed_dim", 512), rnn_units=c.get("prediction_rnn_units", 320), joint_dim=c.get("joint_dim", 1024),
+              prediction_layer_norm=bool(c.get("prediction_layer_norm", True)), vocab_size=int(c.get("vocab_size", 1000)), blank=c.get("blank", 0),
+              dropout=0.0, l2=float((reg.get("config") or {}).get("l2", 1e-6)) if isinstance(reg, dict) else 1e-6,
+              sample_rate=sc.get("sample_rate", 16000), frame_ms=sc.get("frame_ms", 25), stride_ms=sc.get("stride_ms", 10),
+              nfft=sc.get("nfft", 512), num_feature_bins=sc.get("num_feature_bins", 80), preemphasis=sc.get("preemphasis", 0.97))
+    if "time_masking" in aug:
+        kw["time_masking"] = dict(aug["time_masking"])
+    if "freq_masking" in aug:
+        kw["freq_masking"] = dict(aug["freq_masking"])
+    return ConformerConfig(**kw)
+
+
 def contextnet_tiny(vocab_size=29, **over):
     blocks = _cn_blocks([(1, 5, 32, 1, False), (3, 5, 32, 1, True), (3, 5, 32, 2, True), (2, 3, 48, 2, True), (1, 5, 64, 1, False)])
     kw = dict(encoder="contextnet", contextnet_blocks=blocks, contextnet_alpha=0.5, dmodel=32, embed_dim=24, rnn_units=24, joint_dim=40,

@@ -16,6 +16,7 @@ import numpy as np
 import torch
 
 from . import kernels as K
+from .base_model import BaseModel
 from .kernels import ACT_NONE, ACT_SWISH, ACT_TANH_OUT
 from .params import ParamStore
 from .schemas import PredictInput, PredictOutput, TrainData, TrainInput, TrainOutput
@@ -48,7 +49,7 @@ def _split_k(M, N, Kd):
     return (v + 4) // 8 * 8 if v >= 12 else v  # whole k-slices per XCD (gemm_fast.hip split-K mapping needs split % 8 == 0)
 
 
-class ConformerTransducer:
+class ConformerTransducer(BaseModel):
     def __init__(self, cfg, device=None, dtype=torch.bfloat16, seed=0, dp=None):
         if not torch.cuda.is_available():
             raise K._lib.TfasrError("ConformerTransducer needs an MI355X (HIP) device; there is no CPU fallback")
@@ -676,7 +677,8 @@ class ConformerTransducer:
         if P is None:
             P = K._lib.BlockParams()
             P.flat, P.shadow, P.grad = ps.flat.data_ptr(), ps.shadow.data_ptr(), ps.grad.data_ptr()
-            P.bn_mm, P.bn_mv = ps.state[f"enc/block{i}/conv/bn/mm"].data_ptr(), ps.state[f"enc/block{i}/conv/bn/mv"].data_ptr()
+            if self.cfg.convm_dw_norm != "layer":  # (the LayerNormalization variant has no moving statistics; the executor ignores these)
+                P.bn_mm, P.bn_mv = ps.state[f"enc/block{i}/conv/bn/mm"].data_ptr(), ps.state[f"enc/block{i}/conv/bn/mv"].data_ptr()
             for j, nm in enumerate(K._lib.BLOCK_PARAM_NAMES):
                 if nm.startswith("/") and self.cfg.mhsam_use_attention_bias:  # "/enc/u" -> this layer's own bias
                     nm = "mhsa/" + nm.rsplit("/", 1)[1]
@@ -1018,6 +1020,7 @@ class ConformerTransducer:
     def apply_gradients(self, grad_scale=1.0):
         """BaseModel._apply_gradients -> keras Adam (base_model.py:185-192; small.yml.j2:73-87) + L2 regulariser gradient."""
         o = self.optimizer
+        self._gradient_noise()  # gradn_config (base_model.py:185-191): no-op unless compiled with one
         self.step += 1
         # keras evaluates the schedule at `iterations` BEFORE the increment (0 at the first update: the reference's first step has
         # lr = 0 with TransformerSchedule) and bias-corrects with iterations + 1 [ext: keras BaseOptimizer._get_current_learning_rate,
@@ -1042,7 +1045,9 @@ class ConformerTransducer:
             self.zero_grad()
         # the flat buffer accumulates LOCAL micro-gradients; it is all-reduced once, on the apply micro-step, where the
         # bucketed slices still overlap that micro-step's backward (base_model.py:200-209)
+        original_weights = self.apply_gwn()  # gwn_config (base_model.py:156-159): no-op unless compiled with one
         costs = self.loss_and_backward(data, True, masks, reduce=self._ga_count + 1 >= self.ga_steps)
+        self.remove_gwn(original_weights)
         self._ga_count += 1
         if self._ga_count >= self.ga_steps:
             self.apply_gradients(1.0 / self.ga_steps)

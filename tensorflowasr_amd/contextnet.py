@@ -32,6 +32,11 @@ class ContextNetTransducer(ConformerTransducer):
         self.blocks = contextnet_modules(cfg)
         self.native_blocks = False  # the native executor (csrc/block.hip) is the Conformer block
 
+    def _encoder_length(self, t):
+        for blk in self.blocks:
+            t = -(-int(t) // int(blk["stride"]))
+        return t
+
     # ------------------------------------------------------------------------------- one ConvModule
     def _cm_fwd(self, x, mod, B, T, training, ctx):
         """x [B*T, Cin] -> y [B*T2, Cout]."""

@@ -538,6 +538,22 @@ __global__ __launch_bounds__(256) void axpy_kernel(float* __restrict__ y, const 
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) y[i] += alpha * x[i];
 }
 
+// x[i] += stddev * N(0,1), the normal deviate a pure function of (seed, i): two hashed 32-bit uniforms through Box-Muller (one pair of
+// uniforms serves elements 2k and 2k+1: cosine / sine branch).  Weight noise (layer_util.add_gwn, base_transducer.py:382-425) and
+// gradient noise (math_util.add_gauss_noise, base_model.py:185-191).
+__global__ __launch_bounds__(256) void gauss_noise_kernel(float* __restrict__ x, long n, float stddev, uint64_t seed) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const uint64_t pair = (uint64_t)i >> 1;
+    const uint32_t h1 = drop_hash(seed, pair), h2 = drop_hash(seed ^ 0x5851F42D4C957F2DULL, pair);
+    const float u1 = ((float)(h1 >> 8) + 1.0f) * (1.0f / 16777216.0f);  // (0, 1]
+    const float u2 = (float)(h2 >> 8) * (1.0f / 16777216.0f);           // [0, 1)
+    const float r = sqrtf(-2.0f * __logf(u1));
+    float sn, cs;
+    __sincosf(6.283185307179586f * u2, &sn, &cs);
+    x[i] += stddev * r * ((i & 1) ? sn : cs);
+  }
+}
+
 // sum of squares (regularisation loss term); out[0] += sum p^2
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ p, long n, float* __restrict__ out) {
   __shared__ float red[16];
@@ -848,6 +864,14 @@ extern "C" int tfasr_adam(float* p, const float* g, float* m, float* v, long n, 
   const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
   hipLaunchKernelGGL(adam_kernel, dim3(flat_grid(n)), dim3(256), 0, (hipStream_t)stream_, p, g, m, v, n, n_reg, lr, beta1,
                      beta2, eps, weight_decay, l2, grad_scale, bc1, bc2);
+  TFASR_CHECK_LAUNCH();
+  return TFASR_STATUS_SUCCESS;
+}
+
+extern "C" int tfasr_gauss_noise(float* x, long n, float stddev, long seed, void* stream_) {
+  if (!x || n < 0) return TFASR_STATUS_INVALID_VALUE;
+  if (n == 0 || stddev == 0.f) return TFASR_STATUS_SUCCESS;
+  hipLaunchKernelGGL(gauss_noise_kernel, dim3(flat_grid(n)), dim3(256), 0, (hipStream_t)stream_, x, n, stddev, (uint64_t)seed);
   TFASR_CHECK_LAUNCH();
   return TFASR_STATUS_SUCCESS;
 }

@@ -263,3 +263,173 @@ class H5File:
         if arr is None:
             raise KeyError(f"{path} is a group")
         return arr
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# Writer: the same subset of the format, laid out like h5py's default ("earliest") files - superblock version 0, version-1
+# object headers, old-style groups (symbol table message -> v1 B-tree -> symbol nodes + local heap), contiguous little-endian
+# datasets.  What keras' H5IOStore needs to READ a `.weights.h5` (keras.Model.load_weights, base_model.py:59-61) is exactly this.
+# Validated in tests/test_h5lite.py by reading the written file back with the reader above AND with the real HDF5 library
+# (h5py under /opt/conda in the build container, oracle/check_h5_roundtrip.py).
+# ------------------------------------------------------------------------------------------------------------------------
+_LEAF_K, _INTERNAL_K = 4, 16
+
+
+class _Out:
+    def __init__(self):
+        self.b = bytearray()
+
+    def alloc(self, n):
+        """reserve n bytes at the next 8-byte boundary -> address"""
+        pad = (-len(self.b)) % 8
+        self.b += b"\0" * pad
+        a = len(self.b)
+        self.b += b"\0" * n
+        return a
+
+    def put(self, addr, data):
+        self.b[addr:addr + len(data)] = data
+
+
+def _msg(mtype, payload, flags=0):
+    payload = payload + b"\0" * ((-len(payload)) % 8)
+    return struct.pack("<HHB3x", mtype, len(payload), flags) + payload
+
+
+def _object_header(out, msgs):
+    body = b"".join(msgs)
+    a = out.alloc(16 + len(body))
+    out.put(a, struct.pack("<BBHII4x", 1, 0, len(msgs), 1, len(body)) + body)
+    return a
+
+
+def _datatype_msg(dt):
+    dt = np.dtype(dt)
+    if dt.kind == "f" and dt.itemsize in (2, 4, 8):
+        exp_bits, man_bits = {2: (5, 10), 4: (8, 23), 8: (11, 52)}[dt.itemsize]
+        bits = 8 * dt.itemsize
+        head = struct.pack("<BBBBI", 0x11, 0x20, bits - 1, 0, dt.itemsize)  # class 1 (float) v1; LE, implied-msb mantissa; sign bit location
+        props = struct.pack("<HHBBBBI", 0, bits, man_bits, exp_bits, 0, man_bits, (1 << (exp_bits - 1)) - 1)
+    elif dt.kind in "iu":
+        head = struct.pack("<BBBBI", 0x10, 0x08 if dt.kind == "i" else 0x00, 0, 0, dt.itemsize)  # class 0 (fixed point) v1; LE; signed?
+        props = struct.pack("<HH", 0, 8 * dt.itemsize)
+    else:
+        raise H5Error(f"cannot write dtype {dt} (numeric weights only)")
+    return _msg(0x03, head + props, flags=1)
+
+
+def _write_dataset(out, arr):
+    arr = np.asarray(arr, order="C")  # (np.ascontiguousarray would turn a scalar into a one-element vector)
+    if arr.dtype.byteorder == ">":
+        arr = arr.astype(arr.dtype.newbyteorder("<"))
+    raw = arr.tobytes()
+    daddr = out.alloc(len(raw)) if raw else _UNDEF
+    if raw:
+        out.put(daddr, raw)
+    space = struct.pack("<BBB5x", 1, arr.ndim, 0) + b"".join(struct.pack("<Q", int(s)) for s in arr.shape)
+    msgs = [_msg(0x01, space), _datatype_msg(arr.dtype),
+            _msg(0x05, struct.pack("<BBBBI", 2, 2, 2, 1, 0), flags=1),  # fill value v2: late allocation, write if set, default value
+            _msg(0x08, struct.pack("<BBQQ", 3, 1, daddr, len(raw)))]   # layout v3, contiguous
+    return _object_header(out, msgs)
+
+
+def _write_group(out, children):
+    """children: {name: nested dict (group) | ndarray (dataset)} -> (object header address, btree address, heap address)"""
+    names = sorted(children, key=lambda s: s.encode("utf-8"))
+    # children first (depth-first), so every address is known when this group's tables are written
+    entries = []
+    for nm in names:
+        c = children[nm]
+        if isinstance(c, dict):
+            hdr, bt, hp = _write_group(out, c)
+            entries.append((nm, hdr, 1, struct.pack("<QQ", bt, hp)))
+        else:
+            entries.append((nm, _write_dataset(out, c), 0, b"\0" * 16))
+    # local heap: offset 0 = the empty string (the B-tree's leftmost key), then the link names, each padded to 8 bytes
+    heap = bytearray(b"\0" * 8)
+    noff = {}
+    for nm in names:
+        noff[nm] = len(heap)
+        e = nm.encode("utf-8") + b"\0"
+        heap += e + b"\0" * ((-len(e)) % 8)
+    # one free block at the tail (>= 16 bytes: next = 1 (end of list), size) so that the library may add links later
+    free_off = len(heap)
+    heap += struct.pack("<QQ", 1, 32) + b"\0" * 16
+    hdata = out.alloc(len(heap))
+    out.put(hdata, bytes(heap))
+    hp = out.alloc(32)
+    out.put(hp, b"HEAP" + struct.pack("<B3xQQQ", 0, len(heap), free_off, hdata))
+    # symbol nodes of <= 2 * leaf K entries, in name order
+    cap = 2 * _LEAF_K
+    level = []  # (address, heap offset of the largest name below it)
+    for i in range(0, max(len(entries), 1), cap):
+        chunk = entries[i:i + cap]
+        a = out.alloc(8 + cap * 40)
+        body = b"SNOD" + struct.pack("<BBH", 1, 0, len(chunk))
+        for nm, hdr, ctype, scratch in chunk:
+            body += struct.pack("<QQII", noff[nm], hdr, ctype, 0) + scratch
+        out.put(a, body)
+        level.append((a, noff[chunk[-1][0]] if chunk else 0))
+    # v1 B-tree (node type 0) over the symbol nodes; key[0] = "" (offset 0), key[i + 1] = largest name in child i
+    fan = 2 * _INTERNAL_K
+    depth = 0
+    while True:
+        nodes = []
+        for i in range(0, len(level), fan):
+            kids = level[i:i + fan]
+            a = out.alloc(24 + fan * 8 + (fan + 1) * 8)
+            body = b"TREE" + struct.pack("<BBHQQ", 0, depth, len(kids), _UNDEF, _UNDEF) + struct.pack("<Q", 0)
+            for child, key in kids:
+                body += struct.pack("<QQ", child, key)
+            nodes.append((a, body, kids[-1][1]))
+        # sibling links and the first key of every node but the leftmost (= the last key of its left neighbour)
+        for j, (a, body, _k) in enumerate(nodes):
+            left = nodes[j - 1][0] if j else _UNDEF
+            right = nodes[j + 1][0] if j + 1 < len(nodes) else _UNDEF
+            first = nodes[j - 1][2] if j else 0
+            body = body[:8] + struct.pack("<QQ", left, right) + struct.pack("<Q", first) + body[32:]
+            out.put(a, body)
+        level = [(a, k) for a, _b, k in nodes]
+        if len(level) == 1:
+            break
+        depth += 1
+    bt = level[0][0]
+    hdr = _object_header(out, [_msg(0x11, struct.pack("<QQ", bt, hp))])
+    return hdr, bt, hp
+
+
+def write_h5(path, datasets, groups=()):
+    """Write {"a/b/vars/0": ndarray, ...} (+ optional empty groups, e.g. keras' top-level "vars") as an HDF5 file."""
+    tree = {}
+
+    def node(parts):
+        cur = tree
+        for p in parts:
+            nxt = cur.setdefault(p, {})
+            if not isinstance(nxt, dict):
+                raise H5Error(f"{'/'.join(parts)}: a dataset is in the way")
+            cur = nxt
+        return cur
+
+    for g in groups:
+        node([t for t in g.split("/") if t])
+    for p, arr in datasets.items():
+        parts = [t for t in p.split("/") if t]
+        if not parts:
+            raise H5Error("empty dataset path")
+        parent = node(parts[:-1])
+        if parts[-1] in parent:
+            raise H5Error(f"{p}: name already used")
+        parent[parts[-1]] = np.asarray(arr)
+    out = _Out()
+    out.alloc(96)  # superblock, written last
+    root, bt, hp = _write_group(out, tree)
+    out.alloc(0)
+    eof = len(out.b)
+    sb = b"\x89HDF\r\n\x1a\n" + struct.pack("<BBBBBBBB", 0, 0, 0, 0, 0, 8, 8, 0) + struct.pack("<HHI", _LEAF_K, _INTERNAL_K, 0)
+    sb += struct.pack("<QQQQ", 0, _UNDEF, eof, _UNDEF)
+    sb += struct.pack("<QQII", 0, root, 1, 0) + struct.pack("<QQ", bt, hp)
+    out.put(0, sb)
+    with open(path, "wb") as f:
+        f.write(bytes(out.b))
+    return eof

@@ -383,6 +383,13 @@ def adam(p, g, m, v, n_reg, lr, step, beta1=0.9, beta2=0.999, eps=1e-7, weight_d
     check(_L().tfasr_adam(_p(p), _p(g), _p(m), _p(v), p.numel(), n_reg, lr, beta1, beta2, eps, weight_decay, l2, grad_scale, step, _stream()), "adam")
 
 
+def gauss_noise(x, stddev, seed):
+    """x (f32, contiguous) += stddev * N(0,1), counter-based (seed, index)."""
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    check(_L().tfasr_gauss_noise(_p(x), x.numel(), float(stddev), int(seed) & 0x7FFFFFFFFFFFFFFF, _stream()), "gauss_noise")
+    return x
+
+
 def axpy(y, x, alpha=1.0):
     check(_L().tfasr_axpy(_p(y), _p(x), alpha, x.numel(), _stream()), "axpy")
 

@@ -128,7 +128,10 @@ def bn_names(cfg):
         for blk in contextnet_modules(cfg):
             out += [m[0] + "/bn" for m in blk["convs"]] + ([blk["res"][0] + "/bn"] if blk["res"] else [])
         return out
-    return ["enc/sub/bn0", "enc/sub/bn1"] + [f"enc/block{i}/conv/bn" for i in range(cfg.num_blocks)]
+    # encoder_convm_dw_norm_type: layer (encoders/conformer.py:334-340) puts a LayerNormalization in the depthwise-norm slot: no moving
+    # statistics exist for it (a keras LayerNormalization holds gamma and beta only)
+    blocks = [] if getattr(cfg, "convm_dw_norm", "batch") == "layer" else [f"enc/block{i}/conv/bn" for i in range(cfg.num_blocks)]
+    return ["enc/sub/bn0", "enc/sub/bn1"] + blocks
 
 
 class ParamStore:

@@ -23,7 +23,7 @@ def _exported_template(cfg, seed=0):
                 out[name[:-5] + k + "/b"] = t[i * H * dh:(i + 1) * H * dh].reshape(H, dh).clone()
         elif name.endswith("pos/w"):
             out[name] = t.reshape(d, H, dh)
-        elif name.endswith("pos/b") or name in ("enc/u", "enc/v"):
+        elif name.endswith("pos/b") or name in ("enc/u", "enc/v") or name.endswith(("mhsa/u", "mhsa/v")):
             out[name] = t.reshape(H, dh)
         elif name.endswith("mhsa/o/w"):
             out[name] = t.reshape(H, dh, d)
@@ -90,6 +90,98 @@ def test_strict_loading_errors():
         ck.keras_path("enc/cn/block0/whatever")
 
 
+def test_ctc_head_per_layer_biases_and_layernorm_dw_variant_have_keras_paths():
+    """Conformer-CTC (Dense "logits" head, per-layer attention biases) and the streaming Conformer (LayerNormalization in
+    the depthwise-norm slot, named dw_ln, gamma / beta only) round-trip through the Keras-path checkpoint like the transducer."""
+    cfg = configs.conformer_ctc_s(num_blocks=2)
+    tpl = _exported_template(cfg)
+    arrays = ck.to_keras(tpl)
+    assert len(arrays) == len(tpl)
+    H, dh = cfg.num_heads, cfg.head_size
+    assert arrays["conformer_decoder/logits/kernel"].shape == (cfg.dmodel, cfg.vocab_size)
+    assert arrays["conformer_encoder/block_1/mhsa_module/mhsa/content_attention_bias"].shape == (H, dh)
+    assert arrays["conformer_encoder/block_0/mhsa_module/mhsa/positional_attention_bias"].shape == (H, dh)
+    assert "conformer_encoder/content_attention_bias" not in arrays and "joint/vocab/kernel" not in arrays
+    back = ck.from_keras(arrays, tpl)
+    assert all(np.array_equal(back[k], tpl[k].numpy()) for k in tpl)
+    # streaming: dw_ln, no moving statistics anywhere in the conv modules
+    scfg = configs.conformer_tiny(convm_dw_norm="layer", chunk_size=2, history_size=4)
+    assert params.bn_names(scfg) == ["enc/sub/bn0", "enc/sub/bn1"]
+    stpl = _exported_template(scfg)
+    assert not [k for k in stpl if "/conv/bn/m" in k]
+    sarr = ck.to_keras(stpl, dw_norm="layer")
+    assert len(sarr) == len(stpl)
+    assert "conformer_encoder/block_0/conv_module/dw_ln/gamma" in sarr and "conformer_encoder/block_0/conv_module/dw_ln/beta" in sarr
+    assert not [p for p in sarr if "dw_bn" in p or ("conv_module" in p and "moving_" in p)]
+    sback = ck.from_keras(sarr, stpl, dw_norm="layer")
+    assert all(np.array_equal(sback[k], stpl[k].numpy()) for k in stpl)
+    with pytest.raises(KeyError):  # a batch-norm checkpoint does not load into the layer-norm model silently
+        ck.from_keras(ck.to_keras(stpl, dw_norm="batch"), stpl, dw_norm="layer")
+
+
+class _HostModel:
+    """export_keras() of a model without a device (the container / path logic is host code)."""
+
+    def __init__(self, cfg, seed=0):
+        self.cfg = cfg
+        tpl = _exported_template(cfg, seed)
+
+        class PS:
+            def export_keras(self_inner):
+                return tpl
+
+        self.ps, self.tpl = PS(), tpl
+
+
+@pytest.mark.parametrize("make", [lambda: configs.conformer_tiny(), lambda: configs.conformer_ctc_s(num_blocks=2),
+                                  lambda: configs.conformer_tiny(convm_dw_norm="layer", chunk_size=2, history_size=4)])
+def test_weights_h5_writer_round_trip(tmp_path, make):
+    """BaseModel.save_weights -> `.weights.h5` (callbacks.py:190-239, base_model.py:55-61): the file written by save_weights_h5 is read
+    back by the reader, resolves onto every model variable exactly once, and - where the real HDF5 library is available (h5py under
+    /opt/conda in the build container) - reads back identically through libhdf5."""
+    import os
+    import subprocess
+
+    from tensorflowasr_amd.h5lite import H5File
+
+    m = _HostModel(make())
+    path = str(tmp_path / "model.weights.h5")
+    names = ck.save_weights_h5(m, path)
+    assert len(names) == len(m.tpl) and all("/vars/" in n for n in names)
+    with H5File(path) as f:
+        datasets = f.datasets()
+    assert sorted(datasets) == names
+    got, unused = ck.from_weights_h5(datasets, m.tpl)
+    assert unused == [] and sorted(got) == sorted(m.tpl)
+    for k, t in m.tpl.items():
+        np.testing.assert_array_equal(got[k], t.numpy(), err_msg=k)
+    conda = "/opt/conda/bin/python3.9"
+    if os.path.exists(conda) and subprocess.run([conda, "-c", "import h5py"], capture_output=True).returncode == 0:
+        npz = str(tmp_path / "model.npz")
+        np.savez(npz, **{k.replace("/", "|"): v for k, v in datasets.items()})
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        r = subprocess.run([conda, os.path.join(root, "oracle", "check_h5_roundtrip.py"), path, npz], capture_output=True, text=True)
+        assert r.returncode == 0 and r.stdout.startswith("ok:"), r.stdout + r.stderr
+
+
+def test_h5_writer_wide_and_deep_groups(tmp_path):
+    """more children than one symbol node / one B-tree node holds (two-level group B-tree), scalars, empty and 64-bit datasets"""
+    from tensorflowasr_amd.h5lite import H5File, write_h5
+
+    rng = np.random.default_rng(0)
+    ds = {f"wide/n{i}": np.arange(i % 5 + 1, dtype=np.int32) for i in range(300)}
+    ds.update({"a/b/c/d/e/f32": rng.standard_normal((3, 4)).astype(np.float32), "a/f64": rng.standard_normal((2, 2, 2)),
+               "a/scalar": np.float32(3.25), "a/i64": np.int64(-7), "a/empty": np.zeros((0, 4), np.float32), "a/u8": np.arange(17, dtype=np.uint8)})
+    p = str(tmp_path / "t.h5")
+    write_h5(p, ds, groups=["vars", "optimizer/vars"])
+    with H5File(p) as f:
+        got = f.datasets()
+    assert sorted(got) == sorted(ds)
+    for k, a in ds.items():
+        assert got[k].dtype == np.asarray(a).dtype and got[k].shape == np.asarray(a).shape, k
+        np.testing.assert_array_equal(got[k], a)
+
+
 @pytest.mark.gpu
 def test_save_and_load_weights_round_trip(tmp_path):
     from tensorflowasr_amd.conformer import ConformerTransducer
@@ -108,6 +200,36 @@ def test_save_and_load_weights_round_trip(tmp_path):
     assert torch.equal(a.ps.flat, b.ps.flat) and torch.equal(a.ps.shadow, b.ps.shadow)
     for k in a.ps.state:
         assert torch.equal(a.ps.state[k], b.ps.state[k]), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["ctc", "streaming"])
+def test_save_and_load_weights_round_trip_ctc_and_streaming(tmp_path, kind):
+    """npz AND `.weights.h5` save -> load for the Conformer-CTC model (per-layer attention biases, Dense head) and for the
+    streaming configuration (LayerNormalization depthwise norm: no moving statistics)."""
+    from tensorflowasr_amd.conformer import ConformerTransducer
+    from tensorflowasr_amd.ctc_model import ConformerCTC
+
+    dev = torch.device("cuda", 0)
+    if kind == "ctc":
+        cfg = configs.conformer_ctc_s(num_blocks=2)
+        mk = lambda seed: ConformerCTC(cfg, dev, dtype=torch.bfloat16, seed=seed)
+    else:
+        cfg = configs.conformer_tiny(convm_dw_norm="layer", chunk_size=2, history_size=4)
+        mk = lambda seed: ConformerTransducer(cfg, dev, dtype=torch.bfloat16, seed=seed)
+    a = mk(1)
+    for k, v in a.ps.state.items():
+        v.copy_(torch.rand_like(v) + (0.5 if k.endswith("mv") else 0.0))
+    for ext, save, load in ((".npz", ck.save_weights, ck.load_weights), (".weights.h5", ck.save_weights_h5, ck.load_weights_h5)):
+        path = str(tmp_path / ("model" + ext))
+        names = save(a, path)
+        assert not [n for n in names if "dw_bn" in n] or kind == "ctc"
+        b = mk(2)
+        assert not torch.equal(a.ps.flat, b.ps.flat)
+        load(b, path)
+        assert torch.equal(a.ps.flat, b.ps.flat) and torch.equal(a.ps.shadow, b.ps.shadow)
+        for k in a.ps.state:
+            assert torch.equal(a.ps.state[k], b.ps.state[k]), k
 
 
 @pytest.mark.gpu

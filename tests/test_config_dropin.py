@@ -83,3 +83,54 @@ def test_schedule_at_keras_first_update_is_zero():
         assert float(fn(0, 144, 10000, 2.0, 0.05 / 12)) == 0.0
         assert float(fn(0, 144, 10000, 2.0, 0.05 / 12, 1e-6)) == pytest.approx(1e-6)
         assert float(fn(1, 144, 10000, 2.0, 0.05 / 12)) == pytest.approx(2.0 * 144 ** -0.5 * 10000 ** -1.5, rel=1e-5)
+
+
+def _frozen():
+    import json
+
+    return json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_configs.json")))
+
+
+@pytest.mark.skipif(not os.path.exists(REF), reason="reference tree not present")
+def test_frozen_config_fixture_is_the_reference_rendering():
+    """tests/golden/reference_configs.json (what the GPU box builds models from) regenerates from /root/reference."""
+    import jinja2
+    import yaml
+
+    for key, v in _frozen().items():
+        txt = jinja2.Template(open("/root/reference/" + v["source"]).read()).render(decoder_config={"vocabsize": 1000}, modeldir="/tmp/m",
+                                                                                  kaggle_model_handle="x", repodir="/root/reference", datadir="/tmp/d")
+        doc = yaml.safe_load(txt)
+        assert doc["model_config"] == v["model_config"], key
+        assert doc["learning_config"]["optimizer_config"] == v["learning_config"]["optimizer_config"], key
+
+
+def test_optimizer_and_noise_configs_of_the_shipped_ymls():
+    """learning_config.optimizer_config / gwn_config of the four shipped model configs map onto the train step's optimizer
+    (small.yml.j2:73-91, contextnet/small.yml.j2:217-240)."""
+    from tensorflowasr_amd import base_model
+
+    fz = _frozen()
+    o = base_model.optimizer_from_config(fz["transducer/conformer/small"]["learning_config"]["optimizer_config"], 144)
+    assert (o["beta1"], o["beta2"], o["eps"], o["weight_decay"]) == (0.9, 0.98, 1e-9, 1e-6)
+    assert o["schedule"] == dict(dmodel=144, warmup_steps=10000, scale=2.0, max_lr=pytest.approx(0.05 / 12))
+    o = base_model.optimizer_from_config(fz["transducer/contextnet/small"]["learning_config"]["optimizer_config"], 320)
+    assert o["schedule"]["min_lr"] == 1e-6 and o["schedule"]["max_lr"] == 0.0025 and o["schedule"]["warmup_steps"] == 15000
+    assert configs.transformer_schedule(0, **o["schedule"]) == 1e-6
+    assert fz["transducer/contextnet/small"]["learning_config"]["gwn_config"] == {"predict_net_step": 20000, "predict_net_stddev": 0.075}
+    assert base_model.optimizer_from_config({"class_name": "Adam", "config": {"learning_rate": 1e-3}}, 144)["schedule"] == 1e-3
+    with pytest.raises(NotImplementedError):
+        base_model.optimizer_from_config({"class_name": "SGD", "config": {}}, 144)
+    # ContextNet kwargs -> config: identical to the hand-written configs.contextnet()
+    import dataclasses
+
+    c = configs.contextnet_from_reference(fz["transducer/contextnet/small"]["model_config"]["config"])
+    r = configs.contextnet()
+    assert [f.name for f in dataclasses.fields(c) if getattr(c, f.name) != getattr(r, f.name)] == []
+
+
+def test_model_from_config_rejects_models_off_the_path():
+    from tensorflowasr_amd import base_model
+
+    with pytest.raises(NotImplementedError):
+        base_model.model_from_config({"class_name": "tensorflow_asr.models.ctc.jasper>Jasper", "config": {}})

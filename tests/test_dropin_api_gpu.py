@@ -1,0 +1,144 @@
+"""GPU: the reference's Python model surface on models built from the reference's own
+`model_config.class_name` + `config` (frozen renderings of examples/models/**/*.yml.j2, tests/golden/reference_configs.json):
+make / compile / train_step (GA, weight noise, gradient noise) / test_step / predict_step / save_weights / load_weights / tokenizer /
+get_initial_*  (tensorflow_asr/models/base_model.py:41-61,68-135,212-250,316-323; transducer/base_transducer.py:378-425,466-470)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tensorflowasr_amd import base_model, kernels as K
+from tensorflowasr_amd.schemas import TrainData, TrainInput, TrainLabel
+
+pytestmark = pytest.mark.gpu
+
+FZ = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_configs.json")))
+
+
+@pytest.fixture(scope="module")
+def dev():
+    return torch.device("cuda", 0)
+
+
+def _data(V, B=2, N=32000, U=8, seed=0):
+    rng = np.random.default_rng(seed)
+    sig = (rng.standard_normal((B, N)) * 0.1).astype(np.float32)
+    labels = rng.integers(1, V, (B, U)).astype(np.int32)
+    preds = np.concatenate([np.zeros((B, 1), np.int32), labels], 1)
+    return TrainData(TrainInput(torch.from_numpy(sig), torch.full((B,), N, dtype=torch.int32), torch.from_numpy(preds),
+                                torch.full((B,), U + 1, dtype=torch.int32)),
+                     TrainLabel(torch.from_numpy(labels), torch.full((B,), U, dtype=torch.int32)))
+
+
+def _shrink(mc, **over):
+    mc = json.loads(json.dumps(mc))
+    mc["config"].update(over)
+    return mc
+
+
+def test_gauss_noise_kernel_statistics_and_determinism(dev):
+    x = torch.zeros(1 << 20, dtype=torch.float32, device=dev)
+    K.gauss_noise(x, 0.5, seed=123)
+    a = x.cpu().numpy()
+    assert abs(a.mean()) < 3e-3 and abs(a.std() - 0.5) < 3e-3
+    assert abs(np.mean(a ** 3)) < 5e-3 and abs(np.mean(a ** 4) / 0.5 ** 4 - 3.0) < 0.05  # skewness 0, kurtosis 3
+    assert abs(np.corrcoef(a[0::2], a[1::2])[0, 1]) < 5e-3  # the cosine / sine halves of a pair are uncorrelated
+    y = torch.zeros_like(x)
+    K.gauss_noise(y, 0.5, seed=123)
+    assert torch.equal(x, y)
+    K.gauss_noise(y, 0.5, seed=124)
+    assert not torch.equal(2 * x, y)
+
+
+def test_conformer_transducer_from_small_yml_full_surface(dev, tmp_path):
+    ent = FZ["transducer/conformer/small"]
+    mc = _shrink(ent["model_config"], encoder_num_blocks=2)
+    model = base_model.model_from_config(mc, dev, dtype=torch.bfloat16, seed=0)
+    assert type(model).__name__ == "ConformerTransducer" and model.cfg.dmodel == 144 and model.cfg.head_size == 36
+    tok = object()
+    model.tokenizer = tok
+    assert model.tokenizer is tok
+    shapes = model.make(input_shape=[32000], prediction_shape=[9], batch_size=2)
+    assert shapes.logits == [2, 50, 9, 1000] and shapes.logits_length == [2]
+    assert model.make(batch_size=4).logits == [4, None, None, 1000]
+    with pytest.raises(AssertionError):
+        model.make(input_shape=[32000])
+    lc = ent["learning_config"]
+    model.compile(optimizer=lc["optimizer_config"], output_shapes=shapes, ga_steps=2,
+                  gwn_config={"predict_net_step": 0, "predict_net_stddev": 0.075, "encoder_step": 5, "encoder_stddev": 0.01},
+                  gradn_config={"step": 0, "stddev": 1e-3})
+    assert model.ga_steps == 2 and type(model.tfasr_loss).__name__ == "RnntLoss" and model.optimizer["schedule"]["warmup_steps"] == 10000
+    data = _data(1000)
+    before = model.ps.flat.clone()
+    assert model.get_initial_encoder_states(2) == []
+    # one accumulation cycle = one optimizer update; keras evaluates the schedule at iterations = 0 -> lr = 0 at the first update, so the
+    # parameters must come back BIT-EXACT: remove_gwn restored the prediction network's weights after each noisy micro-step
+    l0 = model.train_step(data)["loss"]
+    assert model.step == 0 and model._ga_count == 1
+    l1 = model.train_step(data)["loss"]
+    assert model.step == 1 and model._ga_count == 0
+    assert torch.equal(model.ps.flat, before)
+    assert np.isfinite(l0.cpu().numpy()).all() and not np.allclose(l0.cpu().numpy(), l1.cpu().numpy())  # different noise / dropout draws
+    # the noise is really applied during the step: with it the loss differs from the noiseless forward
+    model.cfg.dropout, model.cfg.time_masking, model.cfg.freq_masking = 0.0, {}, {}
+    clean = model.loss_and_backward(data, True, want_backward=False).cpu().numpy()
+    ow = model.apply_gwn()
+    assert set(ow) == {"predict_net"}  # encoder_step = 5 has not been reached
+    assert not torch.equal(model.ps.flat, before)
+    noisy = model.loss_and_backward(data, True, want_backward=False).cpu().numpy()
+    model.remove_gwn(ow)
+    assert torch.equal(model.ps.flat, before) and not np.allclose(clean, noisy)
+    # gradient noise lands on the whole gradient buffer
+    model.zero_grad()
+    model._gradient_noise()
+    g = model.ps.grad.cpu().numpy()
+    assert abs(g.std() - 1e-3) < 5e-5
+    # test_step / predict_step
+    model.compile(optimizer=lc["optimizer_config"])
+    t = model.test_step(data)["loss"].cpu().numpy()
+    assert t.shape == (2,) and np.isfinite(t).all()
+    p = model.predict_step(data)
+    assert set(p) == {"tokens", "beam_tokens", "labels"} and p["tokens"].shape[0] == 2 and torch.equal(p["labels"], data.labels.labels)
+    assert torch.equal(p["tokens"], p["beam_tokens"])  # the reference's transducer beam search falls back to greedy
+    # save_weights / load_weights: Keras 3 container and npz
+    for name in ("m.weights.h5", "m.npz"):
+        path = str(tmp_path / name)
+        model.save_weights(path)
+        other = base_model.model_from_config(mc, dev, dtype=torch.bfloat16, seed=5)
+        assert not torch.equal(other.ps.flat, model.ps.flat)
+        other.load_weights(path)
+        assert torch.equal(other.ps.flat, model.ps.flat)
+        with pytest.raises(FileExistsError):
+            model.save_weights(path, overwrite=False)
+
+
+@pytest.mark.parametrize("key,cls", [("transducer/conformer/small-streaming", "ConformerTransducer"), ("ctc/conformer/small", "ConformerCTC"),
+                                     ("transducer/contextnet/small", "ContextNetTransducer")])
+def test_other_shipped_configs_build_compile_and_step(dev, key, cls):
+    ent = FZ[key]
+    mc = ent["model_config"]
+    if "encoder_num_blocks" in mc["config"]:
+        mc = _shrink(mc, encoder_num_blocks=2)
+    else:  # ContextNet: first, two middle (one strided) and last block
+        b = mc["config"]["encoder_blocks"]
+        mc = _shrink(mc, encoder_blocks=[b[0], b[1], b[3], b[-1]])
+    model = base_model.model_from_config(mc, dev, dtype=torch.bfloat16, seed=0)
+    assert type(model).__name__ == cls
+    shapes = model.make(input_shape=[32000], prediction_shape=[9], batch_size=2)
+    lc = ent["learning_config"]
+    model.compile(optimizer=lc["optimizer_config"], output_shapes=shapes, gwn_config=lc["gwn_config"], gradn_config=lc["gradn_config"])
+    want_t = 50 if cls != "ContextNetTransducer" else 100
+    assert shapes.logits == ([2, want_t, 1000] if cls == "ConformerCTC" else [2, want_t, 9, 1000])
+    assert type(model.tfasr_loss).__name__ == ("CtcLoss" if cls == "ConformerCTC" else "RnntLoss")
+    data = _data(1000)
+    before = model.ps.flat.clone()
+    for _ in range(3):
+        loss = model.train_step(data)["loss"].cpu().numpy()
+        assert np.isfinite(loss).all()
+    assert model.step == 3 and not torch.equal(model.ps.flat, before)
+    out = model(data.inputs, training=False) if cls != "ConformerCTC" else None
+    if out is not None:
+        assert list(out.logits.shape) == shapes.logits
+    assert np.isfinite(model.test_step(data)["loss"].cpu().numpy()).all()
