@@ -400,3 +400,100 @@ def load_reference_module(rel_path, mod_name, extra_modules=None):
                 sys.modules.pop(k, None)
             else:
                 sys.modules[k] = v
+
+
+def extend_for_ctc_tpu(tf):
+    """Primitives (with TensorFlow's KEYWORD names) that tensorflow_asr/losses/impl/ctc_tpu.py calls, so that the reference's pure-TF
+    CTC (`ctc_loss_tpu`, :1295; ClassicCtcLossData :821-1290) runs over NumPy.  tf.custom_gradient stays the identity (the decorated
+    methods return (value, backprop)): the generator reads `loss` / `gradient` from the loss-data object directly."""
+    A = np.asarray
+    err = dict(invalid="ignore", divide="ignore", over="ignore")
+
+    def ints(v):
+        return [int(A(s)) for s in (v if isinstance(v, (list, tuple)) else A(v).reshape(-1))]
+
+    def w(f):
+        def g(*a, **k):
+            k.pop("name", None)
+            with np.errstate(**err):
+                return _t(f(*a, **k))
+        return g
+
+    tf.inf = np.inf
+    tf.Variable = T
+    tf.stop_gradient = lambda x, name=None: _t(x)
+    tf.constant = lambda value, dtype=None, shape=None, name=None: _t(value, dtype)
+    tf.reduce_logsumexp = lambda input_tensor, axis=None, keepdims=False, name=None: _logsumexp(A(input_tensor), tuple(axis) if isinstance(axis, list) else axis, keepdims)
+    tf.reduce_max = w(lambda input_tensor, axis=None, keepdims=False: np.max(A(input_tensor), axis=tuple(axis) if isinstance(axis, list) else axis, keepdims=keepdims))
+    tf.reduce_sum = w(lambda input_tensor, axis=None, keepdims=False: np.sum(A(input_tensor), axis=tuple(axis) if isinstance(axis, list) else axis, keepdims=keepdims))
+    tf.where = w(lambda condition, x=None, y=None: np.where(A(condition), A(x), A(y)))
+    tf.reshape = lambda tensor, shape, name=None: _t(np.reshape(A(tensor), ints(shape)))
+    tf.transpose = lambda a, perm=None, name=None: _t(np.transpose(A(a), None if perm is None else ints(perm)))
+    tf.expand_dims = lambda input, axis, name=None: _t(np.expand_dims(A(input), int(axis)))  # noqa: A002
+    tf.squeeze = lambda input, axis=None, name=None: _t(np.squeeze(A(input), axis=None if axis is None else tuple(np.atleast_1d(axis))))  # noqa: A002
+    tf.tile = lambda input, multiples, name=None: _t(np.tile(A(input), ints(multiples)))  # noqa: A002
+    tf.stack = lambda values, axis=0, name=None: _t(np.stack([A(v) for v in values], axis=axis))
+    tf.concat = lambda values, axis, name=None: _t(np.concatenate([A(v) for v in values], axis=axis))
+    tf.roll = lambda input, shift, axis, name=None: _t(np.roll(A(input), int(A(shift)), axis=int(axis)))  # noqa: A002
+    tf.gather = lambda params, indices, axis=None, batch_dims=0, name=None: _gather(A(params), A(indices), axis, batch_dims)
+    tf.one_hot = lambda indices, depth, dtype=None, name=None: _t((A(indices)[..., None] == np.arange(int(A(depth)))).astype(_npd(dtype) or np.float32))
+    tf.sequence_mask = lambda lengths, maxlen=None, dtype=None, name=None: _sequence_mask(lengths, None if maxlen is None else int(A(maxlen)), dtype)
+    tf.cumsum = w(lambda x, axis=0, exclusive=False, reverse=False: np.cumsum(A(x), axis=axis))
+    tf.meshgrid = lambda *a, indexing="xy": [_t(v) for v in np.meshgrid(*[A(v) for v in a], indexing=indexing)]
+    tf.eye = lambda num_rows, num_columns=None, dtype=None, name=None: _t(np.eye(int(A(num_rows)), None if num_columns is None else int(A(num_columns)), dtype=_npd(dtype) or np.float32))
+    tf.zeros = lambda shape, dtype=None, name=None: _t(np.zeros(ints(shape), _npd(dtype) or np.float32))
+    tf.ones = lambda shape, dtype=None, name=None: _t(np.ones(ints(shape), _npd(dtype) or np.float32))
+    tf.cast = lambda x, dtype, name=None: _t(A(x).astype(_npd(dtype)))
+    tf.maximum = w(lambda x, y: np.maximum(A(x), A(y)))
+    tf.scatter_nd = lambda indices, updates, shape, name=None: _scatter_nd(A(indices), A(updates), ints(shape))
+    tf.cond = lambda pred, true_fn, false_fn, name=None: (true_fn() if bool(A(pred)) else false_fn())
+
+    def pad(tensor, paddings, mode="CONSTANT", constant_values=0, name=None):
+        p = [[int(A(a)), int(A(b))] for a, b in paddings]
+        return _t(np.pad(A(tensor), p, constant_values=A(constant_values).item()))
+
+    tf.pad = pad
+
+    def band_part(input, num_lower, num_upper, name=None):  # noqa: A002
+        x = A(input)
+        n, m = x.shape[-2:]
+        i, j = np.arange(n)[:, None], np.arange(m)[None, :]
+        keep = ((num_lower < 0) | (i - j <= num_lower)) & ((num_upper < 0) | (j - i <= num_upper))
+        return _t(np.where(keep, x, np.zeros((), x.dtype)))
+
+    def set_diag(input, diagonal, name=None):  # noqa: A002
+        x = np.array(A(input), copy=True)
+        n = min(x.shape[-2:])
+        idx = np.arange(n)
+        x[..., idx, idx] = A(diagonal)
+        return _t(x)
+
+    tf.linalg = types.SimpleNamespace(band_part=band_part, set_diag=set_diag)
+
+    def seg(op, init):
+        def f(data, segment_ids, num_segments, name=None):
+            d, s, n = A(data), A(segment_ids), int(A(num_segments))
+            out = np.full((n,) + d.shape[s.ndim:], init, d.dtype)
+            op.at(out, s.reshape(-1), d.reshape((-1,) + d.shape[s.ndim:]))
+            return _t(out)
+        return f
+
+    tf.math.softplus = w(lambda features: np.logaddexp(0.0, A(features)))
+    tf.math.expm1 = w(lambda x: np.expm1(A(x)))
+    tf.math.log = w(lambda x: np.log(A(x)))
+    tf.math.unsorted_segment_max = seg(np.maximum, -np.inf)  # TF fills empty segments with the dtype's lowest value; never empty here
+    tf.math.unsorted_segment_sum = seg(np.add, 0)
+    return tf
+
+
+def _gather(params, indices, axis, batch_dims):
+    if batch_dims == 0:
+        return _t(np.take(params, indices, axis=0 if axis is None else axis))
+    # batch_dims = b: leading b dims of params / indices are paired; gather along `axis` (default = batch_dims)
+    axis = batch_dims if axis is None else axis
+    lead = params.shape[:batch_dims]
+    out = []
+    for idx in np.ndindex(*lead):
+        out.append(np.take(params[idx], indices[idx], axis=axis - batch_dims))
+    first = out[0]
+    return _t(np.stack(out).reshape(lead + first.shape))

@@ -1123,14 +1123,14 @@ class ConformerTransducer(BaseModel):
         frame_idx = torch.zeros(B, dtype=torch.int32, device=dev)
         tok_idx = torch.full((B,), -1 if mode == 1 else 1, dtype=torch.int32, device=dev)
         prev_tok = (torch.full((B,), self.blank, dtype=torch.int32, device=dev) if previous_tokens is None
-                    else previous_tokens.to(dev).to(torch.int32).reshape(B).contiguous())
+                    else previous_tokens.to(dev).to(torch.int32).reshape(B).clone())  # (updated in place by the search: never the caller's tensor)
         if previous_decoder_states is None:
             h = torch.zeros(B, P, dtype=f32, device=dev)
             cst = torch.zeros(B, P, dtype=f32, device=dev)
         else:
             st = previous_decoder_states.to(dev)
-            h = st[:, 0, 0].float().contiguous()
-            cst = st[:, 0, 1].float().contiguous()
+            h = st[:, 0, 0].float().clone()
+            cst = st[:, 0, 1].float().clone()
         per_frame = torch.zeros(max(int(elen[0]), 1), dtype=torch.int32, device=dev) if mode == 1 else None
         active = torch.ones(1, dtype=torch.int32, device=dev)
         ecur = torch.empty(B, J, dtype=f32, device=dev)
