@@ -365,6 +365,132 @@ def gen_attention_core():
     print("attention_core_reference:", {k: v.shape for k, v in out.items() if k.endswith("_out")})
 
 
+def gen_ctc_tpu():
+    """losses/impl/ctc_tpu.py: the reference's pure-TensorFlow CTC (`ctc_loss_tpu` :1295 -> classic_ctc_loss -> ClassicCtcLossData
+    :821-1290, what CtcLoss.call uses on TPU, ctc_loss.py:47-66) executed over the shim.  tf.custom_gradient is the identity in the
+    shim, so the gradient is read where the reference computes it - `ClassicCtcLossData.gradient` = dLoss/dlog-probabilities (:531-533)
+    - and chained through `logit_to_logproba` (:32-43: log-softmax) by its closed-form VJP  dlogits = g - softmax * sum_v g.
+    Quirk pinned on the way: the loss-data class reads `tf.shape(labels)[1]` as max_label_length + 1 (:442), i.e. the label matrix
+    must carry at least one padding column (the dataset pads to a global maximum, datasets.py:342-365)."""
+    import functools
+    import types
+
+    cp = types.ModuleType("cached_property")
+    cp.cached_property = functools.cached_property
+    mk = tf_shim.make_tf
+    tf_shim.make_tf = lambda: tf_shim.extend_for_ctc_tpu(mk())
+    try:
+        mod, tf = tf_shim.load_reference_module("tensorflow_asr/losses/impl/ctc_tpu.py", "tensorflow_asr.losses.impl.ctc_tpu",
+                                                extra_modules={"cached_property": cp})
+    finally:
+        tf_shim.make_tf = mk
+    cases = {
+        # name: (seed, B, T, V, U, label_len, logit_len, repeats)
+        "small": (31, 2, 6, 5, 3, [3, 2], [6, 4], True),
+        "ragged": (32, 3, 12, 9, 5, [5, 0, 2], [12, 7, 3], True),      # an empty transcript, a short utterance
+        "tight": (33, 2, 5, 6, 3, [3, 2], [5, 2], False),               # T == U: only the blank-free alignment; sample 1 needs every frame
+        "infeasible": (34, 2, 4, 6, 3, [3, 3], [4, 3], True),           # sample 0 has a repeat and T = 4 >= 3 + 1; sample 1: T = 3 with a repeat -> +inf, zero gradient
+        "wide": (35, 4, 40, 64, 12, [12, 9, 1, 6], [40, 33, 25, 40], True),
+    }
+    out = {}
+    for name, (seed, B, T, V, U, ll, tl, rep) in cases.items():
+        rng = np.random.default_rng(seed)
+        logits = (rng.standard_normal((B, T, V)) * 1.5).astype(np.float32)
+        labels = rng.integers(1, V, (B, U + 1)).astype(np.int32)
+        if rep:
+            labels[:, 2] = labels[:, 1]  # repeated label: needs a blank between the two
+        else:
+            for b in range(B):
+                labels[b, :U] = rng.permutation(np.arange(1, V))[:U]
+        ll, tl = np.asarray(ll, np.int32), np.asarray(tl, np.int32)
+        for b in range(B):
+            labels[b, ll[b]:] = 0
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            c = tf.convert_to_tensor
+            loss = np.asarray(mod.ctc_loss_tpu(labels=c(labels), logits=c(logits), label_length=c(ll), logit_length=c(tl), blank_index=0)[0], np.float32)
+            lp = mod.logit_to_logproba(logit=c(logits), axis=2)
+            data = mod.ClassicCtcLossData(labels=c(labels), logprobas=lp, label_length=c(ll), logit_length=c(tl), blank_index=0)
+            g_lp = np.asarray(data.gradient, np.float32)
+            assert np.array_equal(np.asarray(data.loss, np.float32), loss)
+        p = np.exp(np.asarray(lp, np.float64))
+        dlogits = (g_lp.astype(np.float64) - p * g_lp.astype(np.float64).sum(-1, keepdims=True)).astype(np.float32)
+        assert not np.isnan(g_lp).any()
+        for k, v in dict(logits=logits, labels=labels, label_len=ll, logit_len=tl, loss=loss, grad_logproba=g_lp, grad_logits=dlogits).items():
+            out[f"{name}_{k}"] = v
+        print(f"ctc_tpu_reference {name}: loss={loss}")
+    out["names"] = np.asarray(sorted(cases))
+    np.savez_compressed(os.path.join(OUT, "ctc_tpu_reference.npz"), **out)
+
+
+def gen_joint_callnext():
+    """models/transducer/base_transducer.py: the bodies of TransducerJointMerge.call (:199-207), TransducerJoint.call (:280-293),
+    TransducerPrediction.call_next (:134-159) and Transducer.call_next (:437-464) executed over the shim.  The Keras layers they call
+    (Dense, Embedding.call_next, LSTM, LayerNormalization, Activation) are stand-ins built from the oracle's restatement of those
+    layers on the tiny configuration's weights: what is pinned is the reference's own composition - broadcast-add merge, the layer
+    order, the [B, num_rnns, 2, P] <-> [num_rnns, 2, B, P] state transposes, log_softmax over the vocabulary."""
+    import types
+
+    import torch
+
+    from oracle import conformer_ref as R
+
+    tf = tf_shim.make_tf()
+    ns = {"tf": tf, "shape_util": _shape_util(tf)}
+    fns = tf_shim.extract_functions("tensorflow_asr/models/transducer/base_transducer.py",
+                                    ["TransducerJointMerge.call", "TransducerJoint.call", "TransducerPrediction.call_next", "Transducer.call_next"], ns)
+    ocfg = R.conformer_config("tiny")
+    W = R.init_weights(ocfg, seed=6, scale_bias=0.1)
+    P, d, V = W["pred/lstm/rk"].shape[0], ocfg["dmodel"], W["joint/vocab/w"].shape[1]
+    npw = {k: v.numpy() for k, v in W.items()}
+    dense = lambda w, b: (lambda x, training=False: tf.convert_to_tensor(np.asarray(x, np.float32) @ npw[w] + npw[b]))
+    merge_self = types.SimpleNamespace(joint_mode="add")
+    joint_self = types.SimpleNamespace(
+        prejoint_encoder_linear=True, prejoint_prediction_linear=True, postjoint_linear=False,
+        ffn_enc=dense("joint/enc/w", "joint/enc/b"), ffn_pred=dense("joint/pred/w", "joint/pred/b"), ffn_out=dense("joint/vocab/w", "joint/vocab/b"),
+        joint=lambda inputs: fns["TransducerJointMerge.call"](merge_self, inputs),
+        activation=lambda x, training=False: tf.convert_to_tensor(np.tanh(np.asarray(x, np.float32))))
+    joint = lambda inputs, training=False: fns["TransducerJoint.call"](joint_self, inputs, training=training)
+
+    def rnn(x, training=False, initial_state=None):  # keras LSTM(return_sequences=True, return_state=True) on one step: oracle cell
+        h0, c0 = (torch.from_numpy(np.asarray(s, np.float32)) for s in initial_state)
+        with torch.no_grad():
+            y, hn, cn = R.lstm(torch.from_numpy(np.asarray(x, np.float32)), None, W, "pred/lstm/", h0, c0)
+        return tf.convert_to_tensor(y.numpy()), tf.convert_to_tensor(hn.numpy()), tf.convert_to_tensor(cn.numpy())
+
+    def ln(x, training=False):
+        with torch.no_grad():
+            return tf.convert_to_tensor(R.layer_norm(torch.from_numpy(np.asarray(x, np.float32)), W["pred/ln/g"], W["pred/ln/b"]).numpy())
+
+    pred_self = types.SimpleNamespace(name="prediction", label_encoder=types.SimpleNamespace(call_next=lambda tok: tf.convert_to_tensor(npw["pred/emb"][np.asarray(tok)])),
+                                      rnns=[rnn], lns=[ln], projections=[None])
+    model_self = types.SimpleNamespace(name="transducer", joint_net=joint,
+                                       predict_net=types.SimpleNamespace(call_next=lambda tok, st: fns["TransducerPrediction.call_next"](pred_self, tok, st)))
+    rng = np.random.default_rng(61)
+    out = {"wseed": np.asarray(6)}
+    # TransducerJoint.call on a ragged-free batch
+    B, T, U1 = 2, 5, 4
+    enc = rng.standard_normal((B, T, d)).astype(np.float32)
+    pred = rng.standard_normal((B, U1, P)).astype(np.float32)
+    out["joint_enc"], out["joint_pred"] = enc, pred
+    out["joint_logits"] = np.asarray(joint([tf.convert_to_tensor(enc), tf.convert_to_tensor(pred)]), np.float32)
+    a, b = rng.standard_normal((B, T, 3)).astype(np.float32), rng.standard_normal((B, U1, 3)).astype(np.float32)
+    out["merge_a"], out["merge_b"] = a, b
+    out["merge_out"] = np.asarray(fns["TransducerJointMerge.call"](merge_self, (tf.convert_to_tensor(a), tf.convert_to_tensor(b))), np.float32)
+    # Transducer.call_next, three chained steps
+    B = 3
+    frames = rng.standard_normal((3, B, 1, d)).astype(np.float32)
+    toks = rng.integers(0, V, (3, B, 1)).astype(np.int32)
+    st = (rng.standard_normal((B, 1, 2, P)) * 0.3).astype(np.float32)
+    out["next_frames"], out["next_tokens"], out["next_state0"] = frames, toks, st
+    for i in range(3):
+        ytu, st = fns["Transducer.call_next"](model_self, tf.convert_to_tensor(frames[i]), tf.convert_to_tensor(toks[i]), tf.convert_to_tensor(st))
+        out[f"next_ytu{i}"], out[f"next_state{i + 1}"] = np.asarray(ytu, np.float32), np.asarray(st, np.float32)
+        st = np.asarray(st, np.float32)
+    np.savez_compressed(os.path.join(OUT, "joint_callnext_reference.npz"), **out)
+    print("joint_callnext_reference:", {k: v.shape for k, v in out.items() if hasattr(v, "shape") and v.ndim})
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     only = [a for a in sys.argv[1:] if a.startswith("gen_")]
@@ -374,6 +500,6 @@ if __name__ == "__main__":
         sys.exit(0)
     gen_rnnt()
     if "--all" in sys.argv or len(sys.argv) == 1:
-        for fn in ("gen_attention", "gen_posenc", "gen_greedy", "gen_specaugment", "gen_misc", "gen_attention_core"):
+        for fn in ("gen_attention", "gen_posenc", "gen_greedy", "gen_specaugment", "gen_misc", "gen_attention_core", "gen_ctc_tpu", "gen_joint_callnext"):
             if fn in globals():
                 globals()[fn]()

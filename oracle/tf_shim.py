@@ -473,7 +473,7 @@ def extend_for_ctc_tpu(tf):
     def seg(op, init):
         def f(data, segment_ids, num_segments, name=None):
             d, s, n = A(data), A(segment_ids), int(A(num_segments))
-            out = np.full((n,) + d.shape[s.ndim:], init, d.dtype)
+            out = np.full((n,) + d.shape[s.ndim:], init(d.dtype), d.dtype)
             op.at(out, s.reshape(-1), d.reshape((-1,) + d.shape[s.ndim:]))
             return _t(out)
         return f
@@ -481,8 +481,10 @@ def extend_for_ctc_tpu(tf):
     tf.math.softplus = w(lambda features: np.logaddexp(0.0, A(features)))
     tf.math.expm1 = w(lambda x: np.expm1(A(x)))
     tf.math.log = w(lambda x: np.log(A(x)))
-    tf.math.unsorted_segment_max = seg(np.maximum, -np.inf)  # TF fills empty segments with the dtype's lowest value; never empty here
-    tf.math.unsorted_segment_sum = seg(np.add, 0)
+    # TF's kernel starts every segment at numeric_limits<T>::lowest() (FINITE: -3.4e38 for f32) and reduces with max, so a segment
+    # whose data are all -inf reports lowest(), not -inf: ctc_tpu.py:109-117 relies on it (-inf - lowest() = -inf, never NaN)
+    tf.math.unsorted_segment_max = seg(np.maximum, lambda dt: np.finfo(dt).min if np.issubdtype(dt, np.floating) else np.iinfo(dt).min)
+    tf.math.unsorted_segment_sum = seg(np.add, lambda dt: 0)
     return tf
 
 

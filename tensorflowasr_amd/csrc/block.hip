@@ -648,7 +648,8 @@ int check_args(const tfasr_block_cfg* c, const tfasr_block_params* P, const tfas
   if (!c || !P || !io || !ctx) return TFASR_STATUS_INVALID_VALUE;
   if (c->B <= 0 || c->T <= 0 || c->d <= 0 || c->H <= 0 || c->dh <= 0 || c->dff <= 0 || c->ksize <= 0 || c->world <= 0) return TFASR_STATUS_INVALID_VALUE;
   if (c->dtype != TFASR_F32 && c->dtype != TFASR_BF16) return TFASR_STATUS_INVALID_VALUE;
-  if (!P->flat || !P->shadow || !P->grad || !P->bn_mm || !P->bn_mv || !P->pe) return TFASR_STATUS_INVALID_VALUE;
+  if (!P->flat || !P->shadow || !P->grad || !P->pe) return TFASR_STATUS_INVALID_VALUE;
+  if (!c->dw_norm_layer && (!P->bn_mm || !P->bn_mv)) return TFASR_STATUS_INVALID_VALUE;  // (a LayerNormalization depthwise norm has no moving statistics)
   return TFASR_STATUS_SUCCESS;
 }
 

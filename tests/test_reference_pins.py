@@ -149,3 +149,45 @@ def test_oracle_attention_core_matches_reference_body(G, case):
     for b, ln in enumerate(g[f"{case}_lens"].tolist()):
         want = np.roll(table, -(T - ln), axis=0) * (np.arange(2 * T - 1) < 2 * ln - 1)[:, None, None]
         np.testing.assert_array_equal(g[f"{case}_pos"][b], want.astype(np.float32))
+
+
+def test_oracle_ctc_matches_reference_pure_tf_ctc(G):
+    """losses/impl/ctc_tpu.py (`ctc_loss_tpu` :1295, ClassicCtcLossData :821-1290) executed over the shim: per-sample loss and the
+    gradient w.r.t. the logits.  Pins the CTC definition the oracle (torch ctc_loss + autograd) and the HIP kernel implement -
+    repeated labels, empty transcripts, T == U, and the infeasible case (+inf loss, ZERO gradient)."""
+    from oracle import ctc_ref
+
+    g = G("ctc_tpu_reference.npz")
+    for name in [str(n) for n in g["names"]]:
+        logits, labels = g[f"{name}_logits"], g[f"{name}_labels"]
+        ll, tl = g[f"{name}_label_len"], g[f"{name}_logit_len"]
+        U = labels.shape[1] - 1  # the reference's label matrix carries one padding column (ctc_tpu.py:442)
+        assert (labels[:, U] == 0).all()
+        loss, grad = ctc_ref.ctc_loss_and_grad(logits, labels[:, :U], ll, tl)
+        want, wg = g[f"{name}_loss"], g[f"{name}_grad_logits"]
+        ok = np.isfinite(want)
+        assert np.array_equal(np.isfinite(loss), ok), name
+        np.testing.assert_allclose(loss[ok], want[ok], rtol=2e-6, err_msg=name)
+        np.testing.assert_allclose(grad[ok], wg[ok], rtol=5e-4, atol=1e-5, err_msg=name)  # (the reference body runs in f32, the oracle in f64)
+        assert (wg[~ok] == 0).all()  # the reference filters samples of infinite loss out of the gradient (:546-551)
+        for b in range(len(tl)):  # nothing flows into frames beyond the logit length
+            assert (wg[b, tl[b]:] == 0).all()
+    assert not np.isfinite(g["infeasible_loss"]).all()
+
+
+def test_oracle_joint_and_call_next_match_reference_bodies(G):
+    """TransducerJointMerge.call (:199-207), TransducerJoint.call (:280-293), TransducerPrediction.call_next (:134-159) and
+    Transducer.call_next (:437-464) bodies over the shim vs the oracle's joint_net / _call_next on the same weights."""
+    g = G("joint_callnext_reference.npz")
+    W = R.init_weights(R.conformer_config("tiny"), seed=int(g["wseed"]), scale_bias=0.1)
+    np.testing.assert_array_equal(g["merge_out"], g["merge_a"][:, :, None, :] + g["merge_b"][:, None, :, :])
+    with torch.no_grad():
+        logits = R.joint_net(torch.from_numpy(g["joint_enc"]), torch.from_numpy(g["joint_pred"]), W)
+        np.testing.assert_allclose(logits.numpy(), g["joint_logits"], rtol=1e-5, atol=1e-6)
+        st = torch.from_numpy(g["next_state0"])
+        for i in range(3):
+            lsm, hn, cn = R._call_next(torch.from_numpy(g["next_frames"][i]), torch.from_numpy(g["next_tokens"][i]).long(), st[:, 0, 0], st[:, 0, 1], W)
+            np.testing.assert_allclose(lsm.numpy(), g[f"next_ytu{i}"], rtol=1e-5, atol=1e-6)
+            st = torch.stack([hn, cn], 1)[:, None]
+            np.testing.assert_allclose(st.numpy(), g[f"next_state{i + 1}"], rtol=1e-5, atol=1e-6)
+            assert abs(float(torch.logsumexp(lsm, -1).abs().max())) < 1e-5  # a log-softmax
