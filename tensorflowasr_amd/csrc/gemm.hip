@@ -280,13 +280,6 @@ int launch(const tfasr_gemm_args& a, hipStream_t stream) {
 }  // namespace
 
 int tfasr_gemm_fast_try(const tfasr_gemm_args& a, hipStream_t stream);  // gemm_fast.hip (2-stage BK=64, one tile per workgroup)
-int tfasr_gemm_pipe_try(const tfasr_gemm_args& a, hipStream_t stream);  // gemm_pipe.hip (persistent 4-stage BK=32; opt-in: TFASR_GEMM_PIPE=1)
-
-static bool use_pipe_path() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("TFASR_GEMM_PIPE"); v = (e && e[0] == '1') ? 1 : 0; }
-  return v == 1;
-}
 
 static bool use_fast_path() {
   static int v = -1;
@@ -331,7 +324,7 @@ extern "C" int tfasr_gemm(const tfasr_gemm_args* args, void* stream_) {
   if (a.colsum && !(a.accumulate && a.trans_a && !a.trans_b && a.nb1 * a.nb2 == 1)) return TFASR_STATUS_INVALID_VALUE;
   hipStream_t stream = (hipStream_t)stream_;
   if (a.dtype == TFASR_BF16 && use_fast_path()) {
-    const int st = (use_pipe_path() && !a.lse_part && !a.seg_a_off) ? tfasr_gemm_pipe_try(a, stream) : tfasr_gemm_fast_try(a, stream);
+    const int st = tfasr_gemm_fast_try(a, stream);
     if (st != TFASR_STATUS_UNSUPPORTED) return st;
   }
   if (a.lse_part) return TFASR_STATUS_UNSUPPORTED;  // only the bf16 fast path's epilogue produces the row statistics
