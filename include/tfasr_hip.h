@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define TFASR_ABI_VERSION 16
+#define TFASR_ABI_VERSION 17
 
 typedef enum {
   TFASR_STATUS_SUCCESS = 0,
@@ -470,9 +470,11 @@ typedef struct {
   int site0;                        /* first dropout site id of this block */
   long drop_epoch;                  /* bumped once per forward pass: seed = drop_epoch*8192 + site */
   float drop_p, ffm_res, mhsa_res, conv_res, ln_eps, bn_eps, bn_momentum;
-  int chunk_size, history_size;     /* streaming attention mask (chunk_size <= 0: off): unfused attention kernels only */
+  int chunk_size, history_size;     /* streaming attention mask (chunk_size <= 0: off; history_size < 0: unlimited) */
   int dw_norm_layer;                /* 1: LayerNormalization after the depthwise conv (encoder_convm_dw_norm_type "layer",
                                        encoders/conformer.py:334-340) in the CV_BN_G/B parameter slots; no batch statistics */
+  int dh_logical;                   /* the reference's head size (softmax scale 1 / sqrt(dh_logical), multihead_attention.py:554-558) when
+                                       `dh` is a zero-padded physical head dimension (e.g. 36 stored as 64); <= 0: = dh */
 } tfasr_block_cfg;
 
 typedef struct {

@@ -53,7 +53,7 @@ class BlockCfg(Structure):
         ("site0", c_int), ("drop_epoch", c_long),
         ("drop_p", c_float), ("ffm_res", c_float), ("mhsa_res", c_float), ("conv_res", c_float), ("ln_eps", c_float), ("bn_eps", c_float),
         ("bn_momentum", c_float),
-        ("chunk_size", c_int), ("history_size", c_int), ("dw_norm_layer", c_int),
+        ("chunk_size", c_int), ("history_size", c_int), ("dw_norm_layer", c_int), ("dh_logical", c_int),
     ]
 
 
@@ -149,7 +149,7 @@ def load(build_if_missing=True):
     return lib
 
 
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 
 STATUS_UNSUPPORTED = 3

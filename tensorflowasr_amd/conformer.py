@@ -56,7 +56,11 @@ class ConformerTransducer(BaseModel):
         self.cfg = cfg
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self.dtype = dtype
-        self.ps = ParamStore(cfg, self.device, dtype, seed)
+        # bf16 models store attention heads narrower than 64 zero-padded to 64 (ParamStore.__init__): the reference's shipped head sizes
+        # (36, 44) then run on the fused LDS-staged attention kernels, results unchanged
+        pad = (dtype == torch.bfloat16 and cfg.head_size < 64 and getattr(cfg, "encoder", "conformer") == "conformer"
+               and os.environ.get("TFASR_HEAD_PAD", "1") != "0")
+        self.ps = ParamStore(cfg, self.device, dtype, seed, head_phys=64 if pad else None)
         self.dp = dp or SingleProcess()
         self.blank = cfg.blank
         self.time_reduction_factor = cfg.time_reduction_factor
@@ -444,10 +448,10 @@ class ConformerTransducer(BaseModel):
 
     def _mhsa_fwd(self, x, pfx, B, T, elen_dev, ctx, site, training):
         ps, c = self.ps, self.cfg
-        H, dh = c.num_heads, c.head_size
+        H, dh = c.num_heads, ps.head_phys
         HD = H * dh
         R1 = 2 * T
-        scale = 1.0 / math.sqrt(dh)
+        scale = 1.0 / math.sqrt(c.head_size)
         ln, mean, rstd = K.layernorm_fwd(x, ps.p(pfx + "ln/g"), ps.p(pfx + "ln/b"))
         qkv = K.matmul(ln, ps.w2d(pfx + "qkv/w"), bias=ps.p(pfx + "qkv/b"))  # [B*T, 3HD]
         pe = self._pe_ext(T)
@@ -471,10 +475,10 @@ class ConformerTransducer(BaseModel):
         qkv [B*T, 3*H*dh] and the projected position table pext [2T, H*dh] (rows 0..2T-2 = positions T-1..-(T-1), row 2T-1 = the
         projection of a zeroed encoding row).  Returns (context [B*T, H*dh], tensors the backward needs)."""
         ps, c = self.ps, self.cfg
-        H, dh = c.num_heads, c.head_size
+        H, dh = c.num_heads, ps.head_phys
         HD = H * dh
         R1 = 2 * T
-        scale = 1.0 / math.sqrt(dh)
+        scale = 1.0 / math.sqrt(c.head_size)
         ub, vb = self._uv(pfx) if pfx is not None else (ps.p("enc/u"), ps.p("enc/v"))
         if self._fused_attention():
             # flash-style kernel: scores, shift, mask, softmax and P@V never leave the CU (csrc/attn_fused.hip)
@@ -499,10 +503,10 @@ class ConformerTransducer(BaseModel):
 
     def _mhsa_bwd(self, dy, pfx, B, T, elen_dev, ctx):
         ps, c = self.ps, self.cfg
-        H, dh = c.num_heads, c.head_size
+        H, dh = c.num_heads, ps.head_phys
         HD = H * dh
         R1 = 2 * T
-        scale = 1.0 / math.sqrt(dh)
+        scale = 1.0 / math.sqrt(c.head_size)
         s = ctx.pop(pfx)
         qkv = s["qkv"]
         ub, vb = self._uv(pfx)
@@ -547,14 +551,14 @@ class ConformerTransducer(BaseModel):
 
     def _fused_attention(self):
         # the streaming (chunked) mask lives in the unfused softmax kernel only (the reference's streaming model is Conformer-S, head 36)
-        return (self.dtype == torch.bfloat16 and self.cfg.head_size == 64 and not self.cfg.chunk_size
+        return (self.dtype == torch.bfloat16 and self.ps.head_phys == 64 and not self.cfg.chunk_size
                 and os.environ.get("TFASR_ATTN_UNFUSED", "0") != "1")
 
     def _mhsa_bwd_tail(self, dy, pfx, B, T, s, dqkv, dqu, dpos, qv, R1p, scale, dqv=None, dpext=None):
         """dpos [B,H,T,R1p] (gradient of the un-shifted position scores) -> dqv, dpext, bias and projection gradients
         (dqv / dpext already formed by the fused V2 kernels when given)."""
         ps, c = self.ps, self.cfg
-        H, dh = c.num_heads, c.head_size
+        H, dh = c.num_heads, ps.head_phys
         HD = H * dh
         R1 = 2 * T
         if dqv is None:
@@ -656,7 +660,8 @@ class ConformerTransducer(BaseModel):
     def _native_cfg(self, i, B, T, training, save):
         c = self.cfg
         k = K._lib.BlockCfg()
-        k.B, k.T, k.d, k.H, k.dh, k.dff, k.ksize = B, T, c.dmodel, c.num_heads, c.head_size, self.ps.shapes["enc/block0/ff1/d1/w"][1], c.kernel_size
+        k.B, k.T, k.d, k.H, k.dh, k.dff, k.ksize = B, T, c.dmodel, c.num_heads, self.ps.head_phys, self.ps.shapes["enc/block0/ff1/d1/w"][1], c.kernel_size
+        k.dh_logical = c.head_size  # softmax scale 1 / sqrt(head_size); dh is the stored (possibly zero-padded) head dimension
         k.dtype = K._dt(self.ps.shadow)
         k.training, k.save, k.use_mask = int(training), int(save), int(c.use_attention_auto_mask)
         k.force_unfused = int(not self._fused_attention())
@@ -773,7 +778,7 @@ class ConformerTransducer(BaseModel):
             c = self.cfg
             self._zero_pool["fwd"] = torch.zeros(c.num_blocks, -(-(2 * c.dmodel + 1) // 64) * 64, dtype=torch.float32, device=self.device)
             if ctx is not None:
-                self._zero_pool["bwd_shape"] = (c.num_blocks, -(-2 * c.dmodel // 64) * 64 + -(-2 * T * c.num_heads * c.head_size // 64) * 64)
+                self._zero_pool["bwd_shape"] = (c.num_blocks, -(-2 * c.dmodel // 64) * 64 + -(-2 * T * c.num_heads * self.ps.head_phys // 64) * 64)
         for i in range(self.cfg.num_blocks):
             x = self._block_fwd_native(x, i, B, T, elen_dev, training, ctx) if native else self._block_fwd(x, i, B, T, elen_dev, training, ctx)
         if ctx is not None:

@@ -302,7 +302,7 @@ struct Ex {
   // ------------------------------------------------------------------------------------------ MHSAModule
   void mhsa_fwd(const void* x, void* y, int site) {
     const int d = c->d, H = c->H, dh = c->dh, HD = H * dh, T = c->T, B = c->B, R1 = 2 * T;
-    const float scale = 1.f / sqrtf((float)dh);
+    const float scale = 1.f / sqrtf((float)(c->dh_logical > 0 ? c->dh_logical : dh));
     k->at_x = (void*)x;
     k->at_ln = act(stash, rows * d);
     k->at_mean = f32(stash, rows);
@@ -355,7 +355,7 @@ struct Ex {
   void mhsa_bwd(const void* dy, const void* dy_dropped, void* dx, void* dxd, int site, int next_site) {
     const int d = c->d, H = c->H, dh = c->dh, HD = H * dh, T = c->T, B = c->B, R1 = 2 * T;
     const int Tp = (T + 7) / 8 * 8, R1p = (R1 + 7) / 8 * 8;
-    const float scale = 1.f / sqrtf((float)dh);
+    const float scale = 1.f / sqrtf((float)(c->dh_logical > 0 ? c->dh_logical : dh));
     const size_t mark = scratch.off;
     const void* dyd = masked(dy, dy_dropped, rows * d, site);
     void* datt = act(scratch, rows * HD);

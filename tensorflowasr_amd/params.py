@@ -18,12 +18,18 @@ import torch
 from . import kernels as K
 
 
-def param_specs(cfg):
-    """[(name, shape, regularized, init)] in forward order. init in {glorot, zeros, ones, embed, orth, lstm_bias}."""
+def head_padded(name):
+    """variables that carry the attention head dimension (physically padded to 64 in bf16 models, see ParamStore)"""
+    return name.endswith(("mhsa/qkv/w", "mhsa/qkv/b", "mhsa/pos/w", "mhsa/pos/b", "mhsa/o/w", "mhsa/u", "mhsa/v")) or name in ("enc/u", "enc/v")
+
+
+def param_specs(cfg, head_phys=None):
+    """[(name, shape, regularized, init)] in forward order. init in {glorot, zeros, ones, embed, orth, lstm_bias}.
+    head_phys: physical (stored) head dimension of the attention variables, >= cfg.head_size (ParamStore: zero padding)."""
     d, H, dh, C = cfg.dmodel, cfg.num_heads, cfg.head_size, cfg.filters
     Kk, V, E, P, J = cfg.kernel_size, cfg.vocab_size, cfg.embed_dim, cfg.rnn_units, cfg.joint_dim
     F2 = -(-(-(-cfg.num_feature_bins // 2)) // 2)
-    HD = H * dh
+    HD = H * (head_phys or dh)
     s = []
 
     def add(name, shape, reg, init, fans=None):
@@ -137,9 +143,19 @@ def bn_names(cfg):
 class ParamStore:
     ALIGN = 64  # elements; keeps every variable 256-B aligned in f32 and 128-B aligned in bf16
 
-    def __init__(self, cfg, device, dtype, seed=0):
+    def __init__(self, cfg, device, dtype, seed=0, head_phys=None):
+        """head_phys: PHYSICAL head dimension of the attention variables (q/k/v/position projections, output projection rows, u / v
+        biases).  A bf16 model whose heads are narrower than the fused attention kernels' 64 (the reference ships head 36 and 44:
+        small.yml.j2:39, ctc/conformer/small.yml.j2:39) stores those variables zero-padded to 64 per head: the padded q / k / v /
+        position columns are exactly zero, so every score, probability and context value is unchanged, the padded context columns are
+        zero, and every gradient into a padded element is exactly zero (dq_pad = dS k_pad = 0, dk_pad = dS^T q_pad = 0,
+        dv_pad = P^T (dy Wo_pad^T) = 0), so Adam / L2 / weight decay leave the padding at zero forever.  import_keras / export_keras
+        speak the reference's (unpadded) layouts; the softmax scale stays 1 / sqrt(cfg.head_size)."""
         self.cfg, self.device, self.dtype = cfg, device, dtype
-        specs = param_specs(cfg)
+        self.head_phys = int(head_phys or cfg.head_size)
+        if self.head_phys < cfg.head_size:
+            raise ValueError("head_phys must be >= head_size")
+        specs = param_specs(cfg, self.head_phys)
         ordered = [x for x in specs if x[2]] + [x for x in specs if not x[2]]
         self.offsets, self.shapes = {}, {}
         off = 0
@@ -207,19 +223,78 @@ class ParamStore:
     def g2d(self, name):
         return self._view(self.grad, name, True)
 
+    # ------------------------------------------------------------------ head padding
+    def _head_view(self, t, name, dh):
+        """view of a head-carrying variable with the head axis split as [..., H, dh, ...] (dh = physical or logical)"""
+        H, d = self.cfg.num_heads, self.cfg.dmodel
+        if name.endswith("qkv/w"):
+            return t.reshape(d, 3, H, dh)
+        if name.endswith("qkv/b"):
+            return t.reshape(3, H, dh)
+        if name.endswith("pos/w"):
+            return t.reshape(d, H, dh)
+        if name.endswith("o/w"):
+            return t.reshape(H, dh, d)
+        return t.reshape(H, dh)  # pos/b, u, v
+
+    def _pad_heads(self, name, t):
+        """logical layout (head dim cfg.head_size) -> stored layout (head dim head_phys, zero padded)"""
+        dh, dp = self.cfg.head_size, self.head_phys
+        if dp == dh or not head_padded(name):
+            return t
+        v = self._head_view(t, name, dh)
+        ax = 1 if name.endswith("o/w") else v.dim() - 1
+        shp = list(v.shape)
+        shp[ax] = dp
+        out = torch.zeros(shp, dtype=v.dtype, device=v.device)
+        out.narrow(ax, 0, dh).copy_(v)
+        return out.reshape(self.shapes[name])
+
+    def _unpad_heads(self, name, t):
+        dh, dp = self.cfg.head_size, self.head_phys
+        if dp == dh or not head_padded(name):
+            return t
+        v = self._head_view(t, name, dp)
+        ax = 1 if name.endswith("o/w") else v.dim() - 1
+        v = v.narrow(ax, 0, dh).contiguous()
+        if name.endswith("qkv/w"):
+            return v.reshape(self.cfg.dmodel, -1)
+        if name.endswith("pos/w"):
+            return v.reshape(self.cfg.dmodel, -1)
+        if name.endswith("o/w"):
+            return v.reshape(-1, self.cfg.dmodel)
+        return v.reshape(-1)
+
+    def rezero_head_pads(self, buf=None):
+        """restore the zero padding of `buf` (default: the master parameters) after something wrote whole-buffer noise into it"""
+        dh, dp = self.cfg.head_size, self.head_phys
+        if dp == dh:
+            return
+        buf = self.flat if buf is None else buf
+        for name in self.names:
+            if head_padded(name):
+                v = self._head_view(self._view(buf, name), name, dp)
+                v.narrow(1 if name.endswith("o/w") else v.dim() - 1, dh, dp - dh).zero_()
+
     def refresh_shadow(self):
         if self.shadow is not self.flat:
             K.cast(self.flat, self.shadow)
 
     def num_trainable(self):
+        """number of trainable variables' elements in the REFERENCE's layouts (the zero padding of the heads is not a parameter)"""
+        if self.head_phys != self.cfg.head_size:
+            return sum(int(np.prod(x[1])) for x in param_specs(self.cfg))
         return sum(int(np.prod(s)) for s in self.shapes.values())
 
     # ------------------------------------------------------------------ init (Keras defaults, SURVEY.md A.1)
     def _init(self, ordered, seed):
         rng = np.random.default_rng(seed)
         host = np.zeros(self.n, np.float32)
+        logical = {x[0]: x[1] for x in param_specs(self.cfg)} if self.head_phys != self.cfg.head_size else {}
         for name, shape, reg, init, fans in ordered:
             n = int(np.prod(shape))
+            stored = shape
+            shape = logical.get(name, shape)  # the draws are those of the unpadded model (same seed -> same weights), padded afterwards
             if init == "zeros":
                 w = np.zeros(shape, np.float32)
             elif init == "ones":
@@ -238,6 +313,8 @@ class ParamStore:
                 fi, fo = fans if fans else (shape[0], shape[-1])
                 lim = math.sqrt(6.0 / (fi + fo))
                 w = rng.uniform(-lim, lim, shape).astype(np.float32)
+            if shape != stored:
+                w = self._pad_heads(name, torch.from_numpy(w)).numpy()
             host[self.offsets[name]:self.offsets[name] + n] = w.reshape(-1)
         self.flat.copy_(torch.from_numpy(host))
 
@@ -248,7 +325,7 @@ class ParamStore:
         host = self.flat.cpu().clone()
 
         def put(name, t):
-            t = torch.as_tensor(t).detach().float().reshape(-1)
+            t = self._pad_heads(name, torch.as_tensor(t).detach().float().cpu()).reshape(-1)
             o = self.offsets[name]
             assert t.numel() == int(np.prod(self.shapes[name])), name
             host[o:o + t.numel()] = t
@@ -274,7 +351,7 @@ class ParamStore:
         buf = self.flat if buf is None else buf
         out = {}
         for name in self.names:
-            t = self._view(buf, name).detach().float().cpu()
+            t = self._unpad_heads(name, self._view(buf, name).detach().float().cpu())
             if name.endswith("qkv/w"):
                 base = name[:-len("qkv/w")]
                 for i, k in enumerate(("q", "k", "v")):

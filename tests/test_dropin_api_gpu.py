@@ -142,3 +142,57 @@ def test_other_shipped_configs_build_compile_and_step(dev, key, cls):
     if out is not None:
         assert list(out.logits.shape) == shapes.logits
     assert np.isfinite(model.test_step(data)["loss"].cpu().numpy()).all()
+
+
+def test_head_padding_is_invisible(dev, monkeypatch):
+    """bf16 models store attention heads narrower than 64 zero-padded to 64 so that the shipped head sizes (36 / 44) run on the fused
+    attention kernels (ParamStore.__init__).  Against the same model stored unpadded (unfused path): identical reference-layout weights
+    from the same seed, same loss and gradients within bf16 noise, padding exactly zero after training steps with weight / gradient
+    noise, reference-layout export shapes."""
+    from tensorflowasr_amd import configs
+    from tensorflowasr_amd.conformer import ConformerTransducer
+
+    cfg = configs.conformer_tiny(head_size=12, num_heads=2, dmodel=32, dropout=0.0, time_masking={}, freq_masking={})
+    padded = ConformerTransducer(cfg, dev, dtype=torch.bfloat16, seed=3)
+    monkeypatch.setenv("TFASR_HEAD_PAD", "0")
+    plain = ConformerTransducer(cfg, dev, dtype=torch.bfloat16, seed=3)
+    monkeypatch.delenv("TFASR_HEAD_PAD")
+    assert padded.ps.head_phys == 64 and plain.ps.head_phys == 12 and padded._fused_attention() and not plain._fused_attention()
+    assert padded.ps.num_trainable() == plain.ps.num_trainable() and padded.ps.n > plain.ps.n
+    a, b = padded.ps.export_keras(), plain.ps.export_keras()
+    assert set(a) == set(b)
+    for k in a:
+        assert a[k].shape == b[k].shape and torch.equal(a[k], b[k]), k
+    assert a["enc/block0/mhsa/q/w"].shape == (32, 2, 12) and a["enc/block0/mhsa/o/w"].shape == (2, 12, 32) and a["enc/u"].shape == (2, 12)
+    # non-trivial u / v so that the padded bias columns matter if they leak
+    W = dict(a)
+    g = torch.Generator().manual_seed(0)
+    W["enc/u"], W["enc/v"] = torch.randn(2, 12, generator=g) * 0.3, torch.randn(2, 12, generator=g) * 0.3
+    padded.ps.import_keras(W)
+    plain.ps.import_keras(W)
+    data = _data(cfg.vocab_size, B=3, N=24000, U=5)
+    for m in (padded, plain):
+        m.zero_grad()
+    la = padded.loss_and_backward(data, True, (None, None)).cpu().numpy()
+    lb = plain.loss_and_backward(data, True, (None, None)).cpu().numpy()
+    np.testing.assert_allclose(la, lb, rtol=5e-3)
+    ga, gb = padded.ps.export_keras(padded.ps.grad), plain.ps.export_keras(plain.ps.grad)
+    num = sum(float((ga[k].double() - gb[k].double()).pow(2).sum()) for k in ga)
+    den = sum(float(gb[k].double().pow(2).sum()) for k in gb)
+    assert (num / den) ** 0.5 < 5e-2
+    # gradients into the padding are exactly zero, and stay zero through noisy training steps
+    def pads(ps, buf):
+        out = []
+        for name in ps.names:
+            from tensorflowasr_amd.params import head_padded
+            if head_padded(name):
+                v = ps._head_view(ps._view(buf, name), name, ps.head_phys)
+                out.append(v.narrow(1 if name.endswith("o/w") else v.dim() - 1, 12, 52))
+        return out
+    assert all(float(p.abs().max()) == 0.0 for p in pads(padded.ps, padded.ps.grad))
+    padded.compile(optimizer={"class_name": "Adam", "config": {"learning_rate": 1e-2}}, gwn_config={"encoder_step": 0, "encoder_stddev": 0.05},
+                   gradn_config={"step": 0, "stddev": 1e-3})
+    for _ in range(3):
+        padded.train_step(data)
+    assert all(float(p.abs().max()) == 0.0 for p in pads(padded.ps, padded.ps.flat))
+    assert all(float(p.abs().max()) == 0.0 for p in pads(padded.ps, padded.ps.adam_v))
