@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define TFASR_ABI_VERSION 17
+#define TFASR_ABI_VERSION 18
 
 typedef enum {
   TFASR_STATUS_SUCCESS = 0,
@@ -277,10 +277,14 @@ int tfasr_relattn_softmax_fwd_streaming(const void* content, const void* pos, co
 
 /* Fused (flash-style) forward of the same attention: nothing of size T x T is written.  qkv [B*T, 3*H*dh] (fused
  * projection output, q|k|v column blocks), ubias/vbias [H*dh] f32 (content / positional biases), pext [2T, H*dh]
- * (projected relative table + bias row), out [B*T, H*dh], lse [B,H,T] f32.  bf16, dh == 64 only (else UNSUPPORTED). */
+ * (projected relative table + bias row), out [B*T, H*dh], lse [B,H,T] f32.  bf16, dh == 64 only (else UNSUPPORTED; narrower heads are
+ * stored zero-padded to 64 by the caller, scale = 1 / sqrt(reference head size)).
+ * chunk / hist: streaming attention mask (compute_streaming_mask, multihead_attention.py:104-143,331-345): query i sees keys
+ * [max(0, c - hist), min(T, c + chunk)) with c = floor(i / chunk) * chunk; chunk <= 0: off; hist < 0: unlimited history.  Key blocks
+ * outside every window of a query block are skipped.  The same pair of arguments on the backward entry points below. */
 int tfasr_relattn_fused_fwd(const void* qkv, const float* ubias, const float* vbias, const void* pext,
                             const int32_t* lengths, void* out, float* lse, int B, int H, int T, int dh, float scale,
-                            int use_mask, int dtype, void* stream);
+                            int use_mask, int chunk, int hist, int dtype, void* stream);
 
 /* Fused backward, query side: recomputes the probabilities from lse, returns dqu [B*T, H*dh] = d/d(q+u) and the skewed
  * score gradient dpos [B,H,T,ldp] (same meaning as tfasr_relattn_softmax_bwd's dpos, fully written); o/dout [B*T, H*dh]. */
@@ -294,21 +298,21 @@ int tfasr_relattn_fused_bwd_q(const void* qkv, const float* ubias, const float* 
  * and qv = q + v ([B*T, H*dh], tfasr_bias2_fwd): one f32 atomic per (table row, column, sample group). */
 int tfasr_relattn_fused_bwd_q2(const void* qkv, const float* ubias, const float* vbias, const void* pext,
                                const int32_t* lengths, const void* o, const void* dout, const float* lse, void* dqu, void* dqv, void* ds,
-                               float* dvec, float* dpext, int B, int H, int T, int dh, int lds, float scale, int use_mask, int dtype,
-                               void* stream);
+                               float* dvec, float* dpext, int B, int H, int T, int dh, int lds, float scale, int use_mask, int chunk, int hist,
+                               int dtype, void* stream);
 /* _q2 with the query gradient finished in the kernel: dq (row stride lddq, e.g. the q columns of the fused [B*T, 3*H*dh] gradient)
  * = dqu + dqv, du [H*dh] += column sums of dqu, dv += column sums of dqv (what tfasr_bias2_bwd does in a separate pass) */
 int tfasr_relattn_fused_bwd_q3(const void* qkv, const float* ubias, const float* vbias, const void* pext, const int32_t* lengths,
                                const void* o, const void* dout, const float* lse, void* dq, long lddq, float* du, float* dv, void* ds,
-                               float* dvec, float* dpext, int B, int H, int T, int dh, int lds, float scale, int use_mask, int dtype,
-                               void* stream);
+                               float* dvec, float* dpext, int B, int H, int T, int dh, int lds, float scale, int use_mask, int chunk, int hist,
+                               int dtype, void* stream);
 int tfasr_relattn_dpext(const void* ds, const void* qv, const int32_t* lengths, float* dpext, int B, int H, int T, int dh, int lds,
                         int use_mask, int dtype, void* stream);
 /* Fused backward, key side (run after _bwd_q, which also emits dvec [B,H,T] = rowsum(dout*o)): writes the k and v column
  * blocks of dqkv [B*T, 3*H*dh]; qu/qv [B*T, H*dh] = q+u / q+v (tfasr_bias2_fwd). */
 int tfasr_relattn_fused_bwd_k(const void* qkv, const void* qu, const void* qv, const void* pext, const int32_t* lengths,
                               const void* dout, const float* lse, const float* dvec, void* dqkv, int B, int H, int T, int dh,
-                              float scale, int use_mask, int dtype, void* stream);
+                              float scale, int use_mask, int chunk, int hist, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * LSTM cell pointwise stages (keras LSTM, gates i,f,c,o; base_transducer.py:71-85,123-159)

@@ -149,7 +149,7 @@ def load(build_if_missing=True):
     return lib
 
 
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 
 STATUS_UNSUPPORTED = 3

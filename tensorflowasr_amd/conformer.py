@@ -483,7 +483,7 @@ class ConformerTransducer(BaseModel):
         if self._fused_attention():
             # flash-style kernel: scores, shift, mask, softmax and P@V never leave the CU (csrc/attn_fused.hip)
             att, lse = K.relattn_fused_fwd(qkv, ub, vb, pext, elen_dev, B, H, T, dh, scale,
-                                           use_mask=c.use_attention_auto_mask)
+                                           use_mask=c.use_attention_auto_mask, chunk_size=c.chunk_size, history_size=c.history_size)
             return att, dict(lse=lse)
         qu, qv = K.bias2_fwd(qkv, 3 * HD, ub, vb, B * T, HD)
         kk = qkv[:, HD:]
@@ -515,14 +515,15 @@ class ConformerTransducer(BaseModel):
         if "lse" in s:
             R1p = -(-R1 // 8) * 8
             um = c.use_attention_auto_mask
-            if os.environ.get("TFASR_ATTN_DPOS", "0") != "1":
+            if os.environ.get("TFASR_ATTN_DPOS", "0") != "1" or c.chunk_size:
                 # default: no skewed score gradient in HBM (attn_fused.hip V2) - dqv comes out of the query-side kernel, dpext is
                 # accumulated from the unskewed dS by tfasr_relattn_dpext
                 dpext = torch.zeros(R1, HD, dtype=torch.float32, device=self.device)
+                win = dict(chunk_size=c.chunk_size, history_size=c.history_size)
                 dqu, dqv, ds, dvec = K.relattn_fused_bwd_q2(qkv, ub, vb, s["pext"], elen_dev, s["att"], datt, s["lse"], dpext, B, H, T, dh, scale,
-                                                            use_mask=um)
+                                                            use_mask=um, **win)
                 qu, qv = K.bias2_fwd(qkv, 3 * HD, ub, vb, B * T, HD)
-                K.relattn_fused_bwd_k(qkv, qu, qv, s["pext"], elen_dev, datt, s["lse"], dvec, dqkv, B, H, T, dh, scale, use_mask=um)
+                K.relattn_fused_bwd_k(qkv, qu, qv, s["pext"], elen_dev, datt, s["lse"], dvec, dqkv, B, H, T, dh, scale, use_mask=um, **win)
                 K.relattn_dpext(ds, qv, elen_dev, dpext, B, H, T, dh, use_mask=um)
                 return self._mhsa_bwd_tail(dy, pfx, B, T, s, dqkv, dqu, None, qv, R1p, 1.0, dqv=dqv, dpext=dpext)
             dqu, dpos, dvec = K.relattn_fused_bwd_q(qkv, ub, vb, s["pext"], elen_dev, s["att"], datt, s["lse"], B, H, T, dh,
@@ -550,9 +551,9 @@ class ConformerTransducer(BaseModel):
         return self._mhsa_bwd_tail(dy, pfx, B, T, s, dqkv, dqu, dpos, s["qv"], R1p, scale)
 
     def _fused_attention(self):
-        # the streaming (chunked) mask lives in the unfused softmax kernel only (the reference's streaming model is Conformer-S, head 36)
-        return (self.dtype == torch.bfloat16 and self.ps.head_phys == 64 and not self.cfg.chunk_size
-                and os.environ.get("TFASR_ATTN_UNFUSED", "0") != "1")
+        # bf16 with a physical head dimension of 64 (narrower reference heads are stored zero-padded); the streaming (chunked) mask is
+        # handled inside the fused kernels
+        return (self.dtype == torch.bfloat16 and self.ps.head_phys == 64 and os.environ.get("TFASR_ATTN_UNFUSED", "0") != "1")
 
     def _mhsa_bwd_tail(self, dy, pfx, B, T, s, dqkv, dqu, dpos, qv, R1p, scale, dqv=None, dpext=None):
         """dpos [B,H,T,R1p] (gradient of the un-shifted position scores) -> dqv, dpext, bias and projection gradients
@@ -672,7 +673,7 @@ class ConformerTransducer(BaseModel):
         k.ffm_res, k.mhsa_res, k.conv_res = c.ffm_residual, c.mhsam_residual, c.convm_residual
         k.ln_eps, k.bn_eps, k.bn_momentum = 1e-3, 1e-3, 0.99
         k.chunk_size = int(c.chunk_size) if c.chunk_size else 0
-        k.history_size = int(c.history_size) if c.history_size is not None else 0
+        k.history_size = int(c.history_size) if c.history_size is not None else -1
         k.dw_norm_layer = int(c.convm_dw_norm == "layer")
         return k
 

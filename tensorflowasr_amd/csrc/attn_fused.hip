@@ -101,10 +101,19 @@ __device__ __forceinline__ short8_t q_frag(const bf16_t* qrow, const float* bias
   return f;
 }
 
+// streaming window of query i (compute_streaming_mask, multihead_attention.py:104-143): keys [lo, hi) are visible; outside it the
+// reference's score is -1e9 = probability exactly 0.  chunk <= 0: the whole utterance.  hist < 0: unlimited history.
+__device__ __forceinline__ void stream_window(int i, int T, int chunk, int hist, int& lo, int& hi) {
+  const int index = (i / chunk) * chunk;
+  lo = hist < 0 ? 0 : max(0, index - hist);
+  hi = min(T, index + chunk);
+}
+
+template <bool STREAM>
 __global__ __launch_bounds__(256, 3) void relattn_fused_fwd_kernel(
     const bf16_t* __restrict__ qkv, const float* __restrict__ ubias, const float* __restrict__ vbias,
     const bf16_t* __restrict__ pext, const int32_t* __restrict__ lengths, bf16_t* __restrict__ out, float* __restrict__ lse_out,
-    int B, int H, int T, float scale, int use_mask) {
+    int B, int H, int T, float scale, int use_mask, int chunk, int hist) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sK = smem;
   char* sV = sK + SK_BYTES;
@@ -142,6 +151,7 @@ __global__ __launch_bounds__(256, 3) void relattn_fused_fwd_kernel(
   const float scale2 = scale * 1.4426950408889634f;  // scores in log2 units
   const int lim = 2 * len - 1;
   int rr0[4], goff[4], poff[4][4];
+  int wlo[4], whi[4];
   bool qm[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
@@ -149,6 +159,8 @@ __global__ __launch_bounds__(256, 3) void relattn_fused_fwd_kernel(
     rr0[e] = T - 1 - i + r;                       // + jt*16 + j0 = relative-position row of key j
     goff[e] = il * GLDC + (15 - il + r);          // + jt*16 = skewed column of the window scores, relative to the strip's first column
     qm[e] = use_mask && (i >= len);
+    wlo[e] = 0; whi[e] = T;
+    if constexpr (STREAM) { if (!qm[e]) stream_window(min(i, T - 1), T, chunk, hist, wlo[e], whi[e]); }
 #pragma unroll
     for (int jt = 0; jt < 4; ++jt) {
       const int jl = jt * 16 + r;
@@ -162,7 +174,18 @@ __global__ __launch_bounds__(256, 3) void relattn_fused_fwd_kernel(
 #define ATT_TICK(k)
 #endif
   const int njb = (T + BJ - 1) / BJ;
-  for (int jb = 0; jb < njb; ++jb) {
+  int jb_lo = 0, jb_hi = njb;
+  if constexpr (STREAM) {
+    // key blocks no query row of this block can see are skipped - unless the block holds a padded query row (uniform over ALL keys)
+    if (!(use_mask && i0 + BI > len)) {
+      int lo, hi, lo2, hi2;
+      stream_window(i0, T, chunk, hist, lo, hi);
+      stream_window(min(i0 + BI - 1, T - 1), T, chunk, hist, lo2, hi2);
+      jb_lo = lo / BJ;
+      jb_hi = (hi2 + BJ - 1) / BJ;
+    }
+  }
+  for (int jb = jb_lo; jb < jb_hi; ++jb) {
     const int j0 = jb * BJ;
     const int pw0 = (T - 1 - (i0 + BI - 1) + j0) + shift;  // pext row of window column 0
 #ifdef TFASR_ATTN_TIMING
@@ -227,6 +250,7 @@ __global__ __launch_bounds__(256, 3) void relattn_fused_fwd_kernel(
         float s2 = (acc_s[jt][e] + pos) * scale2;
         if (qm[e]) s2 = 0.f;
         if (ragged && j0 + jt * 16 + r >= T) s2 = -INFINITY;
+        if constexpr (STREAM) { const int j = j0 + jt * 16 + r; if (j < wlo[e] || j >= whi[e]) s2 = -INFINITY; }
         acc_s[jt][e] = s2;
         mx = fmaxf(mx, s2);
       }
@@ -238,12 +262,14 @@ __global__ __launch_bounds__(256, 3) void relattn_fused_fwd_kernel(
     // online softmax update + P (bf16) into the per-wave A-operand image
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const float m_new = fmaxf(m_run[e], rmax[e]);
-      const float corr = __builtin_amdgcn_exp2f(m_run[e] - m_new);  // exp2(-inf) = 0 on the first block
+      float m_new = fmaxf(m_run[e], rmax[e]);
+      // streaming: a row may meet a key block that lies entirely outside its window before any visible key (-inf - -inf = NaN)
+      const float m_ref = (STREAM && m_new == -INFINITY) ? 0.f : m_new;
+      const float corr = __builtin_amdgcn_exp2f(m_run[e] - m_ref);  // exp2(-inf) = 0 on the first block
       float rs = 0.f;
 #pragma unroll
       for (int jt = 0; jt < 4; ++jt) {
-        const float p = __builtin_amdgcn_exp2f(acc_s[jt][e] - m_new);  // masked keys: exp2(-inf) = 0
+        const float p = __builtin_amdgcn_exp2f(acc_s[jt][e] - m_ref);  // masked keys: exp2(-inf) = 0
         rs += p;
         *reinterpret_cast<bf16_t*>(sPb + poff[e][jt]) = f32_to_bf16(p);
       }
@@ -296,10 +322,11 @@ __global__ __launch_bounds__(256, 3) void relattn_fused_fwd_kernel(
 constexpr int BJ3 = 32, WIN3 = 96, GLD3 = 49, SG3_BYTES = 16 * GLD3 * 4;
 constexpr int SMEM_FWD32 = 2 * (BJ3 * DH * 2) + WIN3 * DH * 2 + 4 * SG3_BYTES;
 
+template <bool STREAM>
 __global__ __launch_bounds__(256, 4) void relattn_fused_fwd32_kernel(
     const bf16_t* __restrict__ qkv, const float* __restrict__ ubias, const float* __restrict__ vbias,
     const bf16_t* __restrict__ pext, const int32_t* __restrict__ lengths, bf16_t* __restrict__ out, float* __restrict__ lse_out,
-    int B, int H, int T, float scale, int use_mask) {
+    int B, int H, int T, float scale, int use_mask, int chunk, int hist) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sK = smem;                      // [32 j][64 dh]
   char* sV = sK + BJ3 * DH * 2;         // [32 j][64 dh]
@@ -334,6 +361,7 @@ __global__ __launch_bounds__(256, 4) void relattn_fused_fwd32_kernel(
   const float scale2 = scale * 1.4426950408889634f;
   const int lim = 2 * len - 1;
   int rr0[4], goff[4], poff[4][2];
+  int wlo[4], whi[4];
   bool qm[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
@@ -341,6 +369,8 @@ __global__ __launch_bounds__(256, 4) void relattn_fused_fwd32_kernel(
     rr0[e] = T - 1 - i + r;
     goff[e] = il * GLD3 + (15 - il + r);
     qm[e] = use_mask && (i >= len);
+    wlo[e] = 0; whi[e] = T;
+    if constexpr (STREAM) { if (!qm[e]) stream_window(min(i, T - 1), T, chunk, hist, wlo[e], whi[e]); }
 #pragma unroll
     for (int jt = 0; jt < 2; ++jt) {
       const int jl = jt * 16 + r;
@@ -348,7 +378,17 @@ __global__ __launch_bounds__(256, 4) void relattn_fused_fwd32_kernel(
     }
   }
   const int njb = (T + BJ3 - 1) / BJ3;
-  for (int jb = 0; jb < njb; ++jb) {
+  int jb_lo = 0, jb_hi = njb;
+  if constexpr (STREAM) {
+    if (!(use_mask && i0 + BI > len)) {
+      int lo, hi, lo2, hi2;
+      stream_window(i0, T, chunk, hist, lo, hi);
+      stream_window(min(i0 + BI - 1, T - 1), T, chunk, hist, lo2, hi2);
+      jb_lo = lo / BJ3;
+      jb_hi = (hi2 + BJ3 - 1) / BJ3;
+    }
+  }
+  for (int jb = jb_lo; jb < jb_hi; ++jb) {
     const int j0 = jb * BJ3;
     const int pw0 = (T - 1 - (i0 + BI - 1) + j0) + shift;  // pext row of window column 0
     load_rows<BJ3>(sK, kb, LDQ, j0, T, w, lane);
@@ -407,6 +447,7 @@ __global__ __launch_bounds__(256, 4) void relattn_fused_fwd32_kernel(
         float s2 = (acc_s[jt][e] + pos) * scale2;
         if (qm[e]) s2 = 0.f;
         if (ragged && j0 + jt * 16 + r >= T) s2 = -INFINITY;
+        if constexpr (STREAM) { const int j = j0 + jt * 16 + r; if (j < wlo[e] || j >= whi[e]) s2 = -INFINITY; }
         acc_s[jt][e] = s2;
         mx = fmaxf(mx, s2);
       }
@@ -416,11 +457,12 @@ __global__ __launch_bounds__(256, 4) void relattn_fused_fwd32_kernel(
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const float m_new = fmaxf(m_run[e], rmax[e]);
-      const float corr = __builtin_amdgcn_exp2f(m_run[e] - m_new);
+      const float m_ref = (STREAM && m_new == -INFINITY) ? 0.f : m_new;  // (a block entirely outside the row's window, see the 64-key kernel)
+      const float corr = __builtin_amdgcn_exp2f(m_run[e] - m_ref);
       float rs = 0.f;
 #pragma unroll
       for (int jt = 0; jt < 2; ++jt) {
-        const float pv = __builtin_amdgcn_exp2f(acc_s[jt][e] - m_new);
+        const float pv = __builtin_amdgcn_exp2f(acc_s[jt][e] - m_ref);
         rs += pv;
         *reinterpret_cast<bf16_t*>(sPb + poff[e][jt]) = f32_to_bf16(pv);
       }
@@ -473,13 +515,13 @@ __device__ __forceinline__ short8_t row_frag(const bf16_t* row, int k0) {
 // DQ (V2 only): the query gradient leaves the kernel complete - dq = dqu + dqv written into the q columns of the fused qkv gradient
 // (`dqu` = that pointer, row stride `lddq`), du += colsum(dqu), dv += colsum(dqv) accumulated here - instead of two [B*T, H*dh]
 // tensors for a separate bias-gradient pass (tfasr_bias2_bwd).
-template <bool V2, bool DQ = false>
+template <bool V2, bool DQ = false, bool STREAM = false>
 __global__ __launch_bounds__(256, 2) void relattn_fused_bwd_q_kernel(
     const bf16_t* __restrict__ qkv, const float* __restrict__ ubias, const float* __restrict__ vbias,
     const bf16_t* __restrict__ pext, const int32_t* __restrict__ lengths, const bf16_t* __restrict__ o,
     const bf16_t* __restrict__ dout, const float* __restrict__ lse, bf16_t* __restrict__ dqu, bf16_t* __restrict__ dpos,
     float* __restrict__ dvec, int B, int H, int T, int ldp, float scale, int use_mask, bf16_t* __restrict__ dqv, float* __restrict__ dpext,
-    long lddq = 0, float* __restrict__ du = nullptr, float* __restrict__ dv = nullptr) {
+    long lddq = 0, float* __restrict__ du = nullptr, float* __restrict__ dv = nullptr, int chunk = 0, int hist = 0) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sK = smem;              // [64 j][64 dh], read both as rows (k = dh) and transposed (k = j)
   char* sV = sK + SK_BYTES;     // [64 j][64 dh]
@@ -533,6 +575,7 @@ __global__ __launch_bounds__(256, 2) void relattn_fused_bwd_q_kernel(
   const float scale2 = scale * 1.4426950408889634f;
   const int lim = 2 * len - 1;
   int rr0[4], goff[4], poff[4][4];
+  int wlo[4], whi[4];
   bool live[4], inrow[4];
   float lsei2[4];
   bf16_t* prow_e[4];
@@ -543,6 +586,8 @@ __global__ __launch_bounds__(256, 2) void relattn_fused_bwd_q_kernel(
     goff[e] = il * GLD + (63 - w * 16 - il + r);
     inrow[e] = i < T;
     live[e] = inrow[e] && !(use_mask && i >= len);
+    wlo[e] = 0; whi[e] = T;
+    if constexpr (STREAM) { if (live[e]) stream_window(i, T, chunk, hist, wlo[e], whi[e]); }
     lsei2[e] = lsei[e] * 1.4426950408889634f;
     prow_e[e] = dpos + (((long)b * H + h) * T + min(i, T - 1)) * ldp + (V2 ? 0 : (T - 1 - i + shift)) + r;  // + jl + j0 = column (V2: j itself)
 #pragma unroll
@@ -630,7 +675,9 @@ __global__ __launch_bounds__(256, 2) void relattn_fused_bwd_q_kernel(
         const float pos = valid_r ? sG[goff[e] + jt * 16] : gbias;
         float d = 0.f;
         const bool jin = !ragged || (j0 + jt * 16 + r < T);
-        if (live[e] && jin) {
+        bool vis = live[e] && jin;
+        if constexpr (STREAM) { const int j = j0 + jt * 16 + r; vis = vis && j >= wlo[e] && j < whi[e]; }  // outside the window: p = 0
+        if (vis) {
           const float p = __builtin_amdgcn_exp2f((acc_s[jt][e] + pos) * scale2 - lsei2[e]);
           d = p * (acc_p[jt][e] - Di[e]) * scale;
         }
@@ -919,11 +966,12 @@ constexpr int GTLD = 68;
 constexpr int SGT_BYTES = WIN * GTLD * 4;
 constexpr int SMEM_BWD_K = 3 * SK_BYTES + SP_BYTES + SGT_BYTES;  // qu, qv, dO blocks + window + Gt
 
+template <bool STREAM>
 __global__ __launch_bounds__(256, 2) void relattn_fused_bwd_k_kernel(
     const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ qu, const bf16_t* __restrict__ qv,
     const bf16_t* __restrict__ pext, const int32_t* __restrict__ lengths, const bf16_t* __restrict__ dout,
     const float* __restrict__ lse, const float* __restrict__ dvec, bf16_t* __restrict__ dqkv, int B, int H, int T, float scale,
-    int use_mask) {
+    int use_mask, int chunk, int hist) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sQu = smem;
   char* sQv = sQu + SK_BYTES;
@@ -1029,11 +1077,15 @@ __global__ __launch_bounds__(256, 2) void relattn_fused_bwd_k_kernel(
       const bool qmask = use_mask && (i >= len);
       const bool iin = i < T;
       const float gbias = sGt[127 * GTLD + il];
+      int wlo = 0, whi = T;
+      if constexpr (STREAM) { if (!qmask) stream_window(ic, T, chunk, hist, wlo, whi); }
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const float pos = (rrk[e] - i < lim) ? sGt[gtoff[e] + it * 16 * (1 - GTLD)] : gbias;
         float p = 0.f, d = 0.f;
-        if (iin && jin[e]) {
+        bool vis = iin && jin[e];
+        if constexpr (STREAM) { const int j = j0 + w * 16 + g * 4 + e; vis = vis && j >= wlo && j < whi; }
+        if (vis) {
           const float s2 = qmask ? 0.f : (acc_s[it][e] + pos) * scale2;
           p = __builtin_amdgcn_exp2f(s2 - lse2);
           d = qmask ? 0.f : p * (acc_p[it][e] - D_i) * scale;
@@ -1075,7 +1127,7 @@ __global__ __launch_bounds__(256, 2) void relattn_fused_bwd_k_kernel(
 
 extern "C" int tfasr_relattn_fused_fwd(const void* qkv, const float* ubias, const float* vbias, const void* pext,
                                        const int32_t* lengths, void* out, float* lse, int B, int H, int T, int dh, float scale,
-                                       int use_mask, int dtype, void* stream_) {
+                                       int use_mask, int chunk, int hist, int dtype, void* stream_) {
   if (!qkv || !ubias || !vbias || !pext || !out || !lse || B <= 0 || H <= 0 || T <= 0) return TFASR_STATUS_INVALID_VALUE;
   if (dtype != TFASR_BF16 || dh != DH) return TFASR_STATUS_UNSUPPORTED;
   dim3 grid((T + BI - 1) / BI, H, B);
@@ -1089,12 +1141,12 @@ extern "C" int tfasr_relattn_fused_fwd(const void* qkv, const float* ubias, cons
     ncu = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
   }
   const bool fwd32 = env32 ? env32[0] == '1' : (long)grid.x * grid.y * grid.z <= 4L * ncu;
-  if (fwd32)
-    hipLaunchKernelGGL(relattn_fused_fwd32_kernel, grid, dim3(256), SMEM_FWD32, (hipStream_t)stream_, (const bf16_t*)qkv, ubias, vbias,
-                       (const bf16_t*)pext, lengths, (bf16_t*)out, lse, B, H, T, scale, use_mask);
-  else
-  hipLaunchKernelGGL(relattn_fused_fwd_kernel, grid, dim3(256), SMEM_FWD, (hipStream_t)stream_, (const bf16_t*)qkv, ubias, vbias,
-                     (const bf16_t*)pext, lengths, (bf16_t*)out, lse, B, H, T, scale, use_mask);
+  const bool st = chunk > 0;
+#define TFASR_FWD_LAUNCH(KERNEL, SMEM) hipLaunchKernelGGL(KERNEL, grid, dim3(256), SMEM, (hipStream_t)stream_, (const bf16_t*)qkv, ubias, vbias, \
+                                                          (const bf16_t*)pext, lengths, (bf16_t*)out, lse, B, H, T, scale, use_mask, chunk, hist)
+  if (fwd32) { if (st) TFASR_FWD_LAUNCH(relattn_fused_fwd32_kernel<true>, SMEM_FWD32); else TFASR_FWD_LAUNCH(relattn_fused_fwd32_kernel<false>, SMEM_FWD32); }
+  else { if (st) TFASR_FWD_LAUNCH(relattn_fused_fwd_kernel<true>, SMEM_FWD); else TFASR_FWD_LAUNCH(relattn_fused_fwd_kernel<false>, SMEM_FWD); }
+#undef TFASR_FWD_LAUNCH
   TFASR_CHECK_LAUNCH();
   return TFASR_STATUS_SUCCESS;
 }
@@ -1117,11 +1169,16 @@ extern "C" int tfasr_relattn_fused_bwd_q(const void* qkv, const float* ubias, co
 extern "C" int tfasr_relattn_fused_bwd_q2(const void* qkv, const float* ubias, const float* vbias, const void* pext,
                                           const int32_t* lengths, const void* o, const void* dout, const float* lse, void* dqu, void* dqv,
                                           void* ds, float* dvec, float* dpext, int B, int H, int T, int dh, int lds, float scale, int use_mask,
-                                          int dtype, void* stream_) {
+                                          int chunk, int hist, int dtype, void* stream_) {
   if (!qkv || !ubias || !vbias || !pext || !o || !dout || !lse || !dqu || !dqv || !ds || !dvec || !dpext || B <= 0 || H <= 0 || T <= 0 || lds < T || (lds & 7))
     return TFASR_STATUS_INVALID_VALUE;
   if (dtype != TFASR_BF16 || dh != DH) return TFASR_STATUS_UNSUPPORTED;
   dim3 grid((T + BI - 1) / BI, H, B);
+  if (chunk > 0)
+    hipLaunchKernelGGL((relattn_fused_bwd_q_kernel<true, false, true>), grid, dim3(256), SMEM_BWD_Q, (hipStream_t)stream_, (const bf16_t*)qkv, ubias, vbias,
+                       (const bf16_t*)pext, lengths, (const bf16_t*)o, (const bf16_t*)dout, lse, (bf16_t*)dqu, (bf16_t*)ds, dvec, B, H, T, lds,
+                       scale, use_mask, (bf16_t*)dqv, dpext, 0L, (float*)nullptr, (float*)nullptr, chunk, hist);
+  else
   hipLaunchKernelGGL(relattn_fused_bwd_q_kernel<true>, grid, dim3(256), SMEM_BWD_Q, (hipStream_t)stream_, (const bf16_t*)qkv, ubias, vbias,
                      (const bf16_t*)pext, lengths, (const bf16_t*)o, (const bf16_t*)dout, lse, (bf16_t*)dqu, (bf16_t*)ds, dvec, B, H, T, lds,
                      scale, use_mask, (bf16_t*)dqv, dpext);
@@ -1131,13 +1188,18 @@ extern "C" int tfasr_relattn_fused_bwd_q2(const void* qkv, const float* ubias, c
 
 extern "C" int tfasr_relattn_fused_bwd_q3(const void* qkv, const float* ubias, const float* vbias, const void* pext, const int32_t* lengths,
                                           const void* o, const void* dout, const float* lse, void* dq, long lddq, float* du, float* dv, void* ds,
-                                          float* dvec, float* dpext, int B, int H, int T, int dh, int lds, float scale, int use_mask, int dtype,
-                                          void* stream_) {
+                                          float* dvec, float* dpext, int B, int H, int T, int dh, int lds, float scale, int use_mask, int chunk,
+                                          int hist, int dtype, void* stream_) {
   if (!qkv || !ubias || !vbias || !pext || !o || !dout || !lse || !dq || !du || !dv || !ds || !dvec || !dpext || B <= 0 || H <= 0 || T <= 0 || lds < T ||
       (lds & 7) || lddq < (long)H * dh)
     return TFASR_STATUS_INVALID_VALUE;
   if (dtype != TFASR_BF16 || dh != DH) return TFASR_STATUS_UNSUPPORTED;
   dim3 grid((T + BI - 1) / BI, H, B);
+  if (chunk > 0)
+    hipLaunchKernelGGL((relattn_fused_bwd_q_kernel<true, true, true>), grid, dim3(256), SMEM_BWD_Q, (hipStream_t)stream_, (const bf16_t*)qkv, ubias, vbias,
+                       (const bf16_t*)pext, lengths, (const bf16_t*)o, (const bf16_t*)dout, lse, (bf16_t*)dq, (bf16_t*)ds, dvec, B, H, T, lds, scale,
+                       use_mask, (bf16_t*)nullptr, dpext, lddq, du, dv, chunk, hist);
+  else
   hipLaunchKernelGGL((relattn_fused_bwd_q_kernel<true, true>), grid, dim3(256), SMEM_BWD_Q, (hipStream_t)stream_, (const bf16_t*)qkv, ubias, vbias,
                      (const bf16_t*)pext, lengths, (const bf16_t*)o, (const bf16_t*)dout, lse, (bf16_t*)dq, (bf16_t*)ds, dvec, B, H, T, lds, scale,
                      use_mask, (bf16_t*)nullptr, dpext, lddq, du, dv);
@@ -1163,12 +1225,16 @@ extern "C" int tfasr_relattn_dpext(const void* ds, const void* qv, const int32_t
 
 extern "C" int tfasr_relattn_fused_bwd_k(const void* qkv, const void* qu, const void* qv, const void* pext, const int32_t* lengths,
                                          const void* dout, const float* lse, const float* dvec, void* dqkv, int B, int H, int T,
-                                         int dh, float scale, int use_mask, int dtype, void* stream_) {
+                                         int dh, float scale, int use_mask, int chunk, int hist, int dtype, void* stream_) {
   if (!qkv || !qu || !qv || !pext || !dout || !lse || !dvec || !dqkv || B <= 0 || H <= 0 || T <= 0) return TFASR_STATUS_INVALID_VALUE;
   if (dtype != TFASR_BF16 || dh != DH) return TFASR_STATUS_UNSUPPORTED;
   dim3 grid((T + BJ - 1) / BJ, H, B);
-  hipLaunchKernelGGL(relattn_fused_bwd_k_kernel, grid, dim3(256), SMEM_BWD_K, (hipStream_t)stream_, (const bf16_t*)qkv, (const bf16_t*)qu,
-                     (const bf16_t*)qv, (const bf16_t*)pext, lengths, (const bf16_t*)dout, lse, dvec, (bf16_t*)dqkv, B, H, T, scale, use_mask);
+  if (chunk > 0)
+    hipLaunchKernelGGL(relattn_fused_bwd_k_kernel<true>, grid, dim3(256), SMEM_BWD_K, (hipStream_t)stream_, (const bf16_t*)qkv, (const bf16_t*)qu,
+                       (const bf16_t*)qv, (const bf16_t*)pext, lengths, (const bf16_t*)dout, lse, dvec, (bf16_t*)dqkv, B, H, T, scale, use_mask, chunk, hist);
+  else
+  hipLaunchKernelGGL(relattn_fused_bwd_k_kernel<false>, grid, dim3(256), SMEM_BWD_K, (hipStream_t)stream_, (const bf16_t*)qkv, (const bf16_t*)qu,
+                     (const bf16_t*)qv, (const bf16_t*)pext, lengths, (const bf16_t*)dout, lse, dvec, (bf16_t*)dqkv, B, H, T, scale, use_mask, 0, 0);
   TFASR_CHECK_LAUNCH();
   return TFASR_STATUS_SUCCESS;
 }

@@ -321,7 +321,7 @@ struct Ex {
       k->at_lse = f32(stash, (long)B * H * T);
       if (!dry)
         chk(tfasr_relattn_fused_fwd(k->at_qkv, fp(TFASR_BP_AT_U), fp(TFASR_BP_AT_V), k->at_pext, io->lengths, k->at_att, k->at_lse, B, H, T, dh,
-                                    scale, c->use_mask, c->dtype, s));
+                                    scale, c->use_mask, c->chunk_size, c->history_size, c->dtype, s));
     } else {
       const int Tp = (T + 7) / 8 * 8, R1p = (R1 + 7) / 8 * 8;
       k->at_qu = act(stash, rows * HD);
@@ -377,7 +377,7 @@ struct Ex {
     void* dqv = act(scratch, rows * HD);
     // fused path, default: the skewed score gradient never exists in HBM (attn_fused.hip V2); TFASR_ATTN_DPOS=1 restores the old route
     static const bool dpos_route = getenv("TFASR_ATTN_DPOS") && getenv("TFASR_ATTN_DPOS")[0] == '1';
-    const bool v2 = k->fused && !dpos_route;
+    const bool v2 = k->fused && (!dpos_route || c->chunk_size > 0);  // (the streaming mask lives in the V2 kernels only)
     void* dpos = act(scratch, v2 ? (long)B * H * T * Tp : (long)B * H * T * R1p);  // v2: the unskewed dS [B,H,T,Tp]
     const void* qv;
     float tail_scale;
@@ -396,15 +396,16 @@ struct Ex {
         static const bool q3_off = getenv("TFASR_ATTN_Q3") && getenv("TFASR_ATTN_Q3")[0] == '0';
         if (!q3_off) {
           chk(tfasr_relattn_fused_bwd_q3(k->at_qkv, fp(TFASR_BP_AT_U), fp(TFASR_BP_AT_V), k->at_pext, io->lengths, k->at_att, datt, k->at_lse, dqkv,
-                                         3L * HD, gp(TFASR_BP_AT_U), gp(TFASR_BP_AT_V), dpos, dvec, dpext, B, H, T, dh, Tp, scale, c->use_mask, c->dtype, s));
+                                         3L * HD, gp(TFASR_BP_AT_U), gp(TFASR_BP_AT_V), dpos, dvec, dpext, B, H, T, dh, Tp, scale, c->use_mask, c->chunk_size,
+                                         c->history_size, c->dtype, s));
           dq_done = true;
         } else {
           chk(tfasr_relattn_fused_bwd_q2(k->at_qkv, fp(TFASR_BP_AT_U), fp(TFASR_BP_AT_V), k->at_pext, io->lengths, k->at_att, datt, k->at_lse, dqu,
-                                         dqv, dpos, dvec, dpext, B, H, T, dh, Tp, scale, c->use_mask, c->dtype, s));
+                                         dqv, dpos, dvec, dpext, B, H, T, dh, Tp, scale, c->use_mask, c->chunk_size, c->history_size, c->dtype, s));
         }
         chk(tfasr_bias2_fwd(k->at_qkv, 3 * HD, fp(TFASR_BP_AT_U), fp(TFASR_BP_AT_V), qu, qvb, rows, HD, c->dtype, s));
         chk(tfasr_relattn_fused_bwd_k(k->at_qkv, qu, qvb, k->at_pext, io->lengths, datt, k->at_lse, dvec, dqkv, B, H, T, dh, scale, c->use_mask,
-                                      c->dtype, s));
+                                      c->chunk_size, c->history_size, c->dtype, s));
         chk(tfasr_relattn_dpext(dpos, qvb, io->lengths, dpext, B, H, T, dh, Tp, c->use_mask, c->dtype, s));
       }
       qv = qvb;
@@ -418,7 +419,7 @@ struct Ex {
                                       dpos, dvec, B, H, T, dh, R1p, scale, c->use_mask, c->dtype, s));
         chk(tfasr_bias2_fwd(k->at_qkv, 3 * HD, fp(TFASR_BP_AT_U), fp(TFASR_BP_AT_V), qu, qvb, rows, HD, c->dtype, s));
         chk(tfasr_relattn_fused_bwd_k(k->at_qkv, qu, qvb, k->at_pext, io->lengths, datt, k->at_lse, dvec, dqkv, B, H, T, dh, scale, c->use_mask,
-                                      c->dtype, s));
+                                      0, 0, c->dtype, s));
       }
       qv = qvb;
       tail_scale = 1.f;
@@ -665,7 +666,7 @@ void setup(Ex& e, const tfasr_block_cfg* c, const tfasr_block_params* P, const t
   e.scratch = Arena{dry ? nullptr : (char*)io->scratch, 0, dry ? 0 : io->scratch_bytes, true, 0};
 }
 
-bool use_fused(const tfasr_block_cfg* c) { return c->dtype == TFASR_BF16 && c->dh == 64 && !c->force_unfused && c->chunk_size <= 0; }
+bool use_fused(const tfasr_block_cfg* c) { return c->dtype == TFASR_BF16 && c->dh == 64 && !c->force_unfused; }
 
 }  // namespace
 

@@ -430,11 +430,19 @@ def relattn_softmax_bwd(probs, dprobs, lengths, T, ldp, use_mask=True, dcontent=
     return dcontent, dpos
 
 
-def relattn_fused_fwd(qkv, ubias, vbias, pext, lengths, B, H, T, dh, scale, use_mask=True):
+def _window(chunk_size, history_size):
+    """(chunk, hist) of the streaming attention mask for the C ABI: chunk 0 = off, hist < 0 = unlimited history"""
+    if not chunk_size:
+        return 0, 0
+    return int(chunk_size), (-1 if history_size is None else int(history_size))
+
+
+def relattn_fused_fwd(qkv, ubias, vbias, pext, lengths, B, H, T, dh, scale, use_mask=True, chunk_size=None, history_size=None):
     out = torch.empty(B * T, H * dh, dtype=qkv.dtype, device=qkv.device)
     lse = torch.empty(B, H, T, dtype=torch.float32, device=qkv.device)
+    ck, hs = _window(chunk_size, history_size)
     check(_L().tfasr_relattn_fused_fwd(_p(qkv), _p(ubias), _p(vbias), _p(pext), _p(lengths), _p(out), _p(lse), B, H, T, dh, scale,
-                                       int(use_mask), _dt(qkv), _stream()), "relattn_fused_fwd")
+                                       int(use_mask), ck, hs, _dt(qkv), _stream()), "relattn_fused_fwd")
     return out, lse
 
 
@@ -447,7 +455,7 @@ def relattn_fused_bwd_q(qkv, ubias, vbias, pext, lengths, o, dout, lse, B, H, T,
     return dqu, dpos, dvec
 
 
-def relattn_fused_bwd_q2(qkv, ubias, vbias, pext, lengths, o, dout, lse, dpext, B, H, T, dh, scale, use_mask=True):
+def relattn_fused_bwd_q2(qkv, ubias, vbias, pext, lengths, o, dout, lse, dpext, B, H, T, dh, scale, use_mask=True, chunk_size=None, history_size=None):
     """Query side without a skewed score gradient in HBM: -> (dqu, dqv, ds [B,H,T,lds], dvec); adds the bias-row share into dpext."""
     lds = -(-T // 8) * 8
     dqu = torch.empty(B * T, H * dh, dtype=qkv.dtype, device=qkv.device)
@@ -455,7 +463,7 @@ def relattn_fused_bwd_q2(qkv, ubias, vbias, pext, lengths, o, dout, lse, dpext, 
     ds = torch.empty(B, H, T, lds, dtype=qkv.dtype, device=qkv.device)
     dvec = torch.empty(B, H, T, dtype=torch.float32, device=qkv.device)
     check(_L().tfasr_relattn_fused_bwd_q2(_p(qkv), _p(ubias), _p(vbias), _p(pext), _p(lengths), _p(o), _p(dout), _p(lse), _p(dqu), _p(dqv), _p(ds),
-                                          _p(dvec), _p(dpext), B, H, T, dh, lds, scale, int(use_mask), _dt(qkv), _stream()), "relattn_fused_bwd_q2")
+                                          _p(dvec), _p(dpext), B, H, T, dh, lds, scale, int(use_mask), *_window(chunk_size, history_size), _dt(qkv), _stream()), "relattn_fused_bwd_q2")
     return dqu, dqv, ds, dvec
 
 
@@ -464,9 +472,9 @@ def relattn_dpext(ds, qv, lengths, dpext, B, H, T, dh, use_mask=True):
     return dpext
 
 
-def relattn_fused_bwd_k(qkv, qu, qv, pext, lengths, dout, lse, dvec, dqkv, B, H, T, dh, scale, use_mask=True):
+def relattn_fused_bwd_k(qkv, qu, qv, pext, lengths, dout, lse, dvec, dqkv, B, H, T, dh, scale, use_mask=True, chunk_size=None, history_size=None):
     check(_L().tfasr_relattn_fused_bwd_k(_p(qkv), _p(qu), _p(qv), _p(pext), _p(lengths), _p(dout), _p(lse), _p(dvec), _p(dqkv), B, H, T, dh,
-                                         scale, int(use_mask), _dt(qkv), _stream()), "relattn_fused_bwd_k")
+                                         scale, int(use_mask), *_window(chunk_size, history_size), _dt(qkv), _stream()), "relattn_fused_bwd_k")
     return dqkv
 
 

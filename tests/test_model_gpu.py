@@ -122,7 +122,7 @@ def test_streaming_conformer_step_matches_oracle(dev, dtype, chunk, hist):
     logits, loss and every gradient of the train step against the oracle, ragged lengths; native executor and host path."""
     lens, ulens = [4000, 2500, 3100], [6, 3, 5]
     cfg, ocfg, model, W, data, sig, labels, preds = _setup(dev, dtype, lens, ulens, chunk_size=chunk, history_size=hist, convm_dw_norm="layer")
-    assert not model._fused_attention()
+    assert model._fused_attention() == (dtype == torch.bfloat16)  # bf16: streaming mask inside the fused kernels (heads stored padded to 64)
     ref_logits, elen, ref_loss, ref_grads, _ = _oracle_step(ocfg, W, sig, lens, preds, ulens, labels, None)
     # the mask matters: the full-context oracle gives different logits
     ocfg_full = dict(ocfg, chunk_size=None, history_size=None)

@@ -193,6 +193,74 @@ def test_mhsa_module_T743_B8_fused_vs_oracle(dev):
     assert max(errs.values()) < 3e-2, errs
 
 
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("chunk,hist", [(None, None), (16, 64), (8, -1), (5, 3)])
+def test_mhsa_module_S_heads36_fused_and_streaming_vs_oracle(dev, chunk, hist):
+    """Row g2: the head size the reference ships (36, small.yml.j2:39) on the fused LDS-staged attention kernels (heads stored
+    zero-padded to 64) and the streaming mask of small-streaming.yml.j2:26,38-39 (chunk 16 / history 64; also unlimited history and a
+    window narrower than a key block, which exercises the skipped key blocks and rows whose first processed block is fully masked)
+    inside those kernels.  MHSAModule (conformer.py:209-239) at Conformer-S dims, T' = 250, B = 8, ragged: forward output, input
+    gradient and every parameter gradient against the oracle's rel_mhsa (compute_streaming_mask AND auto mask) under autograd."""
+    B, T, d, H, dh = 8, 250, 144, 4, 36
+    lens = [250, 250, 249, 200, 129, 64, 33, 7]
+    cfg = configs.conformer_s(dropout=0.0, num_blocks=1, chunk_size=chunk, history_size=hist)
+    ocfg = R.conformer_config("S")
+    ocfg["num_blocks"] = 1
+    model = ConformerTransducer(cfg, dev, dtype=torch.bfloat16, seed=1)
+    assert model.ps.head_phys == 64 and model._fused_attention()
+    W = R.init_weights(ocfg, seed=5, scale_bias=0.2)
+    model.ps.import_keras(W)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(B, T, d, generator=g)
+    dy = torch.randn(B, T, d, generator=g) * 0.1
+    pfx = "enc/block0/mhsa/"
+    xr = x.clone().requires_grad_(True)
+    names = [pfx + n for n in ("ln/g", "ln/b", "q/w", "q/b", "k/w", "k/b", "v/w", "v/b", "pos/w", "pos/b", "o/w", "o/b")] + ["enc/u", "enc/v"]
+    Wg = {k: (v.clone().requires_grad_(True) if k in names else v) for k, v in W.items()}
+    pe, _ = R.relative_position_encoding(T, d, lens)
+    yr = R.mhsa_module(xr, pe, Wg, pfx, H, dh, lens, Wg["enc/u"], Wg["enc/v"], use_mask=True, chunk_size=chunk, history_size=hist)
+    yr.backward(dy)
+    if chunk:  # the mask matters
+        with torch.no_grad():
+            yfull = R.mhsa_module(x, pe, W, pfx, H, dh, lens, W["enc/u"], W["enc/v"], use_mask=True)
+        assert float((yfull - yr.detach()).abs().max()) > 1e-2
+    elen_dev = torch.tensor(lens, dtype=torch.int32, device=dev)
+    xd = x.to(dev).to(torch.bfloat16).view(B * T, d)
+    dyd = dy.to(dev).to(torch.bfloat16).view(B * T, d)
+
+    def rel(a, b):
+        return float((a.double() - b.double()).norm() / b.double().norm())
+
+    ctx = {}
+    model.zero_grad()
+    y = model._mhsa_fwd(xd, pfx, B, T, elen_dev, ctx, 0, False)
+    dx = model._mhsa_bwd(dyd, pfx, B, T, elen_dev, ctx)
+    torch.cuda.synchronize()
+    e_y, e_dx = rel(y.float().cpu().view(B, T, d), yr.detach()), rel(dx.float().cpu().view(B, T, d), xr.grad)
+    mine = model.ps.export_keras(model.ps.grad)
+    gmax = max(float(Wg[k].grad.double().norm()) for k in names if Wg[k].grad is not None)
+    errs = {k: float((mine[k].double() - Wg[k].grad.double()).norm() / max(float(Wg[k].grad.double().norm()), 1e-3 * gmax))
+            for k in names if Wg[k].grad is not None}
+    print(f"\n[g2] MHSA S dims T'=250 B=8 bf16 fused (heads 36 -> 64), chunk {chunk} history {hist}: y rel L2 {e_y:.3e}, dx rel L2 {e_dx:.3e}, "
+          f"worst parameter gradient {max(errs, key=errs.get)} {max(errs.values()):.3e}")
+    assert np.isfinite(y.float().cpu().numpy()).all() and np.isfinite(dx.float().cpu().numpy()).all()
+    assert e_y < 1e-2 and e_dx < 2e-2, (e_y, e_dx)
+    assert max(errs.values()) < 3e-2, errs
+    # the native block executor queues the same kernels: one whole block, forward + backward, equals the per-kernel host path
+    outs = {}
+    for native in (True, False):
+        model.native_blocks = native
+        model.zero_grad()
+        cx = {}
+        fn = model._block_fwd_native if native else model._block_fwd
+        yb = fn(xd, 0, B, T, elen_dev, True, cx)
+        dxb = model._block_bwd_native(dyd, 0, cx) if native else model._block_bwd(dyd, 0, B, T, elen_dev, cx)
+        torch.cuda.synchronize()
+        outs[native] = (yb.float().cpu(), dxb.float().cpu(), model.ps.grad.clone().cpu())
+    assert rel(outs[True][0], outs[False][0]) < 2e-3 and rel(outs[True][1], outs[False][1]) < 5e-3
+    assert rel(outs[True][2], outs[False][2]) < 5e-3
+
+
 # --------------------------------------------------------------------------------------------- greedy tokens, bf16 vs f32 oracle
 @pytest.mark.timeout(600)
 @pytest.mark.parametrize("sharpen,blank_bias", [(6.0, 5.0), (10.0, 10.0)])
