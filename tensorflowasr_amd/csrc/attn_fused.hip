@@ -185,6 +185,33 @@ __global__ __launch_bounds__(256, 3) void relattn_fused_fwd_kernel(
       jb_hi = (hi2 + BJ - 1) / BJ;
     }
   }
+  if (use_mask && i0 >= len) {
+    // Every query row of this block is padding: the reference's scores are all -1e9 there = uniform attention over ALL T keys (keys are
+    // never masked; general.py:30-41, multihead_attention.py:609-623): out = mean_j v_j, lse = log T.  Same arithmetic as the general
+    // path below (p = 1 exactly, P @ V on the matrix cores in the same order -> bit-identical results) without K, the position window,
+    // the score products and the softmax.  LibriSpeech-shaped batches padded to their longest utterance are 40-60 % such blocks.
+    for (int jb = 0; jb < njb; ++jb) {
+      const int j0 = jb * BJ;
+      load_v(sV, vb, LDQ, j0, T, w, lane);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt)
+          *reinterpret_cast<bf16_t*>(sPb + poff[e][jt]) = (j0 + jt * 16 + r < T) ? (bf16_t)0x3F80 : (bf16_t)0;
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __syncthreads();
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const short8_t ap = frag_rows(sPb, r, kk * 4 + g);
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+          acc_o[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap, frag_v(sV, n * 16, kk * 32 + g * 8, r), acc_o[n], 0, 0, 0);
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { m_run[e] = 0.f; l_run[e] = (float)T; }
+  } else
   for (int jb = jb_lo; jb < jb_hi; ++jb) {
     const int j0 = jb * BJ;
     const int pw0 = (T - 1 - (i0 + BI - 1) + j0) + shift;  // pext row of window column 0
@@ -388,6 +415,33 @@ __global__ __launch_bounds__(256, 4) void relattn_fused_fwd32_kernel(
       jb_hi = (hi2 + BJ3 - 1) / BJ3;
     }
   }
+  if (use_mask && i0 >= len) {  // a block of padded query rows: uniform attention over all T keys (see the 64-key kernel)
+    for (int jb = 0; jb < njb; ++jb) {
+      const int j0 = jb * BJ3;
+      {
+        const int k = w * 8 + (lane >> 3), pc = lane & 7;
+        const int gr = min(j0 + k, T - 1);
+        const bf16_t* src = vb + (long)gr * LDQ + ((pc ^ key_t64(k)) << 3);
+        __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(sV + __builtin_amdgcn_readfirstlane(w * 1024)), 16, 0, 0);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+          *reinterpret_cast<bf16_t*>(sPb + poff[e][jt]) = (j0 + jt * 16 + r < T) ? (bf16_t)0x3F80 : (bf16_t)0;
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __syncthreads();
+      {
+        const short8_t ap = *reinterpret_cast<const short8_t*>(sPb + r * 64 + ((g ^ ((r >> 1) & 3)) << 4));
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+          acc_o[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap, frag_v(sV, n * 16, g * 8, r), acc_o[n], 0, 0, 0);
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { m_run[e] = 0.f; l_run[e] = (float)T; }
+  } else
   for (int jb = jb_lo; jb < jb_hi; ++jb) {
     const int j0 = jb * BJ3;
     const int pw0 = (T - 1 - (i0 + BI - 1) + j0) + shift;  // pext row of window column 0
@@ -539,6 +593,24 @@ __global__ __launch_bounds__(256, 2) void relattn_fused_bwd_q_kernel(
   const bf16_t* vb = qb + 2 * HD;
   const bf16_t* pb = pext + h * DH;
 
+  if constexpr (V2) {
+    if (use_mask && i0 >= len) {
+      // a block of padded query rows: constant scores, so dS = 0 and the query gradient is zero; relattn_dpext_kernel skips these tiles
+      // of dS (never read) and the key-side kernel does not use their D_i.  Only the zero query-gradient rows have to be written.
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int i = i0 + w * 16 + g * 4 + e;
+        if (i < T) {
+#pragma unroll
+          for (int n = 0; n < 4; ++n) {
+            if constexpr (DQ) dqu[((long)b * T + i) * lddq + h * DH + n * 16 + r] = (bf16_t)0;
+            else { dqu[((long)b * T + i) * HD + h * DH + n * 16 + r] = (bf16_t)0; dqv[((long)b * T + i) * HD + h * DH + n * 16 + r] = (bf16_t)0; }
+          }
+        }
+      }
+      return;
+    }
+  }
   const int irow = min(i0 + w * 16 + r, T - 1);
   short8_t aqu[2], aqv[2], ado[2];
   float dpart = 0.f;
@@ -1025,6 +1097,29 @@ __global__ __launch_bounds__(256, 2) void relattn_fused_bwd_k_kernel(
   const int nib = (T + BI - 1) / BI;
   for (int ib = 0; ib < nib; ++ib) {
     const int i0 = ib * BI;
+    if (use_mask && i0 >= len) {
+      // a block of padded query rows: p = 1 / T for every key (exp2(0 - lse), lse = log T), dS = 0: only dv += P^T @ dO remains
+      load_rows<BI>(sdO, dob, HD, i0, T, w, lane);
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int i = i0 + it * 16 + r;
+        const float lse2 = lse[lrow + min(i, T - 1)] * 1.4426950408889634f;
+        const bf16_t pv = f32_to_bf16(__builtin_amdgcn_exp2f(0.f - lse2));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) *reinterpret_cast<bf16_t*>(sAp + aoff[e][it]) = (i < T && jin[e]) ? pv : (bf16_t)0;
+      }
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __syncthreads();
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const short8_t ap = frag_rows(sAp, r, kk * 4 + g);
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+          acc_v[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap, frag_kt(sdO, n * 16, kk * 32 + g * 8, r), acc_v[n], 0, 0, 0);
+      }
+      __syncthreads();
+      continue;
+    }
     const int pw0 = (T - 1 - (i0 + BI - 1) + j0) + shift;
     load_rows<BI>(sQu, qub, HD, i0, T, w, lane);
     load_rows<BI>(sQv, qvb, HD, i0, T, w, lane);
