@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define TFASR_ABI_VERSION 18
+#define TFASR_ABI_VERSION 19
 
 typedef enum {
   TFASR_STATUS_SUCCESS = 0,
@@ -334,6 +334,19 @@ int tfasr_lstm_seq_fwd(const void* xg, const void* rk, const void* h0, long h0_s
                        int dtype, void* stream);
 int tfasr_lstm_seq_bwd(const void* dy, const void* rk, const void* gates, const float* cseq, const int32_t* lengths, void* dz,
                        float* dh_carry, float* dc_carry, float* dhr, int B, int U1, int P, int dtype, void* stream);
+/* The whole recurrence of one direction as ONE persistent launch (csrc/lstm_persist.hip): workgroup j keeps the recurrent
+ * weights of 16 hidden units in registers for the whole sequence, the per-step exchange of h_t (forward) / dz_t (backward) between
+ * the workgroups goes through the sequence buffers themselves with write-through stores, one device-scope arrival counter and one
+ * agent-scope acquire per step.  Same buffers and semantics as tfasr_lstm_seq_fwd / _bwd (which take this path by themselves when it
+ * applies; TFASR_LSTM_PERSIST=0 forces the step kernels).  bf16, B <= 64, P a multiple of 32, P <= 1024, else UNSUPPORTED.
+ * `sync`: tfasr_lstm_persist_sync_bytes() bytes of device memory, zeroed by the call; every spin is bounded (1 s): after a stream
+ * synchronisation the second 32-bit word != 0 means a wait timed out and the results are invalid. */
+size_t tfasr_lstm_persist_sync_bytes(void);
+int tfasr_lstm_persist_fwd(const void* xg, const void* rk, const void* h0, long h0_stride_b, const float* c0, long c0_stride_b,
+                           const int32_t* lengths, void* gates, float* cseq, void* hseq, void* yseq, int B, int U1, int P, int dtype,
+                           void* sync, void* stream);
+int tfasr_lstm_persist_bwd(const void* dy, const void* rk, const void* gates, const float* cseq, const int32_t* lengths, void* dz,
+                           float* dh_carry, float* dc_carry, int B, int U1, int P, int dtype, void* sync, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Greedy transducer search control (Transducer.recognize_batch / recognize_single, base_transducer.py:496-712).

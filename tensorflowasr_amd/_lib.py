@@ -149,7 +149,7 @@ def load(build_if_missing=True):
     return lib
 
 
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 
 STATUS_UNSUPPORTED = 3

@@ -7,6 +7,7 @@
 // The two GEMMs (x@W+b for all steps at once, h_{t-1}@R per step) run on the MFMA GEMM family; these
 // kernels do the per-step gate math, one thread per (batch row, hidden unit).
 #include "common.h"
+#include <stdlib.h>
 #include <string.h>
 
 namespace {
@@ -149,10 +150,22 @@ extern "C" int tfasr_lstm_step_bwd(const void* dy, long dy_stride_b, const float
 // host side at 25.8 of 28.0 ms the GPU idled between the steps of this chain.
 // Layouts as the step kernels take them: xg / gates [B, U1, 4P], cseq (f32) / hseq / yseq [B, U1, P]; hr [B, 4P] f32 scratch.
 // ---------------------------------------------------------------------------------------------------------------------------------
+static bool persist_enabled() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("TFASR_LSTM_PERSIST"); v = (e && e[0] == '0') ? 0 : 1; }
+  return v == 1;
+}
+
 extern "C" int tfasr_lstm_seq_fwd(const void* xg, const void* rk, const void* h0, long h0_stride_b, const float* c0, long c0_stride_b,
                                   const int32_t* lengths, void* gates, float* cseq, void* hseq, void* yseq, float* hr, int B, int U1, int P,
                                   int dtype, void* stream) {
   if (!xg || !rk || !gates || !cseq || !hseq || !hr || B <= 0 || U1 <= 0 || P <= 0) return TFASR_STATUS_INVALID_VALUE;
+  // one persistent launch for the whole sequence where the shape allows it (lstm_persist.hip); its 64-byte synchronisation record
+  // lives at the front of the `hr` scratch (B x 4P floats, unused by that path)
+  if (persist_enabled() && (size_t)B * 4 * P * sizeof(float) >= tfasr_lstm_persist_sync_bytes()) {
+    const int st = tfasr_lstm_persist_fwd(xg, rk, h0, h0_stride_b, c0, c0_stride_b, lengths, gates, cseq, hseq, yseq, B, U1, P, dtype, hr, stream);
+    if (st != TFASR_STATUS_UNSUPPORTED) return st;
+  }
   const long esz = dtype == TFASR_F32 ? 4 : 2;
   for (int t = 0; t < U1; ++t) {
     const char* hprev = t > 0 ? (const char*)hseq + (long)(t - 1) * P * esz : (const char*)h0;
@@ -180,6 +193,10 @@ extern "C" int tfasr_lstm_seq_fwd(const void* xg, const void* rk, const void* h0
 extern "C" int tfasr_lstm_seq_bwd(const void* dy, const void* rk, const void* gates, const float* cseq, const int32_t* lengths, void* dz,
                                   float* dh_carry, float* dc_carry, float* dhr, int B, int U1, int P, int dtype, void* stream) {
   if (!dy || !rk || !gates || !cseq || !dz || !dh_carry || !dc_carry || !dhr || B <= 0 || U1 <= 0 || P <= 0) return TFASR_STATUS_INVALID_VALUE;
+  if (persist_enabled() && (size_t)B * P * sizeof(float) >= tfasr_lstm_persist_sync_bytes()) {  // (synchronisation record at the front of `dhr`)
+    const int st = tfasr_lstm_persist_bwd(dy, rk, gates, cseq, lengths, dz, dh_carry, dc_carry, B, U1, P, dtype, dhr, stream);
+    if (st != TFASR_STATUS_UNSUPPORTED) return st;
+  }
   const long esz = dtype == TFASR_F32 ? 4 : 2;
   for (int t = U1 - 1; t >= 0; --t) {
     int st = tfasr_lstm_step_bwd((const char*)dy + (long)t * P * esz, (long)U1 * P, t < U1 - 1 ? dhr : nullptr, dh_carry, dc_carry,

@@ -503,6 +503,27 @@ def lstm_seq_fwd(xg, rk, h0, c0, lengths, gates, cseq, hseq, yseq, hr):
                                   _p(gates), _p(cseq), _p(hseq), _pv(yseq), _p(hr), B, U1, P, _dt(xg), _stream()), "lstm_seq_fwd")
 
 
+def lstm_persist_sync(device):
+    """64-byte synchronisation record of the persistent LSTM kernels; word [1] != 0 after a sync = a wait timed out"""
+    return torch.zeros(int(_L().tfasr_lstm_persist_sync_bytes()) // 4, dtype=torch.int32, device=device)
+
+
+def lstm_persist_fwd(xg, rk, h0, c0, lengths, gates, cseq, hseq, yseq, sync):
+    """tfasr_lstm_persist_fwd: the whole forward recurrence as ONE launch (raises TfasrUnsupported outside its shape range)."""
+    B, U1, P4 = xg.shape
+    P = P4 // 4
+    assert xg.is_contiguous() and gates.is_contiguous() and cseq.is_contiguous() and hseq.is_contiguous() and (yseq is None or yseq.is_contiguous())
+    check(_L().tfasr_lstm_persist_fwd(_p(xg), _p(rk), _pv(h0), 0 if h0 is None else h0.stride(0), _pv(c0), 0 if c0 is None else c0.stride(0), _pv(lengths),
+                                      _p(gates), _p(cseq), _p(hseq), _pv(yseq), B, U1, P, _dt(xg), _p(sync), _stream()), "lstm_persist_fwd")
+
+
+def lstm_persist_bwd(dy, rk, gates, cseq, lengths, dz, dh_carry, dc_carry, sync):
+    B, U1, P = dy.shape
+    assert dy.is_contiguous() and gates.is_contiguous() and cseq.is_contiguous() and dz.is_contiguous()
+    check(_L().tfasr_lstm_persist_bwd(_p(dy), _p(rk), _p(gates), _p(cseq), _pv(lengths), _p(dz), _p(dh_carry), _p(dc_carry), B, U1, P, _dt(dy),
+                                      _p(sync), _stream()), "lstm_persist_bwd")
+
+
 def lstm_seq_bwd(dy, rk, gates, cseq, lengths, dz, dh_carry, dc_carry, dhr):
     B, U1, P = dy.shape
     assert dy.is_contiguous() and gates.is_contiguous() and cseq.is_contiguous() and dz.is_contiguous()
