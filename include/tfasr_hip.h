@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define TFASR_ABI_VERSION 19
+#define TFASR_ABI_VERSION 20
 
 typedef enum {
   TFASR_STATUS_SUCCESS = 0,
@@ -67,6 +67,11 @@ int tfasr_rnnt_loss(const void* logits, void* grads, const int32_t* labels, cons
  * at sum_b T_b*U1_b instead of B*T*U1 rows.  Workspace: tfasr_rnnt_loss_workspace_size(1, total_cells, 1, V). */
 /* The vocabulary id each lattice row's label transition emits (labels[b, u] for u < label_len[b], else -1), for the GEMM
    epilogue's `row_label`; rows follow the packed (cell_off != NULL) or dense [B,T,U1] lattice order. */
+/* tfasr_rnnt_loss_packed_stats without logits: costs and, instead of the gradient tensor, the per-row coefficients from which a
+ * re-computed logit tile becomes the gradient (tfasr_gemm_args.rgrad_coef): coef [4 * total_cells] f32. */
+int tfasr_rnnt_loss_packed_coef(const int32_t* labels, const int32_t* label_len, const int32_t* logit_len, const float* grad_scale,
+                                const long* cell_off, long total_cells, const float* lse_part, int lse_parts, const float* pick, int B, int T,
+                                int U1, int V, int blank, float* costs, float* coef, void* workspace, size_t workspace_bytes, void* stream);
 int tfasr_rnnt_row_labels(const int32_t* labels, const int32_t* label_len, const int32_t* logit_len, const long* cell_off,
                           long total_cells, int B, int T, int U1, int V, int32_t* row_label, void* stream);
 /* tfasr_rnnt_loss_packed whose log-softmax statistics were already produced by the projection GEMM's epilogue (tfasr_gemm_args
@@ -149,6 +154,13 @@ typedef struct {
      range [s*seg_k, (s+1)*seg_k) reads op(A) from A + seg_a_off[s] and (when seg_b_off != NULL) op(B) from B + seg_b_off[s]
      (element offsets, DEVICE arrays of K / seg_k entries) instead of a contiguous K: a convolution tap = the same rows shifted. */
   const long* seg_a_off; const long* seg_b_off; int seg_k;
+  /* Joint network without materialised lattice logits (SURVEY section 7 step 8 / 8(d) "recompute" variant; base_transducer.py:280-293 +
+     losses/impl/rnnt.py:211-278).  (1) With lse_part set, D may be NULL: the projection's epilogue emits only the row statistics.
+     (2) rgrad_coef != NULL: the product is the RE-computed logit tile and the epilogue turns it into the loss gradient before the
+     store, D[m, v] = exp2(x * log2(e) - c.x) * c.y + [v == 0] c.z + [v == row_label[m]] c.w with c = rgrad_coef[4m .. 4m+3]
+     (tfasr_rnnt_loss_packed_coef: c.x = lse * log2(e), c.y = -(g_blank + g_label) * scale, c.z = g_blank * scale, c.w = g_label * scale).
+     Only the 256-row bf16 kernel (plain NN product + bias) implements both: otherwise UNSUPPORTED. */
+  const float* rgrad_coef;
 } tfasr_gemm_args;
 
 int tfasr_gemm(const tfasr_gemm_args* args, void* stream);

@@ -33,6 +33,7 @@ class GemmArgs(Structure):
         ("ws", c_void_p), ("ws_elems", c_long), ("colsum", c_void_p),
         ("lse_part", c_void_p), ("lse_parts", c_int), ("row_label", c_void_p), ("pick", c_void_p),
         ("seg_a_off", c_void_p), ("seg_b_off", c_void_p), ("seg_k", c_int),
+        ("rgrad_coef", c_void_p),
     ]
 
 
@@ -149,7 +150,7 @@ def load(build_if_missing=True):
     return lib
 
 
-ABI_VERSION = 19
+ABI_VERSION = 20
 
 
 STATUS_UNSUPPORTED = 3

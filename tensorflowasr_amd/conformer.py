@@ -85,6 +85,11 @@ class ConformerTransducer(BaseModel):
         self._blk_params, self._blk_sizes = {}, {}
         self._zero_pool = {}
         self.fuse_joint_stats = os.environ.get("TFASR_JOINT_STATS", "1") != "0"
+        # Joint + loss WITHOUT materialised lattice logits (SURVEY section 7 step 8 / 8(d) "report both"): the projection emits only the
+        # log-softmax statistics, the gradient pass re-computes the logit tile and turns it into the loss gradient in its epilogue
+        # (tfasr_gemm_args.rgrad_coef).  Trades two passes over the [cells, V] tensor for one more vocabulary product: measured SLOWER
+        # than the materialised route on MI355X (bench.py reports both), so opt-in: TFASR_JOINT_RECOMPUTE=1.
+        self.joint_recompute = os.environ.get("TFASR_JOINT_RECOMPUTE", "0") == "1"
         self._after_encoder = "pred/emb" if cfg.head == "transducer" else "dec/logits/w"  # first regularised variable after the encoder
         self.timers = None  # optional dict name -> list[(start_event, end_event)] filled by bench.py
         self.timer_work = {}
@@ -975,6 +980,19 @@ class ConformerTransducer(BaseModel):
                 pick = torch.empty(total, 2, dtype=torch.float32, device=dev)
                 row_label = K.rnnt_row_labels(labels, ul_dev, tl_dev, off_dev, total, T, V)
                 t0 = self._tick("joint_vocab_gemm")
+                if self.joint_recompute and want_backward:
+                    try:
+                        K.gemm(h, ps.w2d("joint/vocab/w"), None, total, V, J, J, V, V, bias=ps.p("joint/vocab/b"), lse=(lse_part, row_label, pick))
+                        self._tock("joint_vocab_gemm", t0, 2.0 * total * J * V)
+                        t0 = self._tick("rnnt_loss")
+                        costs, coef = K.rnnt_loss_packed_coef(labels, ul_dev, tl_dev, off_dev, total, T, V, (lse_part, pick), grad_scale=gscale)
+                        dlogits = torch.empty(total, V, dtype=self.dtype, device=dev)
+                        K.gemm(h, ps.w2d("joint/vocab/w"), dlogits, total, V, J, J, V, V, bias=ps.p("joint/vocab/b"), rgrad=(coef, row_label))
+                        # algorithmic bytes of this variant: the gradient tensor is written once (the logits never exist)
+                        self._tock("rnnt_loss", t0, 1.0 * total * V * dlogits.element_size())
+                        return self._joint_backward_tail(costs, dlogits, h, enc, pred, off_dev, ul_dev, tl_dev, B, T, U1, ctx)
+                    except K._lib.TfasrUnsupported:
+                        t0 = self._tick("joint_vocab_gemm")  # shapes outside the 256-row kernel: the materialised route below
                 try:
                     logits = torch.empty(total, V, dtype=self.dtype, device=dev)
                     K.gemm(h, ps.w2d("joint/vocab/w"), logits, total, V, J, J, V, V, bias=ps.p("joint/vocab/b"), lse=(lse_part, row_label, pick))
@@ -982,6 +1000,8 @@ class ConformerTransducer(BaseModel):
                     self._tock("joint_vocab_gemm", t0, 2.0 * total * J * V)
                 except K._lib.TfasrUnsupported:
                     logits = None
+                    if self.timers is not None:  # (keep the section timers paired: ADVICE r02)
+                        self._tock("joint_vocab_gemm", t0, 0.0)
             if logits is None:
                 t0 = self._tick("joint_vocab_gemm")
                 logits = K.matmul(h, ps.w2d("joint/vocab/w"), bias=ps.p("joint/vocab/b"))  # [total, V]
@@ -992,11 +1012,20 @@ class ConformerTransducer(BaseModel):
             self._tock("rnnt_loss", t0, 2.0 * total * V * logits.element_size())
             if not want_backward:
                 return costs
-            # tanh' folded into the data gradient's epilogue (dact = TANH_OUT: times 1 - h^2): the segment sums read one tensor, not two
-            dh = self._dense_bwd(dlogits, h, "joint/vocab/w", "joint/vocab/b", dact_z=h, dact=ACT_TANH_OUT)
-            de, dp = K.joint_bwd_packed(None, dh, off_dev, ul_dev, tl_dev, B, T, U1)
-            denc = self._dense_bwd(de.view(B * T, J), enc, "joint/enc/w", "joint/enc/b")
-            dpred = self._dense_bwd(dp.view(B * U1, J), pred, "joint/pred/w", "joint/pred/b")
+            return self._joint_backward_tail(costs, dlogits, h, enc, pred, off_dev, ul_dev, tl_dev, B, T, U1, ctx)
+        return self._backward_from_joint(costs, denc, dpred, ctx)
+
+    def _joint_backward_tail(self, costs, dlogits, h, enc, pred, off_dev, ul_dev, tl_dev, B, T, U1, ctx):
+        """packed lattice: gradient of the lattice logits -> gradients of the joint network's inputs (+ its weight gradients)"""
+        J = self.cfg.joint_dim
+        # tanh' folded into the data gradient's epilogue (dact = TANH_OUT: times 1 - h^2): the segment sums read one tensor, not two
+        dh = self._dense_bwd(dlogits, h, "joint/vocab/w", "joint/vocab/b", dact_z=h, dact=ACT_TANH_OUT)
+        de, dp = K.joint_bwd_packed(None, dh, off_dev, ul_dev, tl_dev, B, T, U1)
+        denc = self._dense_bwd(de.view(B * T, J), enc, "joint/enc/w", "joint/enc/b")
+        dpred = self._dense_bwd(dp.view(B * U1, J), pred, "joint/pred/w", "joint/pred/b")
+        return self._backward_from_joint(costs, denc, dpred, ctx)
+
+    def _backward_from_joint(self, costs, denc, dpred, ctx):
         main = torch.cuda.current_stream()
         self.dp.grads_ready(self.ps.offsets["joint/enc/w"], self.ps.n_reg)
         if self.use_pred_stream:

@@ -311,8 +311,9 @@ extern "C" int tfasr_gemm_group(const tfasr_gemm_args* args, int n, void* stream
 }
 
 extern "C" int tfasr_gemm(const tfasr_gemm_args* args, void* stream_) {
-  if (!args || !args->A || !args->B || !args->D) return TFASR_STATUS_INVALID_VALUE;
+  if (!args || !args->A || !args->B || (!args->D && !args->lse_part)) return TFASR_STATUS_INVALID_VALUE;
   tfasr_gemm_args a = *args;
+  if (a.rgrad_coef && (!a.row_label || !a.D || a.lse_part)) return TFASR_STATUS_INVALID_VALUE;
   if (a.M <= 0 || a.N <= 0 || a.K <= 0) return TFASR_STATUS_INVALID_VALUE;
   if (a.nb1 < 1) a.nb1 = 1;
   if (a.nb2 < 1) a.nb2 = 1;
@@ -327,7 +328,7 @@ extern "C" int tfasr_gemm(const tfasr_gemm_args* args, void* stream_) {
     const int st = tfasr_gemm_fast_try(a, stream);
     if (st != TFASR_STATUS_UNSUPPORTED) return st;
   }
-  if (a.lse_part) return TFASR_STATUS_UNSUPPORTED;  // only the bf16 fast path's epilogue produces the row statistics
+  if (a.lse_part || a.rgrad_coef) return TFASR_STATUS_UNSUPPORTED;  // only the bf16 fast path's epilogues produce the row statistics / the loss gradient
   if (a.seg_a_off) return TFASR_STATUS_UNSUPPORTED;  // K-segments: bf16 fast path only (the f32 host path issues one product per segment)
   if (a.colsum) {  // the generic kernels do not fuse the bias gradient: one extra pass over B = dy
     const int st = tfasr_colsum(a.B, a.ldb, a.colsum, a.K, a.N, a.alpha, a.dtype, stream_);

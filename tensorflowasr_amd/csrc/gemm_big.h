@@ -382,6 +382,7 @@ void gemm_big_kernel(const tfasr_gemm_args p, const int gx, const int gy, const 
               reinterpret_cast<float2*>(p.lse_part)[(long)row * p.lse_parts + slice] = make_float2(om, os);
           }
         }
+        if constexpr (C_LSE) { if (!Dt) continue; }  // statistics-only projection (D == NULL): no logits leave the chip, no transposition pass
 #pragma unroll
         for (int ch = 0; ch < NCH; ++ch) {
           const int col0 = cb + ch * CW + c8;
@@ -415,6 +416,18 @@ _Pragma("unroll")
                   for (int q = 0; q < 8; ++q) z[q] = (col0 + q < p.N) ? bf16_to_f32(hz[idx0 + q]) : 0.f;
 #pragma unroll
                 for (int q = 0; q < 8; ++q) y[q] *= 1.f - z[q] * z[q];
+              }
+              if constexpr ((EPI & E_RGRAD) != 0) {
+                // y = the re-computed logits of 8 columns of row `row`: -> d loss / d logit (impl/rnnt.py:233-275; rnnt_grad_kernel's arithmetic)
+                const float4 cf = *reinterpret_cast<const float4*>(p.rgrad_coef + 4L * row);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) y[q] = __builtin_amdgcn_exp2f(y[q] * 1.4426950408889634f - cf.x) * cf.y;
+                if (col0 == 0) y[0] += cf.z;
+                const int lb = p.row_label[row] - col0;
+                if (lb >= 0 && lb < 8) {
+#pragma unroll
+                  for (int q = 0; q < 8; ++q) y[q] += (q == lb) ? cf.w : 0.f;
+                }
               }
               if (full) st8(Dt + idx0, y);
               else
@@ -465,6 +478,8 @@ int launch_big(const tfasr_gemm_args& a, bool generic, int need, bool tanh_out, 
   if (ntiles < min_tiles || ntiles > 0x7fffffffL) return TFASR_STATUS_UNSUPPORTED;
   if (tanh_out && (!TB || seg || a.lse_part)) return TFASR_STATUS_UNSUPPORTED;
   if (a.lse_part && !(a.row_label && a.pick && bn == 256 && a.lse_parts == ((a.N + 127) / 128) * 2)) return TFASR_STATUS_UNSUPPORTED;
+  if (a.rgrad_coef && (TB || seg || tanh_out || bn != 256 || !a.row_label)) return TFASR_STATUS_UNSUPPORTED;
+  if (!a.D && !a.lse_part) return TFASR_STATUS_UNSUPPORTED;
   const int ncu = num_cus();
   const int G = ntiles >= ncu ? (ncu & ~7) : (int)ntiles;
   auto go = [&](auto kern, int smem) {
@@ -484,6 +499,9 @@ int launch_big(const tfasr_gemm_args& a, bool generic, int need, bool tanh_out, 
     else return TFASR_STATUS_UNSUPPORTED;
   } else if (a.lse_part) {
     if constexpr (!TB) go(gemm_big_kernel<false, 256, E_LSE, false>, S256);
+    else return TFASR_STATUS_UNSUPPORTED;
+  } else if (a.rgrad_coef) {
+    if constexpr (!TB) go(gemm_big_kernel<false, 256, E_RGRAD, false>, S256);
     else return TFASR_STATUS_UNSUPPORTED;
   } else if (seg) {
     go(gemm_big_kernel<TB, 256, 0, true>, S256);

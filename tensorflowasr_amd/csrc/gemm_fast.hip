@@ -218,7 +218,7 @@ __device__ __forceinline__ float dact_f(float z, int act) {
 // EPI selects which epilogue terms are COMPILED IN.  The fully generic epilogue (every term behind a runtime branch, tanh /
 // sigmoid / f32 outputs included) is ~20k instructions and thrashes the instruction cache: a plain bias epilogue took 1700
 // cycles per 16-row strip.  The step's common combinations get lean instantiations; anything else falls back to E_GEN.
-enum : int { E_ACT = 1 /* swish(+prez) */, E_DACT = 2 /* * swish'(dact_z) */, E_DROP = 4, E_RES = 8, E_WS = 16 /* split-K partial -> workspace */, E_CSUM = 32 /* + column sums of B (bias gradient) */, E_LSE = 64 /* + log-softmax statistics of the output rows */, E_GEN = 256 };
+enum : int { E_ACT = 1 /* swish(+prez) */, E_DACT = 2 /* * swish'(dact_z) */, E_DROP = 4, E_RES = 8, E_WS = 16 /* split-K partial -> workspace */, E_CSUM = 32 /* + column sums of B (bias gradient) */, E_LSE = 64 /* + log-softmax statistics of the output rows */, E_RGRAD = 128 /* re-computed logits -> RNN-T loss gradient */, E_GEN = 256 };
 
 // Persistent workgroups (2 per CU) walk a strided list of tiles.  Measured on [23808,256]x[256,1024] (cycle counters,
 // tools/hwprobe/gemm_timing.hip): a tile spent 1900 cycles waiting for its first slab, ~2400 per further slab (the LDS-DMA
@@ -977,6 +977,7 @@ int launch_one(const tfasr_gemm_args& a, hipStream_t stream) {
     const int st = launch_big<TB>(a, other, need, tanh_out, stream);
     if (st != TFASR_STATUS_UNSUPPORTED) return st;
   }
+  if (a.rgrad_coef || !a.D) return TFASR_STATUS_UNSUPPORTED;  // gradient epilogue / statistics-only projection: 256-row kernel only
   // (measured: NOT faster than the atomics - 34.8 vs 33.0 us on the [256,1024,19040] weight gradient, +5 ms on the step from
   // the extra workspace traffic - so callers only pass a workspace when TFASR_SPLITK_WS=1; kept as the deterministic option)
   if (a.accumulate && split > 1 && a.nb1 * a.nb2 == 1 && a.ws && a.ws_elems >= (long)split * a.M * a.N && !narrow && !a.colsum) {

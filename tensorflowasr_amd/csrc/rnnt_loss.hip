@@ -374,6 +374,31 @@ __global__ __launch_bounds__(256) void rnnt_grad_kernel(
   }
 }
 
+// Per-row coefficients of the loss gradient for the variant that re-computes the logit tile instead of reading it back
+// (tfasr_gemm_args.rgrad_coef): (lse * log2(e), -(gb + gt) * scale, gb * scale, gt * scale); rows outside the lattice: zero gradient.
+__global__ __launch_bounds__(256) void rnnt_coef_kernel(
+    const int32_t* __restrict__ label_len, const int32_t* __restrict__ logit_len, const float* __restrict__ grad_scale,
+    const long* __restrict__ cell_off, long nrows, int B, int Tm, int U1, const float* __restrict__ lse, const float* __restrict__ blank_lp,
+    const float* __restrict__ truth_lp, const float* __restrict__ alpha, const float* __restrict__ beta, float4* __restrict__ coef) {
+  for (long r = (long)blockIdx.x * blockDim.x + threadIdx.x; r < nrows; r += (long)gridDim.x * blockDim.x) {
+    const Cell cl = locate(r, cell_off, B, Tm, U1, label_len, logit_len);
+    float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (cl.valid) {
+      const int u = cl.u, t = cl.t, b = cl.b, Tl = cl.Tl, Ul = cl.Ul;
+      const int ustride = cell_off ? Ul + 1 : U1;
+      const long lb = cell_off ? cell_off[b] : (long)b * Tm * U1;
+      const float b00 = beta[lb], a = alpha[r];
+      float gb = 0.f, gt = 0.f;
+      if (t < Tl - 1) gb = -__expf(a + beta[r + ustride] + blank_lp[r] - b00);
+      else if (u == Ul) gb = -1.f;
+      if (u < Ul) gt = -__expf(a + beta[r + 1] + truth_lp[r] - b00);
+      const float sc = grad_scale ? grad_scale[b] : 1.f;
+      c = make_float4(lse[r] * 1.4426950408889634f, -(gb + gt) * sc, gb * sc, gt * sc);
+    }
+    coef[r] = c;
+  }
+}
+
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 }  // namespace
@@ -388,8 +413,8 @@ extern "C" int tfasr_rnnt_loss_workspace_size(int B, int T, int U1, int V, size_
 static int rnnt_impl(const void* logits, void* grads, const int32_t* labels, const int32_t* label_len,
                      const int32_t* logit_len, const float* grad_scale, const long* cell_off, long nrows, int B, int T, int U1,
                      int V, int blank, int dtype, float* costs, void* workspace, size_t workspace_bytes, void* stream_,
-                     const float* lse_part = nullptr, int lse_parts = 0, const float* pick = nullptr) {
-  if (!logits || !labels || !label_len || !logit_len || !costs || !workspace) return TFASR_STATUS_INVALID_VALUE;
+                     const float* lse_part = nullptr, int lse_parts = 0, const float* pick = nullptr, float* coef = nullptr) {
+  if ((!logits && !(lse_part && coef && !grads)) || !labels || !label_len || !logit_len || !costs || !workspace) return TFASR_STATUS_INVALID_VALUE;
   if (blank != 0) return TFASR_STATUS_UNSUPPORTED;  // losses/base_loss.py:24
   if (B <= 0 || T <= 0 || U1 <= 0 || V <= 1 || U1 > 1024 || nrows <= 0) return TFASR_STATUS_INVALID_VALUE;
   const size_t n = (size_t)nrows;
@@ -421,6 +446,12 @@ static int rnnt_impl(const void* logits, void* grads, const int32_t* labels, con
   hipLaunchKernelGGL(rnnt_lattice_kernel, dim3(B, 2), dim3(nthr), 2 * nthr * sizeof(float), stream, blank_lp,
                      truth_lp, label_len, logit_len, cell_off, T, U1, alpha, beta, costs);
   TFASR_CHECK_LAUNCH();
+  if (coef) {
+    const int cg = (int)std::min<long>((nrows + 255) / 256, 256L * 8);
+    hipLaunchKernelGGL(rnnt_coef_kernel, dim3(cg), dim3(256), 0, stream, label_len, logit_len, grad_scale, cell_off, nrows, B, T, U1, lse, blank_lp,
+                       truth_lp, alpha, beta, (float4*)coef);
+    TFASR_CHECK_LAUNCH();
+  }
   if (grads) {
     if (dtype == TFASR_F32)
       hipLaunchKernelGGL(rnnt_grad_kernel<float>, dim3(grid), dim3(256), 0, stream, (const float*)logits,
@@ -459,6 +490,15 @@ extern "C" int tfasr_rnnt_loss_packed_stats(const void* logits, void* grads, con
   if (!cell_off || !lse_part || !pick || lse_parts <= 0) return TFASR_STATUS_INVALID_VALUE;
   return rnnt_impl(logits, grads, labels, label_len, logit_len, grad_scale, cell_off, total_cells, B, T, U1, V, blank, dtype,
                    costs, workspace, workspace_bytes, stream_, lse_part, lse_parts, pick);
+}
+
+extern "C" int tfasr_rnnt_loss_packed_coef(const int32_t* labels, const int32_t* label_len, const int32_t* logit_len, const float* grad_scale,
+                                           const long* cell_off, long total_cells, const float* lse_part, int lse_parts, const float* pick, int B,
+                                           int T, int U1, int V, int blank, float* costs, float* coef, void* workspace, size_t workspace_bytes,
+                                           void* stream_) {
+  if (!cell_off || !lse_part || !pick || !coef || lse_parts <= 0) return TFASR_STATUS_INVALID_VALUE;
+  return rnnt_impl(nullptr, nullptr, labels, label_len, logit_len, grad_scale, cell_off, total_cells, B, T, U1, V, blank, TFASR_BF16, costs,
+                   workspace, workspace_bytes, stream_, lse_part, lse_parts, pick, coef);
 }
 
 extern "C" int tfasr_rnnt_row_labels(const int32_t* labels, const int32_t* label_len, const int32_t* logit_len, const long* cell_off,

@@ -122,14 +122,34 @@ def rnnt_loss_packed(logits, labels, label_len, logit_len, cell_off, total_cells
     return costs, (grads if want_grads else None)
 
 
+def rnnt_loss_packed_coef(labels, label_len, logit_len, cell_off, total_cells, T, V, stats, grad_scale=None, blank=0):
+    """The loss WITHOUT logits (joint "recompute" variant): costs [B] and the per-row coefficients [total_cells, 4] f32 from which a
+    re-computed logit tile becomes the gradient (gemm(..., rgrad=(coef, row_label)))."""
+    B, U = labels.shape
+    part, pick = stats
+    costs = torch.empty(B, dtype=torch.float32, device=part.device)
+    coef = torch.empty(total_cells, 4, dtype=torch.float32, device=part.device)
+    ws = workspace(rnnt_loss_workspace_size(1, total_cells, 1, V), part.device, "rnnt")
+    check(_lib.load().tfasr_rnnt_loss_packed_coef(_p(labels), _p(label_len), _p(logit_len), _p(grad_scale), _p(cell_off), total_cells, _p(part),
+                                                  part.shape[1], _p(pick), B, T, U + 1, V, blank, _p(costs), _p(coef), _p(ws), ws.numel(), _stream()),
+          "rnnt_loss_packed_coef")
+    return costs, coef
+
+
 # ---------------------------------------------------------------------------------------------- GEMM
 def gemm(A, B, out, M, N, K, lda, ldb, ldd, trans_a=False, trans_b=False, bias=None, res=None, dact_z=None,
          prez=None, alpha=1.0, beta=1.0, act=ACT_NONE, dact=ACT_NONE, nb1=1, nb2=1, sA=(0, 0), sB=(0, 0), sD=(0, 0),
-         accumulate=False, split_k=1, drop_p=0.0, drop_seed=0, colsum=None, lse=None, seg=None):
+         accumulate=False, split_k=1, drop_p=0.0, drop_seed=0, colsum=None, lse=None, seg=None, rgrad=None):
     """Raw strided (two-level batched) GEMM; see include/tfasr_hip.h.  lse = (lse_part [M, parts, 2] f32, row_label [M] i32,
-    pick [M, 2] f32): fused log-softmax statistics of the output rows (raises TfasrUnsupported when the fast path cannot)."""
+    pick [M, 2] f32): fused log-softmax statistics of the output rows (raises TfasrUnsupported when the fast path cannot); with it
+    `out` may be None (statistics only).  rgrad = (coef [M, 4] f32, row_label [M] i32): the product is a re-computed logit tile and the
+    epilogue stores the RNN-T loss gradient instead (tfasr_gemm_args.rgrad_coef)."""
     a = _gemm_args(A, B, out, M, N, K, lda, ldb, ldd, trans_a, trans_b, bias, res, dact_z, prez, alpha, beta, act, dact, nb1, nb2, sA, sB, sD,
                    accumulate, split_k, drop_p, drop_seed, colsum)
+    if rgrad is not None:
+        coef, row_label = rgrad
+        assert coef.dtype == torch.float32 and coef.is_contiguous() and row_label.dtype == torch.int32
+        a.rgrad_coef, a.row_label = coef.data_ptr(), row_label.data_ptr()
     if seg is not None:  # (seg_a_off i64 device tensor, seg_b_off or None, seg_k): K-segmented operands
         a.seg_a_off, a.seg_b_off, a.seg_k = seg[0].data_ptr(), (seg[1].data_ptr() if seg[1] is not None else None), int(seg[2])
         assert seg[0].dtype == torch.int64 and seg[0].is_cuda
@@ -138,8 +158,8 @@ def gemm(A, B, out, M, N, K, lda, ldb, ldd, trans_a=False, trans_b=False, bias=N
         assert part.dtype == torch.float32 and pick.dtype == torch.float32 and row_label.dtype == torch.int32
         a.lse_part, a.lse_parts, a.row_label, a.pick = part.data_ptr(), part.shape[1], row_label.data_ptr(), pick.data_ptr()
     st = _lib.load().tfasr_gemm(ctypes.byref(a), _stream())
-    if (lse is not None or seg is not None) and st == _lib.STATUS_UNSUPPORTED:
-        raise _lib.TfasrUnsupported("gemm: fused row statistics / K-segments are not available for this product")
+    if (lse is not None or seg is not None or rgrad is not None) and st == _lib.STATUS_UNSUPPORTED:
+        raise _lib.TfasrUnsupported("gemm: fused row statistics / K-segments / gradient epilogue are not available for this product")
     check(st, "gemm")
     return out
 
@@ -157,7 +177,7 @@ def _gemm_args(A, B, out, M, N, K, lda, ldb, ldd, trans_a=False, trans_b=False, 
                prez=None, alpha=1.0, beta=1.0, act=ACT_NONE, dact=ACT_NONE, nb1=1, nb2=1, sA=(0, 0), sB=(0, 0), sD=(0, 0),
                accumulate=False, split_k=1, drop_p=0.0, drop_seed=0, colsum=None):
     a = GemmArgs()
-    a.A, a.B, a.D = A.data_ptr(), B.data_ptr(), out.data_ptr()
+    a.A, a.B, a.D = A.data_ptr(), B.data_ptr(), (out.data_ptr() if out is not None else None)
     a.bias = bias.data_ptr() if bias is not None else None
     a.res = res.data_ptr() if res is not None else None
     a.dact_z = dact_z.data_ptr() if dact_z is not None else None
@@ -170,8 +190,8 @@ def _gemm_args(A, B, out, M, N, K, lda, ldb, ldd, trans_a=False, trans_b=False, 
     a.alpha, a.beta = alpha, beta
     a.act, a.dact = act, dact
     a.dtype = _dt(A)
-    assert B.dtype == A.dtype and A.is_cuda and B.is_cuda and out.is_cuda
-    a.out_f32 = int(out.dtype == torch.float32)
+    assert B.dtype == A.dtype and A.is_cuda and B.is_cuda and (out is None or out.is_cuda)
+    a.out_f32 = int(out is not None and out.dtype == torch.float32)
     a.accumulate = int(accumulate)
     a.split_k = split_k
     a.drop_p, a.drop_seed = drop_p, drop_seed

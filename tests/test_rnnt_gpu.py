@@ -225,3 +225,90 @@ def test_joint_projection_epilogue_statistics_feed_the_loss(dev, V):
     np.testing.assert_allclose(c_stats.cpu().numpy(), ref_loss, rtol=2e-4)       # f32 statistics: closer to the oracle than ...
     np.testing.assert_allclose(c_plain.cpu().numpy(), ref_loss, rtol=3e-3)       # ... statistics of the bf16-rounded logits
     np.testing.assert_allclose(g_stats.float().cpu().numpy(), g_plain.float().cpu().numpy(), rtol=5e-2, atol=2e-3)
+
+
+def test_joint_recompute_variant_without_materialised_logits(dev):
+    """SURVEY section 7 step 8 / 8(d) "recompute" variant of the joint + loss: the vocabulary projection emits ONLY the log-softmax
+    statistics (D = NULL), tfasr_rnnt_loss_packed_coef turns the lattice into per-row coefficients, and a second projection re-computes
+    the logit tile and stores the loss gradient from its epilogue (tfasr_gemm_args.rgrad_coef).  Against the materialised route (same
+    costs bit for bit - both read the statistics of the f32 accumulators - gradients equal up to the bf16 rounding of the stored
+    logits) and against the f64 oracle on the f32 product."""
+    from tensorflowasr_amd import kernels as K
+
+    rng = np.random.default_rng(3)
+    B, T, U, V, J = 6, 120, 60, 1000, 128
+    tl = np.array([120, 97, 120, 60, 111, 120], np.int32)
+    ul = np.array([60, 31, 0, 60, 45, 59], np.int32)
+    labels = rng.integers(1, V, (B, U)).astype(np.int32)
+    off = np.zeros(B + 1, np.int64)
+    off[1:] = np.cumsum(tl.astype(np.int64) * (ul + 1))
+    total = int(off[-1])
+    assert total >= 32768  # enough 256 x 256 tiles for the 256-row kernel (2 per CU)
+    g = torch.Generator().manual_seed(1)
+    h = torch.tanh(torch.randn(total, J, generator=g)).to(dev).to(torch.bfloat16)
+    W = (torch.randn(J, V, generator=g) * 0.25).to(dev).to(torch.bfloat16)
+    bias = (torch.randn(V, generator=g) * 0.5).to(dev)
+    scale = torch.from_numpy(rng.uniform(0.5, 2, B).astype(np.float32)).to(dev)
+    d = lambda a: torch.from_numpy(a).to(dev)
+    lab_d, ul_d, tl_d, off_d = d(labels), d(ul), d(tl), d(off)
+    row_label = K.rnnt_row_labels(lab_d, ul_d, tl_d, off_d, total, T, V)
+    parts = -(-V // 128) * 2
+
+    def stats_buffers():
+        return torch.empty(total, parts, 2, dtype=torch.float32, device=dev), torch.empty(total, 2, dtype=torch.float32, device=dev)
+
+    # materialised route
+    part_a, pick_a = stats_buffers()
+    logits = torch.empty(total, V, dtype=torch.bfloat16, device=dev)
+    K.gemm(h, W, logits, total, V, J, J, V, V, bias=bias, lse=(part_a, row_label, pick_a))
+    costs_a, g_a = K.rnnt_loss_packed(logits, lab_d, ul_d, tl_d, off_d, total, T, grad_scale=scale, stats=(part_a, pick_a))
+    # recompute route: no logits tensor at all
+    part_b, pick_b = stats_buffers()
+    K.gemm(h, W, None, total, V, J, J, V, V, bias=bias, lse=(part_b, row_label, pick_b))
+    costs_b, coef = K.rnnt_loss_packed_coef(lab_d, ul_d, tl_d, off_d, total, T, V, (part_b, pick_b), grad_scale=scale)
+    g_b = torch.full((total, V), float("nan"), dtype=torch.bfloat16, device=dev)
+    K.gemm(h, W, g_b, total, V, J, J, V, V, bias=bias, rgrad=(coef, row_label))
+    torch.cuda.synchronize()
+    assert torch.equal(part_a, part_b) and torch.equal(pick_a, pick_b)
+    np.testing.assert_array_equal(costs_a.cpu().numpy(), costs_b.cpu().numpy())
+    ga, gb = g_a.float().cpu().numpy(), g_b.float().cpu().numpy()
+    assert np.isfinite(gb).all()
+    # oracle on the f32 product of the bf16 operands (dense lattice rebuilt from the packed rows)
+    x = (h.float() @ W.float() + bias).cpu().numpy()
+    dense = np.zeros((B, T, U + 1, V), np.float32)
+    for b in range(B):
+        dense[b, :tl[b], :ul[b] + 1] = x[off[b]:off[b + 1]].reshape(tl[b], ul[b] + 1, V)
+    ref_loss, ref_g = rnnt_ref.rnnt_loss_and_grad(dense, labels, ul, tl)
+    ref_gp = np.concatenate([ref_g[b, :tl[b], :ul[b] + 1].reshape(-1, V) for b in range(B)]) * np.repeat(scale.cpu().numpy(), np.diff(off))[:, None]
+    np.testing.assert_allclose(costs_b.cpu().numpy(), ref_loss, rtol=2e-4)
+    den = np.linalg.norm(ref_gp)
+    ea, eb = np.linalg.norm(ga - ref_gp) / den, np.linalg.norm(gb - ref_gp) / den
+    print(f"\n[joint recompute] gradient rel. L2 error vs the f64 oracle: materialised {ea:.3e}, recompute {eb:.3e}")
+    assert eb < 5e-3 and eb <= ea * 1.05  # the recompute route sees unrounded logits: at least as accurate
+
+
+def test_joint_recompute_variant_in_the_train_step(dev, monkeypatch):
+    """TFASR_JOINT_RECOMPUTE=1 on a model whose lattice is large enough for the 256-row kernel: same losses, same gradients (bf16 noise)."""
+    from tensorflowasr_amd import configs
+    from tensorflowasr_amd.conformer import ConformerTransducer
+    from tensorflowasr_amd.schemas import TrainData, TrainInput, TrainLabel
+
+    cfg = configs.conformer_tiny(vocab_size=1000, joint_dim=128, dropout=0.0, time_masking={}, freq_masking={})
+    rng = np.random.default_rng(0)
+    B, N, U = 8, 64000, 50
+    sig = (rng.standard_normal((B, N)) * 0.1).astype(np.float32)
+    labels = rng.integers(1, 1000, (B, U)).astype(np.int32)
+    preds = np.concatenate([np.zeros((B, 1), np.int32), labels], 1)
+    data = TrainData(TrainInput(torch.from_numpy(sig), torch.full((B,), N, dtype=torch.int32), torch.from_numpy(preds), torch.full((B,), U + 1, dtype=torch.int32)),
+                     TrainLabel(torch.from_numpy(labels), torch.full((B,), U, dtype=torch.int32)))
+    out = {}
+    for flag in (False, True):
+        m = ConformerTransducer(cfg, dev, dtype=torch.bfloat16, seed=0)
+        m.joint_recompute = flag
+        m.zero_grad()
+        costs = m.loss_and_backward(data, True, (None, None)).float().cpu().numpy()
+        torch.cuda.synchronize()
+        out[flag] = (costs, m.ps.grad.clone().cpu())
+    np.testing.assert_allclose(out[True][0], out[False][0], rtol=1e-5)
+    a, b = out[True][1].double(), out[False][1].double()
+    assert not torch.equal(a, b) and float((a - b).norm() / b.norm()) < 2e-2
