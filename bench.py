@@ -90,7 +90,7 @@ def pmc_traffic(flops_per_launch, J, V):
     the figure is looked up: the forward vocabulary projection is the plain NN gemm_fast launch whose WRITE_SIZE equals its
     output (cells x V bf16) - no other launch of the step writes that much from that kernel.  None if it was not profiled."""
     here = os.path.dirname(os.path.abspath(__file__))
-    path = next((q for q in (os.path.join(here, "profiles", f) for f in ("r02_pmc_traffic.json", "r01_pmc_traffic.json")) if os.path.exists(q)), None)
+    path = next((q for q in (os.path.join(here, "profiles", f) for f in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")) if os.path.exists(q)), None)
     if path is None:
         return None
     rows = json.load(open(path))
@@ -303,7 +303,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--model", default="M", choices=["M", "S", "contextnet"], help="M / S = Conformer sizes; contextnet = BASELINE configs[3] family")
+    ap.add_argument("--model", default="M", choices=["M", "S", "S-streaming", "contextnet"],
+                    help="M / S = Conformer sizes; S-streaming = small-streaming.yml.j2 (chunk 16 / history 64, LayerNorm depthwise norm); contextnet = BASELINE configs[3] family")
     ap.add_argument("--alpha", type=float, default=2.0, help="ContextNet width multiplier (0.5 small, 1 medium, 2 large)")
     ap.add_argument("--batch", type=int, default=32, help="utterances per GPU")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
@@ -352,6 +353,8 @@ def main():
         cfg = configs.contextnet(alpha=args.alpha)
     else:
         cfg = configs.conformer_m() if args.model == "M" else configs.conformer_s()
+        if args.model == "S-streaming":  # examples/models/transducer/conformer/small-streaming.yml.j2:26,33,38-39
+            cfg = configs.conformer_s(chunk_size=16, history_size=64, convm_dw_norm="layer")
     if args.no_specaugment:
         cfg.time_masking, cfg.freq_masking = {}, {}
     if args.dropout is not None:
@@ -371,7 +374,7 @@ def main():
         dp.attach(model.ps.grad)
     if args.mode == "decode":
         return bench_decode(args, model, cfg, dev)
-    size = args.workload or ("S-10s" if args.model == "S" else "LibriSpeech-shaped")
+    size = args.workload or ("S-10s" if args.model.startswith("S") else "LibriSpeech-shaped")
     # a few distinct batches per rank, resident in HBM before the timed region
     nb = 2
     # weak scaling with the per-GPU work EXACTLY fixed: every rank runs the same synthetic shard shapes (same seeds), so padded
@@ -438,6 +441,7 @@ def main():
             roof = {"kernel": "gemm_big_kernel<false, 256, E_LSE> (joint vocabulary projection + log-softmax statistics, fwd)", "bound": "mfma", "achieved": round(ach, 2), "peak": peak,
                     "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                     "traffic": pmc_traffic(model.timer_work["joint_vocab_gemm"], cfg.joint_dim, cfg.vocab_size),
+                    "traffic_source": "looked up from the committed rocprofv3 PMC passes of this command (profiles/r0*_pmc_traffic.json), not measured in this run",
                     "ms_per_launch": round(ms, 4)}
             # whole-step view (north_star asks for the step's fraction of the MFMA roofline as well): matrix-core flop of
             # the step / step time; mean over the batches the timed region cycles through
@@ -492,10 +496,41 @@ def main():
                 del rd, rb
             except Exception as e:  # the headline number must still be reported
                 out["reference_padding"] = {"value": None, "error": repr(e)[:200]}
+        if world == 1 and not args.no_extras and args.model in ("M", "S") and not stub and dtype == torch.bfloat16:
+            # SURVEY section 8(d) "report both": the joint + loss WITHOUT materialised lattice logits (statistics-only projection, gradient
+            # epilogue on a re-computed logit tile; TFASR_JOINT_RECOMPUTE=1) next to the default materialised route, same batches
+            try:
+                model.joint_recompute = True
+                model.timers, model.timer_work = {}, {}
+                for i in range(2):
+                    one_step(i)
+                model.timers, model.timer_work = {}, {}
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                nrec = 10
+                for i in range(nrec):
+                    one_step(i)
+                torch.cuda.synchronize()
+                dtq = (time.perf_counter() - t1) / nrec
+                tj, tr = model.timers.get("joint_vocab_gemm") or [], model.timers.get("rnnt_loss") or []
+                by = float(np.mean(model.timer_work["rnnt_loss"])) if tr else 0.0
+                msr = float(np.mean([a.elapsed_time(b) for a, b in tr])) if tr else None
+                out["joint_recompute_variant"] = {
+                    "ms_per_step": round(dtq * 1e3, 3), "steps": nrec,
+                    "projection_statistics_only_ms": round(float(np.mean([a.elapsed_time(b) for a, b in tj])), 4) if tj else None,
+                    "loss_and_gradient_pass_ms": round(msr, 4) if msr else None,
+                    "algorithmic_bytes": by, "achieved_GBps": round(by / (msr * 1e-3) / 1e9, 1) if msr else None,
+                    "note": "no [cells, V] logits in HBM: the gradient tensor is written once by the epilogue of a re-computed vocabulary product "
+                            "(one more matrix product instead of two passes over the tensor); default = the materialised route of the headline line"}
+            except Exception as e:
+                out["joint_recompute_variant"] = {"value": None, "error": repr(e)[:200]}
+            finally:
+                model.joint_recompute = False
+                model.timers = None
         if not args.no_cpu_baseline and world == 1 and not stub:
             try:
                 if args.model != "contextnet":  # the CPU port baseline is the Conformer oracle
-                    out["cpu_baseline"] = cpu_baseline(size if args.model == "S" else "M", cfg.vocab_size)
+                    out["cpu_baseline"] = cpu_baseline(size if args.model.startswith("S") else "M", cfg.vocab_size)
             except Exception as e:  # the GPU number must still be reported
                 out["cpu_baseline"] = {"value": None, "error": repr(e)}
         print(json.dumps(out))

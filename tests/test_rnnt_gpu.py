@@ -236,8 +236,8 @@ def test_joint_recompute_variant_without_materialised_logits(dev):
     from tensorflowasr_amd import kernels as K
 
     rng = np.random.default_rng(3)
-    B, T, U, V, J = 6, 120, 60, 1000, 128
-    tl = np.array([120, 97, 120, 60, 111, 120], np.int32)
+    B, T, U, V, J = 6, 150, 60, 1000, 128
+    tl = np.array([150, 120, 150, 75, 140, 150], np.int32)
     ul = np.array([60, 31, 0, 60, 45, 59], np.int32)
     labels = rng.integers(1, V, (B, U)).astype(np.int32)
     off = np.zeros(B + 1, np.int64)
@@ -269,7 +269,8 @@ def test_joint_recompute_variant_without_materialised_logits(dev):
     g_b = torch.full((total, V), float("nan"), dtype=torch.bfloat16, device=dev)
     K.gemm(h, W, g_b, total, V, J, J, V, V, bias=bias, rgrad=(coef, row_label))
     torch.cuda.synchronize()
-    assert torch.equal(part_a, part_b) and torch.equal(pick_a, pick_b)
+    has = row_label >= 0  # (pick[:, 1] is untouched where a row has no label)
+    assert torch.equal(part_a, part_b) and torch.equal(pick_a[:, 0], pick_b[:, 0]) and torch.equal(pick_a[has, 1], pick_b[has, 1])
     np.testing.assert_array_equal(costs_a.cpu().numpy(), costs_b.cpu().numpy())
     ga, gb = g_a.float().cpu().numpy(), g_b.float().cpu().numpy()
     assert np.isfinite(gb).all()
@@ -309,6 +310,6 @@ def test_joint_recompute_variant_in_the_train_step(dev, monkeypatch):
         costs = m.loss_and_backward(data, True, (None, None)).float().cpu().numpy()
         torch.cuda.synchronize()
         out[flag] = (costs, m.ps.grad.clone().cpu())
-    np.testing.assert_allclose(out[True][0], out[False][0], rtol=1e-5)
+    np.testing.assert_allclose(out[True][0], out[False][0], rtol=2e-3)  # (two forward passes: BatchNorm statistics are atomic sums, bf16 activations)
     a, b = out[True][1].double(), out[False][1].double()
     assert not torch.equal(a, b) and float((a - b).norm() / b.norm()) < 2e-2
