@@ -9,6 +9,7 @@
 #include "common.h"
 #include <algorithm>
 #include <cmath>
+#include <unordered_map>
 #include <vector>
 
 namespace {
@@ -40,6 +41,10 @@ extern "C" int tfasr_ctc_beam_search_host(const float* logits, const int32_t* lo
   std::vector<float> ext_pb;     // [nb][V] blank-ending probability of that same prefix when it is ALSO a current beam
   std::vector<Cand> cand;
   std::vector<int32_t> pa, pc;
+  // (parent node, label) -> node, for the whole utterance: a label sequence has exactly ONE node, also when a prefix drops out of the
+  // beam and is re-created later from its parent while one of its own extensions stayed (their probability mass must merge, as in
+  // TensorFlow's beam-entry children map)
+  std::unordered_map<uint64_t, int> child;
   auto prefix_of = [&](int node, std::vector<int32_t>& out) {
     out.clear();
     for (int n = node; n > 0; n = trie[n].parent) out.push_back(trie[n].label);
@@ -48,6 +53,7 @@ extern "C" int tfasr_ctc_beam_search_host(const float* logits, const int32_t* lo
   for (int b = 0; b < B; ++b) {
     const int Tb = std::min(std::max(logit_len[b], 0), T);
     trie.clear();
+    child.clear();
     trie.push_back(Node{-1, -1, 0});  // node 0 = the empty prefix
     beams.assign(1, Beam{0, 0.f, NEG_INF});
     for (int t = 0; t < Tb; ++t) {
@@ -121,16 +127,17 @@ extern "C" int tfasr_ctc_beam_search_host(const float* logits, const int32_t* lo
           next.push_back(Beam{bm.node, ptot + lp[blank_index], nd.parent >= 0 ? bm.pnb + lp[nd.label] : NEG_INF});
         } else {
           const size_t k = (size_t)cd.src * V + cd.label;
-          // the extended prefix may already be a node (when it was itself a beam): reuse it
-          int node = -1;
-          for (int i = 0; i < nb && node < 0; ++i) {
-            const Node& nd = trie[beams[i].node];
-            if (merged_into[i] == cd.src && nd.label == cd.label) node = beams[i].node;
-          }
-          if (node < 0) {
-            const int par = beams[cd.src].node;
+          // the extended prefix may already be a node (it is a beam now, or was one earlier): reuse it
+          const int par = beams[cd.src].node;
+          const uint64_t key = (uint64_t)par * (uint64_t)V + (uint64_t)cd.label;
+          int node;
+          auto it = child.find(key);
+          if (it != child.end()) {
+            node = it->second;
+          } else {
             trie.push_back(Node{par, cd.label, trie[par].depth + 1});
             node = (int)trie.size() - 1;
+            child.emplace(key, node);
           }
           next.push_back(Beam{node, ext_pb[k], ext[k]});
         }

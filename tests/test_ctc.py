@@ -126,5 +126,14 @@ def test_ctc_beam_search_host_routine_matches_oracle_and_bruteforce():
             lab, p = ctc_ref.ctc_beam_search(x[b], Tb, beam, 11)
             assert toks[b, :n[b]].tolist() == lab, (beam, b)
             assert abs(lp[b] - p) < 1e-3
+    # small alphabets + narrow beams + many frames: prefixes drop out of the beam and come back while their extensions stayed (ADVICE r02:
+    # a label sequence must keep ONE trie node for the whole utterance, or its probability mass splits); 300 random utterances
+    x = rng.standard_normal((300, 14, 3)) * 1.5
+    for beam in (2, 3):
+        toks, n, lp = run(x, [14] * 300, beam, 0)
+        for b in range(300):
+            lab, p = ctc_ref.ctc_beam_search(x[b], 14, beam, 0)
+            assert toks[b, :n[b]].tolist() == lab, (beam, b)
+            assert abs(lp[b] - p) < 1e-3
     # argument checking
     assert lib.tfasr_ctc_beam_search_host(None, None, 1, 1, 2, 1, 0, None, None, None) != 0
