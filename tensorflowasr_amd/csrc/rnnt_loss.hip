@@ -159,30 +159,38 @@ __global__ __launch_bounds__(256) void rnnt_stats_finalize_kernel(const float2* 
                                                                   const int32_t* __restrict__ label_len, const int32_t* __restrict__ logit_len,
                                                                   const long* __restrict__ cell_off, long nrows, int B, int Tm, int U1,
                                                                   float* __restrict__ lse, float* __restrict__ blank_lp, float* __restrict__ truth_lp) {
+  if (nparts == 16) {
+    // V = 1000: a row's 16 (max, sum) pairs are 128 contiguous bytes.  SIXTEEN LANES PER ROW, one pair each: a wave reads 4 rows = 512
+    // contiguous bytes per instruction, the merge is two DPP row reductions.  (One thread per row - 8 x 16-byte loads 128 bytes apart
+    // across the lanes - touched 64 cache lines per instruction: 115 us and 0.7 GB fetched for 47 MB of statistics, rocprofv3 PMC.)
+    const int li = threadIdx.x & 15;
+    const long g0 = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 4, gs = ((long)gridDim.x * blockDim.x) >> 4;
+    const long nr16 = (nrows + gs - 1) / gs * gs;  // every lane of a row group runs the same trip count (DPP needs the whole row active)
+    for (long r = g0; r < nr16; r += gs) {
+      const bool in = r < nrows;
+      const float2 v = in ? part[r * 16 + li] : make_float2(-INFINITY, 0.f);
+      const float mx = row16_max(v.x);
+      const float sm = row16_sum(v.y > 0.f ? v.y * __expf(v.x - mx) : 0.f);  // an empty slice is (-inf, 0)
+      if (in && li == 0) {
+        const Cell cl = locate(r, cell_off, B, Tm, U1, label_len, logit_len);
+        if (cl.valid) {
+          const float l = mx + logf(sm);
+          const float2 pk = *reinterpret_cast<const float2*>(pick + 2 * r);
+          lse[r] = l;
+          blank_lp[r] = pk.x - l;
+          truth_lp[r] = (cl.u < cl.Ul) ? pk.y - l : -INFINITY;
+        }
+      }
+    }
+    return;
+  }
   for (long r = (long)blockIdx.x * blockDim.x + threadIdx.x; r < nrows; r += (long)gridDim.x * blockDim.x) {
     const Cell cl = locate(r, cell_off, B, Tm, U1, label_len, logit_len);
     if (!cl.valid) continue;
     RowStat st{-INFINITY, 0.f};
-    if (nparts == 16) {  // V = 1000: the row's 128 bytes as eight independent 16-byte loads, not sixteen dependent 8-byte ones
-      float4 q[8];
-      const float4* p4 = reinterpret_cast<const float4*>(part + r * 16);
-#pragma unroll
-      for (int c = 0; c < 8; ++c) q[c] = p4[c];
-      float mx = -INFINITY;
-#pragma unroll
-      for (int c = 0; c < 8; ++c) mx = fmaxf(mx, fmaxf(q[c].x, q[c].z));
-      float sm = 0.f;
-#pragma unroll
-      for (int c = 0; c < 8; ++c) {  // sum of s_c * exp(m_c - mx); an empty slice is (-inf, 0)
-        sm += (q[c].y > 0.f ? q[c].y * __expf(q[c].x - mx) : 0.f) + (q[c].w > 0.f ? q[c].w * __expf(q[c].z - mx) : 0.f);
-      }
-      st.m = mx;
-      st.s = sm;
-    } else {
-      for (int c = 0; c < nparts; ++c) {
-        const float2 v = part[r * nparts + c];
-        online_merge(st, v.x, v.y);
-      }
+    for (int c = 0; c < nparts; ++c) {
+      const float2 v = part[r * nparts + c];
+      online_merge(st, v.x, v.y);
     }
     const float l = st.m + logf(st.s);
     lse[r] = l;
@@ -430,7 +438,7 @@ static int rnnt_impl(const void* logits, void* grads, const int32_t* labels, con
   const int wpb = 4;
   int grid = (int)std::min<long>((nrows + wpb - 1) / wpb, 256L * 32);
   if (lse_part) {
-    const int fg = (int)std::min<long>((nrows + 255) / 256, 256L * 8);
+    const int fg = (int)std::min<long>(((lse_parts == 16 ? nrows * 16 : nrows) + 255) / 256, 256L * 16);
     hipLaunchKernelGGL(rnnt_stats_finalize_kernel, dim3(fg), dim3(256), 0, stream, (const float2*)lse_part, lse_parts, pick, label_len, logit_len,
                        cell_off, nrows, B, T, U1, lse, blank_lp, truth_lp);
   } else if (dtype == TFASR_F32)
