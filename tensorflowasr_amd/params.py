@@ -23,10 +23,22 @@ def head_padded(name):
     return name.endswith(("mhsa/qkv/w", "mhsa/qkv/b", "mhsa/pos/w", "mhsa/pos/b", "mhsa/o/w", "mhsa/u", "mhsa/v")) or name in ("enc/u", "enc/v")
 
 
-def param_specs(cfg, head_phys=None):
+_CHAN = ("enc/sub/conv0/w", "enc/sub/conv0/b", "enc/sub/bn0/g", "enc/sub/bn0/b", "enc/sub/conv1/w", "enc/sub/conv1/b", "enc/sub/bn1/g",
+         "enc/sub/bn1/b", "enc/linear/w", "enc/sub/bn0/mm", "enc/sub/bn0/mv", "enc/sub/bn1/mm", "enc/sub/bn1/mv")
+
+
+def chan_padded(name):
+    """variables (and BatchNorm state) that carry the subsampling's channel dimension (physically padded to a multiple of 64 in bf16
+    models, see ParamStore)"""
+    return name in _CHAN
+
+
+def param_specs(cfg, head_phys=None, filt_phys=None):
     """[(name, shape, regularized, init)] in forward order. init in {glorot, zeros, ones, embed, orth, lstm_bias}.
-    head_phys: physical (stored) head dimension of the attention variables, >= cfg.head_size (ParamStore: zero padding)."""
-    d, H, dh, C = cfg.dmodel, cfg.num_heads, cfg.head_size, cfg.filters
+    head_phys: physical (stored) head dimension of the attention variables, >= cfg.head_size (ParamStore: zero padding);
+    filt_phys: physical channel count of the convolutional subsampling, >= cfg.filters (glorot fans stay the reference's)."""
+    d, H, dh, Cl = cfg.dmodel, cfg.num_heads, cfg.head_size, cfg.filters
+    C = filt_phys or Cl
     Kk, V, E, P, J = cfg.kernel_size, cfg.vocab_size, cfg.embed_dim, cfg.rnn_units, cfg.joint_dim
     F2 = -(-(-(-cfg.num_feature_bins // 2)) // 2)
     HD = H * (head_phys or dh)
@@ -38,15 +50,15 @@ def param_specs(cfg, head_phys=None):
     if getattr(cfg, "encoder", "conformer") == "contextnet":
         contextnet_specs(cfg, add)
         return _tail_specs(cfg, add, s)
-    add("enc/sub/conv0/w", (3, 3, 1, C), True, "glorot", (9, 9 * C))
+    add("enc/sub/conv0/w", (3, 3, 1, C), True, "glorot", (9, 9 * Cl))
     add("enc/sub/conv0/b", (C,), False, "zeros")
     add("enc/sub/bn0/b", (C,), True, "zeros")
     add("enc/sub/bn0/g", (C,), True, "ones")
-    add("enc/sub/conv1/w", (3, 3, C, C), True, "glorot", (9 * C, 9 * C))
+    add("enc/sub/conv1/w", (3, 3, C, C), True, "glorot", (9 * Cl, 9 * Cl))
     add("enc/sub/conv1/b", (C,), False, "zeros")
     add("enc/sub/bn1/b", (C,), True, "zeros")
     add("enc/sub/bn1/g", (C,), True, "ones")
-    add("enc/linear/w", (F2 * C, d), True, "glorot")
+    add("enc/linear/w", (F2 * C, d), True, "glorot", (F2 * Cl, d))
     add("enc/linear/b", (d,), False, "zeros")
     per_layer_bias = bool(getattr(cfg, "mhsam_use_attention_bias", False))
     if not per_layer_bias:
@@ -143,19 +155,28 @@ def bn_names(cfg):
 class ParamStore:
     ALIGN = 64  # elements; keeps every variable 256-B aligned in f32 and 128-B aligned in bf16
 
-    def __init__(self, cfg, device, dtype, seed=0, head_phys=None):
+    def __init__(self, cfg, device, dtype, seed=0, head_phys=None, filt_phys=None):
         """head_phys: PHYSICAL head dimension of the attention variables (q/k/v/position projections, output projection rows, u / v
         biases).  A bf16 model whose heads are narrower than the fused attention kernels' 64 (the reference ships head 36 and 44:
         small.yml.j2:39, ctc/conformer/small.yml.j2:39) stores those variables zero-padded to 64 per head: the padded q / k / v /
         position columns are exactly zero, so every score, probability and context value is unchanged, the padded context columns are
         zero, and every gradient into a padded element is exactly zero (dq_pad = dS k_pad = 0, dk_pad = dS^T q_pad = 0,
         dv_pad = P^T (dy Wo_pad^T) = 0), so Adam / L2 / weight decay leave the padding at zero forever.  import_keras / export_keras
-        speak the reference's (unpadded) layouts; the softmax scale stays 1 / sqrt(cfg.head_size)."""
+        speak the reference's (unpadded) layouts; the softmax scale stays 1 / sqrt(cfg.head_size).
+        filt_phys: PHYSICAL channel count of Conv2dSubsampling (subsampling.py:163-254).  The K-segmented conv2 GEMMs over the haloed
+        space-to-depth layout need whole 64-channel slabs; the reference's small model has 144 filters (small.yml.j2:27), stored here as
+        192 with zero weights / biases / BatchNorm gamma and beta in the padded channels: those channels carry exact zeros forward
+        (conv of zero weights, x_hat = 0, swish(0) = 0) and exact zero gradients backward (every path into them multiplies a zero
+        activation or a zero weight), so they stay zero; the linear layer's padded input rows are zero as well."""
         self.cfg, self.device, self.dtype = cfg, device, dtype
         self.head_phys = int(head_phys or cfg.head_size)
         if self.head_phys < cfg.head_size:
             raise ValueError("head_phys must be >= head_size")
-        specs = param_specs(cfg, self.head_phys)
+        conformer = getattr(cfg, "encoder", "conformer") == "conformer"
+        self.filt_phys = int(filt_phys or cfg.filters) if conformer else int(cfg.filters)
+        if self.filt_phys < cfg.filters:
+            raise ValueError("filt_phys must be >= filters")
+        specs = param_specs(cfg, self.head_phys, self.filt_phys)
         ordered = [x for x in specs if x[2]] + [x for x in specs if not x[2]]
         self.offsets, self.shapes = {}, {}
         off = 0
@@ -174,11 +195,12 @@ class ParamStore:
         self.adam_v = torch.zeros(self.n, dtype=torch.float32, device=device)
         self.shadow = self.flat if dtype == torch.float32 else torch.zeros(self.n, dtype=dtype, device=device)
         # non-trainable BatchNorm moving statistics (keras: moving_mean zeros, moving_variance ones)
-        self.state = {}
+        self.state, self.shapes_state = {}, {}
         for nm in bn_names(cfg):
             C = self.shapes[nm + "/g"][0]
             self.state[nm + "/mm"] = torch.zeros(C, dtype=torch.float32, device=device)
             self.state[nm + "/mv"] = torch.ones(C, dtype=torch.float32, device=device)
+            self.shapes_state[nm + "/mm"] = self.shapes_state[nm + "/mv"] = (C,)
         self._init(ordered, seed)
         self.refresh_shadow()
 
@@ -237,8 +259,33 @@ class ParamStore:
             return t.reshape(H, dh, d)
         return t.reshape(H, dh)  # pos/b, u, v
 
+    def _chan_view(self, t, name, C):
+        """view of a subsampling variable with its channel axes explicit (C = physical or logical channel count)"""
+        if name == "enc/sub/conv0/w":
+            return t.reshape(3, 3, 1, C)
+        if name == "enc/sub/conv1/w":
+            return t.reshape(3, 3, C, C)
+        if name == "enc/linear/w":
+            return t.reshape(-1, C, self.cfg.dmodel)  # rows = (ff, c): math_util.merge_two_last_dims
+        return t.reshape(C)
+
+    def _chan_axes(self, name):
+        return {"enc/sub/conv0/w": (3,), "enc/sub/conv1/w": (2, 3), "enc/linear/w": (1,)}.get(name, (0,))
+
     def _pad_heads(self, name, t):
-        """logical layout (head dim cfg.head_size) -> stored layout (head dim head_phys, zero padded)"""
+        """logical layout (head dim cfg.head_size, cfg.filters channels) -> stored layout (head_phys / filt_phys, zero padded)"""
+        Cl, Cp = self.cfg.filters, self.filt_phys
+        if Cp != Cl and chan_padded(name):
+            v = self._chan_view(t, name, Cl)
+            shp = list(v.shape)
+            for ax in self._chan_axes(name):
+                shp[ax] = Cp
+            out = torch.zeros(shp, dtype=v.dtype, device=v.device)
+            sl = out
+            for ax in self._chan_axes(name):
+                sl = sl.narrow(ax, 0, Cl)
+            sl.copy_(v)
+            return out.reshape(self.shapes[name] if name in self.shapes else self.shapes_state[name])
         dh, dp = self.cfg.head_size, self.head_phys
         if dp == dh or not head_padded(name):
             return t
@@ -251,6 +298,13 @@ class ParamStore:
         return out.reshape(self.shapes[name])
 
     def _unpad_heads(self, name, t):
+        Cl, Cp = self.cfg.filters, self.filt_phys
+        if Cp != Cl and chan_padded(name):
+            v = self._chan_view(t, name, Cp)
+            for ax in self._chan_axes(name):
+                v = v.narrow(ax, 0, Cl)
+            v = v.contiguous()
+            return v.reshape(-1, self.cfg.dmodel) if name == "enc/linear/w" else v
         dh, dp = self.cfg.head_size, self.head_phys
         if dp == dh or not head_padded(name):
             return t
@@ -268,13 +322,18 @@ class ParamStore:
     def rezero_head_pads(self, buf=None):
         """restore the zero padding of `buf` (default: the master parameters) after something wrote whole-buffer noise into it"""
         dh, dp = self.cfg.head_size, self.head_phys
-        if dp == dh:
+        Cl, Cp = self.cfg.filters, self.filt_phys
+        if dp == dh and Cp == Cl:
             return
         buf = self.flat if buf is None else buf
         for name in self.names:
-            if head_padded(name):
+            if dp != dh and head_padded(name):
                 v = self._head_view(self._view(buf, name), name, dp)
                 v.narrow(1 if name.endswith("o/w") else v.dim() - 1, dh, dp - dh).zero_()
+            if Cp != Cl and chan_padded(name):
+                v = self._chan_view(self._view(buf, name), name, Cp)
+                for ax in self._chan_axes(name):
+                    v.narrow(ax, Cl, Cp - Cl).zero_()
 
     def refresh_shadow(self):
         if self.shadow is not self.flat:
@@ -282,7 +341,7 @@ class ParamStore:
 
     def num_trainable(self):
         """number of trainable variables' elements in the REFERENCE's layouts (the zero padding of the heads is not a parameter)"""
-        if self.head_phys != self.cfg.head_size:
+        if self.head_phys != self.cfg.head_size or self.filt_phys != self.cfg.filters:
             return sum(int(np.prod(x[1])) for x in param_specs(self.cfg))
         return sum(int(np.prod(s)) for s in self.shapes.values())
 
@@ -290,7 +349,7 @@ class ParamStore:
     def _init(self, ordered, seed):
         rng = np.random.default_rng(seed)
         host = np.zeros(self.n, np.float32)
-        logical = {x[0]: x[1] for x in param_specs(self.cfg)} if self.head_phys != self.cfg.head_size else {}
+        logical = {x[0]: x[1] for x in param_specs(self.cfg)} if (self.head_phys != self.cfg.head_size or self.filt_phys != self.cfg.filters) else {}
         for name, shape, reg, init, fans in ordered:
             n = int(np.prod(shape))
             stored = shape
@@ -342,7 +401,7 @@ class ParamStore:
         self.flat.copy_(host)
         for k in self.state:
             if k in W:
-                self.state[k].copy_(torch.as_tensor(W[k]).float())
+                self.state[k].copy_(self._pad_heads(k, torch.as_tensor(W[k]).detach().float().cpu()))
         self.refresh_shadow()
 
     def export_keras(self, buf=None):
@@ -370,5 +429,5 @@ class ParamStore:
                 out[name] = t.clone()
         if buf is self.flat:
             for k, v in self.state.items():
-                out[k] = v.detach().cpu().clone()
+                out[k] = self._unpad_heads(k, v.detach().cpu().clone())
         return out

@@ -144,6 +144,12 @@ def test_other_shipped_configs_build_compile_and_step(dev, key, cls):
     assert np.isfinite(model.test_step(data)["loss"].cpu().numpy()).all()
 
 
+def a_shape_ok(padded, plain):
+    a, b = padded.ps.export_keras(), plain.ps.export_keras()
+    return a["enc/sub/conv1/w"].shape == (3, 3, 24, 24) == b["enc/sub/conv1/w"].shape and a["enc/linear/w"].shape == b["enc/linear/w"].shape \
+        and a["enc/sub/bn1/mv"].shape == (24,)
+
+
 def test_head_padding_is_invisible(dev, monkeypatch):
     """bf16 models store attention heads narrower than 64 zero-padded to 64 so that the shipped head sizes (36 / 44) run on the fused
     attention kernels (ParamStore.__init__).  Against the same model stored unpadded (unfused path): identical reference-layout weights
@@ -152,12 +158,17 @@ def test_head_padding_is_invisible(dev, monkeypatch):
     from tensorflowasr_amd import configs
     from tensorflowasr_amd.conformer import ConformerTransducer
 
-    cfg = configs.conformer_tiny(head_size=12, num_heads=2, dmodel=32, dropout=0.0, time_masking={}, freq_masking={})
+    cfg = configs.conformer_tiny(head_size=12, num_heads=2, dmodel=32, filters=24, dropout=0.0, time_masking={}, freq_masking={})
     padded = ConformerTransducer(cfg, dev, dtype=torch.bfloat16, seed=3)
     monkeypatch.setenv("TFASR_HEAD_PAD", "0")
+    monkeypatch.setenv("TFASR_FILTER_PAD", "0")
     plain = ConformerTransducer(cfg, dev, dtype=torch.bfloat16, seed=3)
     monkeypatch.delenv("TFASR_HEAD_PAD")
+    monkeypatch.delenv("TFASR_FILTER_PAD")
     assert padded.ps.head_phys == 64 and plain.ps.head_phys == 12 and padded._fused_attention() and not plain._fused_attention()
+    # the subsampling's channels 24 -> 64: K-segmented conv2 over the space-to-depth layout instead of the im2col route
+    assert padded.ps.filt_phys == 64 and plain.ps.filt_phys == 24 and padded._s2d_enabled() and not plain._s2d_enabled()
+    assert a_shape_ok(padded, plain)
     assert padded.ps.num_trainable() == plain.ps.num_trainable() and padded.ps.n > plain.ps.n
     a, b = padded.ps.export_keras(), plain.ps.export_keras()
     assert set(a) == set(b)
@@ -184,10 +195,14 @@ def test_head_padding_is_invisible(dev, monkeypatch):
     def pads(ps, buf):
         out = []
         for name in ps.names:
-            from tensorflowasr_amd.params import head_padded
+            from tensorflowasr_amd.params import chan_padded, head_padded
             if head_padded(name):
                 v = ps._head_view(ps._view(buf, name), name, ps.head_phys)
                 out.append(v.narrow(1 if name.endswith("o/w") else v.dim() - 1, 12, 52))
+            if chan_padded(name):
+                v = ps._chan_view(ps._view(buf, name), name, ps.filt_phys)
+                for ax in ps._chan_axes(name):
+                    out.append(v.narrow(ax, 24, 40))
         return out
     assert all(float(p.abs().max()) == 0.0 for p in pads(padded.ps, padded.ps.grad))
     padded.compile(optimizer={"class_name": "Adam", "config": {"learning_rate": 1e-2}}, gwn_config={"encoder_step": 0, "encoder_stddev": 0.05},
