@@ -306,7 +306,8 @@ int tfasr_relattn_fused_bwd_q(const void* qkv, const float* ubias, const float* 
                               void* stream);
 /* Query side without the skewed score gradient in HBM (default path): also returns dqv [B*T, H*dh] = d/d(q+v) (formed in the
  * kernel against the window rows), stores the UNSKEWED score gradient ds [B,H,T,lds] (lds >= T, multiple of 8) and adds the bias
- * row's share into dpext [2T, H*dh] f32 (zeroed by the caller).  tfasr_relattn_dpext then accumulates the rest of dpext from ds
+ * row's share into dpext [2T, H*dh] f32 (zeroed by the caller).  With use_mask, the ds rows (and D_i) of a 64-row query block that lies
+ * entirely in the padding (i0 >= lengths[b]) are NOT written: their gradient is zero and tfasr_relattn_dpext skips those tiles.  tfasr_relattn_dpext then accumulates the rest of dpext from ds
  * and qv = q + v ([B*T, H*dh], tfasr_bias2_fwd): one f32 atomic per (table row, column, sample group). */
 int tfasr_relattn_fused_bwd_q2(const void* qkv, const float* ubias, const float* vbias, const void* pext,
                                const int32_t* lengths, const void* o, const void* dout, const float* lse, void* dqu, void* dqv, void* ds,

@@ -198,8 +198,9 @@ def test_save_and_load_weights_round_trip(tmp_path):
     assert not torch.equal(a.ps.flat, b.ps.flat)
     ck.load_weights(b, str(path))
     assert torch.equal(a.ps.flat, b.ps.flat) and torch.equal(a.ps.shadow, b.ps.shadow)
+    ea, eb = a.ps.export_keras(), b.ps.export_keras()  # (reference layouts: the zero padding of heads / channels is not checkpointed)
     for k in a.ps.state:
-        assert torch.equal(a.ps.state[k], b.ps.state[k]), k
+        assert torch.equal(ea[k], eb[k]), k
 
 
 @pytest.mark.gpu
@@ -228,8 +229,9 @@ def test_save_and_load_weights_round_trip_ctc_and_streaming(tmp_path, kind):
         assert not torch.equal(a.ps.flat, b.ps.flat)
         load(b, path)
         assert torch.equal(a.ps.flat, b.ps.flat) and torch.equal(a.ps.shadow, b.ps.shadow)
+        ea, eb = a.ps.export_keras(), b.ps.export_keras()
         for k in a.ps.state:
-            assert torch.equal(a.ps.state[k], b.ps.state[k]), k
+            assert torch.equal(ea[k], eb[k]), k
 
 
 @pytest.mark.gpu
