@@ -258,11 +258,22 @@ class ConformerTransducer(BaseModel):
         # bf16: the K-segmented MFMA GEMM needs whole 64-wide slabs per tap; f32 (parity mode) issues one product per tap
         return self.dtype == torch.float32 or self.ps.filt_phys % 64 == 0
 
-    def _salloc(self, rows, width, slack):
-        """[rows, width] buffer with `slack` zeroed rows before and after it (tap shifts reach outside the first / last sample)."""
-        full = torch.empty((rows + 2 * slack) * width, dtype=self.dtype, device=self.device)
-        full[:slack * width].zero_()
-        full[(slack + rows) * width:].zero_()
+    def _salloc(self, rows, width, slack, tag=None):
+        """[rows, width] buffer with `slack` zeroed rows before and after it (tap shifts reach outside the first / last sample).
+        With a `tag` the buffer is kept for the next step (one live forward / backward pair per model: the kernels only ever READ the
+        slack rows, so they are cleared once, not by two fill launches per buffer and step)."""
+        key = ("salloc", tag, rows, width, slack)
+        if tag is not None and slack > 0 and key in self._consts:
+            full = self._consts[key]
+        else:
+            full = torch.empty((rows + 2 * slack) * width, dtype=self.dtype, device=self.device)
+            if slack > 0:
+                full[:slack * width].zero_()
+                full[(slack + rows) * width:].zero_()
+                if tag is not None:
+                    for k in [k for k in self._consts if isinstance(k, tuple) and k[:2] == ("salloc", tag)]:
+                        del self._consts[k]  # another batch shape: the old buffer is not kept
+                    self._consts[key] = full
         return full, full[slack * width:(slack + rows) * width].view(rows, width)
 
     def _seg_tables(self, F2, C):
@@ -315,14 +326,14 @@ class ConformerTransducer(BaseModel):
         else:
             count0 = B * T1 * F1
             K.bn_finalize(None, 1, ps.p(nm + "/g"), ps.p(nm + "/b"), fin0, ps.state[nm + "/mm"], ps.state[nm + "/mv"], 0.99, 1e-3, False)
-        a1_full, a1 = self._salloc(rows, 4 * C, slack)
+        a1_full, a1 = self._salloc(rows, 4 * C, slack, tag="a1")
         K.conv1_bn_apply_s2d(feats, w0, b0, fin0, a1)
         K.halo_zero(a1, B, T2, F2, 4 * C)
         K.s2d_edge_zero(a1, B, T1, F1, C)
         bn0 = (fin0, count0)
         # conv2: every tap reads the same rows shifted by a constant -> one GEMM over 9 K-segments (bf16) / 9 products (f32)
         W = ps.w2d("enc/sub/conv1/w")  # [9C, C]
-        _, o = self._salloc(rows, C, slack)
+        _, o = self._salloc(rows, C, slack, tag="o")
         if self.dtype == torch.float32:
             flat, base = a1_full, slack * 4 * C
             for i in range(9):
@@ -365,7 +376,7 @@ class ConformerTransducer(BaseModel):
         _, da2 = self._salloc(rows, C, 0)
         K.gemm(dx0h, ps.w2d("enc/linear/w"), da2.view(-1)[C:], B * (T2 + 1), F2 * C, d, d, d, (F2 + 1) * C, trans_b=True)
         K.halo_zero(da2, B, T2, F2, C)
-        do_full, do = self._salloc(rows, C, slack)
+        do_full, do = self._salloc(rows, C, slack, tag="do")
         self._bn_bwd(s["o"], da2, "enc/sub/bn1", s["bn1"], ACT_SWISH, dx=do)
         K.halo_zero(do, B, T2, F2, C)
         # conv2 weight gradient: 9 products gW[tap] += a1[rows shifted by the tap]^T @ do; bias gradient = column sums of do
@@ -956,7 +967,10 @@ class ConformerTransducer(BaseModel):
         ul = [min(b, U1 - 1) for b in llen_host]
         tl_dev = self._h2d(tl)
         ul_dev = self._h2d(ul)
-        gscale = torch.full((B,), 1.0 / (B * self.dp.world), dtype=torch.float32, device=dev)
+        gkey = ("gscale", B, self.dp.world)
+        if gkey not in self._consts:
+            self._consts[gkey] = torch.full((B,), 1.0 / (B * self.dp.world), dtype=torch.float32, device=dev)
+        gscale = self._consts[gkey]
         if not packed:
             logits = self.joint_fwd(enc, pred, B, T, U1, ctx)
             t0 = self._tick("rnnt_loss")
