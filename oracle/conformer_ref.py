@@ -282,22 +282,27 @@ def rel_attention_core(q, k, vv, p, u, v, dh, lengths, use_mask=True, chunk_size
     return torch.einsum("bhts,bshe->bthe", probs, vv), probs
 
 
-def ff_module(x, W, pfx, factor=0.5):
-    """FFModule.call (conformer.py:101-109): x + factor * Dense(swish(Dense(LN(x)))) (dropout off)."""
+def _no_drop(site, y):
+    return y
+
+
+def ff_module(x, W, pfx, factor=0.5, drop=_no_drop, site=None):
+    """FFModule.call (conformer.py:101-109): x + factor * do2(Dense(do1(swish(Dense(LN(x)))))).  `drop(site, y)` injects the
+    keras Dropout masks of a training step (default: dropout off); sites `site`, `site + 1` (conformer.py:80,88)."""
     y = layer_norm(x, W[pfx + "ln/g"], W[pfx + "ln/b"])
-    y = swish(y @ W[pfx + "d1/w"] + W[pfx + "d1/b"])
-    y = y @ W[pfx + "d2/w"] + W[pfx + "d2/b"]
+    y = drop(site, swish(y @ W[pfx + "d1/w"] + W[pfx + "d1/b"]))
+    y = drop(None if site is None else site + 1, y @ W[pfx + "d2/w"] + W[pfx + "d2/b"])
     return x + factor * y
 
 
-def mhsa_module(x, pe, W, pfx, H, dh, lengths, u, v, use_mask=True, chunk_size=None, history_size=None):
-    """MHSAModule.call (conformer.py:209-239)."""
+def mhsa_module(x, pe, W, pfx, H, dh, lengths, u, v, use_mask=True, chunk_size=None, history_size=None, drop=_no_drop, site=None):
+    """MHSAModule.call (conformer.py:209-239); Dropout after the attention (conformer.py:193,234)."""
     y = layer_norm(x, W[pfx + "ln/g"], W[pfx + "ln/b"])
-    y = rel_mhsa(y, pe, W, pfx, H, dh, lengths, u, v, use_mask, chunk_size, history_size)
+    y = drop(site, rel_mhsa(y, pe, W, pfx, H, dh, lengths, u, v, use_mask, chunk_size, history_size))
     return x + y
 
 
-def conv_module(x, W, pfx, training=True, stats=None, dw_norm="batch"):
+def conv_module(x, W, pfx, training=True, stats=None, dw_norm="batch", drop=_no_drop, site=None):
     """ConvModule.call (conformer.py:366-377): LN -> pw(2d) -> GLU -> causal depthwise K -> BN -> swish -> pw(d) -> +res."""
     y = layer_norm(x, W[pfx + "ln/g"], W[pfx + "ln/b"])
     y = y @ W[pfx + "pw1/w"] + W[pfx + "pw1/b"]
@@ -313,17 +318,18 @@ def conv_module(x, W, pfx, training=True, stats=None, dw_norm="batch"):
     else:
         y = batch_norm_infer(y, W[pfx + "bn/g"], W[pfx + "bn/b"], W[pfx + "bn/mm"], W[pfx + "bn/mv"])
     y = swish(y)
-    y = y @ W[pfx + "pw2/w"] + W[pfx + "pw2/b"]
+    y = drop(site, y @ W[pfx + "pw2/w"] + W[pfx + "pw2/b"])  # Dropout after pw_conv_2 (conformer.py:353,374)
     return x + y
 
 
-def conformer_block(x, pe, W, pfx, cfg, lengths, u, v, training=True, use_mask=True, stats=None):
-    """ConformerBlock.call (conformer.py:504-535)."""
+def conformer_block(x, pe, W, pfx, cfg, lengths, u, v, training=True, use_mask=True, stats=None, drop=_no_drop, site=None):
+    """ConformerBlock.call (conformer.py:504-535).  Dropout sites of the block (product numbering): site .. site + 5."""
     H, dh = cfg["num_heads"], cfg["head_size"]
-    x = ff_module(x, W, pfx + "ff1/", cfg["ffm_residual"])
-    x = mhsa_module(x, pe, W, pfx + "mhsa/", H, dh, lengths, u, v, use_mask, cfg.get("chunk_size"), cfg.get("history_size"))
-    x = conv_module(x, W, pfx + "conv/", training, stats, cfg.get("convm_dw_norm", "batch"))
-    x = ff_module(x, W, pfx + "ff2/", cfg["ffm_residual"])
+    st = (lambda k: None) if site is None else (lambda k: site + k)
+    x = ff_module(x, W, pfx + "ff1/", cfg["ffm_residual"], drop, st(0))
+    x = mhsa_module(x, pe, W, pfx + "mhsa/", H, dh, lengths, u, v, use_mask, cfg.get("chunk_size"), cfg.get("history_size"), drop, st(2))
+    x = conv_module(x, W, pfx + "conv/", training, stats, cfg.get("convm_dw_norm", "batch"), drop, st(3))
+    x = ff_module(x, W, pfx + "ff2/", cfg["ffm_residual"], drop, st(4))
     return layer_norm(x, W[pfx + "ln/g"], W[pfx + "ln/b"])
 
 
@@ -345,17 +351,19 @@ def subsampling(feat, lengths, W, training=True, stats=None):
     return x.reshape(B, T, Fq * C), ln  # math_util.merge_two_last_dims (math_util.py:130-132)
 
 
-def encoder(feat, lengths, W, cfg, training=True, use_mask=True, stats=None):
-    """ConformerEncoder.call (conformer.py:672-701); dropout off."""
+def encoder(feat, lengths, W, cfg, training=True, use_mask=True, stats=None, drop=_no_drop):
+    """ConformerEncoder.call (conformer.py:672-701).  `drop(site, y)`: the step's Dropout masks (site 0 = after the linear layer,
+    conformer.py:594,682; block i: 16 + 8 i + {0..5}); default = dropout off.  (The relative encoding's own Dropout has rate 0:
+    conformer.py:604-610.)"""
     x, ln = subsampling(feat, lengths, W, training, stats)
-    x = x @ W["enc/linear/w"] + W["enc/linear/b"]
+    x = drop(0, x @ W["enc/linear/w"] + W["enc/linear/b"])
     B, T, d = x.shape
     pe, _ = relative_position_encoding(T, d, ln.tolist(), interleave=True)
     pe = pe.to(x.dtype)
     for i in range(cfg["num_blocks"]):
         # shared encoder-level biases (encoders/conformer.py:647-663) or the layer's own pair (multihead_attention.py:522-538)
         u, v = (W[f"enc/block{i}/mhsa/u"], W[f"enc/block{i}/mhsa/v"]) if cfg.get("mhsam_use_attention_bias") else (W["enc/u"], W["enc/v"])
-        x = conformer_block(x, pe, W, f"enc/block{i}/", cfg, ln, u, v, training, use_mask, stats)
+        x = conformer_block(x, pe, W, f"enc/block{i}/", cfg, ln, u, v, training, use_mask, stats, drop, 16 + 8 * i)
     return x, ln
 
 
@@ -400,9 +408,9 @@ def joint_net(enc, pred, W):
     return h @ W["joint/vocab/w"] + W["joint/vocab/b"]
 
 
-def transducer_forward(features, feat_len, predictions, pred_len, W, cfg, training=True, use_mask=True, stats=None):
+def transducer_forward(features, feat_len, predictions, pred_len, W, cfg, training=True, use_mask=True, stats=None, drop=_no_drop):
     """Transducer.call after the frontend (base_transducer.py:427-435): features [B,T0,F] -> logits [B,T',U1,V]."""
-    enc, ln = encoder(features[..., None], feat_len, W, cfg, training, use_mask, stats)
+    enc, ln = encoder(features[..., None], feat_len, W, cfg, training, use_mask, stats, drop)
     pred = prediction_net(predictions, pred_len, W)
     return joint_net(enc, pred, W), ln
 

@@ -41,7 +41,7 @@ def _setup(dev, dtype, lens, ulens, seed=0, N=4000, U=6, **over):
     return cfg, ocfg, model, W, data, sig, labels, preds
 
 
-def _oracle_step(ocfg, W, sig, lens, preds, ulens, labels, masks=None, use_mask=True):
+def _oracle_step(ocfg, W, sig, lens, preds, ulens, labels, masks=None, use_mask=True, drop=None):
     Wg = {k: v.clone().requires_grad_(R.is_trainable(k)) for k, v in W.items()}
     feat = R.log_mel(sig, ocfg)
     flen = R.get_nframes(lens)
@@ -49,7 +49,7 @@ def _oracle_step(ocfg, W, sig, lens, preds, ulens, labels, masks=None, use_mask=
         feat = R.specaugment_apply(feat, masks[0], masks[1])
     stats = {}
     logits, elen = R.transducer_forward(torch.from_numpy(feat), flen, torch.from_numpy(preds), torch.tensor([u + 1 for u in ulens]),
-                                        Wg, ocfg, training=True, use_mask=use_mask, stats=stats)
+                                        Wg, ocfg, training=True, use_mask=use_mask, stats=stats, **({"drop": drop} if drop else {}))
     tl, ul = rnnt_ref.clamp_lengths(elen.numpy(), np.asarray(ulens))
     loss, g = rnnt_ref.rnnt_loss_and_grad(logits.detach().numpy(), labels, ul, np.minimum(tl, logits.shape[1]), np.float32)
     B = len(lens)
@@ -298,3 +298,51 @@ def test_native_block_executor_matches_per_kernel_host_path(dev, dtype, head):
     # moving mean of a zero-mean activation: absolute scale ~1e-5, f32 atomics order differs between runs
     np.testing.assert_allclose(out[True][2], out[False][2], rtol=1e-5 if dtype == torch.float32 else 1e-2, atol=1e-7 if dtype == torch.float32 else 2e-5)
     np.testing.assert_allclose(out[True][3], out[False][3], rtol=tol, atol=tol)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_step_with_dropout_and_specaugment_on_matches_oracle(dev, dtype):
+    """The whole train step with Dropout (rate 0.1) AND SpecAugment ON, as `bench.py` runs it: the product's
+    masks are a pure function of (seed, element index), so the masks of this very step are regenerated with tfasr_dropout on a tensor
+    of ones and injected into the oracle at the reference's Dropout sites (conformer.py:80-88,193,353,594,682); the SpecAugment draws
+    are the product's own.  Logits, loss and every gradient against the oracle; native block executor and per-kernel host path."""
+    from tensorflowasr_amd import kernels as K
+
+    lens, ulens = [4000, 2500, 3100], [6, 3, 5]
+    cfg, ocfg, model, W, data, sig, labels, preds = _setup(dev, dtype, lens, ulens, dropout=0.1)
+    masks = model.draw_specaugment([int(n) for n in R.get_nframes(lens)])
+    p = 0.1
+    cache = {}
+
+    def drop_for(epoch):
+        def drop(site, y):
+            if site is None:
+                return y
+            key = (epoch, site, tuple(y.shape))
+            if key not in cache:
+                ones = torch.ones(y.shape, dtype=torch.float32, device=dev)  # (f32: the exact 1 / (1 - p) the epilogues multiply by)
+                cache[key] = K.dropout(ones.view(-1), p, (epoch * 8192 + site) & 0x7FFFFFFFFFFF).float().cpu().view(y.shape)
+            m = cache[key]
+            assert 0.8 < float((m > 0).float().mean()) < 0.97 and abs(float(m.max()) - 1.0 / (1.0 - p)) < 1e-2
+            return y * m.to(y.dtype)
+        return drop
+
+    tol = 2e-3 if dtype == torch.float32 else 6e-2
+    for native in (True, False):
+        model.native_blocks = native
+        epoch = model._drop_epoch + 1  # the forward pass below draws its masks under this epoch
+        ref_logits, elen, ref_loss, ref_grads, _ = _oracle_step(ocfg, W, sig, lens, preds, ulens, labels, (masks[0].numpy(), masks[1].numpy()),
+                                                                drop=drop_for(epoch))
+        # the masks matter: without them the oracle's logits differ
+        plain = _oracle_step(ocfg, W, sig, lens, preds, ulens, labels, (masks[0].numpy(), masks[1].numpy()))[0]
+        assert float((plain - ref_logits).abs().max()) > 1e-2
+        model.zero_grad()
+        costs = model.loss_and_backward(data, True, masks).float().cpu().numpy()
+        torch.cuda.synchronize()
+        assert model._drop_epoch == epoch
+        np.testing.assert_allclose(costs, ref_loss, rtol=1e-3 if dtype == torch.float32 else 3e-2)
+        mine = model.ps.export_keras(model.ps.grad)
+        num = sum(float((mine[k].double() - ref_grads[k].double()).pow(2).sum()) for k in ref_grads if k in mine)
+        den = sum(float(ref_grads[k].double().pow(2).sum()) for k in ref_grads if k in mine)
+        err = (num / den) ** 0.5
+        assert err < (2e-3 if dtype == torch.float32 else 0.15), err
