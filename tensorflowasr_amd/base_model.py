@@ -174,7 +174,7 @@ class BaseModel:
                 K.gauss_noise(view, float(sd), seed)
             saved[part] = keep
         if saved:
-            self.ps.rezero_head_pads()  # the zero padding of narrow attention heads is not a weight
+            self.ps.rezero_pads()  # the zero padding of narrow attention heads is not a weight
             self.ps.refresh_shadow()
         return saved
 
@@ -193,7 +193,7 @@ class BaseModel:
             return
         self._gradn_epoch = getattr(self, "_gradn_epoch", 0) + 1
         K.gauss_noise(self.ps.grad, float(g["stddev"]), self._gradn_epoch * 7_368_787 + 5 + ((int(self.dp.rank) & 0x7F) << 48))
-        self.ps.rezero_head_pads(self.ps.grad)
+        self.ps.rezero_pads(self.ps.grad)
 
     # ----------------------------------------------------------------------------------------------- steps
     @torch.no_grad()

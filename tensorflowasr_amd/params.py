@@ -272,7 +272,7 @@ class ParamStore:
     def _chan_axes(self, name):
         return {"enc/sub/conv0/w": (3,), "enc/sub/conv1/w": (2, 3), "enc/linear/w": (1,)}.get(name, (0,))
 
-    def _pad_heads(self, name, t):
+    def _pad(self, name, t):
         """logical layout (head dim cfg.head_size, cfg.filters channels) -> stored layout (head_phys / filt_phys, zero padded)"""
         Cl, Cp = self.cfg.filters, self.filt_phys
         if Cp != Cl and chan_padded(name):
@@ -297,7 +297,7 @@ class ParamStore:
         out.narrow(ax, 0, dh).copy_(v)
         return out.reshape(self.shapes[name])
 
-    def _unpad_heads(self, name, t):
+    def _unpad(self, name, t):
         Cl, Cp = self.cfg.filters, self.filt_phys
         if Cp != Cl and chan_padded(name):
             v = self._chan_view(t, name, Cp)
@@ -319,7 +319,7 @@ class ParamStore:
             return v.reshape(-1, self.cfg.dmodel)
         return v.reshape(-1)
 
-    def rezero_head_pads(self, buf=None):
+    def rezero_pads(self, buf=None):
         """restore the zero padding of `buf` (default: the master parameters) after something wrote whole-buffer noise into it"""
         dh, dp = self.cfg.head_size, self.head_phys
         Cl, Cp = self.cfg.filters, self.filt_phys
@@ -373,7 +373,7 @@ class ParamStore:
                 lim = math.sqrt(6.0 / (fi + fo))
                 w = rng.uniform(-lim, lim, shape).astype(np.float32)
             if shape != stored:
-                w = self._pad_heads(name, torch.from_numpy(w)).numpy()
+                w = self._pad(name, torch.from_numpy(w)).numpy()
             host[self.offsets[name]:self.offsets[name] + n] = w.reshape(-1)
         self.flat.copy_(torch.from_numpy(host))
 
@@ -384,7 +384,7 @@ class ParamStore:
         host = self.flat.cpu().clone()
 
         def put(name, t):
-            t = self._pad_heads(name, torch.as_tensor(t).detach().float().cpu()).reshape(-1)
+            t = self._pad(name, torch.as_tensor(t).detach().float().cpu()).reshape(-1)
             o = self.offsets[name]
             assert t.numel() == int(np.prod(self.shapes[name])), name
             host[o:o + t.numel()] = t
@@ -401,7 +401,7 @@ class ParamStore:
         self.flat.copy_(host)
         for k in self.state:
             if k in W:
-                self.state[k].copy_(self._pad_heads(k, torch.as_tensor(W[k]).detach().float().cpu()))
+                self.state[k].copy_(self._pad(k, torch.as_tensor(W[k]).detach().float().cpu()))
         self.refresh_shadow()
 
     def export_keras(self, buf=None):
@@ -410,7 +410,7 @@ class ParamStore:
         buf = self.flat if buf is None else buf
         out = {}
         for name in self.names:
-            t = self._unpad_heads(name, self._view(buf, name).detach().float().cpu())
+            t = self._unpad(name, self._view(buf, name).detach().float().cpu())
             if name.endswith("qkv/w"):
                 base = name[:-len("qkv/w")]
                 for i, k in enumerate(("q", "k", "v")):
@@ -429,5 +429,5 @@ class ParamStore:
                 out[name] = t.clone()
         if buf is self.flat:
             for k, v in self.state.items():
-                out[k] = self._unpad_heads(k, v.detach().cpu().clone())
+                out[k] = self._unpad(k, v.detach().cpu().clone())
         return out
