@@ -221,13 +221,25 @@ class ConformerTransducer(BaseModel):
         return (None if fm is None else torch.from_numpy(fm)), (None if tm is None else torch.from_numpy(tm))
 
     # =================================================================================== batch norm
+    def _zeros_f32(self, n):
+        """n zeroed f32 accumulators for one launch (BN sums): slices of an arena cleared by ONE fill per ~1 MB instead of one fill
+        launch per use (the ContextNet step had 300 of them).  An exhausted arena is replaced, never re-cleared, so slices that are
+        still referenced stay valid."""
+        n = (n + 63) // 64 * 64
+        size = max(1 << 18, n)
+        arena, cur = self._consts.get("zero_arena", (None, 0))
+        if arena is None or cur + n > arena.numel():
+            arena, cur = torch.zeros(size, dtype=torch.float32, device=self.device), 0
+        self._consts["zero_arena"] = (arena, cur + n)
+        return arena[cur:cur + n]
+
     def _bn_fwd(self, x2d, name, training, act, rows=None, y=None):
         """rows: number of REAL rows when x2d carries exactly-zero padding rows (haloed layouts): zeros change neither sum."""
         ps = self.ps
         C = x2d.shape[1]
         fin = torch.empty(4 * C, dtype=torch.float32, device=self.device)
         if training:
-            stats = torch.zeros(2 * C + 1, dtype=torch.float32, device=self.device)
+            stats = self._zeros_f32(2 * C + 1)[:2 * C + 1]
             K.bn_stats(x2d, stats)
             count = (x2d.shape[0] if rows is None else rows) * self.dp.world
             self.dp.allreduce_stats_(stats[:2 * C])
@@ -242,7 +254,7 @@ class ConformerTransducer(BaseModel):
         fin, count = saved
         ps = self.ps
         C = x2d.shape[1]
-        bstats = torch.zeros(2 * C, dtype=torch.float32, device=self.device)
+        bstats = self._zeros_f32(2 * C)[:2 * C]
         K.bn_bwd_stats(x2d, dy2d, fin, bstats, act)
         self.dp.allreduce_stats_(bstats)
         # bstats = (sum dz, sum dz*xhat) over the GLOBAL batch = the beta / gamma gradients; the flat-gradient all-reduce sums over ranks again
@@ -318,7 +330,7 @@ class ConformerTransducer(BaseModel):
         fin0 = torch.empty(4 * C, dtype=torch.float32, device=self.device)
         nm = "enc/sub/bn0"
         if training:
-            stats = torch.zeros(2 * C + 1, dtype=torch.float32, device=self.device)
+            stats = self._zeros_f32(2 * C + 1)[:2 * C + 1]
             K.conv1_stats(feats, w0, b0, stats)
             count0 = B * T1 * F1 * self.dp.world
             self.dp.allreduce_stats_(stats[:2 * C])

@@ -14,10 +14,12 @@ Kernel mapping: depthwise part = tfasr_dwconv_* (causal, stride 1; a strided cau
 BatchNorm = tfasr_bn_* with the sync-BN all-reduce hook, squeeze-excite = tfasr_se_* + two tiny GEMMs, block tail =
 tfasr_add_act_*.  Everything is HBM-bound except the pointwise GEMMs.
 """
+import os
+
 import torch
 
 from . import kernels as K
-from .conformer import ConformerTransducer
+from .conformer import ConformerTransducer, _split_k
 from .kernels import ACT_NONE, ACT_SIGMOID, ACT_SWISH
 from .params import contextnet_modules
 
@@ -36,6 +38,36 @@ class ContextNetTransducer(ConformerTransducer):
         for blk in self.blocks:
             t = -(-int(t) // int(blk["stride"]))
         return t
+
+    # ------------------------------------------------------------------------------- grouped weight gradients
+    # The pointwise weight gradients (x^T dy, 137 per ContextNet-L step) are independent of everything downstream in the backward
+    # pass: they are queued and issued several per launch (tfasr_gemm_group shares one k-split / XCD placement over the group)
+    # instead of one split-K launch each.  The queue holds the operands alive until it is flushed.
+    _WG_GROUP = 8
+
+    def _dense_bwd(self, dy, x, wname, bname, alpha=1.0, dact_z=None, dact=ACT_NONE, need_dx=True, drop=(0.0, 0)):
+        q = getattr(self, "_wg_queue", None)
+        W = self.ps.w2d(wname)
+        din, dout = W.shape
+        rows = dy.shape[0]
+        if q is None or self.dtype != torch.bfloat16 or rows < 2048 or dout <= 64 or alpha != 1.0:
+            return super()._dense_bwd(dy, x, wname, bname, alpha, dact_z, dact, need_dx, drop)
+        q.append(dict(A=x, B=dy, out=self.ps.g2d(wname), M=din, N=dout, K=rows, lda=x.stride(0), ldb=dy.stride(0), ldd=dout, trans_a=True,
+                      accumulate=True, split_k=_split_k(din, dout, rows), colsum=self.ps.g(bname) if bname is not None else None))
+        if len(q) >= self._WG_GROUP:
+            self._wg_flush()
+        if not need_dx:
+            return None
+        return K.matmul(dy, W, trans_b=True, dact_z=dact_z, dact=dact, drop_p=drop[0], drop_seed=drop[1])
+
+    def _wg_flush(self):
+        q = self._wg_queue
+        if q:
+            if len(q) == 1:
+                K.gemm(**q[0])
+            else:
+                K.gemm_group(q)
+            q.clear()
 
     # ------------------------------------------------------------------------------- one ConvModule
     def _cm_fwd(self, x, mod, B, T, training, ctx):
@@ -137,9 +169,15 @@ class ContextNetTransducer(ConformerTransducer):
 
     def encoder_bwd(self, dx, ctx):
         B = ctx["enc"]["B"]
-        for i in reversed(range(len(self.blocks))):
-            dx = self._block_bwd_cn(dx, self.blocks[i], B, ctx)
-            lo = self.ps.offsets[self.blocks[i]["convs"][0][0] + "/dw"]
-            hi = self.ps.offsets[self.blocks[i + 1]["convs"][0][0] + "/dw"] if i + 1 < len(self.blocks) else self.ps.offsets["pred/emb"]
-            self.dp.grads_ready(lo, hi)
+        self._wg_queue = [] if os.environ.get("TFASR_CN_WGRAD_GROUP", "1") != "0" else None
+        try:
+            for i in reversed(range(len(self.blocks))):
+                dx = self._block_bwd_cn(dx, self.blocks[i], B, ctx)
+                if self._wg_queue is not None:
+                    self._wg_flush()  # this block's gradients are complete before its range is handed to the all-reduce
+                lo = self.ps.offsets[self.blocks[i]["convs"][0][0] + "/dw"]
+                hi = self.ps.offsets[self.blocks[i + 1]["convs"][0][0] + "/dw"] if i + 1 < len(self.blocks) else self.ps.offsets["pred/emb"]
+                self.dp.grads_ready(lo, hi)
+        finally:
+            self._wg_queue = None  # the prediction / joint networks' gradients are issued directly
         # (the input features need no gradient)

@@ -47,33 +47,35 @@ __device__ __forceinline__ float2_t lds2(const char* p) {
 // REV == true : dx[t] = sum_k w[k] dy[t+(K-1)-k]               (data gradient) = same loop with reversed taps
 // The (input step j) x (output i) loops are expanded with compile-time indices (fold over integer sequences) so that the
 // tap / accumulator arrays stay in registers.
-template <int TT, int J, int... I>
-__device__ __forceinline__ void dw_step(float2_t (&acc)[TT], const float2_t (&wk)[MAXK], float2_t xv, std::integer_sequence<int, I...>) {
-  ((void)((J - I >= 0 && J - I < MAXK) ? (acc[I] = fma2(wk[(J - I >= 0 && J - I < MAXK) ? J - I : 0], xv, acc[I]), 0) : 0), ...);
+template <int TT, int KB, int J, int... I>
+__device__ __forceinline__ void dw_step(float2_t (&acc)[TT], const float2_t (&wk)[KB], float2_t xv, std::integer_sequence<int, I...>) {
+  ((void)((J - I >= 0 && J - I < KB) ? (acc[I] = fma2(wk[(J - I >= 0 && J - I < KB) ? J - I : 0], xv, acc[I]), 0) : 0), ...);
 }
-template <int TT, int... J>
-__device__ __forceinline__ void dw_all(float2_t (&acc)[TT], const float2_t (&wk)[MAXK], const char* col, std::integer_sequence<int, J...>) {
-  ((dw_step<TT, J>(acc, wk, lds2(col + J * ROWB), std::make_integer_sequence<int, TT>{})), ...);
+template <int TT, int KB, int... J>
+__device__ __forceinline__ void dw_all(float2_t (&acc)[TT], const float2_t (&wk)[KB], const char* col, std::integer_sequence<int, J...>) {
+  ((dw_step<TT, KB, J>(acc, wk, lds2(col + J * ROWB), std::make_integer_sequence<int, TT>{})), ...);
 }
 // GLU (data gradient only): the GLU backward of the layer in front of the depthwise conv in the same pass - `gx` = the GLU's input
 // [rows, 2C] (a | b halves), y = its gradient [rows, 2C]: da = dx sigma(b), db = dx a sigma(b) (1 - sigma(b)); dx itself is not stored.
-template <bool REV, bool GLU = false>
+// KB = compile-time bound on the kernel size (taps k >= K are zero weights): 32 covers the Conformer's 31/32, 8 the ContextNet's 5
+// (with KB = 32 a 5-tap conv would spend 6x its useful FMAs on zeros and turn this HBM-bound op compute-bound).
+template <bool REV, bool GLU = false, int KB = MAXK>
 __global__ __launch_bounds__(256) void dwconv_tile_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w,
                                                           const float* __restrict__ bias, bf16_t* __restrict__ y, int Tn, int C, int K,
                                                           const bf16_t* __restrict__ gx = nullptr) {
-  extern __shared__ __attribute__((aligned(16))) char lds[];  // (2*TG + MAXK - 1) rows; rows past K-1+2*TG stay zero-weighted
+  extern __shared__ __attribute__((aligned(16))) char lds[];  // (2*TG + KB - 1) rows; rows past K-1+2*TG stay zero-weighted
   const int c0 = blockIdx.x * SLAB;
   const int t0 = blockIdx.y * (2 * TG);
   const long ubase = (long)blockIdx.z * Tn * C;
   const int tin0 = REV ? t0 : t0 - (K - 1);
-  stage_rows(lds, x, ubase, tin0, 2 * TG + MAXK - 1, Tn, C, c0);
+  stage_rows(lds, x, ubase, tin0, 2 * TG + KB - 1, Tn, C, c0);
   const int grp = threadIdx.x >> 7, pr = threadIdx.x & 127;
   const int c = c0 + 2 * pr;
   const bool live = c < C;
   const int cc = live ? c : c0;
-  float2_t wk[MAXK];
+  float2_t wk[KB];
 #pragma unroll
-  for (int k = 0; k < MAXK; ++k) {
+  for (int k = 0; k < KB; ++k) {
     const int kk = max(min(REV ? (K - 1 - k) : k, K - 1), 0);
     const float2_t v = float2_t{w[kk * C + cc], w[kk * C + cc + 1]};
     wk[k] = (k < K) ? v : float2_t{0.f, 0.f};
@@ -83,7 +85,7 @@ __global__ __launch_bounds__(256) void dwconv_tile_kernel(const bf16_t* __restri
 #pragma unroll
   for (int i = 0; i < TG; ++i) acc[i] = bv;
   __syncthreads();
-  dw_all<TG>(acc, wk, lds + (grp * TG) * ROWB + pr * 4, std::make_integer_sequence<int, MAXK - 1 + TG>{});
+  dw_all<TG, KB>(acc, wk, lds + (grp * TG) * ROWB + pr * 4, std::make_integer_sequence<int, KB - 1 + TG>{});
   if (live) {
     const int tg0 = t0 + grp * TG;
 #pragma unroll
@@ -212,6 +214,8 @@ int tfasr_dwconv_wgrad_ws_try(const void* x, const void* dy, float* dw, float* d
     case 32: hipLaunchKernelGGL((dwconv_wgrad_tile_kernel<32>), grid, dim3(256), smem, s, (const bf16_t*)x, (const bf16_t*)dy, dw, dbias, T, C, ws); break;
     case 15: hipLaunchKernelGGL((dwconv_wgrad_tile_kernel<15>), grid, dim3(256), smem, s, (const bf16_t*)x, (const bf16_t*)dy, dw, dbias, T, C, ws); break;
     case 7: hipLaunchKernelGGL((dwconv_wgrad_tile_kernel<7>), grid, dim3(256), smem, s, (const bf16_t*)x, (const bf16_t*)dy, dw, dbias, T, C, ws); break;
+    case 5: hipLaunchKernelGGL((dwconv_wgrad_tile_kernel<5>), grid, dim3(256), smem, s, (const bf16_t*)x, (const bf16_t*)dy, dw, dbias, T, C, ws); break;
+    case 3: hipLaunchKernelGGL((dwconv_wgrad_tile_kernel<3>), grid, dim3(256), smem, s, (const bf16_t*)x, (const bf16_t*)dy, dw, dbias, T, C, ws); break;
     default: return TFASR_STATUS_UNSUPPORTED;
   }
   TFASR_CHECK_LAUNCH();
@@ -244,6 +248,17 @@ int tfasr_dwconv_pair_try(int which, const void* x, const void* dy, const float*
   if (which == 0 || which == 1) {
     const void* in = which == 0 ? x : dy;
     if (!al16(in) || !al4(y)) return TFASR_STATUS_UNSUPPORTED;
+    if (K <= 8) {
+      const int smem = (2 * TG + 8 - 1) * ROWB;
+      if (which == 0)
+        hipLaunchKernelGGL((dwconv_tile_kernel<false, false, 8>), grid, dim3(256), smem, s, (const bf16_t*)in, w, bias, (bf16_t*)y, T, C, K,
+                           (const bf16_t*)nullptr);
+      else
+        hipLaunchKernelGGL((dwconv_tile_kernel<true, false, 8>), grid, dim3(256), smem, s, (const bf16_t*)in, w, (const float*)nullptr, (bf16_t*)y, T,
+                           C, K, (const bf16_t*)nullptr);
+      TFASR_CHECK_LAUNCH();
+      return TFASR_STATUS_SUCCESS;
+    }
     const int smem = (2 * TG + MAXK - 1) * ROWB;
     if (which == 0)
       hipLaunchKernelGGL((dwconv_tile_kernel<false>), grid, dim3(256), smem, s, (const bf16_t*)in, w, bias, (bf16_t*)y, T, C, K);

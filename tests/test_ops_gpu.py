@@ -144,6 +144,28 @@ def test_glu_dwconv(dev, dtype):
     cmp(dx, xr.grad, **tol(dtype, (1e-4, 1e-5), (3e-2, 3e-2)))
 
 
+@pytest.mark.parametrize("Kk,C,T", [(5, 640, 150), (5, 80, 77), (3, 256, 64), (7, 144, 130), (8, 264, 65), (15, 144, 53), (32, 144, 53)])
+def test_dwconv_kernel_sizes(dev, Kk, C, T):
+    """The bf16 depthwise kernels are instantiated per window bound (8 / 32 taps) and per weight-gradient kernel size: every size the
+    reference configs use (ContextNet 5, Conformer 31/32, small test sizes) against the torch restatement."""
+    g = torch.Generator().manual_seed(100 + Kk)
+    B = 3
+    dtype = torch.bfloat16
+    x = rt(torch.randn(B, T, C, generator=g), dtype)
+    w, b = torch.randn(Kk, C, generator=g) * 0.3, torch.randn(C, generator=g) * 0.1
+    dy = rt(torch.randn(B, T, C, generator=g), dtype)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    yr = R.depthwise_conv1d_causal(xr, wr, b)
+    yr.backward(dy)
+    xd, dyd = x.to(dev).to(dtype), dy.to(dev).to(dtype)
+    cmp(K.dwconv_fwd(xd, w.to(dev), b.to(dev)), yr.detach(), **tol(dtype))
+    cmp(K.dwconv_bwd_data(dyd, w.to(dev)), xr.grad, **tol(dtype))
+    dw, db = torch.zeros(Kk, C, device=dev), torch.zeros(C, device=dev)
+    K.dwconv_bwd_weight(xd, dyd, dw, db)
+    cmp(dw, wr.grad, rtol=1e-3, atol=2e-3)
+    cmp(db, dy.sum((0, 1)), rtol=1e-3, atol=1e-3)
+
+
 @pytest.mark.parametrize("dtype", DT)
 def test_bias2_embedding_colsum_cast(dev, dtype):
     g = torch.Generator().manual_seed(2)
