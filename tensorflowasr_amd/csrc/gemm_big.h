@@ -47,6 +47,15 @@ template <bool TB, int BN_, int EPI, bool SEG>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void gemm_big_kernel(const tfasr_gemm_args p, const int gx, const int gy, const int ntiles) {
   constexpr bool C_LSE = (EPI & E_LSE) != 0;
+  // where the DMA pieces of the next slab are issued inside the fragment-read segments: 0 = in front of the reads, 2 = behind them (the
+  // reads' latency then runs under the pieces' issue time: k-strided B, whose 16 transposing reads per k half make that segment the long
+  // one, 878 -> 832 us on the joint projection; k-contiguous B measured 1 % slower), 1 = every piece between the MFMAs instead (probe
+  // only: the partner's fragment reads then crawl under the DMA traffic; 10 % slower on the data gradient)
+#ifdef TFASR_BIG_SCHED
+  constexpr int SCHED = TFASR_BIG_SCHED;
+#else
+  constexpr int SCHED = TB ? 0 : 2;
+#endif
   constexpr int BMB = 256, WNC = BN_ / 2, NI = 4, NJ = WNC / 16;  // 8 waves = 4 (rows) x 2 (columns), wave tile 64 x BN/2
   constexpr int A_B = BMB * BK * 2, B_B = BN_ * BK * 2, STAGE = A_B + B_B;
   constexpr int NA = BMB / 64, NB = BN_ / 64, GI = NA + NB;  // DMA wave-instructions per slab per wave
@@ -186,7 +195,7 @@ void gemm_big_kernel(const tfasr_gemm_args p, const int gx, const int gy, const 
   Tile cur = tile_of(0);
   if (!cur.ok) return;
   if (nfull > 0) issue(cur, 0, 0);
-  if (nsl > 1 && grpB) issue_half(cur, 1, 1, 0);
+  if (nsl > 1 && grpB) { issue_half(cur, 1, 1, 0); if (SCHED == 1) issue_half(cur, 1, 1, 1); }
 
   for (int it = 0;; ++it) {
     float4_t acc[NI][NJ];
@@ -223,7 +232,7 @@ void gemm_big_kernel(const tfasr_gemm_args p, const int gx, const int gy, const 
       }
     };
     // this wave's MFMAs of one k half; (dma) its DMA instructions of `slab` into the stage at `dst` between them
-    auto mma = [&](const bool dma, long da, char* dst) {
+    auto mma = [&](const bool dma, long da, char* dst, const bool dmab = false, long db = 0L) {
 #pragma unroll
       for (int i = 0; i < NI; ++i) {
 #pragma unroll
@@ -231,6 +240,10 @@ void gemm_big_kernel(const tfasr_gemm_args p, const int gx, const int gy, const 
           if (j < 8) mfma_acc<true>(acc[i][j], af[i], bf[j]); else mfma_acc<false>(acc[i][j], af[i], bf[j]);  // BN 320: 128 + 32
         }
         if (dma) dma_a(cur, i, da, dst);  // uniform: a scalar branch around one instruction (NA == NI pieces, one per fragment row)
+        if (dmab) {
+          dma_b(cur, i, db, dst);
+          if (NB > NI && i == NI - 1) dma_b(cur, NB - 1, db, dst);
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
     };
@@ -250,19 +263,26 @@ void gemm_big_kernel(const tfasr_gemm_args p, const int gx, const int gy, const 
       const int nz = s < nfull ? 0 : nzero;
       __builtin_amdgcn_s_barrier();  // A: P1(s)   B: P2(s)
       BIG_TICK(0)
-      if (nx) issue_half(cur, s + 1, (s + 1) & 1, grpB ? 1 : 0);
+      if (SCHED == 0 && nx) issue_half(cur, s + 1, (s + 1) & 1, grpB ? 1 : 0);
       rd(sA, sA + A_B, 0, nz);
+      if (SCHED == 2 && nx) issue_half(cur, s + 1, (s + 1) & 1, grpB ? 1 : 0);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
       BIG_TICK(1)
       __builtin_amdgcn_s_barrier();  // A: P2   B: P3
       BIG_TICK(2)
-      mma(false, 0L, sA);
+      if (SCHED == 1) {
+        const bool dma = !grpB && nx;  // A: every piece of slab s+1 between the MFMAs of M0(s)
+        mma(dma, dma ? dA(s + 1) : 0L, smem + ((s + 1) & 1) * STAGE, dma, dma ? dB(s + 1) : 0L);
+      } else {
+        mma(false, 0L, sA);
+      }
       BIG_TICK(3)
       __builtin_amdgcn_s_barrier();  // A: P3   B: P4
       BIG_TICK(4)
-      if (nx && !grpB) issue_half(cur, s + 1, (s + 1) & 1, 1);
+      if (SCHED == 0 && nx && !grpB) issue_half(cur, s + 1, (s + 1) & 1, 1);
       rd(sA, sA + A_B, 1, nz);
+      if (SCHED == 2 && nx && !grpB) issue_half(cur, s + 1, (s + 1) & 1, 1);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       if (grpB) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // B's pieces of slab s+1 before P1(s+1)
       __builtin_amdgcn_sched_barrier(0);
@@ -271,7 +291,8 @@ void gemm_big_kernel(const tfasr_gemm_args p, const int gx, const int gy, const 
       BIG_TICK(6)
       {
         const bool dma = grpB && s + 2 < nsl;
-        mma(dma, dma ? dA(s + 2) : 0L, sA);
+        if (SCHED == 1) mma(dma, dma ? dA(s + 2) : 0L, sA, dma, dma ? dB(s + 2) : 0L);  // B: every piece of slab s+2 in M1(s)
+        else mma(dma, dma ? dA(s + 2) : 0L, sA);
       }
       if (!grpB) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // A's pieces of slab s+1 before P1(s+1)
       BIG_TICK(7)
@@ -284,9 +305,16 @@ void gemm_big_kernel(const tfasr_gemm_args p, const int gx, const int gy, const 
     const Tile nxt = tile_of(it + 1);
     if (nxt.ok) {
       if (nfull > 0) issue(nxt, 0, 0);
-      if (nsl > 1 && grpB && !ALIAS) issue_half(nxt, 1, 1, 0);
+      if (nsl > 1 && grpB && !ALIAS) { issue_half(nxt, 1, 1, 0); if (SCHED == 1) issue_half(nxt, 1, 1, 1); }
     }
 
+#ifdef TFASR_GEMM_TIMING
+    long long eph[4] = {0, 0, 0, 0};
+    long long etp = __builtin_readcyclecounter();
+#define EPI_TICK(k) { const long long t_ = __builtin_readcyclecounter(); eph[k] += t_ - etp; etp = t_; }
+#else
+#define EPI_TICK(k)
+#endif
     // ---- epilogue ----
     // Per 16-row fragment block: x = alpha * acc + bias in the MFMA C layout (lane (r, g): rows g*4+e, column j*16+r); the log-softmax
     // statistics are taken THERE - a row's 16 columns of one fragment sit in one 16-lane DPP row, so max / sum are register + DPP
@@ -312,14 +340,19 @@ void gemm_big_kernel(const tfasr_gemm_args p, const int gx, const int gy, const 
             lab[i][e] = rw < p.M ? p.row_label[rw] : -1;  // rw >= 0 always (M >= 256)
           }
       }
+      // strip write base of this lane: the writers of pass h are the lanes with (g * 4) / RPP == h, at strip rows (g * 4) % RPP + e
+      float* sw = sc + ((g * 4) % RPP) * SLD + r;
       float bc[NJ];
       bool cv[NJ];
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
         const int col = cb + j * 16 + r;
         cv[j] = col < p.N;
-        bc[j] = (p.bias && cv[j]) ? p.bias[col] : 0.f;
+        // statistics: a column past N carries -inf from here on (exp2 -> 0, never the maximum), so the 128 elements of a fragment block
+        // need no per-element column test (they were a third of this epilogue's vector instructions)
+        bc[j] = cv[j] ? (p.bias ? p.bias[col] : 0.f) : (C_LSE ? -INFINITY : 0.f);
       }
+      EPI_TICK(0)
 #pragma unroll
       for (int i = 0; i < NI; ++i) {
         __builtin_amdgcn_sched_barrier(0);
@@ -338,16 +371,18 @@ void gemm_big_kernel(const tfasr_gemm_args p, const int gx, const int gy, const 
           float pm[4][2], ps[4][2];
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
+            // ONE reference maximum per row for both 64-column slices of this wave (any finite reference >= the slice's own maximum is a
+            // valid (max, sum) pair for the merge): half the DPP row reductions
+            float m = x[0][e];
+#pragma unroll
+            for (int j = 1; j < NJ; ++j) m = fmaxf(m, x[j][e]);
+            m = row16_max(m);
+            const float mb = (m == -INFINITY) ? 0.f : m * L2E;  // every column of the wave past N: sums of exp2(-inf) = 0, no inf - inf
 #pragma unroll
             for (int sl = 0; sl < 2; ++sl) {
-              float m = -INFINITY;
-#pragma unroll
-              for (int jj = 0; jj < 4; ++jj) if (cv[sl * 4 + jj]) m = fmaxf(m, x[sl * 4 + jj][e]);
-              m = row16_max(m);
-              const float mb = m * L2E;
               float ssum = 0.f;
 #pragma unroll
-              for (int jj = 0; jj < 4; ++jj) if (cv[sl * 4 + jj]) ssum += __builtin_amdgcn_exp2f(x[sl * 4 + jj][e] * L2E - mb);
+              for (int jj = 0; jj < 4; ++jj) ssum += __builtin_amdgcn_exp2f(x[sl * 4 + jj][e] * L2E - mb);
               pm[e][sl] = m;
               ps[e][sl] = row16_sum(ssum);
             }
@@ -382,6 +417,7 @@ void gemm_big_kernel(const tfasr_gemm_args p, const int gx, const int gy, const 
               reinterpret_cast<float2*>(p.lse_part)[(long)row * p.lse_parts + slice] = make_float2(om, os);
           }
         }
+        EPI_TICK(1)
         if constexpr (C_LSE) { if (!Dt) continue; }  // statistics-only projection (D == NULL): no logits leave the chip, no transposition pass
 #pragma unroll
         for (int ch = 0; ch < NCH; ++ch) {
@@ -394,7 +430,7 @@ void gemm_big_kernel(const tfasr_gemm_args p, const int gx, const int gy, const 
 #pragma unroll
               for (int jj = 0; jj < JC; ++jj)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) sc[(g * 4 + e - h * RPP) * SLD + jj * 16 + r] = x[ch * JC + jj][e];
+                for (int e = 0; e < 4; ++e) sw[e * SLD + jj * 16] = x[ch * JC + jj][e];  // compile-time offsets from one per-lane base
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             float y[8];
@@ -436,6 +472,7 @@ _Pragma("unroll")
             }
           }
         }
+        EPI_TICK(2)
       }
     }
 #ifdef TFASR_GEMM_TIMING
@@ -444,12 +481,14 @@ _Pragma("unroll")
       long long* o = g_gemm_timing + 12L * ((bid * 2 + it) * 2 + (threadIdx.x >> 8));
       for (int k = 0; k < 8; ++k) o[k] = bph[k];
       o[8] = bt_main - bt_start; o[9] = t_end - bt_main; o[10] = t_end - bt_start;
+      long long* o2 = g_gemm_timing + 16384 + 4L * ((bid * 2 + it) * 2 + (threadIdx.x >> 8));
+      for (int k = 0; k < 3; ++k) o2[k] = eph[k];
     }
 #endif
     if (!nxt.ok) break;
     if constexpr (ALIAS) {
       __syncthreads();  // every wave is done with its strip
-      if (nsl > 1 && grpB) issue_half(nxt, 1, 1, 0);
+      if (nsl > 1 && grpB) { issue_half(nxt, 1, 1, 0); if (SCHED == 1) issue_half(nxt, 1, 1, 1); }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     cur = nxt;

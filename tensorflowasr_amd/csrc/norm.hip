@@ -316,7 +316,9 @@ template <int LPR> __device__ __forceinline__ float seg_sum(float v) {
   return v;
 }
 
-template <typename T, int LPR>
+// U rows in flight per lane group: all U row loads (and the coefficient loads) are issued before anything waits, so a wave's life is one
+// memory round trip + arithmetic + stores instead of a chain of them (one row at a time: 10.2 us for [23808, 256], the device copy 4.7).
+template <typename T, int LPR, int U = 2>
 __global__ __launch_bounds__(256) void ln_fwd_vec_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, T* __restrict__ y,
                                                          float* __restrict__ mean_out, float* __restrict__ rstd_out,
@@ -325,44 +327,57 @@ __global__ __launch_bounds__(256) void ln_fwd_vec_kernel(const T* __restrict__ x
   const int lane = threadIdx.x & 63, li = lane % LPR, sub = lane / LPR;
   const int c0 = li * 8;
   const bool act = c0 < C;
-  float g[8], b[8];
-  ldf8(gamma + c0, g, act);
-  ldf8(beta + c0, b, act);
   const long w0 = ((long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * RPW + sub;
   const long step = (long)gridDim.x * (blockDim.x >> 6) * RPW;
   const float invC = 1.f / C;
-  for (long r = w0; r < rows; r += step) {  // shuffles stay inside one LPR-lane segment (= one row)
-    const bool rv = true;
-    float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (rv && act) ld8(x + r * C + c0, v);
-    float s = 0.f;
+  for (long r0 = w0; r0 < rows; r0 += U * step) {  // shuffles stay inside one LPR-lane segment (= one row)
+    float v[U][8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) s += v[k];
-    const float mean = seg_sum<LPR>(s) * invC;
-    float q = 0.f;
+    for (int u = 0; u < U; ++u) {
 #pragma unroll
-    for (int k = 0; k < 8; ++k) { const float d = act ? v[k] - mean : 0.f; q += d * d; }
-    const float rstd = rsqrtf(seg_sum<LPR>(q) * invC + eps);
-    if (rv && act) {
-#pragma unroll
-      for (int k = 0; k < 8; ++k) v[k] = (v[k] - mean) * rstd * g[k] + b[k];
-      st8(y + r * C + c0, v);
+      for (int k = 0; k < 8; ++k) v[u][k] = 0.f;
+      const long r = r0 + u * step;
+      if (act && r < rows) ld8(x + r * C + c0, v[u]);
     }
-    if (rv && li == 0) { if (mean_out) mean_out[r] = mean; if (rstd_out) rstd_out[r] = rstd; }
+    float g[8], b[8];
+    ldf8(gamma + c0, g, act);
+    ldf8(beta + c0, b, act);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long r = r0 + u * step;
+      float s = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) s += v[u][k];
+      const float mean = seg_sum<LPR>(s) * invC;
+      float q = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { const float d = act ? v[u][k] - mean : 0.f; q += d * d; }
+      const float rstd = rsqrtf(seg_sum<LPR>(q) * invC + eps);
+      if (r < rows) {
+        if (act) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) v[u][k] = (v[u][k] - mean) * rstd * g[k] + b[k];
+          st8(y + r * C + c0, v[u]);
+        }
+        if (li == 0) { if (mean_out) mean_out[r] = mean; if (rstd_out) rstd_out[r] = rstd; }
+      }
+    }
   }
 }
 
 // Row-reduction kernels below end in one global atomicAdd per column per BLOCK, and same-address atomics serialise
 // (~20-30 ns each on this chip): with 512 blocks that tail alone cost ~10 us.  So: few (<= 128) fat 1024-thread blocks,
 // two rows in flight per lane for bandwidth, partial sums combined with LDS atomics, then <= 128 global atomics per column.
-template <typename T, int LPR>
-__global__ __launch_bounds__(512) void ln_bwd_vec_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+// U = rows in flight per lane (bytes in flight are what the memory system rewards: 2 rows x 3 streams x 16 B per lane left a
+// 512-thread block per CU at ~2.7 TB/s), NW = waves per block.
+template <typename T, int LPR, int U = 2, int NW = 8>
+__global__ __launch_bounds__(NW * 64) void ln_bwd_vec_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                           const float* __restrict__ gamma, const float* __restrict__ mean,
                                                           const float* __restrict__ rstd, const T* add, T* dx,
                                                           float* __restrict__ dgamma, float* __restrict__ dbeta, long rows,
                                                           int C, T* dxm, float drop_p, uint64_t drop_seed) {
   constexpr int RPW = 64 / LPR;
-  __shared__ float red[2][8 * RPW][LPR * 8];  // up to 8 waves (512 threads)
+  __shared__ float red[2][NW * RPW][LPR * 8];
   const int lane = threadIdx.x & 63, li = lane % LPR, sub = lane / LPR, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const int c0 = li * 8;
   const bool act = c0 < C;
@@ -374,11 +389,11 @@ __global__ __launch_bounds__(512) void ln_bwd_vec_kernel(const T* __restrict__ d
   const long w0 = ((long)blockIdx.x * nw + w) * RPW + sub;
   const long step = (long)gridDim.x * nw * RPW;
   const float invC = 1.f / C;
-  for (long r0 = w0; r0 < rows; r0 += 2 * step) {
-    float d[2][8], xv[2][8], o[2][8], m[2], rs[2];
-    bool rv[2];
+  for (long r0 = w0; r0 < rows; r0 += U * step) {
+    float d[U][8], xv[U][8], o[U][8], m[U], rs[U];
+    bool rv[U];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < U; ++u) {
       const long r = r0 + u * step;
       rv[u] = act && r < rows;
 #pragma unroll
@@ -390,7 +405,7 @@ __global__ __launch_bounds__(512) void ln_bwd_vec_kernel(const T* __restrict__ d
       }
     }
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < U; ++u) {
       float s1 = 0.f, s2 = 0.f;
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
@@ -512,8 +527,12 @@ extern "C" int tfasr_layernorm_fwd(const void* x, const float* gamma, const floa
   hipStream_t s = (hipStream_t)stream_;
   if (dtype == TFASR_BF16 && (C % 8) == 0 && C <= 512) {
     if (C <= 256) {
-      const int grid = (int)std::min<long>((rows + 7) / 8, 2048L);
-      hipLaunchKernelGGL((ln_fwd_vec_kernel<bf16_t, 32>), dim3(grid), dim3(256), 0, s, (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, rows, C, eps);
+      static const int U = getenv("TFASR_LN_FWD_U") ? atoi(getenv("TFASR_LN_FWD_U")) : 4;
+      static const long cap = getenv("TFASR_LN_FWD_GRID") ? atol(getenv("TFASR_LN_FWD_GRID")) : 2048L;
+      const int grid = (int)std::min<long>((rows + 8 * U - 1) / (8 * U), cap);
+      if (U == 4) hipLaunchKernelGGL((ln_fwd_vec_kernel<bf16_t, 32, 4>), dim3(grid), dim3(256), 0, s, (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, rows, C, eps);
+      else if (U == 1) hipLaunchKernelGGL((ln_fwd_vec_kernel<bf16_t, 32, 1>), dim3(grid), dim3(256), 0, s, (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, rows, C, eps);
+      else hipLaunchKernelGGL((ln_fwd_vec_kernel<bf16_t, 32>), dim3(grid), dim3(256), 0, s, (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, rows, C, eps);
     } else {
       const int grid = (int)std::min<long>((rows + 3) / 4, 2048L);
       hipLaunchKernelGGL((ln_fwd_vec_kernel<bf16_t, 64>), dim3(grid), dim3(256), 0, s, (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, rows, C, eps);
@@ -539,13 +558,18 @@ extern "C" int tfasr_layernorm_bwd_drop(const void* dy, const void* x, const flo
   if (dx_dropped && !(drop_p >= 0.f && drop_p < 1.f)) return TFASR_STATUS_INVALID_VALUE;
   hipStream_t s = (hipStream_t)stream_;
   if (dtype == TFASR_BF16 && (C % 8) == 0 && C <= 512) {
+#define LN_BWD_LAUNCH(LPR, U, NW) hipLaunchKernelGGL((ln_bwd_vec_kernel<bf16_t, LPR, U, NW>), dim3(grid), dim3(NW * 64), 0, s, (const bf16_t*)dy, (const bf16_t*)x, gamma, mean, rstd, (const bf16_t*)add, (bf16_t*)dx, dgamma, dbeta, rows, C, (bf16_t*)dx_dropped, drop_p, (uint64_t)drop_seed)
+    static const int U = getenv("TFASR_LN_BWD_U") ? atoi(getenv("TFASR_LN_BWD_U")) : 2;
+    static const bool wide = getenv("TFASR_LN_BWD_NW") && atoi(getenv("TFASR_LN_BWD_NW")) == 16;
     if (C <= 256) {
-      const int grid = fat_grid(rows, 2);
-      hipLaunchKernelGGL((ln_bwd_vec_kernel<bf16_t, 32>), dim3(grid), dim3(red_threads()), 0, s, (const bf16_t*)dy, (const bf16_t*)x, gamma, mean, rstd, (const bf16_t*)add, (bf16_t*)dx, dgamma, dbeta, rows, C, (bf16_t*)dx_dropped, drop_p, (uint64_t)drop_seed);
+      const int grid = std::max(1, fat_grid(rows, U) / (wide ? 2 : 1));
+      if (U == 4) { if (wide) LN_BWD_LAUNCH(32, 4, 16); else LN_BWD_LAUNCH(32, 4, 8); }
+      else { if (wide) LN_BWD_LAUNCH(32, 2, 16); else LN_BWD_LAUNCH(32, 2, 8); }
     } else {
-      const int grid = fat_grid(rows, 1);
-      hipLaunchKernelGGL((ln_bwd_vec_kernel<bf16_t, 64>), dim3(grid), dim3(red_threads()), 0, s, (const bf16_t*)dy, (const bf16_t*)x, gamma, mean, rstd, (const bf16_t*)add, (bf16_t*)dx, dgamma, dbeta, rows, C, (bf16_t*)dx_dropped, drop_p, (uint64_t)drop_seed);
+      const int grid = std::max(1, fat_grid(rows, 1) / (wide ? 2 : 1));
+      if (wide) LN_BWD_LAUNCH(64, 2, 16); else LN_BWD_LAUNCH(64, 2, 8);
     }
+#undef LN_BWD_LAUNCH
     TFASR_CHECK_LAUNCH();
     return TFASR_STATUS_SUCCESS;
   }
