@@ -50,7 +50,17 @@ void gemm_big_kernel(const tfasr_gemm_args p, const int gx, const int gy, const 
   // where the DMA pieces of the next slab are issued inside the fragment-read segments: 0 = in front of the reads, 2 = behind them (the
   // reads' latency then runs under the pieces' issue time: k-strided B, whose 16 transposing reads per k half make that segment the long
   // one, 878 -> 832 us on the joint projection; k-contiguous B measured 1 % slower), 1 = every piece between the MFMAs instead (probe
-  // only: the partner's fragment reads then crawl under the DMA traffic; 10 % slower on the data gradient)
+  // only: the partner's fragment reads then crawl under the DMA traffic; 10 % slower on the data gradient).  Cycle counters: whatever the
+  // placement, group B's first fragment-read segment of a slab (the one during which the HBM-cold op(A) pieces issued a segment earlier
+  // land in LDS) takes ~1600-1800 clocks against ~550-700 for the other three - the main loop's remaining slack.
+  // k-strided B also issues its pieces through inline asm (see glds16 in gemm_fast.hip: no compiler-made vmcnt(0) in front of the fragment
+  // reads: 780 -> 700 us on the joint projection); the k-contiguous-B kernels measured SLOWER that way (551 -> 627 us on the joint data
+  // gradient, whose reads then overlap the landing of its own pieces), so they keep the builtin.
+#ifdef TFASR_BIG_ASM_DMA
+  constexpr bool ASM_DMA = TFASR_BIG_ASM_DMA != 0;
+#else
+  constexpr bool ASM_DMA = !TB;
+#endif
 #ifdef TFASR_BIG_SCHED
   constexpr int SCHED = TFASR_BIG_SCHED;
 #else
@@ -155,14 +165,14 @@ void gemm_big_kernel(const tfasr_gemm_args p, const int gx, const int gy, const 
     const char* base = (const char*)((const bf16_t*)p.A + ((long)T.m0s + (i >> 1) * 16) * p.lda + da);
     uint32_t o = T.offA[i & 1];
     asm volatile("" : "+v"(o));  // opaque: or the 64-bit sums base + offset are kept (and spilled) per piece across the slab loop
-    __builtin_amdgcn_global_load_lds(GLB_PTR(base + o), LDS_PTR(dst + __builtin_amdgcn_readfirstlane((w * NA + i) * 1024)), 16, 0, 0);
+    glds16_s<ASM_DMA>(base, o, dst + __builtin_amdgcn_readfirstlane((w * NA + i) * 1024));
   };
   auto dma_b = [&](const Tile& T, int i, long db, char* dst) {
     // TB: piece i = rows 16 (i >> 1) further down than piece (i & 1); else: k rows 4 (i >> 1) further
     const char* base = (const char*)((const bf16_t*)p.B + db + (TB ? ((long)T.n0s + (i >> 1) * 16) * p.ldb : (long)(i >> 1) * 4 * p.ldb));
     uint32_t o = T.offB[i & 1];
     asm volatile("" : "+v"(o));
-    __builtin_amdgcn_global_load_lds(GLB_PTR(base + o), LDS_PTR(dst + A_B + __builtin_amdgcn_readfirstlane((w * NB + i) * 1024)), 16, 0, 0);
+    glds16_s<ASM_DMA>(base, o, dst + A_B + __builtin_amdgcn_readfirstlane((w * NB + i) * 1024));
   };
   // this wave's pieces of a slab in two halves: 0 = its NA pieces of op(A), 1 = its NB pieces of op(B)
   auto issue_half = [&](const Tile& T, int slab, int stage, int half) {

@@ -35,6 +35,46 @@ constexpr int A_BYTES = BM * BK * 2;
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 #define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 
+// One LDS-DMA piece (1 KiB per wave instruction): 16 bytes per lane from `g` to LDS byte offset (uniform) `lds` + 16 * lane.
+// Issued through inline asm ON PURPOSE: for the builtin the compiler knows an LDS write is pending and puts `s_waitcnt vmcnt(0)` in
+// front of the wave's next ds_read (it cannot prove the two do not alias) - i.e. it drained the whole prefetch queue in front of every
+// slab's fragment reads, and the main loop ran at one DMA round trip per slab with nothing in flight under the MFMAs (what the cycle
+// counters of round 2 showed and blamed on the hardware).  The pipeline's RAW / WAR ordering is the hand-counted `s_waitcnt vmcnt(N)` +
+// `s_barrier` pairs in the kernels; stores and plain loads the compiler issues keep their own (conservative: vmcnt retires in order)
+// waits.  TFASR_GLDS_BUILTIN=1 (compile time) restores the builtin for A/B runs.
+__device__ __forceinline__ uint32_t lds_u32(const char* s) {
+  // a generic pointer into LDS = the shared aperture (high half) + the LDS byte offset (low half)
+  return (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)s);
+}
+__device__ __forceinline__ void glds16(const void* g, const char* lds_uniform) {
+#ifdef TFASR_GLDS_BUILTIN
+  __builtin_amdgcn_global_load_lds(GLB_PTR(g), LDS_PTR(lds_uniform), 16, 0, 0);
+#else
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(lds_u32(lds_uniform)) : "memory");
+#endif
+}
+// the same with a uniform 64-bit base and a 32-bit per-lane byte offset (saddr form: no 64-bit vector add per piece)
+template <bool ASM = true>
+__device__ __forceinline__ void glds16_s(const char* base_uniform, uint32_t off, const char* lds_uniform) {
+#ifdef TFASR_GLDS_BUILTIN
+  constexpr bool BUILTIN = true;
+#else
+  constexpr bool BUILTIN = !ASM;
+#endif
+  if constexpr (BUILTIN) {
+    __builtin_amdgcn_global_load_lds(GLB_PTR(base_uniform + off), LDS_PTR(lds_uniform), 16, 0, 0);
+    return;
+  }
+#if 1
+  const uint64_t b = (uint64_t)base_uniform;
+  const uint64_t ub = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(b >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b);
+  // s_nop 4: the base usually reaches its SGPR pair through v_readfirstlane, and a VALU write of an SGPR needs 5 wait states before a
+  // vector-memory instruction reads it - the compiler's hazard recogniser does not look inside the asm (without them the piece went out
+  // with the previous base: memory faults at base 0 + lane offset)
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(ub), "s"(lds_u32(lds_uniform)) : "memory");
+#endif
+}
+
 __device__ __forceinline__ int key_d(int row) { return (row >> 1) & 7; }
 __device__ __forceinline__ int key_t(int k) { return ((k & 3) << 1) | (((k >> 3) & 1) << 3); }
 // 64-row trans image: 128-B k-rows, two per 256-B bank row -> spread rows {0..3, 8..11} over the 8 32-B windows
@@ -50,7 +90,7 @@ __device__ __forceinline__ void issue_direct(char* s, const bf16_t* g, long ld, 
     const int row = q * 8 + (lane >> 3), p = lane & 7;
     const int gr = min(rows0 + row, nrows - 1);
     const bf16_t* src = g + (long)gr * ld + kt + ((p ^ key_d(row)) << 3);
-    __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(s + __builtin_amdgcn_readfirstlane(q * 1024)), 16, 0, 0);
+    glds16(src, s + __builtin_amdgcn_readfirstlane(q * 1024));
   }
 }
 // trans: operand stored [K, rows] (ld); image [64 k][128 rows]
@@ -65,7 +105,7 @@ __device__ __forceinline__ void issue_trans(char* s, const bf16_t* g, long ld, i
     const int k = q * KPI + lane / CPR, p = lane % CPR;
     const int c = min((rows0 >> 3) + (p ^ (ROWS >= 128 ? key_t(k) : key_t64(k))), maxchunk);
     const bf16_t* src = g + (long)(kt + k) * ld + ((long)c << 3);
-    __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(s + __builtin_amdgcn_readfirstlane(q * 1024)), 16, 0, 0);
+    glds16(src, s + __builtin_amdgcn_readfirstlane(q * 1024));
   }
 }
 // Per-tile source pointers for the DMA (slab 0), so that issuing a slab costs one 64-bit add per instruction instead of the
@@ -99,7 +139,7 @@ __device__ __forceinline__ void issue_from(char* s, const bf16_t* const (&src)[R
 #pragma unroll
   for (int i = 0; i < ROWS / 32; ++i) {
     const int q = w * (ROWS / 32) + i;
-    __builtin_amdgcn_global_load_lds(GLB_PTR(src[i] + delta), LDS_PTR(s + __builtin_amdgcn_readfirstlane(q * 1024)), 16, 0, 0);
+    glds16(src[i] + delta, s + __builtin_amdgcn_readfirstlane(q * 1024));
   }
 }
 // K-tail staging with zero fill (plain stores into the same swizzled images)

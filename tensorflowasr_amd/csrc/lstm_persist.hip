@@ -285,7 +285,8 @@ __global__ __launch_bounds__(256) void lstm_persist_bwd_kernel(
 #pragma unroll
           for (int kk = 0; kk < KB; ++kk)
 #pragma unroll
-            for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kk][m], bw[k0 + kk], acc[m], 0, 0, 0);
+            for (int m = 0; m < MT; ++m)
+              if (k0 + kk < ks) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kk][m], bw[k0 + kk], acc[m], 0, 0, 0);  // bw[k >= ks] was never loaded
         }
       }
 #pragma unroll
