@@ -260,7 +260,7 @@ void gemm_big_kernel(const tfasr_gemm_args p, const int gx, const int gy, const 
 
     // every wave's pieces of slab 0 have landed BEFORE it arrives at the barrier that lets group A read them (first tile; later tiles
     // are drained after the epilogue anyway)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), compiler-visible (see gemm_fast.hip: tile boundary)
     if (grpB) __builtin_amdgcn_s_barrier();
     // The CU's vector-memory path takes ~16 clocks per 1-KiB piece whoever issues it: all 64-72 pieces of a slab in ONE segment made
     // that segment 1000+ clocks longer for both groups.  So they are spread over three: slab s+1's pieces are issued
@@ -500,7 +500,7 @@ _Pragma("unroll")
       __syncthreads();  // every wave is done with its strip
       if (nsl > 1 && grpB) { issue_half(nxt, 1, 1, 0); if (SCHED == 1) issue_half(nxt, 1, 1, 1); }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), compiler-visible (see gemm_fast.hip: tile boundary)
     cur = nxt;
   }
 }

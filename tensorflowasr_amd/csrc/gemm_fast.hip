@@ -192,9 +192,12 @@ __device__ __forceinline__ short8_t frag_trans(const char* s, int rowbase, int k
   return v;
 }
 
-template <bool TA, bool TB, int BN_, bool CS = false>
+struct NoHook { __device__ __forceinline__ void reads_done() const {} __device__ __forceinline__ void between(int) const {} };
+// Hook: reads_done() runs once every fragment read of the slab has been ISSUED (the caller may wait for them and release the stage),
+// between(q) after the q-th of the 8 groups of MFMAs (the caller's DMA pieces for the slab after next go there).
+template <bool TA, bool TB, int BN_, bool CS = false, typename Hook = NoHook>
 __device__ __forceinline__ void mma_slab(const char* sA, const char* sB, int wm, int wn, int lane, float4_t (&acc)[4][BN_ / 32],
-                                         float4_t* accb = nullptr, bool do_cs = false) {
+                                         float4_t* accb = nullptr, bool do_cs = false, const Hook& hook = Hook()) {
   constexpr int NJ = BN_ / 32, WN = BN_ / 2;
   const int r = lane & 15, g = lane >> 4;
   // All fragment reads of the slab are issued first (LDS returns in order, so the first MFMAs start as soon as their
@@ -215,12 +218,18 @@ __device__ __forceinline__ void mma_slab(const char* sA, const char* sB, int wm,
     }
   }
   __builtin_amdgcn_sched_barrier(0);
+  hook.reads_done();
 #pragma unroll
   for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 4; ++i) {
 #pragma unroll
       for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[kk][i], b[kk][j], acc[i][j], 0, 0, 0);
+      if constexpr (!std::is_same<Hook, NoHook>::value) {
+        hook.between(kk * 4 + i);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
   if constexpr (CS) {
     if (do_cs) {  // all-ones A fragment: every row of the result is sum_k B[k, n] (the bias gradient's share of this slab)
       const short one = (short)0x3F80;
@@ -372,6 +381,16 @@ __device__ __forceinline__ void gemm_fast_body(const tfasr_gemm_args& p, const i
     }
   };
 
+  // piece q of this wave's GI pieces of a slab: q < 4 -> op(A), else op(B)
+  auto issue_piece = [&](const Tile& T, int slab, int stage, int q) {
+    char* sA = smem + stage * STAGE_BYTES;
+    char* sB = sA + A_BYTES;
+    long dA_, dB_;
+    if constexpr (SEG) { dA_ = seg_tab[0][slab]; dB_ = seg_tab[1][slab]; }
+    else { dA_ = slab * stepA; dB_ = slab * stepB; }
+    if (q < 4) glds16(T.sa[q] + dA_, sA + __builtin_amdgcn_readfirstlane((w * 4 + q) * 1024));
+    else glds16(T.sb[q - 4] + dB_, sB + __builtin_amdgcn_readfirstlane((w * (BN_ / 32) + (q - 4)) * 1024));
+  };
   Tile cur = tile_of(0);
   if (cur.nfull < 0) return;
   if (cur.nfull > 0) issue(cur, 0, 0);
@@ -393,6 +412,10 @@ __device__ __forceinline__ void gemm_fast_body(const tfasr_gemm_args& p, const i
     const bool do_cs = C_CS && p.colsum && cur.m0 == 0 && wm == 0;  // first row of tiles, the two waves that cover its columns
 
     const int n = cur.nfull;
+    // compiler-visible vmcnt(0) in front of the slab loop (its bookkeeping otherwise carries a pending vector-memory event into the loop
+    // and puts its own s_waitcnt vmcnt(0) behind the first fragment reads of EVERY slab, draining the prefetch); costs the first tile the
+    // wait for its second slab, later tiles nothing (the tile boundary has drained the queue already)
+    __builtin_amdgcn_s_waitcnt(0x0F70);
 #ifdef TFASR_GEMM_TIMING
     long long ph[5] = {0, 0, 0, 0, 0};
 #define TFASR_TICK(k) { const long long t_ = __builtin_readcyclecounter(); ph[k] += t_ - tp; tp = t_; }
@@ -426,6 +449,7 @@ __device__ __forceinline__ void gemm_fast_body(const tfasr_gemm_args& p, const i
         TFASR_TICK(0)
         __builtin_amdgcn_s_barrier();
         TFASR_TICK(1)
+#ifdef TFASR_FAST_NO_ILV
         mma_slab<TA, TB, BN_, C_CS>(smem + stage * STAGE_BYTES, smem + stage * STAGE_BYTES + A_BYTES, wm, wn, lane, acc, accb, do_cs);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         TFASR_TICK(2)
@@ -433,6 +457,22 @@ __device__ __forceinline__ void gemm_fast_body(const tfasr_gemm_args& p, const i
         TFASR_TICK(3)
         if (s + 2 < n) issue(cur, s + 2, stage);
         TFASR_TICK(4)
+#else
+        // Every fragment of the slab is read into registers FIRST; once all waves' reads have returned the stage is free, and the pieces
+        // of slab s+2 are issued BETWEEN the slab's MFMAs (a piece costs its wave ~90 clocks of issue time: 8 of them in a row after the
+        // MFMAs were a serial 730 clocks per slab next to 512 clocks of matrix work)
+        struct Hook {
+          const decltype(issue_piece)& ip; const Tile& T; int slab, stage; bool on;
+          __device__ __forceinline__ void reads_done() const {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();  // every wave has its fragments: the stage may be refilled
+          }
+          __device__ __forceinline__ void between(int q) const { if (on && q < GI) ip(T, slab, stage, q); }
+        };
+        const Hook hook{issue_piece, cur, s + 2, stage, s + 2 < n};
+        mma_slab<TA, TB, BN_, C_CS, Hook>(smem + stage * STAGE_BYTES, smem + stage * STAGE_BYTES + A_BYTES, wm, wn, lane, acc, accb, do_cs, hook);
+        TFASR_TICK(2)
+#endif
       }
     }
     if (cur.tail) {
@@ -717,7 +757,11 @@ _Pragma("unroll")
     if (nxt.nfull < 0) break;
     // tile boundary: the epilogue's stores / loads are mixed into the vector-memory queue, so counted waits are void until
     // it drains once (the prefetched slabs had the whole epilogue to land)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // (the BUILTIN form, so that the compiler's own wait-count bookkeeping sees the queue empty here: with an asm wait it still believed
+    // the epilogue's stores pending and put its own s_waitcnt vmcnt(0) - for the re-use of their data registers - INSIDE the next tile's
+    // slab loop, where it drained the DMA prefetch once per slab)
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), expcnt / lgkmcnt untouched
+    asm volatile("" ::: "memory");
     drained = true;
     cur = nxt;
   }
