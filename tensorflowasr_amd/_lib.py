@@ -8,7 +8,7 @@ import os
 from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_long, c_size_t, c_void_p
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libtfasr_hip.so")
+LIB_PATH = os.environ.get("TFASR_LIB") or os.path.join(HERE, "lib", "libtfasr_hip.so")  # TFASR_LIB: A/B runs of two builds on one box
 
 TFASR_F32, TFASR_BF16 = 0, 1
 ACT_NONE, ACT_SWISH, ACT_TANH, ACT_SIGMOID, ACT_TANH_OUT = 0, 1, 2, 3, 4

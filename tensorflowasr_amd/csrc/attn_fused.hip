@@ -35,8 +35,15 @@ constexpr int SMEM_FWD = SK_BYTES + SV_BYTES + SP_BYTES + 4 * SGC_BYTES;
 __device__ __forceinline__ int key_d(int row) { return (row >> 1) & 7; }
 __device__ __forceinline__ int key_t64(int k) { return (((k >> 1) & 1) | (((k >> 3) & 1) << 1)) << 1; }
 
+// One LDS-DMA piece through inline asm (see glds16 in gemm_fast.hip): for the builtin the compiler puts s_waitcnt vmcnt(0) in front of the
+// wave's next LDS read, which is what a DOUBLE-BUFFERED loop must not have (the next tile's pieces are meant to stay in flight).  Only the
+// kernels whose waits are hand-counted for that use it; the single-buffered ones keep the builtin.
+__device__ __forceinline__ void glds16_asm(const void* g, const char* lds_uniform) {
+  const uint32_t l = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)lds_uniform);  // generic LDS pointer: low half = offset
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(l) : "memory");
+}
 // [rows][64] bf16 image, 128-B rows, 16-B chunk ^= key_d(row); global rows clamped to [0, nrows-1]
-template <int ROWS>
+template <int ROWS, bool ASM = false>
 __device__ __forceinline__ void load_rows(char* s, const bf16_t* g, long ld, int row0, int nrows, int w, int lane) {
 #pragma unroll
   for (int i = 0; i < ROWS / 32; ++i) {
@@ -44,7 +51,8 @@ __device__ __forceinline__ void load_rows(char* s, const bf16_t* g, long ld, int
     const int row = q * 8 + (lane >> 3), p = lane & 7;
     const int gr = min(max(row0 + row, 0), nrows - 1);
     const bf16_t* src = g + (long)gr * ld + ((p ^ key_d(row)) << 3);
-    __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(s + __builtin_amdgcn_readfirstlane(q * 1024)), 16, 0, 0);
+    if constexpr (ASM) glds16_asm(src, s + __builtin_amdgcn_readfirstlane(q * 1024));
+    else __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(s + __builtin_amdgcn_readfirstlane(q * 1024)), 16, 0, 0);
   }
 }
 // V block as [64 k=j][64 n=dh] "trans" image (128-B k-rows, chunk ^= key_t64(k)); k rows clamped to nrows-1
@@ -958,9 +966,9 @@ __global__ __launch_bounds__(256, 2) void relattn_dpext_kernel(
       const int il = qq / (DPX_TLD / 8), ch = qq % (DPX_TLD / 8);
       const int i = min(t.i0 + il, T - 1);
       const int j = min(max(t.jb0 + ch * 8, 0), lds - 8);
-      __builtin_amdgcn_global_load_lds(GLB_PTR(dsb + (long)i * lds + j), LDS_PTR(buf + __builtin_amdgcn_readfirstlane((w * 7 + q7) * 1024)), 16, 0, 0);
+      glds16_asm(dsb + (long)i * lds + j, buf + __builtin_amdgcn_readfirstlane((w * 7 + q7) * 1024));
     }
-    load_rows<BI>(buf + DPX_TILE_BYTES, qv + (long)t.b * T * HD + h * DH, HD, t.i0, T, w, lane);
+    load_rows<BI, true>(buf + DPX_TILE_BYTES, qv + (long)t.b * T * HD + h * DH, HD, t.i0, T, w, lane);
   };
 
   Tl cur, nxt;
