@@ -222,3 +222,32 @@ def test_data_gradient_times_tanh_prime_from_the_output(dev, M):
     ref = (dy.float() @ W.float().T) * (1 - h.float() ** 2)
     torch.cuda.synchronize()
     assert (out.float() - ref).abs().max().item() <= 0.02 * ref.abs().max().item() + 1e-2
+
+
+@pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, False)])
+@pytest.mark.parametrize("mnk", [(23808, 1024, 256), (23808, 256, 1024), (19200 + 8, 768, 256), (4100, 512, 2304), (12096, 256, 256)])
+def test_pipeline_race_screen_bitwise_repeatable(dev, ta, tb, mnk):
+    """The LDS-DMA pieces of the bf16 GEMMs go out through inline asm and are ordered by hand-counted vmcnt waits + barriers only (the
+    compiler no longer drains the queue in front of the fragment reads): a mis-counted wait would show up as a tile that depends on
+    timing.  Many multi-slab, multi-tile-per-workgroup products (persistent workgroups walk several tiles: the cross-tile prefetch is
+    in play), each run 6 times with other work in between: every run bitwise equal, and equal to the f32 reference within bf16 rounding."""
+    M, N, K = mnk
+    if ta and K > 4096:
+        return  # (weight-gradient layouts of that size accumulate with atomics: not bitwise repeatable by design)
+    g = torch.Generator().manual_seed(M + 3 * N + 7 * K + ta + 2 * tb)
+    A = (torch.randn((K, M) if ta else (M, K), generator=g) * 0.5).to(dev).to(torch.bfloat16)
+    B = (torch.randn((N, K) if tb else (K, N), generator=g) * 0.5).to(dev).to(torch.bfloat16)
+    noise = torch.randn(4096, 4096, device=dev)
+    outs = []
+    for it in range(6):
+        outs.append(kernels.matmul(A, B, trans_a=ta, trans_b=tb))
+        noise = noise * 1.0001 + 0.5  # unrelated traffic between the launches
+        if it % 2:
+            kernels.matmul(B if tb else B.t().contiguous(), B if not tb else B.t().contiguous())  # another GEMM on the same stream
+    torch.cuda.synchronize()
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+    rows = torch.randint(0, M, (64,), generator=g)
+    Af = (A.float().t() if ta else A.float())[rows.to(dev)]
+    ref = Af @ (B.float().t() if tb else B.float())
+    np.testing.assert_allclose(outs[0][rows.to(dev)].float().cpu().numpy(), ref.cpu().numpy(), rtol=2e-2, atol=2e-2 * float(np.sqrt(K)))
