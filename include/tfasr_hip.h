@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define TFASR_ABI_VERSION 20
+#define TFASR_ABI_VERSION 21
 
 typedef enum {
   TFASR_STATUS_SUCCESS = 0,
@@ -426,6 +426,18 @@ int tfasr_conv1_bn_bwd_stats_s2d(const void* x, const float* w, const float* bia
                                  int T0, int F0, int C, int dtype, void* stream);
 int tfasr_conv1_bn_bwd_apply_s2d(const void* x, const float* w, const float* bias, const float* fin, const float* bstats, float count,
                                  const void* dy, float* dw, float* db, int B, int T0, int F0, int C, int dtype, void* stream);
+/* The same through the Gram matrix of conv1's 3x3 patches (conv1 has one input channel: every sum over positions is a function of
+   gram = { G[9][9] = sum p p^T, s[9] = sum p, N } (91 doubles, zeroed and filled by tfasr_conv1_gram from the feature map) and of sums
+   against the incoming gradient): forward statistics [2C] without a pass over C channels x 9 taps per position; backward in ONE pass
+   over the gradient (bstats [2C] as tfasr_conv1_bn_bwd_stats_s2d + pbuf [10][C]: P[k][c] = sum p_k dz_c, row 9 = this rank's sum dz),
+   then tfasr_conv1_bn_bwd_finalize (after the caller's all-reduce of bstats; `count` = positions x world) adds conv1's weight / bias
+   gradients.  Same results as the two-pass route up to summation order (formulas: csrc/conv2d.hip). */
+int tfasr_conv1_gram(const void* x, double* gram, int B, int T0, int F0, int dtype, void* stream);
+int tfasr_conv1_stats_from_gram(const double* gram, const float* w, const float* bias, float* stats, int C, void* stream);
+int tfasr_conv1_bn_bwd_onepass_s2d(const void* x, const float* w, const float* bias, const float* fin, const void* dy, float* bstats,
+                                   float* pbuf, int B, int T0, int F0, int C, int dtype, void* stream);
+int tfasr_conv1_bn_bwd_finalize(const double* gram, const float* w, const float* bias, const float* fin, const float* bstats, float count,
+                                const float* pbuf, float* dw, float* db, int C, void* stream);
 int tfasr_halo_zero(void* x, int B, int T2, int F2, int W, int dtype, void* stream);
 int tfasr_s2d_edge_zero(void* x, int B, int T1, int F1, int C, int dtype, void* stream);
 int tfasr_im2col_3x3s2(const void* x, void* col, int B, int T1, int F1, int C, int dtype, void* stream);

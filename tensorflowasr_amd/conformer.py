@@ -70,6 +70,7 @@ class ConformerTransducer(BaseModel):
         self.time_reduction_factor = cfg.time_reduction_factor
         self.step = 0
         self._consts = {}
+        self._conv1_gram = os.environ.get("TFASR_CONV1_GRAM", "1") != "0"  # conv1 / BatchNorm0 sums through the patch Gram matrix (one backward pass)
         # SpecAugment draws and dropout masks are per replica (MirroredStrategy draws independent randomness on every
         # replica); the parameter initialisation seed above is shared by all ranks
         self._rng = np.random.default_rng([seed + 1000, int(self.dp.rank)])
@@ -329,9 +330,17 @@ class ConformerTransducer(BaseModel):
         w0, b0 = ps.p("enc/sub/conv0/w"), ps.p("enc/sub/conv0/b")
         fin0 = torch.empty(4 * C, dtype=torch.float32, device=self.device)
         nm = "enc/sub/bn0"
+        gram = None
         if training:
             stats = self._zeros_f32(2 * C + 1)[:2 * C + 1]
-            K.conv1_stats(feats, w0, b0, stats)
+            if self._conv1_gram:
+                # conv1 has one input channel: its BatchNorm's sums over positions are functions of the 3x3 patches' Gram matrix (91
+                # numbers from the feature map; csrc/conv2d.hip) - no pass over C channels x 9 taps per position, and the backward
+                # needs ONE pass over the 1 GB gradient instead of two
+                gram = K.conv1_gram(feats, torch.empty(91, dtype=torch.float64, device=self.device))
+                K.conv1_stats_from_gram(gram, w0, b0, stats)
+            else:
+                K.conv1_stats(feats, w0, b0, stats)
             count0 = B * T1 * F1 * self.dp.world
             self.dp.allreduce_stats_(stats[:2 * C])
             K.bn_finalize(stats, count0, ps.p(nm + "/g"), ps.p(nm + "/b"), fin0, ps.state[nm + "/mm"], ps.state[nm + "/mv"], 0.99, 1e-3, True)
@@ -342,7 +351,7 @@ class ConformerTransducer(BaseModel):
         K.conv1_bn_apply_s2d(feats, w0, b0, fin0, a1)
         K.halo_zero(a1, B, T2, F2, 4 * C)
         K.s2d_edge_zero(a1, B, T1, F1, C)
-        bn0 = (fin0, count0)
+        bn0 = (fin0, count0, gram)
         # conv2: every tap reads the same rows shifted by a constant -> one GEMM over 9 K-segments (bf16) / 9 products (f32)
         W = ps.w2d("enc/sub/conv1/w")  # [9C, C]
         _, o = self._salloc(rows, C, slack, tag="o")
@@ -412,12 +421,19 @@ class ConformerTransducer(BaseModel):
             else:
                 K.gemm(do, W, out, rows, C, len(segs) * C, C, C, 4 * C, trans_b=True, seg=(a_off, b_off, C // (a_off.numel() // len(segs))))
         # BatchNorm0 + conv1 backward from the feature map (only the valid slots of da1 are read: its halos need no clearing)
-        fin0, count0 = s["bn0"]
+        fin0, count0, gram = s["bn0"]
         w0, b0 = ps.p("enc/sub/conv0/w"), ps.p("enc/sub/conv0/b")
-        bstats = torch.zeros(2 * C, dtype=torch.float32, device=self.device)
-        K.conv1_bn_bwd_stats_s2d(s["feats"], w0, b0, fin0, da1, bstats)
-        self.dp.allreduce_stats_(bstats)
-        K.conv1_bn_bwd_apply_s2d(s["feats"], w0, b0, fin0, bstats, count0, da1, ps.g("enc/sub/conv0/w"), ps.g("enc/sub/conv0/b"))
+        if gram is not None:
+            zz = self._zeros_f32(12 * C)
+            bstats, pbuf = zz[:2 * C], zz[2 * C:12 * C]
+            K.conv1_bn_bwd_onepass_s2d(s["feats"], w0, b0, fin0, da1, bstats, pbuf)
+            self.dp.allreduce_stats_(bstats)
+            K.conv1_bn_bwd_finalize(gram, w0, b0, fin0, bstats, count0, pbuf, ps.g("enc/sub/conv0/w"), ps.g("enc/sub/conv0/b"))
+        else:
+            bstats = torch.zeros(2 * C, dtype=torch.float32, device=self.device)
+            K.conv1_bn_bwd_stats_s2d(s["feats"], w0, b0, fin0, da1, bstats)
+            self.dp.allreduce_stats_(bstats)
+            K.conv1_bn_bwd_apply_s2d(s["feats"], w0, b0, fin0, bstats, count0, da1, ps.g("enc/sub/conv0/w"), ps.g("enc/sub/conv0/b"))
         inv = 1.0 / self.dp.world
         K.axpy(ps.g("enc/sub/bn0/b"), bstats[:C].contiguous(), inv)
         K.axpy(ps.g("enc/sub/bn0/g"), bstats[C:].contiguous(), inv)

@@ -304,7 +304,7 @@ __global__ __launch_bounds__(256) void conv1_bn_kernel(const T* __restrict__ x, 
   extern __shared__ float sm[];
   float* xs = sm;                       // [3][F0 + 2] input rows of the current output row (zero padded)
   float* red = sm + 3 * (F0 + 2);       // [NQ][C] block reduction
-  constexpr int NQ = MODE == 3 ? 10 : 2;
+  constexpr int NQ = MODE == 3 ? 10 : (MODE == 4 ? 11 : 2);
   const int cgn = C / CPT, FS = 256 / cgn;
   const int cg = threadIdx.x % cgn, fs = threadIdx.x / cgn;
   const bool on = fs < FS;
@@ -369,8 +369,19 @@ __global__ __launch_bounds__(256) void conv1_bn_kernel(const T* __restrict__ x, 
         for (int k = 0; k < CPT; ++k) {
           const float dz = d[k] * dswishf_(a[k] * sc[k] + sh[k]);
           const float xh = (a[k] - mean[k]) * rstd[k];
-          if (MODE == 2) { acc2[0][k] += dz; acc2[1][k] += dz * xh; }
+          if (MODE == 2 || MODE == 4) { acc2[0][k] += dz; acc2[1][k] += dz * xh; }
           else d[k] = sc[k] * (dz - s0[k] - xh * s1[k]);  // gradient w.r.t. conv1's output
+          if (MODE == 4) d[k] = dz;
+        }
+        if (MODE == 4) {  // P[tap][c] += patch[tap] * dz_c: with the patch Gram matrix this is all conv1's weight gradient needs (below)
+#pragma unroll
+          for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+              const float xv = xs[kh * (F0 + 2) + 2 * f + kw];
+#pragma unroll
+              for (int k = 0; k < CPT; ++k) acc2[2 + kh * 3 + kw][k] += d[k] * xv;
+            }
         }
         if (MODE == 3) {
 #pragma unroll
@@ -405,10 +416,136 @@ __global__ __launch_bounds__(256) void conv1_bn_kernel(const T* __restrict__ x, 
     if (MODE == 3) {
       if (q < 9) atomicAdd(out0 + q * C + cc, red[i]);
       else if (out1) atomicAdd(out1 + cc, red[i]);
+    } else if (MODE == 4) {
+      if (q < 2) atomicAdd(out0 + q * C + cc, red[i]);        // bstats (the caller all-reduces them across ranks)
+      if (q >= 2) atomicAdd(out1 + (q - 2) * C + cc, red[i]);  // P[9][C]
+      if (q == 0) atomicAdd(out1 + 9 * C + cc, red[i]);        // this rank's own sum of dz (the bias gradient's first term)
     } else {
       atomicAdd(out0 + q * C + cc, red[i]);  // stats[0:C] = first quantity, stats[C:2C] = second
     }
   }
+}
+
+// ---- conv1 + BatchNorm0 through the GRAM MATRIX of the 3x3 patches ---------------------------------------------------------------
+// conv1 has ONE input channel: z_c(pos) = sum_k W[k,c] p_k(pos) + b_c with the 9-element patch p(pos).  Every sum over positions that
+// the BatchNorm around it needs is therefore a function of  G = sum_pos p p^T (9x9),  s = sum_pos p (9),  N = #positions  - 91 numbers
+// computed once per step from the 30 MB feature map - and of sums against the incoming gradient:
+//   forward statistics   sum z_c   = W_c.s + N b_c                  sum z_c^2 = W_c^T G W_c + 2 b_c W_c.s + N b_c^2
+//   backward             d_c(pos)  = sc_c (dz_c - s0_c - xhat_c s1_c)                    (s0, s1 = global means of dz, dz xhat)
+//                        dW[k,c]   = sum_pos p_k d_c = sc_c (P[k,c] - s0_c s_k - s1_c X[k,c]),   P[k,c] = sum_pos p_k dz_c
+//                        X[k,c]    = sum_pos p_k xhat_c = rstd_c ((G W_c)_k + (b_c - mean_c) s_k)
+//                        db[c]     = sc_c (sum dz_c - s0_c N - s1_c rstd_c (W_c.s + N (b_c - mean_c)))      (all sums of THIS rank)
+// so the backward is ONE pass over the 1 GB gradient (sum dz, sum dz xhat, P) instead of two (statistics, then apply + weight
+// gradient), and the forward statistics pass over 256 channels x 9 taps per position is replaced by the 54 sums of the patch moments.
+// Accumulated in double (the combinations cancel: log-mel features have mean^2 >> variance).
+constexpr int GRAM_N = 81 + 9 + 1;
+template <typename T>
+__global__ __launch_bounds__(256) void conv1_gram_kernel(const T* __restrict__ x, double* __restrict__ out, int B, int T0, int F0, int T1, int F1) {
+  extern __shared__ float sm[];  // [RB][3][F0 + 2]
+  constexpr int RB = 6;
+  const int W2 = F0 + 2;
+  double g[45], sv[9];
+#pragma unroll
+  for (int i = 0; i < 45; ++i) g[i] = 0.0;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) sv[i] = 0.0;
+  const int nrows = B * T1;
+  for (int row0 = blockIdx.x * RB; row0 < nrows; row0 += gridDim.x * RB) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < RB * 3 * W2; i += 256) {
+      const int rr = i / (3 * W2), j = i - rr * 3 * W2, kh = j / W2, fi = j - kh * W2 - 2;
+      const int row = row0 + rr;
+      float v = 0.f;
+      if (row < nrows) {
+        const int b = row / T1, t = row - b * T1, ti = 2 * t + kh - 2;
+        if (ti >= 0 && ti < T0 && fi >= 0 && fi < F0) v = Num<T>::ld(x + ((long)b * T0 + ti) * F0 + fi);
+      }
+      sm[i] = v;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < RB * F1; i += 256) {
+      const int rr = i / F1, f = i - rr * F1;
+      if (row0 + rr >= nrows) continue;
+      double pv[9];
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) pv[kh * 3 + kw] = (double)sm[(rr * 3 + kh) * W2 + 2 * f + kw];
+      int q = 0;
+#pragma unroll
+      for (int a = 0; a < 9; ++a) {
+        sv[a] += pv[a];
+#pragma unroll
+        for (int bb = a; bb < 9; ++bb) g[q++] += pv[a] * pv[bb];
+      }
+    }
+  }
+  // block reduction: wave shuffles, then one LDS slot per wave, then 54 global atomics per block
+  __shared__ double wred[4][54];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < 54; ++i) {
+    double v = i < 45 ? g[i] : sv[i - 45];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    if (lane == 0) wred[w][i] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 54) {
+    const double v = wred[0][threadIdx.x] + wred[1][threadIdx.x] + wred[2][threadIdx.x] + wred[3][threadIdx.x];
+    if (threadIdx.x < 45) {  // upper triangle entry -> both (a, b) and (b, a)
+      int a = 0, rem = threadIdx.x;
+      while (rem >= 9 - a) { rem -= 9 - a; ++a; }
+      const int bb = a + rem;
+      atomicAdd(out + a * 9 + bb, v);
+      if (bb != a) atomicAdd(out + bb * 9 + a, v);
+    } else {
+      atomicAdd(out + 81 + (threadIdx.x - 45), v);
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 64) out[90] = (double)nrows * (double)F1;
+}
+// statistics [2C] = (sum z, sum z^2) from the patch moments
+__global__ __launch_bounds__(256) void conv1_stats_from_gram_kernel(const double* __restrict__ gram, const float* __restrict__ w, const float* __restrict__ bias,
+                                                                    float* __restrict__ stats, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double wc[9], ws = 0.0, wgw = 0.0;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) { wc[k] = (double)w[k * C + c]; ws += wc[k] * gram[81 + k]; }
+#pragma unroll
+  for (int a = 0; a < 9; ++a) {
+    double t = 0.0;
+#pragma unroll
+    for (int bb = 0; bb < 9; ++bb) t += gram[a * 9 + bb] * wc[bb];
+    wgw += wc[a] * t;
+  }
+  const double N = gram[90], b = bias ? (double)bias[c] : 0.0;
+  stats[c] = (float)(ws + N * b);
+  stats[C + c] = (float)(wgw + 2.0 * b * ws + N * b * b);
+}
+// conv1 weight / bias gradients from P (one-pass backward), the patch moments and the (all-reduced) BatchNorm statistics
+__global__ __launch_bounds__(256) void conv1_bn_bwd_finalize_kernel(const double* __restrict__ gram, const float* __restrict__ w, const float* __restrict__ bias,
+                                                                    const float* __restrict__ fin, const float* __restrict__ bstats, float inv_count,
+                                                                    const float* __restrict__ pbuf, float* __restrict__ dw, float* __restrict__ db, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double mean = fin[c], rstd = fin[C + c], sc = fin[2 * C + c];
+  const double s0 = (double)bstats[c] * inv_count, s1 = (double)bstats[C + c] * inv_count;
+  const double N = gram[90], b = bias ? (double)bias[c] : 0.0;
+  double wc[9], ws = 0.0;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) { wc[k] = (double)w[k * C + c]; ws += wc[k] * gram[81 + k]; }
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    double gw = 0.0;
+#pragma unroll
+    for (int bb = 0; bb < 9; ++bb) gw += gram[k * 9 + bb] * wc[bb];
+    const double sk = gram[81 + k];
+    const double X = rstd * (gw + (b - mean) * sk);
+    dw[k * C + c] += (float)(sc * ((double)pbuf[k * C + c] - s0 * sk - s1 * X));
+  }
+  if (db) db[c] += (float)(sc * ((double)pbuf[9 * C + c] - s0 * N - s1 * rstd * (ws + N * (b - mean))));
 }
 
 // Zero the halo rows (tt == 0 or ff == 0) of a [B, T2+1, F2+1, W] tensor (W = 4C for the S layout, C for the conv2 output side).
@@ -520,10 +657,11 @@ static int conv1_bn_launch(const void* x, const float* w, const float* bias, con
                            const void* dy, float* out0, float* out1, int B, int T0, int F0, int C, int dtype, void* stream_) {
   if (!x || !w || B <= 0 || T0 <= 0 || F0 <= 0 || C <= 0 || C > 256 || (C % 8)) return TFASR_STATUS_INVALID_VALUE;
   constexpr int CPT = MODE >= 2 ? 4 : 8;
+  constexpr int NQL = MODE == 3 ? 10 : (MODE == 4 ? 11 : 2);
   const int T1 = (T0 + 1) / 2, F1 = (F0 + 1) / 2;
   hipStream_t s = (hipStream_t)stream_;
   const int grid = std::min(B * T1, MODE == 1 ? 8192 : 1024);
-  const size_t smem = (size_t)(3 * (F0 + 2) + (MODE == 3 ? 10 : 2) * C) * sizeof(float);
+  const size_t smem = (size_t)(3 * (F0 + 2) + NQL * C) * sizeof(float);
   const float inv = count > 0.f ? 1.f / count : 0.f;
   DISPATCH_T(dtype,
              hipLaunchKernelGGL((conv1_bn_kernel<float, MODE, CPT>), dim3(grid), dim3(256), smem, s, (const float*)x, w, bias, fin, bstats, inv, (float*)y,
@@ -554,6 +692,38 @@ extern "C" int tfasr_conv1_bn_bwd_apply_s2d(const void* x, const float* w, const
                                             void* stream_) {
   if (!fin || !bstats || !dy || !dw || count <= 0.f) return TFASR_STATUS_INVALID_VALUE;
   return conv1_bn_launch<3>(x, w, bias, fin, bstats, count, nullptr, dy, dw, db, B, T0, F0, C, dtype, stream_);
+}
+
+extern "C" int tfasr_conv1_gram(const void* x, double* gram, int B, int T0, int F0, int dtype, void* stream_) {
+  if (!x || !gram || B <= 0 || T0 <= 0 || F0 <= 0) return TFASR_STATUS_INVALID_VALUE;
+  const int T1 = (T0 + 1) / 2, F1 = (F0 + 1) / 2;
+  hipStream_t s = (hipStream_t)stream_;
+  if (hipMemsetAsync(gram, 0, GRAM_N * sizeof(double), s) != hipSuccess) return TFASR_STATUS_EXECUTION_FAILED;
+  const int grid = std::max(1, std::min((B * T1 + 5) / 6, 128));
+  const size_t smem = (size_t)6 * 3 * (F0 + 2) * sizeof(float);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(conv1_gram_kernel<float>, dim3(grid), dim3(256), smem, s, (const float*)x, gram, B, T0, F0, T1, F1),
+             hipLaunchKernelGGL(conv1_gram_kernel<bf16_t>, dim3(grid), dim3(256), smem, s, (const bf16_t*)x, gram, B, T0, F0, T1, F1));
+  TFASR_CHECK_LAUNCH();
+  return TFASR_STATUS_SUCCESS;
+}
+extern "C" int tfasr_conv1_stats_from_gram(const double* gram, const float* w, const float* bias, float* stats, int C, void* stream_) {
+  if (!gram || !w || !stats || C <= 0) return TFASR_STATUS_INVALID_VALUE;
+  hipLaunchKernelGGL(conv1_stats_from_gram_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream_, gram, w, bias, stats, C);
+  TFASR_CHECK_LAUNCH();
+  return TFASR_STATUS_SUCCESS;
+}
+extern "C" int tfasr_conv1_bn_bwd_onepass_s2d(const void* x, const float* w, const float* bias, const float* fin, const void* dy, float* bstats,
+                                              float* pbuf, int B, int T0, int F0, int C, int dtype, void* stream_) {
+  if (!fin || !dy || !bstats || !pbuf) return TFASR_STATUS_INVALID_VALUE;
+  return conv1_bn_launch<4>(x, w, bias, fin, nullptr, 0.f, nullptr, dy, bstats, pbuf, B, T0, F0, C, dtype, stream_);
+}
+extern "C" int tfasr_conv1_bn_bwd_finalize(const double* gram, const float* w, const float* bias, const float* fin, const float* bstats,
+                                           float count, const float* pbuf, float* dw, float* db, int C, void* stream_) {
+  if (!gram || !w || !fin || !bstats || !pbuf || !dw || C <= 0 || count <= 0.f) return TFASR_STATUS_INVALID_VALUE;
+  hipLaunchKernelGGL(conv1_bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream_, gram, w, bias, fin, bstats,
+                     1.f / count, pbuf, dw, db, C);
+  TFASR_CHECK_LAUNCH();
+  return TFASR_STATUS_SUCCESS;
 }
 
 extern "C" int tfasr_halo_zero(void* x, int B, int T2, int F2, int W, int dtype, void* stream_) {

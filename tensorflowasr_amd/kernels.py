@@ -601,6 +601,29 @@ def conv1_bn_bwd_apply_s2d(x, w, bias, fin, bstats, count, dy, dw, db):
                                             w.shape[-1], _dt(x), _stream()), "conv1_bn_bwd_apply")
 
 
+def conv1_gram(x, gram):
+    """gram: 91 f64 (G[9][9], s[9], N) of conv1's 3x3 patches over every output position of the feature map x [B, T0, F0]."""
+    B, T0, F0 = x.shape[:3]
+    assert gram.dtype == torch.float64 and gram.numel() >= 91
+    check(_L().tfasr_conv1_gram(_p(x), _p(gram), B, T0, F0, _dt(x), _stream()), "conv1_gram")
+    return gram
+
+
+def conv1_stats_from_gram(gram, w, bias, stats):
+    check(_L().tfasr_conv1_stats_from_gram(_p(gram), _p(w), _p(bias), _p(stats), w.shape[-1], _stream()), "conv1_stats_from_gram")
+
+
+def conv1_bn_bwd_onepass_s2d(x, w, bias, fin, dy, bstats, pbuf):
+    B, T0, F0 = x.shape[:3]
+    check(_L().tfasr_conv1_bn_bwd_onepass_s2d(_p(x), _p(w), _p(bias), _p(fin), _p(dy), _p(bstats), _p(pbuf), B, T0, F0, w.shape[-1], _dt(x),
+                                              _stream()), "conv1_bn_bwd_onepass")
+
+
+def conv1_bn_bwd_finalize(gram, w, bias, fin, bstats, count, pbuf, dw, db):
+    check(_L().tfasr_conv1_bn_bwd_finalize(_p(gram), _p(w), _p(bias), _p(fin), _p(bstats), float(count), _p(pbuf), _p(dw), _p(db), w.shape[-1],
+                                           _stream()), "conv1_bn_bwd_finalize")
+
+
 def halo_zero(x, B, T2, F2, W):
     check(_L().tfasr_halo_zero(_p(x), B, T2, F2, W, _dt(x), _stream()), "halo_zero")
     return x
