@@ -427,11 +427,13 @@ int tfasr_conv1_bn_bwd_stats_s2d(const void* x, const float* w, const float* bia
 int tfasr_conv1_bn_bwd_apply_s2d(const void* x, const float* w, const float* bias, const float* fin, const float* bstats, float count,
                                  const void* dy, float* dw, float* db, int B, int T0, int F0, int C, int dtype, void* stream);
 /* The same through the Gram matrix of conv1's 3x3 patches (conv1 has one input channel: every sum over positions is a function of
-   gram = { G[9][9] = sum p p^T, s[9] = sum p, N } (91 doubles, zeroed and filled by tfasr_conv1_gram from the feature map) and of sums
+   gram = { G[9][9] = sum p p^T, s[9] = sum p, N } (a buffer of TFASR_CONV1_GRAM_DOUBLES doubles: 8 partial copies of the 91 sums, zeroed and
+   filled by tfasr_conv1_gram from the feature map; the consumers add the copies up) and of sums
    against the incoming gradient): forward statistics [2C] without a pass over C channels x 9 taps per position; backward in ONE pass
    over the gradient (bstats [2C] as tfasr_conv1_bn_bwd_stats_s2d + pbuf [10][C]: P[k][c] = sum p_k dz_c, row 9 = this rank's sum dz),
    then tfasr_conv1_bn_bwd_finalize (after the caller's all-reduce of bstats; `count` = positions x world) adds conv1's weight / bias
    gradients.  Same results as the two-pass route up to summation order (formulas: csrc/conv2d.hip). */
+#define TFASR_CONV1_GRAM_DOUBLES 768
 int tfasr_conv1_gram(const void* x, double* gram, int B, int T0, int F0, int dtype, void* stream);
 int tfasr_conv1_stats_from_gram(const double* gram, const float* w, const float* bias, float* stats, int C, void* stream);
 int tfasr_conv1_bn_bwd_onepass_s2d(const void* x, const float* w, const float* bias, const float* fin, const void* dy, float* bstats,

@@ -337,7 +337,7 @@ class ConformerTransducer(BaseModel):
                 # conv1 has one input channel: its BatchNorm's sums over positions are functions of the 3x3 patches' Gram matrix (91
                 # numbers from the feature map; csrc/conv2d.hip) - no pass over C channels x 9 taps per position, and the backward
                 # needs ONE pass over the 1 GB gradient instead of two
-                gram = K.conv1_gram(feats, torch.empty(91, dtype=torch.float64, device=self.device))
+                gram = K.conv1_gram(feats, torch.empty(K.CONV1_GRAM_DOUBLES, dtype=torch.float64, device=self.device))
                 K.conv1_stats_from_gram(gram, w0, b0, stats)
             else:
                 K.conv1_stats(feats, w0, b0, stats)

@@ -439,6 +439,9 @@ __global__ __launch_bounds__(256) void conv1_bn_kernel(const T* __restrict__ x, 
 // gradient), and the forward statistics pass over 256 channels x 9 taps per position is replaced by the 54 sums of the patch moments.
 // Accumulated in double (the combinations cancel: log-mel features have mean^2 >> variance).
 constexpr int GRAM_N = 81 + 9 + 1;
+// the sums are spread over GRAM_COPIES copies (stride GRAM_STRIDE doubles) by block index: same-address atomics serialise (~25 ns each),
+// 1024 blocks on one copy would queue for 25 us; the consumers add the copies up
+constexpr int GRAM_COPIES = 8, GRAM_STRIDE = 96;
 template <typename T>
 __global__ __launch_bounds__(256) void conv1_gram_kernel(const T* __restrict__ x, double* __restrict__ out, int B, int T0, int F0, int T1, int F1) {
   extern __shared__ float sm[];  // [RB][3][F0 + 2]
@@ -491,6 +494,7 @@ __global__ __launch_bounds__(256) void conv1_gram_kernel(const T* __restrict__ x
     if (lane == 0) wred[w][i] = v;
   }
   __syncthreads();
+  out += (blockIdx.x % GRAM_COPIES) * GRAM_STRIDE;
   if (threadIdx.x < 54) {
     const double v = wred[0][threadIdx.x] + wred[1][threadIdx.x] + wred[2][threadIdx.x] + wred[3][threadIdx.x];
     if (threadIdx.x < 45) {  // upper triangle entry -> both (a, b) and (b, a)
@@ -506,8 +510,15 @@ __global__ __launch_bounds__(256) void conv1_gram_kernel(const T* __restrict__ x
   if (blockIdx.x == 0 && threadIdx.x == 64) out[90] = (double)nrows * (double)F1;
 }
 // statistics [2C] = (sum z, sum z^2) from the patch moments
-__global__ __launch_bounds__(256) void conv1_stats_from_gram_kernel(const double* __restrict__ gram, const float* __restrict__ w, const float* __restrict__ bias,
+__global__ __launch_bounds__(256) void conv1_stats_from_gram_kernel(const double* __restrict__ gram_copies, const float* __restrict__ w, const float* __restrict__ bias,
                                                                     float* __restrict__ stats, int C) {
+  __shared__ double gram[GRAM_N];
+  for (int i = threadIdx.x; i < GRAM_N; i += blockDim.x) {
+    double v = 0.0;
+    for (int q = 0; q < GRAM_COPIES; ++q) v += gram_copies[q * GRAM_STRIDE + i];
+    gram[i] = v;
+  }
+  __syncthreads();
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   double wc[9], ws = 0.0, wgw = 0.0;
@@ -525,9 +536,16 @@ __global__ __launch_bounds__(256) void conv1_stats_from_gram_kernel(const double
   stats[C + c] = (float)(wgw + 2.0 * b * ws + N * b * b);
 }
 // conv1 weight / bias gradients from P (one-pass backward), the patch moments and the (all-reduced) BatchNorm statistics
-__global__ __launch_bounds__(256) void conv1_bn_bwd_finalize_kernel(const double* __restrict__ gram, const float* __restrict__ w, const float* __restrict__ bias,
+__global__ __launch_bounds__(256) void conv1_bn_bwd_finalize_kernel(const double* __restrict__ gram_copies, const float* __restrict__ w, const float* __restrict__ bias,
                                                                     const float* __restrict__ fin, const float* __restrict__ bstats, float inv_count,
                                                                     const float* __restrict__ pbuf, float* __restrict__ dw, float* __restrict__ db, int C) {
+  __shared__ double gram[GRAM_N];
+  for (int i = threadIdx.x; i < GRAM_N; i += blockDim.x) {
+    double v = 0.0;
+    for (int q = 0; q < GRAM_COPIES; ++q) v += gram_copies[q * GRAM_STRIDE + i];
+    gram[i] = v;
+  }
+  __syncthreads();
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   const double mean = fin[c], rstd = fin[C + c], sc = fin[2 * C + c];
@@ -698,8 +716,8 @@ extern "C" int tfasr_conv1_gram(const void* x, double* gram, int B, int T0, int 
   if (!x || !gram || B <= 0 || T0 <= 0 || F0 <= 0) return TFASR_STATUS_INVALID_VALUE;
   const int T1 = (T0 + 1) / 2, F1 = (F0 + 1) / 2;
   hipStream_t s = (hipStream_t)stream_;
-  if (hipMemsetAsync(gram, 0, GRAM_N * sizeof(double), s) != hipSuccess) return TFASR_STATUS_EXECUTION_FAILED;
-  const int grid = std::max(1, std::min((B * T1 + 5) / 6, 128));
+  if (hipMemsetAsync(gram, 0, GRAM_COPIES * GRAM_STRIDE * sizeof(double), s) != hipSuccess) return TFASR_STATUS_EXECUTION_FAILED;
+  const int grid = std::max(1, std::min((B * T1 + 5) / 6, 1024));
   const size_t smem = (size_t)6 * 3 * (F0 + 2) * sizeof(float);
   DISPATCH_T(dtype, hipLaunchKernelGGL(conv1_gram_kernel<float>, dim3(grid), dim3(256), smem, s, (const float*)x, gram, B, T0, F0, T1, F1),
              hipLaunchKernelGGL(conv1_gram_kernel<bf16_t>, dim3(grid), dim3(256), smem, s, (const bf16_t*)x, gram, B, T0, F0, T1, F1));

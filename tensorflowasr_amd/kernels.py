@@ -601,10 +601,14 @@ def conv1_bn_bwd_apply_s2d(x, w, bias, fin, bstats, count, dy, dw, db):
                                             w.shape[-1], _dt(x), _stream()), "conv1_bn_bwd_apply")
 
 
+CONV1_GRAM_DOUBLES = 768  # TFASR_CONV1_GRAM_DOUBLES (include/tfasr_hip.h)
+
+
 def conv1_gram(x, gram):
-    """gram: 91 f64 (G[9][9], s[9], N) of conv1's 3x3 patches over every output position of the feature map x [B, T0, F0]."""
+    """gram: CONV1_GRAM_DOUBLES f64 (8 partial copies, stride 96, of G[9][9], s[9], N) of conv1's 3x3 patches over every output position
+    of the feature map x [B, T0, F0]."""
     B, T0, F0 = x.shape[:3]
-    assert gram.dtype == torch.float64 and gram.numel() >= 91
+    assert gram.dtype == torch.float64 and gram.numel() >= CONV1_GRAM_DOUBLES
     check(_L().tfasr_conv1_gram(_p(x), _p(gram), B, T0, F0, _dt(x), _stream()), "conv1_gram")
     return gram
 
