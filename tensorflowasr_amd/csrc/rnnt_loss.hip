@@ -19,6 +19,7 @@
 //   3. rnnt_grad     : one wave per lattice node, rewrites the row with the gradient
 #include "common.h"
 #include <algorithm>
+#include <stdlib.h>
 
 namespace {
 
@@ -387,10 +388,12 @@ __global__ __launch_bounds__(256) void rnnt_grad_kernel(
 __global__ __launch_bounds__(256) void rnnt_coef_kernel(
     const int32_t* __restrict__ label_len, const int32_t* __restrict__ logit_len, const float* __restrict__ grad_scale,
     const long* __restrict__ cell_off, long nrows, int B, int Tm, int U1, const float* __restrict__ lse, const float* __restrict__ blank_lp,
-    const float* __restrict__ truth_lp, const float* __restrict__ alpha, const float* __restrict__ beta, float4* __restrict__ coef) {
+    const float* __restrict__ truth_lp, const float* __restrict__ alpha, const float* __restrict__ beta, float4* __restrict__ coef,
+    const int32_t* __restrict__ labels = nullptr, int V = 0, int32_t* __restrict__ rlab = nullptr) {
   for (long r = (long)blockIdx.x * blockDim.x + threadIdx.x; r < nrows; r += (long)gridDim.x * blockDim.x) {
     const Cell cl = locate(r, cell_off, B, Tm, U1, label_len, logit_len);
-    float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 c = make_float4(3.0e38f, 0.f, 0.f, 0.f);  // outside the lattice: exp2(x - 3e38) = 0, times 0: a zero gradient whatever the logit
+    if (rlab) rlab[r] = (cl.valid && cl.u < cl.Ul) ? min(max(labels[(long)cl.b * (U1 - 1) + cl.u], 0), V - 1) : -1;
     if (cl.valid) {
       const int u = cl.u, t = cl.t, b = cl.b, Tl = cl.Tl, Ul = cl.Ul;
       const int ustride = cell_off ? Ul + 1 : U1;
@@ -407,6 +410,59 @@ __global__ __launch_bounds__(256) void rnnt_coef_kernel(
   }
 }
 
+// Loss gradient as a pure stream over the logits: g = exp2(x log2(e) - c.x) c.y, + c.z in column 0, + c.w in the label's column, with the
+// four per-row coefficients (and the row's label) computed beforehand by rnnt_coef_kernel.  rnnt_grad_kernel does the same in one launch
+// but opens every row with a dependent chain (cell lookup -> alpha / beta / lse / log-probabilities -> exponentials) before it can
+// touch the row: 2.6 TB/s.  Here every load of a row pair is issued up front and only the 16-byte coefficient record is per-row state.
+// Same arithmetic in the same order: bitwise the same gradients.
+template <typename T>
+__global__ __launch_bounds__(256) void rnnt_grad_apply_kernel(const T* __restrict__ logits, T* __restrict__ grads, const float4* __restrict__ coef,
+                                                              const int32_t* __restrict__ rlab, long nrows, int V) {
+  const int lane = threadIdx.x & 63;
+  const long wave0 = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const long nwaves = (long)gridDim.x * (blockDim.x >> 6);
+  constexpr int U = 2, MAXP = 2;  // rows in flight per wave, 512-column passes held in registers (V <= 1024)
+  for (long r0 = wave0; r0 < nrows; r0 += U * nwaves) {
+    float x[U][MAXP][8];
+    float4 c[U];
+    int lab[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long r = r0 + u * nwaves;
+      c[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      lab[u] = -1;
+      if (r < nrows) {
+        c[u] = coef[r];
+        lab[u] = rlab[r];
+#pragma unroll
+        for (int p = 0; p < MAXP; ++p) {
+          const int v0 = p * 512 + lane * 8;
+          if (v0 < V) ld8(logits + r * V + v0, x[u][p]);
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long r = r0 + u * nwaves;
+      if (r >= nrows) continue;
+#pragma unroll
+      for (int p = 0; p < MAXP; ++p) {
+        const int v0 = p * 512 + lane * 8;
+        if (v0 >= V) continue;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) x[u][p][i] = __builtin_amdgcn_exp2f(x[u][p][i] * 1.4426950408889634f - c[u].x) * c[u].y;
+        if (v0 == 0) x[u][p][0] += c[u].z;
+        if (lab[u] >= 0 && (lab[u] >> 3) == (v0 >> 3)) {
+          const int q = lab[u] & 7;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) x[u][p][i] += (i == q) ? c[u].w : 0.f;
+        }
+        st8(grads + r * V + v0, x[u][p]);
+      }
+    }
+  }
+}
+
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 }  // namespace
@@ -414,7 +470,7 @@ inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 extern "C" int tfasr_rnnt_loss_workspace_size(int B, int T, int U1, int V, size_t* bytes) {
   if (!bytes || B <= 0 || T <= 0 || U1 <= 0 || V <= 0) return TFASR_STATUS_INVALID_VALUE;
   const size_t n = (size_t)B * T * U1;
-  *bytes = 5 * align256(n * sizeof(float));  // lse, blank, truth, alpha, beta
+  *bytes = 10 * align256(n * sizeof(float));  // lse, blank, truth, alpha, beta + per-row gradient coefficients [n][4] + row labels
   return TFASR_STATUS_SUCCESS;
 }
 
@@ -454,11 +510,26 @@ static int rnnt_impl(const void* logits, void* grads, const int32_t* labels, con
   hipLaunchKernelGGL(rnnt_lattice_kernel, dim3(B, 2), dim3(nthr), 2 * nthr * sizeof(float), stream, blank_lp,
                      truth_lp, label_len, logit_len, cell_off, T, U1, alpha, beta, costs);
   TFASR_CHECK_LAUNCH();
-  if (coef) {
+  // gradient as coefficient pass + pure stream (rnnt_grad_apply_kernel) when the workspace has room for the coefficients (older callers
+  // sized it for 5 segments: they keep the one-launch kernel); TFASR_RNNT_GRAD_STREAM=0 forces the one-launch kernel
+  static const bool stream_off = getenv("TFASR_RNNT_GRAD_STREAM") && getenv("TFASR_RNNT_GRAD_STREAM")[0] == '0';
+  const bool streamed = grads && !stream_off && (V % 8) == 0 && V <= 1024 && workspace_bytes >= 10 * seg && (dtype == TFASR_F32 || dtype == TFASR_BF16);
+  float4* cbuf = coef ? (float4*)coef : (float4*)(ws + 5 * seg);
+  int32_t* rlab = (int32_t*)(ws + 9 * seg);
+  if (coef || streamed) {
     const int cg = (int)std::min<long>((nrows + 255) / 256, 256L * 8);
     hipLaunchKernelGGL(rnnt_coef_kernel, dim3(cg), dim3(256), 0, stream, label_len, logit_len, grad_scale, cell_off, nrows, B, T, U1, lse, blank_lp,
-                       truth_lp, alpha, beta, (float4*)coef);
+                       truth_lp, alpha, beta, cbuf, streamed ? labels : (const int32_t*)nullptr, V, streamed ? rlab : (int32_t*)nullptr);
     TFASR_CHECK_LAUNCH();
+  }
+  if (streamed) {
+    const int ag = (int)std::min<long>((nrows + 7) / 8, 256L * 16);
+    if (dtype == TFASR_F32)
+      hipLaunchKernelGGL(rnnt_grad_apply_kernel<float>, dim3(ag), dim3(256), 0, stream, (const float*)logits, (float*)grads, cbuf, rlab, nrows, V);
+    else
+      hipLaunchKernelGGL(rnnt_grad_apply_kernel<bf16_t>, dim3(ag), dim3(256), 0, stream, (const bf16_t*)logits, (bf16_t*)grads, cbuf, rlab, nrows, V);
+    TFASR_CHECK_LAUNCH();
+    return TFASR_STATUS_SUCCESS;
   }
   if (grads) {
     if (dtype == TFASR_F32)
