@@ -138,6 +138,10 @@ __global__ __launch_bounds__(256, 3) void relattn_fused_fwd_kernel(
   const bf16_t* kb = qb + HD;
   const bf16_t* vb = qb + 2 * HD;
   const bf16_t* pb = pext + h * DH;
+  // the bias row R of the position table (window row 127 / 95 of every key block): 16 bytes per lane of wave 0, loaded ONCE - inside the
+  // block loop it was a dependent global load between the barrier and the __syncthreads() of every iteration
+  uint4 bias_row = make_uint4(0, 0, 0, 0);
+  if ((threadIdx.x >> 6) == 0 && (threadIdx.x & 63) < 8) bias_row = *reinterpret_cast<const uint4*>(pb + (long)(2 * T - 1) * HD + (((threadIdx.x & 63) ^ key_d(127)) << 3));
 
   // Q fragments (A operand): this lane's row
   const int irow = min(i0 + w * 16 + r, T - 1);
@@ -232,10 +236,7 @@ __global__ __launch_bounds__(256, 3) void relattn_fused_fwd_kernel(
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     // window row 127 <- the bias row R (one 128-B row, written by wave 0 after the DMA so it wins)
-    if (w == 0 && lane < 8) {
-      const uint4 v = *reinterpret_cast<const uint4*>(pb + (long)R * HD + ((lane ^ key_d(127)) << 3));
-      *reinterpret_cast<uint4*>(sP + 127 * 128 + lane * 16) = v;
-    }
+    if (w == 0 && lane < 8) *reinterpret_cast<uint4*>(sP + 127 * 128 + lane * 16) = bias_row;  // loaded once, in front of the loop
     __syncthreads();
     ATT_TICK(0)
 
@@ -378,6 +379,10 @@ __global__ __launch_bounds__(256, 4) void relattn_fused_fwd32_kernel(
   const bf16_t* kb = qb + HD;
   const bf16_t* vb = qb + 2 * HD;
   const bf16_t* pb = pext + h * DH;
+  // the bias row R of the position table (window row 127 / 95 of every key block): 16 bytes per lane of wave 0, loaded ONCE - inside the
+  // block loop it was a dependent global load between the barrier and the __syncthreads() of every iteration
+  uint4 bias_row = make_uint4(0, 0, 0, 0);
+  if ((threadIdx.x >> 6) == 0 && (threadIdx.x & 63) < 8) bias_row = *reinterpret_cast<const uint4*>(pb + (long)(2 * T - 1) * HD + (((threadIdx.x & 63) ^ key_d(WIN3 - 1)) << 3));
 
   const int irow = min(i0 + w * 16 + r, T - 1);
   short8_t aqu[2], aqv[2];
@@ -463,10 +468,7 @@ __global__ __launch_bounds__(256, 4) void relattn_fused_fwd32_kernel(
     load_rows<WIN3>(sP, pb, HD, pw0, R1, w, lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (w == 0 && lane < 8) {  // window row 95 <- the bias row R
-      const uint4 v = *reinterpret_cast<const uint4*>(pb + (long)R * HD + ((lane ^ key_d(WIN3 - 1)) << 3));
-      *reinterpret_cast<uint4*>(sP + (WIN3 - 1) * 128 + lane * 16) = v;
-    }
+    if (w == 0 && lane < 8) *reinterpret_cast<uint4*>(sP + (WIN3 - 1) * 128 + lane * 16) = bias_row;  // window row 95 <- the bias row R
     __syncthreads();
 
     float4_t acc_s[2];
@@ -600,6 +602,10 @@ __global__ __launch_bounds__(256, 2) void relattn_fused_bwd_q_kernel(
   const bf16_t* kb = qb + HD;
   const bf16_t* vb = qb + 2 * HD;
   const bf16_t* pb = pext + h * DH;
+  // the bias row R of the position table (window row 127 / 95 of every key block): 16 bytes per lane of wave 0, loaded ONCE - inside the
+  // block loop it was a dependent global load between the barrier and the __syncthreads() of every iteration
+  uint4 bias_row = make_uint4(0, 0, 0, 0);
+  if ((threadIdx.x >> 6) == 0 && (threadIdx.x & 63) < 8) bias_row = *reinterpret_cast<const uint4*>(pb + (long)(2 * T - 1) * HD + (((threadIdx.x & 63) ^ key_d(127)) << 3));
 
   if constexpr (V2) {
     if (use_mask && i0 >= len) {
@@ -709,10 +715,7 @@ __global__ __launch_bounds__(256, 2) void relattn_fused_bwd_q_kernel(
     load_rows<WIN>(sP, pb, HD, pw0, R1, w, lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (w == 0 && lane < 8) {
-      const uint4 v = *reinterpret_cast<const uint4*>(pb + (long)R * HD + ((lane ^ key_d(127)) << 3));
-      *reinterpret_cast<uint4*>(sP + 127 * 128 + lane * 16) = v;
-    }
+    if (w == 0 && lane < 8) *reinterpret_cast<uint4*>(sP + 127 * 128 + lane * 16) = bias_row;  // loaded once, in front of the loop
     __syncthreads();
     ATT_TICK(0)
 
@@ -1072,6 +1075,10 @@ __global__ __launch_bounds__(256, 2) void relattn_fused_bwd_k_kernel(
   const bf16_t* qvb = qv + (long)b * T * HD + h * DH;
   const bf16_t* dob = dout + (long)b * T * HD + h * DH;
   const bf16_t* pb = pext + h * DH;
+  // the bias row R of the position table (window row 127 / 95 of every key block): 16 bytes per lane of wave 0, loaded ONCE - inside the
+  // block loop it was a dependent global load between the barrier and the __syncthreads() of every iteration
+  uint4 bias_row = make_uint4(0, 0, 0, 0);
+  if ((threadIdx.x >> 6) == 0 && (threadIdx.x & 63) < 8) bias_row = *reinterpret_cast<const uint4*>(pb + (long)(2 * T - 1) * HD + (((threadIdx.x & 63) ^ key_d(127)) << 3));
 
   const int jrow = min(j0 + w * 16 + r, T - 1);
   short8_t ak[2], av[2];
@@ -1135,10 +1142,7 @@ __global__ __launch_bounds__(256, 2) void relattn_fused_bwd_k_kernel(
     load_rows<WIN>(sP, pb, HD, pw0, R1, w, lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (w == 0 && lane < 8) {
-      const uint4 v = *reinterpret_cast<const uint4*>(pb + (long)R * HD + ((lane ^ key_d(127)) << 3));
-      *reinterpret_cast<uint4*>(sP + 127 * 128 + lane * 16) = v;
-    }
+    if (w == 0 && lane < 8) *reinterpret_cast<uint4*>(sP + 127 * 128 + lane * 16) = bias_row;  // loaded once, in front of the loop
     __syncthreads();
 
     // transposed content scores and dP: rows = this wave's 16 keys, cols = 64 queries
