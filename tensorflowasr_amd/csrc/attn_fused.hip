@@ -1136,6 +1136,15 @@ __global__ __launch_bounds__(256, 2) void relattn_fused_bwd_k_kernel(
       continue;
     }
     const int pw0 = (T - 1 - (i0 + BI - 1) + j0) + shift;
+    // the query rows' log-sum-exp and D_i: loaded here, in flight together with the block's DMA pieces (they used to be 8 dependent
+    // global loads in the middle of the iteration, between the score products and the exponentials)
+    float lse2_it[4], Di_it[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int ic = min(i0 + it * 16 + r, T - 1);
+      lse2_it[it] = lse[lrow + ic] * 1.4426950408889634f;
+      Di_it[it] = dvec[lrow + ic];
+    }
     load_rows<BI>(sQu, qub, HD, i0, T, w, lane);
     load_rows<BI>(sQv, qvb, HD, i0, T, w, lane);
     load_rows<BI>(sdO, dob, HD, i0, T, w, lane);
@@ -1179,8 +1188,8 @@ __global__ __launch_bounds__(256, 2) void relattn_fused_bwd_k_kernel(
     for (int it = 0; it < 4; ++it) {
       const int il = it * 16 + r, i = i0 + il;
       const int ic = min(i, T - 1);
-      const float lse2 = lse[lrow + ic] * 1.4426950408889634f;
-      const float D_i = dvec[lrow + ic];
+      const float lse2 = lse2_it[it];
+      const float D_i = Di_it[it];
       const bool qmask = use_mask && (i >= len);
       const bool iin = i < T;
       const float gbias = sGt[127 * GTLD + il];
