@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define TFASR_ABI_VERSION 21
+#define TFASR_ABI_VERSION 22
 
 typedef enum {
   TFASR_STATUS_SUCCESS = 0,
@@ -189,6 +189,15 @@ int tfasr_layernorm_bwd(const void* dy, const void* x, const float* gamma, const
 int tfasr_layernorm_bwd_drop(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
                              const void* add, void* dx, float* dgamma, float* dbeta, void* dx_dropped, float drop_p,
                              long drop_seed, long rows, int C, int dtype, void* stream);
+/* The same with the gamma / beta gradients left as PER-BLOCK partial sums part[nblk][2C] (plain stores; nblk =
+   tfasr_layernorm_bwd_part_blocks(rows, C, dtype), 0 = no such kernel for the shape): the backward's tail is otherwise a chain of
+   ~190 same-address atomics per column (~3 us).  tfasr_layernorm_bwd_fold adds the partial sums of up to 8 LayerNorms (part =
+   [nsets][nblk][2C], same nblk) to their dgamma[i] / dbeta[i] in one launch, one writer per column. */
+int tfasr_layernorm_bwd_part_blocks(long rows, int C, int dtype);
+int tfasr_layernorm_bwd_part(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, const void* add,
+                             void* dx, float* part, void* dx_dropped, float drop_p, long drop_seed, long rows, int C, int dtype,
+                             void* stream);
+int tfasr_layernorm_bwd_fold(const float* part, int nsets, int nblk, int C, float* const* dgamma, float* const* dbeta, void* stream);
 int tfasr_bn_stats(const void* x, float* stats, long rows, int C, int dtype, void* stream);
 int tfasr_bn_finalize(const float* stats, float count, const float* gamma, const float* beta, float* fin,
                       float* moving_mean, float* moving_var, float momentum, float eps, int C, int training,

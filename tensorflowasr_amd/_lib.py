@@ -150,7 +150,7 @@ def load(build_if_missing=True):
     return lib
 
 
-ABI_VERSION = 21
+ABI_VERSION = 22
 
 
 STATUS_UNSUPPORTED = 3

@@ -48,6 +48,10 @@ struct Ctx {
   void *bw_curd, *bw_nxtd;  // dropout(bw_cur / bw_nxt) for the consumer's dropped branch, written by the producing LayerNorm backward
   long drop_epoch;
   int fused;
+  // LayerNorm gamma / beta gradients as per-block partial sums, folded by ONE launch at the end of the block's backward
+  float* ln_part;
+  int ln_nblk, ln_nsets;
+  float *ln_dg[8], *ln_db[8];
 };
 
 // one GEMM launch description (defaults = plain product)
@@ -247,7 +251,17 @@ struct Ex {
   void ln_bwd(const void* dy, const void* x, int gi, int bi, const float* mean, const float* rstd, const void* add, void* dx,
               void* dxd = nullptr, int next_site = -1) {
     if (dry) return;
-    if (dxd && drop_p() > 0.f && next_site >= 0)
+    const bool with_drop = dxd && drop_p() > 0.f && next_site >= 0;
+    if (k->ln_part && k->ln_nsets < 8) {
+      float* part = k->ln_part + (size_t)k->ln_nsets * k->ln_nblk * 2 * c->d;
+      chk(tfasr_layernorm_bwd_part(dy, x, fp(gi), mean, rstd, add, dx, part, with_drop ? dxd : nullptr, with_drop ? drop_p() : 0.f,
+                                   with_drop ? seed(next_site) : 0, rows, c->d, c->dtype, s));
+      k->ln_dg[k->ln_nsets] = gp(gi);
+      k->ln_db[k->ln_nsets] = gp(bi);
+      ++k->ln_nsets;
+      return;
+    }
+    if (with_drop)
       chk(tfasr_layernorm_bwd_drop(dy, x, fp(gi), mean, rstd, add, dx, gp(gi), gp(bi), dxd, drop_p(), seed(next_site), rows, c->d, c->dtype, s));
     else
       chk(tfasr_layernorm_bwd(dy, x, fp(gi), mean, rstd, add, dx, gp(gi), gp(bi), rows, c->d, c->dtype, s));
@@ -623,6 +637,13 @@ struct Ex {
       k->bw_nxt = act(scratch, rows * d);
       k->bw_curd = dr ? act(scratch, rows * d) : nullptr;
       k->bw_nxtd = dr ? act(scratch, rows * d) : nullptr;
+      {  // partial-sum buffers of the block's five LayerNorm backward passes (below every module's rewind mark: they live until the fold)
+        static const bool fold_off = getenv("TFASR_LN_FOLD") && getenv("TFASR_LN_FOLD")[0] == '0';
+        const int nblk = fold_off ? 0 : tfasr_layernorm_bwd_part_blocks(rows, d, c->dtype);
+        k->ln_nblk = nblk;
+        k->ln_nsets = 0;
+        k->ln_part = nblk > 0 ? f32(scratch, (long)8 * nblk * 2 * d) : nullptr;  // up to 8 sets (5 LayerNorms + the LayerNorm variant of the depthwise norm)
+      }
       ln_bwd(io->dy, k->ln_x, TFASR_BP_LN_G, TFASR_BP_LN_B, k->ln_mean, k->ln_rstd, nullptr, k->bw_cur, k->bw_curd, 5);
       ffm_bwd(1, k->bw_cur, k->bw_curd, k->bw_nxt, k->bw_nxtd, 4, 3);
       next_bufs(dr);
@@ -639,6 +660,10 @@ struct Ex {
       next_bufs(dr);
       mhsa_bwd(k->bw_cur, k->bw_curd, k->bw_nxt, k->bw_nxtd, 2, 1);
       ffm_bwd(0, k->bw_nxt, k->bw_nxtd, io->dx, nullptr, 0, -1);
+      if (!dry && k->ln_part && k->ln_nsets > 0) {
+        chk(tfasr_layernorm_bwd_fold(k->ln_part, k->ln_nsets, k->ln_nblk, d, k->ln_dg, k->ln_db, s));
+        k->ln_nsets = 0;
+      }
     }
     flush_wgrads();
     join();

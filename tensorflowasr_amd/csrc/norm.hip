@@ -375,7 +375,7 @@ __global__ __launch_bounds__(NW * 64) void ln_bwd_vec_kernel(const T* __restrict
                                                           const float* __restrict__ gamma, const float* __restrict__ mean,
                                                           const float* __restrict__ rstd, const T* add, T* dx,
                                                           float* __restrict__ dgamma, float* __restrict__ dbeta, long rows,
-                                                          int C, T* dxm, float drop_p, uint64_t drop_seed) {
+                                                          int C, T* dxm, float drop_p, uint64_t drop_seed, float* __restrict__ part = nullptr) {
   constexpr int RPW = 64 / LPR;
   __shared__ float red[2][NW * RPW][LPR * 8];
   const int lane = threadIdx.x & 63, li = lane % LPR, sub = lane / LPR, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -442,8 +442,39 @@ __global__ __launch_bounds__(NW * 64) void ln_bwd_vec_kernel(const T* __restrict
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
     float sg = 0.f, sb = 0.f;
     for (int q = 0; q < nw * RPW; ++q) { sg += red[0][q][c]; sb += red[1][q][c]; }
-    if (dgamma) atomicAdd(dgamma + c, sg);
-    if (dbeta) atomicAdd(dbeta + c, sb);
+    if (part) {  // per-block partial sums, folded later by ln_bwd_fold_kernel (no same-address atomic chain at the end of this kernel)
+      part[(long)blockIdx.x * 2 * C + c] = sg;
+      part[(long)blockIdx.x * 2 * C + C + c] = sb;
+    } else {
+      if (dgamma) atomicAdd(dgamma + c, sg);
+      if (dbeta) atomicAdd(dbeta + c, sb);
+    }
+  }
+}
+
+// dgamma / dbeta of up to LNF_MAX LayerNorms from their per-block partial sums part[set][nblk][2C]: block = (64 columns of one set),
+// 4 thread groups each take a quarter of the partial rows, LDS combine, ONE writer per column (plain +=, no atomics)
+constexpr int LNF_MAX = 8;
+struct LnFoldArgs { float* dg[LNF_MAX]; float* db[LNF_MAX]; };
+__global__ __launch_bounds__(256) void ln_bwd_fold_kernel(const float* __restrict__ part, int nblk, int C, LnFoldArgs a) {
+  __shared__ float red[4][64];
+  const int set = blockIdx.y, col = blockIdx.x * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
+  const float* p = part + (long)set * nblk * 2 * C + col;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (col < 2 * C) {
+    const int per = (nblk + 3) / 4, b0 = grp * per, b1 = min(nblk, b0 + per);
+    int b = b0;
+    for (; b + 4 <= b1; b += 4) {
+      s0 += p[(long)b * 2 * C]; s1 += p[(long)(b + 1) * 2 * C]; s2 += p[(long)(b + 2) * 2 * C]; s3 += p[(long)(b + 3) * 2 * C];
+    }
+    for (; b < b1; ++b) s0 += p[(long)b * 2 * C];
+  }
+  red[grp][threadIdx.x & 63] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (grp == 0 && col < 2 * C) {
+    const float v = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    if (col < C) { if (a.dg[set]) a.dg[set][col] += v; }
+    else if (a.db[set]) a.db[set][col - C] += v;
   }
 }
 
@@ -550,6 +581,56 @@ extern "C" int tfasr_layernorm_fwd(const void* x, const float* gamma, const floa
   return TFASR_STATUS_SUCCESS;
 }
 
+static int num_cus_norm() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0, v = 0;
+    n = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
+  }
+  return n;
+}
+// blocks of the vectorised backward for a shape; the partial-sum variant has no atomic tail to limit, so it takes every CU
+static int ln_bwd_vec_grid(long rows, int C, bool part) {
+  const int rpw = C <= 256 ? 2 : 1;
+  if (!part) return std::max(1, fat_grid(rows, rpw));
+  const long per_block = 8L * rpw;  // rows per block pass (8 waves)
+  return (int)std::max<long>(1, std::min<long>(rows / (2 * per_block) + 1, (long)num_cus_norm()));
+}
+static int ln_bwd_vec_launch(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, const void* add, void* dx,
+                             float* dgamma, float* dbeta, void* dx_dropped, float drop_p, long drop_seed, long rows, int C, float* part,
+                             hipStream_t s) {
+  const int grid = ln_bwd_vec_grid(rows, C, part != nullptr);
+  if (C <= 256)
+    hipLaunchKernelGGL((ln_bwd_vec_kernel<bf16_t, 32, 2, 8>), dim3(grid), dim3(512), 0, s, (const bf16_t*)dy, (const bf16_t*)x, gamma, mean, rstd,
+                       (const bf16_t*)add, (bf16_t*)dx, dgamma, dbeta, rows, C, (bf16_t*)dx_dropped, drop_p, (uint64_t)drop_seed, part);
+  else
+    hipLaunchKernelGGL((ln_bwd_vec_kernel<bf16_t, 64, 2, 8>), dim3(grid), dim3(512), 0, s, (const bf16_t*)dy, (const bf16_t*)x, gamma, mean, rstd,
+                       (const bf16_t*)add, (bf16_t*)dx, dgamma, dbeta, rows, C, (bf16_t*)dx_dropped, drop_p, (uint64_t)drop_seed, part);
+  TFASR_CHECK_LAUNCH();
+  return TFASR_STATUS_SUCCESS;
+}
+
+extern "C" int tfasr_layernorm_bwd_part_blocks(long rows, int C, int dtype) {
+  if (dtype != TFASR_BF16 || rows <= 0 || C <= 0 || (C % 8) || C > 512) return 0;
+  return ln_bwd_vec_grid(rows, C, true);
+}
+extern "C" int tfasr_layernorm_bwd_part(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, const void* add,
+                                        void* dx, float* part, void* dx_dropped, float drop_p, long drop_seed, long rows, int C, int dtype,
+                                        void* stream_) {
+  if (!dy || !x || !gamma || !mean || !rstd || !dx || !part || rows <= 0) return TFASR_STATUS_INVALID_VALUE;
+  if (dx_dropped && !(drop_p >= 0.f && drop_p < 1.f)) return TFASR_STATUS_INVALID_VALUE;
+  if (dtype != TFASR_BF16 || (C % 8) || C > 512 || C <= 0) return TFASR_STATUS_UNSUPPORTED;
+  return ln_bwd_vec_launch(dy, x, gamma, mean, rstd, add, dx, nullptr, nullptr, dx_dropped, drop_p, drop_seed, rows, C, part, (hipStream_t)stream_);
+}
+extern "C" int tfasr_layernorm_bwd_fold(const float* part, int nsets, int nblk, int C, float* const* dgamma, float* const* dbeta, void* stream_) {
+  if (!part || nsets <= 0 || nsets > LNF_MAX || nblk <= 0 || C <= 0 || !dgamma || !dbeta) return TFASR_STATUS_INVALID_VALUE;
+  LnFoldArgs a;
+  for (int i = 0; i < LNF_MAX; ++i) { a.dg[i] = i < nsets ? dgamma[i] : nullptr; a.db[i] = i < nsets ? dbeta[i] : nullptr; }
+  hipLaunchKernelGGL(ln_bwd_fold_kernel, dim3((2 * C + 63) / 64, nsets), dim3(256), 0, (hipStream_t)stream_, part, nblk, C, a);
+  TFASR_CHECK_LAUNCH();
+  return TFASR_STATUS_SUCCESS;
+}
+
 extern "C" int tfasr_layernorm_bwd_drop(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
                                         const void* add, void* dx, float* dgamma, float* dbeta, void* dx_dropped, float drop_p,
                                         long drop_seed, long rows, int C, int dtype, void* stream_) {
@@ -557,22 +638,8 @@ extern "C" int tfasr_layernorm_bwd_drop(const void* dy, const void* x, const flo
     return TFASR_STATUS_INVALID_VALUE;
   if (dx_dropped && !(drop_p >= 0.f && drop_p < 1.f)) return TFASR_STATUS_INVALID_VALUE;
   hipStream_t s = (hipStream_t)stream_;
-  if (dtype == TFASR_BF16 && (C % 8) == 0 && C <= 512) {
-#define LN_BWD_LAUNCH(LPR, U, NW) hipLaunchKernelGGL((ln_bwd_vec_kernel<bf16_t, LPR, U, NW>), dim3(grid), dim3(NW * 64), 0, s, (const bf16_t*)dy, (const bf16_t*)x, gamma, mean, rstd, (const bf16_t*)add, (bf16_t*)dx, dgamma, dbeta, rows, C, (bf16_t*)dx_dropped, drop_p, (uint64_t)drop_seed)
-    static const int U = getenv("TFASR_LN_BWD_U") ? atoi(getenv("TFASR_LN_BWD_U")) : 2;
-    static const bool wide = getenv("TFASR_LN_BWD_NW") && atoi(getenv("TFASR_LN_BWD_NW")) == 16;
-    if (C <= 256) {
-      const int grid = std::max(1, fat_grid(rows, U) / (wide ? 2 : 1));
-      if (U == 4) { if (wide) LN_BWD_LAUNCH(32, 4, 16); else LN_BWD_LAUNCH(32, 4, 8); }
-      else { if (wide) LN_BWD_LAUNCH(32, 2, 16); else LN_BWD_LAUNCH(32, 2, 8); }
-    } else {
-      const int grid = std::max(1, fat_grid(rows, 1) / (wide ? 2 : 1));
-      if (wide) LN_BWD_LAUNCH(64, 2, 16); else LN_BWD_LAUNCH(64, 2, 8);
-    }
-#undef LN_BWD_LAUNCH
-    TFASR_CHECK_LAUNCH();
-    return TFASR_STATUS_SUCCESS;
-  }
+  if (dtype == TFASR_BF16 && (C % 8) == 0 && C <= 512)
+    return ln_bwd_vec_launch(dy, x, gamma, mean, rstd, add, dx, dgamma, dbeta, dx_dropped, drop_p, drop_seed, rows, C, nullptr, s);
   const int grid = (int)std::min<long>((rows + 3) / 4, 256L);
   if (dtype == TFASR_F32)
     hipLaunchKernelGGL(ln_bwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)dy, (const float*)x, gamma, mean,

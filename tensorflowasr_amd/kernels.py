@@ -240,6 +240,23 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, add=None, dx=None, dr
     return dx
 
 
+def layernorm_bwd_fold(dy, x, gamma, mean, rstd, dgamma, dbeta, add=None):
+    """layernorm_bwd with the gamma / beta gradients through per-block partial sums + tfasr_layernorm_bwd_fold (what the native block
+    executor does for the five LayerNorms of a block with ONE fold launch); returns dx, or None when the shape has no such kernel."""
+    rows, C = x.numel() // x.shape[-1], x.shape[-1]
+    nblk = _L().tfasr_layernorm_bwd_part_blocks(rows, C, _dt(x))
+    if nblk <= 0:
+        return None
+    dx = torch.empty_like(x)
+    part = torch.empty(nblk * 2 * C, dtype=torch.float32, device=x.device)
+    check(_L().tfasr_layernorm_bwd_part(_p(dy), _p(x), _p(gamma), _p(mean), _p(rstd), _p(add), _p(dx), _p(part), None, 0.0, 0, rows, C, _dt(x),
+                                        _stream()), "layernorm_bwd_part")
+    dg = (ctypes.c_void_p * 1)(dgamma.data_ptr())
+    db = (ctypes.c_void_p * 1)(dbeta.data_ptr())
+    check(_L().tfasr_layernorm_bwd_fold(_p(part), 1, nblk, C, dg, db, _stream()), "layernorm_bwd_fold")
+    return dx
+
+
 def bn_stats(x, stats):
     rows, C = x.numel() // x.shape[-1], x.shape[-1]
     check(_L().tfasr_bn_stats(_p(x), _p(stats), rows, C, _dt(x), _stream()), "bn_stats")

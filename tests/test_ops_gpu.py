@@ -144,6 +144,28 @@ def test_glu_dwconv(dev, dtype):
     cmp(dx, xr.grad, **tol(dtype, (1e-4, 1e-5), (3e-2, 3e-2)))
 
 
+@pytest.mark.parametrize("rows,C", [(23808, 256), (777, 144), (4096, 512)])
+def test_layernorm_bwd_partial_sums_and_fold(dev, rows, C):
+    """tfasr_layernorm_bwd_part + tfasr_layernorm_bwd_fold (per-block partial sums of the gamma / beta gradients, one writer per column)
+    against tfasr_layernorm_bwd (atomics): same dx bitwise, same sums up to summation order; the fold ADDS to its destinations."""
+    g = torch.Generator().manual_seed(rows + C)
+    dt = torch.bfloat16
+    x = torch.randn(rows, C, generator=g).to(dev).to(dt)
+    dy = torch.randn(rows, C, generator=g).to(dev).to(dt)
+    add = torch.randn(rows, C, generator=g).to(dev).to(dt)
+    gamma, beta = torch.randn(C, generator=g).to(dev), torch.randn(C, generator=g).to(dev)
+    _, mean, rstd = K.layernorm_fwd(x, gamma, beta)
+    dg0, db0 = torch.full((C,), 0.5, device=dev), torch.full((C,), -0.25, device=dev)
+    dg1, db1 = dg0.clone(), db0.clone()
+    dx0 = K.layernorm_bwd(dy, x, gamma, mean, rstd, dg0, db0, add=add)
+    dx1 = K.layernorm_bwd_fold(dy, x, gamma, mean, rstd, dg1, db1, add=add)
+    assert dx1 is not None
+    torch.cuda.synchronize()
+    assert torch.equal(dx0, dx1)
+    cmp(dg1, dg0.cpu(), rtol=2e-4, atol=2e-2)
+    cmp(db1, db0.cpu(), rtol=2e-4, atol=2e-2)
+
+
 @pytest.mark.parametrize("Kk,C,T", [(5, 640, 150), (5, 80, 77), (3, 256, 64), (7, 144, 130), (8, 264, 65), (15, 144, 53), (32, 144, 53)])
 def test_dwconv_kernel_sizes(dev, Kk, C, T):
     """The bf16 depthwise kernels are instantiated per window bound (8 / 32 taps) and per weight-gradient kernel size: every size the
