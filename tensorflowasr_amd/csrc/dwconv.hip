@@ -102,6 +102,19 @@ __global__ __launch_bounds__(256) void dwconv_tile_kernel(const bf16_t* __restri
     wk[k] = (k < K) ? v : float2_t{0.f, 0.f};
   }
   stage_rows<2 * TG + KB - 1>(lds, x, ubase, tin0, Tn, C, c0);
+  // GLU variant: the a | b halves of this thread's 32 output rows are fetched NOW (packed pairs, rows clamped into the tensor), in
+  // flight under the LDS staging and the tap loop; loaded inside the store loop each row was its own dependent round trip
+  // (load a, b -> sigmoid -> two stores, 32 times in a row: 30 us for a 12 us stream)
+  [[maybe_unused]] uint32_t ga[GLU ? TG : 1], gb[GLU ? TG : 1];
+  if constexpr (GLU) {
+    const int tg0p = t0 + grp * TG;
+#pragma unroll
+    for (int i = 0; i < TG; ++i) {
+      const long row2 = (ubase + (long)min(tg0p + i, Tn - 1) * C) * 2;
+      ga[i] = *reinterpret_cast<const uint32_t*>(gx + row2 + cc);
+      gb[i] = *reinterpret_cast<const uint32_t*>(gx + row2 + C + cc);
+    }
+  }
   float2_t acc[TG];
   const float2_t bv = (!REV && bias) ? float2_t{bias[cc], bias[cc + 1]} : float2_t{0.f, 0.f};
 #pragma unroll
@@ -115,7 +128,8 @@ __global__ __launch_bounds__(256) void dwconv_tile_kernel(const bf16_t* __restri
       if (tg0 + i < Tn) {
         if constexpr (GLU) {
           const long row2 = (ubase + (long)(tg0 + i) * C) * 2;  // element offset of the row in the [rows, 2C] tensors
-          const float2_t a = ld2(gx + row2 + c), b = ld2(gx + row2 + C + c);
+          const float2_t a = float2_t{__uint_as_float(ga[i] << 16), __uint_as_float(ga[i] & 0xffff0000u)};
+          const float2_t b = float2_t{__uint_as_float(gb[i] << 16), __uint_as_float(gb[i] & 0xffff0000u)};
           const float s0 = sigmoidf_(b[0]), s1 = sigmoidf_(b[1]);
           st2(y + row2 + c, float2_t{acc[i][0] * s0, acc[i][1] * s1});
           st2(y + row2 + C + c, float2_t{acc[i][0] * a[0] * s0 * (1.f - s0), acc[i][1] * a[1] * s1 * (1.f - s1)});
