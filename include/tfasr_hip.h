@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define TFASR_ABI_VERSION 22
+#define TFASR_ABI_VERSION 23
 
 typedef enum {
   TFASR_STATUS_SUCCESS = 0,
@@ -351,6 +351,12 @@ int tfasr_lstm_step_bwd(const void* dy, long dy_stride_b, const float* dhr, floa
 /* The whole recurrence of the prediction network queued by one call (per step: recurrent GEMM h_{t-1} @ R into `hr` + the cell stage).
  * xg / gates [B,U1,4P], cseq (f32) / hseq / yseq [B,U1,P] row-major; rk = recurrent kernel [P,4P]; h0 / c0 may be NULL (zero state);
  * hr [B,4P], dhr [B,P] f32 scratch; dh_carry / dc_carry [B,P] f32, zero on entry of the backward. */
+/* Which recurrence tfasr_lstm_seq_fwd / _bwd run: mode 1 = the persistent one-launch kernels where the shape allows, 0 = the per-step
+   kernels, -1 = TFASR_LSTM_PERSIST from the environment (default: persistent).  Returns the previous override.  The persistent kernels
+   finish a direction in 0.74 / 1.18 ms at U1 = 111, P = 640 (per-step path: 1.6 / 2.4 ms) but hold P / 16 CUs for that long: beside an
+   encoder running on another stream the per-step path makes the whole train step 0.2 ms FASTER (measured, M and S), so the Python
+   model switches per call (conformer.py: persistent when the prediction network has the device to itself). */
+int tfasr_lstm_set_persist(int mode);
 int tfasr_lstm_seq_fwd(const void* xg, const void* rk, const void* h0, long h0_stride_b, const float* c0, long c0_stride_b,
                        const int32_t* lengths, void* gates, float* cseq, void* hseq, void* yseq, float* hr, int B, int U1, int P,
                        int dtype, void* stream);

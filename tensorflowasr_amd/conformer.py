@@ -76,6 +76,10 @@ class ConformerTransducer(BaseModel):
         self._rng = np.random.default_rng([seed + 1000, int(self.dp.rank)])
         self.pred_stream = torch.cuda.Stream(device=self.device)
         self.use_pred_stream = os.environ.get("TFASR_NO_PRED_STREAM", "0") != "1"
+        # prediction-network recurrence: the persistent one-launch kernels are faster in isolation but hold P/16 CUs for ~2 ms per step;
+        # beside the encoder on the other stream the per-step kernels make the whole step 0.2 ms faster (measured on M and S), so:
+        # persistent only when the prediction network has the device to itself.  TFASR_LSTM_PERSIST=0/1 in the environment overrides.
+        self._lstm_persist_auto = os.environ.get("TFASR_LSTM_PERSIST") is None
         self.optimizer = dict(beta1=0.9, beta2=0.98, eps=1e-9, weight_decay=1e-6, schedule=dict(
             dmodel=cfg.dmodel, warmup_steps=10000, scale=2.0, max_lr=0.05 / math.sqrt(cfg.dmodel)))
         self.ga_steps = 1
@@ -879,6 +883,8 @@ class ConformerTransducer(BaseModel):
         yseq = torch.empty(B, U1, P, dtype=self.dtype, device=self.device)
         hr = torch.empty(B, 4 * P, dtype=torch.float32, device=self.device)
         Wrk = ps.w2d("pred/lstm/rk")
+        if self._lstm_persist_auto:
+            K.lstm_set_persist(0 if (self.use_pred_stream and torch.cuda.current_stream(self.device) == self.pred_stream) else 1)
         K.lstm_seq_fwd(xg, Wrk, h0, c0, plen_dev, gates, cseq, hseq, yseq, hr)  # the U1 steps queued from C (one host call)
         y2 = yseq.view(B * U1, P)
         if c.prediction_layer_norm:
@@ -903,6 +909,8 @@ class ConformerTransducer(BaseModel):
         dc_carry = torch.zeros(B, P, dtype=torch.float32, device=self.device)
         dhr = torch.empty(B, P, dtype=torch.float32, device=self.device)
         Wrk = ps.w2d("pred/lstm/rk")
+        if self._lstm_persist_auto:
+            K.lstm_set_persist(0 if (self.use_pred_stream and torch.cuda.current_stream(self.device) == self.pred_stream) else 1)
         K.lstm_seq_bwd(dy.contiguous(), Wrk, s["gates"], s["cseq"], s["plen"], dz, dh_carry, dc_carry, dhr)
         dz2 = dz.view(B * U1, 4 * P)
         # recurrent kernel: gR += sum_b h[b, :-1]^T @ dz[b, 1:]

@@ -150,10 +150,17 @@ extern "C" int tfasr_lstm_step_bwd(const void* dy, long dy_stride_b, const float
 // host side at 25.8 of 28.0 ms the GPU idled between the steps of this chain.
 // Layouts as the step kernels take them: xg / gates [B, U1, 4P], cseq (f32) / hseq / yseq [B, U1, P]; hr [B, 4P] f32 scratch.
 // ---------------------------------------------------------------------------------------------------------------------------------
+static int g_persist_override = -1;  // tfasr_lstm_set_persist: -1 = TFASR_LSTM_PERSIST from the environment (default on), 0 / 1 = forced
 static bool persist_enabled() {
+  if (g_persist_override >= 0) return g_persist_override == 1;
   static int v = -1;
   if (v < 0) { const char* e = getenv("TFASR_LSTM_PERSIST"); v = (e && e[0] == '0') ? 0 : 1; }
   return v == 1;
+}
+extern "C" int tfasr_lstm_set_persist(int mode) {
+  const int prev = g_persist_override;
+  g_persist_override = mode < 0 ? -1 : (mode ? 1 : 0);
+  return prev;
 }
 
 extern "C" int tfasr_lstm_seq_fwd(const void* xg, const void* rk, const void* h0, long h0_stride_b, const float* c0, long c0_stride_b,

@@ -531,6 +531,11 @@ def lstm_step_bwd(dy_t, dhr, dh_carry, dc_carry, gates_t, c_t, c_prev, lengths, 
         _stream()), "lstm_step_bwd")
 
 
+def lstm_set_persist(mode):
+    """-1: TFASR_LSTM_PERSIST from the environment, 0: per-step kernels, 1: persistent kernels; returns the previous override."""
+    return int(_L().tfasr_lstm_set_persist(int(mode)))
+
+
 def lstm_seq_fwd(xg, rk, h0, c0, lengths, gates, cseq, hseq, yseq, hr):
     """All U1 steps of the recurrence in one host call (contiguous [B,U1,*] buffers)."""
     B, U1, P4 = xg.shape
