@@ -1,0 +1,79 @@
+"""Build-time guard for the LDS-DMA pipelines of csrc/gemm_fast.hip (CPU only: hipcc cross-compiles for gfx950).
+
+The GEMM main loops keep the NEXT slabs' LDS-DMA pieces in flight while the current slab is read and multiplied; ordering is the
+hand-counted `s_waitcnt vmcnt(N)` + `s_barrier` pairs in the source.  Twice this round the COMPILER put its own `s_waitcnt vmcnt(0)`
+into that loop - once because `__builtin_amdgcn_global_load_lds` makes it assume the next `ds_read` may alias the pending LDS write,
+once because its wait-count bookkeeping carried the epilogue's stores into the next tile's loop - and each time the kernels silently ran
+at one DMA round trip per slab.  This test compiles the file to assembly and checks that, between the source's counted wait of a slab
+and the end of that slab's 32 MFMAs, every `s_waitcnt vmcnt` comes from the source's inline asm (inside ;;#ASMSTART / ;;#ASMEND), and that
+the slab's DMA pieces are issued between its MFMAs."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "tensorflowasr_amd", "csrc", "gemm_fast.hip")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+KERNELS = [  # mangled-name fragments: forward FFN (bias + swish), its data gradient (swish' + dropout), plain NT product
+    "gemm_fast_kernelILb0ELb0ELi128ELi5E",
+    "gemm_fast_kernelILb0ELb1ELi128ELi6E",
+    "gemm_fast_kernelILb0ELb1ELi128ELi0E",
+]
+
+
+@pytest.fixture(scope="module")
+def asm(tmp_path_factory):
+    if not shutil.which(HIPCC) and not os.path.exists(HIPCC):
+        pytest.skip("hipcc not available")
+    out = tmp_path_factory.mktemp("isa") / "gemm_fast.s"
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wno-unused-result", "--cuda-device-only", "-S",
+           SRC, "-o", str(out)]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return open(out).read().split("\n")
+
+
+def _body(lines, frag):
+    start = next(i for i, l in enumerate(lines) if frag in l and l.rstrip().endswith(":") is False and re.match(r"^_ZN.*:", l))
+    end = next(i for i in range(start, len(lines)) if "s_endpgm" in lines[i])
+    return lines[start:end]
+
+
+@pytest.mark.parametrize("frag", KERNELS)
+def test_no_compiler_made_vmcnt_wait_inside_the_slab_loop(asm, frag):
+    body = _body(asm, frag)
+    in_asm, counted = False, None
+    for i, l in enumerate(body):
+        if "#ASMSTART" in l:
+            in_asm = True
+        elif "#ASMEND" in l:
+            in_asm = False
+        elif in_asm and re.search(r"s_waitcnt vmcnt\((8|6)\)", l):
+            counted = i
+            break
+    assert counted is not None, "the hand-counted wait of the slab loop was not found"
+    mfma = pieces_between = 0
+    in_asm = True  # we start inside the asm block that holds the counted wait
+    seen_first_mfma = False
+    for l in body[counted + 1:]:
+        if "#ASMSTART" in l:
+            in_asm = True
+            continue
+        if "#ASMEND" in l:
+            in_asm = False
+            continue
+        if "v_mfma_f32_16x16x32" in l:
+            mfma += 1
+            seen_first_mfma = True
+            if mfma == 32:
+                break
+        elif "global_load_lds_dwordx4" in l and seen_first_mfma:
+            pieces_between += 1
+        elif re.search(r"s_waitcnt\s+vmcnt", l) and not in_asm:
+            raise AssertionError(f"compiler-made vector-memory wait inside the slab loop of {frag}: {l.strip()}")
+    assert mfma == 32
+    assert pieces_between >= 6, f"the next-next slab's DMA pieces are no longer issued between the MFMAs ({pieces_between})"
