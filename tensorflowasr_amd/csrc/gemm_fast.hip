@@ -65,14 +65,12 @@ __device__ __forceinline__ void glds16_s(const char* base_uniform, uint32_t off,
     __builtin_amdgcn_global_load_lds(GLB_PTR(base_uniform + off), LDS_PTR(lds_uniform), 16, 0, 0);
     return;
   }
-#if 1
   const uint64_t b = (uint64_t)base_uniform;
   const uint64_t ub = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(b >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b);
   // s_nop 4: the base usually reaches its SGPR pair through v_readfirstlane, and a VALU write of an SGPR needs 5 wait states before a
   // vector-memory instruction reads it - the compiler's hazard recogniser does not look inside the asm (without them the piece went out
   // with the previous base: memory faults at base 0 + lane offset)
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(ub), "s"(lds_u32(lds_uniform)) : "memory");
-#endif
 }
 
 __device__ __forceinline__ int key_d(int row) { return (row >> 1) & 7; }
