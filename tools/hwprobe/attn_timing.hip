@@ -11,8 +11,8 @@ int main(int argc, char** argv) {
   hipMemset(qkv, 0x3c, (size_t)B * T * 3 * HD * 2); hipMemset(pext, 0x3c, (size_t)2 * T * HD * 2); hipMemset(u, 0, HD * 4); hipMemset(v, 0, HD * 4);
   std::vector<int32_t> hl(B, T); hipMemcpy(len, hl.data(), B * 4, hipMemcpyHostToDevice);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  for (int i = 0; i < 3; ++i) tfasr_relattn_fused_fwd(qkv, u, v, pext, len, out, lse, B, H, T, 64, 0.125f, 1, TFASR_BF16, 0);
-  hipEventRecord(e0); for (int i = 0; i < 20; ++i) tfasr_relattn_fused_fwd(qkv, u, v, pext, len, out, lse, B, H, T, 64, 0.125f, 1, TFASR_BF16, 0);
+  for (int i = 0; i < 3; ++i) tfasr_relattn_fused_fwd(qkv, u, v, pext, len, out, lse, B, H, T, 64, 0.125f, 1, 0, -1, TFASR_BF16, 0);
+  hipEventRecord(e0); for (int i = 0; i < 20; ++i) tfasr_relattn_fused_fwd(qkv, u, v, pext, len, out, lse, B, H, T, 64, 0.125f, 1, 0, -1, TFASR_BF16, 0);
   hipEventRecord(e1); hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1);
   const int nblk = ((T + 63) / 64) * H * B;
