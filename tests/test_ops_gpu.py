@@ -364,7 +364,7 @@ def test_subsampling_pieces(dev, dtype):
     cmp(dw2.view(3, 3, C, C), w2r.grad, **tol(dtype, (1e-4, 2e-4), (3e-2, 1e-1)))
 
 
-@pytest.mark.parametrize("n", [160000, 4321])
+@pytest.mark.parametrize("n", [160000, 4321, 160, 100])  # the last two: exactly one hop, shorter than one hop (a single padded frame)
 def test_logmel(dev, n):
     cfg = R.conformer_config("S")
     rng = np.random.default_rng(n)
@@ -374,8 +374,25 @@ def test_logmel(dev, n):
     out = K.logmel(torch.from_numpy(sig).to(dev), torch.from_numpy(R.hann_periodic(400)).to(dev), torch.from_numpy(melw).to(dev),
                    torch.from_numpy(R.mel_bands(melw)).to(dev), 160, 512, 0.97, 1e-6, torch.float32)
     assert out.shape == ref.shape
-    # <= 1e-4 abs in the log domain
-    np.testing.assert_allclose(out.cpu().numpy(), ref, atol=1e-4, rtol=1e-5)
+    # SURVEY 7.4 asks for <= 1e-4 abs in the log domain; the kernel transforms in f64 like the oracle (an f32 FFT leaves ~1e-7 x |frame| of
+    # absolute error in every bin: 2e-4 in the log domain in near-silent bins), so what remains is the f32 mel sum and logf: 2e-6 measured
+    np.testing.assert_allclose(out.cpu().numpy(), ref, atol=2e-5, rtol=0)
+
+
+def test_logmel_no_preemphasis_and_bf16_output(dev):
+    """preemphasis = 0 (feature_extraction.py:170-175 returns the signal unchanged) and the bf16 feature map the bf16 models consume."""
+    cfg = dict(R.conformer_config("S"))
+    cfg["preemphasis"] = 0.0
+    rng = np.random.default_rng(5)
+    sig = np.clip(rng.standard_normal((2, 8000)) * 0.1, -1, 1).astype(np.float32)
+    ref = R.log_mel(sig, cfg)
+    melw = R.mel_weight_matrix()
+    args = (torch.from_numpy(sig).to(dev), torch.from_numpy(R.hann_periodic(400)).to(dev), torch.from_numpy(melw).to(dev),
+            torch.from_numpy(R.mel_bands(melw)).to(dev), 160, 512, 0.0, 1e-6)
+    out = K.logmel(*args, torch.float32)
+    np.testing.assert_allclose(out.cpu().numpy(), ref, atol=2e-5, rtol=0)
+    out16 = K.logmel(*args, torch.bfloat16)
+    assert torch.equal(out16, out.to(torch.bfloat16))  # same f32 value, rounded once
 
 
 def _relattn_reference(qkv, u, v, pext, lens, B, H, T, dh, scale, use_mask=True):
