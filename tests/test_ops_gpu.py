@@ -379,6 +379,22 @@ def test_logmel(dev, n):
     np.testing.assert_allclose(out.cpu().numpy(), ref, atol=2e-5, rtol=0)
 
 
+@pytest.mark.parametrize("nbins", [23, 40, 128])
+def test_logmel_other_filterbank_sizes(dev, nbins):
+    """23 / 40 bins: bands wider than the 16 taps the kernel keeps in LDS (the tail is read from the dense matrix); 128 bins: two full
+    passes of 64 bins, empty bands (a mel bin between two FFT bins has no non-zero tap: log(eps))."""
+    cfg = dict(R.conformer_config("S"))
+    cfg["num_feature_bins"] = nbins
+    rng = np.random.default_rng(nbins)
+    sig = np.clip(rng.standard_normal((2, 6000)) * 0.1, -1, 1).astype(np.float32)
+    ref = R.log_mel(sig, cfg)
+    melw = R.mel_weight_matrix(nbins)
+    out = K.logmel(torch.from_numpy(sig).to(dev), torch.from_numpy(R.hann_periodic(400)).to(dev), torch.from_numpy(melw).to(dev),
+                   torch.from_numpy(R.mel_bands(melw)).to(dev), 160, 512, 0.97, 1e-6, torch.float32)
+    assert out.shape == ref.shape
+    np.testing.assert_allclose(out.cpu().numpy(), ref, atol=2e-5, rtol=0)
+
+
 def test_logmel_no_preemphasis_and_bf16_output(dev):
     """preemphasis = 0 (feature_extraction.py:170-175 returns the signal unchanged) and the bf16 feature map the bf16 models consume."""
     cfg = dict(R.conformer_config("S"))
