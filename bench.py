@@ -16,8 +16,11 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
+# before the HIP runtime initialises: enough hardware queues for main + prediction-network + RCCL streams (tensorflowasr_amd/__init__.py)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -25,6 +28,18 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA
 MFMA_F32_PEAK_TFLOPS = 157.3
+
+
+def flush_c_stdio():
+    """RCCL prints a five-line version banner through C stdio when its first communicator is created; in a pipe or file that buffer
+    is written at exit, i.e. AFTER Python's own output.  Flushing it early keeps the JSON line the last line of rank 0's stdout."""
+    try:
+        import ctypes
+
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
 
 
 def make_batch(cfg, B, seed, padding, size):
@@ -315,6 +330,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the reference-padding second measurement of the default run")
     ap.add_argument("--no-specaugment", action="store_true")
+    ap.add_argument("--dp-hooks", action="store_true",
+                    help="with --gpus 1: run the DATA-PARALLEL code path (split block phases around the sync-BN all-reduces, bucketed gradient "
+                         "all-reduce) through a one-rank RCCL group - what that path costs by itself, wire time excluded")
     ap.add_argument("--dropout", type=float, default=None, help="override encoder dropout (default: reference value 0.1)")
     args = ap.parse_args()
     stub = os.environ.get("TFASR_BENCH_STUB") == "1"
@@ -336,6 +354,19 @@ def main():
         # never print a line whose n_gpus is not what was asked for
         raise SystemExit(f"--gpus {args.gpus} but this process group has WORLD_SIZE={world}: refusing to report a {world}-GPU run as {args.gpus}")
     dp = dpmod.init_from_env(backend="gloo" if stub else None) if world > 1 else None
+    if args.dp_hooks and world == 1 and not stub:
+        import socket
+
+        import torch.distributed as dist
+
+        sock = socket.socket()
+        sock.bind(("127.0.0.1", 0))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(sock.getsockname()[1]))
+        sock.close()
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        dp = dpmod.DataParallel()
     if dp and dp.world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but the process group has {dp.world} ranks")
     rank = dp.rank if dp else 0
@@ -390,6 +421,7 @@ def main():
 
     for i in range(args.warmup):
         one_step(i)
+    flush_c_stdio()  # RCCL's start-up banner (C stdio) leaves every rank's buffer now, long before rank 0's JSON line
     model.timers, model.timer_work = {}, {}
     torch.cuda.synchronize()
     if dp:
@@ -469,7 +501,7 @@ def main():
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "STUB (launch-logic test, not a measurement)" if stub else f"{'ContextNet' if args.model == 'contextnet' else 'Conformer-' + args.model} transducer full train step (fwd+RNN-T loss+bwd+Adam), {size} 16 kHz utterances, "
                                    f"{args.batch}/GPU, padding={args.padding}, SpecAugment {'off' if args.no_specaugment else 'on'}, dropout {cfg.dropout}",
-                       "global_batch": args.batch * world, "parallelism": f"dp{world}", "params": model.ps.num_trainable()},
+                       "global_batch": args.batch * world, "parallelism": f"dp{world}" + (" (data-parallel hooks on, one-rank RCCL group)" if args.dp_hooks and world == 1 else ""), "params": model.ps.num_trainable()},
             "roofline": roof,
             "roofline_rnnt": roof_rnnt,
         }
@@ -533,7 +565,8 @@ def main():
                     out["cpu_baseline"] = cpu_baseline(size if args.model.startswith("S") else "M", cfg.vocab_size)
             except Exception as e:  # the GPU number must still be reported
                 out["cpu_baseline"] = {"value": None, "error": repr(e)}
-        print(json.dumps(out))
+        flush_c_stdio()
+        print(json.dumps(out), flush=True)
     if dp:
         torch.distributed.destroy_process_group()
 

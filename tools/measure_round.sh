@@ -8,6 +8,8 @@ cd $R
 timeout 400 python bench.py > $O/bench_M.json 2> $O/bench_M.err
 timeout 300 python bench.py --model S > $O/bench_S.json 2> $O/bench_S.err
 timeout 200 python bench.py --model S-streaming --no-cpu-baseline --steps 50 > $O/bench_S_streaming.json 2>> $O/bench_S.err
+timeout 200 python bench.py --dp-hooks --no-cpu-baseline --no-extras > $O/bench_M_dp_hooks.json 2>> $O/bench_M.err
+timeout 200 python bench.py --model S --dp-hooks --no-cpu-baseline --no-extras > $O/bench_S_dp_hooks.json 2>> $O/bench_S.err
 timeout 200 python bench.py --mode decode --model S --steps 10 --warmup 2 > $O/decode_S.json 2> $O/decode.err
 timeout 200 python bench.py --mode decode --model M --steps 10 --warmup 2 > $O/decode_M.json 2>> $O/decode.err
 timeout 200 python bench.py --mode ctc-decode --steps 5 --warmup 2 > $O/ctc_decode.json 2>> $O/decode.err
@@ -23,5 +25,5 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 python $R/tools/pmc_traffic.py "$(find $O/pmc_FETCH_SIZE -name '*.db' | head -1)" "$(find $O/pmc_WRITE_SIZE -name '*.db' | head -1)" $O/pmc_traffic.json 30 > $O/pmc_top.txt 2>&1
 rm -rf $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE
-for f in bench_M bench_S bench_S_streaming decode_S decode_M ctc_decode contextnet_L; do echo "== $f"; cut -c1-420 $O/$f.json; done
+for f in bench_M bench_M_dp_hooks bench_S bench_S_dp_hooks bench_S_streaming decode_S decode_M ctc_decode contextnet_L; do echo "== $f"; cut -c1-420 $O/$f.json; done
 cat $O/lstm_persist.txt; tail -2 $O/nccl_selfcheck.txt

@@ -36,6 +36,15 @@ def main():
         by[k][1] += 1
     for k, (t, n) in sorted(by.items(), key=lambda kv: -kv[1][0])[:25]:
         print(f"{t / 1e3:9.1f} us in {n:4d} gaps (avg {t / n / 1e3:5.2f})  {k}")
+    # context of the largest gaps: the dispatches around them in global time order (all streams)
+    def nm(x):
+        return re.sub(r"\(anonymous namespace\)::", "", x).split("(")[0][:60]
+    big = sorted(range(1, len(rows)), key=lambda i: -(rows[i][1] - max(r[2] for r in rows[max(0, i - 8):i])))[:3]
+    for i in sorted(big):
+        prev_end = max(r[2] for r in rows[max(0, i - 8):i])
+        print(f"--- gap of {(rows[i][1] - prev_end) / 1e3:.1f} us before dispatch {i}:")
+        for j in range(max(0, i - 6), min(len(rows), i + 5)):
+            print(f"   {'>>' if j == i else '  '} +{(rows[j][1] - rows[i][1]) / 1e3:9.1f} us  {(rows[j][2] - rows[j][1]) / 1e3:7.1f} us  {nm(rows[j][0])}")
 
 
 if __name__ == "__main__":
