@@ -76,6 +76,9 @@ class ConformerTransducer(BaseModel):
         self._rng = np.random.default_rng([seed + 1000, int(self.dp.rank)])
         self.pred_stream = torch.cuda.Stream(device=self.device)
         self.use_pred_stream = os.environ.get("TFASR_NO_PRED_STREAM", "0") != "1"
+        # probe (bench.py --dp-hooks): take the world > 1 route of the block executor - two phases per block and direction around the sync-BN
+        # all-reduce - with a one-rank group, so everything of a multi-GPU step except the wire time can be measured on one GPU
+        self._dp_force_split = os.environ.get("TFASR_DP_FORCE_SPLIT", "0") == "1" and not isinstance(self.dp, SingleProcess)
         # prediction-network recurrence: the persistent one-launch kernels are faster in isolation but hold P/16 CUs for ~2 ms per step;
         # beside the encoder on the other stream the per-step kernels make the whole step 0.2 ms faster (measured on M and S), so:
         # persistent only when the prediction network has the device to itself.  TFASR_LSTM_PERSIST=0/1 in the environment overrides.
@@ -776,7 +779,7 @@ class ConformerTransducer(BaseModel):
         io.prezeroed = 1 if pool is not None else 0
         io.stash, io.stash_bytes, io.scratch, io.scratch_bytes = stash.data_ptr(), stash_b, scratch.data_ptr(), scratch.numel()
         cbuf = K.block_ctx()
-        if training and self.dp.world > 1 and not cfgk.dw_norm_layer:
+        if training and (self.dp.world > 1 or self._dp_force_split) and not cfgk.dw_norm_layer:
             K.block_fwd(cfgk, P, io, cbuf, K._lib.PHASE_A)
             self.dp.allreduce_stats_(stats[:2 * d])
             K.block_fwd(cfgk, P, io, cbuf, K._lib.PHASE_B)
@@ -813,7 +816,7 @@ class ConformerTransducer(BaseModel):
         io.scratch, io.scratch_bytes = scratch.data_ptr(), scratch.numel()
         io.wgrad_slot = slot
         self._last_wgrad_slot = slot
-        if self.dp.world > 1 and not cfgk.dw_norm_layer:
+        if (self.dp.world > 1 or self._dp_force_split) and not cfgk.dw_norm_layer:
             K.block_bwd(cfgk, P, io, cbuf, K._lib.PHASE_A)
             self.dp.allreduce_stats_(bstats)
             K.block_bwd(cfgk, P, io, cbuf, K._lib.PHASE_B)
