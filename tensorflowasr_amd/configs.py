@@ -10,6 +10,28 @@ import math
 from dataclasses import dataclass, field
 
 
+def speech_kwargs(sc):
+    """`speech_config` of the reference's YAML (FeatureExtraction.__init__, models/layers/feature_extraction.py:32-130) -> the front-end
+    fields of ConformerConfig.  Options the MI355X front end does not implement fail loudly instead of being ignored; the epsilon range
+    check is the reference's (feature_extraction.py:113)."""
+    sc = dict(sc or {})
+    only = {"feature_type": ("log_mel_spectrogram",), "pad_end": (True,), "use_librosa_like_stft": (False,), "log_base": ("e",),
+            "normalize_signal": (False,), "normalize_zscore": (False,), "normalize_min_max": (False,), "padding": (0,)}
+    for k, ok in only.items():
+        if k in sc and sc[k] not in ok:
+            raise NotImplementedError(f"speech_config.{k}={sc[k]!r}: only {ok} is on the MI355X hot path")
+    nfft = sc.get("nfft", 512)
+    if nfft is None:  # the reference falls back to the frame length (feature_extraction.py:121)
+        nfft = int(round(sc.get("sample_rate", 16000) * sc.get("frame_ms", 25) / 1000.0))
+    if nfft != 512 or int(round(sc.get("sample_rate", 16000) * sc.get("frame_ms", 25) / 1000.0)) > 512:
+        raise NotImplementedError(f"speech_config: nfft={nfft} / frame_ms={sc.get('frame_ms', 25)}: the front-end kernel is a 512-point transform (frames of up to 512 samples)")
+    eps = float(sc.get("epsilon", 1e-6))
+    assert eps > 1e-9 and eps <= 0.001, "epsilon must be in (1e-9, 0.001]"
+    return dict(sample_rate=sc.get("sample_rate", 16000), frame_ms=sc.get("frame_ms", 25), stride_ms=sc.get("stride_ms", 10), nfft=nfft,
+                num_feature_bins=sc.get("num_feature_bins", 80), preemphasis=sc.get("preemphasis", 0.97), epsilon=eps,
+                lower_edge_hertz=float(sc.get("lower_edge_hertz", 0.0)), upper_edge_hertz=float(sc.get("upper_edge_hertz", 8000.0)))
+
+
 @dataclass
 class ConformerConfig:
     # speech_config (models/layers/feature_extraction.py:34-55)
@@ -100,8 +122,7 @@ class ConformerConfig:
         reg = c.get("kernel_regularizer") or {}
         l2 = float((reg.get("config") or {}).get("l2", 1e-6)) if isinstance(reg, dict) else 1e-6
         kw = dict(
-            sample_rate=sc.get("sample_rate", 16000), frame_ms=sc.get("frame_ms", 25), stride_ms=sc.get("stride_ms", 10),
-            nfft=sc.get("nfft", 512), num_feature_bins=sc.get("num_feature_bins", 80), preemphasis=sc.get("preemphasis", 0.97),
+            **speech_kwargs(sc),
             filters=(sub.get("filters") or [c.get("encoder_dmodel", 144)])[0], dmodel=c.get("encoder_dmodel", 144),
             num_blocks=c.get("encoder_num_blocks", 16), head_size=c.get("encoder_head_size", 36),
             num_heads=c.get("encoder_num_heads", 4), kernel_size=c.get("encoder_kernel_size", 31),
@@ -181,8 +202,7 @@ def contextnet_from_reference(config: dict):
               embed_dim=c.get("prediction_embed_dim", 512), rnn_units=c.get("prediction_rnn_units", 320), joint_dim=c.get("joint_dim", 1024),
               prediction_layer_norm=bool(c.get("prediction_layer_norm", True)), vocab_size=int(c.get("vocab_size", 1000)), blank=c.get("blank", 0),
               dropout=0.0, l2=float((reg.get("config") or {}).get("l2", 1e-6)) if isinstance(reg, dict) else 1e-6,
-              sample_rate=sc.get("sample_rate", 16000), frame_ms=sc.get("frame_ms", 25), stride_ms=sc.get("stride_ms", 10),
-              nfft=sc.get("nfft", 512), num_feature_bins=sc.get("num_feature_bins", 80), preemphasis=sc.get("preemphasis", 0.97))
+              **speech_kwargs(sc))
     if "time_masking" in aug:
         kw["time_masking"] = dict(aug["time_masking"])
     if "freq_masking" in aug:

@@ -69,6 +69,37 @@ def test_unsupported_options_fail_loudly():
         configs.ConformerConfig.from_reference({"prediction_rnn_type": "gru", "vocab_size": 10})
 
 
+def test_speech_config_options_are_mapped_or_rejected():
+    """FeatureExtraction.__init__ (feature_extraction.py:32-130): epsilon and the mel edges reach the front end; the options the MI355X
+    front end does not implement (signal / feature normalisation, padding, librosa-like framing, log10, other feature types, other
+    transform sizes) raise instead of being ignored; the epsilon range check is the reference's assertion."""
+    base = {"vocab_size": 10}
+    cfg = configs.ConformerConfig.from_reference(dict(base, speech_config={"epsilon": 1e-5, "lower_edge_hertz": 125.0, "upper_edge_hertz": 7600.0,
+                                                                           "preemphasis": 0.0, "num_feature_bins": 40}))
+    assert (cfg.epsilon, cfg.lower_edge_hertz, cfg.upper_edge_hertz, cfg.preemphasis, cfg.num_feature_bins) == (1e-5, 125.0, 7600.0, 0.0, 40)
+    dflt = configs.ConformerConfig.from_reference(dict(base, speech_config={}))
+    assert (dflt.epsilon, dflt.lower_edge_hertz, dflt.upper_edge_hertz, dflt.preemphasis, dflt.nfft) == (1e-6, 0.0, 8000.0, 0.97, 512)
+    for bad in ({"normalize_signal": True}, {"normalize_zscore": True}, {"normalize_min_max": True}, {"padding": 160}, {"log_base": "10"},
+                {"use_librosa_like_stft": True}, {"pad_end": False}, {"feature_type": "mfcc"}, {"nfft": 1024}, {"frame_ms": 40}):
+        with pytest.raises(NotImplementedError):
+            configs.ConformerConfig.from_reference(dict(base, speech_config=bad))
+    with pytest.raises(AssertionError):
+        configs.ConformerConfig.from_reference(dict(base, speech_config={"epsilon": 1e-9}))
+    # explicitly stating the supported values is accepted
+    configs.ConformerConfig.from_reference(dict(base, speech_config={"normalize_signal": False, "padding": 0, "log_base": "e", "pad_end": True,
+                                                                       "feature_type": "log_mel_spectrogram"}))
+
+
+def test_product_mel_matrix_equals_the_oracles_for_other_edges():
+    import numpy as np
+
+    from oracle import conformer_ref as R
+    from tensorflowasr_amd.conformer import _mel_weight_matrix
+
+    for nb, lo, hi in ((80, 0.0, 8000.0), (80, 125.0, 7600.0), (40, 20.0, 4000.0)):
+        assert np.array_equal(_mel_weight_matrix(nb, 257, 16000, lo, hi), R.mel_weight_matrix(nb, 257, 16000, lo, hi))
+
+
 def test_m_config_is_the_paper_shape():
     m = configs.conformer_m()
     assert (m.dmodel, m.num_heads, m.head_size, m.num_blocks, m.rnn_units, m.joint_dim) == (256, 4, 64, 16, 640, 640)
