@@ -113,7 +113,17 @@ class ConformerConfig:
             "prediction_num_rnns": (1,), "joint_activation": ("tanh",), "joint_mode": ("add",),
             "encoder_convm_dw_norm_type": ("batch", "layer"), "prediction_label_encode_mode": ("embedding",),
             "encoder_memory_length": (None,), "encoder_use_attention_causal_mask": (False,),
+            # constructor options of models/transducer/conformer.py:23-77 (models/ctc/conformer.py for the CTC head) that change the
+            # network and are not built: a non-default value must not be ignored silently
+            "encoder_interleave_relpe": (True,), "encoder_mhsam_causal": (False,), "encoder_convm_scale_factor": (2,),
+            "encoder_convm_use_group_conv": (False,), "encoder_module_norm_position": ("pre",), "encoder_block_norm_position": ("post",),
+            "encoder_trainable": (True,), "prediction_trainable": (True,), "joint_trainable": (True,),
+            "prediction_projection_units": (0,), "prejoint_encoder_linear": (True,), "prejoint_prediction_linear": (True,),
+            "postjoint_linear": (False,), "bias_regularizer": (None,), "activity_regularizer": (None,), "recurrent_regularizer": (None,),
         }
+        if "prediction_layer_norm" in c and not c["prediction_layer_norm"] and not (class_name and ".ctc." in class_name):
+            raise NotImplementedError("prediction_layer_norm=False: the Conformer transducer's prediction network ends in a LayerNorm here "
+                                      "(base_transducer.py:123-132 with the YAML default)")
         for k, ok in unsupported.items():
             if k in c and c[k] not in ok:
                 raise NotImplementedError(f"{k}={c[k]!r}: only {ok} is on the MI355X hot path")

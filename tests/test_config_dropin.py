@@ -67,6 +67,16 @@ def test_unsupported_options_fail_loudly():
         configs.ConformerConfig.from_reference({"encoder_mha_type": "mha", "vocab_size": 10})
     with pytest.raises(NotImplementedError):
         configs.ConformerConfig.from_reference({"prediction_rnn_type": "gru", "vocab_size": 10})
+    # every constructor option that would change the network but is not built (models/transducer/conformer.py:23-77)
+    for k, v in (("encoder_interleave_relpe", False), ("encoder_mhsam_causal", True), ("encoder_convm_scale_factor", 4),
+                 ("encoder_convm_use_group_conv", True), ("encoder_module_norm_position", "post"), ("encoder_block_norm_position", "pre"),
+                 ("encoder_trainable", False), ("prediction_projection_units", 256), ("prejoint_encoder_linear", False),
+                 ("postjoint_linear", True), ("prediction_layer_norm", False), ("bias_regularizer", {"class_name": "L2"})):
+        with pytest.raises(NotImplementedError):
+            configs.ConformerConfig.from_reference({k: v, "vocab_size": 10})
+    # options that only choose an implementation of the same mathematics are accepted
+    configs.ConformerConfig.from_reference({"encoder_mhsam_flash_attention": True, "prediction_rnn_implementation": 1, "prediction_rnn_unroll": True,
+                                            "vocab_size": 10})
 
 
 def test_speech_config_options_are_mapped_or_rejected():
