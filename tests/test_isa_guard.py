@@ -77,3 +77,59 @@ def test_no_compiler_made_vmcnt_wait_inside_the_slab_loop(asm, frag):
             raise AssertionError(f"compiler-made vector-memory wait inside the slab loop of {frag}: {l.strip()}")
     assert mfma == 32
     assert pieces_between >= 6, f"the next-next slab's DMA pieces are no longer issued between the MFMAs ({pieces_between})"
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# log-mel front end (csrc/logmel.hip): the next frame's samples are prefetched at the top of the frame loop and consumed in front of
+# the frame's stores.  Three compiler behaviours broke that silently while it was written (a select behind each load, a phantom
+# fetch-without-prepare path, the consumption sunk behind the stores); each shows up as a vmcnt wait where none belongs.
+LOGMEL_SRC = os.path.join(ROOT, "tensorflowasr_amd", "csrc", "logmel.hip")
+
+
+@pytest.fixture(scope="module")
+def logmel_asm(tmp_path_factory):
+    if not shutil.which(HIPCC) and not os.path.exists(HIPCC):
+        pytest.skip("hipcc not available")
+    out = tmp_path_factory.mktemp("isa_lm") / "logmel.s"
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-result", "--cuda-device-only", "-S",
+           LOGMEL_SRC, "-o", str(out)]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return open(out).read().split("\n")
+
+
+@pytest.mark.parametrize("frag", ["logmel_kernelItEE", "logmel_kernelIfEE"])
+def test_logmel_frame_loop_prefetch_is_not_drained(logmel_asm, frag):
+    body = _body(logmel_asm, frag)
+    labels = {l.split(":")[0]: i for i, l in enumerate(body) if re.match(r"^\.LBB\d+_\d+:", l)}
+    # the frame loop = the longest backward branch
+    best = None
+    for i, l in enumerate(body):
+        m = re.search(r"s_c?branch\w*\s+(\.LBB\d+_\d+)", l)
+        if m and m.group(1) in labels and labels[m.group(1)] < i and (best is None or i - labels[m.group(1)] > best[1] - best[0]):
+            best = (labels[m.group(1)], i)
+    assert best is not None
+    loop = body[best[0]:best[1]]
+    loads = [i for i, l in enumerate(loop) if re.match(r"\s+global_load_dword\s", l)]
+    assert len(loads) >= 16, "the 16 sample loads of the next frame are expected inside the frame loop"
+    first, last = loads[0], loads[15]
+    # (1) nothing waits for vector memory between the loop top and the last of the 16 requests (they leave back to back)
+    for l in loop[:last]:
+        assert not re.search(r"s_waitcnt\s+vmcnt", l), f"vector-memory wait in front of / between the prefetch loads: {l.strip()}"
+    # (2) the output stores are the untracked inline-asm ones, and the waits for the prefetched samples come BEFORE them
+    stores = [i for i, l in enumerate(loop) if "global_store" in l]
+    assert stores, "output stores not found in the frame loop"
+    waits = [i for i, l in enumerate(loop) if re.search(r"s_waitcnt\s+vmcnt\(0\)", l)]
+    assert waits and min(waits) < min(stores), "the prefetched samples must be consumed in front of the frame's stores"
+    in_asm = False
+    for i, l in enumerate(loop):
+        if "#ASMSTART" in l:
+            in_asm = True
+        elif "#ASMEND" in l:
+            in_asm = False
+        elif "global_store" in l:
+            assert in_asm, "a compiler-tracked store in the frame loop puts vmcnt(0) (= wait for the stores) in front of the next frame"
+    # (3) no vector-memory wait after the stores inside the loop (the loop-carried samples were consumed already)
+    tail = [l for l in loop[max(stores):] if re.search(r"s_waitcnt\s+vmcnt", l)]
+    # the only loads behind the stores are the mel-band tails read from the dense matrix (bands wider than the LDS taps): their wait is inside that inner loop
+    assert len(tail) <= 1, tail
