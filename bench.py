@@ -319,7 +319,7 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--model", default="M", choices=["M", "S", "S-streaming", "contextnet"],
-                    help="M / S = Conformer sizes; S-streaming = small-streaming.yml.j2 (chunk 16 / history 64, LayerNorm depthwise norm); contextnet = BASELINE configs[3] family")
+                    help="M / S = Conformer sizes; S-streaming = small-streaming.yml.j2 (chunk 16 / history 64, LayerNorm depthwise and subsampling norms); contextnet = BASELINE configs[3] family")
     ap.add_argument("--alpha", type=float, default=2.0, help="ContextNet width multiplier (0.5 small, 1 medium, 2 large)")
     ap.add_argument("--batch", type=int, default=32, help="utterances per GPU")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
@@ -385,7 +385,7 @@ def main():
     else:
         cfg = configs.conformer_m() if args.model == "M" else configs.conformer_s()
         if args.model == "S-streaming":  # examples/models/transducer/conformer/small-streaming.yml.j2:26,33,38-39
-            cfg = configs.conformer_s(chunk_size=16, history_size=64, convm_dw_norm="layer")
+            cfg = configs.conformer_s(chunk_size=16, history_size=64, convm_dw_norm="layer", sub_norm="layer")
     if args.no_specaugment:
         cfg.time_masking, cfg.freq_masking = {}, {}
     if args.dropout is not None:

@@ -333,13 +333,17 @@ def conformer_block(x, pe, W, pfx, cfg, lengths, u, v, training=True, use_mask=T
     return layer_norm(x, W[pfx + "ln/g"], W[pfx + "ln/b"])
 
 
-def subsampling(feat, lengths, W, training=True, stats=None):
-    """Conv2dSubsampling.call (subsampling.py:218-230): feat [B,T0,F,1] -> [B,T',F'*C]."""
+def subsampling(feat, lengths, W, training=True, stats=None, norm="batch"):
+    """Conv2dSubsampling.call (subsampling.py:218-230): feat [B,T0,F,1] -> [B,T',F'*C].  `norm`: the yml's `norms` entry -
+    "batch" (small.yml.j2:31) or "layer" (small-streaming.yml.j2: a keras LayerNormalization over the channel axis of the
+    [B,T,F,C] conv output, subsampling.py:198-207; its gamma / beta live in the bn{i}/g, bn{i}/b slots)."""
     x = feat
     ln = torch.as_tensor(lengths)
     for i in range(2):
         x = conv2d_causal_s2(x, W[f"enc/sub/conv{i}/w"], W[f"enc/sub/conv{i}/b"])
-        if training:
+        if norm == "layer":
+            x = layer_norm(x, W[f"enc/sub/bn{i}/g"], W[f"enc/sub/bn{i}/b"])
+        elif training:
             x, mean, var = batch_norm_train(x, W[f"enc/sub/bn{i}/g"], W[f"enc/sub/bn{i}/b"])
             if stats is not None:
                 stats[f"enc/sub/bn{i}"] = (mean.detach(), var.detach())
@@ -355,7 +359,7 @@ def encoder(feat, lengths, W, cfg, training=True, use_mask=True, stats=None, dro
     """ConformerEncoder.call (conformer.py:672-701).  `drop(site, y)`: the step's Dropout masks (site 0 = after the linear layer,
     conformer.py:594,682; block i: 16 + 8 i + {0..5}); default = dropout off.  (The relative encoding's own Dropout has rate 0:
     conformer.py:604-610.)"""
-    x, ln = subsampling(feat, lengths, W, training, stats)
+    x, ln = subsampling(feat, lengths, W, training, stats, cfg.get("sub_norm", "batch"))
     x = drop(0, x @ W["enc/linear/w"] + W["enc/linear/b"])
     B, T, d = x.shape
     pe, _ = relative_position_encoding(T, d, ln.tolist(), interleave=True)

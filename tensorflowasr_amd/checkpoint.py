@@ -56,7 +56,7 @@ _TAIL = {
 _DW_LN = {"bn/g": "dw_ln/gamma", "bn/b": "dw_ln/beta"}  # encoder_convm_dw_norm_type: layer -> the layer is named dw_ln (encoders/conformer.py:334-340)
 
 
-def keras_path(name, dw_norm="batch"):
+def keras_path(name, dw_norm="batch", sub_norm="batch"):
     """Keras variable path of one tensor of ParamStore.export_keras() (q/k/v already split; BN state as .../mm, .../mv).
     dw_norm = cfg.convm_dw_norm: the depthwise-norm slot of the conv module is `dw_bn` (BatchNormalization) or `dw_ln`."""
     if name in _TAIL:
@@ -64,6 +64,8 @@ def keras_path(name, dw_norm="batch"):
     m = _SUB.match(name)
     if m:
         kind, i, leaf = m.group(1), m.group(2), m.group(3)
+        if kind == "bn" and sub_norm == "layer":  # `norms: layer` -> the layer is named ln_{i} (subsampling.py:205-213)
+            kind = "ln"
         leaf = {"w": "kernel", "b": "bias" if kind == "conv" else "beta", "g": "gamma", "mm": "moving_mean", "mv": "moving_variance"}[leaf]
         return f"conformer_encoder/subsampling/block_{i}/{kind}_{i}/{leaf}"
     m = _BLOCK.match(name)
@@ -95,22 +97,22 @@ def _from_keras_layout(name, a, shape, path=None):
     return a.reshape(shape)
 
 
-def to_keras(exported, dw_norm="batch"):
+def to_keras(exported, dw_norm="batch", sub_norm="batch"):
     """ParamStore.export_keras() dict (name -> tensor) -> {Keras path: float32 ndarray in the Keras layout}."""
     out = {}
     for name, t in exported.items():
         a = np.asarray(t.detach().cpu().numpy() if hasattr(t, "detach") else t, dtype=np.float32)
-        out[keras_path(name, dw_norm)] = _to_keras_layout(name, a)
+        out[keras_path(name, dw_norm, sub_norm)] = _to_keras_layout(name, a)
     return out
 
 
-def from_keras(arrays, template, strict=True, dw_norm="batch"):
+def from_keras(arrays, template, strict=True, dw_norm="batch", sub_norm="batch"):
     """{Keras path: array} -> dict in the layout of `template` (= ParamStore.export_keras(), which fixes names and shapes).
     strict: every variable of the model must be present and no unknown array may remain."""
     arrays = dict(arrays)
     out, missing = {}, []
     for name, t in template.items():
-        path = keras_path(name, dw_norm)
+        path = keras_path(name, dw_norm, sub_norm)
         if path not in arrays:
             missing.append(path)
             continue
@@ -123,7 +125,7 @@ def from_keras(arrays, template, strict=True, dw_norm="batch"):
 
 def save_weights(model, filepath):
     """BaseModel.save_weights (base_model.py:55-57): every trainable variable + BatchNorm moving statistics -> `.npz`."""
-    arrays = to_keras(model.ps.export_keras(), getattr(model.cfg, "convm_dw_norm", "batch"))
+    arrays = to_keras(model.ps.export_keras(), getattr(model.cfg, "convm_dw_norm", "batch"), getattr(model.cfg, "sub_norm", "batch"))
     with open(filepath, "wb") as f:  # (np.savez would append ".npz" to a bare name)
         np.savez(f, **{k.replace("/", "|"): v for k, v in arrays.items()})
     return sorted(arrays)
@@ -136,7 +138,7 @@ def load_weights(model, filepath, strict=True):
     with np.load(filepath) as z:
         arrays = {k.replace("|", "/"): z[k] for k in z.files}
     template = model.ps.export_keras()
-    got = from_keras(arrays, template, strict=strict, dw_norm=getattr(model.cfg, "convm_dw_norm", "batch"))
+    got = from_keras(arrays, template, strict=strict, dw_norm=getattr(model.cfg, "convm_dw_norm", "batch"), sub_norm=getattr(model.cfg, "sub_norm", "batch"))
     merged = {k: (torch.from_numpy(np.ascontiguousarray(got[k])) if k in got else v) for k, v in template.items()}
     model.ps.import_keras(merged)
     return sorted(got)
@@ -171,7 +173,7 @@ def h5_anchors(name):
         seq = ("sequential" if i == 0 else f"sequential_{i}", f"block_{i}")
         if kind == "conv":
             return [("conv_subsampling", "subsampling"), seq, ("conv2d", f"conv_{i}", "conv2d_" + str(i))], idx[leaf], ()
-        return [("conv_subsampling", "subsampling"), seq, ("batch_normalization", f"bn_{i}")], {"g": 0, "b": 1, "mm": 2, "mv": 3}[leaf], ()
+        return [("conv_subsampling", "subsampling"), seq, ("batch_normalization", f"bn_{i}", "layer_normalization", f"ln_{i}")], {"g": 0, "b": 1, "mm": 2, "mv": 3}[leaf], ()
     if name in ("enc/linear/w", "enc/linear/b"):
         return [("linear",)], idx[name[-1]], ("conv_subsampling", "subsampling") + _H5_MODULE_TOKENS
     if name in ("enc/u", "enc/v"):

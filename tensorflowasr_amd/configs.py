@@ -65,6 +65,7 @@ class ConformerConfig:
     chunk_size: int = None
     history_size: int = None
     convm_dw_norm: str = "batch"
+    sub_norm: str = "batch"  # Conv2dSubsampling `norms` (subsampling.py:197-213): "batch" (small.yml.j2) or "layer" (small-streaming.yml.j2)
     # encoder_mhsam_use_attention_bias: True (examples/models/ctc/conformer/small.yml.j2:45): per-layer content / positional
     # attention biases (multihead_attention.py:522-538) instead of the encoder-level shared pair (encoders/conformer.py:647-663)
     mhsam_use_attention_bias: bool = False
@@ -129,6 +130,14 @@ class ConformerConfig:
                 raise NotImplementedError(f"{k}={c[k]!r}: only {ok} is on the MI355X hot path")
         if sub and (list(sub.get("kernels", [3, 3])) != [3, 3] or list(sub.get("strides", [2, 2])) != [2, 2]):
             raise NotImplementedError("only the 3x3 stride-2 causal Conv2dSubsampling of small.yml.j2:26-33 is supported")
+        norms = [str(n) for n in sub.get("norms", ["batch", "batch"])]
+        if norms not in (["batch", "batch"], ["layer", "layer"]):
+            raise NotImplementedError(f"encoder_subsampling.norms={norms}: both blocks 'batch' (small.yml.j2:31) or both 'layer' "
+                                      f"(small-streaming.yml.j2) are built (subsampling.py:197-213)")
+        if [str(a) for a in sub.get("activations", ["swish", "swish"])] not in (["swish", "swish"], ["silu", "silu"]):
+            raise NotImplementedError(f"encoder_subsampling.activations={sub.get('activations')}: only swish (small.yml.j2:32)")
+        if [str(a) for a in sub.get("paddings", ["causal", "causal"])] != ["causal", "causal"]:
+            raise NotImplementedError(f"encoder_subsampling.paddings={sub.get('paddings')}: only causal (small.yml.j2:30)")
         reg = c.get("kernel_regularizer") or {}
         l2 = float((reg.get("config") or {}).get("l2", 1e-6)) if isinstance(reg, dict) else 1e-6
         kw = dict(
@@ -142,7 +151,7 @@ class ConformerConfig:
             embed_dim=c.get("prediction_embed_dim", 512), rnn_units=c.get("prediction_rnn_units", 320),
             joint_dim=c.get("joint_dim", 1024), vocab_size=int(c.get("vocab_size", 1000)), blank=c.get("blank", 0), l2=l2,
             chunk_size=c.get("encoder_chunk_size"), history_size=c.get("encoder_history_size"),
-            convm_dw_norm=c.get("encoder_convm_dw_norm_type", "batch"),
+            convm_dw_norm=c.get("encoder_convm_dw_norm_type", "batch"), sub_norm=norms[0],
             mhsam_use_attention_bias=bool(c.get("encoder_mhsam_use_attention_bias", False)))
         if class_name and ".ctc." in class_name:
             kw["head"] = "ctc"

@@ -62,8 +62,9 @@ class ConformerTransducer(BaseModel):
                and os.environ.get("TFASR_HEAD_PAD", "1") != "0")
         # ... and the convolutional subsampling's channels padded to a multiple of 64 (144 -> 192): conv2 then runs as K-segmented GEMMs
         # over the space-to-depth layout with conv1 + BatchNorm recomputed, like the 256-filter model (Conformer-S: 14.3 -> 13.6 ms/step)
+        # (a LayerNormalization in the subsampling - `norms: layer`, small-streaming.yml.j2 - normalises over the channel axis: no padding)
         cpad = (dtype == torch.bfloat16 and cfg.filters % 64 != 0 and getattr(cfg, "encoder", "conformer") == "conformer"
-                and os.environ.get("TFASR_FILTER_PAD", "1") != "0")
+                and getattr(cfg, "sub_norm", "batch") == "batch" and os.environ.get("TFASR_FILTER_PAD", "1") != "0")
         self.ps = ParamStore(cfg, self.device, dtype, seed, head_phys=64 if pad else None, filt_phys=-(-cfg.filters // 64) * 64 if cpad else None)
         self.dp = dp or SingleProcess()
         self.blank = cfg.blank
@@ -279,8 +280,8 @@ class ConformerTransducer(BaseModel):
     _SEG = [(kh, kw) for kh in range(3) for kw in range(3)]
 
     def _s2d_enabled(self):
-        if os.environ.get("TFASR_CONV2_IM2COL", "0") == "1":
-            return False
+        if os.environ.get("TFASR_CONV2_IM2COL", "0") == "1" or getattr(self.cfg, "sub_norm", "batch") == "layer":
+            return False  # the recomputed conv1 + BatchNorm kernels of the space-to-depth route have no LayerNormalization variant
         # bf16: the K-segmented MFMA GEMM needs whole 64-wide slabs per tap; f32 (parity mode) issues one product per tap
         return self.dtype == torch.float32 or self.ps.filt_phys % 64 == 0
 
@@ -451,6 +452,21 @@ class ConformerTransducer(BaseModel):
         K.axpy(ps.g("enc/sub/bn0/b"), bstats[:C].contiguous(), inv)
         K.axpy(ps.g("enc/sub/bn0/g"), bstats[C:].contiguous(), inv)
 
+    def _sub_norm_fwd(self, x2d, name, training):
+        """the subsampling's norm + swish (subsampling.py:197-214): BatchNormalization, or - `norms: layer` - a LayerNormalization over
+        the channel axis of the [B, T, F, C] conv output (gamma / beta in the bn{i}/g, bn{i}/b slots)."""
+        if self.cfg.sub_norm == "layer":
+            yn, mean, rstd = K.layernorm_fwd(x2d, self.ps.p(name + "/g"), self.ps.p(name + "/b"))
+            return K.add_act_fwd(yn, None, ACT_SWISH), (yn, mean, rstd)
+        return self._bn_fwd(x2d, name, training, ACT_SWISH)
+
+    def _sub_norm_bwd(self, x2d, dy2d, name, saved):
+        if self.cfg.sub_norm == "layer":
+            yn, mean, rstd = saved
+            dyn = K.add_act_bwd(yn, None, dy2d, ACT_SWISH)
+            return K.layernorm_bwd(dyn, x2d, self.ps.p(name + "/g"), mean, rstd, self.ps.g(name + "/g"), self.ps.g(name + "/b"))
+        return self._bn_bwd(x2d, dy2d, name, saved, ACT_SWISH)
+
     def _subsampling_fwd(self, feats, flen, training, ctx):
         if self._s2d_enabled():
             return self._subsampling_fwd_s2d(feats, flen, training, ctx)
@@ -459,12 +475,12 @@ class ConformerTransducer(BaseModel):
         C = ps.filt_phys
         c1 = K.conv1_fwd(feats, ps.p("enc/sub/conv0/w"), ps.p("enc/sub/conv0/b"))  # [B,T1,F1,C]
         T1, F1 = c1.shape[1], c1.shape[2]
-        a1, bn0 = self._bn_fwd(c1.view(-1, C), "enc/sub/bn0", training, ACT_SWISH)
+        a1, bn0 = self._sub_norm_fwd(c1.view(-1, C), "enc/sub/bn0", training)
         a1 = a1.view(B, T1, F1, C)
         col = K.im2col_3x3s2(a1)  # [B*T2*F2, 9C]
         T2, F2 = (T1 + 1) // 2, (F1 + 1) // 2
         c2 = K.matmul(col, ps.w2d("enc/sub/conv1/w"), bias=ps.p("enc/sub/conv1/b"))  # [B*T2*F2, C]
-        a2, bn1 = self._bn_fwd(c2, "enc/sub/bn1", training, ACT_SWISH)
+        a2, bn1 = self._sub_norm_fwd(c2, "enc/sub/bn1", training)
         merged = a2.view(B * T2, F2 * C)  # math_util.merge_two_last_dims
         drop = self._drop(0, training)
         x0 = K.matmul(merged, ps.w2d("enc/linear/w"), bias=ps.p("enc/linear/b"), drop_p=drop[0], drop_seed=drop[1])  # [B*T2, d]
@@ -481,10 +497,10 @@ class ConformerTransducer(BaseModel):
         B, T0, F0, T1, F1, T2, F2 = s["dims"]
         C = ps.filt_phys
         dmerged = self._dense_bwd(self._mask_grad(dx0, s["drop"]), s["merged"], "enc/linear/w", "enc/linear/b")
-        dc2 = self._bn_bwd(s["c2"], dmerged.view(-1, C), "enc/sub/bn1", s["bn1"], ACT_SWISH)
+        dc2 = self._sub_norm_bwd(s["c2"], dmerged.view(-1, C), "enc/sub/bn1", s["bn1"])
         dcol = self._dense_bwd(dc2, s["col"], "enc/sub/conv1/w", "enc/sub/conv1/b")
         da1 = K.col2im_3x3s2(dcol, B, T1, F1, C)
-        dc1 = self._bn_bwd(s["c1"].view(-1, C), da1.view(-1, C), "enc/sub/bn0", s["bn0"], ACT_SWISH)
+        dc1 = self._sub_norm_bwd(s["c1"].view(-1, C), da1.view(-1, C), "enc/sub/bn0", s["bn0"])
         K.conv1_bwd_weight(s["feats"], dc1.view(B, T1, F1, C), ps.g("enc/sub/conv0/w"), ps.g("enc/sub/conv0/b"))
 
     # =================================================================================== conformer block

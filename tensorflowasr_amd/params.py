@@ -149,7 +149,9 @@ def bn_names(cfg):
     # encoder_convm_dw_norm_type: layer (encoders/conformer.py:334-340) puts a LayerNormalization in the depthwise-norm slot: no moving
     # statistics exist for it (a keras LayerNormalization holds gamma and beta only)
     blocks = [] if getattr(cfg, "convm_dw_norm", "batch") == "layer" else [f"enc/block{i}/conv/bn" for i in range(cfg.num_blocks)]
-    return ["enc/sub/bn0", "enc/sub/bn1"] + blocks
+    # encoder_subsampling.norms: layer (subsampling.py:205-213): LayerNormalization in the bn0 / bn1 slots, no moving statistics either
+    sub = [] if getattr(cfg, "sub_norm", "batch") == "layer" else ["enc/sub/bn0", "enc/sub/bn1"]
+    return sub + blocks
 
 
 class ParamStore:

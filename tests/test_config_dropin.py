@@ -39,6 +39,7 @@ def test_small_streaming_yml_maps_onto_config():
     txt = jinja2.Template(open(path).read()).render(decoder_config={"vocabsize": 1000}, modeldir="/tmp/m", kaggle_model_handle="x")
     cfg = configs.ConformerConfig.from_reference(yaml.safe_load(txt)["model_config"]["config"])
     assert (cfg.chunk_size, cfg.history_size, cfg.convm_dw_norm) == (16, 64, "layer")
+    assert cfg.sub_norm == "layer"  # `norms: [layer, layer]` of the yml's encoder_subsampling (subsampling.py:205-213)
     assert (cfg.dmodel, cfg.head_size, cfg.num_blocks, cfg.kernel_size) == (144, 36, 16, 31)
 
 

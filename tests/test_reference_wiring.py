@@ -1,0 +1,185 @@
+"""The oracle against the reference's OWN model classes (CPU).
+
+tests/golden/wiring_*.npz hold inputs, weights and per-stage outputs of `tensorflow_asr.models.transducer.conformer.Conformer` and
+`...contextnet.ContextNet` CONSTRUCTED and RUN from /root/reference over oracle/tf_shim + oracle/keras_shim
+(oracle/gen_wiring_from_reference.py): FeatureExtraction.call, Conv2dSubsampling.call, ConformerEncoder / ConformerBlock / FFModule /
+MHSAModule / ConvModule .call, MultiHeadRelativeAttention.call (mask construction included), Residual.call,
+TransducerPrediction.call, TransducerJoint.call, Transducer.call, ContextNet's ConvModule / SEModule / ConvBlock .call - with the Keras
+mask plumbing executed, so "BatchNorm sees every frame" / "attention masks padded QUERY rows only" are observations, not readings.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import conformer_ref as R
+from oracle import contextnet_ref as CN
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _load(name):
+    z = np.load(os.path.join(GOLD, f"wiring_{name}.npz"))
+    W = {k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("W/")}
+    return z, W
+
+
+def _ocfg(z, **over):
+    cfg = R.conformer_config("tiny")
+    cfg.update(over)
+    return cfg
+
+
+def _seqmask(lens, T):
+    return (np.arange(T)[None, :] < np.asarray(lens)[:, None])
+
+
+def _close(a, b, tol=2e-5):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    err = np.abs(a - b).max() / max(1.0, np.abs(b).max())
+    assert err < tol, err
+
+
+@pytest.mark.parametrize("name,over", [("conformer", {}), ("conformer_streaming", dict(chunk_size=2, history_size=4, convm_dw_norm="layer", sub_norm="layer"))])
+def test_conformer_stages_match_reference_classes(name, over):
+    z, W = _load(name)
+    cfg = _ocfg(z, **over)
+    lens = z["signals_length"]
+    feat = R.log_mel(z["signals"], cfg)
+    flen = R.get_nframes(lens)
+    # a1-a5 FeatureExtraction.call (feature_extraction.py:255-303): features [B, T0, 80, 1] and the frame counts
+    assert np.array_equal(flen, z["train/features_length"])
+    _close(feat, z["train/features"][..., 0], 1e-5)
+    for mode in ("train", "eval"):
+        training = mode == "train"
+        Wm = dict(W)
+        if not training:  # the eval call ran after ONE training call: moving statistics were updated with momentum 0.99
+            for k in z.files:
+                if k.startswith("after_train/"):
+                    Wm[k[len("after_train/"):]] = torch.from_numpy(z[k])
+        t = mode + "/"
+        stats = {}
+        x, ln = R.subsampling(torch.from_numpy(feat)[..., None], flen, Wm, training, stats, cfg.get("sub_norm", "batch"))
+        assert ln.tolist() == z[t + "logits_length"].tolist()
+        _close(x, z[t + "subsampling"])                                              # a7 Conv2dSubsampling.call (subsampling.py:218-230)
+        x = x @ Wm["enc/linear/w"] + Wm["enc/linear/b"]
+        _close(x, z[t + "linear"])
+        B, T, d = x.shape
+        pe, _ = R.relative_position_encoding(T, d, ln.tolist())
+        _close(pe, z[t + "relpe"], 1e-5)                                             # a9
+        u, v = Wm["enc/u"], Wm["enc/v"]
+        for i in range(cfg["num_blocks"]):
+            pfx = f"enc/block{i}/"
+            y = R.ff_module(x, Wm, pfx + "ff1/", cfg["ffm_residual"])
+            _close(y, z[t + f"block{i}/ffm1"])                                       # a10 FFModule.call + Residual.call
+            y = R.mhsa_module(y, pe, Wm, pfx + "mhsa/", cfg["num_heads"], cfg["head_size"], ln, u, v, True, cfg.get("chunk_size"), cfg.get("history_size"))
+            _close(y, z[t + f"block{i}/mhsam"])                                      # a11 / a12 MHSAModule.call, MultiHeadRelativeAttention.call
+            y = R.conv_module(y, Wm, pfx + "conv/", training, stats, cfg.get("convm_dw_norm", "batch"))
+            _close(y, z[t + f"block{i}/convm"])                                      # a13 ConvModule.call
+            x = R.conformer_block(x, pe, Wm, pfx, cfg, ln, u, v, training, True, stats)
+            _close(x, z[t + f"block{i}"])                                            # a14 ConformerBlock.call
+        _close(x, z[t + "encoder"])                                                  # a8
+        pred = R.prediction_net(torch.from_numpy(z["predictions"]), z["predictions_length"], Wm)
+        _close(pred, z[t + "prediction"])                                            # a16 TransducerPrediction.call
+        logits, elen = R.transducer_forward(torch.from_numpy(feat), flen, torch.from_numpy(z["predictions"]), z["predictions_length"], Wm, cfg, training)
+        _close(logits, z[t + "logits"])                                              # a17 / a18 TransducerJoint.call, Transducer.call
+        if training and cfg.get("sub_norm", "batch") == "batch":
+            # keras moving statistics after one training call = 0.99 * old + 0.01 * batch moment (biased variance, all frames)
+            for k, (mean, var) in stats.items():
+                _close(0.99 * W[k + "/mm"] + 0.01 * mean, z["after_train/" + k + "/mm"], 1e-5)
+                _close(0.99 * W[k + "/mv"] + 0.01 * var, z["after_train/" + k + "/mv"], 1e-5)
+
+
+@pytest.mark.parametrize("name", ["conformer", "conformer_streaming", "conformer_dropout"])
+def test_masks_the_reference_classes_produced(name):
+    """What the Keras mask plumbing did when the reference's classes ran (DESIGN section 4 'stated assumption'):
+    * the encoder output carries the sequence mask of the reduced lengths (Conv2dSubsampling.compute_mask, subsampling.py:232-247);
+    * the attention softmax received a [B, 1, T, 1] mask = padded QUERY rows only (multihead_attention.py:609-623: value / key masks
+      are None), AND-ed with the chunk mask in the streaming model;
+    * NO mask reached any BatchNormalization (the reference's conv subclasses, convolution.py, do not support masking, so the
+      BatchNorm moments run over every frame, padded ones included);
+    * the LSTM received the sequence mask of `predictions_length` (Embedding.compute_mask, embedding.py:50-53)."""
+    z, _ = _load(name)
+    ln = z["train/logits_length"]
+    B, T = z["train/encoder"].shape[:2]
+    qmask = _seqmask(ln, T)
+    assert np.array_equal(z["train/encoder_mask"].astype(bool), qmask)
+    for i in range(2):
+        sm = z[f"train/block{i}/softmax_mask"].astype(bool)
+        if name == "conformer_streaming":
+            chunk = R.compute_streaming_mask(2, 4, T)                                # [1, T, T]
+            assert sm.shape == (B, 1, T, T) and np.array_equal(sm[:, 0], qmask[:, :, None] & chunk)
+        else:
+            assert sm.shape == (B, 1, T, 1) and np.array_equal(sm[:, 0, :, 0], qmask)
+        if f"train/block{i}/dw_bn_mask" in z.files:
+            assert z[f"train/block{i}/dw_bn_mask"].tolist() == [-1]                  # None reached the depthwise BatchNorm
+    for j in range(2):
+        if f"train/sub_bn{j}_mask" in z.files:
+            assert z[f"train/sub_bn{j}_mask"].tolist() == [-1]                       # None reached the subsampling BatchNorms
+    U1 = z["predictions"].shape[1]
+    assert np.array_equal(z["train/lstm_mask"].astype(bool), _seqmask(z["predictions_length"], U1))
+    # TransducerJoint.compute_mask (base_transducer.py:185-197): [B, T, U1] = encoder mask AND prediction mask
+    lm = z["train/logits_mask"].astype(bool)
+    assert np.array_equal(lm, qmask[:, :, None] & _seqmask(z["predictions_length"], U1)[:, None, :])
+
+
+def test_dropout_sites_match_reference_classes():
+    """Dropout rate 0.1, training: the masks the reference's 13 Dropout layers drew (conformer.py:80,88,193,353,594; the relative
+    encoding's own Dropout and the attention-probability Dropout have rate 0) injected into the oracle at ITS numbered sites."""
+    z, W = _load("conformer_dropout")
+    cfg = _ocfg(z)
+    rate = float(z["dropout_rate"])
+    masks = {int(k[5:]): torch.from_numpy(z[k]) for k in z.files if k.startswith("drop/")}
+    assert sorted(masks) == [0] + [16 + 8 * i + k for i in range(2) for k in range(6)]
+    used = set()
+
+    def drop(site, y):
+        if site is None:
+            return y
+        used.add(site)
+        return y * masks[site] / (1.0 - rate)
+
+    feat = R.log_mel(z["signals"], cfg)
+    logits, _ = R.transducer_forward(torch.from_numpy(feat), R.get_nframes(z["signals_length"]), torch.from_numpy(z["predictions"]),
+                                     z["predictions_length"], W, cfg, True, drop=drop)
+    assert used == set(masks)
+    _close(logits, z["train/logits"])
+    plain, _ = R.transducer_forward(torch.from_numpy(feat), R.get_nframes(z["signals_length"]), torch.from_numpy(z["predictions"]),
+                                    z["predictions_length"], W, cfg, True)
+    assert float((plain - logits).abs().max()) > 1e-2  # the masks matter
+
+
+def test_contextnet_stages_match_reference_classes():
+    """encoders/contextnet.py ConvModule.call :74-90, SEModule.call :152-165 (conv first, MASKED average pool, tile / multiply),
+    ConvBlock.call :251-263 (residual add, activation), ContextNetEncoder.call :306-311 - reference classes run over the shims."""
+    from tensorflowasr_amd import configs, params
+
+    z, W = _load("contextnet")
+    cfg = configs.contextnet_tiny()
+    blocks = params.contextnet_modules(cfg)
+    ocfg = R.conformer_config("tiny")
+    feat = R.log_mel(z["signals"], ocfg)
+    flen = R.get_nframes(z["signals_length"])
+    _close(feat, z["train/features"][..., 0], 1e-5)
+    stats = {}
+    x, lens = torch.from_numpy(feat), [int(n) for n in flen]
+    for i, blk in enumerate(blocks):  # block by block (contextnet_ref.encoder_forward's loop body)
+        y, l2 = CN.encoder_forward(x, lens, W, [blk], stats)
+        _close(y, z[f"train/block{i}"])
+        assert l2 == z[f"train/block{i}_length"].tolist()
+        x, lens = y, l2
+        # the squeeze-excite pool received the sequence mask of the block's output lengths; its BatchNorms received none
+        assert np.array_equal(z[f"train/block{i}/pool_mask"].astype(bool), _seqmask(l2, y.shape[1]))
+        assert z[f"train/block{i}/last_conv_bn_mask"].tolist() == [-1] and z[f"train/block{i}/se_conv_bn_mask"].tolist() == [-1]
+    enc, elen = CN.encoder_forward(torch.from_numpy(feat), flen, W, blocks)
+    _close(enc, z["train/encoder"])
+    assert elen == z["train/logits_length"].tolist()
+    # prediction network WITHOUT the LayerNorm (contextnet small.yml.j2: prediction_layer_norm False) and the joint network
+    e = W["pred/emb"][torch.from_numpy(z["predictions"]).long()]
+    pred, _, _ = R.lstm(e, z["predictions_length"], W, "pred/lstm/")
+    _close(R.joint_net(enc, pred, W), z["train/logits"])
+    for k, (mean, var) in stats.items():
+        _close(0.99 * W[k + "/mm"] + 0.01 * mean, z["after_train/" + k + "/mm"], 1e-5)
+        _close(0.99 * W[k + "/mv"] + 0.01 * var, z["after_train/" + k + "/mv"], 1e-5)
