@@ -5,12 +5,16 @@ forward pass, greedy decoding and optimizer arithmetic.  Each function cites the
 follows; `[ext]` marks Keras/TF behaviour restated from the documented defaults because
 TensorFlow/Keras are not installable in this container.
 
-Pinning status: `compute_streaming_mask` is pinned by the reference's own truth tables
-(tests/test_mask.py:6-55); `rel_left_shift`, `compute_sinusoid_position_encoding` and the relative-PE
-roll/mask are pinned by tests/golden/relpe_reference.npz (the reference's own function bodies run over
-oracle/tf_shim).  Everything that bottoms out in Keras layers (Dense/LN/BN/LSTM/conv, tf.signal.stft, the
-mel matrix) is restated from the documented defaults: **parity unpinned** for those (no TF here, the
-reference ships no golden vectors for them).
+Pinning status: the WIRING of every function below - layer order, residual factors, dropout sites, norm positions, the attention
+mask's construction, BatchNorm statistics over every frame - is pinned to the reference's own classes: tests/golden/wiring_conformer*.npz
+hold per-stage outputs of `tensorflow_asr.models.transducer.conformer.Conformer` constructed and run from /root/reference over
+oracle/tf_shim + oracle/keras_shim (oracle/gen_wiring_from_reference.py; checked by tests/test_reference_wiring.py).
+`compute_streaming_mask` is also pinned by the reference's own truth tables (tests/test_mask.py:6-55); `rel_left_shift`,
+`compute_sinusoid_position_encoding`, the relative-PE roll/mask, `_compute_attention`, the greedy loops, the joint / call_next bodies, the
+schedule, the accumulator and the RNN-T / CTC losses by the function-level goldens of oracle/gen_golden_from_reference.py.  What the
+Keras / TF LIBRARY kernels compute (Dense/LN/BN/LSTM/conv, tf.signal.stft, the mel matrix) is [ext]: restated from the documented
+defaults, twice and independently (here with torch, in oracle/keras_shim.py with NumPy - the wiring goldens make the two agree to
+2e-5) and library-checked (tests/test_oracle_library_pins.py); no TensorFlow exists here to execute them.
 
 Weights live in a flat dict name -> torch tensor with the Keras layouts of SURVEY.md A.2.
 """

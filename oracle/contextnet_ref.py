@@ -1,11 +1,15 @@
 """TEST INFRASTRUCTURE ONLY (never imported by the product path): torch-CPU restatement of the reference's ContextNet encoder,
 tensorflow_asr/models/encoders/contextnet.py, used as the parity oracle of tensorflowasr_amd/contextnet.py.
 
-Parity status: PARITY UNPINNED - the layers bottom out in Keras kernels (SeparableConv1D, BatchNormalization,
-GlobalAveragePooling1D, Dense) that cannot be executed here (no TensorFlow); they are restated from their documented
-defaults: causal padding = left pad (K-1), VALID, stride s (convolution.py:25-37 semantics for 1-D);
-BatchNormalization momentum 0.99 / epsilon 1e-3, training-mode batch statistics over every frame (no mask);
-GlobalAveragePooling1D honours the propagated sequence mask (masked mean); swish = x*sigmoid(x).
+Parity status: PINNED to the reference's own classes - tests/golden/wiring_contextnet.npz holds per-block outputs, the masks that
+reached the squeeze-excite pool / the BatchNorms, the moving statistics and the logits of
+`tensorflow_asr.models.transducer.contextnet.ContextNet` CONSTRUCTED and RUN from /root/reference over oracle/tf_shim + oracle/keras_shim
+(oracle/gen_wiring_from_reference.py); tests/test_reference_wiring.py checks this file against it block by block and
+tests/test_reference_wiring_gpu.py checks the HIP path.  What the Keras library layers themselves compute (SeparableConv1D,
+BatchNormalization, GlobalAveragePooling1D, Dense) is [ext], restated twice independently (here with torch, in keras_shim with NumPy):
+causal padding = left pad (K-1), VALID, stride s (convolution.py:25-37 semantics for 1-D); BatchNormalization momentum 0.99 /
+epsilon 1e-3, training-mode batch statistics over every frame (observed: no mask reaches them); GlobalAveragePooling1D honours the
+propagated sequence mask (observed: masked mean); swish = x*sigmoid(x).
 
 Weights: dict name -> tensor with the product's names (params.contextnet_specs):
   {m}/dw [K, Cin] (keras depthwise kernel [K, Cin, 1]), {m}/pw/w [Cin, Cout], {m}/pw/b, {m}/bn/g, {m}/bn/b,

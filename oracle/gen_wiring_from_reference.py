@@ -337,8 +337,92 @@ def gen_contextnet(name, lens, ulens, seed):
               f"{sum(1 for k in out if k.startswith('W/'))} variables")
 
 
+def gen_train_step():
+    """models/base_model.py: the bodies of BaseModel._train_step (:149-183), _apply_gradients (:185-192), train_step (:194-198) and
+    train_step_ga (:200-209) executed with a recording stand-in `self` (the Keras trainer pieces they call - `_compute_loss`, the loss
+    tracker, `optimizer.scale_loss / apply`, `tf.GradientTape` - are [ext]): pins the ORDER of the step - weight noise on, forward in
+    training mode, weight noise off, loss, tracker update with the un-scaled loss, loss scaling, gradients w.r.t. the trainable
+    weights, gradient noise gate, optimizer apply; and the accumulate / gradients + apply + reset split of the GA step."""
+    import types
+
+    from oracle import tf_shim
+
+    with K.reference_runtime() as (tf, keras):
+        events = []
+        ev = lambda *a: events.append(" ".join(str(x) for x in a))
+
+        class Tape:
+            def __enter__(self):
+                ev("tape.enter")
+                return self
+
+            def __exit__(self, *a):
+                ev("tape.exit")
+
+            def watch(self, x):
+                ev("tape.watch", x)
+
+            def gradient(self, loss, wrt):
+                ev("tape.gradient", loss, "wrt", wrt)
+                return "grads"
+
+        tf.GradientTape = Tape
+        tree = types.SimpleNamespace(flatten=lambda x: [np.zeros((5, 3))])
+        loss_module = types.SimpleNamespace(unscale_loss_for_distribution=lambda l: f"unscaled({l})")
+        math_util = types.SimpleNamespace(add_gauss_noise=lambda g, stddev: f"noisy({g},{stddev})")
+        ns = {"tf": tf, "tree": tree, "loss_module": loss_module, "math_util": math_util, "schemas": types.SimpleNamespace(TrainData=object, TrainOutput=object)}
+        fns = tf_shim.extract_functions("tensorflow_asr/models/base_model.py",
+                                        ["BaseModel._train_step", "BaseModel._apply_gradients", "BaseModel.train_step", "BaseModel.train_step_ga"], ns)
+        x = types.SimpleNamespace(inputs="x.inputs")
+        y_pred = types.SimpleNamespace(logits="y_pred.logits")
+
+        def make_self(gradn, iterations):
+            me = types.SimpleNamespace(trainable_weights="trainable_weights", gradn_config=gradn)
+            me.apply_gwn = lambda: (ev("apply_gwn"), "orig")[1]
+            me.remove_gwn = lambda o: ev("remove_gwn", o)
+            me.__call__ = None
+            me.tfasr_compute_loss = lambda **kw: (ev("tfasr_compute_loss training=%s" % kw["training"]), "loss")[1]
+            me._loss_tracker = types.SimpleNamespace(update_state=lambda l, sample_weight=None: ev("loss_tracker.update_state", l, "count", int(np.asarray(sample_weight))))
+            me.optimizer = types.SimpleNamespace(scale_loss=lambda l: (ev("optimizer.scale_loss", l), f"scaled({l})")[1], iterations=iterations,
+                                                 apply=lambda g, w: ev("optimizer.apply", g, w))
+            me.get_metrics_result = lambda: "metrics"
+            me.ga = types.SimpleNamespace(accumulate=lambda g, w: ev("ga.accumulate", g), gradients=lambda g, w: (ev("ga.gradients", g), "ga_grads")[1],
+                                          reset=lambda: ev("ga.reset"))
+            me._train_step = lambda data: fns["BaseModel._train_step"](me, data)
+            me._apply_gradients = lambda g: fns["BaseModel._apply_gradients"](me, g)
+            return me
+
+        class Callable(types.SimpleNamespace):
+            def __call__(self, inp, training=False):
+                ev(f"forward training={training}")
+                return y_pred
+
+        out = {}
+        for name, gradn, it in (("plain", None, 0), ("gradn_before", {"step": 10, "stddev": 0.5}, 3), ("gradn_after", {"step": 10, "stddev": 0.5}, 10)):
+            del events[:]
+            me = make_self(gradn, it)
+            me2 = Callable(**vars(me))
+            me2._train_step = lambda data, me2=me2: fns["BaseModel._train_step"](me2, data)
+            me2._apply_gradients = lambda g, me2=me2: fns["BaseModel._apply_gradients"](me2, g)
+            res = fns["BaseModel.train_step"](me2, (x, "y"))
+            assert res == "metrics"
+            out[f"train_step_{name}"] = np.asarray(list(events))
+        for name, do_apply in (("accumulate", None), ("apply", True)):
+            del events[:]
+            me = make_self(None, 0)
+            me2 = Callable(**vars(me))
+            me2._train_step = lambda data, me2=me2: fns["BaseModel._train_step"](me2, data)
+            me2._apply_gradients = lambda g, me2=me2: fns["BaseModel._apply_gradients"](me2, g)
+            fns["BaseModel.train_step_ga"](me2, (x, "y"), do_apply)
+            out[f"train_step_ga_{name}"] = np.asarray(list(events))
+        np.savez_compressed(os.path.join(OUT, "wiring_train_step.npz"), **out)
+        for k, v in out.items():
+            print(k, list(v))
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
+    gen_train_step()
     # ragged batches: T0 = ceil(n / 160) frames, T' = ceil(ceil(T0 / 2) / 2)
     gen_conformer("conformer", "transducer/conformer/small", [9000, 5500, 2100], [6, 3, 5], seed=71, dropout=0.0)
     gen_conformer("conformer_dropout", "transducer/conformer/small", [4000, 2500, 1300], [6, 3, 5], seed=72, dropout=0.1)

@@ -187,12 +187,18 @@ class BaseModel:
         self.ps.refresh_shadow()
 
     def _gradient_noise(self):
-        """math_util.add_gauss_noise on every gradient once optimizer.iterations >= gradn_config["step"] (base_model.py:185-191)."""
+        """math_util.add_gauss_noise on every gradient once optimizer.iterations >= gradn_config["step"] (base_model.py:185-191; order
+        pinned by tests/golden/wiring_train_step.npz: after the GA average, BEFORE `optimizer.apply`, whose cross-replica SUM then adds
+        the replicas' independent draws).  This runs after the gradient all-reduce (the bucketed exchange overlaps the backward), so
+        every rank adds the SAME draw - the seed carries no rank - of the sum of `world` independent N(0, stddev) draws, i.e.
+        N(0, stddev * sqrt(world)): the replicas' parameters stay bit-identical and the update has the reference's
+        distribution."""
         g = self.gradn_config
         if not g or self.step < int(g["step"]):
             return
         self._gradn_epoch = getattr(self, "_gradn_epoch", 0) + 1
-        K.gauss_noise(self.ps.grad, float(g["stddev"]), self._gradn_epoch * 7_368_787 + 5 + ((int(self.dp.rank) & 0x7F) << 48))
+        world = max(1, int(getattr(self.dp, "world", 1)))
+        K.gauss_noise(self.ps.grad, float(g["stddev"]) * math.sqrt(world), self._gradn_epoch * 7_368_787 + 5)
         self.ps.rezero_pads(self.ps.grad)
 
     # ----------------------------------------------------------------------------------------------- steps

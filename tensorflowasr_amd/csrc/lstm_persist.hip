@@ -14,7 +14,9 @@
 // gate q), dh / dc carries in registers.  Per step: gather dz_{t+1} [B, 4P] (published by all workgroups) straight into MFMA A
 // fragments, dhr = dz_{t+1} R^T for the owned units (4 partial k ranges summed through LDS), cell backward, publish dz_t.
 // Every spin is bounded by the wall clock; a timeout raises a flag (second word of the caller's 64-byte `sync` record) that makes every
-// workgroup leave: wrong results, no hang; the caller can check the word after a stream synchronisation.
+// workgroup leave - after overwriting what it owns of the remaining steps with NaN (no hang, and no silently wrong result: the step's loss /
+// gradients are NaN); the caller can also check the word after a stream synchronisation.  The launch itself is refused unless the whole
+// grid can be resident at once (`grid_fits`).
 // Measured (B = 32, U1 = 111, P = 640): 8.7 us per forward step, 13.4 us per backward step - the hand-off itself (drain of the
 // write-through stores, 40 arrivals on one counter, poll, acquire, re-load of the exchanged vector), not the loads' issue order:
 // batching every load of a step in front of its first use changed nothing.
@@ -69,6 +71,14 @@ __device__ __forceinline__ void ld2(const bf16_t* p, float& lo, float& hi) {
   const unsigned v = *reinterpret_cast<const unsigned*>(p);
   lo = __uint_as_float(v << 16);
   hi = __uint_as_float(v & 0xffff0000u);
+}
+
+// A timed-out / aborted launch must not pass for a result: the leaving workgroup overwrites what it owns of the REMAINING
+// steps with NaN, so the loss / the gradients of that step are NaN (what the reference's TerminateOnNaN watches) - no host read needed.
+__device__ __forceinline__ void poison_rows(bf16_t* base, long row_stride, long step_stride, int t_lo, int t_hi, int B, int col0, int width) {
+  for (int t = t_lo; t < t_hi; ++t)
+    for (int i = threadIdx.x; i < B * width; i += blockDim.x)
+      base[(long)(i / width) * row_stride + (long)t * step_stride + col0 + i % width] = (bf16_t)0x7FC0;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -126,7 +136,11 @@ __global__ __launch_bounds__(256) void lstm_persist_fwd_kernel(
         if (in) ld2(xg + ((long)b * U1 + t) * 4 * P + q * P + u0 + u, xz[i][q][0], xz[i][q][1]);
       }
     }
-    if (t > 0 && !wait_count(sync, (unsigned)nwg * (unsigned)t)) return;
+    if (t > 0 && !wait_count(sync, (unsigned)nwg * (unsigned)t)) {
+      poison_rows(hseq, (long)U1 * P, P, t, U1, B, u0, PW);
+      if (yseq) poison_rows(yseq, (long)U1 * P, P, t, U1, B, u0, PW);
+      return;
+    }
     // stage h_{t-1} [Bp][P] (rows >= B: zeros): every load of the tile is issued before the first LDS store, so the step pays ONE
     // memory round trip here, not one per 4 KiB
     const int chunks = P / 8;  // 16-B chunks per row
@@ -261,7 +275,10 @@ __global__ __launch_bounds__(256) void lstm_persist_bwd_kernel(
 #pragma unroll
     for (int i = 0; i < NIT; ++i) dhr[i][0] = dhr[i][1] = 0.f;
     if (t < U1 - 1) {
-      if (!wait_count(sync, (unsigned)nwg * (unsigned)(U1 - 1 - t))) return;
+      if (!wait_count(sync, (unsigned)nwg * (unsigned)(U1 - 1 - t))) {
+        for (int q = 0; q < 4; ++q) poison_rows(dz, (long)U1 * 4 * P, 4 * P, 0, t + 1, B, q * P + u0, PW);
+        return;
+      }
       // dhr = dz_{t+1} @ R^T for the owned units: this wave's k range = gate w's columns of dz
       float4_t acc[MT];
 #pragma unroll
@@ -349,6 +366,22 @@ __global__ __launch_bounds__(256) void lstm_persist_bwd_kernel(
 
 bool persist_ok(int B, int P, int dtype) { return dtype == TFASR_BF16 && B >= 1 && B <= 64 && P % 32 == 0 && P >= 32 && P <= 32 * MAXKS; }
 
+// The workgroups of a launch wait for each other, so ALL of them must be resident at once (an ordinary launch gives no such promise):
+// the launch is refused (UNSUPPORTED -> the caller's per-step kernels) unless resident-blocks-per-CU x CUs covers the grid.
+template <typename KERNEL>
+bool grid_fits(KERNEL kernel, int grid, size_t smem) {
+  static thread_local size_t c_smem = ~(size_t)0;  // one query per (kernel instance, LDS size) and thread, not per launch
+  static thread_local int c_grid = 0, c_ok = 0;
+  if (c_smem == smem && c_grid == grid) return c_ok != 0;
+  c_smem = smem; c_grid = grid; c_ok = 0;
+  int dev = 0, cus = 0, per_cu = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return false;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, smem) != hipSuccess) return false;
+  c_ok = (long)per_cu * cus >= grid ? 1 : 0;
+  return c_ok != 0;
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -364,12 +397,15 @@ extern "C" int tfasr_lstm_persist_fwd(const void* xg, const void* rk, const void
   if (!xg || !rk || !gates || !cseq || !hseq || !sync || B <= 0 || U1 <= 0 || P <= 0) return TFASR_STATUS_INVALID_VALUE;
   if (!persist_ok(B, P, dtype)) return TFASR_STATUS_UNSUPPORTED;
   hipStream_t s = (hipStream_t)stream_;
-  if (hipMemsetAsync(sync, 0, sizeof(Sync), s) != hipSuccess) return TFASR_STATUS_EXECUTION_FAILED;
   const int MT = (B + 15) / 16, Bp = MT * 16;
   const size_t smem = (size_t)Bp * (P * 2 + 16) + (size_t)4 * Bp * PW * 4;
   const dim3 grid(P / PW);
 #define TFASR_LAUNCH(M) hipLaunchKernelGGL(lstm_persist_fwd_kernel<M>, grid, dim3(256), smem, s, (const bf16_t*)xg, (const bf16_t*)rk, (const bf16_t*)h0, \
                                            h0_stride_b, c0, c0_stride_b, lengths, (bf16_t*)gates, cseq, (bf16_t*)hseq, (bf16_t*)yseq, B, U1, P, (Sync*)sync)
+  const bool fits = MT == 1 ? grid_fits(lstm_persist_fwd_kernel<1>, grid.x, smem) : MT == 2 ? grid_fits(lstm_persist_fwd_kernel<2>, grid.x, smem)
+                    : MT == 3 ? grid_fits(lstm_persist_fwd_kernel<3>, grid.x, smem) : grid_fits(lstm_persist_fwd_kernel<4>, grid.x, smem);
+  if (!fits) { (void)hipGetLastError(); return TFASR_STATUS_UNSUPPORTED; }
+  if (hipMemsetAsync(sync, 0, sizeof(Sync), s) != hipSuccess) return TFASR_STATUS_EXECUTION_FAILED;
   switch (MT) { case 1: TFASR_LAUNCH(1); break; case 2: TFASR_LAUNCH(2); break; case 3: TFASR_LAUNCH(3); break; default: TFASR_LAUNCH(4); }
 #undef TFASR_LAUNCH
   TFASR_CHECK_LAUNCH();
@@ -381,12 +417,15 @@ extern "C" int tfasr_lstm_persist_bwd(const void* dy, const void* rk, const void
   if (!dy || !rk || !gates || !cseq || !dz || !dh_carry || !dc_carry || !sync || B <= 0 || U1 <= 0 || P <= 0) return TFASR_STATUS_INVALID_VALUE;
   if (!persist_ok(B, P, dtype)) return TFASR_STATUS_UNSUPPORTED;
   hipStream_t s = (hipStream_t)stream_;
-  if (hipMemsetAsync(sync, 0, sizeof(Sync), s) != hipSuccess) return TFASR_STATUS_EXECUTION_FAILED;
   const int MT = (B + 15) / 16, Bp = MT * 16;
   const size_t smem = (size_t)4 * Bp * PW * 4;
   const dim3 grid(P / PW);
 #define TFASR_LAUNCH(M) hipLaunchKernelGGL(lstm_persist_bwd_kernel<M>, grid, dim3(256), smem, s, (const bf16_t*)dy, (const bf16_t*)rk, (const bf16_t*)gates, cseq, \
                                            lengths, (bf16_t*)dz, dh_carry, dc_carry, B, U1, P, (Sync*)sync)
+  const bool fits = MT == 1 ? grid_fits(lstm_persist_bwd_kernel<1>, grid.x, smem) : MT == 2 ? grid_fits(lstm_persist_bwd_kernel<2>, grid.x, smem)
+                    : MT == 3 ? grid_fits(lstm_persist_bwd_kernel<3>, grid.x, smem) : grid_fits(lstm_persist_bwd_kernel<4>, grid.x, smem);
+  if (!fits) { (void)hipGetLastError(); return TFASR_STATUS_UNSUPPORTED; }
+  if (hipMemsetAsync(sync, 0, sizeof(Sync), s) != hipSuccess) return TFASR_STATUS_EXECUTION_FAILED;
   switch (MT) { case 1: TFASR_LAUNCH(1); break; case 2: TFASR_LAUNCH(2); break; case 3: TFASR_LAUNCH(3); break; default: TFASR_LAUNCH(4); }
 #undef TFASR_LAUNCH
   TFASR_CHECK_LAUNCH();

@@ -142,3 +142,49 @@ def test_two_ranks_with_gradient_accumulation_match_single_process(dev, tmp_path
     for o in outs:
         np.testing.assert_allclose(o["grad"].numpy(), g, rtol=tol, atol=tol * float(np.abs(g).max()))
         np.testing.assert_allclose(o["flat"].numpy(), model.ps.flat.cpu().numpy(), rtol=0, atol=5e-5)
+
+
+def _worker_gradn(rank, world, port, outdir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from tensorflowasr_amd import configs, dp
+    from tensorflowasr_amd.conformer import ConformerTransducer
+
+    torch.cuda.set_device(0)
+    d = dp.init_from_env(backend="gloo")
+    cfg = configs.conformer_tiny(dropout=0.0)
+    model = ConformerTransducer(cfg, torch.device("cuda", 0), dtype=torch.float32, seed=5, dp=d)
+    d.attach(model.ps.grad)
+    model.gradn_config = {"step": 0, "stddev": 0.05}
+    model.optimizer["schedule"] = 1e-3
+    lo, hi = dp.shard_bounds(len(LENS), world, rank)
+    make = _batch(cfg, LENS, ULENS)
+    for _ in range(2):
+        model.train_step(make(lo, hi), masks=(None, None))
+    torch.cuda.synchronize()
+    torch.save(dict(flat=model.ps.flat.cpu(), grad=model.ps.grad.cpu()), os.path.join(outdir, f"gn{rank}.pt"))
+    d.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_gradient_noise_keeps_replicas_identical(dev, tmp_path):
+    """gradn_config with world > 1: the noise is added after the all-reduce with a rank-free seed (the sum of the replicas'
+    independent draws of the reference, base_model.py:185-192, in one N(0, stddev * sqrt(world)) draw), so the parameters of the
+    replicas stay BIT-identical - and the noise really is there (the gradient differs from the noise-free one by ~stddev*sqrt(2))."""
+    world = 2
+    mp.spawn(_worker_gradn, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    a, b = (torch.load(os.path.join(tmp_path, f"gn{r}.pt")) for r in range(world))
+    assert torch.equal(a["flat"], b["flat"]) and torch.equal(a["grad"], b["grad"])
+    from tensorflowasr_amd import configs
+    from tensorflowasr_amd.conformer import ConformerTransducer
+
+    cfg = configs.conformer_tiny(dropout=0.0)
+    model = ConformerTransducer(cfg, dev, dtype=torch.float32, seed=5)
+    model.optimizer["schedule"] = 1e-3
+    make = _batch(cfg, LENS, ULENS)
+    for _ in range(2):
+        model.train_step(make(0, len(LENS)), masks=(None, None))
+    torch.cuda.synchronize()
+    diff = (a["grad"] - model.ps.grad.cpu())
+    live = model.ps.grad.cpu() != 0
+    sd = float(diff[live].std())
+    assert 0.05 * 2 ** 0.5 * 0.8 < sd < 0.05 * 2 ** 0.5 * 1.2, sd

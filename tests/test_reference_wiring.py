@@ -183,3 +183,20 @@ def test_contextnet_stages_match_reference_classes():
     for k, (mean, var) in stats.items():
         _close(0.99 * W[k + "/mm"] + 0.01 * mean, z["after_train/" + k + "/mm"], 1e-5)
         _close(0.99 * W[k + "/mv"] + 0.01 * var, z["after_train/" + k + "/mv"], 1e-5)
+
+
+def test_train_step_order_of_the_reference_bodies():
+    """BaseModel._train_step / _apply_gradients / train_step / train_step_ga (base_model.py:149-209) run with a recording `self`:
+    weight noise ON -> forward(training=True) -> weight noise OFF -> loss -> tracker (un-scaled loss, count = batch) -> scale_loss ->
+    gradients w.r.t. the trainable weights -> [gradient noise once iterations >= gradn step, BEFORE optimizer.apply = before the
+    cross-replica sum] -> optimizer.apply; GA: accumulate, or gradients -> apply -> reset.  The product's train_step follows this
+    order (conformer.train_step / apply_gradients; the noise is added after the all-reduce as ONE draw of the replicas' sum)."""
+    z = np.load(os.path.join(GOLD, "wiring_train_step.npz"))
+    core = ["tape.enter", "tape.watch x.inputs", "apply_gwn", "forward training=True", "tape.watch y_pred.logits", "remove_gwn orig",
+            "tfasr_compute_loss training=True", "loss_tracker.update_state unscaled(loss) count 5", "optimizer.scale_loss loss", "tape.exit",
+            "tape.gradient scaled(loss) wrt trainable_weights"]
+    assert z["train_step_plain"].tolist() == core + ["optimizer.apply grads trainable_weights"]
+    assert z["train_step_gradn_before"].tolist() == core + ["optimizer.apply grads trainable_weights"]
+    assert z["train_step_gradn_after"].tolist() == core + ["optimizer.apply noisy(grads,0.5) trainable_weights"]
+    assert z["train_step_ga_accumulate"].tolist() == core + ["ga.accumulate grads"]
+    assert z["train_step_ga_apply"].tolist() == core + ["ga.gradients grads", "optimizer.apply ga_grads trainable_weights", "ga.reset"]
