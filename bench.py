@@ -99,6 +99,63 @@ def step_matmul_flops(cfg, batch):
     return 2.0 * 3.0 * (enc + pred + joint)
 
 
+def step_useful_flops(cfg, batch):
+    """step_matmul_flops without the padding: every encoder product counted over the REAL frames of each utterance only
+    (rows = sum_b T'_b, attention = sum_b T'_b^2) - what an implementation free to skip padded frames would have to do.  The
+    reference (and this path) DOES compute the padded frames: they enter the BatchNorm moments and are attended to as keys."""
+    nsamp = np.asarray(batch["nsamp"], np.int64)
+    B = len(nsamp)
+    t2 = -(-(-(-(-(-nsamp // cfg.frame_step)) // 2)) // 2)
+    F2 = -(-(-(-cfg.num_feature_bins // 2)) // 2)
+    rows = int(t2.sum())
+    d, C, H, dh, J, V, P, E = cfg.dmodel, cfg.filters, cfg.num_heads, cfg.head_size, cfg.joint_dim, cfg.vocab_size, cfg.rnn_units, cfg.embed_dim
+    enc_block = rows * (2 * (2 * d * 4 * d) + d * 3 * H * dh + H * dh * d + d * 2 * d + d * d) + 2 * int(t2.max()) * H * dh * d
+    attn = int((t2 * t2).sum()) * H * dh * 3
+    enc = cfg.num_blocks * (enc_block + attn) + rows * F2 * 9 * C * C + rows * F2 * C * d
+    ul = np.asarray(batch["ulen"], np.int64)
+    tl = np.minimum(np.maximum(t2, ul), int(t2.max()))
+    cells = int((tl * (ul + 1)).sum())
+    pred = int((ul + 1).sum()) * (E * 4 * P + P * 4 * P)
+    joint = rows * d * J + int((ul + 1).sum()) * P * J + cells * J * V
+    return 2.0 * 3.0 * (enc + pred + joint)
+
+
+def wgrad_group_roofline(cfg, rows, dev, iters=20):
+    """`roofline_by_time`: the kernel family with the largest share of the step's kernel time (profiles/r0*_step*_kernel_stats: the
+    grouped weight gradients of a Conformer block, one launch per block and phase).  The launch sits inside the native block
+    executor, out of reach of host-side events, so it is measured right after the timed region, in isolation, on the step's own
+    shapes (the 8 Dense-layer products of one block over `rows` = B x T' rows; labelled as such)."""
+    from tensorflowasr_amd import kernels as K
+
+    d, H, dh = cfg.dmodel, cfg.num_heads, max(cfg.head_size, 64)
+    f = cfg.ffm_scale * d
+    shapes = [(d, f), (f, d), (d, f), (f, d), (d, 3 * H * dh), (H * dh, d), (d, 2 * d), (d, d)]
+    g = torch.Generator().manual_seed(0)
+    xs = [(torch.randn(rows, m, generator=g) * 0.1).to(dev).to(torch.bfloat16) for m, n in shapes]
+    dys = [(torch.randn(rows, n, generator=g) * 0.1).to(dev).to(torch.bfloat16) for m, n in shapes]
+    outs = [torch.zeros(m, n, device=dev) for m, n in shapes]
+    bs = [torch.zeros(n, device=dev) for m, n in shapes]
+    calls = [dict(A=xs[i], B=dys[i], out=outs[i], M=shapes[i][0], N=shapes[i][1], K=rows, lda=shapes[i][0], ldb=shapes[i][1], ldd=shapes[i][1],
+                  trans_a=True, accumulate=True, split_k=8, colsum=bs[i]) for i in range(len(shapes))]
+    for _ in range(3):
+        K.gemm_group(calls)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        K.gemm_group(calls)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    fl = sum(2.0 * rows * m * n for m, n in shapes)
+    by = sum((rows * (m + n)) * 2.0 + m * n * 4.0 for m, n in shapes)
+    ach = fl / (ms * 1e-3) / 1e12
+    return {"kernel": "wgrad_group_kernel (the 8 Dense-layer weight gradients of one Conformer block, one grouped launch)", "bound": "mfma",
+            "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
+            "ms_per_launch": round(ms, 4), "rows": rows, "algorithmic_bytes": by, "hbm_frac": round(by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+            "how": "isolated launches on the step's shapes right after the timed region (the launch itself sits inside the native block executor)"}
+
+
 def pmc_traffic(flops_per_launch, J, V):
     """HBM bytes per launch of the joint vocabulary GEMM from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE,
     profiles/r01_pmc_traffic.json, collected on this same command).  PMC counters cannot be read inside a timed run, so
@@ -172,7 +229,7 @@ def cpu_baseline_worker(size, vocab):
         step(n + 1)
         n += 1
     dt = (time.perf_counter() - t0) / n
-    return dict(value=(secs_total / 3600.0) / dt, unit="audio-hours/sec", cores=cores, kind="port",
+    return dict(value=(secs_total / 3600.0) / dt, unit="audio-hours/sec", cores=cores, kind="port", batch=B,
                 sample=f"oracle (torch-CPU fp32 restatement of tensorflow_asr; TF unavailable) full train step, Conformer-{ocfg['dmodel']}d, the first "
                        f"{B} utterances of the GPU line's first batch (same generator and seed: {secs_total:.1f} s of audio, padded to {N / 16000.0:.1f} s, "
                        f"U<={U}), {n} timed steps, {dt:.2f} s/step, {cores} threads")
@@ -481,6 +538,8 @@ def main():
                 sf = float(np.mean([step_matmul_flops(cfg, batches[i % nb]) for i in range(args.steps)]))
                 roof["step_matmul_tflops"] = round(sf / (ms_per_step * 1e-3) / 1e12, 1)
                 roof["step_frac"] = round(sf / (ms_per_step * 1e-3) / 1e12 / peak, 4)
+                uf = float(np.mean([step_useful_flops(cfg, batches[i % nb]) for i in range(args.steps)]))
+                roof["useful_step_frac"] = round(uf / (ms_per_step * 1e-3) / 1e12 / peak, 4)  # padded encoder frames not counted
         # RNN-T loss kernels (statistics finalize + alpha/beta lattice + gradient) against the HBM roofline: algorithmic bytes =
         # cells x V x (logit + gradient), time = HIP events around exactly those launches in the timed region
         roof_rnnt = None
@@ -505,6 +564,13 @@ def main():
             "roofline": roof,
             "roofline_rnnt": roof_rnnt,
         }
+        if not stub and args.model in ("M", "S") and dtype == torch.bfloat16 and not args.no_extras:
+            try:
+                nsm = np.asarray(batches[0]["nsamp"], np.int64)
+                rows_b = args.batch * int(-(-(-(-(-(-int(nsm.max()) // cfg.frame_step)) // 2)) // 2))
+                out["roofline_by_time"] = wgrad_group_roofline(cfg, rows_b, dev)
+            except Exception as e:
+                out["roofline_by_time"] = {"value": None, "error": repr(e)[:200]}
         if world == 1 and not args.no_extras and args.model == "M" and args.padding == "batch" and size == "LibriSpeech-shaped":
             # BASELINE.md section 2 "report both": the same step with the reference's dataset-maximum padding (every utterance padded
             # to 475 760 samples / 230 labels, datasets.py:342-365).  The packed lattice and the length-aware kernels make the

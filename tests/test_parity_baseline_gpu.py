@@ -105,7 +105,7 @@ def test_conformer_s_16_blocks_10s_loss_and_gradients_vs_oracle(dev):
         torch.cuda.empty_cache()
     assert out[torch.float32][0] < 1e-4 and out[torch.float32][1] < 2e-3, out
     assert out[torch.bfloat16][0] < 1e-3, out  # BASELINE.json: RNN-T loss within 1e-3 relative
-    assert out[torch.bfloat16][1] < 6e-2, out
+    assert out[torch.bfloat16][1] < 2e-2, out
 
 
 # --------------------------------------------------------------------------------------------- BASELINE configs[2] dimensions
@@ -132,7 +132,7 @@ def test_conformer_m_dims_ragged_bf16_fused_path_vs_oracle(dev, case):
     gl2 = _grad_rel_l2(model, ref_grads)
     print(f"[g1]   gradient relative L2 error over all variables: {gl2:.3e}")
     assert rel.max() < 1e-3, rel
-    assert gl2 < 6e-2, gl2
+    assert gl2 < 2e-2, gl2
     # the f32 parity mode of the same model (different kernels: exact-f32 MFMA GEMMs, unfused attention) on the same input
     cfg, ocfg, model32, W, data, *_ = _make(dev, "M", torch.float32, nsamp, ulens, U, blocks=blocks)
     model32.zero_grad()
