@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define TFASR_ABI_VERSION 23
+#define TFASR_ABI_VERSION 24
 
 typedef enum {
   TFASR_STATUS_SUCCESS = 0,
@@ -180,6 +180,16 @@ int tfasr_gemm_group(const tfasr_gemm_args* args, int n, void* stream);
  * ---------------------------------------------------------------------------------------------- */
 int tfasr_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
                         long rows, int C, float eps, int dtype, void* stream);
+/* FFModule.call forward in ONE launch (tensorflow_asr/models/encoders/conformer.py:101-109 + models/layers/residual.py:58-62):
+ *     y = x + res_factor * dropout2( dropout1( swish( LN(x) W1 + b1 ) ) W2 + b2 )
+ * x, y, ln [rows, d]; W1 [d, F], W2 [F, d] (row-major, compute dtype); gamma / beta / b1 / b2 f32.  Saved for the backward exactly as
+ * the three-launch route (tfasr_layernorm_fwd + two tfasr_gemm) writes them: ln = LN(x), mean / rstd [rows], z = LN(x) W1 + b1 (may be
+ * NULL: not saved), h = dropout1(swish(z)) (may be NULL), same dropout hash and element indices (seed1 on [rows, F], seed2 on [rows, d]).
+ * The F-wide hidden activation is never a GEMM operand in HBM.  TFASR_STATUS_UNSUPPORTED outside bf16 / d = 256 / F % 64 == 0 /
+ * 16-byte aligned pointers (the caller then takes the three-launch route). */
+int tfasr_ffn_fused_fwd(const void* x, const float* gamma, const float* beta, const void* W1, const float* b1, const void* W2,
+                        const float* b2, void* y, void* ln, float* mean, float* rstd, void* z, void* h, long rows, int d, int F,
+                        float ln_eps, float res_factor, float drop_p, long drop_seed1, long drop_seed2, int dtype, void* stream);
 int tfasr_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
                         const void* add, void* dx, float* dgamma, float* dbeta, long rows, int C, int dtype,
                         void* stream);

@@ -150,7 +150,7 @@ def load(build_if_missing=True):
     return lib
 
 
-ABI_VERSION = 23
+ABI_VERSION = 24
 
 
 STATUS_UNSUPPORTED = 3

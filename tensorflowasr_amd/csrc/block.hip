@@ -281,6 +281,13 @@ struct Ex {
     k->ff_rstd[m] = f32(stash, rows);
     k->ff_z[m] = c->save ? act(stash, rows * F) : nullptr;
     k->ff_h[m] = act(stash, rows * F);
+    if (!dry) {  // one launch where the shape allows it (ffn_fused.h); UNSUPPORTED -> the three launches below
+      const int fst = tfasr_ffn_fused_fwd(x, fp(b0), fp(b0 + 1), wp(b0 + 2), fp(b0 + 3), wp(b0 + 4), fp(b0 + 5), y, k->ff_ln[m], k->ff_mean[m], k->ff_rstd[m],
+                                          k->ff_z[m], k->ff_h[m], rows, d, F, c->ln_eps, c->ffm_res, drop_p(), seed(site), seed(site + 1), c->dtype, s);
+      if (fst != TFASR_STATUS_UNSUPPORTED) { chk(fst); return; }
+    } else if (c->dtype == TFASR_BF16 && d == 256 && (F % 64) == 0) {
+      return;  // (sizing run: the fused launch needs no scratch)
+    }
     ln_fwd(x, b0, b0 + 1, k->ff_ln[m], k->ff_mean[m], k->ff_rstd[m]);
     G a; a.act = TFASR_ACT_SWISH; a.prez = k->ff_z[m]; a.drop_p = drop_p(); a.drop_seed = seed(site);
     dense(k->ff_ln[m], b0 + 2, b0 + 3, k->ff_h[m], d, F, a);

@@ -1028,6 +1028,7 @@ int launch_epi(const tfasr_gemm_args& a, dim3 tiles, hipStream_t stream) {
 }
 
 #include "gemm_big.h"
+#include "ffn_fused.h"
 
 template <bool TA, bool TB>
 int launch_one(const tfasr_gemm_args& a, hipStream_t stream) {
@@ -1244,4 +1245,38 @@ int tfasr_gemm_fast_try(const tfasr_gemm_args& a, hipStream_t stream) {
   if (a.K < 8) return TFASR_STATUS_UNSUPPORTED;
   if (a.trans_a) return a.trans_b ? launch_one<true, true>(a, stream) : launch_one<true, false>(a, stream);
   return a.trans_b ? launch_one<false, true>(a, stream) : launch_one<false, false>(a, stream);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// FFModule forward in one launch (ffn_fused.h).  UNSUPPORTED outside its shape range: the caller keeps the three-launch route.
+extern "C" int tfasr_ffn_fused_fwd(const void* x, const float* gamma, const float* beta, const void* W1, const float* b1, const void* W2,
+                                   const float* b2, void* y, void* ln, float* mean, float* rstd, void* z, void* h, long rows, int d, int F,
+                                   float ln_eps, float res_factor, float drop_p, long drop_seed1, long drop_seed2, int dtype, void* stream) {
+  if (!x || !gamma || !beta || !W1 || !b1 || !W2 || !b2 || !y || !ln || !mean || !rstd || rows <= 0 || d <= 0 || F <= 0) return TFASR_STATUS_INVALID_VALUE;
+  if (!(drop_p >= 0.f && drop_p < 1.f)) return TFASR_STATUS_INVALID_VALUE;
+  static const bool off = getenv("TFASR_FFN_FUSED") && getenv("TFASR_FFN_FUSED")[0] == '0';
+  if (off || dtype != TFASR_BF16 || d != 256 || (F % 64) != 0 || F > 1024 || F < 128 || rows * (long)F >= (1L << 40)) return TFASR_STATUS_UNSUPPORTED;
+  const uintptr_t al = (uintptr_t)x | (uintptr_t)W1 | (uintptr_t)W2 | (uintptr_t)y | (uintptr_t)ln | (uintptr_t)z | (uintptr_t)h | (uintptr_t)gamma | (uintptr_t)beta;
+  if (al & 15) return TFASR_STATUS_UNSUPPORTED;
+  FfnArgs a;
+  a.x = (const bf16_t*)x; a.gamma = gamma; a.beta = beta; a.W1 = (const bf16_t*)W1; a.b1 = b1; a.W2 = (const bf16_t*)W2; a.b2 = b2;
+  a.y = (bf16_t*)y; a.ln = (bf16_t*)ln; a.mean = mean; a.rstd = rstd; a.z = (bf16_t*)z; a.h = (bf16_t*)h;
+  a.rows = rows; a.F = F; a.eps = ln_eps; a.res = res_factor; a.drop_p = drop_p; a.seed1 = drop_seed1; a.seed2 = drop_seed2;
+  a.dbg = nullptr;
+#ifdef TFASR_FFN_TIMING
+  static long long* dbg_buf = nullptr;  // probe builds only (tools/hwprobe): 8 cycle sums of workgroup 0, printed by the caller via TFASR_FFN_DBG_DUMP
+  if (!dbg_buf && hipMalloc((void**)&dbg_buf, 64) != hipSuccess) dbg_buf = nullptr;
+  a.dbg = dbg_buf;
+#endif
+  const int st = launch_ffn_fused_fwd(a, (hipStream_t)stream);
+#ifdef TFASR_FFN_TIMING
+  if (getenv("TFASR_FFN_DBG_DUMP") && dbg_buf) {
+    long long h[8];
+    if (hipStreamSynchronize((hipStream_t)stream) == hipSuccess && hipMemcpy(h, dbg_buf, 64, hipMemcpyDeviceToHost) == hipSuccess)
+      fprintf(stderr, "[ffn_timing] prologue %lld | per-kernel sums: wait+barrier %lld dma-issue %lld gemm1 %lld z->lds %lld rowpass %lld gemm2 %lld | epilogue %lld\n",
+              h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
+  }
+#endif
+  TFASR_CHECK_LAUNCH();
+  return st;
 }

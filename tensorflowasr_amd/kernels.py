@@ -227,6 +227,24 @@ def layernorm_fwd(x, gamma, beta, eps=1e-3, save_stats=True):
     return y, mean, rstd
 
 
+def ffn_fused_fwd(x, gamma, beta, W1, b1, W2, b2, res_factor, drop_p=0.0, seed1=0, seed2=0, save_z=True, eps=1e-3):
+    """tfasr_ffn_fused_fwd: FFModule forward in one launch.  Returns (y, ln, mean, rstd, z, h), or None when the shape is outside the fused
+    kernel's range (the caller keeps the layernorm + two GEMM route)."""
+    rows, d = x.shape
+    F = W1.shape[1]
+    y, ln = torch.empty_like(x), torch.empty_like(x)
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    z = torch.empty(rows, F, dtype=x.dtype, device=x.device) if save_z else None
+    h = torch.empty(rows, F, dtype=x.dtype, device=x.device)
+    st = _L().tfasr_ffn_fused_fwd(_p(x), _p(gamma), _p(beta), _p(W1), _p(b1), _p(W2), _p(b2), _p(y), _p(ln), _p(mean), _p(rstd), _pv(z), _p(h),
+                                  rows, d, F, eps, float(res_factor), float(drop_p), int(seed1), int(seed2), _dt(x), _stream())
+    if st == _lib.STATUS_UNSUPPORTED:
+        return None
+    check(st, "ffn_fused_fwd")
+    return y, ln, mean, rstd, z, h
+
+
 def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, add=None, dx=None, dropped=None, drop_p=0.0, drop_seed=0):
     """dropped (optional, same shape as dx): also receives dropout(dx, drop_p, drop_seed) from the same kernel."""
     rows, C = x.numel() // x.shape[-1], x.shape[-1]
