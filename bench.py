@@ -289,6 +289,26 @@ def bench_decode(args, model, cfg, dev):
             out = model.recognize(inp, precision=prec)
         torch.cuda.synchronize()
         res[prec] = ((time.perf_counter() - t0) / args.steps, int((out.tokens != 0).sum().item()))
+    # breakdown of the token-exact mode: front end + encoder vs the greedy search, HIP events around each half
+    twin = model.inference_twin() if model.dtype != torch.float32 else model
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    enc_ms = srch_ms = 0.0
+    nrep = max(3, min(args.steps, 10))
+    for _ in range(nrep):
+        ev[0].record()
+        enc, elen = twin.encode(inp.inputs, inp.inputs_length)
+        ev[1].record()
+        twin.recognize_encoded(enc, elen)
+        ev[2].record()
+        torch.cuda.synchronize()
+        enc_ms += ev[0].elapsed_time(ev[1]) / nrep
+        srch_ms += ev[1].elapsed_time(ev[2]) / nrep
+    T_enc = int(enc.shape[1])
+    # encoder flop of the f32 twin (same formula as the train step's forward share) against the exact-f32 MFMA peak
+    d, C, H, dh, F2 = cfg.dmodel, cfg.filters, cfg.num_heads, cfg.head_size, -(-(-(-cfg.num_feature_bins // 2)) // 2)
+    rows = B * T_enc
+    enc_flop = 2.0 * (cfg.num_blocks * (rows * (2 * (2 * d * 4 * d) + d * 3 * H * dh + H * dh * d + d * 2 * d + d * d) + 2 * T_enc * H * dh * d
+                                        + B * H * T_enc * T_enc * dh * 3) + rows * F2 * 9 * C * C + rows * F2 * C * d)
     dt, ntok = res["f32"]
     line = {"metric": "greedy-decode RTF Conformer-%s RNN-T" % args.model, "value": round(dt / (B * secs), 6), "unit": "RTF (wall s / audio s)",
             "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt * 1e3, 3), "higher_is_better": False,
@@ -296,6 +316,10 @@ def bench_decode(args, model, cfg, dev):
             "config": {"workload": f"greedy search (recognize_batch) over {B} x {secs:.0f} s utterances incl. log-mel + encoder; token-exact mode "
                                    f"(f32 master weights, exact-f32 MFMA encoder; search arithmetic f32), blank bias +{bias:.3f} (calibrated)",
                        "tokens_emitted": ntok, "global_batch": B, "training_storage": args.dtype}}
+    line["breakdown"] = {"frontend_encoder_ms": round(enc_ms, 3), "search_ms": round(srch_ms, 3),
+                         "encoder_f32_tflops": round(enc_flop / (enc_ms * 1e-3) / 1e12, 1), "encoder_f32_mfma_frac": round(enc_flop / (enc_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
+                         "search_us_per_token": round(srch_ms * 1e3 / max(ntok, 1), 2),
+                         "note": "HIP events around model.encode (log-mel + f32 encoder) and recognize_encoded (greedy search); fraction of the exact-f32 MFMA peak"}
     if "bf16" in res:
         line["bf16_encoder"] = {"value": round(res["bf16"][0] / (B * secs), 6), "ms_per_step": round(res["bf16"][0] * 1e3, 3),
                                 "tokens_emitted": res["bf16"][1], "note": "training kernels (bf16 storage); not token-exact vs the f32 reference"}

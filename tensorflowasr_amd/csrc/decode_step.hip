@@ -11,6 +11,7 @@
 // batch row over its k-slice, the slices meet in LDS.  The weight rows a workgroup reads are its own NC columns only, so the
 // matrices stay resident in the L2 of the XCD that owns those columns across the iterations of the search.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -221,6 +222,257 @@ __global__ __launch_bounds__(NT) void decode_vocab_kernel(const float* __restric
   }
 }
 
+
+// =================================================================================================================================
+// Round 4: the same three products on the MATRIX cores in exact f32 (v_mfma_f32_16x16x4_f32).  The vector-ALU kernels above spent their
+// time in the operand path, not the arithmetic: a thread = (batch row, k slice) loads one activation float per k from 32 DIFFERENT rows
+// (64 cache lines per wave instruction) and every weight 16-byte piece 32 times (once per batch lane): 30 / 34 / 12.5 us per launch
+// for 17 MB of weights (rocprofv3, profiles/r04_decode_kernel_stats.md), ~83 us per search iteration.  A step is three skinny GEMMs
+// [B <= 64, K] x [K, 16 columns per workgroup]: as MFMA tiles every lane loads 16 contiguous bytes of its OWN activation row (A: row =
+// lane & 15, four consecutive k per lane) and each weight element is loaded once per workgroup (B: column = lane & 15), the k range is
+// split over the four waves of a workgroup and the partial tiles meet in LDS.  Products are exact f32, the sums run in another order
+// than the sequential loops above (last-ulp differences in the logits; the token decisions are checked against the same goldens).
+// One search iteration = the same four launches; a persistent one-launch search was NOT built: on this chip a device-wide barrier costs
+// 4-7 us and a dependent kernel boundary 1.5-1.9 us (MI355X_MICROARCH.md, barrier-xcd / boundary rows) - four barriers per token would
+// be slower than four launches.
+// k assignment inside a group of 16: MFMA j (0..3) multiplies k = 4 g + j of the group (g = lane >> 4), so a lane's four A values are one
+// float4 and its four B values four rows of the weight matrix at the same column.
+template <int MT>
+__device__ __forceinline__ void mfma_group(float4_t (&acc)[MT], const float4 (&a)[MT], const float (&b)[4]) {
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m].x, b[0], acc[m], 0, 0, 0);
+    acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m].y, b[1], acc[m], 0, 0, 0);
+    acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m].z, b[2], acc[m], 0, 0, 0);
+    acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m].w, b[3], acc[m], 0, 0, 0);
+  }
+}
+// These launches are LATENCY-bound: a kernel of the search is a handful of dependent memory round trips (~1-2 us each at this occupancy),
+// so every load that does not depend on another load is issued up front, in ONE batch per wave: 16 waves per workgroup, each with at most
+// GPW groups of 16 k (operands of a whole launch in flight at once), partial tiles meet in LDS.
+constexpr int NWV = 16, GPW = 5;
+// partial C tiles of the 16 waves -> LDS part[w][MT*16][16]; returns after the barrier
+template <int MT>
+__device__ __forceinline__ void stash_partials(float* part, const float4_t (&acc)[MT], int w, int r, int g) {
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) part[((w * MT + m) * 16 + g * 4 + e) * 16 + r] = acc[m][e];
+  __syncthreads();
+}
+template <int MT>
+__device__ __forceinline__ float sum_partials(const float* part, int b, int cidx) {
+  float sum = 0.f;
+#pragma unroll
+  for (int ww = 0; ww < NWV; ++ww) sum += part[((ww * MT + (b >> 4)) * 16 + (b & 15)) * 16 + cidx];
+  return sum;
+}
+
+// ---- 1'. embedding + LSTM cell for 4 hidden units (16 gate columns) per workgroup ----
+template <int MT>
+__global__ __launch_bounds__(1024) void decode_lstm_mfma_kernel(
+    const float* __restrict__ emb, const float* __restrict__ Wk, const float* __restrict__ Wr, const float* __restrict__ bias,
+    const int32_t* __restrict__ prev_tok, const float* __restrict__ h, const float* __restrict__ c, const int32_t* __restrict__ nframes,
+    const int32_t* __restrict__ frame_idx, const int32_t* __restrict__ tok_idx, int32_t* __restrict__ active, float* __restrict__ h_new,
+    float* __restrict__ c_new, int B, int E, int P, int V, int max_tokens, int mode) {
+  __shared__ float part[NWV * MT * 16 * 16];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
+  const int u0 = blockIdx.x * 4;
+  const long wcol = (long)(r >> 2) * P + u0 + (r & 3);  // column r of the tile = gate r / 4, unit u0 + r % 4
+  const int ngr = (E + P) / 16, per = (ngr + NWV - 1) / NWV;  // per <= GPW (checked by the host)
+  const int g0 = w * per, g1 = min(ngr, g0 + per);
+  // round trip 1: everything that depends on no other load - the weights of this wave's groups, the h rows, the previous tokens
+  float bw[GPW][4];
+  float4 a[GPW][MT];
+  int tok[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) tok[m] = prev_tok[min(m * 16 + r, B - 1)];
+#pragma unroll
+  for (int i = 0; i < GPW; ++i) {
+    const int gr = min(g0 + i, max(g1 - 1, 0));
+    const int k0 = gr * 16 + g * 4;  // this lane's four k of the group
+    const bool in_e = gr * 16 < E;   // (E % 16 == 0: a group never straddles the two operands)
+    const int kk = in_e ? k0 : k0 - E;
+    const float* Wm = (in_e ? Wk : Wr) + (long)kk * 4 * P + wcol;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bw[i][j] = Wm[(long)j * 4 * P];
+    if (!in_e) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m) a[i][m] = *reinterpret_cast<const float4*>(h + (long)min(m * 16 + r, B - 1) * P + kk);
+    }
+  }
+  const bool act = loop_active(nframes, frame_idx, tok_idx, B, max_tokens, mode);  // (its barrier waits for the loads above as well)
+  if (blockIdx.x == 0 && threadIdx.x == 0) active[0] = act ? 1 : 0;
+  if (!act) return;
+  // round trip 2: the embedding rows of the previous tokens
+#pragma unroll
+  for (int i = 0; i < GPW; ++i) {
+    const int gr = min(g0 + i, max(g1 - 1, 0));
+    if (gr * 16 < E) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m) a[i][m] = *reinterpret_cast<const float4*>(emb + (long)min(max(tok[m], 0), V - 1) * E + gr * 16 + g * 4);
+    }
+  }
+  // cell operands of the epilogue threads (independent of the products)
+  const int eb = threadIdx.x >> 2, eu = threadIdx.x & 3;
+  float cb[4] = {0.f, 0.f, 0.f, 0.f}, cprev = 0.f;
+  if (threadIdx.x < B * 4) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) cb[q] = bias[q * P + u0 + eu];
+    cprev = c[(long)eb * P + u0 + eu];
+  }
+  float4_t acc[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) acc[m] = float4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < GPW; ++i)
+    if (g0 + i < g1) mfma_group<MT>(acc, a[i], bw[i]);
+  stash_partials<MT>(part, acc, w, r, g);
+  if (threadIdx.x < B * 4) {
+    float z[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) z[q] = cb[q] + sum_partials<MT>(part, eb, q * 4 + eu);
+    const float ig = sigmoidf_(z[0]), fg = sigmoidf_(z[1]), gg = tanh_fast(z[2]), og = sigmoidf_(z[3]);
+    const float cn = fg * cprev + ig * gg;
+    c_new[(long)eb * P + u0 + eu] = cn;
+    h_new[(long)eb * P + u0 + eu] = og * tanh_fast(cn);
+  }
+}
+
+// ---- 2'. LayerNorm + prediction projection + tanh(enc + pred) for 16 joint columns per workgroup ----
+template <int MT>
+__global__ __launch_bounds__(1024) void decode_joint_mfma_kernel(
+    const float* __restrict__ h_new, const float* __restrict__ ln_g, const float* __restrict__ ln_b, const float* __restrict__ Wjp,
+    const float* __restrict__ bjp, const float* __restrict__ encj, const int32_t* __restrict__ nframes,
+    const int32_t* __restrict__ frame_idx, const int32_t* __restrict__ active, float* __restrict__ z, int B, int T, int P, int J,
+    float ln_eps) {
+  __shared__ float part[NWV * MT * 16 * 16];
+  __shared__ float s_mean[MAXB], s_rstd[MAXB];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
+  const int j0 = blockIdx.x * 16;
+  const int col = min(j0 + r, J - 1);
+  const int ngr = P / 16, per = (ngr + NWV - 1) / NWV;
+  const int g0 = w * per, g1 = min(ngr, g0 + per);
+  // one batch of loads: weights, raw prediction rows, LayerNorm coefficients, the LayerNorm rows of this wave, the encoder frame
+  float bw[GPW][4];
+  float4 a[GPW][MT], gv[GPW], bv[GPW];
+#pragma unroll
+  for (int i = 0; i < GPW; ++i) {
+    const int k0 = min(g0 + i, max(g1 - 1, 0)) * 16 + g * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bw[i][j] = Wjp[(long)(k0 + j) * J + col];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) a[i][m] = *reinterpret_cast<const float4*>(h_new + (long)min(m * 16 + r, B - 1) * P + k0);
+    gv[i] = make_float4(1.f, 1.f, 1.f, 1.f); bv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ln_g) { gv[i] = *reinterpret_cast<const float4*>(ln_g + k0); bv[i] = *reinterpret_cast<const float4*>(ln_b + k0); }
+  }
+  constexpr int RPWV = MAXB / NWV;  // LayerNorm rows per wave (4 at most)
+  constexpr int LNK = 16;           // floats per lane per row: P <= 1024
+  float lnx[RPWV][LNK];
+  if (ln_g) {
+#pragma unroll
+    for (int q = 0; q < RPWV; ++q) {
+      const int b = min(w * RPWV + q, B - 1);
+#pragma unroll
+      for (int t = 0; t < LNK; ++t) lnx[q][t] = (lane + 64 * t < P) ? h_new[(long)b * P + lane + 64 * t] : 0.f;
+    }
+  }
+  const int eb = threadIdx.x >> 4, ec = threadIdx.x & 15;
+  float ebias = 0.f, eenc = 0.f;
+  const bool ethr = threadIdx.x < B * 16 && j0 + ec < J;
+  if (ethr) {
+    ebias = bjp[j0 + ec];
+    int f = min(frame_idx[eb], nframes[eb] - 1);
+    f = max(min(f, T - 1), 0);
+    eenc = encj[((long)eb * T + f) * J + j0 + ec];
+  }
+  if (!active[0]) return;
+  if (ln_g) {  // keras LayerNormalization (eps 1e-3), two passes (mean, then centred second moment) on the row held in registers
+#pragma unroll
+    for (int q = 0; q < RPWV; ++q) {
+      float sum = 0.f;
+#pragma unroll
+      for (int t = 0; t < LNK; ++t) sum += lnx[q][t];
+      const float mu = wave_sum(sum) / P;
+      float qq = 0.f;
+#pragma unroll
+      for (int t = 0; t < LNK; ++t) { const float dlt = (lane + 64 * t < P) ? lnx[q][t] - mu : 0.f; qq += dlt * dlt; }
+      qq = wave_sum(qq);
+      if (lane == 0 && w * RPWV + q < B) { s_mean[w * RPWV + q] = mu; s_rstd[w * RPWV + q] = rsqrtf(qq / P + ln_eps); }
+    }
+  }
+  __syncthreads();
+  float4_t acc[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) acc[m] = float4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < GPW; ++i) {
+    if (g0 + i >= g1) continue;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const int b = min(m * 16 + r, B - 1);
+      const float mu = ln_g ? s_mean[b] : 0.f, rs = ln_g ? s_rstd[b] : 1.f;
+      const float4 x = a[i][m];
+      a[i][m] = make_float4((x.x - mu) * rs * gv[i].x + bv[i].x, (x.y - mu) * rs * gv[i].y + bv[i].y, (x.z - mu) * rs * gv[i].z + bv[i].z,
+                            (x.w - mu) * rs * gv[i].w + bv[i].w);
+    }
+    mfma_group<MT>(acc, a[i], bw[i]);
+  }
+  stash_partials<MT>(part, acc, w, r, g);
+  if (ethr) z[(long)eb * J + j0 + ec] = tanhf(eenc + (ebias + sum_partials<MT>(part, eb, ec)));  // TransducerJointMerge add + tanh (:199-207,291)
+}
+
+// ---- 3'. vocabulary projection for 16 classes per workgroup ----
+template <int MT>
+__global__ __launch_bounds__(1024) void decode_vocab_mfma_kernel(const float* __restrict__ z, const float* __restrict__ Wv, const float* __restrict__ bv,
+                                                                 const int32_t* __restrict__ active, float* __restrict__ logits, int B, int J, int V) {
+  __shared__ float part[NWV * MT * 16 * 16];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
+  const int v0 = blockIdx.x * 16;
+  const int col = min(v0 + r, V - 1);
+  const int ngr = J / 16, per = (ngr + NWV - 1) / NWV;
+  const int g0 = w * per, g1 = min(ngr, g0 + per);
+  float bw[GPW][4];
+  float4 a[GPW][MT];
+#pragma unroll
+  for (int i = 0; i < GPW; ++i) {
+    const int k0 = min(g0 + i, max(g1 - 1, 0)) * 16 + g * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bw[i][j] = Wv[(long)(k0 + j) * V + col];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) a[i][m] = *reinterpret_cast<const float4*>(z + (long)min(m * 16 + r, B - 1) * J + k0);
+  }
+  const int eb = threadIdx.x >> 4, ec = threadIdx.x & 15;
+  const bool ethr = threadIdx.x < B * 16 && v0 + ec < V;
+  const float ebias = ethr ? bv[v0 + ec] : 0.f;
+  if (!active[0]) return;
+  float4_t acc[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) acc[m] = float4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < GPW; ++i)
+    if (g0 + i < g1) mfma_group<MT>(acc, a[i], bw[i]);
+  stash_partials<MT>(part, acc, w, r, g);
+  if (ethr) logits[(long)eb * V + v0 + ec] = ebias + sum_partials<MT>(part, eb, ec);
+}
+
+template <int MT>
+int launch_decode_mfma(const float* emb, const float* lstm_k, const float* lstm_rk, const float* lstm_b, const float* ln_g, const float* ln_b,
+                       const float* joint_pred_w, const float* joint_pred_b, const float* vocab_w, const float* vocab_b, const float* encj,
+                       const int32_t* nframes, const int32_t* frame_idx, const int32_t* tok_idx, const int32_t* prev_tok, const float* h,
+                       const float* c, int32_t* active, float* h_new, float* c_new, float* z, float* logits, int B, int T, int E, int P, int J,
+                       int V, int max_tokens, int mode, float ln_eps, hipStream_t s) {
+  hipLaunchKernelGGL(decode_lstm_mfma_kernel<MT>, dim3(P / 4), dim3(1024), 0, s, emb, lstm_k, lstm_rk, lstm_b, prev_tok, h, c, nframes, frame_idx,
+                     tok_idx, active, h_new, c_new, B, E, P, V, max_tokens, mode);
+  TFASR_CHECK_LAUNCH();
+  hipLaunchKernelGGL(decode_joint_mfma_kernel<MT>, dim3((J + 15) / 16), dim3(1024), 0, s, h_new, ln_g, ln_b, joint_pred_w, joint_pred_b, encj, nframes,
+                     frame_idx, active, z, B, T, P, J, ln_eps);
+  TFASR_CHECK_LAUNCH();
+  hipLaunchKernelGGL(decode_vocab_mfma_kernel<MT>, dim3((V + 15) / 16), dim3(1024), 0, s, z, vocab_w, vocab_b, active, logits, B, J, V);
+  TFASR_CHECK_LAUNCH();
+  return TFASR_STATUS_SUCCESS;
+}
+
 }  // namespace
 
 extern "C" int tfasr_decode_step(const float* emb, const float* lstm_k, const float* lstm_rk, const float* lstm_b, const float* ln_g,
@@ -236,6 +488,17 @@ extern "C" int tfasr_decode_step(const float* emb, const float* lstm_k, const fl
   if ((P % 4) || (J % 4) || (V % 8) || (((uintptr_t)lstm_k | (uintptr_t)lstm_rk | (uintptr_t)joint_pred_w | (uintptr_t)vocab_w) & 15))
     return TFASR_STATUS_UNSUPPORTED;  // float4 weight loads
   hipStream_t s = (hipStream_t)stream_;
+  static const bool mfma_off = getenv("TFASR_DECODE_MFMA") && getenv("TFASR_DECODE_MFMA")[0] == '0';  // A/B probe: the vector-ALU kernels
+  if (!mfma_off && (E % 16) == 0 && (P % 16) == 0 && (J % 16) == 0 && (E + P) <= 16 * NWV * GPW && P <= 1024 && ((((uintptr_t)emb | (uintptr_t)h | (uintptr_t)h_new | (uintptr_t)z | (uintptr_t)ln_g | (uintptr_t)ln_b) & 15) == 0)) {
+    const int mt = (B + 15) / 16;
+#define TFASR_DM(M) return launch_decode_mfma<M>(emb, lstm_k, lstm_rk, lstm_b, ln_g, ln_b, joint_pred_w, joint_pred_b, vocab_w, vocab_b, encj, nframes, frame_idx, \
+                                                 tok_idx, prev_tok, h, c, active, h_new, c_new, z, logits, B, T, E, P, J, V, max_tokens, mode, ln_eps, s)
+    if (mt == 1) TFASR_DM(1);
+    if (mt == 2) TFASR_DM(2);
+    if (mt == 3) TFASR_DM(3);
+    TFASR_DM(4);
+#undef TFASR_DM
+  }
   hipLaunchKernelGGL(decode_lstm_kernel<4>, dim3(P / 4), dim3(NT), 0, s, emb, lstm_k, lstm_rk, lstm_b, prev_tok, h, c, nframes, frame_idx, tok_idx,
                      active, h_new, c_new, B, E, P, V, max_tokens, mode);
   TFASR_CHECK_LAUNCH();

@@ -161,6 +161,7 @@ __global__ __launch_bounds__(256, WGS) void ffn_fused_fwd_kernel(const FfnArgs p
     for (int j = 0; j < 8; ++j) acc2[i][j] = float4_t{0.f, 0.f, 0.f, 0.f};
   const uint32_t dthr = drop_thr(p.drop_p);
   const float dinv = p.drop_p > 0.f ? 1.f / (1.f - p.drop_p) : 1.f;
+  const uint32_t dkey1 = (uint32_t)p.seed1 * 0x9E3779B1u ^ (uint32_t)((uint64_t)p.seed1 >> 32);  // drop_hash's key for pair indices < 2^32
 
   auto gemm1 = [&](int cc, bool fence = true) {  // acc1 = ln W1[:, cc]: wave tile 32 x 32, K = 256, A from registers
     const char* sW1 = smem + W1_OFF + (cc & (NBUF - 1)) * 32768;
@@ -205,7 +206,9 @@ __global__ __launch_bounds__(256, WGS) void ffn_fused_fwd_kernel(const FfnArgs p
     constexpr int RPP = NT / 8;
     bf16_t* zbase = p.z ? p.z + m0 * F + cc * 64 : nullptr;  // uniform bases; the per-lane part is a 32-bit offset
     bf16_t* hbase = p.h ? p.h + m0 * F + cc * 64 : nullptr;
-    const uint64_t ibase = (uint64_t)(m0 * F + cc * 64);
+    // dropout hash of an element PAIR (common.h drop_hash) with everything that does not depend on the pair hoisted: the key is the seed's
+    // share of the hash, the pair index fits 32 bits (rows * F < 2^33 elements, checked by the caller), so a pair costs the finaliser alone
+    const uint32_t pbase = (uint32_t)((uint64_t)(m0 * F + cc * 64) >> 1);
 #pragma unroll
     for (int ps = 0; ps < BMR / RPP; ++ps) {
       const int row = ps * RPP + (threadIdx.x >> 3), pp = threadIdx.x & 7;
@@ -219,10 +222,10 @@ __global__ __launch_bounds__(256, WGS) void ffn_fused_fwd_kernel(const FfnArgs p
 #pragma unroll
       for (int q = 0; q < 8; ++q) hv[q] = swishf_(hv[q]);
       {  // (drop_p = 0: threshold 0 keeps everything, dinv = 1 - no branch)
-        const uint64_t e0 = ibase + (uint32_t)off;  // even: one dropout hash serves an element pair
+        const uint32_t pr0 = pbase + ((uint32_t)off >> 1);  // off is even: one dropout hash serves an element pair
 #pragma unroll
         for (int q = 0; q < 8; q += 2) {
-          const uint32_t hh = drop_hash((uint64_t)p.seed1, (e0 >> 1) + (q >> 1));
+          const uint32_t hh = fmix32((pr0 + (q >> 1)) ^ dkey1);
           hv[q] = (hh & 0xffffu) >= dthr ? hv[q] * dinv : 0.f;
           hv[q + 1] = (hh >> 16) >= dthr ? hv[q + 1] * dinv : 0.f;
         }

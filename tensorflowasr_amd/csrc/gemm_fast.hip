@@ -1255,7 +1255,7 @@ extern "C" int tfasr_ffn_fused_fwd(const void* x, const float* gamma, const floa
   if (!x || !gamma || !beta || !W1 || !b1 || !W2 || !b2 || !y || !ln || !mean || !rstd || rows <= 0 || d <= 0 || F <= 0) return TFASR_STATUS_INVALID_VALUE;
   if (!(drop_p >= 0.f && drop_p < 1.f)) return TFASR_STATUS_INVALID_VALUE;
   static const bool off = getenv("TFASR_FFN_FUSED") && getenv("TFASR_FFN_FUSED")[0] == '0';
-  if (off || dtype != TFASR_BF16 || d != 256 || (F % 64) != 0 || F > 1024 || F < 128 || rows * (long)F >= (1L << 40)) return TFASR_STATUS_UNSUPPORTED;
+  if (off || dtype != TFASR_BF16 || d != 256 || (F % 64) != 0 || F > 1024 || F < 128 || rows * (long)F >= (1L << 32)) return TFASR_STATUS_UNSUPPORTED;
   const uintptr_t al = (uintptr_t)x | (uintptr_t)W1 | (uintptr_t)W2 | (uintptr_t)y | (uintptr_t)ln | (uintptr_t)z | (uintptr_t)h | (uintptr_t)gamma | (uintptr_t)beta;
   if (al & 15) return TFASR_STATUS_UNSUPPORTED;
   FfnArgs a;

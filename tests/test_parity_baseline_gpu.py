@@ -110,7 +110,7 @@ def test_conformer_s_16_blocks_10s_loss_and_gradients_vs_oracle(dev):
 
 # --------------------------------------------------------------------------------------------- BASELINE configs[2] dimensions
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("case", ["T462_B4", "T743_B2", "T150_B3_L16"])
+@pytest.mark.parametrize("case", ["T462_B4", "T743_B2", "T150_B3_L16", "T462_B2_L16"])
 def test_conformer_m_dims_ragged_bf16_fused_path_vs_oracle(dev, case):
     """d=256, dh=64, k=31, J=640 with ragged lengths at the padded lengths of bench.py's two batches: fused attention +
     native executor + packed lattice (bf16) against the oracle, which applies the reference's padded-query mask and the
@@ -119,12 +119,14 @@ def test_conformer_m_dims_ragged_bf16_fused_path_vs_oracle(dev, case):
         nsamp, ulens, U, blocks = [295600, 201000, 131072, 20800], [68, 46, 30, 5], 68, 3
     elif case == "T743_B2":
         nsamp, ulens, U, blocks = [475200, 160000], [40, 37], 40, 2
+    elif case == "T462_B2_L16":  # ALL 16 blocks at one of bench.py's padded lengths (T' = 462), two ragged utterances
+        nsamp, ulens, U, blocks = [295600, 131072], [68, 30], 68, 16
     else:  # ALL 16 blocks of the model bench.py times (depth: bf16 drift through the whole encoder), shorter utterances, ragged incl. padded blocks
         nsamp, ulens, U, blocks = [96000, 70000, 30000], [22, 16, 7], 22, 16
     cfg, ocfg, model, W, data, sig, labels, preds = _make(dev, "M", torch.bfloat16, nsamp, ulens, U, blocks=blocks)
     assert model._fused_attention() and model.native_blocks
     ref_loss, ref_grads, elen = _oracle(ocfg, W, sig, nsamp, preds, ulens, labels)
-    assert int(elen.max()) == {"T462_B4": 462, "T743_B2": 743, "T150_B3_L16": 150}[case]
+    assert int(elen.max()) == {"T462_B4": 462, "T743_B2": 743, "T150_B3_L16": 150, "T462_B2_L16": 462}[case]
     model.zero_grad()
     costs = model.loss_and_backward(data, True, (None, None)).float().cpu().numpy()
     torch.cuda.synchronize()
