@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define TFASR_ABI_VERSION 24
+#define TFASR_ABI_VERSION 25
 
 typedef enum {
   TFASR_STATUS_SUCCESS = 0,
@@ -402,17 +402,24 @@ int tfasr_decode_prepare(const void* encj, const int32_t* nframes, const int32_t
  * P, J % 4 == 0 and V % 8 == 0, else UNSUPPORTED (use tfasr_decode_prepare + the per-op entry points). */
 int tfasr_decode_step(const float* emb, const float* lstm_k, const float* lstm_rk, const float* lstm_b, const float* ln_g,
                       const float* ln_b, const float* joint_pred_w, const float* joint_pred_b, const float* vocab_w,
-                      const float* vocab_b, const float* encj, const int32_t* nframes, const int32_t* frame_idx,
+                      const float* vocab_b, const float* packed, const float* encj, const int32_t* nframes, const int32_t* frame_idx,
                       const int32_t* tok_idx, const int32_t* prev_tok, const float* h, const float* c, int32_t* active,
                       float* h_new, float* c_new, float* z, float* logits, int B, int T, int E, int P, int J, int V,
                       int max_tokens, int mode, float ln_eps, void* stream);
 /* `iters` iterations of (tfasr_decode_step + tfasr_decode_update) queued by one host call (f32 states h, c [B,P]). */
 int tfasr_decode_steps(const float* emb, const float* lstm_k, const float* lstm_rk, const float* lstm_b, const float* ln_g,
                        const float* ln_b, const float* joint_pred_w, const float* joint_pred_b, const float* vocab_w,
-                       const float* vocab_b, const float* encj, const int32_t* nframes, int32_t* frame_idx, int32_t* tok_idx,
-                       int32_t* prev_tok, float* h, float* c, int32_t* active, float* h_new, float* c_new, float* z, float* logits,
-                       int32_t* tokens, int32_t* per_frame, int B, int T, int E, int P, int J, int V, int max_tokens, int blank,
-                       int mode, int max_tokens_per_frame, float ln_eps, int iters, void* stream);
+                       const float* vocab_b, const float* packed, const float* encj, const int32_t* nframes, int32_t* frame_idx,
+                       int32_t* tok_idx, int32_t* prev_tok, float* h, float* c, int32_t* active, float* h_new, float* c_new, float* z,
+                       float* logits, int32_t* tokens, int32_t* per_frame, int B, int T, int E, int P, int J, int V, int max_tokens,
+                       int blank, int mode, int max_tokens_per_frame, float ln_eps, int iters, void* stream);
+/* `packed` of the two entry points above (NULL: the vector-ALU kernels on the row-major masters): the four weight matrices of a search
+ * step re-laid once per recognize call so that the 16 output columns of a workgroup of the exact-f32 MFMA kernels are contiguous, in
+ * fragment order (csrc/decode_step.hip).  tfasr_decode_pack_floats = floats `packed` must hold, 0 when the shapes have no MFMA route
+ * (E, P, J % 16, P <= 1024, E + P and J <= 1280): pass NULL then. */
+size_t tfasr_decode_pack_floats(int E, int P, int J, int V);
+int tfasr_decode_pack(const float* lstm_k, const float* lstm_rk, const float* joint_pred_w, const float* vocab_w, float* packed, int E,
+                      int P, int J, int V, void* stream);
 int tfasr_decode_update(const void* logits, const int32_t* active, const int32_t* nframes, int32_t* frame_idx,
                         int32_t* prev_tok, int32_t* tok_idx, int32_t* tokens, int32_t* per_frame, const void* h_new,
                         const float* c_new, void* h, float* c, int B, int V, int P, int max_tokens, int blank, int mode,

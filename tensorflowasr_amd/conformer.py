@@ -1276,13 +1276,14 @@ class ConformerTransducer(BaseModel):
         zbuf = torch.empty(B, J, dtype=f32, device=dev)
         lng, lnb = (ps.p("pred/ln/g"), ps.p("pred/ln/b")) if c.prediction_layer_norm else (None, None)
         fused = B <= 64 and os.environ.get("TFASR_DECODE_FUSED", "1") != "0"
+        packed = K.decode_pack(Wk, Wrk, Wjp, Wv, ps.p("pred/emb").shape[1]) if fused else None  # tile order of the MFMA step kernels
         while it < max_iters:
             n = min(check_every * 4 if fused else check_every, max_iters - it)  # fused iterations are cheap no-ops once the loop has ended
             if fused:
                 # `n` iterations = 3 skinny-product launches + the bookkeeping kernel each (csrc/decode_step.hip), queued by one host call
                 fused = K.decode_steps(ps.p("pred/emb"), Wk, Wrk, ps.p("pred/lstm/b"), lng, lnb, Wjp, ps.p("joint/pred/b"), Wv,
                                        ps.p("joint/vocab/b"), encj, nframes, frame_idx, tok_idx, prev_tok, h, cst, active, h_new, c_new, zbuf,
-                                       logits, tokens, per_frame, max_tokens, self.blank, mode, max_tokens_per_frame, n)
+                                       logits, tokens, per_frame, max_tokens, self.blank, mode, max_tokens_per_frame, n, packed=packed)
                 if fused:
                     it += n
                     if int(active.item()) == 0:

@@ -227,7 +227,8 @@ __global__ __launch_bounds__(NT) void decode_vocab_kernel(const float* __restric
 // Round 4: the same three products on the MATRIX cores in exact f32 (v_mfma_f32_16x16x4_f32).  The vector-ALU kernels above spent their
 // time in the operand path, not the arithmetic: a thread = (batch row, k slice) loads one activation float per k from 32 DIFFERENT rows
 // (64 cache lines per wave instruction) and every weight 16-byte piece 32 times (once per batch lane): 30 / 34 / 12.5 us per launch
-// for 17 MB of weights (rocprofv3, profiles/r04_decode_kernel_stats.md), ~83 us per search iteration.  A step is three skinny GEMMs
+// for 13 MB of weights, ~83 us per search iteration; these kernels on the packed weights: 10.1 / 11.1 / 7.4 us (rocprofv3,
+// profiles/r04_decode_kernel_stats.md).  A step is three skinny GEMMs
 // [B <= 64, K] x [K, 16 columns per workgroup]: as MFMA tiles every lane loads 16 contiguous bytes of its OWN activation row (A: row =
 // lane & 15, four consecutive k per lane) and each weight element is loaded once per workgroup (B: column = lane & 15), the k range is
 // split over the four waves of a workgroup and the partial tiles meet in LDS.  Products are exact f32, the sums run in another order
@@ -268,20 +269,52 @@ __device__ __forceinline__ float sum_partials(const float* part, int b, int cidx
   return sum;
 }
 
+// ---- weight re-layout for the kernels below (tfasr_decode_pack): tile t = the 16 output columns of workgroup t, inside a tile the
+// operands of one wave instruction are contiguous: float index ((grp * 4 + j) * 4 + g) * 16 + r holds W[k = grp * 16 + 4 g + j][column r
+// of the tile] - a wave's load of MFMA j's B operand is 256 contiguous bytes.  In the [K, N] row-major masters a workgroup's columns are
+// 16-byte (LSTM: 4 units x 4 gates, gate stride P) or 64-byte pieces of a row, every piece in another cache line than the next k's: the
+// fetches moved 4-8x the bytes they used and the 13 MB of weights cost 20+ us per iteration.
+__global__ __launch_bounds__(256) void decode_pack_kernel(const float* __restrict__ Wk, const float* __restrict__ Wr, const float* __restrict__ Wjp,
+                                                          const float* __restrict__ Wv, float* __restrict__ out, int E, int P, int J, int V) {
+  const long nl = (long)(P / 4) * (E + P) * 16, nj = (long)((J + 15) / 16) * P * 16, nv = (long)((V + 15) / 16) * J * 16;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= nl + nj + nv) return;
+  const int sec = idx < nl ? 0 : (idx < nl + nj ? 1 : 2);
+  const long o = idx - (sec == 0 ? 0 : (sec == 1 ? nl : nl + nj));
+  const int K = sec == 0 ? E + P : (sec == 1 ? P : J);
+  const long tile = o / ((long)K * 16);
+  const int rem = (int)(o - tile * K * 16);
+  const int grp = rem >> 8, j = (rem >> 6) & 3, g = (rem >> 4) & 3, r = rem & 15;
+  const int k = grp * 16 + 4 * g + j;
+  float v = 0.f;
+  if (sec == 0) {
+    const long col = (long)(r >> 2) * P + tile * 4 + (r & 3);  // column r of the tile = gate r / 4, unit 4 tile + r % 4
+    v = k < E ? Wk[(long)k * 4 * P + col] : Wr[(long)(k - E) * 4 * P + col];
+  } else if (sec == 1) {
+    const long col = tile * 16 + r;
+    if (col < J) v = Wjp[(long)k * J + col];
+  } else {
+    const long col = tile * 16 + r;
+    if (col < V) v = Wv[(long)k * V + col];
+  }
+  out[idx] = v;
+}
+
 // ---- 1'. embedding + LSTM cell for 4 hidden units (16 gate columns) per workgroup ----
 template <int MT>
 __global__ __launch_bounds__(1024) void decode_lstm_mfma_kernel(
-    const float* __restrict__ emb, const float* __restrict__ Wk, const float* __restrict__ Wr, const float* __restrict__ bias,
+    const float* __restrict__ emb, const float* __restrict__ pk, const float* __restrict__ bias,
     const int32_t* __restrict__ prev_tok, const float* __restrict__ h, const float* __restrict__ c, const int32_t* __restrict__ nframes,
     const int32_t* __restrict__ frame_idx, const int32_t* __restrict__ tok_idx, int32_t* __restrict__ active, float* __restrict__ h_new,
     float* __restrict__ c_new, int B, int E, int P, int V, int max_tokens, int mode) {
   __shared__ float part[NWV * MT * 16 * 16];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
   const int u0 = blockIdx.x * 4;
-  const long wcol = (long)(r >> 2) * P + u0 + (r & 3);  // column r of the tile = gate r / 4, unit u0 + r % 4
+  const float* tile = pk + (long)blockIdx.x * (E + P) * 16;
   const int ngr = (E + P) / 16, per = (ngr + NWV - 1) / NWV;  // per <= GPW (checked by the host)
   const int g0 = w * per, g1 = min(ngr, g0 + per);
-  // round trip 1: everything that depends on no other load - the weights of this wave's groups, the h rows, the previous tokens
+  // round trip 1: everything that depends on no other load - the previous tokens first (the embedding rows hang off them), the weights of
+  // this wave's groups, the h rows
   float bw[GPW][4];
   float4 a[GPW][MT];
   int tok[MT];
@@ -290,27 +323,11 @@ __global__ __launch_bounds__(1024) void decode_lstm_mfma_kernel(
 #pragma unroll
   for (int i = 0; i < GPW; ++i) {
     const int gr = min(g0 + i, max(g1 - 1, 0));
-    const int k0 = gr * 16 + g * 4;  // this lane's four k of the group
-    const bool in_e = gr * 16 < E;   // (E % 16 == 0: a group never straddles the two operands)
-    const int kk = in_e ? k0 : k0 - E;
-    const float* Wm = (in_e ? Wk : Wr) + (long)kk * 4 * P + wcol;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) bw[i][j] = Wm[(long)j * 4 * P];
-    if (!in_e) {
+    for (int j = 0; j < 4; ++j) bw[i][j] = tile[(gr * 4 + j) * 64 + lane];
+    if (gr * 16 >= E) {  // (E % 16 == 0: a group never straddles the two operands)
 #pragma unroll
-      for (int m = 0; m < MT; ++m) a[i][m] = *reinterpret_cast<const float4*>(h + (long)min(m * 16 + r, B - 1) * P + kk);
-    }
-  }
-  const bool act = loop_active(nframes, frame_idx, tok_idx, B, max_tokens, mode);  // (its barrier waits for the loads above as well)
-  if (blockIdx.x == 0 && threadIdx.x == 0) active[0] = act ? 1 : 0;
-  if (!act) return;
-  // round trip 2: the embedding rows of the previous tokens
-#pragma unroll
-  for (int i = 0; i < GPW; ++i) {
-    const int gr = min(g0 + i, max(g1 - 1, 0));
-    if (gr * 16 < E) {
-#pragma unroll
-      for (int m = 0; m < MT; ++m) a[i][m] = *reinterpret_cast<const float4*>(emb + (long)min(max(tok[m], 0), V - 1) * E + gr * 16 + g * 4);
+      for (int m = 0; m < MT; ++m) a[i][m] = *reinterpret_cast<const float4*>(h + (long)min(m * 16 + r, B - 1) * P + gr * 16 + g * 4 - E);
     }
   }
   // cell operands of the epilogue threads (independent of the products)
@@ -321,6 +338,18 @@ __global__ __launch_bounds__(1024) void decode_lstm_mfma_kernel(
     for (int q = 0; q < 4; ++q) cb[q] = bias[q * P + u0 + eu];
     cprev = c[(long)eb * P + u0 + eu];
   }
+  // round trip 2 (waits for the tokens only - loads retire in order): the embedding rows of the previous tokens
+#pragma unroll
+  for (int i = 0; i < GPW; ++i) {
+    const int gr = min(g0 + i, max(g1 - 1, 0));
+    if (gr * 16 < E) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m) a[i][m] = *reinterpret_cast<const float4*>(emb + (long)min(max(tok[m], 0), V - 1) * E + gr * 16 + g * 4);
+    }
+  }
+  const bool act = loop_active(nframes, frame_idx, tok_idx, B, max_tokens, mode);
+  if (blockIdx.x == 0 && threadIdx.x == 0) active[0] = act ? 1 : 0;
+  if (!act) return;
   float4_t acc[MT];
 #pragma unroll
   for (int m = 0; m < MT; ++m) acc[m] = float4_t{0.f, 0.f, 0.f, 0.f};
@@ -340,42 +369,42 @@ __global__ __launch_bounds__(1024) void decode_lstm_mfma_kernel(
 }
 
 // ---- 2'. LayerNorm + prediction projection + tanh(enc + pred) for 16 joint columns per workgroup ----
-template <int MT>
+// LNK = floats of a prediction row per lane (P <= 64 LNK); a wave owns MT rows of the LayerNorm statistics (16 MT rows / 16 waves)
+template <int MT, int LNK>
 __global__ __launch_bounds__(1024) void decode_joint_mfma_kernel(
-    const float* __restrict__ h_new, const float* __restrict__ ln_g, const float* __restrict__ ln_b, const float* __restrict__ Wjp,
+    const float* __restrict__ h_new, const float* __restrict__ ln_g, const float* __restrict__ ln_b, const float* __restrict__ pk,
     const float* __restrict__ bjp, const float* __restrict__ encj, const int32_t* __restrict__ nframes,
     const int32_t* __restrict__ frame_idx, const int32_t* __restrict__ active, float* __restrict__ z, int B, int T, int P, int J,
     float ln_eps) {
   __shared__ float part[NWV * MT * 16 * 16];
   __shared__ float s_mean[MAXB], s_rstd[MAXB];
+  __shared__ __attribute__((aligned(16))) float s_g[1024], s_b[1024];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
   const int j0 = blockIdx.x * 16;
-  const int col = min(j0 + r, J - 1);
+  const float* tile = pk + (long)blockIdx.x * P * 16;
   const int ngr = P / 16, per = (ngr + NWV - 1) / NWV;
   const int g0 = w * per, g1 = min(ngr, g0 + per);
-  // one batch of loads: weights, raw prediction rows, LayerNorm coefficients, the LayerNorm rows of this wave, the encoder frame
+  // one batch of loads: weights, raw prediction rows, LayerNorm coefficients (via LDS), the LayerNorm rows of this wave, the encoder frame
   float bw[GPW][4];
-  float4 a[GPW][MT], gv[GPW], bv[GPW];
+  float4 a[GPW][MT];
 #pragma unroll
   for (int i = 0; i < GPW; ++i) {
-    const int k0 = min(g0 + i, max(g1 - 1, 0)) * 16 + g * 4;
+    const int gr = min(g0 + i, max(g1 - 1, 0));
 #pragma unroll
-    for (int j = 0; j < 4; ++j) bw[i][j] = Wjp[(long)(k0 + j) * J + col];
+    for (int j = 0; j < 4; ++j) bw[i][j] = tile[(gr * 4 + j) * 64 + lane];
 #pragma unroll
-    for (int m = 0; m < MT; ++m) a[i][m] = *reinterpret_cast<const float4*>(h_new + (long)min(m * 16 + r, B - 1) * P + k0);
-    gv[i] = make_float4(1.f, 1.f, 1.f, 1.f); bv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (ln_g) { gv[i] = *reinterpret_cast<const float4*>(ln_g + k0); bv[i] = *reinterpret_cast<const float4*>(ln_b + k0); }
+    for (int m = 0; m < MT; ++m) a[i][m] = *reinterpret_cast<const float4*>(h_new + (long)min(m * 16 + r, B - 1) * P + gr * 16 + g * 4);
   }
-  constexpr int RPWV = MAXB / NWV;  // LayerNorm rows per wave (4 at most)
-  constexpr int LNK = 16;           // floats per lane per row: P <= 1024
-  float lnx[RPWV][LNK];
+  float lnx[MT][LNK];
+  float gl = 1.f, bl = 0.f;
   if (ln_g) {
 #pragma unroll
-    for (int q = 0; q < RPWV; ++q) {
-      const int b = min(w * RPWV + q, B - 1);
+    for (int q = 0; q < MT; ++q) {
+      const int b = min(w * MT + q, B - 1);
 #pragma unroll
       for (int t = 0; t < LNK; ++t) lnx[q][t] = (lane + 64 * t < P) ? h_new[(long)b * P + lane + 64 * t] : 0.f;
     }
+    if ((int)threadIdx.x < P) { gl = ln_g[threadIdx.x]; bl = ln_b[threadIdx.x]; }
   }
   const int eb = threadIdx.x >> 4, ec = threadIdx.x & 15;
   float ebias = 0.f, eenc = 0.f;
@@ -388,8 +417,9 @@ __global__ __launch_bounds__(1024) void decode_joint_mfma_kernel(
   }
   if (!active[0]) return;
   if (ln_g) {  // keras LayerNormalization (eps 1e-3), two passes (mean, then centred second moment) on the row held in registers
+    if ((int)threadIdx.x < P) { s_g[threadIdx.x] = gl; s_b[threadIdx.x] = bl; }
 #pragma unroll
-    for (int q = 0; q < RPWV; ++q) {
+    for (int q = 0; q < MT; ++q) {
       float sum = 0.f;
 #pragma unroll
       for (int t = 0; t < LNK; ++t) sum += lnx[q][t];
@@ -398,7 +428,7 @@ __global__ __launch_bounds__(1024) void decode_joint_mfma_kernel(
 #pragma unroll
       for (int t = 0; t < LNK; ++t) { const float dlt = (lane + 64 * t < P) ? lnx[q][t] - mu : 0.f; qq += dlt * dlt; }
       qq = wave_sum(qq);
-      if (lane == 0 && w * RPWV + q < B) { s_mean[w * RPWV + q] = mu; s_rstd[w * RPWV + q] = rsqrtf(qq / P + ln_eps); }
+      if (lane == 0 && w * MT + q < B) { s_mean[w * MT + q] = mu; s_rstd[w * MT + q] = rsqrtf(qq / P + ln_eps); }
     }
   }
   __syncthreads();
@@ -408,13 +438,16 @@ __global__ __launch_bounds__(1024) void decode_joint_mfma_kernel(
 #pragma unroll
   for (int i = 0; i < GPW; ++i) {
     if (g0 + i >= g1) continue;
+    if (ln_g) {
+      const int k0 = (g0 + i) * 16 + g * 4;
+      const float4 gv = *reinterpret_cast<const float4*>(s_g + k0), bv = *reinterpret_cast<const float4*>(s_b + k0);
 #pragma unroll
-    for (int m = 0; m < MT; ++m) {
-      const int b = min(m * 16 + r, B - 1);
-      const float mu = ln_g ? s_mean[b] : 0.f, rs = ln_g ? s_rstd[b] : 1.f;
-      const float4 x = a[i][m];
-      a[i][m] = make_float4((x.x - mu) * rs * gv[i].x + bv[i].x, (x.y - mu) * rs * gv[i].y + bv[i].y, (x.z - mu) * rs * gv[i].z + bv[i].z,
-                            (x.w - mu) * rs * gv[i].w + bv[i].w);
+      for (int m = 0; m < MT; ++m) {
+        const int b = min(m * 16 + r, B - 1);
+        const float mu = s_mean[b], rs = s_rstd[b];
+        const float4 x = a[i][m];
+        a[i][m] = make_float4((x.x - mu) * rs * gv.x + bv.x, (x.y - mu) * rs * gv.y + bv.y, (x.z - mu) * rs * gv.z + bv.z, (x.w - mu) * rs * gv.w + bv.w);
+      }
     }
     mfma_group<MT>(acc, a[i], bw[i]);
   }
@@ -424,23 +457,23 @@ __global__ __launch_bounds__(1024) void decode_joint_mfma_kernel(
 
 // ---- 3'. vocabulary projection for 16 classes per workgroup ----
 template <int MT>
-__global__ __launch_bounds__(1024) void decode_vocab_mfma_kernel(const float* __restrict__ z, const float* __restrict__ Wv, const float* __restrict__ bv,
+__global__ __launch_bounds__(1024) void decode_vocab_mfma_kernel(const float* __restrict__ z, const float* __restrict__ pk, const float* __restrict__ bv,
                                                                  const int32_t* __restrict__ active, float* __restrict__ logits, int B, int J, int V) {
   __shared__ float part[NWV * MT * 16 * 16];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
   const int v0 = blockIdx.x * 16;
-  const int col = min(v0 + r, V - 1);
+  const float* tile = pk + (long)blockIdx.x * J * 16;
   const int ngr = J / 16, per = (ngr + NWV - 1) / NWV;
   const int g0 = w * per, g1 = min(ngr, g0 + per);
   float bw[GPW][4];
   float4 a[GPW][MT];
 #pragma unroll
   for (int i = 0; i < GPW; ++i) {
-    const int k0 = min(g0 + i, max(g1 - 1, 0)) * 16 + g * 4;
+    const int gr = min(g0 + i, max(g1 - 1, 0));
 #pragma unroll
-    for (int j = 0; j < 4; ++j) bw[i][j] = Wv[(long)(k0 + j) * V + col];
+    for (int j = 0; j < 4; ++j) bw[i][j] = tile[(gr * 4 + j) * 64 + lane];
 #pragma unroll
-    for (int m = 0; m < MT; ++m) a[i][m] = *reinterpret_cast<const float4*>(z + (long)min(m * 16 + r, B - 1) * J + k0);
+    for (int m = 0; m < MT; ++m) a[i][m] = *reinterpret_cast<const float4*>(z + (long)min(m * 16 + r, B - 1) * J + gr * 16 + g * 4);
   }
   const int eb = threadIdx.x >> 4, ec = threadIdx.x & 15;
   const bool ethr = threadIdx.x < B * 16 && v0 + ec < V;
@@ -457,29 +490,55 @@ __global__ __launch_bounds__(1024) void decode_vocab_mfma_kernel(const float* __
 }
 
 template <int MT>
-int launch_decode_mfma(const float* emb, const float* lstm_k, const float* lstm_rk, const float* lstm_b, const float* ln_g, const float* ln_b,
-                       const float* joint_pred_w, const float* joint_pred_b, const float* vocab_w, const float* vocab_b, const float* encj,
-                       const int32_t* nframes, const int32_t* frame_idx, const int32_t* tok_idx, const int32_t* prev_tok, const float* h,
-                       const float* c, int32_t* active, float* h_new, float* c_new, float* z, float* logits, int B, int T, int E, int P, int J,
-                       int V, int max_tokens, int mode, float ln_eps, hipStream_t s) {
-  hipLaunchKernelGGL(decode_lstm_mfma_kernel<MT>, dim3(P / 4), dim3(1024), 0, s, emb, lstm_k, lstm_rk, lstm_b, prev_tok, h, c, nframes, frame_idx,
-                     tok_idx, active, h_new, c_new, B, E, P, V, max_tokens, mode);
+int launch_decode_mfma(const float* emb, const float* packed, const float* lstm_b, const float* ln_g, const float* ln_b, const float* joint_pred_b,
+                       const float* vocab_b, const float* encj, const int32_t* nframes, const int32_t* frame_idx, const int32_t* tok_idx,
+                       const int32_t* prev_tok, const float* h, const float* c, int32_t* active, float* h_new, float* c_new, float* z,
+                       float* logits, int B, int T, int E, int P, int J, int V, int max_tokens, int mode, float ln_eps, hipStream_t s) {
+  const float* pj = packed + (long)(P / 4) * (E + P) * 16;
+  const float* pv = pj + (long)((J + 15) / 16) * P * 16;
+  hipLaunchKernelGGL(decode_lstm_mfma_kernel<MT>, dim3(P / 4), dim3(1024), 0, s, emb, packed, lstm_b, prev_tok, h, c, nframes, frame_idx, tok_idx,
+                     active, h_new, c_new, B, E, P, V, max_tokens, mode);
   TFASR_CHECK_LAUNCH();
-  hipLaunchKernelGGL(decode_joint_mfma_kernel<MT>, dim3((J + 15) / 16), dim3(1024), 0, s, h_new, ln_g, ln_b, joint_pred_w, joint_pred_b, encj, nframes,
-                     frame_idx, active, z, B, T, P, J, ln_eps);
+#define TFASR_DJ(L) hipLaunchKernelGGL((decode_joint_mfma_kernel<MT, L>), dim3((J + 15) / 16), dim3(1024), 0, s, h_new, ln_g, ln_b, pj, joint_pred_b, encj, \
+                                       nframes, frame_idx, active, z, B, T, P, J, ln_eps)
+  if (P <= 320) TFASR_DJ(5);
+  else if (P <= 640) TFASR_DJ(10);
+  else TFASR_DJ(16);
+#undef TFASR_DJ
   TFASR_CHECK_LAUNCH();
-  hipLaunchKernelGGL(decode_vocab_mfma_kernel<MT>, dim3((V + 15) / 16), dim3(1024), 0, s, z, vocab_w, vocab_b, active, logits, B, J, V);
+  hipLaunchKernelGGL(decode_vocab_mfma_kernel<MT>, dim3((V + 15) / 16), dim3(1024), 0, s, z, pv, vocab_b, active, logits, B, J, V);
   TFASR_CHECK_LAUNCH();
   return TFASR_STATUS_SUCCESS;
 }
 
+// shapes the MFMA kernels take (packed weights): whole groups of 16 k, a wave's share of the k range within its register budget
+bool mfma_shapes(int E, int P, int J) {
+  return (E % 16) == 0 && (P % 16) == 0 && (J % 16) == 0 && (E + P) <= 16 * NWV * GPW && P <= 1024 && J <= 16 * NWV * GPW;
+}
+
 }  // namespace
+
+extern "C" size_t tfasr_decode_pack_floats(int E, int P, int J, int V) {
+  if (E <= 0 || P <= 0 || J <= 0 || V <= 1 || !mfma_shapes(E, P, J)) return 0;
+  return (size_t)(P / 4) * (E + P) * 16 + (size_t)((J + 15) / 16) * P * 16 + (size_t)((V + 15) / 16) * J * 16;
+}
+
+extern "C" int tfasr_decode_pack(const float* lstm_k, const float* lstm_rk, const float* joint_pred_w, const float* vocab_w, float* packed, int E,
+                                 int P, int J, int V, void* stream_) {
+  if (!lstm_k || !lstm_rk || !joint_pred_w || !vocab_w || !packed) return TFASR_STATUS_INVALID_VALUE;
+  const size_t n = tfasr_decode_pack_floats(E, P, J, V);
+  if (n == 0) return TFASR_STATUS_UNSUPPORTED;
+  hipLaunchKernelGGL(decode_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, lstm_k, lstm_rk, joint_pred_w, vocab_w,
+                     packed, E, P, J, V);
+  TFASR_CHECK_LAUNCH();
+  return TFASR_STATUS_SUCCESS;
+}
 
 extern "C" int tfasr_decode_step(const float* emb, const float* lstm_k, const float* lstm_rk, const float* lstm_b, const float* ln_g,
                                  const float* ln_b, const float* joint_pred_w, const float* joint_pred_b, const float* vocab_w,
-                                 const float* vocab_b, const float* encj, const int32_t* nframes, const int32_t* frame_idx,
-                                 const int32_t* tok_idx, const int32_t* prev_tok, const float* h, const float* c, int32_t* active,
-                                 float* h_new, float* c_new, float* z, float* logits, int B, int T, int E, int P, int J, int V,
+                                 const float* vocab_b, const float* packed, const float* encj, const int32_t* nframes,
+                                 const int32_t* frame_idx, const int32_t* tok_idx, const int32_t* prev_tok, const float* h, const float* c,
+                                 int32_t* active, float* h_new, float* c_new, float* z, float* logits, int B, int T, int E, int P, int J, int V,
                                  int max_tokens, int mode, float ln_eps, void* stream_) {
   if (!emb || !lstm_k || !lstm_rk || !lstm_b || !joint_pred_w || !joint_pred_b || !vocab_w || !vocab_b || !encj || !nframes || !frame_idx ||
       !tok_idx || !prev_tok || !h || !c || !active || !h_new || !c_new || !z || !logits)
@@ -489,10 +548,11 @@ extern "C" int tfasr_decode_step(const float* emb, const float* lstm_k, const fl
     return TFASR_STATUS_UNSUPPORTED;  // float4 weight loads
   hipStream_t s = (hipStream_t)stream_;
   static const bool mfma_off = getenv("TFASR_DECODE_MFMA") && getenv("TFASR_DECODE_MFMA")[0] == '0';  // A/B probe: the vector-ALU kernels
-  if (!mfma_off && (E % 16) == 0 && (P % 16) == 0 && (J % 16) == 0 && (E + P) <= 16 * NWV * GPW && P <= 1024 && ((((uintptr_t)emb | (uintptr_t)h | (uintptr_t)h_new | (uintptr_t)z | (uintptr_t)ln_g | (uintptr_t)ln_b) & 15) == 0)) {
+  if (packed && !mfma_off && mfma_shapes(E, P, J) &&
+      ((((uintptr_t)emb | (uintptr_t)h | (uintptr_t)h_new | (uintptr_t)z | (uintptr_t)packed) & 15) == 0)) {
     const int mt = (B + 15) / 16;
-#define TFASR_DM(M) return launch_decode_mfma<M>(emb, lstm_k, lstm_rk, lstm_b, ln_g, ln_b, joint_pred_w, joint_pred_b, vocab_w, vocab_b, encj, nframes, frame_idx, \
-                                                 tok_idx, prev_tok, h, c, active, h_new, c_new, z, logits, B, T, E, P, J, V, max_tokens, mode, ln_eps, s)
+#define TFASR_DM(M) return launch_decode_mfma<M>(emb, packed, lstm_b, ln_g, ln_b, joint_pred_b, vocab_b, encj, nframes, frame_idx, tok_idx, prev_tok, h, c, \
+                                                 active, h_new, c_new, z, logits, B, T, E, P, J, V, max_tokens, mode, ln_eps, s)
     if (mt == 1) TFASR_DM(1);
     if (mt == 2) TFASR_DM(2);
     if (mt == 3) TFASR_DM(3);
@@ -515,14 +575,15 @@ extern "C" int tfasr_decode_step(const float* emb, const float* lstm_k, const fl
 // are no-ops on the device (active[0] == 0), so the caller checks `active` only every `iters` iterations.
 extern "C" int tfasr_decode_steps(const float* emb, const float* lstm_k, const float* lstm_rk, const float* lstm_b, const float* ln_g,
                                   const float* ln_b, const float* joint_pred_w, const float* joint_pred_b, const float* vocab_w,
-                                  const float* vocab_b, const float* encj, const int32_t* nframes, int32_t* frame_idx, int32_t* tok_idx,
-                                  int32_t* prev_tok, float* h, float* c, int32_t* active, float* h_new, float* c_new, float* z, float* logits,
-                                  int32_t* tokens, int32_t* per_frame, int B, int T, int E, int P, int J, int V, int max_tokens, int blank,
-                                  int mode, int max_tokens_per_frame, float ln_eps, int iters, void* stream_) {
+                                  const float* vocab_b, const float* packed, const float* encj, const int32_t* nframes, int32_t* frame_idx,
+                                  int32_t* tok_idx, int32_t* prev_tok, float* h, float* c, int32_t* active, float* h_new, float* c_new, float* z,
+                                  float* logits, int32_t* tokens, int32_t* per_frame, int B, int T, int E, int P, int J, int V, int max_tokens,
+                                  int blank, int mode, int max_tokens_per_frame, float ln_eps, int iters, void* stream_) {
   if (iters <= 0 || !tokens) return TFASR_STATUS_INVALID_VALUE;
   for (int i = 0; i < iters; ++i) {
-    int st = tfasr_decode_step(emb, lstm_k, lstm_rk, lstm_b, ln_g, ln_b, joint_pred_w, joint_pred_b, vocab_w, vocab_b, encj, nframes, frame_idx,
-                               tok_idx, prev_tok, h, c, active, h_new, c_new, z, logits, B, T, E, P, J, V, max_tokens, mode, ln_eps, stream_);
+    int st = tfasr_decode_step(emb, lstm_k, lstm_rk, lstm_b, ln_g, ln_b, joint_pred_w, joint_pred_b, vocab_w, vocab_b, packed, encj, nframes,
+                               frame_idx, tok_idx, prev_tok, h, c, active, h_new, c_new, z, logits, B, T, E, P, J, V, max_tokens, mode, ln_eps,
+                               stream_);
     if (st != TFASR_STATUS_SUCCESS) return st;
     st = tfasr_decode_update(logits, active, nframes, frame_idx, prev_tok, tok_idx, tokens, per_frame, h_new, c_new, h, c, B, V, P, max_tokens, blank,
                              mode, max_tokens_per_frame, TFASR_F32, stream_);

@@ -712,15 +712,31 @@ def decode_prepare(encj, nframes, frame_idx, tok_idx, active, ecur, max_tokens, 
                                     mode, _dt(encj), _stream()), "decode_prepare")
 
 
+def decode_pack(lstm_k, lstm_rk, wjp, wv, emb_dim):
+    """The four f32 weight matrices of a search step in the MFMA kernels' tile order (csrc/decode_step.hip); None when the shapes have no
+    MFMA route (the step then runs on the row-major masters).  Made once per recognize call: the weights are constants of the search."""
+    P = lstm_rk.shape[0]
+    J, V = wv.shape
+    n = int(_L().tfasr_decode_pack_floats(int(emb_dim), P, J, V))
+    if n == 0:
+        return None
+    packed = torch.empty(n, dtype=torch.float32, device=lstm_k.device)
+    st = _L().tfasr_decode_pack(_p(lstm_k), _p(lstm_rk), _p(wjp), _p(wv), _p(packed), int(emb_dim), P, J, V, _stream())
+    if st == _lib.STATUS_UNSUPPORTED:
+        return None
+    check(st, "decode_pack")
+    return packed
+
+
 def decode_step(emb, lstm_k, lstm_rk, lstm_b, ln_g, ln_b, wjp, bjp, wv, bv, encj, nframes, frame_idx, tok_idx, prev_tok, h, c, active, h_new, c_new,
-                z, logits, max_tokens, mode, ln_eps=1e-3):
+                z, logits, max_tokens, mode, ln_eps=1e-3, packed=None):
     """Fused search step (three launches up to the f32 logits); returns False when the shapes need the per-op route."""
     B, T, J = encj.shape
     V, E = emb.shape
     P = h.shape[1]
-    st = _L().tfasr_decode_step(_p(emb), _p(lstm_k), _p(lstm_rk), _p(lstm_b), _p(ln_g), _p(ln_b), _p(wjp), _p(bjp), _p(wv), _p(bv), _p(encj),
-                                _p(nframes), _p(frame_idx), _p(tok_idx), _p(prev_tok), _p(h), _p(c), _p(active), _p(h_new), _p(c_new), _p(z),
-                                _p(logits), B, T, E, P, J, V, max_tokens, mode, ln_eps, _stream())
+    st = _L().tfasr_decode_step(_p(emb), _p(lstm_k), _p(lstm_rk), _p(lstm_b), _p(ln_g), _p(ln_b), _p(wjp), _p(bjp), _p(wv), _p(bv), _p(packed),
+                                _p(encj), _p(nframes), _p(frame_idx), _p(tok_idx), _p(prev_tok), _p(h), _p(c), _p(active), _p(h_new), _p(c_new),
+                                _p(z), _p(logits), B, T, E, P, J, V, max_tokens, mode, ln_eps, _stream())
     if st == _lib.STATUS_UNSUPPORTED:
         return False
     check(st, "decode_step")
@@ -728,15 +744,15 @@ def decode_step(emb, lstm_k, lstm_rk, lstm_b, ln_g, ln_b, wjp, bjp, wv, bv, encj
 
 
 def decode_steps(emb, lstm_k, lstm_rk, lstm_b, ln_g, ln_b, wjp, bjp, wv, bv, encj, nframes, frame_idx, tok_idx, prev_tok, h, c, active, h_new, c_new,
-                 z, logits, tokens, per_frame, max_tokens, blank, mode, max_tokens_per_frame, iters, ln_eps=1e-3):
+                 z, logits, tokens, per_frame, max_tokens, blank, mode, max_tokens_per_frame, iters, ln_eps=1e-3, packed=None):
     """`iters` fused search iterations from one host call; False when the shapes need the per-op route."""
     B, T, J = encj.shape
     V, E = emb.shape
     P = h.shape[1]
-    st = _L().tfasr_decode_steps(_p(emb), _p(lstm_k), _p(lstm_rk), _p(lstm_b), _p(ln_g), _p(ln_b), _p(wjp), _p(bjp), _p(wv), _p(bv), _p(encj),
-                                 _p(nframes), _p(frame_idx), _p(tok_idx), _p(prev_tok), _p(h), _p(c), _p(active), _p(h_new), _p(c_new), _p(z),
-                                 _p(logits), _p(tokens), _p(per_frame), B, T, E, P, J, V, max_tokens, blank, mode, max_tokens_per_frame, ln_eps,
-                                 int(iters), _stream())
+    st = _L().tfasr_decode_steps(_p(emb), _p(lstm_k), _p(lstm_rk), _p(lstm_b), _p(ln_g), _p(ln_b), _p(wjp), _p(bjp), _p(wv), _p(bv), _p(packed),
+                                 _p(encj), _p(nframes), _p(frame_idx), _p(tok_idx), _p(prev_tok), _p(h), _p(c), _p(active), _p(h_new), _p(c_new),
+                                 _p(z), _p(logits), _p(tokens), _p(per_frame), B, T, E, P, J, V, max_tokens, blank, mode, max_tokens_per_frame,
+                                 ln_eps, int(iters), _stream())
     if st == _lib.STATUS_UNSUPPORTED:
         return False
     check(st, "decode_steps")
