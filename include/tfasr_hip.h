@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define TFASR_ABI_VERSION 25
+#define TFASR_ABI_VERSION 26
 
 typedef enum {
   TFASR_STATUS_SUCCESS = 0,
@@ -413,13 +413,15 @@ int tfasr_decode_steps(const float* emb, const float* lstm_k, const float* lstm_
                        int32_t* tok_idx, int32_t* prev_tok, float* h, float* c, int32_t* active, float* h_new, float* c_new, float* z,
                        float* logits, int32_t* tokens, int32_t* per_frame, int B, int T, int E, int P, int J, int V, int max_tokens,
                        int blank, int mode, int max_tokens_per_frame, float ln_eps, int iters, void* stream);
-/* `packed` of the two entry points above (NULL: the vector-ALU kernels on the row-major masters): the four weight matrices of a search
- * step re-laid once per recognize call so that the 16 output columns of a workgroup of the exact-f32 MFMA kernels are contiguous, in
- * fragment order (csrc/decode_step.hip).  tfasr_decode_pack_floats = floats `packed` must hold, 0 when the shapes have no MFMA route
- * (E, P, J % 16, P <= 1024, E + P and J <= 1280): pass NULL then. */
+/* `packed` of the two entry points above (NULL: the vector-ALU kernels on the row-major masters): the weights of a search step re-laid
+ * once per recognize call for the exact-f32 MFMA kernels (csrc/decode_step.hip): the recurrent kernel, the joint's prediction projection
+ * and the vocabulary projection with the 16 output columns of a workgroup contiguous in fragment order, and G = emb @ lstm_k [V, 4P]
+ * (keras LSTM: x @ kernel is a product of its own), so that a step gathers the input half of the pre-activation instead of multiplying
+ * the embedding row again.  tfasr_decode_pack_floats = floats `packed` must hold, 0 when the shapes have no MFMA route (P, J % 16,
+ * P <= 1024, J <= 1280): pass NULL then.  With `packed`, `z` also carries the gathered encoder frames between the step's launches. */
 size_t tfasr_decode_pack_floats(int E, int P, int J, int V);
-int tfasr_decode_pack(const float* lstm_k, const float* lstm_rk, const float* joint_pred_w, const float* vocab_w, float* packed, int E,
-                      int P, int J, int V, void* stream);
+int tfasr_decode_pack(const float* emb, const float* lstm_k, const float* lstm_rk, const float* joint_pred_w, const float* vocab_w,
+                      float* packed, int E, int P, int J, int V, void* stream);
 int tfasr_decode_update(const void* logits, const int32_t* active, const int32_t* nframes, int32_t* frame_idx,
                         int32_t* prev_tok, int32_t* tok_idx, int32_t* tokens, int32_t* per_frame, const void* h_new,
                         const float* c_new, void* h, float* c, int B, int V, int P, int max_tokens, int blank, int mode,

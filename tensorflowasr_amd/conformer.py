@@ -1276,7 +1276,7 @@ class ConformerTransducer(BaseModel):
         zbuf = torch.empty(B, J, dtype=f32, device=dev)
         lng, lnb = (ps.p("pred/ln/g"), ps.p("pred/ln/b")) if c.prediction_layer_norm else (None, None)
         fused = B <= 64 and os.environ.get("TFASR_DECODE_FUSED", "1") != "0"
-        packed = K.decode_pack(Wk, Wrk, Wjp, Wv, ps.p("pred/emb").shape[1]) if fused else None  # tile order of the MFMA step kernels
+        packed = K.decode_pack(ps.p("pred/emb"), Wk, Wrk, Wjp, Wv) if fused else None  # tile order of the MFMA step kernels
         while it < max_iters:
             n = min(check_every * 4 if fused else check_every, max_iters - it)  # fused iterations are cheap no-ops once the loop has ended
             if fused:

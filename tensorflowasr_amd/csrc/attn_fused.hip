@@ -766,10 +766,9 @@ __global__ __launch_bounds__(256, 2) void relattn_fused_bwd_q_kernel(
         }
         ds[e][jt] = d;
         if constexpr (V2) {
-          if (inrow[e] && jin) {
-            prow_e[e][jt * 16 + j0] = f32_to_bf16(valid_r ? d : 0.f);
-            if (!valid_r) bias_acc[e] += d;
-          }
+          // (dS itself leaves through the LDS image below as whole 16-byte row pieces: sixteen 2-byte global stores per lane and key
+          // block kept the CU's address path busy longer than everything else in the iteration)
+          if (inrow[e] && jin && !valid_r) bias_acc[e] += d;
         } else {
           if (inrow[e] && jin) {
             if (valid_r) prow_e[e][jt * 16 + j0] = f32_to_bf16(d);
@@ -806,6 +805,21 @@ __global__ __launch_bounds__(256, 2) void relattn_fused_bwd_q_kernel(
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (V2) {
+      // unskewed dS [16 il][64 jl] -> HBM from the A image: lane = (row il, 8 keys), pairs outside the sample's 2 len - 1 relative
+      // positions zeroed (their gradient went to the bias row); columns T .. Tp-1 of a ragged last key block are never read
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int piece = q * 64 + lane, il = piece >> 3, cpc = piece & 7;
+        const int i = i0 + w * 16 + il, jc = j0 + cpc * 8;
+        uint4 v = *reinterpret_cast<const uint4*>(sA + il * 128 + ((cpc ^ key_d(il)) << 4));
+        if (i < T && jc < ldp) {
+          const int nval = lim - (T - 1 - i) - jc;  // keys jc .. jc + nval - 1 of this piece have a relative position inside the table
+          uint32_t* vv = reinterpret_cast<uint32_t*>(&v);
+#pragma unroll
+          for (int dd = 0; dd < 4; ++dd) vv[dd] &= (2 * dd < nval ? 0x0000ffffu : 0u) | (2 * dd + 1 < nval ? 0xffff0000u : 0u);
+          *reinterpret_cast<uint4*>(dpos + (((long)b * H + h) * T + i) * ldp + jc) = v;
+        }
+      }
       // dqv += dG @ window   (A: skewed image, k = window column c; B: the window rows read transposed, k = c)
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {

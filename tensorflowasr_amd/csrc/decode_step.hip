@@ -12,10 +12,19 @@
 // matrices stay resident in the L2 of the XCD that owns those columns across the iterations of the search.
 #include "common.h"
 #include <stdlib.h>
+#include <string.h>
 
 namespace {
 
 constexpr int MAXB = 64;
+#ifdef TFASR_DECODE_TIMING
+// probe builds (tools/decode_timing.sh): shader-clock stamps of thread 0 of the middle workgroup of each step kernel, [kernel][stamp];
+// stamp 15 = the 100 MHz wall clock at entry, 14 = at exit
+__device__ long long g_dec_t[4][16];
+#define DEC_T(kern, k) { if (threadIdx.x == 0 && blockIdx.x == gridDim.x / 2) g_dec_t[kern][k] = (k) >= 14 ? (long long)__builtin_amdgcn_s_memrealtime() : (long long)__builtin_readcyclecounter(); }
+#else
+#define DEC_T(kern, k)
+#endif
 constexpr int NT = 1024;  // threads per workgroup: 16 k-slices at B = 64, 32 at B = 32 (short dependent load chains per thread)
 
 // acc[c] += sum_{k in slice} x(k) * W[k * ldw + col0 + c]   for c < NC (NC % 4 == 0, col0 % 4 == 0 -> float4 loads)
@@ -274,22 +283,39 @@ __device__ __forceinline__ float sum_partials(const float* part, int b, int cidx
 // of the tile] - a wave's load of MFMA j's B operand is 256 contiguous bytes.  In the [K, N] row-major masters a workgroup's columns are
 // 16-byte (LSTM: 4 units x 4 gates, gate stride P) or 64-byte pieces of a row, every piece in another cache line than the next k's: the
 // fetches moved 4-8x the bytes they used and the 13 MB of weights cost 20+ us per iteration.
+// Sections of `packed`: [recurrent kernel tiles (P/4) x P x 16] [joint tiles] [vocabulary tiles] [G = emb @ Wk, [V][P/4][16]] [Wk with
+// its columns in G's order, [E][P/4][16]].  G is the input half of the LSTM pre-activation for EVERY token (keras: x @ kernel, a product
+// of its own, lstm.py [ext]): the step then gathers 64 bytes per (row, workgroup) instead of multiplying the embedding row again, the
+// k range of the step's product shrinks from E + P to P, and the token -> embedding dependent load leaves the critical path (it is
+// consumed by the cell epilogue only).  Column order inside a G tile: u * 4 + q (unit-major: a cell thread's four gates = one float4).
+struct PackDims { long nl, nj, nv, ng, nk; };
+__host__ __device__ inline PackDims pack_dims(int E, int P, int J, int V) {
+  PackDims d;
+  d.nl = (long)(P / 4) * P * 16; d.nj = (long)((J + 15) / 16) * P * 16; d.nv = (long)((V + 15) / 16) * J * 16;
+  d.ng = (long)V * 4 * P; d.nk = (long)E * 4 * P;
+  return d;
+}
 __global__ __launch_bounds__(256) void decode_pack_kernel(const float* __restrict__ Wk, const float* __restrict__ Wr, const float* __restrict__ Wjp,
                                                           const float* __restrict__ Wv, float* __restrict__ out, int E, int P, int J, int V) {
-  const long nl = (long)(P / 4) * (E + P) * 16, nj = (long)((J + 15) / 16) * P * 16, nv = (long)((V + 15) / 16) * J * 16;
+  const PackDims dm = pack_dims(E, P, J, V);
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= nl + nj + nv) return;
-  const int sec = idx < nl ? 0 : (idx < nl + nj ? 1 : 2);
-  const long o = idx - (sec == 0 ? 0 : (sec == 1 ? nl : nl + nj));
-  const int K = sec == 0 ? E + P : (sec == 1 ? P : J);
+  if (idx >= dm.nl + dm.nj + dm.nv + dm.nk) return;
+  if (idx >= dm.nl + dm.nj + dm.nv) {  // Wk, columns in tile order: [e][t][u * 4 + q] = Wk[e][q * P + 4 t + u]
+    const long o = idx - (dm.nl + dm.nj + dm.nv);
+    const int e = (int)(o / (4 * P)), cidx = (int)(o % (4 * P)), t = cidx >> 4, u = (cidx >> 2) & 3, q = cidx & 3;
+    out[dm.nl + dm.nj + dm.nv + dm.ng + o] = Wk[(long)e * 4 * P + (long)q * P + t * 4 + u];
+    return;
+  }
+  const int sec = idx < dm.nl ? 0 : (idx < dm.nl + dm.nj ? 1 : 2);
+  const long o = idx - (sec == 0 ? 0 : (sec == 1 ? dm.nl : dm.nl + dm.nj));
+  const int K = sec == 2 ? J : P;
   const long tile = o / ((long)K * 16);
   const int rem = (int)(o - tile * K * 16);
   const int grp = rem >> 8, j = (rem >> 6) & 3, g = (rem >> 4) & 3, r = rem & 15;
   const int k = grp * 16 + 4 * g + j;
   float v = 0.f;
   if (sec == 0) {
-    const long col = (long)(r >> 2) * P + tile * 4 + (r & 3);  // column r of the tile = gate r / 4, unit 4 tile + r % 4
-    v = k < E ? Wk[(long)k * 4 * P + col] : Wr[(long)(k - E) * 4 * P + col];
+    v = Wr[(long)k * 4 * P + (long)(r >> 2) * P + tile * 4 + (r & 3)];  // column r of the tile = gate r / 4, unit 4 tile + r % 4
   } else if (sec == 1) {
     const long col = tile * 16 + r;
     if (col < J) v = Wjp[(long)k * J + col];
@@ -300,91 +326,121 @@ __global__ __launch_bounds__(256) void decode_pack_kernel(const float* __restric
   out[idx] = v;
 }
 
-// ---- 1'. embedding + LSTM cell for 4 hidden units (16 gate columns) per workgroup ----
+// the while_loop condition of the reference loops (see loop_active above) without LDS or barriers: every wave evaluates the B <= 64 rows
+// itself, one row per lane
+__device__ __forceinline__ bool loop_active_wave(int fi, int nf, int ti, int lane, int B, int max_tokens, int mode) {
+  const bool in = lane < B;
+  const bool frames_left = in && (mode == 0 ? !(fi >= nf - 1) : (fi < nf));
+  const bool tokens_left = in && (mode == 0 ? !(ti >= max_tokens - 1) : true);
+  const bool all_frames = __ballot(frames_left) == 0, all_tokens = __ballot(tokens_left) == 0;
+  return !(all_frames || all_tokens);
+}
+
+// ---- 1'. embedding + LSTM cell for 4 hidden units (16 gate columns) per workgroup; side job of workgroups 0 .. B-1: the encoder
+// frame of row b for the joint kernel (ecur [B, J], a dependent gather that kernel no longer waits for) ----
 template <int MT>
 __global__ __launch_bounds__(1024) void decode_lstm_mfma_kernel(
-    const float* __restrict__ emb, const float* __restrict__ pk, const float* __restrict__ bias,
-    const int32_t* __restrict__ prev_tok, const float* __restrict__ h, const float* __restrict__ c, const int32_t* __restrict__ nframes,
+    const float* __restrict__ G, const float* __restrict__ pk, const float* __restrict__ bias, const int32_t* __restrict__ prev_tok,
+    const float* __restrict__ h, const float* __restrict__ c, const float* __restrict__ encj, const int32_t* __restrict__ nframes,
     const int32_t* __restrict__ frame_idx, const int32_t* __restrict__ tok_idx, int32_t* __restrict__ active, float* __restrict__ h_new,
-    float* __restrict__ c_new, int B, int E, int P, int V, int max_tokens, int mode) {
+    float* __restrict__ c_new, float* __restrict__ ecur, int B, int T, int P, int J, int V, int max_tokens, int mode) {
   __shared__ float part[NWV * MT * 16 * 16];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
   const int u0 = blockIdx.x * 4;
-  const float* tile = pk + (long)blockIdx.x * (E + P) * 16;
-  const int ngr = (E + P) / 16, per = (ngr + NWV - 1) / NWV;  // per <= GPW (checked by the host)
+  const float* tile = pk + (long)blockIdx.x * P * 16;
+  DEC_T(0, 15) DEC_T(0, 0)
+  const int ngr = P / 16, per = (ngr + NWV - 1) / NWV;  // per <= GPW (checked by the host)
   const int g0 = w * per, g1 = min(ngr, g0 + per);
-  // round trip 1: everything that depends on no other load - the previous tokens first (the embedding rows hang off them), the weights of
-  // this wave's groups, the h rows
+  // ONE batch of independent loads: the previous tokens of the cell threads (the G rows hang off them), the loop condition's counters,
+  // the weights of this wave's groups, the h rows, the cell operands
+  const int eb = threadIdx.x >> 2, eu = threadIdx.x & 3;
+  const bool cell = (int)threadIdx.x < B * 4;
+  const int etok = cell ? prev_tok[eb] : 0;
+  int fi = 0, nf = 1, ti = 0;
+  if (lane < B) { fi = frame_idx[lane]; nf = nframes[lane]; ti = tok_idx[lane]; }
   float bw[GPW][4];
   float4 a[GPW][MT];
-  int tok[MT];
-#pragma unroll
-  for (int m = 0; m < MT; ++m) tok[m] = prev_tok[min(m * 16 + r, B - 1)];
 #pragma unroll
   for (int i = 0; i < GPW; ++i) {
     const int gr = min(g0 + i, max(g1 - 1, 0));
 #pragma unroll
     for (int j = 0; j < 4; ++j) bw[i][j] = tile[(gr * 4 + j) * 64 + lane];
-    if (gr * 16 >= E) {  // (E % 16 == 0: a group never straddles the two operands)
 #pragma unroll
-      for (int m = 0; m < MT; ++m) a[i][m] = *reinterpret_cast<const float4*>(h + (long)min(m * 16 + r, B - 1) * P + gr * 16 + g * 4 - E);
-    }
+    for (int m = 0; m < MT; ++m) a[i][m] = *reinterpret_cast<const float4*>(h + (long)min(m * 16 + r, B - 1) * P + gr * 16 + g * 4);
   }
-  // cell operands of the epilogue threads (independent of the products)
-  const int eb = threadIdx.x >> 2, eu = threadIdx.x & 3;
   float cb[4] = {0.f, 0.f, 0.f, 0.f}, cprev = 0.f;
-  if (threadIdx.x < B * 4) {
+  if (cell) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) cb[q] = bias[q * P + u0 + eu];
     cprev = c[(long)eb * P + u0 + eu];
   }
-  // round trip 2 (waits for the tokens only - loads retire in order): the embedding rows of the previous tokens
-#pragma unroll
-  for (int i = 0; i < GPW; ++i) {
-    const int gr = min(g0 + i, max(g1 - 1, 0));
-    if (gr * 16 < E) {
-#pragma unroll
-      for (int m = 0; m < MT; ++m) a[i][m] = *reinterpret_cast<const float4*>(emb + (long)min(max(tok[m], 0), V - 1) * E + gr * 16 + g * 4);
-    }
-  }
-  const bool act = loop_active(nframes, frame_idx, tok_idx, B, max_tokens, mode);
+  // second round trip, consumed by the cell epilogue only: x @ Wk of the previous token = one float4 of G (gates i, f, g, o of this unit)
+  float4 xg = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (cell) xg = *reinterpret_cast<const float4*>(G + ((long)min(max(etok, 0), V - 1) * (P / 4) + blockIdx.x) * 16 + eu * 4);
+  DEC_T(0, 1)
+  const bool act = loop_active_wave(fi, nf, ti, lane, B, max_tokens, mode);
+  DEC_T(0, 2)
   if (blockIdx.x == 0 && threadIdx.x == 0) active[0] = act ? 1 : 0;
   if (!act) return;
+  // side job: ecur[b, :] = encj[b, min(frame, nframes - 1), :] for rows b = blockIdx.x, + gridDim.x, ... (loads here, stores at the end)
+  constexpr int EC = 2;  // J <= 2048
+  float ev[EC];
+  const int eb0 = blockIdx.x;
+  if (eb0 < B) {
+    int f = min(frame_idx[eb0], nframes[eb0] - 1);
+    f = max(min(f, T - 1), 0);
+#pragma unroll
+    for (int t = 0; t < EC; ++t) { const int j = threadIdx.x + 1024 * t; ev[t] = j < J ? encj[((long)eb0 * T + f) * J + j] : 0.f; }
+  }
   float4_t acc[MT];
 #pragma unroll
   for (int m = 0; m < MT; ++m) acc[m] = float4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int i = 0; i < GPW; ++i)
     if (g0 + i < g1) mfma_group<MT>(acc, a[i], bw[i]);
+  DEC_T(0, 3)
   stash_partials<MT>(part, acc, w, r, g);
-  if (threadIdx.x < B * 4) {
-    float z[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) z[q] = cb[q] + sum_partials<MT>(part, eb, q * 4 + eu);
-    const float ig = sigmoidf_(z[0]), fg = sigmoidf_(z[1]), gg = tanh_fast(z[2]), og = sigmoidf_(z[3]);
+  DEC_T(0, 4)
+  if (cell) {
+    // keras LSTMCell: z = x @ kernel + h @ recurrent_kernel, then + bias
+    const float zi = (xg.x + sum_partials<MT>(part, eb, 0 * 4 + eu)) + cb[0], zf = (xg.y + sum_partials<MT>(part, eb, 1 * 4 + eu)) + cb[1];
+    const float zg = (xg.z + sum_partials<MT>(part, eb, 2 * 4 + eu)) + cb[2], zo = (xg.w + sum_partials<MT>(part, eb, 3 * 4 + eu)) + cb[3];
+    const float ig = sigmoidf_(zi), fg = sigmoidf_(zf), gg = tanh_fast(zg), og = sigmoidf_(zo);
     const float cn = fg * cprev + ig * gg;
     c_new[(long)eb * P + u0 + eu] = cn;
     h_new[(long)eb * P + u0 + eu] = og * tanh_fast(cn);
   }
+  if (eb0 < B) {
+#pragma unroll
+    for (int t = 0; t < EC; ++t) { const int j = threadIdx.x + 1024 * t; if (j < J) ecur[(long)eb0 * J + j] = ev[t]; }
+    for (int bb = eb0 + gridDim.x; bb < B; bb += gridDim.x) {  // (fewer workgroups than rows: P < 4 B)
+      int f = min(frame_idx[bb], nframes[bb] - 1);
+      f = max(min(f, T - 1), 0);
+      for (int j = threadIdx.x; j < J; j += 1024) ecur[(long)bb * J + j] = encj[((long)bb * T + f) * J + j];
+    }
+  }
+  DEC_T(0, 5) DEC_T(0, 14)
 }
 
 // ---- 2'. LayerNorm + prediction projection + tanh(enc + pred) for 16 joint columns per workgroup ----
-// LNK = floats of a prediction row per lane (P <= 64 LNK); a wave owns MT rows of the LayerNorm statistics (16 MT rows / 16 waves)
-template <int MT, int LNK>
+// The LayerNorm statistics come from the MFMA A fragments the waves hold anyway (a wave = its k slice of EVERY row): two LDS
+// reductions (sum, then centred squares - keras' two passes) instead of a second copy of the rows in other registers, which doubled the
+// bytes every CU pulls through its L1 (only J / 16 workgroups run, so the launch is bound by per-CU load bandwidth).  `ecur` [B, J] =
+// the encoder frames the LSTM kernel gathered (may alias z: a thread reads its element before it writes it).
+template <int MT>
 __global__ __launch_bounds__(1024) void decode_joint_mfma_kernel(
     const float* __restrict__ h_new, const float* __restrict__ ln_g, const float* __restrict__ ln_b, const float* __restrict__ pk,
-    const float* __restrict__ bjp, const float* __restrict__ encj, const int32_t* __restrict__ nframes,
-    const int32_t* __restrict__ frame_idx, const int32_t* __restrict__ active, float* __restrict__ z, int B, int T, int P, int J,
-    float ln_eps) {
+    const float* __restrict__ bjp, const float* ecur, const int32_t* __restrict__ active, float* z, int B, int P, int J, float ln_eps) {
   __shared__ float part[NWV * MT * 16 * 16];
-  __shared__ float s_mean[MAXB], s_rstd[MAXB];
+  __shared__ float s_red[2][NWV][MAXB];
   __shared__ __attribute__((aligned(16))) float s_g[1024], s_b[1024];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
   const int j0 = blockIdx.x * 16;
   const float* tile = pk + (long)blockIdx.x * P * 16;
+  DEC_T(1, 15) DEC_T(1, 0)
   const int ngr = P / 16, per = (ngr + NWV - 1) / NWV;
   const int g0 = w * per, g1 = min(ngr, g0 + per);
-  // one batch of loads: weights, raw prediction rows, LayerNorm coefficients (via LDS), the LayerNorm rows of this wave, the encoder frame
+  // one batch of loads: weights, raw prediction rows, LayerNorm coefficients (via LDS), the encoder frame, the bias
   float bw[GPW][4];
   float4 a[GPW][MT];
 #pragma unroll
@@ -395,43 +451,59 @@ __global__ __launch_bounds__(1024) void decode_joint_mfma_kernel(
 #pragma unroll
     for (int m = 0; m < MT; ++m) a[i][m] = *reinterpret_cast<const float4*>(h_new + (long)min(m * 16 + r, B - 1) * P + gr * 16 + g * 4);
   }
-  float lnx[MT][LNK];
   float gl = 1.f, bl = 0.f;
-  if (ln_g) {
-#pragma unroll
-    for (int q = 0; q < MT; ++q) {
-      const int b = min(w * MT + q, B - 1);
-#pragma unroll
-      for (int t = 0; t < LNK; ++t) lnx[q][t] = (lane + 64 * t < P) ? h_new[(long)b * P + lane + 64 * t] : 0.f;
-    }
-    if ((int)threadIdx.x < P) { gl = ln_g[threadIdx.x]; bl = ln_b[threadIdx.x]; }
-  }
+  if (ln_g && (int)threadIdx.x < P) { gl = ln_g[threadIdx.x]; bl = ln_b[threadIdx.x]; }
   const int eb = threadIdx.x >> 4, ec = threadIdx.x & 15;
   float ebias = 0.f, eenc = 0.f;
   const bool ethr = threadIdx.x < B * 16 && j0 + ec < J;
-  if (ethr) {
-    ebias = bjp[j0 + ec];
-    int f = min(frame_idx[eb], nframes[eb] - 1);
-    f = max(min(f, T - 1), 0);
-    eenc = encj[((long)eb * T + f) * J + j0 + ec];
-  }
+  if (ethr) { ebias = bjp[j0 + ec]; eenc = ecur[(long)eb * J + j0 + ec]; }
+  DEC_T(1, 1)
   if (!active[0]) return;
-  if (ln_g) {  // keras LayerNormalization (eps 1e-3), two passes (mean, then centred second moment) on the row held in registers
+  DEC_T(1, 2)
+  float mu[MT], rs[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) { mu[m] = 0.f; rs[m] = 1.f; }
+  if (ln_g) {  // keras LayerNormalization (eps 1e-3): mean, then the centred second moment
     if ((int)threadIdx.x < P) { s_g[threadIdx.x] = gl; s_b[threadIdx.x] = bl; }
 #pragma unroll
-    for (int q = 0; q < MT; ++q) {
+    for (int m = 0; m < MT; ++m) {
+      float ps = 0.f;
+#pragma unroll
+      for (int i = 0; i < GPW; ++i)
+        if (g0 + i < g1) ps += (a[i][m].x + a[i][m].y) + (a[i][m].z + a[i][m].w);
+      ps += __shfl_xor(ps, 16, 64);
+      ps += __shfl_xor(ps, 32, 64);
+      if (g == 0) s_red[0][w][m * 16 + r] = ps;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
       float sum = 0.f;
 #pragma unroll
-      for (int t = 0; t < LNK; ++t) sum += lnx[q][t];
-      const float mu = wave_sum(sum) / P;
-      float qq = 0.f;
+      for (int ww = 0; ww < NWV; ++ww) sum += s_red[0][ww][m * 16 + r];
+      mu[m] = sum / P;
+      float qs = 0.f;
 #pragma unroll
-      for (int t = 0; t < LNK; ++t) { const float dlt = (lane + 64 * t < P) ? lnx[q][t] - mu : 0.f; qq += dlt * dlt; }
-      qq = wave_sum(qq);
-      if (lane == 0 && w * MT + q < B) { s_mean[w * MT + q] = mu; s_rstd[w * MT + q] = rsqrtf(qq / P + ln_eps); }
+      for (int i = 0; i < GPW; ++i)
+        if (g0 + i < g1) {
+          const float d0 = a[i][m].x - mu[m], d1 = a[i][m].y - mu[m], d2 = a[i][m].z - mu[m], d3 = a[i][m].w - mu[m];
+          qs += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+        }
+      qs += __shfl_xor(qs, 16, 64);
+      qs += __shfl_xor(qs, 32, 64);
+      if (g == 0) s_red[1][w][m * 16 + r] = qs;
+    }
+    DEC_T(1, 3)
+    __syncthreads();
+    DEC_T(1, 4)
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      float sum = 0.f;
+#pragma unroll
+      for (int ww = 0; ww < NWV; ++ww) sum += s_red[1][ww][m * 16 + r];
+      rs[m] = rsqrtf(sum / P + ln_eps);
     }
   }
-  __syncthreads();
   float4_t acc[MT];
 #pragma unroll
   for (int m = 0; m < MT; ++m) acc[m] = float4_t{0.f, 0.f, 0.f, 0.f};
@@ -443,16 +515,18 @@ __global__ __launch_bounds__(1024) void decode_joint_mfma_kernel(
       const float4 gv = *reinterpret_cast<const float4*>(s_g + k0), bv = *reinterpret_cast<const float4*>(s_b + k0);
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
-        const int b = min(m * 16 + r, B - 1);
-        const float mu = s_mean[b], rs = s_rstd[b];
         const float4 x = a[i][m];
-        a[i][m] = make_float4((x.x - mu) * rs * gv.x + bv.x, (x.y - mu) * rs * gv.y + bv.y, (x.z - mu) * rs * gv.z + bv.z, (x.w - mu) * rs * gv.w + bv.w);
+        a[i][m] = make_float4((x.x - mu[m]) * rs[m] * gv.x + bv.x, (x.y - mu[m]) * rs[m] * gv.y + bv.y, (x.z - mu[m]) * rs[m] * gv.z + bv.z,
+                              (x.w - mu[m]) * rs[m] * gv.w + bv.w);
       }
     }
     mfma_group<MT>(acc, a[i], bw[i]);
   }
+  DEC_T(1, 5)
   stash_partials<MT>(part, acc, w, r, g);
+  DEC_T(1, 6)
   if (ethr) z[(long)eb * J + j0 + ec] = tanhf(eenc + (ebias + sum_partials<MT>(part, eb, ec)));  // TransducerJointMerge add + tanh (:199-207,291)
+  DEC_T(1, 7) DEC_T(1, 14)
 }
 
 // ---- 3'. vocabulary projection for 16 classes per workgroup ----
@@ -463,6 +537,7 @@ __global__ __launch_bounds__(1024) void decode_vocab_mfma_kernel(const float* __
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
   const int v0 = blockIdx.x * 16;
   const float* tile = pk + (long)blockIdx.x * J * 16;
+  DEC_T(2, 15) DEC_T(2, 0)
   const int ngr = J / 16, per = (ngr + NWV - 1) / NWV;
   const int g0 = w * per, g1 = min(ngr, g0 + per);
   float bw[GPW][4];
@@ -478,33 +553,35 @@ __global__ __launch_bounds__(1024) void decode_vocab_mfma_kernel(const float* __
   const int eb = threadIdx.x >> 4, ec = threadIdx.x & 15;
   const bool ethr = threadIdx.x < B * 16 && v0 + ec < V;
   const float ebias = ethr ? bv[v0 + ec] : 0.f;
+  DEC_T(2, 1)
   if (!active[0]) return;
+  DEC_T(2, 2)
   float4_t acc[MT];
 #pragma unroll
   for (int m = 0; m < MT; ++m) acc[m] = float4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int i = 0; i < GPW; ++i)
     if (g0 + i < g1) mfma_group<MT>(acc, a[i], bw[i]);
+  DEC_T(2, 3)
   stash_partials<MT>(part, acc, w, r, g);
+  DEC_T(2, 4)
   if (ethr) logits[(long)eb * V + v0 + ec] = ebias + sum_partials<MT>(part, eb, ec);
+  DEC_T(2, 5) DEC_T(2, 14)
 }
 
 template <int MT>
-int launch_decode_mfma(const float* emb, const float* packed, const float* lstm_b, const float* ln_g, const float* ln_b, const float* joint_pred_b,
+int launch_decode_mfma(const float* packed, const float* lstm_b, const float* ln_g, const float* ln_b, const float* joint_pred_b,
                        const float* vocab_b, const float* encj, const int32_t* nframes, const int32_t* frame_idx, const int32_t* tok_idx,
                        const int32_t* prev_tok, const float* h, const float* c, int32_t* active, float* h_new, float* c_new, float* z,
                        float* logits, int B, int T, int E, int P, int J, int V, int max_tokens, int mode, float ln_eps, hipStream_t s) {
-  const float* pj = packed + (long)(P / 4) * (E + P) * 16;
-  const float* pv = pj + (long)((J + 15) / 16) * P * 16;
-  hipLaunchKernelGGL(decode_lstm_mfma_kernel<MT>, dim3(P / 4), dim3(1024), 0, s, emb, packed, lstm_b, prev_tok, h, c, nframes, frame_idx, tok_idx,
-                     active, h_new, c_new, B, E, P, V, max_tokens, mode);
+  const PackDims dm = pack_dims(E, P, J, V);
+  const float* pj = packed + dm.nl;
+  const float* pv = pj + dm.nj;
+  const float* G = pv + dm.nv;
+  hipLaunchKernelGGL(decode_lstm_mfma_kernel<MT>, dim3(P / 4), dim3(1024), 0, s, G, packed, lstm_b, prev_tok, h, c, encj, nframes, frame_idx, tok_idx,
+                     active, h_new, c_new, z, B, T, P, J, V, max_tokens, mode);  // (z doubles as the gathered encoder frames until the joint kernel)
   TFASR_CHECK_LAUNCH();
-#define TFASR_DJ(L) hipLaunchKernelGGL((decode_joint_mfma_kernel<MT, L>), dim3((J + 15) / 16), dim3(1024), 0, s, h_new, ln_g, ln_b, pj, joint_pred_b, encj, \
-                                       nframes, frame_idx, active, z, B, T, P, J, ln_eps)
-  if (P <= 320) TFASR_DJ(5);
-  else if (P <= 640) TFASR_DJ(10);
-  else TFASR_DJ(16);
-#undef TFASR_DJ
+  hipLaunchKernelGGL(decode_joint_mfma_kernel<MT>, dim3((J + 15) / 16), dim3(1024), 0, s, h_new, ln_g, ln_b, pj, joint_pred_b, z, active, z, B, P, J, ln_eps);
   TFASR_CHECK_LAUNCH();
   hipLaunchKernelGGL(decode_vocab_mfma_kernel<MT>, dim3((V + 15) / 16), dim3(1024), 0, s, z, pv, vocab_b, active, logits, B, J, V);
   TFASR_CHECK_LAUNCH();
@@ -513,25 +590,34 @@ int launch_decode_mfma(const float* emb, const float* packed, const float* lstm_
 
 // shapes the MFMA kernels take (packed weights): whole groups of 16 k, a wave's share of the k range within its register budget
 bool mfma_shapes(int E, int P, int J) {
-  return (E % 16) == 0 && (P % 16) == 0 && (J % 16) == 0 && (E + P) <= 16 * NWV * GPW && P <= 1024 && J <= 16 * NWV * GPW;
+  return E > 0 && (P % 16) == 0 && (J % 16) == 0 && P <= 1024 && P <= 16 * NWV * GPW && J <= 16 * NWV * GPW;
 }
 
 }  // namespace
 
 extern "C" size_t tfasr_decode_pack_floats(int E, int P, int J, int V) {
   if (E <= 0 || P <= 0 || J <= 0 || V <= 1 || !mfma_shapes(E, P, J)) return 0;
-  return (size_t)(P / 4) * (E + P) * 16 + (size_t)((J + 15) / 16) * P * 16 + (size_t)((V + 15) / 16) * J * 16;
+  const PackDims dm = pack_dims(E, P, J, V);
+  return (size_t)(dm.nl + dm.nj + dm.nv + dm.ng + dm.nk);
 }
 
-extern "C" int tfasr_decode_pack(const float* lstm_k, const float* lstm_rk, const float* joint_pred_w, const float* vocab_w, float* packed, int E,
-                                 int P, int J, int V, void* stream_) {
-  if (!lstm_k || !lstm_rk || !joint_pred_w || !vocab_w || !packed) return TFASR_STATUS_INVALID_VALUE;
+extern "C" int tfasr_decode_pack(const float* emb, const float* lstm_k, const float* lstm_rk, const float* joint_pred_w, const float* vocab_w,
+                                 float* packed, int E, int P, int J, int V, void* stream_) {
+  if (!emb || !lstm_k || !lstm_rk || !joint_pred_w || !vocab_w || !packed) return TFASR_STATUS_INVALID_VALUE;
   const size_t n = tfasr_decode_pack_floats(E, P, J, V);
   if (n == 0) return TFASR_STATUS_UNSUPPORTED;
-  hipLaunchKernelGGL(decode_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, lstm_k, lstm_rk, joint_pred_w, vocab_w,
+  const PackDims dm = pack_dims(E, P, J, V);
+  const long nk = dm.nl + dm.nj + dm.nv + dm.nk;  // (threads: every section except G, which the product below fills)
+  hipLaunchKernelGGL(decode_pack_kernel, dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, lstm_k, lstm_rk, joint_pred_w, vocab_w,
                      packed, E, P, J, V);
   TFASR_CHECK_LAUNCH();
-  return TFASR_STATUS_SUCCESS;
+  // G = emb @ Wk (exact f32, columns in tile order): the input half of the LSTM pre-activation of every token
+  tfasr_gemm_args ga;
+  memset(&ga, 0, sizeof(ga));
+  float* G = packed + dm.nl + dm.nj + dm.nv;
+  ga.A = emb; ga.B = G + dm.ng; ga.D = G; ga.M = V; ga.N = 4 * P; ga.K = E; ga.lda = E; ga.ldb = 4 * P; ga.ldd = 4 * P;
+  ga.nb1 = 1; ga.nb2 = 1; ga.alpha = 1.f; ga.beta = 0.f; ga.dtype = TFASR_F32; ga.split_k = 1;
+  return tfasr_gemm(&ga, stream_);
 }
 
 extern "C" int tfasr_decode_step(const float* emb, const float* lstm_k, const float* lstm_rk, const float* lstm_b, const float* ln_g,
@@ -548,10 +634,9 @@ extern "C" int tfasr_decode_step(const float* emb, const float* lstm_k, const fl
     return TFASR_STATUS_UNSUPPORTED;  // float4 weight loads
   hipStream_t s = (hipStream_t)stream_;
   static const bool mfma_off = getenv("TFASR_DECODE_MFMA") && getenv("TFASR_DECODE_MFMA")[0] == '0';  // A/B probe: the vector-ALU kernels
-  if (packed && !mfma_off && mfma_shapes(E, P, J) &&
-      ((((uintptr_t)emb | (uintptr_t)h | (uintptr_t)h_new | (uintptr_t)z | (uintptr_t)packed) & 15) == 0)) {
+  if (packed && !mfma_off && mfma_shapes(E, P, J) && ((((uintptr_t)h | (uintptr_t)h_new | (uintptr_t)z | (uintptr_t)packed) & 15) == 0)) {
     const int mt = (B + 15) / 16;
-#define TFASR_DM(M) return launch_decode_mfma<M>(emb, packed, lstm_b, ln_g, ln_b, joint_pred_b, vocab_b, encj, nframes, frame_idx, tok_idx, prev_tok, h, c, \
+#define TFASR_DM(M) return launch_decode_mfma<M>(packed, lstm_b, ln_g, ln_b, joint_pred_b, vocab_b, encj, nframes, frame_idx, tok_idx, prev_tok, h, c, \
                                                  active, h_new, c_new, z, logits, B, T, E, P, J, V, max_tokens, mode, ln_eps, s)
     if (mt == 1) TFASR_DM(1);
     if (mt == 2) TFASR_DM(2);
@@ -589,5 +674,18 @@ extern "C" int tfasr_decode_steps(const float* emb, const float* lstm_k, const f
                              mode, max_tokens_per_frame, TFASR_F32, stream_);
     if (st != TFASR_STATUS_SUCCESS) return st;
   }
+#ifdef TFASR_DECODE_TIMING
+  if (getenv("TFASR_DECODE_DBG_DUMP")) {
+    long long h[4][16];
+    if (hipStreamSynchronize((hipStream_t)stream_) == hipSuccess && hipMemcpyFromSymbol(h, HIP_SYMBOL(g_dec_t), sizeof(h)) == hipSuccess) {
+      for (int k = 0; k < 3; ++k) {
+        fprintf(stderr, "[decode_timing] kernel %d: wall entry %lld exit %lld (10 ns units; d = %lld) | clocks since entry:", k, h[k][15], h[k][14], h[k][14] - h[k][15]);
+        for (int q = 1; q < 8; ++q) fprintf(stderr, " %lld", h[k][q] ? h[k][q] - h[k][0] : 0LL);
+        fprintf(stderr, "\n");
+      }
+      fprintf(stderr, "[decode_timing] wall gaps: lstm exit -> joint entry %lld, joint exit -> vocab entry %lld (10 ns units)\n", h[1][15] - h[0][14], h[2][15] - h[1][14]);
+    }
+  }
+#endif
   return TFASR_STATUS_SUCCESS;
 }

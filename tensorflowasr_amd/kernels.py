@@ -712,16 +712,17 @@ def decode_prepare(encj, nframes, frame_idx, tok_idx, active, ecur, max_tokens, 
                                     mode, _dt(encj), _stream()), "decode_prepare")
 
 
-def decode_pack(lstm_k, lstm_rk, wjp, wv, emb_dim):
-    """The four f32 weight matrices of a search step in the MFMA kernels' tile order (csrc/decode_step.hip); None when the shapes have no
-    MFMA route (the step then runs on the row-major masters).  Made once per recognize call: the weights are constants of the search."""
+def decode_pack(emb, lstm_k, lstm_rk, wjp, wv):
+    """The f32 weights of a search step in the MFMA kernels' tile order plus G = emb @ lstm_k (csrc/decode_step.hip); None when the shapes
+    have no MFMA route (the step then runs on the row-major masters).  Made once per recognize call: the weights are constants of the search."""
+    V, E = emb.shape
     P = lstm_rk.shape[0]
-    J, V = wv.shape
-    n = int(_L().tfasr_decode_pack_floats(int(emb_dim), P, J, V))
+    J = wv.shape[0]
+    n = int(_L().tfasr_decode_pack_floats(E, P, J, V))
     if n == 0:
         return None
     packed = torch.empty(n, dtype=torch.float32, device=lstm_k.device)
-    st = _L().tfasr_decode_pack(_p(lstm_k), _p(lstm_rk), _p(wjp), _p(wv), _p(packed), int(emb_dim), P, J, V, _stream())
+    st = _L().tfasr_decode_pack(_p(emb), _p(lstm_k), _p(lstm_rk), _p(wjp), _p(wv), _p(packed), E, P, J, V, _stream())
     if st == _lib.STATUS_UNSUPPORTED:
         return None
     check(st, "decode_pack")
