@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define TFASR_ABI_VERSION 26
+#define TFASR_ABI_VERSION 27
 
 typedef enum {
   TFASR_STATUS_SUCCESS = 0,
@@ -212,6 +212,11 @@ int tfasr_bn_stats(const void* x, float* stats, long rows, int C, int dtype, voi
 int tfasr_bn_finalize(const float* stats, float count, const float* gamma, const float* beta, float* fin,
                       float* moving_mean, float* moving_var, float momentum, float eps, int C, int training,
                       void* stream);
+/* tfasr_bn_finalize + tfasr_bn_apply_fwd in one launch (row kernel shapes: C % 8 == 0, 64 <= C <= 2048, 256 % (C/8) == 0, else
+ * UNSUPPORTED): `fin` and the moving statistics are written as tfasr_bn_finalize would. */
+int tfasr_bn_finalize_apply_fwd(const void* x, const float* stats, float count, const float* gamma, const float* beta, float* fin,
+                                float* moving_mean, float* moving_var, float momentum, float eps, void* y, long rows, int C, int act,
+                                int training, int dtype, void* stream);
 int tfasr_bn_apply_fwd(const void* x, const float* fin, void* y, long rows, int C, int act, int dtype, void* stream);
 int tfasr_bn_bwd_stats(const void* x, const void* dy, const float* fin, float* bstats, long rows, int C, int act,
                        int dtype, void* stream);
@@ -333,11 +338,13 @@ int tfasr_relattn_fused_bwd_q2(const void* qkv, const float* ubias, const float*
                                float* dvec, float* dpext, int B, int H, int T, int dh, int lds, float scale, int use_mask, int chunk, int hist,
                                int dtype, void* stream);
 /* _q2 with the query gradient finished in the kernel: dq (row stride lddq, e.g. the q columns of the fused [B*T, 3*H*dh] gradient)
- * = dqu + dqv, du [H*dh] += column sums of dqu, dv += column sums of dqv (what tfasr_bias2_bwd does in a separate pass) */
+ * = dqu + dqv, du [H*dh] += column sums of dqu, dv += column sums of dqv (what tfasr_bias2_bwd does in a separate pass).
+ * qu / qv (both or neither, [B*T, H*dh], 16-byte aligned): also written here = q + u / q + v for tfasr_relattn_fused_bwd_k and
+ * tfasr_relattn_dpext (what tfasr_bias2_fwd writes), except the rows of wholly padded 64-query blocks, which those two never read. */
 int tfasr_relattn_fused_bwd_q3(const void* qkv, const float* ubias, const float* vbias, const void* pext, const int32_t* lengths,
                                const void* o, const void* dout, const float* lse, void* dq, long lddq, float* du, float* dv, void* ds,
-                               float* dvec, float* dpext, int B, int H, int T, int dh, int lds, float scale, int use_mask, int chunk, int hist,
-                               int dtype, void* stream);
+                               float* dvec, float* dpext, void* qu, void* qv, int B, int H, int T, int dh, int lds, float scale, int use_mask,
+                               int chunk, int hist, int dtype, void* stream);
 int tfasr_relattn_dpext(const void* ds, const void* qv, const int32_t* lengths, float* dpext, int B, int H, int T, int dh, int lds,
                         int use_mask, int dtype, void* stream);
 /* Fused backward, key side (run after _bwd_q, which also emits dvec [B,H,T] = rowsum(dout*o)): writes the k and v column

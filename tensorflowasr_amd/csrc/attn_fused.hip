@@ -585,7 +585,8 @@ __global__ __launch_bounds__(256, 2) void relattn_fused_bwd_q_kernel(
     const bf16_t* __restrict__ pext, const int32_t* __restrict__ lengths, const bf16_t* __restrict__ o,
     const bf16_t* __restrict__ dout, const float* __restrict__ lse, bf16_t* __restrict__ dqu, bf16_t* __restrict__ dpos,
     float* __restrict__ dvec, int B, int H, int T, int ldp, float scale, int use_mask, bf16_t* __restrict__ dqv, float* __restrict__ dpext,
-    long lddq = 0, float* __restrict__ du = nullptr, float* __restrict__ dv = nullptr, int chunk = 0, int hist = 0) {
+    long lddq = 0, float* __restrict__ du = nullptr, float* __restrict__ dv = nullptr, int chunk = 0, int hist = 0,
+    bf16_t* __restrict__ qu_out = nullptr, bf16_t* __restrict__ qv_out = nullptr) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sK = smem;              // [64 j][64 dh], read both as rows (k = dh) and transposed (k = j)
   char* sV = sK + SK_BYTES;     // [64 j][64 dh]
@@ -640,6 +641,15 @@ __global__ __launch_bounds__(256, 2) void relattn_fused_bwd_q_kernel(
     ld8(orow, c);
 #pragma unroll
     for (int e = 0; e < 8; ++e) dpart += a[e] * c[e];
+  }
+  // q + u / q + v of this block's rows for the key-side kernel and relattn_dpext_kernel (they skip the blocks this kernel returned from
+  // above): the fragments are exactly those tensors' rows - what tfasr_bias2_fwd wrote in a launch of its own
+  if (qu_out && i0 + w * 16 + r < T) {
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      *reinterpret_cast<short8_t*>(qu_out + ((long)b * T + irow) * HD + h * DH + kk * 32 + g * 8) = aqu[kk];
+      *reinterpret_cast<short8_t*>(qv_out + ((long)b * T + irow) * HD + h * DH + kk * 32 + g * 8) = aqv[kk];
+    }
   }
   // D_i for row r: reduce over the 4 k-groups (lanes r, r+16, r+32, r+48), then re-distribute to the C layout rows g*4+e
   dpart += __shfl_xor(dpart, 16, 64);
@@ -1318,21 +1328,21 @@ extern "C" int tfasr_relattn_fused_bwd_q2(const void* qkv, const float* ubias, c
 
 extern "C" int tfasr_relattn_fused_bwd_q3(const void* qkv, const float* ubias, const float* vbias, const void* pext, const int32_t* lengths,
                                           const void* o, const void* dout, const float* lse, void* dq, long lddq, float* du, float* dv, void* ds,
-                                          float* dvec, float* dpext, int B, int H, int T, int dh, int lds, float scale, int use_mask, int chunk,
-                                          int hist, int dtype, void* stream_) {
+                                          float* dvec, float* dpext, void* qu, void* qv, int B, int H, int T, int dh, int lds, float scale,
+                                          int use_mask, int chunk, int hist, int dtype, void* stream_) {
   if (!qkv || !ubias || !vbias || !pext || !o || !dout || !lse || !dq || !du || !dv || !ds || !dvec || !dpext || B <= 0 || H <= 0 || T <= 0 || lds < T ||
-      (lds & 7) || lddq < (long)H * dh)
+      (lds & 7) || lddq < (long)H * dh || ((qu == nullptr) != (qv == nullptr)) || (((uintptr_t)qu | (uintptr_t)qv) & 15))
     return TFASR_STATUS_INVALID_VALUE;
   if (dtype != TFASR_BF16 || dh != DH) return TFASR_STATUS_UNSUPPORTED;
   dim3 grid((T + BI - 1) / BI, H, B);
   if (chunk > 0)
     hipLaunchKernelGGL((relattn_fused_bwd_q_kernel<true, true, true>), grid, dim3(256), SMEM_BWD_Q, (hipStream_t)stream_, (const bf16_t*)qkv, ubias, vbias,
                        (const bf16_t*)pext, lengths, (const bf16_t*)o, (const bf16_t*)dout, lse, (bf16_t*)dq, (bf16_t*)ds, dvec, B, H, T, lds, scale,
-                       use_mask, (bf16_t*)nullptr, dpext, lddq, du, dv, chunk, hist);
+                       use_mask, (bf16_t*)nullptr, dpext, lddq, du, dv, chunk, hist, (bf16_t*)qu, (bf16_t*)qv);
   else
   hipLaunchKernelGGL((relattn_fused_bwd_q_kernel<true, true>), grid, dim3(256), SMEM_BWD_Q, (hipStream_t)stream_, (const bf16_t*)qkv, ubias, vbias,
                      (const bf16_t*)pext, lengths, (const bf16_t*)o, (const bf16_t*)dout, lse, (bf16_t*)dq, (bf16_t*)ds, dvec, B, H, T, lds, scale,
-                     use_mask, (bf16_t*)nullptr, dpext, lddq, du, dv);
+                     use_mask, (bf16_t*)nullptr, dpext, lddq, du, dv, 0, 0, (bf16_t*)qu, (bf16_t*)qv);
   TFASR_CHECK_LAUNCH();
   return TFASR_STATUS_SUCCESS;
 }

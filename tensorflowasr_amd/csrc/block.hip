@@ -111,6 +111,10 @@ bool wgrad_stream_ready(Side& sd) {
   }
   return sd.wok;
 }
+// A/B switch of the round-4 launch fusions (BatchNorm finalize + apply, q + u / q + v out of the attention backward):
+// TFASR_BLOCK_FUSE=0 restores the separate launches
+inline bool block_fuse() { static const bool v = !(getenv("TFASR_BLOCK_FUSE") && getenv("TFASR_BLOCK_FUSE")[0] == '0'); return v; }
+
 int wgrad_wait(Side& sd, int slot_mask, hipStream_t s) {
   for (int k = 0; k < 2; ++k)
     if ((slot_mask >> k & 1) && sd.wpending[k]) {
@@ -416,15 +420,17 @@ struct Ex {
         // TFASR_ATTN_Q3=0: separate tfasr_bias2_bwd pass over dqu / dqv
         static const bool q3_off = getenv("TFASR_ATTN_Q3") && getenv("TFASR_ATTN_Q3")[0] == '0';
         if (!q3_off) {
+          // (also writes qu / qvb = q + u / q + v for the two kernels below: no tfasr_bias2_fwd launch)
           chk(tfasr_relattn_fused_bwd_q3(k->at_qkv, fp(TFASR_BP_AT_U), fp(TFASR_BP_AT_V), k->at_pext, io->lengths, k->at_att, datt, k->at_lse, dqkv,
-                                         3L * HD, gp(TFASR_BP_AT_U), gp(TFASR_BP_AT_V), dpos, dvec, dpext, B, H, T, dh, Tp, scale, c->use_mask, c->chunk_size,
-                                         c->history_size, c->dtype, s));
+                                         3L * HD, gp(TFASR_BP_AT_U), gp(TFASR_BP_AT_V), dpos, dvec, dpext, block_fuse() ? qu : nullptr,
+                                         block_fuse() ? qvb : nullptr, B, H, T, dh, Tp, scale, c->use_mask, c->chunk_size, c->history_size, c->dtype, s));
+          if (!block_fuse()) chk(tfasr_bias2_fwd(k->at_qkv, 3 * HD, fp(TFASR_BP_AT_U), fp(TFASR_BP_AT_V), qu, qvb, rows, HD, c->dtype, s));
           dq_done = true;
         } else {
           chk(tfasr_relattn_fused_bwd_q2(k->at_qkv, fp(TFASR_BP_AT_U), fp(TFASR_BP_AT_V), k->at_pext, io->lengths, k->at_att, datt, k->at_lse, dqu,
                                          dqv, dpos, dvec, dpext, B, H, T, dh, Tp, scale, c->use_mask, c->chunk_size, c->history_size, c->dtype, s));
+          chk(tfasr_bias2_fwd(k->at_qkv, 3 * HD, fp(TFASR_BP_AT_U), fp(TFASR_BP_AT_V), qu, qvb, rows, HD, c->dtype, s));
         }
-        chk(tfasr_bias2_fwd(k->at_qkv, 3 * HD, fp(TFASR_BP_AT_U), fp(TFASR_BP_AT_V), qu, qvb, rows, HD, c->dtype, s));
         chk(tfasr_relattn_fused_bwd_k(k->at_qkv, qu, qvb, k->at_pext, io->lengths, datt, k->at_lse, dvec, dqkv, B, H, T, dh, scale, c->use_mask,
                                       c->chunk_size, c->history_size, c->dtype, s));
         chk(tfasr_relattn_dpext(dpos, qvb, io->lengths, dpext, B, H, T, dh, Tp, c->use_mask, c->dtype, s));
@@ -531,6 +537,8 @@ struct Ex {
       chk(tfasr_glu_fwd(k->cv_a, k->cv_g, rows, d, c->dtype, s));
       chk(tfasr_dwconv_fwd(k->cv_g, fp(TFASR_BP_CV_DW_W), fp(TFASR_BP_CV_DW_B), k->cv_cv, c->B, c->T, d, c->ksize, c->dtype, s));
       if (c->training && !c->dw_norm_layer) {
+        // (measured and dropped: the statistics inside the conv kernel - 384 workgroups adding into the same 512 addresses are a serial
+        // chain of ~30 ns links, 27.8 us against 15.8 + 11.2 us for the two launches)
         if (!(io->prezeroed & 1)) zero(io->bn_stats, (size_t)(2 * d + 1) * 4);
         chk(tfasr_bn_stats(k->cv_cv, io->bn_stats, rows, d, c->dtype, s));
       }
@@ -542,13 +550,20 @@ struct Ex {
       chk(tfasr_layernorm_fwd(k->cv_cv, fp(TFASR_BP_CV_BN_G), fp(TFASR_BP_CV_BN_B), k->cv_y, k->cv_nmean, k->cv_nrstd, rows, d, c->ln_eps, c->dtype, s));
       chk(tfasr_add_act_fwd(k->cv_y, nullptr, k->cv_sw, rows * d, TFASR_ACT_SWISH, c->dtype, s));
     } else if (!dry) {
-      if (c->training)
-        chk(tfasr_bn_finalize(io->bn_stats, (float)(rows * c->world), fp(TFASR_BP_CV_BN_G), fp(TFASR_BP_CV_BN_B), k->cv_fin, P->bn_mm, P->bn_mv,
-                              c->bn_momentum, c->bn_eps, d, 1, s));
-      else
-        chk(tfasr_bn_finalize(nullptr, 1.f, fp(TFASR_BP_CV_BN_G), fp(TFASR_BP_CV_BN_B), k->cv_fin, P->bn_mm, P->bn_mv, c->bn_momentum, c->bn_eps,
-                              d, 0, s));
-      chk(tfasr_bn_apply_fwd(k->cv_cv, k->cv_fin, k->cv_sw, rows, d, TFASR_ACT_SWISH, c->dtype, s));
+      // statistics -> coefficients (+ moving statistics) -> normalise + swish in one launch; UNSUPPORTED (channel counts outside the row
+      // kernel) -> the two launches
+      const int fst = !block_fuse() ? TFASR_STATUS_UNSUPPORTED : tfasr_bn_finalize_apply_fwd(k->cv_cv, c->training ? io->bn_stats : nullptr, c->training ? (float)(rows * c->world) : 1.f,
+                                                  fp(TFASR_BP_CV_BN_G), fp(TFASR_BP_CV_BN_B), k->cv_fin, P->bn_mm, P->bn_mv, c->bn_momentum, c->bn_eps,
+                                                  k->cv_sw, rows, d, TFASR_ACT_SWISH, c->training ? 1 : 0, c->dtype, s);
+      if (fst == TFASR_STATUS_UNSUPPORTED) {
+        if (c->training)
+          chk(tfasr_bn_finalize(io->bn_stats, (float)(rows * c->world), fp(TFASR_BP_CV_BN_G), fp(TFASR_BP_CV_BN_B), k->cv_fin, P->bn_mm, P->bn_mv,
+                                c->bn_momentum, c->bn_eps, d, 1, s));
+        else
+          chk(tfasr_bn_finalize(nullptr, 1.f, fp(TFASR_BP_CV_BN_G), fp(TFASR_BP_CV_BN_B), k->cv_fin, P->bn_mm, P->bn_mv, c->bn_momentum, c->bn_eps,
+                                d, 0, s));
+        chk(tfasr_bn_apply_fwd(k->cv_cv, k->cv_fin, k->cv_sw, rows, d, TFASR_ACT_SWISH, c->dtype, s));
+      } else chk(fst);
     }
     G o; o.res = k->cv_x; o.beta = c->conv_res; o.drop_p = drop_p(); o.drop_seed = seed(site);
     o.A = k->cv_sw; o.lda = d; o.ta = 0; o.B = wp(TFASR_BP_CV_PW2_W); o.ldb = d; o.tb = 0; o.D = y; o.ldd = d; o.M = (int)rows; o.N = d; o.K = d;

@@ -237,6 +237,59 @@ __global__ __launch_bounds__(256) void bn_apply_fwd_rows_kernel(const T* __restr
     }
   }
 }
+// bn_finalize_kernel + bn_apply_fwd_rows_kernel in one launch: every workgroup derives the coefficients of its lanes' 8 channels from the
+// statistics itself (same arithmetic as bn_finalize_kernel), workgroup 0's first row of lanes also writes `fin` (the backward reads it)
+// and the moving statistics.
+template <typename T>
+__global__ __launch_bounds__(256) void bn_finalize_apply_fwd_rows_kernel(const T* __restrict__ x, const float* __restrict__ stats, float count,
+                                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                         float* __restrict__ fin, float* moving_mean, float* moving_var, float momentum,
+                                                                         float eps, T* __restrict__ y, long rows, int C, int act, int training) {
+  const int lpr = C >> 3, li = threadIdx.x % lpr, sub = threadIdx.x / lpr, rpb = 256 / lpr;
+  const int c = li * 8;
+  float sc[8], sh[8];
+  {
+    float mean[8], var[8], gm[8], bt[8], mm[8], mv[8];
+    ld8(gamma + c, gm); ld8(beta + c, bt);
+    const bool writer = blockIdx.x == 0 && sub == 0;
+    if (training) {
+      float s0[8], s1[8];
+      ld8(stats + c, s0); ld8(stats + C + c, s1);
+      if (writer && moving_mean) { ld8(moving_mean + c, mm); ld8(moving_var + c, mv); }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { mean[k] = s0[k] / count; var[k] = fmaxf(s1[k] / count - mean[k] * mean[k], 0.f); }
+      if (writer && moving_mean) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { mm[k] = mm[k] * momentum + mean[k] * (1.f - momentum); mv[k] = mv[k] * momentum + var[k] * (1.f - momentum); }
+        st8(moving_mean + c, mm); st8(moving_var + c, mv);
+      }
+    } else {
+      ld8(moving_mean + c, mean); ld8(moving_var + c, var);
+    }
+    float rstd[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { rstd[k] = rsqrtf(var[k] + eps); sc[k] = gm[k] * rstd[k]; sh[k] = bt[k] - mean[k] * sc[k]; }
+    if (writer) { st8(fin + c, mean); st8(fin + C + c, rstd); st8(fin + 2 * C + c, sc); st8(fin + 3 * C + c, sh); }
+  }
+  const long step = (long)gridDim.x * rpb;
+  for (long r0 = (long)blockIdx.x * rpb + sub; r0 < rows; r0 += 2 * step) {
+    float v[2][8];
+    const bool two = r0 + step < rows;
+    ld8(x + r0 * C + c, v[0]);
+    if (two) ld8(x + (r0 + step) * C + c, v[1]);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      if (u == 1 && !two) break;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        float z = v[u][k] * sc[k] + sh[k];
+        if (act == TFASR_ACT_SWISH) z = swishf_(z);
+        v[u][k] = z;
+      }
+      st8(y + (r0 + u * step) * C + c, v[u]);
+    }
+  }
+}
 template <typename T>
 __global__ __launch_bounds__(256) void bn_apply_bwd_rows_kernel(const T* __restrict__ x, const T* __restrict__ dy, const float* __restrict__ fin,
                                                                 const float* __restrict__ bstats, float count, T* dx, long rows, int C, int act,
@@ -709,6 +762,25 @@ extern "C" int tfasr_bn_apply_fwd(const void* x, const float* fin, void* y, long
   else
     hipLaunchKernelGGL(bn_apply_fwd_kernel<bf16_t>, dim3(flat_grid(n8)), dim3(256), 0, s, (const bf16_t*)x, fin,
                        (bf16_t*)y, n8, C, act);
+  TFASR_CHECK_LAUNCH();
+  return TFASR_STATUS_SUCCESS;
+}
+
+extern "C" int tfasr_bn_finalize_apply_fwd(const void* x, const float* stats, float count, const float* gamma, const float* beta, float* fin,
+                                           float* moving_mean, float* moving_var, float momentum, float eps, void* y, long rows, int C, int act,
+                                           int training, int dtype, void* stream_) {
+  if (!x || !gamma || !beta || !fin || !y || rows <= 0 || C <= 0) return TFASR_STATUS_INVALID_VALUE;
+  if (training && !stats) return TFASR_STATUS_INVALID_VALUE;
+  if (!training && (!moving_mean || !moving_var)) return TFASR_STATUS_INVALID_VALUE;
+  if ((C % 8) != 0 || !rows_variant_ok(C) || (dtype != TFASR_F32 && dtype != TFASR_BF16)) return TFASR_STATUS_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream_;
+  const int grid = rows_variant_grid(rows, C);
+  if (dtype == TFASR_F32)
+    hipLaunchKernelGGL(bn_finalize_apply_fwd_rows_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, stats, count, gamma, beta, fin, moving_mean,
+                       moving_var, momentum, eps, (float*)y, rows, C, act, training);
+  else
+    hipLaunchKernelGGL(bn_finalize_apply_fwd_rows_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)x, stats, count, gamma, beta, fin, moving_mean,
+                       moving_var, momentum, eps, (bf16_t*)y, rows, C, act, training);
   TFASR_CHECK_LAUNCH();
   return TFASR_STATUS_SUCCESS;
 }
