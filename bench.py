@@ -162,7 +162,7 @@ def pmc_traffic(flops_per_launch, J, V):
     the figure is looked up: the forward vocabulary projection is the plain NN gemm_fast launch whose WRITE_SIZE equals its
     output (cells x V bf16) - no other launch of the step writes that much from that kernel.  None if it was not profiled."""
     here = os.path.dirname(os.path.abspath(__file__))
-    path = next((q for q in (os.path.join(here, "profiles", f) for f in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")) if os.path.exists(q)), None)
+    path = next((q for q in (os.path.join(here, "profiles", f) for f in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")) if os.path.exists(q)), None)
     if path is None:
         return None
     rows = json.load(open(path))

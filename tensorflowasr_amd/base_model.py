@@ -25,10 +25,30 @@ _COMPONENTS = {"encoder": ("enc/",), "predict_net": ("pred/",), "joint_net": ("j
 
 
 def _eval_number(v):
-    """YAML numbers such as `max_lr: 0.05/(144**0.5)` arrive as strings (small.yml.j2:80)."""
-    if isinstance(v, str):
-        return float(eval(v, {"__builtins__": {}}, {"sqrt": math.sqrt}))
-    return v
+    """YAML numbers such as `max_lr: 0.05/(144**0.5)` arrive as strings (small.yml.j2:80).  Only arithmetic is accepted: the expression is
+    walked node by node (numbers, + - * / ** and unary signs, sqrt(...)); anything else raises instead of being evaluated."""
+    if not isinstance(v, str):
+        return v
+    import ast
+    import operator as op
+
+    ops = {ast.Add: op.add, ast.Sub: op.sub, ast.Mult: op.mul, ast.Div: op.truediv, ast.Pow: op.pow, ast.FloorDiv: op.floordiv, ast.Mod: op.mod}
+
+    def ev(n):
+        if isinstance(n, ast.Expression):
+            return ev(n.body)
+        if isinstance(n, ast.Constant) and isinstance(n.value, (int, float)) and not isinstance(n.value, bool):
+            return n.value
+        if isinstance(n, ast.BinOp) and type(n.op) in ops:
+            return ops[type(n.op)](ev(n.left), ev(n.right))
+        if isinstance(n, ast.UnaryOp) and isinstance(n.op, (ast.UAdd, ast.USub)):
+            x = ev(n.operand)
+            return -x if isinstance(n.op, ast.USub) else x
+        if isinstance(n, ast.Call) and isinstance(n.func, ast.Name) and n.func.id == "sqrt" and len(n.args) == 1 and not n.keywords:
+            return math.sqrt(ev(n.args[0]))
+        raise ValueError(f"not a number expression: {v!r}")
+
+    return float(ev(ast.parse(v.strip(), mode="eval")))
 
 
 def optimizer_from_config(cfg, dmodel):

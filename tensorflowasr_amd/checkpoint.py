@@ -246,9 +246,19 @@ def from_weights_h5(datasets, template):
     return out, sorted(set(datasets) - used)
 
 
+def _h5_conformer_only(model):
+    """The `.weights.h5` path table (h5_anchors / keras3_h5_path) is written for the Conformer transducer / CTC variables only.  EXPERIMENTAL
+    either way: the attribute-walk spelling has not been checked against a file written by real Keras (no Keras / h5py in this image);
+    `.npz` (export_keras names) is the tested interchange format."""
+    if getattr(model.cfg, "encoder", "conformer") != "conformer":
+        raise NotImplementedError(f"Keras .weights.h5 import / export is built for the Conformer models only (encoder = {model.cfg.encoder!r}); "
+                                  "use the .npz weights format")
+
+
 def load_weights_h5(model, filepath, strict=True):
     """BaseModel.load_weights (base_model.py:59-61) for a Keras 3 `.weights.h5` file.  strict: every float dataset of the file
     outside `optimizer/` must have been consumed (so a silently ignored layer cannot go unnoticed)."""
+    _h5_conformer_only(model)
     import torch
 
     from .h5lite import H5File
@@ -272,6 +282,7 @@ def save_weights_h5(model, filepath):
     saving_lib, not confirmed against a Keras-written file: see the caveat above.)"""
     from .h5lite import write_h5
 
+    _h5_conformer_only(model)
     datasets = {}
     for name, t in model.ps.export_keras().items():
         a = np.asarray(t.detach().cpu().numpy() if hasattr(t, "detach") else t, dtype=np.float32)
@@ -302,20 +313,23 @@ def keras3_h5_path(name, cfg=None):
 
 def save_state(model, filepath):
     """Everything a resumed run needs beyond the weights: the flat f32 parameters, Adam first / second moments, the
-    optimizer step (= position in the learning-rate schedule), the dropout epoch and the BatchNorm moving statistics."""
+    optimizer step (= position in the learning-rate schedule), the dropout epoch and the BatchNorm moving statistics.  Parameter-shaped
+    vectors are stored in the LOGICAL layout (ParamStore.to_logical: no head / filter zero padding), so the file does not depend on the
+    storage type or on TFASR_HEAD_PAD / TFASR_FILTER_PAD of the run that wrote it."""
     ps = model.ps
-    arrays = {"flat": ps.flat.cpu().numpy(), "adam_m": ps.adam_m.cpu().numpy(), "adam_v": ps.adam_v.cpu().numpy(),
-              "step": np.asarray(model.step, np.int64), "drop_epoch": np.asarray(model._drop_epoch, np.int64),
-              "ga_count": np.asarray(model._ga_count, np.int64), "names": np.asarray(ps.names), "n": np.asarray(ps.n, np.int64)}
+    arrays = {"layout": np.asarray("logical"), "flat": ps.to_logical(ps.flat).numpy(), "adam_m": ps.to_logical(ps.adam_m).numpy(),
+              "adam_v": ps.to_logical(ps.adam_v).numpy(), "step": np.asarray(model.step, np.int64),
+              "drop_epoch": np.asarray(model._drop_epoch, np.int64), "ga_count": np.asarray(model._ga_count, np.int64),
+              "names": np.asarray(ps.names)}
     if model._ga_count > 0:  # saved in the middle of a gradient-accumulation cycle: the partial sum of micro-gradients belongs to the state
-        arrays["grad"] = ps.grad.cpu().numpy()
+        arrays["grad"] = ps.to_logical(ps.grad).numpy()
     rng = getattr(model, "_rng", None)
     if rng is not None:  # SpecAugment draws
         import json
 
         arrays["rng"] = np.asarray(json.dumps(rng.bit_generator.state))
     for k, v in ps.state.items():
-        arrays["state|" + k.replace("/", "|")] = v.cpu().numpy()
+        arrays["state|" + k.replace("/", "|")] = ps._unpad(k, v.detach().cpu().clone()).numpy()
     with open(filepath, "wb") as f:
         np.savez(f, **arrays)
 
@@ -325,15 +339,29 @@ def load_state(model, filepath):
 
     ps = model.ps
     with np.load(filepath) as z:
-        if int(z["n"]) != ps.n or list(z["names"]) != list(ps.names):
-            raise ValueError(f"{filepath} was written by a different model configuration")
-        ps.flat.copy_(torch.from_numpy(z["flat"]))
-        ps.adam_m.copy_(torch.from_numpy(z["adam_m"]))
-        ps.adam_v.copy_(torch.from_numpy(z["adam_v"]))
+        if list(z["names"]) != list(ps.names):
+            raise ValueError(f"{filepath} was written by a different model configuration (parameter names differ)")
+        logical = "layout" in z.files and str(z["layout"]) == "logical"
+        if not logical and int(z["n"]) != ps.n:
+            raise ValueError(f"{filepath} stores the parameters in the padded device layout of the run that wrote it ({int(z['n'])} values; this "
+                             f"model holds {ps.n}): it resumes only into the same storage type and TFASR_HEAD_PAD / TFASR_FILTER_PAD settings")
+
+        def put(key, buf):
+            if logical:
+                try:
+                    ps.from_logical(z[key], buf)
+                except ValueError as e:
+                    raise ValueError(f"{filepath}: {key}: {e} (different model configuration)") from e
+            else:
+                buf.copy_(torch.from_numpy(z[key]))
+
+        put("flat", ps.flat)
+        put("adam_m", ps.adam_m)
+        put("adam_v", ps.adam_v)
         model.step, model._drop_epoch, model._ga_count = int(z["step"]), int(z["drop_epoch"]), int(z["ga_count"])
         if model._ga_count > 0:
             if "grad" in z.files:
-                ps.grad.copy_(torch.from_numpy(z["grad"]))
+                put("grad", ps.grad)
             else:  # a state file without the partial sum: restart the accumulation cycle instead of applying a stale buffer
                 model._ga_count = 0
                 ps.grad.zero_()
@@ -342,5 +370,6 @@ def load_state(model, filepath):
 
             model._rng.bit_generator.state = json.loads(str(z["rng"]))
         for k in ps.state:
-            ps.state[k].copy_(torch.from_numpy(z["state|" + k.replace("/", "|")]))
+            v = torch.from_numpy(z["state|" + k.replace("/", "|")])
+            ps.state[k].copy_(ps._pad(k, v) if logical else v)
     ps.refresh_shadow()

@@ -321,6 +321,27 @@ class ParamStore:
             return v.reshape(-1, self.cfg.dmodel)
         return v.reshape(-1)
 
+    def to_logical(self, buf):
+        """A flat parameter-shaped buffer (parameters, Adam moments, accumulated gradients) as ONE f32 CPU vector in the LOGICAL layout
+        (head size cfg.head_size, cfg.filters channels): independent of the zero padding the device layout carries, so a state file
+        resumes into a model built with another storage type or other TFASR_HEAD_PAD / TFASR_FILTER_PAD settings."""
+        return torch.cat([self._unpad(name, self._view(buf, name).detach().float().cpu()).reshape(-1) for name in self.names])
+
+    def from_logical(self, vec, buf):
+        """inverse of to_logical: scatter (and zero-pad) `vec` into the device buffer `buf`"""
+        vec = torch.as_tensor(vec).float().cpu().reshape(-1)
+        off = 0
+        for name in self.names:
+            n = self._unpad(name, torch.empty(self.shapes[name])).numel()
+            if off + n > vec.numel():
+                raise ValueError("logical state vector is shorter than this model's parameters")
+            piece = vec[off:off + n]
+            off += n
+            phys = self._pad(name, piece.reshape(self._unpad(name, torch.empty(self.shapes[name])).shape))
+            self._view(buf, name).copy_(phys.reshape(self.shapes[name]).to(buf.device))
+        if off != vec.numel():
+            raise ValueError("logical state vector is longer than this model's parameters")
+
     def rezero_pads(self, buf=None):
         """restore the zero padding of `buf` (default: the master parameters) after something wrote whole-buffer noise into it"""
         dh, dp = self.cfg.head_size, self.head_phys

@@ -277,3 +277,44 @@ def test_training_state_round_trip(tmp_path):
     la = a.train_step(data, masks=(None, None))["loss"]
     lb = b.train_step(data, masks=(None, None))["loss"]
     np.testing.assert_allclose(la.cpu().numpy(), lb.cpu().numpy(), rtol=1e-5)
+
+
+@pytest.mark.gpu
+def test_training_state_is_layout_independent(tmp_path):
+    """The state file holds the LOGICAL layout: written by a bf16 model (heads 8 -> 64 and filters 32 -> 64 zero-padded on the device), it
+    resumes into an f32 model (no padding) with the same logical parameters, Adam moments and moving statistics - and back."""
+    from tensorflowasr_amd import _smoke_model
+    from tensorflowasr_amd.conformer import ConformerTransducer
+
+    dev = torch.device("cuda", 0)
+    cfg, a, data, *_ = _smoke_model.make(dev, dtype=torch.bfloat16)
+    assert a.ps.head_phys != cfg.head_size or a.ps.filt_phys != cfg.filters
+    for _ in range(2):
+        a.train_step(data)
+    p = tmp_path / "state.npz"
+    ck.save_state(a, str(p))
+    b = ConformerTransducer(cfg, dev, dtype=torch.float32, seed=5)
+    assert b.ps.n != a.ps.n  # different device layouts
+    ck.load_state(b, str(p))
+    assert b.step == a.step
+    for buf in ("flat", "adam_m", "adam_v"):
+        assert torch.equal(a.ps.to_logical(getattr(a.ps, buf)), b.ps.to_logical(getattr(b.ps, buf))), buf
+    ea, eb = a.ps.export_keras(), b.ps.export_keras()
+    assert ea.keys() == eb.keys() and all(torch.equal(ea[k], eb[k]) for k in ea)
+    p2 = tmp_path / "state2.npz"
+    ck.save_state(b, str(p2))
+    c = ConformerTransducer(cfg, dev, dtype=torch.bfloat16, seed=6)
+    ck.load_state(c, str(p2))
+    for buf in ("flat", "adam_m", "adam_v"):
+        assert torch.equal(getattr(a.ps, buf), getattr(c.ps, buf)), buf
+
+
+def test_h5_weights_refuse_contextnet(tmp_path):
+    """the .weights.h5 path table covers the Conformer variables; ContextNet raises NotImplementedError (not a KeyError from the matcher)"""
+    import types
+
+    fake = types.SimpleNamespace(cfg=types.SimpleNamespace(encoder="contextnet"))
+    with pytest.raises(NotImplementedError):
+        ck.save_weights_h5(fake, str(tmp_path / "w.weights.h5"))
+    with pytest.raises(NotImplementedError):
+        ck.load_weights_h5(fake, str(tmp_path / "w.weights.h5"))

@@ -176,3 +176,15 @@ def test_model_from_config_rejects_models_off_the_path():
 
     with pytest.raises(NotImplementedError):
         base_model.model_from_config({"class_name": "tensorflow_asr.models.ctc.jasper>Jasper", "config": {}})
+
+
+def test_yaml_number_expressions_are_parsed_not_evaluated():
+    """`max_lr: 0.05/(144**0.5)` (small.yml.j2:80) is arithmetic; anything that is not arithmetic raises (no eval)."""
+    from tensorflowasr_amd.base_model import _eval_number
+
+    assert _eval_number("0.05/(144**0.5)") == pytest.approx(0.05 / 12)
+    assert _eval_number("0.05 / sqrt(256)") == pytest.approx(0.05 / 16)
+    assert _eval_number("-1e-3") == -1e-3 and _eval_number(0.25) == 0.25
+    for bad in ("().__class__.__base__.__subclasses__()", "__import__('os').getcwd()", "abs(1)", "sqrt", "1 if 1 else 2", "[1][0]"):
+        with pytest.raises((ValueError, SyntaxError)):
+            _eval_number(bad)
