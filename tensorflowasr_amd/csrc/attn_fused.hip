@@ -43,7 +43,8 @@ __device__ __forceinline__ void glds16_asm(const void* g, const char* lds_unifor
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(l) : "memory");
 }
 // [rows][64] bf16 image, 128-B rows, 16-B chunk ^= key_d(row); global rows clamped to [0, nrows-1]
-template <int ROWS, bool ASM = false>
+// KEEP_LAST: image row ROWS-1 is not written (the lanes that would are switched off): it holds something the caller put there once
+template <int ROWS, bool ASM = false, bool KEEP_LAST = false>
 __device__ __forceinline__ void load_rows(char* s, const bf16_t* g, long ld, int row0, int nrows, int w, int lane) {
 #pragma unroll
   for (int i = 0; i < ROWS / 32; ++i) {
@@ -51,6 +52,7 @@ __device__ __forceinline__ void load_rows(char* s, const bf16_t* g, long ld, int
     const int row = q * 8 + (lane >> 3), p = lane & 7;
     const int gr = min(max(row0 + row, 0), nrows - 1);
     const bf16_t* src = g + (long)gr * ld + ((p ^ key_d(row)) << 3);
+    if (KEEP_LAST && row == ROWS - 1) continue;
     if constexpr (ASM) glds16_asm(src, s + __builtin_amdgcn_readfirstlane(q * 1024));
     else __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(s + __builtin_amdgcn_readfirstlane(q * 1024)), 16, 0, 0);
   }
@@ -108,6 +110,23 @@ __device__ __forceinline__ short8_t q_frag(const bf16_t* qrow, const float* bias
   for (int e = 0; e < 8; ++e) f[e] = (short)f32_to_bf16(x[e] + bias[k0 + e]);
   return f;
 }
+
+// Workgroup -> (sample, head, 64-row block) for the kernels whose grid is (blocks, H, B).  The hardware deals consecutive workgroup ids
+// round-robin over the 8 XCDs (own L2 each) and starts them in id order.  (i) Every block of one (sample, head) goes to ONE XCD, so its
+// K / V / position window - re-read by every block - are fetched into one L2, not eight; (ii) ids are block-major inside an XCD: the
+// low blocks of every sample (always real frames) start first and the high ones - padding for most samples, a fraction of the work -
+// fill the tail, instead of a long-running block starting last.  Launch with a 1-D grid of attn_grid_size() workgroups.
+struct BlockId { int b, h, blk; bool ok; };
+__device__ __forceinline__ BlockId attn_block_id(int B, int H, int nblk) {
+  const int lin = blockIdx.x, xcd = lin & 7, slot = lin >> 3;
+  const int nbh = B * H, per = (nbh + 7) >> 3;
+  const int blk = slot / per, bh = (slot - blk * per) * 8 + xcd;
+  BlockId id;
+  id.ok = bh < nbh && blk < nblk;
+  id.b = bh / H; id.h = bh - id.b * H; id.blk = blk;
+  return id;
+}
+inline unsigned attn_grid_size(int B, int H, int nblk) { return (unsigned)(8 * ((B * H + 7) / 8) * nblk); }
 
 // streaming window of query i (compute_streaming_mask, multihead_attention.py:104-143): keys [lo, hi) are visible; outside it the
 // reference's score is -1e9 = probability exactly 0.  chunk <= 0: the whole utterance.  hist < 0: unlimited history.
@@ -349,6 +368,242 @@ __global__ __launch_bounds__(256, 3) void relattn_fused_fwd_kernel(
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Forward, TRANSPOSED orientation (round 4): the scores are computed as S^T = K (Q+u)^T (rows = keys, columns = this wave's 16 query
+// rows), so that in the MFMA C layout a lane owns ONE query row: the online-softmax state (running maximum, running sum, rescale factor)
+// is a per-lane scalar, the row reductions are in-lane over the lane's 16 keys plus two cross-row-group shuffles (they were eight 4-step
+// DPP chains), and P^T in C layout IS the B operand of O^T += V^T P^T - the probabilities never go through LDS (the row-oriented kernel
+// writes a bf16 P image with 16 two-byte LDS stores per lane and reads it back as A fragments).  For that the key rows of a 32-key
+// group are dealt to the two 16-row MFMA tiles so that a lane's eight probabilities of the group are eight CONSECUTIVE keys
+// (tile 2q: keys 32q + 8g + e, tile 2q+1: keys 32q + 8g + 4 + e) = the k order of the V^T fragment (frag_v).  The window scores are
+// G^T = window (Q+v)^T: a lane holds four consecutive window columns of its query row and stores them with one 16-byte LDS write
+// (four 4-byte ones before); the skewed read-back (column 15 - il + jl of the wave's strip) is four consecutive floats per tile.
+// Same LDS budget as the row-oriented kernel (three workgroups per CU).
+// ---------------------------------------------------------------------------------------------------------------------------------
+// LDS is allocated in 1280-byte granules on gfx950 (160 KB = 128 granules): THREE workgroups per CU need <= 42 granules = 53 760 bytes
+// each.  Strip = [16 il][80 window columns] f32 + the 16 bias-row scores behind it = 5 184 bytes per wave, 53 504 per workgroup (with a
+// row stride of 84 floats it was 54 272 -> 43 granules -> two workgroups per CU: 90 instead of 62 us at T' = 743).
+constexpr int GLDT = 80, SGTT_BYTES = 16 * GLDT * 4 + 64;
+constexpr int SMEM_FWDT = SK_BYTES + SV_BYTES + SP_BYTES + 4 * SGTT_BYTES;
+static_assert((SMEM_FWDT + 1279) / 1280 * 3 <= 128, "three workgroups per CU");
+
+template <bool STREAM>
+__global__ __launch_bounds__(256, 3) void relattn_fused_fwdT_kernel(
+    const bf16_t* __restrict__ qkv, const float* __restrict__ ubias, const float* __restrict__ vbias,
+    const bf16_t* __restrict__ pext, const int32_t* __restrict__ lengths, bf16_t* __restrict__ out, float* __restrict__ lse_out,
+    int B, int H, int T, float scale, int use_mask, int chunk, int hist) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sK = smem;
+  char* sV = sK + SK_BYTES;
+  char* sP = sV + SV_BYTES;
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  float* sG = reinterpret_cast<float*>(sP + SP_BYTES + w * SGTT_BYTES);  // [16 il][80]: window columns 48-16w .. 127-16w; then [16] bias-row scores
+  float* sGb = sG + 16 * GLDT;
+  const int r = lane & 15, g = lane >> 4;
+  const BlockId bid = attn_block_id(B, H, (T + BI - 1) / BI);
+  if (!bid.ok) return;
+  const int b = bid.b, h = bid.h, i0 = bid.blk * BI;
+  const int HD = H * DH, LDQ = 3 * HD, R1 = 2 * T;
+  const int len = lengths ? min(lengths[b], T) : T;
+  const int shift = T - len;
+  const bf16_t* qb = qkv + (long)b * T * LDQ + h * DH;
+  const bf16_t* kb = qb + HD;
+  const bf16_t* vb = qb + 2 * HD;
+  const bf16_t* pb = pext + h * DH;
+  uint4 bias_row = make_uint4(0, 0, 0, 0);
+  if ((threadIdx.x >> 6) == 0 && (threadIdx.x & 63) < 8) bias_row = *reinterpret_cast<const uint4*>(pb + (long)(2 * T - 1) * HD + (((threadIdx.x & 63) ^ key_d(127)) << 3));
+
+  // this lane's query row (B operand column): Q + u, Q + v
+  const int i = i0 + w * 16 + r, irow = min(i, T - 1);
+  short8_t bqu[2], bqv[2];
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) {
+    bqu[kk] = q_frag(qb + (long)irow * LDQ, ubias + h * DH, kk * 32 + g * 8);
+    bqv[kk] = q_frag(qb + (long)irow * LDQ, vbias + h * DH, kk * 32 + g * 8);
+  }
+  float m_run = -INFINITY, l_run = 0.f;
+  float4_t acc_o[4];  // O^T: rows = head dims n*16 + g*4 + e, column = this lane's query
+#pragma unroll
+  for (int n = 0; n < 4; ++n) acc_o[n] = float4_t{0.f, 0.f, 0.f, 0.f};
+
+  const float scale2 = scale * 1.4426950408889634f;
+  const int lim = 2 * len - 1;
+  const bool qm = use_mask && (i >= len);
+  const int jthr = lim - (T - 1 - i);  // keys j < jthr: relative position T-1-i+j inside the sample's 2 len - 1 encodings
+  int klo = 0, khi = T;  // visible keys of this query row
+  if constexpr (STREAM) { if (!qm) stream_window(min(i, T - 1), T, chunk, hist, klo, khi); }
+  const float scale2q = qm ? 0.f : scale2;
+  const int gbase = r * GLDT + 15 - r;  // + jl = this lane's skewed strip column of key jl
+  int jl0[4], krow[4];
+#pragma unroll
+  for (int jt = 0; jt < 4; ++jt) {
+    jl0[jt] = 32 * (jt >> 1) + g * 8 + (jt & 1) * 4;                      // first of this lane's four keys of tile jt (C rows g*4 + e)
+    krow[jt] = 32 * (jt >> 1) + (r >> 2) * 8 + (jt & 1) * 4 + (r & 3);  // key row that is MFMA row r of tile jt (A operand)
+  }
+#ifdef TFASR_ATTN_TIMING
+  long long ph[5] = {0, 0, 0, 0, 0};
+#endif
+  const int njb = (T + BJ - 1) / BJ;
+  int jb_lo = 0, jb_hi = njb;
+  if constexpr (STREAM) {
+    if (!(use_mask && i0 + BI > len)) {
+      int lo, hi, lo2, hi2;
+      stream_window(i0, T, chunk, hist, lo, hi);
+      stream_window(min(i0 + BI - 1, T - 1), T, chunk, hist, lo2, hi2);
+      jb_lo = lo / BJ;
+      jb_hi = (hi2 + BJ - 1) / BJ;
+    }
+  }
+  // window row 127 <- the bias row R of the position table, ONCE: the block loop's DMA leaves that row alone (it was re-written after
+  // every block's DMA, behind a barrier of its own)
+  if (w == 0 && lane < 8) *reinterpret_cast<uint4*>(sP + 127 * 128 + lane * 16) = bias_row;
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (visible to the other waves behind the first block's barrier)
+  if (use_mask && i0 >= len) {
+    // every query row of this block is padding: uniform attention over ALL T keys (see relattn_fused_fwd_kernel): out = mean_j v_j, lse = log T
+    for (int jb = 0; jb < njb; ++jb) {
+      const int j0 = jb * BJ;
+      load_v(sV, vb, LDQ, j0, T, w, lane);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        short8_t pf;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) pf[t] = (j0 + 32 * q + g * 8 + t < T) ? (short)0x3F80 : (short)0;
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+          acc_o[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_v(sV, n * 16, q * 32 + g * 8, r), pf, acc_o[n], 0, 0, 0);
+      }
+      __syncthreads();
+    }
+    m_run = 0.f; l_run = (float)T;
+  } else
+  for (int jb = jb_lo; jb < jb_hi; ++jb) {
+    const int j0 = jb * BJ;
+    const int pw0 = (T - 1 - (i0 + BI - 1) + j0) + shift;  // pext row of window column 0
+#ifdef TFASR_ATTN_TIMING
+    long long tp = __builtin_readcyclecounter();
+#endif
+    load_rows<BJ>(sK, kb, LDQ, j0, T, w, lane);
+    load_v(sV, vb, LDQ, j0, T, w, lane);
+    load_rows<WIN, false, true>(sP, pb, HD, pw0, R1, w, lane);  // (window row 127 = the bias row, written once in front of the loop)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    ATT_TICK(0)
+
+    // content scores, transposed: tile jt = 16 keys x this wave's 16 queries
+    float4_t acc_s[4];
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) {
+      acc_s[jt] = float4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+        acc_s[jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(sK, krow[jt], kk * 4 + g), bqu[kk], acc_s[jt], 0, 0, 0);
+    }
+    // window scores, transposed: G^T[c][il]; this wave's skew needs window columns 48-16w .. 126-16w and column 127 (bias row)
+#pragma unroll
+    for (int gt = 0; gt < 8; ++gt) {
+      if (gt >= 3 - w && (gt <= 7 - w || gt == 7)) {
+        float4_t a = float4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(sP, gt * 16 + r, kk * 4 + g), bqv[kk], a, 0, 0, 0);
+        if (gt <= 7 - w) *reinterpret_cast<float4_t*>(sG + r * GLDT + (gt - (3 - w)) * 16 + g * 4) = a;
+        if (gt == 7 && g == 3) sGb[r] = a[3];  // window column 127 = the bias row's score
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    ATT_TICK(1)
+
+    // every skewed score is read unconditionally (the strip column 15 - il + jl exists for every key of the block), THEN selected against
+    // the bias score: a conditional read compiles to an exec-mask branch per element
+    const float gbias = sGb[r];
+    float gv[4][4];
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) gv[jt][e] = sG[gbase + jl0[jt] + e];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) {
+      const int tr = jthr - j0 - jl0[jt];  // keys e < tr of this tile have a relative position inside the table
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float pos = (e < tr) ? gv[jt][e] : gbias;
+        acc_s[jt][e] = (acc_s[jt][e] + pos) * scale2q;  // (scale2q = 0 for a padded query row: constant scores)
+      }
+    }
+    if (STREAM || j0 + BJ > T) {  // keys outside [klo, khi): past the end of a ragged last block / outside the streaming window
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int j = j0 + jl0[jt] + e;
+          if (j < klo || j >= khi) acc_s[jt][e] = -INFINITY;
+        }
+    }
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) mx = fmaxf(mx, acc_s[jt][e]);
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float m_ref = (STREAM && m_new == -INFINITY) ? 0.f : m_new;
+    const float corr = __builtin_amdgcn_exp2f(m_run - m_ref);
+    float rs = 0.f;
+    short8_t pf[2];
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) {
+      float p[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { p[e] = __builtin_amdgcn_exp2f(acc_s[jt][e] - m_ref); rs += p[e]; }
+      const uint32_t lo = pack2_bf16(p[0], p[1]), hi = pack2_bf16(p[2], p[3]);
+      const int o = (jt & 1) * 4;
+      pf[jt >> 1][o + 0] = (short)(lo & 0xffffu); pf[jt >> 1][o + 1] = (short)(lo >> 16);
+      pf[jt >> 1][o + 2] = (short)(hi & 0xffffu); pf[jt >> 1][o + 3] = (short)(hi >> 16);
+    }
+    rs += __shfl_xor(rs, 16, 64);
+    rs += __shfl_xor(rs, 32, 64);
+    l_run = l_run * corr + rs;
+    m_run = m_new;
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc_o[n][e] *= corr;
+    __builtin_amdgcn_sched_barrier(0);
+    ATT_TICK(2)
+    // O^T += V^T P^T: the probabilities are the B operand straight from registers
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int n = 0; n < 4; ++n)
+        acc_o[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_v(sV, n * 16, q * 32 + g * 8, r), pf[q], acc_o[n], 0, 0, 0);
+    ATT_TICK(3)
+    __syncthreads();  // everyone is done with sK / sV / sP before the next block's DMA lands
+    ATT_TICK(4)
+  }
+#ifdef TFASR_ATTN_TIMING
+  if (threadIdx.x == 0) {
+    long long* o = g_attn_timing + 5L * blockIdx.x;
+    for (int k = 0; k < 5; ++k) o[k] = ph[k];
+  }
+#endif
+
+  if (i < T) {
+    const float inv = 1.f / l_run;
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      uint2 v;
+      v.x = pack2_bf16(acc_o[n][0] * inv, acc_o[n][1] * inv);
+      v.y = pack2_bf16(acc_o[n][2] * inv, acc_o[n][3] * inv);
+      *reinterpret_cast<uint2*>(out + ((long)b * T + i) * HD + h * DH + n * 16 + g * 4) = v;
+    }
+    if (g == 0) lse_out[((long)b * H + h) * T + i] = m_run * 0.6931471805599453f + logf(l_run);
+  }
+}
 
 // ---------------------------------------------------------------------------------------------------------------------------------
 // Forward with 32-key blocks: 4 KB of K, 4 KB of V, a 96-row window (12 KB) and 4 strips of [16][49] f32 = 32.5 KB per workgroup, so
@@ -1282,6 +1537,20 @@ extern "C" int tfasr_relattn_fused_fwd(const void* qkv, const float* ubias, cons
   }
   const bool fwd32 = env32 ? env32[0] == '1' : (long)grid.x * grid.y * grid.z <= 4L * ncu;
   const bool st = chunk > 0;
+  static const bool fwd_t = !(getenv("TFASR_ATTN_FWD_T") && getenv("TFASR_ATTN_FWD_T")[0] == '0');  // 0: the row-oriented kernels (A/B)
+  if (fwd_t && !env32) {
+    const dim3 gridT(attn_grid_size(B, H, (T + BI - 1) / BI));
+#ifdef TFASR_ATTN_TIMING
+    static const int lds_pad = getenv("TFASR_ATTN_LDS_PAD") ? atoi(getenv("TFASR_ATTN_LDS_PAD")) : 0;  // probe: fewer workgroups per CU
+#define SMEM_FWDT (SMEM_FWDT + lds_pad)
+#endif
+    if (st) hipLaunchKernelGGL(relattn_fused_fwdT_kernel<true>, gridT, dim3(256), SMEM_FWDT, (hipStream_t)stream_, (const bf16_t*)qkv, ubias, vbias,
+                               (const bf16_t*)pext, lengths, (bf16_t*)out, lse, B, H, T, scale, use_mask, chunk, hist);
+    else hipLaunchKernelGGL(relattn_fused_fwdT_kernel<false>, gridT, dim3(256), SMEM_FWDT, (hipStream_t)stream_, (const bf16_t*)qkv, ubias, vbias,
+                            (const bf16_t*)pext, lengths, (bf16_t*)out, lse, B, H, T, scale, use_mask, chunk, hist);
+    TFASR_CHECK_LAUNCH();
+    return TFASR_STATUS_SUCCESS;
+  }
 #define TFASR_FWD_LAUNCH(KERNEL, SMEM) hipLaunchKernelGGL(KERNEL, grid, dim3(256), SMEM, (hipStream_t)stream_, (const bf16_t*)qkv, ubias, vbias, \
                                                           (const bf16_t*)pext, lengths, (bf16_t*)out, lse, B, H, T, scale, use_mask, chunk, hist)
   if (fwd32) { if (st) TFASR_FWD_LAUNCH(relattn_fused_fwd32_kernel<true>, SMEM_FWD32); else TFASR_FWD_LAUNCH(relattn_fused_fwd32_kernel<false>, SMEM_FWD32); }

@@ -9,7 +9,11 @@ int main(int argc, char** argv) {
   hipMalloc(&qkv, (size_t)B * T * 3 * HD * 2); hipMalloc(&pext, (size_t)2 * T * HD * 2); hipMalloc(&out, (size_t)B * T * HD * 2);
   hipMalloc(&u, HD * 4); hipMalloc(&v, HD * 4); hipMalloc(&lse, (size_t)B * H * T * 4); hipMalloc(&len, B * 4);
   hipMemset(qkv, 0x3c, (size_t)B * T * 3 * HD * 2); hipMemset(pext, 0x3c, (size_t)2 * T * HD * 2); hipMemset(u, 0, HD * 4); hipMemset(v, 0, HD * 4);
-  std::vector<int32_t> hl(B, T); hipMemcpy(len, hl.data(), B * 4, hipMemcpyHostToDevice);
+  std::vector<int32_t> hl(B, T);
+  if (argc > 2 && atoi(argv[2]) == 1) {  // ragged: lengths spread over [T/6, T] (a LibriSpeech-shaped batch padded to its longest utterance)
+    for (int b = 0; b < B; ++b) hl[b] = T / 6 + (int)((long)(T - T / 6) * ((b * 37) % B) / (B - 1));
+  }
+  hipMemcpy(len, hl.data(), B * 4, hipMemcpyHostToDevice);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for (int i = 0; i < 3; ++i) tfasr_relattn_fused_fwd(qkv, u, v, pext, len, out, lse, B, H, T, 64, 0.125f, 1, 0, -1, TFASR_BF16, 0);
   hipEventRecord(e0); for (int i = 0; i < 20; ++i) tfasr_relattn_fused_fwd(qkv, u, v, pext, len, out, lse, B, H, T, 64, 0.125f, 1, 0, -1, TFASR_BF16, 0);
