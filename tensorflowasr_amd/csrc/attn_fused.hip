@@ -117,10 +117,14 @@ __device__ __forceinline__ short8_t q_frag(const bf16_t* qrow, const float* bias
 // low blocks of every sample (always real frames) start first and the high ones - padding for most samples, a fraction of the work -
 // fill the tail, instead of a long-running block starting last.  Launch with a 1-D grid of attn_grid_size() workgroups.
 struct BlockId { int b, h, blk; bool ok; };
+// BLK_MAJOR = false (key-side backward: every workgroup of a sample runs equally long): the blocks of one (sample, head) are consecutive
+// in their XCD's order instead, so they are also resident at the same TIME and share the query-side tiles they all walk.
+template <bool BLK_MAJOR = true>
 __device__ __forceinline__ BlockId attn_block_id(int B, int H, int nblk) {
   const int lin = blockIdx.x, xcd = lin & 7, slot = lin >> 3;
   const int nbh = B * H, per = (nbh + 7) >> 3;
-  const int blk = slot / per, bh = (slot - blk * per) * 8 + xcd;
+  const int blk = BLK_MAJOR ? slot / per : slot % nblk;
+  const int bh = (BLK_MAJOR ? slot - blk * per : slot / nblk) * 8 + xcd;
   BlockId id;
   id.ok = bh < nbh && blk < nblk;
   id.b = bh / H; id.h = bh - id.b * H; id.blk = blk;
@@ -850,7 +854,9 @@ __global__ __launch_bounds__(256, 2) void relattn_fused_bwd_q_kernel(
   float* sG = reinterpret_cast<float*>(sP + SP_BYTES + w * SG_BYTES);
   char* sA = reinterpret_cast<char*>(sG);  // the G strip is dead once the scores are formed: reuse it for the dS A-image
   const int r = lane & 15, g = lane >> 4;
-  const int b = blockIdx.z, h = blockIdx.y, i0 = blockIdx.x * BI;
+  const BlockId bid = attn_block_id(B, H, (T + BI - 1) / BI);  // XCD-aware, live-first order (1-D grid, see attn_block_id)
+  if (!bid.ok) return;
+  const int b = bid.b, h = bid.h, i0 = bid.blk * BI;
   const int HD = H * DH, LDQ = 3 * HD, R = 2 * T - 1, R1 = 2 * T;
   const int len = lengths ? min(lengths[b], T) : T;
   const int shift = T - len;
@@ -1108,7 +1114,7 @@ __global__ __launch_bounds__(256, 2) void relattn_fused_bwd_q_kernel(
   }
 #ifdef TFASR_ATTN_TIMING
   if (threadIdx.x == 0) {
-    long long* o = g_attn_timing + 5L * (blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z));
+    long long* o = g_attn_timing + 5L * blockIdx.x;
     for (int kq = 0; kq < 5; ++kq) o[kq] = ph[kq];
   }
 #endif
@@ -1344,7 +1350,9 @@ __global__ __launch_bounds__(256, 2) void relattn_fused_bwd_k_kernel(
   char* sAp = sP + w * 4096;         // per-wave A images (P^T then dS^T), carved out of the window once it is dead
   char* sAs = sAp + 2048;
   const int r = lane & 15, g = lane >> 4;
-  const int b = blockIdx.z, h = blockIdx.y, j0 = blockIdx.x * BJ;
+  const BlockId bid = attn_block_id<false>(B, H, (T + BJ - 1) / BJ);  // the key blocks of one (sample, head) on one XCD, back to back (1-D grid)
+  if (!bid.ok) return;
+  const int b = bid.b, h = bid.h, j0 = bid.blk * BJ;
   const int HD = H * DH, LDQ = 3 * HD, R = 2 * T - 1, R1 = 2 * T;
   const int len = lengths ? min(lengths[b], T) : T;
   const int shift = T - len;
@@ -1568,7 +1576,7 @@ extern "C" int tfasr_relattn_fused_bwd_q(const void* qkv, const float* ubias, co
     return TFASR_STATUS_INVALID_VALUE;
   if (dtype != TFASR_BF16 || dh != DH) return TFASR_STATUS_UNSUPPORTED;
   dim3 grid((T + BI - 1) / BI, H, B);
-  hipLaunchKernelGGL(relattn_fused_bwd_q_kernel<false>, grid, dim3(256), SMEM_BWD_Q, (hipStream_t)stream_, (const bf16_t*)qkv, ubias, vbias,
+  hipLaunchKernelGGL(relattn_fused_bwd_q_kernel<false>, dim3(attn_grid_size(B, H, (int)grid.x)), dim3(256), SMEM_BWD_Q, (hipStream_t)stream_, (const bf16_t*)qkv, ubias, vbias,
                      (const bf16_t*)pext, lengths, (const bf16_t*)o, (const bf16_t*)dout, lse, (bf16_t*)dqu, (bf16_t*)dpos, dvec, B, H, T, ldp,
                      scale, use_mask, (bf16_t*)nullptr, (float*)nullptr);
   TFASR_CHECK_LAUNCH();
@@ -1584,11 +1592,11 @@ extern "C" int tfasr_relattn_fused_bwd_q2(const void* qkv, const float* ubias, c
   if (dtype != TFASR_BF16 || dh != DH) return TFASR_STATUS_UNSUPPORTED;
   dim3 grid((T + BI - 1) / BI, H, B);
   if (chunk > 0)
-    hipLaunchKernelGGL((relattn_fused_bwd_q_kernel<true, false, true>), grid, dim3(256), SMEM_BWD_Q, (hipStream_t)stream_, (const bf16_t*)qkv, ubias, vbias,
+    hipLaunchKernelGGL((relattn_fused_bwd_q_kernel<true, false, true>), dim3(attn_grid_size(B, H, (int)grid.x)), dim3(256), SMEM_BWD_Q, (hipStream_t)stream_, (const bf16_t*)qkv, ubias, vbias,
                        (const bf16_t*)pext, lengths, (const bf16_t*)o, (const bf16_t*)dout, lse, (bf16_t*)dqu, (bf16_t*)ds, dvec, B, H, T, lds,
                        scale, use_mask, (bf16_t*)dqv, dpext, 0L, (float*)nullptr, (float*)nullptr, chunk, hist);
   else
-  hipLaunchKernelGGL(relattn_fused_bwd_q_kernel<true>, grid, dim3(256), SMEM_BWD_Q, (hipStream_t)stream_, (const bf16_t*)qkv, ubias, vbias,
+  hipLaunchKernelGGL(relattn_fused_bwd_q_kernel<true>, dim3(attn_grid_size(B, H, (int)grid.x)), dim3(256), SMEM_BWD_Q, (hipStream_t)stream_, (const bf16_t*)qkv, ubias, vbias,
                      (const bf16_t*)pext, lengths, (const bf16_t*)o, (const bf16_t*)dout, lse, (bf16_t*)dqu, (bf16_t*)ds, dvec, B, H, T, lds,
                      scale, use_mask, (bf16_t*)dqv, dpext);
   TFASR_CHECK_LAUNCH();
@@ -1605,11 +1613,11 @@ extern "C" int tfasr_relattn_fused_bwd_q3(const void* qkv, const float* ubias, c
   if (dtype != TFASR_BF16 || dh != DH) return TFASR_STATUS_UNSUPPORTED;
   dim3 grid((T + BI - 1) / BI, H, B);
   if (chunk > 0)
-    hipLaunchKernelGGL((relattn_fused_bwd_q_kernel<true, true, true>), grid, dim3(256), SMEM_BWD_Q, (hipStream_t)stream_, (const bf16_t*)qkv, ubias, vbias,
+    hipLaunchKernelGGL((relattn_fused_bwd_q_kernel<true, true, true>), dim3(attn_grid_size(B, H, (int)grid.x)), dim3(256), SMEM_BWD_Q, (hipStream_t)stream_, (const bf16_t*)qkv, ubias, vbias,
                        (const bf16_t*)pext, lengths, (const bf16_t*)o, (const bf16_t*)dout, lse, (bf16_t*)dq, (bf16_t*)ds, dvec, B, H, T, lds, scale,
                        use_mask, (bf16_t*)nullptr, dpext, lddq, du, dv, chunk, hist, (bf16_t*)qu, (bf16_t*)qv);
   else
-  hipLaunchKernelGGL((relattn_fused_bwd_q_kernel<true, true>), grid, dim3(256), SMEM_BWD_Q, (hipStream_t)stream_, (const bf16_t*)qkv, ubias, vbias,
+  hipLaunchKernelGGL((relattn_fused_bwd_q_kernel<true, true>), dim3(attn_grid_size(B, H, (int)grid.x)), dim3(256), SMEM_BWD_Q, (hipStream_t)stream_, (const bf16_t*)qkv, ubias, vbias,
                      (const bf16_t*)pext, lengths, (const bf16_t*)o, (const bf16_t*)dout, lse, (bf16_t*)dq, (bf16_t*)ds, dvec, B, H, T, lds, scale,
                      use_mask, (bf16_t*)nullptr, dpext, lddq, du, dv, 0, 0, (bf16_t*)qu, (bf16_t*)qv);
   TFASR_CHECK_LAUNCH();
@@ -1639,10 +1647,10 @@ extern "C" int tfasr_relattn_fused_bwd_k(const void* qkv, const void* qu, const 
   if (dtype != TFASR_BF16 || dh != DH) return TFASR_STATUS_UNSUPPORTED;
   dim3 grid((T + BJ - 1) / BJ, H, B);
   if (chunk > 0)
-    hipLaunchKernelGGL(relattn_fused_bwd_k_kernel<true>, grid, dim3(256), SMEM_BWD_K, (hipStream_t)stream_, (const bf16_t*)qkv, (const bf16_t*)qu,
+    hipLaunchKernelGGL(relattn_fused_bwd_k_kernel<true>, dim3(attn_grid_size(B, H, (int)grid.x)), dim3(256), SMEM_BWD_K, (hipStream_t)stream_, (const bf16_t*)qkv, (const bf16_t*)qu,
                        (const bf16_t*)qv, (const bf16_t*)pext, lengths, (const bf16_t*)dout, lse, dvec, (bf16_t*)dqkv, B, H, T, scale, use_mask, chunk, hist);
   else
-  hipLaunchKernelGGL(relattn_fused_bwd_k_kernel<false>, grid, dim3(256), SMEM_BWD_K, (hipStream_t)stream_, (const bf16_t*)qkv, (const bf16_t*)qu,
+  hipLaunchKernelGGL(relattn_fused_bwd_k_kernel<false>, dim3(attn_grid_size(B, H, (int)grid.x)), dim3(256), SMEM_BWD_K, (hipStream_t)stream_, (const bf16_t*)qkv, (const bf16_t*)qu,
                      (const bf16_t*)qv, (const bf16_t*)pext, lengths, (const bf16_t*)dout, lse, dvec, (bf16_t*)dqkv, B, H, T, scale, use_mask, 0, 0);
   TFASR_CHECK_LAUNCH();
   return TFASR_STATUS_SUCCESS;
