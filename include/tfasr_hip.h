@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define TFASR_ABI_VERSION 27
+#define TFASR_ABI_VERSION 28
 
 typedef enum {
   TFASR_STATUS_SUCCESS = 0,
@@ -190,6 +190,15 @@ int tfasr_layernorm_fwd(const void* x, const float* gamma, const float* beta, vo
 int tfasr_ffn_fused_fwd(const void* x, const float* gamma, const float* beta, const void* W1, const float* b1, const void* W2,
                         const float* b2, void* y, void* ln, float* mean, float* rstd, void* z, void* h, long rows, int d, int F,
                         float ln_eps, float res_factor, float drop_p, long drop_seed1, long drop_seed2, int dtype, void* stream);
+/* The data-gradient side of the same module in ONE launch (csrc/ffn_fused_bwd.h): dz = res (dyd W2^T) swish'(z) mask1/(1-p) [rows, F]
+ * (written for the weight gradients), dln = dz W1^T, dx = add + LayerNorm'(dln; x, mean, rstd, gamma) (+ dx_dropped = dropout(dx) with
+ * (drop_p, drop_seed_next), NULL: none); the LayerNorm's gamma / beta sums leave as per-tile partial sums part[tiles][2 d]
+ * (tiles = tfasr_ffn_fused_bwd_tiles(rows); fold with tfasr_layernorm_bwd_fold).  dyd = dy with the second dropout's mask applied.
+ * UNSUPPORTED unless bf16, d == 256, F % 64 == 0, 128 <= F <= 1024, rows * F < 2^32, 16-byte aligned tensors. */
+int tfasr_ffn_fused_bwd_tiles(long rows);
+int tfasr_ffn_fused_bwd(const void* dyd, const void* z, const void* W1, const void* W2, const void* x, const float* gamma, const float* mean,
+                        const float* rstd, const void* add, void* dz, void* dx, void* dx_dropped, float* part, long rows, int d, int F,
+                        float res_factor, float drop_p, long drop_seed1, long drop_seed_next, int dtype, void* stream);
 int tfasr_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
                         const void* add, void* dx, float* dgamma, float* dbeta, long rows, int C, int dtype,
                         void* stream);
@@ -207,6 +216,11 @@ int tfasr_layernorm_bwd_part_blocks(long rows, int C, int dtype);
 int tfasr_layernorm_bwd_part(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, const void* add,
                              void* dx, float* part, void* dx_dropped, float drop_p, long drop_seed, long rows, int C, int dtype,
                              void* stream);
+/* ..._part with an explicit number of partial-sum slots (>= 1; a buffer shared with other producers of LayerNorm partial sums, e.g.
+   tfasr_ffn_fused_bwd, whose slot count differs): exactly nblk blocks run, the ones without rows store zeros. */
+int tfasr_layernorm_bwd_part_n(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, const void* add,
+                               void* dx, float* part, int nblk, void* dx_dropped, float drop_p, long drop_seed, long rows, int C, int dtype,
+                               void* stream);
 int tfasr_layernorm_bwd_fold(const float* part, int nsets, int nblk, int C, float* const* dgamma, float* const* dbeta, void* stream);
 int tfasr_bn_stats(const void* x, float* stats, long rows, int C, int dtype, void* stream);
 int tfasr_bn_finalize(const float* stats, float count, const float* gamma, const float* beta, float* fin,

@@ -150,7 +150,7 @@ def load(build_if_missing=True):
     return lib
 
 
-ABI_VERSION = 27
+ABI_VERSION = 28
 
 
 STATUS_UNSUPPORTED = 3

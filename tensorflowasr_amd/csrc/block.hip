@@ -258,8 +258,8 @@ struct Ex {
     const bool with_drop = dxd && drop_p() > 0.f && next_site >= 0;
     if (k->ln_part && k->ln_nsets < 8) {
       float* part = k->ln_part + (size_t)k->ln_nsets * k->ln_nblk * 2 * c->d;
-      chk(tfasr_layernorm_bwd_part(dy, x, fp(gi), mean, rstd, add, dx, part, with_drop ? dxd : nullptr, with_drop ? drop_p() : 0.f,
-                                   with_drop ? seed(next_site) : 0, rows, c->d, c->dtype, s));
+      chk(tfasr_layernorm_bwd_part_n(dy, x, fp(gi), mean, rstd, add, dx, part, k->ln_nblk, with_drop ? dxd : nullptr, with_drop ? drop_p() : 0.f,
+                                     with_drop ? seed(next_site) : 0, rows, c->d, c->dtype, s));
       k->ln_dg[k->ln_nsets] = gp(gi);
       k->ln_db[k->ln_nsets] = gp(bi);
       ++k->ln_nsets;
@@ -322,6 +322,49 @@ struct Ex {
     dense_bwd(dz, k->ff_ln[m], b0 + 2, b0 + 3, d, F, dln);
     ln_bwd(dln, k->ff_x[m], b0, b0 + 1, k->ff_mean[m], k->ff_rstd[m], dy, dx, dxd, next_site);
     rewind(mark);
+  }
+  // shapes / state for which ffm_bwd takes the one-launch data gradient (csrc/ffn_fused_bwd.h)
+  bool ffn_bwd_fused_ok() const {
+    // OPT-IN (TFASR_FFN_FUSED_BWD=1): measured slower than the three launches it replaces (per module 75 vs 68 us on the same box): the kernel
+    // is bound by its vector work (swish' + dropout hash per hidden element, 2 500 issue clocks per 64-column chunk and wave next to 1 000 of
+    // MFMA), 298 64-row tiles leave most CUs with one workgroup and some with two, and nothing overlaps the per-workgroup chain; the two GEMMs
+    // spread the same vector work over 512 evenly loaded workgroups (csrc/ffn_fused_bwd.h, tools/ffn_bwd_timing.sh)
+    static const bool on = getenv("TFASR_FFN_FUSED_BWD") && getenv("TFASR_FFN_FUSED_BWD")[0] == '1';
+    return on && block_fuse() && c->dtype == TFASR_BF16 && c->d == 256 && (c->dff % 64) == 0 && c->dff >= 128 && c->dff <= 1024 && c->save &&
+           rows * (long)c->dff < (1L << 32);
+  }
+  // FFModule backward with the data gradient in one launch: dz, dln and the LayerNorm backward never meet HBM in between; the two weight
+  // gradients (W2' = h^T dyd, W1' = ln^T dz with the bias gradients as column sums) stay with the block's grouped launch
+  bool ffm_bwd_fused(int m, const void* dy, const void* dy_dropped, void* dx, void* dxd, int site, int next_site) {
+    if (!ffn_bwd_fused_ok() || !k->ln_part || k->ln_nsets >= 8 || k->ln_nblk < tfasr_ffn_fused_bwd_tiles(rows)) return false;
+    const int b0 = m == 0 ? TFASR_BP_FF1_LN_G : TFASR_BP_FF2_LN_G;
+    const int d = c->d, F = c->dff;
+    const size_t mark = scratch.off;
+    const void* dyd = masked(dy, dy_dropped, rows * d, site + 1);
+    void* dz = act(scratch, rows * F);
+    {
+      G w; w.A = k->ff_h[m]; w.lda = F; w.ta = 1; w.B = dyd; w.ldb = d; w.tb = 0; w.D = gp(b0 + 4); w.ldd = d; w.M = F; w.N = d; w.K = (int)rows;
+      w.alpha = c->ffm_res; w.out_f32 = 1; w.accumulate = 1; w.split_k = split_k(F, d, rows);
+      w.colsum = gp(b0 + 5);
+      w.side = 1;
+      gemm(w);
+    }
+    if (!dry) {
+      const bool with_drop = dxd && drop_p() > 0.f && next_site >= 0;
+      float* part = k->ln_part + (size_t)k->ln_nsets * k->ln_nblk * 2 * d;
+      const int tiles = tfasr_ffn_fused_bwd_tiles(rows);
+      if (k->ln_nblk > tiles) zero(part + (size_t)tiles * 2 * d, (size_t)(k->ln_nblk - tiles) * 2 * d * 4);  // (slots this producer does not write)
+      const int st = tfasr_ffn_fused_bwd(dyd, k->ff_z[m], wp(b0 + 2), wp(b0 + 4), k->ff_x[m], fp(b0), k->ff_mean[m], k->ff_rstd[m], dy, dz, dx,
+                                         with_drop ? dxd : nullptr, part, rows, d, F, c->ffm_res, drop_p(), seed(site), with_drop ? seed(next_site) : 0,
+                                         c->dtype, s);
+      chk(st);
+      k->ln_dg[k->ln_nsets] = gp(b0);
+      k->ln_db[k->ln_nsets] = gp(b0 + 1);
+      ++k->ln_nsets;
+    }
+    dense_bwd(dz, k->ff_ln[m], b0 + 2, b0 + 3, d, F, nullptr);  // weight + bias gradient of the first projection only
+    rewind(mark);
+    return true;
   }
 
   // ------------------------------------------------------------------------------------------ MHSAModule
@@ -661,13 +704,15 @@ struct Ex {
       k->bw_nxtd = dr ? act(scratch, rows * d) : nullptr;
       {  // partial-sum buffers of the block's five LayerNorm backward passes (below every module's rewind mark: they live until the fold)
         static const bool fold_off = getenv("TFASR_LN_FOLD") && getenv("TFASR_LN_FOLD")[0] == '0';
-        const int nblk = fold_off ? 0 : tfasr_layernorm_bwd_part_blocks(rows, d, c->dtype);
+        int nblk = fold_off ? 0 : tfasr_layernorm_bwd_part_blocks(rows, d, c->dtype);
+        // the fused FFModule backward (tfasr_ffn_fused_bwd) leaves ITS LayerNorm's sums as one slot per 64-row tile in the same buffer
+        if (nblk > 0 && ffn_bwd_fused_ok()) nblk = std::max(nblk, tfasr_ffn_fused_bwd_tiles(rows));
         k->ln_nblk = nblk;
         k->ln_nsets = 0;
         k->ln_part = nblk > 0 ? f32(scratch, (long)8 * nblk * 2 * d) : nullptr;  // up to 8 sets (5 LayerNorms + the LayerNorm variant of the depthwise norm)
       }
       ln_bwd(io->dy, k->ln_x, TFASR_BP_LN_G, TFASR_BP_LN_B, k->ln_mean, k->ln_rstd, nullptr, k->bw_cur, k->bw_curd, 5);
-      ffm_bwd(1, k->bw_cur, k->bw_curd, k->bw_nxt, k->bw_nxtd, 4, 3);
+      if (!ffm_bwd_fused(1, k->bw_cur, k->bw_curd, k->bw_nxt, k->bw_nxtd, 4, 3)) ffm_bwd(1, k->bw_cur, k->bw_curd, k->bw_nxt, k->bw_nxtd, 4, 3);
       next_bufs(dr);
       conv_bwd_a(k->bw_cur, k->bw_curd, 3);
       k->scratch_off = scratch.off;
@@ -681,7 +726,7 @@ struct Ex {
       rewind(mark);
       next_bufs(dr);
       mhsa_bwd(k->bw_cur, k->bw_curd, k->bw_nxt, k->bw_nxtd, 2, 1);
-      ffm_bwd(0, k->bw_nxt, k->bw_nxtd, io->dx, nullptr, 0, -1);
+      if (!ffm_bwd_fused(0, k->bw_nxt, k->bw_nxtd, io->dx, nullptr, 0, -1)) ffm_bwd(0, k->bw_nxt, k->bw_nxtd, io->dx, nullptr, 0, -1);
       if (!dry && k->ln_part && k->ln_nsets > 0) {
         chk(tfasr_layernorm_bwd_fold(k->ln_part, k->ln_nsets, k->ln_nblk, d, k->ln_dg, k->ln_db, s));
         k->ln_nsets = 0;

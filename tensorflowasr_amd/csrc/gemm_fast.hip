@@ -1029,6 +1029,7 @@ int launch_epi(const tfasr_gemm_args& a, dim3 tiles, hipStream_t stream) {
 
 #include "gemm_big.h"
 #include "ffn_fused.h"
+#include "ffn_fused_bwd.h"
 
 template <bool TA, bool TB>
 int launch_one(const tfasr_gemm_args& a, hipStream_t stream) {
@@ -1249,6 +1250,41 @@ int tfasr_gemm_fast_try(const tfasr_gemm_args& a, hipStream_t stream) {
 
 // ---------------------------------------------------------------------------------------------------------------------
 // FFModule forward in one launch (ffn_fused.h).  UNSUPPORTED outside its shape range: the caller keeps the three-launch route.
+extern "C" int tfasr_ffn_fused_bwd_tiles(long rows) { return rows > 0 ? (int)((rows + 63) / 64) : 0; }
+
+extern "C" int tfasr_ffn_fused_bwd(const void* dyd, const void* z, const void* W1, const void* W2, const void* x, const float* gamma, const float* mean,
+                                   const float* rstd, const void* add, void* dz, void* dx, void* dx_dropped, float* part, long rows, int d, int F,
+                                   float res_factor, float drop_p, long drop_seed1, long drop_seed_next, int dtype, void* stream) {
+  if (!dyd || !z || !W1 || !W2 || !x || !gamma || !mean || !rstd || !dz || !dx || !part || rows <= 0 || d <= 0 || F <= 0) return TFASR_STATUS_INVALID_VALUE;
+  if (!(drop_p >= 0.f && drop_p < 1.f)) return TFASR_STATUS_INVALID_VALUE;
+  if (dtype != TFASR_BF16 || d != 256 || (F % 64) != 0 || F > 1024 || F < 128 || rows * (long)F >= (1L << 32)) return TFASR_STATUS_UNSUPPORTED;
+  const uintptr_t al = (uintptr_t)dyd | (uintptr_t)z | (uintptr_t)W1 | (uintptr_t)W2 | (uintptr_t)x | (uintptr_t)add | (uintptr_t)dz | (uintptr_t)dx |
+                       (uintptr_t)dx_dropped | (uintptr_t)gamma;
+  if (al & 15) return TFASR_STATUS_UNSUPPORTED;
+  FfnBwdArgs a;
+  a.dyd = (const bf16_t*)dyd; a.z = (const bf16_t*)z; a.W1 = (const bf16_t*)W1; a.W2 = (const bf16_t*)W2; a.x = (const bf16_t*)x;
+  a.gamma = gamma; a.mean = mean; a.rstd = rstd; a.add = (const bf16_t*)add;
+  a.dz = (bf16_t*)dz; a.dx = (bf16_t*)dx; a.dxd = (bf16_t*)dx_dropped; a.part = part;
+  a.rows = rows; a.F = F; a.res = res_factor; a.drop_p = drop_p; a.seed1 = drop_seed1; a.seed_next = drop_seed_next;
+  a.dbg = nullptr;
+#ifdef TFASR_FFN_TIMING
+  static long long* dbg_buf = nullptr;  // probe builds only (tools/hwprobe)
+  if (!dbg_buf && hipMalloc((void**)&dbg_buf, 64) != hipSuccess) dbg_buf = nullptr;
+  a.dbg = dbg_buf;
+#endif
+  const int st = launch_ffn_fused_bwd(a, (hipStream_t)stream);
+#ifdef TFASR_FFN_TIMING
+  if (getenv("TFASR_FFN_DBG_DUMP") && dbg_buf) {
+    long long h[8];
+    if (hipStreamSynchronize((hipStream_t)stream) == hipSuccess && hipMemcpy(h, dbg_buf, 64, hipMemcpyDeviceToHost) == hipSuccess)
+      fprintf(stderr, "[ffn_bwd_timing] prologue %lld | sums over the chunks: wait+barrier T %lld gemm1 %lld dz tile %lld barrier A + issue + dz store %lld wait+barrier B %lld gemm2 %lld | epilogue %lld\n",
+              h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
+  }
+#endif
+  TFASR_CHECK_LAUNCH();
+  return st;
+}
+
 extern "C" int tfasr_ffn_fused_fwd(const void* x, const float* gamma, const float* beta, const void* W1, const float* b1, const void* W2,
                                    const float* b2, void* y, void* ln, float* mean, float* rstd, void* z, void* h, long rows, int d, int F,
                                    float ln_eps, float res_factor, float drop_p, long drop_seed1, long drop_seed2, int dtype, void* stream) {

@@ -651,8 +651,9 @@ static int ln_bwd_vec_grid(long rows, int C, bool part) {
 }
 static int ln_bwd_vec_launch(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, const void* add, void* dx,
                              float* dgamma, float* dbeta, void* dx_dropped, float drop_p, long drop_seed, long rows, int C, float* part,
-                             hipStream_t s) {
-  const int grid = ln_bwd_vec_grid(rows, C, part != nullptr);
+                             hipStream_t s, int nblk = 0) {
+  // nblk > 0: the caller's partial-sum buffer has that many slots (shared with other producers): blocks without rows store zeros
+  const int grid = nblk > 0 ? nblk : ln_bwd_vec_grid(rows, C, part != nullptr);
   if (C <= 256)
     hipLaunchKernelGGL((ln_bwd_vec_kernel<bf16_t, 32, 2, 8>), dim3(grid), dim3(512), 0, s, (const bf16_t*)dy, (const bf16_t*)x, gamma, mean, rstd,
                        (const bf16_t*)add, (bf16_t*)dx, dgamma, dbeta, rows, C, (bf16_t*)dx_dropped, drop_p, (uint64_t)drop_seed, part);
@@ -674,6 +675,14 @@ extern "C" int tfasr_layernorm_bwd_part(const void* dy, const void* x, const flo
   if (dx_dropped && !(drop_p >= 0.f && drop_p < 1.f)) return TFASR_STATUS_INVALID_VALUE;
   if (dtype != TFASR_BF16 || (C % 8) || C > 512 || C <= 0) return TFASR_STATUS_UNSUPPORTED;
   return ln_bwd_vec_launch(dy, x, gamma, mean, rstd, add, dx, nullptr, nullptr, dx_dropped, drop_p, drop_seed, rows, C, part, (hipStream_t)stream_);
+}
+extern "C" int tfasr_layernorm_bwd_part_n(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, const void* add,
+                                          void* dx, float* part, int nblk, void* dx_dropped, float drop_p, long drop_seed, long rows, int C, int dtype,
+                                          void* stream_) {
+  if (!dy || !x || !gamma || !mean || !rstd || !dx || !part || rows <= 0 || nblk <= 0) return TFASR_STATUS_INVALID_VALUE;
+  if (dx_dropped && !(drop_p >= 0.f && drop_p < 1.f)) return TFASR_STATUS_INVALID_VALUE;
+  if (dtype != TFASR_BF16 || (C % 8) || C > 512 || C <= 0) return TFASR_STATUS_UNSUPPORTED;
+  return ln_bwd_vec_launch(dy, x, gamma, mean, rstd, add, dx, nullptr, nullptr, dx_dropped, drop_p, drop_seed, rows, C, part, (hipStream_t)stream_, nblk);
 }
 extern "C" int tfasr_layernorm_bwd_fold(const float* part, int nsets, int nblk, int C, float* const* dgamma, float* const* dbeta, void* stream_) {
   if (!part || nsets <= 0 || nsets > LNF_MAX || nblk <= 0 || C <= 0 || !dgamma || !dbeta) return TFASR_STATUS_INVALID_VALUE;

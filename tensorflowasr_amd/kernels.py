@@ -245,6 +245,24 @@ def ffn_fused_fwd(x, gamma, beta, W1, b1, W2, b2, res_factor, drop_p=0.0, seed1=
     return y, ln, mean, rstd, z, h
 
 
+def ffn_fused_bwd(dyd, z, W1, W2, x, gamma, mean, rstd, add, res_factor, drop_p=0.0, seed1=0, seed_next=0, want_dropped=False):
+    """tfasr_ffn_fused_bwd: the FFModule's data gradient in one launch.  Returns (dz, dx, dx_dropped | None, part [tiles, 2 d]) - the LayerNorm's
+    gamma / beta sums are the column sums of `part` (layernorm_bwd_fold's input) - or None when the shape is outside the kernel's range."""
+    rows, d = x.shape
+    F = W1.shape[1]
+    tiles = int(_L().tfasr_ffn_fused_bwd_tiles(rows))
+    dz = torch.empty(rows, F, dtype=x.dtype, device=x.device)
+    dx = torch.empty_like(x)
+    dxd = torch.empty_like(x) if want_dropped else None
+    part = torch.empty(tiles, 2 * d, dtype=torch.float32, device=x.device)
+    st = _L().tfasr_ffn_fused_bwd(_p(dyd), _p(z), _p(W1), _p(W2), _p(x), _p(gamma), _p(mean), _p(rstd), _p(add), _p(dz), _p(dx), _p(dxd), _p(part),
+                                  rows, d, F, float(res_factor), float(drop_p), int(seed1), int(seed_next), _dt(x), _stream())
+    if st == _lib.STATUS_UNSUPPORTED:
+        return None
+    check(st, "ffn_fused_bwd")
+    return dz, dx, dxd, part
+
+
 def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, add=None, dx=None, dropped=None, drop_p=0.0, drop_seed=0):
     """dropped (optional, same shape as dx): also receives dropout(dx, drop_p, drop_seed) from the same kernel."""
     rows, C = x.numel() // x.shape[-1], x.shape[-1]

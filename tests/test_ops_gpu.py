@@ -638,3 +638,55 @@ def test_depthwise_data_gradient_with_glu_backward_fused(dev):
     torch.cuda.synchronize()
     err = (fused.float() - ref.float()).abs().max().item()
     assert err <= 2e-2 * ref.float().abs().max().item() + 1e-3, err
+
+
+@pytest.mark.parametrize("rows,F,p", [(200, 1024, 0.1), (64, 256, 0.0), (333, 512, 0.25)])
+def test_ffn_fused_fwd_and_bwd_match_the_three_launch_arithmetic(dev, rows, F, p):
+    """tfasr_ffn_fused_fwd / tfasr_ffn_fused_bwd (FFModule.call and its data gradient, encoders/conformer.py:101-109) against the same
+    arithmetic written out in f32 torch on the bf16 operands, dropout masks regenerated with tfasr_dropout (a pure function of seed + index);
+    ragged last tile, dropout off / on."""
+    bf = torch.bfloat16
+    d = 256
+    g = torch.Generator().manual_seed(rows + F)
+    rnd = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(dev)
+    x, gm, bt = rnd(rows, d).to(bf), 1.0 + 0.1 * rnd(d), 0.1 * rnd(d)
+    W1, b1, W2, b2 = rnd(d, F, sc=1 / 16).to(bf), 0.1 * rnd(F), rnd(F, d, sc=1 / 32).to(bf), 0.1 * rnd(d)
+    s1, s2, s3, res = 101, 102, 103, 0.5
+    out = K.ffn_fused_fwd(x, gm, bt, W1, b1, W2, b2, res, p, s1, s2)
+    assert out is not None
+    y, ln, mean, rstd, z, h = out
+    ones = lambda n, m: torch.ones(n, m, dtype=bf, device=dev)
+    m1 = K.dropout(ones(rows, F), p, s1).float() if p > 0 else torch.ones(rows, F, device=dev)   # (mask / (1 - p))
+    m2 = K.dropout(ones(rows, d), p, s2).float() if p > 0 else torch.ones(rows, d, device=dev)
+    xf = x.float()
+    mu = xf.mean(1, keepdim=True)
+    var = ((xf - mu) ** 2).mean(1, keepdim=True)
+    ln_ref = ((xf - mu) * torch.rsqrt(var + 1e-3) * gm + bt)
+    torch.testing.assert_close(ln.float(), ln_ref, rtol=2e-2, atol=2e-2)
+    z_ref = ln.float() @ W1.float() + b1
+    torch.testing.assert_close(z.float(), z_ref, rtol=2e-2, atol=2e-2)
+    h_ref = torch.nn.functional.silu(z.float()) * m1
+    torch.testing.assert_close(h.float(), h_ref, rtol=2e-2, atol=2e-2)
+    y_ref = xf + res * ((h.float() @ W2.float() + b2) * m2)
+    torch.testing.assert_close(y.float(), y_ref, rtol=2e-2, atol=3e-2)
+    # backward: dy -> dyd (second dropout's mask) -> dz, dln, LayerNorm backward (+ residual-path gradient), dropped copy for the next module
+    dy = rnd(rows, d).to(bf)
+    dyd = (dy.float() * m2).to(bf)
+    got = K.ffn_fused_bwd(dyd, z, W1, W2, x, gm, mean, rstd, dy, res, p, s1, s3, want_dropped=True)
+    assert got is not None
+    dz, dx, dxd, part = got
+    torch.cuda.synchronize()
+    zf = z.float()
+    sg = torch.sigmoid(zf)
+    dz_ref = res * (dyd.float() @ W2.float().t()) * (sg * (1 + zf * (1 - sg))) * m1
+    rel = lambda a, b: float(((a - b) ** 2).sum().sqrt() / (b ** 2).sum().sqrt())
+    assert rel(dz.float(), dz_ref) < 6e-3
+    dln = dz.float() @ W1.float().t()
+    xh = (xf - mean[:, None]) * rstd[:, None]
+    dg = dln * gm
+    dx_ref = dy.float() + rstd[:, None] * (dg - dg.mean(1, keepdim=True) - xh * (dg * xh).mean(1, keepdim=True))
+    assert rel(dx.float(), dx_ref) < 6e-3
+    m3 = K.dropout(ones(rows, d), p, s3).float() if p > 0 else torch.ones(rows, d, device=dev)
+    torch.testing.assert_close(dxd.float(), (dx.float() * m3).to(bf).float(), rtol=1e-2, atol=1e-3)
+    sums = part.sum(0)
+    assert rel(sums[:d], (dln * xh).sum(0)) < 5e-3 and rel(sums[d:], dln.sum(0)) < 5e-3
