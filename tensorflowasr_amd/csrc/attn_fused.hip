@@ -975,6 +975,9 @@ __global__ __launch_bounds__(256, 2) void relattn_fused_bwd_q_kernel(
   long long ph[5] = {0, 0, 0, 0, 0};
 #endif
   const int njb = (T + BJ - 1) / BJ;
+  // window row 127 <- the bias row R of the position table, ONCE (the block loop's DMA leaves that row alone; visible behind the first barrier)
+  if (w == 0 && lane < 8) *reinterpret_cast<uint4*>(sP + 127 * 128 + lane * 16) = bias_row;
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   for (int jb = 0; jb < njb; ++jb) {
     const int j0 = jb * BJ;
     const int pw0 = (T - 1 - (i0 + BI - 1) + j0) + shift;
@@ -983,11 +986,9 @@ __global__ __launch_bounds__(256, 2) void relattn_fused_bwd_q_kernel(
 #endif
     load_rows<BJ>(sK, kb, LDQ, j0, T, w, lane);
     load_rows<BJ>(sV, vb, LDQ, j0, T, w, lane);
-    load_rows<WIN>(sP, pb, HD, pw0, R1, w, lane);
+    load_rows<WIN, false, true>(sP, pb, HD, pw0, R1, w, lane);  // (window row 127 = the bias row, written once in front of the loop)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (w == 0 && lane < 8) *reinterpret_cast<uint4*>(sP + 127 * 128 + lane * 16) = bias_row;  // loaded once, in front of the loop
-    __syncthreads();
     ATT_TICK(0)
 
     float4_t acc_s[4], acc_p[4];
