@@ -279,7 +279,10 @@ enum : int { E_ACT = 1 /* swish(+prez) */, E_DACT = 2 /* * swish'(dact_z) */, E_
 // (weight gradients), whose main loop runs at the DMA round trip per slab with a single slab in flight).
 // FIXED: the caller chose this workgroup's tile itself: bid = tile index inside the gx x gy grid, G = its k-slice (grouped launch).
 // SEG: K-segments (tfasr_gemm_args.seg_*): slab s of the k loop reads its operands at a table offset instead of s * BK.
-template <bool TA, bool TB, int BN_, int EPI, int NST = 2, bool FIXED = false, bool SEG = false>
+// ONE: every workgroup owns exactly ONE tile (the grid is the tile list): no cross-tile prefetch, so the epilogue strips may lie OVER the
+// (then dead) stage buffers - 48 KiB of LDS for the 64-column variant = 39 granules = THREE workgroups per CU (with its own strips it is
+// 46 granules = two; 596 tiles on 512 persistent slots also ran as two rounds).
+template <bool TA, bool TB, int BN_, int EPI, int NST = 2, bool FIXED = false, bool SEG = false, bool ONE = false>
 __device__ __forceinline__ void gemm_fast_body(const tfasr_gemm_args& p, const int gx, const int gy, const int gz, const int ntiles, const int bid, const int G) {
   constexpr bool GEN = (EPI & E_GEN) != 0;
   constexpr bool C_ACT = GEN || (EPI & E_ACT), C_DACT = GEN || (EPI & E_DACT), C_DROP = GEN || (EPI & E_DROP), C_RES = GEN || (EPI & E_RES);
@@ -508,9 +511,13 @@ __device__ __forceinline__ void gemm_fast_body(const tfasr_gemm_args& p, const i
       }
     }
     // ---- cross-tile prefetch: both stages are idle now ----
-    const Tile nxt = tile_of(it + 1);
-    if (nxt.nfull > 0) issue(nxt, 0, 0);
-    if (nxt.nfull > 1) issue(nxt, 1, 1);
+    Tile nxt;
+    if constexpr (ONE) nxt.nfull = -1;
+    else {
+      nxt = tile_of(it + 1);
+      if (nxt.nfull > 0) issue(nxt, 0, 0);
+      if (nxt.nfull > 1) issue(nxt, 1, 1);
+    }
 #ifdef TFASR_GEMM_TIMING
     const long long t_main = __builtin_readcyclecounter();
 #endif
@@ -559,7 +566,7 @@ __device__ __forceinline__ void gemm_fast_body(const tfasr_gemm_args& p, const i
       constexpr int LPRW = WN / 8;        // lanes per strip row: 8 (BN 128) or 4 (BN 64), 8 columns each
       constexpr int RPP = 64 / LPRW;      // rows per pass: 8 or 16
       constexpr int NPASS = 16 / RPP;     // 2 or 1
-      float* sc = reinterpret_cast<float*>(smem + NST * STAGE_BYTES) + w * (RPP * SLD);
+      float* sc = reinterpret_cast<float*>(smem + (ONE ? 0 : NST * STAGE_BYTES)) + w * (RPP * SLD);  // (ONE: over the dead stages)
       const int prow = lane / LPRW, c8 = (lane % LPRW) * 8;
       const int col0 = n0 + wn * WN + c8;
       const bool vec_ok = C_WS ? ((p.N & 7) == 0) : (((p.ldd & 7) == 0) && ((((uintptr_t)p.D) & 15) == 0) && ((doff & 7) == 0));
@@ -768,6 +775,11 @@ _Pragma("unroll")
 template <bool TA, bool TB, int BN_, int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_fast_kernel(const tfasr_gemm_args p, const int gx, const int gy, const int gz, const int ntiles) {
   gemm_fast_body<TA, TB, BN_, EPI>(p, gx, gy, gz, ntiles, (int)blockIdx.x, (int)gridDim.x);
+}
+// one tile per workgroup, three workgroups per CU (64-column tiles: <= 168 registers, 48 KiB of LDS)
+template <bool TA, bool TB, int EPI>
+__global__ __launch_bounds__(256, 3) void gemm_fast_one_kernel(const tfasr_gemm_args p, const int gx, const int gy, const int gz, const int ntiles) {
+  gemm_fast_body<TA, TB, 64, EPI, 2, false, false, true>(p, gx, gy, gz, ntiles, (int)blockIdx.x, (int)gridDim.x);
 }
 // K-segmented A / B operands (convolution taps as row shifts): same body, slab offsets from a table
 template <bool TA, bool TB>
@@ -1019,6 +1031,16 @@ int launch_epi(const tfasr_gemm_args& a, dim3 tiles, hipStream_t stream) {
   // 2 resident workgroups per CU; TFASR_GEMM_SLOTS=1 is an experiment hook: one persistent workgroup per CU walking more tiles
   static const int per_cu = getenv("TFASR_GEMM_SLOTS") && getenv("TFASR_GEMM_SLOTS")[0] == '1' ? 1 : 2;
   const int slots = per_cu * num_cus();
+  if constexpr (BN_ == 64 && (EPI & (E_WS | E_CSUM | E_LSE)) == 0) {
+    // every tile its own workgroup, three per CU, when the tile list fits three per CU at once (TFASR_GEMM_ONE=0: the persistent kernel)
+    static const bool one_off = getenv("TFASR_GEMM_ONE") && getenv("TFASR_GEMM_ONE")[0] == '0';
+    if (!one_off && a.split_k <= 1 && ntiles > slots && ntiles <= 3L * num_cus()) {
+      constexpr int SMEM1 = 2 * (A_BYTES + 64 * BK * 2);
+      hipLaunchKernelGGL((gemm_fast_one_kernel<TA, TB, EPI>), dim3((unsigned)ntiles), dim3(256), SMEM1, stream, a, (int)tiles.x, (int)tiles.y, (int)tiles.z, (int)ntiles);
+      TFASR_CHECK_LAUNCH();
+      return TFASR_STATUS_SUCCESS;
+    }
+  }
   int G = (int)(ntiles < slots ? ntiles : slots);
   if (ntiles >= slots) G &= ~7;
   constexpr int SMEM = 2 * (A_BYTES + BN_ * BK * 2) + 4 * (64 / (BN_ / 16)) * (BN_ / 2 + 4) * 4;  // stages + 4 waves' strips
@@ -1040,8 +1062,13 @@ int launch_one(const tfasr_gemm_args& a, hipStream_t stream) {
   // workgroups per CU overlap them (14.2 vs 16.9 us on [12096,256,1024]).  TFASR_GEMM_BN64=0 restores the old rule.
   static const bool bn64_off = getenv("TFASR_GEMM_BN64") && getenv("TFASR_GEMM_BN64")[0] == '0';
   const long t128 = (long)((a.N + 127) / 128) * ((a.M + BM - 1) / BM) * a.nb1 * a.nb2 * split;
-  static const long bn64_thr = getenv("TFASR_GEMM_BN64_T") ? atol(getenv("TFASR_GEMM_BN64_T")) : (long)num_cus();
-  const bool narrow = !a.lse_part && !a.seg_a_off && (a.N <= 64 || (!bn64_off && t128 <= bn64_thr && a.N > 64 && !(a.accumulate && a.ws)));
+  // Round 4: up to 1.5 x CUs 128-wide tiles (e.g. 372 for N = 256 at 23.8 k rows: one or two workgroups per CU, unevenly) the product runs
+  // as twice as many 64-column tiles, ONE per workgroup, three workgroups per CU (gemm_fast_one_kernel): 17.0 -> 16.3 us (data gradients),
+  // 16.2 -> 13.0 us (bias + residual + dropout epilogue), -0.1 ms/step.
+  static const long bn64_thr = getenv("TFASR_GEMM_BN64_T") ? atol(getenv("TFASR_GEMM_BN64_T")) : (long)num_cus() * 3 / 2;
+  // (between 1 x and 1.5 x CUs only products the one-tile kernel takes: no split-K, no accumulation / column sums)
+  const long bn64_lim = (split <= 1 && !a.accumulate && !a.colsum) ? bn64_thr : std::min(bn64_thr, (long)num_cus());
+  const bool narrow = !a.lse_part && !a.seg_a_off && (a.N <= 64 || (!bn64_off && t128 <= bn64_lim && a.N > 64 && !(a.accumulate && a.ws)));
   const int bn = narrow ? 64 : 128;
   dim3 grid((a.N + bn - 1) / bn, (a.M + BM - 1) / BM, a.nb1 * a.nb2 * split);
   if ((long)grid.x * grid.y * grid.z > 0x7fffffffL) return TFASR_STATUS_INVALID_VALUE;
