@@ -1034,7 +1034,8 @@ int launch_epi(const tfasr_gemm_args& a, dim3 tiles, hipStream_t stream) {
   if constexpr (BN_ == 64 && (EPI & (E_WS | E_CSUM | E_LSE)) == 0) {
     // every tile its own workgroup, three per CU, when the tile list fits three per CU at once (TFASR_GEMM_ONE=0: the persistent kernel)
     static const bool one_off = getenv("TFASR_GEMM_ONE") && getenv("TFASR_GEMM_ONE")[0] == '0';
-    if (!one_off && a.split_k <= 1 && ntiles > slots && ntiles <= 3L * num_cus()) {
+    static const long one_max = getenv("TFASR_GEMM_ONE_MAX") ? atol(getenv("TFASR_GEMM_ONE_MAX")) : (1L << 30);  // probe: upper bound in tiles per CU
+    if (!one_off && a.split_k <= 1 && ntiles > slots && ntiles <= one_max * num_cus()) {
       constexpr int SMEM1 = 2 * (A_BYTES + 64 * BK * 2);
       hipLaunchKernelGGL((gemm_fast_one_kernel<TA, TB, EPI>), dim3((unsigned)ntiles), dim3(256), SMEM1, stream, a, (int)tiles.x, (int)tiles.y, (int)tiles.z, (int)ntiles);
       TFASR_CHECK_LAUNCH();
@@ -1062,11 +1063,13 @@ int launch_one(const tfasr_gemm_args& a, hipStream_t stream) {
   // workgroups per CU overlap them (14.2 vs 16.9 us on [12096,256,1024]).  TFASR_GEMM_BN64=0 restores the old rule.
   static const bool bn64_off = getenv("TFASR_GEMM_BN64") && getenv("TFASR_GEMM_BN64")[0] == '0';
   const long t128 = (long)((a.N + 127) / 128) * ((a.M + BM - 1) / BM) * a.nb1 * a.nb2 * split;
-  // Round 4: up to 1.5 x CUs 128-wide tiles (e.g. 372 for N = 256 at 23.8 k rows: one or two workgroups per CU, unevenly) the product runs
-  // as twice as many 64-column tiles, ONE per workgroup, three workgroups per CU (gemm_fast_one_kernel): 17.0 -> 16.3 us (data gradients),
-  // 16.2 -> 13.0 us (bias + residual + dropout epilogue), -0.1 ms/step.
-  static const long bn64_thr = getenv("TFASR_GEMM_BN64_T") ? atol(getenv("TFASR_GEMM_BN64_T")) : (long)num_cus() * 3 / 2;
-  // (between 1 x and 1.5 x CUs only products the one-tile kernel takes: no split-K, no accumulation / column sums)
+  // Round 4: every product the one-tile kernel takes (no split-K, no accumulation / column sums) runs as 64-column tiles, ONE per workgroup,
+  // three workgroups per CU (gemm_fast_one_kernel), whatever its size: 744 128-wide tiles on 512 persistent slots are two rounds with half
+  // the chip idle in the second, 1 488 narrow tiles on 768 dynamic slots are 1.94.  Same-box A/B: [rows,256]x[256,768|512] 17.8 -> 17.0 us,
+  // the FFN data gradient with its swish' + dropout epilogue 38.6 -> 34.3, N = 256 products 17.0 -> 16.3 / 16.2 -> 13.0; M 23.23 -> 23.01 ms/step,
+  // S 12.17 -> 12.01.  TFASR_GEMM_BN64_T=<128-wide tiles> restores a threshold (256 = round 3's rule).
+  static const long bn64_thr = getenv("TFASR_GEMM_BN64_T") ? atol(getenv("TFASR_GEMM_BN64_T")) : (1L << 40);
+  // (above 1 x CUs only products the one-tile kernel takes)
   const long bn64_lim = (split <= 1 && !a.accumulate && !a.colsum) ? bn64_thr : std::min(bn64_thr, (long)num_cus());
   const bool narrow = !a.lse_part && !a.seg_a_off && (a.N <= 64 || (!bn64_off && t128 <= bn64_lim && a.N > 64 && !(a.accumulate && a.ws)));
   const int bn = narrow ? 64 : 128;
