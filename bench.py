@@ -319,7 +319,11 @@ def bench_decode(args, model, cfg, dev):
     line["breakdown"] = {"frontend_encoder_ms": round(enc_ms, 3), "search_ms": round(srch_ms, 3),
                          "encoder_f32_tflops": round(enc_flop / (enc_ms * 1e-3) / 1e12, 1), "encoder_f32_mfma_frac": round(enc_flop / (enc_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
                          "search_us_per_token": round(srch_ms * 1e3 / max(ntok, 1), 2),
-                         "note": "HIP events around model.encode (log-mel + f32 encoder) and recognize_encoded (greedy search); fraction of the exact-f32 MFMA peak"}
+                         "search_iterations": int(getattr(twin, "last_search_iterations", 0)),
+                         "search_us_per_iteration": round(srch_ms * 1e3 / max(int(getattr(twin, "last_search_iterations", 0)), 1), 2),
+                         "note": "HIP events around model.encode (log-mel + f32 encoder) and recognize_encoded (greedy search); fraction of the exact-f32 MFMA peak; "
+                                 "search_iterations = iterations of the batch loop (one frame or one token per row each): with random weights one row "
+                                 "never emits blank, so the loop runs to this build's cap T + max_tokens + 2 (the reference's while_loop would not end)"}
     if "bf16" in res:
         line["bf16_encoder"] = {"value": round(res["bf16"][0] / (B * secs), 6), "ms_per_step": round(res["bf16"][0] * 1e3, 3),
                                 "tokens_emitted": res["bf16"][1], "note": "training kernels (bf16 storage); not token-exact vs the f32 reference"}

@@ -1307,6 +1307,7 @@ class ConformerTransducer(BaseModel):
                 it += 1
             if int(active.item()) == 0:
                 break
+        self.last_search_iterations = it  # (queued iterations incl. the no-op tail of the last batch; bench.py reports it)
         states = torch.stack([h, cst], dim=1).unsqueeze(1)  # [B, 1, 2, P]
         return PredictOutput(tokens=tokens[:, :max_tokens], next_tokens=prev_tok.view(B, 1), next_encoder_states=None,
                              next_decoder_states=states)
