@@ -1277,8 +1277,13 @@ class ConformerTransducer(BaseModel):
         lng, lnb = (ps.p("pred/ln/g"), ps.p("pred/ln/b")) if c.prediction_layer_norm else (None, None)
         fused = B <= 64 and os.environ.get("TFASR_DECODE_FUSED", "1") != "0"
         packed = K.decode_pack(ps.p("pred/emb"), Wk, Wrk, Wjp, Wv) if fused else None  # tile order of the MFMA step kernels
+        # Iterations queued per host check (fused route).  A row leaves the loop only after it has consumed its frames, one per blank, so
+        # max_b(frames left) iterations are certain to be needed: that many are queued without looking (the first batch is ~T' long), then
+        # the counters are read back ONCE per batch (one device -> host sync) - 4-5 syncs per search instead of one per 64 iterations; the
+        # no-op tail of the last batch is at most `check_every` iterations.
+        need = int(elen[0]) - 1 if mode == 1 else max(int(v) for v in elen) - 1
         while it < max_iters:
-            n = min(check_every * 4 if fused else check_every, max_iters - it)  # fused iterations are cheap no-ops once the loop has ended
+            n = min(max(need, check_every) if fused else check_every, max_iters - it)
             if fused:
                 # `n` iterations = 3 skinny-product launches + the bookkeeping kernel each (csrc/decode_step.hip), queued by one host call
                 fused = K.decode_steps(ps.p("pred/emb"), Wk, Wrk, ps.p("pred/lstm/b"), lng, lnb, Wjp, ps.p("joint/pred/b"), Wv,
@@ -1286,7 +1291,9 @@ class ConformerTransducer(BaseModel):
                                        logits, tokens, per_frame, max_tokens, self.blank, mode, max_tokens_per_frame, n, packed=packed)
                 if fused:
                     it += n
-                    if int(active.item()) == 0:
+                    left = (nframes - 1 - frame_idx).clamp_(min=0).max()
+                    act_h, need = (int(v) for v in torch.stack([active[0], left]).tolist())  # (one sync)
+                    if act_h == 0:
                         break
                     continue
             for _ in range(n):
