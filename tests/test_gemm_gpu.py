@@ -251,3 +251,35 @@ def test_pipeline_race_screen_bitwise_repeatable(dev, ta, tb, mnk):
     Af = (A.float().t() if ta else A.float())[rows.to(dev)]
     ref = Af @ (B.float().t() if tb else B.float())
     np.testing.assert_allclose(outs[0][rows.to(dev)].float().cpu().numpy(), ref.cpu().numpy(), rtol=2e-2, atol=2e-2 * float(np.sqrt(K)))
+
+
+@pytest.mark.parametrize("N,K", [(256, 1024), (1024, 256)])
+def test_epilogues_on_the_one_tile_per_workgroup_kernel(dev, N, K):
+    """gemm_fast_one_kernel (64-column tiles, one per workgroup, epilogue strips over the dead stage buffers, three workgroups per CU) takes
+    every bf16 product without split-K / accumulation that has more tiles than resident slots: bias + swish + pre-activation, swish' of a
+    stored pre-activation, bias + residual, and the plain NT data-gradient form at a Conformer-M shape (19 072 rows, ragged last row tile)."""
+    M = 19072 - 40
+    bf = torch.bfloat16
+    g = torch.Generator().manual_seed(N + K)
+    A = (torch.randn(M, K, generator=g) * 0.3).to(dev).to(bf)
+    B = (torch.randn(K, N, generator=g) * 0.3).to(dev).to(bf)
+    bias = torch.randn(N, generator=g).to(dev)
+    res = torch.randn(M, N, generator=g).to(dev).to(bf)
+    rows = torch.randint(0, M, (96,), generator=g).to(dev)
+    rows[:4] = torch.tensor([0, 1, M - 2, M - 1], device=dev)
+    Af, Bf = A.float()[rows], B.float()
+    prez = torch.empty(M, N, dtype=bf, device=dev)
+    out = kernels.matmul(A, B, bias=bias, prez=prez, alpha=0.5, act=ACT_SWISH)
+    z = Af @ Bf * 0.5 + bias
+    tol = dict(rtol=3e-2, atol=3e-2 * float(np.sqrt(K)) * 0.3)
+    np.testing.assert_allclose(prez[rows].float().cpu().numpy(), z.cpu().numpy(), **tol)
+    np.testing.assert_allclose(out[rows].float().cpu().numpy(), torch.nn.functional.silu(prez[rows].float()).cpu().numpy(), rtol=2e-2, atol=2e-2)
+    dz = kernels.matmul(A, B, dact_z=prez, dact=ACT_SWISH)
+    zz = prez[rows].float()
+    s = torch.sigmoid(zz)
+    np.testing.assert_allclose(dz[rows].float().cpu().numpy(), ((Af @ Bf) * (s * (1 + zz * (1 - s)))).cpu().numpy(), **tol)
+    out2 = kernels.matmul(A, B, bias=bias, res=res, beta=0.5)
+    np.testing.assert_allclose(out2[rows].float().cpu().numpy(), (res[rows].float() + 0.5 * (Af @ Bf + bias)).cpu().numpy(), **tol)
+    Bt = B.t().contiguous()
+    out3 = kernels.matmul(A, Bt, trans_b=True)
+    np.testing.assert_allclose(out3[rows].float().cpu().numpy(), (Af @ Bf).cpu().numpy(), **tol)
