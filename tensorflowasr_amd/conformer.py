@@ -258,12 +258,16 @@ class ConformerTransducer(BaseModel):
             K.bn_stats(x2d, stats)
             count = (x2d.shape[0] if rows is None else rows) * self.dp.world
             self.dp.allreduce_stats_(stats[:2 * C])
-            K.bn_finalize(stats, count, ps.p(name + "/g"), ps.p(name + "/b"), fin, ps.state[name + "/mm"], ps.state[name + "/mv"], 0.99, 1e-3, True)
         else:
-            count = x2d.shape[0]
-            K.bn_finalize(None, 1, ps.p(name + "/g"), ps.p(name + "/b"), fin, ps.state[name + "/mm"], ps.state[name + "/mv"], 0.99, 1e-3, False)
-        y = K.bn_apply_fwd(x2d, fin, act, y=y)
-        return y, (fin, count)
+            stats, count = None, x2d.shape[0]
+        # statistics -> coefficients (+ moving statistics) -> normalise + activation in ONE launch where the row kernel applies
+        got = K.bn_finalize_apply_fwd(x2d, stats, count if training else 1, ps.p(name + "/g"), ps.p(name + "/b"), fin, ps.state[name + "/mm"],
+                                      ps.state[name + "/mv"], act, y=y, training=training)
+        if got is None:
+            K.bn_finalize(stats, count if training else 1, ps.p(name + "/g"), ps.p(name + "/b"), fin, ps.state[name + "/mm"], ps.state[name + "/mv"],
+                          0.99, 1e-3, training)
+            got = K.bn_apply_fwd(x2d, fin, act, y=y)
+        return got, (fin, count)
 
     def _bn_bwd(self, x2d, dy2d, name, saved, act, dx=None):
         fin, count = saved

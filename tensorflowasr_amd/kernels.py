@@ -303,6 +303,20 @@ def bn_finalize(stats, count, gamma, beta, fin, moving_mean, moving_var, momentu
     check(_L().tfasr_bn_finalize(_p(stats), float(count), _p(gamma), _p(beta), _p(fin), _p(moving_mean), _p(moving_var), momentum, eps, C, int(training), _stream()), "bn_finalize")
 
 
+def bn_finalize_apply_fwd(x, stats, count, gamma, beta, fin, moving_mean, moving_var, act=ACT_NONE, y=None, momentum=0.99, eps=1e-3, training=True):
+    """tfasr_bn_finalize + tfasr_bn_apply_fwd in one launch (fin and the moving statistics written as bn_finalize would); returns y, or None
+    when the channel count is outside the row kernel's range (the caller runs the two launches)."""
+    rows, C = x.numel() // x.shape[-1], x.shape[-1]
+    if y is None:
+        y = torch.empty_like(x)
+    st = _L().tfasr_bn_finalize_apply_fwd(_p(x), _p(stats), float(count), _p(gamma), _p(beta), _p(fin), _p(moving_mean), _p(moving_var), momentum, eps,
+                                          _p(y), rows, C, act, int(training), _dt(x), _stream())
+    if st == _lib.STATUS_UNSUPPORTED:
+        return None
+    check(st, "bn_finalize_apply_fwd")
+    return y
+
+
 def bn_apply_fwd(x, fin, act=ACT_NONE, y=None):
     rows, C = x.numel() // x.shape[-1], x.shape[-1]
     if y is None:
