@@ -1070,7 +1070,10 @@ int launch_one(const tfasr_gemm_args& a, hipStream_t stream) {
   // S 12.17 -> 12.01.  TFASR_GEMM_BN64_T=<128-wide tiles> restores a threshold (256 = round 3's rule).
   static const long bn64_thr = getenv("TFASR_GEMM_BN64_T") ? atol(getenv("TFASR_GEMM_BN64_T")) : (1L << 40);
   // (above 1 x CUs only products the one-tile kernel takes)
-  const long bn64_lim = (split <= 1 && !a.accumulate && !a.colsum) ? bn64_thr : std::min(bn64_thr, (long)num_cus());
+  // ... and with K <= 256 or N <= 256 (the Conformer's d = 256 layers: four slabs per tile, or two 128-wide column tiles).  With both >= 512
+  // (ContextNet's 512 - 1280-channel layers) the 128-wide persistent kernel amortises a tile better (cross-tile prefetch, half the operand
+  // bytes per flop): 33.3 vs 35.5 us per launch there, ContextNet-L 45.0 vs 45.4 ms/step.
+  const long bn64_lim = (split <= 1 && !a.accumulate && !a.colsum && std::min(a.K, a.N) <= 256) ? bn64_thr : std::min(bn64_thr, (long)num_cus());
   const bool narrow = !a.lse_part && !a.seg_a_off && (a.N <= 64 || (!bn64_off && t128 <= bn64_lim && a.N > 64 && !(a.accumulate && a.ws)));
   const int bn = narrow ? 64 : 128;
   dim3 grid((a.N + bn - 1) / bn, (a.M + BM - 1) / BM, a.nb1 * a.nb2 * split);
