@@ -1063,7 +1063,7 @@ int launch_one(const tfasr_gemm_args& a, hipStream_t stream) {
   // workgroups per CU overlap them (14.2 vs 16.9 us on [12096,256,1024]).  TFASR_GEMM_BN64=0 restores the old rule.
   static const bool bn64_off = getenv("TFASR_GEMM_BN64") && getenv("TFASR_GEMM_BN64")[0] == '0';
   const long t128 = (long)((a.N + 127) / 128) * ((a.M + BM - 1) / BM) * a.nb1 * a.nb2 * split;
-  // Round 4: every product the one-tile kernel takes (no split-K, no accumulation / column sums) runs as 64-column tiles, ONE per workgroup,
+  // Round 4: every product the one-tile kernel takes (no split-K, no accumulation / column sums; see bn64_lim below) runs as 64-column tiles, ONE per workgroup,
   // three workgroups per CU (gemm_fast_one_kernel), whatever its size: 744 128-wide tiles on 512 persistent slots are two rounds with half
   // the chip idle in the second, 1 488 narrow tiles on 768 dynamic slots are 1.94.  Same-box A/B: [rows,256]x[256,768|512] 17.8 -> 17.0 us,
   // the FFN data gradient with its swish' + dropout epilogue 38.6 -> 34.3, N = 256 products 17.0 -> 16.3 / 16.2 -> 13.0; M 23.23 -> 23.01 ms/step,
