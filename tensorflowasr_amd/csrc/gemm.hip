@@ -18,7 +18,7 @@ constexpr int BM = 128, BN = 128;
 
 template <typename T> struct Cfg;
 template <> struct Cfg<bf16_t> { static constexpr int BK = 64, LD = 72; };
-template <> struct Cfg<float>  { static constexpr int BK = 16, LD = 17; };
+template <> struct Cfg<float>  { static constexpr int BK = 16, LD = 17; };  // (32-deep slabs measured slower: encoder 22.5 vs 18.3 ms)
 
 __device__ __forceinline__ bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
@@ -127,6 +127,75 @@ __device__ __forceinline__ void load_trans(float* s, const float* g, long ld, in
   }
 }
 
+// f32 slabs in two steps - global -> registers, registers -> LDS - so that slab k+1 can be in flight while slab k is multiplied
+// (same element placement as load_direct / load_trans above; 128 x 16 floats = 2 float4 per thread and operand)
+struct F32Stage { float v[128 * Cfg<float>::BK / 4 / 256][4]; };
+template <int ROWS>
+__device__ __forceinline__ void fetch_direct(F32Stage& st, const float* g, long ld, int rows0, int nrows_total, int kt, int k_end) {
+  constexpr int BK = Cfg<float>::BK;
+#pragma unroll
+  for (int it = 0; it < ROWS * Cfg<float>::BK / 4 / 256; ++it) {
+    const int c = threadIdx.x + it * 256;
+    const int row = c / (BK / 4), kc = (c % (BK / 4)) * 4;
+    const int gr = rows0 + row, gk = kt + kc;
+    float* v = st.v[it];
+    v[0] = v[1] = v[2] = v[3] = 0.f;
+    if (gr < nrows_total) {
+      const float* p = g + (long)gr * ld + gk;
+      if (gk + 4 <= k_end && aligned16(p)) {
+        const float4 q = *reinterpret_cast<const float4*>(p);
+        v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) if (gk + i < k_end) v[i] = p[i];
+      }
+    }
+  }
+}
+template <int ROWS>
+__device__ __forceinline__ void store_direct(float* s, const F32Stage& st) {
+  constexpr int BK = Cfg<float>::BK, LD = Cfg<float>::LD;
+#pragma unroll
+  for (int it = 0; it < ROWS * Cfg<float>::BK / 4 / 256; ++it) {
+    const int c = threadIdx.x + it * 256;
+    const int row = c / (BK / 4), kc = (c % (BK / 4)) * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s[row * LD + kc + i] = st.v[it][i];
+  }
+}
+template <int ROWS>
+__device__ __forceinline__ void fetch_trans(F32Stage& st, const float* g, long ld, int rows0, int nrows_total, int kt, int k_end) {
+#pragma unroll
+  for (int it = 0; it < ROWS * Cfg<float>::BK / 4 / 256; ++it) {
+    const int c = threadIdx.x + it * 256;
+    const int k = c / (ROWS / 4), r4 = (c % (ROWS / 4)) * 4;
+    const int gk = kt + k, gr = rows0 + r4;
+    float* v = st.v[it];
+    v[0] = v[1] = v[2] = v[3] = 0.f;
+    if (gk < k_end && gr < nrows_total) {
+      const float* p = g + (long)gk * ld + gr;
+      if (gr + 4 <= nrows_total && aligned16(p)) {
+        const float4 q = *reinterpret_cast<const float4*>(p);
+        v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) if (gr + i < nrows_total) v[i] = p[i];
+      }
+    }
+  }
+}
+template <int ROWS>
+__device__ __forceinline__ void store_trans(float* s, const F32Stage& st) {
+  constexpr int LD = Cfg<float>::LD;
+#pragma unroll
+  for (int it = 0; it < ROWS * Cfg<float>::BK / 4 / 256; ++it) {
+    const int c = threadIdx.x + it * 256;
+    const int k = c / (ROWS / 4), r4 = (c % (ROWS / 4)) * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s[(r4 + i) * LD + k] = st.v[it][i];
+  }
+}
+
 // ---- MFMA inner product over one LDS slab ---------------------------------------------------
 __device__ __forceinline__ void mma_slab(const bf16_t* sA, const bf16_t* sB, int wm, int wn, int lane,
                                          float4_t (&acc)[4][4]) {
@@ -147,21 +216,22 @@ __device__ __forceinline__ void mma_slab(const bf16_t* sA, const bf16_t* sB, int
       for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
   }
 }
+template <int NJ>  // 16-column fragments per wave: 4 (128-column tile) or 2 (64-column tile)
 __device__ __forceinline__ void mma_slab(const float* sA, const float* sB, int wm, int wn, int lane,
                                          float4_t (&acc)[4][4]) {
   constexpr int BK = Cfg<float>::BK, LD = Cfg<float>::LD;
   const int r = lane & 15, g = lane >> 4;
 #pragma unroll
   for (int kk = 0; kk < BK / 4; ++kk) {
-    float a[4], b[4];
+    float a[4], b[NJ];
 #pragma unroll
     for (int i = 0; i < 4; ++i) a[i] = sA[(wm * 64 + i * 16 + r) * LD + kk * 4 + g];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) b[j] = sB[(wn * 64 + j * 16 + r) * LD + kk * 4 + g];
+    for (int j = 0; j < NJ; ++j) b[j] = sB[(wn * (NJ * 16) + j * 16 + r) * LD + kk * 4 + g];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+      for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
   }
 }
 
@@ -183,10 +253,13 @@ __device__ __forceinline__ float apply_dact(float z, int act) {
   }
 }
 
-template <typename T, bool TA, bool TB>
+// BN_: columns per tile.  64 only for f32: exact-f32 products with few 128-wide tiles (N = 256 at 8 000 rows: 126 tiles for 256 CUs) run as
+// twice as many 128 x 64 tiles - same slabs, same k order per element: bitwise the same results.
+template <typename T, bool TA, bool TB, int BN_ = BN>
 __global__ __launch_bounds__(256) void gemm_kernel(const tfasr_gemm_args p) {
-  constexpr int BK = Cfg<T>::BK, LD = Cfg<T>::LD;
-  __shared__ __attribute__((aligned(16))) T smem[(BM + BN) * LD];
+  constexpr int BK = Cfg<T>::BK, LD = Cfg<T>::LD, NJ = BN_ / 32;
+  static_assert(BN_ == BN || sizeof(T) == 4, "narrow tiles: f32 only");
+  __shared__ __attribute__((aligned(16))) T smem[(BM + BN_) * LD];
   T* sA = smem;
   T* sB = smem + BM * LD;
 
@@ -198,7 +271,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const tfasr_gemm_args p) {
   const T* Bm = (const T*)p.B + b1 * p.sB1 + b2 * p.sB2;
   const long doff = b1 * p.sD1 + b2 * p.sD2;
 
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN_;
   int kchunk = (p.K + split - 1) / split;
   kchunk = ((kchunk + BK - 1) / BK) * BK;
   const int k_begin = ks * kchunk;
@@ -213,6 +286,25 @@ __global__ __launch_bounds__(256) void gemm_kernel(const tfasr_gemm_args p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = float4_t{0.f, 0.f, 0.f, 0.f};
 
+  if constexpr (sizeof(T) == 4) {
+    // exact-f32 path (parity mode, token-exact inference): slab k+1 is fetched into registers BEFORE slab k's 64 MFMAs per wave and stored to
+    // LDS behind them - the load latency (one round trip per 16-deep slab) used to sit between every two slabs.  Same slabs, same k order:
+    // bitwise the same results.
+    F32Stage pa, pb;
+    auto fetch = [&](int kt) {
+      if (TA) fetch_trans<BM>(pa, (const float*)A, p.lda, m0, p.M, kt, k_end); else fetch_direct<BM>(pa, (const float*)A, p.lda, m0, p.M, kt, k_end);
+      if (TB) fetch_direct<BN_>(pb, (const float*)Bm, p.ldb, n0, p.N, kt, k_end); else fetch_trans<BN_>(pb, (const float*)Bm, p.ldb, n0, p.N, kt, k_end);
+    };
+    if (k_begin < k_end) fetch(k_begin);
+    for (int kt = k_begin; kt < k_end; kt += BK) {
+      if (TA) store_trans<BM>((float*)sA, pa); else store_direct<BM>((float*)sA, pa);
+      if (TB) store_direct<BN_>((float*)sB, pb); else store_trans<BN_>((float*)sB, pb);
+      __syncthreads();
+      if (kt + BK < k_end) fetch(kt + BK);
+      mma_slab<NJ>((const float*)sA, (const float*)sB, wm, wn, lane, acc);
+      __syncthreads();
+    }
+  } else {
   for (int kt = k_begin; kt < k_end; kt += BK) {
     if (TA) load_trans(sA, A, p.lda, m0, p.M, kt, k_end); else load_direct(sA, A, p.lda, m0, p.M, kt, k_end);
     // B: trans_b==1 -> stored [N,K] (k contiguous) = "direct"; trans_b==0 -> stored [K,N] = needs transpose
@@ -220,6 +312,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const tfasr_gemm_args p) {
     __syncthreads();
     mma_slab(sA, sB, wm, wn, lane, acc);
     __syncthreads();
+  }
   }
 
   // ---- epilogue ----
@@ -233,8 +326,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const tfasr_gemm_args p) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int col = n0 + wn * 64 + j * 16 + r;
+    for (int j = 0; j < NJ; ++j) {
+      const int col = n0 + wn * (NJ * 16) + j * 16 + r;
       const bool col_ok = col < p.N;
       const float bias = (p.bias && first_split && col_ok) ? p.bias[col] : 0.f;
 #pragma unroll
@@ -266,6 +359,27 @@ int launch(const tfasr_gemm_args& a, hipStream_t stream) {
   dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, a.nb1 * a.nb2 * split);
   if (grid.y > 65535 || grid.z > 65535) return TFASR_STATUS_INVALID_VALUE;
   dim3 block(256);
+  if constexpr (sizeof(T) == 4) {
+    // f32: 128 x 64 tiles while the 128-wide tiling leaves CUs without a workgroup of their own (TFASR_GEMM_F32_NARROW=0: never)
+    static const bool narrow_off = getenv("TFASR_GEMM_F32_NARROW") && getenv("TFASR_GEMM_F32_NARROW")[0] == '0';
+    static int ncu = 0;
+    if (ncu == 0) {
+      int dev = 0, v = 0;
+      ncu = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
+    }
+    if (!narrow_off && a.N > 64 && (long)grid.x * grid.y * grid.z < 2L * ncu) {
+      dim3 g2((a.N + 63) / 64, grid.y, grid.z);
+      if (a.trans_a) {
+        if (a.trans_b) hipLaunchKernelGGL((gemm_kernel<T, true, true, 64>), g2, block, 0, stream, a);
+        else           hipLaunchKernelGGL((gemm_kernel<T, true, false, 64>), g2, block, 0, stream, a);
+      } else {
+        if (a.trans_b) hipLaunchKernelGGL((gemm_kernel<T, false, true, 64>), g2, block, 0, stream, a);
+        else           hipLaunchKernelGGL((gemm_kernel<T, false, false, 64>), g2, block, 0, stream, a);
+      }
+      TFASR_CHECK_LAUNCH();
+      return TFASR_STATUS_SUCCESS;
+    }
+  }
   if (a.trans_a) {
     if (a.trans_b) hipLaunchKernelGGL((gemm_kernel<T, true, true>), grid, block, 0, stream, a);
     else           hipLaunchKernelGGL((gemm_kernel<T, true, false>), grid, block, 0, stream, a);
