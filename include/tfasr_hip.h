@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define TFASR_ABI_VERSION 28
+#define TFASR_ABI_VERSION 29
 
 typedef enum {
   TFASR_STATUS_SUCCESS = 0,
@@ -222,6 +222,10 @@ int tfasr_layernorm_bwd_part_n(const void* dy, const void* x, const float* gamma
                                void* dx, float* part, int nblk, void* dx_dropped, float drop_p, long drop_seed, long rows, int C, int dtype,
                                void* stream);
 int tfasr_layernorm_bwd_fold(const float* part, int nsets, int nblk, int C, float* const* dgamma, float* const* dbeta, void* stream);
+/* The same for up to 128 sets that lie in different buffers (part[i] = [nblk][2C] of set i; host arrays of device pointers): the
+   LayerNorms of every Conformer block of a step in one launch. */
+int tfasr_layernorm_bwd_fold_sets(const float* const* part, int nsets, int nblk, int C, float* const* dgamma, float* const* dbeta,
+                                  void* stream);
 int tfasr_bn_stats(const void* x, float* stats, long rows, int C, int dtype, void* stream);
 int tfasr_bn_finalize(const float* stats, float count, const float* gamma, const float* beta, float* fin,
                       float* moving_mean, float* moving_var, float momentum, float eps, int C, int training,
@@ -249,6 +253,10 @@ int tfasr_cast(const void* src, void* dst, long n, int src_dtype, int dst_dtype,
 int tfasr_dropout(const void* x, void* y, long n, float p, long seed, int dtype, void* stream);
 /* out[c] += scale * sum_r x[r*ld + c]   (bias gradients) */
 int tfasr_colsum(const void* x, long ld, float* out, long rows, int C, float scale, int dtype, void* stream);
+/* nmat <= 64 f32 matrices x + b * stride [rows, C] -> bf16 copies y + b * stride (stride in elements, a multiple of 4; C % 4 == 0) and
+   colsum[b][c] += sum_r x_b[r, c] from the f32 values (host array of device pointers, NULL entries skipped), one launch: the operand and
+   the bias gradient of the positional-projection weight gradients of every Conformer block (tfasr_block_io.defer_pos_grad). */
+int tfasr_cast_colsum_many(const float* x, void* y, long stride, int nmat, int rows, int C, float* const* colsum, void* stream);
 /* GLU over the last axis: x [rows, 2C] -> y [rows, C] = x[:, :C] * sigmoid(x[:, C:])  (activations/glu.py:25-28) */
 int tfasr_glu_fwd(const void* x, void* y, long rows, int C, int dtype, void* stream);
 int tfasr_glu_bwd(const void* x, const void* dy, void* dx, long rows, int C, int dtype, void* stream);
@@ -603,6 +611,21 @@ typedef struct {
      forward stash of a block alive until tfasr_block_wgrad_join, and (iii) calls tfasr_block_wgrad_join before anything reads the
      gradients.  0 = in line on `stream` (default). */
   int wgrad_slot;
+  /* Work that is the same for every block of a step, or independent of a block's dependent chain, taken OUT of the chain (a kernel
+     boundary costs 2.65 us on this chip whatever the kernel does: tools/hwprobe/anyorder_test; 16 blocks x 4 such launches per step):
+     pext_pre != NULL (forward): the projected relative-position table [2T, H*dh] of THIS block (pe @ Wpos + bpos, compute dtype),
+       computed by the caller ahead of the chain (e.g. on another stream while the subsampling runs); the block does not launch the
+       projection.  Must stay alive until the block's backward.
+     defer_pos_grad != 0 (backward; needs dpext_zero): the block only ACCUMULATES the table's gradient into dpext_zero (f32); cast,
+       projection weight gradient (gWpos += pe^T dpext) and bias gradient (column sums) are left to the caller, who runs them for all
+       blocks at once after the last block's backward.
+     ln_part_ext != NULL (backward): caller-owned partial-sum buffer of the block's LayerNorm gamma / beta gradients (at least
+       8 * tfasr_layernorm_bwd_part_blocks(rows, d, dtype) * 2d floats, alive until tfasr_block_ln_fold_all): the block does not launch
+       its own fold; the caller folds every block of the step with ONE launch (tfasr_block_ln_fold_all over the blocks' ctx). */
+  const void* pext_pre;
+  int defer_pos_grad;
+  float* ln_part_ext;
+  size_t ln_part_ext_floats;
 } tfasr_block_io;
 
 size_t tfasr_block_ctx_bytes(void);
@@ -614,6 +637,9 @@ int tfasr_block_fwd(const tfasr_block_cfg* cfg, const tfasr_block_params* params
 int tfasr_block_wgrad_join(int slot_mask, void* stream);
 int tfasr_block_bwd(const tfasr_block_cfg* cfg, const tfasr_block_params* params, const tfasr_block_io* io, void* ctx,
                     int phase, void* stream);
+/* dgamma / dbeta of every LayerNorm of `n` blocks whose backward ran with io->ln_part_ext: one launch instead of one per block.
+   ctx[i] = the ctx of block i's tfasr_block_bwd call (host memory); blocks without pending partial sums are skipped. */
+int tfasr_block_ln_fold_all(void* const* ctx, int n, int d, void* stream);
 
 #ifdef __cplusplus
 }

@@ -97,6 +97,14 @@ class ConformerTransducer(BaseModel):
         self.wgrad_stream = os.environ.get("TFASR_WGRAD_STREAM", "0") == "1"
         self._blk_params, self._blk_sizes = {}, {}
         self._zero_pool = {}
+        # Launches that do not belong to the blocks' dependent chain leave it (a kernel boundary costs 2.65 us on this chip, tools/hwprobe/
+        # anyorder_test, and hipExtAnyOrderLaunch is a no-op on gfx9): every block's positional projection pe @ Wpos + bpos is computed on a
+        # third stream while the subsampling runs (tfasr_block_io.pext_pre), and on ONE GPU the projections' gradients and the LayerNorm
+        # gamma / beta folds of all blocks run once after the last block's backward (defer_pos_grad, ln_part_ext) - with a data-parallel
+        # group a block's gradient slice has to be final when its bucket is released, so the per-block launches stay.  TFASR_BLOCK_HOIST=0: off.
+        self.block_hoist = os.environ.get("TFASR_BLOCK_HOIST", "1") != "0"
+        self.aux_stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
+        self._hoisted = {}
         self.fuse_joint_stats = os.environ.get("TFASR_JOINT_STATS", "1") != "0"
         # Joint + loss WITHOUT materialised lattice logits (SURVEY section 7 step 8 / 8(d) "report both"): the projection emits only the
         # log-softmax statistics, the gradient pass re-computes the logit tile and turns it into the loss gradient in its epilogue
@@ -806,6 +814,9 @@ class ConformerTransducer(BaseModel):
         io.bn_stats = stats.data_ptr()
         io.prezeroed = 1 if pool is not None else 0
         io.stash, io.stash_bytes, io.scratch, io.scratch_bytes = stash.data_ptr(), stash_b, scratch.data_ptr(), scratch.numel()
+        pext_all = self._hoisted.get("pext")
+        if pext_all is not None:
+            io.pext_pre = pext_all[i].data_ptr()
         cbuf = K.block_ctx()
         if training and (self.dp.world > 1 or self._dp_force_split) and not cfgk.dw_norm_layer:
             K.block_fwd(cfgk, P, io, cbuf, K._lib.PHASE_A)
@@ -814,7 +825,7 @@ class ConformerTransducer(BaseModel):
         else:
             K.block_fwd(cfgk, P, io, cbuf, K._lib.PHASE_A | K._lib.PHASE_B)
         if save:
-            ctx[f"enc/block{i}/native"] = dict(cfg=cfgk, P=P, io=io, cbuf=cbuf, keep=(x, y, stash, stats, elen_dev))
+            ctx[f"enc/block{i}/native"] = dict(cfg=cfgk, P=P, io=io, cbuf=cbuf, keep=(x, y, stash, stats, elen_dev, pext_all))
         return y
 
     def _block_bwd_native(self, dy, i, ctx):
@@ -834,6 +845,16 @@ class ConformerTransducer(BaseModel):
             bstats = torch.empty(2 * d, dtype=torch.float32, device=self.device)
             io.prezeroed &= ~2
             io.dpext_zero = None
+        io.defer_pos_grad, io.ln_part_ext, io.ln_part_ext_floats = 0, None, 0
+        hb = self._hoisted.get("bwd")
+        if hb is not None:
+            if io.dpext_zero:
+                io.defer_pos_grad = 1
+                hb["pos"].append(i)
+            if hb["ln_part"] is not None:
+                io.ln_part_ext = hb["ln_part"][i].data_ptr()
+                io.ln_part_ext_floats = hb["ln_part"].shape[1]
+                hb["ctx"].append(cbuf)
         # grouped weight gradients of this block on the executor's second stream, beside the next block's backward: two arenas, alternating
         slot = 0
         if self.wgrad_stream and self.dtype == torch.bfloat16:
@@ -855,12 +876,21 @@ class ConformerTransducer(BaseModel):
     # =================================================================================== encoder
     def encoder_fwd(self, feats, flen, training, ctx):
         """ConformerEncoder.call (conformer.py:672-701): subsample -> linear -> relpe -> blocks.  -> [B*T', d], T', lengths."""
+        native = self.native_blocks and not self.time_sections
+        self._hoisted = {}
+        hoist = native and self.block_hoist and self.dtype == torch.bfloat16 and self._fused_attention() and self.aux_stream is not None
+        if hoist:
+            self._pext_ahead((((feats.shape[1] + 1) // 2) + 1) // 2)
         t0 = self._tick("subsampling_fwd")
         x, T, elen = self._subsampling_fwd(feats, flen, training, ctx)
         self._tock("subsampling_fwd", t0)
         B = feats.shape[0]
         elen_dev = self._h2d(elen)
-        native = self.native_blocks and not self.time_sections
+        if hoist:
+            pext_all = self._hoisted["pext"]
+            assert pext_all.shape[1] == 2 * T
+            torch.cuda.current_stream().wait_stream(self.aux_stream)
+            pext_all.record_stream(torch.cuda.current_stream())
         # one memset clears every block's BatchNorm accumulators (forward) / BN + positional-gradient accumulators (backward)
         # instead of three small in-stream memsets per block (tfasr_block_io.prezeroed)
         self._zero_pool = {}
@@ -872,13 +902,38 @@ class ConformerTransducer(BaseModel):
         for i in range(self.cfg.num_blocks):
             x = self._block_fwd_native(x, i, B, T, elen_dev, training, ctx) if native else self._block_fwd(x, i, B, T, elen_dev, training, ctx)
         if ctx is not None:
-            ctx["enc"] = dict(B=B, T=T, elen_dev=elen_dev)
+            ctx["enc"] = dict(B=B, T=T, elen_dev=elen_dev, hoist=hoist)
         return x, T, elen, elen_dev
+
+    def _pext_ahead(self, T):
+        """Every block's projected relative-position table pe @ Wpos + bpos [2T', H*dh] on the auxiliary stream, beside the subsampling:
+        none of them depends on the activations (MultiHeadRelativeAttention projects the same encoding table in every layer,
+        multihead_attention.py:543-558), so 16 launches leave the blocks' dependent chain."""
+        ps, c = self.ps, self.cfg
+        HD = c.num_heads * ps.head_phys
+        pe = self._pe_ext(T)
+        main = torch.cuda.current_stream()
+        pext_all = torch.empty(c.num_blocks, 2 * T, HD, dtype=self.dtype, device=self.device)
+        self.aux_stream.wait_stream(main)  # (the shadow weights were written on `main` by the previous step's optimizer)
+        pext_all.record_stream(self.aux_stream)
+        with torch.cuda.stream(self.aux_stream):
+            for i in range(c.num_blocks):
+                pfx = f"enc/block{i}/mhsa/"
+                K.matmul(pe, ps.w2d(pfx + "pos/w"), bias=ps.p(pfx + "pos/b"), out=pext_all[i])
+        self._hoisted["pext"] = pext_all
 
     def encoder_bwd(self, dx, ctx):
         e = ctx["enc"]
         if "bwd_shape" in self._zero_pool:
             self._zero_pool["bwd"] = torch.zeros(*self._zero_pool.pop("bwd_shape"), dtype=torch.float32, device=self.device)
+        # one GPU: positional-projection gradients and LayerNorm folds of all blocks after the loop (see __init__); a data-parallel group
+        # releases a block's gradient bucket right behind the block, so there the block finishes them itself
+        self._hoisted["bwd"] = None
+        if e.get("hoist") and isinstance(self.dp, SingleProcess) and self._zero_pool.get("bwd") is not None:
+            c = self.cfg
+            nblk = K.layernorm_bwd_part_blocks(e["B"] * e["T"], c.dmodel, self.dtype)
+            ln_part = torch.empty(c.num_blocks, 8 * nblk * 2 * c.dmodel, dtype=torch.float32, device=self.device) if nblk > 0 else None
+            self._hoisted["bwd"] = dict(pos=[], ctx=[], ln_part=ln_part)
         # a block's gradients are complete once its weight-gradient group on the second stream is: its bucket is released one block
         # later, after this stream has been made to wait for that group (the wait the next user of the slot's arena needs anyway)
         prev = None
@@ -897,9 +952,41 @@ class ConformerTransducer(BaseModel):
             if prev[1]:
                 K.block_wgrad_join(3)
             self._bucket_after_block(prev[0])
+        hb = self._hoisted.pop("bwd", None)
+        if hb is not None:
+            self._deferred_block_grads(hb, e["T"])
         t0 = self._tick("subsampling_bwd")
         self._subsampling_bwd(dx, ctx)
         self._tock("subsampling_bwd", t0)
+
+    def _deferred_block_grads(self, hb, T):
+        """What the blocks left to the caller (tfasr_block_io.defer_pos_grad / ln_part_ext): gWpos_i += pe^T dpext_i and gbpos_i +=
+        colsum(dpext_i) for every block - one cast + column-sum launch over all the f32 tables, the products in grouped launches - and one
+        fold for the LayerNorm gamma / beta gradients of all blocks."""
+        ps, c = self.ps, self.cfg
+        d, HD, R1 = c.dmodel, c.num_heads * ps.head_phys, 2 * T
+        if hb["pos"]:
+            pool = self._zero_pool["bwd"]
+            off = -(-2 * d // 64) * 64
+            # ONE launch: bf16 copies of every block's f32 table gradient (the weight-gradient operands) + the bias gradients from the f32 values
+            pool_t = torch.empty(pool.shape, dtype=self.dtype, device=self.device)
+            nb = pool.shape[0]
+            sums = [ps.g(f"enc/block{i}/mhsa/pos/b") if i in hb["pos"] else None for i in range(nb)]
+            K.cast_colsum_many(pool[:, off:], pool_t[:, off:], pool.shape[1], nb, R1, HD, sums)
+            pe = self._pe_ext(T)
+            calls = []
+            for i in hb["pos"]:
+                pfx = f"enc/block{i}/mhsa/"
+                calls.append(dict(A=pe, B=pool_t[i, off:off + R1 * HD], out=ps.g2d(pfx + "pos/w"), M=d, N=HD, K=R1, lda=d, ldb=HD, ldd=HD, trans_a=True,
+                                  accumulate=True, split_k=1))
+            for j in range(0, len(calls), 8):
+                grp = calls[j:j + 8]
+                if len(grp) == 1:
+                    K.gemm(**grp[0])
+                else:
+                    K.gemm_group(grp)
+        if hb["ctx"]:
+            K.block_ln_fold_all(hb["ctx"], d)
 
     def _bucket_after_block(self, i):
         lo = self.ps.offsets[f"enc/block{i}/ff1/ln/g"]

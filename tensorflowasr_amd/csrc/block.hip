@@ -51,6 +51,7 @@ struct Ctx {
   // LayerNorm gamma / beta gradients as per-block partial sums, folded by ONE launch at the end of the block's backward
   float* ln_part;
   int ln_nblk, ln_nsets;
+  bool ln_ext;  // ln_part is the caller's buffer (tfasr_block_io.ln_part_ext): the fold is tfasr_block_ln_fold_all's
   float *ln_dg[8], *ln_db[8];
 };
 
@@ -380,7 +381,11 @@ struct Ex {
     k->at_att = act(stash, rows * HD);
     ln_fwd(x, TFASR_BP_AT_LN_G, TFASR_BP_AT_LN_B, k->at_ln, k->at_mean, k->at_rstd);
     dense(k->at_ln, TFASR_BP_AT_QKV_W, TFASR_BP_AT_QKV_B, k->at_qkv, d, 3 * HD);
-    {
+    if (!dry && io->pext_pre) {
+      // the projected position table does not depend on the activations: the caller has computed it ahead of the chain (io->pext_pre);
+      // (the stash slot stays allocated so that the arena layout does not depend on the option)
+      k->at_pext = (void*)io->pext_pre;
+    } else {
       G p; p.A = P->pe; p.lda = d; p.ta = 0; p.B = wp(TFASR_BP_AT_POS_W); p.ldb = HD; p.tb = 0; p.D = k->at_pext; p.ldd = HD; p.M = R1; p.N = HD; p.K = d;
       p.bias = fp(TFASR_BP_AT_POS_B);
       gemm(p);
@@ -537,20 +542,22 @@ struct Ex {
       }
     }
     if (!dry && !dq_done) chk(tfasr_bias2_bwd(dqu, dqv, dqkv, 3 * HD, gp(TFASR_BP_AT_U), gp(TFASR_BP_AT_V), rows, HD, c->dtype, s));
-    // positional projection: gWpos += pe^T dpext ; gbpos += colsum(dpext)
+    // positional projection: gWpos += pe^T dpext ; gbpos += colsum(dpext) - unless the caller takes them for all blocks at once
+    // (io->defer_pos_grad: dpext stays in io->dpext_zero; three launches per block leave the chain)
+    const bool pos_deferred = io->defer_pos_grad && io->dpext_zero && dpext == io->dpext_zero;
     const void* dpext_t = dpext;
     if (c->dtype != TFASR_F32) {
-      void* t = act(scratch, (long)R1 * HD);
-      if (!dry) chk(tfasr_cast(dpext, t, (long)R1 * HD, TFASR_F32, c->dtype, s));
+      void* t = act(scratch, (long)R1 * HD);  // (allocated either way: the arena layout does not depend on the option)
+      if (!dry && !pos_deferred) chk(tfasr_cast(dpext, t, (long)R1 * HD, TFASR_F32, c->dtype, s));
       dpext_t = t;
     }
-    {
+    if (!pos_deferred) {
       G a; a.A = P->pe; a.lda = d; a.ta = 1; a.B = dpext_t; a.ldb = HD; a.tb = 0; a.D = gp(TFASR_BP_AT_POS_W); a.ldd = HD; a.M = d; a.N = HD; a.K = R1;
       a.out_f32 = 1; a.accumulate = 1;
       a.side = 1;
       gemm(a);
+      if (!dry) chk(tfasr_colsum(dpext, HD, gp(TFASR_BP_AT_POS_B), R1, HD, 1.f, TFASR_F32, s));
     }
-    if (!dry) chk(tfasr_colsum(dpext, HD, gp(TFASR_BP_AT_POS_B), R1, HD, 1.f, TFASR_F32, s));
     void* dln = act(scratch, rows * d);
     dense_bwd(dqkv, k->at_ln, TFASR_BP_AT_QKV_W, TFASR_BP_AT_QKV_B, d, 3 * HD, dln);
     ln_bwd(dln, k->at_x, TFASR_BP_AT_LN_G, TFASR_BP_AT_LN_B, k->at_mean, k->at_rstd, dy, dx, dxd, next_site);
@@ -710,6 +717,9 @@ struct Ex {
         k->ln_nblk = nblk;
         k->ln_nsets = 0;
         k->ln_part = nblk > 0 ? f32(scratch, (long)8 * nblk * 2 * d) : nullptr;  // up to 8 sets (5 LayerNorms + the LayerNorm variant of the depthwise norm)
+        // caller-owned buffer: the sums outlive this call and tfasr_block_ln_fold_all folds every block of the step in one launch
+        k->ln_ext = !dry && k->ln_part && io->ln_part_ext && io->ln_part_ext_floats >= (size_t)8 * nblk * 2 * d;
+        if (k->ln_ext) k->ln_part = io->ln_part_ext;
       }
       ln_bwd(io->dy, k->ln_x, TFASR_BP_LN_G, TFASR_BP_LN_B, k->ln_mean, k->ln_rstd, nullptr, k->bw_cur, k->bw_curd, 5);
       if (!ffm_bwd_fused(1, k->bw_cur, k->bw_curd, k->bw_nxt, k->bw_nxtd, 4, 3)) ffm_bwd(1, k->bw_cur, k->bw_curd, k->bw_nxt, k->bw_nxtd, 4, 3);
@@ -727,7 +737,7 @@ struct Ex {
       next_bufs(dr);
       mhsa_bwd(k->bw_cur, k->bw_curd, k->bw_nxt, k->bw_nxtd, 2, 1);
       if (!ffm_bwd_fused(0, k->bw_nxt, k->bw_nxtd, io->dx, nullptr, 0, -1)) ffm_bwd(0, k->bw_nxt, k->bw_nxtd, io->dx, nullptr, 0, -1);
-      if (!dry && k->ln_part && k->ln_nsets > 0) {
+      if (!dry && k->ln_part && k->ln_nsets > 0 && !k->ln_ext) {
         chk(tfasr_layernorm_bwd_fold(k->ln_part, k->ln_nsets, k->ln_nblk, d, k->ln_dg, k->ln_db, s));
         k->ln_nsets = 0;
       }
@@ -818,4 +828,34 @@ extern "C" int tfasr_block_bwd(const tfasr_block_cfg* c, const tfasr_block_param
   e.backward(phase);
   if (!e.scratch.ok) return TFASR_STATUS_INVALID_VALUE;
   return e.st;
+}
+
+// One fold launch for every block whose backward left its LayerNorm partial sums in a caller-owned buffer (tfasr_block_io.ln_part_ext).
+extern "C" int tfasr_block_ln_fold_all(void* const* ctx, int n, int d, void* stream) {
+  if (!ctx || n <= 0 || d <= 0) return TFASR_STATUS_INVALID_VALUE;
+  const float* part[128];
+  float* dg[128];
+  float* db[128];
+  int ns = 0, nblk = 0;
+  for (int i = 0; i < n; ++i) {
+    Ctx* k = (Ctx*)ctx[i];
+    if (!k) return TFASR_STATUS_INVALID_VALUE;
+    if (!k->ln_ext || !k->ln_part || k->ln_nsets <= 0) continue;
+    if (nblk == 0) nblk = k->ln_nblk;
+    if (k->ln_nblk != nblk) return TFASR_STATUS_INVALID_VALUE;  // (one batch shape per step: every block has the same slot count)
+    for (int q = 0; q < k->ln_nsets; ++q) {
+      if (ns == 128) {
+        const int st = tfasr_layernorm_bwd_fold_sets(part, ns, nblk, d, dg, db, stream);
+        if (st != TFASR_STATUS_SUCCESS) return st;
+        ns = 0;
+      }
+      part[ns] = k->ln_part + (size_t)q * nblk * 2 * d;
+      dg[ns] = k->ln_dg[q];
+      db[ns] = k->ln_db[q];
+      ++ns;
+    }
+    k->ln_nsets = 0;
+  }
+  if (ns > 0) return tfasr_layernorm_bwd_fold_sets(part, ns, nblk, d, dg, db, stream);
+  return TFASR_STATUS_SUCCESS;
 }

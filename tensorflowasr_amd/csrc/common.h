@@ -78,11 +78,16 @@ __device__ __forceinline__ float row16_sum(float v) {
   v += dpp_mov<0x121>(v);  // row_ror:1
   return v;
 }
+// v_max_f32 with a DPP operand, one instruction per step: fmaxf(v, dpp_mov(v)) compiles to v_mov_b32_dpp + a canonicalising v_max v, v, v
+// (llvm.maxnum quiets a possible signalling NaN of the moved value first) + the v_max itself - 12 instructions for the four steps.
+// The hazard recogniser does not look inside asm: a VGPR written by a VALU instruction needs 2 wait states before a DPP read of it
+// (5 after a VALU write of EXEC: the first s_nop covers that case as well).
 __device__ __forceinline__ float row16_max(float v) {
-  v = fmaxf(v, dpp_mov<0x128>(v));
-  v = fmaxf(v, dpp_mov<0x124>(v));
-  v = fmaxf(v, dpp_mov<0x122>(v));
-  v = fmaxf(v, dpp_mov<0x121>(v));
+  asm("s_nop 4\n\tv_max_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_ror:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_ror:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+      : "+v"(v));
   return v;
 }
 

@@ -94,6 +94,48 @@ __global__ __launch_bounds__(512) void colsum_vec_kernel(const T* __restrict__ x
   }
 }
 
+// f32 matrices x_b [rows, C] (b = blockIdx.z, x_b = x + b * stride) -> bf16 copies y_b (same stride, in elements) AND their f32 column sums
+// added to out.p[b][C]: what the positional-projection gradients of all Conformer blocks need from the accumulated table gradients
+// (the GEMM operand and the bias gradient, the latter from the f32 values) in ONE launch.  A workgroup owns 64 columns of one matrix:
+// 16 lanes x 4 columns per row, 16 rows per iteration, 4 row loads in flight per lane; one writer per column (plain +=).
+constexpr int CCS_MAX = 64;
+struct CastColsumOut { float* p[CCS_MAX]; };
+__global__ __launch_bounds__(256) void cast_colsum_many_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, long stride, int rows, int C,
+                                                              CastColsumOut out) {
+  __shared__ float red[16][64];
+  const int b = blockIdx.z, c0 = blockIdx.x * 64 + (threadIdx.x & 15) * 4, rl = threadIdx.x >> 4;
+  const float* xb = x + (long)b * stride;
+  bf16_t* yb = y + (long)b * stride;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  if (c0 < C) {
+    for (int r = rl; r < rows; r += 64) {
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = (r + 16 * u < rows) ? *reinterpret_cast<const float4*>(xb + (long)(r + 16 * u) * C + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (r + 16 * u < rows) {
+          uint2 pk;
+          pk.x = pack2_bf16(v[u].x, v[u].y);
+          pk.y = pack2_bf16(v[u].z, v[u].w);
+          *reinterpret_cast<uint2*>(yb + (long)(r + 16 * u) * C + c0) = pk;
+        }
+        acc[0] += v[u].x; acc[1] += v[u].y; acc[2] += v[u].z; acc[3] += v[u].w;
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) red[rl][(threadIdx.x & 15) * 4 + k] = acc[k];
+  __syncthreads();
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  if (threadIdx.x < 64 && c < C && out.p[b]) {
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) s += red[q][threadIdx.x];
+    out.p[b][c] += s;
+  }
+}
+
 // ----------------------------------------------------------------------------------------- GLU
 template <typename T>
 __global__ __launch_bounds__(256) void glu_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, long rows, int C) {
@@ -636,6 +678,16 @@ extern "C" int tfasr_colsum(const void* x, long ld, float* out, long rows, int C
   DISPATCH_T(dtype,
              hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, s, (const float*)x, ld, out, rows, C, scale),
              hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, ld, out, rows, C, scale));
+  TFASR_CHECK_LAUNCH();
+  return TFASR_STATUS_SUCCESS;
+}
+
+extern "C" int tfasr_cast_colsum_many(const float* x, void* y, long stride, int nmat, int rows, int C, float* const* colsum, void* stream_) {
+  if (!x || !y || !colsum || nmat <= 0 || nmat > CCS_MAX || rows <= 0 || C <= 0 || stride < (long)rows * C) return TFASR_STATUS_INVALID_VALUE;
+  if ((C & 3) || (stride & 3) || (((uintptr_t)x) & 15) || (((uintptr_t)y) & 7)) return TFASR_STATUS_UNSUPPORTED;
+  CastColsumOut o;
+  for (int i = 0; i < CCS_MAX; ++i) o.p[i] = i < nmat ? colsum[i] : nullptr;
+  hipLaunchKernelGGL(cast_colsum_many_kernel, dim3((C + 63) / 64, 1, nmat), dim3(256), 0, (hipStream_t)stream_, x, (bf16_t*)y, stride, rows, C, o);
   TFASR_CHECK_LAUNCH();
   return TFASR_STATUS_SUCCESS;
 }

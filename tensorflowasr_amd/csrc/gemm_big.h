@@ -369,12 +369,18 @@ void gemm_big_kernel(const tfasr_gemm_args p, const int gx, const int gy, const 
         float x[NJ][4];
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-          float4_t t = acc[i][j];
-          // re-defined HERE as an accumulation-register value: otherwise the copies of every accumulator into vector registers are
-          // placed right behind the main loop and everything else is spilled around them
-          if (j < 8) asm volatile("" : "+a"(t));
+          // every element is read out of its accumulation register HERE, by an explicit v_accvgpr_read: left to the compiler the copies of
+          // every accumulator into vector registers are placed right behind the main loop and everything else is spilled around them; and
+          // re-defining the fragment as an accumulation-register VALUE (asm "+a" on a copy, the first fix) made it a register window -
+          // 28 v_accvgpr_mov + 4 v_accvgpr_write per fragment block shifted the remaining accumulators down to it (9 % of the
+          // epilogue's vector instructions)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) x[j][e] = p.alpha * t[e] + bc[j];
+          for (int e = 0; e < 4; ++e) {
+            float v;
+            if (j < 8) asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(acc[i][j][e]));
+            else v = acc[i][j][e];
+            x[j][e] = p.alpha * v + bc[j];
+          }
         }
         if constexpr (C_LSE) {
           const float L2E = 1.4426950408889634f;

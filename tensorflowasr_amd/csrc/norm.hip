@@ -509,10 +509,10 @@ __global__ __launch_bounds__(NW * 64) void ln_bwd_vec_kernel(const T* __restrict
 // 4 thread groups each take a quarter of the partial rows, LDS combine, ONE writer per column (plain +=, no atomics)
 constexpr int LNF_MAX = 8;
 struct LnFoldArgs { float* dg[LNF_MAX]; float* db[LNF_MAX]; };
-__global__ __launch_bounds__(256) void ln_bwd_fold_kernel(const float* __restrict__ part, int nblk, int C, LnFoldArgs a) {
+// the fold of one (set, 64-column slice): p = the set's partial sums at this thread's column
+__device__ __forceinline__ void ln_fold_slice(const float* __restrict__ p, int nblk, int C, int col, float* dg, float* db) {
   __shared__ float red[4][64];
-  const int set = blockIdx.y, col = blockIdx.x * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
-  const float* p = part + (long)set * nblk * 2 * C + col;
+  const int grp = threadIdx.x >> 6;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   if (col < 2 * C) {
     const int per = (nblk + 3) / 4, b0 = grp * per, b1 = min(nblk, b0 + per);
@@ -526,9 +526,21 @@ __global__ __launch_bounds__(256) void ln_bwd_fold_kernel(const float* __restric
   __syncthreads();
   if (grp == 0 && col < 2 * C) {
     const float v = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
-    if (col < C) { if (a.dg[set]) a.dg[set][col] += v; }
-    else if (a.db[set]) a.db[set][col - C] += v;
+    if (col < C) { if (dg) dg[col] += v; }
+    else if (db) db[col - C] += v;
   }
+}
+__global__ __launch_bounds__(256) void ln_bwd_fold_kernel(const float* __restrict__ part, int nblk, int C, LnFoldArgs a) {
+  const int set = blockIdx.y, col = blockIdx.x * 64 + (threadIdx.x & 63);
+  ln_fold_slice(part + (long)set * nblk * 2 * C + col, nblk, C, col, a.dg[set], a.db[set]);
+}
+// the same for sets that lie in different buffers (the LayerNorms of ALL Conformer blocks of a step: one launch instead of one per block);
+// the table is a kernel argument (3 KiB of the 4 KiB a dispatch may carry)
+constexpr int LNF_SETS_MAX = 128;
+struct LnFoldSets { const float* part[LNF_SETS_MAX]; float* dg[LNF_SETS_MAX]; float* db[LNF_SETS_MAX]; };
+__global__ __launch_bounds__(256) void ln_bwd_fold_sets_kernel(int nblk, int C, LnFoldSets a) {
+  const int set = blockIdx.y, col = blockIdx.x * 64 + (threadIdx.x & 63);
+  ln_fold_slice(a.part[set] + col, nblk, C, col, a.dg[set], a.db[set]);
 }
 
 template <typename T, int MODE, int LPR>
@@ -689,6 +701,21 @@ extern "C" int tfasr_layernorm_bwd_fold(const float* part, int nsets, int nblk, 
   LnFoldArgs a;
   for (int i = 0; i < LNF_MAX; ++i) { a.dg[i] = i < nsets ? dgamma[i] : nullptr; a.db[i] = i < nsets ? dbeta[i] : nullptr; }
   hipLaunchKernelGGL(ln_bwd_fold_kernel, dim3((2 * C + 63) / 64, nsets), dim3(256), 0, (hipStream_t)stream_, part, nblk, C, a);
+  TFASR_CHECK_LAUNCH();
+  return TFASR_STATUS_SUCCESS;
+}
+
+extern "C" int tfasr_layernorm_bwd_fold_sets(const float* const* part, int nsets, int nblk, int C, float* const* dgamma, float* const* dbeta,
+                                             void* stream_) {
+  if (!part || nsets <= 0 || nsets > LNF_SETS_MAX || nblk <= 0 || C <= 0 || !dgamma || !dbeta) return TFASR_STATUS_INVALID_VALUE;
+  LnFoldSets a;
+  for (int i = 0; i < LNF_SETS_MAX; ++i) {
+    a.part[i] = i < nsets ? part[i] : nullptr;
+    a.dg[i] = i < nsets ? dgamma[i] : nullptr;
+    a.db[i] = i < nsets ? dbeta[i] : nullptr;
+    if (i < nsets && !part[i]) return TFASR_STATUS_INVALID_VALUE;
+  }
+  hipLaunchKernelGGL(ln_bwd_fold_sets_kernel, dim3((2 * C + 63) / 64, nsets), dim3(256), 0, (hipStream_t)stream_, nblk, C, a);
   TFASR_CHECK_LAUNCH();
   return TFASR_STATUS_SUCCESS;
 }

@@ -347,6 +347,13 @@ def cast(src, dst):
     return dst
 
 
+def cast_colsum_many(x, y, stride, nmat, rows, C, colsums):
+    """f32 matrices x + b*stride [rows, C] -> bf16 copies in y (same strides) and colsums[b] += their f32 column sums (one launch)."""
+    arr = (ctypes.c_void_p * nmat)(*[(t.data_ptr() if t is not None else None) for t in colsums])
+    check(_L().tfasr_cast_colsum_many(_pv(x), _pv(y), int(stride), int(nmat), int(rows), int(C), arr, _stream()), "cast_colsum_many")
+    return y
+
+
 def dropout(x, p, seed, out=None):
     if out is None:
         out = torch.empty_like(x)
@@ -870,6 +877,16 @@ def block_bwd(cfg, params, io, ctx, phase):
 def block_wgrad_join(slot_mask=3):
     """The current stream waits for the grouped weight-gradient launches queued on the executor's second stream (tfasr_block_io.wgrad_slot)."""
     check(_L().tfasr_block_wgrad_join(int(slot_mask), _stream()), "block_wgrad_join")
+
+
+def block_ln_fold_all(ctxs, d):
+    """One launch for the LayerNorm gamma / beta gradients of every block whose backward ran with io.ln_part_ext (tfasr_block_ln_fold_all)."""
+    arr = (ctypes.c_void_p * len(ctxs))(*[ctypes.addressof(c) for c in ctxs])
+    check(_L().tfasr_block_ln_fold_all(arr, len(ctxs), int(d), _stream()), "block_ln_fold_all")
+
+
+def layernorm_bwd_part_blocks(rows, C, dtype):
+    return int(_L().tfasr_layernorm_bwd_part_blocks(int(rows), int(C), {torch.float32: 0, torch.bfloat16: 1}[dtype] if not isinstance(dtype, int) else dtype))
 
 
 # --------------------------------------------------------------------------------- ContextNet pieces
