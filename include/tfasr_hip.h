@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define TFASR_ABI_VERSION 29
+#define TFASR_ABI_VERSION 30
 
 typedef enum {
   TFASR_STATUS_SUCCESS = 0,
@@ -626,6 +626,11 @@ typedef struct {
   int defer_pos_grad;
   float* ln_part_ext;
   size_t ln_part_ext_floats;
+  /* dcv_keep != NULL (backward, bf16, BatchNorm variant): caller-owned [B*T, d] buffer that receives the gradient of the depthwise conv's
+     output and stays alive until tfasr_block_dwconv_wgrad_all; the block does not launch its depthwise WEIGHT gradient (nothing on the
+     chain waits for it): the caller runs the weight gradients of every block of the step as one launch pair.  The forward stash of the
+     block (its GLU output is the other operand) must stay alive until then as well. */
+  void* dcv_keep;
 } tfasr_block_io;
 
 size_t tfasr_block_ctx_bytes(void);
@@ -640,6 +645,10 @@ int tfasr_block_bwd(const tfasr_block_cfg* cfg, const tfasr_block_params* params
 /* dgamma / dbeta of every LayerNorm of `n` blocks whose backward ran with io->ln_part_ext: one launch instead of one per block.
    ctx[i] = the ctx of block i's tfasr_block_bwd call (host memory); blocks without pending partial sums are skipped. */
 int tfasr_block_ln_fold_all(void* const* ctx, int n, int d, void* stream);
+/* depthwise-conv weight / bias gradients of n <= 32 blocks whose backward ran with io->dcv_keep (dcv[i] = that buffer, ctx[i] / params[i]
+   = the block's; workspace >= n * tfasr_dwconv_bwd_weight_workspace_size(B, T, d, ksize) bytes, else one launch pair per block). */
+int tfasr_block_dwconv_wgrad_all(const tfasr_block_cfg* cfg, const tfasr_block_params* const* params, void* const* ctx, const void* const* dcv,
+                                 int n, void* workspace, size_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -845,7 +845,7 @@ class ConformerTransducer(BaseModel):
             bstats = torch.empty(2 * d, dtype=torch.float32, device=self.device)
             io.prezeroed &= ~2
             io.dpext_zero = None
-        io.defer_pos_grad, io.ln_part_ext, io.ln_part_ext_floats = 0, None, 0
+        io.defer_pos_grad, io.ln_part_ext, io.ln_part_ext_floats, io.dcv_keep = 0, None, 0, None
         hb = self._hoisted.get("bwd")
         if hb is not None:
             if io.dpext_zero:
@@ -855,6 +855,10 @@ class ConformerTransducer(BaseModel):
                 io.ln_part_ext = hb["ln_part"][i].data_ptr()
                 io.ln_part_ext_floats = hb["ln_part"].shape[1]
                 hb["ctx"].append(cbuf)
+            if not cfgk.dw_norm_layer:
+                dcv = torch.empty(cfgk.B * cfgk.T, d, dtype=self.dtype, device=self.device)
+                io.dcv_keep = dcv.data_ptr()
+                hb["dw"].append((cfgk, P, cbuf, dcv, s["keep"]))  # (the stash holds the other operand: alive until the batched launch)
         # grouped weight gradients of this block on the executor's second stream, beside the next block's backward: two arenas, alternating
         slot = 0
         if self.wgrad_stream and self.dtype == torch.bfloat16:
@@ -933,7 +937,7 @@ class ConformerTransducer(BaseModel):
             c = self.cfg
             nblk = K.layernorm_bwd_part_blocks(e["B"] * e["T"], c.dmodel, self.dtype)
             ln_part = torch.empty(c.num_blocks, 8 * nblk * 2 * c.dmodel, dtype=torch.float32, device=self.device) if nblk > 0 else None
-            self._hoisted["bwd"] = dict(pos=[], ctx=[], ln_part=ln_part)
+            self._hoisted["bwd"] = dict(pos=[], ctx=[], ln_part=ln_part, dw=[])
         # a block's gradients are complete once its weight-gradient group on the second stream is: its bucket is released one block
         # later, after this stream has been made to wait for that group (the wait the next user of the slot's arena needs anyway)
         prev = None
@@ -962,7 +966,7 @@ class ConformerTransducer(BaseModel):
     def _deferred_block_grads(self, hb, T):
         """What the blocks left to the caller (tfasr_block_io.defer_pos_grad / ln_part_ext): gWpos_i += pe^T dpext_i and gbpos_i +=
         colsum(dpext_i) for every block - one cast + column-sum launch over all the f32 tables, the products in grouped launches - and one
-        fold for the LayerNorm gamma / beta gradients of all blocks."""
+        fold for the LayerNorm gamma / beta gradients of all blocks; the depthwise-conv weight gradients of all blocks as one launch pair."""
         ps, c = self.ps, self.cfg
         d, HD, R1 = c.dmodel, c.num_heads * ps.head_phys, 2 * T
         if hb["pos"]:
@@ -987,6 +991,9 @@ class ConformerTransducer(BaseModel):
                     K.gemm_group(grp)
         if hb["ctx"]:
             K.block_ln_fold_all(hb["ctx"], d)
+        if hb["dw"]:
+            K.block_dwconv_wgrad_all(hb["dw"][0][0], [t[1] for t in hb["dw"]], [t[2] for t in hb["dw"]], [t[3] for t in hb["dw"]], self.device)
+            hb["dw"].clear()
 
     def _bucket_after_block(self, i):
         lo = self.ps.offsets[f"enc/block{i}/ff1/ln/g"]

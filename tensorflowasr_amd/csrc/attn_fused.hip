@@ -610,6 +610,266 @@ __global__ __launch_bounds__(256, 3) void relattn_fused_fwdT_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
+// Forward, transposed orientation, 32 QUERY ROWS PER WAVE (128 per workgroup): relattn_fused_fwdT_kernel is bound by the LDS (every
+// 1-KiB K / window / V fragment read feeds ONE MFMA at 16 query rows per wave).  Here a wave owns two 16-row query tiles (two B operands
+// in registers), so every fragment read feeds two MFMAs, the K / V / window DMA of a key block is shared by 128 query rows instead of
+// 64, and the two tiles' window ranges overlap in 4 of their 5 tiles (6 tile reads for 10 products).  Per 128 x 64 (query x key) pairs
+// the LDS moves ~1.8 KiB-clocks against 2.9 for two 64-row workgroups.  The window of a 128-row block is 191 table rows + the bias row
+// (24 KiB); the bias-row score reaches the lanes of its query by a wave shuffle (no LDS slot): 8 + 8 + 24 + 8 x 5 KiB = 81 920 B =
+// 64 LDS granules = two workgroups per CU.
+// ---------------------------------------------------------------------------------------------------------------------------------
+constexpr int BI2 = 128, WIN2 = 192, SP2_BYTES = WIN2 * DH * 2;
+constexpr int SGT2_BYTES = 16 * GLDT * 4;  // [16 il][80] f32 per (wave, query tile)
+constexpr int SMEM_FWDT2 = SK_BYTES + SV_BYTES + SP2_BYTES + 8 * SGT2_BYTES;
+static_assert((SMEM_FWDT2 + 1279) / 1280 * 2 <= 128, "two workgroups per CU");
+
+template <bool STREAM>
+__global__ __launch_bounds__(256, 2) void relattn_fused_fwdT2_kernel(
+    const bf16_t* __restrict__ qkv, const float* __restrict__ ubias, const float* __restrict__ vbias,
+    const bf16_t* __restrict__ pext, const int32_t* __restrict__ lengths, bf16_t* __restrict__ out, float* __restrict__ lse_out,
+    int B, int H, int T, float scale, int use_mask, int chunk, int hist) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sK = smem;
+  char* sV = sK + SK_BYTES;
+  char* sP = sV + SV_BYTES;
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  float* sGq[2];
+  sGq[0] = reinterpret_cast<float*>(sP + SP2_BYTES + (w * 2) * SGT2_BYTES);  // [16 il][80]: window columns 112-32w .. 191-32w (query tile 0)
+  sGq[1] = sGq[0] + 16 * GLDT;                                               //              window columns  96-32w .. 175-32w (query tile 1)
+  const int r = lane & 15, g = lane >> 4;
+  const BlockId bid = attn_block_id(B, H, (T + BI2 - 1) / BI2);
+  if (!bid.ok) return;
+  const int b = bid.b, h = bid.h, i0 = bid.blk * BI2;
+  const int HD = H * DH, LDQ = 3 * HD, R1 = 2 * T;
+  const int len = lengths ? min(lengths[b], T) : T;
+  const int shift = T - len;
+  const bf16_t* qb = qkv + (long)b * T * LDQ + h * DH;
+  const bf16_t* kb = qb + HD;
+  const bf16_t* vb = qb + 2 * HD;
+  const bf16_t* pb = pext + h * DH;
+  uint4 bias_row = make_uint4(0, 0, 0, 0);
+  if ((threadIdx.x >> 6) == 0 && (threadIdx.x & 63) < 8)
+    bias_row = *reinterpret_cast<const uint4*>(pb + (long)(2 * T - 1) * HD + (((threadIdx.x & 63) ^ key_d(WIN2 - 1)) << 3));
+
+  // this lane's two query rows (B operand columns): Q + u, Q + v
+  int iq[2];
+  short8_t bqu[2][2], bqv[2][2];
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    iq[qt] = i0 + w * 32 + qt * 16 + r;
+    const int irow = min(iq[qt], T - 1);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bqu[qt][kk] = q_frag(qb + (long)irow * LDQ, ubias + h * DH, kk * 32 + g * 8);
+      bqv[qt][kk] = q_frag(qb + (long)irow * LDQ, vbias + h * DH, kk * 32 + g * 8);
+    }
+  }
+  float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
+  float4_t acc_o[2][4];  // O^T: rows = head dims n*16 + g*4 + e, column = this lane's query of tile qt
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+    for (int n = 0; n < 4; ++n) acc_o[qt][n] = float4_t{0.f, 0.f, 0.f, 0.f};
+
+  const float scale2 = scale * 1.4426950408889634f;
+  const int lim = 2 * len - 1;
+  bool qm[2];
+  int jthr[2], klo[2], khi[2];
+  float scale2q[2];
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    qm[qt] = use_mask && (iq[qt] >= len);
+    jthr[qt] = lim - (T - 1 - iq[qt]);  // keys j < jthr: relative position T-1-i+j inside the sample's 2 len - 1 encodings
+    klo[qt] = 0; khi[qt] = T;
+    if constexpr (STREAM) { if (!qm[qt]) stream_window(min(iq[qt], T - 1), T, chunk, hist, klo[qt], khi[qt]); }
+    scale2q[qt] = qm[qt] ? 0.f : scale2;
+  }
+  const int gbase = r * GLDT + 15 - r;  // + jl = this lane's skewed strip column of key jl (either query tile)
+  int jl0[4], krow[4];
+#pragma unroll
+  for (int jt = 0; jt < 4; ++jt) {
+    jl0[jt] = 32 * (jt >> 1) + g * 8 + (jt & 1) * 4;                      // first of this lane's four keys of tile jt (C rows g*4 + e)
+    krow[jt] = 32 * (jt >> 1) + (r >> 2) * 8 + (jt & 1) * 4 + (r & 3);  // key row that is MFMA row r of tile jt (A operand)
+  }
+  const int njb = (T + BJ - 1) / BJ;
+  int jb_lo = 0, jb_hi = njb;
+  if constexpr (STREAM) {
+    if (!(use_mask && i0 + BI2 > len)) {
+      int lo, hi, lo2, hi2;
+      stream_window(i0, T, chunk, hist, lo, hi);
+      stream_window(min(i0 + BI2 - 1, T - 1), T, chunk, hist, lo2, hi2);
+      jb_lo = lo / BJ;
+      jb_hi = (hi2 + BJ - 1) / BJ;
+    }
+  }
+  // window row 191 <- the bias row R of the position table, once (the block loop's DMA leaves that row alone)
+  if (w == 0 && lane < 8) *reinterpret_cast<uint4*>(sP + (WIN2 - 1) * 128 + lane * 16) = bias_row;
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (visible to the other waves behind the first block's barrier)
+  if (use_mask && i0 >= len) {
+    // every query row of this block is padding: uniform attention over ALL T keys (see relattn_fused_fwd_kernel): out = mean_j v_j, lse = log T
+    for (int jb = 0; jb < njb; ++jb) {
+      const int j0 = jb * BJ;
+      load_v(sV, vb, LDQ, j0, T, w, lane);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        short8_t pf;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) pf[t] = (j0 + 32 * q + g * 8 + t < T) ? (short)0x3F80 : (short)0;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+          const short8_t a = frag_v(sV, n * 16, q * 32 + g * 8, r);
+          acc_o[0][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, pf, acc_o[0][n], 0, 0, 0);
+          acc_o[1][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, pf, acc_o[1][n], 0, 0, 0);
+        }
+      }
+      __syncthreads();
+    }
+    m_run[0] = m_run[1] = 0.f; l_run[0] = l_run[1] = (float)T;
+  } else
+  for (int jb = jb_lo; jb < jb_hi; ++jb) {
+    const int j0 = jb * BJ;
+    const int pw0 = (T - 1 - (i0 + BI2 - 1) + j0) + shift;  // pext row of window column 0
+    load_rows<BJ>(sK, kb, LDQ, j0, T, w, lane);
+    load_v(sV, vb, LDQ, j0, T, w, lane);
+    load_rows<WIN2, false, true>(sP, pb, HD, pw0, R1, w, lane);  // (window row 191 = the bias row, written once in front of the loop)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    // content scores, transposed: tile jt = 16 keys x this wave's 2 x 16 queries; one K fragment read feeds both query tiles
+    float4_t acc_s[2][4];
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) {
+      acc_s[0][jt] = float4_t{0.f, 0.f, 0.f, 0.f};
+      acc_s[1][jt] = float4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const short8_t a = frag_rows(sK, krow[jt], kk * 4 + g);
+        acc_s[0][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bqu[0][kk], acc_s[0][jt], 0, 0, 0);
+        acc_s[1][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bqu[1][kk], acc_s[1][jt], 0, 0, 0);
+      }
+    }
+    // window scores, transposed: G^T[c][il].  Query tile 0 of this wave needs window columns 112-32w .. 190-32w (tiles t0 .. t0+4),
+    // query tile 1 the 16 columns below (tiles t0-1 .. t0+3); column 191 (tile 11, row 15) is the bias row's score for both
+    const int t0 = 7 - 2 * w;
+    float gb[2] = {0.f, 0.f};
+#pragma unroll
+    for (int gt = 0; gt < 12; ++gt) {
+      const bool u0 = gt >= t0 && gt <= t0 + 4, u1 = gt >= t0 - 1 && gt <= t0 + 3, last = gt == 11;
+      if (u0 || u1 || last) {
+        const short8_t a0 = frag_rows(sP, gt * 16 + r, g), a1 = frag_rows(sP, gt * 16 + r, 4 + g);
+        if (u0 || last) {
+          float4_t x = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, bqv[0][0], float4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+          x = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bqv[0][1], x, 0, 0, 0);
+          if (u0) *reinterpret_cast<float4_t*>(sGq[0] + r * GLDT + (gt - t0) * 16 + g * 4) = x;
+          if (last) gb[0] = x[3];
+        }
+        if (u1 || last) {
+          float4_t x = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, bqv[1][0], float4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+          x = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bqv[1][1], x, 0, 0, 0);
+          if (u1) *reinterpret_cast<float4_t*>(sGq[1] + r * GLDT + (gt - (t0 - 1)) * 16 + g * 4) = x;
+          if (last) gb[1] = x[3];
+        }
+      }
+    }
+    // the bias-row score of query r sits in the lanes (g = 3, r): to every lane of that query
+    gb[0] = __shfl(gb[0], 48 + r, 64);
+    gb[1] = __shfl(gb[1], 48 + r, 64);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+
+    short8_t pf[2][2];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+      // every skewed score is read unconditionally (the strip column 15 - il + jl exists for every key of the block), THEN selected against
+      // the bias score: a conditional read compiles to an exec-mask branch per element
+      const float gbias = gb[qt];
+      const float* sG = sGq[qt];
+      float gv[4][4];
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) gv[jt][e] = sG[gbase + jl0[jt] + e];
+      float mx = -INFINITY;
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt) {
+        const int tr = jthr[qt] - j0 - jl0[jt];  // keys e < tr of this tile have a relative position inside the table
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float pos = (e < tr) ? gv[jt][e] : gbias;
+          acc_s[qt][jt][e] = (acc_s[qt][jt][e] + pos) * scale2q[qt];  // (scale2q = 0 for a padded query row: constant scores)
+        }
+      }
+      if (STREAM || j0 + BJ > T) {  // keys outside [klo, khi): past the end of a ragged last block / outside the streaming window
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int j = j0 + jl0[jt] + e;
+            if (j < klo[qt] || j >= khi[qt]) acc_s[qt][jt][e] = -INFINITY;
+          }
+      }
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) mx = fmaxf(mx, acc_s[qt][jt][e]);
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run[qt], mx);
+      const float m_ref = (STREAM && m_new == -INFINITY) ? 0.f : m_new;
+      const float corr = __builtin_amdgcn_exp2f(m_run[qt] - m_ref);
+      float rs = 0.f;
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt) {
+        float p[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { p[e] = __builtin_amdgcn_exp2f(acc_s[qt][jt][e] - m_ref); rs += p[e]; }
+        const uint32_t lo = pack2_bf16(p[0], p[1]), hi = pack2_bf16(p[2], p[3]);
+        const int o = (jt & 1) * 4;
+        pf[qt][jt >> 1][o + 0] = (short)(lo & 0xffffu); pf[qt][jt >> 1][o + 1] = (short)(lo >> 16);
+        pf[qt][jt >> 1][o + 2] = (short)(hi & 0xffffu); pf[qt][jt >> 1][o + 3] = (short)(hi >> 16);
+      }
+      rs += __shfl_xor(rs, 16, 64);
+      rs += __shfl_xor(rs, 32, 64);
+      l_run[qt] = l_run[qt] * corr + rs;
+      m_run[qt] = m_new;
+#pragma unroll
+      for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc_o[qt][n][e] *= corr;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // O^T += V^T P^T: the probabilities are the B operands straight from registers; one V fragment read feeds both query tiles
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        const short8_t a = frag_v(sV, n * 16, q * 32 + g * 8, r);
+        acc_o[0][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, pf[0][q], acc_o[0][n], 0, 0, 0);
+        acc_o[1][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, pf[1][q], acc_o[1][n], 0, 0, 0);
+      }
+    __syncthreads();  // everyone is done with sK / sV / sP before the next block's DMA lands
+  }
+
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    const int i = iq[qt];
+    if (i < T) {
+      const float inv = 1.f / l_run[qt];
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        uint2 v;
+        v.x = pack2_bf16(acc_o[qt][n][0] * inv, acc_o[qt][n][1] * inv);
+        v.y = pack2_bf16(acc_o[qt][n][2] * inv, acc_o[qt][n][3] * inv);
+        *reinterpret_cast<uint2*>(out + ((long)b * T + i) * HD + h * DH + n * 16 + g * 4) = v;
+      }
+      if (g == 0) lse_out[((long)b * H + h) * T + i] = m_run[qt] * 0.6931471805599453f + logf(l_run[qt]);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
 // Forward with 32-key blocks: 4 KB of K, 4 KB of V, a 96-row window (12 KB) and 4 strips of [16][49] f32 = 32.5 KB per workgroup, so
 // FOUR (LDS) workgroups share a CU where the 64-key kernel fits three.  Same arithmetic per (query, key) pair; the online softmax
 // merges twice as many blocks.  Wave w needs window columns 48-16w .. 94-16w (3 tiles) + the bias row in column 95.
@@ -1547,6 +1807,23 @@ extern "C" int tfasr_relattn_fused_fwd(const void* qkv, const float* ubias, cons
   const bool fwd32 = env32 ? env32[0] == '1' : (long)grid.x * grid.y * grid.z <= 4L * ncu;
   const bool st = chunk > 0;
   static const bool fwd_t = !(getenv("TFASR_ATTN_FWD_T") && getenv("TFASR_ATTN_FWD_T")[0] == '0');  // 0: the row-oriented kernels (A/B)
+  // 32 query rows per wave (relattn_fused_fwdT2_kernel): TFASR_ATTN_FWD_QR2=1 / 0 (A/B)
+  static const bool fwd_qr2 = getenv("TFASR_ATTN_FWD_QR2") && getenv("TFASR_ATTN_FWD_QR2")[0] == '1';
+  if (fwd_t && !env32 && fwd_qr2) {
+    const dim3 gridT2(attn_grid_size(B, H, (T + BI2 - 1) / BI2));
+    static bool attr_done = false;
+    if (!attr_done) {
+      (void)hipFuncSetAttribute((const void*)relattn_fused_fwdT2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_FWDT2);
+      (void)hipFuncSetAttribute((const void*)relattn_fused_fwdT2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_FWDT2);
+      attr_done = true;
+    }
+    if (st) hipLaunchKernelGGL(relattn_fused_fwdT2_kernel<true>, gridT2, dim3(256), SMEM_FWDT2, (hipStream_t)stream_, (const bf16_t*)qkv, ubias, vbias,
+                               (const bf16_t*)pext, lengths, (bf16_t*)out, lse, B, H, T, scale, use_mask, chunk, hist);
+    else hipLaunchKernelGGL(relattn_fused_fwdT2_kernel<false>, gridT2, dim3(256), SMEM_FWDT2, (hipStream_t)stream_, (const bf16_t*)qkv, ubias, vbias,
+                            (const bf16_t*)pext, lengths, (bf16_t*)out, lse, B, H, T, scale, use_mask, chunk, hist);
+    TFASR_CHECK_LAUNCH();
+    return TFASR_STATUS_SUCCESS;
+  }
   if (fwd_t && !env32) {
     const dim3 gridT(attn_grid_size(B, H, (T + BI - 1) / BI));
 #ifdef TFASR_ATTN_TIMING

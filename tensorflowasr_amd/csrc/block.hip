@@ -637,6 +637,10 @@ struct Ex {
     tfasr_dwconv_bwd_weight_workspace_size(c->B, c->T, d, c->ksize, &dwws_bytes);
     void* dwws = scratch.get(dwws_bytes);  // per-block partial sums of the depthwise weight gradient
     void* dcv = act(scratch, rows * d);
+    // caller-owned buffer for the depthwise conv's output gradient: it outlives this call, and the depthwise WEIGHT gradient (two launches
+    // that nothing on the chain waits for) is left to tfasr_block_dwconv_wgrad_all - one launch pair for all blocks of the step
+    const bool dw_deferred = !dry && io->dcv_keep && !c->dw_norm_layer && c->dtype == TFASR_BF16;
+    if (dw_deferred) dcv = io->dcv_keep;
     void* dg = act(scratch, rows * d);
     void* da = act(scratch, rows * 2 * d);
     void* dln = act(scratch, rows * d);
@@ -651,7 +655,8 @@ struct Ex {
         chk(tfasr_bn_apply_bwd_grads(k->cv_cv, k->bw_dsw, k->cv_fin, io->bn_bstats, (float)(rows * c->world), dcv, rows, d, TFASR_ACT_SWISH,
                                      gp(TFASR_BP_CV_BN_G), gp(TFASR_BP_CV_BN_B), 1.f / (float)c->world, c->dtype, s));
       }
-      chk(tfasr_dwconv_bwd_weight_ws(k->cv_g, dcv, gp(TFASR_BP_CV_DW_W), gp(TFASR_BP_CV_DW_B), c->B, c->T, d, c->ksize, c->dtype, dwws, dwws_bytes, s));
+      if (!dw_deferred)
+        chk(tfasr_dwconv_bwd_weight_ws(k->cv_g, dcv, gp(TFASR_BP_CV_DW_W), gp(TFASR_BP_CV_DW_B), c->B, c->T, d, c->ksize, c->dtype, dwws, dwws_bytes, s));
       // depthwise data gradient + GLU backward in one launch when the channel-pair kernel applies
       const int fst = tfasr_dwconv_bwd_data_glu(dcv, fp(TFASR_BP_CV_DW_W), k->cv_a, da, c->B, c->T, d, c->ksize, c->dtype, s);
       if (fst == TFASR_STATUS_UNSUPPORTED) {
@@ -857,5 +862,33 @@ extern "C" int tfasr_block_ln_fold_all(void* const* ctx, int n, int d, void* str
     k->ln_nsets = 0;
   }
   if (ns > 0) return tfasr_layernorm_bwd_fold_sets(part, ns, nblk, d, dg, db, stream);
+  return TFASR_STATUS_SUCCESS;
+}
+
+int tfasr_dwconv_wgrad_many_try(const void* const* x, const void* const* dy, float* const* dw, float* const* dbias, int n, int B, int T, int C, int K,
+                                float* ws, size_t ws_bytes, hipStream_t s);  // dwconv.hip
+
+// The depthwise-conv weight / bias gradients of `n` blocks whose backward ran with io->dcv_keep: x = the block's saved GLU output (ctx),
+// dy = dcv[i] (the caller's buffers), one tile launch + one reduce launch for all of them (fallback: one pair per block).
+extern "C" int tfasr_block_dwconv_wgrad_all(const tfasr_block_cfg* c, const tfasr_block_params* const* params, void* const* ctx, const void* const* dcv,
+                                            int n, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!c || !params || !ctx || !dcv || n <= 0 || n > 32) return TFASR_STATUS_INVALID_VALUE;
+  const void* x[32];
+  float* dw[32];
+  float* db[32];
+  for (int i = 0; i < n; ++i) {
+    if (!params[i] || !ctx[i] || !dcv[i] || !params[i]->grad) return TFASR_STATUS_INVALID_VALUE;
+    x[i] = ((const Ctx*)ctx[i])->cv_g;
+    dw[i] = params[i]->grad + params[i]->off[TFASR_BP_CV_DW_W];
+    db[i] = params[i]->grad + params[i]->off[TFASR_BP_CV_DW_B];
+  }
+  if (c->dtype == TFASR_BF16) {
+    const int st = tfasr_dwconv_wgrad_many_try(x, dcv, dw, db, n, c->B, c->T, c->d, c->ksize, (float*)workspace, workspace_bytes, (hipStream_t)stream);
+    if (st != TFASR_STATUS_UNSUPPORTED) return st;
+  }
+  for (int i = 0; i < n; ++i) {
+    const int st = tfasr_dwconv_bwd_weight(x[i], dcv[i], dw[i], db[i], c->B, c->T, c->d, c->ksize, c->dtype, stream);
+    if (st != TFASR_STATUS_SUCCESS) return st;
+  }
   return TFASR_STATUS_SUCCESS;
 }

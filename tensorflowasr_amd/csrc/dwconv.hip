@@ -144,17 +144,19 @@ __global__ __launch_bounds__(256) void dwconv_tile_kernel(const bf16_t* __restri
 // thread group walks its 32 steps with the x window held in a 32-slot circular register buffer (compile-time slots).
 // part != nullptr: the block stores its partial sums to part[block][K+1][C] with plain stores (no atomics; a second kernel
 // reduces over blocks) - with atomics the K x C adds per 64 steps made this kernel 2x slower than the scalar one.
+// (zb = utterance of this block inside x / dy, zpart = its index among the partial slabs: both blockIdx.z for one product; the batched
+// launch of several products - dwconv_wgrad_tile_many_kernel - splits blockIdx.z into (product, utterance))
 template <int K>
-__global__ __launch_bounds__(256) void dwconv_wgrad_tile_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
-                                                                float* __restrict__ dw, float* __restrict__ dbias, int Tn, int C,
-                                                                float* __restrict__ part) {
+__device__ __forceinline__ void dwconv_wgrad_tile_body(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
+                                                       float* __restrict__ dw, float* __restrict__ dbias, int Tn, int C,
+                                                       float* __restrict__ part, const int zb, const int zpart) {
   static_assert(K <= MAXK, "window");
   extern __shared__ __attribute__((aligned(16))) char lds[];
   char* lx = lds;                                   // 2*TG + K - 1 rows
   char* ld = lds + (2 * TG + MAXK - 1) * ROWB;      // 2*TG rows
   const int c0 = blockIdx.x * SLAB;
   const int t0 = blockIdx.y * (2 * TG);
-  const long ubase = (long)blockIdx.z * Tn * C;
+  const long ubase = (long)zb * Tn * C;
   {  // both operands' loads in flight together
     uint4 vx[((2 * TG + K - 1) * (SLAB / 8) + 255) / 256], vd[((2 * TG) * (SLAB / 8) + 255) / 256];
     stage_load<2 * TG + K - 1>(vx, x, ubase, t0 - (K - 1), Tn, C, c0);
@@ -194,7 +196,7 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_tile_kernel(const bf16_t* __
     }
     __syncthreads();
     if (grp == 0 && c < C) {
-      float* o = part + ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * (size_t)(K + 1) * SLAB + 2 * pr;
+      float* o = part + ((size_t)(zpart * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * (size_t)(K + 1) * SLAB + 2 * pr;
 #pragma unroll
       for (int k = 0; k < K; ++k) {
         const float2_t v = acc[k] + red[k * 128 + pr];
@@ -213,10 +215,40 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_tile_kernel(const bf16_t* __
     if (dbias) { atomicAdd(dbias + c, ab[0]); atomicAdd(dbias + c + 1, ab[1]); }
   }
 }
+template <int K>
+__global__ __launch_bounds__(256) void dwconv_wgrad_tile_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
+                                                                float* __restrict__ dw, float* __restrict__ dbias, int Tn, int C,
+                                                                float* __restrict__ part) {
+  dwconv_wgrad_tile_body<K>(x, dy, dw, dbias, Tn, C, part, blockIdx.z, blockIdx.z);
+}
+// The depthwise weight gradients of up to DWM_MAX products of the same shape (the ConvModules of every Conformer block of a step) in
+// ONE launch: a product alone moves 2 x 12 MB in 14 us (1.7 TB/s: launch ramp and tail), and none of them is on the backward's
+// dependent chain.  blockIdx.z = product * Bn + utterance; partial slabs in one workspace, product-major.
+constexpr int DWM_MAX = 32;
+struct DwMany { const bf16_t* x[DWM_MAX]; const bf16_t* dy[DWM_MAX]; };
+struct DwManyOut { float* dw[DWM_MAX]; float* db[DWM_MAX]; };
+template <int K>
+__global__ __launch_bounds__(256) void dwconv_wgrad_tile_many_kernel(const DwMany tab, int Bn, int Tn, int C, float* __restrict__ part) {
+  const int m = blockIdx.z / Bn, zb = blockIdx.z - m * Bn;
+  dwconv_wgrad_tile_body<K>(tab.x[m], tab.dy[m], nullptr, nullptr, Tn, C, part, zb, blockIdx.z);
+}
 
 // dw[k, c] += sum_blocks part[blk][k][c_local] ; dbias likewise (row K).  grid.x = channel slabs, threads over (k, c)
+__device__ __forceinline__ void dwconv_wgrad_reduce_body(const float* __restrict__ part, float* __restrict__ dw, float* __restrict__ dbias,
+                                                         int nblk_per_slab, int nslab, int K, int C, const int zslice, const int nslice);
 __global__ __launch_bounds__(256) void dwconv_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, float* __restrict__ dbias,
                                                                   int nblk_per_slab, int nslab, int K, int C) {
+  dwconv_wgrad_reduce_body(part, dw, dbias, nblk_per_slab, nslab, K, C, blockIdx.z, gridDim.z);
+}
+// (blockIdx.z = product * 16 + slice of the partial slabs)
+__global__ __launch_bounds__(256) void dwconv_wgrad_reduce_many_kernel(const float* __restrict__ part, const DwManyOut out, int nblk_per_slab, int nslab,
+                                                                       int K, int C) {
+  const int m = blockIdx.z >> 4;
+  dwconv_wgrad_reduce_body(part + (size_t)m * nblk_per_slab * nslab * (K + 1) * SLAB, out.dw[m], out.db[m], nblk_per_slab, nslab, K, C,
+                           blockIdx.z & 15, 16);
+}
+__device__ __forceinline__ void dwconv_wgrad_reduce_body(const float* __restrict__ part, float* __restrict__ dw, float* __restrict__ dbias,
+                                                         int nblk_per_slab, int nslab, int K, int C, const int zslice, const int nslice) {
   const int slab = blockIdx.y;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < (K + 1) * SLAB; i += gridDim.x * blockDim.x) {
     const int k = i / SLAB, cl = i - k * SLAB, c = slab * SLAB + cl;
@@ -224,9 +256,9 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_reduce_kernel(const float* _
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     const float* p = part + (size_t)slab * (K + 1) * SLAB + i;
     const size_t stride = (size_t)nslab * (K + 1) * SLAB;
-    // blockIdx.z owns one slice of the partial slabs (a handful of atomics per address instead of one long serial sum)
-    const int per = (nblk_per_slab + gridDim.z - 1) / gridDim.z;
-    const int b0 = blockIdx.z * per, b1 = min(b0 + per, nblk_per_slab);
+    // every slice owns part of the partial slabs (a handful of atomics per address instead of one long serial sum)
+    const int per = (nblk_per_slab + nslice - 1) / nslice;
+    const int b0 = zslice * per, b1 = min(b0 + per, nblk_per_slab);
     int b = b0;
     for (; b + 4 <= b1; b += 4) { s0 += p[(size_t)b * stride]; s1 += p[(size_t)(b + 1) * stride]; s2 += p[(size_t)(b + 2) * stride]; s3 += p[(size_t)(b + 3) * stride]; }
     for (; b < b1; ++b) s0 += p[(size_t)b * stride];
@@ -262,6 +294,37 @@ int tfasr_dwconv_wgrad_ws_try(const void* x, const void* dy, float* dw, float* d
   TFASR_CHECK_LAUNCH();
   dim3 rg(((K + 1) * SLAB + 255) / 256, gx, 16);
   hipLaunchKernelGGL(dwconv_wgrad_reduce_kernel, rg, dim3(256), 0, s, (const float*)ws, dw, dbias, B * gy, gx, K, C);
+  TFASR_CHECK_LAUNCH();
+  return TFASR_STATUS_SUCCESS;
+}
+
+// n products of one shape in one tile launch + one reduce launch (see dwconv_wgrad_tile_many_kernel); UNSUPPORTED -> one by one
+int tfasr_dwconv_wgrad_many_try(const void* const* x, const void* const* dy, float* const* dw, float* const* dbias, int n, int B, int T, int C, int K,
+                                float* ws, size_t ws_bytes, hipStream_t s) {
+  if (n <= 0 || n > DWM_MAX || (C & 7) || !ws || K != 31 && K != 32 && K != 15 && K != 7 && K != 5 && K != 3) return TFASR_STATUS_UNSUPPORTED;
+  const int gx = (C + SLAB - 1) / SLAB, gy = (T + 2 * TG - 1) / (2 * TG);
+  const size_t need = (size_t)n * B * gy * gx * (K + 1) * SLAB * 4;
+  if (ws_bytes < need || (long)n * B > 65535) return TFASR_STATUS_UNSUPPORTED;
+  DwMany tab;
+  DwManyOut out;
+  for (int i = 0; i < DWM_MAX; ++i) {
+    tab.x[i] = (const bf16_t*)(i < n ? x[i] : nullptr); tab.dy[i] = (const bf16_t*)(i < n ? dy[i] : nullptr);
+    out.dw[i] = i < n ? dw[i] : nullptr; out.db[i] = i < n && dbias ? dbias[i] : nullptr;
+    if (i < n && (!x[i] || !dy[i] || !dw[i] || !al16(x[i]) || !al16(dy[i]))) return TFASR_STATUS_UNSUPPORTED;
+  }
+  dim3 grid(gx, gy, n * B);
+  const int smem = (2 * TG + MAXK - 1 + 2 * TG) * ROWB;
+  switch (K) {
+    case 31: hipLaunchKernelGGL((dwconv_wgrad_tile_many_kernel<31>), grid, dim3(256), smem, s, tab, B, T, C, ws); break;
+    case 32: hipLaunchKernelGGL((dwconv_wgrad_tile_many_kernel<32>), grid, dim3(256), smem, s, tab, B, T, C, ws); break;
+    case 15: hipLaunchKernelGGL((dwconv_wgrad_tile_many_kernel<15>), grid, dim3(256), smem, s, tab, B, T, C, ws); break;
+    case 7: hipLaunchKernelGGL((dwconv_wgrad_tile_many_kernel<7>), grid, dim3(256), smem, s, tab, B, T, C, ws); break;
+    case 5: hipLaunchKernelGGL((dwconv_wgrad_tile_many_kernel<5>), grid, dim3(256), smem, s, tab, B, T, C, ws); break;
+    default: hipLaunchKernelGGL((dwconv_wgrad_tile_many_kernel<3>), grid, dim3(256), smem, s, tab, B, T, C, ws); break;
+  }
+  TFASR_CHECK_LAUNCH();
+  dim3 rg(((K + 1) * SLAB + 255) / 256, gx, 16 * n);
+  hipLaunchKernelGGL(dwconv_wgrad_reduce_many_kernel, rg, dim3(256), 0, s, (const float*)ws, out, B * gy, gx, K, C);
   TFASR_CHECK_LAUNCH();
   return TFASR_STATUS_SUCCESS;
 }

@@ -885,6 +885,18 @@ def block_ln_fold_all(ctxs, d):
     check(_L().tfasr_block_ln_fold_all(arr, len(ctxs), int(d), _stream()), "block_ln_fold_all")
 
 
+def block_dwconv_wgrad_all(cfg, params, ctxs, dcvs, device):
+    """Depthwise-conv weight / bias gradients of every block whose backward ran with io.dcv_keep: one launch pair (tfasr_block_dwconv_wgrad_all)."""
+    n = len(ctxs)
+    need = ctypes.c_size_t(0)
+    check(_L().tfasr_dwconv_bwd_weight_workspace_size(cfg.B, cfg.T, cfg.d, cfg.ksize, ctypes.byref(need)), "dwconv_bwd_weight_workspace_size")
+    ws = workspace(n * need.value, device, "dw_wgrad_all")
+    pa = (ctypes.c_void_p * n)(*[ctypes.addressof(p) for p in params])
+    ca = (ctypes.c_void_p * n)(*[ctypes.addressof(c) for c in ctxs])
+    da = (ctypes.c_void_p * n)(*[t.data_ptr() for t in dcvs])
+    check(_L().tfasr_block_dwconv_wgrad_all(ctypes.byref(cfg), pa, ca, da, n, _p(ws), ws.numel(), _stream()), "block_dwconv_wgrad_all")
+
+
 def layernorm_bwd_part_blocks(rows, C, dtype):
     return int(_L().tfasr_layernorm_bwd_part_blocks(int(rows), int(C), {torch.float32: 0, torch.bfloat16: 1}[dtype] if not isinstance(dtype, int) else dtype))
 
