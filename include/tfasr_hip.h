@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define TFASR_ABI_VERSION 30
+#define TFASR_ABI_VERSION 31
 
 typedef enum {
   TFASR_STATUS_SUCCESS = 0,
@@ -631,6 +631,11 @@ typedef struct {
      chain waits for it): the caller runs the weight gradients of every block of the step as one launch pair.  The forward stash of the
      block (its GLU output is the other operand) must stay alive until then as well. */
   void* dcv_keep;
+  /* ds_keep / qv_keep != NULL (backward, with defer_pos_grad, fused attention): caller-owned buffers for the unskewed score gradient
+     dS [B, H, T, ceil8(T)] and q + v [B*T, H*dh] (compute dtype); the block does not launch tfasr_relattn_dpext - the caller accumulates
+     the table gradient into dpext_zero itself (e.g. on another stream beside the next block's backward: nothing on the chain waits for it). */
+  void* ds_keep;
+  void* qv_keep;
 } tfasr_block_io;
 
 size_t tfasr_block_ctx_bytes(void);

@@ -92,9 +92,11 @@ class ConformerTransducer(BaseModel):
         # one native call per Conformer block (csrc/block.hip) instead of ~70 per-kernel calls from Python
         self.native_blocks = os.environ.get("TFASR_NATIVE_BLOCK", "1") != "0"
         # grouped weight gradients of a block on the executor's second stream (tfasr_block_io.wgrad_slot), beside the next block's
-        # backward.  MEASURED slower (same box, Conformer-M, 32 utterances: 29.06 vs 28.45 ms/step, also at lowest stream priority): the
-        # 512-workgroup group launch takes CUs from the dependent chain, which is the critical path.  Opt-in: TFASR_WGRAD_STREAM=1.
-        self.wgrad_stream = os.environ.get("TFASR_WGRAD_STREAM", "0") == "1"
+        # backward.  Round 2 measured it SLOWER (29.06 vs 28.45 ms/step: the 512-workgroup group launch took CUs from the dependent chain);
+        # with the round-4 chain (fused FFModule forward, one-tile GEMMs, hoisted launches) it is FASTER: 22.18 vs 22.45 ms/step, same box,
+        # three interleaved pairs - the chain's kernels now leave more of the chip idle than the group takes.  TFASR_WGRAD_STREAM=0: in line.
+        self.wgrad_stream = os.environ.get("TFASR_WGRAD_STREAM", "1") != "0"
+        self._wgrad_keep = []
         self._blk_params, self._blk_sizes = {}, {}
         self._zero_pool = {}
         # Launches that do not belong to the blocks' dependent chain leave it (a kernel boundary costs 2.65 us on this chip, tools/hwprobe/
@@ -103,6 +105,11 @@ class ConformerTransducer(BaseModel):
         # gamma / beta folds of all blocks run once after the last block's backward (defer_pos_grad, ln_part_ext) - with a data-parallel
         # group a block's gradient slice has to be final when its bucket is released, so the per-block launches stay.  TFASR_BLOCK_HOIST=0: off.
         self.block_hoist = os.environ.get("TFASR_BLOCK_HOIST", "1") != "0"
+        # ... and with the gradients deferred, the kernel that accumulates a block's table gradient from dS (tfasr_relattn_dpext, 37 us per
+        # block, only the deferred products wait for it) runs on the auxiliary stream beside the next block's backward.  TFASR_DPEXT_AUX=0: in line.
+        self.dpext_aux = os.environ.get("TFASR_DPEXT_AUX", "1") != "0"
+        self.joint_wgrad_aux = os.environ.get("TFASR_JOINT_WGRAD_AUX", "0") == "1"  # (A/B: the vocabulary weight gradient on the auxiliary stream)
+        self._aux_pending = False
         self.aux_stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
         self._hoisted = {}
         self.fuse_joint_stats = os.environ.get("TFASR_JOINT_STATS", "1") != "0"
@@ -845,12 +852,19 @@ class ConformerTransducer(BaseModel):
             bstats = torch.empty(2 * d, dtype=torch.float32, device=self.device)
             io.prezeroed &= ~2
             io.dpext_zero = None
-        io.defer_pos_grad, io.ln_part_ext, io.ln_part_ext_floats, io.dcv_keep = 0, None, 0, None
+        io.defer_pos_grad, io.ln_part_ext, io.ln_part_ext_floats, io.dcv_keep, io.ds_keep, io.qv_keep = 0, None, 0, None, None, None
         hb = self._hoisted.get("bwd")
+        aux_dpext = None
         if hb is not None:
             if io.dpext_zero:
                 io.defer_pos_grad = 1
                 hb["pos"].append(i)
+                if self.dpext_aux and cfgk.dh == 64:
+                    Tp = -(-cfgk.T // 8) * 8
+                    ds = torch.empty(cfgk.B, cfgk.H, cfgk.T, Tp, dtype=self.dtype, device=self.device)
+                    qv = torch.empty(cfgk.B * cfgk.T, cfgk.H * cfgk.dh, dtype=self.dtype, device=self.device)
+                    io.ds_keep, io.qv_keep = ds.data_ptr(), qv.data_ptr()
+                    aux_dpext = (ds, qv, pool[i, off:off + n_dpext], s["keep"][4])
             if hb["ln_part"] is not None:
                 io.ln_part_ext = hb["ln_part"][i].data_ptr()
                 io.ln_part_ext_floats = hb["ln_part"].shape[1]
@@ -864,6 +878,10 @@ class ConformerTransducer(BaseModel):
         if self.wgrad_stream and self.dtype == torch.bfloat16:
             self._wgrad_flip = 3 - getattr(self, "_wgrad_flip", 2)
             slot = self._wgrad_flip
+        if slot:
+            # the group on the second stream reads the block's forward stash (and its input / output rows): alive until the join two blocks on
+            self._wgrad_keep.append((s["keep"], dy))
+            del self._wgrad_keep[:-3]
         scratch = K.workspace(bscr_b, self.device, f"blk_bwd{slot}")
         io.dy, io.dx, io.bn_bstats = dy.data_ptr(), dx.data_ptr(), bstats.data_ptr()
         io.scratch, io.scratch_bytes = scratch.data_ptr(), scratch.numel()
@@ -875,6 +893,16 @@ class ConformerTransducer(BaseModel):
             K.block_bwd(cfgk, P, io, cbuf, K._lib.PHASE_B)
         else:
             K.block_bwd(cfgk, P, io, cbuf, K._lib.PHASE_A | K._lib.PHASE_B)
+        if aux_dpext is not None:
+            # the positional table's gradient of this block on the auxiliary stream, beside the next block's backward
+            ds, qv, dpext, elen_dev = aux_dpext
+            main = torch.cuda.current_stream()
+            self.aux_stream.wait_stream(main)
+            for t in (ds, qv):
+                t.record_stream(self.aux_stream)
+            with torch.cuda.stream(self.aux_stream):
+                K.relattn_dpext(ds, qv, elen_dev, dpext, cfgk.B, cfgk.H, cfgk.T, cfgk.dh, use_mask=bool(cfgk.use_mask))
+            hb["aux_used"] = True
         return dx
 
     # =================================================================================== encoder
@@ -956,8 +984,11 @@ class ConformerTransducer(BaseModel):
             if prev[1]:
                 K.block_wgrad_join(3)
             self._bucket_after_block(prev[0])
+        self._wgrad_keep = []
         hb = self._hoisted.pop("bwd", None)
         if hb is not None:
+            if hb.get("aux_used"):
+                torch.cuda.current_stream().wait_stream(self.aux_stream)  # the table gradients accumulated on the auxiliary stream
             self._deferred_block_grads(hb, e["T"])
         t0 = self._tick("subsampling_bwd")
         self._subsampling_bwd(dx, ctx)
@@ -1209,8 +1240,25 @@ class ConformerTransducer(BaseModel):
     def _joint_backward_tail(self, costs, dlogits, h, enc, pred, off_dev, ul_dev, tl_dev, B, T, U1, ctx):
         """packed lattice: gradient of the lattice logits -> gradients of the joint network's inputs (+ its weight gradients)"""
         J = self.cfg.joint_dim
+        ps = self.ps
         # tanh' folded into the data gradient's epilogue (dact = TANH_OUT: times 1 - h^2): the segment sums read one tensor, not two
-        dh = self._dense_bwd(dlogits, h, "joint/vocab/w", "joint/vocab/b", dact_z=h, dact=ACT_TANH_OUT)
+        if self.joint_wgrad_aux and self.aux_stream is not None and isinstance(self.dp, SingleProcess) and self.dtype == torch.bfloat16:
+            # one GPU: the vocabulary projection's weight gradient (nothing waits for it before the optimizer) on the auxiliary stream,
+            # beside its data gradient and the start of the backward chain
+            main = torch.cuda.current_stream()
+            self.aux_stream.wait_stream(main)
+            W = ps.w2d("joint/vocab/w")
+            din, dout = W.shape
+            rows = dlogits.shape[0]
+            for t in (dlogits, h):
+                t.record_stream(self.aux_stream)
+            with torch.cuda.stream(self.aux_stream):
+                K.gemm(h, dlogits, ps.g2d("joint/vocab/w"), din, dout, rows, h.stride(0), dlogits.stride(0), dout, trans_a=True, accumulate=True,
+                       split_k=_split_k(din, dout, rows), colsum=ps.g("joint/vocab/b"))
+            self._aux_pending = True
+            dh = K.matmul(dlogits, W, trans_b=True, dact_z=h, dact=ACT_TANH_OUT)
+        else:
+            dh = self._dense_bwd(dlogits, h, "joint/vocab/w", "joint/vocab/b", dact_z=h, dact=ACT_TANH_OUT)
         de, dp = K.joint_bwd_packed(None, dh, off_dev, ul_dev, tl_dev, B, T, U1)
         denc = self._dense_bwd(de.view(B * T, J), enc, "joint/enc/w", "joint/enc/b")
         dpred = self._dense_bwd(dp.view(B * U1, J), pred, "joint/pred/w", "joint/pred/b")
@@ -1229,6 +1277,9 @@ class ConformerTransducer(BaseModel):
         self.encoder_bwd(denc, ctx)
         if self.use_pred_stream:
             main.wait_stream(self.pred_stream)
+        if getattr(self, "_aux_pending", False):
+            main.wait_stream(self.aux_stream)
+            self._aux_pending = False
         self.dp.finish_grads()
         return costs
 

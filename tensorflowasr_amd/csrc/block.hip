@@ -452,6 +452,10 @@ struct Ex {
     static const bool dpos_route = getenv("TFASR_ATTN_DPOS") && getenv("TFASR_ATTN_DPOS")[0] == '1';
     const bool v2 = k->fused && (!dpos_route || c->chunk_size > 0);  // (the streaming mask lives in the V2 kernels only)
     void* dpos = act(scratch, v2 ? (long)B * H * T * Tp : (long)B * H * T * R1p);  // v2: the unskewed dS [B,H,T,Tp]
+    // caller-owned dS / q + v buffers: they outlive this call and the caller runs tfasr_relattn_dpext itself (on another stream, beside
+    // the next block's backward): the table gradient is only needed by the deferred positional-projection gradients
+    const bool dpext_deferred = !dry && v2 && io->defer_pos_grad && io->dpext_zero && io->ds_keep && io->qv_keep && block_fuse();
+    if (dpext_deferred) dpos = io->ds_keep;
     const void* qv;
     float tail_scale;
     float* dpext = io->dpext_zero;
@@ -463,6 +467,7 @@ struct Ex {
       float* dvec = f32(scratch, (long)B * H * T);
       void* qu = act(scratch, rows * HD);
       void* qvb = act(scratch, rows * HD);
+      if (dpext_deferred) qvb = io->qv_keep;
       if (!dry) {
         // the query gradient (dq = dqu + dqv into the q columns of dqkv) and the u / v bias gradients finished inside the kernel;
         // TFASR_ATTN_Q3=0: separate tfasr_bias2_bwd pass over dqu / dqv
@@ -481,7 +486,7 @@ struct Ex {
         }
         chk(tfasr_relattn_fused_bwd_k(k->at_qkv, qu, qvb, k->at_pext, io->lengths, datt, k->at_lse, dvec, dqkv, B, H, T, dh, scale, c->use_mask,
                                       c->chunk_size, c->history_size, c->dtype, s));
-        chk(tfasr_relattn_dpext(dpos, qvb, io->lengths, dpext, B, H, T, dh, Tp, c->use_mask, c->dtype, s));
+        if (!dpext_deferred) chk(tfasr_relattn_dpext(dpos, qvb, io->lengths, dpext, B, H, T, dh, Tp, c->use_mask, c->dtype, s));
       }
       qv = qvb;
       tail_scale = 1.f;

@@ -80,3 +80,21 @@ def test_hoist_stays_per_block_with_a_process_group(dev):
     g = model.ps.grad
     assert bool(torch.isfinite(g).all())
     assert float((g - ref).abs().max()) <= 2e-2 * float(ref.abs().max())
+
+
+def test_weight_gradient_stream_same_step(dev):
+    """The blocks' grouped weight gradients beside the next block's backward on the executor's second stream (tfasr_block_io.wgrad_slot,
+    the default) against the in-line launches: same gradients (split-K atomics reorder run to run), ragged batch, two steps in a row
+    (the second step reuses the arenas the first step's groups read)."""
+    cfg, ocfg, model, W, data, sig, labels, preds = _setup(dev, torch.bfloat16, [4000, 2500, 3100], [6, 3, 5])
+    out = {}
+    for on in (False, True, True):
+        model.wgrad_stream = on
+        model.zero_grad()
+        costs = model.loss_and_backward(data, True, (None, None))
+        torch.cuda.synchronize()
+        out[on] = (costs.float().cpu().numpy(), model.ps.grad.clone())
+    np.testing.assert_array_equal(out[True][0], out[False][0])
+    g0, g1 = out[False][1], out[True][1]
+    assert bool(torch.isfinite(g1).all())
+    assert float((g1 - g0).abs().max()) <= 2e-3 * float(g0.abs().max())
