@@ -95,7 +95,11 @@ class ConformerTransducer(BaseModel):
         # backward.  Round 2 measured it SLOWER (29.06 vs 28.45 ms/step: the 512-workgroup group launch took CUs from the dependent chain);
         # with the round-4 chain (fused FFModule forward, one-tile GEMMs, hoisted launches) it is FASTER: 22.18 vs 22.45 ms/step, same box,
         # three interleaved pairs - the chain's kernels now leave more of the chip idle than the group takes.  TFASR_WGRAD_STREAM=0: in line.
-        self.wgrad_stream = os.environ.get("TFASR_WGRAD_STREAM", "1") != "0"
+        # ONE GPU only by default: with a process group (bench.py --dp-hooks, one rank) the second stream TOGETHER with the auxiliary stream
+        # of the hoists below made the step 38 instead of 22.7 ms (either alone: 22.8 / 22.7) - not understood yet (RCCL's streams, the
+        # prediction network's stream, these two and the main stream share the hardware queues), so a data-parallel rank keeps the step it
+        # has been measured with since round 3: weight gradients in line, no hoists.  TFASR_WGRAD_STREAM=1 / TFASR_BLOCK_HOIST=1 force them.
+        self.wgrad_stream = {"0": False, "1": True}.get(os.environ.get("TFASR_WGRAD_STREAM"), None)
         self._wgrad_keep = []
         self._blk_params, self._blk_sizes = {}, {}
         self._zero_pool = {}
@@ -104,7 +108,7 @@ class ConformerTransducer(BaseModel):
         # third stream while the subsampling runs (tfasr_block_io.pext_pre), and on ONE GPU the projections' gradients and the LayerNorm
         # gamma / beta folds of all blocks run once after the last block's backward (defer_pos_grad, ln_part_ext) - with a data-parallel
         # group a block's gradient slice has to be final when its bucket is released, so the per-block launches stay.  TFASR_BLOCK_HOIST=0: off.
-        self.block_hoist = os.environ.get("TFASR_BLOCK_HOIST", "1") != "0"
+        self.block_hoist = {"0": False, "1": True}.get(os.environ.get("TFASR_BLOCK_HOIST"), None)  # None: on for one GPU, off in a process group
         # ... and with the gradients deferred, the kernel that accumulates a block's table gradient from dS (tfasr_relattn_dpext, 37 us per
         # block, only the deferred products wait for it) runs on the auxiliary stream beside the next block's backward.  TFASR_DPEXT_AUX=0: in line.
         self.dpext_aux = os.environ.get("TFASR_DPEXT_AUX", "1") != "0"
@@ -875,7 +879,7 @@ class ConformerTransducer(BaseModel):
                 hb["dw"].append((cfgk, P, cbuf, dcv, s["keep"]))  # (the stash holds the other operand: alive until the batched launch)
         # grouped weight gradients of this block on the executor's second stream, beside the next block's backward: two arenas, alternating
         slot = 0
-        if self.wgrad_stream and self.dtype == torch.bfloat16:
+        if self._auto(self.wgrad_stream) and self.dtype == torch.bfloat16:
             self._wgrad_flip = 3 - getattr(self, "_wgrad_flip", 2)
             slot = self._wgrad_flip
         if slot:
@@ -910,7 +914,7 @@ class ConformerTransducer(BaseModel):
         """ConformerEncoder.call (conformer.py:672-701): subsample -> linear -> relpe -> blocks.  -> [B*T', d], T', lengths."""
         native = self.native_blocks and not self.time_sections
         self._hoisted = {}
-        hoist = native and self.block_hoist and self.dtype == torch.bfloat16 and self._fused_attention() and self.aux_stream is not None
+        hoist = native and self._auto(self.block_hoist) and self.dtype == torch.bfloat16 and self._fused_attention() and self.aux_stream is not None
         if hoist:
             self._pext_ahead((((feats.shape[1] + 1) // 2) + 1) // 2)
         t0 = self._tick("subsampling_fwd")
@@ -936,6 +940,10 @@ class ConformerTransducer(BaseModel):
         if ctx is not None:
             ctx["enc"] = dict(B=B, T=T, elen_dev=elen_dev, hoist=hoist)
         return x, T, elen, elen_dev
+
+    def _auto(self, switch):
+        """a tri-state option (None = automatic): on for one GPU, off inside a process group"""
+        return isinstance(self.dp, SingleProcess) if switch is None else bool(switch)
 
     def _pext_ahead(self, T):
         """Every block's projected relative-position table pe @ Wpos + bpos [2T', H*dh] on the auxiliary stream, beside the subsampling:

@@ -12,6 +12,8 @@
 #include <stdlib.h>
 #include <vector>
 
+extern int g_tfasr_group_beside;  // gemm_fast.hip: 1 around a grouped launch that shares the chip with another stream's chain
+
 namespace {
 
 struct Arena {
@@ -194,7 +196,9 @@ struct Ex {
       // beside the next block's backward: everything queued on `s` so far (the operands) precedes the launch, nothing on `s` waits
       // for it until the slot's arena is reused or the caller joins
       if (hipEventRecord(side->wfork, s) != hipSuccess || hipStreamWaitEvent(side->sw, side->wfork, 0) != hipSuccess) chk(TFASR_STATUS_EXECUTION_FAILED);
+      g_tfasr_group_beside = 1;  // (one workgroup per CU: the group shares the chip with the next block's chain)
       chk(tfasr_gemm_group(pending.data(), (int)pending.size(), side->sw));
+      g_tfasr_group_beside = 0;
       if (hipEventRecord(side->wdone[slot - 1], side->sw) != hipSuccess) chk(TFASR_STATUS_EXECUTION_FAILED);
       side->wpending[slot - 1] = true;
     } else {

@@ -1200,6 +1200,10 @@ bool group_eligible(const tfasr_gemm_args& a) {
 
 }  // namespace
 
+// set around a launch that shares the chip with another stream's dependent chain (block.hip: the weight-gradient stream); one host thread
+// per process queues the launches of a device, so a plain global is enough
+int g_tfasr_group_beside = 0;
+
 // One launch for up to GROUP_MAX weight-gradient products (see wgrad_group_kernel).  UNSUPPORTED -> the caller launches them one by one.
 int tfasr_gemm_group_fast_try(const tfasr_gemm_args* a, int n, hipStream_t stream) {
   if (n < 2 || n > GROUP_MAX) return TFASR_STATUS_UNSUPPORTED;
@@ -1214,10 +1218,23 @@ int tfasr_gemm_group_fast_try(const tfasr_gemm_args* a, int n, hipStream_t strea
     ga.gy[i] = (a[i].M + BM - 1) / BM;
     total += (long)ga.gx[i] * ga.gy[i];
   }
-  // k-split shared by the group: fill the resident slots (2 workgroups per CU) once; TFASR_GROUP_SLOTS overrides the slot count
-  static const long slots = getenv("TFASR_GROUP_SLOTS") ? atol(getenv("TFASR_GROUP_SLOTS")) : 2L * num_cus();
+  // k-split shared by the group: fill the resident slots (2 workgroups per CU) once; TFASR_GROUP_SLOTS overrides the slot count.
+  // A group that runs BESIDE another stream's dependent chain (the block executor's weight-gradient stream: g_tfasr_group_beside, set
+  // by the caller around the launch) takes 1.25 slots per CU (256 / 320 / 512 slots for those groups alone: -0.04 / -0.09 / 0 ms per step).
+  // A group of LONG products in line (the nine shifted conv2 weight gradients: K = B T2 F2 = 500 k rows, 36 tiles) also wants about one
+  // workgroup per CU: with 512 slots its 14 k-slices per tile were 8 M atomics and the slices' workgroups drifted apart in L2 - 256 / 320
+  // slots for every group of the step: -0.28 / -0.33 ms per step against 512, of which the block groups beside the chain are 0.04.
+  static const long env_slots = getenv("TFASR_GROUP_SLOTS") ? atol(getenv("TFASR_GROUP_SLOTS")) : 0;
+  long kmax = 0;
+  for (int i = 0; i < n; ++i) kmax = a[i].K > kmax ? a[i].K : kmax;
+  const long slots = env_slots > 0 ? env_slots : ((g_tfasr_group_beside || kmax >= 131072) ? num_cus() * 5L / 4 : 2L * num_cus());
   long split = slots / (total > 0 ? total : 1);
   if (split < 1) split = 1;
+  {
+    static const bool dbg = getenv("TFASR_DEBUG_GROUP") != nullptr;
+    static int dbg_n = 0;
+    if (dbg && dbg_n < 6) { fprintf(stderr, "[group] n %d tiles %ld beside %d slots %ld split %ld\n", n, total, g_tfasr_group_beside, slots, split); ++dbg_n; }
+  }
   // units (product, k-slice), largest first, each onto the XCD with the fewest slots taken so far
   struct U { int q, ks, tiles; };
   U units[GROUP_MAX * 64];

@@ -46,7 +46,8 @@ def test_hoisted_block_launches_same_step(dev, lens, ulens):
 
 
 def test_hoist_stays_per_block_with_a_process_group(dev):
-    """A data-parallel group releases a block's gradient bucket right behind the block: the backward hoists must stay off."""
+    """A data-parallel group releases a block's gradient bucket right behind the block, and the hoists' auxiliary stream together with the
+    weight-gradient stream was measured 1.7x slower under a process group: by default nothing is hoisted there."""
     cfg, ocfg, model, W, data, sig, labels, preds = _setup(dev, torch.bfloat16, [4000, 3300], [6, 4])
 
     class OneRank:  # duck-typed hook object (tensorflowasr_amd.dp.DataParallel is one): not SingleProcess = a process group
@@ -76,7 +77,7 @@ def test_hoist_stays_per_block_with_a_process_group(dev):
     model.zero_grad()
     model.loss_and_backward(data, True, (None, None))
     torch.cuda.synchronize()
-    assert calls == [1] and "pext" in model._hoisted  # group: the forward hoist only
+    assert calls == [1] and "pext" not in model._hoisted  # a process group: the measured round-3 step, nothing hoisted, weight gradients in line
     g = model.ps.grad
     assert bool(torch.isfinite(g).all())
     assert float((g - ref).abs().max()) <= 2e-2 * float(ref.abs().max())

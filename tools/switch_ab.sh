@@ -12,4 +12,4 @@ run() {
   echo "${ms:-FAILED}  $1" | tee -a $O/results.txt
 }
 : > $O/results.txt
-for i in 1 2 3; do run "$SW" "$@"; run "TFASR_NOP=1" "$@"; done
+for i in $(seq 1 ${PAIRS:-3}); do run "$SW" "$@"; run "TFASR_NOP=1" "$@"; done
