@@ -80,6 +80,26 @@ def test_no_compiler_made_vmcnt_wait_inside_the_slab_loop(asm, frag):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
+# 256-row GEMM (csrc/gemm_big.h, the joint vocabulary projection = bench.py's `roofline` kernel): the epilogue reads its 128 pinned
+# accumulators with explicit v_accvgpr_read.  Re-defining a fragment as an accumulation-register VALUE (asm "+a" on a copy) made the
+# compiler build a register window: 28 v_accvgpr_mov + 4 v_accvgpr_write per fragment block; and fmaxf on a DPP-moved value costs three
+# instructions per reduction step instead of one v_max_f32_dpp (common.h row16_max).
+def test_gemm_big_epilogue_reads_accumulators_in_place(asm):
+    body = _body(asm, "gemm_big_kernelILb0ELi256ELi64ELb0E")
+    last_mfma = max(i for i, l in enumerate(body) if "v_mfma_f32_16x16x32" in l)
+    epi = body[last_mfma:]
+    n_mov = sum("v_accvgpr_mov_b32" in l for l in epi)
+    n_read = sum("v_accvgpr_read_b32" in l for l in epi)
+    assert n_mov == 0, f"{n_mov} v_accvgpr_mov in the epilogue: the accumulators are being shuffled again"
+    assert n_read == 128, f"{n_read} accumulator reads (one per element of the wave's 64 x 128 tile expected)"
+    n_dpp_max = sum("v_max_f32_dpp" in l for l in epi)
+    assert n_dpp_max == 64, f"{n_dpp_max} v_max_f32_dpp (16 row reductions x 4 steps expected)"
+    # the canonicalising `v_max_f32 vN, vN, vN` of llvm.maxnum on a DPP-moved value must be gone
+    canon = [l for l in epi if re.match(r"\s*v_max_f32_e32 (v\d+), (v\d+), (v\d+)\s*$", l) and len(set(re.findall(r"v\d+", l)[1:])) == 1]
+    assert len(canon) <= 2, canon[:4]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
 # log-mel front end (csrc/logmel.hip): the next frame's samples are prefetched at the top of the frame loop and consumed in front of
 # the frame's stores.  Three compiler behaviours broke that silently while it was written (a select behind each load, a phantom
 # fetch-without-prepare path, the consumption sunk behind the stores); each shows up as a vmcnt wait where none belongs.
