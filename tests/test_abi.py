@@ -81,3 +81,44 @@ def test_package_import_asks_for_enough_hardware_queues():
     assert out.stdout.strip() == "8", out.stderr[-500:]
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(env, GPU_MAX_HW_QUEUES="2"), cwd=root)
     assert out.stdout.strip() == "2"
+
+
+def test_round4_entry_points_validate_their_arguments_on_the_host():
+    """The entry points that finish deferred per-block work for a whole step refuse bad arguments before anything is launched."""
+    import ctypes
+
+    lib = _lib.load()
+    INVALID = 1
+    assert lib.tfasr_block_ln_fold_all(None, 4, 256, None) == INVALID
+    arr = (ctypes.c_void_p * 2)(None, None)
+    assert lib.tfasr_block_ln_fold_all(arr, 2, 256, None) == INVALID  # a NULL ctx
+    assert lib.tfasr_block_ln_fold_all(arr, 0, 256, None) == INVALID
+    assert lib.tfasr_layernorm_bwd_fold_sets(arr, 129, 8, 256, arr, arr, None) == INVALID  # more sets than the kernel's table holds
+    assert lib.tfasr_layernorm_bwd_fold_sets(arr, 2, 8, 256, arr, arr, None) == INVALID    # NULL partial-sum pointers
+    assert lib.tfasr_cast_colsum_many(None, None, 1024, 2, 8, 64, arr, None) == INVALID
+    k = _lib.BlockCfg()
+    assert lib.tfasr_block_dwconv_wgrad_all(ctypes.byref(k), arr, arr, arr, 2, None, 0, None) == INVALID  # NULL params / ctx entries
+    assert lib.tfasr_block_dwconv_wgrad_all(ctypes.byref(k), arr, arr, arr, 33, None, 0, None) == INVALID
+    # a block io without the options = a zeroed tail: the structure the executor reads must match the header's
+    io = _lib.BlockIO()
+    assert not io.pext_pre and io.defer_pos_grad == 0 and not io.ln_part_ext and not io.dcv_keep and not io.ds_keep and not io.qv_keep
+
+
+def test_ctypes_structures_have_the_header_sizes(tmp_path):
+    """The structures passed by pointer through the C ABI are declared twice (include/tfasr_hip.h and tensorflowasr_amd/_lib.py): their
+    sizes must agree (a field added on one side only shifts everything behind it)."""
+    import ctypes
+    import shutil
+    import subprocess
+
+    import pytest
+
+    if not shutil.which("gcc"):
+        pytest.skip("gcc not available")
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include "tfasr_hip.h"\nint main(void) { printf("%zu %zu %zu %zu\\n", sizeof(tfasr_block_io), '
+                   'sizeof(tfasr_block_cfg), sizeof(tfasr_block_params), sizeof(tfasr_gemm_args)); return 0; }\n')
+    exe = tmp_path / "sz"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    sizes = [int(v) for v in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
+    assert sizes == [ctypes.sizeof(_lib.BlockIO), ctypes.sizeof(_lib.BlockCfg), ctypes.sizeof(_lib.BlockParams), ctypes.sizeof(_lib.GemmArgs)]
