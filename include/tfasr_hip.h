@@ -10,8 +10,13 @@
  *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); nothing synchronises;
  *   - no allocation inside: every scratch buffer is caller-owned, sized by a `*_workspace_size` query;
  *   - every entry returns a tfasr_status_t; `tfasr_status_string` decodes it;
- *   - re-entrant per stream, no global state, no assumption about the process-wide current device
- *     beyond "the pointers and the stream belong to the device that is current on this thread".
+ *   - re-entrant per stream, no assumption about the process-wide current device beyond "the pointers and the stream belong
+ *     to the device that is current on this thread".  State the library keeps: (i) tuning switches read ONCE from the environment
+ *     (TFASR_* variables, function-local statics: A/B switches of the kernels, never results); (ii) the block executor's internal
+ *     second stream + events per device (tfasr_block_io.wgrad_slot), the persistent-LSTM policy (tfasr_lstm_set_persist), and one
+ *     flag set around a grouped launch that shares the chip with another stream - all of them assume what the rest of the design
+ *     assumes anyway: ONE host thread queues the launches of a device.  Results never depend on any of it.
+ *     (The Python package also sets GPU_MAX_HW_QUEUES=8 at import unless the user chose a value - the HIP runtime's own switch.)
  *   - `dtype`: storage type of activation tensors, TFASR_F32 or TFASR_BF16 (raw 16-bit bfloat16).
  *     All arithmetic accumulates in f32. Parameters, gradients and optimizer state are always f32.
  */
