@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define TFASR_ABI_VERSION 31
+#define TFASR_ABI_VERSION 32
 
 typedef enum {
   TFASR_STATUS_SUCCESS = 0,
@@ -281,6 +281,10 @@ int tfasr_dwconv_bwd_weight(const void* x, const void* dy, float* dw, float* dbi
 int tfasr_dwconv_bwd_weight_workspace_size(int B, int T, int C, int K, size_t* bytes);
 int tfasr_dwconv_bwd_weight_ws(const void* x, const void* dy, float* dw, float* dbias, int B, int T, int C, int K, int dtype,
                                void* workspace, size_t workspace_bytes, void* stream);
+/* n <= 32 depthwise weight gradients of ONE shape in one tile launch + one reduce launch (host arrays of device pointers; dbias may be NULL
+   or hold NULL entries; workspace >= n * tfasr_dwconv_bwd_weight_workspace_size(B, T, C, K) bytes, else / f32: one launch pair or launch each). */
+int tfasr_dwconv_bwd_weight_many(const void* const* x, const void* const* dy, float* const* dw, float* const* dbias, int n, int B, int T, int C,
+                                 int K, int dtype, void* workspace, size_t workspace_bytes, void* stream);
 /* y1 = x + u, y2 = x + v (content / positional attention biases, multihead_attention.py:554-558) and its backward */
 int tfasr_bias2_fwd(const void* x, long ldx, const float* u, const float* v, void* y1, void* y2, long rows, int C,
                     int dtype, void* stream);

@@ -152,7 +152,7 @@ def load(build_if_missing=True):
     return lib
 
 
-ABI_VERSION = 31
+ABI_VERSION = 32
 
 
 STATUS_UNSUPPORTED = 3

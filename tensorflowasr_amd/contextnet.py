@@ -69,6 +69,18 @@ class ContextNetTransducer(ConformerTransducer):
                 K.gemm_group(q)
             q.clear()
 
+    def _dw_flush(self):
+        q = self._dw_queue
+        if not q:
+            return
+        groups = {}
+        for it in q:
+            groups.setdefault((tuple(it[0].shape), it[2].shape[0]), []).append(it)
+        for items in groups.values():
+            for j in range(0, len(items), 32):
+                K.dwconv_bwd_weight_many(items[j:j + 32])
+        q.clear()
+
     # ------------------------------------------------------------------------------- one ConvModule
     def _cm_fwd(self, x, mod, B, T, training, ctx):
         """x [B*T, Cin] -> y [B*T2, Cout]."""
@@ -97,7 +109,13 @@ class ContextNetTransducer(ConformerTransducer):
         if stride > 1:
             ddw = K.rows_subsample_bwd(ddw, s["T"], stride)
         x3 = s["x"].view(B, s["T"], ci)
-        K.dwconv_bwd_weight(x3, ddw, ps.g(name + "/dw"), None)
+        dq = getattr(self, "_dw_queue", None)
+        if dq is not None and self.dtype == torch.bfloat16:
+            # nothing on the backward chain waits for a depthwise WEIGHT gradient (two launches at ~0.3 of HBM per layer, 151 layers): the
+            # operands are kept and the layers of one shape go out as one launch pair at the end of the encoder's backward
+            dq.append((x3, ddw, ps.g(name + "/dw").view(Kk, ci), None))
+        else:
+            K.dwconv_bwd_weight(x3, ddw, ps.g(name + "/dw"), None)
         return K.dwconv_bwd_data(ddw, ps.p(name + "/dw")).view(B * s["T"], ci)
 
     # ------------------------------------------------------------------------------- squeeze-and-excite
@@ -170,6 +188,10 @@ class ContextNetTransducer(ConformerTransducer):
     def encoder_bwd(self, dx, ctx):
         B = ctx["enc"]["B"]
         self._wg_queue = [] if os.environ.get("TFASR_CN_WGRAD_GROUP", "1") != "0" else None
+        # one GPU: the depthwise weight gradients of all layers batched by shape after the loop (a data-parallel group releases a block's
+        # gradient range right behind the block); TFASR_CN_DW_BATCH=0: per layer
+        from .conformer import SingleProcess
+        self._dw_queue = [] if (isinstance(self.dp, SingleProcess) and os.environ.get("TFASR_CN_DW_BATCH", "1") != "0") else None
         try:
             for i in reversed(range(len(self.blocks))):
                 dx = self._block_bwd_cn(dx, self.blocks[i], B, ctx)
@@ -178,6 +200,8 @@ class ContextNetTransducer(ConformerTransducer):
                 lo = self.ps.offsets[self.blocks[i]["convs"][0][0] + "/dw"]
                 hi = self.ps.offsets[self.blocks[i + 1]["convs"][0][0] + "/dw"] if i + 1 < len(self.blocks) else self.ps.offsets["pred/emb"]
                 self.dp.grads_ready(lo, hi)
+            self._dw_flush()
         finally:
             self._wg_queue = None  # the prediction / joint networks' gradients are issued directly
+            self._dw_queue = None
         # (the input features need no gradient)

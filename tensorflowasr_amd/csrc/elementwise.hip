@@ -767,6 +767,27 @@ extern "C" int tfasr_dwconv_bwd_weight_ws(const void* x, const void* dy, float* 
   return tfasr_dwconv_bwd_weight(x, dy, dw, dbias, B, T, C, K, dtype, stream_);
 }
 
+int tfasr_dwconv_wgrad_many_try(const void* const* x, const void* const* dy, float* const* dw, float* const* dbias, int n, int B, int T, int C, int K,
+                                float* ws, size_t ws_bytes, hipStream_t s);  // dwconv.hip
+
+// n <= 32 weight gradients of ONE shape (e.g. the layers of a ContextNet stage, or every Conformer block's) as one tile launch + one reduce
+// launch; fallback: one by one.  workspace >= n * tfasr_dwconv_bwd_weight_workspace_size(B, T, C, K) bytes for the batched route.
+extern "C" int tfasr_dwconv_bwd_weight_many(const void* const* x, const void* const* dy, float* const* dw, float* const* dbias, int n, int B, int T, int C,
+                                            int K, int dtype, void* workspace, size_t workspace_bytes, void* stream_) {
+  if (!x || !dy || !dw || n <= 0 || n > 32 || B <= 0 || T <= 0 || C <= 0 || K <= 0 || K > DW_MAXK) return TFASR_STATUS_INVALID_VALUE;
+  for (int i = 0; i < n; ++i)
+    if (!x[i] || !dy[i] || !dw[i]) return TFASR_STATUS_INVALID_VALUE;
+  if (dtype == TFASR_BF16 && workspace) {
+    const int st = tfasr_dwconv_wgrad_many_try(x, dy, dw, dbias, n, B, T, C, K, (float*)workspace, workspace_bytes, (hipStream_t)stream_);
+    if (st != TFASR_STATUS_UNSUPPORTED) return st;
+  }
+  for (int i = 0; i < n; ++i) {
+    const int st = tfasr_dwconv_bwd_weight(x[i], dy[i], dw[i], dbias ? dbias[i] : nullptr, B, T, C, K, dtype, stream_);
+    if (st != TFASR_STATUS_SUCCESS) return st;
+  }
+  return TFASR_STATUS_SUCCESS;
+}
+
 extern "C" int tfasr_dwconv_bwd_weight(const void* x, const void* dy, float* dw, float* dbias, int B, int T, int C,
                                        int K, int dtype, void* stream_) {
   if (!x || !dy || !dw || B <= 0 || T <= 0 || C <= 0 || K <= 0 || K > DW_MAXK) return TFASR_STATUS_INVALID_VALUE;

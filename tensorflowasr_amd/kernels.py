@@ -416,6 +416,21 @@ def dwconv_bwd_weight(x, dy, dw, dbias):
           "dwconv_bwd_weight_ws")
 
 
+def dwconv_bwd_weight_many(items):
+    """Depthwise weight gradients of several layers of ONE shape as one launch pair: items = [(x [B,T,C], dy [B,T,C], dw [K,C] f32, dbias or None)]."""
+    n = len(items)
+    B, T, C = items[0][0].shape
+    Kk = items[0][2].shape[0]
+    need = ctypes.c_size_t(0)
+    check(_L().tfasr_dwconv_bwd_weight_workspace_size(B, T, C, Kk, ctypes.byref(need)), "dwconv_bwd_weight_workspace_size")
+    ws = workspace(n * need.value, items[0][0].device, "dw_wgrad_many")
+    xa = (ctypes.c_void_p * n)(*[_p(t[0]).value for t in items])
+    da = (ctypes.c_void_p * n)(*[_p(t[1]).value for t in items])
+    wa = (ctypes.c_void_p * n)(*[t[2].data_ptr() for t in items])
+    ba = (ctypes.c_void_p * n)(*[(t[3].data_ptr() if t[3] is not None else None) for t in items])
+    check(_L().tfasr_dwconv_bwd_weight_many(xa, da, wa, ba, n, B, T, C, Kk, _dt(items[0][0]), _p(ws), ws.numel(), _stream()), "dwconv_bwd_weight_many")
+
+
 def bias2_fwd(x, ldx, u, v, rows, C):
     y1 = torch.empty(rows, C, dtype=x.dtype, device=x.device)
     y2 = torch.empty(rows, C, dtype=x.dtype, device=x.device)

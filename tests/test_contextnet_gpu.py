@@ -88,3 +88,29 @@ def test_contextnet_recognize_runs_without_prediction_layernorm(dev):
     assert out.tokens.shape == (2, 2 * T + 1)
     one = model.recognize(PredictInput(torch.from_numpy(sig[:1]), torch.tensor([4000], dtype=torch.int32)))
     assert one.tokens.shape[0] == 1
+
+
+def test_batched_depthwise_weight_gradients_match_the_per_layer_launches(dev, monkeypatch):
+    """bf16: the depthwise weight gradients of all layers go out batched by shape after the encoder's backward (one launch pair per shape,
+    tfasr_dwconv_bwd_weight_many); TFASR_CN_DW_BATCH=0 restores one launch pair per layer.  Same gradients (partial sums in another order)."""
+    cfg = configs.contextnet_tiny()
+    model = ContextNetTransducer(cfg, dev, dtype=torch.bfloat16, seed=3)
+    g = torch.Generator().manual_seed(5)
+    lens = [57, 31, 44]
+    B, T0, F = len(lens), max(lens), cfg.num_feature_bins
+    feats = torch.randn(B, T0, F, generator=g).to(dev).to(torch.bfloat16)
+    grads = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("TFASR_CN_DW_BATCH", mode)
+        ctx = {}
+        out, T, elen, _ = model.encoder_fwd(feats, lens, True, ctx)
+        dy = torch.randn(out.shape, generator=torch.Generator().manual_seed(7)).to(dev).to(torch.bfloat16)
+        model.zero_grad()
+        model.encoder_bwd(dy, ctx)
+        torch.cuda.synchronize()
+        grads[mode] = model.ps.grad.clone()
+    g0, g1 = grads["0"], grads["1"]
+    assert bool(torch.isfinite(g1).all()) and float(g0.abs().max()) > 0
+    assert float((g1 - g0).abs().max()) <= 2e-3 * float(g0.abs().max())
+    names = [m[0] + "/dw" for blk in params.contextnet_modules(cfg) for m in blk["convs"]]
+    assert any(float(model.ps.g(n).abs().max()) > 0 for n in names)
