@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define TFASR_ABI_VERSION 32
+#define TFASR_ABI_VERSION 33
 
 typedef enum {
   TFASR_STATUS_SUCCESS = 0,
@@ -312,6 +312,10 @@ int tfasr_joint_bwd_packed(const void* h, const void* dh, void* denc, void* dpre
  * m,v update; p -= lr*sqrt(1-b2^t)/(1-b1^t) * m/(sqrt(v)+eps)   (small.yml.j2:73-87; L2: :67-69) */
 int tfasr_adam(float* p, const float* g, float* m, float* v, long n, long n_reg, float lr, float beta1, float beta2,
                float eps, float weight_decay, float l2, float grad_scale, long step, void* stream);
+/* the same update; shadow_bf16 != NULL: the bf16 copy of the parameters (what the bf16 kernels read as weights) is written in the same
+   pass, bitwise what tfasr_cast of the updated buffer gives. */
+int tfasr_adam_shadow(float* p, const float* g, float* m, float* v, long n, long n_reg, float lr, float beta1, float beta2, float eps,
+                      float weight_decay, float l2, float grad_scale, long step, void* shadow_bf16, void* stream);
 int tfasr_sumsq(const float* p, long n, float* out, void* stream);
 /* x[i] += stddev * N(0,1) over an f32 vector, the deviate a pure function of (seed, i).  Replaces tf.random.normal in variational
  * weight noise (utils/layer_util.py:42-52 add_gwn, models/transducer/base_transducer.py:382-425) and gradient noise

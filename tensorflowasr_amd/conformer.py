@@ -1312,9 +1312,12 @@ class ConformerTransducer(BaseModel):
         # Adam.update_step]
         lr = self.learning_rate(self.step - 1)
         ps = self.ps
+        # bf16 models: the optimizer writes the bf16 shadow of the parameters itself (TFASR_ADAM_SHADOW=0: the separate cast pass)
+        fused = ps.shadow is not ps.flat and ps.shadow.dtype == torch.bfloat16 and os.environ.get("TFASR_ADAM_SHADOW", "1") != "0"
         K.adam(ps.flat, ps.grad, ps.adam_m, ps.adam_v, ps.n_reg, lr, self.step, o["beta1"], o["beta2"], o["eps"], o["weight_decay"],
-               self.cfg.l2, grad_scale)
-        ps.refresh_shadow()
+               self.cfg.l2, grad_scale, shadow=ps.shadow if fused else None)
+        if not fused:
+            ps.refresh_shadow()
         return lr
 
     def regularization_loss(self):

@@ -557,10 +557,12 @@ __global__ __launch_bounds__(128 * JB_RL) void joint_bwd_packed_kernel(const T* 
 // ----------------------------------------------------------------------------------------- Adam
 // keras.optimizers.Adam semantics (bias-corrected, decoupled weight_decay applied first) + the L2
 // kernel regulariser gradient 2*l2*p on the first n_reg elements (small.yml.j2:67-69,73-87).
+// shadow != nullptr: the bf16 copy of the parameters the MFMA kernels read is written in the same pass (it was a separate cast over the
+// whole buffer after the optimizer: one more read of 4 B / parameter and one more launch per step)
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, long n, long n_reg,
                                                    float lr, float b1, float b2, float eps, float wd, float l2,
-                                                   float gscale, float bc1, float bc2) {
+                                                   float gscale, float bc1, float bc2, bf16_t* __restrict__ shadow) {
   const float alpha = lr * sqrtf(bc2) / bc1;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     float pv = p[i];
@@ -571,7 +573,9 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     const float vv = v[i] + (gv * gv - v[i]) * (1.f - b2);
     m[i] = mv;
     v[i] = vv;
-    p[i] = pv - alpha * mv / (sqrtf(vv) + eps);
+    const float pn = pv - alpha * mv / (sqrtf(vv) + eps);
+    p[i] = pn;
+    if (shadow) shadow[i] = f32_to_bf16(pn);
   }
 }
 
@@ -930,15 +934,20 @@ extern "C" int tfasr_joint_bwd_packed(const void* h, const void* dh, void* denc,
   return TFASR_STATUS_SUCCESS;
 }
 
-extern "C" int tfasr_adam(float* p, const float* g, float* m, float* v, long n, long n_reg, float lr, float beta1,
-                          float beta2, float eps, float weight_decay, float l2, float grad_scale, long step,
-                          void* stream_) {
+extern "C" int tfasr_adam_shadow(float* p, const float* g, float* m, float* v, long n, long n_reg, float lr, float beta1,
+                                 float beta2, float eps, float weight_decay, float l2, float grad_scale, long step, void* shadow_bf16,
+                                 void* stream_) {
   if (!p || !g || !m || !v || n <= 0 || step <= 0) return TFASR_STATUS_INVALID_VALUE;
   const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
   hipLaunchKernelGGL(adam_kernel, dim3(flat_grid(n)), dim3(256), 0, (hipStream_t)stream_, p, g, m, v, n, n_reg, lr, beta1,
-                     beta2, eps, weight_decay, l2, grad_scale, bc1, bc2);
+                     beta2, eps, weight_decay, l2, grad_scale, bc1, bc2, (bf16_t*)shadow_bf16);
   TFASR_CHECK_LAUNCH();
   return TFASR_STATUS_SUCCESS;
+}
+extern "C" int tfasr_adam(float* p, const float* g, float* m, float* v, long n, long n_reg, float lr, float beta1,
+                          float beta2, float eps, float weight_decay, float l2, float grad_scale, long step,
+                          void* stream_) {
+  return tfasr_adam_shadow(p, g, m, v, n, n_reg, lr, beta1, beta2, eps, weight_decay, l2, grad_scale, step, nullptr, stream_);
 }
 
 extern "C" int tfasr_gauss_noise(float* x, long n, float stddev, long seed, void* stream_) {

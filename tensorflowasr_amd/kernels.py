@@ -488,8 +488,12 @@ def joint_bwd_packed(h, dh, cell_off, label_len, logit_len, B, T, U1):
     return denc, dpred
 
 
-def adam(p, g, m, v, n_reg, lr, step, beta1=0.9, beta2=0.999, eps=1e-7, weight_decay=0.0, l2=0.0, grad_scale=1.0):
-    check(_L().tfasr_adam(_p(p), _p(g), _p(m), _p(v), p.numel(), n_reg, lr, beta1, beta2, eps, weight_decay, l2, grad_scale, step, _stream()), "adam")
+def adam(p, g, m, v, n_reg, lr, step, beta1=0.9, beta2=0.999, eps=1e-7, weight_decay=0.0, l2=0.0, grad_scale=1.0, shadow=None):
+    """shadow (bf16, p's shape): also receives the updated parameters rounded to bf16, in the same launch"""
+    if shadow is not None:
+        assert shadow.dtype == torch.bfloat16 and shadow.numel() == p.numel()
+    check(_L().tfasr_adam_shadow(_p(p), _p(g), _p(m), _p(v), p.numel(), n_reg, lr, beta1, beta2, eps, weight_decay, l2, grad_scale, step, _p(shadow),
+                                 _stream()), "adam")
 
 
 def gauss_noise(x, stddev, seed):

@@ -261,6 +261,12 @@ def test_adam_specaug(dev):
     out = torch.zeros(1, device=dev)
     K.sumsq(pd, n_reg, out)
     cmp(out, (pd[:n_reg].cpu() ** 2).sum()[None], rtol=1e-5, atol=1e-4)
+    # the optimizer also writes the bf16 shadow of the parameters: the same update, and bitwise the cast of the updated buffer
+    p2, m2, v2 = p.to(dev), m.to(dev), v.to(dev)
+    sh = torch.zeros(n, dtype=torch.bfloat16, device=dev)
+    K.adam(p2, gr.to(dev), m2, v2, n_reg, lr, step, 0.9, 0.98, 1e-9, wd, l2, gs, shadow=sh)
+    assert torch.equal(p2, pd) and torch.equal(m2, md) and torch.equal(v2, vd)
+    assert torch.equal(sh, K.cast(p2, torch.empty(n, dtype=torch.bfloat16, device=dev)))
     # specaugment
     rng = np.random.default_rng(0)
     feat = rng.standard_normal((3, 120, 80)).astype(np.float32)
