@@ -120,40 +120,80 @@ def step_useful_flops(cfg, batch):
     return 2.0 * 3.0 * (enc + pred + joint)
 
 
-def wgrad_group_roofline(cfg, rows, dev, iters=20):
-    """`roofline_by_time`: the kernel family with the largest share of the step's kernel time (profiles/r0*_step*_kernel_stats: the
-    grouped weight gradients of a Conformer block, one launch per block and phase).  The launch sits inside the native block
-    executor, out of reach of host-side events, so it is measured right after the timed region, in isolation, on the step's own
-    shapes (the 8 Dense-layer products of one block over `rows` = B x T' rows; labelled as such)."""
-    from tensorflowasr_amd import kernels as K
-
+def wgrad_group_shapes(cfg):
     d, H, dh = cfg.dmodel, cfg.num_heads, max(cfg.head_size, 64)
     f = cfg.ffm_scale * d
-    shapes = [(d, f), (f, d), (d, f), (f, d), (d, 3 * H * dh), (H * dh, d), (d, 2 * d), (d, d)]
+    return [(d, f), (f, d), (d, f), (f, d), (d, 3 * H * dh), (H * dh, d), (d, 2 * d), (d, d)]
+
+
+def wgrad_group_roofline(cfg, rows_list, dev, in_step=None, iters=24):
+    """`roofline_by_time`: the kernel family with the largest share of the step's kernel time (profiles/r0*_step*_kernel_stats: the
+    grouped weight gradients of a Conformer block, one launch per block).  Two measurements:
+    * `in_step`: HIP events recorded by the block executor around every grouped launch ON THE STREAM IT RUNS ON (its second stream, beside
+      the next block's backward chain) during real train steps (tfasr_block_wgrad_probe) - the number that describes the step;
+    * isolated: the same launch alone on the chip, at the MEAN row count of the batches the step cycles through, rotating over enough
+      operand sets that their total exceeds the 256 MiB Infinity Cache (every launch streams its operands from HBM)."""
+    from tensorflowasr_amd import kernels as K
+
+    shapes = wgrad_group_shapes(cfg)
+    rows = int(round(float(np.mean(rows_list)) / 64.0)) * 64
+    per_set = sum(rows * (m + n) * 2 for m, n in shapes)
+    nsets = max(3, -(-(288 << 20) // per_set))
     g = torch.Generator().manual_seed(0)
-    xs = [(torch.randn(rows, m, generator=g) * 0.1).to(dev).to(torch.bfloat16) for m, n in shapes]
-    dys = [(torch.randn(rows, n, generator=g) * 0.1).to(dev).to(torch.bfloat16) for m, n in shapes]
+    sets = []
+    for _ in range(nsets):
+        xs = [(torch.randn(rows, m, generator=g) * 0.1).to(dev).to(torch.bfloat16) for m, n in shapes]
+        dys = [(torch.randn(rows, n, generator=g) * 0.1).to(dev).to(torch.bfloat16) for m, n in shapes]
+        sets.append((xs, dys))
     outs = [torch.zeros(m, n, device=dev) for m, n in shapes]
     bs = [torch.zeros(n, device=dev) for m, n in shapes]
-    calls = [dict(A=xs[i], B=dys[i], out=outs[i], M=shapes[i][0], N=shapes[i][1], K=rows, lda=shapes[i][0], ldb=shapes[i][1], ldd=shapes[i][1],
-                  trans_a=True, accumulate=True, split_k=8, colsum=bs[i]) for i in range(len(shapes))]
-    for _ in range(3):
-        K.gemm_group(calls)
+    calls = [[dict(A=xs[i], B=dys[i], out=outs[i], M=shapes[i][0], N=shapes[i][1], K=rows, lda=shapes[i][0], ldb=shapes[i][1], ldd=shapes[i][1],
+                   trans_a=True, accumulate=True, split_k=8, colsum=bs[i]) for i in range(len(shapes))] for xs, dys in sets]
+    for k in range(nsets):
+        K.gemm_group(calls[k])
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(iters):
-        K.gemm_group(calls)
+    for it in range(iters):
+        K.gemm_group(calls[it % nsets])
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
     fl = sum(2.0 * rows * m * n for m, n in shapes)
     by = sum((rows * (m + n)) * 2.0 + m * n * 4.0 for m, n in shapes)
     ach = fl / (ms * 1e-3) / 1e12
-    return {"kernel": "wgrad_group_kernel (the 8 Dense-layer weight gradients of one Conformer block, one grouped launch)", "bound": "mfma",
-            "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
-            "ms_per_launch": round(ms, 4), "rows": rows, "algorithmic_bytes": by, "hbm_frac": round(by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
-            "how": "isolated launches on the step's shapes right after the timed region (the launch itself sits inside the native block executor)"}
+    out = {"kernel": "wgrad_group_kernel (the 8 Dense-layer weight gradients of one Conformer block, one grouped launch)", "bound": "mfma",
+           "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
+           "ms_per_launch": round(ms, 4), "rows": rows, "algorithmic_bytes": by, "hbm_frac": round(by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+           "operand_sets": nsets, "operand_bytes_total": nsets * per_set,
+           "how": f"isolated launches at the mean rows of the step's batches, rotating over {nsets} operand sets ({nsets * per_set >> 20} MiB > the 256 MiB "
+                  f"Infinity Cache); `in_step` = HIP events of the block executor around the same launch inside real train steps"}
+    if in_step is not None:
+        ms_in, n_in, fl_in = in_step  # total ms, launches, flop of all of them
+        if n_in > 0 and ms_in > 0:
+            a2 = fl_in / (ms_in * 1e-3) / 1e12
+            out["in_step"] = {"ms_per_launch": round(ms_in / n_in, 4), "launches": n_in, "achieved": round(a2, 1), "frac": round(a2 / MFMA_BF16_PEAK_TFLOPS, 4),
+                              "note": "the launch runs on the executor's second stream beside the next block's backward chain (one GPU) / in line (data-parallel "
+                                      "rank): its duration there, not the step time it costs"}
+            out["in_step_frac"] = out["in_step"]["frac"]
+    return out
+
+
+def dp_route_line(argv_model, steps=10, warmup=3, timeout_s=150):
+    """`dp_route_ms`: the data-parallel code path (bucketed gradient all-reduce hooks, sync-BN reductions, per-rank seeds) through a ONE-rank
+    RCCL group on this GPU, in a child process (a process group cannot be added to this one after the fact): everything a rank of a
+    multi-GPU job does except the wire time, so the cost of the route is visible in every default run."""
+    import subprocess
+
+    cmd = [sys.executable, os.path.abspath(__file__), "--dp-hooks", "--no-cpu-baseline", "--no-extras", "--steps", str(steps), "--warmup", str(warmup)] + argv_model
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s)
+        for line in reversed(r.stdout.splitlines()):
+            if line.startswith("{"):
+                return float(json.loads(line)["ms_per_step"])
+    except Exception:
+        return None
+    return None
 
 
 def pmc_traffic(flops_per_launch, J, V):
@@ -511,12 +551,18 @@ def main():
     torch.cuda.synchronize()
     if dp:
         dp.barrier()
+    n_launch0 = 0
+    if not stub:
+        from tensorflowasr_amd import kernels as _K
+
+        n_launch0 = _K.launch_count()
     t0 = time.perf_counter()
     secs_local = 0.0
     for i in range(args.steps):
         one_step(i)
         secs_local += batches[i % nb]["seconds"]
     t_host = time.perf_counter() - t0  # host-side enqueue time (the GPU may still be running)
+    launches_per_step = None if stub else (_K.launch_count() - n_launch0) / float(args.steps)
     torch.cuda.synchronize()
     if dp:
         dp.barrier()
@@ -591,12 +637,25 @@ def main():
                        "global_batch": args.batch * world, "parallelism": f"dp{world}" + (" (data-parallel hooks on, one-rank RCCL group)" if args.dp_hooks and world == 1 else ""), "params": model.ps.num_trainable()},
             "roofline": roof,
             "roofline_rnnt": roof_rnnt,
+            # kernels this library queued per step (host-side count, tfasr_launch_count; torch's own fills / copies are not in it)
+            "launches_per_step": None if launches_per_step is None else round(launches_per_step, 1),
         }
         if not stub and args.model in ("M", "S") and dtype == torch.bfloat16 and not args.no_extras:
             try:
-                nsm = np.asarray(batches[0]["nsamp"], np.int64)
-                rows_b = args.batch * int(-(-(-(-(-(-int(nsm.max()) // cfg.frame_step)) // 2)) // 2))
-                out["roofline_by_time"] = wgrad_group_roofline(cfg, rows_b, dev)
+                rows_list = [args.batch * int(-(-(-(-(-(-int(np.asarray(b["nsamp"], np.int64).max()) // cfg.frame_step)) // 2)) // 2)) for b in batches]
+                # in-step duration of the grouped weight gradients: a few more steps with the executor's event probe on
+                from tensorflowasr_amd import kernels as _K2
+
+                model.timers = None
+                _K2.block_wgrad_probe(True)
+                nprobe = 4
+                for i in range(nprobe):
+                    one_step(i)
+                torch.cuda.synchronize()
+                ms_in, n_in = _K2.block_wgrad_probe_read()
+                _K2.block_wgrad_probe(False)
+                fl_in = sum(cfg.num_blocks * sum(2.0 * rows_list[i % nb] * m * n for m, n in wgrad_group_shapes(cfg)) for i in range(nprobe))
+                out["roofline_by_time"] = wgrad_group_roofline(cfg, rows_list, dev, in_step=(ms_in, n_in, fl_in))
             except Exception as e:
                 out["roofline_by_time"] = {"value": None, "error": repr(e)[:200]}
         if world == 1 and not args.no_extras and args.model == "M" and args.padding == "batch" and size == "LibriSpeech-shaped":
@@ -653,6 +712,11 @@ def main():
             finally:
                 model.joint_recompute = False
                 model.timers = None
+        if world == 1 and not stub and not args.no_extras and not args.dp_hooks and args.model in ("M", "S") and dtype == torch.bfloat16:
+            # the data-parallel route at one rank: what a rank of an N-GPU job runs, wire time excluded
+            dpm = dp_route_line(["--model", args.model, "--batch", str(args.batch), "--padding", args.padding] + (["--workload", args.workload] if args.workload else []))
+            out["dp_route_ms"] = None if dpm is None else round(dpm, 3)
+            out["dp_route_over_single"] = None if dpm is None else round(dpm / ms_per_step, 4)
         if not args.no_cpu_baseline and world == 1 and not stub:
             try:
                 if args.model != "contextnet":  # the CPU port baseline is the Conformer oracle

@@ -14,7 +14,8 @@
  *     to the device that is current on this thread".  State the library keeps: (i) tuning switches read ONCE from the environment
  *     (TFASR_* variables, function-local statics: A/B switches of the kernels, never results); (ii) the block executor's internal
  *     second stream + events per device (tfasr_block_io.wgrad_slot), the persistent-LSTM policy (tfasr_lstm_set_persist), and one
- *     flag set around a grouped launch that shares the chip with another stream - all of them assume what the rest of the design
+ *     flag set around a grouped launch that shares the chip with another stream; (iii) two measurement aids: a host-side launch counter
+ *     (tfasr_launch_count) and the optional event record of tfasr_block_wgrad_probe - all of them assume what the rest of the design
  *     assumes anyway: ONE host thread queues the launches of a device.  Results never depend on any of it.
  *     (The Python package also sets GPU_MAX_HW_QUEUES=8 at import unless the user chose a value - the HIP runtime's own switch.)
  *   - `dtype`: storage type of activation tensors, TFASR_F32 or TFASR_BF16 (raw 16-bit bfloat16).
@@ -30,7 +31,7 @@
 extern "C" {
 #endif
 
-#define TFASR_ABI_VERSION 33
+#define TFASR_ABI_VERSION 34
 
 typedef enum {
   TFASR_STATUS_SUCCESS = 0,
@@ -44,6 +45,8 @@ typedef enum { TFASR_F32 = 0, TFASR_BF16 = 1 } tfasr_dtype_t;
 const char* tfasr_status_string(int status);
 /* ABI version of this header (bumped on any signature change). */
 int tfasr_abi_version(void);
+/* Kernel launches this library has queued since it was loaded (host-side count; every kernel goes through one launch macro). */
+size_t tfasr_launch_count(void);
 
 /* ------------------------------------------------------------------------------------------------
  * RNN-T loss  (replaces warprnnt_tensorflow.rnnt_loss / rnnt_loss_tf,
@@ -660,6 +663,18 @@ int tfasr_block_fwd(const tfasr_block_cfg* cfg, const tfasr_block_params* params
 int tfasr_block_wgrad_join(int slot_mask, void* stream);
 int tfasr_block_bwd(const tfasr_block_cfg* cfg, const tfasr_block_params* params, const tfasr_block_io* io, void* ctx,
                     int phase, void* stream);
+/* What the last tfasr_block_bwd call with this ctx LEFT TO THE CALLER - the executor, not the caller, decides whether an optional
+   tfasr_block_io request is honoured (it depends on the attention route, the storage type and the executor's own switches), so a caller
+   that asked for a deferral must look here before it runs the deferred launch itself:
+   bit 0: the table gradient from dS (ds_keep / qv_keep are filled; tfasr_relattn_dpext was NOT launched),
+   bit 1: the depthwise-conv weight gradient (dcv_keep is filled), bit 2: the positional-projection gradients (defer_pos_grad),
+   bit 3: the LayerNorm gamma / beta fold (ln_part_ext).  A bit that is clear means the block did that work in line. */
+int tfasr_block_bwd_left(const void* ctx);
+/* Measurement probe: while enabled, tfasr_block_bwd brackets every grouped weight-gradient launch with HIP events on the stream that
+   launch runs on (its own second stream with wgrad_slot != 0).  _read waits for the recorded launches, returns their summed duration and
+   count, and clears the record.  Off by default (two event records per block). */
+int tfasr_block_wgrad_probe(int enable);
+int tfasr_block_wgrad_probe_read(float* total_ms, int* launches);
 /* dgamma / dbeta of every LayerNorm of `n` blocks whose backward ran with io->ln_part_ext: one launch instead of one per block.
    ctx[i] = the ctx of block i's tfasr_block_bwd call (host memory); blocks without pending partial sums are skipped. */
 int tfasr_block_ln_fold_all(void* const* ctx, int n, int d, void* stream);

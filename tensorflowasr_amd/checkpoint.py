@@ -320,7 +320,10 @@ def save_state(model, filepath):
     arrays = {"layout": np.asarray("logical"), "flat": ps.to_logical(ps.flat).numpy(), "adam_m": ps.to_logical(ps.adam_m).numpy(),
               "adam_v": ps.to_logical(ps.adam_v).numpy(), "step": np.asarray(model.step, np.int64),
               "drop_epoch": np.asarray(model._drop_epoch, np.int64), "ga_count": np.asarray(model._ga_count, np.int64),
-              "names": np.asarray(ps.names)}
+              "names": np.asarray(ps.names),
+              # counters behind the gradient / weight noise seeds (base_model._gradient_noise / apply_gwn): a resumed run continues the
+              # sequence of draws instead of replaying the ones from the start of training
+              "gradn_epoch": np.asarray(getattr(model, "_gradn_epoch", 0), np.int64), "gwn_epoch": np.asarray(getattr(model, "_gwn_epoch", 0), np.int64)}
     if model._ga_count > 0:  # saved in the middle of a gradient-accumulation cycle: the partial sum of micro-gradients belongs to the state
         arrays["grad"] = ps.to_logical(ps.grad).numpy()
     rng = getattr(model, "_rng", None)
@@ -359,6 +362,8 @@ def load_state(model, filepath):
         put("adam_m", ps.adam_m)
         put("adam_v", ps.adam_v)
         model.step, model._drop_epoch, model._ga_count = int(z["step"]), int(z["drop_epoch"]), int(z["ga_count"])
+        if "gradn_epoch" in z.files:  # (older state files: the counters restart, as before)
+            model._gradn_epoch, model._gwn_epoch = int(z["gradn_epoch"]), int(z["gwn_epoch"])
         if model._ga_count > 0:
             if "grad" in z.files:
                 put("grad", ps.grad)

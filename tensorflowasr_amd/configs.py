@@ -128,16 +128,29 @@ class ConformerConfig:
         for k, ok in unsupported.items():
             if k in c and c[k] not in ok:
                 raise NotImplementedError(f"{k}={c[k]!r}: only {ok} is on the MI355X hot path")
-        if sub and (list(sub.get("kernels", [3, 3])) != [3, 3] or list(sub.get("strides", [2, 2])) != [2, 2]):
-            raise NotImplementedError("only the 3x3 stride-2 causal Conv2dSubsampling of small.yml.j2:26-33 is supported")
-        norms = [str(n) for n in sub.get("norms", ["batch", "batch"])]
+        # A key the mapping omits takes Conv2dSubsampling's OWN default (subsampling.py:163-176: strides [[2, 1], [2, 1]], kernels
+        # [[3, 3], [3, 3]], paddings causal, norms none, activations relu) - which is not the network of small.yml.j2 and is not built, so
+        # an incomplete mapping raises instead of silently becoming BatchNorm + swish.  No `encoder_subsampling` at all (the
+        # reference's constructor requires one, models/transducer/conformer.py:28): the shipped small.yml.j2 block.
+        ref_def = dict(kernels=[[3, 3], [3, 3]], strides=[[2, 1], [2, 1]], paddings=["causal", "causal"], norms=["none", "none"],
+                       activations=["relu", "relu"])
+        yml_def = dict(kernels=[3, 3], strides=[2, 2], paddings=["causal", "causal"], norms=["batch", "batch"], activations=["swish", "swish"])
+        getd = (lambda k: sub.get(k, ref_def[k])) if sub else (lambda k: yml_def[k])
+
+        def _pairs(v):  # [3, 3] (both layers 3 -> keras broadcasts an int to both axes) and [[3, 3], [3, 3]] describe the same convolutions
+            return [list(x) if isinstance(x, (list, tuple)) else [x, x] for x in v]
+
+        if _pairs(getd("kernels")) != [[3, 3], [3, 3]] or _pairs(getd("strides")) != [[2, 2], [2, 2]]:
+            raise NotImplementedError(f"encoder_subsampling kernels={getd('kernels')} strides={getd('strides')}: only the 3x3 stride-2 causal "
+                                      f"Conv2dSubsampling of small.yml.j2:26-33 is supported")
+        norms = [str(n) for n in getd("norms")]
         if norms not in (["batch", "batch"], ["layer", "layer"]):
             raise NotImplementedError(f"encoder_subsampling.norms={norms}: both blocks 'batch' (small.yml.j2:31) or both 'layer' "
                                       f"(small-streaming.yml.j2) are built (subsampling.py:197-213)")
-        if [str(a) for a in sub.get("activations", ["swish", "swish"])] not in (["swish", "swish"], ["silu", "silu"]):
-            raise NotImplementedError(f"encoder_subsampling.activations={sub.get('activations')}: only swish (small.yml.j2:32)")
-        if [str(a) for a in sub.get("paddings", ["causal", "causal"])] != ["causal", "causal"]:
-            raise NotImplementedError(f"encoder_subsampling.paddings={sub.get('paddings')}: only causal (small.yml.j2:30)")
+        if [str(a) for a in getd("activations")] not in (["swish", "swish"], ["silu", "silu"]):
+            raise NotImplementedError(f"encoder_subsampling.activations={getd('activations')}: only swish (small.yml.j2:32)")
+        if [str(a) for a in getd("paddings")] != ["causal", "causal"]:
+            raise NotImplementedError(f"encoder_subsampling.paddings={getd('paddings')}: only causal (small.yml.j2:30)")
         reg = c.get("kernel_regularizer") or {}
         l2 = float((reg.get("config") or {}).get("l2", 1e-6)) if isinstance(reg, dict) else 1e-6
         kw = dict(

@@ -859,10 +859,13 @@ class ConformerTransducer(BaseModel):
         io.defer_pos_grad, io.ln_part_ext, io.ln_part_ext_floats, io.dcv_keep, io.ds_keep, io.qv_keep = 0, None, 0, None, None, None
         hb = self._hoisted.get("bwd")
         aux_dpext = None
+        dcv = None
         if hb is not None:
+            # REQUESTS: whether the executor honours them depends on its own route (attention kernels, storage type, TFASR_BLOCK_FUSE /
+            # TFASR_ATTN_DPOS): what it actually left to us is read back from tfasr_block_bwd_left after the call (the two sides
+            # used to decide separately, and a disagreement ran tfasr_relattn_dpext on uninitialised buffers)
             if io.dpext_zero:
                 io.defer_pos_grad = 1
-                hb["pos"].append(i)
                 if self.dpext_aux and cfgk.dh == 64:
                     Tp = -(-cfgk.T // 8) * 8
                     ds = torch.empty(cfgk.B, cfgk.H, cfgk.T, Tp, dtype=self.dtype, device=self.device)
@@ -872,11 +875,9 @@ class ConformerTransducer(BaseModel):
             if hb["ln_part"] is not None:
                 io.ln_part_ext = hb["ln_part"][i].data_ptr()
                 io.ln_part_ext_floats = hb["ln_part"].shape[1]
-                hb["ctx"].append(cbuf)
             if not cfgk.dw_norm_layer:
                 dcv = torch.empty(cfgk.B * cfgk.T, d, dtype=self.dtype, device=self.device)
                 io.dcv_keep = dcv.data_ptr()
-                hb["dw"].append((cfgk, P, cbuf, dcv, s["keep"]))  # (the stash holds the other operand: alive until the batched launch)
         # grouped weight gradients of this block on the executor's second stream, beside the next block's backward: two arenas, alternating
         slot = 0
         if self._auto(self.wgrad_stream) and self.dtype == torch.bfloat16:
@@ -897,7 +898,15 @@ class ConformerTransducer(BaseModel):
             K.block_bwd(cfgk, P, io, cbuf, K._lib.PHASE_B)
         else:
             K.block_bwd(cfgk, P, io, cbuf, K._lib.PHASE_A | K._lib.PHASE_B)
-        if aux_dpext is not None:
+        left = K.block_bwd_left(cbuf) if hb is not None else 0
+        if hb is not None:
+            if left & 4:
+                hb["pos"].append(i)
+            if left & 8:
+                hb["ctx"].append(cbuf)
+            if left & 2:
+                hb["dw"].append((cfgk, P, cbuf, dcv, s["keep"]))  # (the stash holds the other operand: alive until the batched launch)
+        if aux_dpext is not None and (left & 1):
             # the positional table's gradient of this block on the auxiliary stream, beside the next block's backward
             ds, qv, dpext, elen_dev = aux_dpext
             main = torch.cuda.current_stream()

@@ -12,3 +12,6 @@ extern "C" const char* tfasr_status_string(int status) {
 }
 
 extern "C" int tfasr_abi_version(void) { return TFASR_ABI_VERSION; }
+
+size_t g_tfasr_launch_count = 0;
+extern "C" size_t tfasr_launch_count(void) { return g_tfasr_launch_count; }

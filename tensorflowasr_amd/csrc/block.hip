@@ -55,6 +55,10 @@ struct Ctx {
   int ln_nblk, ln_nsets;
   bool ln_ext;  // ln_part is the caller's buffer (tfasr_block_io.ln_part_ext): the fold is tfasr_block_ln_fold_all's
   float *ln_dg[8], *ln_db[8];
+  // what the last backward call LEFT TO THE CALLER (tfasr_block_bwd_left): bit 0 = the table gradient from dS (io->ds_keep / qv_keep are
+  // filled, tfasr_relattn_dpext not launched), bit 1 = the depthwise weight gradient (io->dcv_keep), bit 2 = the positional-projection
+  // gradients (defer_pos_grad honoured), bit 3 = the LayerNorm fold (ln_part_ext)
+  int left;
 };
 
 // one GEMM launch description (defaults = plain product)
@@ -83,6 +87,11 @@ struct Side {
   hipEvent_t wfork = nullptr, wdone[2] = {nullptr, nullptr};
   bool wpending[2] = {false, false};
   bool wok = false, wtried = false;
+  // probe (tfasr_block_wgrad_probe): HIP events around every grouped weight-gradient launch ON THE STREAM IT RUNS ON, so that bench.py can
+  // report the group's duration inside the step (beside the next block's chain), not only in an isolated loop
+  bool probe = false;
+  std::vector<hipEvent_t> pev;  // pairs (before, after)
+  size_t pused = 0;
 };
 Side& side_for_device() {
   static Side sides[64];
@@ -107,6 +116,7 @@ bool wgrad_stream_ready(Side& sd) {
     sd.wtried = true;
     int least = 0, greatest = 0;  // lowest priority: the group only fills what the main chain leaves idle
     if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = 0;
+    if (getenv("TFASR_WGRAD_STREAM_PRIO") && getenv("TFASR_WGRAD_STREAM_PRIO")[0] == '0') least = 0;  // (A/B: default priority)
     sd.wok = hipStreamCreateWithPriority(&sd.sw, hipStreamNonBlocking, least) == hipSuccess &&
              hipEventCreateWithFlags(&sd.wfork, hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&sd.wdone[0], hipEventDisableTiming) == hipSuccess &&
@@ -189,6 +199,15 @@ struct Ex {
     }
     chk(tfasr_gemm(&a, s));
   }
+  void probe_mark(hipStream_t st_) {
+    if (!side || !side->probe) return;
+    if (side->pused == side->pev.size()) {
+      hipEvent_t e = nullptr;
+      if (hipEventCreate(&e) != hipSuccess) { side->probe = false; return; }
+      side->pev.push_back(e);
+    }
+    if (hipEventRecord(side->pev[side->pused++], st_) != hipSuccess) chk(TFASR_STATUS_EXECUTION_FAILED);
+  }
   void flush_wgrads() {
     if (pending.empty()) return;
     const int slot = io->wgrad_slot;
@@ -197,12 +216,16 @@ struct Ex {
       // for it until the slot's arena is reused or the caller joins
       if (hipEventRecord(side->wfork, s) != hipSuccess || hipStreamWaitEvent(side->sw, side->wfork, 0) != hipSuccess) chk(TFASR_STATUS_EXECUTION_FAILED);
       g_tfasr_group_beside = 1;  // (one workgroup per CU: the group shares the chip with the next block's chain)
+      probe_mark(side->sw);
       chk(tfasr_gemm_group(pending.data(), (int)pending.size(), side->sw));
+      probe_mark(side->sw);
       g_tfasr_group_beside = 0;
       if (hipEventRecord(side->wdone[slot - 1], side->sw) != hipSuccess) chk(TFASR_STATUS_EXECUTION_FAILED);
       side->wpending[slot - 1] = true;
     } else {
+      probe_mark(s);
       chk(tfasr_gemm_group(pending.data(), (int)pending.size(), s));
+      probe_mark(s);
     }
     pending.clear();
   }
@@ -460,6 +483,7 @@ struct Ex {
     // the next block's backward): the table gradient is only needed by the deferred positional-projection gradients
     const bool dpext_deferred = !dry && v2 && io->defer_pos_grad && io->dpext_zero && io->ds_keep && io->qv_keep && block_fuse();
     if (dpext_deferred) dpos = io->ds_keep;
+    if (!dry && dpext_deferred) k->left |= 1;
     const void* qv;
     float tail_scale;
     float* dpext = io->dpext_zero;
@@ -554,6 +578,7 @@ struct Ex {
     // positional projection: gWpos += pe^T dpext ; gbpos += colsum(dpext) - unless the caller takes them for all blocks at once
     // (io->defer_pos_grad: dpext stays in io->dpext_zero; three launches per block leave the chain)
     const bool pos_deferred = io->defer_pos_grad && io->dpext_zero && dpext == io->dpext_zero;
+    if (!dry && pos_deferred) k->left |= 4;
     const void* dpext_t = dpext;
     if (c->dtype != TFASR_F32) {
       void* t = act(scratch, (long)R1 * HD);  // (allocated either way: the arena layout does not depend on the option)
@@ -649,7 +674,7 @@ struct Ex {
     // caller-owned buffer for the depthwise conv's output gradient: it outlives this call, and the depthwise WEIGHT gradient (two launches
     // that nothing on the chain waits for) is left to tfasr_block_dwconv_wgrad_all - one launch pair for all blocks of the step
     const bool dw_deferred = !dry && io->dcv_keep && !c->dw_norm_layer && c->dtype == TFASR_BF16;
-    if (dw_deferred) dcv = io->dcv_keep;
+    if (dw_deferred) { dcv = io->dcv_keep; k->left |= 2; }
     void* dg = act(scratch, rows * d);
     void* da = act(scratch, rows * 2 * d);
     void* dln = act(scratch, rows * d);
@@ -734,6 +759,7 @@ struct Ex {
         // caller-owned buffer: the sums outlive this call and tfasr_block_ln_fold_all folds every block of the step in one launch
         k->ln_ext = !dry && k->ln_part && io->ln_part_ext && io->ln_part_ext_floats >= (size_t)8 * nblk * 2 * d;
         if (k->ln_ext) k->ln_part = io->ln_part_ext;
+        if (!dry) k->left = k->ln_ext ? 8 : 0;  // (first statement of a backward that touches it: the other bits are set by the modules)
       }
       ln_bwd(io->dy, k->ln_x, TFASR_BP_LN_G, TFASR_BP_LN_B, k->ln_mean, k->ln_rstd, nullptr, k->bw_cur, k->bw_curd, 5);
       if (!ffm_bwd_fused(1, k->bw_cur, k->bw_curd, k->bw_nxt, k->bw_nxtd, 4, 3)) ffm_bwd(1, k->bw_cur, k->bw_curd, k->bw_nxt, k->bw_nxtd, 4, 3);
@@ -827,6 +853,32 @@ extern "C" int tfasr_block_fwd(const tfasr_block_cfg* c, const tfasr_block_param
   if (!e.stash.ok || !e.scratch.ok) return TFASR_STATUS_INVALID_VALUE;  // arena too small
   return e.st;
 }
+
+extern "C" int tfasr_block_wgrad_probe(int enable) {
+  Side& sd = side_for_device();
+  sd.probe = enable != 0;
+  sd.pused = 0;
+  return TFASR_STATUS_SUCCESS;
+}
+
+extern "C" int tfasr_block_wgrad_probe_read(float* total_ms, int* launches) {
+  if (!total_ms || !launches) return TFASR_STATUS_INVALID_VALUE;
+  Side& sd = side_for_device();
+  double tot = 0.0;
+  int n = 0;
+  for (size_t i = 0; i + 1 < sd.pused; i += 2) {
+    float ms = 0.f;
+    if (hipEventSynchronize(sd.pev[i + 1]) != hipSuccess || hipEventElapsedTime(&ms, sd.pev[i], sd.pev[i + 1]) != hipSuccess) return TFASR_STATUS_EXECUTION_FAILED;
+    tot += ms;
+    ++n;
+  }
+  *total_ms = (float)tot;
+  *launches = n;
+  sd.pused = 0;
+  return TFASR_STATUS_SUCCESS;
+}
+
+extern "C" int tfasr_block_bwd_left(const void* ctx) { return ctx ? ((const Ctx*)ctx)->left : 0; }
 
 extern "C" int tfasr_block_wgrad_join(int slot_mask, void* stream) {
   return wgrad_wait(side_for_device(), slot_mask, (hipStream_t)stream);

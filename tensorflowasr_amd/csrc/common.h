@@ -9,6 +9,12 @@
 
 #define TFASR_WAVE 64
 
+// Every kernel of the library is launched through hipLaunchKernelGGL: count the launches (host-side statistic behind tfasr_launch_count(),
+// what bench.py reports as `launches_per_step`; a kernel boundary costs 2.65 us on this chip, so the count is a quantity to watch).
+extern "C" size_t g_tfasr_launch_count;  // api.hip
+#undef hipLaunchKernelGGL
+#define hipLaunchKernelGGL(kernelName, ...) do { ++g_tfasr_launch_count; hipLaunchKernelGGLInternal((kernelName), __VA_ARGS__); } while (0)
+
 typedef uint16_t bf16_t;  // raw bfloat16 bits
 
 typedef __attribute__((ext_vector_type(8))) short short8_t;

@@ -368,18 +368,29 @@ bool persist_ok(int B, int P, int dtype) { return dtype == TFASR_BF16 && B >= 1 
 
 // The workgroups of a launch wait for each other, so ALL of them must be resident at once (an ordinary launch gives no such promise):
 // the launch is refused (UNSUPPORTED -> the caller's per-step kernels) unless resident-blocks-per-CU x CUs covers the grid.
+// NECESSARY, NOT SUFFICIENT: the occupancy query knows nothing about kernels of OTHER streams that hold CUs when the launch starts (the
+// encoder beside the prediction network); a workgroup that is not scheduled in time is caught by the kernels' wall-clock bound and abort
+// flag (results poisoned, `sync` word 1 set), never by a hang.
+// The answer depends on the kernel INSTANCE (the MT variants differ in registers, hence in blocks per CU), the device, the LDS size and the
+// grid: a small per-thread table keyed on all four (the function-pointer type is the same for every MT, so a function-local static would
+// be ONE entry shared by all instantiations - ADVICE r04).
 template <typename KERNEL>
 bool grid_fits(KERNEL kernel, int grid, size_t smem) {
-  static thread_local size_t c_smem = ~(size_t)0;  // one query per (kernel instance, LDS size) and thread, not per launch
-  static thread_local int c_grid = 0, c_ok = 0;
-  if (c_smem == smem && c_grid == grid) return c_ok != 0;
-  c_smem = smem; c_grid = grid; c_ok = 0;
-  int dev = 0, cus = 0, per_cu = 0;
+  struct Entry { const void* fn; int dev; size_t smem; int grid; int ok; };
+  static thread_local Entry cache[16];
+  static thread_local int used = 0;
+  int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return false;
+  const void* fn = reinterpret_cast<const void*>(kernel);
+  for (int i = 0; i < used; ++i)
+    if (cache[i].fn == fn && cache[i].dev == dev && cache[i].smem == smem && cache[i].grid == grid) return cache[i].ok != 0;
+  int cus = 0, per_cu = 0;
   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, smem) != hipSuccess) return false;
-  c_ok = (long)per_cu * cus >= grid ? 1 : 0;
-  return c_ok != 0;
+  const int ok = (long)per_cu * cus >= grid ? 1 : 0;
+  Entry& e = cache[used < 16 ? used++ : (used = 1, 0)];  // (full: start over - 16 distinct launch shapes per thread do not occur in one model)
+  e.fn = fn; e.dev = dev; e.smem = smem; e.grid = grid; e.ok = ok;
+  return ok != 0;
 }
 
 }  // namespace

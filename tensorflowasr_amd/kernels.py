@@ -349,8 +349,12 @@ def cast(src, dst):
 
 def cast_colsum_many(x, y, stride, nmat, rows, C, colsums):
     """f32 matrices x + b*stride [rows, C] -> bf16 copies in y (same strides) and colsums[b] += their f32 column sums (one launch)."""
-    arr = (ctypes.c_void_p * nmat)(*[(t.data_ptr() if t is not None else None) for t in colsums])
-    check(_L().tfasr_cast_colsum_many(_pv(x), _pv(y), int(stride), int(nmat), int(rows), int(C), arr, _stream()), "cast_colsum_many")
+    # (the kernel takes its pointer table as an argument: at most 64 matrices per launch - a model with more blocks takes several)
+    for b0 in range(0, int(nmat), 64):
+        n = min(64, int(nmat) - b0)
+        arr = (ctypes.c_void_p * n)(*[(t.data_ptr() if t is not None else None) for t in colsums[b0:b0 + n]])
+        check(_L().tfasr_cast_colsum_many(x.data_ptr() + b0 * int(stride) * x.element_size(), y.data_ptr() + b0 * int(stride) * y.element_size(),
+                                          int(stride), n, int(rows), int(C), arr, _stream()), "cast_colsum_many")
     return y
 
 
@@ -893,6 +897,27 @@ def block_bwd(cfg, params, io, ctx, phase):
     check(_L().tfasr_block_bwd(ctypes.byref(cfg), ctypes.byref(params), ctypes.byref(io), ctx, phase, _stream()), "block_bwd")
 
 
+def launch_count():
+    """kernel launches the library has queued since it was loaded (tfasr_launch_count)"""
+    return int(_L().tfasr_launch_count())
+
+
+def block_wgrad_probe(enable):
+    check(_L().tfasr_block_wgrad_probe(int(bool(enable))), "block_wgrad_probe")
+
+
+def block_wgrad_probe_read():
+    """(summed milliseconds, launches) of the grouped weight-gradient launches recorded since the probe was enabled / last read"""
+    ms, n = ctypes.c_float(0.0), ctypes.c_int(0)
+    check(_L().tfasr_block_wgrad_probe_read(ctypes.byref(ms), ctypes.byref(n)), "block_wgrad_probe_read")
+    return float(ms.value), int(n.value)
+
+
+def block_bwd_left(ctx):
+    """bit mask of what the last block_bwd with this ctx left to the caller (tfasr_block_bwd_left)"""
+    return int(_L().tfasr_block_bwd_left(ctx))
+
+
 def block_wgrad_join(slot_mask=3):
     """The current stream waits for the grouped weight-gradient launches queued on the executor's second stream (tfasr_block_io.wgrad_slot)."""
     check(_L().tfasr_block_wgrad_join(int(slot_mask), _stream()), "block_wgrad_join")
@@ -906,14 +931,15 @@ def block_ln_fold_all(ctxs, d):
 
 def block_dwconv_wgrad_all(cfg, params, ctxs, dcvs, device):
     """Depthwise-conv weight / bias gradients of every block whose backward ran with io.dcv_keep: one launch pair (tfasr_block_dwconv_wgrad_all)."""
-    n = len(ctxs)
     need = ctypes.c_size_t(0)
     check(_L().tfasr_dwconv_bwd_weight_workspace_size(cfg.B, cfg.T, cfg.d, cfg.ksize, ctypes.byref(need)), "dwconv_bwd_weight_workspace_size")
-    ws = workspace(n * need.value, device, "dw_wgrad_all")
-    pa = (ctypes.c_void_p * n)(*[ctypes.addressof(p) for p in params])
-    ca = (ctypes.c_void_p * n)(*[ctypes.addressof(c) for c in ctxs])
-    da = (ctypes.c_void_p * n)(*[t.data_ptr() for t in dcvs])
-    check(_L().tfasr_block_dwconv_wgrad_all(ctypes.byref(cfg), pa, ca, da, n, _p(ws), ws.numel(), _stream()), "block_dwconv_wgrad_all")
+    for b0 in range(0, len(ctxs), 32):  # (at most 32 blocks per launch pair: deeper encoders take several)
+        n = min(32, len(ctxs) - b0)
+        ws = workspace(n * need.value, device, "dw_wgrad_all")
+        pa = (ctypes.c_void_p * n)(*[ctypes.addressof(p) for p in params[b0:b0 + n]])
+        ca = (ctypes.c_void_p * n)(*[ctypes.addressof(c) for c in ctxs[b0:b0 + n]])
+        da = (ctypes.c_void_p * n)(*[t.data_ptr() for t in dcvs[b0:b0 + n]])
+        check(_L().tfasr_block_dwconv_wgrad_all(ctypes.byref(cfg), pa, ca, da, n, _p(ws), ws.numel(), _stream()), "block_dwconv_wgrad_all")
 
 
 def layernorm_bwd_part_blocks(rows, C, dtype):

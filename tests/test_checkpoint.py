@@ -268,10 +268,12 @@ def test_training_state_round_trip(tmp_path):
     for _ in range(3):
         a.train_step(data)
     p = tmp_path / "state.npz"
+    a._gradn_epoch, a._gwn_epoch = 7, 5  # (counters behind the gradient / weight noise seeds: part of the state)
     ck.save_state(a, str(p))
     b = ConformerTransducer(cfg, dev, dtype=a.dtype, seed=99)
     ck.load_state(b, str(p))
     assert b.step == a.step == 3 and b._drop_epoch == a._drop_epoch
+    assert (b._gradn_epoch, b._gwn_epoch) == (7, 5)
     for name in ("flat", "adam_m", "adam_v", "shadow"):
         assert torch.equal(getattr(a.ps, name), getattr(b.ps, name)), name
     la = a.train_step(data, masks=(None, None))["loss"]

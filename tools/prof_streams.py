@@ -38,6 +38,32 @@ def main():
         names = ", ".join(f"{n} {t / 1e6:.2f} ms" for n, t in top.most_common(3))
         print(f"  queue {q}: {len(ks)} kernels, busy {busy / 1e6:.2f} ms ({100.0 * busy / span:.0f} % of the span), "
               f"{100.0 * ov / max(busy, 1):.0f} % of it beside queue {main_q}'s kernels | {names}")
+    # where the busiest queue WAITS: its idle gaps by (kernel before -> kernel after), and what the other queues ran inside the largest ones
+    def nm(x):
+        import re
+        return re.sub(r"\(anonymous namespace\)::", "", x).split("(")[0].replace("void ", "")[:48]
+    mk = sorted(by_q[main_q])
+    gaps = [(mk[i + 1][0] - mk[i][1], i) for i in range(len(mk) - 1) if mk[i + 1][0] > mk[i][1]]
+    tot = sum(g for g, _ in gaps)
+    print(f"queue {main_q} idle {tot / 1e6:.2f} ms in {len(gaps)} gaps; by (before -> after), gaps >= 20 us:")
+    agg = collections.defaultdict(lambda: [0, 0])
+    for g, i in gaps:
+        if g >= 20000:
+            k = nm(mk[i][2]) + " -> " + nm(mk[i + 1][2])
+            agg[k][0] += g
+            agg[k][1] += 1
+    for k, (t, n) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:14]:
+        print(f"   {t / 1e3:9.1f} us in {n:3d} gaps (avg {t / n / 1e3:7.1f})  {k}")
+    others = sorted((s, e, n, q) for q, ks in by_q.items() if q != main_q for s, e, n in ks)
+    for g, i in sorted(gaps, reverse=True)[:4]:
+        lo, hi = mk[i][1], mk[i + 1][0]
+        inside = [(s, e, n, q) for s, e, n, q in others if e > lo and s < hi]
+        print(f"--- {g / 1e3:.1f} us gap after {nm(mk[i][2])} before {nm(mk[i + 1][2])}: {len(inside)} kernels of other queues inside")
+        for s, e, n, q in inside[:3] + ([("...",) * 4] if len(inside) > 6 else []) + inside[-3:] if len(inside) > 6 else inside:
+            if s == "...":
+                print("      ...")
+            else:
+                print(f"      q{q} +{(s - lo) / 1e3:8.1f} us .. +{(e - lo) / 1e3:8.1f} us  {nm(n)}")
 
 
 if __name__ == "__main__":
