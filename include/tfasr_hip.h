@@ -417,6 +417,14 @@ int tfasr_lstm_seq_fwd(const void* xg, const void* rk, const void* h0, long h0_s
                        int dtype, void* stream);
 int tfasr_lstm_seq_bwd(const void* dy, const void* rk, const void* gates, const float* cseq, const int32_t* lengths, void* dz,
                        float* dh_carry, float* dc_carry, float* dhr, int B, int U1, int P, int dtype, void* stream);
+/* Steps [t0, t1) of the same recurrences with the per-step kernels only (never the persistent launch), so that a caller can queue the
+   chain in slices between other work: forward slices in ascending order, backward slices in DESCENDING order ([t, U1) first); the
+   buffers - including the carries - are those of the whole-sequence calls and live across the slices. */
+int tfasr_lstm_seq_fwd_range(const void* xg, const void* rk, const void* h0, long h0_stride_b, const float* c0, long c0_stride_b,
+                             const int32_t* lengths, void* gates, float* cseq, void* hseq, void* yseq, float* hr, int B, int U1, int P,
+                             int dtype, int t0, int t1, void* stream);
+int tfasr_lstm_seq_bwd_range(const void* dy, const void* rk, const void* gates, const float* cseq, const int32_t* lengths, void* dz,
+                             float* dh_carry, float* dc_carry, float* dhr, int B, int U1, int P, int dtype, int t0, int t1, void* stream);
 /* The whole recurrence of one direction as ONE persistent launch (csrc/lstm_persist.hip): workgroup j keeps the recurrent
  * weights of 16 hidden units in registers for the whole sequence, the per-step exchange of h_t (forward) / dz_t (backward) between
  * the workgroups goes through the sequence buffers themselves with write-through stores, one device-scope arrival counter and one
@@ -670,6 +678,11 @@ int tfasr_block_bwd(const tfasr_block_cfg* cfg, const tfasr_block_params* params
    bit 1: the depthwise-conv weight gradient (dcv_keep is filled), bit 2: the positional-projection gradients (defer_pos_grad),
    bit 3: the LayerNorm gamma / beta fold (ln_part_ext).  A bit that is clear means the block did that work in line. */
 int tfasr_block_bwd_left(const void* ctx);
+/* The executor's second stream of the current device (lowest priority, non-blocking; created on first use): where a block's grouped
+   weight gradients run with wgrad_slot != 0.  A caller with off-chain work of its own (positional tables ahead of the chain, table
+   gradients beside the next block) can queue it THERE instead of on one more stream of its own: every additional HIP stream is one more
+   hardware queue, and on this chip the step time depends on how many are live (38 instead of 23 ms with eight). */
+int tfasr_block_side_stream(void** stream);
 /* Measurement probe: while enabled, tfasr_block_bwd brackets every grouped weight-gradient launch with HIP events on the stream that
    launch runs on (its own second stream with wgrad_slot != 0).  _read waits for the recorded launches, returns their summed duration and
    count, and clears the record.  Off by default (two event records per block). */

@@ -75,7 +75,13 @@ class ConformerTransducer(BaseModel):
         # SpecAugment draws and dropout masks are per replica (MirroredStrategy draws independent randomness on every
         # replica); the parameter initialisation seed above is shared by all ranks
         self._rng = np.random.default_rng([seed + 1000, int(self.dp.rank)])
-        self.pred_stream = torch.cuda.Stream(device=self.device)
+        # Streams = hardware queues, and on this chip the step time depends on how many are live (with eight queues a
+        # data-parallel rank ran 38 instead of 23 ms).  HIP never lets streams of DIFFERENT priority share a queue, so the three streams of the
+        # step sit on three priority levels - the encoder chain on the default stream, the prediction network (hundreds of tiny launches the
+        # joint network waits for) on a HIGH-priority stream, everything nothing on the chain waits for on the executor's LOW-priority stream -
+        # which keeps them on separate queues whatever GPU_MAX_HW_QUEUES is and whatever streams RCCL adds.  TFASR_PRED_PRIO=0: default priority.
+        prio = -1 if os.environ.get("TFASR_PRED_PRIO", "-1") != "0" else 0
+        self.pred_stream = torch.cuda.Stream(device=self.device, priority=prio)
         self.use_pred_stream = os.environ.get("TFASR_NO_PRED_STREAM", "0") != "1"
         # probe (bench.py --dp-hooks): take the world > 1 route of the block executor - two phases per block and direction around the sync-BN
         # all-reduce - with a one-rank group, so everything of a multi-GPU step except the wire time can be measured on one GPU
@@ -95,26 +101,34 @@ class ConformerTransducer(BaseModel):
         # backward.  Round 2 measured it SLOWER (29.06 vs 28.45 ms/step: the 512-workgroup group launch took CUs from the dependent chain);
         # with the round-4 chain (fused FFModule forward, one-tile GEMMs, hoisted launches) it is FASTER: 22.18 vs 22.45 ms/step, same box,
         # three interleaved pairs - the chain's kernels now leave more of the chip idle than the group takes.  TFASR_WGRAD_STREAM=0: in line.
-        # ONE GPU only by default: with a process group (bench.py --dp-hooks, one rank) the second stream TOGETHER with the auxiliary stream
-        # of the hoists below made the step 38 instead of 22.7 ms (either alone: 22.8 / 22.7) - not understood yet (RCCL's streams, the
-        # prediction network's stream, these two and the main stream share the hardware queues), so a data-parallel rank keeps the step it
-        # has been measured with since round 3: weight gradients in line, no hoists.  TFASR_WGRAD_STREAM=1 / TFASR_BLOCK_HOIST=1 force them.
+        # Round 4 kept this to ONE GPU: with a process group the second stream TOGETHER with the auxiliary stream of the hoists below made the
+        # step 38 instead of 22.7 ms.  Round 5 found the cause - the number of live hardware queues (GPU_MAX_HW_QUEUES 2 / 3 / 6: 23.1 ms,
+        # 8 / 12: 39 ms, profiles/r05_dp_queue_sweep.txt) - and merged the two into one low-priority stream: a data-parallel rank runs it too.
         self.wgrad_stream = {"0": False, "1": True}.get(os.environ.get("TFASR_WGRAD_STREAM"), None)
         self._wgrad_keep = []
         self._blk_params, self._blk_sizes = {}, {}
         self._zero_pool = {}
         # Launches that do not belong to the blocks' dependent chain leave it (a kernel boundary costs 2.65 us on this chip, tools/hwprobe/
         # anyorder_test, and hipExtAnyOrderLaunch is a no-op on gfx9): every block's positional projection pe @ Wpos + bpos is computed on a
-        # third stream while the subsampling runs (tfasr_block_io.pext_pre), and on ONE GPU the projections' gradients and the LayerNorm
-        # gamma / beta folds of all blocks run once after the last block's backward (defer_pos_grad, ln_part_ext) - with a data-parallel
-        # group a block's gradient slice has to be final when its bucket is released, so the per-block launches stay.  TFASR_BLOCK_HOIST=0: off.
-        self.block_hoist = {"0": False, "1": True}.get(os.environ.get("TFASR_BLOCK_HOIST"), None)  # None: on for one GPU, off in a process group
+        # third stream while the subsampling runs (tfasr_block_io.pext_pre), and the projections' gradients and the LayerNorm gamma / beta
+        # folds of all blocks run once after the last block's backward (defer_pos_grad, ln_part_ext).  With a data-parallel group a block's
+        # gradient bucket is released right behind the block: the deferred variables therefore live in a region of their own behind the last
+        # block (ParamStore.defer_lo / defer_hi), released after the deferred launches.  TFASR_BLOCK_HOIST=0: off.
+        self.block_hoist = {"0": False, "1": True}.get(os.environ.get("TFASR_BLOCK_HOIST"), None)  # None: on
         # ... and with the gradients deferred, the kernel that accumulates a block's table gradient from dS (tfasr_relattn_dpext, 37 us per
         # block, only the deferred products wait for it) runs on the auxiliary stream beside the next block's backward.  TFASR_DPEXT_AUX=0: in line.
         self.dpext_aux = os.environ.get("TFASR_DPEXT_AUX", "1") != "0"
         self.joint_wgrad_aux = os.environ.get("TFASR_JOINT_WGRAD_AUX", "0") == "1"  # (A/B: the vocabulary weight gradient on the auxiliary stream)
         self._aux_pending = False
-        self.aux_stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
+        # the auxiliary stream IS the block executor's second stream (one queue for the grouped weight gradients, the positional tables ahead
+        # of the chain and the table gradients beside the next block); TFASR_ONE_SIDE_STREAM=0: a stream of its own (A/B)
+        if self.device.type != "cuda":
+            self.aux_stream = None
+        elif os.environ.get("TFASR_ONE_SIDE_STREAM", "1") != "0":
+            with torch.cuda.device(self.device):
+                self.aux_stream = torch.cuda.ExternalStream(K.block_side_stream(), device=self.device)
+        else:
+            self.aux_stream = torch.cuda.Stream(device=self.device)
         self._hoisted = {}
         self.fuse_joint_stats = os.environ.get("TFASR_JOINT_STATS", "1") != "0"
         # Joint + loss WITHOUT materialised lattice logits (SURVEY section 7 step 8 / 8(d) "report both"): the projection emits only the
@@ -946,13 +960,16 @@ class ConformerTransducer(BaseModel):
                 self._zero_pool["bwd_shape"] = (c.num_blocks, -(-2 * c.dmodel // 64) * 64 + -(-2 * T * c.num_heads * self.ps.head_phys // 64) * 64)
         for i in range(self.cfg.num_blocks):
             x = self._block_fwd_native(x, i, B, T, elen_dev, training, ctx) if native else self._block_fwd(x, i, B, T, elen_dev, training, ctx)
+            self._side_tick()  # (a slice of the prediction network on its own stream, if one is pending)
         if ctx is not None:
             ctx["enc"] = dict(B=B, T=T, elen_dev=elen_dev, hoist=hoist)
         return x, T, elen, elen_dev
 
     def _auto(self, switch):
-        """a tri-state option (None = automatic): on for one GPU, off inside a process group"""
-        return isinstance(self.dp, SingleProcess) if switch is None else bool(switch)
+        """a tri-state option (None = automatic).  Rounds 3-4 switched the hoists and the weight-gradient stream OFF inside a process group;
+        since round 5 a data-parallel rank runs the same step as one GPU (deferred gradients in a slice of their own, ParamStore.defer_lo /
+        defer_hi; three streams on three priority levels), so automatic = on."""
+        return True if switch is None else bool(switch)
 
     def _pext_ahead(self, T):
         """Every block's projected relative-position table pe @ Wpos + bpos [2T', H*dh] on the auxiliary stream, beside the subsampling:
@@ -975,10 +992,9 @@ class ConformerTransducer(BaseModel):
         e = ctx["enc"]
         if "bwd_shape" in self._zero_pool:
             self._zero_pool["bwd"] = torch.zeros(*self._zero_pool.pop("bwd_shape"), dtype=torch.float32, device=self.device)
-        # one GPU: positional-projection gradients and LayerNorm folds of all blocks after the loop (see __init__); a data-parallel group
-        # releases a block's gradient bucket right behind the block, so there the block finishes them itself
+        # positional-projection gradients, LayerNorm folds and depthwise weight gradients of all blocks after the loop (see __init__)
         self._hoisted["bwd"] = None
-        if e.get("hoist") and isinstance(self.dp, SingleProcess) and self._zero_pool.get("bwd") is not None:
+        if e.get("hoist") and self._zero_pool.get("bwd") is not None:
             c = self.cfg
             nblk = K.layernorm_bwd_part_blocks(e["B"] * e["T"], c.dmodel, self.dtype)
             ln_part = torch.empty(c.num_blocks, 8 * nblk * 2 * c.dmodel, dtype=torch.float32, device=self.device) if nblk > 0 else None
@@ -997,6 +1013,7 @@ class ConformerTransducer(BaseModel):
                     K.block_wgrad_join(1 << (prev[1] - 1))
                 self._bucket_after_block(prev[0])
             prev = (i, self._last_wgrad_slot)
+            self._side_tick()  # (a slice of the prediction network's backward on its own stream, if one is pending)
         if prev is not None:
             if prev[1]:
                 K.block_wgrad_join(3)
@@ -1007,6 +1024,10 @@ class ConformerTransducer(BaseModel):
             if hb.get("aux_used"):
                 torch.cuda.current_stream().wait_stream(self.aux_stream)  # the table gradients accumulated on the auxiliary stream
             self._deferred_block_grads(hb, e["T"])
+        # the blocks' LayerNorm / positional-projection / depthwise-kernel gradients live in ONE region behind the last block (ParamStore):
+        # final now - after the deferred launches, or after block 0's backward when nothing was deferred - and released as one bucket
+        if self.ps.defer_lo is not None:
+            self.dp.grads_ready(self.ps.defer_lo, self.ps.defer_hi)
         t0 = self._tick("subsampling_bwd")
         self._subsampling_bwd(dx, ctx)
         self._tock("subsampling_bwd", t0)
@@ -1044,8 +1065,9 @@ class ConformerTransducer(BaseModel):
             hb["dw"].clear()
 
     def _bucket_after_block(self, i):
-        lo = self.ps.offsets[f"enc/block{i}/ff1/ln/g"]
-        hi = self.ps.offsets[f"enc/block{i + 1}/ff1/ln/g"] if i + 1 < self.cfg.num_blocks else self.ps.offsets[self._after_encoder]
+        """block i's slice of the flat gradient (its Dense / BatchNorm variables: contiguous, ParamStore) is final: release its bucket"""
+        lo = self.ps.offsets[f"enc/block{i}/ff1/d1/w"]
+        hi = self.ps.offsets[f"enc/block{i + 1}/ff1/d1/w"] if i + 1 < self.cfg.num_blocks else self.ps.defer_lo
         self.dp.grads_ready(lo, hi)
 
     # =================================================================================== prediction network
@@ -1073,6 +1095,91 @@ class ConformerTransducer(BaseModel):
         if ctx is not None:
             ctx["pred"] = dict(tokens=tokens_dev, plen=plen_dev, emb=emb, gates=gates, cseq=cseq, hseq=hseq, y2=y2, mean=mean, rstd=rstd, B=B, U1=U1)
         return pred  # [B*U1, P]
+
+    # ---- the prediction network queued in SLICES between the encoder blocks --------------------------------------------------------------
+    # Its recurrence is ~2 x U1 tiny launches per direction on a stream of its own.  Queued in one go (round 1-4) the host blocked in
+    # hipLaunchKernel as soon as that stream's launch queue was full (it holds ~1 ms of work) and could not feed the ENCODER's stream
+    # meanwhile: the rocprofv3 queue view (tools/prof_streams.py, profiles/r05_streams_*.txt) shows the main queue idle for the whole
+    # duration of the prediction network, once per direction.  A slice per encoder block keeps both queues fed.
+    def _pred_nslices(self, U1):
+        n = int(os.environ.get("TFASR_PRED_SLICES", "8"))
+        return max(1, min(n, U1))
+
+    def _prediction_fwd_gen(self, tokens_dev, plen_dev, ctx):
+        """prediction_fwd as a generator: every next() queues one slice (on the current stream); the last one sets self._side_result"""
+        ps, c = self.ps, self.cfg
+        B, U1 = tokens_dev.shape
+        E, P = c.embed_dim, c.rnn_units
+        emb = K.embedding_fwd(tokens_dev, ps.p("pred/emb"), self.dtype).view(B * U1, E)
+        xg = K.matmul(emb, ps.w2d("pred/lstm/k"), bias=ps.p("pred/lstm/b")).view(B, U1, 4 * P)
+        gates = torch.empty(B, U1, 4 * P, dtype=self.dtype, device=self.device)
+        cseq = torch.empty(B, U1, P, dtype=torch.float32, device=self.device)
+        hseq = torch.empty(B, U1, P, dtype=self.dtype, device=self.device)
+        yseq = torch.empty(B, U1, P, dtype=self.dtype, device=self.device)
+        hr = torch.empty(B, 4 * P, dtype=torch.float32, device=self.device)
+        Wrk = ps.w2d("pred/lstm/rk")
+        step = -(-U1 // self._pred_nslices(U1))
+        for t0 in range(0, U1, step):
+            K.lstm_seq_fwd_range(xg, Wrk, None, None, plen_dev, gates, cseq, hseq, yseq, hr, t0, min(U1, t0 + step))
+            if t0 + step < U1:
+                yield
+        y2 = yseq.view(B * U1, P)
+        if c.prediction_layer_norm:
+            pred, mean, rstd = K.layernorm_fwd(y2, ps.p("pred/ln/g"), ps.p("pred/ln/b"))
+        else:
+            pred, mean, rstd = y2, None, None
+        if ctx is not None:
+            ctx["pred"] = dict(tokens=tokens_dev, plen=plen_dev, emb=emb, gates=gates, cseq=cseq, hseq=hseq, y2=y2, mean=mean, rstd=rstd, B=B, U1=U1)
+        self._side_result = pred
+
+    def _prediction_bwd_gen(self, dpred, ctx):
+        """prediction_bwd as a generator (slices of the backward recurrence in descending time order, then the weight gradients)"""
+        ps, c = self.ps, self.cfg
+        s = ctx["pred"]
+        B, U1 = s["B"], s["U1"]
+        E, P = c.embed_dim, c.rnn_units
+        if c.prediction_layer_norm:
+            dy = K.layernorm_bwd(dpred, s["y2"], ps.p("pred/ln/g"), s["mean"], s["rstd"], ps.g("pred/ln/g"), ps.g("pred/ln/b")).view(B, U1, P)
+        else:
+            dy = dpred.view(B, U1, P)
+        dy = dy.contiguous()
+        dz = torch.empty(B, U1, 4 * P, dtype=self.dtype, device=self.device)
+        dh_carry = torch.zeros(B, P, dtype=torch.float32, device=self.device)
+        dc_carry = torch.zeros(B, P, dtype=torch.float32, device=self.device)
+        dhr = torch.empty(B, P, dtype=torch.float32, device=self.device)
+        Wrk = ps.w2d("pred/lstm/rk")
+        step = -(-U1 // self._pred_nslices(U1))
+        t1 = U1
+        while t1 > 0:
+            t0 = max(0, t1 - step)
+            K.lstm_seq_bwd_range(dy, Wrk, s["gates"], s["cseq"], s["plen"], dz, dh_carry, dc_carry, dhr, t0, t1)
+            t1 = t0
+            yield
+        dz2 = dz.view(B * U1, 4 * P)
+        if U1 > 1:
+            K.gemm(s["hseq"], dz[:, 1:], ps.g2d("pred/lstm/rk"), P, 4 * P, U1 - 1, P, 4 * P, 4 * P, trans_a=True, nb1=B,
+                   sA=(U1 * P, 0), sB=(U1 * 4 * P, 0), sD=(0, 0), accumulate=True)
+        demb = self._dense_bwd(dz2, s["emb"], "pred/lstm/k", "pred/lstm/b")
+        K.embedding_bwd(s["tokens"], demb, ps.g("pred/emb"))
+
+    def _side_tick(self):
+        """queue the next slice of the prediction network (if one is pending) on its stream"""
+        g = getattr(self, "_side_gen", None)
+        if g is None:
+            return
+        with torch.cuda.stream(self.pred_stream):
+            try:
+                next(g)
+            except StopIteration:
+                self._side_gen = None
+
+    def _side_drain(self):
+        while getattr(self, "_side_gen", None) is not None:
+            self._side_tick()
+
+    def _pred_sliced(self):
+        # the per-step kernels are what the overlapped step runs (see _lstm_persist_auto); a forced persistent launch has nothing to slice
+        return self.use_pred_stream and self._lstm_persist_auto and os.environ.get("TFASR_PRED_SLICES", "8") != "0"
 
     def prediction_bwd(self, dpred, ctx):
         ps, c = self.ps, self.cfg
@@ -1148,15 +1255,25 @@ class ConformerTransducer(BaseModel):
         if training and masks is None:
             masks = self.draw_specaugment([-(-int(n) // self.cfg.frame_step) for n in slen])
         feats, flen = self.frontend(sig, slen, training, masks)
+        self._side_gen = None
         if self.use_pred_stream:
             self.pred_stream.wait_stream(main)
             tokens.record_stream(self.pred_stream)
             plen.record_stream(self.pred_stream)
-            with torch.cuda.stream(self.pred_stream):
-                pred = self.prediction_fwd(tokens, plen, ctx)
-            pred.record_stream(main)
+            if self._pred_sliced():
+                K.lstm_set_persist(0)
+                self._side_gen = self._prediction_fwd_gen(tokens, plen, ctx)
+                self._side_tick()  # embedding, input product and the first slice now; the rest between the encoder blocks
+            else:
+                with torch.cuda.stream(self.pred_stream):
+                    pred = self.prediction_fwd(tokens, plen, ctx)
+                pred.record_stream(main)
         enc, T, elen, elen_dev = self.encoder_fwd(feats, flen, training, ctx)
         if self.use_pred_stream:
+            if self._side_gen is not None or getattr(self, "_side_result", None) is not None:
+                self._side_drain()
+                pred, self._side_result = self._side_result, None
+                pred.record_stream(main)
             main.wait_stream(self.pred_stream)
         else:
             pred = self.prediction_fwd(tokens, plen, ctx)
@@ -1284,15 +1401,22 @@ class ConformerTransducer(BaseModel):
     def _backward_from_joint(self, costs, denc, dpred, ctx):
         main = torch.cuda.current_stream()
         self.dp.grads_ready(self.ps.offsets["joint/enc/w"], self.ps.n_reg)
+        self._side_gen = None
         if self.use_pred_stream:
             self.pred_stream.wait_stream(main)
             dpred.record_stream(self.pred_stream)
-            with torch.cuda.stream(self.pred_stream):
-                self.prediction_bwd(dpred, ctx)
+            if self._pred_sliced():
+                K.lstm_set_persist(0)
+                self._side_gen = self._prediction_bwd_gen(dpred, ctx)
+                self._side_tick()
+            else:
+                with torch.cuda.stream(self.pred_stream):
+                    self.prediction_bwd(dpred, ctx)
         else:
             self.prediction_bwd(dpred, ctx)
         self.encoder_bwd(denc, ctx)
         if self.use_pred_stream:
+            self._side_drain()
             main.wait_stream(self.pred_stream)
         if getattr(self, "_aux_pending", False):
             main.wait_stream(self.aux_stream)

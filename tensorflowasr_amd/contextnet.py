@@ -180,6 +180,7 @@ class ContextNetTransducer(ConformerTransducer):
         lens = [int(n) for n in flen]
         for blk in self.blocks:
             x, T, lens = self._block_fwd_cn(x, blk, B, T, lens, training, ctx)
+            self._side_tick()  # (a slice of the prediction network on its own stream, if one is pending)
         elen_dev = self._h2d(lens)
         if ctx is not None:
             ctx["enc"] = dict(B=B, T=T, elen_dev=elen_dev)
@@ -200,6 +201,7 @@ class ContextNetTransducer(ConformerTransducer):
                 lo = self.ps.offsets[self.blocks[i]["convs"][0][0] + "/dw"]
                 hi = self.ps.offsets[self.blocks[i + 1]["convs"][0][0] + "/dw"] if i + 1 < len(self.blocks) else self.ps.offsets["pred/emb"]
                 self.dp.grads_ready(lo, hi)
+                self._side_tick()
             self._dw_flush()
         finally:
             self._wg_queue = None  # the prediction / joint networks' gradients are issued directly

@@ -854,6 +854,14 @@ extern "C" int tfasr_block_fwd(const tfasr_block_cfg* c, const tfasr_block_param
   return e.st;
 }
 
+extern "C" int tfasr_block_side_stream(void** stream) {
+  if (!stream) return TFASR_STATUS_INVALID_VALUE;
+  Side& sd = side_for_device();
+  if (!wgrad_stream_ready(sd)) return TFASR_STATUS_EXECUTION_FAILED;
+  *stream = (void*)sd.sw;
+  return TFASR_STATUS_SUCCESS;
+}
+
 extern "C" int tfasr_block_wgrad_probe(int enable) {
   Side& sd = side_for_device();
   sd.probe = enable != 0;

@@ -163,18 +163,15 @@ extern "C" int tfasr_lstm_set_persist(int mode) {
   return prev;
 }
 
-extern "C" int tfasr_lstm_seq_fwd(const void* xg, const void* rk, const void* h0, long h0_stride_b, const float* c0, long c0_stride_b,
-                                  const int32_t* lengths, void* gates, float* cseq, void* hseq, void* yseq, float* hr, int B, int U1, int P,
-                                  int dtype, void* stream) {
-  if (!xg || !rk || !gates || !cseq || !hseq || !hr || B <= 0 || U1 <= 0 || P <= 0) return TFASR_STATUS_INVALID_VALUE;
-  // one persistent launch for the whole sequence where the shape allows it (lstm_persist.hip); its 64-byte synchronisation record
-  // lives at the front of the `hr` scratch (B x 4P floats, unused by that path)
-  if (persist_enabled() && (size_t)B * 4 * P * sizeof(float) >= tfasr_lstm_persist_sync_bytes()) {
-    const int st = tfasr_lstm_persist_fwd(xg, rk, h0, h0_stride_b, c0, c0_stride_b, lengths, gates, cseq, hseq, yseq, B, U1, P, dtype, hr, stream);
-    if (st != TFASR_STATUS_UNSUPPORTED) return st;
-  }
+// steps [t0, t1) of the forward recurrence with the per-step kernels (never the persistent launch): what a caller uses to queue the chain
+// in SLICES between other work - the host blocks in hipLaunchKernel once a stream's launch queue holds ~1 ms of work, and while it is
+// blocked on this chain's stream the other streams starve (conformer.py interleaves the slices with the encoder blocks)
+extern "C" int tfasr_lstm_seq_fwd_range(const void* xg, const void* rk, const void* h0, long h0_stride_b, const float* c0, long c0_stride_b,
+                                        const int32_t* lengths, void* gates, float* cseq, void* hseq, void* yseq, float* hr, int B, int U1, int P,
+                                        int dtype, int t0, int t1, void* stream) {
+  if (!xg || !rk || !gates || !cseq || !hseq || !hr || B <= 0 || U1 <= 0 || P <= 0 || t0 < 0 || t1 > U1 || t0 > t1) return TFASR_STATUS_INVALID_VALUE;
   const long esz = dtype == TFASR_F32 ? 4 : 2;
-  for (int t = 0; t < U1; ++t) {
+  for (int t = t0; t < t1; ++t) {
     const char* hprev = t > 0 ? (const char*)hseq + (long)(t - 1) * P * esz : (const char*)h0;
     const long hps = t > 0 ? (long)U1 * P : h0_stride_b;
     const float* cprev = t > 0 ? cseq + (long)(t - 1) * P : c0;
@@ -196,16 +193,27 @@ extern "C" int tfasr_lstm_seq_fwd(const void* xg, const void* rk, const void* h0
   return TFASR_STATUS_SUCCESS;
 }
 
-// backward through time: dz [B, U1, 4P] out; dh_carry / dc_carry [B, P] f32 zeroed by the caller; dhr [B, P] f32 scratch
-extern "C" int tfasr_lstm_seq_bwd(const void* dy, const void* rk, const void* gates, const float* cseq, const int32_t* lengths, void* dz,
-                                  float* dh_carry, float* dc_carry, float* dhr, int B, int U1, int P, int dtype, void* stream) {
-  if (!dy || !rk || !gates || !cseq || !dz || !dh_carry || !dc_carry || !dhr || B <= 0 || U1 <= 0 || P <= 0) return TFASR_STATUS_INVALID_VALUE;
-  if (persist_enabled() && (size_t)B * P * sizeof(float) >= tfasr_lstm_persist_sync_bytes()) {  // (synchronisation record at the front of `dhr`)
-    const int st = tfasr_lstm_persist_bwd(dy, rk, gates, cseq, lengths, dz, dh_carry, dc_carry, B, U1, P, dtype, dhr, stream);
+extern "C" int tfasr_lstm_seq_fwd(const void* xg, const void* rk, const void* h0, long h0_stride_b, const float* c0, long c0_stride_b,
+                                  const int32_t* lengths, void* gates, float* cseq, void* hseq, void* yseq, float* hr, int B, int U1, int P,
+                                  int dtype, void* stream) {
+  if (!xg || !rk || !gates || !cseq || !hseq || !hr || B <= 0 || U1 <= 0 || P <= 0) return TFASR_STATUS_INVALID_VALUE;
+  // one persistent launch for the whole sequence where the shape allows it (lstm_persist.hip); its 64-byte synchronisation record
+  // lives at the front of the `hr` scratch (B x 4P floats, unused by that path)
+  if (persist_enabled() && (size_t)B * 4 * P * sizeof(float) >= tfasr_lstm_persist_sync_bytes()) {
+    const int st = tfasr_lstm_persist_fwd(xg, rk, h0, h0_stride_b, c0, c0_stride_b, lengths, gates, cseq, hseq, yseq, B, U1, P, dtype, hr, stream);
     if (st != TFASR_STATUS_UNSUPPORTED) return st;
   }
+  return tfasr_lstm_seq_fwd_range(xg, rk, h0, h0_stride_b, c0, c0_stride_b, lengths, gates, cseq, hseq, yseq, hr, B, U1, P, dtype, 0, U1, stream);
+}
+
+// steps t1-1 down to t0 of the backward recurrence with the per-step kernels (see tfasr_lstm_seq_fwd_range); slices must be queued in
+// descending order: [t, U1), then [t', t), ... - the carries dh_carry / dc_carry / dhr live across the calls
+extern "C" int tfasr_lstm_seq_bwd_range(const void* dy, const void* rk, const void* gates, const float* cseq, const int32_t* lengths, void* dz,
+                                        float* dh_carry, float* dc_carry, float* dhr, int B, int U1, int P, int dtype, int t0, int t1, void* stream) {
+  if (!dy || !rk || !gates || !cseq || !dz || !dh_carry || !dc_carry || !dhr || B <= 0 || U1 <= 0 || P <= 0 || t0 < 0 || t1 > U1 || t0 > t1)
+    return TFASR_STATUS_INVALID_VALUE;
   const long esz = dtype == TFASR_F32 ? 4 : 2;
-  for (int t = U1 - 1; t >= 0; --t) {
+  for (int t = t1 - 1; t >= t0; --t) {
     int st = tfasr_lstm_step_bwd((const char*)dy + (long)t * P * esz, (long)U1 * P, t < U1 - 1 ? dhr : nullptr, dh_carry, dc_carry,
                                  (const char*)gates + (long)t * 4 * P * esz, (long)U1 * 4 * P, cseq + (long)t * P, (long)U1 * P,
                                  t > 0 ? cseq + (long)(t - 1) * P : nullptr, (long)U1 * P, lengths, t, (char*)dz + (long)t * 4 * P * esz, (long)U1 * 4 * P, B, P,
@@ -221,4 +229,15 @@ extern "C" int tfasr_lstm_seq_bwd(const void* dy, const void* rk, const void* ga
     }
   }
   return TFASR_STATUS_SUCCESS;
+}
+
+// backward through time: dz [B, U1, 4P] out; dh_carry / dc_carry [B, P] f32 zeroed by the caller; dhr [B, P] f32 scratch
+extern "C" int tfasr_lstm_seq_bwd(const void* dy, const void* rk, const void* gates, const float* cseq, const int32_t* lengths, void* dz,
+                                  float* dh_carry, float* dc_carry, float* dhr, int B, int U1, int P, int dtype, void* stream) {
+  if (!dy || !rk || !gates || !cseq || !dz || !dh_carry || !dc_carry || !dhr || B <= 0 || U1 <= 0 || P <= 0) return TFASR_STATUS_INVALID_VALUE;
+  if (persist_enabled() && (size_t)B * P * sizeof(float) >= tfasr_lstm_persist_sync_bytes()) {  // (synchronisation record at the front of `dhr`)
+    const int st = tfasr_lstm_persist_bwd(dy, rk, gates, cseq, lengths, dz, dh_carry, dc_carry, B, U1, P, dtype, dhr, stream);
+    if (st != TFASR_STATUS_UNSUPPORTED) return st;
+  }
+  return tfasr_lstm_seq_bwd_range(dy, rk, gates, cseq, lengths, dz, dh_carry, dc_carry, dhr, B, U1, P, dtype, 0, U1, stream);
 }

@@ -625,6 +625,21 @@ def lstm_seq_fwd(xg, rk, h0, c0, lengths, gates, cseq, hseq, yseq, hr):
                                   _p(gates), _p(cseq), _p(hseq), _pv(yseq), _p(hr), B, U1, P, _dt(xg), _stream()), "lstm_seq_fwd")
 
 
+def lstm_seq_fwd_range(xg, rk, h0, c0, lengths, gates, cseq, hseq, yseq, hr, t0, t1):
+    """steps [t0, t1) of lstm_seq_fwd with the per-step kernels (tfasr_lstm_seq_fwd_range)"""
+    B, U1, P4 = xg.shape
+    P = P4 // 4
+    check(_L().tfasr_lstm_seq_fwd_range(_p(xg), _p(rk), _pv(h0), 0 if h0 is None else h0.stride(0), _pv(c0), 0 if c0 is None else c0.stride(0), _pv(lengths),
+                                        _p(gates), _p(cseq), _p(hseq), _pv(yseq), _p(hr), B, U1, P, _dt(xg), int(t0), int(t1), _stream()), "lstm_seq_fwd_range")
+
+
+def lstm_seq_bwd_range(dy, rk, gates, cseq, lengths, dz, dh_carry, dc_carry, dhr, t0, t1):
+    """steps t1-1 .. t0 of lstm_seq_bwd with the per-step kernels (slices in descending order)"""
+    B, U1, P = dy.shape
+    check(_L().tfasr_lstm_seq_bwd_range(_p(dy), _p(rk), _p(gates), _p(cseq), _pv(lengths), _p(dz), _p(dh_carry), _p(dc_carry), _p(dhr), B, U1, P, _dt(dy),
+                                        int(t0), int(t1), _stream()), "lstm_seq_bwd_range")
+
+
 def lstm_persist_sync(device):
     """64-byte synchronisation record of the persistent LSTM kernels; word [1] != 0 after a sync = a wait timed out"""
     return torch.zeros(int(_L().tfasr_lstm_persist_sync_bytes()) // 4, dtype=torch.int32, device=device)
@@ -900,6 +915,13 @@ def block_bwd(cfg, params, io, ctx, phase):
 def launch_count():
     """kernel launches the library has queued since it was loaded (tfasr_launch_count)"""
     return int(_L().tfasr_launch_count())
+
+
+def block_side_stream():
+    """the block executor's low-priority second stream (tfasr_block_side_stream) as a raw hipStream_t value"""
+    ptr = ctypes.c_void_p(0)
+    check(_L().tfasr_block_side_stream(ctypes.byref(ptr)), "block_side_stream")
+    return int(ptr.value)
 
 
 def block_wgrad_probe(enable):

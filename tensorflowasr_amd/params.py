@@ -27,6 +27,12 @@ _CHAN = ("enc/sub/conv0/w", "enc/sub/conv0/b", "enc/sub/bn0/g", "enc/sub/bn0/b",
          "enc/sub/bn1/b", "enc/linear/w", "enc/sub/bn0/mm", "enc/sub/bn0/mv", "enc/sub/bn1/mm", "enc/sub/bn1/mv")
 
 
+def deferred_grad(name):
+    """regularised Conformer-block variables whose gradients are finished by launches that run once for ALL blocks after the last block's
+    backward (conformer._deferred_block_grads): every LayerNorm's gamma / beta, the positional projection's kernel, the depthwise kernel"""
+    return name.startswith("enc/block") and name.endswith(("/ln/g", "/ln/b", "mhsa/pos/w", "conv/dw/w"))
+
+
 def chan_padded(name):
     """variables (and BatchNorm state) that carry the subsampling's channel dimension (physically padded to a multiple of 64 in bf16
     models, see ParamStore)"""
@@ -180,14 +186,38 @@ class ParamStore:
             raise ValueError("filt_phys must be >= filters")
         specs = param_specs(cfg, self.head_phys, self.filt_phys)
         ordered = [x for x in specs if x[2]] + [x for x in specs if not x[2]]
+        # PHYSICAL order = the canonical order above (regularised variables first, forward order) except that the Conformer blocks' small
+        # regularised variables whose gradients the train step finishes AFTER the last block's backward (LayerNorm gamma / beta, the
+        # positional projection, the depthwise kernel: conformer._deferred_block_grads) sit together in ONE region behind the last block:
+        # a block's remaining variables are then a contiguous slice that is final when the block's backward is (the data-parallel bucket
+        # released right behind it), and the deferred region is one more slice released once, after the deferred launches - so a
+        # data-parallel rank keeps the hoisted step.  `names`, the initialisation order and the logical layout of
+        # state files stay canonical: only offsets move.
+        phys, late = [], []
+        for x in ordered:
+            if x[2] and conformer and deferred_grad(x[0]):
+                late.append(x)
+                continue
+            if late is not None and x[2] and not x[0].startswith("enc/"):
+                phys, late = phys + late, None  # first regularised variable behind the encoder: the deferred region goes in front of it
+            if late is not None and not x[2]:
+                phys, late = phys + late, None  # (an encoder-only store)
+            phys.append(x)
+        if late:
+            phys += late
         self.offsets, self.shapes = {}, {}
+        self.defer_lo = self.defer_hi = None
         off = 0
-        for name, shape, reg, init, fans in ordered:
+        for name, shape, reg, init, fans in phys:
+            if reg and conformer and deferred_grad(name) and self.defer_lo is None:
+                self.defer_lo = off
             self.offsets[name] = off
             self.shapes[name] = shape
             off += -(-int(np.prod(shape)) // self.ALIGN) * self.ALIGN
             if reg:
                 self.n_reg = off
+                if conformer and deferred_grad(name):
+                    self.defer_hi = off
         self.n = off
         self.names = [x[0] for x in ordered]
         self._views = {}
