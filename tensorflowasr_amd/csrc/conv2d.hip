@@ -4,6 +4,7 @@
 //   conv2 (Cin = C): im2col -> MFMA GEMM (K = 9*C) -> col2im for the data gradient
 // Layout: activations [B, T, F, C] channel-last; kernels keras-style [kh, kw, cin, cout].
 #include "common.h"
+#include <type_traits>
 #include <algorithm>
 
 namespace {
@@ -296,6 +297,11 @@ template <int N> __device__ __forceinline__ void ldn(const bf16_t* p, float (&v)
     v[k] = __uint_as_float(a.x << 16); v[k + 1] = __uint_as_float(a.x & 0xffff0000u); v[k + 2] = __uint_as_float(a.y << 16); v[k + 3] = __uint_as_float(a.y & 0xffff0000u);
   }
 }
+// Round 5: the arithmetic that is not a transcendental runs as PACKED f32 (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: two channels per
+// instruction - the kernels are VALU-bound: 9 conv FMAs + 9 weight-gradient FMAs + the BatchNorm affine per element against two
+// quarter-rate transcendentals); same fused multiply-adds in the same order per channel, so results are bitwise unchanged.
+typedef __attribute__((ext_vector_type(2))) float c1f2_t;
+__device__ __forceinline__ c1f2_t c1fma(c1f2_t a, c1f2_t b, c1f2_t c) { return __builtin_elementwise_fma(a, b, c); }
 template <typename T, int MODE, int CPT>
 __global__ __launch_bounds__(256) void conv1_bn_kernel(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
                                                        const float* __restrict__ fin, const float* __restrict__ bstats, float inv_count,
@@ -305,32 +311,40 @@ __global__ __launch_bounds__(256) void conv1_bn_kernel(const T* __restrict__ x, 
   float* xs = sm;                       // [3][F0 + 2] input rows of the current output row (zero padded)
   float* red = sm + 3 * (F0 + 2);       // [NQ][C] block reduction
   constexpr int NQ = MODE == 3 ? 10 : (MODE == 4 ? 11 : 2);
+  constexpr int CP2 = CPT / 2;          // channel pairs per thread
+  static_assert(CPT % 2 == 0, "channel pairs");
   const int cgn = C / CPT, FS = 256 / cgn;
   const int cg = threadIdx.x % cgn, fs = threadIdx.x / cgn;
   const bool on = fs < FS;
   const int c = cg * CPT;
   const int T2 = (T1 + 1) / 2, F2 = (F1 + 1) / 2;
-  float wr[9][CPT], br[CPT];
+  c1f2_t wr[9][CP2], br[CP2];
 #pragma unroll
-  for (int k = 0; k < CPT; ++k) br[k] = bias ? bias[c + k] : 0.f;
+  for (int k = 0; k < CP2; ++k) br[k] = bias ? c1f2_t{bias[c + 2 * k], bias[c + 2 * k + 1]} : c1f2_t{0.f, 0.f};
 #pragma unroll
   for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
-    for (int k = 0; k < CPT; ++k) wr[tap][k] = w[tap * C + c + k];
-  float mean[CPT], rstd[CPT], sc[CPT], sh[CPT], s0[CPT], s1[CPT];
+    for (int k = 0; k < CP2; ++k) wr[tap][k] = c1f2_t{w[tap * C + c + 2 * k], w[tap * C + c + 2 * k + 1]};
+  c1f2_t mean[CP2], rstd[CP2], sc[CP2], sh[CP2], s0[CP2], s1[CP2];
   if (MODE >= 1) {
 #pragma unroll
-    for (int k = 0; k < CPT; ++k) { mean[k] = fin[c + k]; rstd[k] = fin[C + c + k]; sc[k] = fin[2 * C + c + k]; sh[k] = fin[3 * C + c + k]; }
+    for (int k = 0; k < CP2; ++k) {
+      mean[k] = c1f2_t{fin[c + 2 * k], fin[c + 2 * k + 1]}; rstd[k] = c1f2_t{fin[C + c + 2 * k], fin[C + c + 2 * k + 1]};
+      sc[k] = c1f2_t{fin[2 * C + c + 2 * k], fin[2 * C + c + 2 * k + 1]}; sh[k] = c1f2_t{fin[3 * C + c + 2 * k], fin[3 * C + c + 2 * k + 1]};
+    }
   }
   if (MODE == 3) {
 #pragma unroll
-    for (int k = 0; k < CPT; ++k) { s0[k] = bstats[c + k] * inv_count; s1[k] = bstats[C + c + k] * inv_count; }
+    for (int k = 0; k < CP2; ++k) {
+      s0[k] = c1f2_t{bstats[c + 2 * k] * inv_count, bstats[c + 2 * k + 1] * inv_count};
+      s1[k] = c1f2_t{bstats[C + c + 2 * k] * inv_count, bstats[C + c + 2 * k + 1] * inv_count};
+    }
   }
-  float acc2[NQ][CPT];
+  c1f2_t acc2[NQ][CP2];
 #pragma unroll
   for (int q = 0; q < NQ; ++q)
 #pragma unroll
-    for (int k = 0; k < CPT; ++k) acc2[q][k] = 0.f;
+    for (int k = 0; k < CP2; ++k) acc2[q][k] = c1f2_t{0.f, 0.f};
   const int nrows = B * T1;
   for (int row = blockIdx.x; row < nrows; row += gridDim.x) {
     const int b = row / T1, t = row - b * T1;
@@ -341,61 +355,71 @@ __global__ __launch_bounds__(256) void conv1_bn_kernel(const T* __restrict__ x, 
     }
     __syncthreads();
     if (!on) continue;
-    for (int f = fs; f < F1; f += FS) {
-      float a[CPT];
-#pragma unroll
-      for (int k = 0; k < CPT; ++k) a[k] = br[k];
+    // one output position: conv1 recomputed, then the mode's sums / stores; `dr` = this thread's channels of the incoming gradient
+    auto body = [&](int f, const float (&dr)[CPT]) {
+      c1f2_t a[CP2];
+      float xv[9];
 #pragma unroll
       for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
-        for (int kw = 0; kw < 3; ++kw) {
-          const float xv = xs[kh * (F0 + 2) + 2 * f + kw];
+        for (int kw = 0; kw < 3; ++kw) xv[kh * 3 + kw] = xs[kh * (F0 + 2) + 2 * f + kw];
 #pragma unroll
-          for (int k = 0; k < CPT; ++k) a[k] += wr[kh * 3 + kw][k] * xv;
-        }
+      for (int k = 0; k < CP2; ++k) a[k] = br[k];
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const c1f2_t x2 = c1f2_t{xv[tap], xv[tap]};
+#pragma unroll
+        for (int k = 0; k < CP2; ++k) a[k] = c1fma(wr[tap][k], x2, a[k]);
+      }
       if (MODE == 0) {
 #pragma unroll
-        for (int k = 0; k < CPT; ++k) { acc2[0][k] += a[k]; acc2[1][k] += a[k] * a[k]; }
+        for (int k = 0; k < CP2; ++k) { acc2[0][k] += a[k]; acc2[1][k] = c1fma(a[k], a[k], acc2[1][k]); }
       } else if (MODE == 1) {
         float o[CPT];
 #pragma unroll
-        for (int k = 0; k < CPT; ++k) o[k] = swishf_(a[k] * sc[k] + sh[k]);
+        for (int k = 0; k < CP2; ++k) {
+          const c1f2_t z = c1fma(a[k], sc[k], sh[k]);
+          o[2 * k] = swishf_(z[0]); o[2 * k + 1] = swishf_(z[1]);
+        }
         static_assert(MODE != 1 || CPT == 8, "apply pass: 8 channels per thread");
         if constexpr (CPT == 8) st8(y + s2d_off(b, t, f, T2, F2, C) + c, o);
       } else {
-        float d[CPT];
-        ldn<CPT>(dy + s2d_off(b, t, f, T2, F2, C) + c, d);
+        c1f2_t d[CP2];
 #pragma unroll
-        for (int k = 0; k < CPT; ++k) {
-          const float dz = d[k] * dswishf_(a[k] * sc[k] + sh[k]);
-          const float xh = (a[k] - mean[k]) * rstd[k];
-          if (MODE == 2 || MODE == 4) { acc2[0][k] += dz; acc2[1][k] += dz * xh; }
-          else d[k] = sc[k] * (dz - s0[k] - xh * s1[k]);  // gradient w.r.t. conv1's output
-          if (MODE == 4) d[k] = dz;
+        for (int k = 0; k < CP2; ++k) {
+          const c1f2_t z = c1fma(a[k], sc[k], sh[k]);
+          const c1f2_t dz = c1f2_t{dr[2 * k] * dswishf_(z[0]), dr[2 * k + 1] * dswishf_(z[1])};
+          const c1f2_t xh = (a[k] - mean[k]) * rstd[k];
+          if (MODE == 2 || MODE == 4) { acc2[0][k] += dz; acc2[1][k] = c1fma(dz, xh, acc2[1][k]); }
+          d[k] = (MODE == 3) ? sc[k] * (dz - s0[k] - xh * s1[k]) : dz;  // MODE 3: gradient w.r.t. conv1's output
         }
         if (MODE == 4) {  // P[tap][c] += patch[tap] * dz_c: with the patch Gram matrix this is all conv1's weight gradient needs (below)
 #pragma unroll
-          for (int kh = 0; kh < 3; ++kh)
+          for (int tap = 0; tap < 9; ++tap) {
+            const c1f2_t x2 = c1f2_t{xv[tap], xv[tap]};
 #pragma unroll
-            for (int kw = 0; kw < 3; ++kw) {
-              const float xv = xs[kh * (F0 + 2) + 2 * f + kw];
-#pragma unroll
-              for (int k = 0; k < CPT; ++k) acc2[2 + kh * 3 + kw][k] += d[k] * xv;
-            }
+            for (int k = 0; k < CP2; ++k) acc2[2 + tap][k] = c1fma(d[k], x2, acc2[2 + tap][k]);
+          }
         }
         if (MODE == 3) {
 #pragma unroll
-          for (int kh = 0; kh < 3; ++kh)
+          for (int tap = 0; tap < 9; ++tap) {
+            const c1f2_t x2 = c1f2_t{xv[tap], xv[tap]};
 #pragma unroll
-            for (int kw = 0; kw < 3; ++kw) {
-              const float xv = xs[kh * (F0 + 2) + 2 * f + kw];
+            for (int k = 0; k < CP2; ++k) acc2[tap][k] = c1fma(d[k], x2, acc2[tap][k]);
+          }
 #pragma unroll
-              for (int k = 0; k < CPT; ++k) acc2[kh * 3 + kw][k] += d[k] * xv;
-            }
-#pragma unroll
-          for (int k = 0; k < CPT; ++k) acc2[9][k] += d[k];
+          for (int k = 0; k < CP2; ++k) acc2[9][k] += d[k];
         }
       }
+    };
+    // (measured and dropped in round 5: requesting the incoming gradient of all ten positions of the row up front - 218 instead of 142
+    // registers = two waves per SIMD instead of three: 596 vs 520 us; the kernel is bound by its ~60 vector instructions per element,
+    // not by the load chain - and packed-f32 FMAs, which are kept, did not move it either: 520 vs 517 us)
+    for (int f = fs; f < F1; f += FS) {
+      float dr[CPT];
+      if (MODE >= 2) ldn<CPT>(dy + s2d_off(b, t, f, T2, F2, C) + c, dr);
+      body(f, dr);
     }
   }
   if (MODE == 1) return;
@@ -408,7 +432,7 @@ __global__ __launch_bounds__(256) void conv1_bn_kernel(const T* __restrict__ x, 
 #pragma unroll
     for (int q = 0; q < NQ; ++q)
 #pragma unroll
-      for (int k = 0; k < CPT; ++k) atomicAdd(&red[q * C + c + k], acc2[q][k]);
+      for (int k = 0; k < CP2; ++k) { atomicAdd(&red[q * C + c + 2 * k], acc2[q][k][0]); atomicAdd(&red[q * C + c + 2 * k + 1], acc2[q][k][1]); }
   }
   __syncthreads();
   for (int i = threadIdx.x; i < NQ * C; i += 256) {
@@ -678,7 +702,24 @@ static int conv1_bn_launch(const void* x, const float* w, const float* bias, con
   constexpr int NQL = MODE == 3 ? 10 : (MODE == 4 ? 11 : 2);
   const int T1 = (T0 + 1) / 2, F1 = (F0 + 1) / 2;
   hipStream_t s = (hipStream_t)stream_;
-  const int grid = std::min(B * T1, MODE == 1 ? 8192 : 1024);
+  const size_t smem_q = (size_t)(3 * (F0 + 2) + NQL * C) * sizeof(float);
+  // backward passes: every block walks ~B*T1/grid rows, so the grid is exactly ONE round of resident blocks (occupancy x CUs, asked once per
+  // instantiation and LDS size): 1024 blocks on 768 slots were a full round plus a third of one.  TFASR_CONV1_GRID overrides (A/B).
+  static const int env_grid = getenv("TFASR_CONV1_GRID") ? atoi(getenv("TFASR_CONV1_GRID")) : 0;
+  static int res_blocks[2] = {0, 0};
+  static size_t res_smem[2] = {0, 0};
+  const int di = dtype == TFASR_F32 ? 0 : 1;
+  if (MODE != 1 && !env_grid && (res_blocks[di] == 0 || res_smem[di] != smem_q)) {
+    int dev = 0, cus = 0, per = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (e == hipSuccess)
+      e = di == 0 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, conv1_bn_kernel<float, MODE, CPT>, 256, smem_q)
+                  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, conv1_bn_kernel<bf16_t, MODE, CPT>, 256, smem_q);
+    res_blocks[di] = (e == hipSuccess && per > 0 && cus > 0) ? per * cus : 768;
+    res_smem[di] = smem_q;
+  }
+  const int grid = std::min(B * T1, MODE == 1 ? 8192 : std::max(64, env_grid ? env_grid : res_blocks[di]));
   const size_t smem = (size_t)(3 * (F0 + 2) + NQL * C) * sizeof(float);
   const float inv = count > 0.f ? 1.f / count : 0.f;
   DISPATCH_T(dtype,

@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256, WGS) void ffn_fused_fwd_kernel(const FfnArgs p
     for (int j = 0; j < 8; ++j) acc2[i][j] = float4_t{0.f, 0.f, 0.f, 0.f};
   const uint32_t dthr = drop_thr(p.drop_p);
   const float dinv = p.drop_p > 0.f ? 1.f / (1.f - p.drop_p) : 1.f;
-  const uint32_t dkey1 = (uint32_t)p.seed1 * 0x9E3779B1u ^ (uint32_t)((uint64_t)p.seed1 >> 32);  // drop_hash's key for pair indices < 2^32
+  const uint32_t dkey1 = drop_key((uint64_t)p.seed1);  // drop_hash's key (pair indices < 2^32 here)
 
   auto gemm1 = [&](int cc, bool fence = true) {  // acc1 = ln W1[:, cc]: wave tile 32 x 32, K = 256, A from registers
     const char* sW1 = smem + W1_OFF + (cc & (NBUF - 1)) * 32768;
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256, WGS) void ffn_fused_fwd_kernel(const FfnArgs p
         const uint32_t pr0 = pbase + ((uint32_t)off >> 1);  // off is even: one dropout hash serves an element pair
 #pragma unroll
         for (int q = 0; q < 8; q += 2) {
-          const uint32_t hh = fmix32((pr0 + (q >> 1)) ^ dkey1);
+          const uint32_t hh = drop_mix(dkey1, pr0 + (q >> 1));
           hv[q] = (hh & 0xffffu) >= dthr ? hv[q] * dinv : 0.f;
           hv[q + 1] = (hh >> 16) >= dthr ? hv[q + 1] * dinv : 0.f;
         }
@@ -397,8 +397,17 @@ __global__ __launch_bounds__(256, WGS) void ffn_fused_fwd_kernel(const FfnArgs p
 
 // Variant for a launch.  One workgroup per CU with 96-row tiles (MR 3, double-buffered weights) or two per CU with 64-row tiles (WGS 2).
 static int launch_ffn_fused_fwd(const FfnArgs& a, hipStream_t stream) {
-  static const int forced = getenv("TFASR_FFN_VARIANT") ? atoi(getenv("TFASR_FFN_VARIANT")) : 0;  // 1: MR 3 x 1 WG/CU, 2: MR 2 x 2 WG/CU, 3: MR 2 x 1
-  const int variant = forced >= 1 && forced <= 3 ? forced : 2;
+  // 1: MR 3 x 1 WG/CU, 2: MR 2 x 2 WG/CU, 3: MR 2 x 1, 4: MR 1 x 2 WG/CU (32-row tiles); 0 / unset: by tile count (below)
+  static const int forced = getenv("TFASR_FFN_VARIANT") ? atoi(getenv("TFASR_FFN_VARIANT")) : 0;
+  static int ncu = 0;
+  if (ncu == 0) {
+    int dev = 0, v = 0;
+    ncu = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
+  }
+  // Round 5 re-measured the 32-row variant per batch shape (variant 4): a [14.8k, 256] batch is 231 64-row workgroups - one per CU - or 462
+  // 32-row ones = two per CU in one round; 50.9 vs ~48 us per launch in line, 21.76 vs 21.45 ms per step when forced everywhere: the
+  // second resident workgroup's overlap does not pay for the halved reuse of the weight images.  64 rows stay the default.
+  const int variant = forced >= 1 && forced <= 4 ? forced : 2;
   auto go = [&](auto kern, int MR, int NBUF) {
     const int smem = 2 * NBUF * 32768 + NBUF * 32 * MR * 128 + a.F * 4;
     static bool attr_done = false;
@@ -406,8 +415,9 @@ static int launch_ffn_fused_fwd(const FfnArgs& a, hipStream_t stream) {
     const long tiles = (a.rows + 32 * MR - 1) / (32 * MR);
     hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), smem, stream, a);
   };
-  if (variant == 1) go(ffn_fused_fwd_kernel<3, 1>, 3, 2);  // (measured and dropped: 32-row tiles x 2 per CU: 64.6 vs 55.9 us)
+  if (variant == 1) go(ffn_fused_fwd_kernel<3, 1>, 3, 2);
   else if (variant == 3) go(ffn_fused_fwd_kernel<2, 1>, 2, 2);
+  else if (variant == 4) go(ffn_fused_fwd_kernel<1, 2>, 1, 1);
   else go(ffn_fused_fwd_kernel<2, 2>, 2, 1);
   return TFASR_STATUS_SUCCESS;
 }

@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256, 2) void ffn_fused_bwd_kernel(const FfnBwdArgs 
     for (int j = 0; j < 8; ++j) acc2[i][j] = float4_t{0.f, 0.f, 0.f, 0.f};
   const uint32_t dthr = drop_thr(p.drop_p);
   const float dinv = p.drop_p > 0.f ? 1.f / (1.f - p.drop_p) : 1.f;
-  const uint32_t dkey1 = (uint32_t)p.seed1 * 0x9E3779B1u ^ (uint32_t)((uint64_t)p.seed1 >> 32);  // drop_hash's key for pair indices < 2^32
+  const uint32_t dkey1 = drop_key((uint64_t)p.seed1);  // drop_hash's key (pair indices < 2^32 here)
   FFN_TICK(0)  // prologue (loads issued)
   // loop-invariant per-lane slots of the C layout (row = wr*32 + i*16 + g*4 + e, column = wc*32 + j*16 + r of the chunk): byte address in the
   // [64][64] bf16 tiles (z and dz share the layout) and the element's share of the dropout pair index
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256, 2) void ffn_fused_bwd_kernel(const FfnBwdArgs 
           const float zv = bf16_to_f32(*reinterpret_cast<const bf16_t*>(smem + SZ_OFF + toff[i][j][e]));
           float v = p.res * acc1[i][j][e];
           v *= dswishf_(zv);
-          const uint32_t hh = fmix32((pbase + pidx[i][j][e]) ^ dkey1);
+          const uint32_t hh = drop_mix(dkey1, pbase + pidx[i][j][e]);
           v = (hi_half ? (hh >> 16) : (hh & 0xffffu)) >= dthr ? v * dinv : 0.f;  // (drop_p = 0: threshold 0 keeps everything, dinv = 1)
           *reinterpret_cast<bf16_t*>(smem + SH_OFF + toff[i][j][e]) = f32_to_bf16(v);
         }

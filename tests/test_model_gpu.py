@@ -230,6 +230,31 @@ def test_dropout_kernel_statistics_and_gemm_consistency(dev):
         np.testing.assert_array_equal((out.float() != 0).cpu().numpy(), (y != 0).cpu().numpy())
 
 
+def test_dropout_mask_is_statistically_independent(dev):
+    """Round 5 replaced the per-pair murmur3 finaliser by two rounds of 24-bit multiply + xor-shift (csrc/common.h drop_mix, full-rate vector
+    instructions).  What a dropout mask has to be: keep rate 1 - p, row / column keep rates with the spread of independent draws (no lattice
+    along the row stride), no correlation at small lags or at the row stride, and masks of neighbouring seeds (consecutive dropout sites,
+    consecutive steps, the rank bits) agreeing no more often than independent ones (0.9^2 + 0.1^2 = 0.82)."""
+    from tensorflowasr_amd import kernels as K
+
+    for rows, C in ((4096, 1024), (19264, 256)):
+        ones = torch.ones(rows, C, device=dev)
+        keep = (K.dropout(ones, 0.1, 8192 * 5 + 16) != 0).float()
+        kr = keep.mean().item()
+        assert abs(kr - 0.9) < 4 * (0.09 / (rows * C)) ** 0.5 + 1e-4
+        col, row = keep.mean(0).std().item(), keep.mean(1).std().item()
+        assert 0.8 < col / (0.09 / rows) ** 0.5 < 1.25, col
+        assert 0.8 < row / (0.09 / C) ** 0.5 < 1.25, row
+        a = (keep - kr).reshape(-1)
+        for lag in (1, 2, 3, 4, C // 2, C, 2 * C):
+            ac = float((a[:-lag] * a[lag:]).mean() / 0.09)
+            assert abs(ac) < 5.0 / (rows * C) ** 0.5 + 2e-3, (lag, ac)
+    base = K.dropout(torch.ones(2048, 1024, device=dev), 0.1, 8192 * 7 + 18) != 0
+    for seed in (8192 * 7 + 19, 8192 * 7 + 20, 8192 * 8 + 18, 8192 * 7 + 18 + (1 << 27), 8192 * 7 + 18 + (1 << 40)):
+        agree = ((K.dropout(torch.ones(2048, 1024, device=dev), 0.1, seed) != 0) == base).float().mean().item()
+        assert abs(agree - 0.82) < 3e-3, (seed, agree)
+
+
 def test_dropout_backward_consistent_finite_difference(dev):
     """With dropout ON the regenerated backward masks must match the forward ones: directional finite difference of the
     mean loss along a random parameter direction vs <grad, direction> (f32 path, fixed mask epoch)."""

@@ -110,7 +110,7 @@ def test_conformer_s_16_blocks_10s_loss_and_gradients_vs_oracle(dev):
 
 # --------------------------------------------------------------------------------------------- BASELINE configs[2] dimensions
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("case", ["T462_B4", "T743_B2", "T150_B3_L16", "T462_B2_L16"])
+@pytest.mark.parametrize("case", ["T462_B4", "T743_B2", "T150_B3_L16", "T462_B2_L16", "T743_B1_L16"])
 def test_conformer_m_dims_ragged_bf16_fused_path_vs_oracle(dev, case):
     """d=256, dh=64, k=31, J=640 with ragged lengths at the padded lengths of bench.py's two batches: fused attention +
     native executor + packed lattice (bf16) against the oracle, which applies the reference's padded-query mask and the
@@ -119,6 +119,8 @@ def test_conformer_m_dims_ragged_bf16_fused_path_vs_oracle(dev, case):
         nsamp, ulens, U, blocks = [295600, 201000, 131072, 20800], [68, 46, 30, 5], 68, 3
     elif case == "T743_B2":
         nsamp, ulens, U, blocks = [475200, 160000], [40, 37], 40, 2
+    elif case == "T743_B1_L16":  # ALL 16 blocks at bench.py's OTHER padded length (T' = 743), one utterance (the oracle's cost sets B)
+        nsamp, ulens, U, blocks = [475200], [40], 40, 16
     elif case == "T462_B2_L16":  # ALL 16 blocks at one of bench.py's padded lengths (T' = 462), two ragged utterances
         nsamp, ulens, U, blocks = [295600, 131072], [68, 30], 68, 16
     else:  # ALL 16 blocks of the model bench.py times (depth: bf16 drift through the whole encoder), shorter utterances, ragged incl. padded blocks
@@ -126,7 +128,7 @@ def test_conformer_m_dims_ragged_bf16_fused_path_vs_oracle(dev, case):
     cfg, ocfg, model, W, data, sig, labels, preds = _make(dev, "M", torch.bfloat16, nsamp, ulens, U, blocks=blocks)
     assert model._fused_attention() and model.native_blocks
     ref_loss, ref_grads, elen = _oracle(ocfg, W, sig, nsamp, preds, ulens, labels)
-    assert int(elen.max()) == {"T462_B4": 462, "T743_B2": 743, "T150_B3_L16": 150, "T462_B2_L16": 462}[case]
+    assert int(elen.max()) == {"T462_B4": 462, "T743_B2": 743, "T150_B3_L16": 150, "T462_B2_L16": 462, "T743_B1_L16": 743}[case]
     model.zero_grad()
     costs = model.loss_and_backward(data, True, (None, None)).float().cpu().numpy()
     torch.cuda.synchronize()
@@ -336,6 +338,45 @@ def test_conformer_s_greedy_tokens_bf16_and_f32_vs_f32_oracle(dev, sharpen, blan
         tok1, _, _, _ = R.recognize_single(enc_ref[:1], elen.tolist()[:1], W)
     np.testing.assert_array_equal(model32.recognize(inp1).tokens.cpu().numpy(), tok1.numpy())
     np.testing.assert_array_equal(model16.recognize(inp1).tokens.cpu().numpy(), tok1.numpy())
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("sharpen,blank_bias", [(1.0, 2.5), (4.0, 12.0)])
+def test_conformer_m_dims_greedy_tokens_bf16_and_f32_vs_f32_oracle(dev, sharpen, blank_bias):
+    """The decode line `bench.py --mode decode --model M` quotes is the token-exact mode of a Conformer-M: the same bit-exactness claim as
+    the Conformer-S test above at the M dimensions (d 256, 4 heads of 64, kernel 31, prediction 640, joint 640; 4 of the 16 blocks - the
+    oracle's cost sets the depth), ragged batch incl. an utterance shorter than the others' padding: f32 model and the bf16-trained model's
+    default mode (f32 inference twin) against the f32 oracle, batch variant and the batch-size-1 variant (recognize_single)."""
+    B = 4
+    nsamp = [64000, 52000, 40000, 24000]
+    ulens = [3] * B
+    cfg, ocfg, model32, W, data, sig, labels, preds = _make(dev, "M", torch.float32, nsamp, ulens, 3, blocks=4, scale_bias=0.0)
+    W = dict(W)
+    W["joint/vocab/w"] = W["joint/vocab/w"] * sharpen
+    W["joint/vocab/b"] = W["joint/vocab/b"].clone()
+    W["joint/vocab/b"][0] += blank_bias
+    model32.ps.import_keras(W)
+    feat = R.log_mel(sig, ocfg)
+    with torch.no_grad():
+        enc_ref, elen = R.encoder(torch.from_numpy(feat)[..., None], R.get_nframes(nsamp), W, ocfg, training=False)
+        tok_ref, _, _, _ = R.recognize_batch(enc_ref, elen.tolist(), W)
+    inp = PredictInput(torch.from_numpy(sig), torch.tensor(nsamp, dtype=torch.int32))
+    np.testing.assert_array_equal(model32.recognize(inp).tokens.cpu().numpy(), tok_ref.numpy())
+    per_utt = [int((tok_ref[b] != 0).sum()) for b in range(B)]
+    print(f"\n[g1] greedy M dims (4 blocks) x{sharpen:g} blank+{blank_bias:g}: tokens per utterance {per_utt} (buffer {tok_ref.shape[1]})")
+    # (1.0, 2.5): three rows saturate their token buffer, one emits a handful; (4.0, 12.0): a few tokens on two rows, none on the others
+    assert sum(per_utt) > 4 and min(per_utt) < 10, per_utt
+    model16 = ConformerTransducer(cfg, dev, dtype=torch.bfloat16, seed=0)
+    model16.ps.import_keras(W)
+    assert model16.decode_precision == "f32"
+    np.testing.assert_array_equal(model16.recognize(inp).tokens.cpu().numpy(), tok_ref.numpy())
+    # batch size 1 -> recognize_single (<= 3 symbols per frame; NOT equivalent to the batch loop in the reference: both reproduced)
+    one = PredictInput(torch.from_numpy(sig[1:2, :nsamp[1]].copy()), torch.tensor(nsamp[1:2], dtype=torch.int32))
+    feat1 = R.log_mel(sig[1:2, :nsamp[1]], ocfg)
+    with torch.no_grad():
+        enc1, elen1 = R.encoder(torch.from_numpy(feat1)[..., None], R.get_nframes(nsamp[1:2]), W, ocfg, training=False)
+        tok1, _, _, _ = R.recognize_single(enc1, elen1.tolist(), W)
+    np.testing.assert_array_equal(model16.recognize(one).tokens.cpu().numpy(), tok1.numpy())
 
 
 def _oracle_margins(enc, elen, W):

@@ -39,7 +39,8 @@ def test_conformer_logits_match_reference_classes(dev, dtype, name, over):
     cfg.time_masking, cfg.freq_masking = {}, {}  # the golden run has no augmentation (SpecAugment: specaugment_reference.npz)
     model = ConformerTransducer(cfg, dev, dtype=dtype, seed=0)
     model.ps.import_keras(W)
-    tol = 2e-3 if dtype == torch.float32 else 4e-2
+    # bf16: 3 x the measured error of this tiny model (d = 32: 1.06e-2 train / 8.3e-3 eval, streaming 8.2e-3); f32 measures 1.5e-6
+    tol = 2e-3 if dtype == torch.float32 else 3.2e-2
     for native in (True, False):
         model.native_blocks = native
         model.ps.import_keras(W)  # (resets the moving statistics)
@@ -48,6 +49,7 @@ def test_conformer_logits_match_reference_classes(dev, dtype, name, over):
         assert elen == z["train/logits_length"].tolist()
         got = logits.float().cpu().numpy()
         # rows past an utterance's encoder length hold whatever the (unmasked) network computes there in the reference too: compared as well
+        print(f"\n[wiring] {name} {str(dtype)[6:]} native={native}: train logits rel L2 {_rel(got, z['train/logits']):.3e}")
         assert _rel(got, z["train/logits"]) < tol, (native, _rel(got, z["train/logits"]))
         if dtype == torch.float32:
             np.testing.assert_allclose(got, z["train/logits"], rtol=2e-3, atol=2e-3)
@@ -57,6 +59,7 @@ def test_conformer_logits_match_reference_classes(dev, dtype, name, over):
         ev, elen2, _ = model._forward(inp, False, None)
         torch.cuda.synchronize()
         assert elen2 == elen
+        print(f"[wiring] {name} {str(dtype)[6:]} native={native}: eval logits rel L2 {_rel(ev.float().cpu().numpy(), z['eval/logits']):.3e}")
         assert _rel(ev.float().cpu().numpy(), z["eval/logits"]) < tol
 
 
@@ -77,6 +80,7 @@ def test_contextnet_logits_match_reference_classes(dev, dtype):
     assert elen == z["train/logits_length"].tolist()
     got = logits.float().cpu().numpy()
     tol = 2e-3 if dtype == torch.float32 else 4e-2
+    print(f"\n[wiring] contextnet {str(dtype)[6:]}: train logits rel L2 {_rel(got, z['train/logits']):.3e}")
     assert _rel(got, z["train/logits"]) < tol, _rel(got, z["train/logits"])
     if dtype == torch.float32:
         np.testing.assert_allclose(got, z["train/logits"], rtol=2e-3, atol=2e-3)
@@ -85,4 +89,5 @@ def test_contextnet_logits_match_reference_classes(dev, dtype):
                 np.testing.assert_allclose(model.ps.state[k[len("after_train/"):]].cpu().numpy(), z[k], rtol=1e-3, atol=1e-5)
     ev, _, _ = model._forward(inp, False, None)
     torch.cuda.synchronize()
+    print(f"[wiring] contextnet {str(dtype)[6:]}: eval logits rel L2 {_rel(ev.float().cpu().numpy(), z['eval/logits']):.3e}")
     assert _rel(ev.float().cpu().numpy(), z["eval/logits"]) < tol
