@@ -86,13 +86,18 @@ template <int MT>  // MT = ceil(B / 16) batch row tiles
 __global__ __launch_bounds__(256) void lstm_persist_fwd_kernel(
     const bf16_t* __restrict__ xg, const bf16_t* __restrict__ rk, const bf16_t* __restrict__ h0, long h0_stride_b,
     const float* __restrict__ c0, long c0_stride_b, const int32_t* __restrict__ lengths, bf16_t* __restrict__ gates,
-    float* __restrict__ cseq, bf16_t* hseq, bf16_t* __restrict__ yseq, int B, int U1, int P, Sync* sync) {
+    float* __restrict__ cseq, bf16_t* hseq, bf16_t* __restrict__ yseq, int B, int U1, int P, Sync* sync,
+    const bf16_t* __restrict__ rk_t = nullptr, int t_begin = 0, int t_end = -1) {
+  // rk_t / [t_begin, t_end): the SAME step body as ONE LAUNCH PER STEP (tfasr_lstm_steps_fwd, round 5): a range of one step never waits and
+  // never arrives; the carried state comes from the sequence buffers (cseq / hseq hold the CARRIED state at every step, masked ones
+  // included); rk_t = R transposed [4P, P] so that the wave's B fragments are twenty 16-byte loads instead of 160 strided 2-byte ones.
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int r = lane & 15, g = lane >> 4;
   const int u0 = blockIdx.x * PW;
   const int nwg = gridDim.x;
   const int Bp = MT * 16;
+  if (t_end < 0) t_end = U1;
   const int ldh = P * 2 + 16;                       // LDS row stride of the staged h tile in bytes (+16: rows land 4 banks apart)
   char* sH = smem;                                  // [Bp][P] bf16
   float* sZ = reinterpret_cast<float*>(smem + (long)Bp * ldh);  // [4 gates][Bp][16] f32
@@ -103,8 +108,11 @@ __global__ __launch_bounds__(256) void lstm_persist_fwd_kernel(
 #pragma unroll
   for (int k = 0; k < MAXKS; ++k) {
     if (k < ks) {
+      if (rk_t) bw[k] = *reinterpret_cast<const short8_t*>(rk_t + (long)(w * P + u0 + r) * P + k * 32 + g * 8);
+      else {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) bw[k][e] = (short)rk[(long)(k * 32 + g * 8 + e) * 4 * P + w * P + u0 + r];
+        for (int e = 0; e < 8; ++e) bw[k][e] = (short)rk[(long)(k * 32 + g * 8 + e) * 4 * P + w * P + u0 + r];
+      }
     }
   }
   // owned items: (batch row b, unit pair up) -> units u0 + 2 up, u0 + 2 up + 1; item = threadIdx.x + 256 * i
@@ -117,13 +125,18 @@ __global__ __launch_bounds__(256) void lstm_persist_fwd_kernel(
     const bool in = it < Bp * (PW / 2) && b < B;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      c_st[i][j] = (in && c0) ? c0[b * c0_stride_b + u0 + u + j] : 0.f;
-      h_st[i][j] = (in && h0) ? bf16_to_f32(h0[b * h0_stride_b + u0 + u + j]) : 0.f;
+      if (t_begin > 0) {  // the carried state of the step in front of the range
+        c_st[i][j] = in ? cseq[((long)b * U1 + (t_begin - 1)) * P + u0 + u + j] : 0.f;
+        h_st[i][j] = in ? bf16_to_f32(hseq[((long)b * U1 + (t_begin - 1)) * P + u0 + u + j]) : 0.f;
+      } else {
+        c_st[i][j] = (in && c0) ? c0[b * c0_stride_b + u0 + u + j] : 0.f;
+        h_st[i][j] = (in && h0) ? bf16_to_f32(h0[b * h0_stride_b + u0 + u + j]) : 0.f;
+      }
     }
     len_b[i] = in ? (lengths ? lengths[b] : U1) : 0;
   }
 
-  for (int t = 0; t < U1; ++t) {
+  for (int t = t_begin; t < t_end; ++t) {
     // input-projection terms of this step for the owned items (independent of the recurrence: in flight during the wait)
     float xz[NIT][4][2];
 #pragma unroll
@@ -136,7 +149,7 @@ __global__ __launch_bounds__(256) void lstm_persist_fwd_kernel(
         if (in) ld2(xg + ((long)b * U1 + t) * 4 * P + q * P + u0 + u, xz[i][q][0], xz[i][q][1]);
       }
     }
-    if (t > 0 && !wait_count(sync, (unsigned)nwg * (unsigned)t)) {
+    if (t > t_begin && !wait_count(sync, (unsigned)nwg * (unsigned)(t - t_begin))) {
       poison_rows(hseq, (long)U1 * P, P, t, U1, B, u0, PW);
       if (yseq) poison_rows(yseq, (long)U1 * P, P, t, U1, B, u0, PW);
       return;
@@ -212,7 +225,7 @@ __global__ __launch_bounds__(256) void lstm_persist_fwd_kernel(
         store_wt2(hseq + so, h_st[i][0], h_st[i][1]);
       }
     }
-    if (t + 1 < U1) arrive(sync);
+    if (t + 1 < t_end) arrive(sync);
   }
 }
 
@@ -221,13 +234,15 @@ template <int MT>
 __global__ __launch_bounds__(256) void lstm_persist_bwd_kernel(
     const bf16_t* __restrict__ dy, const bf16_t* __restrict__ rk, const bf16_t* __restrict__ gates, const float* __restrict__ cseq,
     const int32_t* __restrict__ lengths, bf16_t* dz, float* __restrict__ dh_carry, float* __restrict__ dc_carry, int B, int U1, int P,
-    Sync* sync) {
+    Sync* sync, int t_begin = 0, int t_end = -1) {
+  // [t_begin, t_end): steps t_end - 1 down to t_begin (one launch per step: tfasr_lstm_steps_bwd); the carries live in dh_carry / dc_carry
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int r = lane & 15, g = lane >> 4;
   const int u0 = blockIdx.x * PW;
   const int nwg = gridDim.x;
   const int Bp = MT * 16;
+  if (t_end < 0) t_end = U1;
   float* sZ = reinterpret_cast<float*>(smem);  // [4 k ranges][Bp][16] f32 partial products
   const int ks = P / 32;
   // B fragments: B[k][n] = R[u0 + n][w*P + k] (row u0 + n of R, k-contiguous: 16-B loads)
@@ -249,7 +264,7 @@ __global__ __launch_bounds__(256) void lstm_persist_bwd_kernel(
     }
     len_b[i] = in ? (lengths ? lengths[b] : U1) : 0;
   }
-  for (int t = U1 - 1; t >= 0; --t) {
+  for (int t = t_end - 1; t >= t_begin; --t) {
     // operands of this step's cell backward (independent of the recurrence)
     float gq[NIT][4][2], cc[NIT][2], cp[NIT][2], dyv[NIT][2];
 #pragma unroll
@@ -275,7 +290,7 @@ __global__ __launch_bounds__(256) void lstm_persist_bwd_kernel(
 #pragma unroll
     for (int i = 0; i < NIT; ++i) dhr[i][0] = dhr[i][1] = 0.f;
     if (t < U1 - 1) {
-      if (!wait_count(sync, (unsigned)nwg * (unsigned)(U1 - 1 - t))) {
+      if (t < t_end - 1 && !wait_count(sync, (unsigned)nwg * (unsigned)(t_end - 1 - t))) {
         for (int q = 0; q < 4; ++q) poison_rows(dz, (long)U1 * 4 * P, 4 * P, 0, t + 1, B, q * P + u0, PW);
         return;
       }
@@ -349,7 +364,7 @@ __global__ __launch_bounds__(256) void lstm_persist_bwd_kernel(
         for (int q = 0; q < 4; ++q) store_wt2(dz + go + q * P, d[q][0], d[q][1]);
       }
     }
-    if (t > 0) {
+    if (t > t_begin) {
       __syncthreads();  // sZ is reused by the next step
       arrive(sync);
     }
@@ -393,7 +408,69 @@ bool grid_fits(KERNEL kernel, int grid, size_t smem) {
   return ok != 0;
 }
 
+// R [P, 4P] -> R^T [4P, P] (bf16), 32 x 32 tiles through LDS: once per sequence, for the per-step forward launches
+__global__ __launch_bounds__(256) void lstm_transpose_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int rows, int cols) {
+  __shared__ bf16_t tile[32][33];
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int i = ty; i < 32; i += 8)
+    if (r0 + i < rows && c0 + tx < cols) tile[i][tx] = x[(long)(r0 + i) * cols + c0 + tx];
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8)
+    if (c0 + i < cols && r0 + tx < rows) y[(long)(c0 + i) * rows + r0 + tx] = tile[tx][i];
+}
+
 }  // namespace
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// ONE LAUNCH PER STEP (round 5): the recurrent product and the cell of a step in one kernel - the persistent kernels'
+// step body over a one-step range, so nothing waits on another workgroup - instead of a skinny GEMM launch + a cell launch: the
+// prediction network's stream carries U1 launches per direction, not 2 x U1, each ~3 us of work on P/16 CUs (the GEMM pair was ~20 us).
+// Forward needs R^T [4P, P] (tfasr_lstm_transpose_rk, once per sequence) so that a wave's B fragments are 16-byte loads.
+// UNSUPPORTED outside the persistent kernels' shape range (bf16, B <= 64, P % 32 == 0, P <= 1024).
+// ---------------------------------------------------------------------------------------------------------------------------------
+extern "C" int tfasr_lstm_transpose_rk(const void* rk, void* rk_t, int P, int dtype, void* stream_) {
+  if (!rk || !rk_t || P <= 0) return TFASR_STATUS_INVALID_VALUE;
+  if (dtype != TFASR_BF16) return TFASR_STATUS_UNSUPPORTED;
+  hipLaunchKernelGGL(lstm_transpose_kernel, dim3((4 * P + 31) / 32, (P + 31) / 32), dim3(256), 0, (hipStream_t)stream_, (const bf16_t*)rk, (bf16_t*)rk_t, P, 4 * P);
+  TFASR_CHECK_LAUNCH();
+  return TFASR_STATUS_SUCCESS;
+}
+
+extern "C" int tfasr_lstm_steps_fwd(const void* xg, const void* rk, const void* rk_t, const void* h0, long h0_stride_b, const float* c0, long c0_stride_b,
+                                    const int32_t* lengths, void* gates, float* cseq, void* hseq, void* yseq, int B, int U1, int P, int dtype,
+                                    int t0, int t1, void* stream_) {
+  if (!xg || !rk || !rk_t || !gates || !cseq || !hseq || B <= 0 || U1 <= 0 || P <= 0 || t0 < 0 || t1 > U1 || t0 > t1) return TFASR_STATUS_INVALID_VALUE;
+  if (!persist_ok(B, P, dtype)) return TFASR_STATUS_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream_;
+  const int MT = (B + 15) / 16, Bp = MT * 16;
+  const size_t smem = (size_t)Bp * (P * 2 + 16) + (size_t)4 * Bp * PW * 4;
+  const dim3 grid(P / PW);
+#define TFASR_LAUNCH(M) hipLaunchKernelGGL(lstm_persist_fwd_kernel<M>, grid, dim3(256), smem, s, (const bf16_t*)xg, (const bf16_t*)rk, (const bf16_t*)h0, \
+                                           h0_stride_b, c0, c0_stride_b, lengths, (bf16_t*)gates, cseq, (bf16_t*)hseq, (bf16_t*)yseq, B, U1, P, (Sync*)nullptr, \
+                                           (const bf16_t*)rk_t, t, t + 1)
+  for (int t = t0; t < t1; ++t)
+    switch (MT) { case 1: TFASR_LAUNCH(1); break; case 2: TFASR_LAUNCH(2); break; case 3: TFASR_LAUNCH(3); break; default: TFASR_LAUNCH(4); }
+#undef TFASR_LAUNCH
+  TFASR_CHECK_LAUNCH();
+  return TFASR_STATUS_SUCCESS;
+}
+
+extern "C" int tfasr_lstm_steps_bwd(const void* dy, const void* rk, const void* gates, const float* cseq, const int32_t* lengths, void* dz,
+                                    float* dh_carry, float* dc_carry, int B, int U1, int P, int dtype, int t0, int t1, void* stream_) {
+  if (!dy || !rk || !gates || !cseq || !dz || !dh_carry || !dc_carry || B <= 0 || U1 <= 0 || P <= 0 || t0 < 0 || t1 > U1 || t0 > t1) return TFASR_STATUS_INVALID_VALUE;
+  if (!persist_ok(B, P, dtype)) return TFASR_STATUS_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream_;
+  const int MT = (B + 15) / 16, Bp = MT * 16;
+  const size_t smem = (size_t)4 * Bp * PW * 4;
+  const dim3 grid(P / PW);
+#define TFASR_LAUNCH(M) hipLaunchKernelGGL(lstm_persist_bwd_kernel<M>, grid, dim3(256), smem, s, (const bf16_t*)dy, (const bf16_t*)rk, (const bf16_t*)gates, cseq, \
+                                           lengths, (bf16_t*)dz, dh_carry, dc_carry, B, U1, P, (Sync*)nullptr, t, t + 1)
+  for (int t = t1 - 1; t >= t0; --t)
+    switch (MT) { case 1: TFASR_LAUNCH(1); break; case 2: TFASR_LAUNCH(2); break; case 3: TFASR_LAUNCH(3); break; default: TFASR_LAUNCH(4); }
+#undef TFASR_LAUNCH
+  TFASR_CHECK_LAUNCH();
+  return TFASR_STATUS_SUCCESS;
+}
 
 // ---------------------------------------------------------------------------------------------------------------------------------
 // C ABI.  `sync`: 64 bytes of device memory owned by the caller (tfasr_lstm_persist_sync_bytes), zeroed here (memset node in front of
