@@ -559,6 +559,9 @@ def main():
     data = [to_train_data(b, dev) for b in batches]
     model.timers = {}
     model.time_sections = bool(os.environ.get("TFASR_BENCH_SECTIONS"))
+    if not stub:
+        torch.cuda.synchronize()
+        model.prefetched_inputs = True  # the batches above are complete in HBM before any step is queued (inputs resident: the bench contract)
 
     def one_step(i):
         return model.train_step(data[i % nb])
@@ -685,6 +688,7 @@ def main():
                 model.timers = None
                 rb = [make_batch(cfg, args.batch, seed=10 + 13 * i, padding="reference", size=size) for i in range(nb)]
                 rd = [to_train_data(b, dev) for b in rb]
+                torch.cuda.synchronize()  # (complete in HBM before the first step that reads them: model.prefetched_inputs)
                 for i in range(2):
                     model.train_step(rd[i % nb])
                 torch.cuda.synchronize()

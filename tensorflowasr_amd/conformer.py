@@ -93,6 +93,7 @@ class ConformerTransducer(BaseModel):
         self.optimizer = dict(beta1=0.9, beta2=0.98, eps=1e-9, weight_decay=1e-6, schedule=dict(
             dmodel=cfg.dmodel, warmup_steps=10000, scale=2.0, max_lr=0.05 / math.sqrt(cfg.dmodel)))
         self.ga_steps = 1
+        self.prefetched_inputs = False  # True: every batch handed to train_step is complete in HBM (see _forward: early front end)
         self._ga_count = 0
         self._drop_epoch = 0  # bumped once per forward pass so every step draws fresh dropout masks
         # one native call per Conformer block (csrc/block.hip) instead of ~70 per-kernel calls from Python
@@ -1020,17 +1021,35 @@ class ConformerTransducer(BaseModel):
             self._bucket_after_block(prev[0])
         self._wgrad_keep = []
         hb = self._hoisted.pop("bwd", None)
-        if hb is not None:
-            if hb.get("aux_used"):
-                torch.cuda.current_stream().wait_stream(self.aux_stream)  # the table gradients accumulated on the auxiliary stream
-            self._deferred_block_grads(hb, e["T"])
-        # the blocks' LayerNorm / positional-projection / depthwise-kernel gradients live in ONE region behind the last block (ParamStore):
-        # final now - after the deferred launches, or after block 0's backward when nothing was deferred - and released as one bucket
-        if self.ps.defer_lo is not None:
-            self.dp.grads_ready(self.ps.defer_lo, self.ps.defer_hi)
+        # The blocks' LayerNorm / positional-projection / depthwise-kernel gradients live in ONE region behind the last block (ParamStore):
+        # final after the deferred launches - or after block 0's backward when nothing was deferred - and released as one bucket.
+        # Nothing on the chain waits for the deferred launches (~0.3 ms: one cast + column-sum, two grouped products, one LayerNorm fold, the
+        # depthwise weight-gradient pair moving 0.8 GB), so they run on the SIDE stream beside the subsampling's backward (1.6 ms of chain
+        # left) and are joined in front of the optimizer (_backward_from_joint); TFASR_DEFER_SIDE=0: on the chain as in round 4.
+        if hb is not None and self.aux_stream is not None and os.environ.get("TFASR_DEFER_SIDE", "1") != "0":
+            main = torch.cuda.current_stream()
+            self.aux_stream.wait_stream(main)  # (the table gradients of the blocks are already in this stream's order)
+            # what the launches read was allocated on the main stream: alive until the join, not handed back to its allocator before
+            self._defer_keep = (list(hb["dw"]), hb["ln_part"], self._zero_pool.get("bwd"), list(hb["ctx"]))
+            with torch.cuda.stream(self.aux_stream):
+                self._deferred_block_grads(hb, e["T"])
+                if self.ps.defer_lo is not None:
+                    self.dp.grads_ready(self.ps.defer_lo, self.ps.defer_hi)  # (ordered behind the launches: queued from their stream)
+            self._aux_pending = True
+        else:
+            if hb is not None:
+                if hb.get("aux_used"):
+                    torch.cuda.current_stream().wait_stream(self.aux_stream)  # the table gradients accumulated on the auxiliary stream
+                self._deferred_block_grads(hb, e["T"])
+            if self.ps.defer_lo is not None:
+                self.dp.grads_ready(self.ps.defer_lo, self.ps.defer_hi)
         t0 = self._tick("subsampling_bwd")
         self._subsampling_bwd(dx, ctx)
         self._tock("subsampling_bwd", t0)
+        if getattr(self, "_defer_keep", None) is not None:
+            # join of the deferred launches (every caller of encoder_bwd - transducer, CTC head - gets complete gradients back)
+            torch.cuda.current_stream().wait_stream(self.aux_stream)
+            self._defer_keep = None
 
     def _deferred_block_grads(self, hb, T):
         """What the blocks left to the caller (tfasr_block_io.defer_pos_grad / ln_part_ext): gWpos_i += pe^T dpext_i and gbpos_i +=
@@ -1097,10 +1116,12 @@ class ConformerTransducer(BaseModel):
         return pred  # [B*U1, P]
 
     # ---- the prediction network queued in SLICES between the encoder blocks --------------------------------------------------------------
-    # Its recurrence is ~2 x U1 tiny launches per direction on a stream of its own.  Queued in one go (round 1-4) the host blocked in
-    # hipLaunchKernel as soon as that stream's launch queue was full (it holds ~1 ms of work) and could not feed the ENCODER's stream
-    # meanwhile: the rocprofv3 queue view (tools/prof_streams.py, profiles/r05_streams_*.txt) shows the main queue idle for the whole
-    # duration of the prediction network, once per direction.  A slice per encoder block keeps both queues fed.
+    # Its recurrence is ~2 x U1 tiny launches per direction on a stream of its own.  Queued in one go, a host that is slower than the GPU
+    # (under rocprofv3: tools/prof_streams.py, profiles/r05_streams_single_slices0.txt) blocks in hipLaunchKernel on that stream's full launch
+    # queue and starves the ENCODER's stream meanwhile - the main queue idles for the whole duration of the prediction network, once per
+    # direction, 21 % of the traced span.  A slice per encoder block keeps both queues fed: traced span 155 -> 128 ms for six steps.
+    # Unprofiled the host runs ~3 steps ahead of the GPU (6.5 ms of pure host time per 21.7-ms step), so the gain there is small:
+    # 21.75 -> 21.68 ms/step (two interleaved pairs, profiles/r05_dp_queue_sweep.txt).  TFASR_PRED_SLICES=0: in one go.
     def _pred_nslices(self, U1):
         n = int(os.environ.get("TFASR_PRED_SLICES", "8"))
         return max(1, min(n, U1))
@@ -1256,7 +1277,21 @@ class ConformerTransducer(BaseModel):
         # gets its front end BEFORE the ~170 launches of the prediction network go to the second stream.
         if training and masks is None:
             masks = self.draw_specaugment([-(-int(n) // self.cfg.frame_step) for n in slen])
-        feats, flen = self.frontend(sig, slen, training, masks)
+        # The front end (log-mel + SpecAugment) reads nothing a previous step wrote - no parameters, only this batch's samples - so it does
+        # not have to queue behind the previous step's tail on the main stream (subsampling backward + optimizer, ~1.8 ms): it goes to the
+        # prediction network's stream, idle at this point, and the main stream picks the features up (round 5; TFASR_FRONT_EARLY=0: in line).
+        # Only when the CALLER says its batches are complete in HBM before train_step is called (`prefetched_inputs`, what a double-buffered
+        # input pipeline - the reference's tf.data prefetch - provides and what bench.py does): a batch still being produced by earlier work
+        # on the current stream would otherwise be read too early.
+        if (self.prefetched_inputs and self.use_pred_stream and os.environ.get("TFASR_FRONT_EARLY", "1") != "0"
+                and inputs.inputs.device.type == "cuda" and inputs.inputs.device == sig.device):
+            sig.record_stream(self.pred_stream)
+            with torch.cuda.stream(self.pred_stream):
+                feats, flen = self.frontend(sig, slen, training, masks)
+            main.wait_stream(self.pred_stream)
+            feats.record_stream(main)
+        else:
+            feats, flen = self.frontend(sig, slen, training, masks)
         self._side_gen = None
         if self.use_pred_stream:
             self.pred_stream.wait_stream(main)
