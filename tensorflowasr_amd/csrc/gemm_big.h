@@ -43,10 +43,17 @@ __device__ __forceinline__ short8_t frag_trans_big(const char* sB, uint32_t tb, 
   return v;
 }
 
-template <bool TB, int BN_, int EPI, bool SEG>
+// TR (round 5): TRANSPOSED accumulators - the two fragments of every MFMA swap their operand slots (A and B fragments have the same
+// register layout: lane (r, g) = row / column r, k group g), so the product comes out as D^T: lane (r, g) of fragment (i, j) then holds
+// FOUR CONSECUTIVE COLUMNS j*16 + g*4 + e of ONE row i*16 + r.  The main loop (LDS images, DMA, schedule) is untouched; the epilogue stores
+// 8-byte pieces of a row straight from the accumulators - no LDS transposition strip, whose round trips bounded the row-oriented epilogue
+// (25-30 k of a tile's ~67 k clocks) - and the log-softmax statistics of a row are in-lane work plus two cross-row-group shuffles.
+template <bool TB, int BN_, int EPI, bool SEG, bool TR = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void gemm_big_kernel(const tfasr_gemm_args p, const int gx, const int gy, const int ntiles) {
   constexpr bool C_LSE = (EPI & E_LSE) != 0;
+  static_assert(!TR || (BN_ == 256 && (EPI & ~(E_LSE | E_DACT)) == 0), "transposed accumulators: 256 columns; plain / log-softmax / tanh-out epilogues");
+  static_assert(!TR || !((EPI & E_LSE) && (EPI & E_DACT)), "statistics and tanh-out never meet");
   // where the DMA pieces of the next slab are issued inside the fragment-read segments: 0 = in front of the reads, 2 = behind them (the
   // reads' latency then runs under the pieces' issue time: k-strided B, whose 16 transposing reads per k half make that segment the long
   // one, 878 -> 832 us on the joint projection; k-contiguous B measured 1 % slower), 1 = every piece between the MFMAs instead (probe
@@ -247,7 +254,8 @@ void gemm_big_kernel(const tfasr_gemm_args p, const int gx, const int gy, const 
       for (int i = 0; i < NI; ++i) {
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-          if (j < 8) mfma_acc<true>(acc[i][j], af[i], bf[j]); else mfma_acc<false>(acc[i][j], af[i], bf[j]);  // BN 320: 128 + 32
+          if constexpr (TR) mfma_acc<true>(acc[i][j], bf[j], af[i]);  // D^T: rows = this fragment's 16 columns, columns = its 16 rows
+          else if (j < 8) mfma_acc<true>(acc[i][j], af[i], bf[j]); else mfma_acc<false>(acc[i][j], af[i], bf[j]);  // BN 320: 128 + 32
         }
         if (dma) dma_a(cur, i, da, dst);  // uniform: a scalar branch around one instruction (NA == NI pieces, one per fragment row)
         if (dmab) {
@@ -325,6 +333,219 @@ void gemm_big_kernel(const tfasr_gemm_args p, const int gx, const int gy, const 
 #else
 #define EPI_TICK(k)
 #endif
+    // ---- epilogue, transposed accumulators ----
+    if constexpr (TR) {
+      const int m0 = cur.m0s, mlo = cur.m0, n0 = cur.n0;
+      bf16_t* Dt = (bf16_t*)p.D;
+      int le = lane;
+      asm volatile("" : "+v"(le));  // opaque per tile (see tile_of)
+      const int r = le & 15, g = le >> 4;
+      const int cb = cur.n0s + wn * WNC;          // first column of this wave
+      const int c0l = cb + g * 4;                 // this lane's first column in fragment 0 (fragment j: + 16 j)
+      const bool vec_ok = ((p.ldd & 3) == 0) && ((((uintptr_t)p.D) & 7) == 0) && ((p.N & 3) == 0);
+      const bool vec16_ok = ((p.ldd & 7) == 0) && ((((uintptr_t)p.D) & 15) == 0) && ((p.N & 7) == 0) && (NJ % 2 == 0);  // (uniform)
+      // bias of the tile's 256 columns in LDS (the strip region of the row-oriented epilogue is free here; a column past N carries -inf
+      // into the statistics): 32 registers per lane less than holding this lane's 4 x 8 values across the four fragment blocks
+      float* sBias = reinterpret_cast<float*>(smem + 2 * STAGE);
+      if constexpr (!ALIAS) {
+        if (threadIdx.x < BN_) {
+          const int col = cur.n0s + (int)threadIdx.x;
+          sBias[threadIdx.x] = col < p.N ? (p.bias ? p.bias[col] : 0.f) : (C_LSE ? -INFINITY : 0.f);
+        }
+        __syncthreads();
+      }
+      const float* sb = sBias + wn * WNC + g * 4;
+      int lab[NI];
+      if constexpr (C_LSE) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+          const int rw = m0 + wm * 64 + i * 16 + r;
+          lab[i] = rw < p.M ? p.row_label[rw] : -1;
+        }
+      }
+      EPI_TICK(0)
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        __builtin_amdgcn_sched_barrier(0);
+        const int row = m0 + wm * 64 + i * 16 + r;
+        const bool rok = row >= mlo && row < p.M;
+        if constexpr (!C_LSE) {
+          // no row statistics: one fragment PAIR at a time (8 values live, not the wave's 32-40 - the 320-column kernel has no register to spare)
+          bf16_t* drow = Dt + (long)row * p.ldd;
+          const bool odd = (g & 1) != 0;
+          uint2 zr[(EPI & E_DACT) ? NJ : 1];
+          if constexpr ((EPI & E_DACT) != 0) {  // dact = TANH_OUT: times 1 - h^2, h = the activation's output (row-major like D): this lane's 4 columns per fragment
+            const bf16_t* hz = (const bf16_t*)p.dact_z + (long)row * p.ldd;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+              const int col = c0l + j * 16;
+              zr[j] = make_uint2(0u, 0u);
+              if (rok && col + 4 <= p.N) zr[j] = *reinterpret_cast<const uint2*>(hz + col);  // (ldd, N multiples of 8: launch condition of TR)
+            }
+          }
+#pragma unroll
+          for (int jp = 0; jp < NJ; jp += 2) {
+            float xp[2][4];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+              const int j = jp + q;
+              float bj[4];
+              if constexpr (!ALIAS) {
+                const float4 b4 = *reinterpret_cast<const float4*>(sb + j * 16);
+                bj[0] = b4.x; bj[1] = b4.y; bj[2] = b4.z; bj[3] = b4.w;
+              } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bj[e] = (p.bias && c0l + j * 16 + e < p.N) ? p.bias[c0l + j * 16 + e] : 0.f;
+              }
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                float v;
+                if (j < 8) asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(acc[i][j][e]));
+                else v = acc[i][j][e];
+                xp[q][e] = p.alpha * v + bj[e];
+              }
+              if constexpr ((EPI & E_DACT) != 0) {
+                const float z0 = __uint_as_float(zr[j].x << 16), z1 = __uint_as_float(zr[j].x & 0xffff0000u);
+                const float z2 = __uint_as_float(zr[j].y << 16), z3 = __uint_as_float(zr[j].y & 0xffff0000u);
+                xp[q][0] *= 1.f - z0 * z0; xp[q][1] *= 1.f - z1 * z1; xp[q][2] *= 1.f - z2 * z2; xp[q][3] *= 1.f - z3 * z3;
+              }
+            }
+            uint2 a, b;
+            a.x = pack2_bf16(xp[0][0], xp[0][1]); a.y = pack2_bf16(xp[0][2], xp[0][3]);
+            b.x = pack2_bf16(xp[1][0], xp[1][1]); b.y = pack2_bf16(xp[1][2], xp[1][3]);
+            if (vec16_ok) {
+              const uint2 send = odd ? a : b;
+              uint2 recv;
+              recv.x = (uint32_t)__shfl_xor((int)send.x, 16, 64);
+              recv.y = (uint32_t)__shfl_xor((int)send.y, 16, 64);
+              const uint4 out = odd ? make_uint4(recv.x, recv.y, b.x, b.y) : make_uint4(a.x, a.y, recv.x, recv.y);
+              const int col = cb + (odd ? (jp + 1) * 16 + (g - 1) * 4 : jp * 16 + g * 4);
+              if (rok && col >= n0 && col < p.N) *reinterpret_cast<uint4*>(drow + col) = out;
+            } else if (rok) {
+#pragma unroll
+              for (int q = 0; q < 2; ++q) {
+                const int col = c0l + (jp + q) * 16;
+                const uint2 v = q ? b : a;
+                if (col >= n0) {
+                  if (vec_ok) { if (col < p.N) *reinterpret_cast<uint2*>(drow + col) = v; }
+                  else {
+                    const bf16_t h4[4] = {(bf16_t)(v.x & 0xffffu), (bf16_t)(v.x >> 16), (bf16_t)(v.y & 0xffffu), (bf16_t)(v.y >> 16)};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                      if (col + e < p.N) drow[col + e] = h4[e];
+                  }
+                }
+              }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          continue;
+        }
+        float x[NJ][4];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          float bj[4];
+          if constexpr (!ALIAS) {
+            const float4 b4 = *reinterpret_cast<const float4*>(sb + j * 16);  // (16-byte aligned: wave offset + 4 g + 16 j floats)
+            bj[0] = b4.x; bj[1] = b4.y; bj[2] = b4.z; bj[3] = b4.w;
+          } else {  // BN 320: the stages fill the LDS; its products (the joint's data gradient) carry no bias
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bj[e] = (p.bias && c0l + j * 16 + e < p.N) ? p.bias[c0l + j * 16 + e] : 0.f;
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float v;
+            if (j < 8) asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(acc[i][j][e]));
+            else v = acc[i][j][e];
+            x[j][e] = p.alpha * v + bj[e];
+          }
+        }
+        if constexpr (C_LSE) {
+          const float L2E = 1.4426950408889634f;
+          // one reference maximum of the row over this wave's 128 columns: in-lane over 32 values, then over the four lanes (r, g = 0..3)
+          float m = x[0][0];
+#pragma unroll
+          for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) m = fmaxf(m, x[j][e]);
+          m = fmaxf(m, __shfl_xor(m, 16, 64));
+          m = fmaxf(m, __shfl_xor(m, 32, 64));
+          const float mb = (m == -INFINITY) ? 0.f : m * L2E;
+          float ssum[2] = {0.f, 0.f};
+#pragma unroll
+          for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ssum[j >> 2] += __builtin_amdgcn_exp2f(x[j][e] * L2E - mb);
+#pragma unroll
+          for (int sl = 0; sl < 2; ++sl) {
+            ssum[sl] += __shfl_xor(ssum[sl], 16, 64);
+            ssum[sl] += __shfl_xor(ssum[sl], 32, 64);
+          }
+          if (rok) {
+            // lane g = 0 / 1 stores the (max, sum) pair of slice 0 / 1 of its row
+            const int slice = (cb >> 6) + g;
+            if (g < 2 && slice < p.lse_parts) reinterpret_cast<float2*>(p.lse_part)[(long)row * p.lse_parts + slice] = make_float2(m, g == 0 ? ssum[0] : ssum[1]);
+            if (cb == 0 && g == 0) p.pick[2L * row] = x[0][0];  // the blank logit (column 0)
+            const int d = lab[i] - c0l;  // the label's column is this lane's element (d >> 4, d & 3) when d & 15 < 4
+            if (d >= 0 && d < WNC && (d & 15) < 4) {
+              float ve[4];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                ve[e] = x[0][e];
+#pragma unroll
+                for (int j = 1; j < NJ; ++j) ve[e] = ((d >> 4) == j) ? x[j][e] : ve[e];
+              }
+              const int de = d & 3;
+              p.pick[2L * row + 1] = de == 0 ? ve[0] : (de == 1 ? ve[1] : (de == 2 ? ve[2] : ve[3]));
+            }
+          }
+        }
+        EPI_TICK(1)
+        if constexpr (C_LSE) { if (!Dt) continue; }  // statistics-only projection
+        if (vec16_ok) {
+          // 16-byte stores: the lanes (r, g) and (r, g ^ 1) trade one packed fragment piece (two dwords through the cross-lane network), so
+          // that an even g ends up with EIGHT consecutive columns of fragment jp and an odd g with eight of fragment jp + 1: four store
+          // instructions per 16-row block, each writing 64 contiguous bytes of 16 rows (8-byte pieces were 32 instructions per block and
+          // the vector-memory path's issue time - one instruction per 16 cache lines - was what the first version of this epilogue ran at)
+          bf16_t* drow = Dt + (long)row * p.ldd;
+          const bool odd = (g & 1) != 0;
+#pragma unroll
+          for (int jp = 0; jp < NJ; jp += 2) {
+            uint2 a, b;
+            a.x = pack2_bf16(x[jp][0], x[jp][1]); a.y = pack2_bf16(x[jp][2], x[jp][3]);
+            b.x = pack2_bf16(x[jp + 1][0], x[jp + 1][1]); b.y = pack2_bf16(x[jp + 1][2], x[jp + 1][3]);
+            const uint2 send = odd ? a : b;
+            uint2 recv;
+            recv.x = (uint32_t)__shfl_xor((int)send.x, 16, 64);
+            recv.y = (uint32_t)__shfl_xor((int)send.y, 16, 64);
+            const uint4 out = odd ? make_uint4(recv.x, recv.y, b.x, b.y) : make_uint4(a.x, a.y, recv.x, recv.y);
+            const int col = cb + (odd ? (jp + 1) * 16 + (g - 1) * 4 : jp * 16 + g * 4);
+            if (rok && col >= n0 && col < p.N) *reinterpret_cast<uint4*>(drow + col) = out;
+          }
+        } else if (rok) {
+          bf16_t* drow = Dt + (long)row * p.ldd;
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) {
+            const int col = c0l + j * 16;
+            if (col >= n0) {  // (columns below n0 belong to the previous tile of a shifted last column tile: never with k-strided B)
+              if (vec_ok) {
+                if (col < p.N) {
+                  uint2 v;
+                  v.x = pack2_bf16(x[j][0], x[j][1]);
+                  v.y = pack2_bf16(x[j][2], x[j][3]);
+                  *reinterpret_cast<uint2*>(drow + col) = v;
+                }
+              } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                  if (col + e < p.N) drow[col + e] = f32_to_bf16(x[j][e]);
+              }
+            }
+          }
+        }
+        EPI_TICK(2)
+      }
+    } else
     // ---- epilogue ----
     // Per 16-row fragment block: x = alpha * acc + bias in the MFMA C layout (lane (r, g): rows g*4+e, column j*16+r); the log-softmax
     // statistics are taken THERE - a row's 16 columns of one fragment sit in one 16-lane DPP row, so max / sum are register + DPP
@@ -544,24 +765,30 @@ int launch_big(const tfasr_gemm_args& a, bool generic, int need, bool tanh_out, 
   };
   constexpr int S256 = 2 * (256 * BK * 2 + 256 * BK * 2) + 8 * 8 * 68 * 4;
   constexpr int S320 = 2 * (256 * BK * 2 + 320 * BK * 2);
+  // transposed accumulators (the kernel's TR parameter; 16-byte stores straight from the accumulators): every variant whose output rows
+  // allow them (ldd % 8 == 0, N % 8 == 0, 16-byte aligned D); TFASR_BIG_TR=0 restores the row-oriented epilogues (A/B)
+  static const bool tr_on = !(getenv("TFASR_BIG_TR") && getenv("TFASR_BIG_TR")[0] == '0');
+  const bool tr = tr_on && (a.ldd & 7) == 0 && (a.N & 7) == 0 && (((uintptr_t)a.D) & 15) == 0;
   if (tanh_out) {
     if constexpr (TB) {
+      // (320 columns: the 160 accumulators leave no register for the transposed epilogue - measured at compile time: spill reloads inside
+      // the slab loop, each a vmcnt(0) that drains the DMA prefetch - so the 320-column kernels keep the row-oriented one)
       if (bn == 320) go(gemm_big_kernel<true, 320, E_DACT, false>, S320);
-      else go(gemm_big_kernel<true, 256, E_DACT, false>, S256);
+      else { if (tr) go(gemm_big_kernel<true, 256, E_DACT, false, true>, S256); else go(gemm_big_kernel<true, 256, E_DACT, false>, S256); }
     } else return TFASR_STATUS_UNSUPPORTED;
   } else if (bn == 320) {
     if constexpr (TB) go(gemm_big_kernel<true, 320, 0, false>, S320);
     else return TFASR_STATUS_UNSUPPORTED;
   } else if (a.lse_part) {
-    if constexpr (!TB) go(gemm_big_kernel<false, 256, E_LSE, false>, S256);
+    if constexpr (!TB) { if (tr || (tr_on && !a.D)) go(gemm_big_kernel<false, 256, E_LSE, false, true>, S256); else go(gemm_big_kernel<false, 256, E_LSE, false>, S256); }
     else return TFASR_STATUS_UNSUPPORTED;
   } else if (a.rgrad_coef) {
     if constexpr (!TB) go(gemm_big_kernel<false, 256, E_RGRAD, false>, S256);
     else return TFASR_STATUS_UNSUPPORTED;
   } else if (seg) {
-    go(gemm_big_kernel<TB, 256, 0, true>, S256);
+    if (tr) go(gemm_big_kernel<TB, 256, 0, true, true>, S256); else go(gemm_big_kernel<TB, 256, 0, true>, S256);
   } else {
-    go(gemm_big_kernel<TB, 256, 0, false>, S256);
+    if (tr) go(gemm_big_kernel<TB, 256, 0, false, true>, S256); else go(gemm_big_kernel<TB, 256, 0, false>, S256);
   }
   TFASR_CHECK_LAUNCH();
   return TFASR_STATUS_SUCCESS;

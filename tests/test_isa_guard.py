@@ -85,7 +85,7 @@ def test_no_compiler_made_vmcnt_wait_inside_the_slab_loop(asm, frag):
 # compiler build a register window: 28 v_accvgpr_mov + 4 v_accvgpr_write per fragment block; and fmaxf on a DPP-moved value costs three
 # instructions per reduction step instead of one v_max_f32_dpp (common.h row16_max).
 def test_gemm_big_epilogue_reads_accumulators_in_place(asm):
-    body = _body(asm, "gemm_big_kernelILb0ELi256ELi64ELb0E")
+    body = _body(asm, "gemm_big_kernelILb0ELi256ELi64ELb0ELb0E")  # the row-oriented variant (TFASR_BIG_TR=0)
     last_mfma = max(i for i, l in enumerate(body) if "v_mfma_f32_16x16x32" in l)
     epi = body[last_mfma:]
     n_mov = sum("v_accvgpr_mov_b32" in l for l in epi)
@@ -97,6 +97,20 @@ def test_gemm_big_epilogue_reads_accumulators_in_place(asm):
     # the canonicalising `v_max_f32 vN, vN, vN` of llvm.maxnum on a DPP-moved value must be gone
     canon = [l for l in epi if re.match(r"\s*v_max_f32_e32 (v\d+), (v\d+), (v\d+)\s*$", l) and len(set(re.findall(r"v\d+", l)[1:])) == 1]
     assert len(canon) <= 2, canon[:4]
+
+
+def test_gemm_big_transposed_epilogue_stores_from_the_accumulators(asm):
+    """Round 5: the joint projection's default kernel keeps its accumulators TRANSPOSED (operand slots of every MFMA swapped), so a lane owns
+    four consecutive columns of one row: the epilogue reads the 128 accumulators in place, stores 8-byte row pieces straight from registers
+    and never writes a transposition strip to LDS (only the tile's bias vector), and nothing is spilled."""
+    body = _body(asm, "gemm_big_kernelILb0ELi256ELi64ELb0ELb1E")
+    last_mfma = max(i for i, l in enumerate(body) if "v_mfma_f32_16x16x32" in l)
+    epi = body[last_mfma:]
+    assert sum("v_accvgpr_mov_b32" in l for l in epi) == 0
+    assert sum("v_accvgpr_read_b32" in l for l in epi) == 128
+    assert sum(bool(re.search(r"\bds_write", l)) for l in epi) <= 2, "an LDS strip is back in the transposed epilogue"
+    assert sum("global_store_dwordx4" in l for l in epi) >= 16, "the 16-byte row pieces are no longer stored from registers"
+    assert not any("scratch_" in l for l in body), "spill in the 256-row kernel (a scratch reload costs the DMA prefetch)"
 
 
 # ---------------------------------------------------------------------------------------------------------------------
