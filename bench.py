@@ -202,7 +202,7 @@ def pmc_traffic(flops_per_launch, J, V):
     the figure is looked up: the forward vocabulary projection is the plain NN gemm_fast launch whose WRITE_SIZE equals its
     output (cells x V bf16) - no other launch of the step writes that much from that kernel.  None if it was not profiled."""
     here = os.path.dirname(os.path.abspath(__file__))
-    path = next((q for q in (os.path.join(here, "profiles", f) for f in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")) if os.path.exists(q)), None)
+    path = next((q for q in (os.path.join(here, "profiles", f) for f in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")) if os.path.exists(q)), None)
     if path is None:
         return None
     rows = json.load(open(path))
@@ -680,37 +680,15 @@ def main():
                 out["roofline_by_time"] = wgrad_group_roofline(cfg, rows_list, dev, in_step=(ms_in, n_in, fl_in))
             except Exception as e:
                 out["roofline_by_time"] = {"value": None, "error": repr(e)[:200]}
-        if world == 1 and not args.no_extras and args.model == "M" and args.padding == "batch" and size == "LibriSpeech-shaped":
-            # BASELINE.md section 2 "report both": the same step with the reference's dataset-maximum padding (every utterance padded
-            # to 475 760 samples / 230 labels, datasets.py:342-365).  The packed lattice and the length-aware kernels make the
-            # padded LABEL positions free; the padded encoder frames are computed like the reference computes them.
-            try:
-                model.timers = None
-                rb = [make_batch(cfg, args.batch, seed=10 + 13 * i, padding="reference", size=size) for i in range(nb)]
-                rd = [to_train_data(b, dev) for b in rb]
-                torch.cuda.synchronize()  # (complete in HBM before the first step that reads them: model.prefetched_inputs)
-                for i in range(2):
-                    model.train_step(rd[i % nb])
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                nref = 10
-                for i in range(nref):
-                    model.train_step(rd[i % nb])
-                torch.cuda.synchronize()
-                dtr = (time.perf_counter() - t1) / nref
-                secs_r = float(np.mean([b["seconds"] for b in rb]))
-                out["reference_padding"] = {"ms_per_step": round(dtr * 1e3, 3), "value": round(secs_r / 3600.0 / dtr, 4), "unit": "audio-hours/sec",
-                                            "steps": nref, "padded_to": "475760 samples / 230 labels (datasets.py:342-365)"}
-                del rd, rb
-            except Exception as e:  # the headline number must still be reported
-                out["reference_padding"] = {"value": None, "error": repr(e)[:200]}
+        # (this leg runs BEFORE the reference-padding leg: behind it - other shapes, a differently filled allocator - the same ten steps
+        # measured 3 ms slower than as a run of their own, profiles/r05_ab/recompute_leg_order.txt)
         if world == 1 and not args.no_extras and args.model in ("M", "S") and not stub and dtype == torch.bfloat16:
             # SURVEY section 8(d) "report both": the joint + loss WITHOUT materialised lattice logits (statistics-only projection, gradient
             # epilogue on a re-computed logit tile; TFASR_JOINT_RECOMPUTE=1) next to the default materialised route, same batches
             try:
                 model.joint_recompute = True
                 model.timers, model.timer_work = {}, {}
-                for i in range(2):
+                for i in range(4):
                     one_step(i)
                 model.timers, model.timer_work = {}, {}
                 torch.cuda.synchronize()
@@ -735,6 +713,30 @@ def main():
             finally:
                 model.joint_recompute = False
                 model.timers = None
+        if world == 1 and not args.no_extras and args.model == "M" and args.padding == "batch" and size == "LibriSpeech-shaped":
+            # BASELINE.md section 2 "report both": the same step with the reference's dataset-maximum padding (every utterance padded
+            # to 475 760 samples / 230 labels, datasets.py:342-365).  The packed lattice and the length-aware kernels make the
+            # padded LABEL positions free; the padded encoder frames are computed like the reference computes them.
+            try:
+                model.timers = None
+                rb = [make_batch(cfg, args.batch, seed=10 + 13 * i, padding="reference", size=size) for i in range(nb)]
+                rd = [to_train_data(b, dev) for b in rb]
+                torch.cuda.synchronize()  # (complete in HBM before the first step that reads them: model.prefetched_inputs)
+                for i in range(2):
+                    model.train_step(rd[i % nb])
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                nref = 10
+                for i in range(nref):
+                    model.train_step(rd[i % nb])
+                torch.cuda.synchronize()
+                dtr = (time.perf_counter() - t1) / nref
+                secs_r = float(np.mean([b["seconds"] for b in rb]))
+                out["reference_padding"] = {"ms_per_step": round(dtr * 1e3, 3), "value": round(secs_r / 3600.0 / dtr, 4), "unit": "audio-hours/sec",
+                                            "steps": nref, "padded_to": "475760 samples / 230 labels (datasets.py:342-365)"}
+                del rd, rb
+            except Exception as e:  # the headline number must still be reported
+                out["reference_padding"] = {"value": None, "error": repr(e)[:200]}
         if world == 1 and not stub and not args.no_extras and not args.dp_hooks and args.model in ("M", "S") and dtype == torch.bfloat16:
             # the data-parallel route at one rank: what a rank of an N-GPU job runs, wire time excluded
             dpm = dp_route_line(["--model", args.model, "--batch", str(args.batch), "--padding", args.padding] + (["--workload", args.workload] if args.workload else []))

@@ -373,15 +373,20 @@ void gemm_big_kernel(const tfasr_gemm_args p, const int gx, const int gy, const 
           // no row statistics: one fragment PAIR at a time (8 values live, not the wave's 32-40 - the 320-column kernel has no register to spare)
           bf16_t* drow = Dt + (long)row * p.ldd;
           const bool odd = (g & 1) != 0;
-          uint2 zr[(EPI & E_DACT) ? NJ : 1];
-          if constexpr ((EPI & E_DACT) != 0) {  // dact = TANH_OUT: times 1 - h^2, h = the activation's output (row-major like D): this lane's 4 columns per fragment
-            const bf16_t* hz = (const bf16_t*)p.dact_z + (long)row * p.ldd;
+          // dact = TANH_OUT: times 1 - h^2, h = the activation's output (row-major like D): this lane's 4 columns per fragment, requested ZP
+          // fragments ahead of their use (all of them at 256 columns; two at 320, whose 160 accumulators leave no room for ten pairs)
+          constexpr int ZP = (EPI & E_DACT) ? (BN_ == 256 ? NJ : 4) : 1;
+          uint2 zr[ZP];
+          const bf16_t* hz = (EPI & E_DACT) ? (const bf16_t*)p.dact_z + (long)row * p.ldd : nullptr;
+          auto zload = [&](int j) {
+            const int col = c0l + j * 16;
+            uint2 v = make_uint2(0u, 0u);
+            if (rok && col + 4 <= p.N) v = *reinterpret_cast<const uint2*>(hz + col);  // (ldd, N multiples of 8: launch condition of TR)
+            return v;
+          };
+          if constexpr ((EPI & E_DACT) != 0) {
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-              const int col = c0l + j * 16;
-              zr[j] = make_uint2(0u, 0u);
-              if (rok && col + 4 <= p.N) zr[j] = *reinterpret_cast<const uint2*>(hz + col);  // (ldd, N multiples of 8: launch condition of TR)
-            }
+            for (int j = 0; j < ZP && j < NJ; ++j) zr[j] = zload(j);
           }
 #pragma unroll
           for (int jp = 0; jp < NJ; jp += 2) {
@@ -405,8 +410,10 @@ void gemm_big_kernel(const tfasr_gemm_args p, const int gx, const int gy, const 
                 xp[q][e] = p.alpha * v + bj[e];
               }
               if constexpr ((EPI & E_DACT) != 0) {
-                const float z0 = __uint_as_float(zr[j].x << 16), z1 = __uint_as_float(zr[j].x & 0xffff0000u);
-                const float z2 = __uint_as_float(zr[j].y << 16), z3 = __uint_as_float(zr[j].y & 0xffff0000u);
+                const uint2 zz = zr[j % ZP];
+                if (j + ZP < NJ) zr[j % ZP] = zload(j + ZP);  // (compile-time slot: the loops are unrolled)
+                const float z0 = __uint_as_float(zz.x << 16), z1 = __uint_as_float(zz.x & 0xffff0000u);
+                const float z2 = __uint_as_float(zz.y << 16), z3 = __uint_as_float(zz.y & 0xffff0000u);
                 xp[q][0] *= 1.f - z0 * z0; xp[q][1] *= 1.f - z1 * z1; xp[q][2] *= 1.f - z2 * z2; xp[q][3] *= 1.f - z3 * z3;
               }
             }
@@ -771,8 +778,9 @@ int launch_big(const tfasr_gemm_args& a, bool generic, int need, bool tanh_out, 
   const bool tr = tr_on && (a.ldd & 7) == 0 && (a.N & 7) == 0 && (((uintptr_t)a.D) & 15) == 0;
   if (tanh_out) {
     if constexpr (TB) {
-      // (320 columns: the 160 accumulators leave no register for the transposed epilogue - measured at compile time: spill reloads inside
-      // the slab loop, each a vmcnt(0) that drains the DMA prefetch - so the 320-column kernels keep the row-oriented one)
+      // (320 columns: the 160 accumulators leave no register for the transposed epilogue - seen at compile time, also with the tanh-out
+      // operand requested only two fragments ahead: two spill reloads land INSIDE the slab loop, each followed by a vmcnt(0) that drains
+      // the DMA prefetch - so the 320-column kernels keep the row-oriented epilogue; tests/test_isa_guard.py watches for scratch traffic)
       if (bn == 320) go(gemm_big_kernel<true, 320, E_DACT, false>, S320);
       else { if (tr) go(gemm_big_kernel<true, 256, E_DACT, false, true>, S256); else go(gemm_big_kernel<true, 256, E_DACT, false>, S256); }
     } else return TFASR_STATUS_UNSUPPORTED;
