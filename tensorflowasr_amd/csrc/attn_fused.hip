@@ -1458,6 +1458,273 @@ __global__ __launch_bounds__(256, 2) void relattn_fused_bwd_q_kernel(
 
 
 // ======================================================================================================================
+// Backward, part 1 in TRANSPOSED orientation (round 5; the query-gradient kernel of the default route, tfasr_relattn_fused_bwd_q3).
+// Everything is computed as in relattn_fused_fwdT_kernel: S^T = K (Q+u)^T, dP^T = V dO^T (rows = keys, dealt to the MFMA tiles so that a
+// lane's eight values of a 32-key group are eight CONSECUTIVE keys; column = the lane's ONE query row), so
+//   * the per-row quantities (lse_i, D_i, the bias-row share of the score gradient, the validity thresholds) are per-lane scalars;
+//   * dS^T in the C layout IS the B operand of dq_u^T += K^T dS^T - the dS A-image of the row-oriented kernel (16 two-byte LDS stores and
+//     two fragment reads per lane and key block) is gone, and the unskewed dS leaves for HBM as two 16-byte stores straight from registers;
+//   * the window scores G^T are written with one 16-byte LDS store per tile and read back as four consecutive floats (they were 24 + 16
+//     four-byte accesses); only the SKEWED score gradient (dq_v^T += window^T dG^T needs dS against the window column, not the key) still
+//     goes through a per-wave LDS image, and that image lies over the dead G^T strip: 53.5 KB of LDS per workgroup instead of 65.
+// Per lane and key block: ~34 LDS instructions instead of ~84.  Same arithmetic per (query, key) pair as relattn_fused_bwd_q_kernel<true, true>.
+// ======================================================================================================================
+constexpr int SMEM_BWD_QT = SK_BYTES + SV_BYTES + SP_BYTES + 4 * SGTT_BYTES;
+static_assert(16 * 128 * 2 <= SGTT_BYTES, "the skewed dS image lies over the wave's G^T strip");
+
+template <bool STREAM>
+__global__ __launch_bounds__(256, 2) void relattn_fused_bwd_qT_kernel(
+    const bf16_t* __restrict__ qkv, const float* __restrict__ ubias, const float* __restrict__ vbias,
+    const bf16_t* __restrict__ pext, const int32_t* __restrict__ lengths, const bf16_t* __restrict__ o,
+    const bf16_t* __restrict__ dout, const float* __restrict__ lse, bf16_t* __restrict__ dq, bf16_t* __restrict__ dpos,
+    float* __restrict__ dvec, int B, int H, int T, int ldp, float scale, int use_mask, float* __restrict__ dpext,
+    long lddq, float* __restrict__ du, float* __restrict__ dv, int chunk, int hist, bf16_t* __restrict__ qu_out, bf16_t* __restrict__ qv_out) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sK = smem;              // [64 j][64 dh] row-major: rows = A operand of S^T, transposed = A operand of dq_u^T
+  char* sV = sK + SK_BYTES;     // [64 j][64 dh] row-major: rows = A operand of dP^T
+  char* sP = sV + SV_BYTES;     // window rows (row 127 = the bias row): rows = A operand of G^T, transposed = A operand of dq_v^T
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  float* sG = reinterpret_cast<float*>(sP + SP_BYTES + w * SGTT_BYTES);  // [16 il][80]: window columns 48-16w .. 127-16w; then [16] bias-row scores
+  float* sGb = sG + 16 * GLDT;
+  char* sAg = reinterpret_cast<char*>(sG);  // skewed dS image [16 il][128 c] bf16 (256-B rows, 16-B chunk ^= key_d(il)), over the strip once it is read
+  const int r = lane & 15, g = lane >> 4;
+  const BlockId bid = attn_block_id(B, H, (T + BI - 1) / BI);
+  if (!bid.ok) return;
+  const int b = bid.b, h = bid.h, i0 = bid.blk * BI;
+  const int HD = H * DH, LDQ = 3 * HD, R = 2 * T - 1, R1 = 2 * T;
+  const int len = lengths ? min(lengths[b], T) : T;
+  const int shift = T - len;
+  const bf16_t* qb = qkv + (long)b * T * LDQ + h * DH;
+  const bf16_t* kb = qb + HD;
+  const bf16_t* vb = qb + 2 * HD;
+  const bf16_t* pb = pext + h * DH;
+  uint4 bias_row = make_uint4(0, 0, 0, 0);
+  if ((threadIdx.x >> 6) == 0 && (threadIdx.x & 63) < 8) bias_row = *reinterpret_cast<const uint4*>(pb + (long)(2 * T - 1) * HD + (((threadIdx.x & 63) ^ key_d(127)) << 3));
+
+  const int i = i0 + w * 16 + r;  // this lane's query row
+  if (use_mask && i0 >= len) {
+    // a block of padded query rows: constant scores, dS = 0, zero query gradient (see relattn_fused_bwd_q_kernel)
+    if (i < T) {
+#pragma unroll
+      for (int n = 0; n < 4; ++n) *reinterpret_cast<uint2*>(dq + ((long)b * T + i) * lddq + h * DH + n * 16 + g * 4) = make_uint2(0u, 0u);
+    }
+    return;
+  }
+  const int irow = min(i, T - 1);
+  short8_t bqu[2], bqv[2], bdo[2];
+  float dpart = 0.f;
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) {
+    bqu[kk] = q_frag(qb + (long)irow * LDQ, ubias + h * DH, kk * 32 + g * 8);
+    bqv[kk] = q_frag(qb + (long)irow * LDQ, vbias + h * DH, kk * 32 + g * 8);
+    const bf16_t* dorow = dout + ((long)b * T + irow) * HD + h * DH + kk * 32 + g * 8;
+    const bf16_t* orow = o + ((long)b * T + irow) * HD + h * DH + kk * 32 + g * 8;
+    bdo[kk] = row_frag(dorow, 0);
+    float a[8], c[8];
+    ld8(dorow, a);
+    ld8(orow, c);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dpart += a[e] * c[e];
+  }
+  if (qu_out && i < T) {  // q + u / q + v of this block's rows for the key-side and table-gradient kernels (the fragments ARE those rows)
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      *reinterpret_cast<short8_t*>(qu_out + ((long)b * T + irow) * HD + h * DH + kk * 32 + g * 8) = bqu[kk];
+      *reinterpret_cast<short8_t*>(qv_out + ((long)b * T + irow) * HD + h * DH + kk * 32 + g * 8) = bqv[kk];
+    }
+  }
+  dpart += __shfl_xor(dpart, 16, 64);
+  dpart += __shfl_xor(dpart, 32, 64);  // D_i of this lane's query, in all four lanes of its column
+  if (g == 0 && i < T) dvec[((long)b * H + h) * T + i] = dpart;
+  const float Di = dpart;
+  const float scale2 = scale * 1.4426950408889634f;
+  const float lse2 = lse[((long)b * H + h) * T + irow] * 1.4426950408889634f;
+  const int lim = 2 * len - 1;
+  const bool inrow = i < T;
+  const bool live = inrow && !(use_mask && i >= len);
+  const int jthr = lim - (T - 1 - i);  // keys j < jthr: relative position T-1-i+j inside the sample's 2 len - 1 encodings
+  int klo = 0, khi = T;
+  if constexpr (STREAM) { if (live) stream_window(i, T, chunk, hist, klo, khi); }
+  if (!live) khi = 0;  // (no visible key: dS = 0 everywhere in this row)
+  const int gbase = r * GLDT + 15 - r;  // + jl = this lane's skewed strip column of key jl
+  int jl0[4], krow[4], goffA[4];
+#pragma unroll
+  for (int jt = 0; jt < 4; ++jt) {
+    jl0[jt] = 32 * (jt >> 1) + g * 8 + (jt & 1) * 4;
+    krow[jt] = 32 * (jt >> 1) + (r >> 2) * 8 + (jt & 1) * 4 + (r & 3);
+    goffA[jt] = 63 - w * 16 - r + jl0[jt];  // window column of the tile's first key for this query (+ e: consecutive)
+  }
+  float4_t acc_q[4], acc_v[4];  // dq_u^T / dq_v^T: rows = head dims n*16 + g*4 + e, column = this lane's query
+#pragma unroll
+  for (int n = 0; n < 4; ++n) { acc_q[n] = float4_t{0.f, 0.f, 0.f, 0.f}; acc_v[n] = float4_t{0.f, 0.f, 0.f, 0.f}; }
+  float bias_acc = 0.f;
+  bf16_t* dsrow = dpos + (((long)b * H + h) * T + irow) * ldp;
+  const int kk_lo = w < 2 ? 1 : 0;  // this wave's skew touches window columns 48-16w .. 126-16w: three of the four 32-column groups
+
+  const int njb = (T + BJ - 1) / BJ;
+  if (w == 0 && lane < 8) *reinterpret_cast<uint4*>(sP + 127 * 128 + lane * 16) = bias_row;  // window row 127 <- the bias row, once
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  for (int jb = 0; jb < njb; ++jb) {
+    const int j0 = jb * BJ;
+    const int pw0 = (T - 1 - (i0 + BI - 1) + j0) + shift;
+    load_rows<BJ>(sK, kb, LDQ, j0, T, w, lane);
+    load_rows<BJ>(sV, vb, LDQ, j0, T, w, lane);
+    load_rows<WIN, false, true>(sP, pb, HD, pw0, R1, w, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    float4_t acc_s[4], acc_p[4];
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) {
+      acc_s[jt] = float4_t{0.f, 0.f, 0.f, 0.f};
+      acc_p[jt] = float4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        acc_s[jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(sK, krow[jt], kk * 4 + g), bqu[kk], acc_s[jt], 0, 0, 0);
+        acc_p[jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(sV, krow[jt], kk * 4 + g), bdo[kk], acc_p[jt], 0, 0, 0);
+      }
+    }
+    // window scores, transposed: G^T[c][il]; this wave's skew needs window columns 48-16w .. 126-16w and column 127 (bias row)
+#pragma unroll
+    for (int gt = 0; gt < 8; ++gt) {
+      if (gt >= 3 - w && (gt <= 7 - w || gt == 7)) {
+        float4_t a = float4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(sP, gt * 16 + r, kk * 4 + g), bqv[kk], a, 0, 0, 0);
+        if (gt <= 7 - w) *reinterpret_cast<float4_t*>(sG + r * GLDT + (gt - (3 - w)) * 16 + g * 4) = a;
+        if (gt == 7 && g == 3) sGb[r] = a[3];
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    const float gbias = sGb[r];
+    float gv[4][4];
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) gv[jt][e] = sG[gbase + jl0[jt] + e];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // every score of the strip is in registers: the skewed image may overwrite it
+    // clear the skewed image (this wave's [16 x 128] bf16 strip)
+    {
+      const uint4 z4 = make_uint4(0, 0, 0, 0);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) *reinterpret_cast<uint4*>(sAg + (q * 64 + lane) * 16) = z4;
+    }
+    // dS^T in C layout (rows = this lane's keys jl0[jt] + e, column = its query)
+    short8_t pd[2];   // B fragments of dq_u^T: every visible pair
+    uint4 pz[2];      // the same with the pairs outside the sample's relative positions zeroed (their gradient goes to the bias row)
+    const int jhi = min(khi, T) - j0, jlo = klo - j0;  // visible keys of this row, block-relative
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) {
+      const int tr = jthr - j0 - jl0[jt];  // keys e < tr of this tile have a relative position inside the table
+      float d[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int jl = jl0[jt] + e;
+        const float pos = (e < tr) ? gv[jt][e] : gbias;
+        const float p = __builtin_amdgcn_exp2f((acc_s[jt][e] + pos) * scale2 - lse2);
+        const bool vis = jl >= jlo && jl < jhi;
+        d[e] = vis ? p * (acc_p[jt][e] - Di) * scale : 0.f;
+        if (e >= tr) bias_acc += d[e];  // (d = 0 for pairs that do not exist / are not visible)
+      }
+      const uint32_t lo = pack2_bf16(d[0], d[1]), hi = pack2_bf16(d[2], d[3]);
+      const uint32_t lz = pack2_bf16(0 < tr ? d[0] : 0.f, 1 < tr ? d[1] : 0.f), hz = pack2_bf16(2 < tr ? d[2] : 0.f, 3 < tr ? d[3] : 0.f);
+      const int o4 = (jt & 1) * 4;
+      pd[jt >> 1][o4 + 0] = (short)(lo & 0xffffu); pd[jt >> 1][o4 + 1] = (short)(lo >> 16);
+      pd[jt >> 1][o4 + 2] = (short)(hi & 0xffffu); pd[jt >> 1][o4 + 3] = (short)(hi >> 16);
+      if (jt & 1) { pz[jt >> 1].z = lz; pz[jt >> 1].w = hz; } else { pz[jt >> 1].x = lz; pz[jt >> 1].y = hz; }
+      // skewed image: window column c = goffA[jt] + e of image row r (the zeroed pairs stay zero)
+      const uint32_t zz[2] = {lz, hz};  // (the clear above lands first: one wave's LDS operations execute in order)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int c = goffA[jt] + e;
+        *reinterpret_cast<bf16_t*>(sAg + r * 256 + (((c >> 3) ^ key_d(r)) << 4) + (c & 7) * 2) = (bf16_t)((zz[e >> 1] >> ((e & 1) * 16)) & 0xffffu);
+      }
+    }
+    // unskewed dS -> HBM straight from registers: 8 consecutive keys per 32-key group
+    if (inrow) {
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int jc = j0 + 32 * q + g * 8;
+        if (jc < ldp) *reinterpret_cast<uint4*>(dsrow + jc) = pz[q];
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    // dq_u^T += K^T dS^T (A: the K block read transposed, k = key; B: dS^T from registers)
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int n = 0; n < 4; ++n)
+        acc_q[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_kt(sK, n * 16, q * 32 + g * 8, r), pd[q], acc_q[n], 0, 0, 0);
+    // dq_v^T += window^T dG^T (A: the window rows read transposed, k = window column; B: the skewed image, k = window column)
+#pragma unroll
+    for (int k3 = 0; k3 < 3; ++k3) {
+      const int kk = kk_lo + k3;
+      const short8_t bfr = *reinterpret_cast<const short8_t*>(sAg + r * 256 + (((kk * 4 + g) ^ key_d(r)) << 4));
+#pragma unroll
+      for (int n = 0; n < 4; ++n)
+        acc_v[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_kt(sP, n * 16, kk * 32 + g * 8, r), bfr, acc_v[n], 0, 0, 0);
+    }
+    __syncthreads();  // everyone is done with sK / sV / sP (and this wave with its strip) before the next block's DMA lands
+  }
+
+  // epilogue: dq = dq_u + dq_v (+ the bias row's share), du / dv column sums, the bias row of the table gradient
+  float bsum = bias_acc;
+  bsum += __shfl_xor(bsum, 16, 64);
+  bsum += __shfl_xor(bsum, 32, 64);
+  float su[4][4], sv[4][4];
+#pragma unroll
+  for (int n = 0; n < 4; ++n) {
+    const uint2 pr = *reinterpret_cast<const uint2*>(pb + (long)R * HD + n * 16 + g * 4);  // the bias row of the table, this lane's 4 head dims
+    const float pbias[4] = {__uint_as_float(pr.x << 16), __uint_as_float(pr.x & 0xffff0000u), __uint_as_float(pr.y << 16), __uint_as_float(pr.y & 0xffff0000u)};
+    float gq[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float gqv = acc_v[n][e] + bsum * pbias[e];
+      gq[e] = acc_q[n][e] + gqv;
+      su[n][e] = inrow ? acc_q[n][e] : 0.f;
+      sv[n][e] = inrow ? gqv : 0.f;
+    }
+    if (inrow) {
+      uint2 v;
+      v.x = pack2_bf16(gq[0], gq[1]);
+      v.y = pack2_bf16(gq[2], gq[3]);
+      *reinterpret_cast<uint2*>(dq + ((long)b * T + i) * lddq + h * DH + n * 16 + g * 4) = v;
+    }
+  }
+  // three column sums over the block's 64 rows: du = colsum(dq_u), dv = colsum(dq_v), and the bias row of the table gradient
+  // dpext[R] += sum_i bsum_i (q_i + v).  Over the 16 queries of a wave by DPP, over the 4 waves through LDS (the staged tiles are dead),
+  // then ONE 64-lane atomic instruction per sum and workgroup: the bias-row sum used to leave every wave as 16 four-lane atomics, and
+  // those ~50 k requests per launch onto the same eight cache lines serialised in the L2 for ~110 us - longer than the key loop.
+  __syncthreads();
+  float* red = reinterpret_cast<float*>(smem);  // [4 waves][3][64]
+#pragma unroll
+  for (int n = 0; n < 4; ++n)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float a = row16_sum(su[n][e]), c = row16_sum(sv[n][e]);
+      if (r == 0) { red[(w * 3 + 0) * 64 + n * 16 + g * 4 + e] = a; red[(w * 3 + 1) * 64 + n * 16 + g * 4 + e] = c; }
+    }
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {  // in the B-fragment indexing of bqv: head dim kk*32 + g*8 + t
+      float v = inrow ? bsum * bf16_to_f32((bf16_t)bqv[kk][t]) : 0.f;
+      v = row16_sum(v);
+      if (r == 0) red[(w * 3 + 2) * 64 + kk * 32 + g * 8 + t] = v;
+    }
+  __syncthreads();
+  if (threadIdx.x < 192) {
+    const int which = threadIdx.x >> 6, col = threadIdx.x & 63;
+    const float v = red[(0 * 3 + which) * 64 + col] + red[(1 * 3 + which) * 64 + col] + red[(2 * 3 + which) * 64 + col] + red[(3 * 3 + which) * 64 + col];
+    float* dst = which == 0 ? du + h * DH : which == 1 ? dv + h * DH : dpext + (long)R * HD + h * DH;
+    if (which < 2 || v != 0.f) atomicAdd(dst + col, v);
+  }
+}
+
+
 // Backward, part 3 (V2): the gradient of the projected position table,
 //   dpext[c, :] += sum_b sum_i dS_b[i, j(i,c)] * (q_i + v),     j(i,c) = (c - shift_b) - (T-1-i),   valid iff 0 <= c - shift_b < 2 len_b - 1
 // read from the UNSKEWED dS [B,H,T,lds].  Block = (128 table rows, head, group of samples); the 4 waves own 2 of the 8 16-row tiles
@@ -1890,6 +2157,21 @@ extern "C" int tfasr_relattn_fused_bwd_q3(const void* qkv, const float* ubias, c
     return TFASR_STATUS_INVALID_VALUE;
   if (dtype != TFASR_BF16 || dh != DH) return TFASR_STATUS_UNSUPPORTED;
   dim3 grid((T + BI - 1) / BI, H, B);
+  // transposed orientation (relattn_fused_bwd_qT_kernel, round 5); TFASR_ATTN_BWDQ_T=0: the row-oriented kernel (A/B)
+  const char* bwdq_env = getenv("TFASR_ATTN_BWDQ_T");  // (read per call: the comparison test flips it inside one process)
+  const bool bwdq_t = !(bwdq_env && bwdq_env[0] == '0');
+  if (bwdq_t && (lddq & 3) == 0 && (lds & 7) == 0) {
+    if (chunk > 0)
+      hipLaunchKernelGGL(relattn_fused_bwd_qT_kernel<true>, dim3(attn_grid_size(B, H, (int)grid.x)), dim3(256), SMEM_BWD_QT, (hipStream_t)stream_, (const bf16_t*)qkv, ubias, vbias,
+                         (const bf16_t*)pext, lengths, (const bf16_t*)o, (const bf16_t*)dout, lse, (bf16_t*)dq, (bf16_t*)ds, dvec, B, H, T, lds, scale,
+                         use_mask, dpext, lddq, du, dv, chunk, hist, (bf16_t*)qu, (bf16_t*)qv);
+    else
+      hipLaunchKernelGGL(relattn_fused_bwd_qT_kernel<false>, dim3(attn_grid_size(B, H, (int)grid.x)), dim3(256), SMEM_BWD_QT, (hipStream_t)stream_, (const bf16_t*)qkv, ubias, vbias,
+                         (const bf16_t*)pext, lengths, (const bf16_t*)o, (const bf16_t*)dout, lse, (bf16_t*)dq, (bf16_t*)ds, dvec, B, H, T, lds, scale,
+                         use_mask, dpext, lddq, du, dv, 0, 0, (bf16_t*)qu, (bf16_t*)qv);
+    TFASR_CHECK_LAUNCH();
+    return TFASR_STATUS_SUCCESS;
+  }
   if (chunk > 0)
     hipLaunchKernelGGL((relattn_fused_bwd_q_kernel<true, true, true>), dim3(attn_grid_size(B, H, (int)grid.x)), dim3(256), SMEM_BWD_Q, (hipStream_t)stream_, (const bf16_t*)qkv, ubias, vbias,
                        (const bf16_t*)pext, lengths, (const bf16_t*)o, (const bf16_t*)dout, lse, (bf16_t*)dq, (bf16_t*)ds, dvec, B, H, T, lds, scale,
