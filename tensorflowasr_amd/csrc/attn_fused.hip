@@ -11,7 +11,7 @@
 // Auto-mask semantics as in attention.hip: padded QUERY rows give uniform attention over all T keys; keys are never masked.
 #include "common.h"
 #ifdef TFASR_ATTN_TIMING
-__device__ long long g_attn_timing[5 * 8192];
+__device__ long long g_attn_timing[8 * 8192];
 #endif
 #include <algorithm>
 
@@ -32,7 +32,12 @@ constexpr int SG_BYTES = 16 * GLD * 4, SPB_BYTES = 16 * BJ * 2;
 constexpr int GLDC = 81, SGC_BYTES = 16 * GLDC * 4;
 constexpr int SMEM_FWD = SK_BYTES + SV_BYTES + SP_BYTES + 4 * SGC_BYTES;
 
-__device__ __forceinline__ int key_d(int row) { return (row >> 1) & 7; }
+// chunk swizzle of the 128-byte-row images: bits 0, 1 and 3 of the row.  With it the three ways these images are read are all free of
+// bank conflicts (tools/hwprobe/lds_sim.py): 16 consecutive rows per ds_read_b128 lane group, the key-dealt rows of the transposed kernels
+// (32q + 8a + o + b: rows 0-3, 8-11, 16-19, 24-27 in one group), and the transposed ds_read_b64_tr_b16 fragments (rows k..k+3 and k+8..k+11
+// in one 32-lane group).  The earlier (row >> 1) & 7 served only the first: 2-way conflicts on the other two, SQ_LDS_BANK_CONFLICT =
+// 0.49 / 0.43 of the LDS cycles of the query-backward / forward kernels.
+__device__ __forceinline__ int key_d(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
 __device__ __forceinline__ int key_t64(int k) { return (((k >> 1) & 1) | (((k >> 3) & 1) << 1)) << 1; }
 
 // One LDS-DMA piece through inline asm (see glds16 in gemm_fast.hip): for the builtin the compiler puts s_waitcnt vmcnt(0) in front of the
@@ -1469,11 +1474,19 @@ __global__ __launch_bounds__(256, 2) void relattn_fused_bwd_q_kernel(
 //     goes through a per-wave LDS image, and that image lies over the dead G^T strip: 53.5 KB of LDS per workgroup instead of 65.
 // Per lane and key block: ~34 LDS instructions instead of ~84.  Same arithmetic per (query, key) pair as relattn_fused_bwd_q_kernel<true, true>.
 // ======================================================================================================================
-constexpr int SMEM_BWD_QT = SK_BYTES + SV_BYTES + SP_BYTES + 4 * SGTT_BYTES;
-static_assert(16 * 128 * 2 <= SGTT_BYTES, "the skewed dS image lies over the wave's G^T strip");
+constexpr int QT_IMG_LD = 272;                       // byte stride of a row of the skewed dS image: 128 bf16 columns + 16 B (bank spread, no swizzle)
+constexpr int QT_IMG_BYTES = 16 * QT_IMG_LD;
+#ifndef TFASR_QT_ALIAS
+#define TFASR_QT_ALIAS 0
+#endif
+constexpr bool QT_ALIAS = TFASR_QT_ALIAS;   // the image over the wave's G^T strip (53.5 KB per workgroup, three per CU) or beside it (70.9 KB, two)
+static_assert(QT_IMG_BYTES <= 16 * GLDT * 4, "the skewed dS image fits under the bias scores of the strip");
+constexpr int SMEM_BWD_QT = SK_BYTES + SV_BYTES + SP_BYTES + 4 * SGTT_BYTES + (QT_ALIAS ? 0 : 4 * QT_IMG_BYTES);
+
+typedef float float2_t __attribute__((ext_vector_type(2)));
 
 template <bool STREAM>
-__global__ __launch_bounds__(256, 2) void relattn_fused_bwd_qT_kernel(
+__global__ __launch_bounds__(256, QT_ALIAS ? 3 : 2) void relattn_fused_bwd_qT_kernel(
     const bf16_t* __restrict__ qkv, const float* __restrict__ ubias, const float* __restrict__ vbias,
     const bf16_t* __restrict__ pext, const int32_t* __restrict__ lengths, const bf16_t* __restrict__ o,
     const bf16_t* __restrict__ dout, const float* __restrict__ lse, bf16_t* __restrict__ dq, bf16_t* __restrict__ dpos,
@@ -1486,7 +1499,9 @@ __global__ __launch_bounds__(256, 2) void relattn_fused_bwd_qT_kernel(
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   float* sG = reinterpret_cast<float*>(sP + SP_BYTES + w * SGTT_BYTES);  // [16 il][80]: window columns 48-16w .. 127-16w; then [16] bias-row scores
   float* sGb = sG + 16 * GLDT;
-  char* sAg = reinterpret_cast<char*>(sG);  // skewed dS image [16 il][128 c] bf16 (256-B rows, 16-B chunk ^= key_d(il)), over the strip once it is read
+  // skewed dS image [16 il][128 c] bf16 of this wave, rows QT_IMG_LD bytes apart.  Row il is WRITTEN at columns 63-16w-il .. 126-16w-il
+  // whatever the key block, so it is cleared once: the cells outside that range stay zero, the ones inside are rewritten every block.
+  char* sAg = QT_ALIAS ? reinterpret_cast<char*>(sG) : sP + SP_BYTES + 4 * SGTT_BYTES + w * QT_IMG_BYTES;
   const int r = lane & 15, g = lane >> 4;
   const BlockId bid = attn_block_id(B, H, (T + BI - 1) / BI);
   if (!bid.ok) return;
@@ -1547,13 +1562,14 @@ __global__ __launch_bounds__(256, 2) void relattn_fused_bwd_qT_kernel(
   if constexpr (STREAM) { if (live) stream_window(i, T, chunk, hist, klo, khi); }
   if (!live) khi = 0;  // (no visible key: dS = 0 everywhere in this row)
   const int gbase = r * GLDT + 15 - r;  // + jl = this lane's skewed strip column of key jl
-  int jl0[4], krow[4], goffA[4];
+  int jl0[4], krow[4];
 #pragma unroll
   for (int jt = 0; jt < 4; ++jt) {
     jl0[jt] = 32 * (jt >> 1) + g * 8 + (jt & 1) * 4;
     krow[jt] = 32 * (jt >> 1) + (r >> 2) * 8 + (jt & 1) * 4 + (r & 3);
-    goffA[jt] = 63 - w * 16 - r + jl0[jt];  // window column of the tile's first key for this query (+ e: consecutive)
   }
+  // image cell of this lane's key 8g of the block: window column 63-16w-r+8g; the keys of tile jt, element e are 32(jt>>1)+4(jt&1)+e further
+  char* const img = sAg + r * QT_IMG_LD + (63 - w * 16 - r + g * 8) * 2;
   float4_t acc_q[4], acc_v[4];  // dq_u^T / dq_v^T: rows = head dims n*16 + g*4 + e, column = this lane's query
 #pragma unroll
   for (int n = 0; n < 4; ++n) { acc_q[n] = float4_t{0.f, 0.f, 0.f, 0.f}; acc_v[n] = float4_t{0.f, 0.f, 0.f, 0.f}; }
@@ -1562,16 +1578,44 @@ __global__ __launch_bounds__(256, 2) void relattn_fused_bwd_qT_kernel(
   const int kk_lo = w < 2 ? 1 : 0;  // this wave's skew touches window columns 48-16w .. 126-16w: three of the four 32-column groups
 
   const int njb = (T + BJ - 1) / BJ;
-  if (w == 0 && lane < 8) *reinterpret_cast<uint4*>(sP + 127 * 128 + lane * 16) = bias_row;  // window row 127 <- the bias row, once
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  if (w == 0 && lane < 8) *reinterpret_cast<uint4*>(sP + 127 * 128 + lane * 16) = bias_row;  // window row 127 <- the bias row
+  if constexpr (!QT_ALIAS) {
+    const uint4 z4 = make_uint4(0, 0, 0, 0);
+    for (int q = lane; q < QT_IMG_BYTES / 16; q += 64) *reinterpret_cast<uint4*>(sAg + q * 16) = z4;
+  }
+  __syncthreads();
+  // the bias-row score of this lane's query, (q_i + v) . pext[R]: the same for every key block, so it is formed once (row 15 of the
+  // product of window rows 112..127 with the query fragments; the other fifteen rows of the image are not loaded yet and not looked at)
+  float gbias;
+  {
+    float4_t a = float4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      short8_t f = frag_rows(sP, 112 + r, kk * 4 + g);
+      if (r != 15) f = short8_t{0, 0, 0, 0, 0, 0, 0, 0};  // (stale LDS may hold NaN patterns: keep them out of the product)
+      a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f, bqv[kk], a, 0, 0, 0);
+    }
+    if (g == 3) sGb[r] = a[3];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    gbias = sGb[r];
+  }
+  const float Dis = Di * scale;
+#ifdef TFASR_ATTN_TIMING
+  long long ph[5] = {0, 0, 0, 0, 0};
+  const long long t_begin = __builtin_readcyclecounter();
+#endif
   for (int jb = 0; jb < njb; ++jb) {
     const int j0 = jb * BJ;
     const int pw0 = (T - 1 - (i0 + BI - 1) + j0) + shift;
+#ifdef TFASR_ATTN_TIMING
+    long long tp = __builtin_readcyclecounter();
+#endif
     load_rows<BJ>(sK, kb, LDQ, j0, T, w, lane);
     load_rows<BJ>(sV, vb, LDQ, j0, T, w, lane);
     load_rows<WIN, false, true>(sP, pb, HD, pw0, R1, w, lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    ATT_TICK(0)
 
     float4_t acc_s[4], acc_p[4];
 #pragma unroll
@@ -1584,62 +1628,84 @@ __global__ __launch_bounds__(256, 2) void relattn_fused_bwd_qT_kernel(
         acc_p[jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(sV, krow[jt], kk * 4 + g), bdo[kk], acc_p[jt], 0, 0, 0);
       }
     }
-    // window scores, transposed: G^T[c][il]; this wave's skew needs window columns 48-16w .. 126-16w and column 127 (bias row)
+    // window scores, transposed: G^T[c][il] for the 80 window columns 48-16w .. 127-16w this wave's skew reads (five 16-row tiles from
+    // window row 48-16w on: straight-line code, nothing depends on the wave but the row offset)
+    {
+      const int grow = (3 - w) * 16 + r;
 #pragma unroll
-    for (int gt = 0; gt < 8; ++gt) {
-      if (gt >= 3 - w && (gt <= 7 - w || gt == 7)) {
+      for (int t = 0; t < 5; ++t) {
         float4_t a = float4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
-          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(sP, gt * 16 + r, kk * 4 + g), bqv[kk], a, 0, 0, 0);
-        if (gt <= 7 - w) *reinterpret_cast<float4_t*>(sG + r * GLDT + (gt - (3 - w)) * 16 + g * 4) = a;
-        if (gt == 7 && g == 3) sGb[r] = a[3];
+          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(sP, grow + t * 16, kk * 4 + g), bqv[kk], a, 0, 0, 0);
+        *reinterpret_cast<float4_t*>(sG + r * GLDT + t * 16 + g * 4) = a;
       }
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    const float gbias = sGb[r];
+    // (no waits between the wave's own LDS writes and reads from here to the closing barrier: one wave's LDS operations execute in
+    // order, and the compiler counts the returns it needs - explicit lgkmcnt(0) fences here cost 3 exposed LDS round trips per key block)
+    ATT_TICK(1)
     float gv[4][4];
 #pragma unroll
     for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
       for (int e = 0; e < 4; ++e) gv[jt][e] = sG[gbase + jl0[jt] + e];
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // every score of the strip is in registers: the skewed image may overwrite it
-    // clear the skewed image (this wave's [16 x 128] bf16 strip)
-    {
+    if constexpr (QT_ALIAS) {  // every score of the strip is in registers: clear the image that lies over it (4352 B = 4.25 x 64 lanes x 16 B)
       const uint4 z4 = make_uint4(0, 0, 0, 0);
 #pragma unroll
       for (int q = 0; q < 4; ++q) *reinterpret_cast<uint4*>(sAg + (q * 64 + lane) * 16) = z4;
+      if (lane < 16) *reinterpret_cast<uint4*>(sAg + (256 + lane) * 16) = z4;
     }
     // dS^T in C layout (rows = this lane's keys jl0[jt] + e, column = its query)
     short8_t pd[2];   // B fragments of dq_u^T: every visible pair
     uint4 pz[2];      // the same with the pairs outside the sample's relative positions zeroed (their gradient goes to the bias row)
     const int jhi = min(khi, T) - j0, jlo = klo - j0;  // visible keys of this row, block-relative
+    const int trb = jthr - j0;                          // keys jl < trb of this block have a relative position inside the table
+    // the common key block - every key of it visible to and inside the table for every query of the wave - needs none of the selects
+    const bool plain = __builtin_amdgcn_ballot_w64(trb >= BJ && jlo <= 0 && jhi >= BJ) == ~0ull;
+    if (plain) {
 #pragma unroll
-    for (int jt = 0; jt < 4; ++jt) {
-      const int tr = jthr - j0 - jl0[jt];  // keys e < tr of this tile have a relative position inside the table
-      float d[4];
+      for (int jt = 0; jt < 4; ++jt) {
+        uint32_t pk[2];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int jl = jl0[jt] + e;
-        const float pos = (e < tr) ? gv[jt][e] : gbias;
-        const float p = __builtin_amdgcn_exp2f((acc_s[jt][e] + pos) * scale2 - lse2);
-        const bool vis = jl >= jlo && jl < jhi;
-        d[e] = vis ? p * (acc_p[jt][e] - Di) * scale : 0.f;
-        if (e >= tr) bias_acc += d[e];  // (d = 0 for pairs that do not exist / are not visible)
+        for (int h2 = 0; h2 < 2; ++h2) {
+          const float2_t sc = float2_t{acc_s[jt][2 * h2], acc_s[jt][2 * h2 + 1]} + float2_t{gv[jt][2 * h2], gv[jt][2 * h2 + 1]};
+          const float2_t ex = sc * scale2 - lse2;
+          const float2_t pp = float2_t{__builtin_amdgcn_exp2f(ex[0]), __builtin_amdgcn_exp2f(ex[1])};
+          const float2_t d2 = pp * (float2_t{acc_p[jt][2 * h2], acc_p[jt][2 * h2 + 1]} * scale - Dis);
+          pk[h2] = pack2_bf16(d2[0], d2[1]);
+        }
+        const int o4 = (jt & 1) * 4;
+        pd[jt >> 1][o4 + 0] = (short)(pk[0] & 0xffffu); pd[jt >> 1][o4 + 1] = (short)(pk[0] >> 16);
+        pd[jt >> 1][o4 + 2] = (short)(pk[1] & 0xffffu); pd[jt >> 1][o4 + 3] = (short)(pk[1] >> 16);
+        if (jt & 1) { pz[jt >> 1].z = pk[0]; pz[jt >> 1].w = pk[1]; } else { pz[jt >> 1].x = pk[0]; pz[jt >> 1].y = pk[1]; }
+        char* const cell = img + (32 * (jt >> 1) + 4 * (jt & 1)) * 2;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) *reinterpret_cast<bf16_t*>(cell + e * 2) = (bf16_t)((pk[e >> 1] >> ((e & 1) * 16)) & 0xffffu);
       }
-      const uint32_t lo = pack2_bf16(d[0], d[1]), hi = pack2_bf16(d[2], d[3]);
-      const uint32_t lz = pack2_bf16(0 < tr ? d[0] : 0.f, 1 < tr ? d[1] : 0.f), hz = pack2_bf16(2 < tr ? d[2] : 0.f, 3 < tr ? d[3] : 0.f);
-      const int o4 = (jt & 1) * 4;
-      pd[jt >> 1][o4 + 0] = (short)(lo & 0xffffu); pd[jt >> 1][o4 + 1] = (short)(lo >> 16);
-      pd[jt >> 1][o4 + 2] = (short)(hi & 0xffffu); pd[jt >> 1][o4 + 3] = (short)(hi >> 16);
-      if (jt & 1) { pz[jt >> 1].z = lz; pz[jt >> 1].w = hz; } else { pz[jt >> 1].x = lz; pz[jt >> 1].y = hz; }
-      // skewed image: window column c = goffA[jt] + e of image row r (the zeroed pairs stay zero)
-      const uint32_t zz[2] = {lz, hz};  // (the clear above lands first: one wave's LDS operations execute in order)
+    } else {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int c = goffA[jt] + e;
-        *reinterpret_cast<bf16_t*>(sAg + r * 256 + (((c >> 3) ^ key_d(r)) << 4) + (c & 7) * 2) = (bf16_t)((zz[e >> 1] >> ((e & 1) * 16)) & 0xffffu);
+      for (int jt = 0; jt < 4; ++jt) {
+        const int tr = trb - jl0[jt];  // keys e < tr of this tile have a relative position inside the table
+        float d[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int jl = jl0[jt] + e;
+          const float pos = (e < tr) ? gv[jt][e] : gbias;
+          const float p = __builtin_amdgcn_exp2f((acc_s[jt][e] + pos) * scale2 - lse2);
+          const bool vis = jl >= jlo && jl < jhi;
+          d[e] = vis ? p * (acc_p[jt][e] * scale - Dis) : 0.f;
+          if (e >= tr) bias_acc += d[e];  // (d = 0 for pairs that do not exist / are not visible)
+        }
+        const uint32_t lo = pack2_bf16(d[0], d[1]), hi = pack2_bf16(d[2], d[3]);
+        const uint32_t lz = pack2_bf16(0 < tr ? d[0] : 0.f, 1 < tr ? d[1] : 0.f), hz = pack2_bf16(2 < tr ? d[2] : 0.f, 3 < tr ? d[3] : 0.f);
+        const int o4 = (jt & 1) * 4;
+        pd[jt >> 1][o4 + 0] = (short)(lo & 0xffffu); pd[jt >> 1][o4 + 1] = (short)(lo >> 16);
+        pd[jt >> 1][o4 + 2] = (short)(hi & 0xffffu); pd[jt >> 1][o4 + 3] = (short)(hi >> 16);
+        if (jt & 1) { pz[jt >> 1].z = lz; pz[jt >> 1].w = hz; } else { pz[jt >> 1].x = lz; pz[jt >> 1].y = hz; }
+        const uint32_t zz[2] = {lz, hz};
+        char* const cell = img + (32 * (jt >> 1) + 4 * (jt & 1)) * 2;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) *reinterpret_cast<bf16_t*>(cell + e * 2) = (bf16_t)((zz[e >> 1] >> ((e & 1) * 16)) & 0xffffu);
       }
     }
     // unskewed dS -> HBM straight from registers: 8 consecutive keys per 32-key group
@@ -1650,8 +1716,7 @@ __global__ __launch_bounds__(256, 2) void relattn_fused_bwd_qT_kernel(
         if (jc < ldp) *reinterpret_cast<uint4*>(dsrow + jc) = pz[q];
       }
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
+    ATT_TICK(2)
     // dq_u^T += K^T dS^T (A: the K block read transposed, k = key; B: dS^T from registers)
 #pragma unroll
     for (int q = 0; q < 2; ++q)
@@ -1662,13 +1727,18 @@ __global__ __launch_bounds__(256, 2) void relattn_fused_bwd_qT_kernel(
 #pragma unroll
     for (int k3 = 0; k3 < 3; ++k3) {
       const int kk = kk_lo + k3;
-      const short8_t bfr = *reinterpret_cast<const short8_t*>(sAg + r * 256 + (((kk * 4 + g) ^ key_d(r)) << 4));
+      const short8_t bfr = *reinterpret_cast<const short8_t*>(sAg + r * QT_IMG_LD + (kk * 4 + g) * 16);
 #pragma unroll
       for (int n = 0; n < 4; ++n)
         acc_v[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_kt(sP, n * 16, kk * 32 + g * 8, r), bfr, acc_v[n], 0, 0, 0);
     }
+    ATT_TICK(3)
     __syncthreads();  // everyone is done with sK / sV / sP (and this wave with its strip) before the next block's DMA lands
+    ATT_TICK(4)
   }
+#ifdef TFASR_ATTN_TIMING
+  const long long t_loop = __builtin_readcyclecounter();
+#endif
 
   // epilogue: dq = dq_u + dq_v (+ the bias row's share), du / dv column sums, the bias row of the table gradient
   float bsum = bias_acc;
@@ -1722,6 +1792,13 @@ __global__ __launch_bounds__(256, 2) void relattn_fused_bwd_qT_kernel(
     float* dst = which == 0 ? du + h * DH : which == 1 ? dv + h * DH : dpext + (long)R * HD + h * DH;
     if (which < 2 || v != 0.f) atomicAdd(dst + col, v);
   }
+#ifdef TFASR_ATTN_TIMING
+  if (threadIdx.x == 0 && blockIdx.x < 8192) {  // [5 phase sums of wave 0][loop][epilogue][key blocks]
+    long long* o = g_attn_timing + 8L * blockIdx.x;
+    for (int kq = 0; kq < 5; ++kq) o[kq] = ph[kq];
+    o[5] = t_loop - t_begin; o[6] = __builtin_readcyclecounter() - t_loop; o[7] = njb;
+  }
+#endif
 }
 
 
@@ -2215,3 +2292,11 @@ extern "C" int tfasr_relattn_fused_bwd_k(const void* qkv, const void* qu, const 
   TFASR_CHECK_LAUNCH();
   return TFASR_STATUS_SUCCESS;
 }
+
+#ifdef TFASR_ATTN_TIMING
+// probe build only (tools/attn_timing.sh): per-workgroup phase clocks of the last instrumented attention launch
+extern "C" int tfasr_attn_timing_read(long long* out, int n) {
+  if (hipDeviceSynchronize() != hipSuccess) return 1;
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_attn_timing), sizeof(long long) * n) == hipSuccess ? 0 : 1;
+}
+#endif

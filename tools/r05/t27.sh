@@ -1,0 +1,14 @@
+#!/bin/bash
+# round 5, call 27: new LDS swizzle key of the attention images - attention tests, step, kernel times, conflict counters
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/r5_t27
+mkdir -p $O
+cd $R
+timeout 900 python -m pytest tests/test_attn_bwdq_t_gpu.py tests/test_model_gpu.py tests/test_ops_gpu.py -x -q -m gpu -k "attn or mhsa or stream or step or relattn or block" 2>&1 | tail -3
+B="--steps 20 --warmup 5 --no-cpu-baseline --no-extras"
+timeout 200 python bench.py $B > $O/new1.json 2>> $O/err
+echo "new: $(grep -o '"ms_per_step": [0-9.]*' $O/new1.json | head -1)"
+bash tools/prof_quick.sh r5_t27/prof > $O/prof.txt 2>&1
+grep -i "relattn" $O/prof.txt | cut -c1-40,100-170 | head
+bash tools/pmc_lds.sh > /dev/null 2>&1; cp gpurun_out/lds_conflicts.txt $O/lds.txt
+head -1 $O/lds.txt | cut -c1-200; grep relattn $O/lds.txt | cut -c1-200
