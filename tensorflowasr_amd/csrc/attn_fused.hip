@@ -1476,32 +1476,40 @@ __global__ __launch_bounds__(256, 2) void relattn_fused_bwd_q_kernel(
 // ======================================================================================================================
 constexpr int QT_IMG_LD = 272;                       // byte stride of a row of the skewed dS image: 128 bf16 columns + 16 B (bank spread, no swizzle)
 constexpr int QT_IMG_BYTES = 16 * QT_IMG_LD;
-#ifndef TFASR_QT_ALIAS
-#define TFASR_QT_ALIAS 0
+// QT_PIPE: the K block and the window are double buffered and the next key block's DMA is issued behind the barrier that opens the
+// current one (V, dead after the first products, is refetched behind a second barrier): 32 + 24 KB of tiles, so the image has to lie over
+// the wave's G^T strip again (cleared per key block) to keep two workgroups on a CU: 76.7 KB.
+#ifndef TFASR_QT_PIPE
+#define TFASR_QT_PIPE 1
 #endif
-constexpr bool QT_ALIAS = TFASR_QT_ALIAS;   // the image over the wave's G^T strip (53.5 KB per workgroup, three per CU) or beside it (70.9 KB, two)
+constexpr bool QT_PIPE = TFASR_QT_PIPE;
+constexpr bool QT_ALIAS = QT_PIPE;          // the image over the wave's G^T strip or beside it (70.9 KB per workgroup unpipelined)
 static_assert(QT_IMG_BYTES <= 16 * GLDT * 4, "the skewed dS image fits under the bias scores of the strip");
-constexpr int SMEM_BWD_QT = SK_BYTES + SV_BYTES + SP_BYTES + 4 * SGTT_BYTES + (QT_ALIAS ? 0 : 4 * QT_IMG_BYTES);
+constexpr int QT_TILE_BYTES = (QT_PIPE ? 2 : 1) * (SK_BYTES + SP_BYTES) + SV_BYTES;
+constexpr int SMEM_BWD_QT = QT_TILE_BYTES + 4 * SGTT_BYTES + (QT_ALIAS ? 0 : 4 * QT_IMG_BYTES);
 
 typedef float float2_t __attribute__((ext_vector_type(2)));
 
 template <bool STREAM>
-__global__ __launch_bounds__(256, QT_ALIAS ? 3 : 2) void relattn_fused_bwd_qT_kernel(
+__global__ __launch_bounds__(256, 2) void relattn_fused_bwd_qT_kernel(
     const bf16_t* __restrict__ qkv, const float* __restrict__ ubias, const float* __restrict__ vbias,
     const bf16_t* __restrict__ pext, const int32_t* __restrict__ lengths, const bf16_t* __restrict__ o,
     const bf16_t* __restrict__ dout, const float* __restrict__ lse, bf16_t* __restrict__ dq, bf16_t* __restrict__ dpos,
     float* __restrict__ dvec, int B, int H, int T, int ldp, float scale, int use_mask, float* __restrict__ dpext,
     long lddq, float* __restrict__ du, float* __restrict__ dv, int chunk, int hist, bf16_t* __restrict__ qu_out, bf16_t* __restrict__ qv_out) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* sK = smem;              // [64 j][64 dh] row-major: rows = A operand of S^T, transposed = A operand of dq_u^T
-  char* sV = sK + SK_BYTES;     // [64 j][64 dh] row-major: rows = A operand of dP^T
-  char* sP = sV + SV_BYTES;     // window rows (row 127 = the bias row): rows = A operand of G^T, transposed = A operand of dq_v^T
+  // K block [64 j][64 dh] row-major: rows = A operand of S^T, transposed = A operand of dq_u^T; V block: rows = A operand of dP^T;
+  // window rows: rows = A operand of G^T, transposed = A operand of dq_v^T.  QT_PIPE: K and the window twice.
+  char* const sK0 = smem;
+  char* const sV = sK0 + (QT_PIPE ? 2 : 1) * SK_BYTES;
+  char* const sP0 = sV + SV_BYTES;
+  char* const sStrips = smem + QT_TILE_BYTES;
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  float* sG = reinterpret_cast<float*>(sP + SP_BYTES + w * SGTT_BYTES);  // [16 il][80]: window columns 48-16w .. 127-16w; then [16] bias-row scores
+  float* sG = reinterpret_cast<float*>(sStrips + w * SGTT_BYTES);  // [16 il][80]: window columns 48-16w .. 127-16w; then [16] bias-row scores
   float* sGb = sG + 16 * GLDT;
   // skewed dS image [16 il][128 c] bf16 of this wave, rows QT_IMG_LD bytes apart.  Row il is WRITTEN at columns 63-16w-il .. 126-16w-il
   // whatever the key block, so it is cleared once: the cells outside that range stay zero, the ones inside are rewritten every block.
-  char* sAg = QT_ALIAS ? reinterpret_cast<char*>(sG) : sP + SP_BYTES + 4 * SGTT_BYTES + w * QT_IMG_BYTES;
+  char* sAg = QT_ALIAS ? reinterpret_cast<char*>(sG) : sStrips + 4 * SGTT_BYTES + w * QT_IMG_BYTES;
   const int r = lane & 15, g = lane >> 4;
   const BlockId bid = attn_block_id(B, H, (T + BI - 1) / BI);
   if (!bid.ok) return;
@@ -1514,7 +1522,7 @@ __global__ __launch_bounds__(256, QT_ALIAS ? 3 : 2) void relattn_fused_bwd_qT_ke
   const bf16_t* vb = qb + 2 * HD;
   const bf16_t* pb = pext + h * DH;
   uint4 bias_row = make_uint4(0, 0, 0, 0);
-  if ((threadIdx.x >> 6) == 0 && (threadIdx.x & 63) < 8) bias_row = *reinterpret_cast<const uint4*>(pb + (long)(2 * T - 1) * HD + (((threadIdx.x & 63) ^ key_d(127)) << 3));
+  if (!QT_PIPE && (threadIdx.x >> 6) == 0 && (threadIdx.x & 63) < 8) bias_row = *reinterpret_cast<const uint4*>(pb + (long)(2 * T - 1) * HD + (((threadIdx.x & 63) ^ key_d(127)) << 3));
 
   const int i = i0 + w * 16 + r;  // this lane's query row
   if (use_mask && i0 >= len) {
@@ -1578,16 +1586,30 @@ __global__ __launch_bounds__(256, QT_ALIAS ? 3 : 2) void relattn_fused_bwd_qT_ke
   const int kk_lo = w < 2 ? 1 : 0;  // this wave's skew touches window columns 48-16w .. 126-16w: three of the four 32-column groups
 
   const int njb = (T + BJ - 1) / BJ;
-  if (w == 0 && lane < 8) *reinterpret_cast<uint4*>(sP + 127 * 128 + lane * 16) = bias_row;  // window row 127 <- the bias row
-  if constexpr (!QT_ALIAS) {
-    const uint4 z4 = make_uint4(0, 0, 0, 0);
-    for (int q = lane; q < QT_IMG_BYTES / 16; q += 64) *reinterpret_cast<uint4*>(sAg + q * 16) = z4;
-  }
-  __syncthreads();
-  // the bias-row score of this lane's query, (q_i + v) . pext[R]: the same for every key block, so it is formed once (row 15 of the
-  // product of window rows 112..127 with the query fragments; the other fifteen rows of the image are not loaded yet and not looked at)
+  // the bias-row score of this lane's query, (q_i + v) . pext[R]: the same for every key block, so it is formed once
   float gbias;
-  {
+  if constexpr (QT_PIPE) {
+    // ... as a plain dot product from the fragments (head dims kk*32 + g*8 + t of this lane, the other three quarters in lanes r + 16 m)
+    float part = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      float pr[8];
+      ld8(pb + (long)R * HD + kk * 32 + g * 8, pr);
+#pragma unroll
+      for (int t = 0; t < 8; ++t) part += bf16_to_f32((bf16_t)bqv[kk][t]) * pr[t];
+    }
+    part += __shfl_xor(part, 16, 64);
+    part += __shfl_xor(part, 32, 64);
+    gbias = part;
+  } else {
+    char* const sP = sP0;
+    if (w == 0 && lane < 8) *reinterpret_cast<uint4*>(sP + 127 * 128 + lane * 16) = bias_row;  // window row 127 <- the bias row
+    if constexpr (!QT_ALIAS) {
+      const uint4 z4 = make_uint4(0, 0, 0, 0);
+      for (int q = lane; q < QT_IMG_BYTES / 16; q += 64) *reinterpret_cast<uint4*>(sAg + q * 16) = z4;
+    }
+    __syncthreads();
+    // (row 15 of the product of window rows 112..127 with the query fragments; the other fifteen rows are not loaded yet and not looked at)
     float4_t a = float4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
@@ -1600,6 +1622,13 @@ __global__ __launch_bounds__(256, QT_ALIAS ? 3 : 2) void relattn_fused_bwd_qT_ke
     gbias = sGb[r];
   }
   const float Dis = Di * scale;
+  if constexpr (QT_PIPE) {
+    // every value the prologue loaded is in its register before the first DMA is issued: a compiler-placed s_waitcnt vmcnt(0) for one of
+    // them inside the loop would also wait for the prefetch the loop keeps in flight
+    float l2 = lse2, gb = gbias, ds_ = Dis;
+    asm volatile("" : "+v"(l2), "+v"(gb), "+v"(ds_));
+    (void)l2; (void)gb; (void)ds_;
+  }
 #ifdef TFASR_ATTN_TIMING
   long long ph[5] = {0, 0, 0, 0, 0};
   const long long t_begin = __builtin_readcyclecounter();
@@ -1610,11 +1639,29 @@ __global__ __launch_bounds__(256, QT_ALIAS ? 3 : 2) void relattn_fused_bwd_qT_ke
 #ifdef TFASR_ATTN_TIMING
     long long tp = __builtin_readcyclecounter();
 #endif
-    load_rows<BJ>(sK, kb, LDQ, j0, T, w, lane);
-    load_rows<BJ>(sV, vb, LDQ, j0, T, w, lane);
-    load_rows<WIN, false, true>(sP, pb, HD, pw0, R1, w, lane);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    char* sK = sK0;
+    char* sP = sP0;
+    if constexpr (QT_PIPE) {
+      sK = sK0 + (jb & 1) * SK_BYTES;
+      sP = sP0 + (jb & 1) * SP_BYTES;
+      if (jb == 0) {
+        load_rows<BJ, true>(sK, kb, LDQ, 0, T, w, lane);
+        load_rows<BJ, true>(sV, vb, LDQ, 0, T, w, lane);
+        load_rows<WIN, true>(sP, pb, HD, pw0, R1, w, lane);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this block's tiles (issued one block ago) and the last block's dS stores
+      __builtin_amdgcn_s_barrier();                       // ... of every wave; every wave is also done with the other K / window buffer
+      if (jb + 1 < njb) {
+        load_rows<BJ, true>(sK0 + ((jb + 1) & 1) * SK_BYTES, kb, LDQ, j0 + BJ, T, w, lane);
+        load_rows<WIN, true>(sP0 + ((jb + 1) & 1) * SP_BYTES, pb, HD, pw0 + BJ, R1, w, lane);
+      }
+    } else {
+      load_rows<BJ>(sK, kb, LDQ, j0, T, w, lane);
+      load_rows<BJ>(sV, vb, LDQ, j0, T, w, lane);
+      load_rows<WIN, false, true>(sP, pb, HD, pw0, R1, w, lane);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
     ATT_TICK(0)
 
     float4_t acc_s[4], acc_p[4];
@@ -1640,6 +1687,12 @@ __global__ __launch_bounds__(256, QT_ALIAS ? 3 : 2) void relattn_fused_bwd_qT_ke
           a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(sP, grow + t * 16, kk * 4 + g), bqv[kk], a, 0, 0, 0);
         *reinterpret_cast<float4_t*>(sG + r * GLDT + t * 16 + g * 4) = a;
       }
+    }
+    if constexpr (QT_PIPE) {
+      // V is dead for every wave behind this barrier: fetch the next block's
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (jb + 1 < njb) load_rows<BJ, true>(sV, vb, LDQ, j0 + BJ, T, w, lane);
     }
     // (no waits between the wave's own LDS writes and reads from here to the closing barrier: one wave's LDS operations execute in
     // order, and the compiler counts the returns it needs - explicit lgkmcnt(0) fences here cost 3 exposed LDS round trips per key block)
@@ -1733,7 +1786,7 @@ __global__ __launch_bounds__(256, QT_ALIAS ? 3 : 2) void relattn_fused_bwd_qT_ke
         acc_v[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_kt(sP, n * 16, kk * 32 + g * 8, r), bfr, acc_v[n], 0, 0, 0);
     }
     ATT_TICK(3)
-    __syncthreads();  // everyone is done with sK / sV / sP (and this wave with its strip) before the next block's DMA lands
+    if constexpr (!QT_PIPE) __syncthreads();  // everyone is done with sK / sV / sP (and this wave with its strip) before the next block's DMA lands
     ATT_TICK(4)
   }
 #ifdef TFASR_ATTN_TIMING
@@ -2238,6 +2291,12 @@ extern "C" int tfasr_relattn_fused_bwd_q3(const void* qkv, const float* ubias, c
   const char* bwdq_env = getenv("TFASR_ATTN_BWDQ_T");  // (read per call: the comparison test flips it inside one process)
   const bool bwdq_t = !(bwdq_env && bwdq_env[0] == '0');
   if (bwdq_t && (lddq & 3) == 0 && (lds & 7) == 0) {
+    static bool attr_done = false;
+    if (!attr_done) {
+      (void)hipFuncSetAttribute((const void*)relattn_fused_bwd_qT_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BWD_QT);
+      (void)hipFuncSetAttribute((const void*)relattn_fused_bwd_qT_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BWD_QT);
+      attr_done = true;
+    }
     if (chunk > 0)
       hipLaunchKernelGGL(relattn_fused_bwd_qT_kernel<true>, dim3(attn_grid_size(B, H, (int)grid.x)), dim3(256), SMEM_BWD_QT, (hipStream_t)stream_, (const bf16_t*)qkv, ubias, vbias,
                          (const bf16_t*)pext, lengths, (const bf16_t*)o, (const bf16_t*)dout, lse, (bf16_t*)dq, (bf16_t*)ds, dvec, B, H, T, lds, scale,
