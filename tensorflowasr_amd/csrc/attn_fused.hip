@@ -63,6 +63,7 @@ __device__ __forceinline__ void load_rows(char* s, const bf16_t* g, long ld, int
   }
 }
 // V block as [64 k=j][64 n=dh] "trans" image (128-B k-rows, chunk ^= key_t64(k)); k rows clamped to nrows-1
+template <bool ASM = false>
 __device__ __forceinline__ void load_v(char* s, const bf16_t* g, long ld, int j0, int nrows, int w, int lane) {
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
@@ -70,7 +71,8 @@ __device__ __forceinline__ void load_v(char* s, const bf16_t* g, long ld, int j0
     const int k = q * 8 + (lane >> 3), p = lane & 7;
     const int gr = min(j0 + k, nrows - 1);
     const bf16_t* src = g + (long)gr * ld + ((p ^ key_t64(k)) << 3);
-    __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(s + __builtin_amdgcn_readfirstlane(q * 1024)), 16, 0, 0);
+    if constexpr (ASM) glds16_asm(src, s + __builtin_amdgcn_readfirstlane(q * 1024));
+    else __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(s + __builtin_amdgcn_readfirstlane(q * 1024)), 16, 0, 0);
   }
 }
 __device__ __forceinline__ short8_t frag_rows(const char* s, int row, int c) {
@@ -464,10 +466,25 @@ __global__ __launch_bounds__(256, 3) void relattn_fused_fwdT_kernel(
       jb_hi = (hi2 + BJ - 1) / BJ;
     }
   }
-  // window row 127 <- the bias row R of the position table, ONCE: the block loop's DMA leaves that row alone (it was re-written after
-  // every block's DMA, behind a barrier of its own)
+  // window row 127 <- the bias row R of the position table (the block loop's DMA leaves that row alone), and from it the bias-row score of
+  // this lane's query, (q_i + v) . pext[R]: the same for every key block, so it is formed once - the product of window rows 112..127 with
+  // the query fragments the loop used to repeat per key block (row 15 of it; the other rows are not loaded yet and are kept out)
   if (w == 0 && lane < 8) *reinterpret_cast<uint4*>(sP + 127 * 128 + lane * 16) = bias_row;
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (visible to the other waves behind the first block's barrier)
+  __syncthreads();
+  float gbias;
+  {
+    float4_t a = float4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      short8_t f = frag_rows(sP, 112 + r, kk * 4 + g);
+      if (r != 15) f = short8_t{0, 0, 0, 0, 0, 0, 0, 0};
+      a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f, bqv[kk], a, 0, 0, 0);
+    }
+    if (g == 3) sGb[r] = a[3];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    gbias = sGb[r];
+    asm volatile("" : "+v"(gbias));
+  }
   if (use_mask && i0 >= len) {
     // every query row of this block is padding: uniform attention over ALL T keys (see relattn_fused_fwd_kernel): out = mean_j v_j, lse = log T
     for (int jb = 0; jb < njb; ++jb) {
@@ -487,18 +504,24 @@ __global__ __launch_bounds__(256, 3) void relattn_fused_fwdT_kernel(
       __syncthreads();
     }
     m_run = 0.f; l_run = (float)T;
-  } else
+  } else {
+  // The loop is software pipelined without a second set of tiles: K and the window are dead behind the score products, V until the last
+  // products.  So K / window of block jb+1 are fetched behind a barrier in the middle of block jb (under the softmax and the P V products),
+  // V of block jb behind the barrier that opens it (under the score products): every DMA has half an iteration to land, three barriers
+  // per key block instead of two, the same 53.5 KB.  (The DMA pieces go through inline asm: the compiler does not see them and places no
+  // vmcnt wait of its own; the hand-counted ones below are 2 K + 4 window pieces per wave behind the 2 V pieces.)
+  if (jb_lo < jb_hi) {
+    load_rows<BJ, true>(sK, kb, LDQ, jb_lo * BJ, T, w, lane);
+    load_rows<WIN, true, true>(sP, pb, HD, (T - 1 - (i0 + BI - 1) + jb_lo * BJ) + shift, R1, w, lane);
+  }
   for (int jb = jb_lo; jb < jb_hi; ++jb) {
     const int j0 = jb * BJ;
-    const int pw0 = (T - 1 - (i0 + BI - 1) + j0) + shift;  // pext row of window column 0
 #ifdef TFASR_ATTN_TIMING
     long long tp = __builtin_readcyclecounter();
 #endif
-    load_rows<BJ>(sK, kb, LDQ, j0, T, w, lane);
-    load_v(sV, vb, LDQ, j0, T, w, lane);
-    load_rows<WIN, false, true>(sP, pb, HD, pw0, R1, w, lane);  // (window row 127 = the bias row, written once in front of the loop)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // K and the window of this block
+    __builtin_amdgcn_s_barrier();                       // ... of every wave; every wave is done with the last block's V
+    load_v<true>(sV, vb, LDQ, j0, T, w, lane);
     ATT_TICK(0)
 
     // content scores, transposed: tile jt = 16 keys x this wave's 16 queries
@@ -510,25 +533,29 @@ __global__ __launch_bounds__(256, 3) void relattn_fused_fwdT_kernel(
       for (int kk = 0; kk < 2; ++kk)
         acc_s[jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(sK, krow[jt], kk * 4 + g), bqu[kk], acc_s[jt], 0, 0, 0);
     }
-    // window scores, transposed: G^T[c][il]; this wave's skew needs window columns 48-16w .. 126-16w and column 127 (bias row)
+    // window scores, transposed: G^T[c][il] for the 80 window columns 48-16w .. 127-16w this wave's skew reads: five 16-row tiles from
+    // window row 48-16w on (straight-line code: only the row offset depends on the wave)
+    {
+      const int grow = (3 - w) * 16 + r;
 #pragma unroll
-    for (int gt = 0; gt < 8; ++gt) {
-      if (gt >= 3 - w && (gt <= 7 - w || gt == 7)) {
+      for (int t = 0; t < 5; ++t) {
         float4_t a = float4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
-          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(sP, gt * 16 + r, kk * 4 + g), bqv[kk], a, 0, 0, 0);
-        if (gt <= 7 - w) *reinterpret_cast<float4_t*>(sG + r * GLDT + (gt - (3 - w)) * 16 + g * 4) = a;
-        if (gt == 7 && g == 3) sGb[r] = a[3];  // window column 127 = the bias row's score
+          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(sP, grow + t * 16, kk * 4 + g), bqv[kk], a, 0, 0, 0);
+        *reinterpret_cast<float4_t*>(sG + r * GLDT + t * 16 + g * 4) = a;
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();   // every wave has read K and the window: the next block's may land
+    if (jb + 1 < jb_hi) {
+      load_rows<BJ, true>(sK, kb, LDQ, j0 + BJ, T, w, lane);
+      load_rows<WIN, true, true>(sP, pb, HD, (T - 1 - (i0 + BI - 1) + j0 + BJ) + shift, R1, w, lane);
+    }
     ATT_TICK(1)
 
     // every skewed score is read unconditionally (the strip column 15 - il + jl exists for every key of the block), THEN selected against
     // the bias score: a conditional read compiles to an exec-mask branch per element
-    const float gbias = sGb[r];
     float gv[4][4];
 #pragma unroll
     for (int jt = 0; jt < 4; ++jt)
@@ -582,8 +609,11 @@ __global__ __launch_bounds__(256, 3) void relattn_fused_fwdT_kernel(
     for (int n = 0; n < 4; ++n)
 #pragma unroll
       for (int e = 0; e < 4; ++e) acc_o[n][e] *= corr;
-    __builtin_amdgcn_sched_barrier(0);
     ATT_TICK(2)
+    // this block's V (2 pieces per wave, issued in front of the 6 of the next block's K / window) has landed, for every wave
+    if (jb + 1 < jb_hi) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
     // O^T += V^T P^T: the probabilities are the B operand straight from registers
 #pragma unroll
     for (int q = 0; q < 2; ++q)
@@ -591,8 +621,8 @@ __global__ __launch_bounds__(256, 3) void relattn_fused_fwdT_kernel(
       for (int n = 0; n < 4; ++n)
         acc_o[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_v(sV, n * 16, q * 32 + g * 8, r), pf[q], acc_o[n], 0, 0, 0);
     ATT_TICK(3)
-    __syncthreads();  // everyone is done with sK / sV / sP before the next block's DMA lands
     ATT_TICK(4)
+  }
   }
 #ifdef TFASR_ATTN_TIMING
   if (threadIdx.x == 0) {
