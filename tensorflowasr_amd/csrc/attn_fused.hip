@@ -2035,8 +2035,11 @@ __global__ __launch_bounds__(256, 2) void relattn_fused_bwd_k_kernel(
   char* sP = sdO + SK_BYTES;
   float* sGt = reinterpret_cast<float*>(sP + SP_BYTES);
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  char* sAp = sP + w * 4096;         // per-wave A images (P^T then dS^T), carved out of the window once it is dead
-  char* sAs = sAp + 2048;
+  // per-wave A images (P^T and dS^T, 2 KB each), carved out of what is dead once Gt is complete: the qv block and the first 64 window
+  // rows.  Window row 127 - the bias row, written once in front of the loop and left alone by the loop's DMA - stays intact (with both
+  // images inside the window it was rewritten, behind a barrier of its own, in every iteration).
+  char* sAp = sQv + w * 2048;
+  char* sAs = sP + w * 2048;
   const int r = lane & 15, g = lane >> 4;
   const BlockId bid = attn_block_id<false>(B, H, (T + BJ - 1) / BJ);  // the key blocks of one (sample, head) on one XCD, back to back (1-D grid)
   if (!bid.ok) return;
@@ -2085,6 +2088,7 @@ __global__ __launch_bounds__(256, 2) void relattn_fused_bwd_k_kernel(
     }
   }
   const int nib = (T + BI - 1) / BI;
+  if (w == 0 && lane < 8) *reinterpret_cast<uint4*>(sP + 127 * 128 + lane * 16) = bias_row;  // (visible behind the first iteration's barrier)
   for (int ib = 0; ib < nib; ++ib) {
     const int i0 = ib * BI;
     if (use_mask && i0 >= len) {
@@ -2123,11 +2127,9 @@ __global__ __launch_bounds__(256, 2) void relattn_fused_bwd_k_kernel(
     load_rows<BI>(sQu, qub, HD, i0, T, w, lane);
     load_rows<BI>(sQv, qvb, HD, i0, T, w, lane);
     load_rows<BI>(sdO, dob, HD, i0, T, w, lane);
-    load_rows<WIN>(sP, pb, HD, pw0, R1, w, lane);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    load_rows<WIN, false, true>(sP, pb, HD, pw0, R1, w, lane);  // (window row 127 = the bias row, written once in front of the loop)
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (w == 0 && lane < 8) *reinterpret_cast<uint4*>(sP + 127 * 128 + lane * 16) = bias_row;  // loaded once, in front of the loop
-    __syncthreads();
 
     // transposed content scores and dP: rows = this wave's 16 keys, cols = 64 queries
     float4_t acc_s[4], acc_p[4];
