@@ -41,6 +41,12 @@ def test_hoisted_block_launches_same_step(dev, lens, ulens):
         # LayerNorm gamma / beta: the same partial sums folded in the same order (upstream BatchNorm atomics reorder run to run: not bitwise);
         # positional projection bias: f32 column sums in another order; everything else: split-K atomics
         tol = 1e-4 if k.endswith(("/ln/g", "/ln/b", "/pos/b")) else 2e-3
+        if k.endswith(("sub/conv0/b", "sub/conv1/b", "conv/dw/b")):
+            # a bias in front of a BatchNorm: its exact gradient is ZERO, what is stored is the cancellation residue of bf16 summands three
+            # orders of magnitude larger.  One summand rounding the other way (the BatchNorm backward's f32 atomics reorder run to run)
+            # moves an element by a whole bf16 ulp of the summands (2^-12 seen once in 14 runs of this test; tools/r05/t34.sh) - bounded here
+            # against the residue's own size, not against 2e-3 of it
+            tol = 0.5
         np.testing.assert_allclose(b, a, rtol=0, atol=tol * scale, err_msg=k)
     assert any("/pos/" in k for k in g0) and any(k.endswith("/ln/g") for k in g0)
 
