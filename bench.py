@@ -662,26 +662,9 @@ def main():
             # kernels this library queued per step (host-side count, tfasr_launch_count; torch's own fills / copies are not in it)
             "launches_per_step": None if launches_per_step is None else round(launches_per_step, 1),
         }
-        if not stub and args.model in ("M", "S") and dtype == torch.bfloat16 and not args.no_extras:
-            try:
-                rows_list = [args.batch * int(-(-(-(-(-(-int(np.asarray(b["nsamp"], np.int64).max()) // cfg.frame_step)) // 2)) // 2)) for b in batches]
-                # in-step duration of the grouped weight gradients: a few more steps with the executor's event probe on
-                from tensorflowasr_amd import kernels as _K2
-
-                model.timers = None
-                _K2.block_wgrad_probe(True)
-                nprobe = 4
-                for i in range(nprobe):
-                    one_step(i)
-                torch.cuda.synchronize()
-                ms_in, n_in = _K2.block_wgrad_probe_read()
-                _K2.block_wgrad_probe(False)
-                fl_in = sum(cfg.num_blocks * sum(2.0 * rows_list[i % nb] * m * n for m, n in wgrad_group_shapes(cfg)) for i in range(nprobe))
-                out["roofline_by_time"] = wgrad_group_roofline(cfg, rows_list, dev, in_step=(ms_in, n_in, fl_in))
-            except Exception as e:
-                out["roofline_by_time"] = {"value": None, "error": repr(e)[:200]}
-        # (this leg runs BEFORE the reference-padding leg: behind it - other shapes, a differently filled allocator - the same ten steps
-        # measured 3 ms slower than as a run of their own, profiles/r05_ab/recompute_leg_order.txt)
+        # (this leg runs FIRST of the extra legs, straight behind the timed region: behind the reference-padding leg - other shapes, a
+        # differently filled allocator - the same ten steps measured 3 ms slower than as a run of their own, behind the 874 MiB of rotating
+        # operand sets of the roofline_by_time probe 9 ms slower; profiles/r05_ab/recompute_leg_order.txt)
         if world == 1 and not args.no_extras and args.model in ("M", "S") and not stub and dtype == torch.bfloat16:
             # SURVEY section 8(d) "report both": the joint + loss WITHOUT materialised lattice logits (statistics-only projection, gradient
             # epilogue on a re-computed logit tile; TFASR_JOINT_RECOMPUTE=1) next to the default materialised route, same batches
@@ -713,6 +696,24 @@ def main():
             finally:
                 model.joint_recompute = False
                 model.timers = None
+        if not stub and args.model in ("M", "S") and dtype == torch.bfloat16 and not args.no_extras:
+            try:
+                rows_list = [args.batch * int(-(-(-(-(-(-int(np.asarray(b["nsamp"], np.int64).max()) // cfg.frame_step)) // 2)) // 2)) for b in batches]
+                # in-step duration of the grouped weight gradients: a few more steps with the executor's event probe on
+                from tensorflowasr_amd import kernels as _K2
+
+                model.timers = None
+                _K2.block_wgrad_probe(True)
+                nprobe = 4
+                for i in range(nprobe):
+                    one_step(i)
+                torch.cuda.synchronize()
+                ms_in, n_in = _K2.block_wgrad_probe_read()
+                _K2.block_wgrad_probe(False)
+                fl_in = sum(cfg.num_blocks * sum(2.0 * rows_list[i % nb] * m * n for m, n in wgrad_group_shapes(cfg)) for i in range(nprobe))
+                out["roofline_by_time"] = wgrad_group_roofline(cfg, rows_list, dev, in_step=(ms_in, n_in, fl_in))
+            except Exception as e:
+                out["roofline_by_time"] = {"value": None, "error": repr(e)[:200]}
         if world == 1 and not args.no_extras and args.model == "M" and args.padding == "batch" and size == "LibriSpeech-shaped":
             # BASELINE.md section 2 "report both": the same step with the reference's dataset-maximum padding (every utterance padded
             # to 475 760 samples / 230 labels, datasets.py:342-365).  The packed lattice and the length-aware kernels make the
