@@ -12,7 +12,8 @@
  *   - every entry returns a tfasr_status_t; `tfasr_status_string` decodes it;
  *   - re-entrant per stream, no assumption about the process-wide current device beyond "the pointers and the stream belong
  *     to the device that is current on this thread".  State the library keeps: (i) tuning switches read ONCE from the environment
- *     (TFASR_* variables, function-local statics: A/B switches of the kernels, never results); (ii) the block executor's internal
+ *     (TFASR_* variables, function-local statics: A/B switches of the kernels, never results; TFASR_ATTN_BWDQ_T and TFASR_GEMM_KG2
+ *     are read per call so that a test can compare both routes inside one process); (ii) the block executor's internal
  *     second stream + events per device (tfasr_block_io.wgrad_slot), the persistent-LSTM policy (tfasr_lstm_set_persist), and one
  *     flag set around a grouped launch that shares the chip with another stream; (iii) two measurement aids: a host-side launch counter
  *     (tfasr_launch_count) and the optional event record of tfasr_block_wgrad_probe - all of them assume what the rest of the design
