@@ -1506,27 +1506,30 @@ __global__ __launch_bounds__(256, 2) void relattn_fused_bwd_q_kernel(
 // ======================================================================================================================
 constexpr int QT_IMG_LD = 272;                       // byte stride of a row of the skewed dS image: 128 bf16 columns + 16 B (bank spread, no swizzle)
 constexpr int QT_IMG_BYTES = 16 * QT_IMG_LD;
-// QT_PIPE: the K block and the window are double buffered and the next key block's DMA is issued behind the barrier that opens the
-// current one (V, dead after the first products, is refetched behind a second barrier): 32 + 24 KB of tiles, so the image has to lie over
-// the wave's G^T strip again (cleared per key block) to keep two workgroups on a CU: 76.7 KB.
-#ifndef TFASR_QT_PIPE
-#define TFASR_QT_PIPE 1
-#endif
-constexpr bool QT_PIPE = TFASR_QT_PIPE;
-constexpr bool QT_ALIAS = QT_PIPE;          // the image over the wave's G^T strip or beside it (70.9 KB per workgroup unpipelined)
+// Three builds of the kernel (template parameter MODE; TFASR_ATTN_BWDQ_T picks one, default 1):
+//   1  PIPELINED: the K block and the window are double buffered and the next key block's DMA is issued behind the barrier that opens the
+//      current one (V, dead after the first products, is refetched behind a second barrier): 32 + 24 KB of tiles, the image over the wave's
+//      G^T strip (cleared per key block): 76.7 KB, two workgroups per CU.
+//   2  LEAN: single buffered, the image over the strip (53.5 KB), and the three loop-invariant B fragments (q + u, q + v, dO: 24 registers)
+//      re-read from L2 at the top of every key block instead of held - aimed at 168 registers = THREE workgroups per CU, so that the ~720
+//      live workgroups of a LibriSpeech-shaped batch are one round of resident workgroups instead of 1.4 (= 2).
+//   3  (MODE 0) single buffered with the image beside the strip (70.9 KB): the first version, kept for A/B.
 static_assert(QT_IMG_BYTES <= 16 * GLDT * 4, "the skewed dS image fits under the bias scores of the strip");
-constexpr int QT_TILE_BYTES = (QT_PIPE ? 2 : 1) * (SK_BYTES + SP_BYTES) + SV_BYTES;
-constexpr int SMEM_BWD_QT = QT_TILE_BYTES + 4 * SGTT_BYTES + (QT_ALIAS ? 0 : 4 * QT_IMG_BYTES);
+constexpr int qt_tile_bytes(int mode) { return (mode == 1 ? 2 : 1) * (SK_BYTES + SP_BYTES) + SV_BYTES; }
+constexpr int qt_smem(int mode) { return qt_tile_bytes(mode) + 4 * SGTT_BYTES + (mode == 0 ? 4 * QT_IMG_BYTES : 0); }
+static_assert((qt_smem(2) + 1279) / 1280 * 3 <= 128, "LEAN: three workgroups per CU");
 
 typedef float float2_t __attribute__((ext_vector_type(2)));
 
-template <bool STREAM>
-__global__ __launch_bounds__(256, 2) void relattn_fused_bwd_qT_kernel(
+template <bool STREAM, int MODE>
+__global__ __launch_bounds__(256, MODE == 2 ? 3 : 2) void relattn_fused_bwd_qT_kernel(
     const bf16_t* __restrict__ qkv, const float* __restrict__ ubias, const float* __restrict__ vbias,
     const bf16_t* __restrict__ pext, const int32_t* __restrict__ lengths, const bf16_t* __restrict__ o,
     const bf16_t* __restrict__ dout, const float* __restrict__ lse, bf16_t* __restrict__ dq, bf16_t* __restrict__ dpos,
     float* __restrict__ dvec, int B, int H, int T, int ldp, float scale, int use_mask, float* __restrict__ dpext,
-    long lddq, float* __restrict__ du, float* __restrict__ dv, int chunk, int hist, bf16_t* __restrict__ qu_out, bf16_t* __restrict__ qv_out) {
+    long lddq, float* __restrict__ du, float* __restrict__ dv, int chunk, int hist, bf16_t* qu_out, bf16_t* qv_out) {
+  constexpr bool QT_PIPE = MODE == 1, QT_LEAN = MODE == 2, QT_ALIAS = MODE != 0;
+  constexpr int QT_TILE_BYTES = qt_tile_bytes(MODE);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // K block [64 j][64 dh] row-major: rows = A operand of S^T, transposed = A operand of dq_u^T; V block: rows = A operand of dP^T;
   // window rows: rows = A operand of G^T, transposed = A operand of dq_v^T.  QT_PIPE: K and the window twice.
@@ -1552,7 +1555,7 @@ __global__ __launch_bounds__(256, 2) void relattn_fused_bwd_qT_kernel(
   const bf16_t* vb = qb + 2 * HD;
   const bf16_t* pb = pext + h * DH;
   uint4 bias_row = make_uint4(0, 0, 0, 0);
-  if (!QT_PIPE && (threadIdx.x >> 6) == 0 && (threadIdx.x & 63) < 8) bias_row = *reinterpret_cast<const uint4*>(pb + (long)(2 * T - 1) * HD + (((threadIdx.x & 63) ^ key_d(127)) << 3));
+  if (MODE == 0 && (threadIdx.x >> 6) == 0 && (threadIdx.x & 63) < 8) bias_row = *reinterpret_cast<const uint4*>(pb + (long)(2 * T - 1) * HD + (((threadIdx.x & 63) ^ key_d(127)) << 3));
 
   const int i = i0 + w * 16 + r;  // this lane's query row
   if (use_mask && i0 >= len) {
@@ -1618,7 +1621,7 @@ __global__ __launch_bounds__(256, 2) void relattn_fused_bwd_qT_kernel(
   const int njb = (T + BJ - 1) / BJ;
   // the bias-row score of this lane's query, (q_i + v) . pext[R]: the same for every key block, so it is formed once
   float gbias;
-  if constexpr (QT_PIPE) {
+  if constexpr (QT_PIPE || QT_LEAN) {
     // ... as a plain dot product from the fragments (head dims kk*32 + g*8 + t of this lane, the other three quarters in lanes r + 16 m)
     float part = 0.f;
 #pragma unroll
@@ -1652,6 +1655,12 @@ __global__ __launch_bounds__(256, 2) void relattn_fused_bwd_qT_kernel(
     gbias = sGb[r];
   }
   const float Dis = Di * scale;
+  // LEAN: where this lane's three B fragments are read back from at the top of every key block (q + u / q + v: what this lane itself
+  // stored above - the stores are complete before the first read; rows past T: zeros)
+  const bf16_t* const fr_qu = qu_out + ((long)b * T + irow) * HD + h * DH + g * 8;
+  const bf16_t* const fr_qv = qv_out + ((long)b * T + irow) * HD + h * DH + g * 8;
+  const bf16_t* const fr_do = dout + ((long)b * T + irow) * HD + h * DH + g * 8;
+  if constexpr (QT_LEAN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if constexpr (QT_PIPE) {
     // every value the prologue loaded is in its register before the first DMA is issued: a compiler-placed s_waitcnt vmcnt(0) for one of
     // them inside the loop would also wait for the prefetch the loop keeps in flight
@@ -1686,9 +1695,18 @@ __global__ __launch_bounds__(256, 2) void relattn_fused_bwd_qT_kernel(
         load_rows<WIN, true>(sP0 + ((jb + 1) & 1) * SP_BYTES, pb, HD, pw0 + BJ, R1, w, lane);
       }
     } else {
+      if constexpr (QT_LEAN) {
+        const short8_t z8 = short8_t{0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          bqu[kk] = inrow ? *reinterpret_cast<const short8_t*>(fr_qu + kk * 32) : z8;
+          bqv[kk] = inrow ? *reinterpret_cast<const short8_t*>(fr_qv + kk * 32) : z8;
+          bdo[kk] = inrow ? *reinterpret_cast<const short8_t*>(fr_do + kk * 32) : z8;
+        }
+      }
       load_rows<BJ>(sK, kb, LDQ, j0, T, w, lane);
       load_rows<BJ>(sV, vb, LDQ, j0, T, w, lane);
-      load_rows<WIN, false, true>(sP, pb, HD, pw0, R1, w, lane);
+      load_rows<WIN, false, MODE == 0>(sP, pb, HD, pw0, R1, w, lane);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
     }
@@ -1824,6 +1842,10 @@ __global__ __launch_bounds__(256, 2) void relattn_fused_bwd_qT_kernel(
 #endif
 
   // epilogue: dq = dq_u + dq_v (+ the bias row's share), du / dv column sums, the bias row of the table gradient
+  if constexpr (QT_LEAN) {
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) bqv[kk] = *reinterpret_cast<const short8_t*>(fr_qv + kk * 32);
+  }
   float bsum = bias_acc;
   bsum += __shfl_xor(bsum, 16, 64);
   bsum += __shfl_xor(bsum, 32, 64);
@@ -2323,20 +2345,25 @@ extern "C" int tfasr_relattn_fused_bwd_q3(const void* qkv, const float* ubias, c
   const char* bwdq_env = getenv("TFASR_ATTN_BWDQ_T");  // (read per call: the comparison test flips it inside one process)
   const bool bwdq_t = !(bwdq_env && bwdq_env[0] == '0');
   if (bwdq_t && (lddq & 3) == 0 && (lds & 7) == 0) {
+    // MODE of the transposed kernel: "1" / unset = pipelined, "2" = lean (three workgroups per CU; needs the q + u / q + v outputs), "3" = the
+    // first single-buffered version
+    const int mode = (bwdq_env && bwdq_env[0] == '2' && qu && qv) ? 2 : (bwdq_env && bwdq_env[0] == '3') ? 0 : 1;
     static bool attr_done = false;
     if (!attr_done) {
-      (void)hipFuncSetAttribute((const void*)relattn_fused_bwd_qT_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BWD_QT);
-      (void)hipFuncSetAttribute((const void*)relattn_fused_bwd_qT_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BWD_QT);
+      (void)hipFuncSetAttribute((const void*)relattn_fused_bwd_qT_kernel<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, qt_smem(0));
+      (void)hipFuncSetAttribute((const void*)relattn_fused_bwd_qT_kernel<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, qt_smem(0));
+      (void)hipFuncSetAttribute((const void*)relattn_fused_bwd_qT_kernel<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, qt_smem(1));
+      (void)hipFuncSetAttribute((const void*)relattn_fused_bwd_qT_kernel<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, qt_smem(1));
       attr_done = true;
     }
-    if (chunk > 0)
-      hipLaunchKernelGGL(relattn_fused_bwd_qT_kernel<true>, dim3(attn_grid_size(B, H, (int)grid.x)), dim3(256), SMEM_BWD_QT, (hipStream_t)stream_, (const bf16_t*)qkv, ubias, vbias,
-                         (const bf16_t*)pext, lengths, (const bf16_t*)o, (const bf16_t*)dout, lse, (bf16_t*)dq, (bf16_t*)ds, dvec, B, H, T, lds, scale,
-                         use_mask, dpext, lddq, du, dv, chunk, hist, (bf16_t*)qu, (bf16_t*)qv);
-    else
-      hipLaunchKernelGGL(relattn_fused_bwd_qT_kernel<false>, dim3(attn_grid_size(B, H, (int)grid.x)), dim3(256), SMEM_BWD_QT, (hipStream_t)stream_, (const bf16_t*)qkv, ubias, vbias,
-                         (const bf16_t*)pext, lengths, (const bf16_t*)o, (const bf16_t*)dout, lse, (bf16_t*)dq, (bf16_t*)ds, dvec, B, H, T, lds, scale,
-                         use_mask, dpext, lddq, du, dv, 0, 0, (bf16_t*)qu, (bf16_t*)qv);
+    const dim3 gq(attn_grid_size(B, H, (int)grid.x));
+#define TFASR_QT_LAUNCH(ST, MD)                                                                                                             \
+    hipLaunchKernelGGL((relattn_fused_bwd_qT_kernel<ST, MD>), gq, dim3(256), qt_smem(MD), (hipStream_t)stream_, (const bf16_t*)qkv, ubias, vbias, \
+                       (const bf16_t*)pext, lengths, (const bf16_t*)o, (const bf16_t*)dout, lse, (bf16_t*)dq, (bf16_t*)ds, dvec, B, H, T, lds, scale, \
+                       use_mask, dpext, lddq, du, dv, chunk > 0 ? chunk : 0, chunk > 0 ? hist : 0, (bf16_t*)qu, (bf16_t*)qv)
+    if (chunk > 0) { if (mode == 2) TFASR_QT_LAUNCH(true, 2); else if (mode == 0) TFASR_QT_LAUNCH(true, 0); else TFASR_QT_LAUNCH(true, 1); }
+    else { if (mode == 2) TFASR_QT_LAUNCH(false, 2); else if (mode == 0) TFASR_QT_LAUNCH(false, 0); else TFASR_QT_LAUNCH(false, 1); }
+#undef TFASR_QT_LAUNCH
     TFASR_CHECK_LAUNCH();
     return TFASR_STATUS_SUCCESS;
   }

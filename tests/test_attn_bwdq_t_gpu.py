@@ -14,8 +14,9 @@ from test_model_gpu import _setup
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.parametrize("mode", ["1", "2", "3"])  # pipelined (default) / lean (three workgroups per CU) / first single-buffered version
 @pytest.mark.parametrize("stream", [None, (8, 24), (16, -1)])
-def test_transposed_query_backward_matches_row_oriented_kernel(dev, stream):
+def test_transposed_query_backward_matches_row_oriented_kernel(dev, stream, mode):
     N = 160000  # 1000 frames -> T' = 250: four key blocks, the last one ragged
     lens, ulens = [160000, 70000, 121000], [6, 3, 5]  # sample 1: T' = 110, its last query block is entirely padding
     over = {} if stream is None else dict(chunk_size=stream[0], history_size=stream[1], convm_dw_norm="layer")
@@ -25,7 +26,7 @@ def test_transposed_query_backward_matches_row_oriented_kernel(dev, stream):
     out = {}
     old = os.environ.get("TFASR_ATTN_BWDQ_T")
     try:
-        for tag, flag in (("old", "0"), ("old2", "0"), ("new", "1")):
+        for tag, flag in (("old", "0"), ("old2", "0"), ("new", mode)):
             os.environ["TFASR_ATTN_BWDQ_T"] = flag
             model.zero_grad()
             costs = model.loss_and_backward(data, True, (None, None)).float().cpu().numpy()
