@@ -1655,6 +1655,11 @@ __global__ __launch_bounds__(256, MODE == 2 ? 3 : 2) void relattn_fused_bwd_qT_k
     gbias = sGb[r];
   }
   const float Dis = Di * scale;
+  // the bias row of the table (this lane's 16 head dims n*16 + g*4 + e) for the epilogue: requested here, so that the epilogue has no
+  // global load of its own to wait for (every workgroup pays its prologue and epilogue latencies once, and a launch is two rounds of them)
+  uint2 prb[4];
+#pragma unroll
+  for (int n = 0; n < 4; ++n) prb[n] = *reinterpret_cast<const uint2*>(pb + (long)R * HD + n * 16 + g * 4);
   // LEAN: where this lane's three B fragments are read back from at the top of every key block (q + u / q + v: what this lane itself
   // stored above - the stores are complete before the first read; rows past T: zeros)
   const bf16_t* const fr_qu = qu_out + ((long)b * T + irow) * HD + h * DH + g * 8;
@@ -1814,7 +1819,17 @@ __global__ __launch_bounds__(256, MODE == 2 ? 3 : 2) void relattn_fused_bwd_qT_k
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
         const int jc = j0 + 32 * q + g * 8;
+#if !defined(TFASR_QT_NT) || TFASR_QT_NT
+        // (non-temporal: 73 MB per launch that this kernel never reads again should not push K / V / window lines out of the L2;
+        // 84.1 -> 82.4 us same box; -DTFASR_QT_NT=0: plain stores)
+        if (jc < ldp) {
+          typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+          const u32x4_t v = {pz[q].x, pz[q].y, pz[q].z, pz[q].w};
+          __builtin_nontemporal_store(v, reinterpret_cast<u32x4_t*>(dsrow + jc));
+        }
+#else
         if (jc < ldp) *reinterpret_cast<uint4*>(dsrow + jc) = pz[q];
+#endif
       }
     }
     ATT_TICK(2)
@@ -1852,7 +1867,7 @@ __global__ __launch_bounds__(256, MODE == 2 ? 3 : 2) void relattn_fused_bwd_qT_k
   float su[4][4], sv[4][4];
 #pragma unroll
   for (int n = 0; n < 4; ++n) {
-    const uint2 pr = *reinterpret_cast<const uint2*>(pb + (long)R * HD + n * 16 + g * 4);  // the bias row of the table, this lane's 4 head dims
+    const uint2 pr = prb[n];  // the bias row of the table, this lane's 4 head dims
     const float pbias[4] = {__uint_as_float(pr.x << 16), __uint_as_float(pr.x & 0xffff0000u), __uint_as_float(pr.y << 16), __uint_as_float(pr.y & 0xffff0000u)};
     float gq[4];
 #pragma unroll
