@@ -26,7 +26,15 @@ __device__ __forceinline__ float2_t fma2(float2_t a, float2_t b, float2_t c) { r
 // dependent chain of global loads.
 constexpr int SLAB = 256;             // channels per block
 constexpr int ROWB = SLAB * 2;        // bytes per staged row
-constexpr int TG = 32;                // output steps per thread group (2 groups of 128 channel-pair lanes per block)
+constexpr int TG = 32;                // output steps per thread group (2 groups of 128 channel-pair lanes per block): weight-gradient kernels
+// ... and of the forward / data-gradient kernels: 32 steps per block.  With 64 a Conformer-M layer is 384 blocks - 1.5 per CU, each a single
+// load -> compute -> store round trip - and half the chip idles through the second half of the launch; 768 blocks of 32 steps re-read the
+// K - 1 halo rows twice as often (from L2) and finish sooner: forward 15.9 -> 13.7 us, data gradient + GLU 27.4 -> 22.7 us, step -0.09 ms
+// (same box, tools/r05/t41.sh).  -DTFASR_DW_TGD=32: the old blocks.
+#ifndef TFASR_DW_TGD
+#define TFASR_DW_TGD 16
+#endif
+constexpr int TGD = TFASR_DW_TGD;
 
 // rows [r0, r0+NR) of src (time index = tbase + row) -> LDS, zero filled outside [0, Tn) and beyond C.  NR is a compile-time bound and
 // the loop is fully unrolled into a load batch followed by a store batch: as a run-time loop the compiler kept ONE 16-byte load in flight
@@ -84,9 +92,9 @@ template <bool REV, bool GLU = false, int KB = MAXK>
 __global__ __launch_bounds__(256) void dwconv_tile_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w,
                                                           const float* __restrict__ bias, bf16_t* __restrict__ y, int Tn, int C, int K,
                                                           const bf16_t* __restrict__ gx = nullptr) {
-  extern __shared__ __attribute__((aligned(16))) char lds[];  // (2*TG + KB - 1) rows; rows past K-1+2*TG stay zero-weighted
+  extern __shared__ __attribute__((aligned(16))) char lds[];  // (2*TGD + KB - 1) rows; rows past K-1+2*TGD stay zero-weighted
   const int c0 = blockIdx.x * SLAB;
-  const int t0 = blockIdx.y * (2 * TG);
+  const int t0 = blockIdx.y * (2 * TGD);
   const long ubase = (long)blockIdx.z * Tn * C;
   const int tin0 = REV ? t0 : t0 - (K - 1);
   const int grp = threadIdx.x >> 7, pr = threadIdx.x & 127;
@@ -101,30 +109,30 @@ __global__ __launch_bounds__(256) void dwconv_tile_kernel(const bf16_t* __restri
     const float2_t v = *reinterpret_cast<const float2_t*>(w + kk * C + cc);
     wk[k] = (k < K) ? v : float2_t{0.f, 0.f};
   }
-  stage_rows<2 * TG + KB - 1>(lds, x, ubase, tin0, Tn, C, c0);
+  stage_rows<2 * TGD + KB - 1>(lds, x, ubase, tin0, Tn, C, c0);
   // GLU variant: the a | b halves of this thread's 32 output rows are fetched NOW (packed pairs, rows clamped into the tensor), in
   // flight under the LDS staging and the tap loop; loaded inside the store loop each row was its own dependent round trip
   // (load a, b -> sigmoid -> two stores, 32 times in a row: 30 us for a 12 us stream)
-  [[maybe_unused]] uint32_t ga[GLU ? TG : 1], gb[GLU ? TG : 1];
+  [[maybe_unused]] uint32_t ga[GLU ? TGD : 1], gb[GLU ? TGD : 1];
   if constexpr (GLU) {
-    const int tg0p = t0 + grp * TG;
+    const int tg0p = t0 + grp * TGD;
 #pragma unroll
-    for (int i = 0; i < TG; ++i) {
+    for (int i = 0; i < TGD; ++i) {
       const long row2 = (ubase + (long)min(tg0p + i, Tn - 1) * C) * 2;
       ga[i] = *reinterpret_cast<const uint32_t*>(gx + row2 + cc);
       gb[i] = *reinterpret_cast<const uint32_t*>(gx + row2 + C + cc);
     }
   }
-  float2_t acc[TG];
+  float2_t acc[TGD];
   const float2_t bv = (!REV && bias) ? float2_t{bias[cc], bias[cc + 1]} : float2_t{0.f, 0.f};
 #pragma unroll
-  for (int i = 0; i < TG; ++i) acc[i] = bv;
+  for (int i = 0; i < TGD; ++i) acc[i] = bv;
   __syncthreads();
-  dw_all<TG, KB>(acc, wk, lds + (grp * TG) * ROWB + pr * 4, std::make_integer_sequence<int, KB - 1 + TG>{});
+  dw_all<TGD, KB>(acc, wk, lds + (grp * TGD) * ROWB + pr * 4, std::make_integer_sequence<int, KB - 1 + TGD>{});
   if (live) {
-    const int tg0 = t0 + grp * TG;
+    const int tg0 = t0 + grp * TGD;
 #pragma unroll
-    for (int i = 0; i < TG; ++i)
+    for (int i = 0; i < TGD; ++i)
       if (tg0 + i < Tn) {
         if constexpr (GLU) {
           const long row2 = (ubase + (long)(tg0 + i) * C) * 2;  // element offset of the row in the [rows, 2C] tensors
@@ -335,8 +343,8 @@ extern "C" int tfasr_dwconv_bwd_data_glu(const void* dy, const float* w, const v
   if (!dy || !w || !glu_x || !dglu || B <= 0 || T <= 0 || C <= 0 || K <= 0) return TFASR_STATUS_INVALID_VALUE;
   if (dtype != TFASR_BF16 || (C & 7) || K > MAXK || !al16(dy) || !al4(dglu) || !al4(glu_x)) return TFASR_STATUS_UNSUPPORTED;
   const int gx = (C + SLAB - 1) / SLAB;
-  dim3 grid(gx, (T + 2 * TG - 1) / (2 * TG), B);
-  const int smem = (2 * TG + MAXK - 1) * ROWB;
+  dim3 grid(gx, (T + 2 * TGD - 1) / (2 * TGD), B);
+  const int smem = (2 * TGD + MAXK - 1) * ROWB;
   hipLaunchKernelGGL((dwconv_tile_kernel<true, true>), grid, dim3(256), smem, (hipStream_t)stream_, (const bf16_t*)dy, w, (const float*)nullptr, (bf16_t*)dglu, T, C, K,
                      (const bf16_t*)glu_x);
   TFASR_CHECK_LAUNCH();
@@ -348,12 +356,12 @@ int tfasr_dwconv_pair_try(int which, const void* x, const void* dy, const float*
                           int T, int C, int K, hipStream_t s) {
   if ((C & 7) || K > MAXK) return TFASR_STATUS_UNSUPPORTED;
   const int gx = (C + SLAB - 1) / SLAB;
-  dim3 grid(gx, (T + 2 * TG - 1) / (2 * TG), B);
   if (which == 0 || which == 1) {
+    dim3 grid(gx, (T + 2 * TGD - 1) / (2 * TGD), B);
     const void* in = which == 0 ? x : dy;
     if (!al16(in) || !al4(y)) return TFASR_STATUS_UNSUPPORTED;
     if (K <= 8) {
-      const int smem = (2 * TG + 8 - 1) * ROWB;
+      const int smem = (2 * TGD + 8 - 1) * ROWB;
       if (which == 0)
         hipLaunchKernelGGL((dwconv_tile_kernel<false, false, 8>), grid, dim3(256), smem, s, (const bf16_t*)in, w, bias, (bf16_t*)y, T, C, K,
                            (const bf16_t*)nullptr);
@@ -363,7 +371,7 @@ int tfasr_dwconv_pair_try(int which, const void* x, const void* dy, const float*
       TFASR_CHECK_LAUNCH();
       return TFASR_STATUS_SUCCESS;
     }
-    const int smem = (2 * TG + MAXK - 1) * ROWB;
+    const int smem = (2 * TGD + MAXK - 1) * ROWB;
     if (which == 0)
       hipLaunchKernelGGL((dwconv_tile_kernel<false>), grid, dim3(256), smem, s, (const bf16_t*)in, w, bias, (bf16_t*)y, T, C, K);
     else
@@ -375,6 +383,7 @@ int tfasr_dwconv_pair_try(int which, const void* x, const void* dy, const float*
   // (K x C per 64 steps) dominate; opt-in until it reduces through a workspace instead.
   static const bool wgrad_tile = getenv("TFASR_DWCONV_WGRAD_TILE") != nullptr;
   if (!wgrad_tile || !al16(x) || !al16(dy)) return TFASR_STATUS_UNSUPPORTED;
+  dim3 grid(gx, (T + 2 * TG - 1) / (2 * TG), B);
   const int smem = (2 * TG + MAXK - 1 + 2 * TG) * ROWB;
   switch (K) {
     case 31: hipLaunchKernelGGL((dwconv_wgrad_tile_kernel<31>), grid, dim3(256), smem, s, (const bf16_t*)x, (const bf16_t*)dy, dw, dbias, T, C, (float*)nullptr); break;
