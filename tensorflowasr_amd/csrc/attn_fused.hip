@@ -2253,6 +2253,222 @@ __global__ __launch_bounds__(256, 2) void relattn_fused_bwd_k_kernel(
   }
 }
 
+
+// ======================================================================================================================
+// Backward, part 2 (key side) with a lane owning ONE KEY (round 5; TFASR_ATTN_BWDK_T=1, default off until it measures faster than
+// relattn_fused_bwd_k_kernel).  Scores as S = (Q+u) K^T and dP = dO V^T with the QUERY rows as the MFMA A operand (read from LDS, dealt to
+// the tiles so that a lane's eight values of a 32-query group are eight consecutive queries) and the wave's 16 keys as the B operand from
+// registers, so P and dS in the C layout ARE the B operands of dV^T += dO^T P and dK^T += (Q+u)^T dS: the two per-wave A images of the
+// row-oriented kernel (32 two-byte LDS stores + 4 fragment reads per lane and query block) are gone.  The window scores are produced PER
+// WAVE (a wave's 16 keys and a 16-query tile touch 31 window columns = two 16-column tiles: 8 G^T tiles per query block, the count the
+// block-wide version gives each wave) into a per-wave strip [64 queries][32 columns] with one 16-byte store per tile - no block-wide
+// strip, no barrier between the products and the exponentials: two barriers per query block instead of four.  The per-query quantities
+// (lse, D, the bias-row score) are 64-entry LDS arrays read four at a time.
+// ======================================================================================================================
+constexpr int KT_SLD = 32;                                   // f32 row stride of the per-wave strip
+constexpr int KT_STRIP_BYTES = 64 * KT_SLD * 4;              // 8 KB per wave
+constexpr int SMEM_BWD_KT = 3 * SK_BYTES + SP_BYTES + 4 * KT_STRIP_BYTES + 4 * 256 + 2 * 256;  // tiles, strips, bias scores per wave, lse / D
+
+template <bool STREAM>
+__global__ __launch_bounds__(256, 2) void relattn_fused_bwd_kT_kernel(
+    const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ qu, const bf16_t* __restrict__ qv,
+    const bf16_t* __restrict__ pext, const int32_t* __restrict__ lengths, const bf16_t* __restrict__ dout,
+    const float* __restrict__ lse, const float* __restrict__ dvec, bf16_t* __restrict__ dqkv, int B, int H, int T, float scale,
+    int use_mask, int chunk, int hist) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sQu = smem;
+  char* sQv = sQu + SK_BYTES;
+  char* sdO = sQv + SK_BYTES;
+  char* sP = sdO + SK_BYTES;
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  float* sS = reinterpret_cast<float*>(sP + SP_BYTES + w * KT_STRIP_BYTES);                 // [64 il][32]: window columns 16 (3 - qt + w) .. + 31 of query tile qt
+  float* sGb = reinterpret_cast<float*>(sP + SP_BYTES + 4 * KT_STRIP_BYTES + w * 256);       // [64]: bias-row score of every query of the block (per wave)
+  float* sL = reinterpret_cast<float*>(sP + SP_BYTES + 4 * KT_STRIP_BYTES + 4 * 256);        // [64] lse * log2 e, [64] D
+  float* sD = sL + 64;
+  const int r = lane & 15, g = lane >> 4;
+  const BlockId bid = attn_block_id<false>(B, H, (T + BJ - 1) / BJ);
+  if (!bid.ok) return;
+  const int b = bid.b, h = bid.h, j0 = bid.blk * BJ;
+  const int HD = H * DH, LDQ = 3 * HD, R1 = 2 * T;
+  const int len = lengths ? min(lengths[b], T) : T;
+  const int shift = T - len;
+  const bf16_t* kb = qkv + (long)b * T * LDQ + HD + h * DH;
+  const bf16_t* vb = kb + HD;
+  const bf16_t* qub = qu + (long)b * T * HD + h * DH;
+  const bf16_t* qvb = qv + (long)b * T * HD + h * DH;
+  const bf16_t* dob = dout + (long)b * T * HD + h * DH;
+  const bf16_t* pb = pext + h * DH;
+  uint4 bias_row = make_uint4(0, 0, 0, 0);
+  if ((threadIdx.x >> 6) == 0 && (threadIdx.x & 63) < 8) bias_row = *reinterpret_cast<const uint4*>(pb + (long)(2 * T - 1) * HD + (((threadIdx.x & 63) ^ key_d(127)) << 3));
+
+  const int j = j0 + w * 16 + r;  // this lane's key
+  const int jrow = min(j, T - 1);
+  const bool jin = j < T;
+  short8_t bk[2], bv[2];
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) {
+    bk[kk] = row_frag(kb + (long)jrow * LDQ, kk * 32 + g * 8);
+    bv[kk] = row_frag(vb + (long)jrow * LDQ, kk * 32 + g * 8);
+  }
+  float4_t acc_k[4], acc_v[4];  // dK^T / dV^T: rows = head dims n*16 + g*4 + e, column = this lane's key
+#pragma unroll
+  for (int n = 0; n < 4; ++n) { acc_k[n] = float4_t{0.f, 0.f, 0.f, 0.f}; acc_v[n] = float4_t{0.f, 0.f, 0.f, 0.f}; }
+
+  const float scale2 = scale * 1.4426950408889634f;
+  const int lim = 2 * len - 1;
+  const long lrow = ((long)b * H + h) * T;
+  const int ithr = T - 1 + j - lim;  // queries i > ithr: relative position T-1-i+j inside the sample's 2 len - 1 encodings
+  int il0[4], qrow[4];
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    il0[it] = 32 * (it >> 1) + g * 8 + (it & 1) * 4;                      // first of this lane's four queries of tile it (C rows g*4 + e)
+    qrow[it] = 32 * (it >> 1) + (r >> 2) * 8 + (it & 1) * 4 + (r & 3);  // query row that is MFMA row r of tile it (A operand)
+  }
+  const int nib = (T + BI - 1) / BI;
+  if (w == 0 && lane < 8) *reinterpret_cast<uint4*>(sP + 127 * 128 + lane * 16) = bias_row;  // window row 127 <- the bias row, once
+  for (int ib = 0; ib < nib; ++ib) {
+    const int i0 = ib * BI;
+    const bool padded = use_mask && i0 >= len;  // a block of padded query rows: p = 1 / T for every key, dS = 0: only dV += P^T dO
+    // per-query quantities of the block (the previous block's readers are behind its closing barrier)
+    if (threadIdx.x < 64) {
+      const int ic = min(i0 + (int)threadIdx.x, T - 1);
+      sL[threadIdx.x] = lse[lrow + ic] * 1.4426950408889634f;
+      sD[threadIdx.x] = dvec[lrow + ic];
+    }
+    load_rows<BI>(sdO, dob, HD, i0, T, w, lane);
+    if (!padded) {
+      const int pw0 = (T - 1 - (i0 + BI - 1) + j0) + shift;
+      load_rows<BI>(sQu, qub, HD, i0, T, w, lane);
+      load_rows<BI>(sQv, qvb, HD, i0, T, w, lane);
+      load_rows<WIN, false, true>(sP, pb, HD, pw0, R1, w, lane);  // (window row 127 = the bias row, written once in front of the loop)
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    short8_t pp[2], pd[2];  // P / dS of this lane's key against queries 32q + 8g + 0..7: the B operands of the last products
+    if (padded) {
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const float4_t l4 = *reinterpret_cast<const float4_t*>(sL + il0[it]);
+        uint32_t pk[2];
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+          float pv[2];
+#pragma unroll
+          for (int q2 = 0; q2 < 2; ++q2) {
+            const int e = 2 * h2 + q2;
+            pv[q2] = (i0 + il0[it] + e < T && jin) ? __builtin_amdgcn_exp2f(0.f - l4[e]) : 0.f;
+          }
+          pk[h2] = pack2_bf16(pv[0], pv[1]);
+        }
+        const int o4 = (it & 1) * 4;
+        pp[it >> 1][o4 + 0] = (short)(pk[0] & 0xffffu); pp[it >> 1][o4 + 1] = (short)(pk[0] >> 16);
+        pp[it >> 1][o4 + 2] = (short)(pk[1] & 0xffffu); pp[it >> 1][o4 + 3] = (short)(pk[1] >> 16);
+      }
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+          acc_v[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_kt(sdO, n * 16, q * 32 + g * 8, r), pp[q], acc_v[n], 0, 0, 0);
+      __syncthreads();
+      continue;
+    }
+
+    // content scores and dP: rows = queries (dealt), column = this lane's key
+    float4_t acc_s[4], acc_p[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      acc_s[it] = float4_t{0.f, 0.f, 0.f, 0.f};
+      acc_p[it] = float4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        acc_s[it] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(sQu, qrow[it], kk * 4 + g), bk[kk], acc_s[it], 0, 0, 0);
+        acc_p[it] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(sdO, qrow[it], kk * 4 + g), bv[kk], acc_p[it], 0, 0, 0);
+      }
+    }
+    // window scores of this wave's 16 keys: per 16-query tile qt the two 16-column window tiles from column 16 (3 - qt + w) on, transposed
+    // (rows = window columns, column = query 16 qt + r), and the bias-row score of every query (row 15 of window rows 112..127)
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt) {
+      short8_t bq[2];
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) bq[kk] = frag_rows(sQv, qt * 16 + r, kk * 4 + g);
+      const int ct0 = 3 - qt + w;
+#pragma unroll
+      for (int c2 = 0; c2 < 2; ++c2) {
+        float4_t a = float4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(sP, (ct0 + c2) * 16 + r, kk * 4 + g), bq[kk], a, 0, 0, 0);
+        *reinterpret_cast<float4_t*>(sS + (qt * 16 + r) * KT_SLD + c2 * 16 + g * 4) = a;
+      }
+      float4_t ab = float4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+        ab = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(sP, 112 + r, kk * 4 + g), bq[kk], ab, 0, 0, 0);
+      if (g == 3) sGb[qt * 16 + r] = ab[3];
+    }
+    // P and dS in C layout (rows = this lane's queries il0[it] + e, column = its key)
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const float4_t l4 = *reinterpret_cast<const float4_t*>(sL + il0[it]);
+      const float4_t d4 = *reinterpret_cast<const float4_t*>(sD + il0[it]);
+      const float4_t b4 = *reinterpret_cast<const float4_t*>(sGb + il0[it]);
+      uint32_t pkp[2], pkd[2];
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2) {
+        float pv[2], dv2[2];
+#pragma unroll
+        for (int q2 = 0; q2 < 2; ++q2) {
+          const int e = 2 * h2 + q2;
+          const int il = il0[it] + e, i = i0 + il;
+          const float gsk = sS[il * KT_SLD + 15 - (il & 15) + r];
+          const float pos = (i > ithr) ? gsk : b4[e];
+          const bool qmask = use_mask && (i >= len);
+          bool vis = (i < T) && jin;
+          if constexpr (STREAM) {
+            if (!qmask) { int wlo, whi; stream_window(min(i, T - 1), T, chunk, hist, wlo, whi); vis = vis && j >= wlo && j < whi; }
+          }
+          float p = 0.f, d = 0.f;
+          if (vis) {
+            const float s2 = qmask ? 0.f : (acc_s[it][e] + pos) * scale2;
+            p = __builtin_amdgcn_exp2f(s2 - l4[e]);
+            d = qmask ? 0.f : p * (acc_p[it][e] - d4[e]) * scale;
+          }
+          pv[q2] = p; dv2[q2] = d;
+        }
+        pkp[h2] = pack2_bf16(pv[0], pv[1]);
+        pkd[h2] = pack2_bf16(dv2[0], dv2[1]);
+      }
+      const int o4 = (it & 1) * 4;
+      pp[it >> 1][o4 + 0] = (short)(pkp[0] & 0xffffu); pp[it >> 1][o4 + 1] = (short)(pkp[0] >> 16);
+      pp[it >> 1][o4 + 2] = (short)(pkp[1] & 0xffffu); pp[it >> 1][o4 + 3] = (short)(pkp[1] >> 16);
+      pd[it >> 1][o4 + 0] = (short)(pkd[0] & 0xffffu); pd[it >> 1][o4 + 1] = (short)(pkd[0] >> 16);
+      pd[it >> 1][o4 + 2] = (short)(pkd[1] & 0xffffu); pd[it >> 1][o4 + 3] = (short)(pkd[1] >> 16);
+    }
+    // dV^T += dO^T P ; dK^T += (Q+u)^T dS   (A: the dO / qu blocks read transposed, k = query; B: from registers)
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        acc_v[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_kt(sdO, n * 16, q * 32 + g * 8, r), pp[q], acc_v[n], 0, 0, 0);
+        acc_k[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_kt(sQu, n * 16, q * 32 + g * 8, r), pd[q], acc_k[n], 0, 0, 0);
+      }
+    __syncthreads();
+  }
+  if (jin) {
+    bf16_t* row = dqkv + ((long)b * T + j) * LDQ + h * DH;
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      uint2 vk, vv;
+      vk.x = pack2_bf16(acc_k[n][0], acc_k[n][1]); vk.y = pack2_bf16(acc_k[n][2], acc_k[n][3]);
+      vv.x = pack2_bf16(acc_v[n][0], acc_v[n][1]); vv.y = pack2_bf16(acc_v[n][2], acc_v[n][3]);
+      *reinterpret_cast<uint2*>(row + HD + n * 16 + g * 4) = vk;
+      *reinterpret_cast<uint2*>(row + 2 * HD + n * 16 + g * 4) = vv;
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int tfasr_relattn_fused_fwd(const void* qkv, const float* ubias, const float* vbias, const void* pext,
@@ -2416,6 +2632,24 @@ extern "C" int tfasr_relattn_fused_bwd_k(const void* qkv, const void* qu, const 
   if (!qkv || !qu || !qv || !pext || !dout || !lse || !dvec || !dqkv || B <= 0 || H <= 0 || T <= 0) return TFASR_STATUS_INVALID_VALUE;
   if (dtype != TFASR_BF16 || dh != DH) return TFASR_STATUS_UNSUPPORTED;
   dim3 grid((T + BJ - 1) / BJ, H, B);
+  // one key per lane (relattn_fused_bwd_kT_kernel, round 5): TFASR_ATTN_BWDK_T=1 (read per call); needs 8-byte aligned dK / dV rows
+  const char* kt_env = getenv("TFASR_ATTN_BWDK_T");
+  if (kt_env && kt_env[0] == '1' && ((H * DH) & 3) == 0 && (((uintptr_t)dqkv) & 7) == 0) {
+    static bool attr_done = false;
+    if (!attr_done) {
+      (void)hipFuncSetAttribute((const void*)relattn_fused_bwd_kT_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BWD_KT);
+      (void)hipFuncSetAttribute((const void*)relattn_fused_bwd_kT_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BWD_KT);
+      attr_done = true;
+    }
+    if (chunk > 0)
+      hipLaunchKernelGGL(relattn_fused_bwd_kT_kernel<true>, dim3(attn_grid_size(B, H, (int)grid.x)), dim3(256), SMEM_BWD_KT, (hipStream_t)stream_, (const bf16_t*)qkv, (const bf16_t*)qu,
+                         (const bf16_t*)qv, (const bf16_t*)pext, lengths, (const bf16_t*)dout, lse, dvec, (bf16_t*)dqkv, B, H, T, scale, use_mask, chunk, hist);
+    else
+      hipLaunchKernelGGL(relattn_fused_bwd_kT_kernel<false>, dim3(attn_grid_size(B, H, (int)grid.x)), dim3(256), SMEM_BWD_KT, (hipStream_t)stream_, (const bf16_t*)qkv, (const bf16_t*)qu,
+                         (const bf16_t*)qv, (const bf16_t*)pext, lengths, (const bf16_t*)dout, lse, dvec, (bf16_t*)dqkv, B, H, T, scale, use_mask, 0, 0);
+    TFASR_CHECK_LAUNCH();
+    return TFASR_STATUS_SUCCESS;
+  }
   if (chunk > 0)
     hipLaunchKernelGGL(relattn_fused_bwd_k_kernel<true>, dim3(attn_grid_size(B, H, (int)grid.x)), dim3(256), SMEM_BWD_K, (hipStream_t)stream_, (const bf16_t*)qkv, (const bf16_t*)qu,
                        (const bf16_t*)qv, (const bf16_t*)pext, lengths, (const bf16_t*)dout, lse, dvec, (bf16_t*)dqkv, B, H, T, scale, use_mask, chunk, hist);

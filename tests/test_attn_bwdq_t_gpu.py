@@ -60,3 +60,47 @@ def test_transposed_query_backward_matches_row_oriented_kernel(dev, stream, mode
         if float(a.norm()) < 1e-2 * big:
             continue  # (the key bias: its gradient is zero in exact arithmetic - softmax rows sum to one - and pure rounding here)
         assert n1 <= max(4.0 * n0, 1e-2 * float(a.norm())), (k, n0, n1, float(a.norm()))
+
+
+@pytest.mark.parametrize("stream", [None, (8, 24), (16, -1)])
+def test_key_per_lane_backward_matches_row_oriented_kernel(dev, stream):
+    """relattn_fused_bwd_kT_kernel (a lane owns one key; TFASR_ATTN_BWDK_T=1, read per call) against relattn_fused_bwd_k_kernel: same
+    per-pair arithmetic, dK / dV from registers instead of through the per-wave A images."""
+    N = 160000
+    lens, ulens = [160000, 70000, 121000], [6, 3, 5]
+    over = {} if stream is None else dict(chunk_size=stream[0], history_size=stream[1], convm_dw_norm="layer")
+    cfg, ocfg, model, W, data, sig, labels, preds = _setup(dev, torch.bfloat16, lens, ulens, N=N, **over)
+    assert model._fused_attention()
+    model.native_blocks = True
+    out = {}
+    old = os.environ.get("TFASR_ATTN_BWDK_T")
+    try:
+        for tag, flag in (("old", "0"), ("old2", "0"), ("new", "1")):
+            os.environ["TFASR_ATTN_BWDK_T"] = flag
+            model.zero_grad()
+            costs = model.loss_and_backward(data, True, (None, None)).float().cpu().numpy()
+            torch.cuda.synchronize()
+            out[tag] = (costs, model.ps.export_keras(model.ps.grad))
+    finally:
+        if old is None:
+            os.environ.pop("TFASR_ATTN_BWDK_T", None)
+        else:
+            os.environ["TFASR_ATTN_BWDK_T"] = old
+
+    def rel(a, b):
+        num = sum(float(((a[k].double() - b[k].double()) ** 2).sum()) for k in a)
+        den = sum(float((a[k].double() ** 2).sum()) for k in a)
+        return (num / den) ** 0.5
+
+    g0, g0b, g1 = out["old"][1], out["old2"][1], out["new"][1]
+    noise, diff = rel(g0, g0b), rel(g0, g1)
+    print(f"all gradients, relative L2: old vs old again {noise:.2e}, old vs new {diff:.2e}")
+    assert diff < max(3.0 * noise, 2e-3), (noise, diff)
+    att = [k for k in g0 if "mhsa" in k]
+    big = max(float(g0[k].double().norm()) for k in att)
+    for k in att:
+        a, b, c = g0[k].double(), g0b[k].double(), g1[k].double()
+        n0, n1 = float((a - b).norm()), float((a - c).norm())
+        if float(a.norm()) < 1e-2 * big:
+            continue
+        assert n1 <= max(4.0 * n0, 1e-2 * float(a.norm())), (k, n0, n1, float(a.norm()))
