@@ -2282,7 +2282,7 @@ __global__ __launch_bounds__(256, 2) void relattn_fused_bwd_kT_kernel(
   char* sP = sdO + SK_BYTES;
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   float* sS = reinterpret_cast<float*>(sP + SP_BYTES + w * KT_STRIP_BYTES);                 // [64 il][32]: window columns 16 (3 - qt + w) .. + 31 of query tile qt
-  float* sGb = reinterpret_cast<float*>(sP + SP_BYTES + 4 * KT_STRIP_BYTES + w * 256);       // [64]: bias-row score of every query of the block (per wave)
+  float* sGb = reinterpret_cast<float*>(sP + SP_BYTES + 4 * KT_STRIP_BYTES);                 // [64]: bias-row score of every query of the block (wave w forms queries 16w .. 16w+15)
   float* sL = reinterpret_cast<float*>(sP + SP_BYTES + 4 * KT_STRIP_BYTES + 4 * 256);        // [64] lse * log2 e, [64] D
   float* sD = sL + 64;
   const int r = lane & 15, g = lane >> 4;
@@ -2326,22 +2326,39 @@ __global__ __launch_bounds__(256, 2) void relattn_fused_bwd_kT_kernel(
   }
   const int nib = (T + BI - 1) / BI;
   if (w == 0 && lane < 8) *reinterpret_cast<uint4*>(sP + 127 * 128 + lane * 16) = bias_row;  // window row 127 <- the bias row, once
+  // The loads of query block ib+1 are issued INSIDE block ib: the qv block and the window - dead once the window scores are formed -
+  // behind a barrier in the middle of the block, the qu / dO blocks and the per-query scalars behind the closing barrier (inline-asm DMA:
+  // the compiler places no vmcnt wait of its own in front of the LDS reads; everything is waited for at the top of the next block).
+  auto issue_early = [&](int ibn) {  // qv block + window of query block ibn
+    const int i0n = ibn * BI;
+    load_rows<BI, true>(sQv, qvb, HD, i0n, T, w, lane);
+    load_rows<WIN, true, true>(sP, pb, HD, (T - 1 - (i0n + BI - 1) + j0) + shift, R1, w, lane);  // (row 127 = the bias row stays)
+  };
+  auto issue_late = [&](int ibn, bool pad) {  // per-query scalars, dO block, qu block
+    const int i0n = ibn * BI;
+    // (the scalars' global loads are requested first and stored last: their latency runs under the DMA issue instead of in front of it)
+    float l = 0.f, d = 0.f;
+    if (threadIdx.x < 64) {
+      const int ic = min(i0n + (int)threadIdx.x, T - 1);
+      l = lse[lrow + ic];
+      d = dvec[lrow + ic];
+    }
+    load_rows<BI, true>(sdO, dob, HD, i0n, T, w, lane);
+    if (!pad) load_rows<BI, true>(sQu, qub, HD, i0n, T, w, lane);
+    if (threadIdx.x < 64) {
+      sL[threadIdx.x] = l * 1.4426950408889634f;
+      sD[threadIdx.x] = d;
+    }
+  };
+  if (nib > 0) {
+    const bool pad0 = use_mask && 0 >= len;
+    if (!pad0) issue_early(0);
+    issue_late(0, pad0);
+  }
   for (int ib = 0; ib < nib; ++ib) {
     const int i0 = ib * BI;
     const bool padded = use_mask && i0 >= len;  // a block of padded query rows: p = 1 / T for every key, dS = 0: only dV += P^T dO
-    // per-query quantities of the block (the previous block's readers are behind its closing barrier)
-    if (threadIdx.x < 64) {
-      const int ic = min(i0 + (int)threadIdx.x, T - 1);
-      sL[threadIdx.x] = lse[lrow + ic] * 1.4426950408889634f;
-      sD[threadIdx.x] = dvec[lrow + ic];
-    }
-    load_rows<BI>(sdO, dob, HD, i0, T, w, lane);
-    if (!padded) {
-      const int pw0 = (T - 1 - (i0 + BI - 1) + j0) + shift;
-      load_rows<BI>(sQu, qub, HD, i0, T, w, lane);
-      load_rows<BI>(sQv, qvb, HD, i0, T, w, lane);
-      load_rows<WIN, false, true>(sP, pb, HD, pw0, R1, w, lane);  // (window row 127 = the bias row, written once in front of the loop)
-    }
+    const bool more = ib + 1 < nib, padded_next = use_mask && i0 + BI >= len;
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
@@ -2371,6 +2388,7 @@ __global__ __launch_bounds__(256, 2) void relattn_fused_bwd_kT_kernel(
         for (int n = 0; n < 4; ++n)
           acc_v[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_kt(sdO, n * 16, q * 32 + g * 8, r), pp[q], acc_v[n], 0, 0, 0);
       __syncthreads();
+      if (more) issue_late(ib + 1, true);  // (padded blocks are the tail of the loop: the next one is padded too)
       continue;
     }
 
@@ -2402,13 +2420,46 @@ __global__ __launch_bounds__(256, 2) void relattn_fused_bwd_kT_kernel(
           a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(sP, (ct0 + c2) * 16 + r, kk * 4 + g), bq[kk], a, 0, 0, 0);
         *reinterpret_cast<float4_t*>(sS + (qt * 16 + r) * KT_SLD + c2 * 16 + g * 4) = a;
       }
-      float4_t ab = float4_t{0.f, 0.f, 0.f, 0.f};
+      if (qt == w) {  // the bias-row score of queries 16w .. 16w+15 (row 15 of window rows 112..127): one tile per wave, shared
+        float4_t ab = float4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk)
-        ab = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(sP, 112 + r, kk * 4 + g), bq[kk], ab, 0, 0, 0);
-      if (g == 3) sGb[qt * 16 + r] = ab[3];
+        for (int kk = 0; kk < 2; ++kk)
+          ab = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(sP, 112 + r, kk * 4 + g), bq[kk], ab, 0, 0, 0);
+        if (g == 3) sGb[qt * 16 + r] = ab[3];
+      }
     }
-    // P and dS in C layout (rows = this lane's queries il0[it] + e, column = its key)
+    // every wave has read the qv block and the window, and the bias-row scores of all 64 queries are in LDS
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (more && !padded_next) issue_early(ib + 1);
+    // P and dS in C layout (rows = this lane's queries il0[it] + e, column = its key).  A block whose 64 queries are all real, unmasked and
+    // inside the table for every key of the wave (the common one) needs none of the selects.
+    bool plain = false;
+    if constexpr (!STREAM) plain = __builtin_amdgcn_ballot_w64(jin && i0 + BI <= (use_mask ? min(T, len) : T) && i0 > ithr) == ~0ull;
+    if (plain) {
+      const float Dsc = scale;
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const float4_t l4 = *reinterpret_cast<const float4_t*>(sL + il0[it]);
+        const float4_t d4 = *reinterpret_cast<const float4_t*>(sD + il0[it]);
+        uint32_t pkp[2], pkd[2];
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+          const int e0 = 2 * h2, ila = il0[it] + e0, ilb = ila + 1;
+          const float2_t gs = float2_t{sS[ila * KT_SLD + 15 - (ila & 15) + r], sS[ilb * KT_SLD + 15 - (ilb & 15) + r]};
+          const float2_t ex = (float2_t{acc_s[it][e0], acc_s[it][e0 + 1]} + gs) * scale2 - float2_t{l4[e0], l4[e0 + 1]};
+          const float2_t pv = float2_t{__builtin_amdgcn_exp2f(ex[0]), __builtin_amdgcn_exp2f(ex[1])};
+          const float2_t dv2 = pv * ((float2_t{acc_p[it][e0], acc_p[it][e0 + 1]} - float2_t{d4[e0], d4[e0 + 1]}) * Dsc);
+          pkp[h2] = pack2_bf16(pv[0], pv[1]);
+          pkd[h2] = pack2_bf16(dv2[0], dv2[1]);
+        }
+        const int o4 = (it & 1) * 4;
+        pp[it >> 1][o4 + 0] = (short)(pkp[0] & 0xffffu); pp[it >> 1][o4 + 1] = (short)(pkp[0] >> 16);
+        pp[it >> 1][o4 + 2] = (short)(pkp[1] & 0xffffu); pp[it >> 1][o4 + 3] = (short)(pkp[1] >> 16);
+        pd[it >> 1][o4 + 0] = (short)(pkd[0] & 0xffffu); pd[it >> 1][o4 + 1] = (short)(pkd[0] >> 16);
+        pd[it >> 1][o4 + 2] = (short)(pkd[1] & 0xffffu); pd[it >> 1][o4 + 3] = (short)(pkd[1] >> 16);
+      }
+    } else
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
       const float4_t l4 = *reinterpret_cast<const float4_t*>(sL + il0[it]);
@@ -2455,6 +2506,7 @@ __global__ __launch_bounds__(256, 2) void relattn_fused_bwd_kT_kernel(
         acc_k[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_kt(sQu, n * 16, q * 32 + g * 8, r), pd[q], acc_k[n], 0, 0, 0);
       }
     __syncthreads();
+    if (more) issue_late(ib + 1, padded_next);
   }
   if (jin) {
     bf16_t* row = dqkv + ((long)b * T + j) * LDQ + h * DH;
