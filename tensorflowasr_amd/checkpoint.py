@@ -345,18 +345,21 @@ def load_state(model, filepath):
         if list(z["names"]) != list(ps.names):
             raise ValueError(f"{filepath} was written by a different model configuration (parameter names differ)")
         logical = "layout" in z.files and str(z["layout"]) == "logical"
-        if not logical and int(z["n"]) != ps.n:
-            raise ValueError(f"{filepath} stores the parameters in the padded device layout of the run that wrote it ({int(z['n'])} values; this "
-                             f"model holds {ps.n}): it resumes only into the same storage type and TFASR_HEAD_PAD / TFASR_FILTER_PAD settings")
+        if not logical:
+            # A device-layout file (round 3 or earlier) stores the flat buffer in the PHYSICAL order of the run that wrote it.  That order is
+            # not a contract: round 5 moved every block's LayerNorm / positional / depthwise variables into a region behind the last block
+            # (ParamStore.defer_lo), with `names` and the element count unchanged - a raw copy would land parameters and Adam moments at
+            # permuted offsets without any error.  Such files are refused; weights alone travel through save_weights / load_weights
+            # (per-variable, layout-free).
+            raise ValueError(f"{filepath} stores the training state in the physical device layout of the build that wrote it (no 'layout: logical' "
+                             f"marker).  That layout has changed since; the file cannot be mapped safely.  Re-save it with the build that wrote it "
+                             f"using a version that writes the logical layout, or restore the weights only (load_weights).")
 
         def put(key, buf):
-            if logical:
-                try:
-                    ps.from_logical(z[key], buf)
-                except ValueError as e:
-                    raise ValueError(f"{filepath}: {key}: {e} (different model configuration)") from e
-            else:
-                buf.copy_(torch.from_numpy(z[key]))
+            try:
+                ps.from_logical(z[key], buf)
+            except ValueError as e:
+                raise ValueError(f"{filepath}: {key}: {e} (different model configuration)") from e
 
         put("flat", ps.flat)
         put("adam_m", ps.adam_m)
@@ -376,5 +379,5 @@ def load_state(model, filepath):
             model._rng.bit_generator.state = json.loads(str(z["rng"]))
         for k in ps.state:
             v = torch.from_numpy(z["state|" + k.replace("/", "|")])
-            ps.state[k].copy_(ps._pad(k, v) if logical else v)
+            ps.state[k].copy_(ps._pad(k, v))
     ps.refresh_shadow()

@@ -43,6 +43,13 @@ def test_self_launch_two_ranks_gloo():
     assert out["n_gpus"] == 2 and out["steps"] == 3 and out["warmup"] == 1 and out["scaling"] == "weak"
     assert out["config"]["global_batch"] == 2 * 32 and out["config"]["parallelism"] == "dp2"
     assert out["value"] > 0
+    # three timed regions by default, the line reports the median one; per-rank wire accounting of the data-parallel route
+    reg = out["regions"]
+    assert len(reg["ms_per_step"]) == 3 and reg["min"] <= reg["median"] <= reg["max"] and out["ms_per_step"] == reg["median"]
+    assert len(reg["host_enqueue_ms_per_step"]) == 3
+    dpr = out["dp"]
+    assert dpr["rank0"]["syncbn_wait_calls_per_step"] == 1.0 and dpr["rank_step_ms_min"] <= dpr["rank_step_ms_max"]
+    assert set(dpr["max_over_ranks"]) == {"syncbn_wait_ms", "grad_allreduce_exposed_ms"} and dpr["stats_communicator"] == "own"
 
 
 def test_refuses_world_mismatch():

@@ -320,3 +320,24 @@ def test_h5_weights_refuse_contextnet(tmp_path):
         ck.save_weights_h5(fake, str(tmp_path / "w.weights.h5"))
     with pytest.raises(NotImplementedError):
         ck.load_weights_h5(fake, str(tmp_path / "w.weights.h5"))
+
+
+def test_device_layout_state_files_are_refused(tmp_path):
+    """ADVICE r05: a state file without the logical-layout marker holds the flat buffer in the physical order of the build that wrote it;
+    that order changed (deferred region) while names and count did not, so such a file must be refused, not copied raw."""
+    import pytest
+
+    from tensorflowasr_amd import checkpoint
+
+    class PS:
+        names = ["a", "b"]
+        n = 4
+
+    class M:
+        ps = PS()
+
+    f = tmp_path / "old_state.npz"
+    np.savez(f, names=np.asarray(["a", "b"]), n=np.asarray(4), flat=np.zeros(4, np.float32), adam_m=np.zeros(4, np.float32), adam_v=np.zeros(4, np.float32),
+             step=np.asarray(3), drop_epoch=np.asarray(0), ga_count=np.asarray(0))
+    with pytest.raises(ValueError, match="physical device layout"):
+        checkpoint.load_state(M(), str(f))

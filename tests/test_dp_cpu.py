@@ -102,3 +102,51 @@ def test_two_process_gloo_gradient_accumulation(tmp_path):
             np.testing.assert_allclose(outs[r][micro].numpy(), want.numpy(), rtol=1e-6, atol=1e-6)
         want = sum(g(m, rr) for m in range(ga) for rr in range(world))  # every micro-gradient of every rank exactly ONCE
         np.testing.assert_allclose(outs[r][ga - 1].numpy(), want.numpy(), rtol=1e-5, atol=1e-5)
+
+
+def _worker_wire(rank, world, port, outdir):
+    """bf16 gradient wire vs the f32 wire, the dedicated sync-BN communicator and the per-rank accounting."""
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from tensorflowasr_amd import dp
+
+    d = dp.init_from_env(backend="gloo")
+    assert d.stats_group is not d.group and d.stats_group is not None  # its own communicator
+    d16 = dp.DataParallel(grad_wire="bf16")
+    n = 50_000
+    # gradient-like values, pre-scaled by 1 / (B_local * world) as the step scales them
+    g0 = torch.randn(n, generator=torch.Generator().manual_seed(7 + rank)) * torch.logspace(-6, 0, n) / (4 * world)
+    out = {}
+    for name, hook in (("f32", d), ("bf16", d16)):
+        grad = g0.clone()
+        hook.bucket_bytes = 40_000
+        hook.attach(grad)
+        hook.accounting.enable()
+        hook.grads_ready(30_000, 50_000)
+        hook.grads_ready(20_000, 30_000)
+        hook.grads_ready(0, 5_000)
+        st = torch.full((8,), float(rank + 1))
+        hook.allreduce_stats_(st)
+        hook.finish_grads()
+        acc = hook.accounting.summary(1)
+        assert acc["syncbn_wait_calls_per_step"] == 1 and acc["grad_allreduce_exposed_calls_per_step"] == 1
+        assert acc["syncbn_wait_ms"] >= 0 and acc["grad_allreduce_exposed_ms"] >= 0
+        assert float(st[0]) == sum(range(1, world + 1))
+        out[name] = grad
+    torch.save(out, os.path.join(outdir, f"w{rank}.pt"))
+    d.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_bf16_gradient_wire_matches_f32_wire_within_bf16_rounding(tmp_path):
+    world, n = 2, 50_000
+    mp.spawn(_worker_wire, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    outs = [torch.load(os.path.join(tmp_path, f"w{r}.pt")) for r in range(world)]
+    want = sum(torch.randn(n, generator=torch.Generator().manual_seed(7 + r)) * torch.logspace(-6, 0, n) / (4 * world) for r in range(world))
+    for o in outs:
+        np.testing.assert_allclose(o["f32"].numpy(), want.numpy(), rtol=1e-6, atol=1e-9)
+        # every summand rounded to bf16 once (2^-9 relative each), one bf16 add: |err| <= 2^-8 * sum|summands| elementwise; whole vector far better
+        summ = sum((torch.randn(n, generator=torch.Generator().manual_seed(7 + r)) * torch.logspace(-6, 0, n) / (4 * world)).abs() for r in range(world))
+        assert bool(((o["bf16"] - want).abs() <= 2.0 ** -7 * summ + 1e-12).all())
+        rel = float((o["bf16"] - want).norm() / want.norm())
+        assert rel < 4e-3, rel
+    assert torch.equal(outs[0]["bf16"], outs[1]["bf16"])  # replicas stay bit-identical
