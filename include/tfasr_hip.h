@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define TFASR_ABI_VERSION 34
+#define TFASR_ABI_VERSION 35
 
 typedef enum {
   TFASR_STATUS_SUCCESS = 0,
@@ -199,15 +199,6 @@ int tfasr_layernorm_fwd(const void* x, const float* gamma, const float* beta, vo
 int tfasr_ffn_fused_fwd(const void* x, const float* gamma, const float* beta, const void* W1, const float* b1, const void* W2,
                         const float* b2, void* y, void* ln, float* mean, float* rstd, void* z, void* h, long rows, int d, int F,
                         float ln_eps, float res_factor, float drop_p, long drop_seed1, long drop_seed2, int dtype, void* stream);
-/* The data-gradient side of the same module in ONE launch (csrc/ffn_fused_bwd.h): dz = res (dyd W2^T) swish'(z) mask1/(1-p) [rows, F]
- * (written for the weight gradients), dln = dz W1^T, dx = add + LayerNorm'(dln; x, mean, rstd, gamma) (+ dx_dropped = dropout(dx) with
- * (drop_p, drop_seed_next), NULL: none); the LayerNorm's gamma / beta sums leave as per-tile partial sums part[tiles][2 d]
- * (tiles = tfasr_ffn_fused_bwd_tiles(rows); fold with tfasr_layernorm_bwd_fold).  dyd = dy with the second dropout's mask applied.
- * UNSUPPORTED unless bf16, d == 256, F % 64 == 0, 128 <= F <= 1024, rows * F < 2^32, 16-byte aligned tensors. */
-int tfasr_ffn_fused_bwd_tiles(long rows);
-int tfasr_ffn_fused_bwd(const void* dyd, const void* z, const void* W1, const void* W2, const void* x, const float* gamma, const float* mean,
-                        const float* rstd, const void* add, void* dz, void* dx, void* dx_dropped, float* part, long rows, int d, int F,
-                        float res_factor, float drop_p, long drop_seed1, long drop_seed_next, int dtype, void* stream);
 int tfasr_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
                         const void* add, void* dx, float* dgamma, float* dbeta, long rows, int C, int dtype,
                         void* stream);
@@ -225,8 +216,8 @@ int tfasr_layernorm_bwd_part_blocks(long rows, int C, int dtype);
 int tfasr_layernorm_bwd_part(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, const void* add,
                              void* dx, float* part, void* dx_dropped, float drop_p, long drop_seed, long rows, int C, int dtype,
                              void* stream);
-/* ..._part with an explicit number of partial-sum slots (>= 1; a buffer shared with other producers of LayerNorm partial sums, e.g.
-   tfasr_ffn_fused_bwd, whose slot count differs): exactly nblk blocks run, the ones without rows store zeros. */
+/* ..._part with an explicit number of partial-sum slots (>= 1; a buffer shared with other producers of LayerNorm partial sums whose slot
+   count differs): exactly nblk blocks run, the ones without rows store zeros. */
 int tfasr_layernorm_bwd_part_n(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, const void* add,
                                void* dx, float* part, int nblk, void* dx_dropped, float drop_p, long drop_seed, long rows, int C, int dtype,
                                void* stream);
@@ -361,32 +352,23 @@ int tfasr_relattn_fused_fwd(const void* qkv, const float* ubias, const float* vb
                             const int32_t* lengths, void* out, float* lse, int B, int H, int T, int dh, float scale,
                             int use_mask, int chunk, int hist, int dtype, void* stream);
 
-/* Fused backward, query side: recomputes the probabilities from lse, returns dqu [B*T, H*dh] = d/d(q+u) and the skewed
- * score gradient dpos [B,H,T,ldp] (same meaning as tfasr_relattn_softmax_bwd's dpos, fully written); o/dout [B*T, H*dh]. */
-int tfasr_relattn_fused_bwd_q(const void* qkv, const float* ubias, const float* vbias, const void* pext,
-                              const int32_t* lengths, const void* o, const void* dout, const float* lse, void* dqu, void* dpos,
-                              float* dvec, int B, int H, int T, int dh, int ldp, float scale, int use_mask, int dtype,
-                              void* stream);
-/* Query side without the skewed score gradient in HBM (default path): also returns dqv [B*T, H*dh] = d/d(q+v) (formed in the
- * kernel against the window rows), stores the UNSKEWED score gradient ds [B,H,T,lds] (lds >= T, multiple of 8) and adds the bias
- * row's share into dpext [2T, H*dh] f32 (zeroed by the caller).  With use_mask, the ds rows (and D_i) of a 64-row query block that lies
- * entirely in the padding (i0 >= lengths[b]) are NOT written: their gradient is zero and tfasr_relattn_dpext skips those tiles.  tfasr_relattn_dpext then accumulates the rest of dpext from ds
- * and qv = q + v ([B*T, H*dh], tfasr_bias2_fwd): one f32 atomic per (table row, column, sample group). */
-int tfasr_relattn_fused_bwd_q2(const void* qkv, const float* ubias, const float* vbias, const void* pext,
-                               const int32_t* lengths, const void* o, const void* dout, const float* lse, void* dqu, void* dqv, void* ds,
-                               float* dvec, float* dpext, int B, int H, int T, int dh, int lds, float scale, int use_mask, int chunk, int hist,
-                               int dtype, void* stream);
-/* _q2 with the query gradient finished in the kernel: dq (row stride lddq, e.g. the q columns of the fused [B*T, 3*H*dh] gradient)
- * = dqu + dqv, du [H*dh] += column sums of dqu, dv += column sums of dqv (what tfasr_bias2_bwd does in a separate pass).
- * qu / qv (both or neither, [B*T, H*dh], 16-byte aligned): also written here = q + u / q + v for tfasr_relattn_fused_bwd_k and
- * tfasr_relattn_dpext (what tfasr_bias2_fwd writes), except the rows of wholly padded 64-query blocks, which those two never read. */
+/* Fused backward, query side (transposed orientation, csrc/attn_fused.hip relattn_fused_bwd_qT_kernel): recomputes the probabilities
+ * from lse; o / dout [B*T, H*dh].  The query gradient leaves the kernel complete: dq (row stride lddq, a multiple of 4, e.g. the q
+ * columns of the fused [B*T, 3*H*dh] gradient) = dqu + dqv with dqu = d/d(q+u), dqv = d/d(q+v) (formed against the window rows);
+ * du [H*dh] += column sums of dqu, dv += column sums of dqv.  The UNSKEWED score gradient ds [B,H,T,lds] (lds >= T, multiple of 8) is
+ * stored for tfasr_relattn_dpext, dvec [B,H,T] = rowsum(dout * o) for the key side, and the bias row's share is added into
+ * dpext [2T, H*dh] f32 (zeroed by the caller).  With use_mask, the ds rows (and dvec) of a 64-row query block that lies entirely in the
+ * padding (i0 >= lengths[b]) are NOT written: their gradient is zero and tfasr_relattn_dpext skips those tiles.
+ * qu / qv (both or neither, [B*T, H*dh], 16-byte aligned): also written = q + u / q + v for tfasr_relattn_fused_bwd_k and
+ * tfasr_relattn_dpext (what tfasr_bias2_fwd writes), except the rows of wholly padded 64-query blocks, which those two never read.
+ * (Entry points _bwd_q / _bwd_q2 of ABI <= 34 - the row-oriented kernels - are gone: ABI 35.) */
 int tfasr_relattn_fused_bwd_q3(const void* qkv, const float* ubias, const float* vbias, const void* pext, const int32_t* lengths,
                                const void* o, const void* dout, const float* lse, void* dq, long lddq, float* du, float* dv, void* ds,
                                float* dvec, float* dpext, void* qu, void* qv, int B, int H, int T, int dh, int lds, float scale, int use_mask,
                                int chunk, int hist, int dtype, void* stream);
 int tfasr_relattn_dpext(const void* ds, const void* qv, const int32_t* lengths, float* dpext, int B, int H, int T, int dh, int lds,
                         int use_mask, int dtype, void* stream);
-/* Fused backward, key side (run after _bwd_q, which also emits dvec [B,H,T] = rowsum(dout*o)): writes the k and v column
+/* Fused backward, key side (run after _bwd_q3, which also emits dvec [B,H,T] = rowsum(dout*o)): writes the k and v column
  * blocks of dqkv [B*T, 3*H*dh]; qu/qv [B*T, H*dh] = q+u / q+v (tfasr_bias2_fwd). */
 int tfasr_relattn_fused_bwd_k(const void* qkv, const void* qu, const void* qv, const void* pext, const int32_t* lengths,
                               const void* dout, const float* lse, const float* dvec, void* dqkv, int B, int H, int T, int dh,

@@ -152,7 +152,7 @@ def load(build_if_missing=True):
     return lib
 
 
-ABI_VERSION = 34
+ABI_VERSION = 35
 
 
 STATUS_UNSUPPORTED = 3

@@ -636,24 +636,18 @@ class ConformerTransducer(BaseModel):
         datt = self._dense_bwd(self._mask_grad(dy, s["drop"]), s["att"], pfx + "o/w", pfx + "o/b", alpha=c.mhsam_residual)
         dqkv = torch.empty_like(qkv)
         if "lse" in s:
+            # fused kernels: no skewed score gradient in HBM - the query-side kernel finishes dq = dqu + dqv and the u / v bias gradients,
+            # the key-side kernel writes dk / dv, dpext is accumulated from the unskewed dS by tfasr_relattn_dpext
             R1p = -(-R1 // 8) * 8
             um = c.use_attention_auto_mask
-            if os.environ.get("TFASR_ATTN_DPOS", "0") != "1" or c.chunk_size:
-                # default: no skewed score gradient in HBM (attn_fused.hip V2) - dqv comes out of the query-side kernel, dpext is
-                # accumulated from the unskewed dS by tfasr_relattn_dpext
-                dpext = torch.zeros(R1, HD, dtype=torch.float32, device=self.device)
-                win = dict(chunk_size=c.chunk_size, history_size=c.history_size)
-                dqu, dqv, ds, dvec = K.relattn_fused_bwd_q2(qkv, ub, vb, s["pext"], elen_dev, s["att"], datt, s["lse"], dpext, B, H, T, dh, scale,
-                                                            use_mask=um, **win)
-                qu, qv = K.bias2_fwd(qkv, 3 * HD, ub, vb, B * T, HD)
-                K.relattn_fused_bwd_k(qkv, qu, qv, s["pext"], elen_dev, datt, s["lse"], dvec, dqkv, B, H, T, dh, scale, use_mask=um, **win)
-                K.relattn_dpext(ds, qv, elen_dev, dpext, B, H, T, dh, use_mask=um)
-                return self._mhsa_bwd_tail(dy, pfx, B, T, s, dqkv, dqu, None, qv, R1p, 1.0, dqv=dqv, dpext=dpext)
-            dqu, dpos, dvec = K.relattn_fused_bwd_q(qkv, ub, vb, s["pext"], elen_dev, s["att"], datt, s["lse"], B, H, T, dh,
-                                                    R1p, scale, use_mask=um)
-            qu, qv = K.bias2_fwd(qkv, 3 * HD, ub, vb, B * T, HD)
-            K.relattn_fused_bwd_k(qkv, qu, qv, s["pext"], elen_dev, datt, s["lse"], dvec, dqkv, B, H, T, dh, scale, use_mask=um)
-            return self._mhsa_bwd_tail(dy, pfx, B, T, s, dqkv, dqu, dpos, qv, R1p, 1.0)
+            dpext = torch.zeros(R1, HD, dtype=torch.float32, device=self.device)
+            win = dict(chunk_size=c.chunk_size, history_size=c.history_size)
+            gu, gv = self._uv(pfx, grad=True)
+            ds, dvec, qu, qv = K.relattn_fused_bwd_q3(qkv, ub, vb, s["pext"], elen_dev, s["att"], datt, s["lse"], dqkv, gu, gv, dpext, B, H, T, dh, scale,
+                                                      use_mask=um, **win)
+            K.relattn_fused_bwd_k(qkv, qu, qv, s["pext"], elen_dev, datt, s["lse"], dvec, dqkv, B, H, T, dh, scale, use_mask=um, **win)
+            K.relattn_dpext(ds, qv, elen_dev, dpext, B, H, T, dh, use_mask=um)
+            return self._mhsa_bwd_tail(dy, pfx, B, T, s, dqkv, None, None, qv, R1p, 1.0, dqv=None, dpext=dpext, dq_done=True)
         probs = s["probs"]
         kk, vv = qkv[:, HD:], qkv[:, 2 * HD:]
         # dprobs = datt @ v^T
@@ -678,14 +672,14 @@ class ConformerTransducer(BaseModel):
         # handled inside the fused kernels
         return (self.dtype == torch.bfloat16 and self.ps.head_phys == 64 and os.environ.get("TFASR_ATTN_UNFUSED", "0") != "1")
 
-    def _mhsa_bwd_tail(self, dy, pfx, B, T, s, dqkv, dqu, dpos, qv, R1p, scale, dqv=None, dpext=None):
+    def _mhsa_bwd_tail(self, dy, pfx, B, T, s, dqkv, dqu, dpos, qv, R1p, scale, dqv=None, dpext=None, dq_done=False):
         """dpos [B,H,T,R1p] (gradient of the un-shifted position scores) -> dqv, dpext, bias and projection gradients
-        (dqv / dpext already formed by the fused V2 kernels when given)."""
+        (dq_done: the fused kernels have already written dq and the bias gradients and accumulated dpext)."""
         ps, c = self.ps, self.cfg
         H, dh = c.num_heads, ps.head_phys
         HD = H * dh
         R1 = 2 * T
-        if dqv is None:
+        if dqv is None and not dq_done:
             # dqv = scale * dpos @ pext ; dpext += scale * sum_b dpos^T @ qv
             dqv = torch.empty(B * T, HD, dtype=self.dtype, device=self.device)
             K.gemm(dpos, s["pext"], dqv, T, dh, R1, R1p, HD, HD, nb1=B, nb2=H, sA=(H * T * R1p, T * R1p), sB=(0, dh), sD=(T * HD, dh),
@@ -693,8 +687,9 @@ class ConformerTransducer(BaseModel):
             dpext = torch.zeros(R1, HD, dtype=torch.float32, device=self.device)
             K.gemm(dpos, qv, dpext, R1, dh, T, R1p, HD, HD, trans_a=True, nb1=B, nb2=H, sA=(H * T * R1p, T * R1p), sB=(T * HD, dh),
                    sD=(0, dh), alpha=scale, accumulate=True)
-        gu, gv = self._uv(pfx, grad=True)
-        K.bias2_bwd(dqu, dqv, dqkv, 3 * HD, gu, gv, B * T, HD)
+        if not dq_done:
+            gu, gv = self._uv(pfx, grad=True)
+            K.bias2_bwd(dqu, dqv, dqkv, 3 * HD, gu, gv, B * T, HD)
         # positional projection: gWpos += pe^T dpext ; gbpos += colsum(dpext)
         dpext_t = dpext if self.dtype == torch.float32 else K.cast(dpext, torch.empty(R1, HD, dtype=self.dtype, device=self.device))
         pe = self._pe_ext(T)

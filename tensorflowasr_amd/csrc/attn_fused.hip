@@ -10,8 +10,11 @@
 // strip, runs an online softmax in registers and accumulates P@V.  Saves lse[b,h,i] = log sum_j exp(s_ij) for the backward.
 // Auto-mask semantics as in attention.hip: padded QUERY rows give uniform attention over all T keys; keys are never masked.
 #include "common.h"
-#ifdef TFASR_ATTN_TIMING
+#ifdef TFASR_ATTN_TIMING  // probe build (tools/build_probe_lib.sh attn_fused.hip -DTFASR_ATTN_TIMING): shader clocks per phase
 __device__ long long g_attn_timing[8 * 8192];
+#define ATT_TICK(k) { const long long t_ = __builtin_readcyclecounter(); ph[k] += t_ - tp; tp = t_; }
+#else
+#define ATT_TICK(k)
 #endif
 #include <algorithm>
 
@@ -24,14 +27,6 @@ namespace {
 
 constexpr int DH = 64, BI = 64, BJ = 64, WIN = 128;
 constexpr int SK_BYTES = BJ * DH * 2, SV_BYTES = BJ * DH * 2, SP_BYTES = WIN * DH * 2;
-constexpr int GLD = 132;                                   // f32 row stride of the per-wave G strip
-constexpr int SG_BYTES = 16 * GLD * 4, SPB_BYTES = 16 * BJ * 2;
-// forward: the per-wave G strip holds only the 80 window columns the wave's skew reads + the bias column (stride 81), and the P image
-// of the block is written over it once the scores have been read: 53.5 KB per workgroup = THREE workgroups per CU (it was 74 KB = two;
-// the kernel is a dependent chain load -> MFMA -> LDS -> VALU -> LDS -> MFMA per key block and lives on co-resident workgroups)
-constexpr int GLDC = 81, SGC_BYTES = 16 * GLDC * 4;
-constexpr int SMEM_FWD = SK_BYTES + SV_BYTES + SP_BYTES + 4 * SGC_BYTES;
-
 // chunk swizzle of the 128-byte-row images: bits 0, 1 and 3 of the row.  With it the three ways these images are read are all free of
 // bank conflicts (tools/hwprobe/lds_sim.py): 16 consecutive rows per ds_read_b128 lane group, the key-dealt rows of the transposed kernels
 // (32q + 8a + o + b: rows 0-3, 8-11, 16-19, 24-27 in one group), and the transposed ds_read_b64_tr_b16 fragments (rows k..k+3 and k+8..k+11
@@ -147,237 +142,6 @@ __device__ __forceinline__ void stream_window(int i, int T, int chunk, int hist,
   hi = min(T, index + chunk);
 }
 
-template <bool STREAM>
-__global__ __launch_bounds__(256, 3) void relattn_fused_fwd_kernel(
-    const bf16_t* __restrict__ qkv, const float* __restrict__ ubias, const float* __restrict__ vbias,
-    const bf16_t* __restrict__ pext, const int32_t* __restrict__ lengths, bf16_t* __restrict__ out, float* __restrict__ lse_out,
-    int B, int H, int T, float scale, int use_mask, int chunk, int hist) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* sK = smem;
-  char* sV = sK + SK_BYTES;
-  char* sP = sV + SV_BYTES;
-  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  float* sG = reinterpret_cast<float*>(sP + SP_BYTES + w * SGC_BYTES);  // [16][81]: columns 48-16w .. 127-16w of the window scores, then column 127
-  char* sPb = reinterpret_cast<char*>(sG);                              // P image [16][64] bf16, over the strip once it has been read
-  const int r = lane & 15, g = lane >> 4;
-  const int b = blockIdx.z, h = blockIdx.y, i0 = blockIdx.x * BI;
-  const int HD = H * DH, LDQ = 3 * HD, R = 2 * T - 1, R1 = 2 * T;
-  const int len = lengths ? min(lengths[b], T) : T;
-  const int shift = T - len;
-  const bf16_t* qb = qkv + (long)b * T * LDQ + h * DH;  // q columns of head h
-  const bf16_t* kb = qb + HD;
-  const bf16_t* vb = qb + 2 * HD;
-  const bf16_t* pb = pext + h * DH;
-  // the bias row R of the position table (window row 127 / 95 of every key block): 16 bytes per lane of wave 0, loaded ONCE - inside the
-  // block loop it was a dependent global load between the barrier and the __syncthreads() of every iteration
-  uint4 bias_row = make_uint4(0, 0, 0, 0);
-  if ((threadIdx.x >> 6) == 0 && (threadIdx.x & 63) < 8) bias_row = *reinterpret_cast<const uint4*>(pb + (long)(2 * T - 1) * HD + (((threadIdx.x & 63) ^ key_d(127)) << 3));
-
-  // Q fragments (A operand): this lane's row
-  const int irow = min(i0 + w * 16 + r, T - 1);
-  short8_t aqu[2], aqv[2];
-#pragma unroll
-  for (int kk = 0; kk < 2; ++kk) {
-    aqu[kk] = q_frag(qb + (long)irow * LDQ, ubias + h * DH, kk * 32 + g * 8);
-    aqv[kk] = q_frag(qb + (long)irow * LDQ, vbias + h * DH, kk * 32 + g * 8);
-  }
-
-  float m_run[4], l_run[4];
-  float4_t acc_o[4];
-#pragma unroll
-  for (int e = 0; e < 4; ++e) { m_run[e] = -INFINITY; l_run[e] = 0.f; }
-#pragma unroll
-  for (int n = 0; n < 4; ++n) acc_o[n] = float4_t{0.f, 0.f, 0.f, 0.f};
-
-  // loop-invariant per-lane quantities of the softmax phase
-  const float scale2 = scale * 1.4426950408889634f;  // scores in log2 units
-  const int lim = 2 * len - 1;
-  int rr0[4], goff[4], poff[4][4];
-  int wlo[4], whi[4];
-  bool qm[4];
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const int il = g * 4 + e, i = i0 + w * 16 + il;
-    rr0[e] = T - 1 - i + r;                       // + jt*16 + j0 = relative-position row of key j
-    goff[e] = il * GLDC + (15 - il + r);          // + jt*16 = skewed column of the window scores, relative to the strip's first column
-    qm[e] = use_mask && (i >= len);
-    wlo[e] = 0; whi[e] = T;
-    if constexpr (STREAM) { if (!qm[e]) stream_window(min(i, T - 1), T, chunk, hist, wlo[e], whi[e]); }
-#pragma unroll
-    for (int jt = 0; jt < 4; ++jt) {
-      const int jl = jt * 16 + r;
-      poff[e][jt] = il * 128 + (((jl >> 3) ^ key_d(il)) << 4) + (jl & 7) * 2;
-    }
-  }
-#ifdef TFASR_ATTN_TIMING
-  long long ph[5] = {0, 0, 0, 0, 0};
-#define ATT_TICK(k) { const long long t_ = __builtin_readcyclecounter(); ph[k] += t_ - tp; tp = t_; }
-#else
-#define ATT_TICK(k)
-#endif
-  const int njb = (T + BJ - 1) / BJ;
-  int jb_lo = 0, jb_hi = njb;
-  if constexpr (STREAM) {
-    // key blocks no query row of this block can see are skipped - unless the block holds a padded query row (uniform over ALL keys)
-    if (!(use_mask && i0 + BI > len)) {
-      int lo, hi, lo2, hi2;
-      stream_window(i0, T, chunk, hist, lo, hi);
-      stream_window(min(i0 + BI - 1, T - 1), T, chunk, hist, lo2, hi2);
-      jb_lo = lo / BJ;
-      jb_hi = (hi2 + BJ - 1) / BJ;
-    }
-  }
-  if (use_mask && i0 >= len) {
-    // Every query row of this block is padding: the reference's scores are all -1e9 there = uniform attention over ALL T keys (keys are
-    // never masked; general.py:30-41, multihead_attention.py:609-623): out = mean_j v_j, lse = log T.  Same arithmetic as the general
-    // path below (p = 1 exactly, P @ V on the matrix cores in the same order -> bit-identical results) without K, the position window,
-    // the score products and the softmax.  LibriSpeech-shaped batches padded to their longest utterance are 40-60 % such blocks.
-    for (int jb = 0; jb < njb; ++jb) {
-      const int j0 = jb * BJ;
-      load_v(sV, vb, LDQ, j0, T, w, lane);
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-#pragma unroll
-        for (int jt = 0; jt < 4; ++jt)
-          *reinterpret_cast<bf16_t*>(sPb + poff[e][jt]) = (j0 + jt * 16 + r < T) ? (bf16_t)0x3F80 : (bf16_t)0;
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      __syncthreads();
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        const short8_t ap = frag_rows(sPb, r, kk * 4 + g);
-#pragma unroll
-        for (int n = 0; n < 4; ++n)
-          acc_o[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap, frag_v(sV, n * 16, kk * 32 + g * 8, r), acc_o[n], 0, 0, 0);
-      }
-      __syncthreads();
-    }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { m_run[e] = 0.f; l_run[e] = (float)T; }
-  } else
-  for (int jb = jb_lo; jb < jb_hi; ++jb) {
-    const int j0 = jb * BJ;
-    const int pw0 = (T - 1 - (i0 + BI - 1) + j0) + shift;  // pext row of window column 0
-#ifdef TFASR_ATTN_TIMING
-    long long tp = __builtin_readcyclecounter();
-#endif
-    load_rows<BJ>(sK, kb, LDQ, j0, T, w, lane);
-    load_v(sV, vb, LDQ, j0, T, w, lane);
-    load_rows<WIN>(sP, pb, HD, pw0, R1, w, lane);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    // window row 127 <- the bias row R (one 128-B row, written by wave 0 after the DMA so it wins)
-    if (w == 0 && lane < 8) *reinterpret_cast<uint4*>(sP + 127 * 128 + lane * 16) = bias_row;  // loaded once, in front of the loop
-    __syncthreads();
-    ATT_TICK(0)
-
-    // content scores: 16 query rows x 64 keys
-    float4_t acc_s[4];
-#pragma unroll
-    for (int jt = 0; jt < 4; ++jt) {
-      acc_s[jt] = float4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk)
-        acc_s[jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aqu[kk], frag_rows(sK, jt * 16 + r, kk * 4 + g), acc_s[jt], 0, 0, 0);
-    }
-    // window scores G[il][c], c in [ (3-w)*16, 128 ): this wave's skew needs columns 48-16w .. 126-16w, plus column 127 (bias row)
-#pragma unroll
-    for (int gt = 0; gt < 8; ++gt) {
-      if (gt >= 3 - w && (gt <= 7 - w || gt == 7)) {
-        float4_t a = float4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aqv[kk], frag_rows(sP, gt * 16 + r, kk * 4 + g), a, 0, 0, 0);
-        if (gt <= 7 - w) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) sG[(g * 4 + e) * GLDC + (gt - (3 - w)) * 16 + r] = a[e];
-        }
-        if (gt == 7 && r == 15) {  // the bias row's score (window column 127)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) sG[(g * 4 + e) * GLDC + 80] = a[e];
-        }
-      }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    ATT_TICK(1)
-
-    // scores in C layout: row il = g*4+e, col jl = jt*16 + r.  Everything that does not depend on the key block (skew
-    // read offsets, P-image write offsets, validity thresholds) was hoisted out of the loop; scores are kept in the
-    // log2 domain (scale * log2(e) folded in) so that each probability is one v_exp_f32.
-    float rmax[4];
-    const bool ragged = (j0 + BJ > T);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const float gbias = sG[(g * 4 + e) * GLDC + 80];
-      float mx = -INFINITY;
-#pragma unroll
-      for (int jt = 0; jt < 4; ++jt) {
-        const float pos = (rr0[e] + jt * 16 + j0 < lim) ? sG[goff[e] + jt * 16] : gbias;
-        float s2 = (acc_s[jt][e] + pos) * scale2;
-        if (qm[e]) s2 = 0.f;
-        if (ragged && j0 + jt * 16 + r >= T) s2 = -INFINITY;
-        if constexpr (STREAM) { const int j = j0 + jt * 16 + r; if (j < wlo[e] || j >= whi[e]) s2 = -INFINITY; }
-        acc_s[jt][e] = s2;
-        mx = fmaxf(mx, s2);
-      }
-      rmax[e] = row16_max(mx);
-    }
-    // every score of the strip is in registers: the P image may now overwrite it (the fence keeps the bf16 stores below behind the
-    // f32 loads above - different types, so the compiler would otherwise be free to reorder them)
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    // online softmax update + P (bf16) into the per-wave A-operand image
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      float m_new = fmaxf(m_run[e], rmax[e]);
-      // streaming: a row may meet a key block that lies entirely outside its window before any visible key (-inf - -inf = NaN)
-      const float m_ref = (STREAM && m_new == -INFINITY) ? 0.f : m_new;
-      const float corr = __builtin_amdgcn_exp2f(m_run[e] - m_ref);  // exp2(-inf) = 0 on the first block
-      float rs = 0.f;
-#pragma unroll
-      for (int jt = 0; jt < 4; ++jt) {
-        const float p = __builtin_amdgcn_exp2f(acc_s[jt][e] - m_ref);  // masked keys: exp2(-inf) = 0
-        rs += p;
-        *reinterpret_cast<bf16_t*>(sPb + poff[e][jt]) = f32_to_bf16(p);
-      }
-      rs = row16_sum(rs);
-      l_run[e] = l_run[e] * corr + rs;
-      m_run[e] = m_new;
-#pragma unroll
-      for (int n = 0; n < 4; ++n) acc_o[n][e] *= corr;
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    ATT_TICK(2)
-    // O += P @ V
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      const short8_t ap = frag_rows(sPb, r, kk * 4 + g);
-#pragma unroll
-      for (int n = 0; n < 4; ++n)
-        acc_o[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap, frag_v(sV, n * 16, kk * 32 + g * 8, r), acc_o[n], 0, 0, 0);
-    }
-    ATT_TICK(3)
-    __syncthreads();  // everyone is done with sK / sV / sP before the next block's DMA lands
-    ATT_TICK(4)
-  }
-#ifdef TFASR_ATTN_TIMING
-  if (threadIdx.x == 0) {
-    long long* o = g_attn_timing + 5L * (blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z));
-    for (int k = 0; k < 5; ++k) o[k] = ph[k];
-  }
-#endif
-
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const int i = i0 + w * 16 + g * 4 + e;
-    if (i < T) {
-      const float inv = 1.f / l_run[e];
-#pragma unroll
-      for (int n = 0; n < 4; ++n) out[((long)b * T + i) * HD + h * DH + n * 16 + r] = f32_to_bf16(acc_o[n][e] * inv);
-      if (r == 0) lse_out[((long)b * H + h) * T + i] = m_run[e] * 0.6931471805599453f + logf(l_run[e]);  // back to natural log
-    }
-  }
-}
 
 
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -644,854 +408,6 @@ __global__ __launch_bounds__(256, 3) void relattn_fused_fwdT_kernel(
   }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------------------
-// Forward, transposed orientation, 32 QUERY ROWS PER WAVE (128 per workgroup): relattn_fused_fwdT_kernel is bound by the LDS (every
-// 1-KiB K / window / V fragment read feeds ONE MFMA at 16 query rows per wave).  Here a wave owns two 16-row query tiles (two B operands
-// in registers), so every fragment read feeds two MFMAs, the K / V / window DMA of a key block is shared by 128 query rows instead of
-// 64, and the two tiles' window ranges overlap in 4 of their 5 tiles (6 tile reads for 10 products).  Per 128 x 64 (query x key) pairs
-// the LDS moves ~1.8 KiB-clocks against 2.9 for two 64-row workgroups.  The window of a 128-row block is 191 table rows + the bias row
-// (24 KiB); the bias-row score reaches the lanes of its query by a wave shuffle (no LDS slot): 8 + 8 + 24 + 8 x 5 KiB = 81 920 B =
-// 64 LDS granules = two workgroups per CU.
-// ---------------------------------------------------------------------------------------------------------------------------------
-constexpr int BI2 = 128, WIN2 = 192, SP2_BYTES = WIN2 * DH * 2;
-constexpr int SGT2_BYTES = 16 * GLDT * 4;  // [16 il][80] f32 per (wave, query tile)
-constexpr int SMEM_FWDT2 = SK_BYTES + SV_BYTES + SP2_BYTES + 8 * SGT2_BYTES;
-static_assert((SMEM_FWDT2 + 1279) / 1280 * 2 <= 128, "two workgroups per CU");
-
-template <bool STREAM>
-__global__ __launch_bounds__(256, 2) void relattn_fused_fwdT2_kernel(
-    const bf16_t* __restrict__ qkv, const float* __restrict__ ubias, const float* __restrict__ vbias,
-    const bf16_t* __restrict__ pext, const int32_t* __restrict__ lengths, bf16_t* __restrict__ out, float* __restrict__ lse_out,
-    int B, int H, int T, float scale, int use_mask, int chunk, int hist) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* sK = smem;
-  char* sV = sK + SK_BYTES;
-  char* sP = sV + SV_BYTES;
-  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  float* sGq[2];
-  sGq[0] = reinterpret_cast<float*>(sP + SP2_BYTES + (w * 2) * SGT2_BYTES);  // [16 il][80]: window columns 112-32w .. 191-32w (query tile 0)
-  sGq[1] = sGq[0] + 16 * GLDT;                                               //              window columns  96-32w .. 175-32w (query tile 1)
-  const int r = lane & 15, g = lane >> 4;
-  const BlockId bid = attn_block_id(B, H, (T + BI2 - 1) / BI2);
-  if (!bid.ok) return;
-  const int b = bid.b, h = bid.h, i0 = bid.blk * BI2;
-  const int HD = H * DH, LDQ = 3 * HD, R1 = 2 * T;
-  const int len = lengths ? min(lengths[b], T) : T;
-  const int shift = T - len;
-  const bf16_t* qb = qkv + (long)b * T * LDQ + h * DH;
-  const bf16_t* kb = qb + HD;
-  const bf16_t* vb = qb + 2 * HD;
-  const bf16_t* pb = pext + h * DH;
-  uint4 bias_row = make_uint4(0, 0, 0, 0);
-  if ((threadIdx.x >> 6) == 0 && (threadIdx.x & 63) < 8)
-    bias_row = *reinterpret_cast<const uint4*>(pb + (long)(2 * T - 1) * HD + (((threadIdx.x & 63) ^ key_d(WIN2 - 1)) << 3));
-
-  // this lane's two query rows (B operand columns): Q + u, Q + v
-  int iq[2];
-  short8_t bqu[2][2], bqv[2][2];
-#pragma unroll
-  for (int qt = 0; qt < 2; ++qt) {
-    iq[qt] = i0 + w * 32 + qt * 16 + r;
-    const int irow = min(iq[qt], T - 1);
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      bqu[qt][kk] = q_frag(qb + (long)irow * LDQ, ubias + h * DH, kk * 32 + g * 8);
-      bqv[qt][kk] = q_frag(qb + (long)irow * LDQ, vbias + h * DH, kk * 32 + g * 8);
-    }
-  }
-  float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
-  float4_t acc_o[2][4];  // O^T: rows = head dims n*16 + g*4 + e, column = this lane's query of tile qt
-#pragma unroll
-  for (int qt = 0; qt < 2; ++qt)
-#pragma unroll
-    for (int n = 0; n < 4; ++n) acc_o[qt][n] = float4_t{0.f, 0.f, 0.f, 0.f};
-
-  const float scale2 = scale * 1.4426950408889634f;
-  const int lim = 2 * len - 1;
-  bool qm[2];
-  int jthr[2], klo[2], khi[2];
-  float scale2q[2];
-#pragma unroll
-  for (int qt = 0; qt < 2; ++qt) {
-    qm[qt] = use_mask && (iq[qt] >= len);
-    jthr[qt] = lim - (T - 1 - iq[qt]);  // keys j < jthr: relative position T-1-i+j inside the sample's 2 len - 1 encodings
-    klo[qt] = 0; khi[qt] = T;
-    if constexpr (STREAM) { if (!qm[qt]) stream_window(min(iq[qt], T - 1), T, chunk, hist, klo[qt], khi[qt]); }
-    scale2q[qt] = qm[qt] ? 0.f : scale2;
-  }
-  const int gbase = r * GLDT + 15 - r;  // + jl = this lane's skewed strip column of key jl (either query tile)
-  int jl0[4], krow[4];
-#pragma unroll
-  for (int jt = 0; jt < 4; ++jt) {
-    jl0[jt] = 32 * (jt >> 1) + g * 8 + (jt & 1) * 4;                      // first of this lane's four keys of tile jt (C rows g*4 + e)
-    krow[jt] = 32 * (jt >> 1) + (r >> 2) * 8 + (jt & 1) * 4 + (r & 3);  // key row that is MFMA row r of tile jt (A operand)
-  }
-  const int njb = (T + BJ - 1) / BJ;
-  int jb_lo = 0, jb_hi = njb;
-  if constexpr (STREAM) {
-    if (!(use_mask && i0 + BI2 > len)) {
-      int lo, hi, lo2, hi2;
-      stream_window(i0, T, chunk, hist, lo, hi);
-      stream_window(min(i0 + BI2 - 1, T - 1), T, chunk, hist, lo2, hi2);
-      jb_lo = lo / BJ;
-      jb_hi = (hi2 + BJ - 1) / BJ;
-    }
-  }
-  // window row 191 <- the bias row R of the position table, once (the block loop's DMA leaves that row alone)
-  if (w == 0 && lane < 8) *reinterpret_cast<uint4*>(sP + (WIN2 - 1) * 128 + lane * 16) = bias_row;
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (visible to the other waves behind the first block's barrier)
-  if (use_mask && i0 >= len) {
-    // every query row of this block is padding: uniform attention over ALL T keys (see relattn_fused_fwd_kernel): out = mean_j v_j, lse = log T
-    for (int jb = 0; jb < njb; ++jb) {
-      const int j0 = jb * BJ;
-      load_v(sV, vb, LDQ, j0, T, w, lane);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        short8_t pf;
-#pragma unroll
-        for (int t = 0; t < 8; ++t) pf[t] = (j0 + 32 * q + g * 8 + t < T) ? (short)0x3F80 : (short)0;
-#pragma unroll
-        for (int n = 0; n < 4; ++n) {
-          const short8_t a = frag_v(sV, n * 16, q * 32 + g * 8, r);
-          acc_o[0][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, pf, acc_o[0][n], 0, 0, 0);
-          acc_o[1][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, pf, acc_o[1][n], 0, 0, 0);
-        }
-      }
-      __syncthreads();
-    }
-    m_run[0] = m_run[1] = 0.f; l_run[0] = l_run[1] = (float)T;
-  } else
-  for (int jb = jb_lo; jb < jb_hi; ++jb) {
-    const int j0 = jb * BJ;
-    const int pw0 = (T - 1 - (i0 + BI2 - 1) + j0) + shift;  // pext row of window column 0
-    load_rows<BJ>(sK, kb, LDQ, j0, T, w, lane);
-    load_v(sV, vb, LDQ, j0, T, w, lane);
-    load_rows<WIN2, false, true>(sP, pb, HD, pw0, R1, w, lane);  // (window row 191 = the bias row, written once in front of the loop)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-
-    // content scores, transposed: tile jt = 16 keys x this wave's 2 x 16 queries; one K fragment read feeds both query tiles
-    float4_t acc_s[2][4];
-#pragma unroll
-    for (int jt = 0; jt < 4; ++jt) {
-      acc_s[0][jt] = float4_t{0.f, 0.f, 0.f, 0.f};
-      acc_s[1][jt] = float4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        const short8_t a = frag_rows(sK, krow[jt], kk * 4 + g);
-        acc_s[0][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bqu[0][kk], acc_s[0][jt], 0, 0, 0);
-        acc_s[1][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bqu[1][kk], acc_s[1][jt], 0, 0, 0);
-      }
-    }
-    // window scores, transposed: G^T[c][il].  Query tile 0 of this wave needs window columns 112-32w .. 190-32w (tiles t0 .. t0+4),
-    // query tile 1 the 16 columns below (tiles t0-1 .. t0+3); column 191 (tile 11, row 15) is the bias row's score for both
-    const int t0 = 7 - 2 * w;
-    float gb[2] = {0.f, 0.f};
-#pragma unroll
-    for (int gt = 0; gt < 12; ++gt) {
-      const bool u0 = gt >= t0 && gt <= t0 + 4, u1 = gt >= t0 - 1 && gt <= t0 + 3, last = gt == 11;
-      if (u0 || u1 || last) {
-        const short8_t a0 = frag_rows(sP, gt * 16 + r, g), a1 = frag_rows(sP, gt * 16 + r, 4 + g);
-        if (u0 || last) {
-          float4_t x = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, bqv[0][0], float4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-          x = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bqv[0][1], x, 0, 0, 0);
-          if (u0) *reinterpret_cast<float4_t*>(sGq[0] + r * GLDT + (gt - t0) * 16 + g * 4) = x;
-          if (last) gb[0] = x[3];
-        }
-        if (u1 || last) {
-          float4_t x = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, bqv[1][0], float4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-          x = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bqv[1][1], x, 0, 0, 0);
-          if (u1) *reinterpret_cast<float4_t*>(sGq[1] + r * GLDT + (gt - (t0 - 1)) * 16 + g * 4) = x;
-          if (last) gb[1] = x[3];
-        }
-      }
-    }
-    // the bias-row score of query r sits in the lanes (g = 3, r): to every lane of that query
-    gb[0] = __shfl(gb[0], 48 + r, 64);
-    gb[1] = __shfl(gb[1], 48 + r, 64);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-
-    short8_t pf[2][2];
-#pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
-      // every skewed score is read unconditionally (the strip column 15 - il + jl exists for every key of the block), THEN selected against
-      // the bias score: a conditional read compiles to an exec-mask branch per element
-      const float gbias = gb[qt];
-      const float* sG = sGq[qt];
-      float gv[4][4];
-#pragma unroll
-      for (int jt = 0; jt < 4; ++jt)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) gv[jt][e] = sG[gbase + jl0[jt] + e];
-      float mx = -INFINITY;
-#pragma unroll
-      for (int jt = 0; jt < 4; ++jt) {
-        const int tr = jthr[qt] - j0 - jl0[jt];  // keys e < tr of this tile have a relative position inside the table
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float pos = (e < tr) ? gv[jt][e] : gbias;
-          acc_s[qt][jt][e] = (acc_s[qt][jt][e] + pos) * scale2q[qt];  // (scale2q = 0 for a padded query row: constant scores)
-        }
-      }
-      if (STREAM || j0 + BJ > T) {  // keys outside [klo, khi): past the end of a ragged last block / outside the streaming window
-#pragma unroll
-        for (int jt = 0; jt < 4; ++jt)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int j = j0 + jl0[jt] + e;
-            if (j < klo[qt] || j >= khi[qt]) acc_s[qt][jt][e] = -INFINITY;
-          }
-      }
-#pragma unroll
-      for (int jt = 0; jt < 4; ++jt)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) mx = fmaxf(mx, acc_s[qt][jt][e]);
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float m_new = fmaxf(m_run[qt], mx);
-      const float m_ref = (STREAM && m_new == -INFINITY) ? 0.f : m_new;
-      const float corr = __builtin_amdgcn_exp2f(m_run[qt] - m_ref);
-      float rs = 0.f;
-#pragma unroll
-      for (int jt = 0; jt < 4; ++jt) {
-        float p[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { p[e] = __builtin_amdgcn_exp2f(acc_s[qt][jt][e] - m_ref); rs += p[e]; }
-        const uint32_t lo = pack2_bf16(p[0], p[1]), hi = pack2_bf16(p[2], p[3]);
-        const int o = (jt & 1) * 4;
-        pf[qt][jt >> 1][o + 0] = (short)(lo & 0xffffu); pf[qt][jt >> 1][o + 1] = (short)(lo >> 16);
-        pf[qt][jt >> 1][o + 2] = (short)(hi & 0xffffu); pf[qt][jt >> 1][o + 3] = (short)(hi >> 16);
-      }
-      rs += __shfl_xor(rs, 16, 64);
-      rs += __shfl_xor(rs, 32, 64);
-      l_run[qt] = l_run[qt] * corr + rs;
-      m_run[qt] = m_new;
-#pragma unroll
-      for (int n = 0; n < 4; ++n)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc_o[qt][n][e] *= corr;
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    // O^T += V^T P^T: the probabilities are the B operands straight from registers; one V fragment read feeds both query tiles
-#pragma unroll
-    for (int q = 0; q < 2; ++q)
-#pragma unroll
-      for (int n = 0; n < 4; ++n) {
-        const short8_t a = frag_v(sV, n * 16, q * 32 + g * 8, r);
-        acc_o[0][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, pf[0][q], acc_o[0][n], 0, 0, 0);
-        acc_o[1][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, pf[1][q], acc_o[1][n], 0, 0, 0);
-      }
-    __syncthreads();  // everyone is done with sK / sV / sP before the next block's DMA lands
-  }
-
-#pragma unroll
-  for (int qt = 0; qt < 2; ++qt) {
-    const int i = iq[qt];
-    if (i < T) {
-      const float inv = 1.f / l_run[qt];
-#pragma unroll
-      for (int n = 0; n < 4; ++n) {
-        uint2 v;
-        v.x = pack2_bf16(acc_o[qt][n][0] * inv, acc_o[qt][n][1] * inv);
-        v.y = pack2_bf16(acc_o[qt][n][2] * inv, acc_o[qt][n][3] * inv);
-        *reinterpret_cast<uint2*>(out + ((long)b * T + i) * HD + h * DH + n * 16 + g * 4) = v;
-      }
-      if (g == 0) lse_out[((long)b * H + h) * T + i] = m_run[qt] * 0.6931471805599453f + logf(l_run[qt]);
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------------------------------------
-// Forward with 32-key blocks: 4 KB of K, 4 KB of V, a 96-row window (12 KB) and 4 strips of [16][49] f32 = 32.5 KB per workgroup, so
-// FOUR (LDS) workgroups share a CU where the 64-key kernel fits three.  Same arithmetic per (query, key) pair; the online softmax
-// merges twice as many blocks.  Wave w needs window columns 48-16w .. 94-16w (3 tiles) + the bias row in column 95.
-// ---------------------------------------------------------------------------------------------------------------------------------
-constexpr int BJ3 = 32, WIN3 = 96, GLD3 = 49, SG3_BYTES = 16 * GLD3 * 4;
-constexpr int SMEM_FWD32 = 2 * (BJ3 * DH * 2) + WIN3 * DH * 2 + 4 * SG3_BYTES;
-
-template <bool STREAM>
-__global__ __launch_bounds__(256, 4) void relattn_fused_fwd32_kernel(
-    const bf16_t* __restrict__ qkv, const float* __restrict__ ubias, const float* __restrict__ vbias,
-    const bf16_t* __restrict__ pext, const int32_t* __restrict__ lengths, bf16_t* __restrict__ out, float* __restrict__ lse_out,
-    int B, int H, int T, float scale, int use_mask, int chunk, int hist) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* sK = smem;                      // [32 j][64 dh]
-  char* sV = sK + BJ3 * DH * 2;         // [32 j][64 dh]
-  char* sP = sV + BJ3 * DH * 2;         // [96 c][64 dh]
-  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  float* sG = reinterpret_cast<float*>(sP + WIN3 * DH * 2 + w * SG3_BYTES);
-  char* sPb = reinterpret_cast<char*>(sG);  // P image [16][32] bf16 (64-B rows, 16-B chunk ^= (row >> 1) & 3), over the strip once it has been read
-  const int r = lane & 15, g = lane >> 4;
-  const int b = blockIdx.z, h = blockIdx.y, i0 = blockIdx.x * BI;
-  const int HD = H * DH, LDQ = 3 * HD, R = 2 * T - 1, R1 = 2 * T;
-  const int len = lengths ? min(lengths[b], T) : T;
-  const int shift = T - len;
-  const bf16_t* qb = qkv + (long)b * T * LDQ + h * DH;
-  const bf16_t* kb = qb + HD;
-  const bf16_t* vb = qb + 2 * HD;
-  const bf16_t* pb = pext + h * DH;
-  // the bias row R of the position table (window row 127 / 95 of every key block): 16 bytes per lane of wave 0, loaded ONCE - inside the
-  // block loop it was a dependent global load between the barrier and the __syncthreads() of every iteration
-  uint4 bias_row = make_uint4(0, 0, 0, 0);
-  if ((threadIdx.x >> 6) == 0 && (threadIdx.x & 63) < 8) bias_row = *reinterpret_cast<const uint4*>(pb + (long)(2 * T - 1) * HD + (((threadIdx.x & 63) ^ key_d(WIN3 - 1)) << 3));
-
-  const int irow = min(i0 + w * 16 + r, T - 1);
-  short8_t aqu[2], aqv[2];
-#pragma unroll
-  for (int kk = 0; kk < 2; ++kk) {
-    aqu[kk] = q_frag(qb + (long)irow * LDQ, ubias + h * DH, kk * 32 + g * 8);
-    aqv[kk] = q_frag(qb + (long)irow * LDQ, vbias + h * DH, kk * 32 + g * 8);
-  }
-  float m_run[4], l_run[4];
-  float4_t acc_o[4];
-#pragma unroll
-  for (int e = 0; e < 4; ++e) { m_run[e] = -INFINITY; l_run[e] = 0.f; }
-#pragma unroll
-  for (int n = 0; n < 4; ++n) acc_o[n] = float4_t{0.f, 0.f, 0.f, 0.f};
-
-  const float scale2 = scale * 1.4426950408889634f;
-  const int lim = 2 * len - 1;
-  int rr0[4], goff[4], poff[4][2];
-  int wlo[4], whi[4];
-  bool qm[4];
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const int il = g * 4 + e, i = i0 + w * 16 + il;
-    rr0[e] = T - 1 - i + r;
-    goff[e] = il * GLD3 + (15 - il + r);
-    qm[e] = use_mask && (i >= len);
-    wlo[e] = 0; whi[e] = T;
-    if constexpr (STREAM) { if (!qm[e]) stream_window(min(i, T - 1), T, chunk, hist, wlo[e], whi[e]); }
-#pragma unroll
-    for (int jt = 0; jt < 2; ++jt) {
-      const int jl = jt * 16 + r;
-      poff[e][jt] = il * 64 + (((jl >> 3) ^ ((il >> 1) & 3)) << 4) + (jl & 7) * 2;
-    }
-  }
-  const int njb = (T + BJ3 - 1) / BJ3;
-  int jb_lo = 0, jb_hi = njb;
-  if constexpr (STREAM) {
-    if (!(use_mask && i0 + BI > len)) {
-      int lo, hi, lo2, hi2;
-      stream_window(i0, T, chunk, hist, lo, hi);
-      stream_window(min(i0 + BI - 1, T - 1), T, chunk, hist, lo2, hi2);
-      jb_lo = lo / BJ3;
-      jb_hi = (hi2 + BJ3 - 1) / BJ3;
-    }
-  }
-  if (use_mask && i0 >= len) {  // a block of padded query rows: uniform attention over all T keys (see the 64-key kernel)
-    for (int jb = 0; jb < njb; ++jb) {
-      const int j0 = jb * BJ3;
-      {
-        const int k = w * 8 + (lane >> 3), pc = lane & 7;
-        const int gr = min(j0 + k, T - 1);
-        const bf16_t* src = vb + (long)gr * LDQ + ((pc ^ key_t64(k)) << 3);
-        __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(sV + __builtin_amdgcn_readfirstlane(w * 1024)), 16, 0, 0);
-      }
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-#pragma unroll
-        for (int jt = 0; jt < 2; ++jt)
-          *reinterpret_cast<bf16_t*>(sPb + poff[e][jt]) = (j0 + jt * 16 + r < T) ? (bf16_t)0x3F80 : (bf16_t)0;
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      __syncthreads();
-      {
-        const short8_t ap = *reinterpret_cast<const short8_t*>(sPb + r * 64 + ((g ^ ((r >> 1) & 3)) << 4));
-#pragma unroll
-        for (int n = 0; n < 4; ++n)
-          acc_o[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap, frag_v(sV, n * 16, g * 8, r), acc_o[n], 0, 0, 0);
-      }
-      __syncthreads();
-    }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { m_run[e] = 0.f; l_run[e] = (float)T; }
-  } else
-  for (int jb = jb_lo; jb < jb_hi; ++jb) {
-    const int j0 = jb * BJ3;
-    const int pw0 = (T - 1 - (i0 + BI - 1) + j0) + shift;  // pext row of window column 0
-    load_rows<BJ3>(sK, kb, LDQ, j0, T, w, lane);
-    {  // V block [32 k][64 dh] trans image: one piece per wave (8 k rows)
-      const int k = w * 8 + (lane >> 3), pc = lane & 7;
-      const int gr = min(j0 + k, T - 1);
-      const bf16_t* src = vb + (long)gr * LDQ + ((pc ^ key_t64(k)) << 3);
-      __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(sV + __builtin_amdgcn_readfirstlane(w * 1024)), 16, 0, 0);
-    }
-    load_rows<WIN3>(sP, pb, HD, pw0, R1, w, lane);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (w == 0 && lane < 8) *reinterpret_cast<uint4*>(sP + (WIN3 - 1) * 128 + lane * 16) = bias_row;  // window row 95 <- the bias row R
-    __syncthreads();
-
-    float4_t acc_s[2];
-#pragma unroll
-    for (int jt = 0; jt < 2; ++jt) {
-      acc_s[jt] = float4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk)
-        acc_s[jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aqu[kk], frag_rows(sK, jt * 16 + r, kk * 4 + g), acc_s[jt], 0, 0, 0);
-    }
-#pragma unroll
-    for (int gt = 0; gt < 6; ++gt) {
-      if ((gt >= 3 - w && gt <= 5 - w) || gt == 5) {
-        float4_t a = float4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aqv[kk], frag_rows(sP, gt * 16 + r, kk * 4 + g), a, 0, 0, 0);
-        if (gt <= 5 - w) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) sG[(g * 4 + e) * GLD3 + (gt - (3 - w)) * 16 + r] = a[e];
-        }
-        if (gt == 5 && r == 15) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) sG[(g * 4 + e) * GLD3 + 48] = a[e];
-        }
-      }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-
-    float rmax[4];
-    const bool ragged = (j0 + BJ3 > T);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const float gbias = sG[(g * 4 + e) * GLD3 + 48];
-      float mx = -INFINITY;
-#pragma unroll
-      for (int jt = 0; jt < 2; ++jt) {
-        const float pos = (rr0[e] + jt * 16 + j0 < lim) ? sG[goff[e] + jt * 16] : gbias;
-        float s2 = (acc_s[jt][e] + pos) * scale2;
-        if (qm[e]) s2 = 0.f;
-        if (ragged && j0 + jt * 16 + r >= T) s2 = -INFINITY;
-        if constexpr (STREAM) { const int j = j0 + jt * 16 + r; if (j < wlo[e] || j >= whi[e]) s2 = -INFINITY; }
-        acc_s[jt][e] = s2;
-        mx = fmaxf(mx, s2);
-      }
-      rmax[e] = row16_max(mx);
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the strip is in registers: the P image may overwrite it
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const float m_new = fmaxf(m_run[e], rmax[e]);
-      const float m_ref = (STREAM && m_new == -INFINITY) ? 0.f : m_new;  // (a block entirely outside the row's window, see the 64-key kernel)
-      const float corr = __builtin_amdgcn_exp2f(m_run[e] - m_ref);
-      float rs = 0.f;
-#pragma unroll
-      for (int jt = 0; jt < 2; ++jt) {
-        const float pv = __builtin_amdgcn_exp2f(acc_s[jt][e] - m_ref);
-        rs += pv;
-        *reinterpret_cast<bf16_t*>(sPb + poff[e][jt]) = f32_to_bf16(pv);
-      }
-      rs = row16_sum(rs);
-      l_run[e] = l_run[e] * corr + rs;
-      m_run[e] = m_new;
-#pragma unroll
-      for (int n = 0; n < 4; ++n) acc_o[n][e] *= corr;
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    {  // O += P @ V  (one 32-key step)
-      const short8_t ap = *reinterpret_cast<const short8_t*>(sPb + r * 64 + ((g ^ ((r >> 1) & 3)) << 4));
-#pragma unroll
-      for (int n = 0; n < 4; ++n)
-        acc_o[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap, frag_v(sV, n * 16, g * 8, r), acc_o[n], 0, 0, 0);
-    }
-    __syncthreads();
-  }
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const int i = i0 + w * 16 + g * 4 + e;
-    if (i < T) {
-      const float inv = 1.f / l_run[e];
-#pragma unroll
-      for (int n = 0; n < 4; ++n) out[((long)b * T + i) * HD + h * DH + n * 16 + r] = f32_to_bf16(acc_o[n][e] * inv);
-      if (r == 0) lse_out[((long)b * H + h) * T + i] = m_run[e] * 0.6931471805599453f + logf(l_run[e]);
-    }
-  }
-}
-
-// ======================================================================================================================
-// Backward, part 1 (query side): block = (b, h, 64 query rows), wave = 16 rows, loop over 64-key blocks.
-//   recompute s_ij and p_ij = exp(s_ij - lse_i);  dp_ij = dO_i . v_j;  ds_ij = p_ij (dp_ij - D_i),  D_i = dO_i . O_i
-//   dqu_i  += scale * sum_j ds_ij k_j                       (in registers, written once)
-//   dpos[b,h,i, idx(i,j)] = scale * ds_ij                   (the skewed score gradient, [B,H,T,ldp] like attention.hip's
-//                                                            backward: the (q+v) / pext gradients are two GEMMs on it)
-// ======================================================================================================================
-constexpr int SMEM_BWD_Q = SK_BYTES + SV_BYTES + SP_BYTES + 4 * SG_BYTES;
-
-__device__ __forceinline__ short8_t row_frag(const bf16_t* row, int k0) {
-  return *reinterpret_cast<const short8_t*>(row + k0);
-}
-
-// V2 (no skewed score gradient in HBM): the positional part of the query gradient is formed HERE, dqv_i = sum_j ds_ij pext[idx(i,j)],
-// as one more MFMA product per key block on a skewed image of dS (per-wave [16 x 128] strip, column 63-il+jl) against the window
-// rows already in LDS; dS itself is stored UNSKEWED [B,H,T,ldp] (half the bytes of the skewed [B,H,T,2T] matrix, no zero fill) for
-// relattn_dpext_kernel, and the bias-row share of dpext (pairs whose relative position is outside the sample's 2*len-1 encodings)
-// is accumulated here.  `dpos` / `ldp` then mean dS and its row stride.
-// DQ (V2 only): the query gradient leaves the kernel complete - dq = dqu + dqv written into the q columns of the fused qkv gradient
-// (`dqu` = that pointer, row stride `lddq`), du += colsum(dqu), dv += colsum(dqv) accumulated here - instead of two [B*T, H*dh]
-// tensors for a separate bias-gradient pass (tfasr_bias2_bwd).
-template <bool V2, bool DQ = false, bool STREAM = false>
-__global__ __launch_bounds__(256, 2) void relattn_fused_bwd_q_kernel(
-    const bf16_t* __restrict__ qkv, const float* __restrict__ ubias, const float* __restrict__ vbias,
-    const bf16_t* __restrict__ pext, const int32_t* __restrict__ lengths, const bf16_t* __restrict__ o,
-    const bf16_t* __restrict__ dout, const float* __restrict__ lse, bf16_t* __restrict__ dqu, bf16_t* __restrict__ dpos,
-    float* __restrict__ dvec, int B, int H, int T, int ldp, float scale, int use_mask, bf16_t* __restrict__ dqv, float* __restrict__ dpext,
-    long lddq = 0, float* __restrict__ du = nullptr, float* __restrict__ dv = nullptr, int chunk = 0, int hist = 0,
-    bf16_t* __restrict__ qu_out = nullptr, bf16_t* __restrict__ qv_out = nullptr) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* sK = smem;              // [64 j][64 dh], read both as rows (k = dh) and transposed (k = j)
-  char* sV = sK + SK_BYTES;     // [64 j][64 dh]
-  char* sP = sV + SV_BYTES;     // window rows
-  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  float* sG = reinterpret_cast<float*>(sP + SP_BYTES + w * SG_BYTES);
-  char* sA = reinterpret_cast<char*>(sG);  // the G strip is dead once the scores are formed: reuse it for the dS A-image
-  const int r = lane & 15, g = lane >> 4;
-  const BlockId bid = attn_block_id(B, H, (T + BI - 1) / BI);  // XCD-aware, live-first order (1-D grid, see attn_block_id)
-  if (!bid.ok) return;
-  const int b = bid.b, h = bid.h, i0 = bid.blk * BI;
-  const int HD = H * DH, LDQ = 3 * HD, R = 2 * T - 1, R1 = 2 * T;
-  const int len = lengths ? min(lengths[b], T) : T;
-  const int shift = T - len;
-  const bf16_t* qb = qkv + (long)b * T * LDQ + h * DH;
-  const bf16_t* kb = qb + HD;
-  const bf16_t* vb = qb + 2 * HD;
-  const bf16_t* pb = pext + h * DH;
-  // the bias row R of the position table (window row 127 / 95 of every key block): 16 bytes per lane of wave 0, loaded ONCE - inside the
-  // block loop it was a dependent global load between the barrier and the __syncthreads() of every iteration
-  uint4 bias_row = make_uint4(0, 0, 0, 0);
-  if ((threadIdx.x >> 6) == 0 && (threadIdx.x & 63) < 8) bias_row = *reinterpret_cast<const uint4*>(pb + (long)(2 * T - 1) * HD + (((threadIdx.x & 63) ^ key_d(127)) << 3));
-
-  if constexpr (V2) {
-    if (use_mask && i0 >= len) {
-      // a block of padded query rows: constant scores, so dS = 0 and the query gradient is zero; relattn_dpext_kernel skips these tiles
-      // of dS (never read) and the key-side kernel does not use their D_i.  Only the zero query-gradient rows have to be written.
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int i = i0 + w * 16 + g * 4 + e;
-        if (i < T) {
-#pragma unroll
-          for (int n = 0; n < 4; ++n) {
-            if constexpr (DQ) dqu[((long)b * T + i) * lddq + h * DH + n * 16 + r] = (bf16_t)0;
-            else { dqu[((long)b * T + i) * HD + h * DH + n * 16 + r] = (bf16_t)0; dqv[((long)b * T + i) * HD + h * DH + n * 16 + r] = (bf16_t)0; }
-          }
-        }
-      }
-      return;
-    }
-  }
-  const int irow = min(i0 + w * 16 + r, T - 1);
-  short8_t aqu[2], aqv[2], ado[2];
-  float dpart = 0.f;
-#pragma unroll
-  for (int kk = 0; kk < 2; ++kk) {
-    aqu[kk] = q_frag(qb + (long)irow * LDQ, ubias + h * DH, kk * 32 + g * 8);
-    aqv[kk] = q_frag(qb + (long)irow * LDQ, vbias + h * DH, kk * 32 + g * 8);
-    const bf16_t* dorow = dout + ((long)b * T + irow) * HD + h * DH + kk * 32 + g * 8;
-    const bf16_t* orow = o + ((long)b * T + irow) * HD + h * DH + kk * 32 + g * 8;
-    ado[kk] = row_frag(dorow, 0);
-    float a[8], c[8];
-    ld8(dorow, a);
-    ld8(orow, c);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) dpart += a[e] * c[e];
-  }
-  // q + u / q + v of this block's rows for the key-side kernel and relattn_dpext_kernel (they skip the blocks this kernel returned from
-  // above): the fragments are exactly those tensors' rows - what tfasr_bias2_fwd wrote in a launch of its own
-  if (qu_out && i0 + w * 16 + r < T) {
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      *reinterpret_cast<short8_t*>(qu_out + ((long)b * T + irow) * HD + h * DH + kk * 32 + g * 8) = aqu[kk];
-      *reinterpret_cast<short8_t*>(qv_out + ((long)b * T + irow) * HD + h * DH + kk * 32 + g * 8) = aqv[kk];
-    }
-  }
-  // D_i for row r: reduce over the 4 k-groups (lanes r, r+16, r+32, r+48), then re-distribute to the C layout rows g*4+e
-  dpart += __shfl_xor(dpart, 16, 64);
-  dpart += __shfl_xor(dpart, 32, 64);
-  if (g == 0 && i0 + w * 16 + r < T) dvec[((long)b * H + h) * T + i0 + w * 16 + r] = dpart;  // D_i for the key-side kernel
-  float Di[4], lsei[4];
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    Di[e] = __shfl(dpart, g * 4 + e, 64);
-    const int i = min(i0 + w * 16 + g * 4 + e, T - 1);
-    lsei[e] = lse[((long)b * H + h) * T + i];
-  }
-
-  float4_t acc_q[4];
-#pragma unroll
-  for (int n = 0; n < 4; ++n) acc_q[n] = float4_t{0.f, 0.f, 0.f, 0.f};
-  float bias_acc[4] = {0.f, 0.f, 0.f, 0.f};
-  // loop-invariant per-lane quantities of the dS phase
-  const float scale2 = scale * 1.4426950408889634f;
-  const int lim = 2 * len - 1;
-  int rr0[4], goff[4], poff[4][4];
-  int wlo[4], whi[4];
-  bool live[4], inrow[4];
-  float lsei2[4];
-  bf16_t* prow_e[4];
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const int il = g * 4 + e, i = i0 + w * 16 + il;
-    rr0[e] = T - 1 - i + r;
-    goff[e] = il * GLD + (63 - w * 16 - il + r);
-    inrow[e] = i < T;
-    live[e] = inrow[e] && !(use_mask && i >= len);
-    wlo[e] = 0; whi[e] = T;
-    if constexpr (STREAM) { if (live[e]) stream_window(i, T, chunk, hist, wlo[e], whi[e]); }
-    lsei2[e] = lsei[e] * 1.4426950408889634f;
-    prow_e[e] = dpos + (((long)b * H + h) * T + min(i, T - 1)) * ldp + (V2 ? 0 : (T - 1 - i + shift)) + r;  // + jl + j0 = column (V2: j itself)
-#pragma unroll
-    for (int jt = 0; jt < 4; ++jt) {
-      const int jl = jt * 16 + r;
-      poff[e][jt] = il * 128 + (((jl >> 3) ^ key_d(il)) << 4) + (jl & 7) * 2;
-    }
-  }
-  // V2: slots of the skewed dS image [16 il][128 c] (256-B rows, 16-B chunk ^= key_d(il)): c = 63 - w*16 - il + jl
-  int goffA[4][4];
-  float4_t acc_v[4];
-#pragma unroll
-  for (int n = 0; n < 4; ++n) acc_v[n] = float4_t{0.f, 0.f, 0.f, 0.f};
-  if constexpr (V2) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int il = g * 4 + e;
-#pragma unroll
-      for (int jt = 0; jt < 4; ++jt) {
-        const int c = 63 - w * 16 - il + jt * 16 + r;
-        goffA[e][jt] = il * 256 + (((c >> 3) ^ key_d(il)) << 4) + (c & 7) * 2;
-      }
-    }
-  }
-  char* sAg = sA + 4096;  // dG image (4 KiB) behind the dS image (2 KiB) inside this wave's G strip (8448 B)
-
-#ifdef TFASR_ATTN_TIMING
-  long long ph[5] = {0, 0, 0, 0, 0};
-#endif
-  const int njb = (T + BJ - 1) / BJ;
-  // window row 127 <- the bias row R of the position table, ONCE (the block loop's DMA leaves that row alone; visible behind the first barrier)
-  if (w == 0 && lane < 8) *reinterpret_cast<uint4*>(sP + 127 * 128 + lane * 16) = bias_row;
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  for (int jb = 0; jb < njb; ++jb) {
-    const int j0 = jb * BJ;
-    const int pw0 = (T - 1 - (i0 + BI - 1) + j0) + shift;
-#ifdef TFASR_ATTN_TIMING
-    long long tp = __builtin_readcyclecounter();
-#endif
-    load_rows<BJ>(sK, kb, LDQ, j0, T, w, lane);
-    load_rows<BJ>(sV, vb, LDQ, j0, T, w, lane);
-    load_rows<WIN, false, true>(sP, pb, HD, pw0, R1, w, lane);  // (window row 127 = the bias row, written once in front of the loop)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    ATT_TICK(0)
-
-    float4_t acc_s[4], acc_p[4];
-#pragma unroll
-    for (int jt = 0; jt < 4; ++jt) {
-      acc_s[jt] = float4_t{0.f, 0.f, 0.f, 0.f};
-      acc_p[jt] = float4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        acc_s[jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aqu[kk], frag_rows(sK, jt * 16 + r, kk * 4 + g), acc_s[jt], 0, 0, 0);
-        acc_p[jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ado[kk], frag_rows(sV, jt * 16 + r, kk * 4 + g), acc_p[jt], 0, 0, 0);
-      }
-    }
-#pragma unroll
-    for (int gt = 0; gt < 8; ++gt) {
-      if (gt >= 3 - w && (gt <= 7 - w || gt == 7)) {
-        float4_t a = float4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aqv[kk], frag_rows(sP, gt * 16 + r, kk * 4 + g), a, 0, 0, 0);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) sG[(g * 4 + e) * GLD + gt * 16 + r] = a[e];
-      }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    ATT_TICK(1)
-
-    // ds in C layout (row il = g*4+e, col jl = jt*16+r); skewed copy straight to HBM.  All per-lane offsets (window gather,
-    // dpos row pointer, A-image slot, validity threshold) are loop invariants computed once before the key loop.
-    float ds[4][4];
-    const bool ragged = (j0 + BJ > T);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const float gbias = sG[(g * 4 + e) * GLD + 127];
-#pragma unroll
-      for (int jt = 0; jt < 4; ++jt) {
-        const bool valid_r = rr0[e] + jt * 16 + j0 < lim;
-        const float pos = valid_r ? sG[goff[e] + jt * 16] : gbias;
-        float d = 0.f;
-        const bool jin = !ragged || (j0 + jt * 16 + r < T);
-        bool vis = live[e] && jin;
-        if constexpr (STREAM) { const int j = j0 + jt * 16 + r; vis = vis && j >= wlo[e] && j < whi[e]; }  // outside the window: p = 0
-        if (vis) {
-          const float p = __builtin_amdgcn_exp2f((acc_s[jt][e] + pos) * scale2 - lsei2[e]);
-          d = p * (acc_p[jt][e] - Di[e]) * scale;
-        }
-        ds[e][jt] = d;
-        if constexpr (V2) {
-          // (dS itself leaves through the LDS image below as whole 16-byte row pieces: sixteen 2-byte global stores per lane and key
-          // block kept the CU's address path busy longer than everything else in the iteration)
-          if (inrow[e] && jin && !valid_r) bias_acc[e] += d;
-        } else {
-          if (inrow[e] && jin) {
-            if (valid_r) prow_e[e][jt * 16 + j0] = f32_to_bf16(d);
-            else bias_acc[e] += d;
-          }
-        }
-      }
-    }
-    bool vr[4][4];
-    if constexpr (V2) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-#pragma unroll
-        for (int jt = 0; jt < 4; ++jt) vr[e][jt] = rr0[e] + jt * 16 + j0 < lim;
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    ATT_TICK(2)
-    // dS (bf16) as A operand image [16 rows il][64 k = jl] in the (now dead) G strip
-    if constexpr (V2) {
-      // the skewed image: clear this wave's [16 x 128] strip (the G values that lived there are consumed), then scatter
-      const uint4 z4 = make_uint4(0, 0, 0, 0);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) *reinterpret_cast<uint4*>(sAg + (q * 64 + lane) * 16) = z4;
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    }
-#pragma unroll
-    for (int e = 0; e < 4; ++e)
-#pragma unroll
-      for (int jt = 0; jt < 4; ++jt) {
-        *reinterpret_cast<bf16_t*>(sA + poff[e][jt]) = f32_to_bf16(ds[e][jt]);
-        if constexpr (V2) *reinterpret_cast<bf16_t*>(sAg + goffA[e][jt]) = f32_to_bf16(vr[e][jt] ? ds[e][jt] : 0.f);
-      }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    if constexpr (V2) {
-      // unskewed dS [16 il][64 jl] -> HBM from the A image: lane = (row il, 8 keys), pairs outside the sample's 2 len - 1 relative
-      // positions zeroed (their gradient went to the bias row); columns T .. Tp-1 of a ragged last key block are never read
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const int piece = q * 64 + lane, il = piece >> 3, cpc = piece & 7;
-        const int i = i0 + w * 16 + il, jc = j0 + cpc * 8;
-        uint4 v = *reinterpret_cast<const uint4*>(sA + il * 128 + ((cpc ^ key_d(il)) << 4));
-        if (i < T && jc < ldp) {
-          const int nval = lim - (T - 1 - i) - jc;  // keys jc .. jc + nval - 1 of this piece have a relative position inside the table
-          uint32_t* vv = reinterpret_cast<uint32_t*>(&v);
-#pragma unroll
-          for (int dd = 0; dd < 4; ++dd) vv[dd] &= (2 * dd < nval ? 0x0000ffffu : 0u) | (2 * dd + 1 < nval ? 0xffff0000u : 0u);
-          *reinterpret_cast<uint4*>(dpos + (((long)b * H + h) * T + i) * ldp + jc) = v;
-        }
-      }
-      // dqv += dG @ window   (A: skewed image, k = window column c; B: the window rows read transposed, k = c)
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        const short8_t a = *reinterpret_cast<const short8_t*>(sAg + r * 256 + (((kk * 4 + g) ^ key_d(r)) << 4));
-#pragma unroll
-        for (int n = 0; n < 4; ++n)
-          acc_v[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, frag_kt(sP, n * 16, kk * 32 + g * 8, r), acc_v[n], 0, 0, 0);
-      }
-    }
-    // dqu += dS @ K   (B operand: K block read transposed, k = j)
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      const short8_t a = frag_rows(sA, r, kk * 4 + g);
-#pragma unroll
-      for (int n = 0; n < 4; ++n)
-        acc_q[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, frag_kt(sK, n * 16, kk * 32 + g * 8, r), acc_q[n], 0, 0, 0);
-    }
-    ATT_TICK(3)
-    __syncthreads();
-    ATT_TICK(4)
-  }
-#ifdef TFASR_ATTN_TIMING
-  if (threadIdx.x == 0) {
-    long long* o = g_attn_timing + 5L * blockIdx.x;
-    for (int kq = 0; kq < 5; ++kq) o[kq] = ph[kq];
-  }
-#endif
-
-  // epilogue: dqu, the bias column, and zeros over the part of each dpos row that no (i,j) pair maps to
-  float bsum4[4];
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const int i = i0 + w * 16 + g * 4 + e;
-    float bsum = bias_acc[e];
-    bsum = row16_sum(bsum);
-    bsum4[e] = bsum;
-    if (i < T) {
-      if constexpr (!DQ) {
-#pragma unroll
-        for (int n = 0; n < 4; ++n) dqu[((long)b * T + i) * HD + h * DH + n * 16 + r] = f32_to_bf16(acc_q[n][e]);
-      }
-      if constexpr (!V2) {
-        bf16_t* prow = dpos + (((long)b * H + h) * T + i) * ldp;
-        // valid columns: rr + shift for j in [0,T) with rr = T-1-i+j < 2len-1  ->  [T-1-i+shift, min(2T-1-i, 2len-1)+shift )
-        const int lo = T - 1 - i + shift;
-        const int hi = min(2 * T - 1 - i, 2 * len - 1) + shift;  // exclusive; may be <= lo when no pair is valid
-        const int hi2 = max(hi, lo);
-        for (int c = r; c < ldp; c += 16)
-          if (c < lo || c >= hi2) prow[c] = (c == R) ? f32_to_bf16(bsum) : (bf16_t)0;
-      }
-    }
-  }
-  if constexpr (V2) {
-    // dqv_i = (dG @ window)_i + bsum_i * pext[R]   and   dpext[R] += sum_i bsum_i * (q_i + v)
-    float pbias[4], part[4], su[4], sv[4];
-#pragma unroll
-    for (int n = 0; n < 4; ++n) { pbias[n] = bf16_to_f32(pb[(long)R * HD + n * 16 + r]); part[n] = 0.f; su[n] = 0.f; sv[n] = 0.f; }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int i = i0 + w * 16 + g * 4 + e;
-      if (i < T) {
-#pragma unroll
-        for (int n = 0; n < 4; ++n) {
-          const float gqv = acc_v[n][e] + bsum4[e] * pbias[n];
-          if constexpr (DQ) {
-            dqu[((long)b * T + i) * lddq + h * DH + n * 16 + r] = f32_to_bf16(acc_q[n][e] + gqv);
-            su[n] += acc_q[n][e];
-            sv[n] += gqv;
-          } else {
-            dqv[((long)b * T + i) * HD + h * DH + n * 16 + r] = f32_to_bf16(gqv);
-          }
-          const float qvv = bf16_to_f32(f32_to_bf16(bf16_to_f32(qb[(long)i * LDQ + n * 16 + r]) + vbias[h * DH + n * 16 + r]));
-          part[n] += bsum4[e] * qvv;
-        }
-      }
-    }
-#pragma unroll
-    for (int n = 0; n < 4; ++n) {
-      float v = part[n];
-      v += __shfl_xor(v, 16, 64);
-      v += __shfl_xor(v, 32, 64);
-      if (g == 0 && v != 0.f) atomicAdd(dpext + (long)R * HD + h * DH + n * 16 + r, v);
-    }
-    if constexpr (DQ) {
-      // column sums of this block's 64 rows: over the 4 lane rows by shuffles, over the 4 waves through LDS (the staged tiles are dead)
-      __syncthreads();
-      float* red = reinterpret_cast<float*>(smem);  // [4 waves][2][64]
-#pragma unroll
-      for (int n = 0; n < 4; ++n) {
-        float a = su[n], c = sv[n];
-        a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
-        c += __shfl_xor(c, 16, 64); c += __shfl_xor(c, 32, 64);
-        if (g == 0) { red[(w * 2 + 0) * 64 + n * 16 + r] = a; red[(w * 2 + 1) * 64 + n * 16 + r] = c; }
-      }
-      __syncthreads();
-      if (threadIdx.x < 128) {
-        const int which = threadIdx.x >> 6, col = threadIdx.x & 63;
-        const float v = red[(0 * 2 + which) * 64 + col] + red[(1 * 2 + which) * 64 + col] + red[(2 * 2 + which) * 64 + col] + red[(3 * 2 + which) * 64 + col];
-        atomicAdd((which ? dv : du) + h * DH + col, v);
-      }
-    }
-  }
-}
-
-
 // ======================================================================================================================
 // Backward, part 1 in TRANSPOSED orientation (round 5; the query-gradient kernel of the default route, tfasr_relattn_fused_bwd_q3).
 // Everything is computed as in relattn_fused_fwdT_kernel: S^T = K (Q+u)^T, dP^T = V dO^T (rows = keys, dealt to the MFMA tiles so that a
@@ -1502,22 +418,21 @@ __global__ __launch_bounds__(256, 2) void relattn_fused_bwd_q_kernel(
 //   * the window scores G^T are written with one 16-byte LDS store per tile and read back as four consecutive floats (they were 24 + 16
 //     four-byte accesses); only the SKEWED score gradient (dq_v^T += window^T dG^T needs dS against the window column, not the key) still
 //     goes through a per-wave LDS image, and that image lies over the dead G^T strip: 53.5 KB of LDS per workgroup instead of 65.
-// Per lane and key block: ~34 LDS instructions instead of ~84.  Same arithmetic per (query, key) pair as relattn_fused_bwd_q_kernel<true, true>.
+// Per lane and key block: ~34 LDS instructions instead of ~84 of the row-oriented kernel it replaced (rounds 2-4; profiles/r05_attention_backward_investigation.md).
 // ======================================================================================================================
 constexpr int QT_IMG_LD = 272;                       // byte stride of a row of the skewed dS image: 128 bf16 columns + 16 B (bank spread, no swizzle)
 constexpr int QT_IMG_BYTES = 16 * QT_IMG_LD;
-// Three builds of the kernel (template parameter MODE; TFASR_ATTN_BWDQ_T picks one, default 1):
-//   1  PIPELINED: the K block and the window are double buffered and the next key block's DMA is issued behind the barrier that opens the
-//      current one (V, dead after the first products, is refetched behind a second barrier): 32 + 24 KB of tiles, the image over the wave's
-//      G^T strip (cleared per key block): 76.7 KB, two workgroups per CU.
-//   2  LEAN: single buffered, the image over the strip (53.5 KB), and the three loop-invariant B fragments (q + u, q + v, dO: 24 registers)
-//      re-read from L2 at the top of every key block instead of held - aimed at 168 registers = THREE workgroups per CU, so that the ~720
-//      live workgroups of a LibriSpeech-shaped batch are one round of resident workgroups instead of 1.4 (= 2).
-//   3  (MODE 0) single buffered with the image beside the strip (70.9 KB): the first version, kept for A/B.
+// PIPELINED: the K block and the window are double buffered and the next key block's DMA is issued behind the barrier that opens the current
+// one (V, dead after the first products, is refetched behind a second barrier): 32 + 24 KB of tiles, the image over the wave's G^T strip
+// (cleared per key block): 76.7 KB, two workgroups per CU.  The single-buffered and the lean three-per-CU builds measured slower (97 vs 82 us;
+// profiles/r05_attention_backward_investigation.md) and are gone; MODE stays a template constant of the one build.
 static_assert(QT_IMG_BYTES <= 16 * GLDT * 4, "the skewed dS image fits under the bias scores of the strip");
 constexpr int qt_tile_bytes(int mode) { return (mode == 1 ? 2 : 1) * (SK_BYTES + SP_BYTES) + SV_BYTES; }
 constexpr int qt_smem(int mode) { return qt_tile_bytes(mode) + 4 * SGTT_BYTES + (mode == 0 ? 4 * QT_IMG_BYTES : 0); }
-static_assert((qt_smem(2) + 1279) / 1280 * 3 <= 128, "LEAN: three workgroups per CU");
+
+__device__ __forceinline__ short8_t row_frag(const bf16_t* row, int k0) {
+  return *reinterpret_cast<const short8_t*>(row + k0);
+}
 
 typedef float float2_t __attribute__((ext_vector_type(2)));
 
@@ -2253,274 +1168,6 @@ __global__ __launch_bounds__(256, 2) void relattn_fused_bwd_k_kernel(
   }
 }
 
-
-// ======================================================================================================================
-// Backward, part 2 (key side) with a lane owning ONE KEY (round 5; TFASR_ATTN_BWDK_T=1, default off until it measures faster than
-// relattn_fused_bwd_k_kernel).  Scores as S = (Q+u) K^T and dP = dO V^T with the QUERY rows as the MFMA A operand (read from LDS, dealt to
-// the tiles so that a lane's eight values of a 32-query group are eight consecutive queries) and the wave's 16 keys as the B operand from
-// registers, so P and dS in the C layout ARE the B operands of dV^T += dO^T P and dK^T += (Q+u)^T dS: the two per-wave A images of the
-// row-oriented kernel (32 two-byte LDS stores + 4 fragment reads per lane and query block) are gone.  The window scores are produced PER
-// WAVE (a wave's 16 keys and a 16-query tile touch 31 window columns = two 16-column tiles: 8 G^T tiles per query block, the count the
-// block-wide version gives each wave) into a per-wave strip [64 queries][32 columns] with one 16-byte store per tile - no block-wide
-// strip, no barrier between the products and the exponentials: two barriers per query block instead of four.  The per-query quantities
-// (lse, D, the bias-row score) are 64-entry LDS arrays read four at a time.
-// ======================================================================================================================
-constexpr int KT_SLD = 32;                                   // f32 row stride of the per-wave strip
-constexpr int KT_STRIP_BYTES = 64 * KT_SLD * 4;              // 8 KB per wave
-constexpr int SMEM_BWD_KT = 3 * SK_BYTES + SP_BYTES + 4 * KT_STRIP_BYTES + 4 * 256 + 2 * 256;  // tiles, strips, bias scores per wave, lse / D
-
-template <bool STREAM>
-__global__ __launch_bounds__(256, 2) void relattn_fused_bwd_kT_kernel(
-    const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ qu, const bf16_t* __restrict__ qv,
-    const bf16_t* __restrict__ pext, const int32_t* __restrict__ lengths, const bf16_t* __restrict__ dout,
-    const float* __restrict__ lse, const float* __restrict__ dvec, bf16_t* __restrict__ dqkv, int B, int H, int T, float scale,
-    int use_mask, int chunk, int hist) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* sQu = smem;
-  char* sQv = sQu + SK_BYTES;
-  char* sdO = sQv + SK_BYTES;
-  char* sP = sdO + SK_BYTES;
-  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  float* sS = reinterpret_cast<float*>(sP + SP_BYTES + w * KT_STRIP_BYTES);                 // [64 il][32]: window columns 16 (3 - qt + w) .. + 31 of query tile qt
-  float* sGb = reinterpret_cast<float*>(sP + SP_BYTES + 4 * KT_STRIP_BYTES);                 // [64]: bias-row score of every query of the block (wave w forms queries 16w .. 16w+15)
-  float* sL = reinterpret_cast<float*>(sP + SP_BYTES + 4 * KT_STRIP_BYTES + 4 * 256);        // [64] lse * log2 e, [64] D
-  float* sD = sL + 64;
-  const int r = lane & 15, g = lane >> 4;
-  const BlockId bid = attn_block_id<false>(B, H, (T + BJ - 1) / BJ);
-  if (!bid.ok) return;
-  const int b = bid.b, h = bid.h, j0 = bid.blk * BJ;
-  const int HD = H * DH, LDQ = 3 * HD, R1 = 2 * T;
-  const int len = lengths ? min(lengths[b], T) : T;
-  const int shift = T - len;
-  const bf16_t* kb = qkv + (long)b * T * LDQ + HD + h * DH;
-  const bf16_t* vb = kb + HD;
-  const bf16_t* qub = qu + (long)b * T * HD + h * DH;
-  const bf16_t* qvb = qv + (long)b * T * HD + h * DH;
-  const bf16_t* dob = dout + (long)b * T * HD + h * DH;
-  const bf16_t* pb = pext + h * DH;
-  uint4 bias_row = make_uint4(0, 0, 0, 0);
-  if ((threadIdx.x >> 6) == 0 && (threadIdx.x & 63) < 8) bias_row = *reinterpret_cast<const uint4*>(pb + (long)(2 * T - 1) * HD + (((threadIdx.x & 63) ^ key_d(127)) << 3));
-
-  const int j = j0 + w * 16 + r;  // this lane's key
-  const int jrow = min(j, T - 1);
-  const bool jin = j < T;
-  short8_t bk[2], bv[2];
-#pragma unroll
-  for (int kk = 0; kk < 2; ++kk) {
-    bk[kk] = row_frag(kb + (long)jrow * LDQ, kk * 32 + g * 8);
-    bv[kk] = row_frag(vb + (long)jrow * LDQ, kk * 32 + g * 8);
-  }
-  float4_t acc_k[4], acc_v[4];  // dK^T / dV^T: rows = head dims n*16 + g*4 + e, column = this lane's key
-#pragma unroll
-  for (int n = 0; n < 4; ++n) { acc_k[n] = float4_t{0.f, 0.f, 0.f, 0.f}; acc_v[n] = float4_t{0.f, 0.f, 0.f, 0.f}; }
-
-  const float scale2 = scale * 1.4426950408889634f;
-  const int lim = 2 * len - 1;
-  const long lrow = ((long)b * H + h) * T;
-  const int ithr = T - 1 + j - lim;  // queries i > ithr: relative position T-1-i+j inside the sample's 2 len - 1 encodings
-  int il0[4], qrow[4];
-#pragma unroll
-  for (int it = 0; it < 4; ++it) {
-    il0[it] = 32 * (it >> 1) + g * 8 + (it & 1) * 4;                      // first of this lane's four queries of tile it (C rows g*4 + e)
-    qrow[it] = 32 * (it >> 1) + (r >> 2) * 8 + (it & 1) * 4 + (r & 3);  // query row that is MFMA row r of tile it (A operand)
-  }
-  const int nib = (T + BI - 1) / BI;
-  if (w == 0 && lane < 8) *reinterpret_cast<uint4*>(sP + 127 * 128 + lane * 16) = bias_row;  // window row 127 <- the bias row, once
-  // The loads of query block ib+1 are issued INSIDE block ib: the qv block and the window - dead once the window scores are formed -
-  // behind a barrier in the middle of the block, the qu / dO blocks and the per-query scalars behind the closing barrier (inline-asm DMA:
-  // the compiler places no vmcnt wait of its own in front of the LDS reads; everything is waited for at the top of the next block).
-  auto issue_early = [&](int ibn) {  // qv block + window of query block ibn
-    const int i0n = ibn * BI;
-    load_rows<BI, true>(sQv, qvb, HD, i0n, T, w, lane);
-    load_rows<WIN, true, true>(sP, pb, HD, (T - 1 - (i0n + BI - 1) + j0) + shift, R1, w, lane);  // (row 127 = the bias row stays)
-  };
-  auto issue_late = [&](int ibn, bool pad) {  // per-query scalars, dO block, qu block
-    const int i0n = ibn * BI;
-    // (the scalars' global loads are requested first and stored last: their latency runs under the DMA issue instead of in front of it)
-    float l = 0.f, d = 0.f;
-    if (threadIdx.x < 64) {
-      const int ic = min(i0n + (int)threadIdx.x, T - 1);
-      l = lse[lrow + ic];
-      d = dvec[lrow + ic];
-    }
-    load_rows<BI, true>(sdO, dob, HD, i0n, T, w, lane);
-    if (!pad) load_rows<BI, true>(sQu, qub, HD, i0n, T, w, lane);
-    if (threadIdx.x < 64) {
-      sL[threadIdx.x] = l * 1.4426950408889634f;
-      sD[threadIdx.x] = d;
-    }
-  };
-  if (nib > 0) {
-    const bool pad0 = use_mask && 0 >= len;
-    if (!pad0) issue_early(0);
-    issue_late(0, pad0);
-  }
-  for (int ib = 0; ib < nib; ++ib) {
-    const int i0 = ib * BI;
-    const bool padded = use_mask && i0 >= len;  // a block of padded query rows: p = 1 / T for every key, dS = 0: only dV += P^T dO
-    const bool more = ib + 1 < nib, padded_next = use_mask && i0 + BI >= len;
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-
-    short8_t pp[2], pd[2];  // P / dS of this lane's key against queries 32q + 8g + 0..7: the B operands of the last products
-    if (padded) {
-#pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        const float4_t l4 = *reinterpret_cast<const float4_t*>(sL + il0[it]);
-        uint32_t pk[2];
-#pragma unroll
-        for (int h2 = 0; h2 < 2; ++h2) {
-          float pv[2];
-#pragma unroll
-          for (int q2 = 0; q2 < 2; ++q2) {
-            const int e = 2 * h2 + q2;
-            pv[q2] = (i0 + il0[it] + e < T && jin) ? __builtin_amdgcn_exp2f(0.f - l4[e]) : 0.f;
-          }
-          pk[h2] = pack2_bf16(pv[0], pv[1]);
-        }
-        const int o4 = (it & 1) * 4;
-        pp[it >> 1][o4 + 0] = (short)(pk[0] & 0xffffu); pp[it >> 1][o4 + 1] = (short)(pk[0] >> 16);
-        pp[it >> 1][o4 + 2] = (short)(pk[1] & 0xffffu); pp[it >> 1][o4 + 3] = (short)(pk[1] >> 16);
-      }
-#pragma unroll
-      for (int q = 0; q < 2; ++q)
-#pragma unroll
-        for (int n = 0; n < 4; ++n)
-          acc_v[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_kt(sdO, n * 16, q * 32 + g * 8, r), pp[q], acc_v[n], 0, 0, 0);
-      __syncthreads();
-      if (more) issue_late(ib + 1, true);  // (padded blocks are the tail of the loop: the next one is padded too)
-      continue;
-    }
-
-    // content scores and dP: rows = queries (dealt), column = this lane's key
-    float4_t acc_s[4], acc_p[4];
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      acc_s[it] = float4_t{0.f, 0.f, 0.f, 0.f};
-      acc_p[it] = float4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        acc_s[it] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(sQu, qrow[it], kk * 4 + g), bk[kk], acc_s[it], 0, 0, 0);
-        acc_p[it] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(sdO, qrow[it], kk * 4 + g), bv[kk], acc_p[it], 0, 0, 0);
-      }
-    }
-    // window scores of this wave's 16 keys: per 16-query tile qt the two 16-column window tiles from column 16 (3 - qt + w) on, transposed
-    // (rows = window columns, column = query 16 qt + r), and the bias-row score of every query (row 15 of window rows 112..127)
-#pragma unroll
-    for (int qt = 0; qt < 4; ++qt) {
-      short8_t bq[2];
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) bq[kk] = frag_rows(sQv, qt * 16 + r, kk * 4 + g);
-      const int ct0 = 3 - qt + w;
-#pragma unroll
-      for (int c2 = 0; c2 < 2; ++c2) {
-        float4_t a = float4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(sP, (ct0 + c2) * 16 + r, kk * 4 + g), bq[kk], a, 0, 0, 0);
-        *reinterpret_cast<float4_t*>(sS + (qt * 16 + r) * KT_SLD + c2 * 16 + g * 4) = a;
-      }
-      if (qt == w) {  // the bias-row score of queries 16w .. 16w+15 (row 15 of window rows 112..127): one tile per wave, shared
-        float4_t ab = float4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-          ab = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(sP, 112 + r, kk * 4 + g), bq[kk], ab, 0, 0, 0);
-        if (g == 3) sGb[qt * 16 + r] = ab[3];
-      }
-    }
-    // every wave has read the qv block and the window, and the bias-row scores of all 64 queries are in LDS
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (more && !padded_next) issue_early(ib + 1);
-    // P and dS in C layout (rows = this lane's queries il0[it] + e, column = its key).  A block whose 64 queries are all real, unmasked and
-    // inside the table for every key of the wave (the common one) needs none of the selects.
-    bool plain = false;
-    if constexpr (!STREAM) plain = __builtin_amdgcn_ballot_w64(jin && i0 + BI <= (use_mask ? min(T, len) : T) && i0 > ithr) == ~0ull;
-    if (plain) {
-      const float Dsc = scale;
-#pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        const float4_t l4 = *reinterpret_cast<const float4_t*>(sL + il0[it]);
-        const float4_t d4 = *reinterpret_cast<const float4_t*>(sD + il0[it]);
-        uint32_t pkp[2], pkd[2];
-#pragma unroll
-        for (int h2 = 0; h2 < 2; ++h2) {
-          const int e0 = 2 * h2, ila = il0[it] + e0, ilb = ila + 1;
-          const float2_t gs = float2_t{sS[ila * KT_SLD + 15 - (ila & 15) + r], sS[ilb * KT_SLD + 15 - (ilb & 15) + r]};
-          const float2_t ex = (float2_t{acc_s[it][e0], acc_s[it][e0 + 1]} + gs) * scale2 - float2_t{l4[e0], l4[e0 + 1]};
-          const float2_t pv = float2_t{__builtin_amdgcn_exp2f(ex[0]), __builtin_amdgcn_exp2f(ex[1])};
-          const float2_t dv2 = pv * ((float2_t{acc_p[it][e0], acc_p[it][e0 + 1]} - float2_t{d4[e0], d4[e0 + 1]}) * Dsc);
-          pkp[h2] = pack2_bf16(pv[0], pv[1]);
-          pkd[h2] = pack2_bf16(dv2[0], dv2[1]);
-        }
-        const int o4 = (it & 1) * 4;
-        pp[it >> 1][o4 + 0] = (short)(pkp[0] & 0xffffu); pp[it >> 1][o4 + 1] = (short)(pkp[0] >> 16);
-        pp[it >> 1][o4 + 2] = (short)(pkp[1] & 0xffffu); pp[it >> 1][o4 + 3] = (short)(pkp[1] >> 16);
-        pd[it >> 1][o4 + 0] = (short)(pkd[0] & 0xffffu); pd[it >> 1][o4 + 1] = (short)(pkd[0] >> 16);
-        pd[it >> 1][o4 + 2] = (short)(pkd[1] & 0xffffu); pd[it >> 1][o4 + 3] = (short)(pkd[1] >> 16);
-      }
-    } else
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const float4_t l4 = *reinterpret_cast<const float4_t*>(sL + il0[it]);
-      const float4_t d4 = *reinterpret_cast<const float4_t*>(sD + il0[it]);
-      const float4_t b4 = *reinterpret_cast<const float4_t*>(sGb + il0[it]);
-      uint32_t pkp[2], pkd[2];
-#pragma unroll
-      for (int h2 = 0; h2 < 2; ++h2) {
-        float pv[2], dv2[2];
-#pragma unroll
-        for (int q2 = 0; q2 < 2; ++q2) {
-          const int e = 2 * h2 + q2;
-          const int il = il0[it] + e, i = i0 + il;
-          const float gsk = sS[il * KT_SLD + 15 - (il & 15) + r];
-          const float pos = (i > ithr) ? gsk : b4[e];
-          const bool qmask = use_mask && (i >= len);
-          bool vis = (i < T) && jin;
-          if constexpr (STREAM) {
-            if (!qmask) { int wlo, whi; stream_window(min(i, T - 1), T, chunk, hist, wlo, whi); vis = vis && j >= wlo && j < whi; }
-          }
-          float p = 0.f, d = 0.f;
-          if (vis) {
-            const float s2 = qmask ? 0.f : (acc_s[it][e] + pos) * scale2;
-            p = __builtin_amdgcn_exp2f(s2 - l4[e]);
-            d = qmask ? 0.f : p * (acc_p[it][e] - d4[e]) * scale;
-          }
-          pv[q2] = p; dv2[q2] = d;
-        }
-        pkp[h2] = pack2_bf16(pv[0], pv[1]);
-        pkd[h2] = pack2_bf16(dv2[0], dv2[1]);
-      }
-      const int o4 = (it & 1) * 4;
-      pp[it >> 1][o4 + 0] = (short)(pkp[0] & 0xffffu); pp[it >> 1][o4 + 1] = (short)(pkp[0] >> 16);
-      pp[it >> 1][o4 + 2] = (short)(pkp[1] & 0xffffu); pp[it >> 1][o4 + 3] = (short)(pkp[1] >> 16);
-      pd[it >> 1][o4 + 0] = (short)(pkd[0] & 0xffffu); pd[it >> 1][o4 + 1] = (short)(pkd[0] >> 16);
-      pd[it >> 1][o4 + 2] = (short)(pkd[1] & 0xffffu); pd[it >> 1][o4 + 3] = (short)(pkd[1] >> 16);
-    }
-    // dV^T += dO^T P ; dK^T += (Q+u)^T dS   (A: the dO / qu blocks read transposed, k = query; B: from registers)
-#pragma unroll
-    for (int q = 0; q < 2; ++q)
-#pragma unroll
-      for (int n = 0; n < 4; ++n) {
-        acc_v[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_kt(sdO, n * 16, q * 32 + g * 8, r), pp[q], acc_v[n], 0, 0, 0);
-        acc_k[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_kt(sQu, n * 16, q * 32 + g * 8, r), pd[q], acc_k[n], 0, 0, 0);
-      }
-    __syncthreads();
-    if (more) issue_late(ib + 1, padded_next);
-  }
-  if (jin) {
-    bf16_t* row = dqkv + ((long)b * T + j) * LDQ + h * DH;
-#pragma unroll
-    for (int n = 0; n < 4; ++n) {
-      uint2 vk, vv;
-      vk.x = pack2_bf16(acc_k[n][0], acc_k[n][1]); vk.y = pack2_bf16(acc_k[n][2], acc_k[n][3]);
-      vv.x = pack2_bf16(acc_v[n][0], acc_v[n][1]); vv.y = pack2_bf16(acc_v[n][2], acc_v[n][3]);
-      *reinterpret_cast<uint2*>(row + HD + n * 16 + g * 4) = vk;
-      *reinterpret_cast<uint2*>(row + 2 * HD + n * 16 + g * 4) = vv;
-    }
-  }
-}
-
 }  // namespace
 
 extern "C" int tfasr_relattn_fused_fwd(const void* qkv, const float* ubias, const float* vbias, const void* pext,
@@ -2528,89 +1175,11 @@ extern "C" int tfasr_relattn_fused_fwd(const void* qkv, const float* ubias, cons
                                        int use_mask, int chunk, int hist, int dtype, void* stream_) {
   if (!qkv || !ubias || !vbias || !pext || !out || !lse || B <= 0 || H <= 0 || T <= 0) return TFASR_STATUS_INVALID_VALUE;
   if (dtype != TFASR_BF16 || dh != DH) return TFASR_STATUS_UNSUPPORTED;
-  dim3 grid((T + BI - 1) / BI, H, B);
-  // 32-key blocks / four workgroups per CU when the whole grid is then resident at once (T' = 462, 1024 workgroups: 59.5 -> 53.1 us;
-  // T' = 390: 50.0 -> 46.1); with more workgroups than that the 64-key kernel's three per CU win (T' = 743, 1536 workgroups: 103 vs
-  // 127 us).  TFASR_ATTN_FWD32=0 / 1 forces one of them.
-  static const char* env32 = getenv("TFASR_ATTN_FWD32");
-  static int ncu = 0;
-  if (ncu == 0) {
-    int dev = 0, v = 0;
-    ncu = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
-  }
-  const bool fwd32 = env32 ? env32[0] == '1' : (long)grid.x * grid.y * grid.z <= 4L * ncu;
-  const bool st = chunk > 0;
-  static const bool fwd_t = !(getenv("TFASR_ATTN_FWD_T") && getenv("TFASR_ATTN_FWD_T")[0] == '0');  // 0: the row-oriented kernels (A/B)
-  // 32 query rows per wave (relattn_fused_fwdT2_kernel): TFASR_ATTN_FWD_QR2=1 / 0 (A/B)
-  static const bool fwd_qr2 = getenv("TFASR_ATTN_FWD_QR2") && getenv("TFASR_ATTN_FWD_QR2")[0] == '1';
-  if (fwd_t && !env32 && fwd_qr2) {
-    const dim3 gridT2(attn_grid_size(B, H, (T + BI2 - 1) / BI2));
-    static bool attr_done = false;
-    if (!attr_done) {
-      (void)hipFuncSetAttribute((const void*)relattn_fused_fwdT2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_FWDT2);
-      (void)hipFuncSetAttribute((const void*)relattn_fused_fwdT2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_FWDT2);
-      attr_done = true;
-    }
-    if (st) hipLaunchKernelGGL(relattn_fused_fwdT2_kernel<true>, gridT2, dim3(256), SMEM_FWDT2, (hipStream_t)stream_, (const bf16_t*)qkv, ubias, vbias,
-                               (const bf16_t*)pext, lengths, (bf16_t*)out, lse, B, H, T, scale, use_mask, chunk, hist);
-    else hipLaunchKernelGGL(relattn_fused_fwdT2_kernel<false>, gridT2, dim3(256), SMEM_FWDT2, (hipStream_t)stream_, (const bf16_t*)qkv, ubias, vbias,
-                            (const bf16_t*)pext, lengths, (bf16_t*)out, lse, B, H, T, scale, use_mask, chunk, hist);
-    TFASR_CHECK_LAUNCH();
-    return TFASR_STATUS_SUCCESS;
-  }
-  if (fwd_t && !env32) {
-    const dim3 gridT(attn_grid_size(B, H, (T + BI - 1) / BI));
-#ifdef TFASR_ATTN_TIMING
-    static const int lds_pad = getenv("TFASR_ATTN_LDS_PAD") ? atoi(getenv("TFASR_ATTN_LDS_PAD")) : 0;  // probe: fewer workgroups per CU
-#define SMEM_FWDT (SMEM_FWDT + lds_pad)
-#endif
-    if (st) hipLaunchKernelGGL(relattn_fused_fwdT_kernel<true>, gridT, dim3(256), SMEM_FWDT, (hipStream_t)stream_, (const bf16_t*)qkv, ubias, vbias,
-                               (const bf16_t*)pext, lengths, (bf16_t*)out, lse, B, H, T, scale, use_mask, chunk, hist);
-    else hipLaunchKernelGGL(relattn_fused_fwdT_kernel<false>, gridT, dim3(256), SMEM_FWDT, (hipStream_t)stream_, (const bf16_t*)qkv, ubias, vbias,
-                            (const bf16_t*)pext, lengths, (bf16_t*)out, lse, B, H, T, scale, use_mask, chunk, hist);
-    TFASR_CHECK_LAUNCH();
-    return TFASR_STATUS_SUCCESS;
-  }
-#define TFASR_FWD_LAUNCH(KERNEL, SMEM) hipLaunchKernelGGL(KERNEL, grid, dim3(256), SMEM, (hipStream_t)stream_, (const bf16_t*)qkv, ubias, vbias, \
-                                                          (const bf16_t*)pext, lengths, (bf16_t*)out, lse, B, H, T, scale, use_mask, chunk, hist)
-  if (fwd32) { if (st) TFASR_FWD_LAUNCH(relattn_fused_fwd32_kernel<true>, SMEM_FWD32); else TFASR_FWD_LAUNCH(relattn_fused_fwd32_kernel<false>, SMEM_FWD32); }
-  else { if (st) TFASR_FWD_LAUNCH(relattn_fused_fwd_kernel<true>, SMEM_FWD); else TFASR_FWD_LAUNCH(relattn_fused_fwd_kernel<false>, SMEM_FWD); }
-#undef TFASR_FWD_LAUNCH
-  TFASR_CHECK_LAUNCH();
-  return TFASR_STATUS_SUCCESS;
-}
-
-extern "C" int tfasr_relattn_fused_bwd_q(const void* qkv, const float* ubias, const float* vbias, const void* pext,
-                                         const int32_t* lengths, const void* o, const void* dout, const float* lse, void* dqu,
-                                         void* dpos, float* dvec, int B, int H, int T, int dh, int ldp, float scale, int use_mask, int dtype,
-                                         void* stream_) {
-  if (!qkv || !ubias || !vbias || !pext || !o || !dout || !lse || !dqu || !dpos || !dvec || B <= 0 || H <= 0 || T <= 0 || ldp < 2 * T)
-    return TFASR_STATUS_INVALID_VALUE;
-  if (dtype != TFASR_BF16 || dh != DH) return TFASR_STATUS_UNSUPPORTED;
-  dim3 grid((T + BI - 1) / BI, H, B);
-  hipLaunchKernelGGL(relattn_fused_bwd_q_kernel<false>, dim3(attn_grid_size(B, H, (int)grid.x)), dim3(256), SMEM_BWD_Q, (hipStream_t)stream_, (const bf16_t*)qkv, ubias, vbias,
-                     (const bf16_t*)pext, lengths, (const bf16_t*)o, (const bf16_t*)dout, lse, (bf16_t*)dqu, (bf16_t*)dpos, dvec, B, H, T, ldp,
-                     scale, use_mask, (bf16_t*)nullptr, (float*)nullptr);
-  TFASR_CHECK_LAUNCH();
-  return TFASR_STATUS_SUCCESS;
-}
-
-extern "C" int tfasr_relattn_fused_bwd_q2(const void* qkv, const float* ubias, const float* vbias, const void* pext,
-                                          const int32_t* lengths, const void* o, const void* dout, const float* lse, void* dqu, void* dqv,
-                                          void* ds, float* dvec, float* dpext, int B, int H, int T, int dh, int lds, float scale, int use_mask,
-                                          int chunk, int hist, int dtype, void* stream_) {
-  if (!qkv || !ubias || !vbias || !pext || !o || !dout || !lse || !dqu || !dqv || !ds || !dvec || !dpext || B <= 0 || H <= 0 || T <= 0 || lds < T || (lds & 7))
-    return TFASR_STATUS_INVALID_VALUE;
-  if (dtype != TFASR_BF16 || dh != DH) return TFASR_STATUS_UNSUPPORTED;
-  dim3 grid((T + BI - 1) / BI, H, B);
-  if (chunk > 0)
-    hipLaunchKernelGGL((relattn_fused_bwd_q_kernel<true, false, true>), dim3(attn_grid_size(B, H, (int)grid.x)), dim3(256), SMEM_BWD_Q, (hipStream_t)stream_, (const bf16_t*)qkv, ubias, vbias,
-                       (const bf16_t*)pext, lengths, (const bf16_t*)o, (const bf16_t*)dout, lse, (bf16_t*)dqu, (bf16_t*)ds, dvec, B, H, T, lds,
-                       scale, use_mask, (bf16_t*)dqv, dpext, 0L, (float*)nullptr, (float*)nullptr, chunk, hist);
-  else
-  hipLaunchKernelGGL(relattn_fused_bwd_q_kernel<true>, dim3(attn_grid_size(B, H, (int)grid.x)), dim3(256), SMEM_BWD_Q, (hipStream_t)stream_, (const bf16_t*)qkv, ubias, vbias,
-                     (const bf16_t*)pext, lengths, (const bf16_t*)o, (const bf16_t*)dout, lse, (bf16_t*)dqu, (bf16_t*)ds, dvec, B, H, T, lds,
-                     scale, use_mask, (bf16_t*)dqv, dpext);
+  const dim3 gridT(attn_grid_size(B, H, (T + BI - 1) / BI));
+  if (chunk > 0) hipLaunchKernelGGL(relattn_fused_fwdT_kernel<true>, gridT, dim3(256), SMEM_FWDT, (hipStream_t)stream_, (const bf16_t*)qkv, ubias, vbias,
+                                    (const bf16_t*)pext, lengths, (bf16_t*)out, lse, B, H, T, scale, use_mask, chunk, hist);
+  else hipLaunchKernelGGL(relattn_fused_fwdT_kernel<false>, gridT, dim3(256), SMEM_FWDT, (hipStream_t)stream_, (const bf16_t*)qkv, ubias, vbias,
+                          (const bf16_t*)pext, lengths, (bf16_t*)out, lse, B, H, T, scale, use_mask, chunk, hist);
   TFASR_CHECK_LAUNCH();
   return TFASR_STATUS_SUCCESS;
 }
@@ -2620,44 +1189,22 @@ extern "C" int tfasr_relattn_fused_bwd_q3(const void* qkv, const float* ubias, c
                                           float* dvec, float* dpext, void* qu, void* qv, int B, int H, int T, int dh, int lds, float scale,
                                           int use_mask, int chunk, int hist, int dtype, void* stream_) {
   if (!qkv || !ubias || !vbias || !pext || !o || !dout || !lse || !dq || !du || !dv || !ds || !dvec || !dpext || B <= 0 || H <= 0 || T <= 0 || lds < T ||
-      (lds & 7) || lddq < (long)H * dh || ((qu == nullptr) != (qv == nullptr)) || (((uintptr_t)qu | (uintptr_t)qv) & 15))
+      (lds & 7) || lddq < (long)H * dh || (lddq & 3) || ((qu == nullptr) != (qv == nullptr)) || (((uintptr_t)qu | (uintptr_t)qv) & 15))
     return TFASR_STATUS_INVALID_VALUE;
   if (dtype != TFASR_BF16 || dh != DH) return TFASR_STATUS_UNSUPPORTED;
-  dim3 grid((T + BI - 1) / BI, H, B);
-  // transposed orientation (relattn_fused_bwd_qT_kernel, round 5); TFASR_ATTN_BWDQ_T=0: the row-oriented kernel (A/B)
-  const char* bwdq_env = getenv("TFASR_ATTN_BWDQ_T");  // (read per call: the comparison test flips it inside one process)
-  const bool bwdq_t = !(bwdq_env && bwdq_env[0] == '0');
-  if (bwdq_t && (lddq & 3) == 0 && (lds & 7) == 0) {
-    // MODE of the transposed kernel: "1" / unset = pipelined, "2" = lean (three workgroups per CU; needs the q + u / q + v outputs), "3" = the
-    // first single-buffered version
-    const int mode = (bwdq_env && bwdq_env[0] == '2' && qu && qv) ? 2 : (bwdq_env && bwdq_env[0] == '3') ? 0 : 1;
-    static bool attr_done = false;
-    if (!attr_done) {
-      (void)hipFuncSetAttribute((const void*)relattn_fused_bwd_qT_kernel<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, qt_smem(0));
-      (void)hipFuncSetAttribute((const void*)relattn_fused_bwd_qT_kernel<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, qt_smem(0));
-      (void)hipFuncSetAttribute((const void*)relattn_fused_bwd_qT_kernel<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, qt_smem(1));
-      (void)hipFuncSetAttribute((const void*)relattn_fused_bwd_qT_kernel<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, qt_smem(1));
-      attr_done = true;
-    }
-    const dim3 gq(attn_grid_size(B, H, (int)grid.x));
-#define TFASR_QT_LAUNCH(ST, MD)                                                                                                             \
-    hipLaunchKernelGGL((relattn_fused_bwd_qT_kernel<ST, MD>), gq, dim3(256), qt_smem(MD), (hipStream_t)stream_, (const bf16_t*)qkv, ubias, vbias, \
-                       (const bf16_t*)pext, lengths, (const bf16_t*)o, (const bf16_t*)dout, lse, (bf16_t*)dq, (bf16_t*)ds, dvec, B, H, T, lds, scale, \
-                       use_mask, dpext, lddq, du, dv, chunk > 0 ? chunk : 0, chunk > 0 ? hist : 0, (bf16_t*)qu, (bf16_t*)qv)
-    if (chunk > 0) { if (mode == 2) TFASR_QT_LAUNCH(true, 2); else if (mode == 0) TFASR_QT_LAUNCH(true, 0); else TFASR_QT_LAUNCH(true, 1); }
-    else { if (mode == 2) TFASR_QT_LAUNCH(false, 2); else if (mode == 0) TFASR_QT_LAUNCH(false, 0); else TFASR_QT_LAUNCH(false, 1); }
-#undef TFASR_QT_LAUNCH
-    TFASR_CHECK_LAUNCH();
-    return TFASR_STATUS_SUCCESS;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)relattn_fused_bwd_qT_kernel<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, qt_smem(1));
+    (void)hipFuncSetAttribute((const void*)relattn_fused_bwd_qT_kernel<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, qt_smem(1));
+    attr_done = true;
   }
-  if (chunk > 0)
-    hipLaunchKernelGGL((relattn_fused_bwd_q_kernel<true, true, true>), dim3(attn_grid_size(B, H, (int)grid.x)), dim3(256), SMEM_BWD_Q, (hipStream_t)stream_, (const bf16_t*)qkv, ubias, vbias,
-                       (const bf16_t*)pext, lengths, (const bf16_t*)o, (const bf16_t*)dout, lse, (bf16_t*)dq, (bf16_t*)ds, dvec, B, H, T, lds, scale,
-                       use_mask, (bf16_t*)nullptr, dpext, lddq, du, dv, chunk, hist, (bf16_t*)qu, (bf16_t*)qv);
-  else
-  hipLaunchKernelGGL((relattn_fused_bwd_q_kernel<true, true>), dim3(attn_grid_size(B, H, (int)grid.x)), dim3(256), SMEM_BWD_Q, (hipStream_t)stream_, (const bf16_t*)qkv, ubias, vbias,
-                     (const bf16_t*)pext, lengths, (const bf16_t*)o, (const bf16_t*)dout, lse, (bf16_t*)dq, (bf16_t*)ds, dvec, B, H, T, lds, scale,
-                     use_mask, (bf16_t*)nullptr, dpext, lddq, du, dv, 0, 0, (bf16_t*)qu, (bf16_t*)qv);
+  const dim3 gq(attn_grid_size(B, H, (T + BI - 1) / BI));
+#define TFASR_QT_LAUNCH(ST)                                                                                                                  \
+  hipLaunchKernelGGL((relattn_fused_bwd_qT_kernel<ST, 1>), gq, dim3(256), qt_smem(1), (hipStream_t)stream_, (const bf16_t*)qkv, ubias, vbias,   \
+                     (const bf16_t*)pext, lengths, (const bf16_t*)o, (const bf16_t*)dout, lse, (bf16_t*)dq, (bf16_t*)ds, dvec, B, H, T, lds, scale, \
+                     use_mask, dpext, lddq, du, dv, chunk > 0 ? chunk : 0, chunk > 0 ? hist : 0, (bf16_t*)qu, (bf16_t*)qv)
+  if (chunk > 0) TFASR_QT_LAUNCH(true); else TFASR_QT_LAUNCH(false);
+#undef TFASR_QT_LAUNCH
   TFASR_CHECK_LAUNCH();
   return TFASR_STATUS_SUCCESS;
 }
@@ -2667,8 +1214,9 @@ extern "C" int tfasr_relattn_dpext(const void* ds, const void* qv, const int32_t
   if (!ds || !qv || !dpext || B <= 0 || H <= 0 || T <= 0 || lds < T || (lds & 7)) return TFASR_STATUS_INVALID_VALUE;
   if (dtype != TFASR_BF16 || dh != DH) return TFASR_STATUS_UNSUPPORTED;
   const int cblocks = (2 * T - 1 + 127) / 128;
-  // sample groups: enough workgroups to fill the chip (4 per CU measured best) without multiplying the atomics more than needed
-  static const int target = getenv("TFASR_DPEXT_WGS") ? atoi(getenv("TFASR_DPEXT_WGS")) : 1024;  // (512: +0.12 ms per step, 2048: no further gain)
+  // sample groups: enough workgroups to fill the chip (4 per CU measured best: 512 -> +0.12 ms per step, 2048: no further gain) without
+  // multiplying the atomics more than needed
+  const int target = 1024;
   int groups = std::max(1, std::min(B, target / std::max(1, cblocks * H)));
   const int bchunk = (B + groups - 1) / groups;
   groups = (B + bchunk - 1) / bchunk;
@@ -2683,31 +1231,13 @@ extern "C" int tfasr_relattn_fused_bwd_k(const void* qkv, const void* qu, const 
                                          int dh, float scale, int use_mask, int chunk, int hist, int dtype, void* stream_) {
   if (!qkv || !qu || !qv || !pext || !dout || !lse || !dvec || !dqkv || B <= 0 || H <= 0 || T <= 0) return TFASR_STATUS_INVALID_VALUE;
   if (dtype != TFASR_BF16 || dh != DH) return TFASR_STATUS_UNSUPPORTED;
-  dim3 grid((T + BJ - 1) / BJ, H, B);
-  // one key per lane (relattn_fused_bwd_kT_kernel, round 5): TFASR_ATTN_BWDK_T=1 (read per call); needs 8-byte aligned dK / dV rows
-  const char* kt_env = getenv("TFASR_ATTN_BWDK_T");
-  if (kt_env && kt_env[0] == '1' && ((H * DH) & 3) == 0 && (((uintptr_t)dqkv) & 7) == 0) {
-    static bool attr_done = false;
-    if (!attr_done) {
-      (void)hipFuncSetAttribute((const void*)relattn_fused_bwd_kT_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BWD_KT);
-      (void)hipFuncSetAttribute((const void*)relattn_fused_bwd_kT_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BWD_KT);
-      attr_done = true;
-    }
-    if (chunk > 0)
-      hipLaunchKernelGGL(relattn_fused_bwd_kT_kernel<true>, dim3(attn_grid_size(B, H, (int)grid.x)), dim3(256), SMEM_BWD_KT, (hipStream_t)stream_, (const bf16_t*)qkv, (const bf16_t*)qu,
-                         (const bf16_t*)qv, (const bf16_t*)pext, lengths, (const bf16_t*)dout, lse, dvec, (bf16_t*)dqkv, B, H, T, scale, use_mask, chunk, hist);
-    else
-      hipLaunchKernelGGL(relattn_fused_bwd_kT_kernel<false>, dim3(attn_grid_size(B, H, (int)grid.x)), dim3(256), SMEM_BWD_KT, (hipStream_t)stream_, (const bf16_t*)qkv, (const bf16_t*)qu,
-                         (const bf16_t*)qv, (const bf16_t*)pext, lengths, (const bf16_t*)dout, lse, dvec, (bf16_t*)dqkv, B, H, T, scale, use_mask, 0, 0);
-    TFASR_CHECK_LAUNCH();
-    return TFASR_STATUS_SUCCESS;
-  }
+  const dim3 gk(attn_grid_size(B, H, (T + BJ - 1) / BJ));
   if (chunk > 0)
-    hipLaunchKernelGGL(relattn_fused_bwd_k_kernel<true>, dim3(attn_grid_size(B, H, (int)grid.x)), dim3(256), SMEM_BWD_K, (hipStream_t)stream_, (const bf16_t*)qkv, (const bf16_t*)qu,
+    hipLaunchKernelGGL(relattn_fused_bwd_k_kernel<true>, gk, dim3(256), SMEM_BWD_K, (hipStream_t)stream_, (const bf16_t*)qkv, (const bf16_t*)qu,
                        (const bf16_t*)qv, (const bf16_t*)pext, lengths, (const bf16_t*)dout, lse, dvec, (bf16_t*)dqkv, B, H, T, scale, use_mask, chunk, hist);
   else
-  hipLaunchKernelGGL(relattn_fused_bwd_k_kernel<false>, dim3(attn_grid_size(B, H, (int)grid.x)), dim3(256), SMEM_BWD_K, (hipStream_t)stream_, (const bf16_t*)qkv, (const bf16_t*)qu,
-                     (const bf16_t*)qv, (const bf16_t*)pext, lengths, (const bf16_t*)dout, lse, dvec, (bf16_t*)dqkv, B, H, T, scale, use_mask, 0, 0);
+    hipLaunchKernelGGL(relattn_fused_bwd_k_kernel<false>, gk, dim3(256), SMEM_BWD_K, (hipStream_t)stream_, (const bf16_t*)qkv, (const bf16_t*)qu,
+                       (const bf16_t*)qv, (const bf16_t*)pext, lengths, (const bf16_t*)dout, lse, dvec, (bf16_t*)dqkv, B, H, T, scale, use_mask, 0, 0);
   TFASR_CHECK_LAUNCH();
   return TFASR_STATUS_SUCCESS;
 }

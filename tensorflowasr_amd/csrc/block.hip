@@ -67,20 +67,13 @@ struct G {
   const float* bias = nullptr; const void* res = nullptr; const void* dact_z = nullptr; void* prez = nullptr;
   float alpha = 1.f, beta = 1.f; int act = 0, dact = 0, out_f32 = 0, accumulate = 0, split_k = 1; float drop_p = 0.f; long drop_seed = 0;
   float* colsum = nullptr;
-  int side = 0;  // 1 = may run on the side stream (independent of the next main-stream launch; joined by Ex::join)
+  int side = 0;  // 1 = a weight gradient: collected into the block's grouped launch when the executor defers them
   int nb1 = 1, nb2 = 1; long sA1 = 0, sA2 = 0, sB1 = 0, sB2 = 0, sD1 = 0, sD2 = 0;
 };
 
-// Side stream for weight-gradient GEMMs: a Conformer-block wgrad (split-K, few output tiles) and the data-gradient GEMM that
-// follows it read the same dy and are independent; each alone leaves CUs idle (tile quantisation, prologue / epilogue latency),
-// so the pair is forked onto two streams and joined right after the second launch.  Every later kernel is ordered after both,
-// which keeps the arena lifetimes exactly those of the single-stream schedule.  MEASURED (Conformer-M, batch 32): 37.9 ms/step
-// with the fork/join vs 36.6 ms without - the two barrier packets per pair cost more than the overlap returns - so it is
-// opt-in (TFASR_SIDE_STREAM=1) and off by default.
+// Per-device stream state of the executor: the low-priority stream the grouped weight gradients of a block run on, beside the next
+// block's backward chain (a per-pair fork / join of single weight gradients measured slower - 37.9 vs 36.6 ms per step in round 2 - and is gone).
 struct Side {
-  hipStream_t s2 = nullptr;
-  hipEvent_t fork = nullptr, join = nullptr;
-  bool ok = false;
   // asynchronous grouped weight gradients (tfasr_block_io.wgrad_slot): a stream of their own, per slot the event behind the last
   // launch queued under it
   hipStream_t sw = nullptr;
@@ -101,12 +94,6 @@ Side& side_for_device() {
   Side& sd = sides[dev];
   if (!tried[dev]) {
     tried[dev] = true;
-    const char* e = getenv("TFASR_SIDE_STREAM");
-    if (e && e[0] == '1') {
-      sd.ok = hipStreamCreateWithFlags(&sd.s2, hipStreamNonBlocking) == hipSuccess &&
-              hipEventCreateWithFlags(&sd.fork, hipEventDisableTiming) == hipSuccess &&
-              hipEventCreateWithFlags(&sd.join, hipEventDisableTiming) == hipSuccess;
-    }
   }
   return sd;
 }
@@ -116,7 +103,6 @@ bool wgrad_stream_ready(Side& sd) {
     sd.wtried = true;
     int least = 0, greatest = 0;  // lowest priority: the group only fills what the main chain leaves idle
     if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = 0;
-    if (getenv("TFASR_WGRAD_STREAM_PRIO") && getenv("TFASR_WGRAD_STREAM_PRIO")[0] == '0') least = 0;  // (A/B: default priority)
     sd.wok = hipStreamCreateWithPriority(&sd.sw, hipStreamNonBlocking, least) == hipSuccess &&
              hipEventCreateWithFlags(&sd.wfork, hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&sd.wdone[0], hipEventDisableTiming) == hipSuccess &&
@@ -124,9 +110,6 @@ bool wgrad_stream_ready(Side& sd) {
   }
   return sd.wok;
 }
-// A/B switch of the round-4 launch fusions (BatchNorm finalize + apply, q + u / q + v out of the attention backward):
-// TFASR_BLOCK_FUSE=0 restores the separate launches
-inline bool block_fuse() { static const bool v = !(getenv("TFASR_BLOCK_FUSE") && getenv("TFASR_BLOCK_FUSE")[0] == '0'); return v; }
 
 int wgrad_wait(Side& sd, int slot_mask, hipStream_t s) {
   for (int k = 0; k < 2; ++k)
@@ -145,7 +128,6 @@ struct Ex {
   Arena stash, scratch;
   hipStream_t s;
   Side* side = nullptr;
-  bool forked = false;
   bool dry;
   int st;
   long rows;
@@ -172,11 +154,6 @@ struct Ex {
     float* ws = nullptr;
     long ws_elems = 0;
     const size_t mark = scratch.off;
-    static const bool splitk_ws = getenv("TFASR_SPLITK_WS") && getenv("TFASR_SPLITK_WS")[0] == '1';  // opt-in (not faster, deterministic)
-    if (splitk_ws && g.accumulate && g.split_k > 1 && g.nb1 * g.nb2 == 1) {
-      ws_elems = (long)g.split_k * g.M * g.N;
-      ws = (float*)scratch.get((size_t)ws_elems * 4);
-    }
     scratch.off = mark;
     if (dry) return;
     tfasr_gemm_args a;
@@ -189,14 +166,6 @@ struct Ex {
     a.ws = ws; a.ws_elems = ws ? ws_elems : 0;
     a.colsum = g.colsum;
     if (defer && g.side && !ws) { pending.push_back(a); return; }
-    if (g.side && side && side->ok && !ws) {
-      if (!forked) {
-        if (hipEventRecord(side->fork, s) != hipSuccess || hipStreamWaitEvent(side->s2, side->fork, 0) != hipSuccess) chk(TFASR_STATUS_EXECUTION_FAILED);
-        forked = true;
-      }
-      chk(tfasr_gemm(&a, side->s2));
-      return;
-    }
     chk(tfasr_gemm(&a, s));
   }
   void probe_mark(hipStream_t st_) {
@@ -230,12 +199,6 @@ struct Ex {
     pending.clear();
   }
   void rewind(size_t mark) { if (!defer) scratch.off = mark; }
-  // main stream waits for everything queued on the side stream since the last fork
-  void join() {
-    if (!forked) return;
-    forked = false;
-    if (hipEventRecord(side->join, side->s2) != hipSuccess || hipStreamWaitEvent(s, side->join, 0) != hipSuccess) chk(TFASR_STATUS_EXECUTION_FAILED);
-  }
   // Split-K factor of a block's weight gradient (few 128x128 output tiles, K = B*T rows).  The f32 accumulate costs a flat
   // ~3.1 ns per 1000 atomics (320 G atomics/s, independent of contention or XCD placement: tools/hwprobe/atomic_bench.hip),
   // i.e. every extra k-slice adds M*N atomics, so the sweet spot is ONE workgroup per CU, not two: on [256,1024,12096]
@@ -243,7 +206,7 @@ struct Ex {
   static int split_k(int M, int N, long K) {
     const long tiles = (long)((M + 127) / 128) * ((N + 127) / 128);
     if (tiles >= 256 || K <= 2048) return 1;
-    static const long target = getenv("TFASR_BLOCK_SPLIT_TARGET") ? atol(getenv("TFASR_BLOCK_SPLIT_TARGET")) : 256;
+    const long target = 256;
     long v = target / tiles;
     if (K / 512 < v) v = K / 512;
     if (v >= 8) v = v / 8 * 8;  // whole k-slices per XCD (gemm_fast.hip split-K mapping needs split % 8 == 0)
@@ -263,11 +226,10 @@ struct Ex {
     w.colsum = gp(bi);  // bias gradient in the same launch
     w.side = 1;
     gemm(w);
-    if (!dx) { join(); return; }
+    if (!dx) return;
     G d; d.A = dy; d.lda = dout; d.ta = 0; d.B = wp(wi); d.ldb = dout; d.tb = 1; d.D = dx; d.ldd = din; d.M = (int)rows; d.N = din; d.K = dout;
     d.alpha = alpha; d.dact_z = dact_z; d.dact = dact; d.drop_p = dp; d.drop_seed = dseed;
     gemm(d);
-    join();
   }
   const void* mask_grad(const void* dy, long elems, int site) {
     if (drop_p() <= 0.f) return dy;
@@ -344,57 +306,12 @@ struct Ex {
       G g; g.A = dyd; g.lda = d; g.ta = 0; g.B = wp(b0 + 4); g.ldb = d; g.tb = 1; g.D = dz; g.ldd = F; g.M = (int)rows; g.N = F; g.K = d;
       g.alpha = c->ffm_res; g.dact_z = k->ff_z[m]; g.dact = TFASR_ACT_SWISH; g.drop_p = drop_p(); g.drop_seed = seed(site);
       gemm(g);
-      join();
     }
     void* dln = act(scratch, rows * d);
     dense_bwd(dz, k->ff_ln[m], b0 + 2, b0 + 3, d, F, dln);
     ln_bwd(dln, k->ff_x[m], b0, b0 + 1, k->ff_mean[m], k->ff_rstd[m], dy, dx, dxd, next_site);
     rewind(mark);
   }
-  // shapes / state for which ffm_bwd takes the one-launch data gradient (csrc/ffn_fused_bwd.h)
-  bool ffn_bwd_fused_ok() const {
-    // OPT-IN (TFASR_FFN_FUSED_BWD=1): measured slower than the three launches it replaces (per module 75 vs 68 us on the same box): the kernel
-    // is bound by its vector work (swish' + dropout hash per hidden element, 2 500 issue clocks per 64-column chunk and wave next to 1 000 of
-    // MFMA), 298 64-row tiles leave most CUs with one workgroup and some with two, and nothing overlaps the per-workgroup chain; the two GEMMs
-    // spread the same vector work over 512 evenly loaded workgroups (csrc/ffn_fused_bwd.h, tools/ffn_bwd_timing.sh)
-    static const bool on = getenv("TFASR_FFN_FUSED_BWD") && getenv("TFASR_FFN_FUSED_BWD")[0] == '1';
-    return on && block_fuse() && c->dtype == TFASR_BF16 && c->d == 256 && (c->dff % 64) == 0 && c->dff >= 128 && c->dff <= 1024 && c->save &&
-           rows * (long)c->dff < (1L << 32);
-  }
-  // FFModule backward with the data gradient in one launch: dz, dln and the LayerNorm backward never meet HBM in between; the two weight
-  // gradients (W2' = h^T dyd, W1' = ln^T dz with the bias gradients as column sums) stay with the block's grouped launch
-  bool ffm_bwd_fused(int m, const void* dy, const void* dy_dropped, void* dx, void* dxd, int site, int next_site) {
-    if (!ffn_bwd_fused_ok() || !k->ln_part || k->ln_nsets >= 8 || k->ln_nblk < tfasr_ffn_fused_bwd_tiles(rows)) return false;
-    const int b0 = m == 0 ? TFASR_BP_FF1_LN_G : TFASR_BP_FF2_LN_G;
-    const int d = c->d, F = c->dff;
-    const size_t mark = scratch.off;
-    const void* dyd = masked(dy, dy_dropped, rows * d, site + 1);
-    void* dz = act(scratch, rows * F);
-    {
-      G w; w.A = k->ff_h[m]; w.lda = F; w.ta = 1; w.B = dyd; w.ldb = d; w.tb = 0; w.D = gp(b0 + 4); w.ldd = d; w.M = F; w.N = d; w.K = (int)rows;
-      w.alpha = c->ffm_res; w.out_f32 = 1; w.accumulate = 1; w.split_k = split_k(F, d, rows);
-      w.colsum = gp(b0 + 5);
-      w.side = 1;
-      gemm(w);
-    }
-    if (!dry) {
-      const bool with_drop = dxd && drop_p() > 0.f && next_site >= 0;
-      float* part = k->ln_part + (size_t)k->ln_nsets * k->ln_nblk * 2 * d;
-      const int tiles = tfasr_ffn_fused_bwd_tiles(rows);
-      if (k->ln_nblk > tiles) zero(part + (size_t)tiles * 2 * d, (size_t)(k->ln_nblk - tiles) * 2 * d * 4);  // (slots this producer does not write)
-      const int st = tfasr_ffn_fused_bwd(dyd, k->ff_z[m], wp(b0 + 2), wp(b0 + 4), k->ff_x[m], fp(b0), k->ff_mean[m], k->ff_rstd[m], dy, dz, dx,
-                                         with_drop ? dxd : nullptr, part, rows, d, F, c->ffm_res, drop_p(), seed(site), with_drop ? seed(next_site) : 0,
-                                         c->dtype, s);
-      chk(st);
-      k->ln_dg[k->ln_nsets] = gp(b0);
-      k->ln_db[k->ln_nsets] = gp(b0 + 1);
-      ++k->ln_nsets;
-    }
-    dense_bwd(dz, k->ff_ln[m], b0 + 2, b0 + 3, d, F, nullptr);  // weight + bias gradient of the first projection only
-    rewind(mark);
-    return true;
-  }
-
   // ------------------------------------------------------------------------------------------ MHSAModule
   void mhsa_fwd(const void* x, void* y, int site) {
     const int d = c->d, H = c->H, dh = c->dh, HD = H * dh, T = c->T, B = c->B, R1 = 2 * T;
@@ -469,19 +386,18 @@ struct Ex {
       G g; g.A = dyd; g.lda = d; g.ta = 0; g.B = wp(TFASR_BP_AT_O_W); g.ldb = d; g.tb = 1; g.D = datt; g.ldd = HD; g.M = (int)rows; g.N = HD; g.K = d;
       g.alpha = c->mhsa_res;
       gemm(g);
-      join();
     }
     void* dqkv = act(scratch, rows * 3 * HD);
     bool dq_done = false;
     void* dqu = act(scratch, rows * HD);
     void* dqv = act(scratch, rows * HD);
-    // fused path, default: the skewed score gradient never exists in HBM (attn_fused.hip V2); TFASR_ATTN_DPOS=1 restores the old route
-    static const bool dpos_route = getenv("TFASR_ATTN_DPOS") && getenv("TFASR_ATTN_DPOS")[0] == '1';
-    const bool v2 = k->fused && (!dpos_route || c->chunk_size > 0);  // (the streaming mask lives in the V2 kernels only)
+    // fused path: the skewed score gradient never exists in HBM - the query-side kernel forms dq = dqu + dqv and the u / v bias gradients
+    // itself, stores the UNSKEWED dS, and tfasr_relattn_dpext accumulates the table gradient from it
+    const bool v2 = k->fused;
     void* dpos = act(scratch, v2 ? (long)B * H * T * Tp : (long)B * H * T * R1p);  // v2: the unskewed dS [B,H,T,Tp]
     // caller-owned dS / q + v buffers: they outlive this call and the caller runs tfasr_relattn_dpext itself (on another stream, beside
     // the next block's backward): the table gradient is only needed by the deferred positional-projection gradients
-    const bool dpext_deferred = !dry && v2 && io->defer_pos_grad && io->dpext_zero && io->ds_keep && io->qv_keep && block_fuse();
+    const bool dpext_deferred = !dry && v2 && io->defer_pos_grad && io->dpext_zero && io->ds_keep && io->qv_keep;
     if (dpext_deferred) dpos = io->ds_keep;
     if (!dry && dpext_deferred) k->left |= 1;
     const void* qv;
@@ -497,37 +413,14 @@ struct Ex {
       void* qvb = act(scratch, rows * HD);
       if (dpext_deferred) qvb = io->qv_keep;
       if (!dry) {
-        // the query gradient (dq = dqu + dqv into the q columns of dqkv) and the u / v bias gradients finished inside the kernel;
-        // TFASR_ATTN_Q3=0: separate tfasr_bias2_bwd pass over dqu / dqv
-        static const bool q3_off = getenv("TFASR_ATTN_Q3") && getenv("TFASR_ATTN_Q3")[0] == '0';
-        if (!q3_off) {
-          // (also writes qu / qvb = q + u / q + v for the two kernels below: no tfasr_bias2_fwd launch)
-          chk(tfasr_relattn_fused_bwd_q3(k->at_qkv, fp(TFASR_BP_AT_U), fp(TFASR_BP_AT_V), k->at_pext, io->lengths, k->at_att, datt, k->at_lse, dqkv,
-                                         3L * HD, gp(TFASR_BP_AT_U), gp(TFASR_BP_AT_V), dpos, dvec, dpext, block_fuse() ? qu : nullptr,
-                                         block_fuse() ? qvb : nullptr, B, H, T, dh, Tp, scale, c->use_mask, c->chunk_size, c->history_size, c->dtype, s));
-          if (!block_fuse()) chk(tfasr_bias2_fwd(k->at_qkv, 3 * HD, fp(TFASR_BP_AT_U), fp(TFASR_BP_AT_V), qu, qvb, rows, HD, c->dtype, s));
-          dq_done = true;
-        } else {
-          chk(tfasr_relattn_fused_bwd_q2(k->at_qkv, fp(TFASR_BP_AT_U), fp(TFASR_BP_AT_V), k->at_pext, io->lengths, k->at_att, datt, k->at_lse, dqu,
-                                         dqv, dpos, dvec, dpext, B, H, T, dh, Tp, scale, c->use_mask, c->chunk_size, c->history_size, c->dtype, s));
-          chk(tfasr_bias2_fwd(k->at_qkv, 3 * HD, fp(TFASR_BP_AT_U), fp(TFASR_BP_AT_V), qu, qvb, rows, HD, c->dtype, s));
-        }
+        // (also writes qu / qvb = q + u / q + v for the two kernels below: no tfasr_bias2_fwd launch)
+        chk(tfasr_relattn_fused_bwd_q3(k->at_qkv, fp(TFASR_BP_AT_U), fp(TFASR_BP_AT_V), k->at_pext, io->lengths, k->at_att, datt, k->at_lse, dqkv,
+                                       3L * HD, gp(TFASR_BP_AT_U), gp(TFASR_BP_AT_V), dpos, dvec, dpext, qu, qvb, B, H, T, dh, Tp, scale, c->use_mask,
+                                       c->chunk_size, c->history_size, c->dtype, s));
+        dq_done = true;
         chk(tfasr_relattn_fused_bwd_k(k->at_qkv, qu, qvb, k->at_pext, io->lengths, datt, k->at_lse, dvec, dqkv, B, H, T, dh, scale, c->use_mask,
                                       c->chunk_size, c->history_size, c->dtype, s));
         if (!dpext_deferred) chk(tfasr_relattn_dpext(dpos, qvb, io->lengths, dpext, B, H, T, dh, Tp, c->use_mask, c->dtype, s));
-      }
-      qv = qvb;
-      tail_scale = 1.f;
-    } else if (k->fused) {
-      float* dvec = f32(scratch, (long)B * H * T);
-      void* qu = act(scratch, rows * HD);
-      void* qvb = act(scratch, rows * HD);
-      if (!dry) {
-        chk(tfasr_relattn_fused_bwd_q(k->at_qkv, fp(TFASR_BP_AT_U), fp(TFASR_BP_AT_V), k->at_pext, io->lengths, k->at_att, datt, k->at_lse, dqu,
-                                      dpos, dvec, B, H, T, dh, R1p, scale, c->use_mask, c->dtype, s));
-        chk(tfasr_bias2_fwd(k->at_qkv, 3 * HD, fp(TFASR_BP_AT_U), fp(TFASR_BP_AT_V), qu, qvb, rows, HD, c->dtype, s));
-        chk(tfasr_relattn_fused_bwd_k(k->at_qkv, qu, qvb, k->at_pext, io->lengths, datt, k->at_lse, dvec, dqkv, B, H, T, dh, scale, c->use_mask,
-                                      0, 0, c->dtype, s));
       }
       qv = qvb;
       tail_scale = 1.f;
@@ -636,7 +529,7 @@ struct Ex {
     } else if (!dry) {
       // statistics -> coefficients (+ moving statistics) -> normalise + swish in one launch; UNSUPPORTED (channel counts outside the row
       // kernel) -> the two launches
-      const int fst = !block_fuse() ? TFASR_STATUS_UNSUPPORTED : tfasr_bn_finalize_apply_fwd(k->cv_cv, c->training ? io->bn_stats : nullptr, c->training ? (float)(rows * c->world) : 1.f,
+      const int fst = tfasr_bn_finalize_apply_fwd(k->cv_cv, c->training ? io->bn_stats : nullptr, c->training ? (float)(rows * c->world) : 1.f,
                                                   fp(TFASR_BP_CV_BN_G), fp(TFASR_BP_CV_BN_B), k->cv_fin, P->bn_mm, P->bn_mv, c->bn_momentum, c->bn_eps,
                                                   k->cv_sw, rows, d, TFASR_ACT_SWISH, c->training ? 1 : 0, c->dtype, s);
       if (fst == TFASR_STATUS_UNSUPPORTED) {
@@ -749,10 +642,7 @@ struct Ex {
       k->bw_curd = dr ? act(scratch, rows * d) : nullptr;
       k->bw_nxtd = dr ? act(scratch, rows * d) : nullptr;
       {  // partial-sum buffers of the block's five LayerNorm backward passes (below every module's rewind mark: they live until the fold)
-        static const bool fold_off = getenv("TFASR_LN_FOLD") && getenv("TFASR_LN_FOLD")[0] == '0';
-        int nblk = fold_off ? 0 : tfasr_layernorm_bwd_part_blocks(rows, d, c->dtype);
-        // the fused FFModule backward (tfasr_ffn_fused_bwd) leaves ITS LayerNorm's sums as one slot per 64-row tile in the same buffer
-        if (nblk > 0 && ffn_bwd_fused_ok()) nblk = std::max(nblk, tfasr_ffn_fused_bwd_tiles(rows));
+        int nblk = tfasr_layernorm_bwd_part_blocks(rows, d, c->dtype);
         k->ln_nblk = nblk;
         k->ln_nsets = 0;
         k->ln_part = nblk > 0 ? f32(scratch, (long)8 * nblk * 2 * d) : nullptr;  // up to 8 sets (5 LayerNorms + the LayerNorm variant of the depthwise norm)
@@ -762,7 +652,7 @@ struct Ex {
         if (!dry) k->left = k->ln_ext ? 8 : 0;  // (first statement of a backward that touches it: the other bits are set by the modules)
       }
       ln_bwd(io->dy, k->ln_x, TFASR_BP_LN_G, TFASR_BP_LN_B, k->ln_mean, k->ln_rstd, nullptr, k->bw_cur, k->bw_curd, 5);
-      if (!ffm_bwd_fused(1, k->bw_cur, k->bw_curd, k->bw_nxt, k->bw_nxtd, 4, 3)) ffm_bwd(1, k->bw_cur, k->bw_curd, k->bw_nxt, k->bw_nxtd, 4, 3);
+      ffm_bwd(1, k->bw_cur, k->bw_curd, k->bw_nxt, k->bw_nxtd, 4, 3);
       next_bufs(dr);
       conv_bwd_a(k->bw_cur, k->bw_curd, 3);
       k->scratch_off = scratch.off;
@@ -776,14 +666,13 @@ struct Ex {
       rewind(mark);
       next_bufs(dr);
       mhsa_bwd(k->bw_cur, k->bw_curd, k->bw_nxt, k->bw_nxtd, 2, 1);
-      if (!ffm_bwd_fused(0, k->bw_nxt, k->bw_nxtd, io->dx, nullptr, 0, -1)) ffm_bwd(0, k->bw_nxt, k->bw_nxtd, io->dx, nullptr, 0, -1);
+      ffm_bwd(0, k->bw_nxt, k->bw_nxtd, io->dx, nullptr, 0, -1);
       if (!dry && k->ln_part && k->ln_nsets > 0 && !k->ln_ext) {
         chk(tfasr_layernorm_bwd_fold(k->ln_part, k->ln_nsets, k->ln_nblk, d, k->ln_dg, k->ln_db, s));
         k->ln_nsets = 0;
       }
     }
     flush_wgrads();
-    join();
   }
 };
 
@@ -799,9 +688,7 @@ int check_args(const tfasr_block_cfg* c, const tfasr_block_params* P, const tfas
 void setup(Ex& e, const tfasr_block_cfg* c, const tfasr_block_params* P, const tfasr_block_io* io, void* ctx, void* stream, bool dry) {
   e.c = c; e.P = P; e.io = io; e.k = (Ctx*)ctx; e.s = (hipStream_t)stream; e.dry = dry; e.st = TFASR_STATUS_SUCCESS;
   e.side = dry ? nullptr : &side_for_device();
-  e.forked = false;
-  static const bool group_off = getenv("TFASR_BLOCK_GROUP_WGRAD") && getenv("TFASR_BLOCK_GROUP_WGRAD")[0] == '0';
-  e.defer = !group_off && c->dtype == TFASR_BF16;
+  e.defer = c->dtype == TFASR_BF16;  // the block's Dense weight gradients as ONE grouped launch
   e.rows = (long)c->B * c->T;
   e.esz = c->dtype == TFASR_F32 ? 4 : 2;
   e.stash = Arena{dry ? nullptr : (char*)io->stash, 0, dry ? 0 : io->stash_bytes, true, 0};

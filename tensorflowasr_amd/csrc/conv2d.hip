@@ -705,7 +705,7 @@ static int conv1_bn_launch(const void* x, const float* w, const float* bias, con
   const size_t smem_q = (size_t)(3 * (F0 + 2) + NQL * C) * sizeof(float);
   // backward passes: every block walks ~B*T1/grid rows, so the grid is exactly ONE round of resident blocks (occupancy x CUs, asked once per
   // instantiation and LDS size): 1024 blocks on 768 slots were a full round plus a third of one.  TFASR_CONV1_GRID overrides (A/B).
-  static const int env_grid = getenv("TFASR_CONV1_GRID") ? atoi(getenv("TFASR_CONV1_GRID")) : 0;
+  static const int env_grid = 0;
   static int res_blocks[2] = {0, 0};
   static size_t res_smem[2] = {0, 0};
   const int di = dtype == TFASR_F32 ? 0 : 1;

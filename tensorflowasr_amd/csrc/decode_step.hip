@@ -633,7 +633,7 @@ extern "C" int tfasr_decode_step(const float* emb, const float* lstm_k, const fl
   if ((P % 4) || (J % 4) || (V % 8) || (((uintptr_t)lstm_k | (uintptr_t)lstm_rk | (uintptr_t)joint_pred_w | (uintptr_t)vocab_w) & 15))
     return TFASR_STATUS_UNSUPPORTED;  // float4 weight loads
   hipStream_t s = (hipStream_t)stream_;
-  static const bool mfma_off = getenv("TFASR_DECODE_MFMA") && getenv("TFASR_DECODE_MFMA")[0] == '0';  // A/B probe: the vector-ALU kernels
+  static const bool mfma_off = false;  // A/B probe: the vector-ALU kernels
   if (packed && !mfma_off && mfma_shapes(E, P, J) && ((((uintptr_t)h | (uintptr_t)h_new | (uintptr_t)z | (uintptr_t)packed) & 15) == 0)) {
     const int mt = (B + 15) / 16;
 #define TFASR_DM(M) return launch_decode_mfma<M>(packed, lstm_b, ln_g, ln_b, joint_pred_b, vocab_b, encj, nframes, frame_idx, tok_idx, prev_tok, h, c, \
@@ -675,7 +675,7 @@ extern "C" int tfasr_decode_steps(const float* emb, const float* lstm_k, const f
     if (st != TFASR_STATUS_SUCCESS) return st;
   }
 #ifdef TFASR_DECODE_TIMING
-  if (getenv("TFASR_DECODE_DBG_DUMP")) {
+  {  // probe build (-DTFASR_DECODE_TIMING): always dumps
     long long h[4][16];
     if (hipStreamSynchronize((hipStream_t)stream_) == hipSuccess && hipMemcpyFromSymbol(h, HIP_SYMBOL(g_dec_t), sizeof(h)) == hipSuccess) {
       for (int k = 0; k < 3; ++k) {

@@ -381,7 +381,7 @@ int tfasr_dwconv_pair_try(int which, const void* x, const void* dy, const float*
   }
   // weight gradient: measured slower than the scalar kernel (100 us vs 45 us at B=32,T=744,C=256) because the per-block f32 atomics
   // (K x C per 64 steps) dominate; opt-in until it reduces through a workspace instead.
-  static const bool wgrad_tile = getenv("TFASR_DWCONV_WGRAD_TILE") != nullptr;
+  static const bool wgrad_tile = false;
   if (!wgrad_tile || !al16(x) || !al16(dy)) return TFASR_STATUS_UNSUPPORTED;
   dim3 grid(gx, (T + 2 * TG - 1) / (2 * TG), B);
   const int smem = (2 * TG + MAXK - 1 + 2 * TG) * ROWB;

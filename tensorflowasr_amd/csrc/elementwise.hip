@@ -670,8 +670,8 @@ extern "C" int tfasr_colsum(const void* x, long ld, float* out, long rows, int C
   hipStream_t s = (hipStream_t)stream_;
   if (dtype == TFASR_BF16 && (C % 8) == 0 && (ld % 8) == 0 && ((((uintptr_t)x) & 15) == 0)) {
     const int cb = (C + 255) / 256;
-    static const int thr = getenv("TFASR_RED_THREADS") ? atoi(getenv("TFASR_RED_THREADS")) : 512;
-    static const int cap = getenv("TFASR_RED_GRID") ? atoi(getenv("TFASR_RED_GRID")) : 192;
+    static const int thr = 512;
+    static const int cap = 192;
     dim3 gridv((int)std::max<long>(1, std::min<long>(rows / (thr / 8) + 1, std::max(32, cap / cb))), cb);
     hipLaunchKernelGGL(colsum_vec_kernel<bf16_t>, gridv, dim3(thr), 0, s, (const bf16_t*)x, ld, out, rows, C, scale);
     TFASR_CHECK_LAUNCH();
@@ -832,8 +832,8 @@ extern "C" int tfasr_bias2_bwd(const void* d1, const void* d2, void* dx, long ld
   hipStream_t s = (hipStream_t)stream_;
   auto al = [](const void* p) { return (((uintptr_t)p) & 15) == 0; };
   if (dtype == TFASR_BF16 && (C % 8) == 0 && (lddx % 8) == 0 && al(d1) && al(d2) && al(dx)) {
-    static const int thr = getenv("TFASR_RED_THREADS") ? atoi(getenv("TFASR_RED_THREADS")) : 512;
-    static const int cap = getenv("TFASR_RED_GRID") ? atoi(getenv("TFASR_RED_GRID")) : 192;
+    static const int thr = 512;
+    static const int cap = 192;
     dim3 gridv((int)std::max<long>(1, std::min<long>(rows / (thr / 8) + 1, cap)), (C + 255) / 256);
     hipLaunchKernelGGL(bias2_bwd_vec_kernel, gridv, dim3(thr), 0, s, (const bf16_t*)d1, (const bf16_t*)d2, (bf16_t*)dx, lddx, du, dv, rows, C);
     TFASR_CHECK_LAUNCH();

@@ -398,7 +398,7 @@ __global__ __launch_bounds__(256, WGS) void ffn_fused_fwd_kernel(const FfnArgs p
 // Variant for a launch.  One workgroup per CU with 96-row tiles (MR 3, double-buffered weights) or two per CU with 64-row tiles (WGS 2).
 static int launch_ffn_fused_fwd(const FfnArgs& a, hipStream_t stream) {
   // 1: MR 3 x 1 WG/CU, 2: MR 2 x 2 WG/CU, 3: MR 2 x 1, 4: MR 1 x 2 WG/CU (32-row tiles); 0 / unset: by tile count (below)
-  static const int forced = getenv("TFASR_FFN_VARIANT") ? atoi(getenv("TFASR_FFN_VARIANT")) : 0;
+  static const int forced = 0;
   static int ncu = 0;
   if (ncu == 0) {
     int dev = 0, v = 0;

@@ -361,7 +361,7 @@ int launch(const tfasr_gemm_args& a, hipStream_t stream) {
   dim3 block(256);
   if constexpr (sizeof(T) == 4) {
     // f32: 128 x 64 tiles while the 128-wide tiling leaves CUs without a workgroup of their own (TFASR_GEMM_F32_NARROW=0: never)
-    static const bool narrow_off = getenv("TFASR_GEMM_F32_NARROW") && getenv("TFASR_GEMM_F32_NARROW")[0] == '0';
+    static const bool narrow_off = false;
     static int ncu = 0;
     if (ncu == 0) {
       int dev = 0, v = 0;
@@ -397,7 +397,7 @@ int tfasr_gemm_fast_try(const tfasr_gemm_args& a, hipStream_t stream);  // gemm_
 
 static bool use_fast_path() {
   static int v = -1;
-  if (v < 0) { const char* e = getenv("TFASR_GEMM_SLOW"); v = (e && e[0] == '1') ? 0 : 1; }
+  if (v < 0) v = 1;
   return v == 1;
 }
 
@@ -405,7 +405,7 @@ int tfasr_gemm_group_fast_try(const tfasr_gemm_args* a, int n, hipStream_t strea
 
 extern "C" int tfasr_gemm_group(const tfasr_gemm_args* args, int n, void* stream_) {
   if (!args || n <= 0) return TFASR_STATUS_INVALID_VALUE;
-  static const bool off = getenv("TFASR_GEMM_GROUP") && getenv("TFASR_GEMM_GROUP")[0] == '0';
+  static const bool off = false;
   int i = 0;
   while (i < n) {
     const int m = n - i < 10 ? n - i : 10;

@@ -744,7 +744,7 @@ int g_gemm_big_mode = -1;  // probes / tests: 0 = never, 1 = default rule; -1 = 
 // eligibility + launch; UNSUPPORTED -> the caller continues with the 128-row tiles
 template <bool TB>
 int launch_big(const tfasr_gemm_args& a, bool generic, int need, bool tanh_out, hipStream_t stream) {
-  static const bool env_off = getenv("TFASR_GEMM_BIG") && getenv("TFASR_GEMM_BIG")[0] == '0';
+  static const bool env_off = false;
   const bool off = g_gemm_big_mode < 0 ? env_off : g_gemm_big_mode == 0;
   if (off || generic || need != 0 || a.accumulate || a.split_k > 1 || a.nb1 * a.nb2 != 1 || a.colsum || a.out_f32 || a.K < 2 * BK || (a.K & 7) || a.M < 256 || (TB && (a.N & 7))) return TFASR_STATUS_UNSUPPORTED;
   const bool seg = a.seg_a_off != nullptr;
@@ -757,7 +757,7 @@ int launch_big(const tfasr_gemm_args& a, bool generic, int need, bool tanh_out, 
   if (!bn) return TFASR_STATUS_UNSUPPORTED;
   const int gx = (a.N + bn - 1) / bn, gy = (a.M + 255) / 256;
   const long ntiles = (long)gx * gy;
-  static const long min_tiles = getenv("TFASR_GEMM_BIG_T") ? atol(getenv("TFASR_GEMM_BIG_T")) : 2L * num_cus();
+  static const long min_tiles = 2L * num_cus();
   if (ntiles < min_tiles || ntiles > 0x7fffffffL) return TFASR_STATUS_UNSUPPORTED;
   if (tanh_out && (!TB || seg || a.lse_part)) return TFASR_STATUS_UNSUPPORTED;
   if (a.lse_part && !(a.row_label && a.pick && bn == 256 && a.lse_parts == ((a.N + 127) / 128) * 2)) return TFASR_STATUS_UNSUPPORTED;
@@ -774,7 +774,7 @@ int launch_big(const tfasr_gemm_args& a, bool generic, int need, bool tanh_out, 
   constexpr int S320 = 2 * (256 * BK * 2 + 320 * BK * 2);
   // transposed accumulators (the kernel's TR parameter; 16-byte stores straight from the accumulators): every variant whose output rows
   // allow them (ldd % 8 == 0, N % 8 == 0, 16-byte aligned D); TFASR_BIG_TR=0 restores the row-oriented epilogues (A/B)
-  static const bool tr_on = !(getenv("TFASR_BIG_TR") && getenv("TFASR_BIG_TR")[0] == '0');
+  static const bool tr_on = !(false);
   const bool tr = tr_on && (a.ldd & 7) == 0 && (a.N & 7) == 0 && (((uintptr_t)a.D) & 15) == 0;
   if (tanh_out) {
     if constexpr (TB) {

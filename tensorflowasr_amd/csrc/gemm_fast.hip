@@ -850,171 +850,6 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 
 int num_cus();
 
-// ---------------------------------------------------------------------------------------------------------------------
-// Small-output weight gradient: D[M,N] (f32) += alpha * A^T B over K = rows, A stored [K, M], B stored [K, N], few output tiles.
-// The f32 accumulate costs a flat ~3.1 us per million atomics (tools/hwprobe/atomic_bench.hip), i.e. `workgroups x tile area`,
-// while filling the chip needs ~one workgroup per CU - so the only way to pay fewer atomics at full occupancy is to reduce
-// INSIDE the CU first.  One 8-wave workgroup per (128x64 tile, k-slice): its two 4-wave groups run the 2-stage LDS-DMA
-// pipeline of gemm_fast_kernel on the two halves of the slice (they overlap each other's DMA-issue stalls like two resident
-// workgroups would), then group 1 hands its accumulators to group 0 through LDS and group 0 alone issues the atomics:
-// half the atomics of two independent 128x64 workgroups per CU, a quarter of the 128x128 split-K kernel at one per CU.
-// A partial last slab (K % 64) is DMA'd from clamped rows and its invalid k-rows of the B image are zeroed in LDS.
-template <bool CS>
-__global__ __launch_bounds__(512, 1) void wgrad_kg2_kernel(const tfasr_gemm_args p, const int gx, const int gy, const int split) {
-  constexpr int BN_ = 64, NJ = 2, WN = 32;
-  constexpr int B_BYTES = BN_ * BK * 2;
-  constexpr int STAGE_BYTES = A_BYTES + B_BYTES;      // 24 KiB
-  constexpr int GROUP_BYTES = 2 * STAGE_BYTES;        // 48 KiB per wave group
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int grp = w >> 2, w4 = w & 3, wm = w4 >> 1, wn = w4 & 1;
-  const int r = lane & 15, g = lane >> 4;
-  const int t256 = threadIdx.x & 255;
-  char* gmem = smem + grp * GROUP_BYTES;
-
-  // (tile, k-slice) of this workgroup; with split % 8 == 0 a whole k-slice (all its tiles re-read the same rows) stays on one XCD
-  const int tpp = gx * gy;
-  int ks, t;
-  if ((split & 7) == 0 && (gridDim.x & 7) == 0) { const int x = blockIdx.x & 7, j = blockIdx.x >> 3; ks = x + 8 * (j / tpp); t = j % tpp; }
-  else { ks = blockIdx.x / tpp; t = blockIdx.x % tpp; }
-  const int m0 = (t / gx) * BM, n0 = (t % gx) * BN_;
-  int kchunk = (p.K + split - 1) / split;
-  kchunk = ((kchunk + BK - 1) / BK) * BK;
-  const int k_begin = ks * kchunk, k_end = min(p.K, k_begin + kchunk);
-  const int len = max(k_end - k_begin, 0);
-  const int nsl = (len + BK - 1) / BK;                // slabs of this workgroup (the last one may be partial)
-  if (nsl == 0) return;                               // uniform over the workgroup
-  const int kv_last = len - (nsl - 1) * BK;           // valid k-rows of the last slab (64 = full)
-  const int n_g0 = (nsl + 1) >> 1;                    // group 0: slabs [0, n_g0), group 1: [n_g0, nsl)
-  const int base = grp ? n_g0 : 0, n_g = grp ? nsl - n_g0 : n_g0;
-  const int part_grp = nsl >= 2 ? 1 : 0, part_idx = (nsl >= 2 ? nsl - n_g0 : n_g0) - 1;  // owner / local index of the last slab
-  const bool has_part = kv_last < BK;
-
-  const bf16_t* A = (const bf16_t*)p.A;
-  const bf16_t* B = (const bf16_t*)p.B;
-  const bf16_t* sa[4];
-  const bf16_t* sb[2];
-  prep_trans<128>(sa, A, p.lda, m0, p.M, k_begin + base * BK, w4, lane);
-  prep_trans<BN_>(sb, B, p.ldb, n0, p.N, k_begin + base * BK, w4, lane);
-  const long stepA = (long)BK * p.lda, stepB = (long)BK * p.ldb;
-  auto issue = [&](int s, int stage) {  // group-local slab s
-    char* sA = gmem + stage * STAGE_BYTES;
-    char* sB = sA + A_BYTES;
-    if (has_part && grp == part_grp && s == part_idx) {
-      // partial slab: k-rows past the end are fetched from the last valid row (finite data), then zeroed in LDS
-      const int kt = k_begin + (base + s) * BK, kmax = p.K - 1;
-      const int maxa = ((p.M + 7) >> 3) - 1, maxb = ((p.N + 7) >> 3) - 1;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int q = w4 * 4 + i, k = q * 4 + lane / 16, c = min((m0 >> 3) + ((lane % 16) ^ key_t(k)), maxa);
-        __builtin_amdgcn_global_load_lds(GLB_PTR(A + (long)min(kt + k, kmax) * p.lda + ((long)c << 3)), LDS_PTR(sA + __builtin_amdgcn_readfirstlane(q * 1024)), 16, 0, 0);
-      }
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int q = w4 * 2 + i, k = q * 8 + lane / 8, c = min((n0 >> 3) + ((lane % 8) ^ key_t64(k)), maxb);
-        __builtin_amdgcn_global_load_lds(GLB_PTR(B + (long)min(kt + k, kmax) * p.ldb + ((long)c << 3)), LDS_PTR(sB + __builtin_amdgcn_readfirstlane(q * 1024)), 16, 0, 0);
-      }
-    } else {
-      issue_from<128>(sA, sa, s * stepA, w4);
-      issue_from<BN_>(sB, sb, s * stepB, w4);
-    }
-  };
-
-  float4_t acc[4][NJ];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) acc[i][j] = float4_t{0.f, 0.f, 0.f, 0.f};
-  float4_t accb[NJ];
-#pragma unroll
-  for (int j = 0; j < NJ; ++j) accb[j] = float4_t{0.f, 0.f, 0.f, 0.f};
-  const bool do_cs = CS && p.colsum && m0 == 0 && wm == 0;
-
-  if (n_g > 0) issue(0, 0);
-  if (n_g > 1) issue(1, 1);
-  // both groups run n_g0 iterations (group 1 may idle through the last one): the barriers are workgroup-wide
-  for (int s = 0; s < n_g0; ++s) {
-    const int stage = s & 1;
-    const bool active = s < n_g;
-    if (active) {
-      if (s + 1 < n_g) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier();
-    if (has_part && s == part_idx) {  // uniform: every wave takes this branch in the same iteration
-      if (grp == part_grp) {
-        char* sB = gmem + stage * STAGE_BYTES + A_BYTES;
-        for (int c = t256; c < (BK - kv_last) * 8; c += 256) *reinterpret_cast<uint4*>(sB + kv_last * 128 + c * 16) = make_uint4(0, 0, 0, 0);
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-    }
-    if (active) mma_slab<true, false, BN_, CS>(gmem + stage * STAGE_BYTES, gmem + stage * STAGE_BYTES + A_BYTES, wm, wn, lane, acc, accb, do_cs);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (active && s + 2 < n_g) issue(s + 2, stage);
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-
-  // ---- reduce group 1 into group 0 through LDS (element-major layout: consecutive lanes, consecutive dwords) ----
-  float* red = reinterpret_cast<float*>(smem + GROUP_BYTES);  // group 1's own (now idle) stages: 40 x 256 floats = 40 KiB <= 48 KiB
-  if (grp == 1) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < NJ; ++j)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) red[((i * NJ + j) * 4 + e) * 256 + t256] = acc[i][j][e];
-    if constexpr (CS) {
-#pragma unroll
-      for (int j = 0; j < NJ; ++j)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) red[(32 + j * 4 + e) * 256 + t256] = accb[j][e];
-    }
-  }
-  __syncthreads();
-  if (grp == 1) return;
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < NJ; ++j)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) acc[i][j][e] += red[((i * NJ + j) * 4 + e) * 256 + t256];
-  if constexpr (CS) {
-#pragma unroll
-    for (int j = 0; j < NJ; ++j)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) accb[j][e] += red[(32 + j * 4 + e) * 256 + t256];
-    if (do_cs && g == 0) {
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        const int col = n0 + wn * WN + j * 16 + r;
-        if (col < p.N) atomicAdd(p.colsum + col, p.alpha * accb[j][0]);
-      }
-    }
-  }
-  float* Df = (float*)p.D;
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-      const int col = n0 + wn * WN + j * 16 + r;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int row = m0 + wm * 64 + i * 16 + g * 4 + e;
-        if (col < p.N && row < p.M) atomicAdd(Df + (long)row * p.ldd + col, p.alpha * acc[i][j][e]);
-      }
-    }
-}
-
-// the k-split this kernel wants: one workgroup per CU, at least two slabs per workgroup
-inline int wgrad_kg2_split(long tiles64, int K) {
-  long v = num_cus() / tiles64;
-  if (K / 128 < v) v = K / 128;
-  if (v >= 8) v = v / 8 * 8;
-  return (int)(v < 1 ? 1 : v);
-}
-
 int num_cus() {
   static int n = 0;
   if (n == 0) {
@@ -1029,12 +864,12 @@ template <bool TA, bool TB, int BN_, int EPI>
 int launch_epi(const tfasr_gemm_args& a, dim3 tiles, hipStream_t stream) {
   const long ntiles = (long)tiles.x * tiles.y * tiles.z;
   // 2 resident workgroups per CU; TFASR_GEMM_SLOTS=1 is an experiment hook: one persistent workgroup per CU walking more tiles
-  static const int per_cu = getenv("TFASR_GEMM_SLOTS") && getenv("TFASR_GEMM_SLOTS")[0] == '1' ? 1 : 2;
+  static const int per_cu = 2;
   const int slots = per_cu * num_cus();
   if constexpr (BN_ == 64 && (EPI & (E_WS | E_CSUM | E_LSE)) == 0) {
     // every tile its own workgroup, three per CU, when the tile list fits three per CU at once (TFASR_GEMM_ONE=0: the persistent kernel)
-    static const bool one_off = getenv("TFASR_GEMM_ONE") && getenv("TFASR_GEMM_ONE")[0] == '0';
-    static const long one_max = getenv("TFASR_GEMM_ONE_MAX") ? atol(getenv("TFASR_GEMM_ONE_MAX")) : (1L << 30);  // probe: upper bound in tiles per CU
+    static const bool one_off = false;
+    static const long one_max = (1L << 30);  // probe: upper bound in tiles per CU
     if (!one_off && a.split_k <= 1 && ntiles > slots && ntiles <= one_max * num_cus()) {
       constexpr int SMEM1 = 2 * (A_BYTES + 64 * BK * 2);
       hipLaunchKernelGGL((gemm_fast_one_kernel<TA, TB, EPI>), dim3((unsigned)ntiles), dim3(256), SMEM1, stream, a, (int)tiles.x, (int)tiles.y, (int)tiles.z, (int)ntiles);
@@ -1052,7 +887,6 @@ int launch_epi(const tfasr_gemm_args& a, dim3 tiles, hipStream_t stream) {
 
 #include "gemm_big.h"
 #include "ffn_fused.h"
-#include "ffn_fused_bwd.h"
 
 template <bool TA, bool TB>
 int launch_one(const tfasr_gemm_args& a, hipStream_t stream) {
@@ -1061,14 +895,14 @@ int launch_one(const tfasr_gemm_args& a, hipStream_t stream) {
   // would leave at most one workgroup per CU (the N = 256 Dense layers of a Conformer block: 190 tiles): with a single resident
   // workgroup the DMA issue, the fragment reads and the MFMAs of a slab serialise (1530 cycles / slab measured); two 128x64
   // workgroups per CU overlap them (14.2 vs 16.9 us on [12096,256,1024]).  TFASR_GEMM_BN64=0 restores the old rule.
-  static const bool bn64_off = getenv("TFASR_GEMM_BN64") && getenv("TFASR_GEMM_BN64")[0] == '0';
+  static const bool bn64_off = false;
   const long t128 = (long)((a.N + 127) / 128) * ((a.M + BM - 1) / BM) * a.nb1 * a.nb2 * split;
   // Round 4: every product the one-tile kernel takes (no split-K, no accumulation / column sums; see bn64_lim below) runs as 64-column tiles, ONE per workgroup,
   // three workgroups per CU (gemm_fast_one_kernel), whatever its size: 744 128-wide tiles on 512 persistent slots are two rounds with half
   // the chip idle in the second, 1 488 narrow tiles on 768 dynamic slots are 1.94.  Same-box A/B: [rows,256]x[256,768|512] 17.8 -> 17.0 us,
   // the FFN data gradient with its swish' + dropout epilogue 38.6 -> 34.3, N = 256 products 17.0 -> 16.3 / 16.2 -> 13.0; M 23.23 -> 23.01 ms/step,
   // S 12.17 -> 12.01.  TFASR_GEMM_BN64_T=<128-wide tiles> restores a threshold (256 = round 3's rule).
-  static const long bn64_thr = getenv("TFASR_GEMM_BN64_T") ? atol(getenv("TFASR_GEMM_BN64_T")) : (1L << 40);
+  static const long bn64_thr = (1L << 40);
   // (above 1 x CUs only products the one-tile kernel takes)
   // ... and with K <= 256 or N <= 256 (the Conformer's d = 256 layers: four slabs per tile, or two 128-wide column tiles).  With both >= 512
   // (ContextNet's 512 - 1280-channel layers) the 128-wide persistent kernel amortises a tile better (cross-tile prefetch, half the operand
@@ -1105,24 +939,6 @@ int launch_one(const tfasr_gemm_args& a, hipStream_t stream) {
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rg), dim3(256), 0, stream, (const float*)a.ws, (float*)a.D, a.M, a.N, a.ldd, split);
     TFASR_CHECK_LAUNCH();
     return TFASR_STATUS_SUCCESS;
-  }
-  if constexpr (TA && !TB) {
-    // small-output weight gradients: reduce the k-slices inside the CU before the atomics (wgrad_kg2_kernel).  OPT-IN
-    // (TFASR_GEMM_KG2=1, read per call so that tests can switch it): in isolation it wins (FFN layer 22.4 -> 18.6 us, L2-warm
-    // operands), inside the train step it lost 0.26 ms (36.45 vs 36.19 ms/step on the same box) - one 8-wave workgroup per CU
-    // with two 2-stage pipelines hides the HBM-cold operand latency worse than two independent 128x64 workgroups do.
-    const char* kg2_env = getenv("TFASR_GEMM_KG2");
-    const bool kg2_on = kg2_env && kg2_env[0] == '1';
-    const long tiles64 = (long)((a.N + 63) / 64) * ((a.M + BM - 1) / BM);
-    if (kg2_on && a.accumulate && a.out_f32 && !a.ws && !a.bias && a.nb1 * a.nb2 == 1 && split > 1 && tiles64 <= 128 && a.N > 64) {
-      const int ks = wgrad_kg2_split(tiles64, a.K);
-      const int gxx = (a.N + 63) / 64, gyy = (a.M + BM - 1) / BM;
-      constexpr int SMEM = 4 * (A_BYTES + 64 * BK * 2);
-      if (a.colsum) hipLaunchKernelGGL(wgrad_kg2_kernel<true>, dim3(gxx * gyy * ks), dim3(512), SMEM, stream, a, gxx, gyy, ks);
-      else hipLaunchKernelGGL(wgrad_kg2_kernel<false>, dim3(gxx * gyy * ks), dim3(512), SMEM, stream, a, gxx, gyy, ks);
-      TFASR_CHECK_LAUNCH();
-      return TFASR_STATUS_SUCCESS;
-    }
   }
   if (a.colsum) {
     if constexpr (TA && !TB) {
@@ -1212,7 +1028,7 @@ int tfasr_gemm_group_fast_try(const tfasr_gemm_args* a, int n, hipStream_t strea
   GroupArgs ga;
   memset(&ga, 0, sizeof(ga));
   long total = 0;
-  static const int bn = getenv("TFASR_GROUP_BN") ? atoi(getenv("TFASR_GROUP_BN")) : 128;
+  static const int bn = 128;
   for (int i = 0; i < n; ++i) {
     ga.gx[i] = (a[i].N + bn - 1) / bn;
     ga.gy[i] = (a[i].M + BM - 1) / BM;
@@ -1224,14 +1040,14 @@ int tfasr_gemm_group_fast_try(const tfasr_gemm_args* a, int n, hipStream_t strea
   // A group of LONG products in line (the nine shifted conv2 weight gradients: K = B T2 F2 = 500 k rows, 36 tiles) also wants about one
   // workgroup per CU: with 512 slots its 14 k-slices per tile were 8 M atomics and the slices' workgroups drifted apart in L2 - 256 / 320
   // slots for every group of the step: -0.28 / -0.33 ms per step against 512, of which the block groups beside the chain are 0.04.
-  static const long env_slots = getenv("TFASR_GROUP_SLOTS") ? atol(getenv("TFASR_GROUP_SLOTS")) : 0;
+  static const long env_slots = 0;
   long kmax = 0;
   for (int i = 0; i < n; ++i) kmax = a[i].K > kmax ? a[i].K : kmax;
   const long slots = env_slots > 0 ? env_slots : ((g_tfasr_group_beside || kmax >= 131072) ? num_cus() * 5L / 4 : 2L * num_cus());
   long split = slots / (total > 0 ? total : 1);
   if (split < 1) split = 1;
   {
-    static const bool dbg = getenv("TFASR_DEBUG_GROUP") != nullptr;
+    static const bool dbg = false;
     static int dbg_n = 0;
     if (dbg && dbg_n < 6) { fprintf(stderr, "[group] n %d tiles %ld beside %d slots %ld split %ld\n", n, total, g_tfasr_group_beside, slots, split); ++dbg_n; }
   }
@@ -1272,7 +1088,7 @@ int tfasr_gemm_group_fast_try(const tfasr_gemm_args* a, int n, hipStream_t strea
   int maxload = 0;
   for (int x = 0; x < 8; ++x)
     if (load[x] > maxload) maxload = load[x];
-  static const int nst = getenv("TFASR_GROUP_NST") ? atoi(getenv("TFASR_GROUP_NST")) : 2;
+  static const int nst = 2;
   // accumulate epilogue: atomics from the fragments, no strips in LDS
   if (bn == 64) {
     constexpr int STAGE = A_BYTES + 64 * BK * 2;
@@ -1300,41 +1116,6 @@ int tfasr_gemm_fast_try(const tfasr_gemm_args& a, hipStream_t stream) {
 
 // ---------------------------------------------------------------------------------------------------------------------
 // FFModule forward in one launch (ffn_fused.h).  UNSUPPORTED outside its shape range: the caller keeps the three-launch route.
-extern "C" int tfasr_ffn_fused_bwd_tiles(long rows) { return rows > 0 ? (int)((rows + 63) / 64) : 0; }
-
-extern "C" int tfasr_ffn_fused_bwd(const void* dyd, const void* z, const void* W1, const void* W2, const void* x, const float* gamma, const float* mean,
-                                   const float* rstd, const void* add, void* dz, void* dx, void* dx_dropped, float* part, long rows, int d, int F,
-                                   float res_factor, float drop_p, long drop_seed1, long drop_seed_next, int dtype, void* stream) {
-  if (!dyd || !z || !W1 || !W2 || !x || !gamma || !mean || !rstd || !dz || !dx || !part || rows <= 0 || d <= 0 || F <= 0) return TFASR_STATUS_INVALID_VALUE;
-  if (!(drop_p >= 0.f && drop_p < 1.f)) return TFASR_STATUS_INVALID_VALUE;
-  if (dtype != TFASR_BF16 || d != 256 || (F % 64) != 0 || F > 1024 || F < 128 || rows * (long)F >= (1L << 32)) return TFASR_STATUS_UNSUPPORTED;
-  const uintptr_t al = (uintptr_t)dyd | (uintptr_t)z | (uintptr_t)W1 | (uintptr_t)W2 | (uintptr_t)x | (uintptr_t)add | (uintptr_t)dz | (uintptr_t)dx |
-                       (uintptr_t)dx_dropped | (uintptr_t)gamma;
-  if (al & 15) return TFASR_STATUS_UNSUPPORTED;
-  FfnBwdArgs a;
-  a.dyd = (const bf16_t*)dyd; a.z = (const bf16_t*)z; a.W1 = (const bf16_t*)W1; a.W2 = (const bf16_t*)W2; a.x = (const bf16_t*)x;
-  a.gamma = gamma; a.mean = mean; a.rstd = rstd; a.add = (const bf16_t*)add;
-  a.dz = (bf16_t*)dz; a.dx = (bf16_t*)dx; a.dxd = (bf16_t*)dx_dropped; a.part = part;
-  a.rows = rows; a.F = F; a.res = res_factor; a.drop_p = drop_p; a.seed1 = drop_seed1; a.seed_next = drop_seed_next;
-  a.dbg = nullptr;
-#ifdef TFASR_FFN_TIMING
-  static long long* dbg_buf = nullptr;  // probe builds only (tools/hwprobe)
-  if (!dbg_buf && hipMalloc((void**)&dbg_buf, 64) != hipSuccess) dbg_buf = nullptr;
-  a.dbg = dbg_buf;
-#endif
-  const int st = launch_ffn_fused_bwd(a, (hipStream_t)stream);
-#ifdef TFASR_FFN_TIMING
-  if (getenv("TFASR_FFN_DBG_DUMP") && dbg_buf) {
-    long long h[8];
-    if (hipStreamSynchronize((hipStream_t)stream) == hipSuccess && hipMemcpy(h, dbg_buf, 64, hipMemcpyDeviceToHost) == hipSuccess)
-      fprintf(stderr, "[ffn_bwd_timing] prologue %lld | sums over the chunks: wait+barrier T %lld gemm1 %lld dz tile %lld barrier A + issue + dz store %lld wait+barrier B %lld gemm2 %lld | epilogue %lld\n",
-              h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
-  }
-#endif
-  TFASR_CHECK_LAUNCH();
-  return st;
-}
-
 extern "C" int tfasr_ffn_fused_fwd(const void* x, const float* gamma, const float* beta, const void* W1, const float* b1, const void* W2,
                                    const float* b2, void* y, void* ln, float* mean, float* rstd, void* z, void* h, long rows, int d, int F,
                                    float ln_eps, float res_factor, float drop_p, long drop_seed1, long drop_seed2, int dtype, void* stream) {
@@ -1356,7 +1137,7 @@ extern "C" int tfasr_ffn_fused_fwd(const void* x, const float* gamma, const floa
 #endif
   const int st = launch_ffn_fused_fwd(a, (hipStream_t)stream);
 #ifdef TFASR_FFN_TIMING
-  if (getenv("TFASR_FFN_DBG_DUMP") && dbg_buf) {
+  if (dbg_buf) {  // probe build (-DTFASR_FFN_TIMING): always dumps
     long long h[8];
     if (hipStreamSynchronize((hipStream_t)stream) == hipSuccess && hipMemcpy(h, dbg_buf, 64, hipMemcpyDeviceToHost) == hipSuccess)
       fprintf(stderr, "[ffn_timing] prologue %lld | per-kernel sums: wait+barrier %lld dma-issue %lld gemm1 %lld z->lds %lld rowpass %lld gemm2 %lld | epilogue %lld\n",

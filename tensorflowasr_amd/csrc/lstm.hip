@@ -174,7 +174,7 @@ extern "C" int tfasr_lstm_set_persist(int mode) {
 // whole SIMD to drain - 21 / 25 us per launch under the profiler for ~3 us of work - while the pair's small kernels slip into what the
 // encoder leaves free.  Worth it only with a step body of <= 64 registers and no LDS (gate exchange by DPP inside a quad): not built.
 static bool fused_step_enabled() {
-  static const bool v = getenv("TFASR_LSTM_FUSED_STEP") && getenv("TFASR_LSTM_FUSED_STEP")[0] == '1';
+  static const bool v = false;
   return v;
 }
 

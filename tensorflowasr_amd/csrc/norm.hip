@@ -603,8 +603,8 @@ __global__ __launch_bounds__(512) void bn_stats_vec_kernel(const T* __restrict__
 }
 
 // launch shape of the fat row-reduction kernels: 1024 threads, <= 128 blocks, >= 2 row-pairs per wave
-inline int red_threads() { static int v = 0; if (!v) { const char* e = getenv("TFASR_RED_THREADS"); v = e ? atoi(e) : 512; } return v; }
-inline int red_grid_cap() { static int v = 0; if (!v) { const char* e = getenv("TFASR_RED_GRID"); v = e ? atoi(e) : 192; } return v; }
+inline int red_threads() { return 512; }
+inline int red_grid_cap() { return 192; }
 inline int fat_grid(long rows, int rows_per_wave_iter) {
   const long per_block = (long)(red_threads() / 64) * rows_per_wave_iter;
   // the per-block atomic tail (~17 ns per block per column) is only worth limiting for small inputs
@@ -623,8 +623,8 @@ extern "C" int tfasr_layernorm_fwd(const void* x, const float* gamma, const floa
   hipStream_t s = (hipStream_t)stream_;
   if (dtype == TFASR_BF16 && (C % 8) == 0 && C <= 512) {
     if (C <= 256) {
-      static const int U = getenv("TFASR_LN_FWD_U") ? atoi(getenv("TFASR_LN_FWD_U")) : 4;
-      static const long cap = getenv("TFASR_LN_FWD_GRID") ? atol(getenv("TFASR_LN_FWD_GRID")) : 2048L;
+      static const int U = 4;
+      static const long cap = 2048L;
       const int grid = (int)std::min<long>((rows + 8 * U - 1) / (8 * U), cap);
       if (U == 4) hipLaunchKernelGGL((ln_fwd_vec_kernel<bf16_t, 32, 4>), dim3(grid), dim3(256), 0, s, (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, rows, C, eps);
       else if (U == 1) hipLaunchKernelGGL((ln_fwd_vec_kernel<bf16_t, 32, 1>), dim3(grid), dim3(256), 0, s, (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, rows, C, eps);

@@ -632,8 +632,8 @@ static int rnnt_impl(const void* logits, void* grads, const int32_t* labels, con
     return TFASR_STATUS_INVALID_VALUE;
   TFASR_CHECK_LAUNCH();
   const int nthr = ((U1 + 63) / 64) * 64;
-  static const bool wave_off = getenv("TFASR_RNNT_LATTICE_WAVE") && getenv("TFASR_RNNT_LATTICE_WAVE")[0] == '0';  // A/B probe: the workgroup kernel
-  static const bool fast = !(getenv("TFASR_RNNT_LATTICE_FAST") && getenv("TFASR_RNNT_LATTICE_FAST")[0] == '0');
+  static const bool wave_off = false;  // A/B probe: the workgroup kernel
+  static const bool fast = !(false);
 #define TFASR_LW(E) do { if (fast) hipLaunchKernelGGL((rnnt_lattice_wave_kernel<E, true>), dim3(B, 2), dim3(64), 0, stream, blank_lp, truth_lp, label_len, logit_len, cell_off, T, U1, alpha, beta, costs); \
                          else hipLaunchKernelGGL((rnnt_lattice_wave_kernel<E, false>), dim3(B, 2), dim3(64), 0, stream, blank_lp, truth_lp, label_len, logit_len, cell_off, T, U1, alpha, beta, costs); } while (0)
   if (!wave_off && U1 <= 64) TFASR_LW(1);
@@ -645,7 +645,7 @@ static int rnnt_impl(const void* logits, void* grads, const int32_t* labels, con
   TFASR_CHECK_LAUNCH();
   // gradient as coefficient pass + pure stream (rnnt_grad_apply_kernel) when the workspace has room for the coefficients (older callers
   // sized it for 5 segments: they keep the one-launch kernel); TFASR_RNNT_GRAD_STREAM=0 forces the one-launch kernel
-  static const bool stream_off = getenv("TFASR_RNNT_GRAD_STREAM") && getenv("TFASR_RNNT_GRAD_STREAM")[0] == '0';
+  static const bool stream_off = false;
   const bool streamed = grads && !stream_off && (V % 8) == 0 && V <= 1024 && workspace_bytes >= 10 * seg && (dtype == TFASR_F32 || dtype == TFASR_BF16);
   float4* cbuf = coef ? (float4*)coef : (float4*)(ws + 5 * seg);
   int32_t* rlab = (int32_t*)(ws + 9 * seg);

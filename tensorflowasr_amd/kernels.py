@@ -245,24 +245,6 @@ def ffn_fused_fwd(x, gamma, beta, W1, b1, W2, b2, res_factor, drop_p=0.0, seed1=
     return y, ln, mean, rstd, z, h
 
 
-def ffn_fused_bwd(dyd, z, W1, W2, x, gamma, mean, rstd, add, res_factor, drop_p=0.0, seed1=0, seed_next=0, want_dropped=False):
-    """tfasr_ffn_fused_bwd: the FFModule's data gradient in one launch.  Returns (dz, dx, dx_dropped | None, part [tiles, 2 d]) - the LayerNorm's
-    gamma / beta sums are the column sums of `part` (layernorm_bwd_fold's input) - or None when the shape is outside the kernel's range."""
-    rows, d = x.shape
-    F = W1.shape[1]
-    tiles = int(_L().tfasr_ffn_fused_bwd_tiles(rows))
-    dz = torch.empty(rows, F, dtype=x.dtype, device=x.device)
-    dx = torch.empty_like(x)
-    dxd = torch.empty_like(x) if want_dropped else None
-    part = torch.empty(tiles, 2 * d, dtype=torch.float32, device=x.device)
-    st = _L().tfasr_ffn_fused_bwd(_p(dyd), _p(z), _p(W1), _p(W2), _p(x), _p(gamma), _p(mean), _p(rstd), _p(add), _p(dz), _p(dx), _p(dxd), _p(part),
-                                  rows, d, F, float(res_factor), float(drop_p), int(seed1), int(seed_next), _dt(x), _stream())
-    if st == _lib.STATUS_UNSUPPORTED:
-        return None
-    check(st, "ffn_fused_bwd")
-    return dz, dx, dxd, part
-
-
 def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, add=None, dx=None, dropped=None, drop_p=0.0, drop_seed=0):
     """dropped (optional, same shape as dx): also receives dropout(dx, drop_p, drop_seed) from the same kernel."""
     rows, C = x.numel() // x.shape[-1], x.shape[-1]
@@ -563,25 +545,22 @@ def relattn_fused_fwd(qkv, ubias, vbias, pext, lengths, B, H, T, dh, scale, use_
     return out, lse
 
 
-def relattn_fused_bwd_q(qkv, ubias, vbias, pext, lengths, o, dout, lse, B, H, T, dh, ldp, scale, use_mask=True):
-    dqu = torch.empty(B * T, H * dh, dtype=qkv.dtype, device=qkv.device)
-    dpos = torch.empty(B, H, T, ldp, dtype=qkv.dtype, device=qkv.device)
-    dvec = torch.empty(B, H, T, dtype=torch.float32, device=qkv.device)
-    check(_L().tfasr_relattn_fused_bwd_q(_p(qkv), _p(ubias), _p(vbias), _p(pext), _p(lengths), _p(o), _p(dout), _p(lse), _p(dqu), _p(dpos),
-                                         _p(dvec), B, H, T, dh, ldp, scale, int(use_mask), _dt(qkv), _stream()), "relattn_fused_bwd_q")
-    return dqu, dpos, dvec
-
-
-def relattn_fused_bwd_q2(qkv, ubias, vbias, pext, lengths, o, dout, lse, dpext, B, H, T, dh, scale, use_mask=True, chunk_size=None, history_size=None):
-    """Query side without a skewed score gradient in HBM: -> (dqu, dqv, ds [B,H,T,lds], dvec); adds the bias-row share into dpext."""
+def relattn_fused_bwd_q3(qkv, ubias, vbias, pext, lengths, o, dout, lse, dqkv, du, dv, dpext, B, H, T, dh, scale, use_mask=True, chunk_size=None,
+                         history_size=None, ds=None, qv=None):
+    """Query side of the fused attention backward (tfasr_relattn_fused_bwd_q3): writes dq = dqu + dqv into the q columns of dqkv
+    [B*T, 3*H*dh], adds the u / v bias gradients into du / dv [H*dh] f32 and the bias row's share into dpext [2T, H*dh] f32.
+    -> (ds [B,H,T,lds] unskewed score gradient, dvec [B,H,T], qu, qv = q + u / q + v for the key side and tfasr_relattn_dpext)."""
     lds = -(-T // 8) * 8
-    dqu = torch.empty(B * T, H * dh, dtype=qkv.dtype, device=qkv.device)
-    dqv = torch.empty(B * T, H * dh, dtype=qkv.dtype, device=qkv.device)
-    ds = torch.empty(B, H, T, lds, dtype=qkv.dtype, device=qkv.device)
+    if ds is None:
+        ds = torch.empty(B, H, T, lds, dtype=qkv.dtype, device=qkv.device)
     dvec = torch.empty(B, H, T, dtype=torch.float32, device=qkv.device)
-    check(_L().tfasr_relattn_fused_bwd_q2(_p(qkv), _p(ubias), _p(vbias), _p(pext), _p(lengths), _p(o), _p(dout), _p(lse), _p(dqu), _p(dqv), _p(ds),
-                                          _p(dvec), _p(dpext), B, H, T, dh, lds, scale, int(use_mask), *_window(chunk_size, history_size), _dt(qkv), _stream()), "relattn_fused_bwd_q2")
-    return dqu, dqv, ds, dvec
+    qu = torch.empty(B * T, H * dh, dtype=qkv.dtype, device=qkv.device)
+    if qv is None:
+        qv = torch.empty(B * T, H * dh, dtype=qkv.dtype, device=qkv.device)
+    check(_L().tfasr_relattn_fused_bwd_q3(_p(qkv), _p(ubias), _p(vbias), _p(pext), _p(lengths), _p(o), _p(dout), _p(lse), _p(dqkv), dqkv.stride(0),
+                                          _p(du), _p(dv), _p(ds), _p(dvec), _p(dpext), _p(qu), _p(qv), B, H, T, dh, lds, scale, int(use_mask),
+                                          *_window(chunk_size, history_size), _dt(qkv), _stream()), "relattn_fused_bwd_q3")
+    return ds, dvec, qu, qv
 
 
 def relattn_dpext(ds, qv, lengths, dpext, B, H, T, dh, use_mask=True):

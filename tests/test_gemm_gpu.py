@@ -94,26 +94,6 @@ def test_split_k_accumulate(dev, split):
         np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=rtol, atol=atol * 70)
 
 
-@pytest.mark.parametrize("M,N,K", [(256, 1024, 12096), (144, 576, 200), (144, 576, 72), (130, 100, 40), (256, 768, 1000)])
-def test_small_output_weight_gradient_in_cu_reduction(dev, M, N, K, monkeypatch):
-    """wgrad_kg2_kernel (opt-in TFASR_GEMM_KG2=1; bf16, few output tiles, split_k > 1): both wave groups active / one idle,
-    partial last slab owned by either group, a single slab, M and N edges; with and without the fused bias gradient."""
-    monkeypatch.setenv("TFASR_GEMM_KG2", "1")
-    g = torch.Generator().manual_seed(K)
-    X, dY = torch.randn(K, M, generator=g), torch.randn(K, N, generator=g)
-    Xd, Yd = X.to(dev).to(torch.bfloat16), dY.to(dev).to(torch.bfloat16)
-    ref = 1.0 + 0.25 * (Xd.float().cpu().T @ Yd.float().cpu())
-    refb = 3.0 + 0.25 * Yd.float().cpu().sum(0)
-    for with_bias in (False, True):
-        out = torch.ones(M, N, dtype=torch.float32, device=dev)
-        gb = torch.full((N,), 3.0, dtype=torch.float32, device=dev) if with_bias else None
-        ldx, ldy = Xd.stride(0), Yd.stride(0)
-        kernels.gemm(Xd, Yd, out, M, N, K, ldx, ldy, N, trans_a=True, accumulate=True, split_k=4, alpha=0.25, colsum=gb)
-        np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=2e-3, atol=0.05 + 2e-3 * K ** 0.5)
-        if with_bias:
-            np.testing.assert_allclose(gb.cpu().numpy(), refb.numpy(), rtol=2e-3, atol=0.05)
-
-
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_attention_product_shapes_narrow_tile(dev, dtype):
     """probs @ v and probs^T @ dctx with head size 64 and a padded score stride (the N<=64 tile variant + tr-read path)."""
