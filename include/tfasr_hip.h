@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define TFASR_ABI_VERSION 35
+#define TFASR_ABI_VERSION 36
 
 typedef enum {
   TFASR_STATUS_SUCCESS = 0,
@@ -221,6 +221,16 @@ int tfasr_layernorm_bwd_part(const void* dy, const void* x, const float* gamma, 
 int tfasr_layernorm_bwd_part_n(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, const void* add,
                                void* dx, float* part, int nblk, void* dx_dropped, float drop_p, long drop_seed, long rows, int C, int dtype,
                                void* stream);
+/* Dense data gradient + the LayerNorm backward in front of it in ONE launch (bf16, d = 256, K % 64 == 0; else UNSUPPORTED and the caller
+ * keeps tfasr_gemm + tfasr_layernorm_bwd_part_n): the backward of `y = Dense(LayerNorm(x))` heads (FFModule encoders/conformer.py:66-109,
+ * the fused q/k/v projection multihead_attention.py:628-637, ConvModule's first pointwise conv convolution.py:159-228):
+ *     dln = alpha * dy @ W^T  (never stored);  dx = add + LayerNorm'(dln | x, gamma, mean, rstd);  part[tile] = (sum dln*xhat, sum dln)
+ * dy [rows, K], W [d, K] row-major (the Dense kernel as stored, [din = d, dout = K]); x / add / dx / dx_dropped [rows, d]; part =
+ * [nblk][2d] partial sums exactly as tfasr_layernorm_bwd_part_n leaves them (slots without rows are zeroed); dx_dropped (optional) =
+ * tfasr_dropout(dx, drop_p, drop_seed).  UNSUPPORTED also when rows need more than nblk tiles of 96 rows. */
+int tfasr_dense_ln_bwd(const void* dy, const void* W, int K, const void* x, const float* gamma, const float* mean, const float* rstd,
+                       const void* add, void* dx, float* part, int nblk, void* dx_dropped, float drop_p, long drop_seed, long rows,
+                       int d, float alpha, int dtype, void* stream);
 int tfasr_layernorm_bwd_fold(const float* part, int nsets, int nblk, int C, float* const* dgamma, float* const* dbeta, void* stream);
 /* The same for up to 128 sets that lie in different buffers (part[i] = [nblk][2C] of set i; host arrays of device pointers): the
    LayerNorms of every Conformer block of a step in one launch. */

@@ -260,6 +260,29 @@ struct Ex {
     else
       chk(tfasr_layernorm_bwd(dy, x, fp(gi), mean, rstd, add, dx, gp(gi), gp(bi), rows, c->d, c->dtype, s));
   }
+  // Dense data gradient + the LayerNorm backward in front of the layer in ONE launch (tfasr_dense_ln_bwd) where its shape range allows;
+  // the weight / bias gradients are queued as by dense_bwd.  false = nothing was launched for the data side: the caller takes the
+  // two-launch route.  (dry runs take that route too: it allocates a superset.)
+  bool dense_ln_bwd(const void* dy, const void* xw, int wi, int bi, int dout, const void* x, int gi, int bi_ln, const float* mean, const float* rstd,
+                    const void* add, void* dx, void* dxd, int next_site) {
+    if (dry || !k->ln_part || k->ln_nsets >= 8 || c->dtype != TFASR_BF16 || c->d != 256 || (dout % 64) != 0 || !fuse_dense_ln()) return false;
+    if ((rows + 95) / 96 > k->ln_nblk) return false;
+    const bool with_drop = dxd && drop_p() > 0.f && next_site >= 0;
+    float* part = k->ln_part + (size_t)k->ln_nsets * k->ln_nblk * 2 * c->d;
+    const int fst = tfasr_dense_ln_bwd(dy, wp(wi), dout, x, fp(gi), mean, rstd, add, dx, part, k->ln_nblk, with_drop ? dxd : nullptr,
+                                       with_drop ? drop_p() : 0.f, with_drop ? seed(next_site) : 0, rows, c->d, 1.f, c->dtype, s);
+    if (fst == TFASR_STATUS_UNSUPPORTED) return false;
+    chk(fst);
+    k->ln_dg[k->ln_nsets] = gp(gi);
+    k->ln_db[k->ln_nsets] = gp(bi_ln);
+    ++k->ln_nsets;
+    dense_bwd(dy, xw, wi, bi, c->d, dout, nullptr);  // weight / bias gradient only
+    return true;
+  }
+  static bool fuse_dense_ln() {
+    static const bool on = !(getenv("TFASR_DENSE_LN") && getenv("TFASR_DENSE_LN")[0] == '0');  // A/B switch of the fused launch
+    return on;
+  }
   const void* masked(const void* dy, const void* pre, long elems, int site) {
     if (drop_p() <= 0.f) return dy;
     return pre ? pre : mask_grad(dy, elems, site);
@@ -308,8 +331,10 @@ struct Ex {
       gemm(g);
     }
     void* dln = act(scratch, rows * d);
-    dense_bwd(dz, k->ff_ln[m], b0 + 2, b0 + 3, d, F, dln);
-    ln_bwd(dln, k->ff_x[m], b0, b0 + 1, k->ff_mean[m], k->ff_rstd[m], dy, dx, dxd, next_site);
+    if (!dense_ln_bwd(dz, k->ff_ln[m], b0 + 2, b0 + 3, F, k->ff_x[m], b0, b0 + 1, k->ff_mean[m], k->ff_rstd[m], dy, dx, dxd, next_site)) {
+      dense_bwd(dz, k->ff_ln[m], b0 + 2, b0 + 3, d, F, dln);
+      ln_bwd(dln, k->ff_x[m], b0, b0 + 1, k->ff_mean[m], k->ff_rstd[m], dy, dx, dxd, next_site);
+    }
     rewind(mark);
   }
   // ------------------------------------------------------------------------------------------ MHSAModule
@@ -486,8 +511,11 @@ struct Ex {
       if (!dry) chk(tfasr_colsum(dpext, HD, gp(TFASR_BP_AT_POS_B), R1, HD, 1.f, TFASR_F32, s));
     }
     void* dln = act(scratch, rows * d);
-    dense_bwd(dqkv, k->at_ln, TFASR_BP_AT_QKV_W, TFASR_BP_AT_QKV_B, d, 3 * HD, dln);
-    ln_bwd(dln, k->at_x, TFASR_BP_AT_LN_G, TFASR_BP_AT_LN_B, k->at_mean, k->at_rstd, dy, dx, dxd, next_site);
+    if (!dense_ln_bwd(dqkv, k->at_ln, TFASR_BP_AT_QKV_W, TFASR_BP_AT_QKV_B, 3 * HD, k->at_x, TFASR_BP_AT_LN_G, TFASR_BP_AT_LN_B, k->at_mean, k->at_rstd,
+                      dy, dx, dxd, next_site)) {
+      dense_bwd(dqkv, k->at_ln, TFASR_BP_AT_QKV_W, TFASR_BP_AT_QKV_B, d, 3 * HD, dln);
+      ln_bwd(dln, k->at_x, TFASR_BP_AT_LN_G, TFASR_BP_AT_LN_B, k->at_mean, k->at_rstd, dy, dx, dxd, next_site);
+    }
     rewind(mark);
   }
 
@@ -591,8 +619,11 @@ struct Ex {
         chk(tfasr_glu_bwd(k->cv_a, dg, da, rows, d, c->dtype, s));
       } else chk(fst);
     }
-    dense_bwd(da, k->cv_ln, TFASR_BP_CV_PW1_W, TFASR_BP_CV_PW1_B, d, 2 * d, dln);
-    ln_bwd(dln, k->cv_x, TFASR_BP_CV_LN_G, TFASR_BP_CV_LN_B, k->cv_mean, k->cv_rstd, dy, dx, dxd, next_site);
+    if (!dense_ln_bwd(da, k->cv_ln, TFASR_BP_CV_PW1_W, TFASR_BP_CV_PW1_B, 2 * d, k->cv_x, TFASR_BP_CV_LN_G, TFASR_BP_CV_LN_B, k->cv_mean, k->cv_rstd, dy,
+                      dx, dxd, next_site)) {
+      dense_bwd(da, k->cv_ln, TFASR_BP_CV_PW1_W, TFASR_BP_CV_PW1_B, d, 2 * d, dln);
+      ln_bwd(dln, k->cv_x, TFASR_BP_CV_LN_G, TFASR_BP_CV_LN_B, k->cv_mean, k->cv_rstd, dy, dx, dxd, next_site);
+    }
   }
 
   // ------------------------------------------------------------------------------------------ block

@@ -887,6 +887,7 @@ int launch_epi(const tfasr_gemm_args& a, dim3 tiles, hipStream_t stream) {
 
 #include "gemm_big.h"
 #include "ffn_fused.h"
+#include "dense_ln.h"
 
 template <bool TA, bool TB>
 int launch_one(const tfasr_gemm_args& a, hipStream_t stream) {
@@ -1146,4 +1147,24 @@ extern "C" int tfasr_ffn_fused_fwd(const void* x, const float* gamma, const floa
 #endif
   TFASR_CHECK_LAUNCH();
   return st;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Dense data gradient + the LayerNorm backward in front of it in one launch (dense_ln.h).  UNSUPPORTED outside its shape range.
+extern "C" int tfasr_dense_ln_bwd(const void* dy, const void* W, int K, const void* x, const float* gamma, const float* mean, const float* rstd,
+                                  const void* add, void* dx, float* part, int nblk, void* dx_dropped, float drop_p, long drop_seed, long rows,
+                                  int d, float alpha, int dtype, void* stream) {
+  if (!dy || !W || !x || !gamma || !mean || !rstd || !dx || !part || rows <= 0 || d <= 0 || K <= 0 || nblk <= 0) return TFASR_STATUS_INVALID_VALUE;
+  if (dx_dropped && !(drop_p >= 0.f && drop_p < 1.f)) return TFASR_STATUS_INVALID_VALUE;
+  if (dtype != TFASR_BF16 || d != DLN_D || (K % 64) != 0 || rows * (long)d >= (1L << 32)) return TFASR_STATUS_UNSUPPORTED;
+  const uintptr_t al = (uintptr_t)dy | (uintptr_t)W | (uintptr_t)x | (uintptr_t)add | (uintptr_t)dx | (uintptr_t)dx_dropped | (uintptr_t)gamma;
+  if (al & 15) return TFASR_STATUS_UNSUPPORTED;
+  DenseLnArgs a;
+  a.dy = (const bf16_t*)dy; a.ldy = K; a.W = (const bf16_t*)W; a.ldw = K; a.K = K; a.x = (const bf16_t*)x; a.gamma = gamma; a.mean = mean; a.rstd = rstd;
+  a.add = (const bf16_t*)add; a.dx = (bf16_t*)dx; a.dxd = (bf16_t*)dx_dropped; a.drop_p = dx_dropped ? drop_p : 0.f; a.drop_seed = (uint64_t)drop_seed;
+  a.part = part; a.rows = rows; a.alpha = alpha; a.ntiles = 0;
+  const int st = launch_dense_ln_bwd(a, nblk, (hipStream_t)stream);
+  if (st != TFASR_STATUS_SUCCESS) return st;
+  TFASR_CHECK_LAUNCH();
+  return TFASR_STATUS_SUCCESS;
 }

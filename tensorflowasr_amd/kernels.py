@@ -275,6 +275,28 @@ def layernorm_bwd_fold(dy, x, gamma, mean, rstd, dgamma, dbeta, add=None):
     return dx
 
 
+def dense_ln_bwd(dy, W, x, gamma, mean, rstd, dgamma, dbeta, add=None, dropped=None, drop_p=0.0, drop_seed=0, alpha=1.0):
+    """tfasr_dense_ln_bwd: dx of `Dense(LayerNorm(x))` in one launch (dln = alpha * dy @ W^T never stored), gamma / beta gradients through
+    partial sums + tfasr_layernorm_bwd_fold.  dy [rows, K], W [d, K] (the Dense kernel as stored).  Returns dx, or None when the shape is
+    outside the fused kernel's range (the caller keeps gemm + layernorm_bwd)."""
+    rows, d = x.numel() // x.shape[-1], x.shape[-1]
+    K = dy.shape[-1]
+    nblk = _L().tfasr_layernorm_bwd_part_blocks(rows, d, _dt(x))
+    if nblk <= 0:
+        return None
+    dx = torch.empty_like(x)
+    part = torch.empty(nblk * 2 * d, dtype=torch.float32, device=x.device)
+    st = _L().tfasr_dense_ln_bwd(_p(dy), _p(W), K, _p(x), _p(gamma), _p(mean), _p(rstd), _p(add), _p(dx), _p(part), nblk, _p(dropped), float(drop_p),
+                                 int(drop_seed), rows, d, float(alpha), _dt(x), _stream())
+    if st == _lib.STATUS_UNSUPPORTED:
+        return None
+    check(st, "dense_ln_bwd")
+    dg = (ctypes.c_void_p * 1)(dgamma.data_ptr())
+    db = (ctypes.c_void_p * 1)(dbeta.data_ptr())
+    check(_L().tfasr_layernorm_bwd_fold(_p(part), 1, nblk, d, dg, db, _stream()), "layernorm_bwd_fold")
+    return dx
+
+
 def bn_stats(x, stats):
     rows, C = x.numel() // x.shape[-1], x.shape[-1]
     check(_L().tfasr_bn_stats(_p(x), _p(stats), rows, C, _dt(x), _stream()), "bn_stats")

@@ -166,6 +166,51 @@ def test_layernorm_bwd_partial_sums_and_fold(dev, rows, C):
     cmp(db1, db0.cpu(), rtol=2e-4, atol=2e-2)
 
 
+@pytest.mark.parametrize("rows,Kd,p", [(23776, 1024, 0.1), (14784, 768, 0.1), (777, 512, 0.0), (40, 64, 0.25), (24500, 256, 0.1), (30000, 256, 0.1)])
+def test_dense_ln_bwd_one_launch(dev, rows, Kd, p):
+    """tfasr_dense_ln_bwd: the backward of `Dense(LayerNorm(x))` (FFModule encoders/conformer.py:66-109, the q/k/v projection
+    multihead_attention.py:628-637, ConvModule's first pointwise conv convolution.py:159-228) in one launch, against (a) the oracle's
+    autograd of the same expression (torch-CPU f32: dx incl. the residual `add`, gamma / beta gradients) and (b) the two-launch route
+    (tfasr_gemm + tfasr_layernorm_bwd_drop: the product rounded to bf16 in between, so only close).  Row counts: the two bench batches
+    (96- and 64-row tiles, one round of workgroups), a ragged last tile, fewer rows than one tile, 24500 rows (256 tiles of 96), and a
+    row count outside the range (UNSUPPORTED: more 96-row tiles than partial-sum slots)."""
+    g = torch.Generator().manual_seed(rows + Kd)
+    dt, d = torch.bfloat16, 256
+    x = rt(torch.randn(rows, d, generator=g) * 1.5 + 0.3, dt)
+    W = rt(torch.randn(d, Kd, generator=g) / math.sqrt(d), dt)
+    dy = rt(torch.randn(rows, Kd, generator=g) * 0.5, dt)
+    add = rt(torch.randn(rows, d, generator=g), dt)
+    gam, bet = torch.randn(d, generator=g) * 0.5 + 1.0, torch.randn(d, generator=g) * 0.1
+    xr, gr, br = x.clone().requires_grad_(True), gam.clone().requires_grad_(True), bet.clone().requires_grad_(True)
+    (R.layer_norm(xr, gr, br) @ W).backward(dy)
+    xd, Wd, dyd, addd, gd, bd = x.to(dev).to(dt), W.to(dev).to(dt), dy.to(dev).to(dt), add.to(dev).to(dt), gam.to(dev), bet.to(dev)
+    _, mean, rstd = K.layernorm_fwd(xd, gd, bd)
+    dg, db = torch.zeros(d, device=dev), torch.zeros(d, device=dev)
+    dropped = torch.empty_like(xd) if p > 0 else None
+    dx = K.dense_ln_bwd(dyd, Wd, xd, gd, mean, rstd, dg, db, add=addd, dropped=dropped, drop_p=p, drop_seed=4711)
+    if rows > 96 * 256:  # more 96-row tiles than partial-sum slots (= CUs): outside the kernel's range, the caller keeps the two launches
+        assert dx is None
+        return
+    assert dx is not None
+    torch.cuda.synchronize()
+    cmp(dx, xr.grad + add, rtol=3e-2, atol=3e-2)
+    rel = float((dx.float().cpu() - (xr.grad + add)).norm() / (xr.grad + add).norm())
+    assert rel < 4e-3, rel  # (bf16 output rounding only: the product stays f32 inside the launch)
+    scale_g = float(gr.grad.abs().max())
+    cmp(dg, gr.grad, rtol=2e-3, atol=2e-3 * scale_g)
+    cmp(db, br.grad, rtol=2e-3, atol=2e-3 * float(br.grad.abs().max()))
+    if p > 0:
+        assert torch.equal(dropped, K.dropout(dx, p, 4711))  # the same mask and rounding as tfasr_dropout(dx)
+    # the two-launch route
+    dln = torch.empty(rows, d, dtype=dt, device=dev)
+    K.gemm(dyd, Wd, dln, rows, d, Kd, Kd, Kd, d, trans_b=True)
+    dg2, db2 = torch.zeros(d, device=dev), torch.zeros(d, device=dev)
+    dx2 = K.layernorm_bwd(dln, xd, gd, mean, rstd, dg2, db2, add=addd)
+    rel2 = float((dx.float() - dx2.float()).norm() / dx2.float().norm())
+    assert rel2 < 6e-3, rel2
+    cmp(dg, dg2.cpu(), rtol=5e-3, atol=5e-3 * scale_g)
+
+
 @pytest.mark.parametrize("Kk,C,T", [(5, 640, 150), (5, 80, 77), (3, 256, 64), (7, 144, 130), (8, 264, 65), (15, 144, 53), (32, 144, 53)])
 def test_dwconv_kernel_sizes(dev, Kk, C, T):
     """The bf16 depthwise kernels are instantiated per window bound (8 / 32 taps) and per weight-gradient kernel size: every size the

@@ -2,7 +2,7 @@
 //   ./gemm_ws_test [M] [N] [K] [mul]      D[M,N] = A[M,K] @ Wt[N,K]^T (* mul[M,N])
 // prints us/launch of both, max abs difference, and checks a sample of entries against a host f64 sum.
 #include "../../tensorflowasr_amd/csrc/gemm_fast.hip"
-#include "../../tensorflowasr_amd/csrc/gemm_ws.h"
+#include "gemm_ws.h"
 #include <string.h>
 #include <stdlib.h>
 #include <vector>
