@@ -11,14 +11,33 @@
  *   - no allocation inside: every scratch buffer is caller-owned, sized by a `*_workspace_size` query;
  *   - every entry returns a tfasr_status_t; `tfasr_status_string` decodes it;
  *   - re-entrant per stream, no assumption about the process-wide current device beyond "the pointers and the stream belong
- *     to the device that is current on this thread".  State the library keeps: (i) tuning switches read ONCE from the environment
- *     (TFASR_* variables, function-local statics: A/B switches of the kernels, never results; TFASR_ATTN_BWDQ_T and TFASR_GEMM_KG2
- *     are read per call so that a test can compare both routes inside one process); (ii) the block executor's internal
- *     second stream + events per device (tfasr_block_io.wgrad_slot), the persistent-LSTM policy (tfasr_lstm_set_persist), and one
- *     flag set around a grouped launch that shares the chip with another stream; (iii) two measurement aids: a host-side launch counter
- *     (tfasr_launch_count) and the optional event record of tfasr_block_wgrad_probe - all of them assume what the rest of the design
- *     assumes anyway: ONE host thread queues the launches of a device.  Results never depend on any of it.
- *     (The Python package also sets GPU_MAX_HW_QUEUES=8 at import unless the user chose a value - the HIP runtime's own switch.)
+ *     to the device that is current on this thread".  State the library keeps: (i) the three switches of the table below that it reads itself
+ *     (once, function-local statics); (ii) the block executor's internal second stream + events per device (tfasr_block_io.wgrad_slot), the
+ *     persistent-LSTM policy (tfasr_lstm_set_persist), and one flag set around a grouped launch that shares the chip with another stream;
+ *     (iii) two measurement aids: a host-side launch counter (tfasr_launch_count) and the optional event record of tfasr_block_wgrad_probe -
+ *     all of them assume what the rest of the design assumes anyway: ONE host thread queues the launches of a device.  Results never
+ *     depend on any of it.  (The Python package also sets GPU_MAX_HW_QUEUES=8 at import unless the user chose a value - the HIP
+ *     runtime's own switch.)
+ *
+ *     Environment switches (all of them; A/B aids, never needed for a result).  Read by the library:
+ *       TFASR_FFN_FUSED=0        FFModule forward as LayerNorm + two products instead of tfasr_ffn_fused_fwd
+ *       TFASR_LSTM_PERSIST=0|1   force the per-step / the persistent LSTM kernels (default: the caller's tfasr_lstm_set_persist policy)
+ *       TFASR_DENSE_LN=0         (block executor) Dense data gradient and LayerNorm backward as two launches instead of tfasr_dense_ln_bwd
+ *     Read by the Python host (tensorflowasr_amd/, bench.py):
+ *       TFASR_LIB=<path>         load another build of this library (same-box A/B of two builds; probe builds)
+ *       TFASR_HEAD_PAD=0, TFASR_FILTER_PAD=0   logical head size / subsampling filters instead of the 64-multiples
+ *       TFASR_NATIVE_BLOCK=0     per-kernel Python path instead of the native block executor
+ *       TFASR_ATTN_UNFUSED=1     unfused attention (score matrices in HBM; what f32 models always take)
+ *       TFASR_CONV2_IM2COL=1     im2col route of the subsampling's second convolution
+ *       TFASR_NO_PRED_STREAM=1, TFASR_PRED_SLICES=<n>   prediction network in line / in n slices between the encoder blocks
+ *       TFASR_WGRAD_STREAM=0|1, TFASR_BLOCK_HOIST=0|1, TFASR_DEFER_SIDE=0, TFASR_FRONT_EARLY=0   stream placement of the weight gradients,
+ *                                the hoisted per-block launches, the deferred small gradients, the front end (DESIGN.md section 2 "Streams")
+ *       TFASR_JOINT_RECOMPUTE=1  joint + loss without materialised lattice logits (bench.py reports both)
+ *       TFASR_DECODE_PRECISION=f32|bf16   encoder of the greedy search (token-exact f32 twin / training kernels)
+ *       TFASR_DP_GRAD_WIRE=f32|bf16, TFASR_DP_FORCE_SPLIT=1   data-parallel gradient wire type; the world > 1 block route at one rank
+ *       TFASR_BENCH_HOST=1, TFASR_BENCH_SECTIONS=1, TFASR_BENCH_STUB=1   bench.py: host enqueue time, per-section timers, launch-logic test
+ *     Compile-time probe defines (tools/build_probe_lib.sh, tools/hwprobe/): TFASR_ATTN_TIMING, TFASR_GEMM_TIMING, TFASR_FFN_TIMING,
+ *     TFASR_DECODE_TIMING, TFASR_DLN_TIMING (shader-clock stamps), TFASR_GLDS_BUILTIN, TFASR_QT_NT=0 (builtin LDS-DMA / plain dS stores).
  *   - `dtype`: storage type of activation tensors, TFASR_F32 or TFASR_BF16 (raw 16-bit bfloat16).
  *     All arithmetic accumulates in f32. Parameters, gradients and optimizer state are always f32.
  */

@@ -71,7 +71,7 @@ class ConformerTransducer(BaseModel):
         self.time_reduction_factor = cfg.time_reduction_factor
         self.step = 0
         self._consts = {}
-        self._conv1_gram = os.environ.get("TFASR_CONV1_GRAM", "1") != "0"  # conv1 / BatchNorm0 sums through the patch Gram matrix (one backward pass)
+        self._conv1_gram = True  # conv1 / BatchNorm0 sums through the patch Gram matrix (one backward pass); False: the two-pass kernels (tests)
         # SpecAugment draws and dropout masks are per replica (MirroredStrategy draws independent randomness on every
         # replica); the parameter initialisation seed above is shared by all ranks
         self._rng = np.random.default_rng([seed + 1000, int(self.dp.rank)])
@@ -79,8 +79,8 @@ class ConformerTransducer(BaseModel):
         # data-parallel rank ran 38 instead of 23 ms).  HIP never lets streams of DIFFERENT priority share a queue, so the three streams of the
         # step sit on three priority levels - the encoder chain on the default stream, the prediction network (hundreds of tiny launches the
         # joint network waits for) on a HIGH-priority stream, everything nothing on the chain waits for on the executor's LOW-priority stream -
-        # which keeps them on separate queues whatever GPU_MAX_HW_QUEUES is and whatever streams RCCL adds.  TFASR_PRED_PRIO=0: default priority.
-        prio = -1 if os.environ.get("TFASR_PRED_PRIO", "-1") != "0" else 0
+        # which keeps them on separate queues whatever GPU_MAX_HW_QUEUES is and whatever streams RCCL adds.
+        prio = -1
         self.pred_stream = torch.cuda.Stream(device=self.device, priority=prio)
         self.use_pred_stream = os.environ.get("TFASR_NO_PRED_STREAM", "0") != "1"
         # probe (bench.py --dp-hooks): take the world > 1 route of the block executor - two phases per block and direction around the sync-BN
@@ -117,21 +117,19 @@ class ConformerTransducer(BaseModel):
         # block (ParamStore.defer_lo / defer_hi), released after the deferred launches.  TFASR_BLOCK_HOIST=0: off.
         self.block_hoist = {"0": False, "1": True}.get(os.environ.get("TFASR_BLOCK_HOIST"), None)  # None: on
         # ... and with the gradients deferred, the kernel that accumulates a block's table gradient from dS (tfasr_relattn_dpext, 37 us per
-        # block, only the deferred products wait for it) runs on the auxiliary stream beside the next block's backward.  TFASR_DPEXT_AUX=0: in line.
-        self.dpext_aux = os.environ.get("TFASR_DPEXT_AUX", "1") != "0"
-        self.joint_wgrad_aux = os.environ.get("TFASR_JOINT_WGRAD_AUX", "0") == "1"  # (A/B: the vocabulary weight gradient on the auxiliary stream)
+        # block, only the deferred products wait for it) runs on the auxiliary stream beside the next block's backward (attribute False: in line).
+        self.dpext_aux = True
+        self.joint_wgrad_aux = False  # (measured no gain: the vocabulary weight gradient on the auxiliary stream)
         self._aux_pending = False
         # the auxiliary stream IS the block executor's second stream (one queue for the grouped weight gradients, the positional tables ahead
-        # of the chain and the table gradients beside the next block); TFASR_ONE_SIDE_STREAM=0: a stream of its own (A/B)
+        # of the chain and the table gradients beside the next block; a fourth stream of its own measured slower, profiles/r05_dp_queue_sweep.txt)
         if self.device.type != "cuda":
             self.aux_stream = None
-        elif os.environ.get("TFASR_ONE_SIDE_STREAM", "1") != "0":
+        else:
             with torch.cuda.device(self.device):
                 self.aux_stream = torch.cuda.ExternalStream(K.block_side_stream(), device=self.device)
-        else:
-            self.aux_stream = torch.cuda.Stream(device=self.device)
         self._hoisted = {}
-        self.fuse_joint_stats = os.environ.get("TFASR_JOINT_STATS", "1") != "0"
+        self.fuse_joint_stats = True
         # Joint + loss WITHOUT materialised lattice logits (SURVEY section 7 step 8 / 8(d) "report both"): the projection emits only the
         # log-softmax statistics, the gradient pass re-computes the logit tile and turns it into the loss gradient in its epilogue
         # (tfasr_gemm_args.rgrad_coef).  Trades two passes over the [cells, V] tensor for one more vocabulary product: measured SLOWER
@@ -145,6 +143,7 @@ class ConformerTransducer(BaseModel):
         # bf16 encoder cannot promise (near-tied arg-max decisions flip).  Inference therefore runs on the f32 master weights with the
         # exact-f32 MFMA kernels by default, whatever the training storage type ("bf16" = the training kernels, faster, not token-exact)
         self.decode_precision = os.environ.get("TFASR_DECODE_PRECISION", "f32")
+        self.decode_fused = True  # the fused search step (4 launches per iteration, queued from C); False: the per-kernel loop (tests)
         self._twin = None
 
     # =================================================================================== constants
@@ -356,7 +355,7 @@ class ConformerTransducer(BaseModel):
             # other, so that consecutive slabs read the SAME rows of the S tensor shifted by one slot (taps of a parity block differ by a
             # row shift only) while they are still in L2 - in tap-major order (a whole 256-channel tap at a time) every tap re-fetched
             # its rows: 1.48 GB fetched for a 0.51 GB input (rocprofv3 FETCH_SIZE), L2 hit rate 0.49
-            nck = C // 64 if C % 64 == 0 and os.environ.get("TFASR_CONV2_TAPMAJOR", "0") != "1" else 1
+            nck = C // 64 if C % 64 == 0 else 1
             ck = C // nck
             order = sorted(range(9), key=lambda i: (blk[i], i))
             fwd_a = torch.tensor([shift[i] * 4 * C + blk[i] * C + cc * ck for cc in range(nck) for i in order], dtype=torch.int64, device=dev)
@@ -1477,8 +1476,8 @@ class ConformerTransducer(BaseModel):
         # Adam.update_step]
         lr = self.learning_rate(self.step - 1)
         ps = self.ps
-        # bf16 models: the optimizer writes the bf16 shadow of the parameters itself (TFASR_ADAM_SHADOW=0: the separate cast pass)
-        fused = ps.shadow is not ps.flat and ps.shadow.dtype == torch.bfloat16 and os.environ.get("TFASR_ADAM_SHADOW", "1") != "0"
+        # bf16 models: the optimizer writes the bf16 shadow of the parameters itself
+        fused = ps.shadow is not ps.flat and ps.shadow.dtype == torch.bfloat16
         K.adam(ps.flat, ps.grad, ps.adam_m, ps.adam_v, ps.n_reg, lr, self.step, o["beta1"], o["beta2"], o["eps"], o["weight_decay"],
                self.cfg.l2, grad_scale, shadow=ps.shadow if fused else None)
         if not fused:
@@ -1600,7 +1599,7 @@ class ConformerTransducer(BaseModel):
         it = 0
         zbuf = torch.empty(B, J, dtype=f32, device=dev)
         lng, lnb = (ps.p("pred/ln/g"), ps.p("pred/ln/b")) if c.prediction_layer_norm else (None, None)
-        fused = B <= 64 and os.environ.get("TFASR_DECODE_FUSED", "1") != "0"
+        fused = B <= 64 and self.decode_fused
         packed = K.decode_pack(ps.p("pred/emb"), Wk, Wrk, Wjp, Wv) if fused else None  # tile order of the MFMA step kernels
         # Iterations queued per host check (fused route).  A row leaves the loop only after it has consumed its frames, one per blank, so
         # max_b(frames left) iterations are certain to be needed: that many are queued without looking (the first batch is ~T' long), then

@@ -188,11 +188,11 @@ class ContextNetTransducer(ConformerTransducer):
 
     def encoder_bwd(self, dx, ctx):
         B = ctx["enc"]["B"]
-        self._wg_queue = [] if os.environ.get("TFASR_CN_WGRAD_GROUP", "1") != "0" else None
+        self._wg_queue = []
         # one GPU: the depthwise weight gradients of all layers batched by shape after the loop (a data-parallel group releases a block's
-        # gradient range right behind the block); TFASR_CN_DW_BATCH=0: per layer
+        # gradient range right behind the block); dw_batch=False: per layer
         from .conformer import SingleProcess
-        self._dw_queue = [] if (isinstance(self.dp, SingleProcess) and os.environ.get("TFASR_CN_DW_BATCH", "1") != "0") else None
+        self._dw_queue = [] if (isinstance(self.dp, SingleProcess) and getattr(self, "dw_batch", True)) else None
         try:
             for i in reversed(range(len(self.blocks))):
                 dx = self._block_bwd_cn(dx, self.blocks[i], B, ctx)

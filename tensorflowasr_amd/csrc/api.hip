@@ -13,5 +13,5 @@ extern "C" const char* tfasr_status_string(int status) {
 
 extern "C" int tfasr_abi_version(void) { return TFASR_ABI_VERSION; }
 
-size_t g_tfasr_launch_count = 0;
-extern "C" size_t tfasr_launch_count(void) { return g_tfasr_launch_count; }
+std::atomic<size_t> g_tfasr_launch_count{0};
+extern "C" size_t tfasr_launch_count(void) { return g_tfasr_launch_count.load(std::memory_order_relaxed); }

@@ -154,10 +154,10 @@ extern "C" int tfasr_relattn_softmax_fwd_streaming(const void* content, const vo
   hipStream_t s = (hipStream_t)stream_;
   const int grid = rows_grid((long)B * H * T);
   if (dtype == TFASR_F32)
-    hipLaunchKernelGGL(relattn_softmax_fwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)content,
+    TFASR_KLAUNCH(relattn_softmax_fwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)content,
                        (const float*)pos, lengths, (float*)probs, B, H, T, ldc, ldp, use_mask, chunk, hist);
   else if (dtype == TFASR_BF16)
-    hipLaunchKernelGGL(relattn_softmax_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)content,
+    TFASR_KLAUNCH(relattn_softmax_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)content,
                        (const bf16_t*)pos, lengths, (bf16_t*)probs, B, H, T, ldc, ldp, use_mask, chunk, hist);
   else return TFASR_STATUS_INVALID_VALUE;
   TFASR_CHECK_LAUNCH();
@@ -172,10 +172,10 @@ extern "C" int tfasr_relattn_softmax_bwd(const void* probs, const void* dprobs, 
   const int grid = rows_grid((long)B * H * T);
   const size_t shmem = 4 * (size_t)T * sizeof(float);
   if (dtype == TFASR_F32)
-    hipLaunchKernelGGL(relattn_softmax_bwd_kernel<float>, dim3(grid), dim3(256), shmem, s, (const float*)probs,
+    TFASR_KLAUNCH(relattn_softmax_bwd_kernel<float>, dim3(grid), dim3(256), shmem, s, (const float*)probs,
                        (const float*)dprobs, lengths, (float*)dcontent, (float*)dpos, B, H, T, ldc, ldp, use_mask);
   else if (dtype == TFASR_BF16)
-    hipLaunchKernelGGL(relattn_softmax_bwd_kernel<bf16_t>, dim3(grid), dim3(256), shmem, s, (const bf16_t*)probs,
+    TFASR_KLAUNCH(relattn_softmax_bwd_kernel<bf16_t>, dim3(grid), dim3(256), shmem, s, (const bf16_t*)probs,
                        (const bf16_t*)dprobs, lengths, (bf16_t*)dcontent, (bf16_t*)dpos, B, H, T, ldc, ldp, use_mask);
   else return TFASR_STATUS_INVALID_VALUE;
   TFASR_CHECK_LAUNCH();

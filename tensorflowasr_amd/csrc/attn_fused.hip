@@ -1176,9 +1176,9 @@ extern "C" int tfasr_relattn_fused_fwd(const void* qkv, const float* ubias, cons
   if (!qkv || !ubias || !vbias || !pext || !out || !lse || B <= 0 || H <= 0 || T <= 0) return TFASR_STATUS_INVALID_VALUE;
   if (dtype != TFASR_BF16 || dh != DH) return TFASR_STATUS_UNSUPPORTED;
   const dim3 gridT(attn_grid_size(B, H, (T + BI - 1) / BI));
-  if (chunk > 0) hipLaunchKernelGGL(relattn_fused_fwdT_kernel<true>, gridT, dim3(256), SMEM_FWDT, (hipStream_t)stream_, (const bf16_t*)qkv, ubias, vbias,
+  if (chunk > 0) TFASR_KLAUNCH(relattn_fused_fwdT_kernel<true>, gridT, dim3(256), SMEM_FWDT, (hipStream_t)stream_, (const bf16_t*)qkv, ubias, vbias,
                                     (const bf16_t*)pext, lengths, (bf16_t*)out, lse, B, H, T, scale, use_mask, chunk, hist);
-  else hipLaunchKernelGGL(relattn_fused_fwdT_kernel<false>, gridT, dim3(256), SMEM_FWDT, (hipStream_t)stream_, (const bf16_t*)qkv, ubias, vbias,
+  else TFASR_KLAUNCH(relattn_fused_fwdT_kernel<false>, gridT, dim3(256), SMEM_FWDT, (hipStream_t)stream_, (const bf16_t*)qkv, ubias, vbias,
                           (const bf16_t*)pext, lengths, (bf16_t*)out, lse, B, H, T, scale, use_mask, chunk, hist);
   TFASR_CHECK_LAUNCH();
   return TFASR_STATUS_SUCCESS;
@@ -1200,7 +1200,7 @@ extern "C" int tfasr_relattn_fused_bwd_q3(const void* qkv, const float* ubias, c
   }
   const dim3 gq(attn_grid_size(B, H, (T + BI - 1) / BI));
 #define TFASR_QT_LAUNCH(ST)                                                                                                                  \
-  hipLaunchKernelGGL((relattn_fused_bwd_qT_kernel<ST, 1>), gq, dim3(256), qt_smem(1), (hipStream_t)stream_, (const bf16_t*)qkv, ubias, vbias,   \
+  TFASR_KLAUNCH((relattn_fused_bwd_qT_kernel<ST, 1>), gq, dim3(256), qt_smem(1), (hipStream_t)stream_, (const bf16_t*)qkv, ubias, vbias,   \
                      (const bf16_t*)pext, lengths, (const bf16_t*)o, (const bf16_t*)dout, lse, (bf16_t*)dq, (bf16_t*)ds, dvec, B, H, T, lds, scale, \
                      use_mask, dpext, lddq, du, dv, chunk > 0 ? chunk : 0, chunk > 0 ? hist : 0, (bf16_t*)qu, (bf16_t*)qv)
   if (chunk > 0) TFASR_QT_LAUNCH(true); else TFASR_QT_LAUNCH(false);
@@ -1220,7 +1220,7 @@ extern "C" int tfasr_relattn_dpext(const void* ds, const void* qv, const int32_t
   int groups = std::max(1, std::min(B, target / std::max(1, cblocks * H)));
   const int bchunk = (B + groups - 1) / groups;
   groups = (B + bchunk - 1) / bchunk;
-  hipLaunchKernelGGL(relattn_dpext_kernel, dim3(cblocks, H, groups), dim3(256), SMEM_DPX, (hipStream_t)stream_, (const bf16_t*)ds, (const bf16_t*)qv,
+  TFASR_KLAUNCH(relattn_dpext_kernel, dim3(cblocks, H, groups), dim3(256), SMEM_DPX, (hipStream_t)stream_, (const bf16_t*)ds, (const bf16_t*)qv,
                      lengths, dpext, B, H, T, lds, use_mask, bchunk);
   TFASR_CHECK_LAUNCH();
   return TFASR_STATUS_SUCCESS;
@@ -1233,10 +1233,10 @@ extern "C" int tfasr_relattn_fused_bwd_k(const void* qkv, const void* qu, const 
   if (dtype != TFASR_BF16 || dh != DH) return TFASR_STATUS_UNSUPPORTED;
   const dim3 gk(attn_grid_size(B, H, (T + BJ - 1) / BJ));
   if (chunk > 0)
-    hipLaunchKernelGGL(relattn_fused_bwd_k_kernel<true>, gk, dim3(256), SMEM_BWD_K, (hipStream_t)stream_, (const bf16_t*)qkv, (const bf16_t*)qu,
+    TFASR_KLAUNCH(relattn_fused_bwd_k_kernel<true>, gk, dim3(256), SMEM_BWD_K, (hipStream_t)stream_, (const bf16_t*)qkv, (const bf16_t*)qu,
                        (const bf16_t*)qv, (const bf16_t*)pext, lengths, (const bf16_t*)dout, lse, dvec, (bf16_t*)dqkv, B, H, T, scale, use_mask, chunk, hist);
   else
-    hipLaunchKernelGGL(relattn_fused_bwd_k_kernel<false>, gk, dim3(256), SMEM_BWD_K, (hipStream_t)stream_, (const bf16_t*)qkv, (const bf16_t*)qu,
+    TFASR_KLAUNCH(relattn_fused_bwd_k_kernel<false>, gk, dim3(256), SMEM_BWD_K, (hipStream_t)stream_, (const bf16_t*)qkv, (const bf16_t*)qu,
                        (const bf16_t*)qv, (const bf16_t*)pext, lengths, (const bf16_t*)dout, lse, dvec, (bf16_t*)dqkv, B, H, T, scale, use_mask, 0, 0);
   TFASR_CHECK_LAUNCH();
   return TFASR_STATUS_SUCCESS;

@@ -9,11 +9,16 @@
 
 #define TFASR_WAVE 64
 
-// Every kernel of the library is launched through hipLaunchKernelGGL: count the launches (host-side statistic behind tfasr_launch_count(),
-// what bench.py reports as `launches_per_step`; a kernel boundary costs 2.65 us on this chip, so the count is a quantity to watch).
-extern "C" size_t g_tfasr_launch_count;  // api.hip
-#undef hipLaunchKernelGGL
-#define hipLaunchKernelGGL(kernelName, ...) do { ++g_tfasr_launch_count; hipLaunchKernelGGLInternal((kernelName), __VA_ARGS__); } while (0)
+// Every kernel of the library is launched through TFASR_KLAUNCH (the chevron launch + a host-side count: the statistic behind
+// tfasr_launch_count(), what bench.py reports as `launches_per_step`; a kernel boundary costs 1.5-2.7 us on this chip, so the count is a
+// quantity to watch).  Arguments as hipLaunchKernelGGL's; a templated kernel name goes in parentheses.
+#include <atomic>
+extern std::atomic<size_t> g_tfasr_launch_count;  // api.hip
+#define TFASR_KLAUNCH(kernelName, numBlocks, numThreads, memPerBlock, streamId, ...)                  \
+  do {                                                                                                \
+    g_tfasr_launch_count.fetch_add(1, std::memory_order_relaxed);                                     \
+    kernelName<<<(numBlocks), (numThreads), (memPerBlock), (streamId)>>>(__VA_ARGS__);               \
+  } while (0)
 
 typedef uint16_t bf16_t;  // raw bfloat16 bits
 

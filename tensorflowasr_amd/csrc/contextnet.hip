@@ -161,8 +161,8 @@ extern "C" int tfasr_rows_subsample_fwd(const void* x, void* y, int B, int T, in
   const int T2 = (T + stride - 1) / stride;
   hipStream_t s = (hipStream_t)stream_;
   const int g = flat_grid((long)B * T2 * C / 8);
-  CN_DISPATCH(dtype, hipLaunchKernelGGL(subsample_fwd_kernel<float>, dim3(g), dim3(256), 0, s, (const float*)x, (float*)y, B, T, T2, C, stride),
-              hipLaunchKernelGGL(subsample_fwd_kernel<bf16_t>, dim3(g), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, B, T, T2, C, stride));
+  CN_DISPATCH(dtype, TFASR_KLAUNCH(subsample_fwd_kernel<float>, dim3(g), dim3(256), 0, s, (const float*)x, (float*)y, B, T, T2, C, stride),
+              TFASR_KLAUNCH(subsample_fwd_kernel<bf16_t>, dim3(g), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, B, T, T2, C, stride));
   TFASR_CHECK_LAUNCH();
   return TFASR_STATUS_SUCCESS;
 }
@@ -171,8 +171,8 @@ extern "C" int tfasr_rows_subsample_bwd(const void* dy, void* dx, int B, int T, 
   const int T2 = (T + stride - 1) / stride;
   hipStream_t s = (hipStream_t)stream_;
   const int g = flat_grid((long)B * T * C / 8);
-  CN_DISPATCH(dtype, hipLaunchKernelGGL(subsample_bwd_kernel<float>, dim3(g), dim3(256), 0, s, (const float*)dy, (float*)dx, B, T, T2, C, stride),
-              hipLaunchKernelGGL(subsample_bwd_kernel<bf16_t>, dim3(g), dim3(256), 0, s, (const bf16_t*)dy, (bf16_t*)dx, B, T, T2, C, stride));
+  CN_DISPATCH(dtype, TFASR_KLAUNCH(subsample_bwd_kernel<float>, dim3(g), dim3(256), 0, s, (const float*)dy, (float*)dx, B, T, T2, C, stride),
+              TFASR_KLAUNCH(subsample_bwd_kernel<bf16_t>, dim3(g), dim3(256), 0, s, (const bf16_t*)dy, (bf16_t*)dx, B, T, T2, C, stride));
   TFASR_CHECK_LAUNCH();
   return TFASR_STATUS_SUCCESS;
 }
@@ -180,8 +180,8 @@ extern "C" int tfasr_se_pool(const void* x, const int32_t* lengths, float* pool,
   if (!x || !pool || B <= 0 || T <= 0 || C <= 0 || (C & 7)) return TFASR_STATUS_INVALID_VALUE;
   hipStream_t s = (hipStream_t)stream_;
   dim3 g((C + 255) / 256, B);
-  CN_DISPATCH(dtype, hipLaunchKernelGGL((se_reduce_kernel<float, 0>), g, dim3(256), 0, s, (const float*)x, (const float*)nullptr, lengths, pool, T, C),
-              hipLaunchKernelGGL((se_reduce_kernel<bf16_t, 0>), g, dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)nullptr, lengths, pool, T, C));
+  CN_DISPATCH(dtype, TFASR_KLAUNCH((se_reduce_kernel<float, 0>), g, dim3(256), 0, s, (const float*)x, (const float*)nullptr, lengths, pool, T, C),
+              TFASR_KLAUNCH((se_reduce_kernel<bf16_t, 0>), g, dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)nullptr, lengths, pool, T, C));
   TFASR_CHECK_LAUNCH();
   return TFASR_STATUS_SUCCESS;
 }
@@ -189,8 +189,8 @@ extern "C" int tfasr_se_scale_fwd(const void* x, const float* scale, void* y, in
   if (!x || !scale || !y || B <= 0 || T <= 0 || C <= 0 || (C & 7)) return TFASR_STATUS_INVALID_VALUE;
   hipStream_t s = (hipStream_t)stream_;
   const int g = flat_grid((long)B * T * C / 8);
-  CN_DISPATCH(dtype, hipLaunchKernelGGL(se_scale_kernel<float>, dim3(g), dim3(256), 0, s, (const float*)x, scale, (float*)y, B, T, C),
-              hipLaunchKernelGGL(se_scale_kernel<bf16_t>, dim3(g), dim3(256), 0, s, (const bf16_t*)x, scale, (bf16_t*)y, B, T, C));
+  CN_DISPATCH(dtype, TFASR_KLAUNCH(se_scale_kernel<float>, dim3(g), dim3(256), 0, s, (const float*)x, scale, (float*)y, B, T, C),
+              TFASR_KLAUNCH(se_scale_kernel<bf16_t>, dim3(g), dim3(256), 0, s, (const bf16_t*)x, scale, (bf16_t*)y, B, T, C));
   TFASR_CHECK_LAUNCH();
   return TFASR_STATUS_SUCCESS;
 }
@@ -198,8 +198,8 @@ extern "C" int tfasr_se_scale_bwd_reduce(const void* x, const void* dy, float* d
   if (!x || !dy || !dscale || B <= 0 || T <= 0 || C <= 0 || (C & 7)) return TFASR_STATUS_INVALID_VALUE;
   hipStream_t s = (hipStream_t)stream_;
   dim3 g((C + 255) / 256, B);
-  CN_DISPATCH(dtype, hipLaunchKernelGGL((se_reduce_kernel<float, 1>), g, dim3(256), 0, s, (const float*)x, (const float*)dy, (const int32_t*)nullptr, dscale, T, C),
-              hipLaunchKernelGGL((se_reduce_kernel<bf16_t, 1>), g, dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)dy, (const int32_t*)nullptr, dscale, T, C));
+  CN_DISPATCH(dtype, TFASR_KLAUNCH((se_reduce_kernel<float, 1>), g, dim3(256), 0, s, (const float*)x, (const float*)dy, (const int32_t*)nullptr, dscale, T, C),
+              TFASR_KLAUNCH((se_reduce_kernel<bf16_t, 1>), g, dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)dy, (const int32_t*)nullptr, dscale, T, C));
   TFASR_CHECK_LAUNCH();
   return TFASR_STATUS_SUCCESS;
 }
@@ -208,8 +208,8 @@ extern "C" int tfasr_se_bwd_apply(const void* dy, const float* scale, const floa
   if (!dy || !scale || !dpool || !dx || B <= 0 || T <= 0 || C <= 0 || (C & 7)) return TFASR_STATUS_INVALID_VALUE;
   hipStream_t s = (hipStream_t)stream_;
   const int g = flat_grid((long)B * T * C / 8);
-  CN_DISPATCH(dtype, hipLaunchKernelGGL(se_bwd_apply_kernel<float>, dim3(g), dim3(256), 0, s, (const float*)dy, scale, dpool, lengths, (float*)dx, B, T, C),
-              hipLaunchKernelGGL(se_bwd_apply_kernel<bf16_t>, dim3(g), dim3(256), 0, s, (const bf16_t*)dy, scale, dpool, lengths, (bf16_t*)dx, B, T, C));
+  CN_DISPATCH(dtype, TFASR_KLAUNCH(se_bwd_apply_kernel<float>, dim3(g), dim3(256), 0, s, (const float*)dy, scale, dpool, lengths, (float*)dx, B, T, C),
+              TFASR_KLAUNCH(se_bwd_apply_kernel<bf16_t>, dim3(g), dim3(256), 0, s, (const bf16_t*)dy, scale, dpool, lengths, (bf16_t*)dx, B, T, C));
   TFASR_CHECK_LAUNCH();
   return TFASR_STATUS_SUCCESS;
 }
@@ -217,8 +217,8 @@ extern "C" int tfasr_add_act_fwd(const void* a, const void* b, void* y, long n, 
   if (!a || !y || n <= 0 || (n & 7)) return TFASR_STATUS_INVALID_VALUE;
   hipStream_t s = (hipStream_t)stream_;
   const int g = flat_grid(n / 8);
-  CN_DISPATCH(dtype, hipLaunchKernelGGL(add_act_fwd_kernel<float>, dim3(g), dim3(256), 0, s, (const float*)a, (const float*)b, (float*)y, n / 8, act),
-              hipLaunchKernelGGL(add_act_fwd_kernel<bf16_t>, dim3(g), dim3(256), 0, s, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)y, n / 8, act));
+  CN_DISPATCH(dtype, TFASR_KLAUNCH(add_act_fwd_kernel<float>, dim3(g), dim3(256), 0, s, (const float*)a, (const float*)b, (float*)y, n / 8, act),
+              TFASR_KLAUNCH(add_act_fwd_kernel<bf16_t>, dim3(g), dim3(256), 0, s, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)y, n / 8, act));
   TFASR_CHECK_LAUNCH();
   return TFASR_STATUS_SUCCESS;
 }
@@ -226,8 +226,8 @@ extern "C" int tfasr_add_act_bwd(const void* a, const void* b, const void* dy, v
   if (!a || !dy || !d || n <= 0 || (n & 7)) return TFASR_STATUS_INVALID_VALUE;
   hipStream_t s = (hipStream_t)stream_;
   const int g = flat_grid(n / 8);
-  CN_DISPATCH(dtype, hipLaunchKernelGGL(add_act_bwd_kernel<float>, dim3(g), dim3(256), 0, s, (const float*)a, (const float*)b, (const float*)dy, (float*)d, n / 8, act),
-              hipLaunchKernelGGL(add_act_bwd_kernel<bf16_t>, dim3(g), dim3(256), 0, s, (const bf16_t*)a, (const bf16_t*)b, (const bf16_t*)dy, (bf16_t*)d, n / 8, act));
+  CN_DISPATCH(dtype, TFASR_KLAUNCH(add_act_bwd_kernel<float>, dim3(g), dim3(256), 0, s, (const float*)a, (const float*)b, (const float*)dy, (float*)d, n / 8, act),
+              TFASR_KLAUNCH(add_act_bwd_kernel<bf16_t>, dim3(g), dim3(256), 0, s, (const bf16_t*)a, (const bf16_t*)b, (const bf16_t*)dy, (bf16_t*)d, n / 8, act));
   TFASR_CHECK_LAUNCH();
   return TFASR_STATUS_SUCCESS;
 }

@@ -637,8 +637,8 @@ static int conv1_fwd_impl(const void* x, const float* w, const float* bias, void
   if (C == 256 && F0 + 2 <= 260) {
     const int g2 = std::min(B * T1, 8192);
     DISPATCH_T(dtype,
-               hipLaunchKernelGGL(conv1_fwd_rows_kernel<float>, dim3(g2), dim3(256), 0, s, (const float*)x, w, bias, (float*)y, B, T0, F0, T1, F1, s2d),
-               hipLaunchKernelGGL(conv1_fwd_rows_kernel<bf16_t>, dim3(g2), dim3(256), 0, s, (const bf16_t*)x, w, bias, (bf16_t*)y, B, T0, F0, T1, F1, s2d));
+               TFASR_KLAUNCH(conv1_fwd_rows_kernel<float>, dim3(g2), dim3(256), 0, s, (const float*)x, w, bias, (float*)y, B, T0, F0, T1, F1, s2d),
+               TFASR_KLAUNCH(conv1_fwd_rows_kernel<bf16_t>, dim3(g2), dim3(256), 0, s, (const bf16_t*)x, w, bias, (bf16_t*)y, B, T0, F0, T1, F1, s2d));
     TFASR_CHECK_LAUNCH();
     return TFASR_STATUS_SUCCESS;
   }
@@ -648,8 +648,8 @@ static int conv1_fwd_impl(const void* x, const float* w, const float* bias, void
     grid = ((grid + c8n - 1) / c8n) * c8n;
   }
   DISPATCH_T(dtype,
-             hipLaunchKernelGGL(conv1_fwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, w, bias, (float*)y, B, T0, F0, T1, F1, C, s2d),
-             hipLaunchKernelGGL(conv1_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)x, w, bias, (bf16_t*)y, B, T0, F0, T1, F1, C, s2d));
+             TFASR_KLAUNCH(conv1_fwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, w, bias, (float*)y, B, T0, F0, T1, F1, C, s2d),
+             TFASR_KLAUNCH(conv1_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)x, w, bias, (bf16_t*)y, B, T0, F0, T1, F1, C, s2d));
   TFASR_CHECK_LAUNCH();
   return TFASR_STATUS_SUCCESS;
 }
@@ -671,16 +671,16 @@ static int conv1_bwd_weight_impl(const void* x, const void* dy, float* dw, float
   if (C == 256 && F0 + 2 <= 260) {
     const int g2 = std::min(B * T1, 1024);
     DISPATCH_T(dtype,
-               hipLaunchKernelGGL(conv1_bwd_weight_rows_kernel<float>, dim3(g2), dim3(256), 0, s, (const float*)x, (const float*)dy, dw, db, B, T0, F0, T1, F1, s2d),
-               hipLaunchKernelGGL(conv1_bwd_weight_rows_kernel<bf16_t>, dim3(g2), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)dy, dw, db, B, T0, F0, T1, F1, s2d));
+               TFASR_KLAUNCH(conv1_bwd_weight_rows_kernel<float>, dim3(g2), dim3(256), 0, s, (const float*)x, (const float*)dy, dw, db, B, T0, F0, T1, F1, s2d),
+               TFASR_KLAUNCH(conv1_bwd_weight_rows_kernel<bf16_t>, dim3(g2), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)dy, dw, db, B, T0, F0, T1, F1, s2d));
     TFASR_CHECK_LAUNCH();
     return TFASR_STATUS_SUCCESS;
   }
   const long npos = (long)B * T1 * F1;
   const int grid = (int)std::max<long>(1, std::min<long>(npos / 64 + 1, 1024));
   DISPATCH_T(dtype,
-             hipLaunchKernelGGL((conv1_bwd_weight_kernel<float, 32>), dim3(grid), dim3(256), 0, s, (const float*)x, (const float*)dy, dw, db, B, T0, F0, T1, F1, C, s2d),
-             hipLaunchKernelGGL((conv1_bwd_weight_kernel<bf16_t, 32>), dim3(grid), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)dy, dw, db, B, T0, F0, T1, F1, C, s2d));
+             TFASR_KLAUNCH((conv1_bwd_weight_kernel<float, 32>), dim3(grid), dim3(256), 0, s, (const float*)x, (const float*)dy, dw, db, B, T0, F0, T1, F1, C, s2d),
+             TFASR_KLAUNCH((conv1_bwd_weight_kernel<bf16_t, 32>), dim3(grid), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)dy, dw, db, B, T0, F0, T1, F1, C, s2d));
   TFASR_CHECK_LAUNCH();
   return TFASR_STATUS_SUCCESS;
 }
@@ -723,9 +723,9 @@ static int conv1_bn_launch(const void* x, const float* w, const float* bias, con
   const size_t smem = (size_t)(3 * (F0 + 2) + NQL * C) * sizeof(float);
   const float inv = count > 0.f ? 1.f / count : 0.f;
   DISPATCH_T(dtype,
-             hipLaunchKernelGGL((conv1_bn_kernel<float, MODE, CPT>), dim3(grid), dim3(256), smem, s, (const float*)x, w, bias, fin, bstats, inv, (float*)y,
+             TFASR_KLAUNCH((conv1_bn_kernel<float, MODE, CPT>), dim3(grid), dim3(256), smem, s, (const float*)x, w, bias, fin, bstats, inv, (float*)y,
                                 (const float*)dy, out0, out1, B, T0, F0, T1, F1, C),
-             hipLaunchKernelGGL((conv1_bn_kernel<bf16_t, MODE, CPT>), dim3(grid), dim3(256), smem, s, (const bf16_t*)x, w, bias, fin, bstats, inv, (bf16_t*)y,
+             TFASR_KLAUNCH((conv1_bn_kernel<bf16_t, MODE, CPT>), dim3(grid), dim3(256), smem, s, (const bf16_t*)x, w, bias, fin, bstats, inv, (bf16_t*)y,
                                 (const bf16_t*)dy, out0, out1, B, T0, F0, T1, F1, C));
   TFASR_CHECK_LAUNCH();
   return TFASR_STATUS_SUCCESS;
@@ -760,14 +760,14 @@ extern "C" int tfasr_conv1_gram(const void* x, double* gram, int B, int T0, int 
   if (hipMemsetAsync(gram, 0, GRAM_COPIES * GRAM_STRIDE * sizeof(double), s) != hipSuccess) return TFASR_STATUS_EXECUTION_FAILED;
   const int grid = std::max(1, std::min((B * T1 + 5) / 6, 1024));
   const size_t smem = (size_t)6 * 3 * (F0 + 2) * sizeof(float);
-  DISPATCH_T(dtype, hipLaunchKernelGGL(conv1_gram_kernel<float>, dim3(grid), dim3(256), smem, s, (const float*)x, gram, B, T0, F0, T1, F1),
-             hipLaunchKernelGGL(conv1_gram_kernel<bf16_t>, dim3(grid), dim3(256), smem, s, (const bf16_t*)x, gram, B, T0, F0, T1, F1));
+  DISPATCH_T(dtype, TFASR_KLAUNCH(conv1_gram_kernel<float>, dim3(grid), dim3(256), smem, s, (const float*)x, gram, B, T0, F0, T1, F1),
+             TFASR_KLAUNCH(conv1_gram_kernel<bf16_t>, dim3(grid), dim3(256), smem, s, (const bf16_t*)x, gram, B, T0, F0, T1, F1));
   TFASR_CHECK_LAUNCH();
   return TFASR_STATUS_SUCCESS;
 }
 extern "C" int tfasr_conv1_stats_from_gram(const double* gram, const float* w, const float* bias, float* stats, int C, void* stream_) {
   if (!gram || !w || !stats || C <= 0) return TFASR_STATUS_INVALID_VALUE;
-  hipLaunchKernelGGL(conv1_stats_from_gram_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream_, gram, w, bias, stats, C);
+  TFASR_KLAUNCH(conv1_stats_from_gram_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream_, gram, w, bias, stats, C);
   TFASR_CHECK_LAUNCH();
   return TFASR_STATUS_SUCCESS;
 }
@@ -779,7 +779,7 @@ extern "C" int tfasr_conv1_bn_bwd_onepass_s2d(const void* x, const float* w, con
 extern "C" int tfasr_conv1_bn_bwd_finalize(const double* gram, const float* w, const float* bias, const float* fin, const float* bstats,
                                            float count, const float* pbuf, float* dw, float* db, int C, void* stream_) {
   if (!gram || !w || !fin || !bstats || !pbuf || !dw || C <= 0 || count <= 0.f) return TFASR_STATUS_INVALID_VALUE;
-  hipLaunchKernelGGL(conv1_bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream_, gram, w, bias, fin, bstats,
+  TFASR_KLAUNCH(conv1_bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream_, gram, w, bias, fin, bstats,
                      1.f / count, pbuf, dw, db, C);
   TFASR_CHECK_LAUNCH();
   return TFASR_STATUS_SUCCESS;
@@ -789,8 +789,8 @@ extern "C" int tfasr_halo_zero(void* x, int B, int T2, int F2, int W, int dtype,
   if (!x || B <= 0 || T2 <= 0 || F2 <= 0 || W <= 0 || W % 8) return TFASR_STATUS_INVALID_VALUE;
   hipStream_t s = (hipStream_t)stream_;
   const int grid = flat_grid((long)B * ((F2 + 1) + T2) * (W / 8));
-  DISPATCH_T(dtype, hipLaunchKernelGGL(halo_zero_kernel<float>, dim3(grid), dim3(256), 0, s, (float*)x, B, T2, F2, W),
-             hipLaunchKernelGGL(halo_zero_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (bf16_t*)x, B, T2, F2, W));
+  DISPATCH_T(dtype, TFASR_KLAUNCH(halo_zero_kernel<float>, dim3(grid), dim3(256), 0, s, (float*)x, B, T2, F2, W),
+             TFASR_KLAUNCH(halo_zero_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (bf16_t*)x, B, T2, F2, W));
   TFASR_CHECK_LAUNCH();
   return TFASR_STATUS_SUCCESS;
 }
@@ -801,8 +801,8 @@ extern "C" int tfasr_s2d_edge_zero(void* x, int B, int T1, int F1, int C, int dt
   const int T2 = (T1 + 1) / 2, F2 = (F1 + 1) / 2;
   hipStream_t s = (hipStream_t)stream_;
   const int grid = flat_grid((long)B * (((T1 & 1) ? F2 * 2 : 0) + ((F1 & 1) ? T2 * 2 : 0)) * (C / 8));
-  DISPATCH_T(dtype, hipLaunchKernelGGL(s2d_edge_zero_kernel<float>, dim3(grid), dim3(256), 0, s, (float*)x, B, T1, F1, T2, F2, C),
-             hipLaunchKernelGGL(s2d_edge_zero_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (bf16_t*)x, B, T1, F1, T2, F2, C));
+  DISPATCH_T(dtype, TFASR_KLAUNCH(s2d_edge_zero_kernel<float>, dim3(grid), dim3(256), 0, s, (float*)x, B, T1, F1, T2, F2, C),
+             TFASR_KLAUNCH(s2d_edge_zero_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (bf16_t*)x, B, T1, F1, T2, F2, C));
   TFASR_CHECK_LAUNCH();
   return TFASR_STATUS_SUCCESS;
 }
@@ -813,8 +813,8 @@ extern "C" int tfasr_im2col_3x3s2(const void* x, void* col, int B, int T1, int F
   hipStream_t s = (hipStream_t)stream_;
   const int grid = flat_grid((long)B * T2 * F2 * 9 * C / 8);
   DISPATCH_T(dtype,
-             hipLaunchKernelGGL(im2col_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, (float*)col, B, T1, F1, T2, F2, C),
-             hipLaunchKernelGGL(im2col_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)col, B, T1, F1, T2, F2, C));
+             TFASR_KLAUNCH(im2col_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, (float*)col, B, T1, F1, T2, F2, C),
+             TFASR_KLAUNCH(im2col_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)col, B, T1, F1, T2, F2, C));
   TFASR_CHECK_LAUNCH();
   return TFASR_STATUS_SUCCESS;
 }
@@ -825,8 +825,8 @@ extern "C" int tfasr_col2im_3x3s2(const void* dcol, void* dx, int B, int T1, int
   hipStream_t s = (hipStream_t)stream_;
   const int grid = flat_grid((long)B * T1 * F1 * C / 8);
   DISPATCH_T(dtype,
-             hipLaunchKernelGGL(col2im_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)dcol, (float*)dx, B, T1, F1, T2, F2, C),
-             hipLaunchKernelGGL(col2im_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)dcol, (bf16_t*)dx, B, T1, F1, T2, F2, C));
+             TFASR_KLAUNCH(col2im_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)dcol, (float*)dx, B, T1, F1, T2, F2, C),
+             TFASR_KLAUNCH(col2im_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)dcol, (bf16_t*)dx, B, T1, F1, T2, F2, C));
   TFASR_CHECK_LAUNCH();
   return TFASR_STATUS_SUCCESS;
 }

@@ -187,13 +187,13 @@ extern "C" int tfasr_ctc_loss(const void* logits, void* grads, const int32_t* la
   const int grid = (int)std::max<long>(1, std::min<long>((rows + 3) / 4, 8192));
   const int nthr = (int)((S + 63) / 64) * 64;
   if (dtype == TFASR_F32) {
-    hipLaunchKernelGGL(ctc_lse_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)logits, lse, (int32_t*)nullptr, rows, V);
-    hipLaunchKernelGGL(ctc_scan_kernel<float>, dim3(B, 2), dim3(nthr), 2 * nthr * sizeof(float), s, (const float*)logits, lse, labels, label_len, logit_len, T, U, V, blank, alpha, beta, costs);
-    if (grads) hipLaunchKernelGGL(ctc_grad_kernel<float>, dim3(B * T), dim3(256), V * sizeof(float), s, (const float*)logits, (float*)grads, lse, labels, label_len, logit_len, grad_scale, alpha, beta, costs, T, U, V, blank);
+    TFASR_KLAUNCH(ctc_lse_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)logits, lse, (int32_t*)nullptr, rows, V);
+    TFASR_KLAUNCH(ctc_scan_kernel<float>, dim3(B, 2), dim3(nthr), 2 * nthr * sizeof(float), s, (const float*)logits, lse, labels, label_len, logit_len, T, U, V, blank, alpha, beta, costs);
+    if (grads) TFASR_KLAUNCH(ctc_grad_kernel<float>, dim3(B * T), dim3(256), V * sizeof(float), s, (const float*)logits, (float*)grads, lse, labels, label_len, logit_len, grad_scale, alpha, beta, costs, T, U, V, blank);
   } else if (dtype == TFASR_BF16) {
-    hipLaunchKernelGGL(ctc_lse_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)logits, lse, (int32_t*)nullptr, rows, V);
-    hipLaunchKernelGGL(ctc_scan_kernel<bf16_t>, dim3(B, 2), dim3(nthr), 2 * nthr * sizeof(float), s, (const bf16_t*)logits, lse, labels, label_len, logit_len, T, U, V, blank, alpha, beta, costs);
-    if (grads) hipLaunchKernelGGL(ctc_grad_kernel<bf16_t>, dim3(B * T), dim3(256), V * sizeof(float), s, (const bf16_t*)logits, (bf16_t*)grads, lse, labels, label_len, logit_len, grad_scale, alpha, beta, costs, T, U, V, blank);
+    TFASR_KLAUNCH(ctc_lse_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)logits, lse, (int32_t*)nullptr, rows, V);
+    TFASR_KLAUNCH(ctc_scan_kernel<bf16_t>, dim3(B, 2), dim3(nthr), 2 * nthr * sizeof(float), s, (const bf16_t*)logits, lse, labels, label_len, logit_len, T, U, V, blank, alpha, beta, costs);
+    if (grads) TFASR_KLAUNCH(ctc_grad_kernel<bf16_t>, dim3(B * T), dim3(256), V * sizeof(float), s, (const bf16_t*)logits, (bf16_t*)grads, lse, labels, label_len, logit_len, grad_scale, alpha, beta, costs, T, U, V, blank);
   } else return TFASR_STATUS_INVALID_VALUE;
   TFASR_CHECK_LAUNCH();
   return TFASR_STATUS_SUCCESS;
@@ -205,10 +205,10 @@ extern "C" int tfasr_ctc_greedy_decode(const void* logits, const int32_t* logit_
   hipStream_t s = (hipStream_t)stream_;
   const long rows = (long)B * T;
   const int grid = (int)std::max<long>(1, std::min<long>((rows + 3) / 4, 8192));
-  if (dtype == TFASR_F32) hipLaunchKernelGGL(ctc_lse_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)logits, (float*)nullptr, workspace_argmax, rows, V);
-  else if (dtype == TFASR_BF16) hipLaunchKernelGGL(ctc_lse_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)logits, (float*)nullptr, workspace_argmax, rows, V);
+  if (dtype == TFASR_F32) TFASR_KLAUNCH(ctc_lse_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)logits, (float*)nullptr, workspace_argmax, rows, V);
+  else if (dtype == TFASR_BF16) TFASR_KLAUNCH(ctc_lse_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)logits, (float*)nullptr, workspace_argmax, rows, V);
   else return TFASR_STATUS_INVALID_VALUE;
-  hipLaunchKernelGGL(ctc_collapse_kernel, dim3((B + 63) / 64), dim3(64), 0, s, workspace_argmax, logit_len, tokens, tokens_len, B, T, blank);
+  TFASR_KLAUNCH(ctc_collapse_kernel, dim3((B + 63) / 64), dim3(64), 0, s, workspace_argmax, logit_len, tokens, tokens_len, B, T, blank);
   TFASR_CHECK_LAUNCH();
   return TFASR_STATUS_SUCCESS;
 }

@@ -213,9 +213,9 @@ extern "C" int tfasr_decode_prepare(const void* encj, const int32_t* nframes, co
   if (!encj || !nframes || !frame_idx || !tok_idx || !active || !ecur || B <= 0 || T <= 0 || J <= 0) return TFASR_STATUS_INVALID_VALUE;
   hipStream_t s = (hipStream_t)stream_;
   if (dtype == TFASR_F32)
-    hipLaunchKernelGGL(decode_prepare_kernel<float>, dim3(1), dim3(256), 0, s, (const float*)encj, nframes, frame_idx, tok_idx, active, (float*)ecur, B, T, J, max_tokens, mode);
+    TFASR_KLAUNCH(decode_prepare_kernel<float>, dim3(1), dim3(256), 0, s, (const float*)encj, nframes, frame_idx, tok_idx, active, (float*)ecur, B, T, J, max_tokens, mode);
   else if (dtype == TFASR_BF16)
-    hipLaunchKernelGGL(decode_prepare_kernel<bf16_t>, dim3(1), dim3(256), 0, s, (const bf16_t*)encj, nframes, frame_idx, tok_idx, active, (bf16_t*)ecur, B, T, J, max_tokens, mode);
+    TFASR_KLAUNCH(decode_prepare_kernel<bf16_t>, dim3(1), dim3(256), 0, s, (const bf16_t*)encj, nframes, frame_idx, tok_idx, active, (bf16_t*)ecur, B, T, J, max_tokens, mode);
   else return TFASR_STATUS_INVALID_VALUE;
   TFASR_CHECK_LAUNCH();
   return TFASR_STATUS_SUCCESS;
@@ -230,16 +230,16 @@ extern "C" int tfasr_decode_update(const void* logits, const int32_t* active, co
   if (B <= 0 || V <= 0 || P <= 0 || (mode == 1 && (B != 1 || !per_frame))) return TFASR_STATUS_INVALID_VALUE;
   hipStream_t s = (hipStream_t)stream_;
   if (dtype == TFASR_F32 && P <= 1024 && V <= 4096) {
-#define TFASR_DU(NV) hipLaunchKernelGGL(decode_update_regs_kernel<NV>, dim3(B), dim3(256), 0, s, (const float*)logits, active, nframes, frame_idx, prev_tok, \
+#define TFASR_DU(NV) TFASR_KLAUNCH(decode_update_regs_kernel<NV>, dim3(B), dim3(256), 0, s, (const float*)logits, active, nframes, frame_idx, prev_tok, \
                                         tok_idx, tokens, per_frame, (const float*)h_new, c_new, (float*)h, c, B, V, P, max_tokens, blank, mode, max_tokens_per_frame)
     if (V <= 1024) TFASR_DU(4);
     else if (V <= 2048) TFASR_DU(8);
     else TFASR_DU(16);
 #undef TFASR_DU
   } else if (dtype == TFASR_F32)
-    hipLaunchKernelGGL(decode_update_kernel<float>, dim3(B), dim3(256), 0, s, (const float*)logits, active, nframes, frame_idx, prev_tok, tok_idx, tokens, per_frame, (const float*)h_new, c_new, (float*)h, c, B, V, P, max_tokens, blank, mode, max_tokens_per_frame);
+    TFASR_KLAUNCH(decode_update_kernel<float>, dim3(B), dim3(256), 0, s, (const float*)logits, active, nframes, frame_idx, prev_tok, tok_idx, tokens, per_frame, (const float*)h_new, c_new, (float*)h, c, B, V, P, max_tokens, blank, mode, max_tokens_per_frame);
   else if (dtype == TFASR_BF16)
-    hipLaunchKernelGGL(decode_update_kernel<bf16_t>, dim3(B), dim3(256), 0, s, (const bf16_t*)logits, active, nframes, frame_idx, prev_tok, tok_idx, tokens, per_frame, (const bf16_t*)h_new, c_new, (bf16_t*)h, c, B, V, P, max_tokens, blank, mode, max_tokens_per_frame);
+    TFASR_KLAUNCH(decode_update_kernel<bf16_t>, dim3(B), dim3(256), 0, s, (const bf16_t*)logits, active, nframes, frame_idx, prev_tok, tok_idx, tokens, per_frame, (const bf16_t*)h_new, c_new, (bf16_t*)h, c, B, V, P, max_tokens, blank, mode, max_tokens_per_frame);
   else return TFASR_STATUS_INVALID_VALUE;
   TFASR_CHECK_LAUNCH();
   return TFASR_STATUS_SUCCESS;

@@ -578,12 +578,12 @@ int launch_decode_mfma(const float* packed, const float* lstm_b, const float* ln
   const float* pj = packed + dm.nl;
   const float* pv = pj + dm.nj;
   const float* G = pv + dm.nv;
-  hipLaunchKernelGGL(decode_lstm_mfma_kernel<MT>, dim3(P / 4), dim3(1024), 0, s, G, packed, lstm_b, prev_tok, h, c, encj, nframes, frame_idx, tok_idx,
+  TFASR_KLAUNCH(decode_lstm_mfma_kernel<MT>, dim3(P / 4), dim3(1024), 0, s, G, packed, lstm_b, prev_tok, h, c, encj, nframes, frame_idx, tok_idx,
                      active, h_new, c_new, z, B, T, P, J, V, max_tokens, mode);  // (z doubles as the gathered encoder frames until the joint kernel)
   TFASR_CHECK_LAUNCH();
-  hipLaunchKernelGGL(decode_joint_mfma_kernel<MT>, dim3((J + 15) / 16), dim3(1024), 0, s, h_new, ln_g, ln_b, pj, joint_pred_b, z, active, z, B, P, J, ln_eps);
+  TFASR_KLAUNCH(decode_joint_mfma_kernel<MT>, dim3((J + 15) / 16), dim3(1024), 0, s, h_new, ln_g, ln_b, pj, joint_pred_b, z, active, z, B, P, J, ln_eps);
   TFASR_CHECK_LAUNCH();
-  hipLaunchKernelGGL(decode_vocab_mfma_kernel<MT>, dim3((V + 15) / 16), dim3(1024), 0, s, z, pv, vocab_b, active, logits, B, J, V);
+  TFASR_KLAUNCH(decode_vocab_mfma_kernel<MT>, dim3((V + 15) / 16), dim3(1024), 0, s, z, pv, vocab_b, active, logits, B, J, V);
   TFASR_CHECK_LAUNCH();
   return TFASR_STATUS_SUCCESS;
 }
@@ -608,7 +608,7 @@ extern "C" int tfasr_decode_pack(const float* emb, const float* lstm_k, const fl
   if (n == 0) return TFASR_STATUS_UNSUPPORTED;
   const PackDims dm = pack_dims(E, P, J, V);
   const long nk = dm.nl + dm.nj + dm.nv + dm.nk;  // (threads: every section except G, which the product below fills)
-  hipLaunchKernelGGL(decode_pack_kernel, dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, lstm_k, lstm_rk, joint_pred_w, vocab_w,
+  TFASR_KLAUNCH(decode_pack_kernel, dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, lstm_k, lstm_rk, joint_pred_w, vocab_w,
                      packed, E, P, J, V);
   TFASR_CHECK_LAUNCH();
   // G = emb @ Wk (exact f32, columns in tile order): the input half of the LSTM pre-activation of every token
@@ -644,13 +644,13 @@ extern "C" int tfasr_decode_step(const float* emb, const float* lstm_k, const fl
     TFASR_DM(4);
 #undef TFASR_DM
   }
-  hipLaunchKernelGGL(decode_lstm_kernel<4>, dim3(P / 4), dim3(NT), 0, s, emb, lstm_k, lstm_rk, lstm_b, prev_tok, h, c, nframes, frame_idx, tok_idx,
+  TFASR_KLAUNCH(decode_lstm_kernel<4>, dim3(P / 4), dim3(NT), 0, s, emb, lstm_k, lstm_rk, lstm_b, prev_tok, h, c, nframes, frame_idx, tok_idx,
                      active, h_new, c_new, B, E, P, V, max_tokens, mode);
   TFASR_CHECK_LAUNCH();
-  hipLaunchKernelGGL(decode_joint_kernel<4>, dim3((J + 3) / 4), dim3(NT), 0, s, h_new, ln_g, ln_b, joint_pred_w, joint_pred_b, encj, nframes,
+  TFASR_KLAUNCH(decode_joint_kernel<4>, dim3((J + 3) / 4), dim3(NT), 0, s, h_new, ln_g, ln_b, joint_pred_w, joint_pred_b, encj, nframes,
                      frame_idx, active, z, B, T, P, J, ln_eps);
   TFASR_CHECK_LAUNCH();
-  hipLaunchKernelGGL(decode_vocab_kernel<8>, dim3((V + 7) / 8), dim3(NT), 0, s, z, vocab_w, vocab_b, active, logits, B, J, V);
+  TFASR_KLAUNCH(decode_vocab_kernel<8>, dim3((V + 7) / 8), dim3(NT), 0, s, z, vocab_w, vocab_b, active, logits, B, J, V);
   TFASR_CHECK_LAUNCH();
   return TFASR_STATUS_SUCCESS;
 }

@@ -297,7 +297,7 @@ static int launch_dense_ln_bwd(DenseLnArgs a, int nblk, hipStream_t stream) {
   auto go = [&](auto kern, int m) {
     static bool attr_done = false;
     if (!attr_done) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, dln_smem(m)); attr_done = true; }
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(512), dln_smem(m), stream, a);
+    TFASR_KLAUNCH(kern, dim3((unsigned)nblk), dim3(512), dln_smem(m), stream, a);
   };
   if (mt == 2) go(dense_ln_bwd_kernel<2>, 2);
   else if (mt == 4) go(dense_ln_bwd_kernel<4>, 4);

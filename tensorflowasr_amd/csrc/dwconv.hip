@@ -291,17 +291,17 @@ int tfasr_dwconv_wgrad_ws_try(const void* x, const void* dy, float* dw, float* d
   dim3 grid(gx, gy, B);
   const int smem = (2 * TG + MAXK - 1 + 2 * TG) * ROWB;
   switch (K) {
-    case 31: hipLaunchKernelGGL((dwconv_wgrad_tile_kernel<31>), grid, dim3(256), smem, s, (const bf16_t*)x, (const bf16_t*)dy, dw, dbias, T, C, ws); break;
-    case 32: hipLaunchKernelGGL((dwconv_wgrad_tile_kernel<32>), grid, dim3(256), smem, s, (const bf16_t*)x, (const bf16_t*)dy, dw, dbias, T, C, ws); break;
-    case 15: hipLaunchKernelGGL((dwconv_wgrad_tile_kernel<15>), grid, dim3(256), smem, s, (const bf16_t*)x, (const bf16_t*)dy, dw, dbias, T, C, ws); break;
-    case 7: hipLaunchKernelGGL((dwconv_wgrad_tile_kernel<7>), grid, dim3(256), smem, s, (const bf16_t*)x, (const bf16_t*)dy, dw, dbias, T, C, ws); break;
-    case 5: hipLaunchKernelGGL((dwconv_wgrad_tile_kernel<5>), grid, dim3(256), smem, s, (const bf16_t*)x, (const bf16_t*)dy, dw, dbias, T, C, ws); break;
-    case 3: hipLaunchKernelGGL((dwconv_wgrad_tile_kernel<3>), grid, dim3(256), smem, s, (const bf16_t*)x, (const bf16_t*)dy, dw, dbias, T, C, ws); break;
+    case 31: TFASR_KLAUNCH((dwconv_wgrad_tile_kernel<31>), grid, dim3(256), smem, s, (const bf16_t*)x, (const bf16_t*)dy, dw, dbias, T, C, ws); break;
+    case 32: TFASR_KLAUNCH((dwconv_wgrad_tile_kernel<32>), grid, dim3(256), smem, s, (const bf16_t*)x, (const bf16_t*)dy, dw, dbias, T, C, ws); break;
+    case 15: TFASR_KLAUNCH((dwconv_wgrad_tile_kernel<15>), grid, dim3(256), smem, s, (const bf16_t*)x, (const bf16_t*)dy, dw, dbias, T, C, ws); break;
+    case 7: TFASR_KLAUNCH((dwconv_wgrad_tile_kernel<7>), grid, dim3(256), smem, s, (const bf16_t*)x, (const bf16_t*)dy, dw, dbias, T, C, ws); break;
+    case 5: TFASR_KLAUNCH((dwconv_wgrad_tile_kernel<5>), grid, dim3(256), smem, s, (const bf16_t*)x, (const bf16_t*)dy, dw, dbias, T, C, ws); break;
+    case 3: TFASR_KLAUNCH((dwconv_wgrad_tile_kernel<3>), grid, dim3(256), smem, s, (const bf16_t*)x, (const bf16_t*)dy, dw, dbias, T, C, ws); break;
     default: return TFASR_STATUS_UNSUPPORTED;
   }
   TFASR_CHECK_LAUNCH();
   dim3 rg(((K + 1) * SLAB + 255) / 256, gx, 16);
-  hipLaunchKernelGGL(dwconv_wgrad_reduce_kernel, rg, dim3(256), 0, s, (const float*)ws, dw, dbias, B * gy, gx, K, C);
+  TFASR_KLAUNCH(dwconv_wgrad_reduce_kernel, rg, dim3(256), 0, s, (const float*)ws, dw, dbias, B * gy, gx, K, C);
   TFASR_CHECK_LAUNCH();
   return TFASR_STATUS_SUCCESS;
 }
@@ -323,16 +323,16 @@ int tfasr_dwconv_wgrad_many_try(const void* const* x, const void* const* dy, flo
   dim3 grid(gx, gy, n * B);
   const int smem = (2 * TG + MAXK - 1 + 2 * TG) * ROWB;
   switch (K) {
-    case 31: hipLaunchKernelGGL((dwconv_wgrad_tile_many_kernel<31>), grid, dim3(256), smem, s, tab, B, T, C, ws); break;
-    case 32: hipLaunchKernelGGL((dwconv_wgrad_tile_many_kernel<32>), grid, dim3(256), smem, s, tab, B, T, C, ws); break;
-    case 15: hipLaunchKernelGGL((dwconv_wgrad_tile_many_kernel<15>), grid, dim3(256), smem, s, tab, B, T, C, ws); break;
-    case 7: hipLaunchKernelGGL((dwconv_wgrad_tile_many_kernel<7>), grid, dim3(256), smem, s, tab, B, T, C, ws); break;
-    case 5: hipLaunchKernelGGL((dwconv_wgrad_tile_many_kernel<5>), grid, dim3(256), smem, s, tab, B, T, C, ws); break;
-    default: hipLaunchKernelGGL((dwconv_wgrad_tile_many_kernel<3>), grid, dim3(256), smem, s, tab, B, T, C, ws); break;
+    case 31: TFASR_KLAUNCH((dwconv_wgrad_tile_many_kernel<31>), grid, dim3(256), smem, s, tab, B, T, C, ws); break;
+    case 32: TFASR_KLAUNCH((dwconv_wgrad_tile_many_kernel<32>), grid, dim3(256), smem, s, tab, B, T, C, ws); break;
+    case 15: TFASR_KLAUNCH((dwconv_wgrad_tile_many_kernel<15>), grid, dim3(256), smem, s, tab, B, T, C, ws); break;
+    case 7: TFASR_KLAUNCH((dwconv_wgrad_tile_many_kernel<7>), grid, dim3(256), smem, s, tab, B, T, C, ws); break;
+    case 5: TFASR_KLAUNCH((dwconv_wgrad_tile_many_kernel<5>), grid, dim3(256), smem, s, tab, B, T, C, ws); break;
+    default: TFASR_KLAUNCH((dwconv_wgrad_tile_many_kernel<3>), grid, dim3(256), smem, s, tab, B, T, C, ws); break;
   }
   TFASR_CHECK_LAUNCH();
   dim3 rg(((K + 1) * SLAB + 255) / 256, gx, 16 * n);
-  hipLaunchKernelGGL(dwconv_wgrad_reduce_many_kernel, rg, dim3(256), 0, s, (const float*)ws, out, B * gy, gx, K, C);
+  TFASR_KLAUNCH(dwconv_wgrad_reduce_many_kernel, rg, dim3(256), 0, s, (const float*)ws, out, B * gy, gx, K, C);
   TFASR_CHECK_LAUNCH();
   return TFASR_STATUS_SUCCESS;
 }
@@ -345,7 +345,7 @@ extern "C" int tfasr_dwconv_bwd_data_glu(const void* dy, const float* w, const v
   const int gx = (C + SLAB - 1) / SLAB;
   dim3 grid(gx, (T + 2 * TGD - 1) / (2 * TGD), B);
   const int smem = (2 * TGD + MAXK - 1) * ROWB;
-  hipLaunchKernelGGL((dwconv_tile_kernel<true, true>), grid, dim3(256), smem, (hipStream_t)stream_, (const bf16_t*)dy, w, (const float*)nullptr, (bf16_t*)dglu, T, C, K,
+  TFASR_KLAUNCH((dwconv_tile_kernel<true, true>), grid, dim3(256), smem, (hipStream_t)stream_, (const bf16_t*)dy, w, (const float*)nullptr, (bf16_t*)dglu, T, C, K,
                      (const bf16_t*)glu_x);
   TFASR_CHECK_LAUNCH();
   return TFASR_STATUS_SUCCESS;
@@ -363,19 +363,19 @@ int tfasr_dwconv_pair_try(int which, const void* x, const void* dy, const float*
     if (K <= 8) {
       const int smem = (2 * TGD + 8 - 1) * ROWB;
       if (which == 0)
-        hipLaunchKernelGGL((dwconv_tile_kernel<false, false, 8>), grid, dim3(256), smem, s, (const bf16_t*)in, w, bias, (bf16_t*)y, T, C, K,
+        TFASR_KLAUNCH((dwconv_tile_kernel<false, false, 8>), grid, dim3(256), smem, s, (const bf16_t*)in, w, bias, (bf16_t*)y, T, C, K,
                            (const bf16_t*)nullptr);
       else
-        hipLaunchKernelGGL((dwconv_tile_kernel<true, false, 8>), grid, dim3(256), smem, s, (const bf16_t*)in, w, (const float*)nullptr, (bf16_t*)y, T,
+        TFASR_KLAUNCH((dwconv_tile_kernel<true, false, 8>), grid, dim3(256), smem, s, (const bf16_t*)in, w, (const float*)nullptr, (bf16_t*)y, T,
                            C, K, (const bf16_t*)nullptr);
       TFASR_CHECK_LAUNCH();
       return TFASR_STATUS_SUCCESS;
     }
     const int smem = (2 * TGD + MAXK - 1) * ROWB;
     if (which == 0)
-      hipLaunchKernelGGL((dwconv_tile_kernel<false>), grid, dim3(256), smem, s, (const bf16_t*)in, w, bias, (bf16_t*)y, T, C, K);
+      TFASR_KLAUNCH((dwconv_tile_kernel<false>), grid, dim3(256), smem, s, (const bf16_t*)in, w, bias, (bf16_t*)y, T, C, K);
     else
-      hipLaunchKernelGGL((dwconv_tile_kernel<true>), grid, dim3(256), smem, s, (const bf16_t*)in, w, (const float*)nullptr, (bf16_t*)y, T, C, K);
+      TFASR_KLAUNCH((dwconv_tile_kernel<true>), grid, dim3(256), smem, s, (const bf16_t*)in, w, (const float*)nullptr, (bf16_t*)y, T, C, K);
     TFASR_CHECK_LAUNCH();
     return TFASR_STATUS_SUCCESS;
   }
@@ -386,10 +386,10 @@ int tfasr_dwconv_pair_try(int which, const void* x, const void* dy, const float*
   dim3 grid(gx, (T + 2 * TG - 1) / (2 * TG), B);
   const int smem = (2 * TG + MAXK - 1 + 2 * TG) * ROWB;
   switch (K) {
-    case 31: hipLaunchKernelGGL((dwconv_wgrad_tile_kernel<31>), grid, dim3(256), smem, s, (const bf16_t*)x, (const bf16_t*)dy, dw, dbias, T, C, (float*)nullptr); break;
-    case 32: hipLaunchKernelGGL((dwconv_wgrad_tile_kernel<32>), grid, dim3(256), smem, s, (const bf16_t*)x, (const bf16_t*)dy, dw, dbias, T, C, (float*)nullptr); break;
-    case 15: hipLaunchKernelGGL((dwconv_wgrad_tile_kernel<15>), grid, dim3(256), smem, s, (const bf16_t*)x, (const bf16_t*)dy, dw, dbias, T, C, (float*)nullptr); break;
-    case 7: hipLaunchKernelGGL((dwconv_wgrad_tile_kernel<7>), grid, dim3(256), smem, s, (const bf16_t*)x, (const bf16_t*)dy, dw, dbias, T, C, (float*)nullptr); break;
+    case 31: TFASR_KLAUNCH((dwconv_wgrad_tile_kernel<31>), grid, dim3(256), smem, s, (const bf16_t*)x, (const bf16_t*)dy, dw, dbias, T, C, (float*)nullptr); break;
+    case 32: TFASR_KLAUNCH((dwconv_wgrad_tile_kernel<32>), grid, dim3(256), smem, s, (const bf16_t*)x, (const bf16_t*)dy, dw, dbias, T, C, (float*)nullptr); break;
+    case 15: TFASR_KLAUNCH((dwconv_wgrad_tile_kernel<15>), grid, dim3(256), smem, s, (const bf16_t*)x, (const bf16_t*)dy, dw, dbias, T, C, (float*)nullptr); break;
+    case 7: TFASR_KLAUNCH((dwconv_wgrad_tile_kernel<7>), grid, dim3(256), smem, s, (const bf16_t*)x, (const bf16_t*)dy, dw, dbias, T, C, (float*)nullptr); break;
     default: return TFASR_STATUS_UNSUPPORTED;
   }
   TFASR_CHECK_LAUNCH();

@@ -643,13 +643,13 @@ extern "C" int tfasr_cast(const void* src, void* dst, long n, int src_dtype, int
   hipStream_t s = (hipStream_t)stream_;
   const int grid = flat_grid(n / 8 + 1);
   if (src_dtype == TFASR_F32 && dst_dtype == TFASR_BF16)
-    hipLaunchKernelGGL((cast_kernel<float, bf16_t>), dim3(grid), dim3(256), 0, s, (const float*)src, (bf16_t*)dst, n);
+    TFASR_KLAUNCH((cast_kernel<float, bf16_t>), dim3(grid), dim3(256), 0, s, (const float*)src, (bf16_t*)dst, n);
   else if (src_dtype == TFASR_BF16 && dst_dtype == TFASR_F32)
-    hipLaunchKernelGGL((cast_kernel<bf16_t, float>), dim3(grid), dim3(256), 0, s, (const bf16_t*)src, (float*)dst, n);
+    TFASR_KLAUNCH((cast_kernel<bf16_t, float>), dim3(grid), dim3(256), 0, s, (const bf16_t*)src, (float*)dst, n);
   else if (src_dtype == TFASR_F32 && dst_dtype == TFASR_F32)
-    hipLaunchKernelGGL((cast_kernel<float, float>), dim3(grid), dim3(256), 0, s, (const float*)src, (float*)dst, n);
+    TFASR_KLAUNCH((cast_kernel<float, float>), dim3(grid), dim3(256), 0, s, (const float*)src, (float*)dst, n);
   else if (src_dtype == TFASR_BF16 && dst_dtype == TFASR_BF16)
-    hipLaunchKernelGGL((cast_kernel<bf16_t, bf16_t>), dim3(grid), dim3(256), 0, s, (const bf16_t*)src, (bf16_t*)dst, n);
+    TFASR_KLAUNCH((cast_kernel<bf16_t, bf16_t>), dim3(grid), dim3(256), 0, s, (const bf16_t*)src, (bf16_t*)dst, n);
   else return TFASR_STATUS_INVALID_VALUE;
   TFASR_CHECK_LAUNCH();
   return TFASR_STATUS_SUCCESS;
@@ -659,8 +659,8 @@ extern "C" int tfasr_dropout(const void* x, void* y, long n, float p, long seed,
   if (!x || !y || n <= 0 || p < 0.f || p >= 1.f) return TFASR_STATUS_INVALID_VALUE;
   hipStream_t s = (hipStream_t)stream_;
   const int grid = flat_grid(n / 8 + 1);
-  DISPATCH_T(dtype, hipLaunchKernelGGL(dropout_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, (float*)y, n, p, (uint64_t)seed),
-             hipLaunchKernelGGL(dropout_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, n, p, (uint64_t)seed));
+  DISPATCH_T(dtype, TFASR_KLAUNCH(dropout_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, (float*)y, n, p, (uint64_t)seed),
+             TFASR_KLAUNCH(dropout_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, n, p, (uint64_t)seed));
   TFASR_CHECK_LAUNCH();
   return TFASR_STATUS_SUCCESS;
 }
@@ -673,15 +673,15 @@ extern "C" int tfasr_colsum(const void* x, long ld, float* out, long rows, int C
     static const int thr = 512;
     static const int cap = 192;
     dim3 gridv((int)std::max<long>(1, std::min<long>(rows / (thr / 8) + 1, std::max(32, cap / cb))), cb);
-    hipLaunchKernelGGL(colsum_vec_kernel<bf16_t>, gridv, dim3(thr), 0, s, (const bf16_t*)x, ld, out, rows, C, scale);
+    TFASR_KLAUNCH(colsum_vec_kernel<bf16_t>, gridv, dim3(thr), 0, s, (const bf16_t*)x, ld, out, rows, C, scale);
     TFASR_CHECK_LAUNCH();
     return TFASR_STATUS_SUCCESS;
   }
   const int gx = (int)std::max<long>(1, std::min<long>(rows / 64 + 1, 256));
   dim3 grid(gx, (C + 63) / 64);
   DISPATCH_T(dtype,
-             hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, s, (const float*)x, ld, out, rows, C, scale),
-             hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, ld, out, rows, C, scale));
+             TFASR_KLAUNCH(colsum_kernel<float>, grid, dim3(256), 0, s, (const float*)x, ld, out, rows, C, scale),
+             TFASR_KLAUNCH(colsum_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, ld, out, rows, C, scale));
   TFASR_CHECK_LAUNCH();
   return TFASR_STATUS_SUCCESS;
 }
@@ -691,7 +691,7 @@ extern "C" int tfasr_cast_colsum_many(const float* x, void* y, long stride, int 
   if ((C & 3) || (stride & 3) || (((uintptr_t)x) & 15) || (((uintptr_t)y) & 7)) return TFASR_STATUS_UNSUPPORTED;
   CastColsumOut o;
   for (int i = 0; i < CCS_MAX; ++i) o.p[i] = i < nmat ? colsum[i] : nullptr;
-  hipLaunchKernelGGL(cast_colsum_many_kernel, dim3((C + 63) / 64, 1, nmat), dim3(256), 0, (hipStream_t)stream_, x, (bf16_t*)y, stride, rows, C, o);
+  TFASR_KLAUNCH(cast_colsum_many_kernel, dim3((C + 63) / 64, 1, nmat), dim3(256), 0, (hipStream_t)stream_, x, (bf16_t*)y, stride, rows, C, o);
   TFASR_CHECK_LAUNCH();
   return TFASR_STATUS_SUCCESS;
 }
@@ -700,8 +700,8 @@ extern "C" int tfasr_glu_fwd(const void* x, void* y, long rows, int C, int dtype
   if (!x || !y || rows <= 0 || C <= 0 || C % 8) return TFASR_STATUS_INVALID_VALUE;
   hipStream_t s = (hipStream_t)stream_;
   const int grid = flat_grid(rows * C / 8);
-  DISPATCH_T(dtype, hipLaunchKernelGGL(glu_fwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, (float*)y, rows, C),
-             hipLaunchKernelGGL(glu_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, rows, C));
+  DISPATCH_T(dtype, TFASR_KLAUNCH(glu_fwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, (float*)y, rows, C),
+             TFASR_KLAUNCH(glu_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, rows, C));
   TFASR_CHECK_LAUNCH();
   return TFASR_STATUS_SUCCESS;
 }
@@ -710,8 +710,8 @@ extern "C" int tfasr_glu_bwd(const void* x, const void* dy, void* dx, long rows,
   hipStream_t s = (hipStream_t)stream_;
   const int grid = flat_grid(rows * C / 8);
   DISPATCH_T(dtype,
-             hipLaunchKernelGGL(glu_bwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, (const float*)dy, (float*)dx, rows, C),
-             hipLaunchKernelGGL(glu_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)dx, rows, C));
+             TFASR_KLAUNCH(glu_bwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, (const float*)dy, (float*)dx, rows, C),
+             TFASR_KLAUNCH(glu_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)dx, rows, C));
   TFASR_CHECK_LAUNCH();
   return TFASR_STATUS_SUCCESS;
 }
@@ -731,8 +731,8 @@ extern "C" int tfasr_dwconv_fwd(const void* x, const float* w, const float* bias
   const int bx = C >= 256 ? 256 : ((C + 63) / 64) * 64;
   dim3 grid((C + bx - 1) / bx, (T + DW_TT - 1) / DW_TT, B);
   DISPATCH_T(dtype,
-             hipLaunchKernelGGL(dwconv_fwd_kernel<float>, grid, dim3(bx), 0, s, (const float*)x, w, bias, (float*)y, T, C, K),
-             hipLaunchKernelGGL(dwconv_fwd_kernel<bf16_t>, grid, dim3(bx), 0, s, (const bf16_t*)x, w, bias, (bf16_t*)y, T, C, K));
+             TFASR_KLAUNCH(dwconv_fwd_kernel<float>, grid, dim3(bx), 0, s, (const float*)x, w, bias, (float*)y, T, C, K),
+             TFASR_KLAUNCH(dwconv_fwd_kernel<bf16_t>, grid, dim3(bx), 0, s, (const bf16_t*)x, w, bias, (bf16_t*)y, T, C, K));
   TFASR_CHECK_LAUNCH();
   return TFASR_STATUS_SUCCESS;
 }
@@ -747,8 +747,8 @@ extern "C" int tfasr_dwconv_bwd_data(const void* dy, const float* w, void* dx, i
   const int bx = C >= 256 ? 256 : ((C + 63) / 64) * 64;
   dim3 grid((C + bx - 1) / bx, (T + DW_TT - 1) / DW_TT, B);
   DISPATCH_T(dtype,
-             hipLaunchKernelGGL(dwconv_bwd_data_kernel<float>, grid, dim3(bx), 0, s, (const float*)dy, w, (float*)dx, T, C, K),
-             hipLaunchKernelGGL(dwconv_bwd_data_kernel<bf16_t>, grid, dim3(bx), 0, s, (const bf16_t*)dy, w, (bf16_t*)dx, T, C, K));
+             TFASR_KLAUNCH(dwconv_bwd_data_kernel<float>, grid, dim3(bx), 0, s, (const float*)dy, w, (float*)dx, T, C, K),
+             TFASR_KLAUNCH(dwconv_bwd_data_kernel<bf16_t>, grid, dim3(bx), 0, s, (const bf16_t*)dy, w, (bf16_t*)dx, T, C, K));
   TFASR_CHECK_LAUNCH();
   return TFASR_STATUS_SUCCESS;
 }
@@ -803,8 +803,8 @@ extern "C" int tfasr_dwconv_bwd_weight(const void* x, const void* dy, float* dw,
   const int bx = C >= 256 ? 256 : ((C + 63) / 64) * 64;
   dim3 grid((C + bx - 1) / bx, (T + DW_WT - 1) / DW_WT, B);
   DISPATCH_T(dtype,
-             hipLaunchKernelGGL(dwconv_bwd_weight_kernel<float>, grid, dim3(bx), 0, s, (const float*)x, (const float*)dy, dw, dbias, T, C, K),
-             hipLaunchKernelGGL(dwconv_bwd_weight_kernel<bf16_t>, grid, dim3(bx), 0, s, (const bf16_t*)x, (const bf16_t*)dy, dw, dbias, T, C, K));
+             TFASR_KLAUNCH(dwconv_bwd_weight_kernel<float>, grid, dim3(bx), 0, s, (const float*)x, (const float*)dy, dw, dbias, T, C, K),
+             TFASR_KLAUNCH(dwconv_bwd_weight_kernel<bf16_t>, grid, dim3(bx), 0, s, (const bf16_t*)x, (const bf16_t*)dy, dw, dbias, T, C, K));
   TFASR_CHECK_LAUNCH();
   return TFASR_STATUS_SUCCESS;
 }
@@ -815,14 +815,14 @@ extern "C" int tfasr_bias2_fwd(const void* x, long ldx, const float* u, const fl
   hipStream_t s = (hipStream_t)stream_;
   auto al = [](const void* p) { return (((uintptr_t)p) & 15) == 0; };
   if (dtype == TFASR_BF16 && (C % 8) == 0 && (ldx % 8) == 0 && al(x) && al(u) && al(v) && al(y1) && al(y2)) {
-    hipLaunchKernelGGL(bias2_fwd_vec_kernel, dim3(flat_grid(rows * C / 8)), dim3(256), 0, s, (const bf16_t*)x, ldx, u, v, (bf16_t*)y1, (bf16_t*)y2, rows, C);
+    TFASR_KLAUNCH(bias2_fwd_vec_kernel, dim3(flat_grid(rows * C / 8)), dim3(256), 0, s, (const bf16_t*)x, ldx, u, v, (bf16_t*)y1, (bf16_t*)y2, rows, C);
     TFASR_CHECK_LAUNCH();
     return TFASR_STATUS_SUCCESS;
   }
   const int grid = flat_grid(rows * C);
   DISPATCH_T(dtype,
-             hipLaunchKernelGGL(bias2_fwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, ldx, u, v, (float*)y1, (float*)y2, rows, C),
-             hipLaunchKernelGGL(bias2_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)x, ldx, u, v, (bf16_t*)y1, (bf16_t*)y2, rows, C));
+             TFASR_KLAUNCH(bias2_fwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, ldx, u, v, (float*)y1, (float*)y2, rows, C),
+             TFASR_KLAUNCH(bias2_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)x, ldx, u, v, (bf16_t*)y1, (bf16_t*)y2, rows, C));
   TFASR_CHECK_LAUNCH();
   return TFASR_STATUS_SUCCESS;
 }
@@ -835,15 +835,15 @@ extern "C" int tfasr_bias2_bwd(const void* d1, const void* d2, void* dx, long ld
     static const int thr = 512;
     static const int cap = 192;
     dim3 gridv((int)std::max<long>(1, std::min<long>(rows / (thr / 8) + 1, cap)), (C + 255) / 256);
-    hipLaunchKernelGGL(bias2_bwd_vec_kernel, gridv, dim3(thr), 0, s, (const bf16_t*)d1, (const bf16_t*)d2, (bf16_t*)dx, lddx, du, dv, rows, C);
+    TFASR_KLAUNCH(bias2_bwd_vec_kernel, gridv, dim3(thr), 0, s, (const bf16_t*)d1, (const bf16_t*)d2, (bf16_t*)dx, lddx, du, dv, rows, C);
     TFASR_CHECK_LAUNCH();
     return TFASR_STATUS_SUCCESS;
   }
   const int gx = (int)std::max<long>(1, std::min<long>(rows / 64 + 1, 256));
   dim3 grid(gx, (C + 63) / 64);
   DISPATCH_T(dtype,
-             hipLaunchKernelGGL(bias2_bwd_kernel<float>, grid, dim3(256), 0, s, (const float*)d1, (const float*)d2, (float*)dx, lddx, du, dv, rows, C),
-             hipLaunchKernelGGL(bias2_bwd_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)d1, (const bf16_t*)d2, (bf16_t*)dx, lddx, du, dv, rows, C));
+             TFASR_KLAUNCH(bias2_bwd_kernel<float>, grid, dim3(256), 0, s, (const float*)d1, (const float*)d2, (float*)dx, lddx, du, dv, rows, C),
+             TFASR_KLAUNCH(bias2_bwd_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)d1, (const bf16_t*)d2, (bf16_t*)dx, lddx, du, dv, rows, C));
   TFASR_CHECK_LAUNCH();
   return TFASR_STATUS_SUCCESS;
 }
@@ -854,8 +854,8 @@ extern "C" int tfasr_embedding_fwd(const int32_t* idx, const float* table, void*
   hipStream_t s = (hipStream_t)stream_;
   const int grid = flat_grid(rows * E);
   DISPATCH_T(dtype,
-             hipLaunchKernelGGL(embedding_fwd_kernel<float>, dim3(grid), dim3(256), 0, s, idx, table, (float*)out, rows, E, V),
-             hipLaunchKernelGGL(embedding_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, idx, table, (bf16_t*)out, rows, E, V));
+             TFASR_KLAUNCH(embedding_fwd_kernel<float>, dim3(grid), dim3(256), 0, s, idx, table, (float*)out, rows, E, V),
+             TFASR_KLAUNCH(embedding_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, idx, table, (bf16_t*)out, rows, E, V));
   TFASR_CHECK_LAUNCH();
   return TFASR_STATUS_SUCCESS;
 }
@@ -865,8 +865,8 @@ extern "C" int tfasr_embedding_bwd(const int32_t* idx, const void* dout, float* 
   hipStream_t s = (hipStream_t)stream_;
   const int grid = flat_grid(rows * E);
   DISPATCH_T(dtype,
-             hipLaunchKernelGGL(embedding_bwd_kernel<float>, dim3(grid), dim3(256), 0, s, idx, (const float*)dout, dtable, rows, E, V),
-             hipLaunchKernelGGL(embedding_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, idx, (const bf16_t*)dout, dtable, rows, E, V));
+             TFASR_KLAUNCH(embedding_bwd_kernel<float>, dim3(grid), dim3(256), 0, s, idx, (const float*)dout, dtable, rows, E, V),
+             TFASR_KLAUNCH(embedding_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, idx, (const bf16_t*)dout, dtable, rows, E, V));
   TFASR_CHECK_LAUNCH();
   return TFASR_STATUS_SUCCESS;
 }
@@ -877,8 +877,8 @@ extern "C" int tfasr_joint_fwd(const void* enc, const void* pred, void* h, int B
   hipStream_t s = (hipStream_t)stream_;
   const int grid = flat_grid((long)B * T * U1 * J / 8);
   DISPATCH_T(dtype,
-             hipLaunchKernelGGL(joint_fwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)enc, (const float*)pred, (float*)h, B, T, U1, J),
-             hipLaunchKernelGGL(joint_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)enc, (const bf16_t*)pred, (bf16_t*)h, B, T, U1, J));
+             TFASR_KLAUNCH(joint_fwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)enc, (const float*)pred, (float*)h, B, T, U1, J),
+             TFASR_KLAUNCH(joint_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)enc, (const bf16_t*)pred, (bf16_t*)h, B, T, U1, J));
   TFASR_CHECK_LAUNCH();
   return TFASR_STATUS_SUCCESS;
 }
@@ -889,10 +889,10 @@ extern "C" int tfasr_joint_bwd(const void* h, const void* dh, void* denc, void* 
   const int gy = (J / 8 + 127) / 128;
   dim3 g0(B * T, gy), g1(B * U1, gy);
   DISPATCH_T(dtype,
-             { hipLaunchKernelGGL((joint_bwd_kernel<float, 0>), g0, dim3(128), 0, s, (const float*)h, (const float*)dh, (float*)denc, B, T, U1, J);
-               hipLaunchKernelGGL((joint_bwd_kernel<float, 1>), g1, dim3(128), 0, s, (const float*)h, (const float*)dh, (float*)dpred, B, T, U1, J); },
-             { hipLaunchKernelGGL((joint_bwd_kernel<bf16_t, 0>), g0, dim3(128), 0, s, (const bf16_t*)h, (const bf16_t*)dh, (bf16_t*)denc, B, T, U1, J);
-               hipLaunchKernelGGL((joint_bwd_kernel<bf16_t, 1>), g1, dim3(128), 0, s, (const bf16_t*)h, (const bf16_t*)dh, (bf16_t*)dpred, B, T, U1, J); });
+             { TFASR_KLAUNCH((joint_bwd_kernel<float, 0>), g0, dim3(128), 0, s, (const float*)h, (const float*)dh, (float*)denc, B, T, U1, J);
+               TFASR_KLAUNCH((joint_bwd_kernel<float, 1>), g1, dim3(128), 0, s, (const float*)h, (const float*)dh, (float*)dpred, B, T, U1, J); },
+             { TFASR_KLAUNCH((joint_bwd_kernel<bf16_t, 0>), g0, dim3(128), 0, s, (const bf16_t*)h, (const bf16_t*)dh, (bf16_t*)denc, B, T, U1, J);
+               TFASR_KLAUNCH((joint_bwd_kernel<bf16_t, 1>), g1, dim3(128), 0, s, (const bf16_t*)h, (const bf16_t*)dh, (bf16_t*)dpred, B, T, U1, J); });
   TFASR_CHECK_LAUNCH();
   return TFASR_STATUS_SUCCESS;
 }
@@ -905,15 +905,15 @@ extern "C" int tfasr_joint_fwd_packed(const void* enc, const void* pred, void* h
   if (J / 8 <= 256) {
     dim3 g2(T, B);
     DISPATCH_T(dtype,
-               hipLaunchKernelGGL(joint_fwd_packed_rows_kernel<float>, g2, dim3(256), 0, s, (const float*)enc, (const float*)pred, (float*)h, cell_off, label_len, T, U1, J),
-               hipLaunchKernelGGL(joint_fwd_packed_rows_kernel<bf16_t>, g2, dim3(256), 0, s, (const bf16_t*)enc, (const bf16_t*)pred, (bf16_t*)h, cell_off, label_len, T, U1, J));
+               TFASR_KLAUNCH(joint_fwd_packed_rows_kernel<float>, g2, dim3(256), 0, s, (const float*)enc, (const float*)pred, (float*)h, cell_off, label_len, T, U1, J),
+               TFASR_KLAUNCH(joint_fwd_packed_rows_kernel<bf16_t>, g2, dim3(256), 0, s, (const bf16_t*)enc, (const bf16_t*)pred, (bf16_t*)h, cell_off, label_len, T, U1, J));
     TFASR_CHECK_LAUNCH();
     return TFASR_STATUS_SUCCESS;
   }
   const int grid = flat_grid(total_cells * J / 8);
   DISPATCH_T(dtype,
-             hipLaunchKernelGGL(joint_fwd_packed_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)enc, (const float*)pred, (float*)h, cell_off, label_len, total_cells, B, T, U1, J),
-             hipLaunchKernelGGL(joint_fwd_packed_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)enc, (const bf16_t*)pred, (bf16_t*)h, cell_off, label_len, total_cells, B, T, U1, J));
+             TFASR_KLAUNCH(joint_fwd_packed_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)enc, (const float*)pred, (float*)h, cell_off, label_len, total_cells, B, T, U1, J),
+             TFASR_KLAUNCH(joint_fwd_packed_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)enc, (const bf16_t*)pred, (bf16_t*)h, cell_off, label_len, total_cells, B, T, U1, J));
   TFASR_CHECK_LAUNCH();
   return TFASR_STATUS_SUCCESS;
 }
@@ -926,10 +926,10 @@ extern "C" int tfasr_joint_bwd_packed(const void* h, const void* dh, void* denc,
   const int gy = (J / 8 + 127) / 128;
   dim3 g0(B * T, gy), g1(B * U1, gy);
   DISPATCH_T(dtype,
-             { hipLaunchKernelGGL((joint_bwd_packed_kernel<float, 0>), g0, dim3(128, JB_RL), 0, s, (const float*)h, (const float*)dh, (float*)denc, cell_off, label_len, logit_len, B, T, U1, J);
-               hipLaunchKernelGGL((joint_bwd_packed_kernel<float, 1>), g1, dim3(128, JB_RL), 0, s, (const float*)h, (const float*)dh, (float*)dpred, cell_off, label_len, logit_len, B, T, U1, J); },
-             { hipLaunchKernelGGL((joint_bwd_packed_kernel<bf16_t, 0>), g0, dim3(128, JB_RL), 0, s, (const bf16_t*)h, (const bf16_t*)dh, (bf16_t*)denc, cell_off, label_len, logit_len, B, T, U1, J);
-               hipLaunchKernelGGL((joint_bwd_packed_kernel<bf16_t, 1>), g1, dim3(128, JB_RL), 0, s, (const bf16_t*)h, (const bf16_t*)dh, (bf16_t*)dpred, cell_off, label_len, logit_len, B, T, U1, J); });
+             { TFASR_KLAUNCH((joint_bwd_packed_kernel<float, 0>), g0, dim3(128, JB_RL), 0, s, (const float*)h, (const float*)dh, (float*)denc, cell_off, label_len, logit_len, B, T, U1, J);
+               TFASR_KLAUNCH((joint_bwd_packed_kernel<float, 1>), g1, dim3(128, JB_RL), 0, s, (const float*)h, (const float*)dh, (float*)dpred, cell_off, label_len, logit_len, B, T, U1, J); },
+             { TFASR_KLAUNCH((joint_bwd_packed_kernel<bf16_t, 0>), g0, dim3(128, JB_RL), 0, s, (const bf16_t*)h, (const bf16_t*)dh, (bf16_t*)denc, cell_off, label_len, logit_len, B, T, U1, J);
+               TFASR_KLAUNCH((joint_bwd_packed_kernel<bf16_t, 1>), g1, dim3(128, JB_RL), 0, s, (const bf16_t*)h, (const bf16_t*)dh, (bf16_t*)dpred, cell_off, label_len, logit_len, B, T, U1, J); });
   TFASR_CHECK_LAUNCH();
   return TFASR_STATUS_SUCCESS;
 }
@@ -939,7 +939,7 @@ extern "C" int tfasr_adam_shadow(float* p, const float* g, float* m, float* v, l
                                  void* stream_) {
   if (!p || !g || !m || !v || n <= 0 || step <= 0) return TFASR_STATUS_INVALID_VALUE;
   const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
-  hipLaunchKernelGGL(adam_kernel, dim3(flat_grid(n)), dim3(256), 0, (hipStream_t)stream_, p, g, m, v, n, n_reg, lr, beta1,
+  TFASR_KLAUNCH(adam_kernel, dim3(flat_grid(n)), dim3(256), 0, (hipStream_t)stream_, p, g, m, v, n, n_reg, lr, beta1,
                      beta2, eps, weight_decay, l2, grad_scale, bc1, bc2, (bf16_t*)shadow_bf16);
   TFASR_CHECK_LAUNCH();
   return TFASR_STATUS_SUCCESS;
@@ -953,21 +953,21 @@ extern "C" int tfasr_adam(float* p, const float* g, float* m, float* v, long n, 
 extern "C" int tfasr_gauss_noise(float* x, long n, float stddev, long seed, void* stream_) {
   if (!x || n < 0) return TFASR_STATUS_INVALID_VALUE;
   if (n == 0 || stddev == 0.f) return TFASR_STATUS_SUCCESS;
-  hipLaunchKernelGGL(gauss_noise_kernel, dim3(flat_grid(n)), dim3(256), 0, (hipStream_t)stream_, x, n, stddev, (uint64_t)seed);
+  TFASR_KLAUNCH(gauss_noise_kernel, dim3(flat_grid(n)), dim3(256), 0, (hipStream_t)stream_, x, n, stddev, (uint64_t)seed);
   TFASR_CHECK_LAUNCH();
   return TFASR_STATUS_SUCCESS;
 }
 
 extern "C" int tfasr_axpy(float* y, const float* x, float alpha, long n, void* stream_) {
   if (!x || !y || n <= 0) return TFASR_STATUS_INVALID_VALUE;
-  hipLaunchKernelGGL(axpy_kernel, dim3(flat_grid(n)), dim3(256), 0, (hipStream_t)stream_, y, x, alpha, n);
+  TFASR_KLAUNCH(axpy_kernel, dim3(flat_grid(n)), dim3(256), 0, (hipStream_t)stream_, y, x, alpha, n);
   TFASR_CHECK_LAUNCH();
   return TFASR_STATUS_SUCCESS;
 }
 
 extern "C" int tfasr_sumsq(const float* p, long n, float* out, void* stream_) {
   if (!p || !out || n <= 0) return TFASR_STATUS_INVALID_VALUE;
-  hipLaunchKernelGGL(sumsq_kernel, dim3(flat_grid(n)), dim3(256), 0, (hipStream_t)stream_, p, n, out);
+  TFASR_KLAUNCH(sumsq_kernel, dim3(flat_grid(n)), dim3(256), 0, (hipStream_t)stream_, p, n, out);
   TFASR_CHECK_LAUNCH();
   return TFASR_STATUS_SUCCESS;
 }
@@ -978,8 +978,8 @@ extern "C" int tfasr_specaugment(void* x, const int32_t* fmask, const int32_t* t
   hipStream_t s = (hipStream_t)stream_;
   const int grid = flat_grid((long)B * T * F);
   DISPATCH_T(dtype,
-             hipLaunchKernelGGL(specaug_kernel<float>, dim3(grid), dim3(256), 0, s, (float*)x, fmask, tmask, nf, nt, B, T, F, mask_value),
-             hipLaunchKernelGGL(specaug_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (bf16_t*)x, fmask, tmask, nf, nt, B, T, F, mask_value));
+             TFASR_KLAUNCH(specaug_kernel<float>, dim3(grid), dim3(256), 0, s, (float*)x, fmask, tmask, nf, nt, B, T, F, mask_value),
+             TFASR_KLAUNCH(specaug_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (bf16_t*)x, fmask, tmask, nf, nt, B, T, F, mask_value));
   TFASR_CHECK_LAUNCH();
   return TFASR_STATUS_SUCCESS;
 }

@@ -399,11 +399,6 @@ __global__ __launch_bounds__(256, WGS) void ffn_fused_fwd_kernel(const FfnArgs p
 static int launch_ffn_fused_fwd(const FfnArgs& a, hipStream_t stream) {
   // 1: MR 3 x 1 WG/CU, 2: MR 2 x 2 WG/CU, 3: MR 2 x 1, 4: MR 1 x 2 WG/CU (32-row tiles); 0 / unset: by tile count (below)
   static const int forced = 0;
-  static int ncu = 0;
-  if (ncu == 0) {
-    int dev = 0, v = 0;
-    ncu = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
-  }
   // Round 5 re-measured the 32-row variant per batch shape (variant 4): a [14.8k, 256] batch is 231 64-row workgroups - one per CU - or 462
   // 32-row ones = two per CU in one round; 50.9 vs ~48 us per launch in line, 21.76 vs 21.45 ms per step when forced everywhere: the
   // second resident workgroup's overlap does not pay for the halved reuse of the weight images.  64 rows stay the default.
@@ -413,7 +408,7 @@ static int launch_ffn_fused_fwd(const FfnArgs& a, hipStream_t stream) {
     static bool attr_done = false;
     if (!attr_done) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem); attr_done = true; }
     const long tiles = (a.rows + 32 * MR - 1) / (32 * MR);
-    hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), smem, stream, a);
+    TFASR_KLAUNCH(kern, dim3((unsigned)tiles), dim3(256), smem, stream, a);
   };
   if (variant == 1) go(ffn_fused_fwd_kernel<3, 1>, 3, 2);
   else if (variant == 3) go(ffn_fused_fwd_kernel<2, 1>, 2, 2);

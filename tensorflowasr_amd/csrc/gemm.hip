@@ -370,22 +370,22 @@ int launch(const tfasr_gemm_args& a, hipStream_t stream) {
     if (!narrow_off && a.N > 64 && (long)grid.x * grid.y * grid.z < 2L * ncu) {
       dim3 g2((a.N + 63) / 64, grid.y, grid.z);
       if (a.trans_a) {
-        if (a.trans_b) hipLaunchKernelGGL((gemm_kernel<T, true, true, 64>), g2, block, 0, stream, a);
-        else           hipLaunchKernelGGL((gemm_kernel<T, true, false, 64>), g2, block, 0, stream, a);
+        if (a.trans_b) TFASR_KLAUNCH((gemm_kernel<T, true, true, 64>), g2, block, 0, stream, a);
+        else           TFASR_KLAUNCH((gemm_kernel<T, true, false, 64>), g2, block, 0, stream, a);
       } else {
-        if (a.trans_b) hipLaunchKernelGGL((gemm_kernel<T, false, true, 64>), g2, block, 0, stream, a);
-        else           hipLaunchKernelGGL((gemm_kernel<T, false, false, 64>), g2, block, 0, stream, a);
+        if (a.trans_b) TFASR_KLAUNCH((gemm_kernel<T, false, true, 64>), g2, block, 0, stream, a);
+        else           TFASR_KLAUNCH((gemm_kernel<T, false, false, 64>), g2, block, 0, stream, a);
       }
       TFASR_CHECK_LAUNCH();
       return TFASR_STATUS_SUCCESS;
     }
   }
   if (a.trans_a) {
-    if (a.trans_b) hipLaunchKernelGGL((gemm_kernel<T, true, true>), grid, block, 0, stream, a);
-    else           hipLaunchKernelGGL((gemm_kernel<T, true, false>), grid, block, 0, stream, a);
+    if (a.trans_b) TFASR_KLAUNCH((gemm_kernel<T, true, true>), grid, block, 0, stream, a);
+    else           TFASR_KLAUNCH((gemm_kernel<T, true, false>), grid, block, 0, stream, a);
   } else {
-    if (a.trans_b) hipLaunchKernelGGL((gemm_kernel<T, false, true>), grid, block, 0, stream, a);
-    else           hipLaunchKernelGGL((gemm_kernel<T, false, false>), grid, block, 0, stream, a);
+    if (a.trans_b) TFASR_KLAUNCH((gemm_kernel<T, false, true>), grid, block, 0, stream, a);
+    else           TFASR_KLAUNCH((gemm_kernel<T, false, false>), grid, block, 0, stream, a);
   }
   TFASR_CHECK_LAUNCH();
   return TFASR_STATUS_SUCCESS;

@@ -768,7 +768,7 @@ int launch_big(const tfasr_gemm_args& a, bool generic, int need, bool tanh_out, 
   auto go = [&](auto kern, int smem) {
     static bool attr_done = false;  // per instantiation (the lambda's static lives in the template instance)
     if (!attr_done) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem); attr_done = true; }
-    hipLaunchKernelGGL(kern, dim3(G), dim3(512), smem, stream, a, gx, gy, (int)ntiles);
+    TFASR_KLAUNCH(kern, dim3(G), dim3(512), smem, stream, a, gx, gy, (int)ntiles);
   };
   constexpr int S256 = 2 * (256 * BK * 2 + 256 * BK * 2) + 8 * 8 * 68 * 4;
   constexpr int S320 = 2 * (256 * BK * 2 + 320 * BK * 2);

@@ -872,7 +872,7 @@ int launch_epi(const tfasr_gemm_args& a, dim3 tiles, hipStream_t stream) {
     static const long one_max = (1L << 30);  // probe: upper bound in tiles per CU
     if (!one_off && a.split_k <= 1 && ntiles > slots && ntiles <= one_max * num_cus()) {
       constexpr int SMEM1 = 2 * (A_BYTES + 64 * BK * 2);
-      hipLaunchKernelGGL((gemm_fast_one_kernel<TA, TB, EPI>), dim3((unsigned)ntiles), dim3(256), SMEM1, stream, a, (int)tiles.x, (int)tiles.y, (int)tiles.z, (int)ntiles);
+      TFASR_KLAUNCH((gemm_fast_one_kernel<TA, TB, EPI>), dim3((unsigned)ntiles), dim3(256), SMEM1, stream, a, (int)tiles.x, (int)tiles.y, (int)tiles.z, (int)ntiles);
       TFASR_CHECK_LAUNCH();
       return TFASR_STATUS_SUCCESS;
     }
@@ -880,7 +880,7 @@ int launch_epi(const tfasr_gemm_args& a, dim3 tiles, hipStream_t stream) {
   int G = (int)(ntiles < slots ? ntiles : slots);
   if (ntiles >= slots) G &= ~7;
   constexpr int SMEM = 2 * (A_BYTES + BN_ * BK * 2) + 4 * (64 / (BN_ / 16)) * (BN_ / 2 + 4) * 4;  // stages + 4 waves' strips
-  hipLaunchKernelGGL((gemm_fast_kernel<TA, TB, BN_, EPI>), dim3(G), dim3(256), SMEM, stream, a, (int)tiles.x, (int)tiles.y, (int)tiles.z, (int)ntiles);
+  TFASR_KLAUNCH((gemm_fast_kernel<TA, TB, BN_, EPI>), dim3(G), dim3(256), SMEM, stream, a, (int)tiles.x, (int)tiles.y, (int)tiles.z, (int)ntiles);
   TFASR_CHECK_LAUNCH();
   return TFASR_STATUS_SUCCESS;
 }
@@ -937,7 +937,7 @@ int launch_one(const tfasr_gemm_args& a, hipStream_t stream) {
     if (st != TFASR_STATUS_SUCCESS) return st;
     const long work = ((long)a.M * a.N + 3) / 4;
     const int rg = (int)(work / 256 + 1 < 2048 ? work / 256 + 1 : 2048);
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rg), dim3(256), 0, stream, (const float*)a.ws, (float*)a.D, a.M, a.N, a.ldd, split);
+    TFASR_KLAUNCH(splitk_reduce_kernel, dim3(rg), dim3(256), 0, stream, (const float*)a.ws, (float*)a.D, a.M, a.N, a.ldd, split);
     TFASR_CHECK_LAUNCH();
     return TFASR_STATUS_SUCCESS;
   }
@@ -977,7 +977,7 @@ int launch_one(const tfasr_gemm_args& a, hipStream_t stream) {
         int G = (int)(ntiles < slots ? ntiles : slots);
         if (ntiles >= slots) G &= ~7;
         constexpr int SMEM = 2 * (A_BYTES + 128 * BK * 2) + 4 * (64 / (128 / 16)) * (128 / 2 + 4) * 4;
-        hipLaunchKernelGGL((gemm_seg_kernel<TA, TB>), dim3(G), dim3(256), SMEM, stream, a, (int)g128.x, (int)g128.y, 1, (int)ntiles);
+        TFASR_KLAUNCH((gemm_seg_kernel<TA, TB>), dim3(G), dim3(256), SMEM, stream, a, (int)g128.x, (int)g128.y, 1, (int)ntiles);
         TFASR_CHECK_LAUNCH();
         return TFASR_STATUS_SUCCESS;
       }
@@ -1093,11 +1093,11 @@ int tfasr_gemm_group_fast_try(const tfasr_gemm_args* a, int n, hipStream_t strea
   // accumulate epilogue: atomics from the fragments, no strips in LDS
   if (bn == 64) {
     constexpr int STAGE = A_BYTES + 64 * BK * 2;
-    if (nst == 3) hipLaunchKernelGGL((wgrad_group_kernel<E_CSUM, 3, 64>), dim3(8 * maxload), dim3(256), 3 * STAGE, stream, ga);
-    else hipLaunchKernelGGL((wgrad_group_kernel<E_CSUM, 2, 64>), dim3(8 * maxload), dim3(256), 2 * STAGE, stream, ga);
+    if (nst == 3) TFASR_KLAUNCH((wgrad_group_kernel<E_CSUM, 3, 64>), dim3(8 * maxload), dim3(256), 3 * STAGE, stream, ga);
+    else TFASR_KLAUNCH((wgrad_group_kernel<E_CSUM, 2, 64>), dim3(8 * maxload), dim3(256), 2 * STAGE, stream, ga);
   } else {
     constexpr int STAGE = A_BYTES + 128 * BK * 2;
-    hipLaunchKernelGGL((wgrad_group_kernel<E_CSUM, 2, 128>), dim3(8 * maxload), dim3(256), 2 * STAGE, stream, ga);
+    TFASR_KLAUNCH((wgrad_group_kernel<E_CSUM, 2, 128>), dim3(8 * maxload), dim3(256), 2 * STAGE, stream, ga);
   }
   TFASR_CHECK_LAUNCH();
   return TFASR_STATUS_SUCCESS;

@@ -230,10 +230,10 @@ extern "C" int tfasr_logmel(const float* signal, int B, int N, float preemph, co
   }
   const int grid = (int)std::max<long>(1, std::min<long>((nframes + 3) / 4, (long)std::max(cus, 1) * occ[oi]));
   if (dtype == TFASR_F32)
-    hipLaunchKernelGGL(logmel_kernel<float>, dim3(grid), dim3(256), dyn, s, signal, B, N, preemph, window, frame_len,
+    TFASR_KLAUNCH(logmel_kernel<float>, dim3(grid), dim3(256), dyn, s, signal, B, N, preemph, window, frame_len,
                        frame_step, melw, band, F, eps, (float*)out, T0);
   else if (dtype == TFASR_BF16)
-    hipLaunchKernelGGL(logmel_kernel<bf16_t>, dim3(grid), dim3(256), dyn, s, signal, B, N, preemph, window, frame_len,
+    TFASR_KLAUNCH(logmel_kernel<bf16_t>, dim3(grid), dim3(256), dyn, s, signal, B, N, preemph, window, frame_len,
                        frame_step, melw, band, F, eps, (bf16_t*)out, T0);
   else return TFASR_STATUS_INVALID_VALUE;
   TFASR_CHECK_LAUNCH();

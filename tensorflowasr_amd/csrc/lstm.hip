@@ -112,11 +112,11 @@ extern "C" int tfasr_lstm_step_fwd(const void* xg, long xg_stride_b, const float
   hipStream_t s = (hipStream_t)stream_;
   const int grid = (B * P + 255) / 256;
   if (dtype == TFASR_F32)
-    hipLaunchKernelGGL(lstm_step_fwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)xg, xg_stride_b, hr,
+    TFASR_KLAUNCH(lstm_step_fwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)xg, xg_stride_b, hr,
                        (const float*)h_prev, hprev_stride_b, c_prev, cprev_stride_b, lengths, t, (float*)gates,
                        gates_stride_b, c_out, c_stride_b, (float*)h_out, h_stride_b, (float*)y_out, y_stride_b, B, P);
   else if (dtype == TFASR_BF16)
-    hipLaunchKernelGGL(lstm_step_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)xg, xg_stride_b, hr,
+    TFASR_KLAUNCH(lstm_step_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)xg, xg_stride_b, hr,
                        (const bf16_t*)h_prev, hprev_stride_b, c_prev, cprev_stride_b, lengths, t, (bf16_t*)gates,
                        gates_stride_b, c_out, c_stride_b, (bf16_t*)h_out, h_stride_b, (bf16_t*)y_out, y_stride_b, B, P);
   else return TFASR_STATUS_INVALID_VALUE;
@@ -132,11 +132,11 @@ extern "C" int tfasr_lstm_step_bwd(const void* dy, long dy_stride_b, const float
   hipStream_t s = (hipStream_t)stream_;
   const int grid = (B * P + 255) / 256;
   if (dtype == TFASR_F32)
-    hipLaunchKernelGGL(lstm_step_bwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)dy, dy_stride_b, dhr,
+    TFASR_KLAUNCH(lstm_step_bwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)dy, dy_stride_b, dhr,
                        dh_carry, dc_carry, (const float*)gates, gates_stride_b, c_t, c_stride_b, c_prev, cprev_stride_b,
                        lengths, t, (float*)dz, dz_stride_b, B, P);
   else if (dtype == TFASR_BF16)
-    hipLaunchKernelGGL(lstm_step_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)dy, dy_stride_b, dhr,
+    TFASR_KLAUNCH(lstm_step_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)dy, dy_stride_b, dhr,
                        dh_carry, dc_carry, (const bf16_t*)gates, gates_stride_b, c_t, c_stride_b, c_prev, cprev_stride_b,
                        lengths, t, (bf16_t*)dz, dz_stride_b, B, P);
   else return TFASR_STATUS_INVALID_VALUE;

@@ -431,7 +431,7 @@ __global__ __launch_bounds__(256) void lstm_transpose_kernel(const bf16_t* __res
 extern "C" int tfasr_lstm_transpose_rk(const void* rk, void* rk_t, int P, int dtype, void* stream_) {
   if (!rk || !rk_t || P <= 0) return TFASR_STATUS_INVALID_VALUE;
   if (dtype != TFASR_BF16) return TFASR_STATUS_UNSUPPORTED;
-  hipLaunchKernelGGL(lstm_transpose_kernel, dim3((4 * P + 31) / 32, (P + 31) / 32), dim3(256), 0, (hipStream_t)stream_, (const bf16_t*)rk, (bf16_t*)rk_t, P, 4 * P);
+  TFASR_KLAUNCH(lstm_transpose_kernel, dim3((4 * P + 31) / 32, (P + 31) / 32), dim3(256), 0, (hipStream_t)stream_, (const bf16_t*)rk, (bf16_t*)rk_t, P, 4 * P);
   TFASR_CHECK_LAUNCH();
   return TFASR_STATUS_SUCCESS;
 }
@@ -445,7 +445,7 @@ extern "C" int tfasr_lstm_steps_fwd(const void* xg, const void* rk, const void* 
   const int MT = (B + 15) / 16, Bp = MT * 16;
   const size_t smem = (size_t)Bp * (P * 2 + 16) + (size_t)4 * Bp * PW * 4;
   const dim3 grid(P / PW);
-#define TFASR_LAUNCH(M) hipLaunchKernelGGL(lstm_persist_fwd_kernel<M>, grid, dim3(256), smem, s, (const bf16_t*)xg, (const bf16_t*)rk, (const bf16_t*)h0, \
+#define TFASR_LAUNCH(M) TFASR_KLAUNCH(lstm_persist_fwd_kernel<M>, grid, dim3(256), smem, s, (const bf16_t*)xg, (const bf16_t*)rk, (const bf16_t*)h0, \
                                            h0_stride_b, c0, c0_stride_b, lengths, (bf16_t*)gates, cseq, (bf16_t*)hseq, (bf16_t*)yseq, B, U1, P, (Sync*)nullptr, \
                                            (const bf16_t*)rk_t, t, t + 1)
   for (int t = t0; t < t1; ++t)
@@ -463,7 +463,7 @@ extern "C" int tfasr_lstm_steps_bwd(const void* dy, const void* rk, const void* 
   const int MT = (B + 15) / 16, Bp = MT * 16;
   const size_t smem = (size_t)4 * Bp * PW * 4;
   const dim3 grid(P / PW);
-#define TFASR_LAUNCH(M) hipLaunchKernelGGL(lstm_persist_bwd_kernel<M>, grid, dim3(256), smem, s, (const bf16_t*)dy, (const bf16_t*)rk, (const bf16_t*)gates, cseq, \
+#define TFASR_LAUNCH(M) TFASR_KLAUNCH(lstm_persist_bwd_kernel<M>, grid, dim3(256), smem, s, (const bf16_t*)dy, (const bf16_t*)rk, (const bf16_t*)gates, cseq, \
                                            lengths, (bf16_t*)dz, dh_carry, dc_carry, B, U1, P, (Sync*)nullptr, t, t + 1)
   for (int t = t1 - 1; t >= t0; --t)
     switch (MT) { case 1: TFASR_LAUNCH(1); break; case 2: TFASR_LAUNCH(2); break; case 3: TFASR_LAUNCH(3); break; default: TFASR_LAUNCH(4); }
@@ -488,7 +488,7 @@ extern "C" int tfasr_lstm_persist_fwd(const void* xg, const void* rk, const void
   const int MT = (B + 15) / 16, Bp = MT * 16;
   const size_t smem = (size_t)Bp * (P * 2 + 16) + (size_t)4 * Bp * PW * 4;
   const dim3 grid(P / PW);
-#define TFASR_LAUNCH(M) hipLaunchKernelGGL(lstm_persist_fwd_kernel<M>, grid, dim3(256), smem, s, (const bf16_t*)xg, (const bf16_t*)rk, (const bf16_t*)h0, \
+#define TFASR_LAUNCH(M) TFASR_KLAUNCH(lstm_persist_fwd_kernel<M>, grid, dim3(256), smem, s, (const bf16_t*)xg, (const bf16_t*)rk, (const bf16_t*)h0, \
                                            h0_stride_b, c0, c0_stride_b, lengths, (bf16_t*)gates, cseq, (bf16_t*)hseq, (bf16_t*)yseq, B, U1, P, (Sync*)sync)
   const bool fits = MT == 1 ? grid_fits(lstm_persist_fwd_kernel<1>, grid.x, smem) : MT == 2 ? grid_fits(lstm_persist_fwd_kernel<2>, grid.x, smem)
                     : MT == 3 ? grid_fits(lstm_persist_fwd_kernel<3>, grid.x, smem) : grid_fits(lstm_persist_fwd_kernel<4>, grid.x, smem);
@@ -508,7 +508,7 @@ extern "C" int tfasr_lstm_persist_bwd(const void* dy, const void* rk, const void
   const int MT = (B + 15) / 16, Bp = MT * 16;
   const size_t smem = (size_t)4 * Bp * PW * 4;
   const dim3 grid(P / PW);
-#define TFASR_LAUNCH(M) hipLaunchKernelGGL(lstm_persist_bwd_kernel<M>, grid, dim3(256), smem, s, (const bf16_t*)dy, (const bf16_t*)rk, (const bf16_t*)gates, cseq, \
+#define TFASR_LAUNCH(M) TFASR_KLAUNCH(lstm_persist_bwd_kernel<M>, grid, dim3(256), smem, s, (const bf16_t*)dy, (const bf16_t*)rk, (const bf16_t*)gates, cseq, \
                                            lengths, (bf16_t*)dz, dh_carry, dc_carry, B, U1, P, (Sync*)sync)
   const bool fits = MT == 1 ? grid_fits(lstm_persist_bwd_kernel<1>, grid.x, smem) : MT == 2 ? grid_fits(lstm_persist_bwd_kernel<2>, grid.x, smem)
                     : MT == 3 ? grid_fits(lstm_persist_bwd_kernel<3>, grid.x, smem) : grid_fits(lstm_persist_bwd_kernel<4>, grid.x, smem);

@@ -626,21 +626,21 @@ extern "C" int tfasr_layernorm_fwd(const void* x, const float* gamma, const floa
       static const int U = 4;
       static const long cap = 2048L;
       const int grid = (int)std::min<long>((rows + 8 * U - 1) / (8 * U), cap);
-      if (U == 4) hipLaunchKernelGGL((ln_fwd_vec_kernel<bf16_t, 32, 4>), dim3(grid), dim3(256), 0, s, (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, rows, C, eps);
-      else if (U == 1) hipLaunchKernelGGL((ln_fwd_vec_kernel<bf16_t, 32, 1>), dim3(grid), dim3(256), 0, s, (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, rows, C, eps);
-      else hipLaunchKernelGGL((ln_fwd_vec_kernel<bf16_t, 32>), dim3(grid), dim3(256), 0, s, (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, rows, C, eps);
+      if (U == 4) TFASR_KLAUNCH((ln_fwd_vec_kernel<bf16_t, 32, 4>), dim3(grid), dim3(256), 0, s, (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, rows, C, eps);
+      else if (U == 1) TFASR_KLAUNCH((ln_fwd_vec_kernel<bf16_t, 32, 1>), dim3(grid), dim3(256), 0, s, (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, rows, C, eps);
+      else TFASR_KLAUNCH((ln_fwd_vec_kernel<bf16_t, 32>), dim3(grid), dim3(256), 0, s, (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, rows, C, eps);
     } else {
       const int grid = (int)std::min<long>((rows + 3) / 4, 2048L);
-      hipLaunchKernelGGL((ln_fwd_vec_kernel<bf16_t, 64>), dim3(grid), dim3(256), 0, s, (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, rows, C, eps);
+      TFASR_KLAUNCH((ln_fwd_vec_kernel<bf16_t, 64>), dim3(grid), dim3(256), 0, s, (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, rows, C, eps);
     }
     TFASR_CHECK_LAUNCH();
     return TFASR_STATUS_SUCCESS;
   }
   if (dtype == TFASR_F32)
-    hipLaunchKernelGGL(ln_fwd_kernel<float>, dim3(rows_grid(rows)), dim3(256), 0, s, (const float*)x, gamma, beta,
+    TFASR_KLAUNCH(ln_fwd_kernel<float>, dim3(rows_grid(rows)), dim3(256), 0, s, (const float*)x, gamma, beta,
                        (float*)y, mean, rstd, rows, C, eps);
   else
-    hipLaunchKernelGGL(ln_fwd_kernel<bf16_t>, dim3(rows_grid(rows)), dim3(256), 0, s, (const bf16_t*)x, gamma, beta,
+    TFASR_KLAUNCH(ln_fwd_kernel<bf16_t>, dim3(rows_grid(rows)), dim3(256), 0, s, (const bf16_t*)x, gamma, beta,
                        (bf16_t*)y, mean, rstd, rows, C, eps);
   TFASR_CHECK_LAUNCH();
   return TFASR_STATUS_SUCCESS;
@@ -667,10 +667,10 @@ static int ln_bwd_vec_launch(const void* dy, const void* x, const float* gamma, 
   // nblk > 0: the caller's partial-sum buffer has that many slots (shared with other producers): blocks without rows store zeros
   const int grid = nblk > 0 ? nblk : ln_bwd_vec_grid(rows, C, part != nullptr);
   if (C <= 256)
-    hipLaunchKernelGGL((ln_bwd_vec_kernel<bf16_t, 32, 2, 8>), dim3(grid), dim3(512), 0, s, (const bf16_t*)dy, (const bf16_t*)x, gamma, mean, rstd,
+    TFASR_KLAUNCH((ln_bwd_vec_kernel<bf16_t, 32, 2, 8>), dim3(grid), dim3(512), 0, s, (const bf16_t*)dy, (const bf16_t*)x, gamma, mean, rstd,
                        (const bf16_t*)add, (bf16_t*)dx, dgamma, dbeta, rows, C, (bf16_t*)dx_dropped, drop_p, (uint64_t)drop_seed, part);
   else
-    hipLaunchKernelGGL((ln_bwd_vec_kernel<bf16_t, 64, 2, 8>), dim3(grid), dim3(512), 0, s, (const bf16_t*)dy, (const bf16_t*)x, gamma, mean, rstd,
+    TFASR_KLAUNCH((ln_bwd_vec_kernel<bf16_t, 64, 2, 8>), dim3(grid), dim3(512), 0, s, (const bf16_t*)dy, (const bf16_t*)x, gamma, mean, rstd,
                        (const bf16_t*)add, (bf16_t*)dx, dgamma, dbeta, rows, C, (bf16_t*)dx_dropped, drop_p, (uint64_t)drop_seed, part);
   TFASR_CHECK_LAUNCH();
   return TFASR_STATUS_SUCCESS;
@@ -700,7 +700,7 @@ extern "C" int tfasr_layernorm_bwd_fold(const float* part, int nsets, int nblk, 
   if (!part || nsets <= 0 || nsets > LNF_MAX || nblk <= 0 || C <= 0 || !dgamma || !dbeta) return TFASR_STATUS_INVALID_VALUE;
   LnFoldArgs a;
   for (int i = 0; i < LNF_MAX; ++i) { a.dg[i] = i < nsets ? dgamma[i] : nullptr; a.db[i] = i < nsets ? dbeta[i] : nullptr; }
-  hipLaunchKernelGGL(ln_bwd_fold_kernel, dim3((2 * C + 63) / 64, nsets), dim3(256), 0, (hipStream_t)stream_, part, nblk, C, a);
+  TFASR_KLAUNCH(ln_bwd_fold_kernel, dim3((2 * C + 63) / 64, nsets), dim3(256), 0, (hipStream_t)stream_, part, nblk, C, a);
   TFASR_CHECK_LAUNCH();
   return TFASR_STATUS_SUCCESS;
 }
@@ -715,7 +715,7 @@ extern "C" int tfasr_layernorm_bwd_fold_sets(const float* const* part, int nsets
     a.db[i] = i < nsets ? dbeta[i] : nullptr;
     if (i < nsets && !part[i]) return TFASR_STATUS_INVALID_VALUE;
   }
-  hipLaunchKernelGGL(ln_bwd_fold_sets_kernel, dim3((2 * C + 63) / 64, nsets), dim3(256), 0, (hipStream_t)stream_, nblk, C, a);
+  TFASR_KLAUNCH(ln_bwd_fold_sets_kernel, dim3((2 * C + 63) / 64, nsets), dim3(256), 0, (hipStream_t)stream_, nblk, C, a);
   TFASR_CHECK_LAUNCH();
   return TFASR_STATUS_SUCCESS;
 }
@@ -731,10 +731,10 @@ extern "C" int tfasr_layernorm_bwd_drop(const void* dy, const void* x, const flo
     return ln_bwd_vec_launch(dy, x, gamma, mean, rstd, add, dx, dgamma, dbeta, dx_dropped, drop_p, drop_seed, rows, C, nullptr, s);
   const int grid = (int)std::min<long>((rows + 3) / 4, 256L);
   if (dtype == TFASR_F32)
-    hipLaunchKernelGGL(ln_bwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)dy, (const float*)x, gamma, mean,
+    TFASR_KLAUNCH(ln_bwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)dy, (const float*)x, gamma, mean,
                        rstd, (const float*)add, (float*)dx, dgamma, dbeta, rows, C);
   else
-    hipLaunchKernelGGL(ln_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x, gamma,
+    TFASR_KLAUNCH(ln_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x, gamma,
                        mean, rstd, (const bf16_t*)add, (bf16_t*)dx, dgamma, dbeta, rows, C);
   TFASR_CHECK_LAUNCH();
   // shapes outside the vectorised kernel: the dropped copy is a separate pass (same mask, same rounding)
@@ -752,17 +752,17 @@ extern "C" int tfasr_bn_stats(const void* x, float* stats, long rows, int C, int
   if (!x || !stats || rows <= 0 || C <= 0 || (C > 64 * MAXC_PER_LANE && (dtype != TFASR_BF16 || (C % 8)))) return TFASR_STATUS_INVALID_VALUE;
   hipStream_t s = (hipStream_t)stream_;
   if (dtype == TFASR_BF16 && (C % 8) == 0) {
-    if (C <= 256) hipLaunchKernelGGL((bn_stats_vec_kernel<bf16_t, 0, 32>), dim3(fat_grid(rows, 2)), dim3(red_threads()), 0, s, (const bf16_t*)x, (const bf16_t*)nullptr, (const float*)nullptr, stats, rows, C, 0);
-    else hipLaunchKernelGGL((bn_stats_vec_kernel<bf16_t, 0, 64>), dim3(fat_grid(rows, 1), (C + 511) / 512), dim3(red_threads()), 0, s, (const bf16_t*)x, (const bf16_t*)nullptr, (const float*)nullptr, stats, rows, C, 0);
+    if (C <= 256) TFASR_KLAUNCH((bn_stats_vec_kernel<bf16_t, 0, 32>), dim3(fat_grid(rows, 2)), dim3(red_threads()), 0, s, (const bf16_t*)x, (const bf16_t*)nullptr, (const float*)nullptr, stats, rows, C, 0);
+    else TFASR_KLAUNCH((bn_stats_vec_kernel<bf16_t, 0, 64>), dim3(fat_grid(rows, 1), (C + 511) / 512), dim3(red_threads()), 0, s, (const bf16_t*)x, (const bf16_t*)nullptr, (const float*)nullptr, stats, rows, C, 0);
     TFASR_CHECK_LAUNCH();
     return TFASR_STATUS_SUCCESS;
   }
   const int grid = (int)std::min<long>((rows + 3) / 4, 1024L);
   if (dtype == TFASR_F32)
-    hipLaunchKernelGGL((bn_stats_kernel<float, 0>), dim3(grid), dim3(256), 0, s, (const float*)x, (const float*)nullptr,
+    TFASR_KLAUNCH((bn_stats_kernel<float, 0>), dim3(grid), dim3(256), 0, s, (const float*)x, (const float*)nullptr,
                        (const float*)nullptr, stats, rows, C, 0);
   else
-    hipLaunchKernelGGL((bn_stats_kernel<bf16_t, 0>), dim3(grid), dim3(256), 0, s, (const bf16_t*)x,
+    TFASR_KLAUNCH((bn_stats_kernel<bf16_t, 0>), dim3(grid), dim3(256), 0, s, (const bf16_t*)x,
                        (const bf16_t*)nullptr, (const float*)nullptr, stats, rows, C, 0);
   TFASR_CHECK_LAUNCH();
   return TFASR_STATUS_SUCCESS;
@@ -774,7 +774,7 @@ extern "C" int tfasr_bn_finalize(const float* stats, float count, const float* g
   if (!gamma || !beta || !fin || C <= 0) return TFASR_STATUS_INVALID_VALUE;
   if (training && !stats) return TFASR_STATUS_INVALID_VALUE;
   if (!training && (!moving_mean || !moving_var)) return TFASR_STATUS_INVALID_VALUE;
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream_, stats, count, gamma,
+  TFASR_KLAUNCH(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream_, stats, count, gamma,
                      beta, fin, moving_mean, moving_var, momentum, eps, C, training);
   TFASR_CHECK_LAUNCH();
   return TFASR_STATUS_SUCCESS;
@@ -787,16 +787,16 @@ extern "C" int tfasr_bn_apply_fwd(const void* x, const float* fin, void* y, long
   hipStream_t s = (hipStream_t)stream_;
   if (rows_variant_ok(C)) {
     const int grid = rows_variant_grid(rows, C);
-    if (dtype == TFASR_F32) hipLaunchKernelGGL(bn_apply_fwd_rows_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, fin, (float*)y, rows, C, act);
-    else hipLaunchKernelGGL(bn_apply_fwd_rows_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)x, fin, (bf16_t*)y, rows, C, act);
+    if (dtype == TFASR_F32) TFASR_KLAUNCH(bn_apply_fwd_rows_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, fin, (float*)y, rows, C, act);
+    else TFASR_KLAUNCH(bn_apply_fwd_rows_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)x, fin, (bf16_t*)y, rows, C, act);
     TFASR_CHECK_LAUNCH();
     return TFASR_STATUS_SUCCESS;
   }
   if (dtype == TFASR_F32)
-    hipLaunchKernelGGL(bn_apply_fwd_kernel<float>, dim3(flat_grid(n8)), dim3(256), 0, s, (const float*)x, fin, (float*)y,
+    TFASR_KLAUNCH(bn_apply_fwd_kernel<float>, dim3(flat_grid(n8)), dim3(256), 0, s, (const float*)x, fin, (float*)y,
                        n8, C, act);
   else
-    hipLaunchKernelGGL(bn_apply_fwd_kernel<bf16_t>, dim3(flat_grid(n8)), dim3(256), 0, s, (const bf16_t*)x, fin,
+    TFASR_KLAUNCH(bn_apply_fwd_kernel<bf16_t>, dim3(flat_grid(n8)), dim3(256), 0, s, (const bf16_t*)x, fin,
                        (bf16_t*)y, n8, C, act);
   TFASR_CHECK_LAUNCH();
   return TFASR_STATUS_SUCCESS;
@@ -812,10 +812,10 @@ extern "C" int tfasr_bn_finalize_apply_fwd(const void* x, const float* stats, fl
   hipStream_t s = (hipStream_t)stream_;
   const int grid = rows_variant_grid(rows, C);
   if (dtype == TFASR_F32)
-    hipLaunchKernelGGL(bn_finalize_apply_fwd_rows_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, stats, count, gamma, beta, fin, moving_mean,
+    TFASR_KLAUNCH(bn_finalize_apply_fwd_rows_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, stats, count, gamma, beta, fin, moving_mean,
                        moving_var, momentum, eps, (float*)y, rows, C, act, training);
   else
-    hipLaunchKernelGGL(bn_finalize_apply_fwd_rows_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)x, stats, count, gamma, beta, fin, moving_mean,
+    TFASR_KLAUNCH(bn_finalize_apply_fwd_rows_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)x, stats, count, gamma, beta, fin, moving_mean,
                        moving_var, momentum, eps, (bf16_t*)y, rows, C, act, training);
   TFASR_CHECK_LAUNCH();
   return TFASR_STATUS_SUCCESS;
@@ -826,17 +826,17 @@ extern "C" int tfasr_bn_bwd_stats(const void* x, const void* dy, const float* fi
   if (!x || !dy || !fin || !bstats || rows <= 0 || C <= 0 || (C > 64 * MAXC_PER_LANE && (dtype != TFASR_BF16 || (C % 8)))) return TFASR_STATUS_INVALID_VALUE;
   hipStream_t s = (hipStream_t)stream_;
   if (dtype == TFASR_BF16 && (C % 8) == 0) {
-    if (C <= 256) hipLaunchKernelGGL((bn_stats_vec_kernel<bf16_t, 1, 32>), dim3(fat_grid(rows, 2)), dim3(red_threads()), 0, s, (const bf16_t*)x, (const bf16_t*)dy, fin, bstats, rows, C, act);
-    else hipLaunchKernelGGL((bn_stats_vec_kernel<bf16_t, 1, 64>), dim3(fat_grid(rows, 1), (C + 511) / 512), dim3(red_threads()), 0, s, (const bf16_t*)x, (const bf16_t*)dy, fin, bstats, rows, C, act);
+    if (C <= 256) TFASR_KLAUNCH((bn_stats_vec_kernel<bf16_t, 1, 32>), dim3(fat_grid(rows, 2)), dim3(red_threads()), 0, s, (const bf16_t*)x, (const bf16_t*)dy, fin, bstats, rows, C, act);
+    else TFASR_KLAUNCH((bn_stats_vec_kernel<bf16_t, 1, 64>), dim3(fat_grid(rows, 1), (C + 511) / 512), dim3(red_threads()), 0, s, (const bf16_t*)x, (const bf16_t*)dy, fin, bstats, rows, C, act);
     TFASR_CHECK_LAUNCH();
     return TFASR_STATUS_SUCCESS;
   }
   const int grid = (int)std::min<long>((rows + 3) / 4, 1024L);
   if (dtype == TFASR_F32)
-    hipLaunchKernelGGL((bn_stats_kernel<float, 1>), dim3(grid), dim3(256), 0, s, (const float*)x, (const float*)dy, fin,
+    TFASR_KLAUNCH((bn_stats_kernel<float, 1>), dim3(grid), dim3(256), 0, s, (const float*)x, (const float*)dy, fin,
                        bstats, rows, C, act);
   else
-    hipLaunchKernelGGL((bn_stats_kernel<bf16_t, 1>), dim3(grid), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)dy,
+    TFASR_KLAUNCH((bn_stats_kernel<bf16_t, 1>), dim3(grid), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)dy,
                        fin, bstats, rows, C, act);
   TFASR_CHECK_LAUNCH();
   return TFASR_STATUS_SUCCESS;
@@ -849,8 +849,8 @@ extern "C" int tfasr_bn_apply_bwd_grads(const void* x, const void* dy, const flo
   hipStream_t s = (hipStream_t)stream_;
   if (rows_variant_ok(C)) {
     const int grid = rows_variant_grid(rows, C);
-    if (dtype == TFASR_F32) hipLaunchKernelGGL(bn_apply_bwd_rows_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, (const float*)dy, fin, bstats, count, (float*)dx, rows, C, act, dgamma, dbeta, grad_scale);
-    else hipLaunchKernelGGL(bn_apply_bwd_rows_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)dy, fin, bstats, count, (bf16_t*)dx, rows, C, act, dgamma, dbeta, grad_scale);
+    if (dtype == TFASR_F32) TFASR_KLAUNCH(bn_apply_bwd_rows_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, (const float*)dy, fin, bstats, count, (float*)dx, rows, C, act, dgamma, dbeta, grad_scale);
+    else TFASR_KLAUNCH(bn_apply_bwd_rows_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)dy, fin, bstats, count, (bf16_t*)dx, rows, C, act, dgamma, dbeta, grad_scale);
     TFASR_CHECK_LAUNCH();
     return TFASR_STATUS_SUCCESS;
   }
@@ -858,10 +858,10 @@ extern "C" int tfasr_bn_apply_bwd_grads(const void* x, const void* dy, const flo
   if (dbeta) { const int st = tfasr_axpy(dbeta, bstats, grad_scale, C, stream_); if (st != TFASR_STATUS_SUCCESS) return st; }
   if (dgamma) { const int st = tfasr_axpy(dgamma, bstats + C, grad_scale, C, stream_); if (st != TFASR_STATUS_SUCCESS) return st; }
   if (dtype == TFASR_F32)
-    hipLaunchKernelGGL(bn_apply_bwd_kernel<float>, dim3(flat_grid(n8)), dim3(256), 0, s, (const float*)x,
+    TFASR_KLAUNCH(bn_apply_bwd_kernel<float>, dim3(flat_grid(n8)), dim3(256), 0, s, (const float*)x,
                        (const float*)dy, fin, bstats, count, (float*)dx, n8, C, act);
   else
-    hipLaunchKernelGGL(bn_apply_bwd_kernel<bf16_t>, dim3(flat_grid(n8)), dim3(256), 0, s, (const bf16_t*)x,
+    TFASR_KLAUNCH(bn_apply_bwd_kernel<bf16_t>, dim3(flat_grid(n8)), dim3(256), 0, s, (const bf16_t*)x,
                        (const bf16_t*)dy, fin, bstats, count, (bf16_t*)dx, n8, C, act);
   TFASR_CHECK_LAUNCH();
   return TFASR_STATUS_SUCCESS;

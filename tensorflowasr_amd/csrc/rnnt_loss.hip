@@ -620,13 +620,13 @@ static int rnnt_impl(const void* logits, void* grads, const int32_t* labels, con
   int grid = (int)std::min<long>((nrows + wpb - 1) / wpb, 256L * 32);
   if (lse_part) {
     const int fg = (int)std::min<long>(((lse_parts == 16 ? nrows * 16 : nrows) + 255) / 256, 256L * 16);
-    hipLaunchKernelGGL(rnnt_stats_finalize_kernel, dim3(fg), dim3(256), 0, stream, (const float2*)lse_part, lse_parts, pick, label_len, logit_len,
+    TFASR_KLAUNCH(rnnt_stats_finalize_kernel, dim3(fg), dim3(256), 0, stream, (const float2*)lse_part, lse_parts, pick, label_len, logit_len,
                        cell_off, nrows, B, T, U1, lse, blank_lp, truth_lp);
   } else if (dtype == TFASR_F32)
-    hipLaunchKernelGGL(rnnt_logprobs_kernel<float>, dim3(grid), dim3(256), 0, stream, (const float*)logits, labels,
+    TFASR_KLAUNCH(rnnt_logprobs_kernel<float>, dim3(grid), dim3(256), 0, stream, (const float*)logits, labels,
                        label_len, logit_len, cell_off, nrows, B, T, U1, V, lse, blank_lp, truth_lp);
   else if (dtype == TFASR_BF16)
-    hipLaunchKernelGGL(rnnt_logprobs_kernel<bf16_t>, dim3(grid), dim3(256), 0, stream, (const bf16_t*)logits, labels,
+    TFASR_KLAUNCH(rnnt_logprobs_kernel<bf16_t>, dim3(grid), dim3(256), 0, stream, (const bf16_t*)logits, labels,
                        label_len, logit_len, cell_off, nrows, B, T, U1, V, lse, blank_lp, truth_lp);
   else
     return TFASR_STATUS_INVALID_VALUE;
@@ -634,13 +634,13 @@ static int rnnt_impl(const void* logits, void* grads, const int32_t* labels, con
   const int nthr = ((U1 + 63) / 64) * 64;
   static const bool wave_off = false;  // A/B probe: the workgroup kernel
   static const bool fast = !(false);
-#define TFASR_LW(E) do { if (fast) hipLaunchKernelGGL((rnnt_lattice_wave_kernel<E, true>), dim3(B, 2), dim3(64), 0, stream, blank_lp, truth_lp, label_len, logit_len, cell_off, T, U1, alpha, beta, costs); \
-                         else hipLaunchKernelGGL((rnnt_lattice_wave_kernel<E, false>), dim3(B, 2), dim3(64), 0, stream, blank_lp, truth_lp, label_len, logit_len, cell_off, T, U1, alpha, beta, costs); } while (0)
+#define TFASR_LW(E) do { if (fast) TFASR_KLAUNCH((rnnt_lattice_wave_kernel<E, true>), dim3(B, 2), dim3(64), 0, stream, blank_lp, truth_lp, label_len, logit_len, cell_off, T, U1, alpha, beta, costs); \
+                         else TFASR_KLAUNCH((rnnt_lattice_wave_kernel<E, false>), dim3(B, 2), dim3(64), 0, stream, blank_lp, truth_lp, label_len, logit_len, cell_off, T, U1, alpha, beta, costs); } while (0)
   if (!wave_off && U1 <= 64) TFASR_LW(1);
   else if (!wave_off && U1 <= 128) TFASR_LW(2);
   else if (!wave_off && U1 <= 256) TFASR_LW(4);
   else
-    hipLaunchKernelGGL(rnnt_lattice_kernel, dim3(B, 2), dim3(nthr), 2 * nthr * sizeof(float), stream, blank_lp,
+    TFASR_KLAUNCH(rnnt_lattice_kernel, dim3(B, 2), dim3(nthr), 2 * nthr * sizeof(float), stream, blank_lp,
                        truth_lp, label_len, logit_len, cell_off, T, U1, alpha, beta, costs);
   TFASR_CHECK_LAUNCH();
   // gradient as coefficient pass + pure stream (rnnt_grad_apply_kernel) when the workspace has room for the coefficients (older callers
@@ -651,26 +651,26 @@ static int rnnt_impl(const void* logits, void* grads, const int32_t* labels, con
   int32_t* rlab = (int32_t*)(ws + 9 * seg);
   if (coef || streamed) {
     const int cg = (int)std::min<long>((nrows + 255) / 256, 256L * 8);
-    hipLaunchKernelGGL(rnnt_coef_kernel, dim3(cg), dim3(256), 0, stream, label_len, logit_len, grad_scale, cell_off, nrows, B, T, U1, lse, blank_lp,
+    TFASR_KLAUNCH(rnnt_coef_kernel, dim3(cg), dim3(256), 0, stream, label_len, logit_len, grad_scale, cell_off, nrows, B, T, U1, lse, blank_lp,
                        truth_lp, alpha, beta, cbuf, streamed ? labels : (const int32_t*)nullptr, V, streamed ? rlab : (int32_t*)nullptr);
     TFASR_CHECK_LAUNCH();
   }
   if (streamed) {
     const int ag = (int)std::min<long>((nrows + 7) / 8, 256L * 16);
     if (dtype == TFASR_F32)
-      hipLaunchKernelGGL(rnnt_grad_apply_kernel<float>, dim3(ag), dim3(256), 0, stream, (const float*)logits, (float*)grads, cbuf, rlab, nrows, V);
+      TFASR_KLAUNCH(rnnt_grad_apply_kernel<float>, dim3(ag), dim3(256), 0, stream, (const float*)logits, (float*)grads, cbuf, rlab, nrows, V);
     else
-      hipLaunchKernelGGL(rnnt_grad_apply_kernel<bf16_t>, dim3(ag), dim3(256), 0, stream, (const bf16_t*)logits, (bf16_t*)grads, cbuf, rlab, nrows, V);
+      TFASR_KLAUNCH(rnnt_grad_apply_kernel<bf16_t>, dim3(ag), dim3(256), 0, stream, (const bf16_t*)logits, (bf16_t*)grads, cbuf, rlab, nrows, V);
     TFASR_CHECK_LAUNCH();
     return TFASR_STATUS_SUCCESS;
   }
   if (grads) {
     if (dtype == TFASR_F32)
-      hipLaunchKernelGGL(rnnt_grad_kernel<float>, dim3(grid), dim3(256), 0, stream, (const float*)logits,
+      TFASR_KLAUNCH(rnnt_grad_kernel<float>, dim3(grid), dim3(256), 0, stream, (const float*)logits,
                          (float*)grads, labels, label_len, logit_len, grad_scale, cell_off, nrows, B, T, U1, V, lse, blank_lp,
                          truth_lp, alpha, beta);
     else
-      hipLaunchKernelGGL(rnnt_grad_kernel<bf16_t>, dim3(grid), dim3(256), 0, stream, (const bf16_t*)logits,
+      TFASR_KLAUNCH(rnnt_grad_kernel<bf16_t>, dim3(grid), dim3(256), 0, stream, (const bf16_t*)logits,
                          (bf16_t*)grads, labels, label_len, logit_len, grad_scale, cell_off, nrows, B, T, U1, V, lse, blank_lp,
                          truth_lp, alpha, beta);
     TFASR_CHECK_LAUNCH();
@@ -717,7 +717,7 @@ extern "C" int tfasr_rnnt_row_labels(const int32_t* labels, const int32_t* label
                                      long total_cells, int B, int T, int U1, int V, int32_t* row_label, void* stream_) {
   if (!labels || !label_len || !logit_len || !row_label || total_cells <= 0 || B <= 0 || T <= 0 || U1 <= 0 || V <= 1) return TFASR_STATUS_INVALID_VALUE;
   const int g = (int)std::min<long>((total_cells + 255) / 256, 256L * 8);
-  hipLaunchKernelGGL(rnnt_row_labels_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream_, labels, label_len, logit_len, cell_off, total_cells, B, T,
+  TFASR_KLAUNCH(rnnt_row_labels_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream_, labels, label_len, logit_len, cell_off, total_cells, B, T,
                      U1, V, row_label);
   TFASR_CHECK_LAUNCH();
   return TFASR_STATUS_SUCCESS;

@@ -128,7 +128,7 @@ class DataParallel:
         if stats_group == "own":
             # same ranks, second communicator (a collective call: every rank of `group` constructs its DataParallel at the same point)
             ranks = dist.get_process_group_ranks(group) if group is not None else list(range(dist.get_world_size()))
-            stats_group = dist.new_group(ranks=ranks) if os.environ.get("TFASR_DP_STATS_GROUP", "1") != "0" else group
+            stats_group = dist.new_group(ranks=ranks)
         self.stats_group = stats_group
         self.accounting = Accounting()
         self._done = []

@@ -11,7 +11,7 @@ from . import _lib
 from ._lib import ACT_NONE, ACT_SIGMOID, ACT_SWISH, ACT_TANH, ACT_TANH_OUT, TFASR_BF16, TFASR_F32, GemmArgs, check  # noqa: F401
 
 _WS_CACHE = {}
-_SPLITK_WS = os.environ.get("TFASR_SPLITK_WS", "0") == "1"
+_SPLITK_WS = False  # k-slices of a split product through a workspace (deterministic sums; measured slower than the f32 atomics: tests set it)
 
 
 def _dt(t):

@@ -104,3 +104,49 @@ def test_hoists_survive_a_process_group_and_buckets_are_final_when_released(dev)
         assert torch.equal(snap, ps.grad[lo:hi]), f"bucket [{lo}, {hi}) changed after it was released"
     gmax = float(ref.abs().max())
     np.testing.assert_allclose(ps.grad.cpu().numpy(), ref.cpu().numpy(), rtol=0, atol=2e-3 * gmax)  # (split-K / BatchNorm atomics reorder run to run)
+
+
+def _grads_after_two_steps(model, data):
+    """gradients of the SECOND of two consecutive backward passes (the side stream's two scratch arenas and event slots are reused)"""
+    out = None
+    for _ in range(2):
+        model.zero_grad()
+        costs = model.loss_and_backward(data, True, (None, None))
+        torch.cuda.synchronize()
+        out = (costs.float().cpu().numpy(), model.ps.grad.clone())
+    return out
+
+
+def test_side_stream_weight_gradients_and_deferred_launches_same_gradients(dev, monkeypatch):
+    """the grouped weight gradients on the low-priority side stream (wgrad_slot arenas reused across two steps) against the
+    in-line launches, and the deferred small gradients beside the subsampling's backward (TFASR_DEFER_SIDE=1, default) against the chain
+    (TFASR_DEFER_SIDE=0): same costs bitwise, same gradients up to the order of the f32 atomics."""
+    cfg, ocfg, model, W, data, sig, labels, preds = _setup(dev, torch.bfloat16, [4000, 2500, 3100], [6, 3, 5])
+    res = {}
+    for name, ws, defer in (("side", True, "1"), ("inline", False, "1"), ("side_chain", True, "0")):
+        model.wgrad_stream = ws
+        monkeypatch.setenv("TFASR_DEFER_SIDE", defer)
+        res[name] = _grads_after_two_steps(model, data)
+    gmax = float(res["inline"][1].abs().max())
+    for name in ("side", "side_chain"):
+        np.testing.assert_array_equal(res[name][0], res["inline"][0])
+        np.testing.assert_allclose(res[name][1].cpu().numpy(), res["inline"][1].cpu().numpy(), rtol=0, atol=2e-3 * gmax, err_msg=name)
+
+
+def test_front_end_on_the_prediction_stream_same_step(dev):
+    """`prefetched_inputs` (what bench.py sets: log-mel + SpecAugment on the prediction network's stream ahead of the previous
+    step's tail) against the in-line front end, over two consecutive steps with an optimizer update in between (the second step's front end
+    really runs beside the first one's tail): same features path -> same costs bitwise, same parameters after both updates."""
+    outs = {}
+    for pre in (False, True):
+        cfg, ocfg, model, W, data, sig, labels, preds = _setup(dev, torch.bfloat16, [4000, 2500, 3100], [6, 3, 5])
+        model.prefetched_inputs = pre
+        costs = []
+        for _ in range(2):
+            out = model.train_step(data)
+            torch.cuda.synchronize()
+            costs.append(out["loss"].float().cpu().numpy().tolist())
+        outs[pre] = (costs, model.ps.flat.clone())
+    assert outs[True][0] == outs[False][0], outs
+    pmax = float(outs[False][1].abs().max())
+    np.testing.assert_allclose(outs[True][1].cpu().numpy(), outs[False][1].cpu().numpy(), rtol=0, atol=1e-5 * pmax)

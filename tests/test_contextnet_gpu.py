@@ -92,7 +92,7 @@ def test_contextnet_recognize_runs_without_prediction_layernorm(dev):
 
 def test_batched_depthwise_weight_gradients_match_the_per_layer_launches(dev, monkeypatch):
     """bf16: the depthwise weight gradients of all layers go out batched by shape after the encoder's backward (one launch pair per shape,
-    tfasr_dwconv_bwd_weight_many); TFASR_CN_DW_BATCH=0 restores one launch pair per layer.  Same gradients (partial sums in another order)."""
+    tfasr_dwconv_bwd_weight_many); `model.dw_batch = False` restores one launch pair per layer.  Same gradients (partial sums in another order)."""
     cfg = configs.contextnet_tiny()
     model = ContextNetTransducer(cfg, dev, dtype=torch.bfloat16, seed=3)
     g = torch.Generator().manual_seed(5)
@@ -101,7 +101,7 @@ def test_batched_depthwise_weight_gradients_match_the_per_layer_launches(dev, mo
     feats = torch.randn(B, T0, F, generator=g).to(dev).to(torch.bfloat16)
     grads = {}
     for mode in ("0", "1"):
-        monkeypatch.setenv("TFASR_CN_DW_BATCH", mode)
+        model.dw_batch = mode == "1"
         ctx = {}
         out, T, elen, _ = model.encoder_fwd(feats, lens, True, ctx)
         dy = torch.randn(out.shape, generator=torch.Generator().manual_seed(7)).to(dev).to(torch.bfloat16)

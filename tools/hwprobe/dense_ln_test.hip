@@ -5,7 +5,7 @@
 #include <vector>
 #include <random>
 #include <algorithm>
-extern "C" size_t g_tfasr_launch_count = 0;
+std::atomic<size_t> g_tfasr_launch_count{0};
 
 int main(int argc, char** argv) {
   const long rows = argc > 1 ? atol(argv[1]) : 23776;

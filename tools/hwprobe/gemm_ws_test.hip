@@ -7,7 +7,7 @@
 #include <stdlib.h>
 #include <vector>
 #include <random>
-extern "C" size_t g_tfasr_launch_count = 0;
+std::atomic<size_t> g_tfasr_launch_count{0};
 
 template <int K, int CG, int MT, bool MUL>
 static float run_ws(const ws::Args& a0, int iters) {
