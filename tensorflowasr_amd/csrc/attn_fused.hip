@@ -320,37 +320,46 @@ __global__ __launch_bounds__(256, 3) void relattn_fused_fwdT_kernel(
 
     // every skewed score is read unconditionally (the strip column 15 - il + jl exists for every key of the block), THEN selected against
     // the bias score: a conditional read compiles to an exec-mask branch per element
-    float gv[4][4];
+    float4_t gv[4];
 #pragma unroll
     for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
       for (int e = 0; e < 4; ++e) gv[jt][e] = sG[gbase + jl0[jt] + e];
-    float mx = -INFINITY;
+    // t = content + position score, UNSCALED (the softmax scale is positive: the maximum commutes with it, and the exponent below is one
+    // fused multiply-add per element).  The common key block - every key inside the sample's relative positions for every query of the
+    // wave - needs no select against the bias score (wave-uniform ballot, as in the query-side backward)
+    const int trb = jthr - j0;  // keys jl < trb of this block have a relative position inside the table
+    if (__builtin_amdgcn_ballot_w64(trb >= BJ) == ~0ull) {
 #pragma unroll
-    for (int jt = 0; jt < 4; ++jt) {
-      const int tr = jthr - j0 - jl0[jt];  // keys e < tr of this tile have a relative position inside the table
+      for (int jt = 0; jt < 4; ++jt) acc_s[jt] += gv[jt];
+    } else {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float pos = (e < tr) ? gv[jt][e] : gbias;
-        acc_s[jt][e] = (acc_s[jt][e] + pos) * scale2q;  // (scale2q = 0 for a padded query row: constant scores)
+      for (int jt = 0; jt < 4; ++jt) {
+        const int tr = trb - jl0[jt];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc_s[jt][e] += (e < tr) ? gv[jt][e] : gbias;
       }
     }
-    if (STREAM || j0 + BJ > T) {  // keys outside [klo, khi): past the end of a ragged last block / outside the streaming window
+    const bool edge = STREAM || j0 + BJ > T;  // keys outside [klo, khi): past the end of a ragged last block / outside the streaming window
+    float mx;
+    if (edge) {
+      mx = -INFINITY;
 #pragma unroll
       for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int j = j0 + jl0[jt] + e;
-          if (j < klo || j >= khi) acc_s[jt][e] = -INFINITY;
+          mx = fmaxf(mx, (j < klo || j >= khi) ? -INFINITY : acc_s[jt][e]);
         }
+    } else {
+      float m4[4];
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt) m4[jt] = fmaxf(fmaxf(acc_s[jt][0], acc_s[jt][1]), fmaxf(acc_s[jt][2], acc_s[jt][3]));
+      mx = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
     }
-#pragma unroll
-    for (int jt = 0; jt < 4; ++jt)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) mx = fmaxf(mx, acc_s[jt][e]);
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);
+    mx = xor32_max(xor16_max(mx));
+    // (scale2q = 0 for a padded query row: constant scores; its keys are finite, so 0 * mx = 0)
+    const float m_new = fmaxf(m_run, mx == -INFINITY ? -INFINITY : mx * scale2q);
     const float m_ref = (STREAM && m_new == -INFINITY) ? 0.f : m_new;
     const float corr = __builtin_amdgcn_exp2f(m_run - m_ref);
     float rs = 0.f;
@@ -359,20 +368,25 @@ __global__ __launch_bounds__(256, 3) void relattn_fused_fwdT_kernel(
     for (int jt = 0; jt < 4; ++jt) {
       float p[4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { p[e] = __builtin_amdgcn_exp2f(acc_s[jt][e] - m_ref); rs += p[e]; }
+      for (int e = 0; e < 4; ++e) p[e] = __builtin_amdgcn_exp2f(__builtin_fmaf(acc_s[jt][e], scale2q, -m_ref));
+      if (edge) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int j = j0 + jl0[jt] + e;
+          if (j < klo || j >= khi) p[e] = 0.f;
+        }
+      }
+      rs += (p[0] + p[1]) + (p[2] + p[3]);
       const uint32_t lo = pack2_bf16(p[0], p[1]), hi = pack2_bf16(p[2], p[3]);
       const int o = (jt & 1) * 4;
       pf[jt >> 1][o + 0] = (short)(lo & 0xffffu); pf[jt >> 1][o + 1] = (short)(lo >> 16);
       pf[jt >> 1][o + 2] = (short)(hi & 0xffffu); pf[jt >> 1][o + 3] = (short)(hi >> 16);
     }
-    rs += __shfl_xor(rs, 16, 64);
-    rs += __shfl_xor(rs, 32, 64);
+    rs = xor32_sum(xor16_sum(rs));
     l_run = l_run * corr + rs;
     m_run = m_new;
 #pragma unroll
-    for (int n = 0; n < 4; ++n)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) acc_o[n][e] *= corr;
+    for (int n = 0; n < 4; ++n) acc_o[n] *= corr;
     ATT_TICK(2)
     // this block's V (2 pieces per wave, issued in front of the 6 of the next block's K / window) has landed, for every wave
     if (jb + 1 < jb_hi) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
@@ -504,8 +518,7 @@ __global__ __launch_bounds__(256, MODE == 2 ? 3 : 2) void relattn_fused_bwd_qT_k
       *reinterpret_cast<short8_t*>(qv_out + ((long)b * T + irow) * HD + h * DH + kk * 32 + g * 8) = bqv[kk];
     }
   }
-  dpart += __shfl_xor(dpart, 16, 64);
-  dpart += __shfl_xor(dpart, 32, 64);  // D_i of this lane's query, in all four lanes of its column
+  dpart = xor32_sum(xor16_sum(dpart));  // D_i of this lane's query, in all four lanes of its column
   if (g == 0 && i < T) dvec[((long)b * H + h) * T + i] = dpart;
   const float Di = dpart;
   const float scale2 = scale * 1.4426950408889634f;
@@ -546,8 +559,7 @@ __global__ __launch_bounds__(256, MODE == 2 ? 3 : 2) void relattn_fused_bwd_qT_k
 #pragma unroll
       for (int t = 0; t < 8; ++t) part += bf16_to_f32((bf16_t)bqv[kk][t]) * pr[t];
     }
-    part += __shfl_xor(part, 16, 64);
-    part += __shfl_xor(part, 32, 64);
+    part = xor32_sum(xor16_sum(part));
     gbias = part;
   } else {
     char* const sP = sP0;
@@ -777,8 +789,7 @@ __global__ __launch_bounds__(256, MODE == 2 ? 3 : 2) void relattn_fused_bwd_qT_k
     for (int kk = 0; kk < 2; ++kk) bqv[kk] = *reinterpret_cast<const short8_t*>(fr_qv + kk * 32);
   }
   float bsum = bias_acc;
-  bsum += __shfl_xor(bsum, 16, 64);
-  bsum += __shfl_xor(bsum, 32, 64);
+  bsum = xor32_sum(xor16_sum(bsum));
   float su[4][4], sv[4][4];
 #pragma unroll
   for (int n = 0; n < 4; ++n) {

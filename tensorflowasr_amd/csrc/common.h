@@ -102,6 +102,33 @@ __device__ __forceinline__ float row16_max(float v) {
   return v;
 }
 
+// Cross-row steps of a wave reduction WITHOUT the LDS crossbar (__shfl_xor compiles to ds_bpermute_b32: an LDS round trip, ~100 cycles in
+// a dependent chain): gfx950's v_permlane16_swap / v_permlane32_swap exchange the odd 16-lane rows (the upper 32 lanes) of one register with
+// the even rows (the lower lanes) of another.  Given the same value in both, the two results hold (own row group, partner row group) in
+// every lane: one VALU op each for lane ^ 16 and lane ^ 32.
+__device__ __forceinline__ float xor16_sum(float v) {
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float xor32_sum(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float xor16_max(float v) {
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __builtin_fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float xor32_max(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __builtin_fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+
+// the value lane ^ 16 holds (one v_permlane16_swap + one select instead of a ds_bpermute round trip); `odd_row` = (lane >> 4) & 1
+__device__ __forceinline__ uint32_t xor16_get(uint32_t v, bool odd_row) {
+  const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+  return odd_row ? r[0] : r[1];
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -471,8 +471,7 @@ __global__ __launch_bounds__(1024) void decode_joint_mfma_kernel(
 #pragma unroll
       for (int i = 0; i < GPW; ++i)
         if (g0 + i < g1) ps += (a[i][m].x + a[i][m].y) + (a[i][m].z + a[i][m].w);
-      ps += __shfl_xor(ps, 16, 64);
-      ps += __shfl_xor(ps, 32, 64);
+      ps = xor32_sum(xor16_sum(ps));
       if (g == 0) s_red[0][w][m * 16 + r] = ps;
     }
     __syncthreads();
@@ -489,8 +488,7 @@ __global__ __launch_bounds__(1024) void decode_joint_mfma_kernel(
           const float d0 = a[i][m].x - mu[m], d1 = a[i][m].y - mu[m], d2 = a[i][m].z - mu[m], d3 = a[i][m].w - mu[m];
           qs += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
         }
-      qs += __shfl_xor(qs, 16, 64);
-      qs += __shfl_xor(qs, 32, 64);
+      qs = xor32_sum(xor16_sum(qs));
       if (g == 0) s_red[1][w][m * 16 + r] = qs;
     }
     DEC_T(1, 3)

@@ -18,7 +18,7 @@
 // The accumulators are TRANSPOSED (the operand slots of the MFMA swapped, as gemm_big's TR epilogue): lane (r, g) of fragment (i, j)
 // holds row i*16 + r, four CONSECUTIVE columns j*16 + g*4 + e.  So the LayerNorm backward runs straight from the accumulators: x / add /
 // dx are 8-byte pieces per lane (the four j of a lane group cover one 128-byte line per row), a row's sums are in-lane over 16 values +
-// two cross-group shuffles + one LDS exchange between the four column waves, the gamma / beta column sums are DPP sums over the 16 rows
+// two cross-group lane swaps + one LDS exchange between the four column waves, the gamma / beta column sums are DPP sums over the 16 rows
 // of a fragment.  No transposition through LDS (a first version with 16-row LDS strips spent 24 k of its 58 k clocks per tile there).
 #pragma once
 
@@ -203,8 +203,8 @@ __global__ __launch_bounds__(512, 2) void dense_ln_bwd_kernel(const DenseLnArgs 
         ab[j][e] += d;
       }
     }
-    s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
-    s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
+    s1 = xor32_sum(xor16_sum(s1));
+    s2 = xor32_sum(xor16_sum(s2));
     if (g == 0) *reinterpret_cast<float2*>(red + ((wn * ROWS + (wm * MTW + i) * 16 + r) * 2)) = make_float2(s1, s2);
   }
   __syncthreads();

@@ -126,13 +126,13 @@ __global__ __launch_bounds__(256, WGS) void ffn_fused_fwd_kernel(const FfnArgs p
 #pragma unroll
       for (int q = 0; q < 8; ++q) s += v[q];
       s = row16_sum(s);
-      s += __shfl_xor(s, 16, 64);
+      s = xor16_sum(s);
       const float mean = s * (1.f / D);
       float qq = 0.f;
 #pragma unroll
       for (int q = 0; q < 8; ++q) { const float dd = v[q] - mean; qq += dd * dd; }
       qq = row16_sum(qq);
-      qq += __shfl_xor(qq, 16, 64);
+      qq = xor16_sum(qq);
       const float rstd = rsqrtf(qq * (1.f / D) + p.eps);
 #pragma unroll
       for (int q = 0; q < 8; ++q) v[q] = (v[q] - mean) * rstd * gm[q] + bt[q];

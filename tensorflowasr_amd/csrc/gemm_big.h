@@ -423,8 +423,8 @@ void gemm_big_kernel(const tfasr_gemm_args p, const int gx, const int gy, const 
             if (vec16_ok) {
               const uint2 send = odd ? a : b;
               uint2 recv;
-              recv.x = (uint32_t)__shfl_xor((int)send.x, 16, 64);
-              recv.y = (uint32_t)__shfl_xor((int)send.y, 16, 64);
+              recv.x = xor16_get(send.x, odd);
+              recv.y = xor16_get(send.y, odd);
               const uint4 out = odd ? make_uint4(recv.x, recv.y, b.x, b.y) : make_uint4(a.x, a.y, recv.x, recv.y);
               const int col = cb + (odd ? (jp + 1) * 16 + (g - 1) * 4 : jp * 16 + g * 4);
               if (rok && col >= n0 && col < p.N) *reinterpret_cast<uint4*>(drow + col) = out;
@@ -475,8 +475,7 @@ void gemm_big_kernel(const tfasr_gemm_args p, const int gx, const int gy, const 
           for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int e = 0; e < 4; ++e) m = fmaxf(m, x[j][e]);
-          m = fmaxf(m, __shfl_xor(m, 16, 64));
-          m = fmaxf(m, __shfl_xor(m, 32, 64));
+          m = xor32_max(xor16_max(m));
           const float mb = (m == -INFINITY) ? 0.f : m * L2E;
           float ssum[2] = {0.f, 0.f};
 #pragma unroll
@@ -485,8 +484,7 @@ void gemm_big_kernel(const tfasr_gemm_args p, const int gx, const int gy, const 
             for (int e = 0; e < 4; ++e) ssum[j >> 2] += __builtin_amdgcn_exp2f(x[j][e] * L2E - mb);
 #pragma unroll
           for (int sl = 0; sl < 2; ++sl) {
-            ssum[sl] += __shfl_xor(ssum[sl], 16, 64);
-            ssum[sl] += __shfl_xor(ssum[sl], 32, 64);
+            ssum[sl] = xor32_sum(xor16_sum(ssum[sl]));
           }
           if (rok) {
             // lane g = 0 / 1 stores the (max, sum) pair of slice 0 / 1 of its row
@@ -523,8 +521,8 @@ void gemm_big_kernel(const tfasr_gemm_args p, const int gx, const int gy, const 
             b.x = pack2_bf16(x[jp + 1][0], x[jp + 1][1]); b.y = pack2_bf16(x[jp + 1][2], x[jp + 1][3]);
             const uint2 send = odd ? a : b;
             uint2 recv;
-            recv.x = (uint32_t)__shfl_xor((int)send.x, 16, 64);
-            recv.y = (uint32_t)__shfl_xor((int)send.y, 16, 64);
+            recv.x = xor16_get(send.x, odd);
+            recv.y = xor16_get(send.y, odd);
             const uint4 out = odd ? make_uint4(recv.x, recv.y, b.x, b.y) : make_uint4(a.x, a.y, recv.x, recv.y);
             const int col = cb + (odd ? (jp + 1) * 16 + (g - 1) * 4 : jp * 16 + g * 4);
             if (rok && col >= n0 && col < p.N) *reinterpret_cast<uint4*>(drow + col) = out;
