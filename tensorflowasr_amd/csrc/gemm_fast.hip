@@ -412,6 +412,35 @@ __device__ __forceinline__ void gemm_fast_body(const tfasr_gemm_args& p, const i
     for (int j = 0; j < (C_CS ? NJ : 1); ++j) accb[j] = float4_t{0.f, 0.f, 0.f, 0.f};
     const bool do_cs = C_CS && p.colsum && cur.m0 == 0 && wm == 0;  // first row of tiles, the two waves that cover its columns
 
+    // ---- the swish' argument of the whole tile: inside each 16-row strip it cost one dependent global round trip per strip, 8 per tile (FFN
+    // data gradient 43.1 -> 37.8 us once it was loaded behind the slab loop, round 4).  ONE (a workgroup owns one tile): requested in FRONT of
+    // the slab loop, behind the tile's first two slabs - the compiler-visible vmcnt(0) below waits for all of them together, so the round
+    // trip lies under the first slabs' DMA instead of between the slab loop and the epilogue (16 registers held through the loop).
+    // Only the compiled swish' epilogues: the residual variants did not gain and the generic one started to spill.
+    constexpr int PF_LPRW = (BN_ / 2) / 8, PF_RPP = 64 / PF_LPRW, PF_NPASS = 16 / PF_RPP;
+    constexpr bool PF_Z = C_DACT && !GEN && !C_WS;
+    [[maybe_unused]] uint4 pf_z[PF_Z ? 4 : 1][PF_Z ? PF_NPASS : 1];
+    [[maybe_unused]] bool pf_ok = false;
+    auto prefetch_z = [&]() {
+      if constexpr (PF_Z) {
+        if (!p.accumulate) {
+          const int prow = lane / PF_LPRW, col0 = cur.n0 + wn * (BN_ / 2) + (lane % PF_LPRW) * 8;
+          pf_ok = ((p.ldd & 7) == 0) && ((cur.doff & 7) == 0) && (col0 + 8 <= p.N) &&
+                  p.dact_z && ((((uintptr_t)p.dact_z) & 15) == 0);
+          if (pf_ok) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+              for (int h = 0; h < PF_NPASS; ++h) {
+                const int row = min(cur.m0 + wm * 64 + i * 16 + h * PF_RPP + prow, p.M - 1);
+                const long idx0 = cur.doff + (long)row * p.ldd + col0;
+                pf_z[i][h] = *reinterpret_cast<const uint4*>((const bf16_t*)p.dact_z + idx0);
+              }
+          }
+        }
+      }
+    };
+    if constexpr (ONE) prefetch_z();
     const int n = cur.nfull;
     // compiler-visible vmcnt(0) in front of the slab loop (its bookkeeping otherwise carries a pending vector-memory event into the loop
     // and puts its own s_waitcnt vmcnt(0) behind the first fragment reads of EVERY slab, draining the prefetch); costs the first tile the
@@ -486,30 +515,7 @@ __device__ __forceinline__ void gemm_fast_body(const tfasr_gemm_args& p, const i
       mma_slab<TA, TB, BN_, C_CS>(sA, sB, wm, wn, lane, acc, accb, do_cs);
       __syncthreads();
     }
-    // ---- the swish' argument of the whole tile, loaded BEFORE anything else is queued: inside each 16-row strip it cost one dependent
-    // global round trip per strip, 8 per tile (FFN data gradient 43.1 -> 37.8 us).  Only the compiled swish' epilogues: the residual
-    // variants did not gain and the generic one started to spill.
-    constexpr int PF_LPRW = (BN_ / 2) / 8, PF_RPP = 64 / PF_LPRW, PF_NPASS = 16 / PF_RPP;
-    constexpr bool PF_Z = C_DACT && !GEN && !C_WS;
-    [[maybe_unused]] uint4 pf_z[PF_Z ? 4 : 1][PF_Z ? PF_NPASS : 1];
-    [[maybe_unused]] bool pf_ok = false;
-    if constexpr (PF_Z) {
-      if (!p.accumulate) {
-        const int prow = lane / PF_LPRW, col0 = cur.n0 + wn * (BN_ / 2) + (lane % PF_LPRW) * 8;
-        pf_ok = ((p.ldd & 7) == 0) && ((cur.doff & 7) == 0) && (col0 + 8 <= p.N) &&
-                p.dact_z && ((((uintptr_t)p.dact_z) & 15) == 0);
-        if (pf_ok) {
-#pragma unroll
-          for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int h = 0; h < PF_NPASS; ++h) {
-              const int row = min(cur.m0 + wm * 64 + i * 16 + h * PF_RPP + prow, p.M - 1);
-              const long idx0 = cur.doff + (long)row * p.ldd + col0;
-              pf_z[i][h] = *reinterpret_cast<const uint4*>((const bf16_t*)p.dact_z + idx0);
-            }
-        }
-      }
-    }
+    if constexpr (!ONE) prefetch_z();
     // ---- cross-tile prefetch: both stages are idle now ----
     Tile nxt;
     if constexpr (ONE) nxt.nfull = -1;
