@@ -51,7 +51,7 @@
 extern "C" {
 #endif
 
-#define TFASR_ABI_VERSION 36
+#define TFASR_ABI_VERSION 37
 
 typedef enum {
   TFASR_STATUS_SUCCESS = 0,
@@ -434,16 +434,7 @@ int tfasr_lstm_seq_bwd(const void* dy, const void* rk, const void* gates, const 
    buffers - including the carries - are those of the whole-sequence calls and live across the slices. */
 int tfasr_lstm_seq_fwd_range(const void* xg, const void* rk, const void* h0, long h0_stride_b, const float* c0, long c0_stride_b,
                              const int32_t* lengths, void* gates, float* cseq, void* hseq, void* yseq, float* hr, int B, int U1, int P,
-                             int dtype, int t0, int t1, const void* rk_t, void* stream);
-/* One launch per step: the recurrent product and the cell of a step in ONE kernel (the persistent kernels' step body over a one-step
-   range; bf16, B <= 64, P % 32 == 0, P <= 1024, else UNSUPPORTED).  The forward reads R transposed, rk_t [4P, P], written by
-   tfasr_lstm_transpose_rk once per sequence; the _range functions above take this path by themselves (forward: when rk_t != NULL). */
-int tfasr_lstm_transpose_rk(const void* rk, void* rk_t, int P, int dtype, void* stream);
-int tfasr_lstm_steps_fwd(const void* xg, const void* rk, const void* rk_t, const void* h0, long h0_stride_b, const float* c0, long c0_stride_b,
-                         const int32_t* lengths, void* gates, float* cseq, void* hseq, void* yseq, int B, int U1, int P, int dtype,
-                         int t0, int t1, void* stream);
-int tfasr_lstm_steps_bwd(const void* dy, const void* rk, const void* gates, const float* cseq, const int32_t* lengths, void* dz,
-                         float* dh_carry, float* dc_carry, int B, int U1, int P, int dtype, int t0, int t1, void* stream);
+                             int dtype, int t0, int t1, void* stream);
 int tfasr_lstm_seq_bwd_range(const void* dy, const void* rk, const void* gates, const float* cseq, const int32_t* lengths, void* dz,
                              float* dh_carry, float* dc_carry, float* dhr, int B, int U1, int P, int dtype, int t0, int t1, void* stream);
 /* The whole recurrence of one direction as ONE persistent launch (csrc/lstm_persist.hip): workgroup j keeps the recurrent

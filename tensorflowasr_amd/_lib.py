@@ -152,7 +152,7 @@ def load(build_if_missing=True):
     return lib
 
 
-ABI_VERSION = 36
+ABI_VERSION = 37
 
 
 STATUS_UNSUPPORTED = 3

@@ -1133,11 +1133,9 @@ class ConformerTransducer(BaseModel):
         yseq = torch.empty(B, U1, P, dtype=self.dtype, device=self.device)
         hr = torch.empty(B, 4 * P, dtype=torch.float32, device=self.device)
         Wrk = ps.w2d("pred/lstm/rk")
-        # one launch per step (recurrent product + cell in one kernel) reads R transposed: one small transpose per sequence
-        rk_t = K.lstm_transpose_rk(Wrk, torch.empty(4 * P, P, dtype=self.dtype, device=self.device)) if self.dtype == torch.bfloat16 else None
         step = -(-U1 // self._pred_nslices(U1))
         for t0 in range(0, U1, step):
-            K.lstm_seq_fwd_range(xg, Wrk, None, None, plen_dev, gates, cseq, hseq, yseq, hr, t0, min(U1, t0 + step), rk_t=rk_t)
+            K.lstm_seq_fwd_range(xg, Wrk, None, None, plen_dev, gates, cseq, hseq, yseq, hr, t0, min(U1, t0 + step))
             if t0 + step < U1:
                 yield
         y2 = yseq.view(B * U1, P)

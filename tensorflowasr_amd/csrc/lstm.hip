@@ -166,26 +166,10 @@ extern "C" int tfasr_lstm_set_persist(int mode) {
 // steps [t0, t1) of the forward recurrence with the per-step kernels (never the persistent launch): what a caller uses to queue the chain
 // in SLICES between other work - the host blocks in hipLaunchKernel once a stream's launch queue holds ~1 ms of work, and while it is
 // blocked on this chain's stream the other streams starve (conformer.py interleaves the slices with the encoder blocks)
-// One launch per step (recurrent product + cell in one kernel, lstm_persist.hip: tfasr_lstm_steps_*) instead of the GEMM + cell pair.
-// OPT-IN (TFASR_LSTM_FUSED_STEP=1), measured in round 5 on Conformer-M (same box, two interleaved pairs, profiles/r05_ab/lstm_fused_step.txt):
-// launches per train step 980 -> 802 (the prediction network's stream: 2 x U1 + 10 instead of 4 x U1 + 10), step time 21.65 / 21.69 ->
-// 21.71 / 21.79 ms, data-parallel route 21.82 -> 21.92 / 21.98.  The fused kernels are the persistent kernels' step body: 352 / 274 vector
-// registers and 50 KB of LDS per workgroup, so beside the encoder's kernels (two waves of ~220 registers per SIMD) a workgroup waits for a
-// whole SIMD to drain - 21 / 25 us per launch under the profiler for ~3 us of work - while the pair's small kernels slip into what the
-// encoder leaves free.  Worth it only with a step body of <= 64 registers and no LDS (gate exchange by DPP inside a quad): not built.
-static bool fused_step_enabled() {
-  static const bool v = false;
-  return v;
-}
-
 extern "C" int tfasr_lstm_seq_fwd_range(const void* xg, const void* rk, const void* h0, long h0_stride_b, const float* c0, long c0_stride_b,
                                         const int32_t* lengths, void* gates, float* cseq, void* hseq, void* yseq, float* hr, int B, int U1, int P,
-                                        int dtype, int t0, int t1, const void* rk_t, void* stream) {
+                                        int dtype, int t0, int t1, void* stream) {
   if (!xg || !rk || !gates || !cseq || !hseq || !hr || B <= 0 || U1 <= 0 || P <= 0 || t0 < 0 || t1 > U1 || t0 > t1) return TFASR_STATUS_INVALID_VALUE;
-  if (rk_t && fused_step_enabled()) {  // one launch per step (lstm_persist.hip) where the shape allows it
-    const int st = tfasr_lstm_steps_fwd(xg, rk, rk_t, h0, h0_stride_b, c0, c0_stride_b, lengths, gates, cseq, hseq, yseq, B, U1, P, dtype, t0, t1, stream);
-    if (st != TFASR_STATUS_UNSUPPORTED) return st;
-  }
   const long esz = dtype == TFASR_F32 ? 4 : 2;
   for (int t = t0; t < t1; ++t) {
     const char* hprev = t > 0 ? (const char*)hseq + (long)(t - 1) * P * esz : (const char*)h0;
@@ -219,7 +203,7 @@ extern "C" int tfasr_lstm_seq_fwd(const void* xg, const void* rk, const void* h0
     const int st = tfasr_lstm_persist_fwd(xg, rk, h0, h0_stride_b, c0, c0_stride_b, lengths, gates, cseq, hseq, yseq, B, U1, P, dtype, hr, stream);
     if (st != TFASR_STATUS_UNSUPPORTED) return st;
   }
-  return tfasr_lstm_seq_fwd_range(xg, rk, h0, h0_stride_b, c0, c0_stride_b, lengths, gates, cseq, hseq, yseq, hr, B, U1, P, dtype, 0, U1, nullptr, stream);
+  return tfasr_lstm_seq_fwd_range(xg, rk, h0, h0_stride_b, c0, c0_stride_b, lengths, gates, cseq, hseq, yseq, hr, B, U1, P, dtype, 0, U1, stream);
 }
 
 // steps t1-1 down to t0 of the backward recurrence with the per-step kernels (see tfasr_lstm_seq_fwd_range); slices must be queued in
@@ -228,10 +212,6 @@ extern "C" int tfasr_lstm_seq_bwd_range(const void* dy, const void* rk, const vo
                                         float* dh_carry, float* dc_carry, float* dhr, int B, int U1, int P, int dtype, int t0, int t1, void* stream) {
   if (!dy || !rk || !gates || !cseq || !dz || !dh_carry || !dc_carry || !dhr || B <= 0 || U1 <= 0 || P <= 0 || t0 < 0 || t1 > U1 || t0 > t1)
     return TFASR_STATUS_INVALID_VALUE;
-  if (fused_step_enabled()) {  // one launch per step (lstm_persist.hip) where the shape allows it
-    const int st = tfasr_lstm_steps_bwd(dy, rk, gates, cseq, lengths, dz, dh_carry, dc_carry, B, U1, P, dtype, t0, t1, stream);
-    if (st != TFASR_STATUS_UNSUPPORTED) return st;
-  }
   const long esz = dtype == TFASR_F32 ? 4 : 2;
   for (int t = t1 - 1; t >= t0; --t) {
     int st = tfasr_lstm_step_bwd((const char*)dy + (long)t * P * esz, (long)U1 * P, t < U1 - 1 ? dhr : nullptr, dh_carry, dc_carry,

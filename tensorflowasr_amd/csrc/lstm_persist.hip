@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void lstm_persist_fwd_kernel(
     const float* __restrict__ c0, long c0_stride_b, const int32_t* __restrict__ lengths, bf16_t* __restrict__ gates,
     float* __restrict__ cseq, bf16_t* hseq, bf16_t* __restrict__ yseq, int B, int U1, int P, Sync* sync,
     const bf16_t* __restrict__ rk_t = nullptr, int t_begin = 0, int t_end = -1) {
-  // rk_t / [t_begin, t_end): the SAME step body as ONE LAUNCH PER STEP (tfasr_lstm_steps_fwd, round 5): a range of one step never waits and
+  // rk_t / [t_begin, t_end): the SAME step body as ONE LAUNCH PER STEP (round 5; measured slower beside the encoder, its entry points removed in round 6: profiles/r05_ab/lstm_fused_step.txt): a range of one step never waits and
   // never arrives; the carried state comes from the sequence buffers (cseq / hseq hold the CARRIED state at every step, masked ones
   // included); rk_t = R transposed [4P, P] so that the wave's B fragments are twenty 16-byte loads instead of 160 strided 2-byte ones.
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256) void lstm_persist_bwd_kernel(
     const bf16_t* __restrict__ dy, const bf16_t* __restrict__ rk, const bf16_t* __restrict__ gates, const float* __restrict__ cseq,
     const int32_t* __restrict__ lengths, bf16_t* dz, float* __restrict__ dh_carry, float* __restrict__ dc_carry, int B, int U1, int P,
     Sync* sync, int t_begin = 0, int t_end = -1) {
-  // [t_begin, t_end): steps t_end - 1 down to t_begin (one launch per step: tfasr_lstm_steps_bwd); the carries live in dh_carry / dc_carry
+  // [t_begin, t_end): steps t_end - 1 down to t_begin (one launch per step: round 5, entry points removed in round 6); the carries live in dh_carry / dc_carry
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int r = lane & 15, g = lane >> 4;
@@ -409,68 +409,8 @@ bool grid_fits(KERNEL kernel, int grid, size_t smem) {
 }
 
 // R [P, 4P] -> R^T [4P, P] (bf16), 32 x 32 tiles through LDS: once per sequence, for the per-step forward launches
-__global__ __launch_bounds__(256) void lstm_transpose_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int rows, int cols) {
-  __shared__ bf16_t tile[32][33];
-  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  for (int i = ty; i < 32; i += 8)
-    if (r0 + i < rows && c0 + tx < cols) tile[i][tx] = x[(long)(r0 + i) * cols + c0 + tx];
-  __syncthreads();
-  for (int i = ty; i < 32; i += 8)
-    if (c0 + i < cols && r0 + tx < rows) y[(long)(c0 + i) * rows + r0 + tx] = tile[tx][i];
-}
 
 }  // namespace
-
-// ---------------------------------------------------------------------------------------------------------------------------------
-// ONE LAUNCH PER STEP (round 5): the recurrent product and the cell of a step in one kernel - the persistent kernels'
-// step body over a one-step range, so nothing waits on another workgroup - instead of a skinny GEMM launch + a cell launch: the
-// prediction network's stream carries U1 launches per direction, not 2 x U1, each ~3 us of work on P/16 CUs (the GEMM pair was ~20 us).
-// Forward needs R^T [4P, P] (tfasr_lstm_transpose_rk, once per sequence) so that a wave's B fragments are 16-byte loads.
-// UNSUPPORTED outside the persistent kernels' shape range (bf16, B <= 64, P % 32 == 0, P <= 1024).
-// ---------------------------------------------------------------------------------------------------------------------------------
-extern "C" int tfasr_lstm_transpose_rk(const void* rk, void* rk_t, int P, int dtype, void* stream_) {
-  if (!rk || !rk_t || P <= 0) return TFASR_STATUS_INVALID_VALUE;
-  if (dtype != TFASR_BF16) return TFASR_STATUS_UNSUPPORTED;
-  TFASR_KLAUNCH(lstm_transpose_kernel, dim3((4 * P + 31) / 32, (P + 31) / 32), dim3(256), 0, (hipStream_t)stream_, (const bf16_t*)rk, (bf16_t*)rk_t, P, 4 * P);
-  TFASR_CHECK_LAUNCH();
-  return TFASR_STATUS_SUCCESS;
-}
-
-extern "C" int tfasr_lstm_steps_fwd(const void* xg, const void* rk, const void* rk_t, const void* h0, long h0_stride_b, const float* c0, long c0_stride_b,
-                                    const int32_t* lengths, void* gates, float* cseq, void* hseq, void* yseq, int B, int U1, int P, int dtype,
-                                    int t0, int t1, void* stream_) {
-  if (!xg || !rk || !rk_t || !gates || !cseq || !hseq || B <= 0 || U1 <= 0 || P <= 0 || t0 < 0 || t1 > U1 || t0 > t1) return TFASR_STATUS_INVALID_VALUE;
-  if (!persist_ok(B, P, dtype)) return TFASR_STATUS_UNSUPPORTED;
-  hipStream_t s = (hipStream_t)stream_;
-  const int MT = (B + 15) / 16, Bp = MT * 16;
-  const size_t smem = (size_t)Bp * (P * 2 + 16) + (size_t)4 * Bp * PW * 4;
-  const dim3 grid(P / PW);
-#define TFASR_LAUNCH(M) TFASR_KLAUNCH(lstm_persist_fwd_kernel<M>, grid, dim3(256), smem, s, (const bf16_t*)xg, (const bf16_t*)rk, (const bf16_t*)h0, \
-                                           h0_stride_b, c0, c0_stride_b, lengths, (bf16_t*)gates, cseq, (bf16_t*)hseq, (bf16_t*)yseq, B, U1, P, (Sync*)nullptr, \
-                                           (const bf16_t*)rk_t, t, t + 1)
-  for (int t = t0; t < t1; ++t)
-    switch (MT) { case 1: TFASR_LAUNCH(1); break; case 2: TFASR_LAUNCH(2); break; case 3: TFASR_LAUNCH(3); break; default: TFASR_LAUNCH(4); }
-#undef TFASR_LAUNCH
-  TFASR_CHECK_LAUNCH();
-  return TFASR_STATUS_SUCCESS;
-}
-
-extern "C" int tfasr_lstm_steps_bwd(const void* dy, const void* rk, const void* gates, const float* cseq, const int32_t* lengths, void* dz,
-                                    float* dh_carry, float* dc_carry, int B, int U1, int P, int dtype, int t0, int t1, void* stream_) {
-  if (!dy || !rk || !gates || !cseq || !dz || !dh_carry || !dc_carry || B <= 0 || U1 <= 0 || P <= 0 || t0 < 0 || t1 > U1 || t0 > t1) return TFASR_STATUS_INVALID_VALUE;
-  if (!persist_ok(B, P, dtype)) return TFASR_STATUS_UNSUPPORTED;
-  hipStream_t s = (hipStream_t)stream_;
-  const int MT = (B + 15) / 16, Bp = MT * 16;
-  const size_t smem = (size_t)4 * Bp * PW * 4;
-  const dim3 grid(P / PW);
-#define TFASR_LAUNCH(M) TFASR_KLAUNCH(lstm_persist_bwd_kernel<M>, grid, dim3(256), smem, s, (const bf16_t*)dy, (const bf16_t*)rk, (const bf16_t*)gates, cseq, \
-                                           lengths, (bf16_t*)dz, dh_carry, dc_carry, B, U1, P, (Sync*)nullptr, t, t + 1)
-  for (int t = t1 - 1; t >= t0; --t)
-    switch (MT) { case 1: TFASR_LAUNCH(1); break; case 2: TFASR_LAUNCH(2); break; case 3: TFASR_LAUNCH(3); break; default: TFASR_LAUNCH(4); }
-#undef TFASR_LAUNCH
-  TFASR_CHECK_LAUNCH();
-  return TFASR_STATUS_SUCCESS;
-}
 
 // ---------------------------------------------------------------------------------------------------------------------------------
 // C ABI.  `sync`: 64 bytes of device memory owned by the caller (tfasr_lstm_persist_sync_bytes), zeroed here (memset node in front of

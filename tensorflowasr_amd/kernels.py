@@ -626,33 +626,12 @@ def lstm_seq_fwd(xg, rk, h0, c0, lengths, gates, cseq, hseq, yseq, hr):
                                   _p(gates), _p(cseq), _p(hseq), _pv(yseq), _p(hr), B, U1, P, _dt(xg), _stream()), "lstm_seq_fwd")
 
 
-def lstm_transpose_rk(rk, rk_t):
-    """R [P, 4P] -> R^T [4P, P]: what the one-launch-per-step forward reads (tfasr_lstm_transpose_rk)"""
-    check(_L().tfasr_lstm_transpose_rk(_p(rk), _p(rk_t), rk.shape[0], _dt(rk), _stream()), "lstm_transpose_rk")
-    return rk_t
-
-
-def lstm_steps_fwd(xg, rk, rk_t, h0, c0, lengths, gates, cseq, hseq, yseq, t0, t1):
-    """steps [t0, t1), ONE launch each (recurrent product + cell fused: tfasr_lstm_steps_fwd); raises TfasrUnsupported outside its shapes"""
-    B, U1, P4 = xg.shape
-    P = P4 // 4
-    check(_L().tfasr_lstm_steps_fwd(_p(xg), _p(rk), _p(rk_t), _pv(h0), 0 if h0 is None else h0.stride(0), _pv(c0), 0 if c0 is None else c0.stride(0),
-                                    _pv(lengths), _p(gates), _p(cseq), _p(hseq), _pv(yseq), B, U1, P, _dt(xg), int(t0), int(t1), _stream()), "lstm_steps_fwd")
-
-
-def lstm_steps_bwd(dy, rk, gates, cseq, lengths, dz, dh_carry, dc_carry, t0, t1):
-    """steps t1-1 .. t0, ONE launch each (tfasr_lstm_steps_bwd)"""
-    B, U1, P = dy.shape
-    check(_L().tfasr_lstm_steps_bwd(_p(dy), _p(rk), _p(gates), _p(cseq), _pv(lengths), _p(dz), _p(dh_carry), _p(dc_carry), B, U1, P, _dt(dy),
-                                    int(t0), int(t1), _stream()), "lstm_steps_bwd")
-
-
-def lstm_seq_fwd_range(xg, rk, h0, c0, lengths, gates, cseq, hseq, yseq, hr, t0, t1, rk_t=None):
-    """steps [t0, t1) of lstm_seq_fwd with the per-step kernels (tfasr_lstm_seq_fwd_range); rk_t = lstm_transpose_rk(rk): one launch per step"""
+def lstm_seq_fwd_range(xg, rk, h0, c0, lengths, gates, cseq, hseq, yseq, hr, t0, t1):
+    """steps [t0, t1) of lstm_seq_fwd with the per-step kernels (tfasr_lstm_seq_fwd_range)"""
     B, U1, P4 = xg.shape
     P = P4 // 4
     check(_L().tfasr_lstm_seq_fwd_range(_p(xg), _p(rk), _pv(h0), 0 if h0 is None else h0.stride(0), _pv(c0), 0 if c0 is None else c0.stride(0), _pv(lengths),
-                                        _p(gates), _p(cseq), _p(hseq), _pv(yseq), _p(hr), B, U1, P, _dt(xg), int(t0), int(t1), _pv(rk_t), _stream()),
+                                        _p(gates), _p(cseq), _p(hseq), _pv(yseq), _p(hr), B, U1, P, _dt(xg), int(t0), int(t1), _stream()),
           "lstm_seq_fwd_range")
 
 

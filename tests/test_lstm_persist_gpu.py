@@ -97,18 +97,14 @@ def test_persistent_lstm_matches_oracle(dev, B, U1, P, state):
 
 
 @pytest.mark.parametrize("B,U1,P,slices", [(32, 23, 640, 4), (32, 40, 320, 8), (5, 9, 64, 3), (33, 7, 96, 7)])
-def test_one_launch_per_step_ranges_match_oracle(dev, B, U1, P, slices):
-    """Round 5: the prediction network's recurrence is queued in slices between the encoder blocks (tfasr_lstm_seq_fwd_range / _bwd_range),
-    and a step can be ONE launch (recurrent product + cell in one kernel: the persistent kernels' step body over one-step ranges, forward
-    on R transposed - tfasr_lstm_steps_fwd / _bwd; opt-in inside the range functions, called directly here).  Any slicing gives the whole
-    sequence: outputs, carried state and masked steps against the oracle, and BITWISE equal to the same launches queued as one range (a
-    step only reads what earlier launches wrote); the range functions' default path (GEMM + cell pair) agrees within bf16 noise."""
+def test_sliced_ranges_match_oracle(dev, B, U1, P, slices):
+    """The prediction network's recurrence is queued in slices between the encoder blocks (tfasr_lstm_seq_fwd_range / _bwd_range: the
+    recurrent GEMM + cell launch pair per step).  Any slicing gives the whole sequence: outputs, carried state and masked steps against the
+    oracle, and BITWISE equal to the same launches queued as one range (a step only reads what earlier launches wrote)."""
     xg, rk, lens, h0, c0, dy = _case(B, U1, P, seed=B * 77 + P)
     y_ref, h_ref, c_ref, dx_ref = _oracle(xg, rk, lens, None, None, dy)
     d = lambda t: None if t is None else t.to(dev).contiguous()
     xd, rd, ld_, dyd = d(xg), d(rk), d(lens), d(dy)
-    rk_t = K.lstm_transpose_rk(rd, torch.empty(4 * P, P, dtype=torch.bfloat16, device=dev))
-    assert torch.equal(rk_t, rd.t().contiguous())
     out = {}
     for ns in (1, slices):
         gates = torch.empty(B, U1, 4 * P, dtype=torch.bfloat16, device=dev)
@@ -118,7 +114,7 @@ def test_one_launch_per_step_ranges_match_oracle(dev, B, U1, P, slices):
         hr = torch.empty(B, 4 * P, dtype=torch.float32, device=dev)
         step = -(-U1 // ns)
         for t0 in range(0, U1, step):
-            K.lstm_steps_fwd(xd, rd, rk_t, None, None, ld_, gates, cseq, hseq, yseq, t0, min(U1, t0 + step))
+            K.lstm_seq_fwd_range(xd, rd, None, None, ld_, gates, cseq, hseq, yseq, hr, t0, min(U1, t0 + step))
         dz = torch.empty(B, U1, 4 * P, dtype=torch.bfloat16, device=dev)
         dhc = torch.zeros(B, P, dtype=torch.float32, device=dev)
         dcc = torch.zeros(B, P, dtype=torch.float32, device=dev)
@@ -126,7 +122,7 @@ def test_one_launch_per_step_ranges_match_oracle(dev, B, U1, P, slices):
         t1 = U1
         while t1 > 0:
             t0 = max(0, t1 - step)
-            K.lstm_steps_bwd(dyd, rd, gates, cseq, ld_, dz, dhc, dcc, t0, t1)
+            K.lstm_seq_bwd_range(dyd, rd, gates, cseq, ld_, dz, dhc, dcc, dhr, t0, t1)
             t1 = t0
         torch.cuda.synchronize()
         out[ns] = (yseq, hseq, cseq, gates, dz)
@@ -143,24 +139,6 @@ def test_one_launch_per_step_ranges_match_oracle(dev, B, U1, P, slices):
             assert torch.equal(hseq[b, n:], hseq[b, n - 1:n].expand(U1 - n, P))
     err = float((dz.float().cpu() - dx_ref).norm() / dx_ref.norm())
     assert err < 3e-2, err
-    # the sliced range functions (what the train step calls; default = the recurrent GEMM + cell launch pair)
-    g2, c2, h2, y2 = torch.empty_like(gates), torch.empty_like(cseq), torch.empty_like(hseq), torch.empty_like(yseq)
-    hr = torch.empty(B, 4 * P, dtype=torch.float32, device=dev)
-    step = -(-U1 // slices)
-    for t0 in range(0, U1, step):
-        K.lstm_seq_fwd_range(xd, rd, None, None, ld_, g2, c2, h2, y2, hr, t0, min(U1, t0 + step), rk_t=rk_t)
-    dz2 = torch.empty_like(dz)
-    dhc = torch.zeros(B, P, dtype=torch.float32, device=dev)
-    dcc = torch.zeros(B, P, dtype=torch.float32, device=dev)
-    dhr = torch.empty(B, P, dtype=torch.float32, device=dev)
-    t1 = U1
-    while t1 > 0:
-        t0 = max(0, t1 - step)
-        K.lstm_seq_bwd_range(dyd, rd, g2, c2, ld_, dz2, dhc, dcc, dhr, t0, t1)
-        t1 = t0
-    torch.cuda.synchronize()
-    assert float((y2.float() - yseq.float()).abs().max()) < 3e-2
-    assert float((dz2.float().cpu() - dx_ref).norm() / dx_ref.norm()) < 3e-2
 
 
 def test_persistent_lstm_is_what_the_prediction_network_runs(dev):
