@@ -160,6 +160,12 @@ __device__ __forceinline__ void stream_window(int i, int T, int chunk, int hist,
 // each.  Strip = [16 il][80 window columns] f32 + the 16 bias-row scores behind it = 5 184 bytes per wave, 53 504 per workgroup (with a
 // row stride of 84 floats it was 54 272 -> 43 granules -> two workgroups per CU: 90 instead of 62 us at T' = 743).
 constexpr int GLDT = 80, SGTT_BYTES = 16 * GLDT * 4 + 64;
+// Strip column swizzle: the 16-byte chunk (4 window columns) of row il is stored at chunk ^ ((il >> 1) & 3).  With a row stride of 80 floats
+// (what three workgroups per CU leave room for) the rows il and il + 2 start 160 dwords = 0 banks (mod 32) apart, so the eight lanes of a
+// ds_write_b128 service group - eight rows, the same chunk - hit four banks-of-four twice over: 4-way conflicts on the five G^T writes of
+// every key block, 0.41 of the forward's LDS cycles (profiles/r06_lds_conflicts.txt).  The key keeps a chunk inside its aligned group of
+// four (20 chunks per row) and spreads the eight rows over all 32 banks (bank model of the guide, tools/hwprobe/lds_sim.py).
+__device__ __forceinline__ int strip_col(int il, int x) { return (((x >> 2) ^ ((il >> 1) & 3)) << 2) | (x & 3); }
 constexpr int SMEM_FWDT = SK_BYTES + SV_BYTES + SP_BYTES + 4 * SGTT_BYTES;
 static_assert((SMEM_FWDT + 1279) / 1280 * 3 <= 128, "three workgroups per CU");
 
@@ -209,13 +215,17 @@ __global__ __launch_bounds__(256, 3) void relattn_fused_fwdT_kernel(
   int klo = 0, khi = T;  // visible keys of this query row
   if constexpr (STREAM) { if (!qm) stream_window(min(i, T - 1), T, chunk, hist, klo, khi); }
   const float scale2q = qm ? 0.f : scale2;
-  const int gbase = r * GLDT + 15 - r;  // + jl = this lane's skewed strip column of key jl
   int jl0[4], krow[4];
 #pragma unroll
   for (int jt = 0; jt < 4; ++jt) {
     jl0[jt] = 32 * (jt >> 1) + g * 8 + (jt & 1) * 4;                      // first of this lane's four keys of tile jt (C rows g*4 + e)
     krow[jt] = 32 * (jt >> 1) + (r >> 2) * 8 + (jt & 1) * 4 + (r & 3);  // key row that is MFMA row r of tile jt (A operand)
   }
+  int goff[4][4];  // strip offset of this lane's skewed score of key jl0[jt] + e: row il = r, window column 15 - r + jl (swizzled)
+#pragma unroll
+  for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) goff[jt][e] = r * GLDT + strip_col(r, 15 - r + jl0[jt] + e);
 #ifdef TFASR_ATTN_TIMING
   long long ph[5] = {0, 0, 0, 0, 0};
 #endif
@@ -307,7 +317,7 @@ __global__ __launch_bounds__(256, 3) void relattn_fused_fwdT_kernel(
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
           a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(sP, grow + t * 16, kk * 4 + g), bqv[kk], a, 0, 0, 0);
-        *reinterpret_cast<float4_t*>(sG + r * GLDT + t * 16 + g * 4) = a;
+        *reinterpret_cast<float4_t*>(sG + r * GLDT + strip_col(r, t * 16 + g * 4)) = a;
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -324,7 +334,7 @@ __global__ __launch_bounds__(256, 3) void relattn_fused_fwdT_kernel(
 #pragma unroll
     for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) gv[jt][e] = sG[gbase + jl0[jt] + e];
+      for (int e = 0; e < 4; ++e) gv[jt][e] = sG[goff[jt][e]];
     // t = content + position score, UNSCALED (the softmax scale is positive: the maximum commutes with it, and the exponent below is one
     // fused multiply-add per element).  The common key block - every key inside the sample's relative positions for every query of the
     // wave - needs no select against the bias score (wave-uniform ballot, as in the query-side backward)
@@ -530,13 +540,17 @@ __global__ __launch_bounds__(256, MODE == 2 ? 3 : 2) void relattn_fused_bwd_qT_k
   int klo = 0, khi = T;
   if constexpr (STREAM) { if (live) stream_window(i, T, chunk, hist, klo, khi); }
   if (!live) khi = 0;  // (no visible key: dS = 0 everywhere in this row)
-  const int gbase = r * GLDT + 15 - r;  // + jl = this lane's skewed strip column of key jl
   int jl0[4], krow[4];
 #pragma unroll
   for (int jt = 0; jt < 4; ++jt) {
     jl0[jt] = 32 * (jt >> 1) + g * 8 + (jt & 1) * 4;
     krow[jt] = 32 * (jt >> 1) + (r >> 2) * 8 + (jt & 1) * 4 + (r & 3);
   }
+  int goff[4][4];  // strip offset of this lane's skewed score of key jl0[jt] + e (swizzled column, see strip_col)
+#pragma unroll
+  for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) goff[jt][e] = r * GLDT + strip_col(r, 15 - r + jl0[jt] + e);
   // image cell of this lane's key 8g of the block: window column 63-16w-r+8g; the keys of tile jt, element e are 32(jt>>1)+4(jt&1)+e further
   char* const img = sAg + r * QT_IMG_LD + (63 - w * 16 - r + g * 8) * 2;
   float4_t acc_q[4], acc_v[4];  // dq_u^T / dq_v^T: rows = head dims n*16 + g*4 + e, column = this lane's query
@@ -665,7 +679,7 @@ __global__ __launch_bounds__(256, MODE == 2 ? 3 : 2) void relattn_fused_bwd_qT_k
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
           a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(sP, grow + t * 16, kk * 4 + g), bqv[kk], a, 0, 0, 0);
-        *reinterpret_cast<float4_t*>(sG + r * GLDT + t * 16 + g * 4) = a;
+        *reinterpret_cast<float4_t*>(sG + r * GLDT + strip_col(r, t * 16 + g * 4)) = a;
       }
     }
     if constexpr (QT_PIPE) {
@@ -681,7 +695,7 @@ __global__ __launch_bounds__(256, MODE == 2 ? 3 : 2) void relattn_fused_bwd_qT_k
 #pragma unroll
     for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) gv[jt][e] = sG[gbase + jl0[jt] + e];
+      for (int e = 0; e < 4; ++e) gv[jt][e] = sG[goff[jt][e]];
     if constexpr (QT_ALIAS) {  // every score of the strip is in registers: clear the image that lies over it (4352 B = 4.25 x 64 lanes x 16 B)
       const uint4 z4 = make_uint4(0, 0, 0, 0);
 #pragma unroll
