@@ -995,8 +995,11 @@ __global__ __launch_bounds__(256, 2) void relattn_dpext_kernel(
 //   dv_j += sum_i pT[j,i] dO_i ;   dk_j += sum_i dsT[j,i] qu_i
 // The window scores are produced block-wide as Gt[c, i] = window_c . qv_i (each wave 2 of the 8 c-tiles) in LDS.
 // ======================================================================================================================
-constexpr int GTLD = 68;
-constexpr int SGT_BYTES = WIN * GTLD * 4;
+// window scores of a query block, stored [64 il][GTLD c] (c fastest: a lane's four consecutive window rows of one query are ONE 16-byte
+// store per tile - as [c][il] they were four scalar stores, 32 per lane and query block; 132 = 4 mod 32 banks: the eight rows of a
+// ds_write_b128 service group cover all 32 banks)
+constexpr int GTLD = WIN + 4;
+constexpr int SGT_BYTES = BI * GTLD * 4;
 constexpr int SMEM_BWD_K = 3 * SK_BYTES + SP_BYTES + SGT_BYTES;  // qu, qv, dO blocks + window + Gt
 
 template <bool STREAM>
@@ -1056,7 +1059,7 @@ __global__ __launch_bounds__(256, 2) void relattn_fused_bwd_k_kernel(
   for (int e = 0; e < 4; ++e) {
     const int jl = w * 16 + g * 4 + e, row = g * 4 + e;
     rrk[e] = T - 1 + j0 + jl;                          // - i = relative-position row
-    gtoff[e] = (63 + jl) * GTLD + r * (1 - GTLD);      // + it*16*(1-GTLD): Gt[(63 - il) + jl][il]
+    gtoff[e] = r * (GTLD - 1) + 63 + jl;              // + it*16*(GTLD-1): Gt[il][(63 - il) + jl], il = it*16 + r
     jin[e] = j0 + jl < T;
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
@@ -1130,8 +1133,7 @@ __global__ __launch_bounds__(256, 2) void relattn_fused_bwd_k_kernel(
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
           a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(sP, ct * 16 + r, kk * 4 + g), frag_rows(sQv, it * 16 + r, kk * 4 + g), a, 0, 0, 0);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) sGt[(ct * 16 + g * 4 + e) * GTLD + it * 16 + r] = a[e];
+        *reinterpret_cast<float4_t*>(sGt + (it * 16 + r) * GTLD + ct * 16 + g * 4) = a;
       }
     }
     __syncthreads();  // Gt complete; the window and the qv block are dead from here on
@@ -1146,12 +1148,12 @@ __global__ __launch_bounds__(256, 2) void relattn_fused_bwd_k_kernel(
       const float D_i = Di_it[it];
       const bool qmask = use_mask && (i >= len);
       const bool iin = i < T;
-      const float gbias = sGt[127 * GTLD + il];
+      const float gbias = sGt[il * GTLD + 127];
       int wlo = 0, whi = T;
       if constexpr (STREAM) { if (!qmask) stream_window(ic, T, chunk, hist, wlo, whi); }
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float pos = (rrk[e] - i < lim) ? sGt[gtoff[e] + it * 16 * (1 - GTLD)] : gbias;
+        const float pos = (rrk[e] - i < lim) ? sGt[gtoff[e] + it * 16 * (GTLD - 1)] : gbias;
         float p = 0.f, d = 0.f;
         bool vis = iin && jin[e];
         if constexpr (STREAM) { const int j = j0 + w * 16 + g * 4 + e; vis = vis && j >= wlo && j < whi; }
