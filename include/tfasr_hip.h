@@ -385,7 +385,7 @@ int tfasr_relattn_fused_fwd(const void* qkv, const float* ubias, const float* vb
  * from lse; o / dout [B*T, H*dh].  The query gradient leaves the kernel complete: dq (row stride lddq, a multiple of 4, e.g. the q
  * columns of the fused [B*T, 3*H*dh] gradient) = dqu + dqv with dqu = d/d(q+u), dqv = d/d(q+v) (formed against the window rows);
  * du [H*dh] += column sums of dqu, dv += column sums of dqv.  The UNSKEWED score gradient ds [B,H,T,lds] (lds >= T, multiple of 8) is
- * stored for tfasr_relattn_dpext, dvec [B,H,T] = rowsum(dout * o) for the key side, and the bias row's share is added into
+ * stored for tfasr_relattn_dpext, dvec [2,B,H,T] = rowsum(dout * o) and the bias-row score (q_i + v) . pext[2T-1] of every query for the key side, and the bias row's share is added into
  * dpext [2T, H*dh] f32 (zeroed by the caller).  With use_mask, the ds rows (and dvec) of a 64-row query block that lies entirely in the
  * padding (i0 >= lengths[b]) are NOT written: their gradient is zero and tfasr_relattn_dpext skips those tiles.
  * qu / qv (both or neither, [B*T, H*dh], 16-byte aligned): also written = q + u / q + v for tfasr_relattn_fused_bwd_k and
@@ -397,7 +397,7 @@ int tfasr_relattn_fused_bwd_q3(const void* qkv, const float* ubias, const float*
                                int chunk, int hist, int dtype, void* stream);
 int tfasr_relattn_dpext(const void* ds, const void* qv, const int32_t* lengths, float* dpext, int B, int H, int T, int dh, int lds,
                         int use_mask, int dtype, void* stream);
-/* Fused backward, key side (run after _bwd_q3, which also emits dvec [B,H,T] = rowsum(dout*o)): writes the k and v column
+/* Fused backward, key side (run after _bwd_q3, which also emits dvec [2,B,H,T] = rowsum(dout*o) | bias-row scores): writes the k and v column
  * blocks of dqkv [B*T, 3*H*dh]; qu/qv [B*T, H*dh] = q+u / q+v (tfasr_bias2_fwd). */
 int tfasr_relattn_fused_bwd_k(const void* qkv, const void* qu, const void* qv, const void* pext, const int32_t* lengths,
                               const void* dout, const float* lse, const float* dvec, void* dqkv, int B, int H, int T, int dh,

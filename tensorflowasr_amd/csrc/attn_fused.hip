@@ -17,6 +17,7 @@ __device__ long long g_attn_timing[8 * 8192];
 #define ATT_TICK(k)
 #endif
 #include <algorithm>
+#include <stdlib.h>
 
 typedef __attribute__((ext_vector_type(4))) short short4_t;
 
@@ -595,6 +596,7 @@ __global__ __launch_bounds__(256, MODE == 2 ? 3 : 2) void relattn_fused_bwd_qT_k
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     gbias = sGb[r];
   }
+  if (g == 0 && i < T) dvec[(long)B * H * T + ((long)b * H + h) * T + i] = gbias;  // second plane of dvec: for the key-side kernel
   const float Dis = Di * scale;
   // the bias row of the table (this lane's 16 head dims n*16 + g*4 + e) for the epilogue: requested here, so that the epilogue has no
   // global load of its own to wait for (every workgroup pays its prologue and epilogue latencies once, and a launch is two rounds of them)
@@ -989,18 +991,52 @@ __global__ __launch_bounds__(256, 2) void relattn_dpext_kernel(
 
 
 // ======================================================================================================================
-// Backward, part 2 (key side): block = (b, h, 64 key rows), wave = 16 key rows, loop over 64-query blocks.  Everything is
-// computed transposed (rows = keys) so dK / dV accumulate in registers:
+// Backward, part 2 (key side): block = (b, h, 64 key rows), wave = 16 key rows, loop over 64-query blocks.  Everything is computed
+// transposed (rows = keys) so dK / dV accumulate in registers:
 //   sT[j,i] = k_j.qu_i + G[i, c(i,j)],  pT = exp(sT - lse_i),  dpT[j,i] = v_j.dO_i,  dsT = pT (dpT - D_i) scale
 //   dv_j += sum_i pT[j,i] dO_i ;   dk_j += sum_i dsT[j,i] qu_i
-// The window scores are produced block-wide as Gt[c, i] = window_c . qv_i (each wave 2 of the 8 c-tiles) in LDS.
+// PIPELINED (round 6).  Against the kernel of rounds 2-5 (block-wide window scores through a 34 KB strip, single-buffered tiles, row-major
+// images written with 2-byte stores: 88 us per layer, removed) four changes:
+//  * the window scores are PRIVATE to a wave: for its 16 keys and the 16 queries of tile `it` the relative positions span 31 window rows =
+//    two 16-row tiles (3 - it + w, 4 - it + w) of the block's window - 16 MFMAs per wave and query block, exactly what its share of the
+//    block-wide 128 x 64 product was, but into a 2.3 KB strip of its own (two slots) instead of a 34 KB strip every wave waits for: one
+//    workgroup barrier and 26 KB of LDS less;
+//  * the freed LDS double-buffers the qu / dO blocks (live for the whole iteration: the next block's are requested at the top of the
+//    current one) and lets the qv / window blocks (dead behind the score products) be refetched behind the barrier that ends those products,
+//    under the exponentials and the dK / dV products (inline-asm DMA, one hand-placed vmcnt(0) per iteration) - 74 KB, two workgroups per CU;
+//  * the P^T / dS^T operand images are stored TRANSPOSED with one 8-byte store per (query, image) and read back through the transposing
+//    LDS read (img_store / img_frag): 8 instead of 32 LDS stores per lane and query block, no two lanes sharing a dword;
+//  * the bias-row score (q_i + v) . pext[R] of a query comes from the query-side kernel (second plane of `dvec`) instead of from window
+//    tile 7, which most waves do not compute any more.
+// Two workgroup barriers per query block instead of three, no exposed DMA wait at the top of an iteration (104 clocks: tools/attn_timing.py);
+// per live query block 8 400 -> 7 300 clocks of wave 0, 88 -> 80 us per layer, step -0.09 ms same box.
 // ======================================================================================================================
-// window scores of a query block, stored [64 il][GTLD c] (c fastest: a lane's four consecutive window rows of one query are ONE 16-byte
-// store per tile - as [c][il] they were four scalar stores, 32 per lane and query block; 132 = 4 mod 32 banks: the eight rows of a
-// ds_write_b128 service group cover all 32 banks)
-constexpr int GTLD = WIN + 4;
-constexpr int SGT_BYTES = BI * GTLD * 4;
-constexpr int SMEM_BWD_K = 3 * SK_BYTES + SP_BYTES + SGT_BYTES;  // qu, qv, dO blocks + window + Gt
+constexpr int K2_GLD = 36, K2_SLOT = 16 * K2_GLD * 4, K2_WAVE = 2 * K2_SLOT;  // strip slots [16 il][36] f32; the 2 x 2 KB images lie over them
+static_assert(K2_WAVE >= 4096, "the P^T and dS^T images fit over the strip slots");
+constexpr int SMEM_BWD_K = 4 * SK_BYTES + SK_BYTES + SP_BYTES + 4 * K2_WAVE;  // (qu, dO) x 2 + qv + window + per-wave regions
+static_assert((SMEM_BWD_K + 1279) / 1280 * 2 <= 128, "two workgroups per CU");
+
+// A-operand images of the key-side kernel, TRANSPOSED: [64 k = il][16 rows = jl] bf16 (32-byte k-rows, 2 KB).  A lane's four values of a
+// query (keys g*4 .. +3) are ONE 8-byte store (slot g ^ ((il >> 2) & 3): the 16 lanes of a ds_write_b64 group cover all 32 banks) - in the
+// row-major [16 jl][64 il] image they were four 2-byte stores into four rows, 32 per lane and query block for the two images, two lanes
+// sharing every dword.  The fragment (row jl = r, k = kbase .. +7) comes back through the transposing read, as frag_kt's.
+__device__ __forceinline__ void img_store(char* s, int il, int g, float v0, float v1, float v2, float v3) {
+  uint2 u;
+  u.x = pack2_bf16(v0, v1);
+  u.y = pack2_bf16(v2, v3);
+  *reinterpret_cast<uint2*>(s + il * 32 + ((g ^ ((il >> 2) & 3)) << 3)) = u;
+}
+__device__ __forceinline__ short8_t img_frag(const char* s, int kbase, int r) {
+  const int k0 = kbase + (r >> 2), k1 = k0 + 4, c = r & 3;
+  const short4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (__attribute__((address_space(3))) short4_t*)(s + k0 * 32 + ((c ^ ((k0 >> 2) & 3)) << 3)));
+  const short4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (__attribute__((address_space(3))) short4_t*)(s + k1 * 32 + ((c ^ ((k1 >> 2) & 3)) << 3)));
+  short8_t v;
+  v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
+  v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+  return v;
+}
 
 template <bool STREAM>
 __global__ __launch_bounds__(256, 2) void relattn_fused_bwd_k_kernel(
@@ -1009,22 +1045,20 @@ __global__ __launch_bounds__(256, 2) void relattn_fused_bwd_k_kernel(
     const float* __restrict__ lse, const float* __restrict__ dvec, bf16_t* __restrict__ dqkv, int B, int H, int T, float scale,
     int use_mask, int chunk, int hist) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* sQu = smem;
-  char* sQv = sQu + SK_BYTES;
-  char* sdO = sQv + SK_BYTES;
-  char* sP = sdO + SK_BYTES;
-  float* sGt = reinterpret_cast<float*>(sP + SP_BYTES);
+  char* const sQu0 = smem;                    // [2] qu blocks
+  char* const sdO0 = sQu0 + 2 * SK_BYTES;     // [2] dO blocks
+  char* const sQv = sdO0 + 2 * SK_BYTES;
+  char* const sP = sQv + SK_BYTES;
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  // per-wave A images (P^T and dS^T, 2 KB each), carved out of what is dead once Gt is complete: the qv block and the first 64 window
-  // rows.  Window row 127 - the bias row, written once in front of the loop and left alone by the loop's DMA - stays intact (with both
-  // images inside the window it was rewritten, behind a barrier of its own, in every iteration).
-  char* sAp = sQv + w * 2048;
-  char* sAs = sP + w * 2048;
+  char* const sW = sP + SP_BYTES + w * K2_WAVE;  // this wave's region: strip slots, then (over them) the two A images
+  float* const sS = reinterpret_cast<float*>(sW);
+  char* const sAp = sW;
+  char* const sAs = sW + 2048;
   const int r = lane & 15, g = lane >> 4;
-  const BlockId bid = attn_block_id<false>(B, H, (T + BJ - 1) / BJ);  // the key blocks of one (sample, head) on one XCD, back to back (1-D grid)
+  const BlockId bid = attn_block_id<false>(B, H, (T + BJ - 1) / BJ);
   if (!bid.ok) return;
   const int b = bid.b, h = bid.h, j0 = bid.blk * BJ;
-  const int HD = H * DH, LDQ = 3 * HD, R = 2 * T - 1, R1 = 2 * T;
+  const int HD = H * DH, LDQ = 3 * HD, R1 = 2 * T;
   const int len = lengths ? min(lengths[b], T) : T;
   const int shift = T - len;
   const bf16_t* kb = qkv + (long)b * T * LDQ + HD + h * DH;
@@ -1033,8 +1067,6 @@ __global__ __launch_bounds__(256, 2) void relattn_fused_bwd_k_kernel(
   const bf16_t* qvb = qv + (long)b * T * HD + h * DH;
   const bf16_t* dob = dout + (long)b * T * HD + h * DH;
   const bf16_t* pb = pext + h * DH;
-  // the bias row R of the position table (window row 127 / 95 of every key block): 16 bytes per lane of wave 0, loaded ONCE - inside the
-  // block loop it was a dependent global load between the barrier and the __syncthreads() of every iteration
   uint4 bias_row = make_uint4(0, 0, 0, 0);
   if ((threadIdx.x >> 6) == 0 && (threadIdx.x & 63) < 8) bias_row = *reinterpret_cast<const uint4*>(pb + (long)(2 * T - 1) * HD + (((threadIdx.x & 63) ^ key_d(127)) << 3));
 
@@ -1049,70 +1081,91 @@ __global__ __launch_bounds__(256, 2) void relattn_fused_bwd_k_kernel(
 #pragma unroll
   for (int n = 0; n < 4; ++n) { acc_k[n] = float4_t{0.f, 0.f, 0.f, 0.f}; acc_v[n] = float4_t{0.f, 0.f, 0.f, 0.f}; }
 
-  // loop-invariant per-lane quantities of the pT / dsT phase (this block's keys are fixed: j = j0 + w*16 + g*4 + e)
   const float scale2 = scale * 1.4426950408889634f;
   const int lim = 2 * len - 1;
   const long lrow = ((long)b * H + h) * T;
-  int rrk[4], gtoff[4], aoff[4][4];
+  const long plane = (long)B * H * T;  // second plane of dvec: the bias-row score of every query (relattn_fused_bwd_qT_kernel)
+  int rrk[4];
   bool jin[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
-    const int jl = w * 16 + g * 4 + e, row = g * 4 + e;
-    rrk[e] = T - 1 + j0 + jl;                          // - i = relative-position row
-    gtoff[e] = r * (GTLD - 1) + 63 + jl;              // + it*16*(GTLD-1): Gt[il][(63 - il) + jl], il = it*16 + r
+    const int jl = w * 16 + g * 4 + e;
+    rrk[e] = T - 1 + j0 + jl;
     jin[e] = j0 + jl < T;
+  }
+  const int soff = r * K2_GLD + 15 - r + g * 4;  // + e: this lane's skewed score of key g*4 + e in a strip slot (window column 15 - il + jl of the pair of tiles)
+  const int nib = (T + BI - 1) / BI;
+  auto full_block = [&](int ib) { return !(use_mask && ib * BI >= len); };
+  auto issue_a = [&](int ib) {  // qu / dO blocks of query block ib -> buffer ib & 1
+    load_rows<BI, true>(sQu0 + (ib & 1) * SK_BYTES, qub, HD, ib * BI, T, w, lane);
+    load_rows<BI, true>(sdO0 + (ib & 1) * SK_BYTES, dob, HD, ib * BI, T, w, lane);
+  };
+  auto issue_b = [&](int ib) {  // qv block and the window of (query block ib, this key block)
+    load_rows<BI, true>(sQv, qvb, HD, ib * BI, T, w, lane);
+    load_rows<WIN, true, true>(sP, pb, HD, (T - 1 - (ib * BI + BI - 1) + j0) + shift, R1, w, lane);  // (row 127 = the bias row, written once)
+  };
+  // per-query scalars of a block: log-sum-exp, D_i, bias-row score (plain loads: issued in FRONT of the DMA pieces they travel with)
+  float lse_nx[4], Di_nx[4], gb_nx[4];
+  auto load_scalars = [&](int ib) {
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
-      const int il = it * 16 + r;
-      aoff[e][it] = row * 128 + (((il >> 3) ^ key_d(row)) << 4) + (il & 7) * 2;
+      const int ic = min(ib * BI + it * 16 + r, T - 1);
+      lse_nx[it] = lse[lrow + ic] * 1.4426950408889634f;
+      Di_nx[it] = dvec[lrow + ic];
+      gb_nx[it] = dvec[plane + lrow + ic];
     }
-  }
-  const int nib = (T + BI - 1) / BI;
+  };
   if (w == 0 && lane < 8) *reinterpret_cast<uint4*>(sP + 127 * 128 + lane * 16) = bias_row;  // (visible behind the first iteration's barrier)
+  load_scalars(0);
+  issue_a(0);
+  if (full_block(0)) issue_b(0);
+#ifdef TFASR_ATTN_TIMING
+  long long ph[5] = {0, 0, 0, 0, 0};
+  int nfull = 0;
+  const long long t_begin = __builtin_readcyclecounter();
+#endif
   for (int ib = 0; ib < nib; ++ib) {
     const int i0 = ib * BI;
-    if (use_mask && i0 >= len) {
+    const bool full = full_block(ib);
+#ifdef TFASR_ATTN_TIMING
+    long long tp = __builtin_readcyclecounter();
+#endif
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this block's tiles and scalars (requested one / half an iteration ago)
+    __builtin_amdgcn_s_barrier();                      // ... of every wave; every wave is done with the other qu / dO buffer and with its images
+    if (full) { ATT_TICK(0) }
+    float lse2_it[4], Di_it[4], gb_it[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) { lse2_it[it] = lse_nx[it]; Di_it[it] = Di_nx[it]; gb_it[it] = gb_nx[it]; }
+    if (ib + 1 < nib) issue_a(ib + 1);
+    const char* sQu = sQu0 + (ib & 1) * SK_BYTES;
+    const char* sdO = sdO0 + (ib & 1) * SK_BYTES;
+    if (!full) {
       // a block of padded query rows: p = 1 / T for every key (exp2(0 - lse), lse = log T), dS = 0: only dv += P^T @ dO remains
-      load_rows<BI>(sdO, dob, HD, i0, T, w, lane);
+      if (ib + 1 < nib) load_scalars(ib + 1);  // (padded query blocks are a suffix: the next one needs no qv / window either)
 #pragma unroll
       for (int it = 0; it < 4; ++it) {
         const int i = i0 + it * 16 + r;
-        const float lse2 = lse[lrow + min(i, T - 1)] * 1.4426950408889634f;
-        const bf16_t pv = f32_to_bf16(__builtin_amdgcn_exp2f(0.f - lse2));
-#pragma unroll
-        for (int e = 0; e < 4; ++e) *reinterpret_cast<bf16_t*>(sAp + aoff[e][it]) = (i < T && jin[e]) ? pv : (bf16_t)0;
+        const float pv = i < T ? __builtin_amdgcn_exp2f(0.f - lse2_it[it]) : 0.f;
+        img_store(sAp, it * 16 + r, g, jin[0] ? pv : 0.f, jin[1] ? pv : 0.f, jin[2] ? pv : 0.f, jin[3] ? pv : 0.f);
       }
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      __syncthreads();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
-        const short8_t ap = frag_rows(sAp, r, kk * 4 + g);
+        const short8_t ap = img_frag(sAp, kk * 32 + g * 8, r);
 #pragma unroll
         for (int n = 0; n < 4; ++n)
           acc_v[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap, frag_kt(sdO, n * 16, kk * 32 + g * 8, r), acc_v[n], 0, 0, 0);
       }
-      __syncthreads();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       continue;
     }
-    const int pw0 = (T - 1 - (i0 + BI - 1) + j0) + shift;
-    // the query rows' log-sum-exp and D_i: loaded here, in flight together with the block's DMA pieces (they used to be 8 dependent
-    // global loads in the middle of the iteration, between the score products and the exponentials)
-    float lse2_it[4], Di_it[4];
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int ic = min(i0 + it * 16 + r, T - 1);
-      lse2_it[it] = lse[lrow + ic] * 1.4426950408889634f;
-      Di_it[it] = dvec[lrow + ic];
-    }
-    load_rows<BI>(sQu, qub, HD, i0, T, w, lane);
-    load_rows<BI>(sQv, qvb, HD, i0, T, w, lane);
-    load_rows<BI>(sdO, dob, HD, i0, T, w, lane);
-    load_rows<WIN, false, true>(sP, pb, HD, pw0, R1, w, lane);  // (window row 127 = the bias row, written once in front of the loop)
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-
-    // transposed content scores and dP: rows = this wave's 16 keys, cols = 64 queries
-    float4_t acc_s[4], acc_p[4];
+    // transposed content scores and dP (rows = this wave's 16 keys, columns = the 16 queries of tile it), and the wave's own window scores.
+    // Staged so that nothing waits inside: all 32 products first (their fragment reads stream under them), THEN the strip round trips -
+    // tiles 0 / 1 through the two slots, tiles 2 / 3 behind them (one wave's LDS operations execute in order: the second pair of writes
+    // cannot pass the first pair of reads).  As one loop over `it` every tile's write -> read round trip sat between two groups of products:
+    // 3 045 of a query block's 8 400 clocks (tools/attn_timing.py).
+    float4_t acc_s[4], acc_p[4], ga[4][2];
+    float gvv[4][4];
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
       acc_s[it] = float4_t{0.f, 0.f, 0.f, 0.f};
@@ -1123,23 +1176,48 @@ __global__ __launch_bounds__(256, 2) void relattn_fused_bwd_k_kernel(
         acc_p[it] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[kk], frag_rows(sdO, it * 16 + r, kk * 4 + g), acc_p[it], 0, 0, 0);
       }
     }
-    // Gt[c, i] for c-tiles 2w, 2w+1
 #pragma unroll
-    for (int cc = 0; cc < 2; ++cc) {
-      const int ct = 2 * w + cc;
+    for (int it = 0; it < 4; ++it) {
+      short8_t fq[2];
 #pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        float4_t a = float4_t{0.f, 0.f, 0.f, 0.f};
+      for (int kk = 0; kk < 2; ++kk) fq[kk] = frag_rows(sQv, it * 16 + r, kk * 4 + g);
+#pragma unroll
+      for (int cc = 0; cc < 2; ++cc) {
+        const int ct = 3 - it + w + cc;  // window tile: rows ct*16 .. +15 (0 <= ct <= 7)
+        ga[it][cc] = float4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
-          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(sP, ct * 16 + r, kk * 4 + g), frag_rows(sQv, it * 16 + r, kk * 4 + g), a, 0, 0, 0);
-        *reinterpret_cast<float4_t*>(sGt + (it * 16 + r) * GTLD + ct * 16 + g * 4) = a;
+          ga[it][cc] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(sP, ct * 16 + r, kk * 4 + g), fq[kk], ga[it][cc], 0, 0, 0);
       }
     }
-    __syncthreads();  // Gt complete; the window and the qv block are dead from here on
-
-    // pT and dsT in C layout (row jl = g*4+e of this wave, col il = it*16+r) -> A-operand images [16 jl][64 k = il]
-    // (window-gather offsets, image slots and the validity threshold are loop invariants hoisted above the query loop)
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int hp = 0; hp < 2; ++hp) {
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int it = hp * 2 + q;
+        float* slot = sS + q * (K2_SLOT / 4);
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) *reinterpret_cast<float4_t*>(slot + r * K2_GLD + cc * 16 + g * 4) = ga[it][cc];  // G[il = r][c_local = cc*16 + g*4 + e]
+      }
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int it = hp * 2 + q;
+        const float* slot = sS + q * (K2_SLOT / 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) gvv[it][e] = slot[soff + e];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    ATT_TICK(1)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // every wave has read the qv block and the window: the next block's may land (and the strips are in registers)
+    if (ib + 1 < nib) {
+      load_scalars(ib + 1);
+      if (full_block(ib + 1)) issue_b(ib + 1);
+    }
+    ATT_TICK(2)
+    // pT and dsT in C layout (row jl = g*4+e of this wave, col il = it*16+r) -> A-operand images [16 jl][64 k = il] over the strip slots
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
       const int il = it * 16 + r, i = i0 + il;
@@ -1148,12 +1226,13 @@ __global__ __launch_bounds__(256, 2) void relattn_fused_bwd_k_kernel(
       const float D_i = Di_it[it];
       const bool qmask = use_mask && (i >= len);
       const bool iin = i < T;
-      const float gbias = sGt[il * GTLD + 127];
+      const float gbias = gb_it[it];
       int wlo = 0, whi = T;
       if constexpr (STREAM) { if (!qmask) stream_window(ic, T, chunk, hist, wlo, whi); }
+      float pp[4], dd[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float pos = (rrk[e] - i < lim) ? sGt[gtoff[e] + it * 16 * (GTLD - 1)] : gbias;
+        const float pos = (rrk[e] - i < lim) ? gvv[it][e] : gbias;
         float p = 0.f, d = 0.f;
         bool vis = iin && jin[e];
         if constexpr (STREAM) { const int j = j0 + w * 16 + g * 4 + e; vis = vis && j >= wlo && j < whi; }
@@ -1162,25 +1241,39 @@ __global__ __launch_bounds__(256, 2) void relattn_fused_bwd_k_kernel(
           p = __builtin_amdgcn_exp2f(s2 - lse2);
           d = qmask ? 0.f : p * (acc_p[it][e] - D_i) * scale;
         }
-        *reinterpret_cast<bf16_t*>(sAp + aoff[e][it]) = f32_to_bf16(p);
-        *reinterpret_cast<bf16_t*>(sAs + aoff[e][it]) = f32_to_bf16(d);
+        pp[e] = p;
+        dd[e] = d;
       }
+      img_store(sAp, il, g, pp[0], pp[1], pp[2], pp[3]);
+      img_store(sAs, il, g, dd[0], dd[1], dd[2], dd[3]);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
+    ATT_TICK(3)
     // dv += pT @ dO ; dk += dsT @ qu    (B operands: the dO / qu blocks read transposed, k = i)
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-      const short8_t ap = frag_rows(sAp, r, kk * 4 + g);
-      const short8_t as = frag_rows(sAs, r, kk * 4 + g);
+      const short8_t ap = img_frag(sAp, kk * 32 + g * 8, r);
+      const short8_t as = img_frag(sAs, kk * 32 + g * 8, r);
 #pragma unroll
       for (int n = 0; n < 4; ++n) {
         acc_v[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap, frag_kt(sdO, n * 16, kk * 32 + g * 8, r), acc_v[n], 0, 0, 0);
         acc_k[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as, frag_kt(sQu, n * 16, kk * 32 + g * 8, r), acc_k[n], 0, 0, 0);
       }
     }
-    __syncthreads();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the fragments are in registers before the next iteration's barrier releases the buffers)
+    ATT_TICK(4)
+#ifdef TFASR_ATTN_TIMING
+    ++nfull;
+#endif
   }
+#ifdef TFASR_ATTN_TIMING
+  if (threadIdx.x == 0 && blockIdx.x < 8192) {  // [5 phase sums of wave 0 over the live query blocks][loop][0][live query blocks]
+    long long* o = g_attn_timing + 8L * blockIdx.x;
+    for (int kq = 0; kq < 5; ++kq) o[kq] = ph[kq];
+    o[5] = __builtin_readcyclecounter() - t_begin; o[6] = 0; o[7] = nfull;
+  }
+#endif
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     const int j = j0 + w * 16 + g * 4 + e;
@@ -1259,12 +1352,17 @@ extern "C" int tfasr_relattn_fused_bwd_k(const void* qkv, const void* qu, const 
   if (!qkv || !qu || !qv || !pext || !dout || !lse || !dvec || !dqkv || B <= 0 || H <= 0 || T <= 0) return TFASR_STATUS_INVALID_VALUE;
   if (dtype != TFASR_BF16 || dh != DH) return TFASR_STATUS_UNSUPPORTED;
   const dim3 gk(attn_grid_size(B, H, (T + BJ - 1) / BJ));
-  if (chunk > 0)
-    TFASR_KLAUNCH(relattn_fused_bwd_k_kernel<true>, gk, dim3(256), SMEM_BWD_K, (hipStream_t)stream_, (const bf16_t*)qkv, (const bf16_t*)qu,
-                       (const bf16_t*)qv, (const bf16_t*)pext, lengths, (const bf16_t*)dout, lse, dvec, (bf16_t*)dqkv, B, H, T, scale, use_mask, chunk, hist);
-  else
-    TFASR_KLAUNCH(relattn_fused_bwd_k_kernel<false>, gk, dim3(256), SMEM_BWD_K, (hipStream_t)stream_, (const bf16_t*)qkv, (const bf16_t*)qu,
-                       (const bf16_t*)qv, (const bf16_t*)pext, lengths, (const bf16_t*)dout, lse, dvec, (bf16_t*)dqkv, B, H, T, scale, use_mask, 0, 0);
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)relattn_fused_bwd_k_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BWD_K);
+    (void)hipFuncSetAttribute((const void*)relattn_fused_bwd_k_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BWD_K);
+    attr_done = true;
+  }
+#define TFASR_BK_LAUNCH(KERN, SMEM, ST, CH, HI)                                                                                         \
+  TFASR_KLAUNCH((KERN<ST>), gk, dim3(256), SMEM, (hipStream_t)stream_, (const bf16_t*)qkv, (const bf16_t*)qu, (const bf16_t*)qv,        \
+                (const bf16_t*)pext, lengths, (const bf16_t*)dout, lse, dvec, (bf16_t*)dqkv, B, H, T, scale, use_mask, CH, HI)
+  if (chunk > 0) TFASR_BK_LAUNCH(relattn_fused_bwd_k_kernel, SMEM_BWD_K, true, chunk, hist); else TFASR_BK_LAUNCH(relattn_fused_bwd_k_kernel, SMEM_BWD_K, false, 0, 0);
+#undef TFASR_BK_LAUNCH
   TFASR_CHECK_LAUNCH();
   return TFASR_STATUS_SUCCESS;
 }

@@ -433,7 +433,7 @@ struct Ex {
         dpext = f32(scratch, (long)R1 * HD);
         zero(dpext, (size_t)R1 * HD * 4);
       }
-      float* dvec = f32(scratch, (long)B * H * T);
+      float* dvec = f32(scratch, 2L * B * H * T);  // rowsum(dO * o) and the bias-row score of every query (two planes)
       void* qu = act(scratch, rows * HD);
       void* qvb = act(scratch, rows * HD);
       if (dpext_deferred) qvb = io->qv_keep;

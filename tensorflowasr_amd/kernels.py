@@ -571,11 +571,11 @@ def relattn_fused_bwd_q3(qkv, ubias, vbias, pext, lengths, o, dout, lse, dqkv, d
                          history_size=None, ds=None, qv=None):
     """Query side of the fused attention backward (tfasr_relattn_fused_bwd_q3): writes dq = dqu + dqv into the q columns of dqkv
     [B*T, 3*H*dh], adds the u / v bias gradients into du / dv [H*dh] f32 and the bias row's share into dpext [2T, H*dh] f32.
-    -> (ds [B,H,T,lds] unskewed score gradient, dvec [B,H,T], qu, qv = q + u / q + v for the key side and tfasr_relattn_dpext)."""
+    -> (ds [B,H,T,lds] unskewed score gradient, dvec [2,B,H,T], qu, qv = q + u / q + v for the key side and tfasr_relattn_dpext)."""
     lds = -(-T // 8) * 8
     if ds is None:
         ds = torch.empty(B, H, T, lds, dtype=qkv.dtype, device=qkv.device)
-    dvec = torch.empty(B, H, T, dtype=torch.float32, device=qkv.device)
+    dvec = torch.empty(2, B, H, T, dtype=torch.float32, device=qkv.device)  # rowsum(dout * o) | the bias-row score of every query
     qu = torch.empty(B * T, H * dh, dtype=qkv.dtype, device=qkv.device)
     if qv is None:
         qv = torch.empty(B * T, H * dh, dtype=qkv.dtype, device=qkv.device)

@@ -1,4 +1,4 @@
-"""Per-phase shader clocks of the query-side attention backward (relattn_fused_bwd_qT_kernel) inside a Conformer-M train step.
+"""Per-phase shader clocks of the KEY-side attention backward (relattn_fused_bwd_k_kernel: it runs last and owns the probe buffer) inside a Conformer-M train step.
 Probe build: tools/build_probe_lib.sh attn_fused.hip -DTFASR_ATTN_TIMING, then
   TFASR_LIB=$PWD/tools/hwprobe/libtfasr_probe.so python tools/attn_timing.py
 Each workgroup's wave 0 sums the clocks of five phases of its key-block loop: 0 DMA issue + wait + barrier, 1 S^T / dP^T / G^T products +
@@ -25,7 +25,7 @@ a = np.frombuffer(buf, dtype=np.int64).reshape(8192, 8)
 live = a[(a[:, 7] > 0) & (a[:, 5] > 0)]
 print("workgroups with a key loop:", len(live), "key blocks each:", int(np.median(live[:, 7])))
 per = live[:, :5] / live[:, 7:8]
-names = ["DMA issue + wait + barrier", "S^T dP^T G^T products", "scores, exp, dS, image, store", "dq products", "closing barrier"]
+names = ["top wait + barrier", "S^T dP^T products, own window scores", "barrier + prefetch issue", "exp, dS, images", "dK dV products"]  # relattn_fused_bwd_k_kernel runs last in a step and owns the buffer
 for i, nm in enumerate(names):
     print(f"  phase {i} {nm:32s} median {np.median(per[:, i]):8.0f} clocks per key block   mean {per[:, i].mean():8.0f}")
 print(f"  loop total per key block: median {np.median(live[:, 5] / live[:, 7]):.0f}; loop median {np.median(live[:, 5]):.0f}, epilogue median {np.median(live[:, 6]):.0f} max {live[:, 6].max()}")
