@@ -1267,7 +1267,7 @@ __global__ __launch_bounds__(256, 2) void relattn_fused_bwd_k_kernel(
     ++nfull;
 #endif
   }
-#ifdef TFASR_ATTN_TIMING
+#if defined(TFASR_ATTN_TIMING) && TFASR_ATTN_TIMING == 3  // (-DTFASR_ATTN_TIMING=3: this kernel owns the probe buffer; =1: the query-side backward)
   if (threadIdx.x == 0 && blockIdx.x < 8192) {  // [5 phase sums of wave 0 over the live query blocks][loop][0][live query blocks]
     long long* o = g_attn_timing + 8L * blockIdx.x;
     for (int kq = 0; kq < 5; ++kq) o[kq] = ph[kq];
