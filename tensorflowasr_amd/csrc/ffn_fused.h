@@ -181,22 +181,27 @@ __global__ __launch_bounds__(256, WGS) void ffn_fused_fwd_kernel(const FfnArgs p
 #pragma unroll
         for (int i = 0; i < MR; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j) acc1[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lnf[i][2 * kp + kk], bf[kk][j], acc1[i][j], 0, 0, 0);
+          for (int j = 0; j < 2; ++j) acc1[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[kk][j], lnf[i][2 * kp + kk], acc1[i][j], 0, 0, 0);  // (transposed: see zlds)
       if (fence) __builtin_amdgcn_sched_barrier(0);
     }
   };
-  auto zlds = [&](int cc) {  // acc1 + b1 -> z (bf16) -> sH[cc % 2] (scattered 2-byte writes from the MFMA C layout)
+  // GEMM1's accumulators are TRANSPOSED (the operand slots of the MFMA swapped: the A and B fragment layouts are the same): lane (r, g) of
+  // tile (i, j) holds row i*16 + r, FOUR CONSECUTIVE hidden columns j*16 + g*4 + e - one 8-byte LDS store per tile (they were four 2-byte
+  // stores into four rows: 16 per lane and chunk), the bias a 16-byte read
+  auto zlds = [&](int cc) {  // acc1 + b1 -> z (bf16) -> sH[cc % 2]
     char* sH = smem + SH_OFF + (cc & (NBUF - 1)) * SH_BYTES;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const float bzj = sB1[cc * 64 + wc * 32 + j * 16 + r];
+      const int k = wc * 32 + j * 16 + g * 4;
+      const float4 bz = *reinterpret_cast<const float4*>(sB1 + cc * 64 + k);
 #pragma unroll
-      for (int i = 0; i < MR; ++i)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int row = wr * WR + i * 16 + g * 4 + e, k = wc * 32 + j * 16 + r;
-          *reinterpret_cast<bf16_t*>(sH + row * 128 + (((k >> 3) ^ key_d(row)) << 4) + (k & 7) * 2) = f32_to_bf16(acc1[i][j][e] + bzj);
-        }
+      for (int i = 0; i < MR; ++i) {
+        const int row = wr * WR + i * 16 + r;
+        uint2 v;
+        v.x = pack2_bf16(acc1[i][j][0] + bz.x, acc1[i][j][1] + bz.y);
+        v.y = pack2_bf16(acc1[i][j][2] + bz.z, acc1[i][j][3] + bz.w);
+        *reinterpret_cast<uint2*>(sH + row * 128 + (((k >> 3) ^ key_d(row)) << 4) + (k & 7) * 2) = v;
+      }
     }
   };
   // FAST (full tile, z and h stored): no branch inside, so the pass and the matrix instructions of the other product form ONE basic block
