@@ -16,8 +16,8 @@
 // k-contiguous ("direct" images of gemm_fast.hip), THREE LDS stages (a slab has two iterations to land), LDS-DMA by inline asm with
 // hand-counted vmcnt, and the fragments of slab s+1 are read into a second register set between the MFMAs of slab s (one barrier per slab).
 // The accumulators are TRANSPOSED (the operand slots of the MFMA swapped, as gemm_big's TR epilogue): lane (r, g) of fragment (i, j)
-// holds row i*16 + r, four CONSECUTIVE columns j*16 + g*4 + e.  So the LayerNorm backward runs straight from the accumulators: x / add /
-// dx are 8-byte pieces per lane (the four j of a lane group cover one 128-byte line per row), a row's sums are in-lane over 16 values +
+// holds row i*16 + r, four CONSECUTIVE columns j*16 + g*4 + e.  So the LayerNorm backward runs straight from the accumulators: after one
+// lane-pair exchange x / add / dx are 16-byte pieces per lane (eight consecutive columns), a row's sums are in-lane over 16 values +
 // two cross-group lane swaps + one LDS exchange between the four column waves, the gamma / beta column sums are DPP sums over the 16 rows
 // of a fragment.  No transposition through LDS (a first version with 16-row LDS strips spent 24 k of its 58 k clocks per tile there).
 #pragma once
@@ -151,9 +151,29 @@ __global__ __launch_bounds__(512, 2) void dense_ln_bwd_kernel(const DenseLnArgs 
   DLN_TICK(3)
 
   // ---- epilogue: LayerNorm backward straight from the transposed accumulators --------------------------------------------------------
-  // lane (r, g), fragment (i, j): row = row0 + (wm*MTW + i)*16 + r, columns cb + j*16 .. +3 with cb = wn*64 + g*4
-  const int cb = wn * 64 + g * 4;
-  uint2 xr[MTW][4], ar[MTW][4];
+  // lane (r, g), fragment (i, j): row = row0 + (wm*MTW + i)*16 + r, columns wn*64 + j*16 + g*4 .. +3.  The lanes g and g ^ 1 first trade one
+  // fragment of every pair (j, j + 1) through the lane-swap network (as gemm_big's transposed epilogue does): an even g then owns EIGHT
+  // consecutive columns of fragment j, an odd g eight of fragment j + 1 - x / add are 16-byte loads, dx / dx_dropped 16-byte stores
+  // (8-byte accesses run at 0.54-0.70 of the 16-byte rate, and this phase is the memory system's)
+  const bool odd = (g & 1) != 0;
+  float d8[MTW][2][8];
+#pragma unroll
+  for (int i = 0; i < MTW; ++i)
+#pragma unroll
+    for (int jp = 0; jp < 2; ++jp) {
+      float recv[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        recv[e] = __uint_as_float(xor16_get(__float_as_uint(odd ? acc[i][2 * jp][e] : acc[i][2 * jp + 1][e]), odd));
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        d8[i][jp][e] = odd ? recv[e] : acc[i][2 * jp][e];
+        d8[i][jp][4 + e] = odd ? acc[i][2 * jp + 1][e] : recv[e];
+      }
+    }
+  // this lane's eight columns of pair jp: cb + jp*32 .. +7
+  const int cb = wn * 64 + (odd ? 16 : 0) + (g & 2) * 4;
+  uint4 xr[MTW][2], ar[MTW][2];
   float mr[MTW], rr[MTW];
   bool live[MTW];
 #pragma unroll
@@ -164,43 +184,40 @@ __global__ __launch_bounds__(512, 2) void dense_ln_bwd_kernel(const DenseLnArgs 
     mr[i] = p.mean[rc];
     rr[i] = p.rstd[rc];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      xr[i][j] = *reinterpret_cast<const uint2*>(p.x + rc * DLN_D + cb + j * 16);
-      ar[i][j] = p.add ? *reinterpret_cast<const uint2*>(p.add + rc * DLN_D + cb + j * 16) : make_uint2(0u, 0u);
+    for (int jp = 0; jp < 2; ++jp) {
+      xr[i][jp] = *reinterpret_cast<const uint4*>(p.x + rc * DLN_D + cb + jp * 32);
+      ar[i][jp] = p.add ? *reinterpret_cast<const uint4*>(p.add + rc * DLN_D + cb + jp * 32) : make_uint4(0u, 0u, 0u, 0u);
     }
   }
-  float gm[4][4];
+  float gm[2][8];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const float4 t = *reinterpret_cast<const float4*>(p.gamma + cb + j * 16);
-    gm[j][0] = t.x; gm[j][1] = t.y; gm[j][2] = t.z; gm[j][3] = t.w;
-  }
+  for (int jp = 0; jp < 2; ++jp) ld8(p.gamma + cb + jp * 32, gm[jp]);
   __builtin_amdgcn_s_barrier();  // every wave is past its last fragment read: the stages are dead
   float* red = reinterpret_cast<float*>(smem);  // [4 wn][ROWS][2] row sums, then [2][256] column sums of the upper row half
-  float ag[4][4], ab[4][4];
+  float ag[2][8], ab[2][8];
 #pragma unroll
-  for (int j = 0; j < 4; ++j)
+  for (int jp = 0; jp < 2; ++jp)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { ag[j][e] = 0.f; ab[j][e] = 0.f; }
-  float xh[MTW][4][4];
+    for (int e = 0; e < 8; ++e) { ag[jp][e] = 0.f; ab[jp][e] = 0.f; }
+  float xh[MTW][2][8];
 #pragma unroll
   for (int i = 0; i < MTW; ++i) {
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float xv[4] = {__uint_as_float(xr[i][j].x << 16), __uint_as_float(xr[i][j].x & 0xffff0000u), __uint_as_float(xr[i][j].y << 16),
-                           __uint_as_float(xr[i][j].y & 0xffff0000u)};
+    for (int jp = 0; jp < 2; ++jp) {
+      float xv[8];
+      unpack8(xr[i][jp], xv);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float d = live[i] ? acc[i][j][e] * p.alpha : 0.f;
-        acc[i][j][e] = d;
+      for (int e = 0; e < 8; ++e) {
+        const float d = live[i] ? d8[i][jp][e] * p.alpha : 0.f;
+        d8[i][jp][e] = d;
         const float xhat = (xv[e] - mr[i]) * rr[i];
-        xh[i][j][e] = xhat;
-        const float dg = d * gm[j][e];
+        xh[i][jp][e] = xhat;
+        const float dg = d * gm[jp][e];
         s1 += dg;
         s2 += dg * xhat;
-        ag[j][e] += d * xhat;
-        ab[j][e] += d;
+        ag[jp][e] += d * xhat;
+        ab[jp][e] += d;
       }
     }
     s1 = xor32_sum(xor16_sum(s1));
@@ -222,27 +239,26 @@ __global__ __launch_bounds__(512, 2) void dense_ln_bwd_kernel(const DenseLnArgs 
     const long row = row0 + rl;
     if (live[i]) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float av[4] = {__uint_as_float(ar[i][j].x << 16), __uint_as_float(ar[i][j].x & 0xffff0000u), __uint_as_float(ar[i][j].y << 16),
-                             __uint_as_float(ar[i][j].y & 0xffff0000u)};
-        float o[4];
+      for (int jp = 0; jp < 2; ++jp) {
+        float o[8];
+        unpack8(ar[i][jp], o);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = av[e] + rr[i] * (acc[i][j][e] * gm[j][e] - s1 - xh[i][j][e] * s2);
-        uint2 v;
-        v.x = pack2_bf16(o[0], o[1]);
-        v.y = pack2_bf16(o[2], o[3]);
-        *reinterpret_cast<uint2*>(p.dx + row * DLN_D + cb + j * 16) = v;
+        for (int e = 0; e < 8; ++e) o[e] += rr[i] * (d8[i][jp][e] * gm[jp][e] - s1 - xh[i][jp][e] * s2);
+        uint4 v;
+        v.x = pack2_bf16(o[0], o[1]); v.y = pack2_bf16(o[2], o[3]); v.z = pack2_bf16(o[4], o[5]); v.w = pack2_bf16(o[6], o[7]);
+        *reinterpret_cast<uint4*>(p.dx + row * DLN_D + cb + jp * 32) = v;
         if (drop) {  // dropout of the ROUNDED dx (= tfasr_dropout(dx)): an even / odd element pair shares one hash
-          const uint64_t e0 = (uint64_t)(row * DLN_D + cb + j * 16);
-          const uint32_t h0 = drop_mix(dkey, (uint32_t)(e0 >> 1), (uint32_t)(e0 >> 33)), h1 = drop_mix(dkey, (uint32_t)((e0 + 2) >> 1), (uint32_t)((e0 + 2) >> 33));
-          const float q0 = (h0 & 0xffffu) >= dthr ? __uint_as_float(v.x << 16) * drop_inv : 0.f;
-          const float q1 = (h0 >> 16) >= dthr ? __uint_as_float(v.x & 0xffff0000u) * drop_inv : 0.f;
-          const float q2 = (h1 & 0xffffu) >= dthr ? __uint_as_float(v.y << 16) * drop_inv : 0.f;
-          const float q3 = (h1 >> 16) >= dthr ? __uint_as_float(v.y & 0xffff0000u) * drop_inv : 0.f;
-          uint2 u;
-          u.x = pack2_bf16(q0, q1);
-          u.y = pack2_bf16(q2, q3);
-          *reinterpret_cast<uint2*>(p.dxd + row * DLN_D + cb + j * 16) = u;
+          const uint64_t e0 = (uint64_t)(row * DLN_D + cb + jp * 32);
+          const uint32_t vv[4] = {v.x, v.y, v.z, v.w};
+          uint32_t uu[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const uint32_t hh = drop_mix(dkey, (uint32_t)((e0 + 2 * q) >> 1), (uint32_t)((e0 + 2 * q) >> 33));
+            const float q0 = (hh & 0xffffu) >= dthr ? __uint_as_float(vv[q] << 16) * drop_inv : 0.f;
+            const float q1 = (hh >> 16) >= dthr ? __uint_as_float(vv[q] & 0xffff0000u) * drop_inv : 0.f;
+            uu[q] = pack2_bf16(q0, q1);
+          }
+          *reinterpret_cast<uint4*>(p.dxd + row * DLN_D + cb + jp * 32) = make_uint4(uu[0], uu[1], uu[2], uu[3]);
         }
       }
     }
@@ -250,25 +266,29 @@ __global__ __launch_bounds__(512, 2) void dense_ln_bwd_kernel(const DenseLnArgs 
   DLN_TICK(4)
   // gamma / beta partial sums of the tile: over the 16 rows of a fragment by DPP, over the two row halves through LDS, one writer per column
 #pragma unroll
-  for (int j = 0; j < 4; ++j)
+  for (int jp = 0; jp < 2; ++jp)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { ag[j][e] = row16_sum(ag[j][e]); ab[j][e] = row16_sum(ab[j][e]); }
+    for (int e = 0; e < 8; ++e) { ag[jp][e] = row16_sum(ag[jp][e]); ab[jp][e] = row16_sum(ab[jp][e]); }
   __syncthreads();  // (the row sums have been read)
   if (wm == 1 && r == 0) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      *reinterpret_cast<float4*>(red + cb + j * 16) = make_float4(ag[j][0], ag[j][1], ag[j][2], ag[j][3]);
-      *reinterpret_cast<float4*>(red + DLN_D + cb + j * 16) = make_float4(ab[j][0], ab[j][1], ab[j][2], ab[j][3]);
+    for (int jp = 0; jp < 2; ++jp) {
+      st8(red + cb + jp * 32, ag[jp]);
+      st8(red + DLN_D + cb + jp * 32, ab[jp]);
     }
   }
   __syncthreads();
   if (wm == 0 && r == 0) {
     float* po = p.part + (long)tile * 2 * DLN_D;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float4 u = *reinterpret_cast<const float4*>(red + cb + j * 16), v = *reinterpret_cast<const float4*>(red + DLN_D + cb + j * 16);
-      *reinterpret_cast<float4*>(po + cb + j * 16) = make_float4(ag[j][0] + u.x, ag[j][1] + u.y, ag[j][2] + u.z, ag[j][3] + u.w);
-      *reinterpret_cast<float4*>(po + DLN_D + cb + j * 16) = make_float4(ab[j][0] + v.x, ab[j][1] + v.y, ab[j][2] + v.z, ab[j][3] + v.w);
+    for (int jp = 0; jp < 2; ++jp) {
+      float u[8], v[8];
+      ld8(red + cb + jp * 32, u);
+      ld8(red + DLN_D + cb + jp * 32, v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { u[e] += ag[jp][e]; v[e] += ab[jp][e]; }
+      st8(po + cb + jp * 32, u);
+      st8(po + DLN_D + cb + jp * 32, v);
     }
   }
 #ifdef TFASR_DLN_TIMING
