@@ -1154,7 +1154,7 @@ __global__ __launch_bounds__(256, 2) void relattn_fused_bwd_k_kernel(
         const short8_t ap = img_frag(sAp, kk * 32 + g * 8, r);
 #pragma unroll
         for (int n = 0; n < 4; ++n)
-          acc_v[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap, frag_kt(sdO, n * 16, kk * 32 + g * 8, r), acc_v[n], 0, 0, 0);
+          acc_v[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_kt(sdO, n * 16, kk * 32 + g * 8, r), ap, acc_v[n], 0, 0, 0);
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       continue;
@@ -1250,15 +1250,15 @@ __global__ __launch_bounds__(256, 2) void relattn_fused_bwd_k_kernel(
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     ATT_TICK(3)
-    // dv += pT @ dO ; dk += dsT @ qu    (B operands: the dO / qu blocks read transposed, k = i)
+    // dv^T += dO^T @ p ; dk^T += qu^T @ ds   (A operands: the dO / qu blocks read transposed, k = i; B operands: the images)
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       const short8_t ap = img_frag(sAp, kk * 32 + g * 8, r);
       const short8_t as = img_frag(sAs, kk * 32 + g * 8, r);
 #pragma unroll
       for (int n = 0; n < 4; ++n) {
-        acc_v[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap, frag_kt(sdO, n * 16, kk * 32 + g * 8, r), acc_v[n], 0, 0, 0);
-        acc_k[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as, frag_kt(sQu, n * 16, kk * 32 + g * 8, r), acc_k[n], 0, 0, 0);
+        acc_v[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_kt(sdO, n * 16, kk * 32 + g * 8, r), ap, acc_v[n], 0, 0, 0);
+        acc_k[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_kt(sQu, n * 16, kk * 32 + g * 8, r), as, acc_k[n], 0, 0, 0);
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the fragments are in registers before the next iteration's barrier releases the buffers)
@@ -1274,15 +1274,19 @@ __global__ __launch_bounds__(256, 2) void relattn_fused_bwd_k_kernel(
     o[5] = __builtin_readcyclecounter() - t_begin; o[6] = 0; o[7] = nfull;
   }
 #endif
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const int j = j0 + w * 16 + g * 4 + e;
+  // dK^T / dV^T are accumulated TRANSPOSED (the operand slots of the two products swapped): lane (r, g) holds key j0 + w*16 + r, four
+  // consecutive head dims n*16 + g*4 + e - eight 8-byte stores per lane (they were 32 two-byte ones)
+  {
+    const int j = j0 + w * 16 + r;
     if (j < T) {
       bf16_t* row = dqkv + ((long)b * T + j) * LDQ + h * DH;
 #pragma unroll
       for (int n = 0; n < 4; ++n) {
-        row[HD + n * 16 + r] = f32_to_bf16(acc_k[n][e]);
-        row[2 * HD + n * 16 + r] = f32_to_bf16(acc_v[n][e]);
+        uint2 vk, vv;
+        vk.x = pack2_bf16(acc_k[n][0], acc_k[n][1]); vk.y = pack2_bf16(acc_k[n][2], acc_k[n][3]);
+        vv.x = pack2_bf16(acc_v[n][0], acc_v[n][1]); vv.y = pack2_bf16(acc_v[n][2], acc_v[n][3]);
+        *reinterpret_cast<uint2*>(row + HD + n * 16 + g * 4) = vk;
+        *reinterpret_cast<uint2*>(row + 2 * HD + n * 16 + g * 4) = vv;
       }
     }
   }
