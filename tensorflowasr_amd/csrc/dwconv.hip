@@ -129,22 +129,35 @@ __global__ __launch_bounds__(256) void dwconv_tile_kernel(const bf16_t* __restri
   for (int i = 0; i < TGD; ++i) acc[i] = bv;
   __syncthreads();
   dw_all<TGD, KB>(acc, wk, lds + (grp * TGD) * ROWB + pr * 4, std::make_integer_sequence<int, KB - 1 + TGD>{});
-  if (live) {
-    const int tg0 = t0 + grp * TGD;
+  // output through the (now dead) staging rows: every lane parks its 4-byte results, then the block stores whole 16-byte pieces -
+  // 2 * TGD / 8 store instructions per lane instead of TGD four-byte ones (the output is half of the launch's bytes or more).
+  // GLU: rows 0 .. 2 TGD - 1 hold da, rows 2 TGD .. 4 TGD - 1 hold db (the launcher sizes the LDS for max(staging, 4 TGD) rows)
+  __syncthreads();  // every lane is done reading the staged input
 #pragma unroll
-    for (int i = 0; i < TGD; ++i)
-      if (tg0 + i < Tn) {
-        if constexpr (GLU) {
-          const long row2 = (ubase + (long)(tg0 + i) * C) * 2;  // element offset of the row in the [rows, 2C] tensors
-          const float2_t a = float2_t{__uint_as_float(ga[i] << 16), __uint_as_float(ga[i] & 0xffff0000u)};
-          const float2_t b = float2_t{__uint_as_float(gb[i] << 16), __uint_as_float(gb[i] & 0xffff0000u)};
-          const float s0 = sigmoidf_(b[0]), s1 = sigmoidf_(b[1]);
-          st2(y + row2 + c, float2_t{acc[i][0] * s0, acc[i][1] * s1});
-          st2(y + row2 + C + c, float2_t{acc[i][0] * a[0] * s0 * (1.f - s0), acc[i][1] * a[1] * s1 * (1.f - s1)});
-        } else {
-          st2(y + ubase + (long)(tg0 + i) * C + c, acc[i]);
-        }
-      }
+  for (int i = 0; i < TGD; ++i) {
+    char* slot = lds + (grp * TGD + i) * ROWB + pr * 4;
+    if constexpr (GLU) {
+      const float2_t a = float2_t{__uint_as_float(ga[i] << 16), __uint_as_float(ga[i] & 0xffff0000u)};
+      const float2_t b = float2_t{__uint_as_float(gb[i] << 16), __uint_as_float(gb[i] & 0xffff0000u)};
+      const float s0 = sigmoidf_(b[0]), s1 = sigmoidf_(b[1]);
+      *reinterpret_cast<uint32_t*>(slot) = pack2_bf16(acc[i][0] * s0, acc[i][1] * s1);
+      *reinterpret_cast<uint32_t*>(slot + 2 * TGD * ROWB) = pack2_bf16(acc[i][0] * a[0] * s0 * (1.f - s0), acc[i][1] * a[1] * s1 * (1.f - s1));
+    } else {
+      *reinterpret_cast<uint32_t*>(slot) = pack2_bf16(acc[i][0], acc[i][1]);
+    }
+  }
+  __syncthreads();
+  constexpr int TOT = (GLU ? 4 : 2) * TGD * (SLAB / 8);
+  static_assert(TOT % 256 == 0, "pieces per thread");
+#pragma unroll
+  for (int q = 0; q < TOT / 256; ++q) {
+    const int id = threadIdx.x + 256 * q;
+    const int lrow = id / (SLAB / 8), ch = (id % (SLAB / 8)) * 8;
+    const int half = GLU ? lrow / (2 * TGD) : 0, row = lrow - half * 2 * TGD;
+    if (t0 + row < Tn && c0 + ch < C) {
+      const long off = GLU ? (ubase + (long)(t0 + row) * C) * 2 + half * C : ubase + (long)(t0 + row) * C;
+      *reinterpret_cast<uint4*>(y + off + c0 + ch) = *reinterpret_cast<const uint4*>(lds + lrow * ROWB + ch * 2);
+    }
   }
 }
 
@@ -341,10 +354,10 @@ int tfasr_dwconv_wgrad_many_try(const void* const* x, const void* const* dy, flo
 extern "C" int tfasr_dwconv_bwd_data_glu(const void* dy, const float* w, const void* glu_x, void* dglu, int B, int T, int C, int K, int dtype,
                                          void* stream_) {
   if (!dy || !w || !glu_x || !dglu || B <= 0 || T <= 0 || C <= 0 || K <= 0) return TFASR_STATUS_INVALID_VALUE;
-  if (dtype != TFASR_BF16 || (C & 7) || K > MAXK || !al16(dy) || !al4(dglu) || !al4(glu_x)) return TFASR_STATUS_UNSUPPORTED;
+  if (dtype != TFASR_BF16 || (C & 7) || K > MAXK || !al16(dy) || !al16(dglu) || !al4(glu_x)) return TFASR_STATUS_UNSUPPORTED;
   const int gx = (C + SLAB - 1) / SLAB;
   dim3 grid(gx, (T + 2 * TGD - 1) / (2 * TGD), B);
-  const int smem = (2 * TGD + MAXK - 1) * ROWB;
+  const int smem = (2 * TGD + MAXK - 1 > 4 * TGD ? 2 * TGD + MAXK - 1 : 4 * TGD) * ROWB;
   TFASR_KLAUNCH((dwconv_tile_kernel<true, true>), grid, dim3(256), smem, (hipStream_t)stream_, (const bf16_t*)dy, w, (const float*)nullptr, (bf16_t*)dglu, T, C, K,
                      (const bf16_t*)glu_x);
   TFASR_CHECK_LAUNCH();
@@ -359,7 +372,7 @@ int tfasr_dwconv_pair_try(int which, const void* x, const void* dy, const float*
   if (which == 0 || which == 1) {
     dim3 grid(gx, (T + 2 * TGD - 1) / (2 * TGD), B);
     const void* in = which == 0 ? x : dy;
-    if (!al16(in) || !al4(y)) return TFASR_STATUS_UNSUPPORTED;
+    if (!al16(in) || !al16(y)) return TFASR_STATUS_UNSUPPORTED;
     if (K <= 8) {
       const int smem = (2 * TGD + 8 - 1) * ROWB;
       if (which == 0)

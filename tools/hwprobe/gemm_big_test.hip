@@ -1,8 +1,11 @@
 // gemm_big (256-row tiles) against gemm_fast (128-row tiles) on the joint-network shapes: bitwise comparison + timing.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=fast -Iinclude tools/hwprobe/gemm_big_test.hip -o tools/hwprobe/gemm_big_test
+#ifndef TFASR_PROBE_PLAIN  // -DTFASR_PROBE_PLAIN: no cycle counters in the kernels (s_memtime turns every counted LDS wait into lgkmcnt(0))
 #define TFASR_GEMM_TIMING 1
+#endif
 #include "../../tensorflowasr_amd/csrc/gemm_fast.hip"
 #include <vector>
+std::atomic<size_t> g_tfasr_launch_count{0};
 #include <stdio.h>
 static uint16_t rnd_bf16(uint64_t i, uint64_t seed) {
   uint64_t x = (i + 1) * 0x9E3779B97F4A7C15ull ^ seed * 0xD1B54A32D192ED03ull;
@@ -26,6 +29,7 @@ static size_t diff(const void* a, const void* b, size_t bytes, const char* what)
   return n;
 }
 static void dump_phases(const char* what) {
+#ifdef TFASR_GEMM_TIMING
   std::vector<long long> h(16384 + 4L * 2 * 2 * 256);
   hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_gemm_timing), h.size() * 8);
   for (int it = 0; it < 2; ++it)
@@ -38,6 +42,7 @@ static void dump_phases(const char* what) {
       for (int b = 0; b < 256; ++b) for (int k = 0; k < 3; ++k) e[k] += h[16384 + 4L * ((b * 2 + it) * 2 + grp) + k];
       printf("      epilogue: setup (next-tile DMA issue, labels, bias) %.0f  statistics %.0f  transposition + stores %.0f\n", e[0] / 256, e[1] / 256, e[2] / 256);
     }
+#endif
 }
 static float timeit(const tfasr_gemm_args& a, int mode) {
   g_gemm_big_mode = mode;
