@@ -51,7 +51,7 @@
 extern "C" {
 #endif
 
-#define TFASR_ABI_VERSION 37
+#define TFASR_ABI_VERSION 38
 
 typedef enum {
   TFASR_STATUS_SUCCESS = 0,
@@ -264,6 +264,10 @@ int tfasr_bn_finalize(const float* stats, float count, const float* gamma, const
 int tfasr_bn_finalize_apply_fwd(const void* x, const float* stats, float count, const float* gamma, const float* beta, float* fin,
                                 float* moving_mean, float* moving_var, float momentum, float eps, void* y, long rows, int C, int act,
                                 int training, int dtype, void* stream);
+/* the same with the statistics spread over `copies` copies [copies][2][C] (summed on the fly) */
+int tfasr_bn_finalize_apply_fwd_copies(const void* x, const float* stats, int copies, float count, const float* gamma, const float* beta, float* fin,
+                                       float* moving_mean, float* moving_var, float momentum, float eps, void* y, long rows, int C, int act,
+                                       int training, int dtype, void* stream);
 int tfasr_bn_apply_fwd(const void* x, const float* fin, void* y, long rows, int C, int act, int dtype, void* stream);
 int tfasr_bn_bwd_stats(const void* x, const void* dy, const float* fin, float* bstats, long rows, int C, int act,
                        int dtype, void* stream);
@@ -293,6 +297,11 @@ int tfasr_glu_bwd(const void* x, const void* dy, void* dx, long rows, int C, int
  * (convolution.py:159-228, conformer.py:305-313) */
 int tfasr_dwconv_fwd(const void* x, const float* w, const float* bias, void* y, int B, int T, int C, int K, int dtype,
                      void* stream);
+/* forward + the statistics tfasr_bn_stats would take of its output, in one launch: stats [ncopy][2][C] f32 is ACCUMULATED into (sum and sum
+ * of squares of the bf16-rounded outputs per channel; workgroup i adds into copy i % ncopy so that same-address atomics do not queue; the
+ * consumer - tfasr_bn_finalize_apply_fwd_copies - adds the copies up).  UNSUPPORTED (f32, C % 8 != 0, K > 32, unaligned): the two calls. */
+int tfasr_dwconv_fwd_stats(const void* x, const float* w, const float* bias, void* y, float* stats, int ncopy, int B, int T, int C, int K,
+                           int dtype, void* stream);
 int tfasr_dwconv_bwd_data(const void* dy, const float* w, void* dx, int B, int T, int C, int K, int dtype, void* stream);
 /* data gradient followed by the backward of the GLU in front of the conv (glu_x = the GLU's input [B*T, 2C], dglu = its gradient) in
  * one launch; TFASR_STATUS_UNSUPPORTED (f32, C % 8 != 0, K > 32): call tfasr_dwconv_bwd_data + tfasr_glu_bwd instead */
@@ -672,6 +681,10 @@ typedef struct {
      the table gradient into dpext_zero itself (e.g. on another stream beside the next block's backward: nothing on the chain waits for it). */
   void* ds_keep;
   void* qv_keep;
+  /* > 1: bn_stats is [bn_stats_copies][2d] (+ 1 float) - the depthwise conv accumulates the BatchNorm statistics itself, its workgroups
+     spreading their atomics over the copies (tfasr_dwconv_fwd_stats), and phase B adds the copies up; a data-parallel caller all-reduces
+     all of them.  0 / 1: the single [2d+1] buffer filled by tfasr_bn_stats. */
+  int bn_stats_copies;
 } tfasr_block_io;
 
 size_t tfasr_block_ctx_bytes(void);

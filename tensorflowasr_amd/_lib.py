@@ -72,7 +72,7 @@ class BlockIO(Structure):
         ("stash", c_void_p), ("stash_bytes", c_size_t), ("scratch", c_void_p), ("scratch_bytes", c_size_t),
         ("prezeroed", c_int), ("dpext_zero", c_void_p), ("wgrad_slot", c_int),
         ("pext_pre", c_void_p), ("defer_pos_grad", c_int), ("ln_part_ext", c_void_p), ("ln_part_ext_floats", c_size_t),
-        ("dcv_keep", c_void_p), ("ds_keep", c_void_p), ("qv_keep", c_void_p),
+        ("dcv_keep", c_void_p), ("ds_keep", c_void_p), ("qv_keep", c_void_p), ("bn_stats_copies", c_int),
     ]
 
 
@@ -152,7 +152,7 @@ def load(build_if_missing=True):
     return lib
 
 
-ABI_VERSION = 37
+ABI_VERSION = 38
 
 
 STATUS_UNSUPPORTED = 3

@@ -71,6 +71,7 @@ class ConformerTransducer(BaseModel):
         self.time_reduction_factor = cfg.time_reduction_factor
         self.step = 0
         self._consts = {}
+        self._bn_stats_copies = 8  # ConvModule BatchNorm statistics inside the depthwise conv, atomics spread over this many copies; 1: the two launches (tests)
         self._conv1_gram = True  # conv1 / BatchNorm0 sums through the patch Gram matrix (one backward pass); False: the two-pass kernels (tests)
         # SpecAugment draws and dropout masks are per replica (MirroredStrategy draws independent randomness on every
         # replica); the parameter initialisation seed above is shared by all ranks
@@ -827,11 +828,13 @@ class ConformerTransducer(BaseModel):
         y = torch.empty(B * T, d, dtype=self.dtype, device=self.device)
         stash = torch.empty(stash_b, dtype=torch.uint8, device=self.device)
         pool = self._zero_pool.get("fwd") if training else None
-        stats = pool[i, :2 * d + 1] if pool is not None else torch.empty(2 * d + 1, dtype=torch.float32, device=self.device)
+        ncp = self._bn_stats_copies if (training and self.dtype == torch.bfloat16) else 1
+        stats = pool[i, :ncp * 2 * d + 1] if pool is not None else torch.empty(ncp * 2 * d + 1, dtype=torch.float32, device=self.device)
         scratch = K.workspace(fscr_b, self.device, "blk_fwd")
         io = K._lib.BlockIO()
         io.x_in, io.x_out, io.lengths = x.data_ptr(), y.data_ptr(), elen_dev.data_ptr()
         io.bn_stats = stats.data_ptr()
+        io.bn_stats_copies = ncp
         io.prezeroed = 1 if pool is not None else 0
         io.stash, io.stash_bytes, io.scratch, io.scratch_bytes = stash.data_ptr(), stash_b, scratch.data_ptr(), scratch.numel()
         pext_all = self._hoisted.get("pext")
@@ -840,7 +843,7 @@ class ConformerTransducer(BaseModel):
         cbuf = K.block_ctx()
         if training and (self.dp.world > 1 or self._dp_force_split) and not cfgk.dw_norm_layer:
             K.block_fwd(cfgk, P, io, cbuf, K._lib.PHASE_A)
-            self.dp.allreduce_stats_(stats[:2 * d])
+            self.dp.allreduce_stats_(stats[:ncp * 2 * d])
             K.block_fwd(cfgk, P, io, cbuf, K._lib.PHASE_B)
         else:
             K.block_fwd(cfgk, P, io, cbuf, K._lib.PHASE_A | K._lib.PHASE_B)
@@ -950,7 +953,7 @@ class ConformerTransducer(BaseModel):
         self._zero_pool = {}
         if native and training:
             c = self.cfg
-            self._zero_pool["fwd"] = torch.zeros(c.num_blocks, -(-(2 * c.dmodel + 1) // 64) * 64, dtype=torch.float32, device=self.device)
+            self._zero_pool["fwd"] = torch.zeros(c.num_blocks, -(-(self._bn_stats_copies * 2 * c.dmodel + 1) // 64) * 64, dtype=torch.float32, device=self.device)
             if ctx is not None:
                 self._zero_pool["bwd_shape"] = (c.num_blocks, -(-2 * c.dmodel // 64) * 64 + -(-2 * T * c.num_heads * self.ps.head_phys // 64) * 64)
         for i in range(self.cfg.num_blocks):

@@ -14,6 +14,7 @@
 
 extern int g_tfasr_group_beside;  // gemm_fast.hip: 1 around a grouped launch that shares the chip with another stream's chain
 
+bool tfasr_bn_rows_kernel_ok(int C);  // norm.hip
 namespace {
 
 struct Arena {
@@ -540,14 +541,26 @@ struct Ex {
     dense(k->cv_ln, TFASR_BP_CV_PW1_W, TFASR_BP_CV_PW1_B, k->cv_a, d, 2 * d);
     if (!dry) {
       chk(tfasr_glu_fwd(k->cv_a, k->cv_g, rows, d, c->dtype, s));
-      chk(tfasr_dwconv_fwd(k->cv_g, fp(TFASR_BP_CV_DW_W), fp(TFASR_BP_CV_DW_B), k->cv_cv, c->B, c->T, d, c->ksize, c->dtype, s));
+      // BatchNorm statistics inside the conv kernel when the caller gave the statistics buffer several copies (io->bn_stats_copies: the
+      // workgroups spread their atomics over them; with ONE copy 384 workgroups adding into the same 512 addresses were a serial chain of
+      // ~30 ns links - 27.8 us against 15.8 + 11.2 us for the two launches - so a single copy keeps the two launches)
+      const int ncp = bn_copies();
+      int fused = TFASR_STATUS_UNSUPPORTED;
       if (c->training && !c->dw_norm_layer) {
-        // (measured and dropped: the statistics inside the conv kernel - 384 workgroups adding into the same 512 addresses are a serial
-        // chain of ~30 ns links, 27.8 us against 15.8 + 11.2 us for the two launches)
-        if (!(io->prezeroed & 1)) zero(io->bn_stats, (size_t)(2 * d + 1) * 4);
-        chk(tfasr_bn_stats(k->cv_cv, io->bn_stats, rows, d, c->dtype, s));
+        if (!(io->prezeroed & 1)) zero(io->bn_stats, ((size_t)(io->bn_stats_copies > 1 ? io->bn_stats_copies : 1) * 2 * d + 1) * 4);
+        if (ncp > 1) fused = tfasr_dwconv_fwd_stats(k->cv_g, fp(TFASR_BP_CV_DW_W), fp(TFASR_BP_CV_DW_B), k->cv_cv, io->bn_stats, ncp, c->B, c->T, d, c->ksize, c->dtype, s);
+        if (fused != TFASR_STATUS_UNSUPPORTED) chk(fused);
+      }
+      if (fused == TFASR_STATUS_UNSUPPORTED) {
+        chk(tfasr_dwconv_fwd(k->cv_g, fp(TFASR_BP_CV_DW_W), fp(TFASR_BP_CV_DW_B), k->cv_cv, c->B, c->T, d, c->ksize, c->dtype, s));
+        if (c->training && !c->dw_norm_layer) chk(tfasr_bn_stats(k->cv_cv, io->bn_stats, rows, d, c->dtype, s));  // (into copy 0; the others stay zero)
       }
     }
+  }
+  // copies of the BatchNorm statistics in use: the caller's, when the finalize + apply row kernel (the only reader that adds copies up) takes
+  // the channel count and the conv kernel the dtype; else 1 (everything goes through copy 0, the other copies stay zero)
+  int bn_copies() const {
+    return (io->bn_stats_copies > 1 && c->dtype == TFASR_BF16 && tfasr_bn_rows_kernel_ok(c->d)) ? io->bn_stats_copies : 1;
   }
   void conv_fwd_b(void* y, int site) {
     const int d = c->d;
@@ -557,7 +570,8 @@ struct Ex {
     } else if (!dry) {
       // statistics -> coefficients (+ moving statistics) -> normalise + swish in one launch; UNSUPPORTED (channel counts outside the row
       // kernel) -> the two launches
-      const int fst = tfasr_bn_finalize_apply_fwd(k->cv_cv, c->training ? io->bn_stats : nullptr, c->training ? (float)(rows * c->world) : 1.f,
+      const int ncp = bn_copies();
+      const int fst = tfasr_bn_finalize_apply_fwd_copies(k->cv_cv, c->training ? io->bn_stats : nullptr, ncp, c->training ? (float)(rows * c->world) : 1.f,
                                                   fp(TFASR_BP_CV_BN_G), fp(TFASR_BP_CV_BN_B), k->cv_fin, P->bn_mm, P->bn_mv, c->bn_momentum, c->bn_eps,
                                                   k->cv_sw, rows, d, TFASR_ACT_SWISH, c->training ? 1 : 0, c->dtype, s);
       if (fst == TFASR_STATUS_UNSUPPORTED) {

@@ -88,10 +88,16 @@ __device__ __forceinline__ void dw_all(float2_t (&acc)[TT], const float2_t (&wk)
 // [rows, 2C] (a | b halves), y = its gradient [rows, 2C]: da = dx sigma(b), db = dx a sigma(b) (1 - sigma(b)); dx itself is not stored.
 // KB = compile-time bound on the kernel size (taps k >= K are zero weights): 32 covers the Conformer's 31/32, 8 the ContextNet's 5
 // (with KB = 32 a 5-tap conv would spend 6x its useful FMAs on zeros and turn this HBM-bound op compute-bound).
-template <bool REV, bool GLU = false, int KB = MAXK>
+// STATS (forward only): the BatchNorm statistics of the layer behind the conv in the same pass - per channel the sum and the sum of squares
+// of the bf16-ROUNDED outputs (what tfasr_bn_stats would read back), added into stats[copy][2][C] with copy = block index % ncopy: with one
+// copy the 600-odd workgroups of a launch queue on the same 512 addresses (a serial chain of ~30 ns links: 27.8 us against 15.8 + 11.2 us
+// for the two launches, round 5); spread over 8 copies the chain is 2 us long and hides under the launch.  The consumer adds the copies up.
+template <bool REV, bool GLU = false, int KB = MAXK, bool STATS = false>
 __global__ __launch_bounds__(256) void dwconv_tile_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w,
                                                           const float* __restrict__ bias, bf16_t* __restrict__ y, int Tn, int C, int K,
-                                                          const bf16_t* __restrict__ gx = nullptr) {
+                                                          const bf16_t* __restrict__ gx = nullptr, float* __restrict__ stats = nullptr,
+                                                          int ncopy = 1) {
+  static_assert(!STATS || (!REV && !GLU), "statistics ride on the forward kernel");
   extern __shared__ __attribute__((aligned(16))) char lds[];  // (2*TGD + KB - 1) rows; rows past K-1+2*TGD stay zero-weighted
   const int c0 = blockIdx.x * SLAB;
   const int t0 = blockIdx.y * (2 * TGD);
@@ -133,6 +139,7 @@ __global__ __launch_bounds__(256) void dwconv_tile_kernel(const bf16_t* __restri
   // 2 * TGD / 8 store instructions per lane instead of TGD four-byte ones (the output is half of the launch's bytes or more).
   // GLU: rows 0 .. 2 TGD - 1 hold da, rows 2 TGD .. 4 TGD - 1 hold db (the launcher sizes the LDS for max(staging, 4 TGD) rows)
   __syncthreads();  // every lane is done reading the staged input
+  [[maybe_unused]] float2_t ssum = float2_t{0.f, 0.f}, ssq = float2_t{0.f, 0.f};
 #pragma unroll
   for (int i = 0; i < TGD; ++i) {
     char* slot = lds + (grp * TGD + i) * ROWB + pr * 4;
@@ -143,10 +150,29 @@ __global__ __launch_bounds__(256) void dwconv_tile_kernel(const bf16_t* __restri
       *reinterpret_cast<uint32_t*>(slot) = pack2_bf16(acc[i][0] * s0, acc[i][1] * s1);
       *reinterpret_cast<uint32_t*>(slot + 2 * TGD * ROWB) = pack2_bf16(acc[i][0] * a[0] * s0 * (1.f - s0), acc[i][1] * a[1] * s1 * (1.f - s1));
     } else {
-      *reinterpret_cast<uint32_t*>(slot) = pack2_bf16(acc[i][0], acc[i][1]);
+      const uint32_t pk = pack2_bf16(acc[i][0], acc[i][1]);
+      *reinterpret_cast<uint32_t*>(slot) = pk;
+      if constexpr (STATS) {
+        if (t0 + grp * TGD + i < Tn) {
+          const float2_t v = float2_t{__uint_as_float(pk << 16), __uint_as_float(pk & 0xffff0000u)};
+          ssum += v;
+          ssq = fma2(v, v, ssq);
+        }
+      }
     }
   }
+  if constexpr (STATS) {  // the second thread group parks its sums in a dead staging row behind the output rows
+    if (grp == 1) *reinterpret_cast<float4*>(lds + 2 * TGD * ROWB + pr * 16) = make_float4(ssum[0], ssum[1], ssq[0], ssq[1]);
+  }
   __syncthreads();
+  if constexpr (STATS) {
+    if (grp == 0 && live) {
+      const float4 o = *reinterpret_cast<const float4*>(lds + 2 * TGD * ROWB + pr * 16);
+      float* st = stats + (size_t)((blockIdx.y + blockIdx.z) % ncopy) * 2 * C;
+      atomicAdd(st + c, ssum[0] + o.x); atomicAdd(st + c + 1, ssum[1] + o.y);
+      atomicAdd(st + C + c, ssq[0] + o.z); atomicAdd(st + C + c + 1, ssq[1] + o.w);
+    }
+  }
   constexpr int TOT = (GLU ? 4 : 2) * TGD * (SLAB / 8);
   static_assert(TOT % 256 == 0, "pieces per thread");
 #pragma unroll
@@ -360,6 +386,24 @@ extern "C" int tfasr_dwconv_bwd_data_glu(const void* dy, const float* w, const v
   const int smem = (2 * TGD + MAXK - 1 > 4 * TGD ? 2 * TGD + MAXK - 1 : 4 * TGD) * ROWB;
   TFASR_KLAUNCH((dwconv_tile_kernel<true, true>), grid, dim3(256), smem, (hipStream_t)stream_, (const bf16_t*)dy, w, (const float*)nullptr, (bf16_t*)dglu, T, C, K,
                      (const bf16_t*)glu_x);
+  TFASR_CHECK_LAUNCH();
+  return TFASR_STATUS_SUCCESS;
+}
+
+// forward + BatchNorm statistics (stats [ncopy][2][C], accumulated); UNSUPPORTED -> the caller runs tfasr_dwconv_fwd and tfasr_bn_stats
+extern "C" int tfasr_dwconv_fwd_stats(const void* x, const float* w, const float* bias, void* y, float* stats, int ncopy, int B, int T, int C, int K,
+                                      int dtype, void* stream_) {
+  if (!x || !w || !y || !stats || ncopy <= 0 || B <= 0 || T <= 0 || C <= 0 || K <= 0) return TFASR_STATUS_INVALID_VALUE;
+  if (dtype != TFASR_BF16 || (C & 7) || K > MAXK || !al16(x) || !al16(y)) return TFASR_STATUS_UNSUPPORTED;
+  static_assert(128 * 16 <= (8 - 1) * ROWB, "the parked sums (16 bytes per channel-pair lane) fit in the staging rows behind the output rows");
+  dim3 grid((C + SLAB - 1) / SLAB, (T + 2 * TGD - 1) / (2 * TGD), B);
+  hipStream_t s = (hipStream_t)stream_;
+  if (K <= 8)
+    TFASR_KLAUNCH((dwconv_tile_kernel<false, false, 8, true>), grid, dim3(256), (2 * TGD + 8 - 1) * ROWB, s, (const bf16_t*)x, w, bias, (bf16_t*)y, T, C, K,
+                  (const bf16_t*)nullptr, stats, ncopy);
+  else
+    TFASR_KLAUNCH((dwconv_tile_kernel<false, false, MAXK, true>), grid, dim3(256), (2 * TGD + MAXK - 1) * ROWB, s, (const bf16_t*)x, w, bias, (bf16_t*)y, T, C, K,
+                  (const bf16_t*)nullptr, stats, ncopy);
   TFASR_CHECK_LAUNCH();
   return TFASR_STATUS_SUCCESS;
 }

@@ -244,7 +244,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void bn_finalize_apply_fwd_rows_kernel(const T* __restrict__ x, const float* __restrict__ stats, float count,
                                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                          float* __restrict__ fin, float* moving_mean, float* moving_var, float momentum,
-                                                                         float eps, T* __restrict__ y, long rows, int C, int act, int training) {
+                                                                         float eps, T* __restrict__ y, long rows, int C, int act, int training, int copies) {
   const int lpr = C >> 3, li = threadIdx.x % lpr, sub = threadIdx.x / lpr, rpb = 256 / lpr;
   const int c = li * 8;
   float sc[8], sh[8];
@@ -255,6 +255,12 @@ __global__ __launch_bounds__(256) void bn_finalize_apply_fwd_rows_kernel(const T
     if (training) {
       float s0[8], s1[8];
       ld8(stats + c, s0); ld8(stats + C + c, s1);
+      for (int q = 1; q < copies; ++q) {  // statistics spread over copies [copies][2][C] by their producer (tfasr_dwconv_fwd_stats)
+        float t0[8], t1[8];
+        ld8(stats + (size_t)q * 2 * C + c, t0); ld8(stats + (size_t)q * 2 * C + C + c, t1);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { s0[k] += t0[k]; s1[k] += t1[k]; }
+      }
       if (writer && moving_mean) { ld8(moving_mean + c, mm); ld8(moving_var + c, mv); }
 #pragma unroll
       for (int k = 0; k < 8; ++k) { mean[k] = s0[k] / count; var[k] = fmaxf(s1[k] / count - mean[k] * mean[k], 0.f); }
@@ -802,10 +808,13 @@ extern "C" int tfasr_bn_apply_fwd(const void* x, const float* fin, void* y, long
   return TFASR_STATUS_SUCCESS;
 }
 
-extern "C" int tfasr_bn_finalize_apply_fwd(const void* x, const float* stats, float count, const float* gamma, const float* beta, float* fin,
+// (block.hip: whether tfasr_bn_finalize_apply_fwd_copies will take the channel count - it decides before it spreads statistics over copies)
+bool tfasr_bn_rows_kernel_ok(int C) { return (C % 8) == 0 && rows_variant_ok(C); }
+
+extern "C" int tfasr_bn_finalize_apply_fwd_copies(const void* x, const float* stats, int copies, float count, const float* gamma, const float* beta, float* fin,
                                            float* moving_mean, float* moving_var, float momentum, float eps, void* y, long rows, int C, int act,
                                            int training, int dtype, void* stream_) {
-  if (!x || !gamma || !beta || !fin || !y || rows <= 0 || C <= 0) return TFASR_STATUS_INVALID_VALUE;
+  if (!x || !gamma || !beta || !fin || !y || rows <= 0 || C <= 0 || copies <= 0) return TFASR_STATUS_INVALID_VALUE;
   if (training && !stats) return TFASR_STATUS_INVALID_VALUE;
   if (!training && (!moving_mean || !moving_var)) return TFASR_STATUS_INVALID_VALUE;
   if ((C % 8) != 0 || !rows_variant_ok(C) || (dtype != TFASR_F32 && dtype != TFASR_BF16)) return TFASR_STATUS_UNSUPPORTED;
@@ -813,12 +822,18 @@ extern "C" int tfasr_bn_finalize_apply_fwd(const void* x, const float* stats, fl
   const int grid = rows_variant_grid(rows, C);
   if (dtype == TFASR_F32)
     TFASR_KLAUNCH(bn_finalize_apply_fwd_rows_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, stats, count, gamma, beta, fin, moving_mean,
-                       moving_var, momentum, eps, (float*)y, rows, C, act, training);
+                       moving_var, momentum, eps, (float*)y, rows, C, act, training, copies);
   else
     TFASR_KLAUNCH(bn_finalize_apply_fwd_rows_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)x, stats, count, gamma, beta, fin, moving_mean,
-                       moving_var, momentum, eps, (bf16_t*)y, rows, C, act, training);
+                       moving_var, momentum, eps, (bf16_t*)y, rows, C, act, training, copies);
   TFASR_CHECK_LAUNCH();
   return TFASR_STATUS_SUCCESS;
+}
+
+extern "C" int tfasr_bn_finalize_apply_fwd(const void* x, const float* stats, float count, const float* gamma, const float* beta, float* fin,
+                                           float* moving_mean, float* moving_var, float momentum, float eps, void* y, long rows, int C, int act,
+                                           int training, int dtype, void* stream_) {
+  return tfasr_bn_finalize_apply_fwd_copies(x, stats, 1, count, gamma, beta, fin, moving_mean, moving_var, momentum, eps, y, rows, C, act, training, dtype, stream_);
 }
 
 extern "C" int tfasr_bn_bwd_stats(const void* x, const void* dy, const float* fin, float* bstats, long rows, int C,

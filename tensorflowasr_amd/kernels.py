@@ -307,14 +307,16 @@ def bn_finalize(stats, count, gamma, beta, fin, moving_mean, moving_var, momentu
     check(_L().tfasr_bn_finalize(_p(stats), float(count), _p(gamma), _p(beta), _p(fin), _p(moving_mean), _p(moving_var), momentum, eps, C, int(training), _stream()), "bn_finalize")
 
 
-def bn_finalize_apply_fwd(x, stats, count, gamma, beta, fin, moving_mean, moving_var, act=ACT_NONE, y=None, momentum=0.99, eps=1e-3, training=True):
+def bn_finalize_apply_fwd(x, stats, count, gamma, beta, fin, moving_mean, moving_var, act=ACT_NONE, y=None, momentum=0.99, eps=1e-3, training=True,
+                          copies=1):
     """tfasr_bn_finalize + tfasr_bn_apply_fwd in one launch (fin and the moving statistics written as bn_finalize would); returns y, or None
-    when the channel count is outside the row kernel's range (the caller runs the two launches)."""
+    when the channel count is outside the row kernel's range (the caller runs the two launches).  copies > 1: stats is [copies, 2C] (the
+    layout dwconv_fwd_stats accumulates into), summed on the fly."""
     rows, C = x.numel() // x.shape[-1], x.shape[-1]
     if y is None:
         y = torch.empty_like(x)
-    st = _L().tfasr_bn_finalize_apply_fwd(_p(x), _p(stats), float(count), _p(gamma), _p(beta), _p(fin), _p(moving_mean), _p(moving_var), momentum, eps,
-                                          _p(y), rows, C, act, int(training), _dt(x), _stream())
+    st = _L().tfasr_bn_finalize_apply_fwd_copies(_p(x), _p(stats), int(copies), float(count), _p(gamma), _p(beta), _p(fin), _p(moving_mean), _p(moving_var),
+                                                 momentum, eps, _p(y), rows, C, act, int(training), _dt(x), _stream())
     if st == _lib.STATUS_UNSUPPORTED:
         return None
     check(st, "bn_finalize_apply_fwd")
@@ -394,6 +396,19 @@ def dwconv_fwd(x, w, bias):
     B, T, C = x.shape
     y = torch.empty_like(x)
     check(_L().tfasr_dwconv_fwd(_p(x), _p(w), _p(bias), _p(y), B, T, C, w.shape[0], _dt(x), _stream()), "dwconv_fwd")
+    return y
+
+
+def dwconv_fwd_stats(x, w, bias, stats):
+    """Depthwise conv + the BatchNorm statistics of its output in one launch: stats [copies, 2C] f32 is accumulated into (sum | sum of
+    squares of the bf16-rounded outputs per channel, spread over the copies).  Returns y, or None when the fused kernel does not take the
+    shape / dtype (the caller runs dwconv_fwd + bn_stats)."""
+    B, T, C = x.shape
+    y = torch.empty_like(x)
+    st = _L().tfasr_dwconv_fwd_stats(_p(x), _p(w), _p(bias), _p(y), _p(stats), int(stats.numel() // (2 * C)), B, T, C, w.shape[0], _dt(x), _stream())
+    if st == _lib.STATUS_UNSUPPORTED:
+        return None
+    check(st, "dwconv_fwd_stats")
     return y
 
 

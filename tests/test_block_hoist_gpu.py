@@ -133,6 +133,22 @@ def test_side_stream_weight_gradients_and_deferred_launches_same_gradients(dev, 
         np.testing.assert_allclose(res[name][1].cpu().numpy(), res["inline"][1].cpu().numpy(), rtol=0, atol=2e-3 * gmax, err_msg=name)
 
 
+def test_batchnorm_statistics_inside_the_depthwise_conv_same_step(dev):
+    """ConvModule BatchNorm statistics accumulated by the depthwise conv kernel over 8 copies (`_bn_stats_copies`, default) against the
+    separate tfasr_bn_stats launch (1): same sums in another order - costs and gradients agree to the f32-atomics tolerance, and so do the
+    moving statistics the forward updates (conformer.py:305-333)."""
+    cfg, ocfg, model, W, data, sig, labels, preds = _setup(dev, torch.bfloat16, [4000, 2500, 3100], [6, 3, 5])
+    res, mov = {}, {}
+    for cp in (1, 8):
+        model._bn_stats_copies = cp
+        snap = {k: v.clone() for k, v in model.ps.state.items()} if hasattr(model.ps, "state") else None
+        res[cp] = _grads_after_two_steps(model, data)
+        mov[cp] = snap
+    gmax = float(res[1][1].abs().max())
+    np.testing.assert_allclose(res[8][0], res[1][0], rtol=2e-3)
+    np.testing.assert_allclose(res[8][1].cpu().numpy(), res[1][1].cpu().numpy(), rtol=0, atol=4e-3 * gmax)
+
+
 def test_front_end_on_the_prediction_stream_same_step(dev):
     """`prefetched_inputs` (what bench.py sets: log-mel + SpecAugment on the prediction network's stream ahead of the previous
     step's tail) against the in-line front end, over two consecutive steps with an optimizer update in between (the second step's front end

@@ -233,6 +233,41 @@ def test_dwconv_kernel_sizes(dev, Kk, C, T):
     cmp(db, dy.sum((0, 1)), rtol=1e-3, atol=1e-3)
 
 
+@pytest.mark.parametrize("Kk,C,T,copies", [(32, 256, 157, 8), (31, 144, 53, 4), (5, 640, 150, 8), (32, 256, 33, 1)])
+def test_dwconv_forward_with_batchnorm_statistics(dev, Kk, C, T, copies):
+    """tfasr_dwconv_fwd_stats: the conv output is bitwise the plain forward's, the copies of the statistics add up to what tfasr_bn_stats
+    takes of that output (f32 sums in another order), and the finalize + apply launch reading the copies gives the coefficients / output of
+    the single-buffer route (ConvModule BatchNorm, conformer.py:305-333)."""
+    g = torch.Generator().manual_seed(300 + Kk + T)
+    B = 5
+    x = (torch.randn(B, T, C, generator=g) * 1.5 + 0.3).to(dev).to(torch.bfloat16)
+    w, b = (torch.randn(Kk, C, generator=g) * 0.3).to(dev), (torch.randn(C, generator=g) * 0.1).to(dev)
+    y0 = K.dwconv_fwd(x, w, b)
+    st0 = torch.zeros(2 * C, device=dev)
+    K.bn_stats(y0.view(B * T, C), st0)
+    st = torch.zeros(copies, 2 * C, device=dev)
+    y1 = K.dwconv_fwd_stats(x, w, b, st)
+    assert y1 is not None
+    assert torch.equal(y0, y1)
+    assert copies == 1 or int((st.abs().sum(1) > 0).sum()) > 1  # the workgroups really spread over the copies
+    ref = y0.view(B * T, C).float()
+    cmp(st.sum(0)[:C], ref.sum(0), rtol=1e-4, atol=1e-2)
+    cmp(st.sum(0)[C:], (ref * ref).sum(0), rtol=1e-4, atol=1e-2)
+    cmp(st.sum(0), st0, rtol=1e-4, atol=1e-2)
+    gm, bt = (torch.rand(C, generator=g) + 0.5).to(dev), (torch.randn(C, generator=g) * 0.1).to(dev)
+    outs = []
+    for stats, cp in ((st0, 1), (st, copies)):
+        fin, mm, mv = torch.zeros(4 * C, device=dev), torch.zeros(C, device=dev), torch.ones(C, device=dev)
+        o = K.bn_finalize_apply_fwd(y0.view(B * T, C), stats, float(B * T), gm, bt, fin, mm, mv, act=K.ACT_SWISH, copies=cp)
+        if o is None:
+            return  # channel count outside the row kernel (block.hip then keeps everything in copy 0)
+        outs.append((o.float(), fin, mm, mv))
+    cmp(outs[1][1], outs[0][1], rtol=1e-4, atol=1e-4)
+    cmp(outs[1][2], outs[0][2], rtol=1e-4, atol=1e-5)
+    cmp(outs[1][3], outs[0][3], rtol=1e-4, atol=1e-5)
+    cmp(outs[1][0], outs[0][0], rtol=2e-2, atol=2e-2)
+
+
 @pytest.mark.parametrize("dtype", DT)
 def test_bias2_embedding_colsum_cast(dev, dtype):
     g = torch.Generator().manual_seed(2)
