@@ -189,6 +189,13 @@ typedef struct {
      (tfasr_rnnt_loss_packed_coef: c.x = lse * log2(e), c.y = -(g_blank + g_label) * scale, c.z = g_blank * scale, c.w = g_label * scale).
      Only the 256-row bf16 kernel (plain NN product + bias) implements both: otherwise UNSUPPORTED. */
   const float* rgrad_coef;
+  /* Optional BatchNorm backward statistics of the OUTPUT (bf16 fast path, plain NT product D = alpha A B^T, 64-column tiles, N % 8 == 0;
+     anything else: UNSUPPORTED and nothing is launched): the product is the gradient w.r.t. swish(BatchNorm(x)) (ConvModule,
+     conformer.py:305-333) and the epilogue adds what tfasr_bn_bwd_stats would take of it in a second pass - per channel c
+     sum dz and sum dz * xhat with dz = D * swish'(x * fin[2N + c] + fin[3N + c]), xhat = (x - fin[c]) * fin[N + c] - into
+     bns_out[copy][2][N] (workgroup i adds into copy i % bns_copies; the consumer adds the copies up).  bns_x = the BatchNorm input
+     [M, N] (compute dtype, row stride ldd). */
+  const void* bns_x; const float* bns_fin; float* bns_out; int bns_copies;
 } tfasr_gemm_args;
 
 int tfasr_gemm(const tfasr_gemm_args* args, void* stream);
@@ -275,6 +282,9 @@ int tfasr_bn_bwd_stats(const void* x, const void* dy, const float* fin, float* b
  * (either may be NULL) */
 int tfasr_bn_apply_bwd_grads(const void* x, const void* dy, const float* fin, const float* bstats, float count, void* dx, long rows,
                             int C, int act, float* dgamma, float* dbeta, float grad_scale, int dtype, void* stream);
+/* the same with the sums spread over `copies` copies [copies][2][C] (added up on the fly; row-kernel channel counts only, else UNSUPPORTED) */
+int tfasr_bn_apply_bwd_grads_copies(const void* x, const void* dy, const float* fin, const float* bstats, int copies, float count, void* dx,
+                                    long rows, int C, int act, float* dgamma, float* dbeta, float grad_scale, int dtype, void* stream);
 int tfasr_bn_apply_bwd(const void* x, const void* dy, const float* fin, const float* bstats, float count, void* dx,
                        long rows, int C, int act, int dtype, void* stream);
 
@@ -683,7 +693,8 @@ typedef struct {
   void* qv_keep;
   /* > 1: bn_stats is [bn_stats_copies][2d] (+ 1 float) - the depthwise conv accumulates the BatchNorm statistics itself, its workgroups
      spreading their atomics over the copies (tfasr_dwconv_fwd_stats), and phase B adds the copies up; a data-parallel caller all-reduces
-     all of them.  0 / 1: the single [2d+1] buffer filled by tfasr_bn_stats. */
+     all of them.  Likewise bn_bstats [bn_stats_copies][2d]: filled by the epilogue of the pointwise conv's data gradient
+     (tfasr_gemm_args.bns_out).  0 / 1: the single [2d+1] / [2d] buffers filled by tfasr_bn_stats / tfasr_bn_bwd_stats. */
   int bn_stats_copies;
 } tfasr_block_io;
 

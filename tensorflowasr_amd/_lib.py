@@ -34,6 +34,7 @@ class GemmArgs(Structure):
         ("lse_part", c_void_p), ("lse_parts", c_int), ("row_label", c_void_p), ("pick", c_void_p),
         ("seg_a_off", c_void_p), ("seg_b_off", c_void_p), ("seg_k", c_int),
         ("rgrad_coef", c_void_p),
+        ("bns_x", c_void_p), ("bns_fin", c_void_p), ("bns_out", c_void_p), ("bns_copies", c_int),
     ]
 
 

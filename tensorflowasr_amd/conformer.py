@@ -859,13 +859,14 @@ class ConformerTransducer(BaseModel):
         dx = torch.empty(cfgk.B * cfgk.T, d, dtype=self.dtype, device=self.device)
         pool = self._zero_pool.get("bwd")
         n_dpext = 2 * cfgk.T * cfgk.H * cfgk.dh
-        off = -(-2 * d // 64) * 64
+        ncp = max(int(io.bn_stats_copies), 1)  # (the forward's choice: both statistics buffers of a block have that many copies)
+        off = self._bwd_pool_off()
         if pool is not None and pool.shape[1] >= off + n_dpext:
-            bstats = pool[i, :2 * d]
+            bstats = pool[i, :ncp * 2 * d]
             io.prezeroed |= 2
             io.dpext_zero = pool[i, off:off + n_dpext].data_ptr()
         else:
-            bstats = torch.empty(2 * d, dtype=torch.float32, device=self.device)
+            bstats = torch.empty(ncp * 2 * d, dtype=torch.float32, device=self.device)
             io.prezeroed &= ~2
             io.dpext_zero = None
         io.defer_pos_grad, io.ln_part_ext, io.ln_part_ext_floats, io.dcv_keep, io.ds_keep, io.qv_keep = 0, None, 0, None, None, None
@@ -955,7 +956,7 @@ class ConformerTransducer(BaseModel):
             c = self.cfg
             self._zero_pool["fwd"] = torch.zeros(c.num_blocks, -(-(self._bn_stats_copies * 2 * c.dmodel + 1) // 64) * 64, dtype=torch.float32, device=self.device)
             if ctx is not None:
-                self._zero_pool["bwd_shape"] = (c.num_blocks, -(-2 * c.dmodel // 64) * 64 + -(-2 * T * c.num_heads * self.ps.head_phys // 64) * 64)
+                self._zero_pool["bwd_shape"] = (c.num_blocks, self._bwd_pool_off() + -(-2 * T * c.num_heads * self.ps.head_phys // 64) * 64)
         for i in range(self.cfg.num_blocks):
             x = self._block_fwd_native(x, i, B, T, elen_dev, training, ctx) if native else self._block_fwd(x, i, B, T, elen_dev, training, ctx)
             self._side_tick()  # (a slice of the prediction network on its own stream, if one is pending)
@@ -1048,6 +1049,10 @@ class ConformerTransducer(BaseModel):
             torch.cuda.current_stream().wait_stream(self.aux_stream)
             self._defer_keep = None
 
+    def _bwd_pool_off(self):
+        """floats in front of a block's table-gradient accumulator in the zeroed backward pool: its BatchNorm backward sums, all copies"""
+        return -(-self._bn_stats_copies * 2 * self.cfg.dmodel // 64) * 64
+
     def _deferred_block_grads(self, hb, T):
         """What the blocks left to the caller (tfasr_block_io.defer_pos_grad / ln_part_ext): gWpos_i += pe^T dpext_i and gbpos_i +=
         colsum(dpext_i) for every block - one cast + column-sum launch over all the f32 tables, the products in grouped launches - and one
@@ -1056,7 +1061,7 @@ class ConformerTransducer(BaseModel):
         d, HD, R1 = c.dmodel, c.num_heads * ps.head_phys, 2 * T
         if hb["pos"]:
             pool = self._zero_pool["bwd"]
-            off = -(-2 * d // 64) * 64
+            off = self._bwd_pool_off()
             # ONE launch: bf16 copies of every block's f32 table gradient (the weight-gradient operands) + the bias gradients from the f32 values
             pool_t = torch.empty(pool.shape, dtype=self.dtype, device=self.device)
             nb = pool.shape[0]

@@ -68,6 +68,7 @@ struct G {
   const float* bias = nullptr; const void* res = nullptr; const void* dact_z = nullptr; void* prez = nullptr;
   float alpha = 1.f, beta = 1.f; int act = 0, dact = 0, out_f32 = 0, accumulate = 0, split_k = 1; float drop_p = 0.f; long drop_seed = 0;
   float* colsum = nullptr;
+  const void* bns_x = nullptr; const float* bns_fin = nullptr; float* bns_out = nullptr; int bns_copies = 0;  // tfasr_gemm_args.bns_*
   int side = 0;  // 1 = a weight gradient: collected into the block's grouped launch when the executor defers them
   int nb1 = 1, nb2 = 1; long sA1 = 0, sA2 = 0, sB1 = 0, sB2 = 0, sD1 = 0, sD2 = 0;
 };
@@ -166,9 +167,17 @@ struct Ex {
     a.accumulate = g.accumulate; a.split_k = g.split_k; a.drop_p = g.drop_p; a.drop_seed = g.drop_seed;
     a.ws = ws; a.ws_elems = ws ? ws_elems : 0;
     a.colsum = g.colsum;
+    a.bns_x = g.bns_x; a.bns_fin = g.bns_fin; a.bns_out = g.bns_out; a.bns_copies = g.bns_copies;
     if (defer && g.side && !ws) { pending.push_back(a); return; }
-    chk(tfasr_gemm(&a, s));
+    int st = tfasr_gemm(&a, s);
+    if (st == TFASR_STATUS_UNSUPPORTED && a.bns_out) {  // the statistics epilogue does not take this product: plain product, the caller's second pass
+      a.bns_x = nullptr; a.bns_fin = nullptr; a.bns_out = nullptr; a.bns_copies = 0;
+      st = tfasr_gemm(&a, s);
+      bns_done = false;
+    }
+    chk(st);
   }
+  bool bns_done = false;  // set by the caller before a product with bns_out, cleared when the epilogue was not available
   void probe_mark(hipStream_t st_) {
     if (!side || !side->probe) return;
     if (side->pused == side->pev.size()) {
@@ -221,7 +230,8 @@ struct Ex {
   }
   // gW += alpha x^T dy ; gb += alpha colsum(dy) ; dx = alpha (dy @ W^T) [* act'(z)] [* dropmask]
   void dense_bwd(const void* dy, const void* x, int wi, int bi, int din, int dout, void* dx, float alpha = 1.f, const void* dact_z = nullptr,
-                 int dact = 0, float dp = 0.f, long dseed = 0) {
+                 int dact = 0, float dp = 0.f, long dseed = 0, const void* bns_x = nullptr, const float* bns_fin = nullptr, float* bns_out = nullptr,
+                 int bns_copies = 0) {
     G w; w.A = x; w.lda = din; w.ta = 1; w.B = dy; w.ldb = dout; w.tb = 0; w.D = gp(wi); w.ldd = dout; w.M = din; w.N = dout; w.K = (int)rows;
     w.alpha = alpha; w.out_f32 = 1; w.accumulate = 1; w.split_k = split_k(din, dout, rows);
     w.colsum = gp(bi);  // bias gradient in the same launch
@@ -230,6 +240,7 @@ struct Ex {
     if (!dx) return;
     G d; d.A = dy; d.lda = dout; d.ta = 0; d.B = wp(wi); d.ldb = dout; d.tb = 1; d.D = dx; d.ldd = din; d.M = (int)rows; d.N = din; d.K = dout;
     d.alpha = alpha; d.dact_z = dact_z; d.dact = dact; d.drop_p = dp; d.drop_seed = dseed;
+    d.bns_x = bns_x; d.bns_fin = bns_fin; d.bns_out = bns_out; d.bns_copies = bns_copies;
     gemm(d);
   }
   const void* mask_grad(const void* dy, long elems, int site) {
@@ -593,9 +604,15 @@ struct Ex {
     const int d = c->d;
     const void* dyd = masked(dy, dy_dropped, rows * d, site);
     void* dsw = act(scratch, rows * d);
-    dense_bwd(dyd, k->cv_sw, TFASR_BP_CV_PW2_W, TFASR_BP_CV_PW2_B, d, d, dsw, c->conv_res);
-    if (!c->dw_norm_layer) {
-      if (!(io->prezeroed & 2)) zero(io->bn_bstats, (size_t)2 * d * 4);
+    // BatchNorm backward sums (sum dz, sum dz xhat) in the epilogue of the pointwise conv's data gradient when the caller gave the buffer
+    // several copies (the second pass over x and dsw - tfasr_bn_bwd_stats, 20 us - otherwise)
+    const int ncp = bn_copies();
+    const bool fuse = !c->dw_norm_layer && ncp > 1;
+    if (!c->dw_norm_layer && !(io->prezeroed & 2)) zero(io->bn_bstats, (size_t)(io->bn_stats_copies > 1 ? io->bn_stats_copies : 1) * 2 * d * 4);
+    bns_done = fuse;
+    if (fuse) dense_bwd(dyd, k->cv_sw, TFASR_BP_CV_PW2_W, TFASR_BP_CV_PW2_B, d, d, dsw, c->conv_res, nullptr, 0, 0.f, 0, k->cv_cv, k->cv_fin, io->bn_bstats, ncp);
+    else dense_bwd(dyd, k->cv_sw, TFASR_BP_CV_PW2_W, TFASR_BP_CV_PW2_B, d, d, dsw, c->conv_res);
+    if (!c->dw_norm_layer && !(bns_done && fuse)) {
       if (!dry) chk(tfasr_bn_bwd_stats(k->cv_cv, dsw, k->cv_fin, io->bn_bstats, rows, d, TFASR_ACT_SWISH, c->dtype, s));
     }
     k->bw_dsw = dsw;
@@ -621,7 +638,7 @@ struct Ex {
                                 c->dtype, s));
       } else {
         // bstats = (sum dz, sum dz xhat) over the GLOBAL batch = the beta / gamma gradients; the flat-gradient all-reduce sums over ranks again
-        chk(tfasr_bn_apply_bwd_grads(k->cv_cv, k->bw_dsw, k->cv_fin, io->bn_bstats, (float)(rows * c->world), dcv, rows, d, TFASR_ACT_SWISH,
+        chk(tfasr_bn_apply_bwd_grads_copies(k->cv_cv, k->bw_dsw, k->cv_fin, io->bn_bstats, bn_copies(), (float)(rows * c->world), dcv, rows, d, TFASR_ACT_SWISH,
                                      gp(TFASR_BP_CV_BN_G), gp(TFASR_BP_CV_BN_B), 1.f / (float)c->world, c->dtype, s));
       }
       if (!dw_deferred)

@@ -442,7 +442,7 @@ extern "C" int tfasr_gemm(const tfasr_gemm_args* args, void* stream_) {
     const int st = tfasr_gemm_fast_try(a, stream);
     if (st != TFASR_STATUS_UNSUPPORTED) return st;
   }
-  if (a.lse_part || a.rgrad_coef) return TFASR_STATUS_UNSUPPORTED;  // only the bf16 fast path's epilogues produce the row statistics / the loss gradient
+  if (a.lse_part || a.rgrad_coef || a.bns_out) return TFASR_STATUS_UNSUPPORTED;  // only the bf16 fast path's epilogues produce the row statistics / the loss gradient / the BatchNorm sums
   if (a.seg_a_off) return TFASR_STATUS_UNSUPPORTED;  // K-segments: bf16 fast path only (the f32 host path issues one product per segment)
   if (a.colsum) {  // the generic kernels do not fuse the bias gradient: one extra pass over B = dy
     const int st = tfasr_colsum(a.B, a.ldb, a.colsum, a.K, a.N, a.alpha, a.dtype, stream_);

@@ -265,7 +265,7 @@ __device__ __forceinline__ float dact_f(float z, int act) {
 // EPI selects which epilogue terms are COMPILED IN.  The fully generic epilogue (every term behind a runtime branch, tanh /
 // sigmoid / f32 outputs included) is ~20k instructions and thrashes the instruction cache: a plain bias epilogue took 1700
 // cycles per 16-row strip.  The step's common combinations get lean instantiations; anything else falls back to E_GEN.
-enum : int { E_ACT = 1 /* swish(+prez) */, E_DACT = 2 /* * swish'(dact_z) */, E_DROP = 4, E_RES = 8, E_WS = 16 /* split-K partial -> workspace */, E_CSUM = 32 /* + column sums of B (bias gradient) */, E_LSE = 64 /* + log-softmax statistics of the output rows */, E_RGRAD = 128 /* re-computed logits -> RNN-T loss gradient */, E_GEN = 256 };
+enum : int { E_ACT = 1 /* swish(+prez) */, E_DACT = 2 /* * swish'(dact_z) */, E_DROP = 4, E_RES = 8, E_WS = 16 /* split-K partial -> workspace */, E_CSUM = 32 /* + column sums of B (bias gradient) */, E_LSE = 64 /* + log-softmax statistics of the output rows */, E_RGRAD = 128 /* re-computed logits -> RNN-T loss gradient */, E_GEN = 256, E_BNS = 512 /* + BatchNorm backward statistics of the output */ };
 
 // Persistent workgroups (2 per CU) walk a strided list of tiles.  Measured on [23808,256]x[256,1024] (cycle counters,
 // tools/hwprobe/gemm_timing.hip): a tile spent 1900 cycles waiting for its first slab, ~2400 per further slab (the LDS-DMA
@@ -289,6 +289,7 @@ __device__ __forceinline__ void gemm_fast_body(const tfasr_gemm_args& p, const i
   constexpr bool C_WS = (EPI & E_WS) != 0;
   constexpr bool C_CS = (EPI & E_CSUM) != 0;
   constexpr bool C_LSE = (EPI & E_LSE) != 0;
+  constexpr bool C_BNS = (EPI & E_BNS) != 0;
   constexpr int BN = BN_, NJ = BN_ / 32, WN = BN_ / 2;
   constexpr int STAGE_BYTES = A_BYTES + BN_ * BK * 2;
   constexpr int GI = 4 + BN_ / 32;  // DMA wave-instructions per slab per wave
@@ -603,6 +604,28 @@ __device__ __forceinline__ void gemm_fast_body(const tfasr_gemm_args& p, const i
             lse_lab[ii][hh] = (rw < p.M) ? p.row_label[rw] : -1;
           }
       }
+      // E_BNS: BatchNorm backward statistics of this lane's 8 columns over the rows it passes (tfasr_gemm_args.bns_*); the BatchNorm inputs
+      // of all its rows are requested in one batch in front of the strips
+      [[maybe_unused]] float bs0[C_BNS ? 8 : 1], bs1[C_BNS ? 8 : 1], fsc[C_BNS ? 8 : 1], fsh[C_BNS ? 8 : 1], frs[C_BNS ? 8 : 1], fm2[C_BNS ? 8 : 1];
+      [[maybe_unused]] uint4 bnx[C_BNS ? 4 : 1][C_BNS ? NPASS : 1];
+      if constexpr (C_BNS) {
+        const bool cok = col0 + 8 <= p.N;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          bs0[q] = 0.f; bs1[q] = 0.f;
+          const int cc = cok ? col0 + q : 0;
+          const float mean = p.bns_fin[cc], rstd = p.bns_fin[p.N + cc];
+          fsc[q] = p.bns_fin[2 * p.N + cc]; fsh[q] = p.bns_fin[3 * p.N + cc]; frs[q] = rstd; fm2[q] = -mean * rstd;
+        }
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+          for (int hh = 0; hh < NPASS; ++hh) {
+            const int rw = m0 + wm * 64 + ii * 16 + hh * RPP + prow;
+            bnx[ii][hh] = make_uint4(0u, 0u, 0u, 0u);
+            if (rw < p.M && cok) bnx[ii][hh] = *reinterpret_cast<const uint4*>((const bf16_t*)p.bns_x + doff + (long)rw * p.ldd + col0);
+          }
+      }
       auto strip = [&](auto I_, auto H_) {
         constexpr int i = decltype(I_)::value, h = decltype(H_)::value;
         if ((g * 4) / RPP == h) {
@@ -624,6 +647,20 @@ __device__ __forceinline__ void gemm_fast_body(const tfasr_gemm_args& p, const i
           const long idx0 = (long)row * p.ldd + col0;
 #pragma unroll
           for (int q = 0; q < 8; ++q) x[q] = p.alpha * x[q] + bv[q];
+          if constexpr (C_BNS) {
+            if (full) {
+              float xv[8];
+              unpack8(bnx[i][h], xv);
+#pragma unroll
+              for (int q = 0; q < 8; q += 2) {
+                const uint32_t pk = pack2_bf16(x[q], x[q + 1]);  // the gradient as the second pass would read it back
+                const float d0 = __uint_as_float(pk << 16), d1 = __uint_as_float(pk & 0xffff0000u);
+                const float dz0 = d0 * dswishf_(xv[q] * fsc[q] + fsh[q]), dz1 = d1 * dswishf_(xv[q + 1] * fsc[q + 1] + fsh[q + 1]);
+                bs0[q] += dz0; bs1[q] += dz0 * (xv[q] * frs[q] + fm2[q]);
+                bs0[q + 1] += dz1; bs1[q + 1] += dz1 * (xv[q + 1] * frs[q + 1] + fm2[q + 1]);
+              }
+            }
+          }
           if constexpr (C_ACT) {
             if (prez) {
               if (full) st8(prez + idx0, x);
@@ -748,6 +785,19 @@ _Pragma("unroll")
       strips(std::integral_constant<int, 1>{});
       strips(std::integral_constant<int, 2>{});
       strips(std::integral_constant<int, 3>{});
+      if constexpr (C_BNS) {
+        // over the RPP lanes that share the columns (lane = row * LPRW + column group): inside a 16-lane row by rotations, across rows by swaps
+        static_assert(LPRW == 4 || LPRW == 8, "rows of 4 or 8 lanes");
+        float* out = p.bns_out + (size_t)(bid % (p.bns_copies > 0 ? p.bns_copies : 1)) * 2 * p.N;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          float a0 = bs0[q], a1 = bs1[q];
+          a0 += dpp_mov<0x128>(a0); a1 += dpp_mov<0x128>(a1);
+          if constexpr (LPRW == 4) { a0 += dpp_mov<0x124>(a0); a1 += dpp_mov<0x124>(a1); }
+          a0 = xor32_sum(xor16_sum(a0)); a1 = xor32_sum(xor16_sum(a1));
+          if (lane < LPRW && col0 + 8 <= p.N) { atomicAdd(out + col0 + q, a0); atomicAdd(out + p.N + col0 + q, a1); }
+        }
+      }
     }
 #ifdef TFASR_GEMM_TIMING
     if (threadIdx.x == 0 && it == 0) {
@@ -928,6 +978,14 @@ int launch_one(const tfasr_gemm_args& a, hipStream_t stream) {
     if (a.dact_z) { if (a.dact == TFASR_ACT_SWISH) need |= E_DACT; else generic = true; }
     if (a.drop_p > 0.f) need |= E_DROP;
     if (a.res) need |= E_RES;
+  }
+  if (a.bns_out) {  // BatchNorm backward statistics in the epilogue: the plain NT product on 64-column tiles, or nothing at all
+    if constexpr (!TA && TB) {
+      if (narrow && !generic && need == 0 && !a.accumulate && !a.bias && split == 1 && a.nb1 * a.nb2 == 1 && a.bns_x && a.bns_fin && (a.N & 7) == 0 && (a.ldd & 7) == 0 &&
+          (((uintptr_t)a.D | (uintptr_t)a.bns_x) & 15) == 0 && !a.colsum && !a.lse_part && !a.seg_a_off && !a.rgrad_coef)
+        return launch_epi<TA, TB, 64, E_BNS>(a, grid, stream);
+    }
+    return TFASR_STATUS_UNSUPPORTED;
   }
   if constexpr (!TA) {  // thousands of tiles: 256-row tiles, one 8-wave workgroup per CU (gemm_big.h)
     const bool tanh_out = !a.accumulate && a.dact_z && a.dact == TFASR_ACT_TANH_OUT;  // the only epilogue term gemm_big knows beyond bias

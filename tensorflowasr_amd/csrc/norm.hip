@@ -240,6 +240,24 @@ __global__ __launch_bounds__(256) void bn_apply_fwd_rows_kernel(const T* __restr
 // bn_finalize_kernel + bn_apply_fwd_rows_kernel in one launch: every workgroup derives the coefficients of its lanes' 8 channels from the
 // statistics itself (same arithmetic as bn_finalize_kernel), workgroup 0's first row of lanes also writes `fin` (the backward reads it)
 // and the moving statistics.
+// Statistics spread over `copies` copies [copies][2][C] by their producer (tfasr_dwconv_fwd_stats, the E_BNS epilogue of tfasr_gemm): the
+// workgroup adds them up ONCE through LDS - thread i owns four consecutive floats of the 2C sums and requests its (up to 8) copies of them
+// in one batch - instead of every lane walking the copies of its own eight channels (a chain of dependent round trips in front of a
+// 12 us kernel: +3.9 us measured).  sred [2C] floats; call from every thread of the block.
+constexpr int BN_COPIES_MAX = 8;
+__device__ __forceinline__ void bn_sum_copies(const float* __restrict__ stats, int copies, int C, float* sred) {
+  for (int u = threadIdx.x; u < (2 * C) / 4; u += blockDim.x) {
+    float4 t[BN_COPIES_MAX];
+#pragma unroll
+    for (int q = 0; q < BN_COPIES_MAX; ++q) t[q] = *reinterpret_cast<const float4*>(stats + (size_t)min(q, copies - 1) * 2 * C + u * 4);
+    float4 a = t[0];
+#pragma unroll
+    for (int q = 1; q < BN_COPIES_MAX; ++q)
+      if (q < copies) { a.x += t[q].x; a.y += t[q].y; a.z += t[q].z; a.w += t[q].w; }
+    *reinterpret_cast<float4*>(sred + u * 4) = a;
+  }
+  __syncthreads();
+}
 template <typename T>
 __global__ __launch_bounds__(256) void bn_finalize_apply_fwd_rows_kernel(const T* __restrict__ x, const float* __restrict__ stats, float count,
                                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -247,6 +265,8 @@ __global__ __launch_bounds__(256) void bn_finalize_apply_fwd_rows_kernel(const T
                                                                          float eps, T* __restrict__ y, long rows, int C, int act, int training, int copies) {
   const int lpr = C >> 3, li = threadIdx.x % lpr, sub = threadIdx.x / lpr, rpb = 256 / lpr;
   const int c = li * 8;
+  __shared__ __attribute__((aligned(16))) float sred[2 * 2048];  // (the row kernels take C <= 2048)
+  if (training && copies > 1) bn_sum_copies(stats, copies, C, sred);
   float sc[8], sh[8];
   {
     float mean[8], var[8], gm[8], bt[8], mm[8], mv[8];
@@ -254,13 +274,8 @@ __global__ __launch_bounds__(256) void bn_finalize_apply_fwd_rows_kernel(const T
     const bool writer = blockIdx.x == 0 && sub == 0;
     if (training) {
       float s0[8], s1[8];
-      ld8(stats + c, s0); ld8(stats + C + c, s1);
-      for (int q = 1; q < copies; ++q) {  // statistics spread over copies [copies][2][C] by their producer (tfasr_dwconv_fwd_stats)
-        float t0[8], t1[8];
-        ld8(stats + (size_t)q * 2 * C + c, t0); ld8(stats + (size_t)q * 2 * C + C + c, t1);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) { s0[k] += t0[k]; s1[k] += t1[k]; }
-      }
+      if (copies > 1) { ld8(sred + c, s0); ld8(sred + C + c, s1); }
+      else { ld8(stats + c, s0); ld8(stats + C + c, s1); }
       if (writer && moving_mean) { ld8(moving_mean + c, mm); ld8(moving_var + c, mv); }
 #pragma unroll
       for (int k = 0; k < 8; ++k) { mean[k] = s0[k] / count; var[k] = fmaxf(s1[k] / count - mean[k] * mean[k], 0.f); }
@@ -299,14 +314,17 @@ __global__ __launch_bounds__(256) void bn_finalize_apply_fwd_rows_kernel(const T
 template <typename T>
 __global__ __launch_bounds__(256) void bn_apply_bwd_rows_kernel(const T* __restrict__ x, const T* __restrict__ dy, const float* __restrict__ fin,
                                                                 const float* __restrict__ bstats, float count, T* dx, long rows, int C, int act,
-                                                                float* dgamma, float* dbeta, float gscale) {
+                                                                float* dgamma, float* dbeta, float gscale, int copies) {
   const int lpr = C >> 3, li = threadIdx.x % lpr, sub = threadIdx.x / lpr, rpb = 256 / lpr;
   const int c = li * 8;
+  __shared__ __attribute__((aligned(16))) float sred[2 * 2048];
+  if (copies > 1) bn_sum_copies(bstats, copies, C, sred);
   float sc[8], sh[8], cb[8], cd[8];  // dx = sc * dz + cb * x + cd  (dz = dy * act'(sc x + sh))
   {
     float mean[8], rstd[8], s0[8], s1[8];
     ld8(fin + c, mean); ld8(fin + C + c, rstd); ld8(fin + 2 * C + c, sc); ld8(fin + 3 * C + c, sh);
-    ld8(bstats + c, s0); ld8(bstats + C + c, s1);
+    if (copies > 1) { ld8(sred + c, s0); ld8(sred + C + c, s1); }
+    else { ld8(bstats + c, s0); ld8(bstats + C + c, s1); }
     // the BatchNorm parameter gradients are the two statistics themselves: dbeta += gscale * sum dz, dgamma += gscale * sum dz xhat
     // (one writer: block 0's first row of lanes; they were two extra axpy launches per BatchNorm)
     if (blockIdx.x == 0 && sub == 0) {
@@ -814,7 +832,7 @@ bool tfasr_bn_rows_kernel_ok(int C) { return (C % 8) == 0 && rows_variant_ok(C);
 extern "C" int tfasr_bn_finalize_apply_fwd_copies(const void* x, const float* stats, int copies, float count, const float* gamma, const float* beta, float* fin,
                                            float* moving_mean, float* moving_var, float momentum, float eps, void* y, long rows, int C, int act,
                                            int training, int dtype, void* stream_) {
-  if (!x || !gamma || !beta || !fin || !y || rows <= 0 || C <= 0 || copies <= 0) return TFASR_STATUS_INVALID_VALUE;
+  if (!x || !gamma || !beta || !fin || !y || rows <= 0 || C <= 0 || copies <= 0 || copies > BN_COPIES_MAX) return TFASR_STATUS_INVALID_VALUE;
   if (training && !stats) return TFASR_STATUS_INVALID_VALUE;
   if (!training && (!moving_mean || !moving_var)) return TFASR_STATUS_INVALID_VALUE;
   if ((C % 8) != 0 || !rows_variant_ok(C) || (dtype != TFASR_F32 && dtype != TFASR_BF16)) return TFASR_STATUS_UNSUPPORTED;
@@ -857,15 +875,16 @@ extern "C" int tfasr_bn_bwd_stats(const void* x, const void* dy, const float* fi
   return TFASR_STATUS_SUCCESS;
 }
 
-extern "C" int tfasr_bn_apply_bwd_grads(const void* x, const void* dy, const float* fin, const float* bstats, float count, void* dx, long rows,
+extern "C" int tfasr_bn_apply_bwd_grads_copies(const void* x, const void* dy, const float* fin, const float* bstats, int copies, float count, void* dx, long rows,
                                         int C, int act, float* dgamma, float* dbeta, float grad_scale, int dtype, void* stream_) {
-  if (!x || !dy || !fin || !bstats || !dx || rows <= 0 || C <= 0 || (C % 8) != 0) return TFASR_STATUS_INVALID_VALUE;
+  if (!x || !dy || !fin || !bstats || !dx || rows <= 0 || C <= 0 || (C % 8) != 0 || copies <= 0 || copies > BN_COPIES_MAX) return TFASR_STATUS_INVALID_VALUE;
+  if (copies > 1 && !rows_variant_ok(C)) return TFASR_STATUS_UNSUPPORTED;  // only the row kernel adds copies up
   const long n8 = rows * C / 8;
   hipStream_t s = (hipStream_t)stream_;
   if (rows_variant_ok(C)) {
     const int grid = rows_variant_grid(rows, C);
-    if (dtype == TFASR_F32) TFASR_KLAUNCH(bn_apply_bwd_rows_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, (const float*)dy, fin, bstats, count, (float*)dx, rows, C, act, dgamma, dbeta, grad_scale);
-    else TFASR_KLAUNCH(bn_apply_bwd_rows_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)dy, fin, bstats, count, (bf16_t*)dx, rows, C, act, dgamma, dbeta, grad_scale);
+    if (dtype == TFASR_F32) TFASR_KLAUNCH(bn_apply_bwd_rows_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, (const float*)dy, fin, bstats, count, (float*)dx, rows, C, act, dgamma, dbeta, grad_scale, copies);
+    else TFASR_KLAUNCH(bn_apply_bwd_rows_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)dy, fin, bstats, count, (bf16_t*)dx, rows, C, act, dgamma, dbeta, grad_scale, copies);
     TFASR_CHECK_LAUNCH();
     return TFASR_STATUS_SUCCESS;
   }
@@ -880,6 +899,11 @@ extern "C" int tfasr_bn_apply_bwd_grads(const void* x, const void* dy, const flo
                        (const bf16_t*)dy, fin, bstats, count, (bf16_t*)dx, n8, C, act);
   TFASR_CHECK_LAUNCH();
   return TFASR_STATUS_SUCCESS;
+}
+
+extern "C" int tfasr_bn_apply_bwd_grads(const void* x, const void* dy, const float* fin, const float* bstats, float count, void* dx, long rows,
+                                        int C, int act, float* dgamma, float* dbeta, float grad_scale, int dtype, void* stream_) {
+  return tfasr_bn_apply_bwd_grads_copies(x, dy, fin, bstats, 1, count, dx, rows, C, act, dgamma, dbeta, grad_scale, dtype, stream_);
 }
 
 extern "C" int tfasr_bn_apply_bwd(const void* x, const void* dy, const float* fin, const float* bstats, float count,

@@ -139,8 +139,9 @@ def rnnt_loss_packed_coef(labels, label_len, logit_len, cell_off, total_cells, T
 # ---------------------------------------------------------------------------------------------- GEMM
 def gemm(A, B, out, M, N, K, lda, ldb, ldd, trans_a=False, trans_b=False, bias=None, res=None, dact_z=None,
          prez=None, alpha=1.0, beta=1.0, act=ACT_NONE, dact=ACT_NONE, nb1=1, nb2=1, sA=(0, 0), sB=(0, 0), sD=(0, 0),
-         accumulate=False, split_k=1, drop_p=0.0, drop_seed=0, colsum=None, lse=None, seg=None, rgrad=None):
-    """Raw strided (two-level batched) GEMM; see include/tfasr_hip.h.  lse = (lse_part [M, parts, 2] f32, row_label [M] i32,
+         accumulate=False, split_k=1, drop_p=0.0, drop_seed=0, colsum=None, lse=None, seg=None, rgrad=None, bns=None):
+    """Raw strided (two-level batched) GEMM; see include/tfasr_hip.h.  bns = (x [M, N], fin [4N] f32, out [copies, 2N] f32): the BatchNorm
+    backward sums of the output in the epilogue (tfasr_gemm_args.bns_*; raises TfasrUnsupported when the product is not the plain NT one).  lse = (lse_part [M, parts, 2] f32, row_label [M] i32,
     pick [M, 2] f32): fused log-softmax statistics of the output rows (raises TfasrUnsupported when the fast path cannot); with it
     `out` may be None (statistics only).  rgrad = (coef [M, 4] f32, row_label [M] i32): the product is a re-computed logit tile and the
     epilogue stores the RNN-T loss gradient instead (tfasr_gemm_args.rgrad_coef)."""
@@ -153,12 +154,16 @@ def gemm(A, B, out, M, N, K, lda, ldb, ldd, trans_a=False, trans_b=False, bias=N
     if seg is not None:  # (seg_a_off i64 device tensor, seg_b_off or None, seg_k): K-segmented operands
         a.seg_a_off, a.seg_b_off, a.seg_k = seg[0].data_ptr(), (seg[1].data_ptr() if seg[1] is not None else None), int(seg[2])
         assert seg[0].dtype == torch.int64 and seg[0].is_cuda
+    if bns is not None:
+        bx, bfin, bout = bns
+        assert bfin.dtype == torch.float32 and bout.dtype == torch.float32 and bout.is_contiguous() and bx.is_contiguous()
+        a.bns_x, a.bns_fin, a.bns_out, a.bns_copies = bx.data_ptr(), bfin.data_ptr(), bout.data_ptr(), bout.numel() // (2 * N)
     if lse is not None:
         part, row_label, pick = lse
         assert part.dtype == torch.float32 and pick.dtype == torch.float32 and row_label.dtype == torch.int32
         a.lse_part, a.lse_parts, a.row_label, a.pick = part.data_ptr(), part.shape[1], row_label.data_ptr(), pick.data_ptr()
     st = _lib.load().tfasr_gemm(ctypes.byref(a), _stream())
-    if (lse is not None or seg is not None or rgrad is not None) and st == _lib.STATUS_UNSUPPORTED:
+    if (lse is not None or seg is not None or rgrad is not None or bns is not None) and st == _lib.STATUS_UNSUPPORTED:
         raise _lib.TfasrUnsupported("gemm: fused row statistics / K-segments / gradient epilogue are not available for this product")
     check(st, "gemm")
     return out
@@ -336,14 +341,15 @@ def bn_bwd_stats(x, dy, fin, bstats, act=ACT_NONE):
     check(_L().tfasr_bn_bwd_stats(_p(x), _p(dy), _p(fin), _p(bstats), rows, C, act, _dt(x), _stream()), "bn_bwd_stats")
 
 
-def bn_apply_bwd(x, dy, fin, bstats, count, act=ACT_NONE, dx=None, dgamma=None, dbeta=None, grad_scale=1.0):
-    """dgamma / dbeta (f32 views of the gradient buffer): += grad_scale * the two statistics, in the same launch."""
+def bn_apply_bwd(x, dy, fin, bstats, count, act=ACT_NONE, dx=None, dgamma=None, dbeta=None, grad_scale=1.0, copies=1):
+    """dgamma / dbeta (f32 views of the gradient buffer): += grad_scale * the two statistics, in the same launch.  copies > 1: bstats is
+    [copies, 2C] (the layout the gemm's bns epilogue accumulates into), added up on the fly."""
     rows, C = x.numel() // x.shape[-1], x.shape[-1]
     if dx is None:
         dx = torch.empty_like(x)
-    check(_L().tfasr_bn_apply_bwd_grads(_p(x), _p(dy), _p(fin), _p(bstats), float(count), _p(dx), rows, C, act,
-                                        _p(dgamma) if dgamma is not None else None, _p(dbeta) if dbeta is not None else None, float(grad_scale),
-                                        _dt(x), _stream()), "bn_apply_bwd")
+    check(_L().tfasr_bn_apply_bwd_grads_copies(_p(x), _p(dy), _p(fin), _p(bstats), int(copies), float(count), _p(dx), rows, C, act,
+                                               _p(dgamma) if dgamma is not None else None, _p(dbeta) if dbeta is not None else None, float(grad_scale),
+                                               _dt(x), _stream()), "bn_apply_bwd")
     return dx
 
 

@@ -268,6 +268,36 @@ def test_dwconv_forward_with_batchnorm_statistics(dev, Kk, C, T, copies):
     cmp(outs[1][0], outs[0][0], rtol=2e-2, atol=2e-2)
 
 
+@pytest.mark.parametrize("rows,C,copies", [(12 * 256 + 37, 256, 8), (9000, 256, 1), (40000, 128, 4)])
+def test_gemm_epilogue_batchnorm_backward_sums(dev, rows, C, copies):
+    """tfasr_gemm_args.bns_*: the data gradient of the ConvModule's second pointwise conv with the BatchNorm backward sums in its epilogue
+    against the two-pass route (tfasr_gemm, then tfasr_bn_bwd_stats over x and the stored gradient): same product bitwise, same sums up
+    to the order of the f32 additions, same apply pass from the copies (conformer.py:305-333)."""
+    g = torch.Generator().manual_seed(rows + C)
+    bf = torch.bfloat16
+    dy = (torch.randn(rows, C, generator=g) * 0.5).to(dev).to(bf)
+    W = (torch.randn(C, C, generator=g) / 16).to(dev).to(bf)        # [din, dout]: dx = dy @ W^T
+    x = (torch.randn(rows, C, generator=g) * 1.3 + 0.2).to(dev).to(bf)
+    mean, var = x.float().mean(0), x.float().var(0, unbiased=False)
+    rstd = torch.rsqrt(var + 1e-3)
+    gm, bt = (torch.rand(C, generator=g) + 0.5).to(dev), (torch.randn(C, generator=g) * 0.1).to(dev)
+    fin = torch.cat([mean, rstd, gm * rstd, bt - mean * gm * rstd]).contiguous()
+    d0 = torch.empty(rows, C, dtype=bf, device=dev)
+    K.gemm(dy, W, d0, rows, C, C, C, C, C, trans_b=True, alpha=0.5)
+    st0 = torch.zeros(2 * C, device=dev)
+    K.bn_bwd_stats(x, d0, fin, st0, K.ACT_SWISH)
+    d1 = torch.empty(rows, C, dtype=bf, device=dev)
+    st = torch.zeros(copies, 2 * C, device=dev)
+    K.gemm(dy, W, d1, rows, C, C, C, C, C, trans_b=True, alpha=0.5, bns=(x, fin, st))
+    assert torch.equal(d0, d1)
+    scale = float(st0.abs().max())
+    cmp(st.sum(0), st0, rtol=1e-3, atol=2e-4 * scale)
+    assert copies == 1 or int((st.abs().sum(1) > 0).sum()) > 1
+    dx0 = K.bn_apply_bwd(x, d0, fin, st0, float(rows), K.ACT_SWISH)
+    dx1 = K.bn_apply_bwd(x, d0, fin, st, float(rows), K.ACT_SWISH, copies=copies)
+    cmp(dx1, dx0, rtol=2e-2, atol=2e-3)
+
+
 @pytest.mark.parametrize("dtype", DT)
 def test_bias2_embedding_colsum_cast(dev, dtype):
     g = torch.Generator().manual_seed(2)
