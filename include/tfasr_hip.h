@@ -51,7 +51,7 @@
 extern "C" {
 #endif
 
-#define TFASR_ABI_VERSION 38
+#define TFASR_ABI_VERSION 39
 
 typedef enum {
   TFASR_STATUS_SUCCESS = 0,
@@ -142,7 +142,8 @@ int tfasr_ctc_greedy_decode(const void* logits, const int32_t* logit_len, int32_
  * A, B, res, dact_z, prez are `dtype`; bias is f32.
  * ---------------------------------------------------------------------------------------------- */
 /* TANH_OUT is a `dact` only: dact_z holds tanh's OUTPUT h (not its argument), the factor is 1 - h^2 (the joint network keeps h) */
-typedef enum { TFASR_ACT_NONE = 0, TFASR_ACT_SWISH = 1, TFASR_ACT_TANH = 2, TFASR_ACT_SIGMOID = 3, TFASR_ACT_TANH_OUT = 4 } tfasr_act_t;
+typedef enum { TFASR_ACT_NONE = 0, TFASR_ACT_SWISH = 1, TFASR_ACT_TANH = 2, TFASR_ACT_SIGMOID = 3, TFASR_ACT_TANH_OUT = 4,
+               TFASR_ACT_FACTOR = 5 /* dact only: dact_z holds the derivative factor itself (tfasr_ffn_fused_fwd2) */ } tfasr_act_t;
 
 typedef struct {
   const void* A; const void* B; void* D;
@@ -225,6 +226,12 @@ int tfasr_layernorm_fwd(const void* x, const float* gamma, const float* beta, vo
 int tfasr_ffn_fused_fwd(const void* x, const float* gamma, const float* beta, const void* W1, const float* b1, const void* W2,
                         const float* b2, void* y, void* ln, float* mean, float* rstd, void* z, void* h, long rows, int d, int F,
                         float ln_eps, float res_factor, float drop_p, long drop_seed1, long drop_seed2, int dtype, void* stream);
+/* z_factor != 0: `z` receives the backward's factor g = swish'(LN(x) W1 + b1) * mask1 / (1 - p) (compute dtype) instead of the
+ * pre-activation: the data gradient of the second Dense layer is then tfasr_gemm with dact_z = g, dact = TFASR_ACT_FACTOR and NO dropout
+ * term (one multiply per element in its epilogue instead of swish' and the dropout hash). */
+int tfasr_ffn_fused_fwd2(const void* x, const float* gamma, const float* beta, const void* W1, const float* b1, const void* W2,
+                         const float* b2, void* y, void* ln, float* mean, float* rstd, void* z, int z_factor, void* h, long rows, int d, int F,
+                         float ln_eps, float res_factor, float drop_p, long drop_seed1, long drop_seed2, int dtype, void* stream);
 int tfasr_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
                         const void* add, void* dx, float* dgamma, float* dbeta, long rows, int C, int dtype,
                         void* stream);

@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TFASR_LIB") or os.path.join(HERE, "lib", "libtfasr_hip.so")  # TFASR_LIB: A/B runs of two builds on one box
 
 TFASR_F32, TFASR_BF16 = 0, 1
-ACT_NONE, ACT_SWISH, ACT_TANH, ACT_SIGMOID, ACT_TANH_OUT = 0, 1, 2, 3, 4
+ACT_NONE, ACT_SWISH, ACT_TANH, ACT_SIGMOID, ACT_TANH_OUT, ACT_FACTOR = 0, 1, 2, 3, 4, 5
 
 
 class TfasrError(RuntimeError):
@@ -153,7 +153,7 @@ def load(build_if_missing=True):
     return lib
 
 
-ABI_VERSION = 38
+ABI_VERSION = 39
 
 
 STATUS_UNSUPPORTED = 3

@@ -36,6 +36,7 @@ struct Ctx {
   // feed-forward modules
   void *ff_x[2], *ff_ln[2], *ff_z[2], *ff_h[2];
   float *ff_mean[2], *ff_rstd[2];
+  int ff_zfactor[2];  // 1: ff_z holds the data gradient's factor swish'(z) * mask1 / (1 - p) (fused forward), 0: the pre-activation z
   // attention
   void *at_x, *at_ln, *at_qkv, *at_pext, *at_att, *at_qu, *at_qv, *at_probs;
   float *at_mean, *at_rstd, *at_lse;
@@ -301,6 +302,7 @@ struct Ex {
   }
 
   // ------------------------------------------------------------------------------------------ FFModule
+  static bool ffn_factor() { return true; }  // (same-box A/B against storing z: -0.16 ms per step, profiles/r06_ab/ffn_backward_factor.txt)
   void ffm_fwd(int m, const void* x, void* y, int site) {
     const int b0 = m == 0 ? TFASR_BP_FF1_LN_G : TFASR_BP_FF2_LN_G;
     const int d = c->d, F = c->dff;
@@ -311,12 +313,14 @@ struct Ex {
     k->ff_z[m] = c->save ? act(stash, rows * F) : nullptr;
     k->ff_h[m] = act(stash, rows * F);
     if (!dry) {  // one launch where the shape allows it (ffn_fused.h); UNSUPPORTED -> the three launches below
-      const int fst = tfasr_ffn_fused_fwd(x, fp(b0), fp(b0 + 1), wp(b0 + 2), fp(b0 + 3), wp(b0 + 4), fp(b0 + 5), y, k->ff_ln[m], k->ff_mean[m], k->ff_rstd[m],
-                                          k->ff_z[m], k->ff_h[m], rows, d, F, c->ln_eps, c->ffm_res, drop_p(), seed(site), seed(site + 1), c->dtype, s);
-      if (fst != TFASR_STATUS_UNSUPPORTED) { chk(fst); return; }
+      // the fused launch stores the data gradient's FACTOR swish'(z) * mask1 / (1 - p) where the three-launch route stores z (k->ff_zfactor)
+      const int fst = tfasr_ffn_fused_fwd2(x, fp(b0), fp(b0 + 1), wp(b0 + 2), fp(b0 + 3), wp(b0 + 4), fp(b0 + 5), y, k->ff_ln[m], k->ff_mean[m], k->ff_rstd[m],
+                                           k->ff_z[m], ffn_factor() ? 1 : 0, k->ff_h[m], rows, d, F, c->ln_eps, c->ffm_res, drop_p(), seed(site), seed(site + 1), c->dtype, s);
+      if (fst != TFASR_STATUS_UNSUPPORTED) { chk(fst); k->ff_zfactor[m] = ffn_factor() ? 1 : 0; return; }
     } else if (c->dtype == TFASR_BF16 && d == 256 && (F % 64) == 0) {
       return;  // (sizing run: the fused launch needs no scratch)
     }
+    k->ff_zfactor[m] = 0;
     ln_fwd(x, b0, b0 + 1, k->ff_ln[m], k->ff_mean[m], k->ff_rstd[m]);
     G a; a.act = TFASR_ACT_SWISH; a.prez = k->ff_z[m]; a.drop_p = drop_p(); a.drop_seed = seed(site);
     dense(k->ff_ln[m], b0 + 2, b0 + 3, k->ff_h[m], d, F, a);
@@ -339,7 +343,9 @@ struct Ex {
       w.side = 1;
       gemm(w);
       G g; g.A = dyd; g.lda = d; g.ta = 0; g.B = wp(b0 + 4); g.ldb = d; g.tb = 1; g.D = dz; g.ldd = F; g.M = (int)rows; g.N = F; g.K = d;
-      g.alpha = c->ffm_res; g.dact_z = k->ff_z[m]; g.dact = TFASR_ACT_SWISH; g.drop_p = drop_p(); g.drop_seed = seed(site);
+      g.alpha = c->ffm_res; g.dact_z = k->ff_z[m];
+      if (k->ff_zfactor[m]) g.dact = TFASR_ACT_FACTOR;  // the forward stored swish'(z) * mask1 / (1 - p)
+      else { g.dact = TFASR_ACT_SWISH; g.drop_p = drop_p(); g.drop_seed = seed(site); }
       gemm(g);
     }
     void* dln = act(scratch, rows * d);

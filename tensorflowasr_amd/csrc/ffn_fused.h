@@ -23,6 +23,7 @@ struct FfnArgs {
   const bf16_t* x; const float* gamma; const float* beta; const bf16_t* W1; const float* b1; const bf16_t* W2; const float* b2;
   bf16_t* y; bf16_t* ln; float* mean; float* rstd; bf16_t* z; bf16_t* h;
   long rows; int F; float eps, res, drop_p; long seed1, seed2;
+  int zfactor;     // 1: the `z` output holds the backward's factor swish'(z) * mask1 / (1 - p) instead of the pre-activation (tfasr_ffn_fused_fwd2)
   long long* dbg;  // TFASR_FFN_TIMING builds: per-phase cycle sums of workgroup 0 / wave 0 (tools/ffn_fused_check.py)
 };
 
@@ -54,7 +55,11 @@ __device__ __forceinline__ void lds_only_barrier() { asm volatile("s_waitcnt lgk
 //         GEMM1(c); zlds(c)
 //         barrier A; issue W1(c+1)                (W1 buffer released)
 //         rowpass(c); wait W2(c); barrier B; GEMM2(c)
-template <int MR, int WGS>  // 16 * MR rows per wave; 4 waves (2 x 2): BMR = 32 * MR rows per workgroup
+// ZF: the `z` tensor is written as the data gradient's FACTOR g = swish'(z) * mask1 / (1 - p) (bf16) instead of the pre-activation: the
+// backward's d(4d -> d) product then multiplies by g in its epilogue (gemm_fast E_MUL) instead of recomputing swish' (v_exp + v_rcp + 6)
+// and the dropout hash per element - what bounded that epilogue (53 us per launch against 23 for the bare product).  The row pass has
+// sigmoid(z) and the mask at hand: five more vector instructions per element here.  h is unchanged (same expression as swishf_).
+template <int MR, int WGS, bool ZF = false>  // 16 * MR rows per wave; 4 waves (2 x 2): BMR = 32 * MR rows per workgroup
 __global__ __launch_bounds__(256, WGS) void ffn_fused_fwd_kernel(const FfnArgs p) {
 #ifdef TFASR_FFN_TIMING
   long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -220,20 +225,35 @@ __global__ __launch_bounds__(256, WGS) void ffn_fused_fwd_kernel(const FfnArgs p
       char* sp = sH + row * 128 + ((pp ^ key_d(row)) << 4);
       const uint4 zv = *reinterpret_cast<const uint4*>(sp);
       const int off = row * F + pp * 8;
-      if constexpr (FAST) *reinterpret_cast<uint4*>(zbase + off) = zv;
-      else if (zbase && row < nrow_tile) *reinterpret_cast<uint4*>(zbase + off) = zv;
+      if constexpr (!ZF) {
+        if constexpr (FAST) *reinterpret_cast<uint4*>(zbase + off) = zv;
+        else if (zbase && row < nrow_tile) *reinterpret_cast<uint4*>(zbase + off) = zv;
+      }
       float hv[8];
+      [[maybe_unused]] float gv[8];
       unpack8(zv, hv);
 #pragma unroll
-      for (int q = 0; q < 8; ++q) hv[q] = swishf_(hv[q]);
+      for (int q = 0; q < 8; ++q) {
+        const float sg = sigmoidf_(hv[q]);
+        if constexpr (ZF) gv[q] = sg * (1.f + hv[q] * (1.f - sg));  // dswishf_
+        hv[q] = hv[q] * sg;                                          // swishf_
+      }
       {  // (drop_p = 0: threshold 0 keeps everything, dinv = 1 - no branch)
         const uint32_t pr0 = pbase + ((uint32_t)off >> 1);  // off is even: one dropout hash serves an element pair
 #pragma unroll
         for (int q = 0; q < 8; q += 2) {
           const uint32_t hh = drop_mix(dkey1, pr0 + (q >> 1));
-          hv[q] = (hh & 0xffffu) >= dthr ? hv[q] * dinv : 0.f;
-          hv[q + 1] = (hh >> 16) >= dthr ? hv[q + 1] * dinv : 0.f;
+          const bool k0 = (hh & 0xffffu) >= dthr, k1 = (hh >> 16) >= dthr;
+          hv[q] = k0 ? hv[q] * dinv : 0.f;
+          hv[q + 1] = k1 ? hv[q + 1] * dinv : 0.f;
+          if constexpr (ZF) { gv[q] = k0 ? gv[q] * dinv : 0.f; gv[q + 1] = k1 ? gv[q + 1] * dinv : 0.f; }
         }
+      }
+      if constexpr (ZF) {
+        uint4 gp;
+        gp.x = pack2_bf16(gv[0], gv[1]); gp.y = pack2_bf16(gv[2], gv[3]); gp.z = pack2_bf16(gv[4], gv[5]); gp.w = pack2_bf16(gv[6], gv[7]);
+        if constexpr (FAST) *reinterpret_cast<uint4*>(zbase + off) = gp;
+        else if (zbase && row < nrow_tile) *reinterpret_cast<uint4*>(zbase + off) = gp;
       }
       uint4 hp;
       hp.x = pack2_bf16(hv[0], hv[1]); hp.y = pack2_bf16(hv[2], hv[3]); hp.z = pack2_bf16(hv[4], hv[5]); hp.w = pack2_bf16(hv[6], hv[7]);
@@ -400,14 +420,12 @@ __global__ __launch_bounds__(256, WGS) void ffn_fused_fwd_kernel(const FfnArgs p
 #endif
 }
 
-// Variant for a launch.  One workgroup per CU with 96-row tiles (MR 3, double-buffered weights) or two per CU with 64-row tiles (WGS 2).
+// Two workgroups per CU with 64-row tiles (MR 2, WGS 2: weights single buffered).  Measured alternatives, removed in round 6 (the kernel is
+// still a template over them): 96-row tiles with one workgroup per CU and double-buffered weights; 32-row tiles (round 5, per batch shape:
+// a [14.8k, 256] batch is 231 64-row workgroups - one per CU - or 462 32-row ones = two per CU in one round; 50.9 vs ~48 us per launch in
+// line, 21.76 vs 21.45 ms per step when forced everywhere: the second resident workgroup's overlap does not pay for the halved reuse of
+// the weight images).
 static int launch_ffn_fused_fwd(const FfnArgs& a, hipStream_t stream) {
-  // 1: MR 3 x 1 WG/CU, 2: MR 2 x 2 WG/CU, 3: MR 2 x 1, 4: MR 1 x 2 WG/CU (32-row tiles); 0 / unset: by tile count (below)
-  static const int forced = 0;
-  // Round 5 re-measured the 32-row variant per batch shape (variant 4): a [14.8k, 256] batch is 231 64-row workgroups - one per CU - or 462
-  // 32-row ones = two per CU in one round; 50.9 vs ~48 us per launch in line, 21.76 vs 21.45 ms per step when forced everywhere: the
-  // second resident workgroup's overlap does not pay for the halved reuse of the weight images.  64 rows stay the default.
-  const int variant = forced >= 1 && forced <= 4 ? forced : 2;
   auto go = [&](auto kern, int MR, int NBUF) {
     const int smem = 2 * NBUF * 32768 + NBUF * 32 * MR * 128 + a.F * 4;
     static bool attr_done = false;
@@ -415,9 +433,7 @@ static int launch_ffn_fused_fwd(const FfnArgs& a, hipStream_t stream) {
     const long tiles = (a.rows + 32 * MR - 1) / (32 * MR);
     TFASR_KLAUNCH(kern, dim3((unsigned)tiles), dim3(256), smem, stream, a);
   };
-  if (variant == 1) go(ffn_fused_fwd_kernel<3, 1>, 3, 2);
-  else if (variant == 3) go(ffn_fused_fwd_kernel<2, 1>, 2, 2);
-  else if (variant == 4) go(ffn_fused_fwd_kernel<1, 2>, 1, 1);
-  else go(ffn_fused_fwd_kernel<2, 2>, 2, 1);
+  if (a.zfactor && a.z) go(ffn_fused_fwd_kernel<2, 2, true>, 2, 1);
+  else go(ffn_fused_fwd_kernel<2, 2, false>, 2, 1);
   return TFASR_STATUS_SUCCESS;
 }

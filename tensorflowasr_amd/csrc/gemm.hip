@@ -249,6 +249,7 @@ __device__ __forceinline__ float apply_dact(float z, int act) {
     case TFASR_ACT_TANH: { const float t = tanhf(z); return 1.f - t * t; }
     case TFASR_ACT_SIGMOID: { const float s = sigmoidf_(z); return s * (1.f - s); }
     case TFASR_ACT_TANH_OUT: return 1.f - z * z;
+    case TFASR_ACT_FACTOR: return z;
     default: return 1.f;
   }
 }

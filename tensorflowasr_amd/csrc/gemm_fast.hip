@@ -258,6 +258,7 @@ __device__ __forceinline__ float dact_f(float z, int act) {
     case TFASR_ACT_TANH: { const float t = tanhf(z); return 1.f - t * t; }
     case TFASR_ACT_SIGMOID: { const float s = sigmoidf_(z); return s * (1.f - s); }
     case TFASR_ACT_TANH_OUT: return 1.f - z * z;
+    case TFASR_ACT_FACTOR: return z;
     default: return 1.f;
   }
 }
@@ -265,7 +266,7 @@ __device__ __forceinline__ float dact_f(float z, int act) {
 // EPI selects which epilogue terms are COMPILED IN.  The fully generic epilogue (every term behind a runtime branch, tanh /
 // sigmoid / f32 outputs included) is ~20k instructions and thrashes the instruction cache: a plain bias epilogue took 1700
 // cycles per 16-row strip.  The step's common combinations get lean instantiations; anything else falls back to E_GEN.
-enum : int { E_ACT = 1 /* swish(+prez) */, E_DACT = 2 /* * swish'(dact_z) */, E_DROP = 4, E_RES = 8, E_WS = 16 /* split-K partial -> workspace */, E_CSUM = 32 /* + column sums of B (bias gradient) */, E_LSE = 64 /* + log-softmax statistics of the output rows */, E_RGRAD = 128 /* re-computed logits -> RNN-T loss gradient */, E_GEN = 256, E_BNS = 512 /* + BatchNorm backward statistics of the output */ };
+enum : int { E_ACT = 1 /* swish(+prez) */, E_DACT = 2 /* * swish'(dact_z) */, E_DROP = 4, E_RES = 8, E_WS = 16 /* split-K partial -> workspace */, E_CSUM = 32 /* + column sums of B (bias gradient) */, E_LSE = 64 /* + log-softmax statistics of the output rows */, E_RGRAD = 128 /* re-computed logits -> RNN-T loss gradient */, E_GEN = 256, E_BNS = 512 /* + BatchNorm backward statistics of the output */, E_MUL = 1024 /* * dact_z (the stored derivative factor) */ };
 
 // Persistent workgroups (2 per CU) walk a strided list of tiles.  Measured on [23808,256]x[256,1024] (cycle counters,
 // tools/hwprobe/gemm_timing.hip): a tile spent 1900 cycles waiting for its first slab, ~2400 per further slab (the LDS-DMA
@@ -290,6 +291,7 @@ __device__ __forceinline__ void gemm_fast_body(const tfasr_gemm_args& p, const i
   constexpr bool C_CS = (EPI & E_CSUM) != 0;
   constexpr bool C_LSE = (EPI & E_LSE) != 0;
   constexpr bool C_BNS = (EPI & E_BNS) != 0;
+  constexpr bool C_MUL = (EPI & E_MUL) != 0;  // like E_DACT with the activation derivative already in dact_z (TFASR_ACT_FACTOR)
   constexpr int BN = BN_, NJ = BN_ / 32, WN = BN_ / 2;
   constexpr int STAGE_BYTES = A_BYTES + BN_ * BK * 2;
   constexpr int GI = 4 + BN_ / 32;  // DMA wave-instructions per slab per wave
@@ -419,7 +421,7 @@ __device__ __forceinline__ void gemm_fast_body(const tfasr_gemm_args& p, const i
     // trip lies under the first slabs' DMA instead of between the slab loop and the epilogue (16 registers held through the loop).
     // Only the compiled swish' epilogues: the residual variants did not gain and the generic one started to spill.
     constexpr int PF_LPRW = (BN_ / 2) / 8, PF_RPP = 64 / PF_LPRW, PF_NPASS = 16 / PF_RPP;
-    constexpr bool PF_Z = C_DACT && !GEN && !C_WS;
+    constexpr bool PF_Z = (C_DACT || C_MUL) && !GEN && !C_WS;
     [[maybe_unused]] uint4 pf_z[PF_Z ? 4 : 1][PF_Z ? PF_NPASS : 1];
     [[maybe_unused]] bool pf_ok = false;
     auto prefetch_z = [&]() {
@@ -678,7 +680,7 @@ _Pragma("unroll")
               for (int q = 0; q < 8; ++q) x[q] = swishf_(x[q]);
             }
           }
-          if constexpr (C_DACT) if (dz) {
+          if constexpr (C_DACT || C_MUL) if (dz) {
             float z[8];
             bool got = false;
             if constexpr (PF_Z) {
@@ -691,7 +693,7 @@ _Pragma("unroll")
                 for (int q = 0; q < 8; ++q) z[q] = (col0 + q < p.N) ? bf16_to_f32(dz[idx0 + q]) : 0.f;
             }
 #pragma unroll
-            for (int q = 0; q < 8; ++q) x[q] *= GEN ? dact_f(z[q], p.dact) : dswishf_(z[q]);
+            for (int q = 0; q < 8; ++q) x[q] *= GEN ? dact_f(z[q], p.dact) : (C_MUL ? z[q] : dswishf_(z[q]));
           }
           if constexpr (C_DROP) if (p.drop_p > 0.f) {
             const uint64_t e0 = (uint64_t)(doff + idx0);
@@ -975,7 +977,7 @@ int launch_one(const tfasr_gemm_args& a, hipStream_t stream) {
   if (!a.accumulate) {
     if (a.out_f32) generic = true;
     if (a.act != TFASR_ACT_NONE || a.prez) { if (a.act == TFASR_ACT_SWISH) need |= E_ACT; else generic = true; }
-    if (a.dact_z) { if (a.dact == TFASR_ACT_SWISH) need |= E_DACT; else generic = true; }
+    if (a.dact_z) { if (a.dact == TFASR_ACT_SWISH) need |= E_DACT; else if (a.dact == TFASR_ACT_FACTOR) need |= E_MUL; else generic = true; }
     if (a.drop_p > 0.f) need |= E_DROP;
     if (a.res) need |= E_RES;
   }
@@ -1027,6 +1029,7 @@ int launch_one(const tfasr_gemm_args& a, hipStream_t stream) {
       if constexpr (!TA && TB) {
         if (need == E_DACT) return launch_epi<TA, TB, 64, E_DACT>(a, grid, stream);
         if (need == (E_DACT | E_DROP)) return launch_epi<TA, TB, 64, E_DACT | E_DROP>(a, grid, stream);
+        if (need == E_MUL) return launch_epi<TA, TB, 64, E_MUL>(a, grid, stream);
       }
     }
     return launch_epi<TA, TB, 64, E_GEN>(a, grid, stream);
@@ -1066,6 +1069,7 @@ int launch_one(const tfasr_gemm_args& a, hipStream_t stream) {
     if constexpr (!TA && TB) {  // data gradients (dy @ W^T)
       if (need == E_DACT) return launch_epi<TA, TB, 128, E_DACT>(a, grid, stream);
       if (need == (E_DACT | E_DROP)) return launch_epi<TA, TB, 128, E_DACT | E_DROP>(a, grid, stream);
+      if (need == E_MUL) return launch_epi<TA, TB, 128, E_MUL>(a, grid, stream);
     }
   }
   return launch_epi<TA, TB, 128, E_GEN>(a, grid, stream);
@@ -1181,9 +1185,17 @@ int tfasr_gemm_fast_try(const tfasr_gemm_args& a, hipStream_t stream) {
 
 // ---------------------------------------------------------------------------------------------------------------------
 // FFModule forward in one launch (ffn_fused.h).  UNSUPPORTED outside its shape range: the caller keeps the three-launch route.
+extern "C" int tfasr_ffn_fused_fwd2(const void* x, const float* gamma, const float* beta, const void* W1, const float* b1, const void* W2,
+                                    const float* b2, void* y, void* ln, float* mean, float* rstd, void* z, int z_factor, void* h, long rows, int d, int F,
+                                    float ln_eps, float res_factor, float drop_p, long drop_seed1, long drop_seed2, int dtype, void* stream);
 extern "C" int tfasr_ffn_fused_fwd(const void* x, const float* gamma, const float* beta, const void* W1, const float* b1, const void* W2,
                                    const float* b2, void* y, void* ln, float* mean, float* rstd, void* z, void* h, long rows, int d, int F,
                                    float ln_eps, float res_factor, float drop_p, long drop_seed1, long drop_seed2, int dtype, void* stream) {
+  return tfasr_ffn_fused_fwd2(x, gamma, beta, W1, b1, W2, b2, y, ln, mean, rstd, z, 0, h, rows, d, F, ln_eps, res_factor, drop_p, drop_seed1, drop_seed2, dtype, stream);
+}
+extern "C" int tfasr_ffn_fused_fwd2(const void* x, const float* gamma, const float* beta, const void* W1, const float* b1, const void* W2,
+                                    const float* b2, void* y, void* ln, float* mean, float* rstd, void* z, int z_factor, void* h, long rows, int d, int F,
+                                    float ln_eps, float res_factor, float drop_p, long drop_seed1, long drop_seed2, int dtype, void* stream) {
   if (!x || !gamma || !beta || !W1 || !b1 || !W2 || !b2 || !y || !ln || !mean || !rstd || rows <= 0 || d <= 0 || F <= 0) return TFASR_STATUS_INVALID_VALUE;
   if (!(drop_p >= 0.f && drop_p < 1.f)) return TFASR_STATUS_INVALID_VALUE;
   static const bool off = getenv("TFASR_FFN_FUSED") && getenv("TFASR_FFN_FUSED")[0] == '0';
@@ -1194,6 +1206,7 @@ extern "C" int tfasr_ffn_fused_fwd(const void* x, const float* gamma, const floa
   a.x = (const bf16_t*)x; a.gamma = gamma; a.beta = beta; a.W1 = (const bf16_t*)W1; a.b1 = b1; a.W2 = (const bf16_t*)W2; a.b2 = b2;
   a.y = (bf16_t*)y; a.ln = (bf16_t*)ln; a.mean = mean; a.rstd = rstd; a.z = (bf16_t*)z; a.h = (bf16_t*)h;
   a.rows = rows; a.F = F; a.eps = ln_eps; a.res = res_factor; a.drop_p = drop_p; a.seed1 = drop_seed1; a.seed2 = drop_seed2;
+  a.zfactor = z_factor ? 1 : 0;
   a.dbg = nullptr;
 #ifdef TFASR_FFN_TIMING
   static long long* dbg_buf = nullptr;  // probe builds only (tools/hwprobe): 8 cycle sums of workgroup 0, printed by the caller via TFASR_FFN_DBG_DUMP

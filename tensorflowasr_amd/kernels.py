@@ -8,7 +8,7 @@ import os
 import torch
 
 from . import _lib
-from ._lib import ACT_NONE, ACT_SIGMOID, ACT_SWISH, ACT_TANH, ACT_TANH_OUT, TFASR_BF16, TFASR_F32, GemmArgs, check  # noqa: F401
+from ._lib import ACT_FACTOR, ACT_NONE, ACT_SIGMOID, ACT_SWISH, ACT_TANH, ACT_TANH_OUT, TFASR_BF16, TFASR_F32, GemmArgs, check  # noqa: F401
 
 _WS_CACHE = {}
 _SPLITK_WS = False  # k-slices of a split product through a workspace (deterministic sums; measured slower than the f32 atomics: tests set it)
@@ -232,9 +232,10 @@ def layernorm_fwd(x, gamma, beta, eps=1e-3, save_stats=True):
     return y, mean, rstd
 
 
-def ffn_fused_fwd(x, gamma, beta, W1, b1, W2, b2, res_factor, drop_p=0.0, seed1=0, seed2=0, save_z=True, eps=1e-3):
-    """tfasr_ffn_fused_fwd: FFModule forward in one launch.  Returns (y, ln, mean, rstd, z, h), or None when the shape is outside the fused
-    kernel's range (the caller keeps the layernorm + two GEMM route)."""
+def ffn_fused_fwd(x, gamma, beta, W1, b1, W2, b2, res_factor, drop_p=0.0, seed1=0, seed2=0, save_z=True, eps=1e-3, z_factor=False):
+    """tfasr_ffn_fused_fwd2: FFModule forward in one launch.  Returns (y, ln, mean, rstd, z, h), or None when the shape is outside the fused
+    kernel's range (the caller keeps the layernorm + two GEMM route).  z_factor: `z` is the data gradient's factor swish'(z) * mask1 / (1 - p)
+    (use it as dact_z with dact=ACT_FACTOR and no dropout term) instead of the pre-activation."""
     rows, d = x.shape
     F = W1.shape[1]
     y, ln = torch.empty_like(x), torch.empty_like(x)
@@ -242,8 +243,8 @@ def ffn_fused_fwd(x, gamma, beta, W1, b1, W2, b2, res_factor, drop_p=0.0, seed1=
     rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
     z = torch.empty(rows, F, dtype=x.dtype, device=x.device) if save_z else None
     h = torch.empty(rows, F, dtype=x.dtype, device=x.device)
-    st = _L().tfasr_ffn_fused_fwd(_p(x), _p(gamma), _p(beta), _p(W1), _p(b1), _p(W2), _p(b2), _p(y), _p(ln), _p(mean), _p(rstd), _pv(z), _p(h),
-                                  rows, d, F, eps, float(res_factor), float(drop_p), int(seed1), int(seed2), _dt(x), _stream())
+    st = _L().tfasr_ffn_fused_fwd2(_p(x), _p(gamma), _p(beta), _p(W1), _p(b1), _p(W2), _p(b2), _p(y), _p(ln), _p(mean), _p(rstd), _pv(z), int(bool(z_factor)),
+                                   _p(h), rows, d, F, eps, float(res_factor), float(drop_p), int(seed1), int(seed2), _dt(x), _stream())
     if st == _lib.STATUS_UNSUPPORTED:
         return None
     check(st, "ffn_fused_fwd")

@@ -731,6 +731,38 @@ def test_depthwise_data_gradient_with_glu_backward_fused(dev):
     assert err <= 2e-2 * ref.float().abs().max().item() + 1e-3, err
 
 
+@pytest.mark.parametrize("rows,F,p", [(9000, 1024, 0.1), (333, 512, 0.25), (20000, 1024, 0.0)])
+def test_ffn_fused_forward_stores_the_backward_factor(dev, rows, F, p):
+    """tfasr_ffn_fused_fwd2 with z_factor: y / ln / h bitwise those of the z-storing launch, the stored factor = swish'(z) * mask1 / (1 - p) of
+    the same bf16 z, and the data gradient of the second Dense layer through it (dact = TFASR_ACT_FACTOR, no dropout term) = the one through
+    z + swish' + the regenerated mask, up to the factor's bf16 rounding (FFModule backward, encoders/conformer.py:101-109)."""
+    bf = torch.bfloat16
+    d = 256
+    g = torch.Generator().manual_seed(rows + F + 7)
+    rnd = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(dev)
+    x, gm, bt = rnd(rows, d).to(bf), 1.0 + 0.1 * rnd(d), 0.1 * rnd(d)
+    W1, b1, W2, b2 = rnd(d, F, sc=1 / 16).to(bf), 0.1 * rnd(F), rnd(F, d, sc=1 / 32).to(bf), 0.1 * rnd(d)
+    s1, s2, res = 201, 202, 0.5
+    y0, ln0, _, _, z0, h0 = K.ffn_fused_fwd(x, gm, bt, W1, b1, W2, b2, res, p, s1, s2)
+    y1, ln1, _, _, g1, h1 = K.ffn_fused_fwd(x, gm, bt, W1, b1, W2, b2, res, p, s1, s2, z_factor=True)
+    assert torch.equal(y0, y1) and torch.equal(ln0, ln1) and torch.equal(h0, h1)
+    ones = torch.ones(rows, F, dtype=bf, device=dev)
+    m1 = K.dropout(ones, p, s1).float() if p > 0 else ones.float()
+    zf = z0.float()
+    sg = torch.sigmoid(zf)
+    g_ref = sg * (1.0 + zf * (1.0 - sg)) * m1
+    torch.testing.assert_close(g1.float(), g_ref, rtol=1e-2, atol=1e-2)
+    dy = rnd(rows, d, sc=0.3).to(bf)
+    dz0 = torch.empty(rows, F, dtype=bf, device=dev)
+    dz1 = torch.empty(rows, F, dtype=bf, device=dev)
+    K.gemm(dy, W2, dz0, rows, F, d, d, d, F, trans_b=True, alpha=res, dact_z=z0, dact=K.ACT_SWISH, drop_p=p, drop_seed=s1)
+    K.gemm(dy, W2, dz1, rows, F, d, d, d, F, trans_b=True, alpha=res, dact_z=g1, dact=K.ACT_FACTOR)
+    ref = res * (dy.float() @ W2.float().t()) * g_ref
+    scale = float(ref.abs().max())
+    torch.testing.assert_close(dz1.float(), ref, rtol=2e-2, atol=1e-2 * scale)
+    torch.testing.assert_close(dz1.float(), dz0.float(), rtol=2e-2, atol=1e-2 * scale)
+
+
 @pytest.mark.parametrize("rows,F,p", [(200, 1024, 0.1), (64, 256, 0.0), (333, 512, 0.25)])
 def test_ffn_fused_fwd_matches_the_three_launch_arithmetic(dev, rows, F, p):
     """tfasr_ffn_fused_fwd (FFModule.call, encoders/conformer.py:101-109) against the same
