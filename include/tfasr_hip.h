@@ -51,7 +51,7 @@
 extern "C" {
 #endif
 
-#define TFASR_ABI_VERSION 39
+#define TFASR_ABI_VERSION 40
 
 typedef enum {
   TFASR_STATUS_SUCCESS = 0,
@@ -319,6 +319,11 @@ int tfasr_dwconv_fwd(const void* x, const float* w, const float* bias, void* y, 
  * consumer - tfasr_bn_finalize_apply_fwd_copies - adds the copies up).  UNSUPPORTED (f32, C % 8 != 0, K > 32, unaligned): the two calls. */
 int tfasr_dwconv_fwd_stats(const void* x, const float* w, const float* bias, void* y, float* stats, int ncopy, int B, int T, int C, int K,
                            int dtype, void* stream);
+/* ... with the GLU in front of the conv (ConvModule, conformer.py:300-313) in the same launch: glu_x [B*T, 2C] -> g = a * sigmoid(b)
+ * [B*T, C] (written: the depthwise weight gradient's operand; bitwise tfasr_glu_fwd) -> y, stats.  UNSUPPORTED (f32, C % 8, K <= 8 or
+ * > 32, unaligned): tfasr_glu_fwd + tfasr_dwconv_fwd_stats. */
+int tfasr_glu_dwconv_fwd_stats(const void* glu_x, void* g, const float* w, const float* bias, void* y, float* stats, int ncopy, int B, int T,
+                               int C, int K, int dtype, void* stream);
 int tfasr_dwconv_bwd_data(const void* dy, const float* w, void* dx, int B, int T, int C, int K, int dtype, void* stream);
 /* data gradient followed by the backward of the GLU in front of the conv (glu_x = the GLU's input [B*T, 2C], dglu = its gradient) in
  * one launch; TFASR_STATUS_UNSUPPORTED (f32, C % 8 != 0, K > 32): call tfasr_dwconv_bwd_data + tfasr_glu_bwd instead */

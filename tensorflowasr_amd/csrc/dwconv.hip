@@ -92,12 +92,16 @@ __device__ __forceinline__ void dw_all(float2_t (&acc)[TT], const float2_t (&wk)
 // of the bf16-ROUNDED outputs (what tfasr_bn_stats would read back), added into stats[copy][2][C] with copy = block index % ncopy: with one
 // copy the 600-odd workgroups of a launch queue on the same 512 addresses (a serial chain of ~30 ns links: 27.8 us against 15.8 + 11.2 us
 // for the two launches, round 5); spread over 8 copies the chain is 2 us long and hides under the launch.  The consumer adds the copies up.
-template <bool REV, bool GLU = false, int KB = MAXK, bool STATS = false>
+// GIN (forward only): the input is the GLU of `x` = [rows, 2C] (a | b halves, glu.py:25-28) - the staging pass forms g = a * sigmoid(b)
+// (the arithmetic of glu_fwd_kernel, bitwise) on its way into LDS and the workgroup stores the rows it owns to `gx_out` [rows, C] (the
+// weight gradient's operand): the GLU launch and one read of g are gone; the halo rows are gated twice (K - 1 of 2 TGD + K - 1 staged rows).
+template <bool REV, bool GLU = false, int KB = MAXK, bool STATS = false, bool GIN = false>
 __global__ __launch_bounds__(256) void dwconv_tile_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w,
                                                           const float* __restrict__ bias, bf16_t* __restrict__ y, int Tn, int C, int K,
                                                           const bf16_t* __restrict__ gx = nullptr, float* __restrict__ stats = nullptr,
-                                                          int ncopy = 1) {
+                                                          int ncopy = 1, bf16_t* __restrict__ gx_out = nullptr) {
   static_assert(!STATS || (!REV && !GLU), "statistics ride on the forward kernel");
+  static_assert(!GIN || (!REV && !GLU), "the gated input belongs to the forward kernel");
   extern __shared__ __attribute__((aligned(16))) char lds[];  // (2*TGD + KB - 1) rows; rows past K-1+2*TGD stay zero-weighted
   const int c0 = blockIdx.x * SLAB;
   const int t0 = blockIdx.y * (2 * TGD);
@@ -115,7 +119,42 @@ __global__ __launch_bounds__(256) void dwconv_tile_kernel(const bf16_t* __restri
     const float2_t v = *reinterpret_cast<const float2_t*>(w + kk * C + cc);
     wk[k] = (k < K) ? v : float2_t{0.f, 0.f};
   }
-  stage_rows<2 * TGD + KB - 1>(lds, x, ubase, tin0, Tn, C, c0);
+  if constexpr (GIN) {
+    constexpr int NR = 2 * TGD + KB - 1, TOT = NR * (SLAB / 8), NIT = (TOT + 255) / 256;
+    uint4 va[NIT], vb[NIT];
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {  // one batch of loads: the a and b pieces of every staged row
+      const int id = threadIdx.x + 256 * i;
+      const int row = id / (SLAB / 8), ch = (id % (SLAB / 8)) * 8;
+      const int ti = tin0 + row;
+      va[i] = make_uint4(0, 0, 0, 0); vb[i] = make_uint4(0, 0, 0, 0);
+      if (id < TOT && ti >= 0 && ti < Tn && c0 + ch < C) {
+        const bf16_t* pa = x + 2 * ubase + (long)ti * 2 * C + c0 + ch;
+        va[i] = *reinterpret_cast<const uint4*>(pa);
+        vb[i] = *reinterpret_cast<const uint4*>(pa + C);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      const int id = threadIdx.x + 256 * i;
+      const int row = id / (SLAB / 8), ch = (id % (SLAB / 8)) * 8;
+      const int ti = tin0 + row;
+      const uint32_t ua[4] = {va[i].x, va[i].y, va[i].z, va[i].w}, ub[4] = {vb[i].x, vb[i].y, vb[i].z, vb[i].w};
+      uint32_t ug[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float a0 = __uint_as_float(ua[q] << 16), a1 = __uint_as_float(ua[q] & 0xffff0000u);
+        const float b0 = __uint_as_float(ub[q] << 16), b1 = __uint_as_float(ub[q] & 0xffff0000u);
+        ug[q] = pack2_bf16(a0 * sigmoidf_(b0), a1 * sigmoidf_(b1));
+      }
+      const uint4 gv = make_uint4(ug[0], ug[1], ug[2], ug[3]);
+      if (id < TOT) *reinterpret_cast<uint4*>(lds + row * ROWB + ch * 2) = gv;
+      // rows this workgroup owns (its output steps; the K - 1 rows in front belong to its predecessor)
+      if (id < TOT && ti >= t0 && ti < t0 + 2 * TGD && ti < Tn && c0 + ch < C) *reinterpret_cast<uint4*>(gx_out + ubase + (long)ti * C + c0 + ch) = gv;
+    }
+  } else {
+    stage_rows<2 * TGD + KB - 1>(lds, x, ubase, tin0, Tn, C, c0);
+  }
   // GLU variant: the a | b halves of this thread's 32 output rows are fetched NOW (packed pairs, rows clamped into the tensor), in
   // flight under the LDS staging and the tap loop; loaded inside the store loop each row was its own dependent round trip
   // (load a, b -> sigmoid -> two stores, 32 times in a row: 30 us for a 12 us stream)
@@ -404,6 +443,18 @@ extern "C" int tfasr_dwconv_fwd_stats(const void* x, const float* w, const float
   else
     TFASR_KLAUNCH((dwconv_tile_kernel<false, false, MAXK, true>), grid, dim3(256), (2 * TGD + MAXK - 1) * ROWB, s, (const bf16_t*)x, w, bias, (bf16_t*)y, T, C, K,
                   (const bf16_t*)nullptr, stats, ncopy);
+  TFASR_CHECK_LAUNCH();
+  return TFASR_STATUS_SUCCESS;
+}
+
+// GLU + forward + BatchNorm statistics: glu_x [B*T, 2C] -> g [B*T, C] (stored for the backward) -> y, stats as tfasr_dwconv_fwd_stats
+extern "C" int tfasr_glu_dwconv_fwd_stats(const void* glu_x, void* g, const float* w, const float* bias, void* y, float* stats, int ncopy, int B, int T,
+                                          int C, int K, int dtype, void* stream_) {
+  if (!glu_x || !g || !w || !y || !stats || ncopy <= 0 || B <= 0 || T <= 0 || C <= 0 || K <= 0) return TFASR_STATUS_INVALID_VALUE;
+  if (dtype != TFASR_BF16 || (C & 7) || K > MAXK || K <= 8 || !al16(glu_x) || !al16(g) || !al16(y)) return TFASR_STATUS_UNSUPPORTED;
+  dim3 grid((C + SLAB - 1) / SLAB, (T + 2 * TGD - 1) / (2 * TGD), B);
+  TFASR_KLAUNCH((dwconv_tile_kernel<false, false, MAXK, true, true>), grid, dim3(256), (2 * TGD + MAXK - 1) * ROWB, (hipStream_t)stream_, (const bf16_t*)glu_x, w, bias,
+                (bf16_t*)y, T, C, K, (const bf16_t*)nullptr, stats, ncopy, (bf16_t*)g);
   TFASR_CHECK_LAUNCH();
   return TFASR_STATUS_SUCCESS;
 }

@@ -419,6 +419,20 @@ def dwconv_fwd_stats(x, w, bias, stats):
     return y
 
 
+def glu_dwconv_fwd_stats(glu_x, w, bias, stats):
+    """GLU + depthwise conv + BatchNorm statistics in one launch: glu_x [B, T, 2C] -> (g [B, T, C], y [B, T, C]); stats [copies, 2C] is
+    accumulated into.  None when the fused kernel does not take the shape (glu_fwd + dwconv_fwd_stats)."""
+    B, T, C2 = glu_x.shape
+    C = C2 // 2
+    g = torch.empty(B, T, C, dtype=glu_x.dtype, device=glu_x.device)
+    y = torch.empty_like(g)
+    st = _L().tfasr_glu_dwconv_fwd_stats(_p(glu_x), _p(g), _p(w), _p(bias), _p(y), _p(stats), int(stats.numel() // (2 * C)), B, T, C, w.shape[0], _dt(glu_x), _stream())
+    if st == _lib.STATUS_UNSUPPORTED:
+        return None
+    check(st, "glu_dwconv_fwd_stats")
+    return g, y
+
+
 def dwconv_bwd_data(dy, w):
     B, T, C = dy.shape
     dx = torch.empty_like(dy)

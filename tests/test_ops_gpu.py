@@ -268,6 +268,27 @@ def test_dwconv_forward_with_batchnorm_statistics(dev, Kk, C, T, copies):
     cmp(outs[1][0], outs[0][0], rtol=2e-2, atol=2e-2)
 
 
+@pytest.mark.parametrize("Kk,C,T,copies", [(32, 256, 157, 8), (31, 144, 53, 4), (15, 512, 33, 2)])
+def test_glu_depthwise_conv_and_statistics_in_one_launch(dev, Kk, C, T, copies):
+    """tfasr_glu_dwconv_fwd_stats against the three launches it replaces (tfasr_glu_fwd, tfasr_dwconv_fwd, tfasr_bn_stats): gated input and
+    conv output bitwise, statistics up to the order of the f32 additions (ConvModule, encoders/conformer.py:300-333)."""
+    g = torch.Generator().manual_seed(500 + Kk + T)
+    B = 4
+    gx = (torch.randn(B, T, 2 * C, generator=g) * 1.2).to(dev).to(torch.bfloat16)
+    w, b = (torch.randn(Kk, C, generator=g) * 0.3).to(dev), (torch.randn(C, generator=g) * 0.1).to(dev)
+    g0 = K.glu_fwd(gx.view(B * T, 2 * C)).view(B, T, C)
+    y0 = K.dwconv_fwd(g0, w, b)
+    st0 = torch.zeros(2 * C, device=dev)
+    K.bn_stats(y0.view(B * T, C), st0)
+    st = torch.zeros(copies, 2 * C, device=dev)
+    out = K.glu_dwconv_fwd_stats(gx, w, b, st)
+    assert out is not None
+    g1, y1 = out
+    assert torch.equal(g0, g1)
+    assert torch.equal(y0, y1)
+    cmp(st.sum(0), st0, rtol=1e-4, atol=1e-2)
+
+
 @pytest.mark.parametrize("rows,C,copies", [(12 * 256 + 37, 256, 8), (9000, 256, 1), (40000, 128, 4)])
 def test_gemm_epilogue_batchnorm_backward_sums(dev, rows, C, copies):
     """tfasr_gemm_args.bns_*: the data gradient of the ConvModule's second pointwise conv with the BatchNorm backward sums in its epilogue

@@ -1,6 +1,6 @@
 #!/bin/bash
 # per-phase cycle sums of the fused FFN forward (probe build with -DTFASR_FFN_TIMING, see tools/README.md)
-for n in 3; do for rows in 19072; do
+for n in 2; do for rows in 19072 14784; do
 echo "=== MR $n rows $rows"
 TFASR_LIB=$PWD/tools/hwprobe/libtfasr_probe.so TFASR_FFN_MR=$n TFASR_FFN_DBG_DUMP=1 timeout 120 python - <<PY 2>&1 | grep ffn_timing | tail -2
 import sys, torch
