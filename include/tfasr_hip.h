@@ -51,7 +51,7 @@
 extern "C" {
 #endif
 
-#define TFASR_ABI_VERSION 40
+#define TFASR_ABI_VERSION 41
 
 typedef enum {
   TFASR_STATUS_SUCCESS = 0,
@@ -319,6 +319,13 @@ int tfasr_dwconv_fwd(const void* x, const float* w, const float* bias, void* y, 
  * consumer - tfasr_bn_finalize_apply_fwd_copies - adds the copies up).  UNSUPPORTED (f32, C % 8 != 0, K > 32, unaligned): the two calls. */
 int tfasr_dwconv_fwd_stats(const void* x, const float* w, const float* bias, void* y, float* stats, int ncopy, int B, int T, int C, int K,
                            int dtype, void* stream);
+/* ConvModule backward between the two pointwise convs in ONE launch (conformer.py:300-333): the BatchNorm backward's apply pass
+ * (tfasr_bn_apply_bwd_grads_copies with act = swish: dcv = gradient w.r.t. the depthwise conv's output, WRITTEN - the depthwise weight
+ * gradient's operand - and dgamma / dbeta accumulated), the depthwise data gradient and the GLU backward (tfasr_dwconv_bwd_data_glu).
+ * bn_x = the BatchNorm input, dsw = the gradient w.r.t. its swish output, both [B*T, C].  UNSUPPORTED: the two calls. */
+int tfasr_bn_dwconv_bwd_data_glu(const void* bn_x, const void* dsw, const float* fin, const float* bstats, int copies, float count, float* dgamma,
+                                 float* dbeta, float grad_scale, void* dcv, const float* w, const void* glu_x, void* dglu, int B, int T, int C,
+                                 int K, int dtype, void* stream);
 /* ... with the GLU in front of the conv (ConvModule, conformer.py:300-313) in the same launch: glu_x [B*T, 2C] -> g = a * sigmoid(b)
  * [B*T, C] (written: the depthwise weight gradient's operand; bitwise tfasr_glu_fwd) -> y, stats.  UNSUPPORTED (f32, C % 8, K <= 8 or
  * > 32, unaligned): tfasr_glu_fwd + tfasr_dwconv_fwd_stats. */

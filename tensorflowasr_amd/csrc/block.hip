@@ -302,6 +302,7 @@ struct Ex {
   }
 
   // ------------------------------------------------------------------------------------------ FFModule
+  static bool bn_in_conv() { return true; }   // (32.9 us against 20.0 + 19.6 for the two launches; step -0.03 ms, 4 pairs on one box)
   static bool glu_in_conv() { return true; }  // (18.1 us against 6.4 + 13.2 for the two launches; step -0.04 ms, 4 pairs on one box)
   static bool ffn_factor() { return true; }  // (same-box A/B against storing z: -0.16 ms per step, profiles/r06_ab/ffn_backward_factor.txt)
   void ffm_fwd(int m, const void* x, void* y, int site) {
@@ -648,11 +649,17 @@ struct Ex {
     void* da = act(scratch, rows * 2 * d);
     void* dln = act(scratch, rows * d);
     void* dyn = c->dw_norm_layer ? act(scratch, rows * d) : nullptr;
+    int bn_fused = TFASR_STATUS_UNSUPPORTED;
     if (!dry) {
       if (c->dw_norm_layer) {
         chk(tfasr_add_act_bwd(k->cv_y, nullptr, k->bw_dsw, dyn, rows * d, TFASR_ACT_SWISH, c->dtype, s));
         chk(tfasr_layernorm_bwd(dyn, k->cv_cv, fp(TFASR_BP_CV_BN_G), k->cv_nmean, k->cv_nrstd, nullptr, dcv, gp(TFASR_BP_CV_BN_G), gp(TFASR_BP_CV_BN_B), rows, d,
                                 c->dtype, s));
+      } else if (bn_in_conv() && c->dtype == TFASR_BF16 &&
+                 (bn_fused = tfasr_bn_dwconv_bwd_data_glu(k->cv_cv, k->bw_dsw, k->cv_fin, io->bn_bstats, bn_copies(), (float)(rows * c->world), gp(TFASR_BP_CV_BN_G),
+                                                         gp(TFASR_BP_CV_BN_B), 1.f / (float)c->world, dcv, fp(TFASR_BP_CV_DW_W), k->cv_a, da, c->B, c->T, d, c->ksize,
+                                                         c->dtype, s)) != TFASR_STATUS_UNSUPPORTED) {
+        chk(bn_fused);  // BatchNorm apply pass + depthwise data gradient + GLU backward as one launch (dcv written for the weight gradient)
       } else {
         // bstats = (sum dz, sum dz xhat) over the GLOBAL batch = the beta / gamma gradients; the flat-gradient all-reduce sums over ranks again
         chk(tfasr_bn_apply_bwd_grads_copies(k->cv_cv, k->bw_dsw, k->cv_fin, io->bn_bstats, bn_copies(), (float)(rows * c->world), dcv, rows, d, TFASR_ACT_SWISH,
@@ -661,7 +668,8 @@ struct Ex {
       if (!dw_deferred)
         chk(tfasr_dwconv_bwd_weight_ws(k->cv_g, dcv, gp(TFASR_BP_CV_DW_W), gp(TFASR_BP_CV_DW_B), c->B, c->T, d, c->ksize, c->dtype, dwws, dwws_bytes, s));
       // depthwise data gradient + GLU backward in one launch when the channel-pair kernel applies
-      const int fst = tfasr_dwconv_bwd_data_glu(dcv, fp(TFASR_BP_CV_DW_W), k->cv_a, da, c->B, c->T, d, c->ksize, c->dtype, s);
+      const int fst = bn_fused == TFASR_STATUS_SUCCESS ? TFASR_STATUS_SUCCESS
+                                                        : tfasr_dwconv_bwd_data_glu(dcv, fp(TFASR_BP_CV_DW_W), k->cv_a, da, c->B, c->T, d, c->ksize, c->dtype, s);
       if (fst == TFASR_STATUS_UNSUPPORTED) {
         chk(tfasr_dwconv_bwd_data(dcv, fp(TFASR_BP_CV_DW_W), dg, c->B, c->T, d, c->ksize, c->dtype, s));
         chk(tfasr_glu_bwd(k->cv_a, dg, da, rows, d, c->dtype, s));

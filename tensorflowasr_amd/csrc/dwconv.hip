@@ -92,14 +92,20 @@ __device__ __forceinline__ void dw_all(float2_t (&acc)[TT], const float2_t (&wk)
 // of the bf16-ROUNDED outputs (what tfasr_bn_stats would read back), added into stats[copy][2][C] with copy = block index % ncopy: with one
 // copy the 600-odd workgroups of a launch queue on the same 512 addresses (a serial chain of ~30 ns links: 27.8 us against 15.8 + 11.2 us
 // for the two launches, round 5); spread over 8 copies the chain is 2 us long and hides under the launch.  The consumer adds the copies up.
+// BNIN (data gradient + GLU backward only): the input is the BatchNorm backward of the layer behind the conv, formed by the staging pass -
+// d = sc * dz + cb * x + cd with dz = dsw * swish'(sc * x + sh) (the arithmetic of bn_apply_bwd_rows_kernel; x = bn.x the BatchNorm
+// input, dsw = the kernel's `x` argument) from the sums bn.bstats [copies][2][C] - and the rows a workgroup owns are stored to bn.dcv
+// (the depthwise weight gradient's operand).  Workgroup (0, 0, 0) also adds the BatchNorm parameter gradients.
+struct DwBn { const bf16_t* x; const float* fin; const float* bstats; int copies; float inv_count; float* dgamma; float* dbeta; float gscale; bf16_t* dcv; };
 // GIN (forward only): the input is the GLU of `x` = [rows, 2C] (a | b halves, glu.py:25-28) - the staging pass forms g = a * sigmoid(b)
 // (the arithmetic of glu_fwd_kernel, bitwise) on its way into LDS and the workgroup stores the rows it owns to `gx_out` [rows, C] (the
 // weight gradient's operand): the GLU launch and one read of g are gone; the halo rows are gated twice (K - 1 of 2 TGD + K - 1 staged rows).
-template <bool REV, bool GLU = false, int KB = MAXK, bool STATS = false, bool GIN = false>
+template <bool REV, bool GLU = false, int KB = MAXK, bool STATS = false, bool GIN = false, bool BNIN = false>
 __global__ __launch_bounds__(256) void dwconv_tile_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w,
                                                           const float* __restrict__ bias, bf16_t* __restrict__ y, int Tn, int C, int K,
                                                           const bf16_t* __restrict__ gx = nullptr, float* __restrict__ stats = nullptr,
-                                                          int ncopy = 1, bf16_t* __restrict__ gx_out = nullptr) {
+                                                          int ncopy = 1, bf16_t* __restrict__ gx_out = nullptr, const DwBn bn = DwBn{}) {
+  static_assert(!BNIN || (REV && GLU), "the BatchNorm backward in the staging pass belongs to the data-gradient kernel");
   static_assert(!STATS || (!REV && !GLU), "statistics ride on the forward kernel");
   static_assert(!GIN || (!REV && !GLU), "the gated input belongs to the forward kernel");
   extern __shared__ __attribute__((aligned(16))) char lds[];  // (2*TGD + KB - 1) rows; rows past K-1+2*TGD stay zero-weighted
@@ -151,6 +157,77 @@ __global__ __launch_bounds__(256) void dwconv_tile_kernel(const bf16_t* __restri
       if (id < TOT) *reinterpret_cast<uint4*>(lds + row * ROWB + ch * 2) = gv;
       // rows this workgroup owns (its output steps; the K - 1 rows in front belong to its predecessor)
       if (id < TOT && ti >= t0 && ti < t0 + 2 * TGD && ti < Tn && c0 + ch < C) *reinterpret_cast<uint4*>(gx_out + ubase + (long)ti * C + c0 + ch) = gv;
+    }
+  } else if constexpr (BNIN) {
+    constexpr int NR = 2 * TGD + KB - 1, TOT = NR * (SLAB / 8), NIT = (TOT + 255) / 256;
+    uint4 vx[NIT], vd[NIT];
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {  // one batch of loads: the BatchNorm input and the incoming gradient of every staged row
+      const int id = threadIdx.x + 256 * i;
+      const int row = id / (SLAB / 8), ch = (id % (SLAB / 8)) * 8;
+      const int ti = tin0 + row;
+      vx[i] = make_uint4(0, 0, 0, 0); vd[i] = make_uint4(0, 0, 0, 0);
+      if (id < TOT && ti >= 0 && ti < Tn && c0 + ch < C) {
+        vx[i] = *reinterpret_cast<const uint4*>(bn.x + ubase + (long)ti * C + c0 + ch);
+        vd[i] = *reinterpret_cast<const uint4*>(x + ubase + (long)ti * C + c0 + ch);
+      }
+    }
+    // the sums of this slab's channels, copies added up through LDS (thread u: four consecutive floats of the 2 x SLAB sums)
+    const int chq = (threadIdx.x % (SLAB / 8)) * 8;  // (every piece of a thread covers the same 8 channels)
+    float* sred = reinterpret_cast<float*>(lds);
+    if (threadIdx.x < 2 * SLAB / 4) {
+      const int q4 = threadIdx.x * 4, half = q4 / SLAB, cl = q4 - half * SLAB;
+      float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (c0 + cl < C)
+        for (int q = 0; q < bn.copies; ++q) {
+          const float4 t = *reinterpret_cast<const float4*>(bn.bstats + (size_t)q * 2 * C + (size_t)half * C + c0 + cl);
+          a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
+        }
+      *reinterpret_cast<float4*>(sred + q4) = a;
+    }
+    __syncthreads();
+    float sc[8], sh[8], cb[8], cd[8];
+    {
+      const int cq = min(c0 + chq, C - 8);
+      float mean[8], rstd[8], s0[8], s1[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        mean[q] = bn.fin[cq + q]; rstd[q] = bn.fin[C + cq + q]; sc[q] = bn.fin[2 * C + cq + q]; sh[q] = bn.fin[3 * C + cq + q];
+        s0[q] = sred[chq + q]; s1[q] = sred[SLAB + chq + q];
+      }
+      if (blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x < SLAB / 8 && c0 + chq < C) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          if (bn.dbeta) bn.dbeta[c0 + chq + q] += bn.gscale * s0[q];
+          if (bn.dgamma) bn.dgamma[c0 + chq + q] += bn.gscale * s1[q];
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const float qq = sc[q] * rstd[q] * s1[q] * bn.inv_count;
+        cb[q] = -qq;
+        cd[q] = qq * mean[q] - sc[q] * s0[q] * bn.inv_count;
+      }
+    }
+    __syncthreads();  // the sums are read: the staging rows may be written
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      const int id = threadIdx.x + 256 * i;
+      const int row = id / (SLAB / 8), ch = (id % (SLAB / 8)) * 8;
+      const int ti = tin0 + row;
+      const bool in = id < TOT && ti >= 0 && ti < Tn && c0 + ch < C;
+      const uint32_t ux[4] = {vx[i].x, vx[i].y, vx[i].z, vx[i].w}, ud[4] = {vd[i].x, vd[i].y, vd[i].z, vd[i].w};
+      uint32_t uo[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float x0 = __uint_as_float(ux[q] << 16), x1 = __uint_as_float(ux[q] & 0xffff0000u);
+        const float d0 = __uint_as_float(ud[q] << 16), d1 = __uint_as_float(ud[q] & 0xffff0000u);
+        const float dz0 = d0 * dswishf_(x0 * sc[2 * q] + sh[2 * q]), dz1 = d1 * dswishf_(x1 * sc[2 * q + 1] + sh[2 * q + 1]);
+        uo[q] = pack2_bf16(sc[2 * q] * dz0 + cb[2 * q] * x0 + cd[2 * q], sc[2 * q + 1] * dz1 + cb[2 * q + 1] * x1 + cd[2 * q + 1]);
+      }
+      const uint4 ov = in ? make_uint4(uo[0], uo[1], uo[2], uo[3]) : make_uint4(0, 0, 0, 0);  // rows outside the utterance contribute nothing
+      if (id < TOT) *reinterpret_cast<uint4*>(lds + row * ROWB + ch * 2) = ov;
+      if (in && ti < t0 + 2 * TGD) *reinterpret_cast<uint4*>(bn.dcv + ubase + (long)ti * C + c0 + ch) = ov;
     }
   } else {
     stage_rows<2 * TGD + KB - 1>(lds, x, ubase, tin0, Tn, C, c0);
@@ -443,6 +520,23 @@ extern "C" int tfasr_dwconv_fwd_stats(const void* x, const float* w, const float
   else
     TFASR_KLAUNCH((dwconv_tile_kernel<false, false, MAXK, true>), grid, dim3(256), (2 * TGD + MAXK - 1) * ROWB, s, (const bf16_t*)x, w, bias, (bf16_t*)y, T, C, K,
                   (const bf16_t*)nullptr, stats, ncopy);
+  TFASR_CHECK_LAUNCH();
+  return TFASR_STATUS_SUCCESS;
+}
+
+// BatchNorm backward (apply pass + parameter gradients) + depthwise data gradient + GLU backward in one launch; UNSUPPORTED -> the caller runs
+// tfasr_bn_apply_bwd_grads_copies and tfasr_dwconv_bwd_data_glu
+extern "C" int tfasr_bn_dwconv_bwd_data_glu(const void* bn_x, const void* dsw, const float* fin, const float* bstats, int copies, float count, float* dgamma,
+                                            float* dbeta, float grad_scale, void* dcv, const float* w, const void* glu_x, void* dglu, int B, int T, int C,
+                                            int K, int dtype, void* stream_) {
+  if (!bn_x || !dsw || !fin || !bstats || !dcv || !w || !glu_x || !dglu || copies <= 0 || !(count > 0.f) || B <= 0 || T <= 0 || C <= 0 || K <= 0) return TFASR_STATUS_INVALID_VALUE;
+  if (dtype != TFASR_BF16 || (C & 7) || K > MAXK || !al16(bn_x) || !al16(dsw) || !al16(dcv) || !al16(dglu) || !al4(glu_x) || !al16(bstats) || (C & 3))
+    return TFASR_STATUS_UNSUPPORTED;
+  dim3 grid((C + SLAB - 1) / SLAB, (T + 2 * TGD - 1) / (2 * TGD), B);
+  const int smem = (2 * TGD + MAXK - 1 > 4 * TGD ? 2 * TGD + MAXK - 1 : 4 * TGD) * ROWB;
+  DwBn bn{(const bf16_t*)bn_x, fin, bstats, copies, 1.f / count, dgamma, dbeta, grad_scale, (bf16_t*)dcv};
+  TFASR_KLAUNCH((dwconv_tile_kernel<true, true, MAXK, false, false, true>), grid, dim3(256), smem, (hipStream_t)stream_, (const bf16_t*)dsw, w, (const float*)nullptr,
+                (bf16_t*)dglu, T, C, K, (const bf16_t*)glu_x, (float*)nullptr, 1, (bf16_t*)nullptr, bn);
   TFASR_CHECK_LAUNCH();
   return TFASR_STATUS_SUCCESS;
 }

@@ -419,6 +419,21 @@ def dwconv_fwd_stats(x, w, bias, stats):
     return y
 
 
+def bn_dwconv_bwd_data_glu(bn_x, dsw, fin, bstats, count, w, glu_x, dgamma=None, dbeta=None, grad_scale=1.0):
+    """BatchNorm backward apply pass (swish) + depthwise data gradient + GLU backward in one launch; bstats [copies, 2C].  Returns
+    (dcv [B, T, C], dglu [B, T, 2C]) or None when the fused kernel does not take the shape."""
+    B, T, C = bn_x.shape
+    dcv = torch.empty_like(bn_x)
+    dglu = torch.empty(B, T, 2 * C, dtype=bn_x.dtype, device=bn_x.device)
+    st = _L().tfasr_bn_dwconv_bwd_data_glu(_p(bn_x), _p(dsw), _p(fin), _p(bstats), int(bstats.numel() // (2 * C)), float(count),
+                                           _p(dgamma) if dgamma is not None else None, _p(dbeta) if dbeta is not None else None, float(grad_scale), _p(dcv),
+                                           _p(w), _p(glu_x), _p(dglu), B, T, C, w.shape[0], _dt(bn_x), _stream())
+    if st == _lib.STATUS_UNSUPPORTED:
+        return None
+    check(st, "bn_dwconv_bwd_data_glu")
+    return dcv, dglu
+
+
 def glu_dwconv_fwd_stats(glu_x, w, bias, stats):
     """GLU + depthwise conv + BatchNorm statistics in one launch: glu_x [B, T, 2C] -> (g [B, T, C], y [B, T, C]); stats [copies, 2C] is
     accumulated into.  None when the fused kernel does not take the shape (glu_fwd + dwconv_fwd_stats)."""

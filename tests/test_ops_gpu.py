@@ -289,6 +289,48 @@ def test_glu_depthwise_conv_and_statistics_in_one_launch(dev, Kk, C, T, copies):
     cmp(st.sum(0), st0, rtol=1e-4, atol=1e-2)
 
 
+@pytest.mark.parametrize("Kk,C,T,copies", [(32, 256, 157, 8), (31, 144, 53, 1), (15, 512, 33, 4)])
+def test_batchnorm_backward_depthwise_gradient_and_glu_backward_in_one_launch(dev, Kk, C, T, copies):
+    """tfasr_bn_dwconv_bwd_data_glu against the two launches it replaces (tfasr_bn_apply_bwd_grads_copies with swish, then
+    tfasr_dwconv_bwd_data_glu): dcv bitwise (same arithmetic per element), the GLU gradient bitwise from it, the BatchNorm parameter
+    gradients equal (ConvModule backward, encoders/conformer.py:300-333)."""
+    g = torch.Generator().manual_seed(700 + Kk + T)
+    B = 3
+    bf = torch.bfloat16
+    x = (torch.randn(B, T, C, generator=g) * 1.3 + 0.2).to(dev).to(bf)
+    dsw = (torch.randn(B, T, C, generator=g) * 0.4).to(dev).to(bf)
+    gx = (torch.randn(B, T, 2 * C, generator=g)).to(dev).to(bf)
+    w = (torch.randn(Kk, C, generator=g) * 0.3).to(dev)
+    xf = x.float().view(-1, C)
+    mean, var = xf.mean(0), xf.var(0, unbiased=False)
+    rstd = torch.rsqrt(var + 1e-3)
+    gm, bt = (torch.rand(C, generator=g) + 0.5).to(dev), (torch.randn(C, generator=g) * 0.1).to(dev)
+    fin = torch.cat([mean, rstd, gm * rstd, bt - mean * gm * rstd]).contiguous()
+    st1 = torch.zeros(2 * C, device=dev)
+    K.bn_bwd_stats(x.view(-1, C), dsw.view(-1, C), fin, st1, K.ACT_SWISH)
+    st = torch.zeros(copies, 2 * C, device=dev)
+    st[0] = st1 * 0.25
+    st[-1] += st1 * 0.75
+    count = float(B * T)
+    dg0, db0 = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+    dcv0 = K.bn_apply_bwd(x.view(-1, C), dsw.view(-1, C), fin, st, count, K.ACT_SWISH, dgamma=dg0, dbeta=db0, grad_scale=0.5, copies=copies) if _rows_ok(C) else None
+    if dcv0 is None:
+        dcv0 = K.bn_apply_bwd(x.view(-1, C), dsw.view(-1, C), fin, st.sum(0), count, K.ACT_SWISH, dgamma=dg0, dbeta=db0, grad_scale=0.5)
+    dglu0 = K.dwconv_bwd_data_glu(dcv0.view(B, T, C), w, gx)
+    dg1, db1 = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+    out = K.bn_dwconv_bwd_data_glu(x, dsw, fin, st, count, w, gx, dgamma=dg1, dbeta=db1, grad_scale=0.5)
+    assert out is not None and dglu0 is not None
+    dcv1, dglu1 = out
+    cmp(dcv1.view(-1, C), dcv0, rtol=1e-2, atol=1e-2 * float(dcv0.float().abs().max()))
+    cmp(dglu1, dglu0, rtol=2e-2, atol=2e-2 * float(dglu0.float().abs().max()))
+    cmp(dg1, dg0, rtol=1e-5, atol=1e-5)
+    cmp(db1, db0, rtol=1e-5, atol=1e-5)
+
+
+def _rows_ok(C):
+    return C % 8 == 0 and 64 <= C <= 2048 and 256 % (C // 8) == 0
+
+
 @pytest.mark.parametrize("rows,C,copies", [(12 * 256 + 37, 256, 8), (9000, 256, 1), (40000, 128, 4)])
 def test_gemm_epilogue_batchnorm_backward_sums(dev, rows, C, copies):
     """tfasr_gemm_args.bns_*: the data gradient of the ConvModule's second pointwise conv with the BatchNorm backward sums in its epilogue
