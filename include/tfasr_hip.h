@@ -51,7 +51,7 @@
 extern "C" {
 #endif
 
-#define TFASR_ABI_VERSION 41
+#define TFASR_ABI_VERSION 42
 
 typedef enum {
   TFASR_STATUS_SUCCESS = 0,
@@ -232,6 +232,13 @@ int tfasr_ffn_fused_fwd(const void* x, const float* gamma, const float* beta, co
 int tfasr_ffn_fused_fwd2(const void* x, const float* gamma, const float* beta, const void* W1, const float* b1, const void* W2,
                          const float* b2, void* y, void* ln, float* mean, float* rstd, void* z, int z_factor, void* h, long rows, int d, int F,
                          float ln_eps, float res_factor, float drop_p, long drop_seed1, long drop_seed2, int dtype, void* stream);
+/* LayerNormalization + Dense in ONE launch (the head of MHSAModule / ConvModule, conformer.py:59-64 + the fused q/k/v projection
+ * multihead_attention.py:628-637 / the first pointwise conv convolution.py:159-228): out [rows, N] = LN(x) W + b, ln / mean / rstd
+ * stored as tfasr_layernorm_fwd writes them (row sums in another order: single-ulp differences); out bitwise tfasr_gemm on that ln.
+ * UNSUPPORTED outside bf16 /
+ * d = 256 / N % 64 == 0 / 128 <= N <= 1024 / 16-byte aligned pointers. */
+int tfasr_ln_dense_fwd(const void* x, const float* gamma, const float* beta, const void* W, const float* b, void* out, void* ln, float* mean,
+                       float* rstd, long rows, int d, int N, float ln_eps, int dtype, void* stream);
 int tfasr_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
                         const void* add, void* dx, float* dgamma, float* dbeta, long rows, int C, int dtype,
                         void* stream);

@@ -153,7 +153,7 @@ def load(build_if_missing=True):
     return lib
 
 
-ABI_VERSION = 41
+ABI_VERSION = 42
 
 
 STATUS_UNSUPPORTED = 3

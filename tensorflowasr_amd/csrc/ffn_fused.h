@@ -59,8 +59,12 @@ __device__ __forceinline__ void lds_only_barrier() { asm volatile("s_waitcnt lgk
 // backward's d(4d -> d) product then multiplies by g in its epilogue (gemm_fast E_MUL) instead of recomputing swish' (v_exp + v_rcp + 6)
 // and the dropout hash per element - what bounded that epilogue (53 us per launch against 23 for the bare product).  The row pass has
 // sigmoid(z) and the mask at hand: five more vector instructions per element here.  h is unchanged (same expression as swishf_).
-template <int MR, int WGS, bool ZF = false>  // 16 * MR rows per wave; 4 waves (2 x 2): BMR = 32 * MR rows per workgroup
+// DENSE: only the first half - out = LayerNorm(x) W1 + b1 (`z` = the output [rows, F]; W2 / b2 / h / y unused): the LayerNorm in front of the
+// fused q/k/v projection and of the ConvModule's first pointwise conv with its Dense layer in one launch (tfasr_ln_dense_fwd).  The weight
+// chunks alternate between the two 32-KiB buffers (the W2 buffer is idle), chunk c + 1 is issued at the top of chunk c: two barriers per chunk.
+template <int MR, int WGS, bool ZF = false, bool DENSE = false>  // 16 * MR rows per wave; 4 waves (2 x 2): BMR = 32 * MR rows per workgroup
 __global__ __launch_bounds__(256, WGS) void ffn_fused_fwd_kernel(const FfnArgs p) {
+  static_assert(!DENSE || (WGS == 2 && !ZF), "the Dense-only mode is built on the two-workgroups-per-CU schedule");
 #ifdef TFASR_FFN_TIMING
   long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   long long tp = __builtin_readcyclecounter();
@@ -78,7 +82,7 @@ __global__ __launch_bounds__(256, WGS) void ffn_fused_fwd_kernel(const FfnArgs p
   const long m0 = (long)blockIdx.x * BMR;
   const int F = p.F, NC = F / 64;
   const int nrow_tile = (int)min((long)BMR, p.rows - m0);  // rows of this tile that exist
-  const bool counted = nrow_tile == BMR && p.z != nullptr && p.h != nullptr;  // the store count per chunk is the S = 2 MR the counted waits assume
+  const bool counted = nrow_tile == BMR && p.z != nullptr && (DENSE || p.h != nullptr);  // the store count per chunk is the S = 2 MR the counted waits assume
 
   // per-lane byte offsets of this wave's DMA pieces inside a chunk (loop invariant; the chunk moves the uniform base)
   uint32_t off1[PCS], off2[PCS];
@@ -91,7 +95,7 @@ __global__ __launch_bounds__(256, WGS) void ffn_fused_fwd_kernel(const FfnArgs p
       off2[n] = (uint32_t)((k * D + ((hf * 16 + (pp ^ key_t(k))) << 3)) * 2); }
   }
   auto issue_w1 = [&](int cc) {  // W1[:, 64 cc .. 64 cc + 64) -> W1 buffer cc % 2: slab s = k / 64, image [64 k][64 n] (128-B k-rows)
-    char* base = smem + W1_OFF + (cc & (NBUF - 1)) * 32768;
+    char* base = smem + (DENSE ? ((cc & 1) ? W2_OFF : W1_OFF) : W1_OFF + (cc & (NBUF - 1)) * 32768);
     const char* src = reinterpret_cast<const char*>(p.W1 + min(cc, NC - 1) * 64);
 #pragma unroll
     for (int n = 0; n < PCS; ++n) glds16_s(src, off1[n], base + __builtin_amdgcn_readfirstlane((w + n * NW) * 1024));
@@ -169,7 +173,7 @@ __global__ __launch_bounds__(256, WGS) void ffn_fused_fwd_kernel(const FfnArgs p
   const uint32_t dkey1 = drop_key((uint64_t)p.seed1);  // drop_hash's key (pair indices < 2^32 here)
 
   auto gemm1 = [&](int cc, bool fence = true) {  // acc1 = ln W1[:, cc]: wave tile 32 x 32, K = 256, A from registers
-    const char* sW1 = smem + W1_OFF + (cc & (NBUF - 1)) * 32768;
+    const char* sW1 = smem + (DENSE ? ((cc & 1) ? W2_OFF : W1_OFF) : W1_OFF + (cc & (NBUF - 1)) * 32768);
 #pragma unroll
     for (int i = 0; i < MR; ++i)
 #pragma unroll
@@ -225,6 +229,11 @@ __global__ __launch_bounds__(256, WGS) void ffn_fused_fwd_kernel(const FfnArgs p
       char* sp = sH + row * 128 + ((pp ^ key_d(row)) << 4);
       const uint4 zv = *reinterpret_cast<const uint4*>(sp);
       const int off = row * F + pp * 8;
+      if constexpr (DENSE) {
+        if constexpr (FAST) *reinterpret_cast<uint4*>(zbase + off) = zv;
+        else if (row < nrow_tile) *reinterpret_cast<uint4*>(zbase + off) = zv;
+        continue;
+      }
       if constexpr (!ZF) {
         if constexpr (FAST) *reinterpret_cast<uint4*>(zbase + off) = zv;
         else if (zbase && row < nrow_tile) *reinterpret_cast<uint4*>(zbase + off) = zv;
@@ -284,7 +293,22 @@ __global__ __launch_bounds__(256, WGS) void ffn_fused_fwd_kernel(const FfnArgs p
     }
   };
 
-  if constexpr (WGS == 2) {
+  if constexpr (DENSE) {
+    // the normalised rows are in registers: the LN image (in the second buffer) is dead once every wave holds its fragments
+    lds_only_barrier();
+    if (NC > 1) issue_w1(1);
+    for (int c = 0; c < NC; ++c) {
+      // own pieces of W1(c): issued one chunk ago; only the previous chunk's MR stores were issued after them (c = 0 / 1: drain)
+      if (counted && c > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MR) : "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      lds_only_barrier();   // T: W1(c) visible; every wave is done with rowpass(c-1) (sH) and GEMM1(c-1) (the other buffer)
+      if (c > 0 && c + 1 < NC) issue_w1(c + 1);
+      gemm1(c);
+      zlds(c);
+      lds_only_barrier();   // A: z(c) complete
+      if (counted) rowpass(c, std::true_type{}); else rowpass(c, std::false_type{});
+    }
+    return;
+  } else if constexpr (WGS == 2) {
     for (int c = 0; c < NC; ++c) {
       // own pieces of W1(c): only the last chunk's z / h stores (2 MR instructions) were issued after them
       if (counted && c > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * MR) : "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -433,7 +457,8 @@ static int launch_ffn_fused_fwd(const FfnArgs& a, hipStream_t stream) {
     const long tiles = (a.rows + 32 * MR - 1) / (32 * MR);
     TFASR_KLAUNCH(kern, dim3((unsigned)tiles), dim3(256), smem, stream, a);
   };
-  if (a.zfactor && a.z) go(ffn_fused_fwd_kernel<2, 2, true>, 2, 1);
+  if (a.y == nullptr) go(ffn_fused_fwd_kernel<2, 2, false, true>, 2, 1);  // (Dense-only mode: tfasr_ln_dense_fwd)
+  else if (a.zfactor && a.z) go(ffn_fused_fwd_kernel<2, 2, true>, 2, 1);
   else go(ffn_fused_fwd_kernel<2, 2, false>, 2, 1);
   return TFASR_STATUS_SUCCESS;
 }

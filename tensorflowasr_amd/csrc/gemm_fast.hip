@@ -1226,6 +1226,24 @@ extern "C" int tfasr_ffn_fused_fwd2(const void* x, const float* gamma, const flo
   return st;
 }
 
+// LayerNorm + Dense in one launch: out = LN(x) W + b, with ln / mean / rstd stored as tfasr_layernorm_fwd would (the Dense-only mode of the
+// fused FFModule kernel, ffn_fused.h).  UNSUPPORTED outside bf16 / d = 256 / N % 64 == 0, N <= 1024 / aligned pointers.
+extern "C" int tfasr_ln_dense_fwd(const void* x, const float* gamma, const float* beta, const void* W, const float* b, void* out, void* ln, float* mean,
+                                  float* rstd, long rows, int d, int N, float ln_eps, int dtype, void* stream) {
+  if (!x || !gamma || !beta || !W || !b || !out || !ln || !mean || !rstd || rows <= 0 || d <= 0 || N <= 0) return TFASR_STATUS_INVALID_VALUE;
+  if (dtype != TFASR_BF16 || d != 256 || (N % 64) != 0 || N > 1024 || N < 128 || rows * (long)N >= (1L << 32)) return TFASR_STATUS_UNSUPPORTED;
+  const uintptr_t al = (uintptr_t)x | (uintptr_t)W | (uintptr_t)out | (uintptr_t)ln | (uintptr_t)gamma | (uintptr_t)beta;
+  if (al & 15) return TFASR_STATUS_UNSUPPORTED;
+  FfnArgs a;
+  memset(&a, 0, sizeof(a));
+  a.x = (const bf16_t*)x; a.gamma = gamma; a.beta = beta; a.W1 = (const bf16_t*)W; a.b1 = b;
+  a.y = nullptr; a.ln = (bf16_t*)ln; a.mean = mean; a.rstd = rstd; a.z = (bf16_t*)out; a.h = nullptr;
+  a.rows = rows; a.F = N; a.eps = ln_eps;
+  const int st = launch_ffn_fused_fwd(a, (hipStream_t)stream);
+  TFASR_CHECK_LAUNCH();
+  return st;
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // Dense data gradient + the LayerNorm backward in front of it in one launch (dense_ln.h).  UNSUPPORTED outside its shape range.
 extern "C" int tfasr_dense_ln_bwd(const void* dy, const void* W, int K, const void* x, const float* gamma, const float* mean, const float* rstd,

@@ -251,6 +251,21 @@ def ffn_fused_fwd(x, gamma, beta, W1, b1, W2, b2, res_factor, drop_p=0.0, seed1=
     return y, ln, mean, rstd, z, h
 
 
+def ln_dense_fwd(x, gamma, beta, W, b, eps=1e-3):
+    """tfasr_ln_dense_fwd: out = LayerNorm(x) W + b in one launch.  Returns (out, ln, mean, rstd) or None (shape outside the kernel's range)."""
+    rows, d = x.shape
+    N = W.shape[1]
+    out = torch.empty(rows, N, dtype=x.dtype, device=x.device)
+    ln = torch.empty_like(x)
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    st = _L().tfasr_ln_dense_fwd(_p(x), _p(gamma), _p(beta), _p(W), _p(b), _p(out), _p(ln), _p(mean), _p(rstd), rows, d, N, eps, _dt(x), _stream())
+    if st == _lib.STATUS_UNSUPPORTED:
+        return None
+    check(st, "ln_dense_fwd")
+    return out, ln, mean, rstd
+
+
 def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, add=None, dx=None, dropped=None, drop_p=0.0, drop_seed=0):
     """dropped (optional, same shape as dx): also receives dropout(dx, drop_p, drop_seed) from the same kernel."""
     rows, C = x.numel() // x.shape[-1], x.shape[-1]

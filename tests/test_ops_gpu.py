@@ -794,6 +794,28 @@ def test_depthwise_data_gradient_with_glu_backward_fused(dev):
     assert err <= 2e-2 * ref.float().abs().max().item() + 1e-3, err
 
 
+@pytest.mark.parametrize("rows,N", [(9000, 768), (333, 512), (64, 128), (20011, 512), (15000, 1024)])
+def test_layernorm_and_dense_in_one_launch(dev, rows, N):
+    """tfasr_ln_dense_fwd against tfasr_layernorm_fwd + tfasr_gemm: ln / mean / rstd to the order of the row sums, the Dense output bitwise
+    that of tfasr_gemm on the stored normalised rows (same bf16 operands, same k order), ragged last tile (MHSAModule / ConvModule heads, encoders/conformer.py:59-64)."""
+    bf = torch.bfloat16
+    d = 256
+    g = torch.Generator().manual_seed(rows + N)
+    rnd = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(dev)
+    x, gm, bt = rnd(rows, d).to(bf), 1.0 + 0.1 * rnd(d), 0.1 * rnd(d)
+    W, b = rnd(d, N, sc=1 / 16).to(bf), 0.1 * rnd(N)
+    out = K.ln_dense_fwd(x, gm, bt, W, b)
+    assert out is not None
+    y1, ln1, mean1, rstd1 = out
+    ln0, mean0, rstd0 = K.layernorm_fwd(x, gm, bt)
+    cmp(ln1, ln0, rtol=1e-2, atol=1e-2)          # (the row sums are taken in another order: single bf16 ulps)
+    cmp(mean1, mean0, rtol=1e-5, atol=1e-6)
+    cmp(rstd1, rstd0, rtol=1e-5, atol=1e-6)
+    y0 = torch.empty(rows, N, dtype=bf, device=dev)
+    K.gemm(ln1, W, y0, rows, N, d, d, N, N, bias=b)   # the Dense layer on the launch's own normalised rows: bitwise
+    assert torch.equal(y0, y1)
+
+
 @pytest.mark.parametrize("rows,F,p", [(9000, 1024, 0.1), (333, 512, 0.25), (20000, 1024, 0.0)])
 def test_ffn_fused_forward_stores_the_backward_factor(dev, rows, F, p):
     """tfasr_ffn_fused_fwd2 with z_factor: y / ln / h bitwise those of the z-storing launch, the stored factor = swish'(z) * mask1 / (1 - p) of
