@@ -336,8 +336,11 @@ class ConformerTransducer(BaseModel):
                 full[:slack * width].zero_()
                 full[(slack + rows) * width:].zero_()
                 if tag is not None:
-                    for k in [k for k in self._consts if isinstance(k, tuple) and k[:2] == ("salloc", tag)]:
-                        del self._consts[k]  # another batch shape: the old buffer is not kept
+                    # a few batch shapes are kept per tag (bucketed batches alternate between shapes: with one buffer per tag every step
+                    # re-allocated and re-cleared all of them); the oldest goes when a fifth shape turns up
+                    old = [k for k in self._consts if isinstance(k, tuple) and k[:2] == ("salloc", tag)]
+                    for k in old[:max(0, len(old) - 3)]:
+                        del self._consts[k]
                     self._consts[key] = full
         return full, full[slack * width:(slack + rows) * width].view(rows, width)
 
