@@ -51,7 +51,7 @@
 extern "C" {
 #endif
 
-#define TFASR_ABI_VERSION 42
+#define TFASR_ABI_VERSION 43
 
 typedef enum {
   TFASR_STATUS_SUCCESS = 0,
@@ -197,6 +197,7 @@ typedef struct {
      bns_out[copy][2][N] (workgroup i adds into copy i % bns_copies; the consumer adds the copies up).  bns_x = the BatchNorm input
      [M, N] (compute dtype, row stride ldd). */
   const void* bns_x; const float* bns_fin; float* bns_out; int bns_copies;
+  int bns_c;  /* > 0: the N columns are (position, channel) pairs, channel = column % bns_c (bns_fin [4][bns_c], bns_out [copies][2][bns_c]); 0: N channels */
 } tfasr_gemm_args;
 
 int tfasr_gemm(const tfasr_gemm_args* args, void* stream);

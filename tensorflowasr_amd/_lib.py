@@ -34,7 +34,7 @@ class GemmArgs(Structure):
         ("lse_part", c_void_p), ("lse_parts", c_int), ("row_label", c_void_p), ("pick", c_void_p),
         ("seg_a_off", c_void_p), ("seg_b_off", c_void_p), ("seg_k", c_int),
         ("rgrad_coef", c_void_p),
-        ("bns_x", c_void_p), ("bns_fin", c_void_p), ("bns_out", c_void_p), ("bns_copies", c_int),
+        ("bns_x", c_void_p), ("bns_fin", c_void_p), ("bns_out", c_void_p), ("bns_copies", c_int), ("bns_c", c_int),
     ]
 
 
@@ -153,7 +153,7 @@ def load(build_if_missing=True):
     return lib
 
 
-ABI_VERSION = 42
+ABI_VERSION = 43
 
 
 STATUS_UNSUPPORTED = 3

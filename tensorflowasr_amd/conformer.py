@@ -71,6 +71,7 @@ class ConformerTransducer(BaseModel):
         self.time_reduction_factor = cfg.time_reduction_factor
         self.step = 0
         self._consts = {}
+        self._bn1_sums_in_gemm = True  # subsampling BatchNorm1 backward sums in the linear layer's data gradient
         self._bn_stats_copies = 8  # ConvModule BatchNorm statistics inside the depthwise conv, atomics spread over this many copies; 1: the two launches (tests)
         self._conv1_gram = True  # conv1 / BatchNorm0 sums through the patch Gram matrix (one backward pass); False: the two-pass kernels (tests)
         # SpecAugment draws and dropout masks are per replica (MirroredStrategy draws independent randomness on every
@@ -450,10 +451,27 @@ class ConformerTransducer(BaseModel):
         K.gemm(a2flat[C:], dx0h, ps.g2d("enc/linear/w"), F2 * C, d, B * (T2 + 1), (F2 + 1) * C, d, d, trans_a=True, accumulate=True,
                split_k=_split_k(F2 * C, d, B * (T2 + 1)), colsum=ps.g("enc/linear/b"))
         _, da2 = self._salloc(rows, C, 0)
-        K.gemm(dx0h, ps.w2d("enc/linear/w"), da2.view(-1)[C:], B * (T2 + 1), F2 * C, d, d, d, (F2 + 1) * C, trans_b=True)
+        # the BatchNorm1 backward sums (sum dz, sum dz xhat per channel) in the epilogue of this product - its columns are (frequency,
+        # channel) pairs - instead of a pass of their own over o and da2 (2 x 196 MB at the bench shape)
+        bst, ncp = None, 8
+        if self._bn1_sums_in_gemm and self.dtype == torch.bfloat16 and C % 8 == 0 and 256 % (C // 8) == 0 and 64 <= C <= 2048:
+            bst = self._zeros_f32(ncp * 2 * C)[:ncp * 2 * C].view(ncp, 2 * C)
+            try:
+                K.gemm(dx0h, ps.w2d("enc/linear/w"), da2.view(-1)[C:], B * (T2 + 1), F2 * C, d, d, d, (F2 + 1) * C, trans_b=True,
+                       bns=(s["o"].view(-1)[C:], s["bn1"][0], bst, C))
+            except K._lib.TfasrUnsupported:
+                bst = None
+        if bst is None:
+            K.gemm(dx0h, ps.w2d("enc/linear/w"), da2.view(-1)[C:], B * (T2 + 1), F2 * C, d, d, d, (F2 + 1) * C, trans_b=True)
         K.halo_zero(da2, B, T2, F2, C)
         do_full, do = self._salloc(rows, C, slack, tag="do")
-        self._bn_bwd(s["o"], da2, "enc/sub/bn1", s["bn1"], ACT_SWISH, dx=do)
+        if bst is None:
+            self._bn_bwd(s["o"], da2, "enc/sub/bn1", s["bn1"], ACT_SWISH, dx=do)
+        else:
+            fin1, count1 = s["bn1"]
+            self.dp.allreduce_stats_(bst.view(-1))
+            K.bn_apply_bwd(s["o"], da2, fin1, bst, count1, ACT_SWISH, dx=do, dgamma=ps.g("enc/sub/bn1/g"), dbeta=ps.g("enc/sub/bn1/b"),
+                           grad_scale=1.0 / self.dp.world, copies=ncp)
         K.halo_zero(do, B, T2, F2, C)
         # conv2 weight gradient: 9 products gW[tap] += a1[rows shifted by the tap]^T @ do; bias gradient = column sums of do
         a1_full, base = s["a1_full"], slack * 4 * C

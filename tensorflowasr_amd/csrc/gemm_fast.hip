@@ -610,14 +610,18 @@ __device__ __forceinline__ void gemm_fast_body(const tfasr_gemm_args& p, const i
       // of all its rows are requested in one batch in front of the strips
       [[maybe_unused]] float bs0[C_BNS ? 8 : 1], bs1[C_BNS ? 8 : 1], fsc[C_BNS ? 8 : 1], fsh[C_BNS ? 8 : 1], frs[C_BNS ? 8 : 1], fm2[C_BNS ? 8 : 1];
       [[maybe_unused]] uint4 bnx[C_BNS ? 4 : 1][C_BNS ? NPASS : 1];
+      // (bns_c channels: column n of the product belongs to channel n % bns_c - the subsampling's linear layer, whose columns are
+      // (frequency, channel) pairs; 0 = one channel per column)
+      [[maybe_unused]] const int bnc = C_BNS ? (p.bns_c > 0 ? p.bns_c : p.N) : 0;
+      [[maybe_unused]] const int bcol = C_BNS ? col0 % bnc : 0;
       if constexpr (C_BNS) {
         const bool cok = col0 + 8 <= p.N;
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
           bs0[q] = 0.f; bs1[q] = 0.f;
-          const int cc = cok ? col0 + q : 0;
-          const float mean = p.bns_fin[cc], rstd = p.bns_fin[p.N + cc];
-          fsc[q] = p.bns_fin[2 * p.N + cc]; fsh[q] = p.bns_fin[3 * p.N + cc]; frs[q] = rstd; fm2[q] = -mean * rstd;
+          const int cc = cok ? bcol + q : 0;
+          const float mean = p.bns_fin[cc], rstd = p.bns_fin[bnc + cc];
+          fsc[q] = p.bns_fin[2 * bnc + cc]; fsh[q] = p.bns_fin[3 * bnc + cc]; frs[q] = rstd; fm2[q] = -mean * rstd;
         }
 #pragma unroll
         for (int ii = 0; ii < 4; ++ii)
@@ -790,14 +794,14 @@ _Pragma("unroll")
       if constexpr (C_BNS) {
         // over the RPP lanes that share the columns (lane = row * LPRW + column group): inside a 16-lane row by rotations, across rows by swaps
         static_assert(LPRW == 4 || LPRW == 8, "rows of 4 or 8 lanes");
-        float* out = p.bns_out + (size_t)(bid % (p.bns_copies > 0 ? p.bns_copies : 1)) * 2 * p.N;
+        float* out = p.bns_out + (size_t)(bid % (p.bns_copies > 0 ? p.bns_copies : 1)) * 2 * bnc;
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
           float a0 = bs0[q], a1 = bs1[q];
           a0 += dpp_mov<0x128>(a0); a1 += dpp_mov<0x128>(a1);
           if constexpr (LPRW == 4) { a0 += dpp_mov<0x124>(a0); a1 += dpp_mov<0x124>(a1); }
           a0 = xor32_sum(xor16_sum(a0)); a1 = xor32_sum(xor16_sum(a1));
-          if (lane < LPRW && col0 + 8 <= p.N) { atomicAdd(out + col0 + q, a0); atomicAdd(out + p.N + col0 + q, a1); }
+          if (lane < LPRW && col0 + 8 <= p.N) { atomicAdd(out + bcol + q, a0); atomicAdd(out + bnc + bcol + q, a1); }
         }
       }
     }
@@ -984,6 +988,7 @@ int launch_one(const tfasr_gemm_args& a, hipStream_t stream) {
   if (a.bns_out) {  // BatchNorm backward statistics in the epilogue: the plain NT product on 64-column tiles, or nothing at all
     if constexpr (!TA && TB) {
       if (narrow && !generic && need == 0 && !a.accumulate && !a.bias && split == 1 && a.nb1 * a.nb2 == 1 && a.bns_x && a.bns_fin && (a.N & 7) == 0 && (a.ldd & 7) == 0 &&
+          (a.bns_c == 0 || (a.bns_c > 0 && (a.bns_c & 7) == 0 && a.N % a.bns_c == 0)) &&
           (((uintptr_t)a.D | (uintptr_t)a.bns_x) & 15) == 0 && !a.colsum && !a.lse_part && !a.seg_a_off && !a.rgrad_coef)
         return launch_epi<TA, TB, 64, E_BNS>(a, grid, stream);
     }

@@ -155,9 +155,11 @@ def gemm(A, B, out, M, N, K, lda, ldb, ldd, trans_a=False, trans_b=False, bias=N
         a.seg_a_off, a.seg_b_off, a.seg_k = seg[0].data_ptr(), (seg[1].data_ptr() if seg[1] is not None else None), int(seg[2])
         assert seg[0].dtype == torch.int64 and seg[0].is_cuda
     if bns is not None:
-        bx, bfin, bout = bns
-        assert bfin.dtype == torch.float32 and bout.dtype == torch.float32 and bout.is_contiguous() and bx.is_contiguous()
-        a.bns_x, a.bns_fin, a.bns_out, a.bns_copies = bx.data_ptr(), bfin.data_ptr(), bout.data_ptr(), bout.numel() // (2 * N)
+        bx, bfin, bout = bns[:3]
+        bc = int(bns[3]) if len(bns) > 3 else N   # channels (the columns are (position, channel) pairs when < N)
+        assert bfin.dtype == torch.float32 and bout.dtype == torch.float32 and bout.is_contiguous()
+        a.bns_x, a.bns_fin, a.bns_out, a.bns_copies = bx.data_ptr(), bfin.data_ptr(), bout.data_ptr(), bout.numel() // (2 * bc)
+        a.bns_c = 0 if bc == N else bc
     if lse is not None:
         part, row_label, pick = lse
         assert part.dtype == torch.float32 and pick.dtype == torch.float32 and row_label.dtype == torch.int32

@@ -361,6 +361,33 @@ def test_gemm_epilogue_batchnorm_backward_sums(dev, rows, C, copies):
     cmp(dx1, dx0, rtol=2e-2, atol=2e-3)
 
 
+def test_gemm_epilogue_batchnorm_sums_with_position_channel_columns(dev):
+    """tfasr_gemm_args.bns_c: the product's columns are (position, channel) pairs and its rows carry a wider stride (the subsampling's linear
+    layer writing into the haloed layout, subsampling.py:197-230): sums per CHANNEL over rows and positions against tfasr_bn_bwd_stats over
+    the [rows * positions, C] view, product unchanged."""
+    g = torch.Generator().manual_seed(99)
+    bf = torch.bfloat16
+    rows, C, npos, Kd = 4000, 256, 5, 256
+    N, ldd = npos * C, (npos + 1) * C
+    dy = (torch.randn(rows, Kd, generator=g) * 0.5).to(dev).to(bf)
+    W = (torch.randn(N, Kd, generator=g) / 16).to(dev).to(bf)              # [N, K] row-major: D = dy @ W^T
+    xfull = (torch.randn(rows, ldd, generator=g) * 1.3 + 0.2).to(dev).to(bf)
+    xv = xfull.float()[:, C:].reshape(rows * npos, C)
+    mean, var = xv.mean(0), xv.var(0, unbiased=False)
+    rstd = torch.rsqrt(var + 1e-3)
+    gm, bt = (torch.rand(C, generator=g) + 0.5).to(dev), (torch.randn(C, generator=g) * 0.1).to(dev)
+    fin = torch.cat([mean, rstd, gm * rstd, bt - mean * gm * rstd]).contiguous()
+    d0 = torch.zeros(rows, ldd, dtype=bf, device=dev)
+    d1 = torch.zeros(rows, ldd, dtype=bf, device=dev)
+    K.gemm(dy, W, d0.view(-1)[C:], rows, N, Kd, Kd, Kd, ldd, trans_b=True)
+    st = torch.zeros(8, 2 * C, device=dev)
+    K.gemm(dy, W, d1.view(-1)[C:], rows, N, Kd, Kd, Kd, ldd, trans_b=True, bns=(xfull.view(-1)[C:], fin, st, C))
+    assert torch.equal(d0, d1)
+    st0 = torch.zeros(2 * C, device=dev)
+    K.bn_bwd_stats(xfull[:, C:].reshape(rows * npos, C).contiguous(), d0[:, C:].reshape(rows * npos, C).contiguous(), fin, st0, K.ACT_SWISH)
+    cmp(st.sum(0), st0, rtol=1e-3, atol=2e-4 * float(st0.abs().max()))
+
+
 @pytest.mark.parametrize("dtype", DT)
 def test_bias2_embedding_colsum_cast(dev, dtype):
     g = torch.Generator().manual_seed(2)
